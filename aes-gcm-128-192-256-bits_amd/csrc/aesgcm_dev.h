@@ -1,0 +1,553 @@
+// aesgcm_dev.h -- per-lane arithmetic of the MI355X AES-GCM path (gfx950).
+//
+// Everything here is __host__ __device__ so that the exact lane code the kernels run can also be
+// driven by a CPU harness (tests/host_emul) in the GPU-less build container.  The kernels that
+// compose these pieces are in aesgcm_kernels.hip.
+//
+// Data conventions (DESIGN.md "Layout"):
+//   * a 16-byte block lives in registers as 4 dwords in MEMORY order ("mo"): d0 = bytes 0..3 loaded
+//     little-endian, exactly what global_load_dwordx4 returns.  AES state columns are therefore
+//     little-endian words (row 0 in the low byte); the T-table is built for that convention, so no
+//     byte swap is ever needed on the data path.
+//   * GF(2^128) arithmetic that needs shifts (the bit-serial multiply) works on big-endian words
+//     ("be"): w[0] holds GCM bits 0..31 with bit 0 in the MSB (src/ghash_gfmul.vhd:44-57: VHDL bit
+//     127 = leftmost).  mo <-> be is one byte swap per word.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+#define AESGCM_WG 512          /* lanes per workgroup = GHASH lane stride S */
+#define AESGCM_GMAX 512        /* max workgroups per launch (2 per CU on 256 CUs) */
+#define AESGCM_LDS_GH 8192     /* bytes: 32 nibble positions x 16 entries x 16 B */
+#define AESGCM_LDS_AES 65536   /* bytes: 256 entries x (32 replicas of T0 | 32 replicas of T2) */
+#define AESGCM_LDS_BYTES (AESGCM_LDS_AES + AESGCM_LDS_GH)
+
+#define HD __host__ __device__ __forceinline__
+
+struct G128 { u32 w[4]; };     // big-endian words (math form)
+
+HD u32 bswap32(u32 x) { return __builtin_bswap32(x); }
+HD u32 rotl32(u32 x, int r) { return (x << r) | (x >> (32 - r)); }
+
+HD G128 mo_to_be(uint4 m) { G128 g; g.w[0] = bswap32(m.x); g.w[1] = bswap32(m.y); g.w[2] = bswap32(m.z); g.w[3] = bswap32(m.w); return g; }
+HD uint4 be_to_mo(G128 g) { return make_uint4(bswap32(g.w[0]), bswap32(g.w[1]), bswap32(g.w[2]), bswap32(g.w[3])); }
+HD uint4 xor4(uint4 a, uint4 b) { return make_uint4(a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w); }
+
+// v_perm_b32: result byte i = pool[sel.byte[i]] with pool = {src1 bytes 0..3, src0 bytes 4..7},
+// selector 0x0c = constant 0x00.
+HD u32 perm_b32(u32 src0, u32 src1, u32 sel) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(src0, src1, sel);
+#else
+    u64 pool = ((u64)src0 << 32) | src1;
+    u32 r = 0;
+    for (int i = 0; i < 4; i++) {
+        u32 s = (sel >> (8 * i)) & 0xff;
+        u32 b = (s <= 7) ? (u32)((pool >> (8 * s)) & 0xff) : 0u;   // only 0..7 and 0x0c are used here
+        r |= b << (8 * i);
+    }
+    return r;
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// GF(2^8) helpers and the S-box (src/aes_func.vhd:187-210 xtime2/xtime3, :228-301 sbox).  The S-box
+// is computed from its FIPS-197 definition by a 256-thread init kernel, never typed in.
+// ------------------------------------------------------------------------------------------------
+HD u32 xtime2(u32 d) { return ((d << 1) ^ ((d & 0x80) ? 0x1Bu : 0u)) & 0xff; }
+HD u32 gf8_mul(u32 a, u32 b) { u32 r = 0; for (int i = 0; i < 8; i++) { if (b & 1) r ^= a; a = xtime2(a); b >>= 1; } return r; }
+HD u32 sbox_calc(u32 x) {
+    u32 inv = 0;
+    if (x) { u32 p = 1, b = x; for (int e = 254; e; e >>= 1) { if (e & 1) p = gf8_mul(p, b); b = gf8_mul(b, b); } inv = p; }
+    u32 s = inv, r = inv;
+    for (int k = 0; k < 4; k++) { r = ((r << 1) | (r >> 7)) & 0xff; s ^= r; }
+    return s ^ 0x63;
+}
+// T0 in the memory-order convention: column bytes (row0..row3) = (2s, s, s, 3s) -> LE word.
+// = mix_columns(aes_func.vhd:159-169) applied to a column whose row 0 holds sbox(x).
+HD u32 te0_calc(u32 s) { u32 s2 = xtime2(s); return s2 | (s << 8) | (s << 16) | ((s2 ^ s) << 24); }
+
+// ------------------------------------------------------------------------------------------------
+// Literal single-block AES and key schedule, byte oriented, in the reference's own bracketing.
+// Used only in one-off setup lanes (key expansion, H, E_K(J0)); the bulk path is aes_rounds_lds().
+// ------------------------------------------------------------------------------------------------
+// FIPS-197 KeyExpansion (tb/key_exp.py:79-114; config/config_aes_kexp.py:128-159: RotWord/SubWord,
+// rcon doubled by xtime2 :150, 256-bit "skip" step = SubWord only :147-152).  rk = 16*(nr+1) bytes.
+HD int key_expand_bytes(const uint8_t *key, int key_len, const uint8_t *sbox, uint8_t *rk) {
+    int nk = key_len / 4, nr = nk + 6, total = 4 * (nr + 1);
+    for (int i = 0; i < key_len; i++) rk[i] = key[i];
+    u32 rcon = 1;
+    for (int w = nk; w < total; w++) {
+        uint8_t t0 = rk[4 * w - 4], t1 = rk[4 * w - 3], t2 = rk[4 * w - 2], t3 = rk[4 * w - 1];
+        if (w % nk == 0) {
+            uint8_t r0 = sbox[t1], r1 = sbox[t2], r2 = sbox[t3], r3 = sbox[t0];      // rot_word then sub_word
+            t0 = (uint8_t)(r0 ^ rcon); t1 = r1; t2 = r2; t3 = r3;
+            rcon = xtime2(rcon);
+        } else if (nk == 8 && (w % nk) == 4) {
+            t0 = sbox[t0]; t1 = sbox[t1]; t2 = sbox[t2]; t3 = sbox[t3];
+        }
+        rk[4 * w + 0] = rk[4 * (w - nk) + 0] ^ t0; rk[4 * w + 1] = rk[4 * (w - nk) + 1] ^ t1;
+        rk[4 * w + 2] = rk[4 * (w - nk) + 2] ^ t2; rk[4 * w + 3] = rk[4 * (w - nk) + 3] ^ t3;
+    }
+    return nr;
+}
+// round r = 1..Nr: s = MC?(SR(SB(s ^ k[r-1]))), MC skipped at r = Nr (config/config_aes_round.py:120-126);
+// then out = s ^ k[Nr] (src/aes_last_round.vhd:76).  State byte 4*c + r = column c, row r.
+HD void aes_block_bytes(const uint8_t *rk, int nr, const uint8_t *sbox, const uint8_t in[16], uint8_t out[16]) {
+    uint8_t s[16], t[16];
+    for (int i = 0; i < 16; i++) s[i] = in[i];
+    for (int r = 1; r <= nr; r++) {
+        for (int i = 0; i < 16; i++) s[i] = sbox[s[i] ^ rk[16 * (r - 1) + i]];                 // ARK, SubBytes
+        for (int c = 0; c < 4; c++) for (int q = 0; q < 4; q++) t[4 * c + q] = s[4 * ((c + q) & 3) + q];   // ShiftRows
+        if (r != nr) {
+            for (int c = 0; c < 4; c++) {                                                      // MixColumns
+                u32 a0 = t[4 * c], a1 = t[4 * c + 1], a2 = t[4 * c + 2], a3 = t[4 * c + 3];
+                s[4 * c + 0] = (uint8_t)(xtime2(a0) ^ xtime2(a1) ^ a1 ^ a2 ^ a3);
+                s[4 * c + 1] = (uint8_t)(a0 ^ xtime2(a1) ^ xtime2(a2) ^ a2 ^ a3);
+                s[4 * c + 2] = (uint8_t)(a0 ^ a1 ^ xtime2(a2) ^ xtime2(a3) ^ a3);
+                s[4 * c + 3] = (uint8_t)(xtime2(a0) ^ a0 ^ a1 ^ a2 ^ xtime2(a3));
+            }
+        } else {
+            for (int i = 0; i < 16; i++) s[i] = t[i];
+        }
+    }
+    for (int i = 0; i < 16; i++) out[i] = s[i] ^ rk[16 * nr + i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// GF(2^128): bit-serial multiply, SP 800-38D Algorithm 1 as src/ghash_gfmul.vhd:37-64 states it
+// (V starts as the second operand, is shifted right once per bit of the first, R = 0xE1 || 0^120).
+// Variable x variable; used off the hot loop only (setup tables, per-lane tail power, combine).
+// ------------------------------------------------------------------------------------------------
+HD G128 gf_mul(G128 x, G128 v) {
+    u32 z0 = 0, z1 = 0, z2 = 0, z3 = 0;
+    u32 v0 = v.w[0], v1 = v.w[1], v2 = v.w[2], v3 = v.w[3];
+    u32 x0 = x.w[0], x1 = x.w[1], x2 = x.w[2], x3 = x.w[3];
+#pragma unroll 1
+    for (int wi = 0; wi < 4; wi++) {
+        u32 xw = x0; x0 = x1; x1 = x2; x2 = x3;
+#pragma unroll 8
+        for (int b = 0; b < 32; b++) {
+            u32 m = (u32)((int32_t)xw >> 31);      // GCM bit order: MSB first
+            xw <<= 1;
+            z0 ^= v0 & m; z1 ^= v1 & m; z2 ^= v2 & m; z3 ^= v3 & m;
+            u32 lsb = 0u - (v3 & 1u);
+            v3 = (v3 >> 1) | (v2 << 31); v2 = (v2 >> 1) | (v1 << 31); v1 = (v1 >> 1) | (v0 << 31);
+            v0 = (v0 >> 1) ^ (lsb & 0xE1000000u);
+        }
+    }
+    G128 z; z.w[0] = z0; z.w[1] = z1; z.w[2] = z2; z.w[3] = z3;
+    return z;
+}
+HD uint4 gf_mul_mo(uint4 a, uint4 b) { return be_to_mo(gf_mul(mo_to_be(a), mo_to_be(b))); }
+HD uint4 gf_one_mo() { return make_uint4(0x80u, 0u, 0u, 0u); }   // the field's 1: byte 0 = 0x80
+
+// element whose nibble position p (0 = high nibble of byte 0 ... 31 = low nibble of byte 15) holds v
+HD uint4 nibble_elem_mo(int p, u32 v) {
+    u32 w[4] = {0, 0, 0, 0};
+    int b = p >> 1;
+    u32 byte = (p & 1) ? v : (v << 4);
+    w[b >> 2] = byte << (8 * (b & 3));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS access.  The kernels' dynamic LDS segment starts at LDS address 0 (k_main has no static LDS), so
+// table addresses are plain integers: this lets the compiler put the table base into the 16-bit
+// `offset:` field of ds_read_* instead of spending a v_add per lookup.  Layout of the 72 KiB segment:
+//   [0, 8 KiB)        32 GHASH nibble tables of the launch constant K, 256 B (one LDS bank row) each
+//   [8 KiB, 72 KiB)   AES: entry for byte value x at 8192 + x*256 + sel*128 + (lane&31)*4
+//                     (sel 0 = T0, sel 1 = T2 = rotl16(T0)), 32 replicas so lane l always reads bank l&31
+// On the host (tests/host_emul) `lds` is an ordinary array with the same layout.
+// ------------------------------------------------------------------------------------------------
+#define AESGCM_LDS_GH_OFF 0u
+#define AESGCM_LDS_AES_OFF 8192u
+typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LDS_LD32(lds, off) (*(const __attribute__((address_space(3))) u32 *)(uintptr_t)(off))
+#define LDS_LD128(lds, off) (*(const __attribute__((address_space(3))) u32x4_t *)(uintptr_t)(off))
+HD u32 xor3(u32 a, u32 b, u32 c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+#else
+#define LDS_LD32(lds, off) (*(const u32 *)((lds) + (off)))
+#define LDS_LD128(lds, off) (*(const u32x4_t *)((lds) + (off)))
+HD u32 xor3(u32 a, u32 b, u32 c) { return a ^ b ^ c; }
+#endif
+
+// ------------------------------------------------------------------------------------------------
+// Hot loop piece 1: Nr AES rounds on one counter/ECB block per lane, T-table lookups from LDS.
+//   lb   : (lane&31)*4.  One v_perm_b32 builds each address: (byte_k(s) << 8) | lb; the table base
+//          and the T0/T2 select ride in the ds_read offset field.  A wave64 ds_read_b32 is served in
+//          two 32-lane groups and lane l always hits bank l&31: conflict-free (MI355X_MICROARCH LDS).
+//   rk   : round keys as memory-order words (wave-uniform -> scalar operands).
+// Per column: out = T0[r0] ^ T2[r2] ^ rotl8(T0[r1] ^ T2[r3]) ^ rk   (T1 = rotl8 T0, T3 = rotl8 T2).
+// This is aes_round's SB->SR->MC (config/config_aes_round.py:121-124) folded into the table, with
+// the ARK of the NEXT round (:120) applied at the end, i.e. the standard FIPS-197 bracketing of the
+// same cipher; the final round drops MC (:124 cnt = thr) and ends with aes_last_round.vhd:76.
+// ------------------------------------------------------------------------------------------------
+#define SEL_B(k) (0x0c0c0000u | ((4u + (k)) << 8))
+#define T0_AT(lds, s, k, lb) LDS_LD32(lds, perm_b32(s, lb, SEL_B(k)) + AESGCM_LDS_AES_OFF)
+#define T2_AT(lds, s, k, lb) LDS_LD32(lds, perm_b32(s, lb, SEL_B(k)) + (AESGCM_LDS_AES_OFF + 128u))
+
+// one full round (SubBytes, ShiftRows, MixColumns, AddRoundKey(rkr)) on the whole state
+HD void aes_round_lds(u32 &s0, u32 &s1, u32 &s2, u32 &s3, const u32 *__restrict__ rkr, const unsigned char *lds, u32 lb) {
+    const u32 a0 = T0_AT(lds, s0, 0, lb), a1 = T0_AT(lds, s1, 1, lb), a2 = T2_AT(lds, s2, 2, lb), a3 = T2_AT(lds, s3, 3, lb);
+    const u32 b0 = T0_AT(lds, s1, 0, lb), b1 = T0_AT(lds, s2, 1, lb), b2 = T2_AT(lds, s3, 2, lb), b3 = T2_AT(lds, s0, 3, lb);
+    const u32 c0 = T0_AT(lds, s2, 0, lb), c1 = T0_AT(lds, s3, 1, lb), c2 = T2_AT(lds, s0, 2, lb), c3 = T2_AT(lds, s1, 3, lb);
+    const u32 d0 = T0_AT(lds, s3, 0, lb), d1 = T0_AT(lds, s0, 1, lb), d2 = T2_AT(lds, s1, 2, lb), d3 = T2_AT(lds, s2, 3, lb);
+    s0 = xor3(a0, a2, rkr[0]) ^ rotl32(a1 ^ a3, 8);
+    s1 = xor3(b0, b2, rkr[1]) ^ rotl32(b1 ^ b3, 8);
+    s2 = xor3(c0, c2, rkr[2]) ^ rotl32(c1 ^ c3, 8);
+    s3 = xor3(d0, d2, rkr[3]) ^ rotl32(d1 ^ d3, 8);
+}
+// final round: SubBytes + ShiftRows + AddRoundKey.  S[x] sits in bytes 1,2 of T0[x] and bytes 0,3 of
+// T2[x], so every output byte is already in place: row0 <- T2 byte0, row1 <- T0 byte1, row2 <- T0 byte2,
+// row3 <- T2 byte3.
+HD u32 merge_rows(u32 r0, u32 r1, u32 r2, u32 r3) {
+    return (r0 & 0x000000ffu) | (r1 & 0x0000ff00u) | (r2 & 0x00ff0000u) | (r3 & 0xff000000u);
+}
+HD void aes_final_lds(u32 &s0, u32 &s1, u32 &s2, u32 &s3, const u32 *__restrict__ rkr, const unsigned char *lds, u32 lb) {
+    const u32 a0 = T2_AT(lds, s0, 0, lb), a1 = T0_AT(lds, s1, 1, lb), a2 = T0_AT(lds, s2, 2, lb), a3 = T2_AT(lds, s3, 3, lb);
+    const u32 b0 = T2_AT(lds, s1, 0, lb), b1 = T0_AT(lds, s2, 1, lb), b2 = T0_AT(lds, s3, 2, lb), b3 = T2_AT(lds, s0, 3, lb);
+    const u32 c0 = T2_AT(lds, s2, 0, lb), c1 = T0_AT(lds, s3, 1, lb), c2 = T0_AT(lds, s0, 2, lb), c3 = T2_AT(lds, s1, 3, lb);
+    const u32 d0 = T2_AT(lds, s3, 0, lb), d1 = T0_AT(lds, s0, 1, lb), d2 = T0_AT(lds, s1, 2, lb), d3 = T2_AT(lds, s2, 3, lb);
+    s0 = merge_rows(a0, a1, a2, a3) ^ rkr[0];
+    s1 = merge_rows(b0, b1, b2, b3) ^ rkr[1];
+    s2 = merge_rows(c0, c1, c2, c3) ^ rkr[2];
+    s3 = merge_rows(d0, d1, d2, d3) ^ rkr[3];
+}
+// generic: state already has rk[0..3] applied
+template <int NR>
+HD void aes_rounds_lds(u32 &s0, u32 &s1, u32 &s2, u32 &s3, const u32 *__restrict__ rk, const unsigned char *lds, u32 lb) {
+#pragma unroll
+    for (int r = 1; r < NR; r++) aes_round_lds(s0, s1, s2, s3, rk + 4 * r, lds, lb);
+    aes_final_lds(s0, s1, s2, s3, rk + 4 * NR, lds, lb);
+}
+
+// CTR specialisation: in a counter block only the last word varies (IV || cnt, aes_icb.vhd:118), so 12 of
+// round 1's 16 lookups are the same for every block of the message.  ctr_round1_consts() folds them (and
+// round key 1) into four per-message constants once; ctr_rounds_lds() then does 4 lookups in round 1.
+struct CtrConsts { u32 c0, c1, c2, c3; };
+HD CtrConsts ctr_round1_consts(u32 iv0, u32 iv1, u32 iv2, const u32 *__restrict__ rk, const unsigned char *lds, u32 lb) {
+    const u32 s0 = iv0 ^ rk[0], s1 = iv1 ^ rk[1], s2 = iv2 ^ rk[2];
+    CtrConsts k;
+    k.c0 = xor3(T0_AT(lds, s0, 0, lb), T2_AT(lds, s2, 2, lb), rk[4]) ^ rotl32(T0_AT(lds, s1, 1, lb), 8);   // + rotl8(T2[s3.b3])
+    k.c1 = xor3(T0_AT(lds, s1, 0, lb), rotl32(T0_AT(lds, s2, 1, lb) ^ T2_AT(lds, s0, 3, lb), 8), rk[5]);  // + T2[s3.b2]
+    k.c2 = xor3(T0_AT(lds, s2, 0, lb), T2_AT(lds, s0, 2, lb), rk[6]) ^ rotl32(T2_AT(lds, s1, 3, lb), 8);   // + rotl8(T0[s3.b1])
+    k.c3 = xor3(T2_AT(lds, s1, 2, lb), rotl32(T0_AT(lds, s0, 1, lb) ^ T2_AT(lds, s2, 3, lb), 8), rk[7]);  // + T0[s3.b0]
+    return k;
+}
+template <int NR>
+HD void ctr_rounds_lds(u32 ctr_be_word, const CtrConsts &k, u32 &s0, u32 &s1, u32 &s2, u32 &s3,
+                       const u32 *__restrict__ rk, const unsigned char *lds, u32 lb) {
+    const u32 w3 = ctr_be_word ^ rk[3];
+    s0 = k.c0 ^ rotl32(T2_AT(lds, w3, 3, lb), 8);
+    s1 = k.c1 ^ T2_AT(lds, w3, 2, lb);
+    s2 = k.c2 ^ rotl32(T0_AT(lds, w3, 1, lb), 8);
+    s3 = k.c3 ^ T0_AT(lds, w3, 0, lb);
+#pragma unroll
+    for (int r = 2; r < NR; r++) aes_round_lds(s0, s1, s2, s3, rk + 4 * r, lds, lb);
+    aes_final_lds(s0, s1, s2, s3, rk + 4 * NR, lds, lb);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Hot loop piece 2: multiply the lane's GHASH accumulator by the launch constant K = H^(lane stride)
+// through 32 nibble tables in LDS: Y*K = xor_p T_p[nibble_p(Y)] (multiplication by a constant is
+// GF(2)-linear -- the generalisation of the RTL's 2-way split, src/gcm_ghash.vhd:317-333).
+// Table p is one 256-byte LDS bank row (16 entries x 16 B), so within a ds_read_b128 lane group two
+// lanes either read the same address (broadcast) or different 16-byte slots: conflict-free by
+// construction.
+// ------------------------------------------------------------------------------------------------
+HD uint4 ghash_mul_const_lds(uint4 y, const unsigned char *lds) {
+    u32x4_t r0 = {0, 0, 0, 0}, r1 = {0, 0, 0, 0};
+    const u32 w[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+    for (int wi = 0; wi < 4; wi++) {
+#pragma unroll
+        for (int bb = 0; bb < 4; bb++) {
+            const int b = 4 * wi + bb;
+            const u32 hi = (bb == 0) ? (w[wi] & 0xF0u) : ((w[wi] >> (8 * bb)) & 0xF0u);
+            const u32 lo = (bb == 0) ? ((w[wi] << 4) & 0xF0u) : ((w[wi] >> (8 * bb - 4)) & 0xF0u);
+            r0 ^= LDS_LD128(lds, hi + (AESGCM_LDS_GH_OFF + (2 * b) * 256));
+            r1 ^= LDS_LD128(lds, lo + (AESGCM_LDS_GH_OFF + (2 * b + 1) * 256));
+        }
+    }
+    r0 ^= r1;
+    return make_uint4(r0.x, r0.y, r0.z, r0.w);
+}
+
+// ================================================================================================
+// Device-resident structures and the per-lane bodies of the kernels.  The __global__ wrappers in
+// aesgcm_kernels.hip only add LDS staging, barriers and cross-lane reductions around these, so the
+// CPU harness (tests/host_emul) executes the same lane code against the same structures.
+// ================================================================================================
+struct DevTables {           // per device
+    uint8_t sbox[256];
+    u32 te0[256];
+};
+
+struct KeyMaterial {         // per context (device memory)
+    u32 rk[60];              // expanded key, memory-order words
+    u32 nr;
+    u32 G;                   // workgroups the K table was built for
+    u32 _pad[2];
+    uint4 h;                 // H = E_K(0^128)
+    uint4 pw[4][513];        // pw[d][k] = H^(k * 512^d)
+    uint4 bp2[513];          // bp2[k] = beta^k * H^2, beta = H^512
+    uint4 ktab[512];         // nibble tables of K = H^(G*512): entry p*16+v
+    uint8_t rk_bytes[240];   // expanded key as the byte string tb/key_exp.py produces
+};
+
+enum { MODE_ENC = 0, MODE_DEC = 1, MODE_KS = 2, MODE_ECB = 3 };
+
+struct MainParams {
+    const unsigned char *in;     // data in (16-byte aligned) or NULL (MODE_KS)
+    unsigned char *out;
+    const unsigned char *aad;    // AAD bytes or NULL
+    uint4 *parts;                // workgroup partials out (GHASH modes)
+    u64 aad_len;                 // bytes
+    u64 n_aad;                   // AAD blocks
+    u64 len;                     // data bytes
+    u64 n_seq;                   // n_aad + data blocks
+    u64 pad;                     // T*GS - n_seq
+    u64 GS;                      // G' * 512
+    u32 T;                       // iterations
+    u32 ctr0;                    // counter of data block 0 (2 + first_block)
+    u32 iv0, iv1, iv2;           // IV as memory-order words
+    u32 aad_aligned;             // AAD pointer 16-byte aligned
+};
+
+// launch geometry for a GHASH sequence of n_seq blocks on a device that runs G workgroups per full launch
+HD void main_geometry(u64 n_seq, u32 G, u64 *Gp, u64 *T) {
+    const u64 full = (u64)G * AESGCM_WG;
+    if (n_seq <= full) { *T = 1; *Gp = (n_seq + AESGCM_WG - 1) / AESGCM_WG; }
+    else { *T = (n_seq + full - 1) / full; *Gp = G; }
+}
+
+HD u32 load_le32(const uint8_t *b) { return (u32)b[0] | ((u32)b[1] << 8) | ((u32)b[2] << 16) | ((u32)b[3] << 24); }
+
+// ---- k_setup pieces ----------------------------------------------------------------------------
+// lane 0: key schedule (aes_kexp) or pre-expanded copy, H = E_K(0) (gcm_gctr.vhd:141-144); seeds tab[0..1]
+HD void setup_lane0(KeyMaterial *km, const uint8_t *sbox, const uint8_t *key, int key_len, int preexpanded_nr, u32 G, uint4 *tab) {
+    int nr;
+    if (preexpanded_nr) {
+        nr = preexpanded_nr;
+        for (int i = 0; i < 16 * (nr + 1); i++) km->rk_bytes[i] = key[i];
+    } else {
+        uint8_t k[32];
+        for (int i = 0; i < key_len; i++) k[i] = key[i];
+        nr = key_expand_bytes(k, key_len, sbox, km->rk_bytes);
+    }
+    for (int w = 0; w < 4 * (nr + 1); w++) km->rk[w] = load_le32(km->rk_bytes + 4 * w);
+    for (int w = 4 * (nr + 1); w < 60; w++) km->rk[w] = 0;
+    km->nr = (u32)nr;
+    km->G = G;
+    uint8_t zero[16] = {0}, hb[16];
+    aes_block_bytes(km->rk_bytes, nr, sbox, zero, hb);
+    km->h = make_uint4(load_le32(hb), load_le32(hb + 4), load_le32(hb + 8), load_le32(hb + 12));
+    tab[0] = gf_one_mo();
+    tab[1] = km->h;
+}
+// doubling level j of a power table: tab[2^j + k] = tab[k] * tab[2^j] for k = 1..2^j
+HD bool setup_level(const uint4 *tab, int j, int tid, uint4 *prod) {
+    const int base = 1 << j;
+    if (tid < 1 || tid > base) return false;
+    *prod = gf_mul_mo(tab[tid], tab[base]);
+    return true;
+}
+// after the beta table (d == 1) is complete in tab: bp2 and the nibble table of K = beta^G
+HD void setup_beta_lane(KeyMaterial *km, const uint4 *tab, int tid) {
+    const uint4 h2 = km->pw[0][2];
+    for (int k = tid; k < 513; k += 512) km->bp2[k] = gf_mul_mo(tab[k], h2);
+    km->ktab[tid] = gf_mul_mo(nibble_elem_mo(tid >> 4, (u32)(tid & 15)), tab[km->G]);
+}
+
+// ---- k_main pieces -----------------------------------------------------------------------------
+// LDS image of one workgroup: what thread `tid` of AESGCM_WG writes
+HD void main_fill_lds(unsigned char *smem, const KeyMaterial *km, const DevTables *tb, u32 tid, bool gh) {
+    if (gh) reinterpret_cast<uint4 *>(smem + AESGCM_LDS_GH_OFF)[tid] = km->ktab[tid];
+    uint4 *dst = reinterpret_cast<uint4 *>(smem + AESGCM_LDS_AES_OFF);
+    for (u32 q = tid; q < AESGCM_LDS_AES / 16; q += AESGCM_WG) {
+        const u32 t0 = tb->te0[q >> 4];
+        const u32 v = ((q >> 3) & 1) ? rotl32(t0, 16) : t0;
+        dst[q] = make_uint4(v, v, v, v);
+    }
+}
+
+// block loads/stores with the ragged last block handled bytewise (gcm_ghash.vhd:225-246 byte-valid
+// mask = zero padding on the right; gcm_gctr.vhd:184 byte-valid passthrough on the data output)
+HD uint4 load_block_bytes(const unsigned char *p, u32 nbytes) {
+    u32 w[4] = {0, 0, 0, 0};
+    for (u32 k = 0; k < nbytes; k++) w[k >> 2] |= (u32)p[k] << (8 * (k & 3));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+HD void store_block_bytes(unsigned char *p, uint4 v, u32 nbytes) {
+    const u32 w[4] = {v.x, v.y, v.z, v.w};
+    for (u32 k = 0; k < nbytes; k++) p[k] = (unsigned char)(w[k >> 2] >> (8 * (k & 3)));
+}
+HD uint4 mask_block(uint4 v, u32 nbytes) {
+    u32 w[4] = {v.x, v.y, v.z, v.w};
+    for (u32 k = 0; k < 4; k++) {
+        int keep = (int)nbytes - 4 * (int)k;           // bytes of word k that are valid
+        if (keep <= 0) w[k] = 0;
+        else if (keep < 4) w[k] &= (1u << (8 * keep)) - 1u;
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// the hot loop of lane `tid` of workgroup `wg`: returns the lane's GHASH accumulator
+template <int NR, int MODE>
+HD uint4 main_lane(const KeyMaterial *__restrict__ km, const MainParams &p, const unsigned char *smem, u32 wg, u32 tid) {
+    constexpr bool GH = (MODE == MODE_ENC || MODE == MODE_DEC);
+    const u32 *__restrict__ rk = km->rk;
+    const u32 lb = (tid & 31u) << 2;
+    CtrConsts cc = {0, 0, 0, 0};
+    if (MODE != MODE_ECB) cc = ctr_round1_consts(p.iv0, p.iv1, p.iv2, rk, smem, lb);
+    const u64 n_data_blocks = p.n_seq - p.n_aad;
+    const u32 tail_bytes = (u32)(p.len & 15);          // 0 = last data block is full
+    const u32 aad_tail = (u32)(p.aad_len & 15);
+    uint4 acc = make_uint4(0, 0, 0, 0);
+
+    for (u32 t = 0; t < p.T; ++t) {
+        const u64 v = (u64)t * p.GS + (u64)wg * AESGCM_WG + tid;
+        if (GH && t > 0) acc = ghash_mul_const_lds(acc, smem);
+        if (v < p.pad) continue;                       // front padding: contributes zero
+        const u64 j = v - p.pad;                       // index in the GHASH sequence (AAD blocks then data blocks)
+        uint4 gin;
+        if (GH && j < p.n_aad) {
+            const unsigned char *ap = p.aad + 16 * j;
+            if (j == p.n_aad - 1 && aad_tail) gin = load_block_bytes(ap, aad_tail);
+            else if (p.aad_aligned) gin = *reinterpret_cast<const uint4 *>(ap);
+            else gin = load_block_bytes(ap, 16);
+        } else {
+            const u64 i = j - p.n_aad;                 // data block index within this launch
+            const bool ragged = tail_bytes && (i == n_data_blocks - 1);
+            uint4 x = make_uint4(0, 0, 0, 0);
+            if (MODE != MODE_KS) {
+                if (ragged) x = load_block_bytes(p.in + 16 * i, tail_bytes);
+                else x = *reinterpret_cast<const uint4 *>(p.in + 16 * i);
+            }
+            u32 s0, s1, s2, s3;
+            if (MODE == MODE_ECB) {
+                s0 = x.x ^ rk[0]; s1 = x.y ^ rk[1]; s2 = x.z ^ rk[2]; s3 = x.w ^ rk[3];
+                aes_rounds_lds<NR>(s0, s1, s2, s3, rk, smem, lb);
+            } else {
+                // counter block IV || cnt, cnt big-endian, low 32 bits only (aes_icb.vhd:97-100,118)
+                ctr_rounds_lds<NR>(bswap32(p.ctr0 + (u32)i), cc, s0, s1, s2, s3, rk, smem, lb);
+            }
+            uint4 y;
+            if (MODE == MODE_ECB) y = make_uint4(s0, s1, s2, s3);
+            else y = make_uint4(x.x ^ s0, x.y ^ s1, x.z ^ s2, x.w ^ s3);        // gcm_gctr.vhd:150
+            if (ragged) { y = mask_block(y, tail_bytes); store_block_bytes(p.out + 16 * i, y, tail_bytes); }
+            else *reinterpret_cast<uint4 *>(p.out + 16 * i) = y;
+            gin = (MODE == MODE_DEC) ? x : y;           // aes_gcm.vhd:207-211
+        }
+        if (GH) acc = xor4(acc, gin);
+    }
+    return acc;
+}
+// lane L carries H^(511-L) into the workgroup reduction
+HD G128 main_lane_tail(const KeyMaterial *__restrict__ km, uint4 acc, u32 tid) {
+    return gf_mul(mo_to_be(acc), mo_to_be(km->pw[0][AESGCM_WG - 1 - tid]));
+}
+
+// ---- k_combine pieces --------------------------------------------------------------------------
+#define COMBINE_THREADS 576   /* 512 partial lanes + the length-block lane + the E_K(J0) lane, rounded to waves */
+struct CombineParams {
+    const uint4 *parts; u32 np; u32 gathered;
+    u32 want_tag;                // 1 = TAG, 0 = POLY
+    u64 e;                       // POLY: exponent applied to the folded partials
+    const uint4 *carry; u64 e_carry; u32 has_carry;
+    u64 aad_len, ct_len;         // bytes, for the length block
+    u32 iv0, iv1, iv2;
+    uint4 *out;
+};
+// what lane `tid` contributes to the XOR fold
+HD G128 combine_lane(const KeyMaterial *__restrict__ km, const uint8_t *sbox, const CombineParams &p, u32 tid) {
+    G128 z; z.w[0] = z.w[1] = z.w[2] = z.w[3] = 0;
+    const bool tag = p.want_tag != 0;
+    if (tid < p.np) {
+        uint4 m;
+        if (p.gathered) m = tag ? km->bp2[0] : gf_one_mo();
+        else m = tag ? km->bp2[p.np - 1 - tid] : km->pw[1][p.np - 1 - tid];
+        z = gf_mul(mo_to_be(p.parts[tid]), mo_to_be(m));
+    } else if (tag && tid == AESGCM_GMAX) {
+        // length block [8*len(A)]_64 || [8*len(C)]_64 (gcm_ghash.vhd:257) times H
+        G128 L; const u64 a = p.aad_len * 8, c = p.ct_len * 8;
+        L.w[0] = (u32)(a >> 32); L.w[1] = (u32)a; L.w[2] = (u32)(c >> 32); L.w[3] = (u32)c;
+        z = gf_mul(L, mo_to_be(km->h));
+    } else if (tag && tid == AESGCM_GMAX + 1) {
+        // E_K(IV || 0^31 1): the J0 block the RTL latches first (gcm_ghash.vhd:158-169)
+        uint8_t j0[16], o[16];
+        const u32 ivw[3] = {p.iv0, p.iv1, p.iv2};
+        for (int k = 0; k < 12; k++) j0[k] = (uint8_t)(ivw[k >> 2] >> (8 * (k & 3)));
+        j0[12] = 0; j0[13] = 0; j0[14] = 0; j0[15] = 1;
+        aes_block_bytes(km->rk_bytes, (int)km->nr, sbox, j0, o);
+        z = mo_to_be(make_uint4(load_le32(o), load_le32(o + 4), load_le32(o + 8), load_le32(o + 12)));
+    }
+    return z;
+}
+// H^e as the product of its four radix-512 digit entries (e < 2^36)
+HD G128 gf_pow_h_digit(const KeyMaterial *km, u64 e, u32 d) { return mo_to_be(km->pw[d][(e >> (9 * d)) & 511u]); }
+
+// ---- host-side planning (shared by the C ABI and the CPU harness) -------------------------------
+static inline void iv_to_words(const uint8_t iv[12], u32 w[3]) { for (int q = 0; q < 3; q++) w[q] = load_le32(iv + 4 * q); }
+
+// Fill MainParams for one launch; returns the number of workgroups (0 = nothing to launch).
+static inline u32 plan_main(MainParams &p, int mode, u32 G, const uint8_t *iv, const void *aad, u64 aad_len,
+                            const void *in, u64 len, void *out, u64 first_block, uint4 *parts) {
+    const bool gh = (mode == MODE_ENC || mode == MODE_DEC);
+    const u64 n_aad = gh ? (aad_len + 15) / 16 : 0;
+    const u64 n_seq = n_aad + (len + 15) / 16;
+    if (n_seq == 0) return 0;
+    u64 Gp, T;
+    main_geometry(n_seq, G, &Gp, &T);
+    p.in = (const unsigned char *)in; p.out = (unsigned char *)out; p.aad = (const unsigned char *)aad;
+    p.parts = parts;
+    p.aad_len = gh ? aad_len : 0; p.n_aad = n_aad; p.len = len; p.n_seq = n_seq;
+    p.GS = Gp * AESGCM_WG; p.T = (u32)T; p.pad = T * p.GS - n_seq;
+    p.ctr0 = (u32)(2 + first_block);
+    u32 w[3] = {0, 0, 0};
+    if (iv) iv_to_words(iv, w);
+    p.iv0 = w[0]; p.iv1 = w[1]; p.iv2 = w[2];
+    p.aad_aligned = (((uintptr_t)aad) & 15) == 0;
+    return (u32)Gp;
+}
+// whole-message tag from local workgroup partials:  P*H^2 ^ L*H ^ E_K(J0)
+static inline CombineParams plan_combine_tag(const uint4 *parts, u32 np, bool gathered, const uint8_t iv[12],
+                                             u64 aad_len, u64 ct_len, uint4 *out) {
+    CombineParams q = {};
+    q.parts = parts; q.np = np; q.gathered = gathered ? 1u : 0u; q.want_tag = 1;
+    q.aad_len = aad_len; q.ct_len = ct_len;
+    u32 w[3]; iv_to_words(iv, w); q.iv0 = w[0]; q.iv1 = w[1]; q.iv2 = w[2];
+    q.out = out;
+    return q;
+}
+// polynomial value of local partials times H^e (shard partial, aesgcm_ghash)
+static inline CombineParams plan_combine_poly(const uint4 *parts, u32 np, u64 e, uint4 *out) {
+    CombineParams q = {};
+    q.parts = parts; q.np = np; q.e = e; q.out = out;
+    return q;
+}
+// streaming: Y' = Y * H^nb ^ P(new blocks)
+static inline CombineParams plan_combine_carry(const uint4 *parts, u32 np, uint4 *state, u64 nb) {
+    CombineParams q = {};
+    q.parts = parts; q.np = np; q.carry = state; q.has_carry = 1; q.e_carry = nb; q.out = state;
+    return q;
+}
+// streaming final: tag = Y*H^2 ^ L*H ^ E_K(J0)
+static inline CombineParams plan_combine_final(uint4 *state, const uint8_t iv[12], u64 aad_len, u64 ct_len, uint4 *out) {
+    CombineParams q = plan_combine_tag(nullptr, 0, false, iv, aad_len, ct_len, out);
+    q.carry = state; q.has_carry = 1; q.e_carry = 0;
+    return q;
+}
+
+// SplitMix64 at word position w; shared with oracle/aesgcm_oracle.c by definition.
+HD u64 splitmix64_at(u64 seed, u64 w) {
+    u64 z = seed + (w + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}

@@ -1,0 +1,757 @@
+// aesgcm_kernels.hip -- HIP kernels (gfx950) + the C ABI of include/aesgcm.h.
+//
+// Kernels
+//   k_init_tables   per device, once: S-box (256 B) and T0 (1 KiB) computed from their definitions.
+//   k_setup         per key: aes_kexp (or pre-expanded load), H = E_K(0), H-power tables, nibble table of K.
+//   k_main<NR,MODE> the hot path: fused AES-CTR + GHASH partial evaluation (also ECB / keystream modes).
+//   k_combine       per message: folds the workgroup partials with powers of beta = H^512, optional
+//                   H^e weighting (shards / streaming), length block, E_K(J0) -> tag.
+//   k_gfmul, k_fill small utility kernels.
+//
+// GHASH re-association (DESIGN.md "GHASH as a polynomial"): the GHASH input sequence
+// A_0..A_{u-1}, C_0..C_{c-1} (n = u + c blocks) is right-aligned into a virtual index space of
+// T * G * 512 slots (front padding = zeros, which do not change a polynomial).  Slot
+// v = t*(G*512) + g*512 + L belongs to iteration t, workgroup g, lane L.  Each lane runs Horner with
+// the launch constant K = H^(G*512):  acc = acc*K ^ X.  After the loop lane L multiplies by
+// H^(511-L), the workgroup XOR-reduces to P_g, and k_combine forms  P = sum_g P_g * beta^(G-1-g)
+// = sum_i X_i H^(n-1-i).  The tag is (P*H ^ L)*H ^ E_K(J0) = P*H^2 ^ L*H ^ E_K(J0).
+#include "aesgcm_dev.h"
+#include "../../include/aesgcm.h"
+
+#include <mutex>
+#include <new>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+// ------------------------------------------------------------------------------------------------
+__global__ void k_init_tables(DevTables *t) {
+    u32 x = threadIdx.x;
+    u32 s = sbox_calc(x);
+    t->sbox[x] = (uint8_t)s;
+    t->te0[x] = te0_calc(s);
+}
+
+// one GF multiply per thread: z[i] = x[i] * h[i]   (aesgcm_gfmul; replaces src/ghash_gfmul.vhd:37-64)
+__global__ void k_gfmul(const uint4 *h, const uint4 *x, uint4 *z, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) z[i] = gf_mul_mo(x[i], h[i]);
+}
+
+__global__ void k_fill_splitmix64(u64 *buf, size_t n_words, size_t tail_bytes, u64 seed, u64 first_word) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += stride)
+        buf[i] = splitmix64_at(seed, first_word + i);
+    if (tail_bytes && blockIdx.x == 0 && threadIdx.x == 0) {
+        u64 z = splitmix64_at(seed, first_word + n_words);
+        unsigned char *p = reinterpret_cast<unsigned char *>(buf + n_words);
+        for (size_t k = 0; k < tail_bytes; k++) p[k] = (unsigned char)(z >> (8 * k));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_setup: one workgroup of 512 lanes, once per key.
+//   lane 0      : key schedule (aes_kexp) or pre-expanded copy, H = E_K(0)  (gcm_gctr.vhd:141-144)
+//   all lanes   : four 513-entry power tables by doubling (9 multiply levels each), bp2, nibble table of K.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_setup(KeyMaterial *km, const DevTables *tb, const uint8_t *key, int key_len,
+                                               int preexpanded_nr, u32 G) {
+    __shared__ uint4 tab[513];
+    __shared__ uint8_t s_sbox[256];
+    const int tid = threadIdx.x;
+    if (tid < 256) s_sbox[tid] = tb->sbox[tid];
+    __syncthreads();
+    if (tid == 0) setup_lane0(km, s_sbox, key, key_len, preexpanded_nr, G, tab);
+    __syncthreads();
+    for (int d = 0; d < 4; d++) {
+        for (int j = 0; j < 9; j++) {
+            uint4 prod;
+            const bool act = setup_level(tab, j, tid, &prod);
+            __syncthreads();
+            if (act) tab[(1 << j) + tid] = prod;
+            __syncthreads();
+        }
+        for (int k = tid; k < 513; k += 512) km->pw[d][k] = tab[k];
+        __syncthreads();
+        if (d == 1) setup_beta_lane(km, tab, tid);
+        if (d < 3) {
+            uint4 next = tab[512];
+            __syncthreads();
+            if (tid == 0) { tab[0] = gf_one_mo(); tab[1] = next; }
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_main: the fused hot path.  One 16-byte block per lane per iteration (lane body: main_lane()).
+// ------------------------------------------------------------------------------------------------
+template <int NR, int MODE>
+__global__ __launch_bounds__(AESGCM_WG, 4) void k_main(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const MainParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr bool GH = (MODE == MODE_ENC || MODE == MODE_DEC);
+    const u32 tid = threadIdx.x;
+    main_fill_lds(smem, km, tb, tid, GH);
+    __syncthreads();
+    const uint4 acc = main_lane<NR, MODE>(km, p, smem, blockIdx.x, tid);
+    if (GH) {
+        G128 z = main_lane_tail(km, acc, tid);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            z.w[0] ^= __shfl_xor(z.w[0], off); z.w[1] ^= __shfl_xor(z.w[1], off);
+            z.w[2] ^= __shfl_xor(z.w[2], off); z.w[3] ^= __shfl_xor(z.w[3], off);
+        }
+        __syncthreads();                               // every wave is done with the LDS tables
+        uint4 *red = reinterpret_cast<uint4 *>(smem);
+        if ((tid & 63u) == 0) red[tid >> 6] = be_to_mo(z);
+        __syncthreads();
+        if (tid == 0) {
+            uint4 r = red[0];
+            for (int k = 1; k < AESGCM_WG / 64; k++) r = xor4(r, red[k]);
+            p.parts[blockIdx.x] = r;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_combine: one workgroup, per message.
+//   acc = sum_g parts[g] * M_g  where M_g = beta^(np-1-g) (local partials) or 1 (gathered, already weighted)
+//   POLY: out = acc * H^e                                (shard partial W_g, streaming state, aesgcm_ghash)
+//   TAG : out = acc*H^2 ^ L*H ^ E_K(IV||1)               (gcm_ghash.vhd:257 length block, :293 tag)
+//   a previous chaining value `carry` (streaming) enters as carry * H^(e_carry).
+// ------------------------------------------------------------------------------------------------
+// product of the four radix-512 digit entries of H^e, computed by lanes 0..3 of a wave + 2 tree levels
+__device__ __forceinline__ G128 gf_pow_h(const KeyMaterial *km, u64 e, u32 lane) {
+    G128 v = mo_to_be(gf_one_mo());
+    if (lane < 4) v = gf_pow_h_digit(km, e, lane);
+    for (int off = 1; off <= 2; off <<= 1) {
+        G128 o;
+        o.w[0] = __shfl_xor(v.w[0], off); o.w[1] = __shfl_xor(v.w[1], off);
+        o.w[2] = __shfl_xor(v.w[2], off); o.w[3] = __shfl_xor(v.w[3], off);
+        v = gf_mul(v, o);
+    }
+    return v;       // lanes 0..3 all hold the product
+}
+
+__global__ __launch_bounds__(COMBINE_THREADS) void k_combine(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const CombineParams p) {
+    __shared__ uint4 red[COMBINE_THREADS / 64];
+    __shared__ uint8_t s_sbox[256];
+    const u32 tid = threadIdx.x;
+    if (tid < 256) s_sbox[tid] = tb->sbox[tid];
+    __syncthreads();
+    G128 z = combine_lane(km, s_sbox, p, tid);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        z.w[0] ^= __shfl_xor(z.w[0], off); z.w[1] ^= __shfl_xor(z.w[1], off);
+        z.w[2] ^= __shfl_xor(z.w[2], off); z.w[3] ^= __shfl_xor(z.w[3], off);
+    }
+    if ((tid & 63u) == 0) red[tid >> 6] = be_to_mo(z);
+    __syncthreads();
+    if (tid < 64) {
+        uint4 r = red[0];
+        for (int k = 1; k < COMBINE_THREADS / 64; k++) r = xor4(r, red[k]);
+        G128 acc = mo_to_be(r);
+        const bool tag = p.want_tag != 0;
+        if (!tag && p.e) acc = gf_mul(acc, gf_pow_h(km, p.e, tid));
+        if (p.has_carry) {
+            G128 c = mo_to_be(*p.carry);
+            if (p.e_carry) c = gf_mul(c, gf_pow_h(km, p.e_carry, tid));
+            // TAG mode: the carried value is a plain polynomial prefix, it still needs * H^2
+            if (tag) c = gf_mul(c, mo_to_be(km->pw[0][2]));
+            acc.w[0] ^= c.w[0]; acc.w[1] ^= c.w[1]; acc.w[2] ^= c.w[2]; acc.w[3] ^= c.w[3];
+        }
+        if (tid == 0) *p.out = be_to_mo(acc);
+    }
+}
+
+// ================================================================================================
+// host side
+// ================================================================================================
+static thread_local char g_err[256] = "";
+static int hip_fail(hipError_t e, const char *what) {
+    snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
+    return AESGCM_EHIP;
+}
+#define HIPCHK(call) do { hipError_t _e = (call); if (_e != hipSuccess) return hip_fail(_e, #call); } while (0)
+
+struct DeviceState { DevTables *tables = nullptr; int n_cu = 0; bool attrs = false; };
+static std::mutex g_mu;
+static std::vector<DeviceState> g_dev;
+
+static int device_state(int device, DeviceState **out) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int n = 0;
+    HIPCHK(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) { snprintf(g_err, sizeof g_err, "device %d out of range (%d visible)", device, n); return AESGCM_EHIP; }
+    if ((int)g_dev.size() < n) g_dev.resize(n);
+    DeviceState &d = g_dev[device];
+    if (!d.tables) {
+        HIPCHK(hipSetDevice(device));
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, device));
+        d.n_cu = prop.multiProcessorCount;
+        DevTables *t = nullptr;
+        HIPCHK(hipMalloc(&t, sizeof(DevTables)));
+        hipLaunchKernelGGL(k_init_tables, dim3(1), dim3(256), 0, 0, t);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipDeviceSynchronize());
+        d.tables = t;
+    }
+    *out = &d;
+    return AESGCM_OK;
+}
+
+struct aesgcm_ctx {
+    int device = 0;
+    int nr = 0;
+    int G = 0;                         // workgroups per full launch
+    DevTables *tables = nullptr;
+    KeyMaterial *km = nullptr;
+    uint4 *parts = nullptr;            // G partials
+    uint4 *d_tag = nullptr;            // [0] tag / poly result, [1] streaming state Y
+    hipStream_t stream = nullptr;
+    // host-API staging
+    unsigned char *st_in = nullptr, *st_out = nullptr, *st_aad = nullptr;
+    size_t st_in_cap = 0, st_out_cap = 0, st_aad_cap = 0;
+    // streaming state
+    bool s_active = false, s_data = false, s_ragged = false;
+    int s_dec = 0;
+    uint8_t s_iv[12];
+    u64 s_aad_len = 0, s_len = 0, s_blocks = 0;   // s_blocks = GHASH blocks absorbed so far
+    // timing
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+};
+
+static inline hipStream_t pick_stream(aesgcm_ctx *c, void *s) { return s ? (hipStream_t)s : c->stream; }
+
+static const u64 MAX_DATA = (((u64)1) << 36) - 32;      // aes_icb.vhd:114
+static const u64 MAX_SEQ_BLOCKS = ((u64)1) << 36;
+
+template <int MODE>
+static hipError_t launch_main_nr(int nr, dim3 grid, hipStream_t st, const KeyMaterial *km, const DevTables *tb, const MainParams &p) {
+    switch (nr) {
+    case 10: hipLaunchKernelGGL((k_main<10, MODE>), grid, dim3(AESGCM_WG), AESGCM_LDS_BYTES, st, km, tb, p); break;
+    case 12: hipLaunchKernelGGL((k_main<12, MODE>), grid, dim3(AESGCM_WG), AESGCM_LDS_BYTES, st, km, tb, p); break;
+    default: hipLaunchKernelGGL((k_main<14, MODE>), grid, dim3(AESGCM_WG), AESGCM_LDS_BYTES, st, km, tb, p); break;
+    }
+    return hipGetLastError();
+}
+static hipError_t launch_main(int mode, int nr, dim3 grid, hipStream_t st, const KeyMaterial *km, const DevTables *tb, const MainParams &p) {
+    switch (mode) {
+    case MODE_ENC: return launch_main_nr<MODE_ENC>(nr, grid, st, km, tb, p);
+    case MODE_DEC: return launch_main_nr<MODE_DEC>(nr, grid, st, km, tb, p);
+    case MODE_KS:  return launch_main_nr<MODE_KS>(nr, grid, st, km, tb, p);
+    default:       return launch_main_nr<MODE_ECB>(nr, grid, st, km, tb, p);
+    }
+}
+
+static int set_lds_attrs(int device, DeviceState *ds) {
+    // 72 KiB of dynamic LDS per workgroup exceeds the 64 KiB default cap: opt in once per kernel instance and device.
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (ds->attrs) return AESGCM_OK;
+    HIPCHK(hipSetDevice(device));
+#define SETATTR(NR, MODE) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_main<NR, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, AESGCM_LDS_BYTES))
+    SETATTR(10, MODE_ENC); SETATTR(12, MODE_ENC); SETATTR(14, MODE_ENC);
+    SETATTR(10, MODE_DEC); SETATTR(12, MODE_DEC); SETATTR(14, MODE_DEC);
+    SETATTR(10, MODE_KS);  SETATTR(12, MODE_KS);  SETATTR(14, MODE_KS);
+    SETATTR(10, MODE_ECB); SETATTR(12, MODE_ECB); SETATTR(14, MODE_ECB);
+#undef SETATTR
+    ds->attrs = true;
+    return AESGCM_OK;
+}
+
+// Enqueue the fused kernel over (aad, data) and return the number of partials it wrote.
+// mode ENC/DEC: GHASH partials into c->parts.  mode KS/ECB: no GHASH.
+static int enqueue_main(aesgcm_ctx *c, int mode, const uint8_t iv[12], const void *d_aad, u64 aad_len,
+                        const void *d_in, u64 len, void *d_out, u64 first_block, hipStream_t st, u32 *np_out) {
+    const bool gh = (mode == MODE_ENC || mode == MODE_DEC);
+    if (np_out) *np_out = 0;
+    if (((uintptr_t)d_in & 15) || ((uintptr_t)d_out & 15)) return AESGCM_EALIGN;
+    MainParams p;
+    memset(&p, 0, sizeof p);
+    const u32 Gp = plan_main(p, mode, (u32)c->G, iv, d_aad, aad_len, d_in, len, d_out, first_block, c->parts);
+    if (!Gp) return AESGCM_OK;
+    std::pair<hipEvent_t, hipEvent_t> evp;
+    if (c->timing) {
+        if (!c->ev_pool.empty()) { evp = c->ev_pool.back(); c->ev_pool.pop_back(); }
+        else { HIPCHK(hipEventCreate(&evp.first)); HIPCHK(hipEventCreate(&evp.second)); }
+        HIPCHK(hipEventRecord(evp.first, st));
+    }
+    HIPCHK(launch_main(mode, c->nr, dim3((unsigned)Gp), st, c->km, c->tables, p));
+    if (c->timing) { HIPCHK(hipEventRecord(evp.second, st)); c->ev.push_back(evp); }
+    if (np_out) *np_out = gh ? (u32)Gp : 0;
+    return AESGCM_OK;
+}
+
+static int enqueue_combine(aesgcm_ctx *c, const CombineParams &p, hipStream_t st) {
+    hipLaunchKernelGGL(k_combine, dim3(1), dim3(COMBINE_THREADS), 0, st, c->km, c->tables, p);
+    HIPCHK(hipGetLastError());
+    return AESGCM_OK;
+}
+
+static int check_lengths(u64 aad_len, u64 len) {
+    if (len > MAX_DATA) return AESGCM_ETOOLONG;
+    if ((aad_len + 15) / 16 + (len + 15) / 16 >= MAX_SEQ_BLOCKS) return AESGCM_ETOOLONG;
+    return AESGCM_OK;
+}
+
+// whole message on device pointers; leaves the tag in c->d_tag[0]
+static int crypt_dev(aesgcm_ctx *c, int dec, const uint8_t iv[12], const void *d_aad, u64 aad_len,
+                     const void *d_in, u64 len, void *d_out, hipStream_t st) {
+    int rc = check_lengths(aad_len, len);
+    if (rc) return rc;
+    if (aad_len && !d_aad) return AESGCM_EARG;
+    if (len && (!d_in || !d_out)) return AESGCM_EARG;
+    HIPCHK(hipSetDevice(c->device));
+    u32 np = 0;
+    rc = enqueue_main(c, dec ? MODE_DEC : MODE_ENC, iv, d_aad, aad_len, d_in, len, d_out, 0, st, &np);
+    if (rc) return rc;
+    return enqueue_combine(c, plan_combine_tag(c->parts, np, false, iv, aad_len, len, c->d_tag), st);
+}
+
+static int ct_compare16(const uint8_t *a, const uint8_t *b) {
+    unsigned d = 0;
+    for (int i = 0; i < 16; i++) d |= (unsigned)(a[i] ^ b[i]);
+    return d == 0;
+}
+
+static int grow(unsigned char **p, size_t *cap, size_t need) {
+    if (need <= *cap) return AESGCM_OK;
+    if (*p) { hipError_t e = hipFree(*p); *p = nullptr; *cap = 0; if (e != hipSuccess) return hip_fail(e, "hipFree"); }
+    size_t n = need < 4096 ? 4096 : need;
+    hipError_t e = hipMalloc((void **)p, n);
+    if (e == hipErrorOutOfMemory) return AESGCM_ENOMEM;
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc");
+    *cap = n;
+    return AESGCM_OK;
+}
+
+extern "C" {
+
+int aesgcm_abi_version(void) { return AESGCM_ABI_VERSION; }
+
+const char *aesgcm_strerror(int code) {
+    switch (code) {
+    case AESGCM_OK: return "ok";
+    case AESGCM_EARG: return "invalid argument";
+    case AESGCM_EKEYLEN: return "key length must be 16, 24 or 32 bytes";
+    case AESGCM_EIVLEN: return "IV must be 12 bytes";
+    case AESGCM_ETOOLONG: return "message exceeds the GCM counter space (2^36 - 32 bytes)";
+    case AESGCM_EAUTH: return "authentication tag mismatch";
+    case AESGCM_EHIP: return "HIP runtime error (see aesgcm_last_error)";
+    case AESGCM_ENOMEM: return "out of device memory";
+    case AESGCM_ESTATE: return "streaming call out of order";
+    case AESGCM_EALIGN: return "device data pointer must be 16-byte aligned";
+    default: return "unknown error";
+    }
+}
+const char *aesgcm_last_error(void) { return g_err; }
+
+int aesgcm_device_count(int *n) {
+    if (!n) return AESGCM_EARG;
+    HIPCHK(hipGetDeviceCount(n));
+    return AESGCM_OK;
+}
+int aesgcm_device_name(int device, char *buf, size_t buflen) {
+    if (!buf || !buflen) return AESGCM_EARG;
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    snprintf(buf, buflen, "%s %s (%d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return AESGCM_OK;
+}
+
+static int ctx_create_common(aesgcm_ctx **out, int device, const uint8_t *key, size_t key_len, int pre_nr) {
+    if (!out || !key) return AESGCM_EARG;
+    *out = nullptr;
+    DeviceState *ds;
+    int rc = device_state(device, &ds);
+    if (rc) return rc;
+    rc = set_lds_attrs(device, ds);
+    if (rc) return rc;
+    aesgcm_ctx *c = new (std::nothrow) aesgcm_ctx();
+    if (!c) return AESGCM_ENOMEM;
+    c->device = device;
+    c->tables = ds->tables;
+    c->nr = pre_nr ? pre_nr : (int)(key_len / 4 + 6);
+    int G = 2 * ds->n_cu;
+    if (G > AESGCM_GMAX) G = AESGCM_GMAX;
+    if (G < 1) G = 1;
+    c->G = G;
+    HIPCHK(hipSetDevice(device));
+    hipError_t e;
+    if ((e = hipStreamCreate(&c->stream)) != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate"); }
+    if ((e = hipMalloc(&c->km, sizeof(KeyMaterial))) != hipSuccess ||
+        (e = hipMalloc(&c->parts, sizeof(uint4) * AESGCM_GMAX)) != hipSuccess ||
+        (e = hipMalloc(&c->d_tag, sizeof(uint4) * 4)) != hipSuccess) { aesgcm_ctx_destroy(c); return hip_fail(e, "hipMalloc"); }
+    uint8_t *d_key = nullptr;
+    size_t kb = pre_nr ? (size_t)16 * (pre_nr + 1) : key_len;
+    if ((e = hipMalloc(&d_key, 256)) != hipSuccess) { aesgcm_ctx_destroy(c); return hip_fail(e, "hipMalloc"); }
+    e = hipMemcpyAsync(d_key, key, kb, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_setup, dim3(1), dim3(512), 0, c->stream, c->km, c->tables, d_key, (int)key_len, pre_nr, (u32)G);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemsetAsync(d_key, 0, 256, c->stream);    // do not leave key bytes behind
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d_key);
+    if (e != hipSuccess) { aesgcm_ctx_destroy(c); return hip_fail(e, "k_setup"); }
+    *out = c;
+    return AESGCM_OK;
+}
+
+int aesgcm_ctx_create(aesgcm_ctx **out, int device, const uint8_t *key, size_t key_len) {
+    if (key_len != 16 && key_len != 24 && key_len != 32) return AESGCM_EKEYLEN;
+    return ctx_create_common(out, device, key, key_len, 0);
+}
+int aesgcm_ctx_create_preexpanded(aesgcm_ctx **out, int device, const uint8_t *rk, int nr) {
+    if (nr != 10 && nr != 12 && nr != 14) return AESGCM_EKEYLEN;
+    return ctx_create_common(out, device, rk, (size_t)(4 * (nr - 6)), nr);
+}
+int aesgcm_ctx_destroy(aesgcm_ctx *c) {
+    if (!c) return AESGCM_OK;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (auto &e : c->ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    for (auto &e : c->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    if (c->km) { hipMemset(c->km, 0, sizeof(KeyMaterial)); hipFree(c->km); }
+    if (c->parts) hipFree(c->parts);
+    if (c->d_tag) hipFree(c->d_tag);
+    if (c->st_in) hipFree(c->st_in);
+    if (c->st_out) hipFree(c->st_out);
+    if (c->st_aad) hipFree(c->st_aad);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return AESGCM_OK;
+}
+int aesgcm_ctx_device(const aesgcm_ctx *c) { return c ? c->device : AESGCM_EARG; }
+int aesgcm_ctx_geometry(const aesgcm_ctx *c, int *n_wg, int *wg_lanes, int *lds_bytes) {
+    if (!c) return AESGCM_EARG;
+    if (n_wg) *n_wg = c->G;
+    if (wg_lanes) *wg_lanes = AESGCM_WG;
+    if (lds_bytes) *lds_bytes = AESGCM_LDS_BYTES;
+    return AESGCM_OK;
+}
+
+// ---------------------------------------------------------------- unit-level
+int aesgcm_key_expand(int device, const uint8_t *key, size_t key_len, uint8_t rk[240], int *nr) {
+    if (!key || !rk) return AESGCM_EARG;
+    if (key_len != 16 && key_len != 24 && key_len != 32) return AESGCM_EKEYLEN;
+    aesgcm_ctx *c = nullptr;
+    int rc = aesgcm_ctx_create(&c, device, key, key_len);
+    if (rc) return rc;
+    hipError_t e = hipMemcpy(rk, c->km->rk_bytes, (size_t)16 * (c->nr + 1), hipMemcpyDeviceToHost);
+    if (nr) *nr = c->nr;
+    aesgcm_ctx_destroy(c);
+    if (e != hipSuccess) return hip_fail(e, "hipMemcpy");
+    return AESGCM_OK;
+}
+
+int aesgcm_get_h(aesgcm_ctx *c, uint8_t h[16]) {
+    if (!c || !h) return AESGCM_EARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpy(h, &c->km->h, 16, hipMemcpyDeviceToHost));
+    return AESGCM_OK;
+}
+
+int aesgcm_gfmul(int device, const uint8_t *h, const uint8_t *x, uint8_t *z, size_t n) {
+    if (!h || !x || !z) return AESGCM_EARG;
+    if (!n) return AESGCM_OK;
+    DeviceState *ds;
+    int rc = device_state(device, &ds);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(device));
+    uint4 *d = nullptr;
+    HIPCHK(hipMalloc(&d, 48 * n));
+    hipError_t e = hipMemcpy(d, h, 16 * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + n, x, 16 * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_gfmul, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d, d + n, d + 2 * n, n);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(z, d + 2 * n, 16 * n, hipMemcpyDeviceToHost);
+    hipFree(d);
+    if (e != hipSuccess) return hip_fail(e, "aesgcm_gfmul");
+    return AESGCM_OK;
+}
+
+// ---------------------------------------------------------------- host-pointer wrappers
+static int stage_in(aesgcm_ctx *c, const uint8_t *aad, size_t aad_len, const uint8_t *in, size_t len) {
+    int rc;
+    if ((rc = grow(&c->st_aad, &c->st_aad_cap, aad_len))) return rc;
+    if ((rc = grow(&c->st_in, &c->st_in_cap, len))) return rc;
+    if ((rc = grow(&c->st_out, &c->st_out_cap, len))) return rc;
+    if (aad_len) HIPCHK(hipMemcpyAsync(c->st_aad, aad, aad_len, hipMemcpyHostToDevice, c->stream));
+    if (len) HIPCHK(hipMemcpyAsync(c->st_in, in, len, hipMemcpyHostToDevice, c->stream));
+    return AESGCM_OK;
+}
+
+int aesgcm_encrypt_dev(aesgcm_ctx *c, const uint8_t iv[12], const void *d_aad, size_t aad_len,
+                       const void *d_pt, size_t len, void *d_ct, uint8_t tag[16], void *stream) {
+    if (!c || !iv) return AESGCM_EARG;
+    hipStream_t st = pick_stream(c, stream);
+    int rc = crypt_dev(c, 0, iv, d_aad, aad_len, d_pt, len, d_ct, st);
+    if (rc) return rc;
+    if (tag) { HIPCHK(hipMemcpyAsync(tag, c->d_tag, 16, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st)); }
+    return AESGCM_OK;
+}
+int aesgcm_decrypt_dev(aesgcm_ctx *c, const uint8_t iv[12], const void *d_aad, size_t aad_len,
+                       const void *d_ct, size_t len, void *d_pt, const uint8_t *expect_tag, uint8_t tag_out[16], void *stream) {
+    if (!c || !iv) return AESGCM_EARG;
+    hipStream_t st = pick_stream(c, stream);
+    int rc = crypt_dev(c, 1, iv, d_aad, aad_len, d_ct, len, d_pt, st);
+    if (rc) return rc;
+    if (tag_out || expect_tag) {
+        uint8_t t[16];
+        HIPCHK(hipMemcpyAsync(t, c->d_tag, 16, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (tag_out) memcpy(tag_out, t, 16);
+        if (expect_tag && !ct_compare16(t, expect_tag)) return AESGCM_EAUTH;
+    }
+    return AESGCM_OK;
+}
+int aesgcm_last_tag(aesgcm_ctx *c, uint8_t tag[16], void *stream) {
+    if (!c || !tag) return AESGCM_EARG;
+    hipStream_t st = pick_stream(c, stream);
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(tag, c->d_tag, 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return AESGCM_OK;
+}
+
+int aesgcm_encrypt(aesgcm_ctx *c, const uint8_t iv[12], const uint8_t *aad, size_t aad_len,
+                   const uint8_t *pt, size_t len, uint8_t *ct, uint8_t tag[16]) {
+    if (!c || !iv || !tag || (aad_len && !aad) || (len && (!pt || !ct))) return AESGCM_EARG;
+    int rc = check_lengths(aad_len, len);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(c->device));
+    if ((rc = stage_in(c, aad, aad_len, pt, len))) return rc;
+    if ((rc = crypt_dev(c, 0, iv, c->st_aad, aad_len, c->st_in, len, c->st_out, c->stream))) return rc;
+    if (len) HIPCHK(hipMemcpyAsync(ct, c->st_out, len, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(tag, c->d_tag, 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return AESGCM_OK;
+}
+int aesgcm_decrypt(aesgcm_ctx *c, const uint8_t iv[12], const uint8_t *aad, size_t aad_len,
+                   const uint8_t *ct, size_t len, uint8_t *pt, const uint8_t *expect_tag, uint8_t tag_out[16]) {
+    if (!c || !iv || (aad_len && !aad) || (len && (!ct || !pt))) return AESGCM_EARG;
+    int rc = check_lengths(aad_len, len);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(c->device));
+    if ((rc = stage_in(c, aad, aad_len, ct, len))) return rc;
+    if ((rc = crypt_dev(c, 1, iv, c->st_aad, aad_len, c->st_in, len, c->st_out, c->stream))) return rc;
+    uint8_t t[16];
+    if (len) HIPCHK(hipMemcpyAsync(pt, c->st_out, len, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(t, c->d_tag, 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (tag_out) memcpy(tag_out, t, 16);
+    if (expect_tag && !ct_compare16(t, expect_tag)) return AESGCM_EAUTH;
+    return AESGCM_OK;
+}
+
+int aesgcm_ecb_encrypt(aesgcm_ctx *c, const uint8_t *in, size_t nblocks, uint8_t *out) {
+    if (!c || (nblocks && (!in || !out))) return AESGCM_EARG;
+    if (!nblocks) return AESGCM_OK;
+    HIPCHK(hipSetDevice(c->device));
+    int rc;
+    if ((rc = stage_in(c, nullptr, 0, in, 16 * nblocks))) return rc;
+    if ((rc = enqueue_main(c, MODE_ECB, nullptr, nullptr, 0, c->st_in, 16 * (u64)nblocks, c->st_out, 0, c->stream, nullptr))) return rc;
+    HIPCHK(hipMemcpyAsync(out, c->st_out, 16 * nblocks, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return AESGCM_OK;
+}
+
+int aesgcm_keystream_dev(aesgcm_ctx *c, const uint8_t iv[12], uint64_t first_block, uint64_t nblocks, void *d_out, void *stream) {
+    if (!c || !iv || (nblocks && !d_out)) return AESGCM_EARG;
+    if (first_block + nblocks > (((u64)1) << 32) - 2) return AESGCM_ETOOLONG;
+    if (!nblocks) return AESGCM_OK;
+    HIPCHK(hipSetDevice(c->device));
+    return enqueue_main(c, MODE_KS, iv, nullptr, 0, d_out /*unused in*/, 16 * nblocks, d_out, first_block, pick_stream(c, stream), nullptr);
+}
+int aesgcm_keystream(aesgcm_ctx *c, const uint8_t iv[12], uint64_t first_block, uint64_t nblocks, uint8_t *out) {
+    if (!c || !iv || (nblocks && !out)) return AESGCM_EARG;
+    if (!nblocks) return AESGCM_OK;
+    HIPCHK(hipSetDevice(c->device));
+    int rc;
+    if ((rc = grow(&c->st_out, &c->st_out_cap, 16 * nblocks))) return rc;
+    if ((rc = aesgcm_keystream_dev(c, iv, first_block, nblocks, c->st_out, nullptr))) return rc;
+    HIPCHK(hipMemcpyAsync(out, c->st_out, 16 * nblocks, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return AESGCM_OK;
+}
+
+int aesgcm_ghash(aesgcm_ctx *c, const uint8_t *data, size_t len, uint8_t y[16]) {
+    if (!c || !y || (len && !data)) return AESGCM_EARG;
+    if ((len + 15) / 16 >= MAX_SEQ_BLOCKS) return AESGCM_ETOOLONG;
+    HIPCHK(hipSetDevice(c->device));
+    int rc;
+    if ((rc = stage_in(c, data, len, nullptr, 0))) return rc;
+    u32 np = 0;
+    uint8_t iv0[12] = {0};
+    // the data rides in the AAD slot of the GHASH sequence (GHASH only, no AES)
+    if ((rc = enqueue_main(c, MODE_ENC, iv0, c->st_aad, len, c->st_in, 0, c->st_out, 0, c->stream, &np))) return rc;
+    if ((rc = enqueue_combine(c, plan_combine_poly(c->parts, np, 1, c->d_tag), c->stream))) return rc;   // Y = P * H
+    HIPCHK(hipMemcpyAsync(y, c->d_tag, 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return AESGCM_OK;
+}
+
+// ---------------------------------------------------------------- shards
+int aesgcm_shard_crypt_dev(aesgcm_ctx *c, int decrypt, const uint8_t iv[12], const void *d_aad, size_t aad_len,
+                           const void *d_in, size_t len, void *d_out, uint64_t first_block, uint64_t total_len,
+                           void *d_partial, void *stream) {
+    if (!c || !iv || !d_partial || (len && (!d_in || !d_out))) return AESGCM_EARG;
+    int rc = check_lengths(first_block == 0 ? aad_len : 0, total_len);
+    if (rc) return rc;
+    const u64 total_blocks = (total_len + 15) / 16;
+    const u64 my_blocks = ((u64)len + 15) / 16;
+    if (first_block + my_blocks > total_blocks) return AESGCM_EARG;
+    if ((len & 15) && first_block + my_blocks != total_blocks) return AESGCM_EARG;   // only the last shard may be ragged
+    if (first_block != 0 && aad_len) return AESGCM_EARG;
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = pick_stream(c, stream);
+    u32 np = 0;
+    if ((rc = enqueue_main(c, decrypt ? MODE_DEC : MODE_ENC, iv, d_aad, aad_len, d_in, len, d_out, first_block, st, &np))) return rc;
+    return enqueue_combine(c, plan_combine_poly(c->parts, np, total_blocks - (first_block + my_blocks), (uint4 *)d_partial), st);
+}
+int aesgcm_shard_finalize_dev(aesgcm_ctx *c, const uint8_t iv[12], const void *d_partials, size_t n_partials,
+                              size_t aad_len, uint64_t total_len, uint8_t tag[16], void *stream) {
+    if (!c || !iv || (n_partials && !d_partials) || n_partials > AESGCM_GMAX) return AESGCM_EARG;
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = pick_stream(c, stream);
+    int rc = enqueue_combine(c, plan_combine_tag((const uint4 *)d_partials, (u32)n_partials, true, iv, aad_len, total_len, c->d_tag), st);
+    if (rc) return rc;
+    if (tag) { HIPCHK(hipMemcpyAsync(tag, c->d_tag, 16, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st)); }
+    return AESGCM_OK;
+}
+
+// ---------------------------------------------------------------- streaming
+// state Y (c->d_tag[1]) = polynomial of everything absorbed so far: sum X_i H^(n-1-i)
+int aesgcm_stream_begin(aesgcm_ctx *c, const uint8_t iv[12], int decrypt) {
+    if (!c || !iv) return AESGCM_EARG;
+    HIPCHK(hipSetDevice(c->device));
+    memcpy(c->s_iv, iv, 12);
+    c->s_active = true; c->s_data = false; c->s_ragged = false; c->s_dec = decrypt ? 1 : 0;
+    c->s_aad_len = 0; c->s_len = 0; c->s_blocks = 0;
+    HIPCHK(hipMemsetAsync(c->d_tag + 1, 0, 16, c->stream));
+    return AESGCM_OK;
+}
+static int stream_absorb(aesgcm_ctx *c, const void *d_aad, u64 aad_len, const void *d_in, u64 len, void *d_out, u64 first_block) {
+    u32 np = 0;
+    int rc = enqueue_main(c, c->s_dec ? MODE_DEC : MODE_ENC, c->s_iv, d_aad, aad_len, d_in, len, d_out, first_block, c->stream, &np);
+    if (rc) return rc;
+    const u64 nb = (aad_len + 15) / 16 + (len + 15) / 16;
+    c->s_blocks += nb;
+    return enqueue_combine(c, plan_combine_carry(c->parts, np, c->d_tag + 1, nb), c->stream);       // Y' = Y * H^nb ^ P
+}
+int aesgcm_stream_aad(aesgcm_ctx *c, const uint8_t *aad, size_t len) {
+    if (!c || (len && !aad)) return AESGCM_EARG;
+    if (!c->s_active || c->s_data || c->s_ragged) return AESGCM_ESTATE;
+    if (!len) return AESGCM_OK;
+    if (check_lengths(c->s_aad_len + len, 0)) return AESGCM_ETOOLONG;
+    HIPCHK(hipSetDevice(c->device));
+    int rc;
+    if ((rc = stage_in(c, aad, len, nullptr, 0))) return rc;
+    if ((rc = stream_absorb(c, c->st_aad, len, c->st_in, 0, c->st_out, 0))) return rc;
+    c->s_aad_len += len;
+    if (len & 15) c->s_ragged = true;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return AESGCM_OK;
+}
+int aesgcm_stream_update(aesgcm_ctx *c, const uint8_t *in, size_t len, uint8_t *out) {
+    if (!c || (len && (!in || !out))) return AESGCM_EARG;
+    if (!c->s_active) return AESGCM_ESTATE;
+    if (c->s_data && c->s_ragged) return AESGCM_ESTATE;      // a ragged data chunk must be the last one
+    if (!len) return AESGCM_OK;
+    if (check_lengths(c->s_aad_len, c->s_len + len)) return AESGCM_ETOOLONG;
+    HIPCHK(hipSetDevice(c->device));
+    int rc;
+    if ((rc = stage_in(c, nullptr, 0, in, len))) return rc;
+    c->s_ragged = false;
+    if ((rc = stream_absorb(c, nullptr, 0, c->st_in, len, c->st_out, c->s_len / 16))) return rc;
+    c->s_data = true;
+    c->s_len += len;
+    if (len & 15) c->s_ragged = true;
+    HIPCHK(hipMemcpyAsync(out, c->st_out, len, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return AESGCM_OK;
+}
+int aesgcm_stream_final(aesgcm_ctx *c, uint8_t tag[16]) {
+    if (!c || !tag) return AESGCM_EARG;
+    if (!c->s_active) return AESGCM_ESTATE;
+    HIPCHK(hipSetDevice(c->device));
+    int rc = enqueue_combine(c, plan_combine_final(c->d_tag + 1, c->s_iv, c->s_aad_len, c->s_len, c->d_tag), c->stream);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(tag, c->d_tag, 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->s_active = false;
+    return AESGCM_OK;
+}
+
+// ---------------------------------------------------------------- memory helpers
+int aesgcm_dev_alloc(int device, void **p, size_t bytes) {
+    if (!p) return AESGCM_EARG;
+    HIPCHK(hipSetDevice(device));
+    hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+    if (e == hipErrorOutOfMemory) return AESGCM_ENOMEM;
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc");
+    return AESGCM_OK;
+}
+int aesgcm_dev_free(int device, void *p) {
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipFree(p));
+    return AESGCM_OK;
+}
+int aesgcm_dev_upload(int device, void *d, const void *h, size_t n) {
+    HIPCHK(hipSetDevice(device));
+    if (n) HIPCHK(hipMemcpy(d, h, n, hipMemcpyHostToDevice));
+    return AESGCM_OK;
+}
+int aesgcm_dev_download(int device, void *h, const void *d, size_t n) {
+    HIPCHK(hipSetDevice(device));
+    if (n) HIPCHK(hipMemcpy(h, d, n, hipMemcpyDeviceToHost));
+    return AESGCM_OK;
+}
+int aesgcm_dev_sync(int device) {
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipDeviceSynchronize());
+    return AESGCM_OK;
+}
+int aesgcm_fill_splitmix64_dev(int device, void *d_buf, size_t len, uint64_t seed, uint64_t first_word, void *stream) {
+    if (len && !d_buf) return AESGCM_EARG;
+    if ((uintptr_t)d_buf & 7) return AESGCM_EALIGN;
+    if (!len) return AESGCM_OK;
+    HIPCHK(hipSetDevice(device));
+    size_t nw = len / 8;
+    size_t blocks = (nw + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_fill_splitmix64, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (u64 *)d_buf, nw, len & 7, seed, first_word);
+    HIPCHK(hipGetLastError());
+    return AESGCM_OK;
+}
+
+// ---------------------------------------------------------------- timing
+int aesgcm_ctx_timing_enable(aesgcm_ctx *c, int on) {
+    if (!c) return AESGCM_EARG;
+    c->timing = on != 0;
+    return AESGCM_OK;
+}
+int aesgcm_ctx_timing_read(aesgcm_ctx *c, uint64_t *n, double *total_ms, int reset) {
+    if (!c) return AESGCM_EARG;
+    HIPCHK(hipSetDevice(c->device));
+    double tot = 0;
+    for (auto &e : c->ev) {
+        HIPCHK(hipEventSynchronize(e.second));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, e.first, e.second));
+        tot += ms;
+    }
+    if (n) *n = c->ev.size();
+    if (total_ms) *total_ms = tot;
+    if (reset) { for (auto &e : c->ev) c->ev_pool.push_back(e); c->ev.clear(); }
+    return AESGCM_OK;
+}
+
+}  // extern "C"

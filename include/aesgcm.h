@@ -1,0 +1,179 @@
+/*
+ * aesgcm.h -- C ABI of libaesgcm_hip.so: MI355X (gfx950) AES-GCM bulk path.
+ *
+ * This is the drop-in boundary for the hot path of BLu85/AES-GCM-128-192-256-bits.  The reference
+ * has no FFI of its own: its software surface is the Python class tb/gcm_model.py:5-51, which
+ * forwards every call to pycryptodome (tb/gcm_model.py:18 AES.new(..MODE_GCM..), :22 update,
+ * :26 encrypt, :30 decrypt, :35 digest, :44 verify).  Each entry point below names the reference
+ * item whose arithmetic it replaces (paths relative to the reference checkout); the Python binding
+ * a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no C++/torch/HIP types in any signature
+ *     (a HIP stream is passed as void*; NULL = the context's own stream).
+ *   - every function returns AESGCM_OK (0) or a negative AESGCM_E* code; nothing throws or aborts.
+ *   - ALL cryptographic arithmetic (key expansion, H, GHASH tables, CTR, GHASH, tag) runs in HIP
+ *     kernels on the selected device.  There is no CPU fallback: without a usable HIP device every
+ *     compute entry point fails with AESGCM_EHIP.
+ *   - the caller owns every buffer it passes; the library owns only opaque contexts.
+ *   - a context is not thread-safe; distinct contexts may be used from distinct threads.
+ *   - IV is always 96 bits (src/gcm_pkg.vhd:15-17, tb/gcm_gctr.py:251); tag is the full 128 bits
+ *     (src/gcm_ghash.vhd:293).
+ *   - length rule: data <= 2^36 - 32 bytes (the 32-bit block counter stops at all-ones,
+ *     src/aes_icb.vhd:114) and AAD blocks + data blocks < 2^36 -> AESGCM_ETOOLONG otherwise.
+ */
+#ifndef AESGCM_H
+#define AESGCM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AESGCM_ABI_VERSION 1
+
+#define AESGCM_OK        0
+#define AESGCM_EARG     (-1)   /* NULL/invalid argument                                        */
+#define AESGCM_EKEYLEN  (-2)   /* key length not 16/24/32 (aes_pkg.vhd:60-63 modes 128/192/256) */
+#define AESGCM_EIVLEN   (-3)   /* reserved: IV is fixed at 12 bytes by the signatures            */
+#define AESGCM_ETOOLONG (-4)   /* message exceeds the counter space (aes_icb.vhd:114)            */
+#define AESGCM_EAUTH    (-5)   /* tag mismatch on decrypt (tb/gcm_model.py:47 ValueError branch) */
+#define AESGCM_EHIP     (-6)   /* HIP runtime error / no device; see aesgcm_last_error()         */
+#define AESGCM_ENOMEM   (-7)
+#define AESGCM_ESTATE   (-8)   /* streaming call out of order (AAD after data, ragged chunk)     */
+#define AESGCM_EALIGN   (-9)   /* device data pointer not 16-byte aligned                        */
+
+typedef struct aesgcm_ctx aesgcm_ctx;
+
+/* ---------------------------------------------------------------- library / device */
+int         aesgcm_abi_version(void);
+const char *aesgcm_strerror(int code);
+const char *aesgcm_last_error(void);              /* thread-local detail of the last AESGCM_EHIP */
+int         aesgcm_device_count(int *n);
+int         aesgcm_device_name(int device, char *buf, size_t buflen);
+
+/* ---------------------------------------------------------------- unit-level entry points
+ * One per arithmetic block of the RTL so that each can be parity-tested in isolation.  All run
+ * on the GPU (small kernels), results are copied back to the host buffers given. */
+
+/* FIPS-197 KeyExpansion.  Replaces aes_kexp (config/config_aes_kexp.py:113-159, window update
+ * :189-219) and its software twin tb/key_exp.py:79-121 aes_expand_key.  rk receives
+ * 16*(nr+1) bytes, stage i = bytes 16i..16i+15 (the layout load_pre_exp_key streams,
+ * tb/gcm_gctr.py:199-207); *nr = 10/12/14 (aes_pkg.vhd:31-33). */
+int aesgcm_key_expand(int device, const uint8_t *key, size_t key_len, uint8_t rk[240], int *nr);
+
+/* nblocks independent ECB encryptions under the context key through the same LDS T-table round
+ * code the CTR kernel uses.  Replaces aes_round x Nr + aes_last_round
+ * (config/config_aes_round.py:120-126, src/aes_last_round.vhd:76) as instantiated by aes_ecb
+ * (config/config_aes_ecb.py:250-327). */
+int aesgcm_ecb_encrypt(aesgcm_ctx *ctx, const uint8_t *in, size_t nblocks, uint8_t *out);
+
+/* n independent GF(2^128) products z[i] = x[i] * h[i] (16-byte big-endian blocks, GCM bit order).
+ * Replaces ghash_gfmul (src/ghash_gfmul.vhd:37-64). */
+int aesgcm_gfmul(int device, const uint8_t *h, const uint8_t *x, uint8_t *z, size_t n);
+
+/* GHASH chaining value after absorbing `len` bytes (last block zero-padded) from Y = 0 under the
+ * context's H = E_K(0^128):  Y_i = (Y_{i-1} xor X_i) * H  (src/gcm_ghash.vhd:174-186, :259-272),
+ * WITHOUT the length block.  Computed by the parallel H-power path, not by serial Horner. */
+int aesgcm_ghash(aesgcm_ctx *ctx, const uint8_t *data, size_t len, uint8_t y[16]);
+
+/* H = E_K(0^128) as latched by gcm_ghash (src/gcm_gctr.vhd:141-144, src/gcm_ghash.vhd:128-139). */
+int aesgcm_get_h(aesgcm_ctx *ctx, uint8_t h[16]);
+
+/* ---------------------------------------------------------------- context
+ * A context = (device, expanded key, H, H-power tables, scratch).  Creating it runs the on-GPU key
+ * expansion and table build once per key (the RTL's "load key" phase, tb/gcm_gctr.py:144-175). */
+int aesgcm_ctx_create(aesgcm_ctx **out, int device, const uint8_t *key, size_t key_len);
+/* Pre-expanded key load path (config/config_aes_kprexp.py:66-106, tb/gcm_gctr.py:180-214):
+ * rk = 16*(nr+1) bytes exactly as aesgcm_key_expand / tb/key_exp.py produce them. */
+int aesgcm_ctx_create_preexpanded(aesgcm_ctx **out, int device, const uint8_t *rk, int nr);
+int aesgcm_ctx_destroy(aesgcm_ctx *ctx);
+int aesgcm_ctx_device(const aesgcm_ctx *ctx);
+
+/* ---------------------------------------------------------------- whole messages, host pointers
+ * Replaces the model's update/encrypt/digest sequence (tb/gcm_model.py:21-35) i.e. the aes_gcm
+ * top level in encrypt mode (src/aes_gcm.vhd:207-211: GHASH consumes the GCTR output).
+ * Copies H2D/D2H around the device path below; meant for parity tests and small messages. */
+int aesgcm_encrypt(aesgcm_ctx *ctx, const uint8_t iv[12], const uint8_t *aad, size_t aad_len,
+                   const uint8_t *pt, size_t len, uint8_t *ct, uint8_t tag[16]);
+/* Decrypt mode (tb/gcm_model.py:29-30,43-51; src/aes_gcm.vhd:207-211: GHASH consumes the input).
+ * Plaintext is always written (the model emits data before the tag is checked).  tag_out (may be
+ * NULL) receives the computed tag.  If expect_tag != NULL it is compared in constant time and
+ * AESGCM_EAUTH is returned on mismatch. */
+int aesgcm_decrypt(aesgcm_ctx *ctx, const uint8_t iv[12], const uint8_t *aad, size_t aad_len,
+                   const uint8_t *ct, size_t len, uint8_t *pt, const uint8_t *expect_tag, uint8_t tag_out[16]);
+
+/* ---------------------------------------------------------------- whole messages, device pointers
+ * The benchmarked path: d_in/d_out are device pointers (16-byte aligned, may alias for in-place),
+ * d_aad a device pointer (any alignment) or NULL.  Work is enqueued on `stream` (a hipStream_t
+ * passed as void*, NULL = context stream); the only host traffic is the 16-byte tag, whose copy
+ * synchronises the stream.  Pass tag = NULL to skip the copy and the synchronisation; the tag then
+ * stays in the context and can be fetched with aesgcm_last_tag(). */
+int aesgcm_encrypt_dev(aesgcm_ctx *ctx, const uint8_t iv[12], const void *d_aad, size_t aad_len,
+                       const void *d_pt, size_t len, void *d_ct, uint8_t tag[16], void *stream);
+int aesgcm_decrypt_dev(aesgcm_ctx *ctx, const uint8_t iv[12], const void *d_aad, size_t aad_len,
+                       const void *d_ct, size_t len, void *d_pt, const uint8_t *expect_tag,
+                       uint8_t tag_out[16], void *stream);
+int aesgcm_last_tag(aesgcm_ctx *ctx, uint8_t tag[16], void *stream);
+
+/* CTR keystream blocks [first_block, first_block+nblocks): E_K(IV || (2+i) mod 2^32)
+ * (src/aes_icb.vhd:97-100,118; src/gcm_gctr.vhd:150 before the xor). */
+int aesgcm_keystream(aesgcm_ctx *ctx, const uint8_t iv[12], uint64_t first_block, uint64_t nblocks, uint8_t *out);
+int aesgcm_keystream_dev(aesgcm_ctx *ctx, const uint8_t iv[12], uint64_t first_block, uint64_t nblocks,
+                         void *d_out, void *stream);
+
+/* ---------------------------------------------------------------- one message sharded over ranks
+ * (no reference counterpart: the RTL is one pipeline; the algebra is gcm_ghash.vhd:317-333's
+ * linear split generalised).  Rank g owns data blocks [first_block, first_block + ceil(len/16)) of a
+ * message with total_len bytes of data and aad_len bytes of AAD; only the LAST shard may have a
+ * ragged length.  The rank that owns first_block == 0 also absorbs the AAD (pass d_aad there, NULL
+ * elsewhere).  The call en/decrypts the shard and writes its 16-byte WEIGHTED GHASH partial
+ *    W_g = (sum_{i in shard} X_i * H^(end_g-1-i)) * H^(n_total_blocks - end_g)
+ * to d_partial (device memory).  Partials of all ranks are exchanged by the caller (one 16-byte
+ * all-gather, e.g. RCCL) and handed to aesgcm_shard_finalize, which XOR-folds them on the device and
+ * produces tag = GHASH xor E_K(IV||1). */
+int aesgcm_shard_crypt_dev(aesgcm_ctx *ctx, int decrypt, const uint8_t iv[12],
+                           const void *d_aad, size_t aad_len,
+                           const void *d_in, size_t len, void *d_out,
+                           uint64_t first_block, uint64_t total_len,
+                           void *d_partial, void *stream);
+int aesgcm_shard_finalize_dev(aesgcm_ctx *ctx, const uint8_t iv[12], const void *d_partials, size_t n_partials,
+                              size_t aad_len, uint64_t total_len, uint8_t tag[16], void *stream);
+
+/* ---------------------------------------------------------------- streaming (beat-by-beat) interface
+ * Mirrors the call order the reference harness drives its model with (tb/gcm_test.py:76-85 ->
+ * tb/gcm_model.py:21-35): all AAD first, then data; every chunk except the last of its kind must be
+ * a multiple of 16 bytes (the harness sends 16-byte beats, tb/gcm_sequencer.py:129-140).  Output for a
+ * chunk is complete when the call returns.  State (running GHASH value, block counter) lives on the
+ * device between calls. */
+int aesgcm_stream_begin(aesgcm_ctx *ctx, const uint8_t iv[12], int decrypt);
+int aesgcm_stream_aad(aesgcm_ctx *ctx, const uint8_t *aad, size_t len);
+int aesgcm_stream_update(aesgcm_ctx *ctx, const uint8_t *in, size_t len, uint8_t *out);
+int aesgcm_stream_final(aesgcm_ctx *ctx, uint8_t tag[16]);
+
+/* ---------------------------------------------------------------- device memory helpers
+ * (so that a Python/ctypes host needs no other GPU runtime binding) */
+int aesgcm_dev_alloc(int device, void **d_ptr, size_t bytes);
+int aesgcm_dev_free(int device, void *d_ptr);
+int aesgcm_dev_upload(int device, void *d_dst, const void *h_src, size_t bytes);
+int aesgcm_dev_download(int device, void *h_dst, const void *d_src, size_t bytes);
+int aesgcm_dev_sync(int device);
+/* SplitMix64 counter-based synthetic stream: little-endian 64-bit word w of stream
+ * `seed` for w = first_word ..; bytes [0, len) of the buffer. */
+int aesgcm_fill_splitmix64_dev(int device, void *d_buf, size_t len, uint64_t seed, uint64_t first_word, void *stream);
+
+/* ---------------------------------------------------------------- measurement support
+ * When enabled, every launch of the fused CTR+GHASH kernel on this context is bracketed with HIP
+ * events on the stream it is launched on.  aesgcm_ctx_timing_read synchronises those events and
+ * returns the number of launches and their summed duration since the last reset. */
+int aesgcm_ctx_timing_enable(aesgcm_ctx *ctx, int on);
+int aesgcm_ctx_timing_read(aesgcm_ctx *ctx, uint64_t *n_launches, double *total_ms, int reset);
+/* geometry the context chose (workgroups, lanes per workgroup, LDS bytes per workgroup) */
+int aesgcm_ctx_geometry(const aesgcm_ctx *ctx, int *n_workgroups, int *wg_lanes, int *lds_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AESGCM_H */
