@@ -1,0 +1,368 @@
+"""ctypes binding of libaesgcm_hip.so -- one Python function per entry point of include/aesgcm.h.
+
+Mirrors the C ABI one to one (same names without the aesgcm_ prefix, same argument meaning, error
+codes turned into exceptions).  No torch, no numpy requirement (numpy arrays are accepted as
+buffers).  Loading fails loudly when the library is missing; compute calls fail loudly
+(AesGcmError: AESGCM_EHIP) when no HIP device is usable -- there is no CPU path to fall back to.
+"""
+import ctypes
+import os
+
+from .build import SO, build
+
+OK, EARG, EKEYLEN, EIVLEN, ETOOLONG, EAUTH, EHIP, ENOMEM, ESTATE, EALIGN = 0, -1, -2, -3, -4, -5, -6, -7, -8, -9
+
+# every symbol include/aesgcm.h declares (tests check the .so exports exactly these)
+SYMBOLS = [
+    "aesgcm_abi_version", "aesgcm_strerror", "aesgcm_last_error", "aesgcm_device_count", "aesgcm_device_name",
+    "aesgcm_key_expand", "aesgcm_ecb_encrypt", "aesgcm_gfmul", "aesgcm_ghash", "aesgcm_get_h",
+    "aesgcm_ctx_create", "aesgcm_ctx_create_preexpanded", "aesgcm_ctx_destroy", "aesgcm_ctx_device",
+    "aesgcm_encrypt", "aesgcm_decrypt", "aesgcm_encrypt_dev", "aesgcm_decrypt_dev", "aesgcm_last_tag",
+    "aesgcm_keystream", "aesgcm_keystream_dev",
+    "aesgcm_shard_crypt_dev", "aesgcm_shard_finalize_dev",
+    "aesgcm_stream_begin", "aesgcm_stream_aad", "aesgcm_stream_update", "aesgcm_stream_final",
+    "aesgcm_dev_alloc", "aesgcm_dev_free", "aesgcm_dev_upload", "aesgcm_dev_download", "aesgcm_dev_sync",
+    "aesgcm_fill_splitmix64_dev",
+    "aesgcm_ctx_timing_enable", "aesgcm_ctx_timing_read", "aesgcm_ctx_geometry",
+]
+
+
+class AesGcmError(RuntimeError):
+    def __init__(self, code, detail=""):
+        self.code = code
+        msg = _strerror(code)
+        if detail:
+            msg += ": " + detail
+        super().__init__("aesgcm error %d: %s" % (code, msg))
+
+
+class AuthenticationError(AesGcmError, ValueError):
+    """Tag mismatch on decrypt (the ValueError pycryptodome's verify() raises, tb/gcm_model.py:47)."""
+
+
+_L = None
+vp, sz, u64, cint = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint64, ctypes.c_int
+cp = ctypes.c_char_p
+
+
+def load():
+    """Load (building first if sources are newer) and type the library."""
+    global _L
+    if _L is not None:
+        return _L
+    if not os.path.exists(SO):
+        build()
+    L = ctypes.CDLL(SO)
+    L.aesgcm_strerror.restype = cp
+    L.aesgcm_strerror.argtypes = [cint]
+    L.aesgcm_last_error.restype = cp
+    L.aesgcm_device_count.argtypes = [ctypes.POINTER(cint)]
+    L.aesgcm_device_name.argtypes = [cint, cp, sz]
+    L.aesgcm_key_expand.argtypes = [cint, vp, sz, vp, ctypes.POINTER(cint)]
+    L.aesgcm_ecb_encrypt.argtypes = [vp, vp, sz, vp]
+    L.aesgcm_gfmul.argtypes = [cint, vp, vp, vp, sz]
+    L.aesgcm_ghash.argtypes = [vp, vp, sz, vp]
+    L.aesgcm_get_h.argtypes = [vp, vp]
+    L.aesgcm_ctx_create.argtypes = [ctypes.POINTER(vp), cint, vp, sz]
+    L.aesgcm_ctx_create_preexpanded.argtypes = [ctypes.POINTER(vp), cint, vp, cint]
+    L.aesgcm_ctx_destroy.argtypes = [vp]
+    L.aesgcm_ctx_device.argtypes = [vp]
+    L.aesgcm_encrypt.argtypes = [vp, vp, vp, sz, vp, sz, vp, vp]
+    L.aesgcm_decrypt.argtypes = [vp, vp, vp, sz, vp, sz, vp, vp, vp]
+    L.aesgcm_encrypt_dev.argtypes = [vp, vp, vp, sz, vp, sz, vp, vp, vp]
+    L.aesgcm_decrypt_dev.argtypes = [vp, vp, vp, sz, vp, sz, vp, vp, vp, vp]
+    L.aesgcm_last_tag.argtypes = [vp, vp, vp]
+    L.aesgcm_keystream.argtypes = [vp, vp, u64, u64, vp]
+    L.aesgcm_keystream_dev.argtypes = [vp, vp, u64, u64, vp, vp]
+    L.aesgcm_shard_crypt_dev.argtypes = [vp, cint, vp, vp, sz, vp, sz, vp, u64, u64, vp, vp]
+    L.aesgcm_shard_finalize_dev.argtypes = [vp, vp, vp, sz, sz, u64, vp, vp]
+    L.aesgcm_stream_begin.argtypes = [vp, vp, cint]
+    L.aesgcm_stream_aad.argtypes = [vp, vp, sz]
+    L.aesgcm_stream_update.argtypes = [vp, vp, sz, vp]
+    L.aesgcm_stream_final.argtypes = [vp, vp]
+    L.aesgcm_dev_alloc.argtypes = [cint, ctypes.POINTER(vp), sz]
+    L.aesgcm_dev_free.argtypes = [cint, vp]
+    L.aesgcm_dev_upload.argtypes = [cint, vp, vp, sz]
+    L.aesgcm_dev_download.argtypes = [cint, vp, vp, sz]
+    L.aesgcm_dev_sync.argtypes = [cint]
+    L.aesgcm_fill_splitmix64_dev.argtypes = [cint, vp, sz, u64, u64, vp]
+    L.aesgcm_ctx_timing_enable.argtypes = [vp, cint]
+    L.aesgcm_ctx_timing_read.argtypes = [vp, ctypes.POINTER(u64), ctypes.POINTER(ctypes.c_double), cint]
+    L.aesgcm_ctx_geometry.argtypes = [vp, ctypes.POINTER(cint), ctypes.POINTER(cint), ctypes.POINTER(cint)]
+    if L.aesgcm_abi_version() != 1:
+        raise ImportError("libaesgcm_hip.so ABI %d, expected 1" % L.aesgcm_abi_version())
+    _L = L
+    return L
+
+
+def _strerror(code):
+    try:
+        return load().aesgcm_strerror(code).decode()
+    except Exception:
+        return "code %d" % code
+
+
+def _chk(rc):
+    if rc == OK:
+        return
+    detail = load().aesgcm_last_error().decode() if rc == EHIP else ""
+    if rc == EAUTH:
+        raise AuthenticationError(rc, "MAC check failed")
+    raise AesGcmError(rc, detail)
+
+
+class _Buf:
+    """(address, length, keepalive) view of bytes / bytearray / memoryview / numpy array / None."""
+
+    def __init__(self, obj, writable=False):
+        self.keep = obj
+        if obj is None:
+            self.addr, self.n = None, 0
+        elif isinstance(obj, bytes):
+            if writable:
+                raise TypeError("output buffer must be writable")
+            self.n = len(obj)
+            self.addr = ctypes.cast(ctypes.c_char_p(obj), vp).value if self.n else None
+        elif hasattr(obj, "ctypes") and hasattr(obj, "nbytes"):          # numpy
+            self.n = obj.nbytes
+            self.addr = obj.ctypes.data if self.n else None
+        else:
+            mv = memoryview(obj).cast("B")
+            self.n = mv.nbytes
+            if self.n == 0:
+                self.addr = None
+            elif mv.readonly:
+                if writable:
+                    raise TypeError("output buffer must be writable")
+                self.keep = bytes(mv)
+                self.addr = ctypes.cast(ctypes.c_char_p(self.keep), vp).value
+            else:
+                self.keep = (ctypes.c_char * self.n).from_buffer(mv)
+                self.addr = ctypes.addressof(self.keep)
+
+
+def _fixed(b, n, what):
+    b = bytes(b)
+    if len(b) != n:
+        raise AesGcmError(EIVLEN if what == "iv" else EARG, "%s must be %d bytes, got %d" % (what, n, len(b)))
+    return b
+
+
+# ---------------------------------------------------------------- module-level (no context)
+def device_count():
+    n = cint(0)
+    _chk(load().aesgcm_device_count(ctypes.byref(n)))
+    return n.value
+
+
+def device_name(device=0):
+    b = ctypes.create_string_buffer(256)
+    _chk(load().aesgcm_device_name(device, b, 256))
+    return b.value.decode()
+
+
+def key_expand(key, device=0):
+    """-> (expanded key bytes (16*(nr+1)), nr).  GPU twin of tb/key_exp.py aes_expand_key."""
+    key = bytes(key)
+    rk = ctypes.create_string_buffer(240)
+    nr = cint(0)
+    _chk(load().aesgcm_key_expand(device, key, len(key), rk, ctypes.byref(nr)))
+    return rk.raw[:16 * (nr.value + 1)], nr.value
+
+
+def gfmul(h, x, device=0):
+    """Element-wise GF(2^128) products of equal-length sequences of 16-byte blocks."""
+    h, x = bytes(h), bytes(x)
+    if len(h) != len(x) or len(h) % 16:
+        raise AesGcmError(EARG, "h and x must be equal-length multiples of 16 bytes")
+    z = ctypes.create_string_buffer(max(len(h), 1))
+    _chk(load().aesgcm_gfmul(device, h, x, z, len(h) // 16))
+    return z.raw[:len(h)]
+
+
+class DeviceBuffer:
+    """Device memory owned by the library (hipMalloc); upload/download/fill helpers."""
+
+    def __init__(self, nbytes, device=0):
+        self.device, self.nbytes = device, nbytes
+        p = vp()
+        _chk(load().aesgcm_dev_alloc(device, ctypes.byref(p), nbytes))
+        self.ptr = p.value
+
+    def upload(self, data, offset=0):
+        b = _Buf(data)
+        if offset + b.n > self.nbytes:
+            raise AesGcmError(EARG, "upload past end of buffer")
+        _chk(load().aesgcm_dev_upload(self.device, self.ptr + offset, b.addr, b.n))
+
+    def download(self, nbytes=None, offset=0, out=None):
+        n = self.nbytes - offset if nbytes is None else nbytes
+        if out is None:
+            out = bytearray(n)
+        b = _Buf(out, writable=True)
+        _chk(load().aesgcm_dev_download(self.device, b.addr, self.ptr + offset, n))
+        return out
+
+    def fill_splitmix64(self, seed, first_word=0, nbytes=None, offset=0, stream=None):
+        n = self.nbytes - offset if nbytes is None else nbytes
+        _chk(load().aesgcm_fill_splitmix64_dev(self.device, self.ptr + offset, n, seed, first_word, stream))
+
+    def free(self):
+        if self.ptr:
+            load().aesgcm_dev_free(self.device, self.ptr)
+            self.ptr = None
+
+    __del__ = free
+
+
+def dev_sync(device=0):
+    _chk(load().aesgcm_dev_sync(device))
+
+
+# ---------------------------------------------------------------- context
+class Context:
+    """aesgcm_ctx: (device, expanded key, H, H-power tables).  One per key."""
+
+    def __init__(self, key=None, device=0, expanded_key=None):
+        self._c = None
+        L = load()
+        c = vp()
+        if expanded_key is not None:
+            ek = bytes(expanded_key)
+            nr = len(ek) // 16 - 1
+            if len(ek) % 16 or nr not in (10, 12, 14):
+                raise AesGcmError(EKEYLEN, "expanded key must be 176/208/240 bytes")
+            _chk(L.aesgcm_ctx_create_preexpanded(ctypes.byref(c), device, ek, nr))
+        else:
+            key = bytes(key)
+            _chk(L.aesgcm_ctx_create(ctypes.byref(c), device, key, len(key)))
+        self._c = c.value
+        self.device = device
+
+    def close(self):
+        if self._c:
+            load().aesgcm_ctx_destroy(self._c)
+            self._c = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # unit level
+    def h(self):
+        b = ctypes.create_string_buffer(16)
+        _chk(load().aesgcm_get_h(self._c, b))
+        return b.raw
+
+    def ecb_encrypt(self, blocks):
+        b = _Buf(blocks)
+        if b.n % 16:
+            raise AesGcmError(EARG, "ECB input must be a multiple of 16 bytes")
+        out = bytearray(b.n)
+        o = _Buf(out, writable=True)
+        _chk(load().aesgcm_ecb_encrypt(self._c, b.addr, b.n // 16, o.addr))
+        return bytes(out)
+
+    def ghash(self, data):
+        b = _Buf(data)
+        y = ctypes.create_string_buffer(16)
+        _chk(load().aesgcm_ghash(self._c, b.addr, b.n, y))
+        return y.raw
+
+    def keystream(self, iv, first_block, nblocks):
+        out = bytearray(16 * nblocks)
+        o = _Buf(out, writable=True)
+        _chk(load().aesgcm_keystream(self._c, _fixed(iv, 12, "iv"), first_block, nblocks, o.addr))
+        return bytes(out)
+
+    # whole messages, host buffers
+    def encrypt(self, iv, aad, pt, out=None):
+        """-> (ct, tag)"""
+        a, p = _Buf(aad), _Buf(pt)
+        ret = out if out is not None else bytearray(p.n)
+        o = _Buf(ret, writable=True)
+        tag = ctypes.create_string_buffer(16)
+        _chk(load().aesgcm_encrypt(self._c, _fixed(iv, 12, "iv"), a.addr, a.n, p.addr, p.n, o.addr, tag))
+        return (bytes(ret) if out is None else ret), tag.raw
+
+    def decrypt(self, iv, aad, ct, tag=None, out=None):
+        """-> (pt, computed_tag); raises AuthenticationError when `tag` is given and does not match
+        (the plaintext has been produced regardless, as in the reference model)."""
+        a, c = _Buf(aad), _Buf(ct)
+        ret = out if out is not None else bytearray(c.n)
+        o = _Buf(ret, writable=True)
+        tout = ctypes.create_string_buffer(16)
+        exp = _fixed(tag, 16, "tag") if tag is not None else None
+        rc = load().aesgcm_decrypt(self._c, _fixed(iv, 12, "iv"), a.addr, a.n, c.addr, c.n, o.addr, exp, tout)
+        self.last_plaintext = bytes(ret) if out is None else ret
+        _chk(rc)
+        return self.last_plaintext, tout.raw
+
+    # whole messages, device buffers
+    def encrypt_dev(self, iv, d_pt, nbytes, d_ct, d_aad=None, aad_len=0, stream=None, want_tag=True):
+        tag = ctypes.create_string_buffer(16) if want_tag else None
+        _chk(load().aesgcm_encrypt_dev(self._c, _fixed(iv, 12, "iv"), d_aad, aad_len, d_pt, nbytes, d_ct, tag, stream))
+        return tag.raw if want_tag else None
+
+    def decrypt_dev(self, iv, d_ct, nbytes, d_pt, d_aad=None, aad_len=0, tag=None, stream=None, want_tag=True):
+        tout = ctypes.create_string_buffer(16) if want_tag else None
+        exp = _fixed(tag, 16, "tag") if tag is not None else None
+        _chk(load().aesgcm_decrypt_dev(self._c, _fixed(iv, 12, "iv"), d_aad, aad_len, d_ct, nbytes, d_pt, exp, tout, stream))
+        return tout.raw if want_tag else None
+
+    def last_tag(self, stream=None):
+        t = ctypes.create_string_buffer(16)
+        _chk(load().aesgcm_last_tag(self._c, t, stream))
+        return t.raw
+
+    def keystream_dev(self, iv, first_block, nblocks, d_out, stream=None):
+        _chk(load().aesgcm_keystream_dev(self._c, _fixed(iv, 12, "iv"), first_block, nblocks, d_out, stream))
+
+    # shards
+    def shard_crypt_dev(self, decrypt, iv, d_in, nbytes, d_out, first_block, total_len, d_partial,
+                        d_aad=None, aad_len=0, stream=None):
+        _chk(load().aesgcm_shard_crypt_dev(self._c, int(bool(decrypt)), _fixed(iv, 12, "iv"), d_aad, aad_len,
+                                           d_in, nbytes, d_out, first_block, total_len, d_partial, stream))
+
+    def shard_finalize_dev(self, iv, d_partials, n_partials, aad_len, total_len, stream=None, want_tag=True):
+        tag = ctypes.create_string_buffer(16) if want_tag else None
+        _chk(load().aesgcm_shard_finalize_dev(self._c, _fixed(iv, 12, "iv"), d_partials, n_partials, aad_len, total_len, tag, stream))
+        return tag.raw if want_tag else None
+
+    # streaming
+    def stream_begin(self, iv, decrypt=False):
+        _chk(load().aesgcm_stream_begin(self._c, _fixed(iv, 12, "iv"), int(bool(decrypt))))
+
+    def stream_aad(self, aad):
+        b = _Buf(aad)
+        _chk(load().aesgcm_stream_aad(self._c, b.addr, b.n))
+
+    def stream_update(self, data):
+        b = _Buf(data)
+        out = bytearray(b.n)
+        o = _Buf(out, writable=True)
+        _chk(load().aesgcm_stream_update(self._c, b.addr, b.n, o.addr))
+        return bytes(out)
+
+    def stream_final(self):
+        t = ctypes.create_string_buffer(16)
+        _chk(load().aesgcm_stream_final(self._c, t))
+        return t.raw
+
+    # measurement
+    def timing_enable(self, on=True):
+        _chk(load().aesgcm_ctx_timing_enable(self._c, int(on)))
+
+    def timing_read(self, reset=True):
+        n, ms = u64(0), ctypes.c_double(0)
+        _chk(load().aesgcm_ctx_timing_read(self._c, ctypes.byref(n), ctypes.byref(ms), int(reset)))
+        return n.value, ms.value
+
+    def geometry(self):
+        a, b, c = cint(0), cint(0), cint(0)
+        _chk(load().aesgcm_ctx_geometry(self._c, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return dict(workgroups=a.value, wg_lanes=b.value, lds_bytes=c.value)

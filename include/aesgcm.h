@@ -34,6 +34,12 @@ extern "C" {
 
 #define AESGCM_ABI_VERSION 1
 
+#if defined(__GNUC__)
+#define AESGCM_API __attribute__((visibility("default")))
+#else
+#define AESGCM_API
+#endif
+
 #define AESGCM_OK        0
 #define AESGCM_EARG     (-1)   /* NULL/invalid argument                                        */
 #define AESGCM_EKEYLEN  (-2)   /* key length not 16/24/32 (aes_pkg.vhd:60-63 modes 128/192/256) */
@@ -48,11 +54,11 @@ extern "C" {
 typedef struct aesgcm_ctx aesgcm_ctx;
 
 /* ---------------------------------------------------------------- library / device */
-int         aesgcm_abi_version(void);
-const char *aesgcm_strerror(int code);
-const char *aesgcm_last_error(void);              /* thread-local detail of the last AESGCM_EHIP */
-int         aesgcm_device_count(int *n);
-int         aesgcm_device_name(int device, char *buf, size_t buflen);
+AESGCM_API int         aesgcm_abi_version(void);
+AESGCM_API const char *aesgcm_strerror(int code);
+AESGCM_API const char *aesgcm_last_error(void);              /* thread-local detail of the last AESGCM_EHIP */
+AESGCM_API int         aesgcm_device_count(int *n);
+AESGCM_API int         aesgcm_device_name(int device, char *buf, size_t buflen);
 
 /* ---------------------------------------------------------------- unit-level entry points
  * One per arithmetic block of the RTL so that each can be parity-tested in isolation.  All run
@@ -62,47 +68,47 @@ int         aesgcm_device_name(int device, char *buf, size_t buflen);
  * :189-219) and its software twin tb/key_exp.py:79-121 aes_expand_key.  rk receives
  * 16*(nr+1) bytes, stage i = bytes 16i..16i+15 (the layout load_pre_exp_key streams,
  * tb/gcm_gctr.py:199-207); *nr = 10/12/14 (aes_pkg.vhd:31-33). */
-int aesgcm_key_expand(int device, const uint8_t *key, size_t key_len, uint8_t rk[240], int *nr);
+AESGCM_API int aesgcm_key_expand(int device, const uint8_t *key, size_t key_len, uint8_t rk[240], int *nr);
 
 /* nblocks independent ECB encryptions under the context key through the same LDS T-table round
  * code the CTR kernel uses.  Replaces aes_round x Nr + aes_last_round
  * (config/config_aes_round.py:120-126, src/aes_last_round.vhd:76) as instantiated by aes_ecb
  * (config/config_aes_ecb.py:250-327). */
-int aesgcm_ecb_encrypt(aesgcm_ctx *ctx, const uint8_t *in, size_t nblocks, uint8_t *out);
+AESGCM_API int aesgcm_ecb_encrypt(aesgcm_ctx *ctx, const uint8_t *in, size_t nblocks, uint8_t *out);
 
 /* n independent GF(2^128) products z[i] = x[i] * h[i] (16-byte big-endian blocks, GCM bit order).
  * Replaces ghash_gfmul (src/ghash_gfmul.vhd:37-64). */
-int aesgcm_gfmul(int device, const uint8_t *h, const uint8_t *x, uint8_t *z, size_t n);
+AESGCM_API int aesgcm_gfmul(int device, const uint8_t *h, const uint8_t *x, uint8_t *z, size_t n);
 
 /* GHASH chaining value after absorbing `len` bytes (last block zero-padded) from Y = 0 under the
  * context's H = E_K(0^128):  Y_i = (Y_{i-1} xor X_i) * H  (src/gcm_ghash.vhd:174-186, :259-272),
  * WITHOUT the length block.  Computed by the parallel H-power path, not by serial Horner. */
-int aesgcm_ghash(aesgcm_ctx *ctx, const uint8_t *data, size_t len, uint8_t y[16]);
+AESGCM_API int aesgcm_ghash(aesgcm_ctx *ctx, const uint8_t *data, size_t len, uint8_t y[16]);
 
 /* H = E_K(0^128) as latched by gcm_ghash (src/gcm_gctr.vhd:141-144, src/gcm_ghash.vhd:128-139). */
-int aesgcm_get_h(aesgcm_ctx *ctx, uint8_t h[16]);
+AESGCM_API int aesgcm_get_h(aesgcm_ctx *ctx, uint8_t h[16]);
 
 /* ---------------------------------------------------------------- context
  * A context = (device, expanded key, H, H-power tables, scratch).  Creating it runs the on-GPU key
  * expansion and table build once per key (the RTL's "load key" phase, tb/gcm_gctr.py:144-175). */
-int aesgcm_ctx_create(aesgcm_ctx **out, int device, const uint8_t *key, size_t key_len);
+AESGCM_API int aesgcm_ctx_create(aesgcm_ctx **out, int device, const uint8_t *key, size_t key_len);
 /* Pre-expanded key load path (config/config_aes_kprexp.py:66-106, tb/gcm_gctr.py:180-214):
  * rk = 16*(nr+1) bytes exactly as aesgcm_key_expand / tb/key_exp.py produce them. */
-int aesgcm_ctx_create_preexpanded(aesgcm_ctx **out, int device, const uint8_t *rk, int nr);
-int aesgcm_ctx_destroy(aesgcm_ctx *ctx);
-int aesgcm_ctx_device(const aesgcm_ctx *ctx);
+AESGCM_API int aesgcm_ctx_create_preexpanded(aesgcm_ctx **out, int device, const uint8_t *rk, int nr);
+AESGCM_API int aesgcm_ctx_destroy(aesgcm_ctx *ctx);
+AESGCM_API int aesgcm_ctx_device(const aesgcm_ctx *ctx);
 
 /* ---------------------------------------------------------------- whole messages, host pointers
  * Replaces the model's update/encrypt/digest sequence (tb/gcm_model.py:21-35) i.e. the aes_gcm
  * top level in encrypt mode (src/aes_gcm.vhd:207-211: GHASH consumes the GCTR output).
  * Copies H2D/D2H around the device path below; meant for parity tests and small messages. */
-int aesgcm_encrypt(aesgcm_ctx *ctx, const uint8_t iv[12], const uint8_t *aad, size_t aad_len,
+AESGCM_API int aesgcm_encrypt(aesgcm_ctx *ctx, const uint8_t iv[12], const uint8_t *aad, size_t aad_len,
                    const uint8_t *pt, size_t len, uint8_t *ct, uint8_t tag[16]);
 /* Decrypt mode (tb/gcm_model.py:29-30,43-51; src/aes_gcm.vhd:207-211: GHASH consumes the input).
  * Plaintext is always written (the model emits data before the tag is checked).  tag_out (may be
  * NULL) receives the computed tag.  If expect_tag != NULL it is compared in constant time and
  * AESGCM_EAUTH is returned on mismatch. */
-int aesgcm_decrypt(aesgcm_ctx *ctx, const uint8_t iv[12], const uint8_t *aad, size_t aad_len,
+AESGCM_API int aesgcm_decrypt(aesgcm_ctx *ctx, const uint8_t iv[12], const uint8_t *aad, size_t aad_len,
                    const uint8_t *ct, size_t len, uint8_t *pt, const uint8_t *expect_tag, uint8_t tag_out[16]);
 
 /* ---------------------------------------------------------------- whole messages, device pointers
@@ -111,17 +117,17 @@ int aesgcm_decrypt(aesgcm_ctx *ctx, const uint8_t iv[12], const uint8_t *aad, si
  * passed as void*, NULL = context stream); the only host traffic is the 16-byte tag, whose copy
  * synchronises the stream.  Pass tag = NULL to skip the copy and the synchronisation; the tag then
  * stays in the context and can be fetched with aesgcm_last_tag(). */
-int aesgcm_encrypt_dev(aesgcm_ctx *ctx, const uint8_t iv[12], const void *d_aad, size_t aad_len,
+AESGCM_API int aesgcm_encrypt_dev(aesgcm_ctx *ctx, const uint8_t iv[12], const void *d_aad, size_t aad_len,
                        const void *d_pt, size_t len, void *d_ct, uint8_t tag[16], void *stream);
-int aesgcm_decrypt_dev(aesgcm_ctx *ctx, const uint8_t iv[12], const void *d_aad, size_t aad_len,
+AESGCM_API int aesgcm_decrypt_dev(aesgcm_ctx *ctx, const uint8_t iv[12], const void *d_aad, size_t aad_len,
                        const void *d_ct, size_t len, void *d_pt, const uint8_t *expect_tag,
                        uint8_t tag_out[16], void *stream);
-int aesgcm_last_tag(aesgcm_ctx *ctx, uint8_t tag[16], void *stream);
+AESGCM_API int aesgcm_last_tag(aesgcm_ctx *ctx, uint8_t tag[16], void *stream);
 
 /* CTR keystream blocks [first_block, first_block+nblocks): E_K(IV || (2+i) mod 2^32)
  * (src/aes_icb.vhd:97-100,118; src/gcm_gctr.vhd:150 before the xor). */
-int aesgcm_keystream(aesgcm_ctx *ctx, const uint8_t iv[12], uint64_t first_block, uint64_t nblocks, uint8_t *out);
-int aesgcm_keystream_dev(aesgcm_ctx *ctx, const uint8_t iv[12], uint64_t first_block, uint64_t nblocks,
+AESGCM_API int aesgcm_keystream(aesgcm_ctx *ctx, const uint8_t iv[12], uint64_t first_block, uint64_t nblocks, uint8_t *out);
+AESGCM_API int aesgcm_keystream_dev(aesgcm_ctx *ctx, const uint8_t iv[12], uint64_t first_block, uint64_t nblocks,
                          void *d_out, void *stream);
 
 /* ---------------------------------------------------------------- one message sharded over ranks
@@ -134,12 +140,12 @@ int aesgcm_keystream_dev(aesgcm_ctx *ctx, const uint8_t iv[12], uint64_t first_b
  * to d_partial (device memory).  Partials of all ranks are exchanged by the caller (one 16-byte
  * all-gather, e.g. RCCL) and handed to aesgcm_shard_finalize, which XOR-folds them on the device and
  * produces tag = GHASH xor E_K(IV||1). */
-int aesgcm_shard_crypt_dev(aesgcm_ctx *ctx, int decrypt, const uint8_t iv[12],
+AESGCM_API int aesgcm_shard_crypt_dev(aesgcm_ctx *ctx, int decrypt, const uint8_t iv[12],
                            const void *d_aad, size_t aad_len,
                            const void *d_in, size_t len, void *d_out,
                            uint64_t first_block, uint64_t total_len,
                            void *d_partial, void *stream);
-int aesgcm_shard_finalize_dev(aesgcm_ctx *ctx, const uint8_t iv[12], const void *d_partials, size_t n_partials,
+AESGCM_API int aesgcm_shard_finalize_dev(aesgcm_ctx *ctx, const uint8_t iv[12], const void *d_partials, size_t n_partials,
                               size_t aad_len, uint64_t total_len, uint8_t tag[16], void *stream);
 
 /* ---------------------------------------------------------------- streaming (beat-by-beat) interface
@@ -148,30 +154,30 @@ int aesgcm_shard_finalize_dev(aesgcm_ctx *ctx, const uint8_t iv[12], const void 
  * a multiple of 16 bytes (the harness sends 16-byte beats, tb/gcm_sequencer.py:129-140).  Output for a
  * chunk is complete when the call returns.  State (running GHASH value, block counter) lives on the
  * device between calls. */
-int aesgcm_stream_begin(aesgcm_ctx *ctx, const uint8_t iv[12], int decrypt);
-int aesgcm_stream_aad(aesgcm_ctx *ctx, const uint8_t *aad, size_t len);
-int aesgcm_stream_update(aesgcm_ctx *ctx, const uint8_t *in, size_t len, uint8_t *out);
-int aesgcm_stream_final(aesgcm_ctx *ctx, uint8_t tag[16]);
+AESGCM_API int aesgcm_stream_begin(aesgcm_ctx *ctx, const uint8_t iv[12], int decrypt);
+AESGCM_API int aesgcm_stream_aad(aesgcm_ctx *ctx, const uint8_t *aad, size_t len);
+AESGCM_API int aesgcm_stream_update(aesgcm_ctx *ctx, const uint8_t *in, size_t len, uint8_t *out);
+AESGCM_API int aesgcm_stream_final(aesgcm_ctx *ctx, uint8_t tag[16]);
 
 /* ---------------------------------------------------------------- device memory helpers
  * (so that a Python/ctypes host needs no other GPU runtime binding) */
-int aesgcm_dev_alloc(int device, void **d_ptr, size_t bytes);
-int aesgcm_dev_free(int device, void *d_ptr);
-int aesgcm_dev_upload(int device, void *d_dst, const void *h_src, size_t bytes);
-int aesgcm_dev_download(int device, void *h_dst, const void *d_src, size_t bytes);
-int aesgcm_dev_sync(int device);
+AESGCM_API int aesgcm_dev_alloc(int device, void **d_ptr, size_t bytes);
+AESGCM_API int aesgcm_dev_free(int device, void *d_ptr);
+AESGCM_API int aesgcm_dev_upload(int device, void *d_dst, const void *h_src, size_t bytes);
+AESGCM_API int aesgcm_dev_download(int device, void *h_dst, const void *d_src, size_t bytes);
+AESGCM_API int aesgcm_dev_sync(int device);
 /* SplitMix64 counter-based synthetic stream: little-endian 64-bit word w of stream
  * `seed` for w = first_word ..; bytes [0, len) of the buffer. */
-int aesgcm_fill_splitmix64_dev(int device, void *d_buf, size_t len, uint64_t seed, uint64_t first_word, void *stream);
+AESGCM_API int aesgcm_fill_splitmix64_dev(int device, void *d_buf, size_t len, uint64_t seed, uint64_t first_word, void *stream);
 
 /* ---------------------------------------------------------------- measurement support
  * When enabled, every launch of the fused CTR+GHASH kernel on this context is bracketed with HIP
  * events on the stream it is launched on.  aesgcm_ctx_timing_read synchronises those events and
  * returns the number of launches and their summed duration since the last reset. */
-int aesgcm_ctx_timing_enable(aesgcm_ctx *ctx, int on);
-int aesgcm_ctx_timing_read(aesgcm_ctx *ctx, uint64_t *n_launches, double *total_ms, int reset);
+AESGCM_API int aesgcm_ctx_timing_enable(aesgcm_ctx *ctx, int on);
+AESGCM_API int aesgcm_ctx_timing_read(aesgcm_ctx *ctx, uint64_t *n_launches, double *total_ms, int reset);
 /* geometry the context chose (workgroups, lanes per workgroup, LDS bytes per workgroup) */
-int aesgcm_ctx_geometry(const aesgcm_ctx *ctx, int *n_workgroups, int *wg_lanes, int *lds_bytes);
+AESGCM_API int aesgcm_ctx_geometry(const aesgcm_ctx *ctx, int *n_workgroups, int *wg_lanes, int *lds_bytes);
 
 #ifdef __cplusplus
 }

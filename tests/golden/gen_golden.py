@@ -292,7 +292,7 @@ def stream_case(name, kbytes, pt_seed, n_bytes, iv_tweak=0, first_word=0, aad=b"
     while done < n_bytes:
         m = min(chunk, n_bytes - done)
         # parallel fill
-        per = (m // threads + 7) // 8 * 8
+        per = ((m + threads - 1) // threads + 7) // 8 * 8
         ths = []
         for t in range(threads):
             lo = t * per

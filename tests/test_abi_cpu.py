@@ -1,0 +1,78 @@
+"""CPU: the C-ABI library builds for gfx950, loads, exports exactly what include/aesgcm.h declares,
+and refuses to compute without a GPU (no CPU fallback)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+import aesgcm_amd  # noqa: F401
+from aesgcm_amd import lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "aesgcm.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    return sorted(set(re.findall(r"AESGCM_API\s+[\w \*]+?\b(aesgcm_\w+)\s*\(", src)))
+
+
+def test_header_and_binding_list_agree():
+    assert declared_symbols() == sorted(lib.SYMBOLS)
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    from aesgcm_amd.build import build, SO
+    build()
+    out = subprocess.check_output(["nm", "-D", "--defined-only", SO], text=True)
+    exported = set(re.findall(r" T (aesgcm_\w+)", out))
+    assert exported == set(declared_symbols())
+    L = lib.load()
+    assert L.aesgcm_abi_version() == 1
+    for s in declared_symbols():
+        assert hasattr(L, s)
+
+
+def test_code_object_targets_gfx950_only():
+    from aesgcm_amd.build import SO
+    blob = open(SO, "rb").read()
+    assert b"gfx950" in blob
+    for other in (b"gfx942", b"gfx90a", b"sm_"):
+        assert other not in blob
+
+
+def test_strerror_covers_all_codes():
+    L = lib.load()
+    for code in range(0, -10, -1):
+        assert L.aesgcm_strerror(code).decode() not in ("", "unknown error")
+    assert L.aesgcm_strerror(-99).decode() == "unknown error"
+
+
+def test_header_compiles_as_plain_c():
+    # the boundary is a C ABI: the header must be consumable by gcc -std=c99 with no HIP/C++ types
+    code = '#include "aesgcm.h"\nint main(void){return AESGCM_ABI_VERSION==1?0:1;}\n'
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-x", "c", "-", "-fsyntax-only"],
+                   input=code.encode(), check=True)
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
+def test_no_cpu_fallback_without_gpu():
+    with pytest.raises(lib.AesGcmError) as e:
+        lib.Context(b"k" * 16)
+    assert e.value.code == lib.EHIP
+    from aesgcm_amd import gcm_model
+    with pytest.raises(lib.AesGcmError):
+        gcm_model.encrypt(b"k" * 16, b"i" * 12, b"", b"data")
+    with pytest.raises(lib.AesGcmError):
+        gcm_model.gcm({'data': '00' * 16, 'n_bytes': 16}, {'data': '00' * 12, 'n_bytes': 12}, 'enc')
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "aes-gcm-128-192-256-bits_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.replace("oracle/aesgcm_oracle.c by definition", ""), f
+                assert "libcrypto" not in txt and "Crypto.Cipher" not in txt.replace("from Crypto.Cipher import AES", ""), f

@@ -1,0 +1,246 @@
+"""GPU: parity of the HIP path (through the C ABI) against the oracle and the golden fixtures.
+Bar: bit-exact ciphertext and tag (integer/byte work)."""
+import hashlib
+
+import pytest
+
+from util import golden, matrix_inputs, splitmix_bytes, stream_key_iv
+
+pytestmark = pytest.mark.gpu
+
+
+# ---------------------------------------------------------------- unit level
+def test_key_expand_matches_reference_key_exp(hip):
+    for name, v in golden("key_schedule.json")["vectors"].items():
+        rk, nr = hip.key_expand(bytes.fromhex(v["key"]))
+        assert rk.hex() == v["expanded"], name
+        assert nr == {"128": 10, "192": 12, "256": 14}[v["size"]]
+
+
+def test_preexpanded_key_context_equals_on_gpu_expansion(hip, orc):
+    for klen in (16, 24, 32):
+        key, iv = splitmix_bytes(70 + klen, klen), splitmix_bytes(71, 12)
+        rk, _ = orc.key_expand(key)
+        a = hip.Context(key)
+        b = hip.Context(expanded_key=rk)
+        pt = splitmix_bytes(72, 1000)
+        assert a.encrypt(iv, b"hdr", pt) == b.encrypt(iv, b"hdr", pt)
+        assert a.h() == b.h() == orc.Fast(key).h
+
+
+def test_ecb_blocks_fips197_and_random(hip, orc):
+    pt = bytes.fromhex("00112233445566778899aabbccddeeff")
+    for klen, exp in ((16, "69c4e0d86a7b0430d8cdb78070b4c55a"), (24, "dda97ca4864cdfe06eaf70a0ec0d7191"),
+                      (32, "8ea2b7ca516745bfeafc49904b496089")):
+        c = hip.Context(bytes(range(klen)))
+        assert c.ecb_encrypt(pt).hex() == exp
+        blocks = splitmix_bytes(5 + klen, 16 * 3001)
+        f = orc.Fast(bytes(range(klen)))
+        want = b"".join(f.encrypt_block(blocks[i:i + 16]) for i in range(0, len(blocks), 16))
+        assert c.ecb_encrypt(blocks) == want
+
+
+def test_gfmul_vectors(hip):
+    g = golden("gfmul.json")["mul"]
+    h = b"".join(bytes.fromhex(v["h"]) for v in g)
+    x = b"".join(bytes.fromhex(v["x"]) for v in g)
+    z = hip.gfmul(h, x)
+    assert z == b"".join(bytes.fromhex(v["z"]) for v in g)
+
+
+def test_ghash_chaining_value(hip, orc):
+    key = splitmix_bytes(33, 32)
+    c = hip.Context(key)
+    h = orc.Fast(key).h
+    assert c.h() == h
+    f = orc.Fast(key)
+    for n in (0, 1, 15, 16, 17, 8191, 8192, 8193, 100000, 5 << 20):
+        data = splitmix_bytes(34 + n, n)
+        got = c.ghash(data)
+        assert got == orc.gfmul(h, f.ghash_poly(data)) if n else got == bytes(16)
+        if n <= 100000:
+            assert got == orc.ghash_update(h, bytes(16), data)      # literal serial Horner
+
+
+def test_keystream_blocks(hip, orc):
+    key, iv = splitmix_bytes(40, 24), splitmix_bytes(41, 12)
+    c, f = hip.Context(key), orc.Fast(key)
+    for first, n in ((0, 1), (0, 700), (12345, 513), (0xFFFFFF00 - 2, 600), ((1 << 32) - 2 - 5, 5)):
+        assert c.keystream(iv, first, n) == f.keystream(iv, first, n)
+    with pytest.raises(hip.AesGcmError) as e:
+        c.keystream(iv, (1 << 32) - 3, 2)
+    assert e.value.code == hip.ETOOLONG
+
+
+# ---------------------------------------------------------------- whole messages
+def test_kat_vectors(hip):
+    for v in golden("kat.json")["vectors"]:
+        key, iv, aad, pt = (bytes.fromhex(v[k]) for k in ("key", "iv", "aad", "pt"))
+        c = hip.Context(key)
+        ct, tag = c.encrypt(iv, aad, pt)
+        assert (ct.hex(), tag.hex()) == (v["ct"], v["tag"]), v["name"]
+        back, t2 = c.decrypt(iv, aad, ct, tag=tag)
+        assert back == pt and t2 == tag
+
+
+def test_length_matrix_encrypt_decrypt(hip):
+    ctxs = {}
+    for cell in golden("length_matrix.json")["cells"]:
+        key, iv, aad, pt = matrix_inputs(cell["kbits"], cell["aad_len"], cell["pt_len"])
+        c = ctxs.setdefault(key, hip.Context(key))
+        ct, tag = c.encrypt(iv, aad, pt)
+        assert tag.hex() == cell["tag"], cell
+        assert hashlib.sha256(ct).hexdigest() == cell["ct_sha256"], cell
+        back, t2 = c.decrypt(iv, aad, ct, tag=bytes.fromhex(cell["tag"]))
+        assert back == pt and t2 == tag
+
+
+def test_u_shaped_random_lengths_vs_oracle(hip, orc):
+    """The reference's own length distribution: int(betavariate(.1,.1) * max) for AAD and data,
+    independently (tb/gcm_gctr.py:279-281), all three key sizes, both directions."""
+    import random
+    rng = random.Random(0xC0C07B)
+    for it in range(60):
+        klen = rng.choice((16, 24, 32))
+        mx = rng.choice(((1 << 12) - 1, (1 << 16) - 1, (1 << 20) - 1))
+        al = int(rng.betavariate(.1, .1) * min(mx, (1 << 16) - 1))
+        pl = int(rng.betavariate(.1, .1) * mx)
+        key, iv = splitmix_bytes(1000 + it, klen), splitmix_bytes(2000 + it, 12)
+        aad, pt = splitmix_bytes(3000 + it, al), splitmix_bytes(4000 + it, pl)
+        want = orc.Fast(key).encrypt(iv, aad, pt)
+        c = hip.Context(key)
+        assert c.encrypt(iv, aad, pt) == want, (klen, al, pl)
+        assert c.decrypt(iv, aad, want[0], tag=want[1]) == (pt, want[1])
+
+
+def test_block_boundary_lengths_around_workgroup_and_grid_edges(hip, orc):
+    """Lengths that straddle the launch geometry: 512-lane workgroups, the full grid (T = 1 -> 2)."""
+    key, iv = splitmix_bytes(50, 32), splitmix_bytes(51, 12)
+    c, f = hip.Context(key), orc.Fast(key)
+    g = c.geometry()
+    full = g["workgroups"] * g["wg_lanes"] * 16
+    sizes = [511 * 16, 512 * 16, 513 * 16, 512 * 16 + 1, 1024 * 16 - 1,
+             full - 16, full - 1, full, full + 1, full + 16, 2 * full + 5, 3 * full - 7]
+    for n in sizes:
+        for al in (0, 20, 16 * 600 + 3):
+            aad, pt = splitmix_bytes(52 + al, al), splitmix_bytes(53 + n, n)
+            assert c.encrypt(iv, aad, pt) == f.encrypt(iv, aad, pt), (n, al)
+
+
+def test_tamper_detection(hip):
+    key, iv, aad, pt = splitmix_bytes(60, 16), splitmix_bytes(61, 12), splitmix_bytes(62, 28), splitmix_bytes(63, 48)
+    c = hip.Context(key)
+    ct, tag = c.encrypt(iv, aad, pt)
+    bad_tag = bytes([tag[0] ^ 1]) + tag[1:]
+    with pytest.raises(hip.AuthenticationError):
+        c.decrypt(iv, aad, ct, tag=bad_tag)
+    assert c.last_plaintext == pt                       # plaintext is still produced (tb/gcm_model.py:30 then :44)
+    bad_ct = ct[:7] + bytes([ct[7] ^ 0x80]) + ct[8:]
+    with pytest.raises(ValueError):                     # AuthenticationError is a ValueError, as pycryptodome's
+        c.decrypt(iv, aad, bad_ct, tag=tag)
+    with pytest.raises(hip.AuthenticationError):
+        c.decrypt(iv, aad + b"x", ct, tag=tag)
+    assert c.decrypt(iv, aad, ct)[1] == tag             # no expected tag: returns the computed one
+
+
+def test_argument_errors(hip):
+    with pytest.raises(hip.AesGcmError) as e:
+        hip.Context(b"x" * 20)
+    assert e.value.code == hip.EKEYLEN
+    c = hip.Context(b"x" * 16)
+    with pytest.raises(hip.AesGcmError) as e:
+        c.encrypt(b"short iv", b"", b"data")
+    assert e.value.code == hip.EIVLEN
+
+
+# ---------------------------------------------------------------- device-pointer path, in place, streams
+def test_device_pointer_path_in_place_and_stream_fixtures(hip):
+    for case in golden("streams.json")["cases"]:
+        if case["n_bytes"] > (64 << 20):
+            continue
+        key, iv = stream_key_iv(case)
+        aad = bytes.fromhex(case["aad"])
+        n = case["n_bytes"]
+        c = hip.Context(key)
+        buf = hip.DeviceBuffer(n + 16)
+        buf.fill_splitmix64(case["pt_seed"], case["first_word"], nbytes=n)
+        d_aad = None
+        if aad:
+            d_aad = hip.DeviceBuffer(len(aad))
+            d_aad.upload(aad)
+        tag = c.encrypt_dev(iv, buf.ptr, n, buf.ptr, d_aad=d_aad.ptr if aad else None, aad_len=len(aad))   # in place
+        assert tag.hex() == case["tag"], case["name"]
+        ct = buf.download(n)
+        assert hashlib.sha256(ct).hexdigest() == case["ct_sha256"], case["name"]
+        assert bytes(ct[:64]).hex() == case["ct_head"] and bytes(ct[-64:]).hex() == case["ct_tail"]
+        # decrypt in place back to the generator's plaintext
+        t2 = c.decrypt_dev(iv, buf.ptr, n, buf.ptr, d_aad=d_aad.ptr if aad else None, aad_len=len(aad), tag=tag)
+        assert t2 == tag
+        ref = hip.DeviceBuffer(n + 16)
+        ref.fill_splitmix64(case["pt_seed"], case["first_word"], nbytes=n)
+        assert hashlib.sha256(buf.download(n)).digest() == hashlib.sha256(ref.download(n)).digest()
+        buf.free(); ref.free()
+
+
+def test_device_fill_matches_host_generator(hip, orc):
+    for n, fw in ((0, 0), (1, 0), (7, 3), (8, 0), (4099, 17), (1 << 20, 123456789)):
+        b = hip.DeviceBuffer(max(n, 8))
+        b.fill_splitmix64(0xAE5C0003, fw, nbytes=n)
+        assert bytes(b.download(n)) == bytes(orc.fill_splitmix64(n, 0xAE5C0003, fw))
+
+
+def test_misaligned_device_pointer_is_rejected(hip):
+    c = hip.Context(b"k" * 32)
+    b = hip.DeviceBuffer(4096)
+    with pytest.raises(hip.AesGcmError) as e:
+        c.encrypt_dev(b"i" * 12, b.ptr + 4, 64, b.ptr + 4)
+    assert e.value.code == hip.EALIGN
+
+
+# ---------------------------------------------------------------- shards (multi-GPU algebra on one GPU)
+def test_shard_partials_match_fixture_and_fold_to_tag(hip):
+    s = golden("shards.json")
+    key, iv, aad, pt = (bytes.fromhex(s[k]) for k in ("key", "iv", "aad", "pt"))
+    c = hip.Context(key)
+    n = len(pt)
+    din, dout = hip.DeviceBuffer(n + 16), hip.DeviceBuffer(n + 16)
+    din.upload(pt)
+    d_aad = hip.DeviceBuffer(len(aad)); d_aad.upload(aad)
+    parts = hip.DeviceBuffer(16 * len(s["shards"]))
+    for g, sh in enumerate(s["shards"]):
+        first, end = sh["first_block"], sh["end_block"]
+        ln = min(n, 16 * end) - 16 * first
+        c.shard_crypt_dev(False, iv, din.ptr + 16 * first, ln, dout.ptr + 16 * first, first, n, parts.ptr + 16 * g,
+                          d_aad=d_aad.ptr if g == 0 else None, aad_len=len(aad) if g == 0 else 0)
+    got = bytes(parts.download())
+    # fixture weights exclude the AAD; shard 0 on the GPU also carries the AAD polynomial: check shards 1..7 directly
+    for g, sh in enumerate(s["shards"]):
+        if g:
+            assert got[16 * g:16 * g + 16].hex() == sh["weighted"], g
+    tag = c.shard_finalize_dev(iv, parts.ptr, len(s["shards"]), len(aad), n)
+    assert tag.hex() == s["tag"]
+    assert bytes(dout.download(n)).hex() == s["ct"]
+
+
+def test_sharded_message_equals_single_launch(hip, orc):
+    key, iv = splitmix_bytes(80, 32), splitmix_bytes(81, 12)
+    c = hip.Context(key)
+    for n, al, ranks in ((16 * 100000 + 9, 33, 8), (5 << 20, 0, 4), (16 * 7, 20, 8), (1 << 20, 0, 2)):
+        aad = splitmix_bytes(82, al)
+        din, dout = hip.DeviceBuffer(n + 16), hip.DeviceBuffer(n + 16)
+        din.fill_splitmix64(83, 0, nbytes=n)
+        pt = bytes(din.download(n))
+        want_ct, want_tag = orc.Fast(key).encrypt(iv, aad, pt)
+        d_aad = hip.DeviceBuffer(max(al, 1)); d_aad.upload(aad)
+        parts = hip.DeviceBuffer(16 * ranks)
+        total_blocks = (n + 15) // 16
+        first = 0
+        for r in range(ranks):
+            blocks = total_blocks // ranks + (1 if r < total_blocks % ranks else 0)
+            end = first + blocks
+            ln = (n if end == total_blocks else 16 * end) - 16 * first
+            c.shard_crypt_dev(False, iv, din.ptr + 16 * first, ln, dout.ptr + 16 * first, first, n, parts.ptr + 16 * r,
+                              d_aad=d_aad.ptr if r == 0 else None, aad_len=al if r == 0 else 0)
+            first = end
+        assert c.shard_finalize_dev(iv, parts.ptr, ranks, al, n) == want_tag
+        assert bytes(dout.download(n)) == want_ct

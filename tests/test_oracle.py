@@ -1,0 +1,130 @@
+"""CPU: pins oracle/ (the C restatement of the reference's arithmetic) against every golden vector.
+
+Fixture provenance is in tests/golden/gen_golden.py: the reference's own tb/key_exp.py (key schedules,
+S-box), its two README vectors with the IEEE 802.1AE published outputs, GCM-spec KATs, and libcrypto +
+node cross-checked matrices."""
+import hashlib
+
+import pytest
+
+from util import golden, matrix_inputs, splitmix_bytes, stream_key_iv, batch_inputs
+
+
+def test_sbox_matches_reference_table(orc):
+    assert bytes(orc.sbox_table()).hex() == golden("sbox.json")["sbox"]
+
+
+def test_key_schedule_matches_reference_key_exp(orc):
+    for name, v in golden("key_schedule.json")["vectors"].items():
+        rk, nr = orc.key_expand(bytes.fromhex(v["key"]))
+        assert nr == {"128": 10, "192": 12, "256": 14}[v["size"]], name
+        assert rk.hex() == v["expanded"], name
+
+
+def test_key_expand_rejects_bad_length(orc):
+    with pytest.raises(ValueError):
+        orc.key_expand(b"\0" * 20)
+
+
+def test_aes_block_fips197_appendix_c(orc):
+    pt = bytes.fromhex("00112233445566778899aabbccddeeff")
+    for klen, exp in ((16, "69c4e0d86a7b0430d8cdb78070b4c55a"), (24, "dda97ca4864cdfe06eaf70a0ec0d7191"),
+                      (32, "8ea2b7ca516745bfeafc49904b496089")):
+        assert orc.aes_encrypt_block(bytes(range(klen)), pt).hex() == exp
+        assert orc.Fast(bytes(range(klen))).encrypt_block(pt).hex() == exp
+
+
+def test_gfmul_and_pow_vectors(orc):
+    g = golden("gfmul.json")
+    for v in g["mul"]:
+        assert orc.gfmul(bytes.fromhex(v["h"]), bytes.fromhex(v["x"])).hex() == v["z"]
+    for v in g["pow"]:
+        assert orc.gfpow(bytes.fromhex(v["h"]), v["e"]).hex() == v["z"]
+
+
+def test_kat_literal_and_fast(orc):
+    for v in golden("kat.json")["vectors"]:
+        key, iv, aad, pt = (bytes.fromhex(v[k]) for k in ("key", "iv", "aad", "pt"))
+        assert orc.gcm_encrypt(key, iv, aad, pt) == (bytes.fromhex(v["ct"]), bytes.fromhex(v["tag"])), v["name"]
+        assert orc.Fast(key).encrypt(iv, aad, pt) == (bytes.fromhex(v["ct"]), bytes.fromhex(v["tag"])), v["name"]
+        assert orc.gcm_decrypt(key, iv, aad, bytes.fromhex(v["ct"])) == (pt, bytes.fromhex(v["tag"])), v["name"]
+
+
+def test_length_matrix(orc):
+    cells = golden("length_matrix.json")["cells"]
+    assert len(cells) == 243
+    fast = {}
+    for c in cells:
+        key, iv, aad, pt = matrix_inputs(c["kbits"], c["aad_len"], c["pt_len"])
+        f = fast.setdefault(key, orc.Fast(key))
+        ct, tag = f.encrypt(iv, aad, pt)
+        assert tag.hex() == c["tag"], c
+        assert hashlib.sha256(ct).hexdigest() == c["ct_sha256"], c
+        assert f.decrypt(iv, aad, ct) == (pt, tag)
+        if c["pt_len"] <= 4096:           # literal layer on the cheaper cells
+            assert orc.gcm_encrypt(key, iv, aad, pt) == (ct, tag)
+
+
+def test_streams_up_to_64MiB(orc):
+    import numpy as np
+    for c in golden("streams.json")["cases"]:
+        if c["n_bytes"] > (64 << 20):
+            continue
+        key, iv = stream_key_iv(c)
+        pt = np.frombuffer(orc.fill_splitmix64(c["n_bytes"], c["pt_seed"], c["first_word"]), dtype=np.uint8)
+        ct = np.empty_like(pt)
+        f = orc.Fast(key)
+        # chunked on purpose: exercises the streaming interface the GiB-scale GPU checks rely on
+        f.begin(iv)
+        f.aad(bytes.fromhex(c["aad"]))
+        step = 16 << 20
+        for off in range(0, c["n_bytes"], step):
+            f.update(pt[off:off + step], ct[off:off + step])
+        assert f.final().hex() == c["tag"], c["name"]
+        assert hashlib.sha256(ct.data).hexdigest() == c["ct_sha256"], c["name"]
+        assert bytes(ct[:64]).hex() == c["ct_head"]
+
+
+def test_shard_algebra(orc):
+    s = golden("shards.json")
+    h = bytes.fromhex(s["h"])
+    ct = bytes.fromhex(s["ct"])
+    f = orc.Fast(bytes.fromhex(s["key"]))
+    assert f.h == h
+    fold = bytes(16)
+    for sh in s["shards"]:
+        data = ct[16 * sh["first_block"]:16 * sh["end_block"]]
+        p = orc.ghash_poly(h, data)
+        assert p.hex() == sh["poly"] and f.ghash_poly(data).hex() == sh["poly"]
+        w = orc.gfmul(orc.gfpow(h, sh["weight_exp"]), p)
+        assert w.hex() == sh["weighted"]
+        fold = bytes(a ^ b for a, b in zip(fold, w))
+    assert fold.hex() == s["folded"]
+
+
+def test_batch_first64(orc):
+    b = golden("batch.json")
+    keys, ivs, pt = batch_inputs(0, 64, 4096)
+    sha = hashlib.sha256()
+    for p in range(64):
+        ct, tag = orc.Fast(keys[16 * p:16 * p + 16]).encrypt(ivs[12 * p:12 * p + 12], b"", pt[4096 * p:4096 * (p + 1)])
+        assert tag.hex() == b["first64_tags"][p]
+        sha.update(ct)
+    assert sha.hexdigest() == b["first64_ct_sha256"]
+
+
+def test_keystream_and_length_limit(orc):
+    key, iv = splitmix_bytes(1, 32), splitmix_bytes(2, 12)
+    f = orc.Fast(key)
+    ks = f.keystream(iv, 5, 3)
+    ct, _ = f.encrypt(iv, b"", bytes(16 * 8))
+    assert ks == ct[16 * 5:16 * 8]
+
+
+def test_external_libcrypto_agrees_when_present(orc):
+    from oracle import libcrypto_ref as R
+    if not R.available():
+        pytest.skip("no libcrypto")
+    for n in (0, 5, 16, 1000, 70000):
+        key, iv, aad, pt = splitmix_bytes(9, 24), splitmix_bytes(10, 12), splitmix_bytes(11, 21), splitmix_bytes(12, n)
+        assert R.encrypt(key, iv, aad, pt) == orc.Fast(key).encrypt(iv, aad, pt)
