@@ -115,6 +115,18 @@ def cpu_baseline(n_threads, budget_s=12.0):
     return out
 
 
+def usable_cores():
+    """cores this process may really use: affinity mask capped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(p) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def pmc_traffic(tag):
     """HBM bytes per launch of the fused kernel from a committed rocprofv3 PMC summary, if one exists
     for this workload (profiles/pmc_<tag>.json written by profiles/collect_pmc.py); else None."""
@@ -283,7 +295,7 @@ def main():
         }
         if N == 1 and not args.no_cpu_baseline:
             try:
-                line["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+                line["cpu_baseline"] = cpu_baseline(usable_cores())
             except Exception as e:
                 line["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)
