@@ -4,7 +4,8 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SO = os.path.join(HERE, "libaesgcm_hip.so")
+# AESGCM_LIB selects an alternative build of the same sources (A/B experiments with other -D settings)
+SO = os.environ.get("AESGCM_LIB") or os.path.join(HERE, "libaesgcm_hip.so")
 
 
 def needs_build():
@@ -18,6 +19,8 @@ def needs_build():
 
 def build(force=False, quiet=True):
     """Compile csrc/*.hip -> libaesgcm_hip.so.  Raises if hipcc is unavailable and no .so exists."""
+    if os.environ.get("AESGCM_LIB"):
+        return SO
     if not force and not needs_build():
         return SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -19,8 +19,12 @@
 typedef uint32_t u32;
 typedef uint64_t u64;
 
-#define AESGCM_WG 512          /* lanes per workgroup = GHASH lane stride S */
+#ifndef AESGCM_LOG_WG
+#define AESGCM_LOG_WG 10       /* log2(lanes per workgroup); 9 and 10 are supported */
+#endif
+#define AESGCM_WG (1 << AESGCM_LOG_WG)   /* lanes per workgroup = GHASH lane stride S = radix of the H-power tables */
 #define AESGCM_GMAX 512        /* max workgroups per launch (2 per CU on 256 CUs) */
+#define AESGCM_NPW (AESGCM_WG + 1)       /* entries per power table: exponent digits 0..WG */
 #define AESGCM_LDS_GH 8192     /* bytes: 32 nibble positions x 16 entries x 16 B */
 #define AESGCM_LDS_AES 65536   /* bytes: 256 entries x (32 replicas of T0 | 32 replicas of T2) */
 #define AESGCM_LDS_BYTES (AESGCM_LDS_AES + AESGCM_LDS_GH)
@@ -294,9 +298,9 @@ struct KeyMaterial {         // per context (device memory)
     u32 G;                   // workgroups the K table was built for
     u32 _pad[2];
     uint4 h;                 // H = E_K(0^128)
-    uint4 pw[4][513];        // pw[d][k] = H^(k * 512^d)
-    uint4 bp2[513];          // bp2[k] = beta^k * H^2, beta = H^512
-    uint4 ktab[512];         // nibble tables of K = H^(G*512): entry p*16+v
+    uint4 pw[4][AESGCM_NPW]; // pw[d][k] = H^(k * WG^d)
+    uint4 bp2[AESGCM_GMAX + 1]; // bp2[k] = beta^k * H^2, beta = H^WG
+    uint4 ktab[512];         // nibble tables of K = H^64 (lane stride of a wave): entry p*16+v
     uint8_t rk_bytes[240];   // expanded key as the byte string tb/key_exp.py produces
 };
 
@@ -306,24 +310,40 @@ struct MainParams {
     const unsigned char *in;     // data in (16-byte aligned) or NULL (MODE_KS)
     unsigned char *out;
     const unsigned char *aad;    // AAD bytes or NULL
-    uint4 *parts;                // workgroup partials out (GHASH modes)
+    uint4 *parts;                // one GHASH partial per chunk (GHASH modes)
+    u32 *counter;                // chunk dispenser (atomic); chunk index = fetched value - counter_base
     u64 aad_len;                 // bytes
     u64 n_aad;                   // AAD blocks
     u64 len;                     // data bytes
     u64 n_seq;                   // n_aad + data blocks
-    u64 pad;                     // T*GS - n_seq
-    u64 GS;                      // G' * 512
-    u32 T;                       // iterations
+    u64 rows;                    // R = ceil(n_seq / 64): one row = one 64-lane wave iteration
+    u32 pad;                     // 64*R - n_seq front-padding slots (< 64, all in row 0)
+    u32 Tw;                      // rows per chunk
+    u32 C;                       // chunks = ceil(R / Tw); chunk 0 is the short one (R0 rows)
+    u32 R0;                      // rows in chunk 0 = R - (C-1)*Tw
+    u32 counter_base;
     u32 ctr0;                    // counter of data block 0 (2 + first_block)
     u32 iv0, iv1, iv2;           // IV as memory-order words
     u32 aad_aligned;             // AAD pointer 16-byte aligned
+    u32 flags;                   // experiment switches (AESGCM_FLAGS)
+    u64 *trace;                  // optional per-workgroup {start, end, HW_ID | XCC_ID << 32, chunks done} (measurement support)
 };
 
-// launch geometry for a GHASH sequence of n_seq blocks on a device that runs G workgroups per full launch
-HD void main_geometry(u64 n_seq, u32 G, u64 *Gp, u64 *T) {
-    const u64 full = (u64)G * AESGCM_WG;
-    if (n_seq <= full) { *T = 1; *Gp = (n_seq + AESGCM_WG - 1) / AESGCM_WG; }
-    else { *T = (n_seq + full - 1) / full; *Gp = G; }
+#define AESGCM_MAX_CHUNKS (AESGCM_GMAX * AESGCM_WG)   /* two-stage combine capacity: GMAX stage-1 workgroups x WG lanes */
+
+// Chunking of a GHASH sequence of n_seq blocks: rows of 64 blocks, Tw rows per chunk.  Enough chunks to
+// load-balance ~8k resident waves (>= 16 per wave when the message allows), long enough to amortise the
+// per-chunk tail multiply, and never more than the two-stage combine can fold.
+HD void main_geometry(u64 n_seq, u32 tw_override, u64 *rows, u32 *Tw, u32 *C) {
+    const u64 R = (n_seq + 63) / 64;
+    u64 t;
+    if (tw_override) t = tw_override;
+    else if (R <= (u64)16 * 131072) t = 16;
+    else { t = R / 131072; if (t > 256) t = 256; }
+    const u64 tmin = (R + AESGCM_MAX_CHUNKS - 1) / AESGCM_MAX_CHUNKS;
+    if (t < tmin) t = tmin;
+    if (t < 1) t = 1;
+    *rows = R; *Tw = (u32)t; *C = (u32)((R + t - 1) / t);
 }
 
 HD u32 load_le32(const uint8_t *b) { return (u32)b[0] | ((u32)b[1] << 8) | ((u32)b[2] << 16) | ((u32)b[3] << 24); }
@@ -357,17 +377,17 @@ HD bool setup_level(const uint4 *tab, int j, int tid, uint4 *prod) {
     *prod = gf_mul_mo(tab[tid], tab[base]);
     return true;
 }
-// after the beta table (d == 1) is complete in tab: bp2 and the nibble table of K = beta^G
+// after the beta table (d == 1) is complete in tab: bp2 (beta^k * H^2) and the nibble table of K = H^64
 HD void setup_beta_lane(KeyMaterial *km, const uint4 *tab, int tid) {
     const uint4 h2 = km->pw[0][2];
-    for (int k = tid; k < 513; k += 512) km->bp2[k] = gf_mul_mo(tab[k], h2);
-    km->ktab[tid] = gf_mul_mo(nibble_elem_mo(tid >> 4, (u32)(tid & 15)), tab[km->G]);
+    for (int k = tid; k <= AESGCM_GMAX; k += AESGCM_WG) km->bp2[k] = gf_mul_mo(tab[k], h2);
+    if (tid < 512) km->ktab[tid] = gf_mul_mo(nibble_elem_mo(tid >> 4, (u32)(tid & 15)), km->pw[0][64]);
 }
 
 // ---- k_main pieces -----------------------------------------------------------------------------
 // LDS image of one workgroup: what thread `tid` of AESGCM_WG writes
 HD void main_fill_lds(unsigned char *smem, const KeyMaterial *km, const DevTables *tb, u32 tid, bool gh) {
-    if (gh) reinterpret_cast<uint4 *>(smem + AESGCM_LDS_GH_OFF)[tid] = km->ktab[tid];
+    if (gh && tid < 512) reinterpret_cast<uint4 *>(smem + AESGCM_LDS_GH_OFF)[tid] = km->ktab[tid];
     uint4 *dst = reinterpret_cast<uint4 *>(smem + AESGCM_LDS_AES_OFF);
     for (u32 q = tid; q < AESGCM_LDS_AES / 16; q += AESGCM_WG) {
         const u32 t0 = tb->te0[q >> 4];
@@ -397,22 +417,23 @@ HD uint4 mask_block(uint4 v, u32 nbytes) {
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-// the hot loop of lane `tid` of workgroup `wg`: returns the lane's GHASH accumulator
+// The hot loop: lane `lane` (0..63) of the wave that owns chunk `c`.  Rows of the chunk are consecutive
+// 64-block groups; the lane runs Horner with K = H^64 (its own blocks are 64 apart).  Returns the lane's
+// GHASH accumulator for the chunk: sum_r X[row_r, lane] * K^(rows-1-r).
 template <int NR, int MODE>
-HD uint4 main_lane(const KeyMaterial *__restrict__ km, const MainParams &p, const unsigned char *smem, u32 wg, u32 tid) {
+HD uint4 main_chunk_lane(const KeyMaterial *__restrict__ km, const MainParams &p, const unsigned char *smem, const CtrConsts &cc, u32 c, u32 lane) {
     constexpr bool GH = (MODE == MODE_ENC || MODE == MODE_DEC);
     const u32 *__restrict__ rk = km->rk;
-    const u32 lb = (tid & 31u) << 2;
-    CtrConsts cc = {0, 0, 0, 0};
-    if (MODE != MODE_ECB) cc = ctr_round1_consts(p.iv0, p.iv1, p.iv2, rk, smem, lb);
+    const u32 lb = (lane & 31u) << 2;
     const u64 n_data_blocks = p.n_seq - p.n_aad;
     const u32 tail_bytes = (u32)(p.len & 15);          // 0 = last data block is full
     const u32 aad_tail = (u32)(p.aad_len & 15);
+    const u64 row0 = c ? (u64)p.R0 + (u64)(c - 1) * p.Tw : 0;
+    const u32 nrows = c ? p.Tw : p.R0;
     uint4 acc = make_uint4(0, 0, 0, 0);
-
-    for (u32 t = 0; t < p.T; ++t) {
-        const u64 v = (u64)t * p.GS + (u64)wg * AESGCM_WG + tid;
-        if (GH && t > 0) acc = ghash_mul_const_lds(acc, smem);
+    u64 v = row0 * 64 + lane;                          // virtual slot (front padding included)
+    for (u32 r = 0; r < nrows; ++r, v += 64) {
+        if (GH && r > 0) acc = ghash_mul_const_lds(acc, smem);
         if (v < p.pad) continue;                       // front padding: contributes zero
         const u64 j = v - p.pad;                       // index in the GHASH sequence (AAD blocks then data blocks)
         uint4 gin;
@@ -448,13 +469,27 @@ HD uint4 main_lane(const KeyMaterial *__restrict__ km, const MainParams &p, cons
     }
     return acc;
 }
-// lane L carries H^(511-L) into the workgroup reduction
-HD G128 main_lane_tail(const KeyMaterial *__restrict__ km, uint4 acc, u32 tid) {
-    return gf_mul(mo_to_be(acc), mo_to_be(km->pw[0][AESGCM_WG - 1 - tid]));
+// per-message constants a lane computes once (round-1 hoisting)
+template <int MODE>
+HD CtrConsts main_lane_consts(const KeyMaterial *__restrict__ km, const MainParams &p, const unsigned char *smem, u32 lane) {
+    CtrConsts cc = {0, 0, 0, 0};
+    if (MODE != MODE_ECB) cc = ctr_round1_consts(p.iv0, p.iv1, p.iv2, km->rk, smem, (lane & 31u) << 2);
+    return cc;
+}
+// lane L of a wave carries H^(63-L) into the wave fold -> P_chunk = sum_{i in chunk} X_i H^(end-1-i)
+HD G128 main_lane_tail(uint4 acc, G128 tailpow_be) { return gf_mul(mo_to_be(acc), tailpow_be); }
+HD G128 main_lane_tailpow(const KeyMaterial *__restrict__ km, u32 lane) { return mo_to_be(km->pw[0][63 - lane]); }
+
+// stage 1 of the two-stage fold: chunk partial c weighted to the end of the sequence, H^((C-1-c)*Bc)
+HD G128 gf_pow_h_serial(const KeyMaterial *km, u64 e);
+HD G128 weigh_lane(const KeyMaterial *__restrict__ km, const uint4 *parts, u32 C, u64 Bc, u32 c) {
+    G128 z; z.w[0] = z.w[1] = z.w[2] = z.w[3] = 0;
+    if (c < C) z = gf_mul(mo_to_be(parts[c]), gf_pow_h_serial(km, (u64)(C - 1 - c) * Bc));
+    return z;
 }
 
 // ---- k_combine pieces --------------------------------------------------------------------------
-#define COMBINE_THREADS 576   /* 512 partial lanes + the length-block lane + the E_K(J0) lane, rounded to waves */
+#define COMBINE_THREADS (AESGCM_GMAX + 64)   /* GMAX partial lanes + the length-block lane + the E_K(J0) lane, rounded to waves */
 struct CombineParams {
     const uint4 *parts; u32 np; u32 gathered;
     u32 want_tag;                // 1 = TAG, 0 = POLY
@@ -489,32 +524,42 @@ HD G128 combine_lane(const KeyMaterial *__restrict__ km, const uint8_t *sbox, co
     }
     return z;
 }
-// H^e as the product of its four radix-512 digit entries (e < 2^36)
-HD G128 gf_pow_h_digit(const KeyMaterial *km, u64 e, u32 d) { return mo_to_be(km->pw[d][(e >> (9 * d)) & 511u]); }
+// H^e as the product of its four radix-WG digit entries (e < WG^4 >= 2^36)
+HD G128 gf_pow_h_digit(const KeyMaterial *km, u64 e, u32 d) { return mo_to_be(km->pw[d][(e >> (AESGCM_LOG_WG * d)) & (u64)(AESGCM_WG - 1)]); }
+
+HD G128 gf_pow_h_serial(const KeyMaterial *km, u64 e) {
+    G128 v = gf_pow_h_digit(km, e, 0);
+    for (u32 d = 1; d < 4; d++) { const u64 dig = (e >> (AESGCM_LOG_WG * d)) & (u64)(AESGCM_WG - 1); if (dig) v = gf_mul(v, gf_pow_h_digit(km, e, d)); }
+    return v;
+}
 
 // ---- host-side planning (shared by the C ABI and the CPU harness) -------------------------------
 static inline void iv_to_words(const uint8_t iv[12], u32 w[3]) { for (int q = 0; q < 3; q++) w[q] = load_le32(iv + 4 * q); }
 
-// Fill MainParams for one launch; returns the number of workgroups (0 = nothing to launch).
-static inline u32 plan_main(MainParams &p, int mode, u32 G, const uint8_t *iv, const void *aad, u64 aad_len,
+// Fill MainParams for one launch; returns the number of chunks (0 = nothing to launch).
+static inline u32 plan_main(MainParams &p, int mode, u32 tw_override, const uint8_t *iv, const void *aad, u64 aad_len,
                             const void *in, u64 len, void *out, u64 first_block, uint4 *parts) {
     const bool gh = (mode == MODE_ENC || mode == MODE_DEC);
     const u64 n_aad = gh ? (aad_len + 15) / 16 : 0;
     const u64 n_seq = n_aad + (len + 15) / 16;
     if (n_seq == 0) return 0;
-    u64 Gp, T;
-    main_geometry(n_seq, G, &Gp, &T);
+    u64 R; u32 Tw, C;
+    main_geometry(n_seq, tw_override, &R, &Tw, &C);
     p.in = (const unsigned char *)in; p.out = (unsigned char *)out; p.aad = (const unsigned char *)aad;
     p.parts = parts;
     p.aad_len = gh ? aad_len : 0; p.n_aad = n_aad; p.len = len; p.n_seq = n_seq;
-    p.GS = Gp * AESGCM_WG; p.T = (u32)T; p.pad = T * p.GS - n_seq;
+    p.rows = R; p.pad = (u32)(64 * R - n_seq); p.Tw = Tw; p.C = C; p.R0 = (u32)(R - (u64)(C - 1) * Tw);
     p.ctr0 = (u32)(2 + first_block);
     u32 w[3] = {0, 0, 0};
     if (iv) iv_to_words(iv, w);
     p.iv0 = w[0]; p.iv1 = w[1]; p.iv2 = w[2];
     p.aad_aligned = (((uintptr_t)aad) & 15) == 0;
-    return (u32)Gp;
+    return C;
 }
+// chunk partials are spaced Bc = 64*Tw blocks apart.  If that equals the table radix (Tw = 16) and there are
+// at most GMAX of them, k_combine folds them directly with the beta tables; otherwise k_weigh runs first.
+static inline bool needs_weigh(u32 C, u32 Tw) { return !(C <= AESGCM_GMAX && 64u * Tw == (u32)AESGCM_WG); }
+
 // whole-message tag from local workgroup partials:  P*H^2 ^ L*H ^ E_K(J0)
 static inline CombineParams plan_combine_tag(const uint4 *parts, u32 np, bool gathered, const uint8_t iv[12],
                                              u64 aad_len, u64 ct_len, uint4 *out) {
@@ -526,15 +571,15 @@ static inline CombineParams plan_combine_tag(const uint4 *parts, u32 np, bool ga
     return q;
 }
 // polynomial value of local partials times H^e (shard partial, aesgcm_ghash)
-static inline CombineParams plan_combine_poly(const uint4 *parts, u32 np, u64 e, uint4 *out) {
+static inline CombineParams plan_combine_poly(const uint4 *parts, u32 np, bool gathered, u64 e, uint4 *out) {
     CombineParams q = {};
-    q.parts = parts; q.np = np; q.e = e; q.out = out;
+    q.parts = parts; q.np = np; q.gathered = gathered ? 1u : 0u; q.e = e; q.out = out;
     return q;
 }
 // streaming: Y' = Y * H^nb ^ P(new blocks)
-static inline CombineParams plan_combine_carry(const uint4 *parts, u32 np, uint4 *state, u64 nb) {
+static inline CombineParams plan_combine_carry(const uint4 *parts, u32 np, bool gathered, uint4 *state, u64 nb) {
     CombineParams q = {};
-    q.parts = parts; q.np = np; q.carry = state; q.has_carry = 1; q.e_carry = nb; q.out = state;
+    q.parts = parts; q.np = np; q.gathered = gathered ? 1u : 0u; q.carry = state; q.has_carry = 1; q.e_carry = nb; q.out = state;
     return q;
 }
 // streaming final: tag = Y*H^2 ^ L*H ^ E_K(J0)

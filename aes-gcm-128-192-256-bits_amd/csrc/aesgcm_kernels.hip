@@ -4,23 +4,26 @@
 //   k_init_tables   per device, once: S-box (256 B) and T0 (1 KiB) computed from their definitions.
 //   k_setup         per key: aes_kexp (or pre-expanded load), H = E_K(0), H-power tables, nibble table of K.
 //   k_main<NR,MODE> the hot path: fused AES-CTR + GHASH partial evaluation (also ECB / keystream modes).
-//   k_combine       per message: folds the workgroup partials with powers of beta = H^512, optional
+//   k_weigh         large messages: weights every chunk partial to the end of the sequence (H^e, generic e).
+//   k_combine       per message: folds the workgroup partials with powers of beta = H^WG, optional
 //                   H^e weighting (shards / streaming), length block, E_K(J0) -> tag.
 //   k_gfmul, k_fill small utility kernels.
 //
 // GHASH re-association (DESIGN.md "GHASH as a polynomial"): the GHASH input sequence
-// A_0..A_{u-1}, C_0..C_{c-1} (n = u + c blocks) is right-aligned into a virtual index space of
-// T * G * 512 slots (front padding = zeros, which do not change a polynomial).  Slot
-// v = t*(G*512) + g*512 + L belongs to iteration t, workgroup g, lane L.  Each lane runs Horner with
-// the launch constant K = H^(G*512):  acc = acc*K ^ X.  After the loop lane L multiplies by
-// H^(511-L), the workgroup XOR-reduces to P_g, and k_combine forms  P = sum_g P_g * beta^(G-1-g)
-// = sum_i X_i H^(n-1-i).  The tag is (P*H ^ L)*H ^ E_K(J0) = P*H^2 ^ L*H ^ E_K(J0).
+// A_0..A_{u-1}, C_0..C_{c-1} (n = u + c blocks) is right-aligned into rows of 64 slots (front padding =
+// zeros, which do not change a polynomial) and cut into chunks of Tw rows.  Waves pull chunks from an atomic
+// dispenser; inside a chunk lane L runs Horner over its column with the per-key constant K = H^64
+// (acc = acc*K ^ X), multiplies by H^(63-L) and the wave XOR-folds to the chunk partial
+// P_c = sum_{i in chunk} X_i H^(end_c-1-i).  Folding P = sum_c P_c H^(n-end_c) happens in k_combine
+// (directly when the chunk spacing equals the table radix, after k_weigh otherwise).
+// The tag is (P*H ^ L)*H ^ E_K(J0) = P*H^2 ^ L*H ^ E_K(J0).
 #include "aesgcm_dev.h"
 #include "../../include/aesgcm.h"
 
 #include <mutex>
 #include <new>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -54,9 +57,9 @@ __global__ void k_fill_splitmix64(u64 *buf, size_t n_words, size_t tail_bytes, u
 //   lane 0      : key schedule (aes_kexp) or pre-expanded copy, H = E_K(0)  (gcm_gctr.vhd:141-144)
 //   all lanes   : four 513-entry power tables by doubling (9 multiply levels each), bp2, nibble table of K.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void k_setup(KeyMaterial *km, const DevTables *tb, const uint8_t *key, int key_len,
-                                               int preexpanded_nr, u32 G) {
-    __shared__ uint4 tab[513];
+__global__ __launch_bounds__(AESGCM_WG) void k_setup(KeyMaterial *km, const DevTables *tb, const uint8_t *key, int key_len,
+                                                     int preexpanded_nr, u32 G) {
+    __shared__ uint4 tab[AESGCM_NPW];
     __shared__ uint8_t s_sbox[256];
     const int tid = threadIdx.x;
     if (tid < 256) s_sbox[tid] = tb->sbox[tid];
@@ -64,18 +67,18 @@ __global__ __launch_bounds__(512) void k_setup(KeyMaterial *km, const DevTables 
     if (tid == 0) setup_lane0(km, s_sbox, key, key_len, preexpanded_nr, G, tab);
     __syncthreads();
     for (int d = 0; d < 4; d++) {
-        for (int j = 0; j < 9; j++) {
+        for (int j = 0; j < AESGCM_LOG_WG; j++) {
             uint4 prod;
             const bool act = setup_level(tab, j, tid, &prod);
             __syncthreads();
             if (act) tab[(1 << j) + tid] = prod;
             __syncthreads();
         }
-        for (int k = tid; k < 513; k += 512) km->pw[d][k] = tab[k];
+        for (int k = tid; k < AESGCM_NPW; k += AESGCM_WG) km->pw[d][k] = tab[k];
         __syncthreads();
         if (d == 1) setup_beta_lane(km, tab, tid);
         if (d < 3) {
-            uint4 next = tab[512];
+            uint4 next = tab[AESGCM_WG];
             __syncthreads();
             if (tid == 0) { tab[0] = gf_one_mo(); tab[1] = next; }
             __syncthreads();
@@ -84,32 +87,68 @@ __global__ __launch_bounds__(512) void k_setup(KeyMaterial *km, const DevTables 
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_main: the fused hot path.  One 16-byte block per lane per iteration (lane body: main_lane()).
+// k_main: the fused hot path.  Persistent workgroups; after the LDS tables are staged every WAVE is
+// autonomous: it pulls chunk indices from the dispenser and processes one 16-byte block per lane per row
+// (lane body: main_chunk_lane()).  No barrier after the staging one, so the age-ordered issue arbitration
+// of the CU (older waves first) only changes WHO does the work, never how long the kernel's tail is.
 // ------------------------------------------------------------------------------------------------
+#ifndef AESGCM_WAVES_PER_SIMD
+#define AESGCM_WAVES_PER_SIMD (2 * AESGCM_WG / 256)   /* two workgroups per CU */
+#endif
+__device__ __forceinline__ G128 wave_xor_fold(G128 z) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        z.w[0] ^= __shfl_xor(z.w[0], off); z.w[1] ^= __shfl_xor(z.w[1], off);
+        z.w[2] ^= __shfl_xor(z.w[2], off); z.w[3] ^= __shfl_xor(z.w[3], off);
+    }
+    return z;
+}
 template <int NR, int MODE>
-__global__ __launch_bounds__(AESGCM_WG, 4) void k_main(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const MainParams p) {
+__global__ __launch_bounds__(AESGCM_WG, AESGCM_WAVES_PER_SIMD) void k_main(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const MainParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr bool GH = (MODE == MODE_ENC || MODE == MODE_DEC);
-    const u32 tid = threadIdx.x;
+    const u32 tid = threadIdx.x, lane = tid & 63u;
+    if (p.trace && tid == 0) {
+        u64 *tr = p.trace + 4 * (u64)blockIdx.x;
+        tr[0] = wall_clock64();
+        tr[2] = (u64)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((u64)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xF) << 32);
+    }
     main_fill_lds(smem, km, tb, tid, GH);
     __syncthreads();
-    const uint4 acc = main_lane<NR, MODE>(km, p, smem, blockIdx.x, tid);
-    if (GH) {
-        G128 z = main_lane_tail(km, acc, tid);
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            z.w[0] ^= __shfl_xor(z.w[0], off); z.w[1] ^= __shfl_xor(z.w[1], off);
-            z.w[2] ^= __shfl_xor(z.w[2], off); z.w[3] ^= __shfl_xor(z.w[3], off);
+    const CtrConsts cc = main_lane_consts<MODE>(km, p, smem, lane);
+    G128 tailpow;
+    if (GH) tailpow = main_lane_tailpow(km, lane);
+    u32 done = 0;
+    for (;;) {
+        u32 c = 0;
+        if (lane == 0) c = atomicAdd(p.counter, 1u) - p.counter_base;
+        c = __builtin_amdgcn_readfirstlane(c);
+        if (c >= p.C) break;
+        const uint4 acc = main_chunk_lane<NR, MODE>(km, p, smem, cc, c, lane);
+        if (GH) {
+            const G128 z = wave_xor_fold(main_lane_tail(acc, tailpow));
+            if (lane == 0) p.parts[c] = be_to_mo(z);
         }
-        __syncthreads();                               // every wave is done with the LDS tables
-        uint4 *red = reinterpret_cast<uint4 *>(smem);
-        if ((tid & 63u) == 0) red[tid >> 6] = be_to_mo(z);
-        __syncthreads();
-        if (tid == 0) {
-            uint4 r = red[0];
-            for (int k = 1; k < AESGCM_WG / 64; k++) r = xor4(r, red[k]);
-            p.parts[blockIdx.x] = r;
-        }
+        ++done;
+    }
+    if (p.trace && lane == 0) {
+        u64 *tr = p.trace + 4 * (u64)blockIdx.x;
+        atomicMax((unsigned long long *)&tr[1], (unsigned long long)wall_clock64());
+        atomicAdd((unsigned long long *)&tr[3], (unsigned long long)done);
+    }
+}
+
+// k_weigh: one lane per chunk partial, z = P_c * H^((C-1-c)*Bc); workgroup XOR-fold -> out[blockIdx.x]
+__global__ __launch_bounds__(AESGCM_WG) void k_weigh(const KeyMaterial *__restrict__ km, const uint4 *__restrict__ parts, u32 C, u64 Bc, uint4 *out) {
+    __shared__ uint4 red[AESGCM_WG / 64];
+    const u32 tid = threadIdx.x;
+    const G128 z = wave_xor_fold(weigh_lane(km, parts, C, Bc, blockIdx.x * AESGCM_WG + tid));
+    if ((tid & 63u) == 0) red[tid >> 6] = be_to_mo(z);
+    __syncthreads();
+    if (tid == 0) {
+        uint4 r = red[0];
+        for (int k = 1; k < AESGCM_WG / 64; k++) r = xor4(r, red[k]);
+        out[blockIdx.x] = r;
     }
 }
 
@@ -207,8 +246,16 @@ struct aesgcm_ctx {
     int G = 0;                         // workgroups per full launch
     DevTables *tables = nullptr;
     KeyMaterial *km = nullptr;
-    uint4 *parts = nullptr;            // G partials
+    uint4 *parts = nullptr;            // one partial per chunk (grown on demand)
+    size_t parts_cap = 0;              // entries
+    uint4 *stage1 = nullptr;           // GMAX outputs of k_weigh
+    u32 *d_counter = nullptr;          // chunk dispenser
+    u32 counter_base = 0;              // value the dispenser holds before the next launch
+    u32 tw_override = 0;               // AESGCM_TW
     uint4 *d_tag = nullptr;            // [0] tag / poly result, [1] streaming state Y
+    u64 *d_trace = nullptr;            // per-workgroup trace of the last k_main launch (timing mode only)
+    u32 last_np = 0;
+    u32 flags = 0;                     // AESGCM_FLAGS experiment switches
     hipStream_t stream = nullptr;
     // host-API staging
     unsigned char *st_in = nullptr, *st_out = nullptr, *st_aad = nullptr;
@@ -264,24 +311,64 @@ static int set_lds_attrs(int device, DeviceState *ds) {
 
 // Enqueue the fused kernel over (aad, data) and return the number of partials it wrote.
 // mode ENC/DEC: GHASH partials into c->parts.  mode KS/ECB: no GHASH.
+// What the fold stage needs to know about the partials a launch produced.
+struct Partials { const uint4 *ptr = nullptr; u32 np = 0; bool gathered = false; };
+
+static int grow_parts(aesgcm_ctx *c, size_t need) {
+    if (need <= c->parts_cap) return AESGCM_OK;
+    if (c->parts) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->parts)); c->parts = nullptr; c->parts_cap = 0; }
+    size_t n = need < 4096 ? 4096 : need;
+    hipError_t e = hipMalloc(&c->parts, n * sizeof(uint4));
+    if (e == hipErrorOutOfMemory) return AESGCM_ENOMEM;
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc");
+    c->parts_cap = n;
+    return AESGCM_OK;
+}
+
+// Enqueue the fused kernel over (aad, data) (+ k_weigh when the chunk partials need generic weights) and
+// describe the partials for k_combine.  mode ENC/DEC: GHASH partials.  mode KS/ECB: no GHASH.
 static int enqueue_main(aesgcm_ctx *c, int mode, const uint8_t iv[12], const void *d_aad, u64 aad_len,
-                        const void *d_in, u64 len, void *d_out, u64 first_block, hipStream_t st, u32 *np_out) {
+                        const void *d_in, u64 len, void *d_out, u64 first_block, hipStream_t st, Partials *po) {
     const bool gh = (mode == MODE_ENC || mode == MODE_DEC);
-    if (np_out) *np_out = 0;
+    if (po) *po = Partials();
     if (((uintptr_t)d_in & 15) || ((uintptr_t)d_out & 15)) return AESGCM_EALIGN;
     MainParams p;
     memset(&p, 0, sizeof p);
-    const u32 Gp = plan_main(p, mode, (u32)c->G, iv, d_aad, aad_len, d_in, len, d_out, first_block, c->parts);
-    if (!Gp) return AESGCM_OK;
+    const u32 C = plan_main(p, mode, c->tw_override, iv, d_aad, aad_len, d_in, len, d_out, first_block, nullptr);
+    if (!C) return AESGCM_OK;
+    int rc;
+    if (gh && (rc = grow_parts(c, C))) return rc;
+    p.parts = c->parts;
+    p.counter = c->d_counter;
+    p.counter_base = c->counter_base;
+    p.flags = c->flags;
+    u32 wgs = (C + AESGCM_WG / 64 - 1) / (AESGCM_WG / 64);          // one wave per chunk is enough for small inputs
+    if (wgs > (u32)c->G) wgs = (u32)c->G;
+    c->counter_base += C + wgs * (AESGCM_WG / 64);                 // every wave makes exactly one failing fetch
+    p.trace = nullptr;
+    if (c->timing) {
+        p.trace = c->d_trace;
+        HIPCHK(hipMemsetAsync(c->d_trace, 0, sizeof(u64) * 4 * AESGCM_GMAX, st));
+    }
+    c->last_np = wgs;
     std::pair<hipEvent_t, hipEvent_t> evp;
     if (c->timing) {
         if (!c->ev_pool.empty()) { evp = c->ev_pool.back(); c->ev_pool.pop_back(); }
         else { HIPCHK(hipEventCreate(&evp.first)); HIPCHK(hipEventCreate(&evp.second)); }
         HIPCHK(hipEventRecord(evp.first, st));
     }
-    HIPCHK(launch_main(mode, c->nr, dim3((unsigned)Gp), st, c->km, c->tables, p));
+    HIPCHK(launch_main(mode, c->nr, dim3(wgs), st, c->km, c->tables, p));
     if (c->timing) { HIPCHK(hipEventRecord(evp.second, st)); c->ev.push_back(evp); }
-    if (np_out) *np_out = gh ? (u32)Gp : 0;
+    if (gh && po) {
+        if (needs_weigh(C, p.Tw)) {
+            const u32 nw = (C + AESGCM_WG - 1) / AESGCM_WG;
+            hipLaunchKernelGGL(k_weigh, dim3(nw), dim3(AESGCM_WG), 0, st, c->km, c->parts, C, (u64)64 * p.Tw, c->stage1);
+            HIPCHK(hipGetLastError());
+            po->ptr = c->stage1; po->np = nw; po->gathered = true;
+        } else {
+            po->ptr = c->parts; po->np = C; po->gathered = false;
+        }
+    }
     return AESGCM_OK;
 }
 
@@ -305,10 +392,10 @@ static int crypt_dev(aesgcm_ctx *c, int dec, const uint8_t iv[12], const void *d
     if (aad_len && !d_aad) return AESGCM_EARG;
     if (len && (!d_in || !d_out)) return AESGCM_EARG;
     HIPCHK(hipSetDevice(c->device));
-    u32 np = 0;
-    rc = enqueue_main(c, dec ? MODE_DEC : MODE_ENC, iv, d_aad, aad_len, d_in, len, d_out, 0, st, &np);
+    Partials pp;
+    rc = enqueue_main(c, dec ? MODE_DEC : MODE_ENC, iv, d_aad, aad_len, d_in, len, d_out, 0, st, &pp);
     if (rc) return rc;
-    return enqueue_combine(c, plan_combine_tag(c->parts, np, false, iv, aad_len, len, c->d_tag), st);
+    return enqueue_combine(c, plan_combine_tag(pp.ptr, pp.np, pp.gathered, iv, aad_len, len, c->d_tag), st);
 }
 
 static int ct_compare16(const uint8_t *a, const uint8_t *b) {
@@ -375,7 +462,11 @@ static int ctx_create_common(aesgcm_ctx **out, int device, const uint8_t *key, s
     c->device = device;
     c->tables = ds->tables;
     c->nr = pre_nr ? pre_nr : (int)(key_len / 4 + 6);
-    int G = 2 * ds->n_cu;
+    int per_cu = 2;
+    if (const char *e = getenv("AESGCM_WGS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 2) per_cu = v; }
+    if (const char *e = getenv("AESGCM_FLAGS")) c->flags = (u32)strtoul(e, nullptr, 0);
+    if (const char *e = getenv("AESGCM_TW")) c->tw_override = (u32)strtoul(e, nullptr, 0);
+    int G = per_cu * ds->n_cu;
     if (G > AESGCM_GMAX) G = AESGCM_GMAX;
     if (G < 1) G = 1;
     c->G = G;
@@ -383,14 +474,17 @@ static int ctx_create_common(aesgcm_ctx **out, int device, const uint8_t *key, s
     hipError_t e;
     if ((e = hipStreamCreate(&c->stream)) != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate"); }
     if ((e = hipMalloc(&c->km, sizeof(KeyMaterial))) != hipSuccess ||
-        (e = hipMalloc(&c->parts, sizeof(uint4) * AESGCM_GMAX)) != hipSuccess ||
-        (e = hipMalloc(&c->d_tag, sizeof(uint4) * 4)) != hipSuccess) { aesgcm_ctx_destroy(c); return hip_fail(e, "hipMalloc"); }
+        (e = hipMalloc(&c->stage1, sizeof(uint4) * AESGCM_GMAX)) != hipSuccess ||
+        (e = hipMalloc(&c->d_counter, 64)) != hipSuccess ||
+        (e = hipMemset(c->d_counter, 0, 64)) != hipSuccess ||
+        (e = hipMalloc(&c->d_tag, sizeof(uint4) * 4)) != hipSuccess ||
+        (e = hipMalloc(&c->d_trace, sizeof(u64) * 4 * AESGCM_GMAX)) != hipSuccess) { aesgcm_ctx_destroy(c); return hip_fail(e, "hipMalloc"); }
     uint8_t *d_key = nullptr;
     size_t kb = pre_nr ? (size_t)16 * (pre_nr + 1) : key_len;
     if ((e = hipMalloc(&d_key, 256)) != hipSuccess) { aesgcm_ctx_destroy(c); return hip_fail(e, "hipMalloc"); }
     e = hipMemcpyAsync(d_key, key, kb, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_setup, dim3(1), dim3(512), 0, c->stream, c->km, c->tables, d_key, (int)key_len, pre_nr, (u32)G);
+        hipLaunchKernelGGL(k_setup, dim3(1), dim3(AESGCM_WG), 0, c->stream, c->km, c->tables, d_key, (int)key_len, pre_nr, (u32)G);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemsetAsync(d_key, 0, 256, c->stream);    // do not leave key bytes behind
@@ -417,7 +511,10 @@ int aesgcm_ctx_destroy(aesgcm_ctx *c) {
     for (auto &e : c->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     if (c->km) { hipMemset(c->km, 0, sizeof(KeyMaterial)); hipFree(c->km); }
     if (c->parts) hipFree(c->parts);
+    if (c->stage1) hipFree(c->stage1);
+    if (c->d_counter) hipFree(c->d_counter);
     if (c->d_tag) hipFree(c->d_tag);
+    if (c->d_trace) hipFree(c->d_trace);
     if (c->st_in) hipFree(c->st_in);
     if (c->st_out) hipFree(c->st_out);
     if (c->st_aad) hipFree(c->st_aad);
@@ -587,11 +684,11 @@ int aesgcm_ghash(aesgcm_ctx *c, const uint8_t *data, size_t len, uint8_t y[16]) 
     HIPCHK(hipSetDevice(c->device));
     int rc;
     if ((rc = stage_in(c, data, len, nullptr, 0))) return rc;
-    u32 np = 0;
+    Partials pp;
     uint8_t iv0[12] = {0};
     // the data rides in the AAD slot of the GHASH sequence (GHASH only, no AES)
-    if ((rc = enqueue_main(c, MODE_ENC, iv0, c->st_aad, len, c->st_in, 0, c->st_out, 0, c->stream, &np))) return rc;
-    if ((rc = enqueue_combine(c, plan_combine_poly(c->parts, np, 1, c->d_tag), c->stream))) return rc;   // Y = P * H
+    if ((rc = enqueue_main(c, MODE_ENC, iv0, c->st_aad, len, c->st_in, 0, c->st_out, 0, c->stream, &pp))) return rc;
+    if ((rc = enqueue_combine(c, plan_combine_poly(pp.ptr, pp.np, pp.gathered, 1, c->d_tag), c->stream))) return rc;   // Y = P * H
     HIPCHK(hipMemcpyAsync(y, c->d_tag, 16, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return AESGCM_OK;
@@ -611,9 +708,9 @@ int aesgcm_shard_crypt_dev(aesgcm_ctx *c, int decrypt, const uint8_t iv[12], con
     if (first_block != 0 && aad_len) return AESGCM_EARG;
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = pick_stream(c, stream);
-    u32 np = 0;
-    if ((rc = enqueue_main(c, decrypt ? MODE_DEC : MODE_ENC, iv, d_aad, aad_len, d_in, len, d_out, first_block, st, &np))) return rc;
-    return enqueue_combine(c, plan_combine_poly(c->parts, np, total_blocks - (first_block + my_blocks), (uint4 *)d_partial), st);
+    Partials pp;
+    if ((rc = enqueue_main(c, decrypt ? MODE_DEC : MODE_ENC, iv, d_aad, aad_len, d_in, len, d_out, first_block, st, &pp))) return rc;
+    return enqueue_combine(c, plan_combine_poly(pp.ptr, pp.np, pp.gathered, total_blocks - (first_block + my_blocks), (uint4 *)d_partial), st);
 }
 int aesgcm_shard_finalize_dev(aesgcm_ctx *c, const uint8_t iv[12], const void *d_partials, size_t n_partials,
                               size_t aad_len, uint64_t total_len, uint8_t tag[16], void *stream) {
@@ -638,12 +735,12 @@ int aesgcm_stream_begin(aesgcm_ctx *c, const uint8_t iv[12], int decrypt) {
     return AESGCM_OK;
 }
 static int stream_absorb(aesgcm_ctx *c, const void *d_aad, u64 aad_len, const void *d_in, u64 len, void *d_out, u64 first_block) {
-    u32 np = 0;
-    int rc = enqueue_main(c, c->s_dec ? MODE_DEC : MODE_ENC, c->s_iv, d_aad, aad_len, d_in, len, d_out, first_block, c->stream, &np);
+    Partials pp;
+    int rc = enqueue_main(c, c->s_dec ? MODE_DEC : MODE_ENC, c->s_iv, d_aad, aad_len, d_in, len, d_out, first_block, c->stream, &pp);
     if (rc) return rc;
     const u64 nb = (aad_len + 15) / 16 + (len + 15) / 16;
     c->s_blocks += nb;
-    return enqueue_combine(c, plan_combine_carry(c->parts, np, c->d_tag + 1, nb), c->stream);       // Y' = Y * H^nb ^ P
+    return enqueue_combine(c, plan_combine_carry(pp.ptr, pp.np, pp.gathered, c->d_tag + 1, nb), c->stream);       // Y' = Y * H^nb ^ P
 }
 int aesgcm_stream_aad(aesgcm_ctx *c, const uint8_t *aad, size_t len) {
     if (!c || (len && !aad)) return AESGCM_EARG;
@@ -751,6 +848,16 @@ int aesgcm_ctx_timing_read(aesgcm_ctx *c, uint64_t *n, double *total_ms, int res
     if (n) *n = c->ev.size();
     if (total_ms) *total_ms = tot;
     if (reset) { for (auto &e : c->ev) c->ev_pool.push_back(e); c->ev.clear(); }
+    return AESGCM_OK;
+}
+
+int aesgcm_ctx_wg_trace(aesgcm_ctx *c, uint64_t *out, size_t max_wgs, size_t *n_wgs) {
+    if (!c || !out || !n_wgs) return AESGCM_EARG;
+    HIPCHK(hipSetDevice(c->device));
+    size_t n = c->last_np < max_wgs ? c->last_np : max_wgs;
+    HIPCHK(hipDeviceSynchronize());
+    if (n) HIPCHK(hipMemcpy(out, c->d_trace, n * 4 * sizeof(u64), hipMemcpyDeviceToHost));
+    *n_wgs = n;
     return AESGCM_OK;
 }
 

@@ -23,7 +23,7 @@ SYMBOLS = [
     "aesgcm_stream_begin", "aesgcm_stream_aad", "aesgcm_stream_update", "aesgcm_stream_final",
     "aesgcm_dev_alloc", "aesgcm_dev_free", "aesgcm_dev_upload", "aesgcm_dev_download", "aesgcm_dev_sync",
     "aesgcm_fill_splitmix64_dev",
-    "aesgcm_ctx_timing_enable", "aesgcm_ctx_timing_read", "aesgcm_ctx_geometry",
+    "aesgcm_ctx_timing_enable", "aesgcm_ctx_timing_read", "aesgcm_ctx_geometry", "aesgcm_ctx_wg_trace",
 ]
 
 
@@ -88,6 +88,7 @@ def load():
     L.aesgcm_fill_splitmix64_dev.argtypes = [cint, vp, sz, u64, u64, vp]
     L.aesgcm_ctx_timing_enable.argtypes = [vp, cint]
     L.aesgcm_ctx_timing_read.argtypes = [vp, ctypes.POINTER(u64), ctypes.POINTER(ctypes.c_double), cint]
+    L.aesgcm_ctx_wg_trace.argtypes = [vp, vp, sz, ctypes.POINTER(sz)]
     L.aesgcm_ctx_geometry.argtypes = [vp, ctypes.POINTER(cint), ctypes.POINTER(cint), ctypes.POINTER(cint)]
     if L.aesgcm_abi_version() != 1:
         raise ImportError("libaesgcm_hip.so ABI %d, expected 1" % L.aesgcm_abi_version())
@@ -361,6 +362,13 @@ class Context:
         n, ms = u64(0), ctypes.c_double(0)
         _chk(load().aesgcm_ctx_timing_read(self._c, ctypes.byref(n), ctypes.byref(ms), int(reset)))
         return n.value, ms.value
+
+    def wg_trace(self, max_wgs=512):
+        """[(start, end, hw_id, xcc_id)] per workgroup of the last timed launch (100 MHz wall clock)."""
+        buf = (u64 * (4 * max_wgs))()
+        n = sz(0)
+        _chk(load().aesgcm_ctx_wg_trace(self._c, buf, max_wgs, ctypes.byref(n)))
+        return [tuple(buf[4 * i:4 * i + 4]) for i in range(n.value)]
 
     def geometry(self):
         a, b, c = cint(0), cint(0), cint(0)

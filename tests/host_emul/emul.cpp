@@ -28,47 +28,47 @@ static void init_tables() { for (u32 x = 0; x < 256; x++) { u32 s = sbox_calc(x)
 
 // emulated k_setup (same barrier structure: compute every lane's product, then commit)
 static void emu_setup(KeyMaterial *km, const uint8_t *key, int key_len, int pre_nr, u32 G) {
-    static uint4 tab[513];
+    static uint4 tab[AESGCM_NPW];
     setup_lane0(km, g_tb.sbox, key, key_len, pre_nr, G, tab);
     for (int d = 0; d < 4; d++) {
-        for (int j = 0; j < 9; j++) {
-            static uint4 prod[512]; static bool act[512];
-            for (int tid = 0; tid < 512; tid++) act[tid] = setup_level(tab, j, tid, &prod[tid]);
-            for (int tid = 0; tid < 512; tid++) if (act[tid]) tab[(1 << j) + tid] = prod[tid];
+        for (int j = 0; j < AESGCM_LOG_WG; j++) {
+            static uint4 prod[AESGCM_WG]; static bool act[AESGCM_WG];
+            for (int tid = 0; tid < AESGCM_WG; tid++) act[tid] = setup_level(tab, j, tid, &prod[tid]);
+            for (int tid = 0; tid < AESGCM_WG; tid++) if (act[tid]) tab[(1 << j) + tid] = prod[tid];
         }
-        for (int k = 0; k < 513; k++) km->pw[d][k] = tab[k];
-        if (d == 1) for (int tid = 0; tid < 512; tid++) setup_beta_lane(km, tab, tid);
-        if (d < 3) { uint4 next = tab[512]; tab[0] = gf_one_mo(); tab[1] = next; }
+        for (int k = 0; k < AESGCM_NPW; k++) km->pw[d][k] = tab[k];
+        if (d == 1) for (int tid = 0; tid < AESGCM_WG; tid++) setup_beta_lane(km, tab, tid);
+        if (d < 3) { uint4 next = tab[AESGCM_WG]; tab[0] = gf_one_mo(); tab[1] = next; }
     }
 }
 
 static void xor_g(G128 &a, const G128 &b) { for (int k = 0; k < 4; k++) a.w[k] ^= b.w[k]; }
 
 template <int NR, int MODE>
-static void emu_main_nr(const KeyMaterial *km, const MainParams &p, u32 Gp) {
+static void emu_main_nr(const KeyMaterial *km, const MainParams &p) {
     static unsigned char smem[AESGCM_LDS_BYTES] __attribute__((aligned(16)));
     constexpr bool GH = (MODE == MODE_ENC || MODE == MODE_DEC);
     for (u32 tid = 0; tid < AESGCM_WG; tid++) main_fill_lds(smem, km, &g_tb, tid, GH);   // image is workgroup independent
-    for (u32 wg = 0; wg < Gp; wg++) {
+    // the dispenser hands chunk c to whichever wave asks next; results do not depend on who that is, so the
+    // harness walks the chunks in a scrambled order to make any accidental order dependence visible
+    for (u32 k = 0; k < p.C; k++) {
+        const u32 c = (p.C - 1) - k;      // reverse order
         G128 fold = {{0, 0, 0, 0}};
-        for (u32 tid = 0; tid < AESGCM_WG; tid++) {
-            uint4 acc = main_lane<NR, MODE>(km, p, smem, wg, tid);
-            if (GH) xor_g(fold, main_lane_tail(km, acc, tid));
+        for (u32 lane = 0; lane < 64; lane++) {
+            const CtrConsts cc = main_lane_consts<MODE>(km, p, smem, lane);
+            uint4 acc = main_chunk_lane<NR, MODE>(km, p, smem, cc, c, lane);
+            if (GH) xor_g(fold, main_lane_tail(acc, main_lane_tailpow(km, lane)));
         }
-        if (GH) p.parts[wg] = be_to_mo(fold);
+        if (GH) p.parts[c] = be_to_mo(fold);
     }
 }
-static void emu_main(int mode, const KeyMaterial *km, const MainParams &p, u32 Gp) {
-#define D(NR) switch (mode) { case MODE_ENC: emu_main_nr<NR, MODE_ENC>(km, p, Gp); break; case MODE_DEC: emu_main_nr<NR, MODE_DEC>(km, p, Gp); break; \
-                              case MODE_KS: emu_main_nr<NR, MODE_KS>(km, p, Gp); break; default: emu_main_nr<NR, MODE_ECB>(km, p, Gp); }
+static void emu_main(int mode, const KeyMaterial *km, const MainParams &p) {
+#define D(NR) switch (mode) { case MODE_ENC: emu_main_nr<NR, MODE_ENC>(km, p); break; case MODE_DEC: emu_main_nr<NR, MODE_DEC>(km, p); break; \
+                              case MODE_KS: emu_main_nr<NR, MODE_KS>(km, p); break; default: emu_main_nr<NR, MODE_ECB>(km, p); }
     if (km->nr == 10) { D(10) } else if (km->nr == 12) { D(12) } else { D(14) }
 #undef D
 }
-static G128 emu_pow_h(const KeyMaterial *km, u64 e) {
-    G128 v = gf_pow_h_digit(km, e, 0);
-    for (u32 d = 1; d < 4; d++) v = gf_mul(v, gf_pow_h_digit(km, e, d));
-    return v;
-}
+static G128 emu_pow_h(const KeyMaterial *km, u64 e) { return gf_pow_h_serial(km, e); }
 static void emu_combine(const KeyMaterial *km, const CombineParams &p) {
     G128 acc = {{0, 0, 0, 0}};
     for (u32 tid = 0; tid < COMBINE_THREADS; tid++) xor_g(acc, combine_lane(km, g_tb.sbox, p, tid));
@@ -83,15 +83,35 @@ static void emu_combine(const KeyMaterial *km, const CombineParams &p) {
     *p.out = be_to_mo(acc);
 }
 
+struct Parts { const uint4 *ptr; u32 np; bool gathered; };
 struct Emu {
-    KeyMaterial km; u32 G; std::vector<uint4> parts;
-    Emu(const uint8_t *key, int key_len, u32 G_) : G(G_), parts(AESGCM_GMAX) { emu_setup(&km, key, key_len, 0, G); }
-    void crypt(int dec, const uint8_t iv[12], const uint8_t *aad, u64 aad_len, const uint8_t *in, u64 len, uint8_t *out, uint8_t tag[16]) {
+    KeyMaterial km; u32 tw; std::vector<uint4> parts, stage1;
+    Emu(const uint8_t *key, int key_len, u32 tw_) : tw(tw_), parts(1 << 16), stage1(AESGCM_GMAX) { emu_setup(&km, key, key_len, 0, 512); }
+    // mirrors enqueue_main(): launch + optional k_weigh
+    Parts run(int mode, const uint8_t *iv, const void *aad, u64 aad_len, const void *in, u64 len, void *out, u64 first_block) {
         MainParams p; memset(&p, 0, sizeof p);
-        u32 Gp = plan_main(p, dec ? MODE_DEC : MODE_ENC, G, iv, aad, aad_len, in, len, out, 0, parts.data());
-        if (Gp) emu_main(dec ? MODE_DEC : MODE_ENC, &km, p, Gp);
+        u32 C = plan_main(p, mode, tw, iv, aad, aad_len, in, len, out, first_block, nullptr);
+        Parts r = {nullptr, 0, false};
+        if (!C) return r;
+        if (parts.size() < C) parts.resize(C);
+        p.parts = parts.data();
+        emu_main(mode, &km, p);
+        if (mode != MODE_ENC && mode != MODE_DEC) return r;
+        if (needs_weigh(C, p.Tw)) {
+            u32 nw = (C + AESGCM_WG - 1) / AESGCM_WG;
+            for (u32 w = 0; w < nw; w++) {
+                G128 fold = {{0, 0, 0, 0}};
+                for (u32 tid = 0; tid < AESGCM_WG; tid++) xor_g(fold, weigh_lane(&km, parts.data(), C, (u64)64 * p.Tw, w * AESGCM_WG + tid));
+                stage1[w] = be_to_mo(fold);
+            }
+            r.ptr = stage1.data(); r.np = nw; r.gathered = true;
+        } else { r.ptr = parts.data(); r.np = C; r.gathered = false; }
+        return r;
+    }
+    void crypt(int dec, const uint8_t iv[12], const uint8_t *aad, u64 aad_len, const uint8_t *in, u64 len, uint8_t *out, uint8_t tag[16]) {
+        Parts pp = run(dec ? MODE_DEC : MODE_ENC, iv, aad, aad_len, in, len, out, 0);
         uint4 t;
-        emu_combine(&km, plan_combine_tag(parts.data(), Gp, false, iv, aad_len, len, &t));
+        emu_combine(&km, plan_combine_tag(pp.ptr, pp.np, pp.gathered, iv, aad_len, len, &t));
         memcpy(tag, &t, 16);
     }
 };
@@ -118,7 +138,7 @@ static void test_units() {
     }
 }
 
-static void test_key(int key_len, u32 G, u64 seed, const std::vector<std::pair<u64, u64>> &sizes) {
+static void test_key(int key_len, u32 G /* rows per chunk override, 0 = production rule */, u64 seed, const std::vector<std::pair<u64, u64>> &sizes) {
     auto key = rnd(key_len, seed);
     Emu E(key.data(), key_len, G);
     uint8_t rk[240]; int nr;
@@ -130,26 +150,24 @@ static void test_key(int key_len, u32 G, u64 seed, const std::vector<std::pair<u
     // power tables spot checks: pw[0][k] = H^k via oracle repeated multiply
     {
         uint8_t acc[16] = {0x80};
-        for (int k = 0; k <= 512; k++) {
-            if (k == 0 || k == 1 || k == 2 || k == 3 || k == 255 || k == 256 || k == 257 || k == 511 || k == 512)
+        for (int k = 0; k <= AESGCM_WG; k++) {
+            if (k == 0 || k == 1 || k == 2 || k == 3 || k == 255 || k == 256 || k == 257 || k == 511 || k == 512 || k == AESGCM_WG - 1 || k == AESGCM_WG)
                 CHECK(memcmp(&E.km.pw[0][k], acc, 16) == 0, "pw[0][%d]", k);
             orc_gfmul(h, acc, acc);
         }
-        CHECK(memcmp(&E.km.pw[1][1], &E.km.pw[0][512], 16) == 0, "beta");
+        CHECK(memcmp(&E.km.pw[1][1], &E.km.pw[0][AESGCM_WG], 16) == 0, "beta");
         uint4 b2 = gf_mul_mo(E.km.pw[1][1], E.km.pw[1][1]);
         CHECK(memcmp(&E.km.pw[1][2], &b2, 16) == 0, "beta^2");
         uint4 g3 = gf_mul_mo(gf_mul_mo(E.km.pw[2][1], E.km.pw[2][1]), E.km.pw[2][1]);
         CHECK(memcmp(&E.km.pw[2][3], &g3, 16) == 0, "gamma^3");
-        CHECK(memcmp(&E.km.pw[3][1], &E.km.pw[2][512], 16) == 0, "delta");
+        CHECK(memcmp(&E.km.pw[3][1], &E.km.pw[2][AESGCM_WG], 16) == 0, "delta");
     }
     // ECB through the LDS round code
     {
         const size_t nb = 700;
         ABuf in(16 * nb), out(16 * nb);
         orc_fill_splitmix64(in.p, 16 * nb, seed + 5, 0);
-        MainParams p; memset(&p, 0, sizeof p);
-        u32 Gp = plan_main(p, MODE_ECB, G, nullptr, nullptr, 0, in.p, 16 * nb, out.p, 0, E.parts.data());
-        emu_main(MODE_ECB, &E.km, p, Gp);
+        E.run(MODE_ECB, nullptr, nullptr, 0, in.p, 16 * nb, out.p, 0);
         for (size_t i = 0; i < nb; i++) { uint8_t o[16]; orc_aes_encrypt_block(rk, nr, in.p + 16 * i, o); CHECK(memcmp(o, out.p + 16 * i, 16) == 0, "ecb block %zu", i); }
     }
     for (auto &sz : sizes) {
@@ -187,10 +205,8 @@ static void test_shards(int key_len, u32 G, u64 al, u64 n, int R, u64 seed) {
         u64 blocks = total_blocks / R + ((u64)r < total_blocks % R ? 1 : 0);
         u64 end = first + blocks;
         u64 len = (end == total_blocks ? n : 16 * end) - 16 * first;
-        MainParams p; memset(&p, 0, sizeof p);
-        u32 Gp = plan_main(p, MODE_ENC, G, iv.data(), r == 0 ? aad.data() : nullptr, r == 0 ? al : 0, pt.p + 16 * first, len, ct.p + 16 * first, first, E.parts.data());
-        if (Gp) emu_main(MODE_ENC, &E.km, p, Gp);
-        emu_combine(&E.km, plan_combine_poly(E.parts.data(), Gp, total_blocks - end, &gathered[r]));
+        Parts pp = E.run(MODE_ENC, iv.data(), r == 0 ? aad.data() : nullptr, r == 0 ? al : 0, pt.p + 16 * first, len, ct.p + 16 * first, first);
+        emu_combine(&E.km, plan_combine_poly(pp.ptr, pp.np, pp.gathered, total_blocks - end, &gathered[r]));
         first = end;
     }
     uint4 t;
@@ -210,17 +226,13 @@ static void test_stream(int key_len, u32 G, u64 al, u64 n, u64 chunk, u64 seed) 
     uint4 Y = make_uint4(0, 0, 0, 0);
     for (u64 off = 0; off < al; off += chunk) {
         u64 m = al - off < chunk ? al - off : chunk;
-        MainParams p; memset(&p, 0, sizeof p);
-        u32 Gp = plan_main(p, MODE_ENC, G, iv.data(), aad.data() + off, m, nullptr, 0, nullptr, 0, E.parts.data());
-        emu_main(MODE_ENC, &E.km, p, Gp);
-        emu_combine(&E.km, plan_combine_carry(E.parts.data(), Gp, &Y, (m + 15) / 16));
+        Parts pp = E.run(MODE_ENC, iv.data(), aad.data() + off, m, nullptr, 0, nullptr, 0);
+        emu_combine(&E.km, plan_combine_carry(pp.ptr, pp.np, pp.gathered, &Y, (m + 15) / 16));
     }
     for (u64 off = 0; off < n; off += chunk) {
         u64 m = n - off < chunk ? n - off : chunk;
-        MainParams p; memset(&p, 0, sizeof p);
-        u32 Gp = plan_main(p, MODE_ENC, G, iv.data(), nullptr, 0, pt.p + off, m, ct.p + off, off / 16, E.parts.data());
-        emu_main(MODE_ENC, &E.km, p, Gp);
-        emu_combine(&E.km, plan_combine_carry(E.parts.data(), Gp, &Y, (m + 15) / 16));
+        Parts pp = E.run(MODE_ENC, iv.data(), nullptr, 0, pt.p + off, m, ct.p + off, off / 16);
+        emu_combine(&E.km, plan_combine_carry(pp.ptr, pp.np, pp.gathered, &Y, (m + 15) / 16));
     }
     uint4 t;
     emu_combine(&E.km, plan_combine_final(&Y, iv.data(), al, n, &t));
@@ -234,9 +246,7 @@ static void test_keystream_and_ghash(u64 seed) {
     uint8_t rk[240]; int nr; orc_key_expand(key.data(), 32, rk, &nr);
     const u64 first = 0x01FFFF00ull - 2, nb = 600;      // counter crosses a 2^8, 2^16, 2^24 carry boundary
     ABuf out(16 * nb);
-    MainParams p; memset(&p, 0, sizeof p);
-    u32 Gp = plan_main(p, MODE_KS, E.G, iv.data(), nullptr, 0, out.p, 16 * nb, out.p, first, E.parts.data());
-    emu_main(MODE_KS, &E.km, p, Gp);
+    E.run(MODE_KS, iv.data(), nullptr, 0, out.p, 16 * nb, out.p, first);
     for (u64 i = 0; i < nb; i++) {
         uint8_t cb[16], o[16]; memcpy(cb, iv.data(), 12);
         u32 c = (u32)(2 + first + i); cb[12] = c >> 24; cb[13] = c >> 16; cb[14] = c >> 8; cb[15] = c;
@@ -246,10 +256,8 @@ static void test_keystream_and_ghash(u64 seed) {
     // GHASH chaining value Y = P*H
     for (u64 n : {1ull, 16ull, 17ull, 8191ull, 20000ull}) {
         auto d = rnd(n, seed + n);
-        memset(&p, 0, sizeof p);
-        Gp = plan_main(p, MODE_ENC, E.G, iv.data(), d.data(), n, nullptr, 0, nullptr, 0, E.parts.data());
-        emu_main(MODE_ENC, &E.km, p, Gp);
-        uint4 y; emu_combine(&E.km, plan_combine_poly(E.parts.data(), Gp, 1, &y));
+        Parts pp = E.run(MODE_ENC, iv.data(), d.data(), n, nullptr, 0, nullptr, 0);
+        uint4 y; emu_combine(&E.km, plan_combine_poly(pp.ptr, pp.np, pp.gathered, 1, &y));
         uint8_t yo[16] = {0}; orc_ghash_update((const uint8_t *)&E.km.h, yo, d.data(), n);
         CHECK(memcmp(&y, yo, 16) == 0, "ghash len %llu", (unsigned long long)n);
     }
@@ -259,24 +267,27 @@ int main(int argc, char **argv) {
     int level = argc > 1 ? atoi(argv[1]) : 1;
     init_tables();
     test_units();
-    const std::vector<std::pair<u64, u64>> small = {{0, 0}, {0, 1}, {0, 15}, {0, 16}, {0, 17}, {1, 0}, {20, 48}, {28, 48}, {68, 0}, {16, 511 * 16}, {17, 512 * 16}, {0, 513 * 16 + 5}, {4095, 4097}};
-    test_key(16, 1, 1, small);
-    test_key(24, 2, 2, small);
-    test_key(32, 3, 3, small);
-    // T > 1 (Horner with K = H^(G*512)) incl. ragged tails and front padding
-    test_key(16, 1, 4, {{0, 16 * 512 * 3}, {5, 16 * 512 * 2 + 7}, {33, 16 * 1500 + 1}});
-    test_key(32, 2, 5, {{0, 16 * 1024 * 2}, {16, 16 * 1024 * 2 - 16}, {40, 16 * 1024 * 3 + 13}, {1000 * 16, 16 * 3000}});
-    test_key(24, 4, 6, {{7, 16 * 2048 * 2 + 9}});
+    const u64 W = AESGCM_WG;     // blocks per chunk at the production Tw = 16
+    const std::vector<std::pair<u64, u64>> small = {{0, 0}, {0, 1}, {0, 15}, {0, 16}, {0, 17}, {1, 0}, {20, 48}, {28, 48}, {68, 0}, {16, 63 * 16}, {17, 64 * 16}, {0, 65 * 16 + 5},
+                                                    {16, (W - 1) * 16}, {17, W * 16}, {0, (W + 1) * 16 + 5}, {4095, 4097}};
+    test_key(16, 0, 1, small);          // production chunking rule (Tw = 16: direct fold with the beta tables)
+    test_key(24, 1, 2, small);          // Tw = 1: every row its own chunk -> k_weigh path, many chunks
+    test_key(32, 3, 3, small);          // Tw = 3: ragged first chunk
+    // several rows per chunk (Horner with K = H^64), ragged tails, front padding, > GMAX chunks
+    test_key(16, 0, 4, {{0, 16 * W * 3}, {5, 16 * W * 2 + 7}, {33, 16 * (W * 3 - 36) + 1}});
+    test_key(32, 2, 5, {{0, 16 * 2048 * 2}, {16, 16 * 2048 * 2 - 16}, {40, 16 * 2048 * 3 + 13}, {1000 * 16, 16 * 6144}});
+    test_key(24, 5, 6, {{7, 16 * 8192 + 9}});
+    test_key(32, 1, 9, {{3, 16 * 64 * 700 + 11}});      // 700+ chunks > GMAX -> two-stage fold with > 1 stage-1 lanes... one stage-1 workgroup
     test_shards(32, 2, 37, 203 * 16 + 5, 8, 77);
-    test_shards(16, 1, 0, 16 * 5000 + 3, 3, 78);
-    test_shards(24, 2, 20, 16 * 7, 8, 79);      // fewer blocks than ranks: some shards are empty
+    test_shards(16, 0, 0, 16 * (W * 5 + 100) + 3, 3, 78);
+    test_shards(24, 1, 20, 16 * 7, 8, 79);      // fewer blocks than ranks: some shards are empty
     test_stream(32, 2, 40, 1000, 16, 90);
-    test_stream(16, 1, 0, 16 * 2100 + 9, 16 * 700, 91);
+    test_stream(16, 0, 0, 16 * (W * 4 + 52) + 9, 16 * (W + 188), 91);
     test_stream(24, 3, 16 * 40 + 3, 33, 16 * 8, 92);
     test_keystream_and_ghash(55);
     if (level > 1) {
-        test_key(32, 8, 7, {{123, 16 * 4096 * 5 + 11}});
-        test_key(16, 512, 8, {{0, 16 * 3000}});              // production G with T = 1
+        test_key(32, 1, 7, {{123, 16 * 64 * 1100 + 11}});     // 1100 chunks: two stage-1 workgroups
+        test_key(16, 0, 8, {{0, 16 * W * 600}});              // production rule, > GMAX chunks of Tw = 16
     }
     printf(g_fail ? "EMUL FAILED (%d)\n" : "EMUL OK\n", g_fail);
     return g_fail ? 1 : 0;
