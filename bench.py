@@ -164,7 +164,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     import aesgcm_amd  # noqa: F401
-    from aesgcm_amd import lib
+    from aesgcm_amd import lib, sharding
     from oracle import oracle as O          # cpu_baseline leg + fixture cross-check only
 
     dev = local
@@ -179,25 +179,21 @@ def main():
     d_ct = lib.DeviceBuffer(per_gpu, device=dev)
 
     standard = (args.gib_per_gpu == 16.0 and args.key_bits == 256)
+    plan = sharding.plan_job(N, per_gpu, rank)
+    pt_seed = 0xAE5C0003 if N == 1 else 0xAE5C0004
+    msgs = []
+    for m in plan:
+        fixture = None
+        if standard:
+            fixture = "cfg3_aes256_16GiB" if N == 1 else "cfg4_aes256_msg%d_32GiB" % m["msg"]
+        msgs.append(dict(iv=sharding.tweak_iv(iv0, m["iv_tweak"]), total=m["total"], first_block=m["first_block"],
+                         off=m["off"], len=m["len"], fixture=fixture))
+        d_pt.fill_splitmix64(pt_seed, m["stream_word"], nbytes=m["len"], offset=m["off"])
     if N == 1:
-        msgs = [dict(iv=iv0, total=per_gpu, first_block=0, off=0, len=per_gpu, fixture="cfg3_aes256_16GiB" if standard else None)]
-        d_pt.fill_splitmix64(0xAE5C0003, 0)
-        workload = "cfg3: AES-256-GCM, one %.3g GiB message, SplitMix64 PT seed 0xAE5C0003, empty AAD" % (per_gpu / GiB)
-        if args.key_bits != 256:
-            workload = workload.replace("AES-256", "AES-%d" % args.key_bits)
+        workload = "cfg3: AES-%d-GCM, one %.3g GiB message, SplitMix64 PT seed 0xAE5C0003, empty AAD" % (args.key_bits, per_gpu / GiB)
     else:
-        msg_bytes = 2 * per_gpu                      # 32 GiB messages at 16 GiB per GPU
-        M = N // 2 if N >= 2 else 1
-        shard = msg_bytes // N
-        msgs = []
-        for m in range(M):
-            iv = bytearray(iv0)
-            iv[11] = (iv[11] + m) & 0xFF
-            msgs.append(dict(iv=bytes(iv), total=msg_bytes, first_block=rank * shard // 16, off=m * shard, len=shard,
-                             fixture="cfg4_aes256_msg%d_32GiB" % m if standard else None))
-            d_pt.fill_splitmix64(0xAE5C0004, (m * msg_bytes + rank * shard) // 8, nbytes=shard, offset=m * shard)
-        workload = ("cfg4 cut to %d ranks: %d AES-256-GCM message(s) of %.3g GiB (SplitMix64 seed 0xAE5C0004), each sharded over "
-                    "all %d ranks, one 16 B x %d x %d RCCL all-gather per step" % (N, M, msg_bytes / GiB, N, N, M))
+        workload = ("cfg4 cut to %d ranks: %d AES-%d-GCM message(s) of %.3g GiB (SplitMix64 seed 0xAE5C0004), each sharded over "
+                    "all %d ranks, one 16 B x %d x %d RCCL all-gather per step" % (N, len(msgs), args.key_bits, msgs[0]["total"] / GiB, N, N, len(msgs)))
     lib.dev_sync(dev)
 
     stream = None

@@ -1,0 +1,79 @@
+"""GPU, GiB scale: BASELINE.json's full sizes.  Ciphertext is checked bit-for-bit through SHA-256 of the
+whole stream (downloaded in 256 MiB slices) against fixtures produced by libcrypto over the same SplitMix64
+plaintext (tests/golden/gen_golden.py --large), the tag against the same fixture; decryption is checked by
+its tag (GHASH over the input) plus plaintext windows against the generator, and by size-independent
+properties (in-place == out-of-place, sharded == whole)."""
+import hashlib
+import random
+
+import pytest
+
+from util import golden, stream_key_iv
+
+pytestmark = [pytest.mark.gpu, pytest.mark.slow]
+SLICE = 256 << 20
+
+
+def _case(name):
+    for c in golden("streams.json")["cases"]:
+        if c["name"] == name:
+            return c
+    pytest.skip("fixture %s not generated" % name)
+
+
+def _sha_device(buf, n):
+    sha = hashlib.sha256()
+    host = bytearray(SLICE)
+    for off in range(0, n, SLICE):
+        m = min(SLICE, n - off)
+        view = memoryview(host)[:m]
+        buf.download(m, off, out=view)
+        sha.update(view)
+    return sha.hexdigest()
+
+
+@pytest.mark.parametrize("name", ["cfg2_aes128_1GiB", "aes256_1GiB", "cfg3_aes256_16GiB"])
+def test_full_size_stream_bit_exact(hip, orc, name):
+    c = _case(name)
+    n = c["n_bytes"]
+    key, iv = stream_key_iv(c)
+    ctx = hip.Context(key)
+    pt, ct = hip.DeviceBuffer(n), hip.DeviceBuffer(n)
+    pt.fill_splitmix64(c["pt_seed"], c["first_word"])
+    tag = ctx.encrypt_dev(iv, pt.ptr, n, ct.ptr)
+    assert tag.hex() == c["tag"]
+    assert bytes(ct.download(64, 0)).hex() == c["ct_head"] and bytes(ct.download(64, n - 64)).hex() == c["ct_tail"]
+    assert _sha_device(ct, n) == c["ct_sha256"]
+    # decrypt into the plaintext buffer (overwriting it), authenticated against the fixture tag
+    t2 = ctx.decrypt_dev(iv, ct.ptr, n, pt.ptr, tag=bytes.fromhex(c["tag"]))
+    assert t2 == tag
+    rng = random.Random(n)
+    win = 1 << 20
+    for off in [0, n - win] + [rng.randrange(0, n - win) // 16 * 16 for _ in range(8)]:
+        assert bytes(pt.download(win, off)) == bytes(orc.fill_splitmix64(win, c["pt_seed"], c["first_word"] + off // 8)), off
+    # in place == out of place
+    t3 = ctx.encrypt_dev(iv, pt.ptr, n, pt.ptr)
+    assert t3 == tag
+    for off in [0, n - win, (n // 2) // 16 * 16]:
+        assert bytes(pt.download(win, off)) == bytes(ct.download(win, off))
+    pt.free(); ct.free()
+
+
+def test_sharded_16GiB_equals_fixture(hip):
+    """cfg3 stream cut into 8 shards on one GPU (the multi-GPU algebra at full size): same tag, same CT."""
+    c = _case("cfg3_aes256_16GiB")
+    n = c["n_bytes"]
+    key, iv = stream_key_iv(c)
+    ctx = hip.Context(key)
+    pt, ct = hip.DeviceBuffer(n), hip.DeviceBuffer(n)
+    pt.fill_splitmix64(c["pt_seed"], c["first_word"])
+    import aesgcm_amd  # noqa: F401
+    from aesgcm_amd import sharding
+    ranks = 8
+    parts = hip.DeviceBuffer(16 * ranks)
+    for r in range(ranks):
+        first, end, ln = sharding.shard_bounds(n, ranks, r)
+        ctx.shard_crypt_dev(False, iv, pt.ptr + 16 * first, ln, ct.ptr + 16 * first, first, n, parts.ptr + 16 * r)
+    assert ctx.shard_finalize_dev(iv, parts.ptr, ranks, 0, n).hex() == c["tag"]
+    assert _sha_device(ct, n) == c["ct_sha256"]
+    pt.free(); ct.free()
