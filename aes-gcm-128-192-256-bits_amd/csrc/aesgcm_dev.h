@@ -265,7 +265,7 @@ HD void ctr_rounds_lds(u32 ctr_be_word, const CtrConsts &k, u32 &s0, u32 &s1, u3
 // construction.
 // ------------------------------------------------------------------------------------------------
 HD uint4 ghash_mul_const_lds(uint4 y, const unsigned char *lds) {
-    u32x4_t r0 = {0, 0, 0, 0}, r1 = {0, 0, 0, 0};
+    u32x4_t r = {0, 0, 0, 0};
     const u32 w[4] = {y.x, y.y, y.z, y.w};
 #pragma unroll
     for (int wi = 0; wi < 4; wi++) {
@@ -274,12 +274,12 @@ HD uint4 ghash_mul_const_lds(uint4 y, const unsigned char *lds) {
             const int b = 4 * wi + bb;
             const u32 hi = (bb == 0) ? (w[wi] & 0xF0u) : ((w[wi] >> (8 * bb)) & 0xF0u);
             const u32 lo = (bb == 0) ? ((w[wi] << 4) & 0xF0u) : ((w[wi] >> (8 * bb - 4)) & 0xF0u);
-            r0 ^= LDS_LD128(lds, hi + (AESGCM_LDS_GH_OFF + (2 * b) * 256));
-            r1 ^= LDS_LD128(lds, lo + (AESGCM_LDS_GH_OFF + (2 * b + 1) * 256));
+            const u32x4_t a = LDS_LD128(lds, hi + (AESGCM_LDS_GH_OFF + (2 * b) * 256));
+            const u32x4_t c = LDS_LD128(lds, lo + (AESGCM_LDS_GH_OFF + (2 * b + 1) * 256));
+            r.x = xor3(r.x, a.x, c.x); r.y = xor3(r.y, a.y, c.y); r.z = xor3(r.z, a.z, c.z); r.w = xor3(r.w, a.w, c.w);
         }
     }
-    r0 ^= r1;
-    return make_uint4(r0.x, r0.y, r0.z, r0.w);
+    return make_uint4(r.x, r.y, r.z, r.w);
 }
 
 // ================================================================================================
@@ -587,6 +587,114 @@ static inline CombineParams plan_combine_final(uint4 *state, const uint8_t iv[12
     CombineParams q = plan_combine_tag(nullptr, 0, false, iv, aad_len, ct_len, out);
     q.carry = state; q.has_carry = 1; q.e_carry = 0;
     return q;
+}
+
+// ================================================================================================
+// Batch path (BASELINE config 5): many short independent packets, each with its OWN key and IV.
+// One wave per packet.  No per-key context exists, so everything key-dependent is rebuilt per packet
+// inside the kernel: aes_kexp (round keys end up wave-uniform -> scalar registers), H and E_K(J0), and
+// -- because H-power tables cannot be amortised -- GHASH uses Shoup's 4-bit method: a 16-entry table
+// T[v] = v*c per constant c (256 B in LDS per wave; one bank row, conflict-free) and
+//     Y*c = Horner over Y's 32 nibbles:  Z = Z*x^4 xor T[nibble]   (x^4 = shift right 4 + 16-bit reduction).
+// The packet polynomial is evaluated as: lane L runs serial Horner with H over its q consecutive blocks,
+// then a 6-level cross-lane tree multiplies by c_j = H^(q*2^j) (c_{j+1} = c_j^2, table rebuilt per level).
+// ================================================================================================
+#define BATCH_WAVE_LDS 512u                     /* per wave: table of H (256 B) + table of the tree constant (256 B) */
+#define BATCH_LDS_WAVE_OFF 0u                   /* the 8 KiB the bulk kernel uses for the K table: 16 waves x 512 B */
+#define BATCH_LDS_RTAB_OFF (AESGCM_LDS_AES_OFF + AESGCM_LDS_AES)            /* 16 x u32 reduction table */
+#define BATCH_LDS_BYTES (BATCH_LDS_RTAB_OFF + 64u)
+
+struct BatchParams {
+    const unsigned char *keys;   // n_pkts * key_len bytes
+    const unsigned char *ivs;    // n_pkts * 12 bytes
+    const unsigned char *aad;    // n_pkts * aad_len bytes or NULL
+    const unsigned char *in;     // n_pkts * pkt_len bytes (pkt_len multiple of 16 => 16-byte aligned blocks)
+    unsigned char *out;
+    unsigned char *tags;         // enc: n_pkts * 16 written.  dec: computed tags written here too
+    const unsigned char *expect; // dec: expected tags or NULL
+    int *auth;                   // dec: per-packet 1 = tag ok, 0 = mismatch (NULL = skip)
+    u32 *counter; u32 counter_base;
+    u32 n_pkts, pkt_len, aad_len;
+    u32 aligned;                 // in/out rows are 16-byte aligned for every packet
+};
+
+// reduction of the 4 bits shifted out by Z*x^4: r(v) for v = Z's last nibble, as the top 16 bits of word 0.
+// (bit k of v is GCM bit 124+k; after the shift it is x^(128+k'), reduced with R = 0xE1 || 0^120.)
+HD u32 shoup_rem_calc(u32 v) {
+    // multiply the nibble (as a 4-bit polynomial sitting at x^124..x^127) by x^4 and reduce: do it literally
+    G128 z; z.w[0] = z.w[1] = z.w[2] = 0; z.w[3] = v;          // BE words: low nibble of w3 = GCM bits 124..127
+    for (int k = 0; k < 4; k++) {                              // four multiplications by x
+        const u32 lsb = 0u - (z.w[3] & 1u);
+        z.w[3] = (z.w[3] >> 1) | (z.w[2] << 31); z.w[2] = (z.w[2] >> 1) | (z.w[1] << 31); z.w[1] = (z.w[1] >> 1) | (z.w[0] << 31);
+        z.w[0] = (z.w[0] >> 1) ^ (lsb & 0xE1000000u);
+    }
+    return z.w[0];                                             // only the top 16 bits can be set
+}
+// multiply a field element by x (one right shift with reduction)
+HD G128 gf_mulx(G128 v) {
+    const u32 lsb = 0u - (v.w[3] & 1u);
+    G128 r;
+    r.w[3] = (v.w[3] >> 1) | (v.w[2] << 31); r.w[2] = (v.w[2] >> 1) | (v.w[1] << 31); r.w[1] = (v.w[1] >> 1) | (v.w[0] << 31);
+    r.w[0] = (v.w[0] >> 1) ^ (lsb & 0xE1000000u);
+    return r;
+}
+// entry v (0..15) of the Shoup table of constant c: (v as polynomial v3 + v2 x + v1 x^2 + v0 x^3, GCM bit order:
+// the nibble's MSB is x^0) times c
+HD G128 shoup_entry(G128 c, u32 v) {
+    G128 r; r.w[0] = r.w[1] = r.w[2] = r.w[3] = 0;
+    G128 t = c;
+    for (int k = 3; k >= 0; k--) {                             // bit 3 of v <-> x^0, bit 0 <-> x^3
+        const u32 m = 0u - ((v >> k) & 1u);
+        r.w[0] ^= t.w[0] & m; r.w[1] ^= t.w[1] & m; r.w[2] ^= t.w[2] & m; r.w[3] ^= t.w[3] & m;
+        t = gf_mulx(t);
+    }
+    return r;
+}
+// Y * c through the table at LDS byte offset `tab` (16 entries x 4 BE words) and the reduction table
+HD G128 shoup_mul(G128 y, const unsigned char *lds, u32 tab) {
+    u32 z0 = 0, z1 = 0, z2 = 0, z3 = 0;
+#pragma unroll
+    for (int wi = 3; wi >= 0; wi--) {
+        const u32 yw = y.w[wi];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {                          // nibbles of the word, last (lowest) first
+            const u32 nib16 = (k == 0) ? ((yw << 4) & 0xF0u) : ((yw >> (4 * k - 4)) & 0xF0u);
+            if (!(wi == 3 && k == 0)) {                        // Z = Z * x^4 (skipped while Z is still zero)
+                const u32 rem = LDS_LD32(lds, ((z3 & 0xFu) << 2) + BATCH_LDS_RTAB_OFF);
+                z3 = (z3 >> 4) | (z2 << 28); z2 = (z2 >> 4) | (z1 << 28); z1 = (z1 >> 4) | (z0 << 28);
+                z0 = (z0 >> 4) ^ rem;
+            }
+            const u32x4_t t = LDS_LD128(lds, nib16 + tab);
+            z0 ^= t.x; z1 ^= t.y; z2 ^= t.z; z3 ^= t.w;
+        }
+    }
+    G128 z; z.w[0] = z0; z.w[1] = z1; z.w[2] = z2; z.w[3] = z3;
+    return z;
+}
+
+// aes_kexp per packet (config/config_aes_kexp.py:128-159 / tb/key_exp.py:79-114) on memory-order words, S-box
+// taken from byte 1 of the LDS T0 entry.  Every lane computes the same words (uniform addresses broadcast).
+template <int NR>
+HD void batch_key_expand(const unsigned char *key, u32 *rk, const unsigned char *lds, u32 lb) {
+    constexpr int NK = NR - 6;
+#pragma unroll
+    for (int w = 0; w < NK; w++) rk[w] = load_le32(key + 4 * w);
+    u32 rcon = 1;
+#pragma unroll
+    for (int w = NK; w < 4 * (NR + 1); w++) {
+        u32 t = rk[w - 1];
+        if (w % NK == 0) {
+            t = (t >> 8) | (t << 24);                                            // RotWord on a little-endian word
+            t = ((T0_AT(lds, t, 0, lb) >> 8) & 0xFFu) | (T0_AT(lds, t, 1, lb) & 0xFF00u) |
+                (T0_AT(lds, t, 2, lb) & 0xFF0000u) | ((T0_AT(lds, t, 3, lb) << 8) & 0xFF000000u);   // SubWord
+            t ^= rcon;
+            rcon = xtime2(rcon);
+        } else if (NK == 8 && (w % NK) == 4) {
+            t = ((T0_AT(lds, t, 0, lb) >> 8) & 0xFFu) | (T0_AT(lds, t, 1, lb) & 0xFF00u) |
+                (T0_AT(lds, t, 2, lb) & 0xFF0000u) | ((T0_AT(lds, t, 3, lb) << 8) & 0xFF000000u);
+        }
+        rk[w] = rk[w - NK] ^ t;
+    }
 }
 
 // SplitMix64 at word position w; shared with oracle/aesgcm_oracle.c by definition.

@@ -203,6 +203,150 @@ __global__ __launch_bounds__(COMBINE_THREADS) void k_combine(const KeyMaterial *
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_batch: BASELINE config 5 -- independent packets, per-packet key and IV.  One wave per packet, packets
+// pulled from the dispenser.  See the "Batch path" block in aesgcm_dev.h for the algorithm.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ G128 wave_bcast(G128 v, int src) {
+    G128 r;
+    r.w[0] = __builtin_amdgcn_readlane(v.w[0], src); r.w[1] = __builtin_amdgcn_readlane(v.w[1], src);
+    r.w[2] = __builtin_amdgcn_readlane(v.w[2], src); r.w[3] = __builtin_amdgcn_readlane(v.w[3], src);
+    return r;
+}
+__device__ __forceinline__ void shoup_build(unsigned char *smem, u32 tab, G128 c, u32 lane) {
+    if (lane < 16) {
+        const G128 e = shoup_entry(c, lane);
+        *reinterpret_cast<uint4 *>(smem + tab + 16 * lane) = make_uint4(e.w[0], e.w[1], e.w[2], e.w[3]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// block j of the packet's GHASH sequence (AAD blocks then data blocks), zero padded, as big-endian words
+__device__ __forceinline__ G128 batch_seq_block(const BatchParams &p, const unsigned char *aad, const unsigned char *data,
+                                                u32 n_aad, u32 j) {
+    uint4 m;
+    if (j < n_aad) {
+        const u32 off = 16 * j, rem = p.aad_len - off;
+        m = load_block_bytes(aad + off, rem < 16 ? rem : 16);
+    } else {
+        const u32 off = 16 * (j - n_aad), rem = p.pkt_len - off;
+        if (p.aligned && rem >= 16) m = *reinterpret_cast<const uint4 *>(data + off);
+        else m = load_block_bytes(data + off, rem < 16 ? rem : 16);
+    }
+    return mo_to_be(m);
+}
+
+template <int NR, int DEC>
+__global__ __launch_bounds__(AESGCM_WG, AESGCM_WAVES_PER_SIMD) void k_batch(const DevTables *__restrict__ tb, const BatchParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    main_fill_lds(smem, nullptr, tb, tid, false);
+    if (tid < 16) *reinterpret_cast<u32 *>(smem + BATCH_LDS_RTAB_OFF + 4 * tid) = shoup_rem_calc(tid);
+    __syncthreads();
+    const u32 lb = (lane & 31u) << 2;
+    const u32 tabH = BATCH_LDS_WAVE_OFF + wave * BATCH_WAVE_LDS, tabC = tabH + 256u;
+    constexpr u32 KEYLEN = 4 * (NR - 6);
+    const u32 n_aad = (p.aad_len + 15) / 16, n_ct = (p.pkt_len + 15) / 16, n_seq = n_aad + n_ct;
+    const u32 q = (n_seq + 63) / 64;                       // blocks per lane (0 for an empty packet)
+    const u32 pad = 64 * q - n_seq;                        // front padding slots
+    for (;;) {
+        u32 pkt = 0;
+        if (lane == 0) pkt = atomicAdd(p.counter, 1u) - p.counter_base;
+        pkt = __builtin_amdgcn_readfirstlane(pkt);
+        if (pkt >= p.n_pkts) break;
+        const unsigned char *key = p.keys + (size_t)pkt * KEYLEN;
+        const unsigned char *ivp = p.ivs + (size_t)pkt * 12;
+        const unsigned char *aad = p.aad ? p.aad + (size_t)pkt * p.aad_len : nullptr;
+        const unsigned char *in = p.in + (size_t)pkt * p.pkt_len;
+        unsigned char *out = p.out + (size_t)pkt * p.pkt_len;
+
+        // ---- aes_kexp for this packet; round keys become wave-uniform scalars
+        u32 rk[4 * (NR + 1)];
+        batch_key_expand<NR>(key, rk, smem, lb);
+#pragma unroll
+        for (int w = 0; w < 4 * (NR + 1); w++) rk[w] = __builtin_amdgcn_readfirstlane(rk[w]);
+        const u32 iv0 = load_le32(ivp), iv1 = load_le32(ivp + 4), iv2 = load_le32(ivp + 8);
+
+        // ---- H = E_K(0^128) on lane 0 and E_K(IV || 1) on lane 1 (gcm_gctr.vhd:141-145), one pass for both
+        G128 h, ej0;
+        {
+            u32 s0 = (lane == 0 ? 0u : iv0) ^ rk[0], s1 = (lane == 0 ? 0u : iv1) ^ rk[1], s2 = (lane == 0 ? 0u : iv2) ^ rk[2];
+            u32 s3 = (lane == 0 ? 0u : 0x01000000u) ^ rk[3];
+            aes_rounds_lds<NR>(s0, s1, s2, s3, rk, smem, lb);
+            const G128 e = mo_to_be(make_uint4(s0, s1, s2, s3));
+            h = wave_bcast(e, 0);
+            ej0 = wave_bcast(e, 1);
+        }
+        shoup_build(smem, tabH, h, lane);
+
+        G128 acc; acc.w[0] = acc.w[1] = acc.w[2] = acc.w[3] = 0;
+        // GHASH over the input must precede the CTR pass when decrypting (in-place safe); after it when encrypting
+#pragma unroll
+        for (int phase = 0; phase < 2; phase++) {
+            const bool do_ghash = (phase == 0) == (DEC != 0);
+            if (do_ghash) {
+                if (!DEC) __threadfence_block();           // this wave's ciphertext stores are visible to its other lanes
+                for (u32 k = 0; k < q; k++) {
+                    if (k) acc = shoup_mul(acc, smem, tabH);
+                    const u32 v = lane * q + k;
+                    if (v >= pad) {
+                        const G128 b = batch_seq_block(p, aad, DEC ? in : out, n_aad, v - pad);
+                        acc.w[0] ^= b.w[0]; acc.w[1] ^= b.w[1]; acc.w[2] ^= b.w[2]; acc.w[3] ^= b.w[3];
+                    }
+                }
+            } else {
+                const CtrConsts cc = ctr_round1_consts(iv0, iv1, iv2, rk, smem, lb);
+                for (u32 i = lane; i < n_ct; i += 64) {
+                    const u32 off = 16 * i, rem = p.pkt_len - off;
+                    uint4 x;
+                    const bool full = p.aligned && rem >= 16;
+                    if (full) x = *reinterpret_cast<const uint4 *>(in + off);
+                    else x = load_block_bytes(in + off, rem < 16 ? rem : 16);
+                    u32 s0, s1, s2, s3;
+                    ctr_rounds_lds<NR>(bswap32(2u + i), cc, s0, s1, s2, s3, rk, smem, lb);
+                    const uint4 y = make_uint4(x.x ^ s0, x.y ^ s1, x.z ^ s2, x.w ^ s3);
+                    if (full) *reinterpret_cast<uint4 *>(out + off) = y;
+                    else store_block_bytes(out + off, y, rem < 16 ? rem : 16);
+                }
+            }
+        }
+
+        // ---- cross-lane tree: c_0 = H^q, c_{j+1} = c_j^2
+        G128 cpow = h;
+        for (u32 k = 1; k < q; k++) cpow = shoup_mul(cpow, smem, tabH);
+        if (q) {
+#pragma unroll 1
+            for (int j = 0; j < 6; j++) {
+                shoup_build(smem, tabC, cpow, lane);
+                const G128 t = shoup_mul(acc, smem, tabC);
+                G128 o;
+                o.w[0] = __shfl_xor(t.w[0], 1 << j); o.w[1] = __shfl_xor(t.w[1], 1 << j);
+                o.w[2] = __shfl_xor(t.w[2], 1 << j); o.w[3] = __shfl_xor(t.w[3], 1 << j);
+                if (lane & (1u << j)) { acc.w[0] ^= o.w[0]; acc.w[1] ^= o.w[1]; acc.w[2] ^= o.w[2]; acc.w[3] ^= o.w[3]; }
+                if (j < 5) cpow = shoup_mul(cpow, smem, tabC);
+            }
+        }
+        // ---- lane 63 holds P = sum X_i H^(n-1-i); tag = ((P*H) ^ L)*H ^ E_K(J0)
+        G128 y = shoup_mul(acc, smem, tabH);
+        y.w[1] ^= p.aad_len * 8u; y.w[3] ^= p.pkt_len * 8u;       // both < 2^32 bits by the ABI's limits
+        y = shoup_mul(y, smem, tabH);
+        y.w[0] ^= ej0.w[0]; y.w[1] ^= ej0.w[1]; y.w[2] ^= ej0.w[2]; y.w[3] ^= ej0.w[3];
+        if (lane == 63) {
+            const uint4 tag = be_to_mo(y);
+            store_block_bytes(p.tags + (size_t)pkt * 16, tag, 16);
+            if (DEC && p.auth) {
+                int ok = 1;
+                if (p.expect) {
+                    const uint4 e = load_block_bytes(p.expect + (size_t)pkt * 16, 16);
+                    ok = ((e.x ^ tag.x) | (e.y ^ tag.y) | (e.z ^ tag.z) | (e.w ^ tag.w)) == 0;
+                }
+                p.auth[pkt] = ok;
+            }
+        }
+    }
+}
+
 // ================================================================================================
 // host side
 // ================================================================================================
@@ -213,7 +357,7 @@ static int hip_fail(hipError_t e, const char *what) {
 }
 #define HIPCHK(call) do { hipError_t _e = (call); if (_e != hipSuccess) return hip_fail(_e, #call); } while (0)
 
-struct DeviceState { DevTables *tables = nullptr; int n_cu = 0; bool attrs = false; };
+struct DeviceState { DevTables *tables = nullptr; int n_cu = 0; bool attrs = false; u32 *batch_counter = nullptr; u32 batch_base = 0; };
 static std::mutex g_mu;
 static std::vector<DeviceState> g_dev;
 
@@ -235,6 +379,8 @@ static int device_state(int device, DeviceState **out) {
         HIPCHK(hipGetLastError());
         HIPCHK(hipDeviceSynchronize());
         d.tables = t;
+        HIPCHK(hipMalloc(&d.batch_counter, 64));
+        HIPCHK(hipMemset(d.batch_counter, 0, 64));
     }
     *out = &d;
     return AESGCM_OK;
@@ -305,6 +451,9 @@ static int set_lds_attrs(int device, DeviceState *ds) {
     SETATTR(10, MODE_KS);  SETATTR(12, MODE_KS);  SETATTR(14, MODE_KS);
     SETATTR(10, MODE_ECB); SETATTR(12, MODE_ECB); SETATTR(14, MODE_ECB);
 #undef SETATTR
+#define SETATTRB(NR, D) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch<NR, D>), hipFuncAttributeMaxDynamicSharedMemorySize, BATCH_LDS_BYTES))
+    SETATTRB(10, 0); SETATTRB(12, 0); SETATTRB(14, 0); SETATTRB(10, 1); SETATTRB(12, 1); SETATTRB(14, 1);
+#undef SETATTRB
     ds->attrs = true;
     return AESGCM_OK;
 }
@@ -783,6 +932,45 @@ int aesgcm_stream_final(aesgcm_ctx *c, uint8_t tag[16]) {
     HIPCHK(hipMemcpyAsync(tag, c->d_tag, 16, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->s_active = false;
+    return AESGCM_OK;
+}
+
+// ---------------------------------------------------------------- batch (per-packet key and IV)
+int aesgcm_batch_crypt_dev(int device, int decrypt, size_t n_pkts, size_t key_len, const void *d_keys, const void *d_ivs,
+                           const void *d_aad, size_t aad_len, const void *d_in, size_t pkt_len, void *d_out,
+                           void *d_tags, const void *d_expect_tags, int *d_auth, void *stream) {
+    if (key_len != 16 && key_len != 24 && key_len != 32) return AESGCM_EKEYLEN;
+    if (!n_pkts) return AESGCM_OK;
+    if (!d_keys || !d_ivs || !d_tags || (aad_len && !d_aad) || (pkt_len && (!d_in || !d_out))) return AESGCM_EARG;
+    if (n_pkts >= (((size_t)1) << 31) || pkt_len >= (((size_t)1) << 28) || aad_len >= (((size_t)1) << 28)) return AESGCM_ETOOLONG;
+    DeviceState *ds;
+    int rc = device_state(device, &ds);
+    if (rc) return rc;
+    if ((rc = set_lds_attrs(device, ds))) return rc;
+    HIPCHK(hipSetDevice(device));
+    BatchParams p;
+    memset(&p, 0, sizeof p);
+    p.keys = (const unsigned char *)d_keys; p.ivs = (const unsigned char *)d_ivs; p.aad = (const unsigned char *)d_aad;
+    p.in = (const unsigned char *)d_in; p.out = (unsigned char *)d_out; p.tags = (unsigned char *)d_tags;
+    p.expect = (const unsigned char *)d_expect_tags; p.auth = d_auth;
+    p.n_pkts = (u32)n_pkts; p.pkt_len = (u32)pkt_len; p.aad_len = (u32)aad_len;
+    p.aligned = (pkt_len % 16 == 0) && (((uintptr_t)d_in | (uintptr_t)d_out) & 15) == 0;
+    const u32 waves_per_wg = AESGCM_WG / 64;
+    u32 wgs = (u32)((n_pkts + waves_per_wg - 1) / waves_per_wg);
+    const u32 gmax = (u32)(2 * ds->n_cu > AESGCM_GMAX ? AESGCM_GMAX : 2 * ds->n_cu);
+    if (wgs > gmax) wgs = gmax;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        p.counter = ds->batch_counter; p.counter_base = ds->batch_base;
+        ds->batch_base += (u32)n_pkts + wgs * waves_per_wg;
+    }
+    const int nr = (int)(key_len / 4 + 6);
+    hipStream_t st = (hipStream_t)stream;
+#define LB(NR, D) hipLaunchKernelGGL((k_batch<NR, D>), dim3(wgs), dim3(AESGCM_WG), BATCH_LDS_BYTES, st, ds->tables, p)
+    if (decrypt) { if (nr == 10) LB(10, 1); else if (nr == 12) LB(12, 1); else LB(14, 1); }
+    else         { if (nr == 10) LB(10, 0); else if (nr == 12) LB(12, 0); else LB(14, 0); }
+#undef LB
+    HIPCHK(hipGetLastError());
     return AESGCM_OK;
 }
 

@@ -19,7 +19,7 @@ SYMBOLS = [
     "aesgcm_ctx_create", "aesgcm_ctx_create_preexpanded", "aesgcm_ctx_destroy", "aesgcm_ctx_device",
     "aesgcm_encrypt", "aesgcm_decrypt", "aesgcm_encrypt_dev", "aesgcm_decrypt_dev", "aesgcm_last_tag",
     "aesgcm_keystream", "aesgcm_keystream_dev",
-    "aesgcm_shard_crypt_dev", "aesgcm_shard_finalize_dev",
+    "aesgcm_shard_crypt_dev", "aesgcm_shard_finalize_dev", "aesgcm_batch_crypt_dev",
     "aesgcm_stream_begin", "aesgcm_stream_aad", "aesgcm_stream_update", "aesgcm_stream_final",
     "aesgcm_dev_alloc", "aesgcm_dev_free", "aesgcm_dev_upload", "aesgcm_dev_download", "aesgcm_dev_sync",
     "aesgcm_fill_splitmix64_dev",
@@ -76,6 +76,7 @@ def load():
     L.aesgcm_keystream_dev.argtypes = [vp, vp, u64, u64, vp, vp]
     L.aesgcm_shard_crypt_dev.argtypes = [vp, cint, vp, vp, sz, vp, sz, vp, u64, u64, vp, vp]
     L.aesgcm_shard_finalize_dev.argtypes = [vp, vp, vp, sz, sz, u64, vp, vp]
+    L.aesgcm_batch_crypt_dev.argtypes = [cint, cint, sz, sz, vp, vp, vp, sz, vp, sz, vp, vp, vp, vp, vp]
     L.aesgcm_stream_begin.argtypes = [vp, vp, cint]
     L.aesgcm_stream_aad.argtypes = [vp, vp, sz]
     L.aesgcm_stream_update.argtypes = [vp, vp, sz, vp]
@@ -214,6 +215,13 @@ class DeviceBuffer:
             self.ptr = None
 
     __del__ = free
+
+
+def batch_crypt_dev(decrypt, n_pkts, key_len, d_keys, d_ivs, d_in, pkt_len, d_out, d_tags, d_aad=None, aad_len=0,
+                    d_expect_tags=None, d_auth=None, device=0, stream=None):
+    """n independent packets with per-packet key and IV, all arrays contiguous device memory (aesgcm.h)."""
+    _chk(load().aesgcm_batch_crypt_dev(device, int(bool(decrypt)), n_pkts, key_len, d_keys, d_ivs, d_aad, aad_len,
+                                       d_in, pkt_len, d_out, d_tags, d_expect_tags, d_auth, stream))
 
 
 def dev_sync(device=0):

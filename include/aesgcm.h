@@ -148,6 +148,18 @@ AESGCM_API int aesgcm_shard_crypt_dev(aesgcm_ctx *ctx, int decrypt, const uint8_
 AESGCM_API int aesgcm_shard_finalize_dev(aesgcm_ctx *ctx, const uint8_t iv[12], const void *d_partials, size_t n_partials,
                               size_t aad_len, uint64_t total_len, uint8_t tag[16], void *stream);
 
+/* ---------------------------------------------------------------- batch: independent packets, per-packet key + IV
+ * (BASELINE config 5; the RTL equivalent is reloading key and IV between packets, tb/gcm_gctr.py:144-175,
+ * with aes_kexp run per packet, config/config_aes_kexp.py:113-159.)  All arrays are contiguous device memory:
+ * keys[n][key_len], ivs[n][12], aad[n][aad_len] (or NULL), in[n][pkt_len], out[n][pkt_len], tags[n][16].
+ * One wave per packet; key expansion, H, E_K(J0) and the GHASH tables are rebuilt per packet on the GPU.
+ * decrypt != 0: GHASH runs over the input, tags[] receives the COMPUTED tags; if d_auth != NULL it receives
+ * one int per packet (1 = equals d_expect_tags[p], 0 = mismatch; all 1 when d_expect_tags is NULL).
+ * Asynchronous on `stream`; in == out is allowed. */
+AESGCM_API int aesgcm_batch_crypt_dev(int device, int decrypt, size_t n_pkts, size_t key_len, const void *d_keys, const void *d_ivs,
+                           const void *d_aad, size_t aad_len, const void *d_in, size_t pkt_len, void *d_out,
+                           void *d_tags, const void *d_expect_tags, int *d_auth, void *stream);
+
 /* ---------------------------------------------------------------- streaming (beat-by-beat) interface
  * Mirrors the call order the reference harness drives its model with (tb/gcm_test.py:76-85 ->
  * tb/gcm_model.py:21-35): all AAD first, then data; every chunk except the last of its kind must be

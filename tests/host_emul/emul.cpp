@@ -138,6 +138,36 @@ static void test_units() {
     }
 }
 
+// batch-path pieces: Shoup 4-bit multiply against the bit-serial multiply, in-kernel key schedule against the oracle
+static void test_batch_pieces() {
+    static unsigned char smem[BATCH_LDS_BYTES] __attribute__((aligned(16)));
+    for (u32 tid = 0; tid < AESGCM_WG; tid++) main_fill_lds(smem, nullptr, &g_tb, tid, false);
+    for (u32 v = 0; v < 16; v++) *reinterpret_cast<u32 *>(smem + BATCH_LDS_RTAB_OFF + 4 * v) = shoup_rem_calc(v);
+    for (int it = 0; it < 50; it++) {
+        auto cb = rnd(16, 7000 + it), yb = rnd(16, 8000 + it);
+        if (it == 1) memset(yb.data(), 0xFF, 16);
+        if (it == 2) { memset(yb.data(), 0, 16); yb[15] = 1; }
+        uint4 cm, ym; memcpy(&cm, cb.data(), 16); memcpy(&ym, yb.data(), 16);
+        const G128 c = mo_to_be(cm), y = mo_to_be(ym);
+        const u32 tab = 256 * (it % 8);
+        for (u32 v = 0; v < 16; v++) { G128 e = shoup_entry(c, v); *reinterpret_cast<uint4 *>(smem + tab + 16 * v) = make_uint4(e.w[0], e.w[1], e.w[2], e.w[3]); }
+        const G128 z = shoup_mul(y, smem, tab), want = gf_mul(y, c);
+        CHECK(memcmp(&z, &want, 16) == 0, "shoup_mul %d", it);
+    }
+    for (int klen : {16, 24, 32}) {
+        auto key = rnd(klen, 9000 + klen);
+        uint8_t rkb[240]; int nr; orc_key_expand(key.data(), klen, rkb, &nr);
+        u32 rk[60];
+        for (u32 lane : {0u, 17u, 63u}) {
+            const u32 lb = (lane & 31u) << 2;
+            if (klen == 16) batch_key_expand<10>(key.data(), rk, smem, lb);
+            else if (klen == 24) batch_key_expand<12>(key.data(), rk, smem, lb);
+            else batch_key_expand<14>(key.data(), rk, smem, lb);
+            CHECK(memcmp(rk, rkb, 16 * (nr + 1)) == 0, "batch_key_expand %d lane %u", klen, lane);
+        }
+    }
+}
+
 static void test_key(int key_len, u32 G /* rows per chunk override, 0 = production rule */, u64 seed, const std::vector<std::pair<u64, u64>> &sizes) {
     auto key = rnd(key_len, seed);
     Emu E(key.data(), key_len, G);
@@ -285,6 +315,7 @@ int main(int argc, char **argv) {
     test_stream(16, 0, 0, 16 * (W * 4 + 52) + 9, 16 * (W + 188), 91);
     test_stream(24, 3, 16 * 40 + 3, 33, 16 * 8, 92);
     test_keystream_and_ghash(55);
+    test_batch_pieces();
     if (level > 1) {
         test_key(32, 1, 7, {{123, 16 * 64 * 1100 + 11}});     // 1100 chunks: two stage-1 workgroups
         test_key(16, 0, 8, {{0, 16 * W * 600}});              // production rule, > GMAX chunks of Tw = 16

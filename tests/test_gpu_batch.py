@@ -1,0 +1,92 @@
+"""GPU: batch path (BASELINE config 5) -- independent packets with per-packet key and IV, on-GPU aes_kexp."""
+import hashlib
+import random
+
+import pytest
+
+from util import golden, batch_inputs, splitmix_bytes
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(hip, decrypt, keys, ivs, data, pkt_len, key_len, aad=b"", aad_len=0, expect=None, inplace=False):
+    n = len(ivs) // 12
+    d_keys, d_ivs = hip.DeviceBuffer(max(len(keys), 16)), hip.DeviceBuffer(max(len(ivs), 16))
+    d_keys.upload(keys); d_ivs.upload(ivs)
+    d_in = hip.DeviceBuffer(max(len(data), 16)); d_in.upload(data)
+    d_out = d_in if inplace else hip.DeviceBuffer(max(len(data), 16))
+    d_tags = hip.DeviceBuffer(16 * n)
+    d_aad = None
+    if aad_len:
+        d_aad = hip.DeviceBuffer(len(aad)); d_aad.upload(aad)
+    d_exp = d_auth = None
+    if expect is not None:
+        d_exp = hip.DeviceBuffer(16 * n); d_exp.upload(expect)
+        d_auth = hip.DeviceBuffer(4 * n)
+    hip.batch_crypt_dev(decrypt, n, key_len, d_keys.ptr, d_ivs.ptr, d_in.ptr, pkt_len, d_out.ptr, d_tags.ptr,
+                        d_aad=d_aad.ptr if d_aad else None, aad_len=aad_len,
+                        d_expect_tags=d_exp.ptr if d_exp else None, d_auth=d_auth.ptr if d_auth else None)
+    hip.dev_sync()
+    out = bytes(d_out.download(len(data))) if data else b""
+    tags = bytes(d_tags.download(16 * n))
+    auth = None
+    if d_auth is not None:
+        raw = bytes(d_auth.download(4 * n))
+        auth = [int.from_bytes(raw[4 * i:4 * i + 4], "little") for i in range(n)]
+    return out, tags, auth
+
+
+def test_cfg5_first_64_packets_match_fixture(hip):
+    fx = golden("batch.json")
+    keys, ivs, pt = batch_inputs(0, 64, 4096)
+    ct, tags, _ = _run(hip, False, keys, ivs, pt, 4096, 16)
+    assert [tags[16 * p:16 * p + 16].hex() for p in range(64)] == fx["first64_tags"]
+    assert hashlib.sha256(ct).hexdigest() == fx["first64_ct_sha256"]
+    # decrypt in place, authenticated
+    back, tags2, auth = _run(hip, True, keys, ivs, ct, 4096, 16, expect=tags, inplace=True)
+    assert back == pt and tags2 == tags and auth == [1] * 64
+
+
+def test_batch_shapes_vs_oracle(hip, orc):
+    rng = random.Random(5)
+    for klen, pkt_len, aad_len, n in ((16, 0, 0, 3), (16, 1, 0, 5), (24, 15, 7, 9), (32, 16, 16, 17), (16, 48, 28, 33), (32, 1000, 20, 40),
+                                      (24, 1024, 0, 70), (16, 4096, 13, 130), (32, 9001, 68, 21), (16, 65536, 0, 6)):
+        keys = splitmix_bytes(100 + pkt_len, klen * n)
+        ivs = splitmix_bytes(200 + pkt_len, 12 * n)
+        aad = splitmix_bytes(300 + pkt_len, aad_len * n)
+        pt = splitmix_bytes(400 + pkt_len, pkt_len * n)
+        ct, tags, _ = _run(hip, False, keys, ivs, pt, pkt_len, klen, aad=aad, aad_len=aad_len)
+        for p in range(n):
+            want_ct, want_tag = orc.Fast(keys[klen * p:klen * (p + 1)]).encrypt(ivs[12 * p:12 * p + 12], aad[aad_len * p:aad_len * (p + 1)], pt[pkt_len * p:pkt_len * (p + 1)])
+            assert ct[pkt_len * p:pkt_len * (p + 1)] == want_ct, (klen, pkt_len, aad_len, p)
+            assert tags[16 * p:16 * p + 16] == want_tag, (klen, pkt_len, aad_len, p)
+        # tamper one packet's tag and one packet's ciphertext: exactly those two fail authentication
+        if n >= 3 and pkt_len:
+            bad = bytearray(tags); bad[16 * 1] ^= 1
+            ctb = bytearray(ct); ctb[pkt_len * 2] ^= 0x80
+            back, _, auth = _run(hip, True, keys, ivs, bytes(ctb), pkt_len, klen, aad=aad, aad_len=aad_len, expect=bytes(bad))
+            assert auth == [0 if p in (1, 2) else 1 for p in range(n)]
+            assert back[:pkt_len] == pt[:pkt_len]
+
+
+@pytest.mark.slow
+def test_cfg5_full_million_packets(hip):
+    fx = golden("batch.json")
+    if "full_tags_sha256" not in fx:
+        pytest.skip("full batch fixture not generated")
+    n, pkt = fx["full_n_pkts"], 4096
+    d_keys, d_ivw, d_ivs = hip.DeviceBuffer(16 * n), hip.DeviceBuffer(16 * n), hip.DeviceBuffer(12 * n)
+    d_keys.fill_splitmix64(0x4B4559)
+    d_ivw.fill_splitmix64(0x4956)
+    ivw = bytes(d_ivw.download())
+    d_ivs.upload(b"".join(ivw[16 * p:16 * p + 12] for p in range(n)))
+    d_pt, d_ct, d_tags = hip.DeviceBuffer(pkt * n), hip.DeviceBuffer(pkt * n), hip.DeviceBuffer(16 * n)
+    d_pt.fill_splitmix64(0xAE5C0005)
+    hip.batch_crypt_dev(False, n, 16, d_keys.ptr, d_ivs.ptr, d_pt.ptr, pkt, d_ct.ptr, d_tags.ptr)
+    hip.dev_sync()
+    assert hashlib.sha256(bytes(d_tags.download())).hexdigest() == fx["full_tags_sha256"]
+    sha = hashlib.sha256()
+    step = 256 << 20
+    for off in range(0, pkt * n, step):
+        sha.update(d_ct.download(min(step, pkt * n - off), off))
+    assert sha.hexdigest() == fx["full_ct_sha256"]
