@@ -113,6 +113,7 @@ __global__ __launch_bounds__(AESGCM_WG, AESGCM_WAVES_PER_SIMD) void k_main(const
         tr[0] = wall_clock64();
         tr[2] = (u64)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((u64)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xF) << 32);
     }
+    const u64 cyc0 = p.trace ? clock64() : 0;
     main_fill_lds(smem, km, tb, tid, GH);
     __syncthreads();
     const CtrConsts cc = main_lane_consts<MODE>(km, p, smem, lane);
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(AESGCM_WG, AESGCM_WAVES_PER_SIMD) void k_main(const
     if (p.trace && lane == 0) {
         u64 *tr = p.trace + 4 * (u64)blockIdx.x;
         atomicMax((unsigned long long *)&tr[1], (unsigned long long)wall_clock64());
-        atomicAdd((unsigned long long *)&tr[3], (unsigned long long)done);
+        atomicAdd((unsigned long long *)&tr[3], (unsigned long long)done | ((unsigned long long)((clock64() - cyc0) >> 10) << 32));
     }
 }
 

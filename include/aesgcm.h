@@ -189,7 +189,8 @@ AESGCM_API int aesgcm_fill_splitmix64_dev(int device, void *d_buf, size_t len, u
 AESGCM_API int aesgcm_ctx_timing_enable(aesgcm_ctx *ctx, int on);
 AESGCM_API int aesgcm_ctx_timing_read(aesgcm_ctx *ctx, uint64_t *n_launches, double *total_ms, int reset);
 /* Per-workgroup trace of the most recent fused-kernel launch made while timing was enabled: for each of
- * the *n_wgs workgroups four uint64 {start, end of its last wave (100 MHz wall clock), HW_ID | XCC_ID << 32, chunks its waves processed}. */
+ * the *n_wgs workgroups four uint64 {start, end of its last wave (100 MHz wall clock), HW_ID | XCC_ID << 32,
+ * (chunks its waves processed) | (sum over its waves of shader-clock kilocycles resident) << 32}. */
 AESGCM_API int aesgcm_ctx_wg_trace(aesgcm_ctx *ctx, uint64_t *out, size_t max_wgs, size_t *n_wgs);
 /* geometry the context chose (workgroups, lanes per workgroup, LDS bytes per workgroup) */
 AESGCM_API int aesgcm_ctx_geometry(const aesgcm_ctx *ctx, int *n_workgroups, int *wg_lanes, int *lds_bytes);

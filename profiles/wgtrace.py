@@ -42,5 +42,8 @@ print("distinct CUs used:", len(per_cu), " workgroups per CU histogram:", collec
 for x in sorted(per_xcc):
     v = sorted(per_xcc[x])
     print("xcc %d: %3d wgs, end med %.1f max %.1f us" % (x, len(v), v[len(v) // 2], v[-1]))
-chunks = sorted(t[3] for t in tr)
+chunks = sorted(t[3] & 0xFFFFFFFF for t in tr)
+kc = sum(t[3] >> 32 for t in tr) * 1024.0          # shader cycles summed over all waves
+waves = len(tr) * 16
+print("mean shader clock while resident: %.0f MHz" % (kc / waves / (ms * 1e3)))
 print("chunks per workgroup: min %d med %d max %d (total %d)" % (chunks[0], chunks[len(chunks) // 2], chunks[-1], sum(chunks)))
