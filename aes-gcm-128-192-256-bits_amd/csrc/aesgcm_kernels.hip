@@ -407,6 +407,11 @@ struct aesgcm_ctx {
     // host-API staging
     unsigned char *st_in = nullptr, *st_out = nullptr, *st_aad = nullptr;
     size_t st_in_cap = 0, st_out_cap = 0, st_aad_cap = 0;
+    // pipelined host path: two device chunk slots, copy streams and events
+    unsigned char *pl_buf[2] = {nullptr, nullptr};
+    size_t pl_cap = 0;
+    hipStream_t pl_in = nullptr, pl_out = nullptr;
+    hipEvent_t pl_ev_h2d[2] = {nullptr, nullptr}, pl_ev_k[2] = {nullptr, nullptr}, pl_ev_d2h[2] = {nullptr, nullptr};
     // streaming state
     bool s_active = false, s_data = false, s_ragged = false;
     int s_dec = 0;
@@ -665,6 +670,14 @@ int aesgcm_ctx_destroy(aesgcm_ctx *c) {
     if (c->d_counter) hipFree(c->d_counter);
     if (c->d_tag) hipFree(c->d_tag);
     if (c->d_trace) hipFree(c->d_trace);
+    for (int i = 0; i < 2; i++) {
+        if (c->pl_buf[i]) hipFree(c->pl_buf[i]);
+        if (c->pl_ev_h2d[i]) hipEventDestroy(c->pl_ev_h2d[i]);
+        if (c->pl_ev_k[i]) hipEventDestroy(c->pl_ev_k[i]);
+        if (c->pl_ev_d2h[i]) hipEventDestroy(c->pl_ev_d2h[i]);
+    }
+    if (c->pl_in) hipStreamDestroy(c->pl_in);
+    if (c->pl_out) hipStreamDestroy(c->pl_out);
     if (c->st_in) hipFree(c->st_in);
     if (c->st_out) hipFree(c->st_out);
     if (c->st_aad) hipFree(c->st_aad);
@@ -972,6 +985,100 @@ int aesgcm_batch_crypt_dev(int device, int decrypt, size_t n_pkts, size_t key_le
     else         { if (nr == 10) LB(10, 0); else if (nr == 12) LB(12, 0); else LB(14, 0); }
 #undef LB
     HIPCHK(hipGetLastError());
+    return AESGCM_OK;
+}
+
+// ---------------------------------------------------------------- pipelined host-buffer path
+// H2D of chunk k+1, the fused kernel on chunk k and D2H of chunk k-1 overlap on three streams; the GHASH
+// value is carried from chunk to chunk on the device (Y' = Y*H^blocks ^ P, the same combine the beat-by-beat
+// interface uses), so the result is bit-identical to one launch over the whole message.
+static int pipeline_prepare(aesgcm_ctx *c, size_t chunk) {
+    if (!c->pl_in) {
+        HIPCHK(hipStreamCreateWithFlags(&c->pl_in, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&c->pl_out, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) {
+            HIPCHK(hipEventCreateWithFlags(&c->pl_ev_h2d[i], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&c->pl_ev_k[i], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&c->pl_ev_d2h[i], hipEventDisableTiming));
+        }
+    }
+    if (chunk > c->pl_cap) {
+        for (int i = 0; i < 2; i++) {
+            if (c->pl_buf[i]) { HIPCHK(hipFree(c->pl_buf[i])); c->pl_buf[i] = nullptr; }
+            hipError_t e = hipMalloc((void **)&c->pl_buf[i], chunk);
+            if (e == hipErrorOutOfMemory) { c->pl_cap = 0; return AESGCM_ENOMEM; }
+            if (e != hipSuccess) return hip_fail(e, "hipMalloc");
+        }
+        c->pl_cap = chunk;
+    }
+    return AESGCM_OK;
+}
+
+static int crypt_pipelined(aesgcm_ctx *c, int dec, const uint8_t iv[12], const uint8_t *aad, size_t aad_len,
+                           const uint8_t *in, size_t len, uint8_t *out, uint8_t tag[16], size_t chunk) {
+    int rc = check_lengths(aad_len, len);
+    if (rc) return rc;
+    if (!chunk) chunk = (size_t)64 << 20;
+    chunk = (chunk + 1023) / 1024 * 1024;                    // whole rows, 16-byte aligned chunk starts
+    if (chunk > len) chunk = (len + 1023) / 1024 * 1024;
+    if (!chunk) chunk = 1024;
+    HIPCHK(hipSetDevice(c->device));
+    if ((rc = pipeline_prepare(c, chunk))) return rc;
+    // state Y <- 0, then the AAD (small; through the staging buffer on the compute stream)
+    memcpy(c->s_iv, iv, 12);
+    c->s_dec = dec ? 1 : 0;
+    HIPCHK(hipMemsetAsync(c->d_tag + 1, 0, 16, c->stream));
+    if (aad_len) {
+        if ((rc = stage_in(c, aad, aad_len, nullptr, 0))) return rc;
+        if ((rc = stream_absorb(c, c->st_aad, aad_len, c->st_in, 0, c->st_out, 0))) return rc;
+    }
+    const size_t n_chunks = (len + chunk - 1) / chunk;
+    for (size_t k = 0; k < n_chunks; k++) {
+        const int s = (int)(k & 1);
+        const size_t off = k * chunk, m = (len - off < chunk) ? len - off : chunk;
+        if (k >= 2) HIPCHK(hipStreamWaitEvent(c->pl_in, c->pl_ev_d2h[s], 0));     // slot free again
+        HIPCHK(hipMemcpyAsync(c->pl_buf[s], in + off, m, hipMemcpyHostToDevice, c->pl_in));
+        HIPCHK(hipEventRecord(c->pl_ev_h2d[s], c->pl_in));
+        HIPCHK(hipStreamWaitEvent(c->stream, c->pl_ev_h2d[s], 0));
+        if ((rc = stream_absorb(c, nullptr, 0, c->pl_buf[s], m, c->pl_buf[s], off / 16))) return rc;   // in place
+        HIPCHK(hipEventRecord(c->pl_ev_k[s], c->stream));
+        HIPCHK(hipStreamWaitEvent(c->pl_out, c->pl_ev_k[s], 0));
+        HIPCHK(hipMemcpyAsync(out + off, c->pl_buf[s], m, hipMemcpyDeviceToHost, c->pl_out));
+        HIPCHK(hipEventRecord(c->pl_ev_d2h[s], c->pl_out));
+    }
+    if ((rc = enqueue_combine(c, plan_combine_final(c->d_tag + 1, iv, aad_len, len, c->d_tag), c->stream))) return rc;
+    HIPCHK(hipMemcpyAsync(tag, c->d_tag, 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipStreamSynchronize(c->pl_out));
+    return AESGCM_OK;
+}
+
+int aesgcm_encrypt_pipelined(aesgcm_ctx *c, const uint8_t iv[12], const uint8_t *aad, size_t aad_len,
+                             const uint8_t *pt, size_t len, uint8_t *ct, uint8_t tag[16], size_t chunk_bytes) {
+    if (!c || !iv || !tag || (aad_len && !aad) || (len && (!pt || !ct))) return AESGCM_EARG;
+    return crypt_pipelined(c, 0, iv, aad, aad_len, pt, len, ct, tag, chunk_bytes);
+}
+int aesgcm_decrypt_pipelined(aesgcm_ctx *c, const uint8_t iv[12], const uint8_t *aad, size_t aad_len,
+                             const uint8_t *ct, size_t len, uint8_t *pt, const uint8_t *expect_tag, uint8_t tag_out[16],
+                             size_t chunk_bytes) {
+    if (!c || !iv || (aad_len && !aad) || (len && (!ct || !pt))) return AESGCM_EARG;
+    uint8_t t[16];
+    int rc = crypt_pipelined(c, 1, iv, aad, aad_len, ct, len, pt, t, chunk_bytes);
+    if (rc) return rc;
+    if (tag_out) memcpy(tag_out, t, 16);
+    if (expect_tag && !ct_compare16(t, expect_tag)) return AESGCM_EAUTH;
+    return AESGCM_OK;
+}
+// page-locked host memory, so that the pipelined path's copies are true DMA (pageable buffers work, slower)
+int aesgcm_host_alloc(void **p, size_t bytes) {
+    if (!p) return AESGCM_EARG;
+    hipError_t e = hipHostMalloc(p, bytes ? bytes : 16, hipHostMallocDefault);
+    if (e == hipErrorOutOfMemory) return AESGCM_ENOMEM;
+    if (e != hipSuccess) return hip_fail(e, "hipHostMalloc");
+    return AESGCM_OK;
+}
+int aesgcm_host_free(void *p) {
+    HIPCHK(hipHostFree(p));
     return AESGCM_OK;
 }
 

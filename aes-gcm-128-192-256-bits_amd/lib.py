@@ -17,6 +17,7 @@ SYMBOLS = [
     "aesgcm_abi_version", "aesgcm_strerror", "aesgcm_last_error", "aesgcm_device_count", "aesgcm_device_name",
     "aesgcm_key_expand", "aesgcm_ecb_encrypt", "aesgcm_gfmul", "aesgcm_ghash", "aesgcm_get_h",
     "aesgcm_ctx_create", "aesgcm_ctx_create_preexpanded", "aesgcm_ctx_destroy", "aesgcm_ctx_device",
+    "aesgcm_encrypt_pipelined", "aesgcm_decrypt_pipelined", "aesgcm_host_alloc", "aesgcm_host_free",
     "aesgcm_encrypt", "aesgcm_decrypt", "aesgcm_encrypt_dev", "aesgcm_decrypt_dev", "aesgcm_last_tag",
     "aesgcm_keystream", "aesgcm_keystream_dev",
     "aesgcm_shard_crypt_dev", "aesgcm_shard_finalize_dev", "aesgcm_batch_crypt_dev",
@@ -69,6 +70,10 @@ def load():
     L.aesgcm_ctx_device.argtypes = [vp]
     L.aesgcm_encrypt.argtypes = [vp, vp, vp, sz, vp, sz, vp, vp]
     L.aesgcm_decrypt.argtypes = [vp, vp, vp, sz, vp, sz, vp, vp, vp]
+    L.aesgcm_encrypt_pipelined.argtypes = [vp, vp, vp, sz, vp, sz, vp, vp, sz]
+    L.aesgcm_decrypt_pipelined.argtypes = [vp, vp, vp, sz, vp, sz, vp, vp, vp, sz]
+    L.aesgcm_host_alloc.argtypes = [ctypes.POINTER(vp), sz]
+    L.aesgcm_host_free.argtypes = [vp]
     L.aesgcm_encrypt_dev.argtypes = [vp, vp, vp, sz, vp, sz, vp, vp, vp]
     L.aesgcm_decrypt_dev.argtypes = [vp, vp, vp, sz, vp, sz, vp, vp, vp, vp]
     L.aesgcm_last_tag.argtypes = [vp, vp, vp]
@@ -224,6 +229,26 @@ def batch_crypt_dev(decrypt, n_pkts, key_len, d_keys, d_ivs, d_in, pkt_len, d_ou
                                        d_in, pkt_len, d_out, d_tags, d_expect_tags, d_auth, stream))
 
 
+class PinnedBuffer:
+    """Page-locked host memory (hipHostMalloc) exposed as a writable memoryview / numpy-compatible buffer."""
+
+    def __init__(self, nbytes):
+        p = vp()
+        _chk(load().aesgcm_host_alloc(ctypes.byref(p), nbytes))
+        self.ptr, self.nbytes = p.value, nbytes
+        self._arr = (ctypes.c_ubyte * max(nbytes, 1)).from_address(self.ptr)
+        self.view = memoryview(self._arr).cast("B")[:nbytes]
+
+    def free(self):
+        if self.ptr:
+            self.view = None
+            self._arr = None
+            load().aesgcm_host_free(self.ptr)
+            self.ptr = None
+
+    __del__ = free
+
+
 def dev_sync(device=0):
     _chk(load().aesgcm_dev_sync(device))
 
@@ -307,6 +332,26 @@ class Context:
         tout = ctypes.create_string_buffer(16)
         exp = _fixed(tag, 16, "tag") if tag is not None else None
         rc = load().aesgcm_decrypt(self._c, _fixed(iv, 12, "iv"), a.addr, a.n, c.addr, c.n, o.addr, exp, tout)
+        self.last_plaintext = bytes(ret) if out is None else ret
+        _chk(rc)
+        return self.last_plaintext, tout.raw
+
+    def encrypt_pipelined(self, iv, aad, pt, out=None, chunk_bytes=0):
+        """Host buffers, H2D / kernel / D2H overlapped in chunks -> (ct, tag)."""
+        a, p = _Buf(aad), _Buf(pt)
+        ret = out if out is not None else bytearray(p.n)
+        o = _Buf(ret, writable=True)
+        tag = ctypes.create_string_buffer(16)
+        _chk(load().aesgcm_encrypt_pipelined(self._c, _fixed(iv, 12, "iv"), a.addr, a.n, p.addr, p.n, o.addr, tag, chunk_bytes))
+        return (bytes(ret) if out is None else ret), tag.raw
+
+    def decrypt_pipelined(self, iv, aad, ct, tag=None, out=None, chunk_bytes=0):
+        a, c = _Buf(aad), _Buf(ct)
+        ret = out if out is not None else bytearray(c.n)
+        o = _Buf(ret, writable=True)
+        tout = ctypes.create_string_buffer(16)
+        exp = _fixed(tag, 16, "tag") if tag is not None else None
+        rc = load().aesgcm_decrypt_pipelined(self._c, _fixed(iv, 12, "iv"), a.addr, a.n, c.addr, c.n, o.addr, exp, tout, chunk_bytes)
         self.last_plaintext = bytes(ret) if out is None else ret
         _chk(rc)
         return self.last_plaintext, tout.raw

@@ -171,6 +171,20 @@ AESGCM_API int aesgcm_stream_aad(aesgcm_ctx *ctx, const uint8_t *aad, size_t len
 AESGCM_API int aesgcm_stream_update(aesgcm_ctx *ctx, const uint8_t *in, size_t len, uint8_t *out);
 AESGCM_API int aesgcm_stream_final(aesgcm_ctx *ctx, uint8_t tag[16]);
 
+/* ---------------------------------------------------------------- whole messages, host pointers, pipelined
+ * For data that does not start on the GPU: the message is cut into chunk_bytes
+ * pieces (0 = 64 MiB); H2D of chunk k+1, the fused kernel on chunk k and D2H of chunk k-1 overlap on three
+ * HIP streams, and the running GHASH value is carried between chunks on the device (state the RTL and the
+ * pycryptodome model cannot export).  Results are bit-identical to aesgcm_encrypt/aesgcm_decrypt.  Buffers from
+ * aesgcm_host_alloc (page-locked) make the copies true DMA; pageable buffers work but copy slower. */
+AESGCM_API int aesgcm_encrypt_pipelined(aesgcm_ctx *ctx, const uint8_t iv[12], const uint8_t *aad, size_t aad_len,
+                             const uint8_t *pt, size_t len, uint8_t *ct, uint8_t tag[16], size_t chunk_bytes);
+AESGCM_API int aesgcm_decrypt_pipelined(aesgcm_ctx *ctx, const uint8_t iv[12], const uint8_t *aad, size_t aad_len,
+                             const uint8_t *ct, size_t len, uint8_t *pt, const uint8_t *expect_tag, uint8_t tag_out[16],
+                             size_t chunk_bytes);
+AESGCM_API int aesgcm_host_alloc(void **h_ptr, size_t bytes);
+AESGCM_API int aesgcm_host_free(void *h_ptr);
+
 /* ---------------------------------------------------------------- device memory helpers
  * (so that a Python/ctypes host needs no other GPU runtime binding) */
 AESGCM_API int aesgcm_dev_alloc(int device, void **d_ptr, size_t bytes);
