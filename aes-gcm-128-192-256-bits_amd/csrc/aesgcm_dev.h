@@ -331,15 +331,20 @@ struct MainParams {
 
 #define AESGCM_MAX_CHUNKS (AESGCM_GMAX * AESGCM_WG)   /* two-stage combine capacity: GMAX stage-1 workgroups x WG lanes */
 
-// Chunking of a GHASH sequence of n_seq blocks: rows of 64 blocks, Tw rows per chunk.  Enough chunks to
-// load-balance ~8k resident waves (>= 16 per wave when the message allows), long enough to amortise the
-// per-chunk tail multiply, and never more than the two-stage combine can fold.
+// Chunking of a GHASH sequence of n_seq blocks: rows of 64 blocks, Tw rows per chunk.  Measured on MI355X
+// (profiles/overhead_probe.py): a chunk costs its rows plus ~2.4 rows for the tail multiply, a lone wave needs
+// ~10 us per row when the CU is full, and ~8k waves are resident.  Small inputs therefore want MANY short
+// chunks (parallelism), large ones long chunks (amortised tail) but still >= 16 per resident wave (balance),
+// and never more chunks than the two-stage fold can take.
 HD void main_geometry(u64 n_seq, u32 tw_override, u64 *rows, u32 *Tw, u32 *C) {
     const u64 R = (n_seq + 63) / 64;
     u64 t;
     if (tw_override) t = tw_override;
-    else if (R <= (u64)16 * 131072) t = 16;
-    else { t = R / 131072; if (t > 256) t = 256; }
+    else if (R <= 32768) { t = R / 2048; if (t < 1) t = 1; }      // <= 32 MiB: ~2k chunks
+    else {
+        t = R / 16384; if (t < 16) t = 16; if (t > 64) t = 64;       // ~16k chunks up to 1 GiB, 64-row chunks beyond
+        if (R / t > 65536) { t = R / 65536; if (t > 256) t = 256; }    // >= 8 chunks per resident wave, <= 256 rows
+    }
     const u64 tmin = (R + AESGCM_MAX_CHUNKS - 1) / AESGCM_MAX_CHUNKS;
     if (t < tmin) t = tmin;
     if (t < 1) t = 1;
