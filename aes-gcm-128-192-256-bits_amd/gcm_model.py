@@ -21,45 +21,62 @@ except Exception:                       # cocotb is not installed outside the si
     log = logging.getLogger("gcm_model")
 
 
-# ======================================================================================
 class gcm:
-    """Same contract as tb/gcm_model.py:5-51.
+    """Same contract as the reference model class (tb/gcm_model.py:5-51), backed by the HIP library.
 
-    key = {'data': HEX, 'n_bytes': 16|24|32}, icb = {'data': HEX, 'n_bytes': 12}, ed = 'enc'|'dec'.
-    All AAD first (<=16 bytes per call), then data (16 bytes per call, only the last may be shorter);
-    each load_* call appends its output chunk to data_out before returning, get_tag appends one 16-byte
-    entry to tag.
+    gcm(key, icb, ed) with key = {'data': HEX, 'n_bytes': 16|24|32}, icb = {'data': HEX, 'n_bytes': 12},
+    ed = 'enc' | 'dec'.  The harness feeds all AAD first (<= 16 bytes per call), then data (16 bytes per call,
+    only the last may be shorter).  Every load_plain_text / load_cipher_text call appends its output chunk to
+    `data_out` before returning; get_tag(dut_tag) appends exactly one 16-byte entry to `tag`:
+      enc : the tag this model computed;
+      dec : the received tag if it authenticates, otherwise its bitwise complement, which makes the
+            scoreboard comparison fail (the reference's convention, tb/gcm_model.py:47-51).
     """
 
-    # ======================================================================================
     def __init__(self, key, icb, ed, device=0):
-        # encryption/decryption
         self.ed = ed
-
         self.data_out = []
         self.tag = []
-
-        _key = int(key['data'], 16).to_bytes(key['n_bytes'], byteorder='big')     # tb/gcm_model.py:16
-        _icb = int(icb['data'], 16).to_bytes(icb['n_bytes'], byteorder='big')     # tb/gcm_model.py:17
-        if len(_icb) != 12:
+        key_bytes = int(key['data'], 16).to_bytes(key['n_bytes'], byteorder='big')
+        iv_bytes = int(icb['data'], 16).to_bytes(icb['n_bytes'], byteorder='big')
+        if len(iv_bytes) != 12:
             raise ValueError("the IP core and this model support 96-bit IVs only (src/gcm_pkg.vhd:15-17)")
-        self.model = lib.Context(_key, device=device)      # AES.new(_key, mode=AES.MODE_GCM, nonce=_icb)
-        self.model.stream_begin(_icb, decrypt=(ed != 'enc'))
-        self._finished = False
+        self.model = lib.Context(key_bytes, device=device)      # key load: on-GPU key expansion + H tables
+        self.model.stream_begin(iv_bytes, decrypt=(ed != 'enc'))
+        self._final_tag = None
 
-    # ======================================================================================
+    # -- monitor callbacks (tb/gcm_test.py:76-85) ---------------------------------------------------
     def load_aad(self, aad):
-        self._state(self.model.stream_aad, aad)                           # model.update(aad)
+        self._call(self.model.stream_aad, aad)
 
-    # ======================================================================================
     def load_plain_text(self, pt):
-        self.data_out.append(self._state(self.model.stream_update, pt))   # model.encrypt(pt)
+        self.data_out.append(self._call(self.model.stream_update, pt))
 
-    # ======================================================================================
     def load_cipher_text(self, ct):
-        self.data_out.append(self._state(self.model.stream_update, ct))   # model.decrypt(ct)
+        self.data_out.append(self._call(self.model.stream_update, ct))
 
-    def _state(self, fn, data):
+    def get_tag(self, tag):
+        if self._final_tag is None:
+            self._final_tag = self.model.stream_final()
+        mine = self._final_tag
+        if self.ed == 'enc':
+            self.tag.append(mine)
+            log.info('model tag %032X', int.from_bytes(mine, 'big'))
+            if bytes(tag) == mine:
+                log.info('tags match')
+            else:
+                log.error('tag mismatch: DUT %s, model %s', bytes(tag).hex(), mine.hex())
+            return
+        if _ct_equal(bytes(tag), mine):
+            self.tag.append(tag)
+            log.info('tag verified: the message is authentic')
+        else:
+            log.error('authentication failed: key or IV incorrect, or message corrupted')
+            flipped = ~int.from_bytes(tag, 'big') & ((1 << 128) - 1)
+            self.tag.append(flipped.to_bytes(16, 'big'))
+
+    # -- helpers -----------------------------------------------------------------------------------
+    def _call(self, fn, data):
         try:
             return fn(bytes(data))
         except AesGcmError as e:
@@ -69,27 +86,6 @@ class gcm:
             if e.code == lib.ETOOLONG:
                 raise ValueError("message exceeds the GCM length limit") from e
             raise
-
-    # ======================================================================================
-    def get_tag(self, tag):
-        model_tag = self.model.stream_final() if not self._finished else self._tag
-        self._finished, self._tag = True, model_tag
-        if self.ed == 'enc':
-            self.tag.append(model_tag)                                    # model.digest()
-            log.info('Model\tTAG ' + '{:032X}'.format(int.from_bytes(model_tag, 'big')))
-            if tag == model_tag:
-                log.info('\33[92m' + "OK:\tTAGs match. " + '\33[00m')
-            else:
-                log.error('ERROR: TAGs mismatch')
-        else:
-            if _ct_equal(bytes(tag), model_tag):                          # model.verify(tag)
-                self.tag.append(tag)
-                log.info('\33[92m' + "OK:\tTAGs match. " + '\33[00m' + "the message is authentic!")
-            else:
-                log.error("ERROR:\tKEY or IV incorrect, or message corrupted")
-                # Force TAG error: invert received TAG (tb/gcm_model.py:49-51)
-                not_tag = ~(int.from_bytes(tag, 'big'))
-                self.tag.append((not_tag & ((1 << 128) - 1)).to_bytes(16, 'big'))
 
 
 def _ct_equal(a, b):
