@@ -347,6 +347,9 @@ def gen_streams(large, huge):
         # cfg4: 128 GiB aggregate = 4 messages x 32 GiB of ONE SplitMix64 stream (seed 0xAE5C0004), IV last byte + m.
         for m in range(4):
             want("cfg4_aes256_msg%d_32GiB" % m, 32, 0xAE5C0004, 32 * GiB, iv_tweak=m, first_word=m * (32 * GiB // 8))
+    if huge:
+        # the largest message GCM (and the RTL's 32-bit block counter, src/aes_icb.vhd:114) allows: 2^36 - 32 bytes
+        want("aes256_max_message", 32, 0xAE5C0006, (1 << 36) - 32, aad=splitmix_bytes(0x414144, 20))
     # keep previously generated big cases even when run without --large/--huge
     names = {c["name"] for c in cases}
     for n, c in prev.items():

@@ -77,3 +77,53 @@ def test_sharded_16GiB_equals_fixture(hip):
     assert ctx.shard_finalize_dev(iv, parts.ptr, ranks, 0, n).hex() == c["tag"]
     assert _sha_device(ct, n) == c["ct_sha256"]
     pt.free(); ct.free()
+
+
+def test_maximum_message_and_length_limit(hip, orc):
+    """2^36 - 32 bytes: the largest message the 32-bit block counter allows (src/aes_icb.vhd:114), in place,
+    with a 20-byte AAD; one byte more must be refused."""
+    c = _case("aes256_max_message")
+    n = c["n_bytes"]
+    assert n == (1 << 36) - 32
+    key, iv = stream_key_iv(c)
+    aad = bytes.fromhex(c["aad"])
+    ctx = hip.Context(key)
+    buf = hip.DeviceBuffer(n + 64)
+    buf.fill_splitmix64(c["pt_seed"], c["first_word"], nbytes=n)
+    d_aad = hip.DeviceBuffer(len(aad)); d_aad.upload(aad)
+    tag = ctx.encrypt_dev(iv, buf.ptr, n, buf.ptr, d_aad=d_aad.ptr, aad_len=len(aad))
+    assert tag.hex() == c["tag"]
+    assert bytes(buf.download(64, 0)).hex() == c["ct_head"] and bytes(buf.download(64, n - 64)).hex() == c["ct_tail"]
+    # ciphertext windows against keystream from the oracle (counter values near 2^32 included)
+    f = orc.Fast(key)
+    win = 1 << 16
+    for off in (0, (1 << 35) - win, n - win + 0):
+        off = off // 16 * 16
+        m = min(win, n - off)
+        pt = bytes(orc.fill_splitmix64(m, c["pt_seed"], c["first_word"] + off // 8))
+        ks = f.keystream(iv, off // 16, (m + 15) // 16)[:m]
+        assert bytes(buf.download(m, off)) == bytes(a ^ b for a, b in zip(pt, ks)), off
+    with pytest.raises(hip.AesGcmError) as e:
+        ctx.encrypt_dev(iv, buf.ptr, n + 1, buf.ptr)
+    assert e.value.code == hip.ETOOLONG
+    buf.free()
+
+
+def test_large_unaligned_aad(hip, orc):
+    """256 MiB of AAD from a misaligned device pointer + a short ragged message: the AAD rides the same chunked
+    polynomial evaluation as the data."""
+    key, iv = bytes(range(32)), bytes(range(12))
+    ctx = hip.Context(key)
+    n_aad = (256 << 20) + 5
+    d = hip.DeviceBuffer(n_aad + 64)
+    d.fill_splitmix64(0xA11)
+    import numpy as np
+    host = np.frombuffer(d.download(), dtype=np.uint8)
+    aad = host[3:3 + n_aad]
+    pt = bytes(orc.fill_splitmix64(1000, 0xB22))
+    d_pt, d_ct = hip.DeviceBuffer(1024), hip.DeviceBuffer(1024)
+    d_pt.upload(pt)
+    tag = ctx.encrypt_dev(iv, d_pt.ptr, len(pt), d_ct.ptr, d_aad=d.ptr + 3, aad_len=n_aad)
+    f = orc.Fast(key)
+    f.begin(iv); f.aad(aad); want_ct = bytes(f.update(pt)); want_tag = f.final()
+    assert tag == want_tag and bytes(d_ct.download(len(pt))) == want_ct
