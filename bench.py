@@ -145,6 +145,11 @@ def main():
     ap.add_argument("--gib-per-gpu", type=float, default=16.0, help="resident plaintext per GPU (default: the metric's 16 GiB)")
     ap.add_argument("--key-bits", type=int, default=256, choices=(128, 192, 256))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="collective backend for N > 1 (gloo: debug on one GPU, partials staged through the host)")
+    ap.add_argument("--one-device", action="store_true", help="debug: every rank uses GPU 0 (with --backend gloo)")
+    ap.add_argument("--selfcheck", action="store_true",
+                    help="rank 0 also encrypts every whole message alone and compares tags (needs the extra memory)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -160,8 +165,13 @@ def main():
         # torch FIRST: its bundled HIP runtime must be the one (and only) copy in the process
         import torch
         import torch.distributed as dist
+        if args.one_device:
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import aesgcm_amd  # noqa: F401
     from aesgcm_amd import lib, sharding
@@ -210,7 +220,12 @@ def main():
         for i, m in enumerate(msgs):
             ctx.shard_crypt_dev(False, m["iv"], d_pt.ptr + m["off"], m["len"], d_ct.ptr + m["off"], m["first_block"], m["total"],
                                 local_parts[i].data_ptr(), stream=stream)
-        dist.all_gather_into_tensor(gathered, local_parts)
+        if args.backend == "nccl":
+            dist.all_gather_into_tensor(gathered, local_parts)
+        else:                                                     # debug path: 16 B x msgs through the host
+            lst = [torch.zeros((len(msgs), 16), dtype=torch.uint8) for _ in range(world)]
+            dist.all_gather(lst, local_parts.cpu())
+            gathered.copy_(torch.stack(lst))
         per_msg = gathered.permute(1, 0, 2).contiguous()          # [msg][rank][16]
         return [ctx.shard_finalize_dev(m["iv"], per_msg[i].data_ptr(), world, 0, m["total"], stream=stream)
                 for i, m in enumerate(msgs)]
@@ -241,6 +256,21 @@ def main():
             head = bytes(d_ct.download(64, 0))
             tail = bytes(d_ct.download(64, per_gpu - 64))
             ct_ok = (head.hex() == fx["ct_head"] and tail.hex() == fx["ct_tail"])
+    selfcheck = None
+    if args.selfcheck and dist is not None and rank == 0:
+        selfcheck = True
+        for m, t in zip(plan, tags):
+            whole_pt, whole_ct = lib.DeviceBuffer(m["total"], device=dev), lib.DeviceBuffer(m["total"], device=dev)
+            whole_pt.fill_splitmix64(pt_seed, m["msg"] * m["total"] // 8)
+            lib.dev_sync(dev)
+            t_one = ctx.encrypt_dev(sharding.tweak_iv(iv0, m["iv_tweak"]), whole_pt.ptr, m["total"], whole_ct.ptr)
+            mine = bytes(d_ct.download(min(m["len"], 1 << 20), m["off"]))
+            ref = bytes(whole_ct.download(min(m["len"], 1 << 20), 16 * m["first_block"]))
+            selfcheck = selfcheck and (t_one == t) and (mine == ref)
+            whole_pt.free(); whole_ct.free()
+        if not selfcheck:
+            log("SELFCHECK FAILURE: sharded tags/ciphertext differ from the single-launch result")
+            tag_ok = False
     if tag_ok is False or ct_ok is False:
         log("PARITY FAILURE rank %d: tag_ok=%s ct_ok=%s tags=%s" % (rank, tag_ok, ct_ok, [t.hex() for t in tags]))
 
@@ -286,7 +316,7 @@ def main():
             "config": {"workload": workload, "bytes_per_gpu": per_gpu, "messages_per_step": len(msgs),
                        "parallelism": "single" if N == 1 else "shard%d" % N, "key_bits": args.key_bits,
                        "workgroups": geo["workgroups"], "wg_lanes": geo["wg_lanes"], "lds_bytes_per_wg": geo["lds_bytes"]},
-            "tag_ok": tag_ok, "ct_head_tail_ok": ct_ok, "tags": [t.hex() for t in tags],
+            "tag_ok": tag_ok, "ct_head_tail_ok": ct_ok, "selfcheck": selfcheck, "tags": [t.hex() for t in tags],
             "roofline": roofline,
         }
         if N == 1 and not args.no_cpu_baseline:
