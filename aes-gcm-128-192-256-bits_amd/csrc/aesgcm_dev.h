@@ -621,6 +621,9 @@ struct BatchParams {
     u32 *counter; u32 counter_base;
     u32 n_pkts, pkt_len, aad_len;
     u32 aligned;                 // in/out rows are 16-byte aligned for every packet
+    // variable-length form (all NULL = fixed pkt_len / aad_len, packets back to back):
+    const u64 *data_off;         // n_pkts + 1 byte offsets into in/out: packet p = [data_off[p], data_off[p+1])
+    const u64 *aad_off;          // n_pkts + 1 byte offsets into aad (or NULL = no AAD)
 };
 
 // reduction of the 4 bits shifted out by Z*x^4: r(v) for v = Z's last nibble, as the top 16 bits of word 0.

@@ -224,15 +224,15 @@ __device__ __forceinline__ void shoup_build(unsigned char *smem, u32 tab, G128 c
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 // block j of the packet's GHASH sequence (AAD blocks then data blocks), zero padded, as big-endian words
-__device__ __forceinline__ G128 batch_seq_block(const BatchParams &p, const unsigned char *aad, const unsigned char *data,
+__device__ __forceinline__ G128 batch_seq_block(bool aligned, u32 aad_len, u32 pkt_len, const unsigned char *aad, const unsigned char *data,
                                                 u32 n_aad, u32 j) {
     uint4 m;
     if (j < n_aad) {
-        const u32 off = 16 * j, rem = p.aad_len - off;
+        const u32 off = 16 * j, rem = aad_len - off;
         m = load_block_bytes(aad + off, rem < 16 ? rem : 16);
     } else {
-        const u32 off = 16 * (j - n_aad), rem = p.pkt_len - off;
-        if (p.aligned && rem >= 16) m = *reinterpret_cast<const uint4 *>(data + off);
+        const u32 off = 16 * (j - n_aad), rem = pkt_len - off;
+        if (aligned && rem >= 16) m = *reinterpret_cast<const uint4 *>(data + off);
         else m = load_block_bytes(data + off, rem < 16 ? rem : 16);
     }
     return mo_to_be(m);
@@ -248,9 +248,6 @@ __global__ __launch_bounds__(AESGCM_WG, AESGCM_WAVES_PER_SIMD) void k_batch(cons
     const u32 lb = (lane & 31u) << 2;
     const u32 tabH = BATCH_LDS_WAVE_OFF + wave * BATCH_WAVE_LDS, tabC = tabH + 256u;
     constexpr u32 KEYLEN = 4 * (NR - 6);
-    const u32 n_aad = (p.aad_len + 15) / 16, n_ct = (p.pkt_len + 15) / 16, n_seq = n_aad + n_ct;
-    const u32 q = (n_seq + 63) / 64;                       // blocks per lane (0 for an empty packet)
-    const u32 pad = 64 * q - n_seq;                        // front padding slots
     for (;;) {
         u32 pkt = 0;
         if (lane == 0) pkt = atomicAdd(p.counter, 1u) - p.counter_base;
@@ -258,9 +255,18 @@ __global__ __launch_bounds__(AESGCM_WG, AESGCM_WAVES_PER_SIMD) void k_batch(cons
         if (pkt >= p.n_pkts) break;
         const unsigned char *key = p.keys + (size_t)pkt * KEYLEN;
         const unsigned char *ivp = p.ivs + (size_t)pkt * 12;
-        const unsigned char *aad = p.aad ? p.aad + (size_t)pkt * p.aad_len : nullptr;
-        const unsigned char *in = p.in + (size_t)pkt * p.pkt_len;
-        unsigned char *out = p.out + (size_t)pkt * p.pkt_len;
+        // packet geometry: fixed-size records, or per-packet extents from the offset arrays (MACsec-shaped traffic)
+        u32 pkt_len = p.pkt_len, aad_len = p.aad_len;
+        u64 doff = (u64)pkt * p.pkt_len, aoff = (u64)pkt * p.aad_len;
+        if (p.data_off) { doff = p.data_off[pkt]; pkt_len = (u32)(p.data_off[pkt + 1] - doff); }
+        if (p.aad_off) { aoff = p.aad_off[pkt]; aad_len = (u32)(p.aad_off[pkt + 1] - aoff); }
+        const bool aligned = p.aligned && ((doff & 15) == 0);
+        const unsigned char *aad = p.aad ? p.aad + aoff : nullptr;
+        const unsigned char *in = p.in + doff;
+        unsigned char *out = p.out + doff;
+        const u32 n_aad = (aad_len + 15) / 16, n_ct = (pkt_len + 15) / 16, n_seq = n_aad + n_ct;
+        const u32 q = (n_seq + 63) / 64;                   // blocks per lane (0 for an empty packet)
+        const u32 pad = 64 * q - n_seq;                    // front padding slots
 
         // ---- aes_kexp for this packet; round keys become wave-uniform scalars
         u32 rk[4 * (NR + 1)];
@@ -292,16 +298,16 @@ __global__ __launch_bounds__(AESGCM_WG, AESGCM_WAVES_PER_SIMD) void k_batch(cons
                     if (k) acc = shoup_mul(acc, smem, tabH);
                     const u32 v = lane * q + k;
                     if (v >= pad) {
-                        const G128 b = batch_seq_block(p, aad, DEC ? in : out, n_aad, v - pad);
+                        const G128 b = batch_seq_block(aligned, aad_len, pkt_len, aad, DEC ? in : out, n_aad, v - pad);
                         acc.w[0] ^= b.w[0]; acc.w[1] ^= b.w[1]; acc.w[2] ^= b.w[2]; acc.w[3] ^= b.w[3];
                     }
                 }
             } else {
                 const CtrConsts cc = ctr_round1_consts(iv0, iv1, iv2, rk, smem, lb);
                 for (u32 i = lane; i < n_ct; i += 64) {
-                    const u32 off = 16 * i, rem = p.pkt_len - off;
+                    const u32 off = 16 * i, rem = pkt_len - off;
                     uint4 x;
-                    const bool full = p.aligned && rem >= 16;
+                    const bool full = aligned && rem >= 16;
                     if (full) x = *reinterpret_cast<const uint4 *>(in + off);
                     else x = load_block_bytes(in + off, rem < 16 ? rem : 16);
                     u32 s0, s1, s2, s3;
@@ -330,7 +336,7 @@ __global__ __launch_bounds__(AESGCM_WG, AESGCM_WAVES_PER_SIMD) void k_batch(cons
         }
         // ---- lane 63 holds P = sum X_i H^(n-1-i); tag = ((P*H) ^ L)*H ^ E_K(J0)
         G128 y = shoup_mul(acc, smem, tabH);
-        y.w[1] ^= p.aad_len * 8u; y.w[3] ^= p.pkt_len * 8u;       // both < 2^32 bits by the ABI's limits
+        y.w[1] ^= aad_len * 8u; y.w[3] ^= pkt_len * 8u;           // both < 2^32 bits by the ABI's limits
         y = shoup_mul(y, smem, tabH);
         y.w[0] ^= ej0.w[0]; y.w[1] ^= ej0.w[1]; y.w[2] ^= ej0.w[2]; y.w[3] ^= ej0.w[3];
         if (lane == 63) {
@@ -950,25 +956,15 @@ int aesgcm_stream_final(aesgcm_ctx *c, uint8_t tag[16]) {
 }
 
 // ---------------------------------------------------------------- batch (per-packet key and IV)
-int aesgcm_batch_crypt_dev(int device, int decrypt, size_t n_pkts, size_t key_len, const void *d_keys, const void *d_ivs,
-                           const void *d_aad, size_t aad_len, const void *d_in, size_t pkt_len, void *d_out,
-                           void *d_tags, const void *d_expect_tags, int *d_auth, void *stream) {
+static int batch_launch(int device, int decrypt, size_t n_pkts, size_t key_len, BatchParams &p, void *stream) {
     if (key_len != 16 && key_len != 24 && key_len != 32) return AESGCM_EKEYLEN;
-    if (!n_pkts) return AESGCM_OK;
-    if (!d_keys || !d_ivs || !d_tags || (aad_len && !d_aad) || (pkt_len && (!d_in || !d_out))) return AESGCM_EARG;
-    if (n_pkts >= (((size_t)1) << 31) || pkt_len >= (((size_t)1) << 28) || aad_len >= (((size_t)1) << 28)) return AESGCM_ETOOLONG;
+    if (n_pkts >= (((size_t)1) << 31)) return AESGCM_ETOOLONG;
     DeviceState *ds;
     int rc = device_state(device, &ds);
     if (rc) return rc;
     if ((rc = set_lds_attrs(device, ds))) return rc;
     HIPCHK(hipSetDevice(device));
-    BatchParams p;
-    memset(&p, 0, sizeof p);
-    p.keys = (const unsigned char *)d_keys; p.ivs = (const unsigned char *)d_ivs; p.aad = (const unsigned char *)d_aad;
-    p.in = (const unsigned char *)d_in; p.out = (unsigned char *)d_out; p.tags = (unsigned char *)d_tags;
-    p.expect = (const unsigned char *)d_expect_tags; p.auth = d_auth;
-    p.n_pkts = (u32)n_pkts; p.pkt_len = (u32)pkt_len; p.aad_len = (u32)aad_len;
-    p.aligned = (pkt_len % 16 == 0) && (((uintptr_t)d_in | (uintptr_t)d_out) & 15) == 0;
+    p.n_pkts = (u32)n_pkts;
     const u32 waves_per_wg = AESGCM_WG / 64;
     u32 wgs = (u32)((n_pkts + waves_per_wg - 1) / waves_per_wg);
     const u32 gmax = (u32)(2 * ds->n_cu > AESGCM_GMAX ? AESGCM_GMAX : 2 * ds->n_cu);
@@ -986,6 +982,37 @@ int aesgcm_batch_crypt_dev(int device, int decrypt, size_t n_pkts, size_t key_le
 #undef LB
     HIPCHK(hipGetLastError());
     return AESGCM_OK;
+}
+
+int aesgcm_batch_crypt_dev(int device, int decrypt, size_t n_pkts, size_t key_len, const void *d_keys, const void *d_ivs,
+                           const void *d_aad, size_t aad_len, const void *d_in, size_t pkt_len, void *d_out,
+                           void *d_tags, const void *d_expect_tags, int *d_auth, void *stream) {
+    if (!n_pkts) return AESGCM_OK;
+    if (!d_keys || !d_ivs || !d_tags || (aad_len && !d_aad) || (pkt_len && (!d_in || !d_out))) return AESGCM_EARG;
+    if (pkt_len >= (((size_t)1) << 28) || aad_len >= (((size_t)1) << 28)) return AESGCM_ETOOLONG;
+    BatchParams p;
+    memset(&p, 0, sizeof p);
+    p.keys = (const unsigned char *)d_keys; p.ivs = (const unsigned char *)d_ivs; p.aad = (const unsigned char *)d_aad;
+    p.in = (const unsigned char *)d_in; p.out = (unsigned char *)d_out; p.tags = (unsigned char *)d_tags;
+    p.expect = (const unsigned char *)d_expect_tags; p.auth = d_auth;
+    p.pkt_len = (u32)pkt_len; p.aad_len = (u32)aad_len;
+    p.aligned = (pkt_len % 16 == 0) && (((uintptr_t)d_in | (uintptr_t)d_out) & 15) == 0;
+    return batch_launch(device, decrypt, n_pkts, key_len, p, stream);
+}
+
+int aesgcm_batch_crypt_var_dev(int device, int decrypt, size_t n_pkts, size_t key_len, const void *d_keys, const void *d_ivs,
+                               const void *d_aad, const uint64_t *d_aad_off, const void *d_in, const uint64_t *d_data_off,
+                               void *d_out, void *d_tags, const void *d_expect_tags, int *d_auth, void *stream) {
+    if (!n_pkts) return AESGCM_OK;
+    if (!d_keys || !d_ivs || !d_tags || !d_data_off || !d_in || !d_out || (d_aad_off && !d_aad)) return AESGCM_EARG;
+    BatchParams p;
+    memset(&p, 0, sizeof p);
+    p.keys = (const unsigned char *)d_keys; p.ivs = (const unsigned char *)d_ivs; p.aad = d_aad_off ? (const unsigned char *)d_aad : nullptr;
+    p.in = (const unsigned char *)d_in; p.out = (unsigned char *)d_out; p.tags = (unsigned char *)d_tags;
+    p.expect = (const unsigned char *)d_expect_tags; p.auth = d_auth;
+    p.data_off = (const u64 *)d_data_off; p.aad_off = (const u64 *)d_aad_off;
+    p.aligned = (((uintptr_t)d_in | (uintptr_t)d_out) & 15) == 0;      // per packet: and its offset is a multiple of 16
+    return batch_launch(device, decrypt, n_pkts, key_len, p, stream);
 }
 
 // ---------------------------------------------------------------- pipelined host-buffer path

@@ -20,7 +20,7 @@ SYMBOLS = [
     "aesgcm_encrypt_pipelined", "aesgcm_decrypt_pipelined", "aesgcm_host_alloc", "aesgcm_host_free",
     "aesgcm_encrypt", "aesgcm_decrypt", "aesgcm_encrypt_dev", "aesgcm_decrypt_dev", "aesgcm_last_tag",
     "aesgcm_keystream", "aesgcm_keystream_dev",
-    "aesgcm_shard_crypt_dev", "aesgcm_shard_finalize_dev", "aesgcm_batch_crypt_dev",
+    "aesgcm_shard_crypt_dev", "aesgcm_shard_finalize_dev", "aesgcm_batch_crypt_dev", "aesgcm_batch_crypt_var_dev",
     "aesgcm_stream_begin", "aesgcm_stream_aad", "aesgcm_stream_update", "aesgcm_stream_final",
     "aesgcm_dev_alloc", "aesgcm_dev_free", "aesgcm_dev_upload", "aesgcm_dev_download", "aesgcm_dev_sync",
     "aesgcm_fill_splitmix64_dev",
@@ -82,6 +82,7 @@ def load():
     L.aesgcm_shard_crypt_dev.argtypes = [vp, cint, vp, vp, sz, vp, sz, vp, u64, u64, vp, vp]
     L.aesgcm_shard_finalize_dev.argtypes = [vp, vp, vp, sz, sz, u64, vp, vp]
     L.aesgcm_batch_crypt_dev.argtypes = [cint, cint, sz, sz, vp, vp, vp, sz, vp, sz, vp, vp, vp, vp, vp]
+    L.aesgcm_batch_crypt_var_dev.argtypes = [cint, cint, sz, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.aesgcm_stream_begin.argtypes = [vp, vp, cint]
     L.aesgcm_stream_aad.argtypes = [vp, vp, sz]
     L.aesgcm_stream_update.argtypes = [vp, vp, sz, vp]
@@ -227,6 +228,13 @@ def batch_crypt_dev(decrypt, n_pkts, key_len, d_keys, d_ivs, d_in, pkt_len, d_ou
     """n independent packets with per-packet key and IV, all arrays contiguous device memory (aesgcm.h)."""
     _chk(load().aesgcm_batch_crypt_dev(device, int(bool(decrypt)), n_pkts, key_len, d_keys, d_ivs, d_aad, aad_len,
                                        d_in, pkt_len, d_out, d_tags, d_expect_tags, d_auth, stream))
+
+
+def batch_crypt_var_dev(decrypt, n_pkts, key_len, d_keys, d_ivs, d_in, d_data_off, d_out, d_tags, d_aad=None, d_aad_off=None,
+                        d_expect_tags=None, d_auth=None, device=0, stream=None):
+    """Variable-length packets: uint64 offset arrays (n_pkts + 1 entries, device memory) delimit data and AAD."""
+    _chk(load().aesgcm_batch_crypt_var_dev(device, int(bool(decrypt)), n_pkts, key_len, d_keys, d_ivs, d_aad, d_aad_off,
+                                           d_in, d_data_off, d_out, d_tags, d_expect_tags, d_auth, stream))
 
 
 class PinnedBuffer:

@@ -160,6 +160,15 @@ AESGCM_API int aesgcm_batch_crypt_dev(int device, int decrypt, size_t n_pkts, si
                            const void *d_aad, size_t aad_len, const void *d_in, size_t pkt_len, void *d_out,
                            void *d_tags, const void *d_expect_tags, int *d_auth, void *stream);
 
+/* Variable-length form (MACsec-shaped traffic like the reference's README vectors: short frames with a
+ * per-frame header as AAD, README.md:251-257): packet p occupies bytes [d_data_off[p], d_data_off[p+1]) of
+ * in/out and, when d_aad_off != NULL, bytes [d_aad_off[p], d_aad_off[p+1]) of aad.  Offset arrays have
+ * n_pkts + 1 uint64 entries in device memory.  Each packet < 2^28 bytes.  Packets whose data offset is a
+ * multiple of 16 take the aligned fast path. */
+AESGCM_API int aesgcm_batch_crypt_var_dev(int device, int decrypt, size_t n_pkts, size_t key_len, const void *d_keys, const void *d_ivs,
+                               const void *d_aad, const uint64_t *d_aad_off, const void *d_in, const uint64_t *d_data_off,
+                               void *d_out, void *d_tags, const void *d_expect_tags, int *d_auth, void *stream);
+
 /* ---------------------------------------------------------------- streaming (beat-by-beat) interface
  * Mirrors the call order the reference harness drives its model with (tb/gcm_test.py:76-85 ->
  * tb/gcm_model.py:21-35): all AAD first, then data; every chunk except the last of its kind must be
