@@ -4,7 +4,7 @@
 #include <stdio.h>
 #include <stdint.h>
 typedef uint32_t u32;
-enum { OP_XOR, OP_BITOP3, OP_PERM, OP_ALIGNBIT, OP_ANDOR, OP_LSHR_AND, OP_BFE, OP_ADD, OP_MOV_SGPRXOR };
+enum { OP_XOR, OP_BITOP3, OP_PERM, OP_ALIGNBIT, OP_ANDOR, OP_LSHR_AND, OP_BFE, OP_ADD, OP_MOV_SGPRXOR, OP_SDWA_MOV, OP_MOV, OP_ROT };
 template <int OP>
 __device__ __forceinline__ u32 op(u32 a, u32 b, u32 c, u32 sk) {
     if (OP == OP_XOR) return a ^ b;
@@ -15,6 +15,9 @@ __device__ __forceinline__ u32 op(u32 a, u32 b, u32 c, u32 sk) {
     if (OP == OP_LSHR_AND) return (a >> 12) & 0xF0u;                          // 2 instructions
     if (OP == OP_BFE) return __builtin_amdgcn_ubfe(a, 8, 8);
     if (OP == OP_ADD) return a + b;
+    if (OP == OP_SDWA_MOV) { u32 d = a; asm volatile("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2" : "+v"(d) : "v"(b)); return d; }
+    if (OP == OP_MOV) { u32 d; asm volatile("v_mov_b32 %0, %1" : "=v"(d) : "v"(a)); return d; }
+    if (OP == OP_ROT) { u32 d; asm volatile("v_alignbit_b32 %0, %1, %1, 24" : "=v"(d) : "v"(a)); return d; }
     return a ^ sk;                                                            // xor with a scalar operand
 }
 template <int OP>
@@ -63,6 +66,8 @@ int main() {
     run<OP_LSHR_AND>("v_lshrrev+v_and", out, cyc, n_cu, 2);
     run<OP_BFE>("v_bfe_u32", out, cyc, n_cu, 1);
     run<OP_ADD>("v_add_u32", out, cyc, n_cu, 1);
-    run<OP_MOV_SGPRXOR>("v_xor_b32 (sgpr operand)", out, cyc, n_cu, 1);
+    run<OP_SDWA_MOV>("v_mov_b32_sdwa byte->byte", out, cyc, n_cu, 1);
+    run<OP_MOV>("v_mov_b32", out, cyc, n_cu, 1);
+    run<OP_ROT>("v_alignbit_b32 (rotate)", out, cyc, n_cu, 1);
     return 0;
 }

@@ -1,0 +1,90 @@
+"""GPU: randomized differential test against the oracle -- key size, AAD/data lengths biased to block, row (64 blocks),
+chunk and grid boundaries, chunk-size overrides (so both fold paths and ragged first chunks are hit), device
+pointer paths with misaligned AAD, in-place, decrypt, shard splits at random block boundaries."""
+import os
+import random
+
+import pytest
+
+from util import splitmix_bytes
+
+pytestmark = pytest.mark.gpu
+
+
+def _len(rng, cap):
+    kind = rng.random()
+    if kind < 0.15:
+        return rng.choice((0, 1, 15, 16, 17, 31, 32, 33))
+    if kind < 0.55:                                   # around row / chunk multiples
+        base = rng.choice((64, 128, 1024, 2048, 16384, 65536)) * 16 * rng.randint(1, 6)
+        return max(0, min(cap, base + rng.randint(-40, 40)))
+    return int(rng.betavariate(.3, .3) * cap)
+
+
+def test_fuzz_one_shot_and_device_paths(hip, orc):
+    rng = random.Random(20260101)
+    old = os.environ.get("AESGCM_TW")
+    try:
+        for it in range(220):
+            klen = rng.choice((16, 24, 32))
+            tw = rng.choice((None, None, 1, 2, 3, 5, 16, 64))
+            if tw is None:
+                os.environ.pop("AESGCM_TW", None)
+            else:
+                os.environ["AESGCM_TW"] = str(tw)
+            key, iv = splitmix_bytes(9000 + it, klen), splitmix_bytes(9500 + it, 12)
+            al = _len(rng, 1 << 16) if rng.random() < 0.7 else 0
+            n = _len(rng, 6 << 20)
+            aad, pt = splitmix_bytes(10000 + it, al), splitmix_bytes(11000 + it, n)
+            f = orc.Fast(key)
+            want = f.encrypt(iv, aad, pt)
+            ctx = hip.Context(key)                                    # reads AESGCM_TW at creation
+            mode = rng.choice(("host", "dev", "inplace", "pipe"))
+            if mode == "host":
+                got = ctx.encrypt(iv, aad, pt)
+            elif mode == "pipe":
+                got = ctx.encrypt_pipelined(iv, aad, pt, chunk_bytes=rng.choice((0, 1 << 16, 1 << 20)))
+            else:
+                d_in = hip.DeviceBuffer(n + 32); d_in.upload(pt)
+                d_out = d_in if mode == "inplace" else hip.DeviceBuffer(n + 32)
+                shift = rng.choice((0, 1, 7, 16))
+                d_aad = hip.DeviceBuffer(al + 64); d_aad.upload(aad, offset=shift)
+                tag = ctx.encrypt_dev(iv, d_in.ptr, n, d_out.ptr, d_aad=d_aad.ptr + shift if al else None, aad_len=al)
+                got = (bytes(d_out.download(n)), tag)
+            assert got == want, (it, klen, al, n, tw, mode)
+            back, t2 = ctx.decrypt(iv, aad, want[0], tag=want[1])
+            assert back == pt and t2 == want[1], (it, "dec")
+            ctx.close()
+    finally:
+        if old is None:
+            os.environ.pop("AESGCM_TW", None)
+        else:
+            os.environ["AESGCM_TW"] = old
+
+
+def test_fuzz_random_shard_splits(hip, orc):
+    rng = random.Random(77)
+    for it in range(40):
+        klen = rng.choice((16, 24, 32))
+        key, iv = splitmix_bytes(12000 + it, klen), splitmix_bytes(12500 + it, 12)
+        al, n = rng.choice((0, 13, 64, 1000)), _len(rng, 3 << 20)
+        aad, pt = splitmix_bytes(13000 + it, al), splitmix_bytes(14000 + it, n)
+        want = orc.Fast(key).encrypt(iv, aad, pt)
+        ctx = hip.Context(key)
+        nb = (n + 15) // 16
+        ranks = rng.randint(1, 8)
+        cuts = sorted(rng.randint(0, nb) for _ in range(ranks - 1))
+        bounds = [0] + cuts + [nb]                                    # arbitrary (possibly empty) shards
+        d_in, d_out = hip.DeviceBuffer(n + 32), hip.DeviceBuffer(n + 32)
+        d_in.upload(pt)
+        d_aad = hip.DeviceBuffer(al + 16); d_aad.upload(aad)
+        parts = hip.DeviceBuffer(16 * ranks)
+        for r in range(ranks):
+            first, end = bounds[r], bounds[r + 1]
+            ln = max(0, (n if end == nb else 16 * end) - 16 * first)
+            ctx.shard_crypt_dev(False, iv, d_in.ptr + 16 * first, ln, d_out.ptr + 16 * first, first, n, parts.ptr + 16 * r,
+                                d_aad=d_aad.ptr if (first == 0 and r == 0 and al) else None, aad_len=al if (first == 0 and r == 0) else 0)
+        # the AAD belongs to the shard that starts at block 0; if rank 0 is empty the next rank starting at 0 must not re-add it
+        tag = ctx.shard_finalize_dev(iv, parts.ptr, ranks, al, n)
+        assert tag == want[1], (it, ranks, bounds, al, n)
+        assert bytes(d_out.download(n)) == want[0]
