@@ -295,8 +295,7 @@ struct DevTables {           // per device
 struct KeyMaterial {         // per context (device memory)
     u32 rk[60];              // expanded key, memory-order words
     u32 nr;
-    u32 G;                   // workgroups the K table was built for
-    u32 _pad[2];
+    u32 _pad[3];
     uint4 h;                 // H = E_K(0^128)
     uint4 pw[4][AESGCM_NPW]; // pw[d][k] = H^(k * WG^d)
     uint4 bp2[AESGCM_GMAX + 1]; // bp2[k] = beta^k * H^2, beta = H^WG
@@ -325,7 +324,6 @@ struct MainParams {
     u32 ctr0;                    // counter of data block 0 (2 + first_block)
     u32 iv0, iv1, iv2;           // IV as memory-order words
     u32 aad_aligned;             // AAD pointer 16-byte aligned
-    u32 flags;                   // experiment switches (AESGCM_FLAGS)
     u64 *trace;                  // optional per-workgroup {start, end, HW_ID | XCC_ID << 32, chunks done} (measurement support)
 };
 
@@ -368,7 +366,7 @@ HD void setup_lane0(KeyMaterial *km, const uint8_t *sbox, const uint8_t *key, in
     for (int w = 0; w < 4 * (nr + 1); w++) km->rk[w] = load_le32(km->rk_bytes + 4 * w);
     for (int w = 4 * (nr + 1); w < 60; w++) km->rk[w] = 0;
     km->nr = (u32)nr;
-    km->G = G;
+    (void)G;
     uint8_t zero[16] = {0}, hb[16];
     aes_block_bytes(km->rk_bytes, nr, sbox, zero, hb);
     km->h = make_uint4(load_le32(hb), load_le32(hb + 4), load_le32(hb + 8), load_le32(hb + 12));

@@ -364,7 +364,8 @@ static int hip_fail(hipError_t e, const char *what) {
 }
 #define HIPCHK(call) do { hipError_t _e = (call); if (_e != hipSuccess) return hip_fail(_e, #call); } while (0)
 
-struct DeviceState { DevTables *tables = nullptr; int n_cu = 0; bool attrs = false; u32 *batch_counter = nullptr; u32 batch_base = 0; };
+#define BATCH_DISPENSERS 256
+struct DeviceState { DevTables *tables = nullptr; int n_cu = 0; bool attrs = false; u32 *batch_counter = nullptr; u32 batch_slot = 0; };   // ring of dispensers: concurrent batch launches never share one
 static std::mutex g_mu;
 static std::vector<DeviceState> g_dev;
 
@@ -386,8 +387,8 @@ static int device_state(int device, DeviceState **out) {
         HIPCHK(hipGetLastError());
         HIPCHK(hipDeviceSynchronize());
         d.tables = t;
-        HIPCHK(hipMalloc(&d.batch_counter, 64));
-        HIPCHK(hipMemset(d.batch_counter, 0, 64));
+        HIPCHK(hipMalloc(&d.batch_counter, 4 * BATCH_DISPENSERS));
+        HIPCHK(hipMemset(d.batch_counter, 0, 4 * BATCH_DISPENSERS));
     }
     *out = &d;
     return AESGCM_OK;
@@ -408,7 +409,6 @@ struct aesgcm_ctx {
     uint4 *d_tag = nullptr;            // [0] tag / poly result, [1] streaming state Y
     u64 *d_trace = nullptr;            // per-workgroup trace of the last k_main launch (timing mode only)
     u32 last_np = 0;
-    u32 flags = 0;                     // AESGCM_FLAGS experiment switches
     hipStream_t stream = nullptr;
     // host-API staging
     unsigned char *st_in = nullptr, *st_out = nullptr, *st_aad = nullptr;
@@ -470,14 +470,12 @@ static int set_lds_attrs(int device, DeviceState *ds) {
     return AESGCM_OK;
 }
 
-// Enqueue the fused kernel over (aad, data) and return the number of partials it wrote.
-// mode ENC/DEC: GHASH partials into c->parts.  mode KS/ECB: no GHASH.
 // What the fold stage needs to know about the partials a launch produced.
 struct Partials { const uint4 *ptr = nullptr; u32 np = 0; bool gathered = false; };
 
 static int grow_parts(aesgcm_ctx *c, size_t need) {
     if (need <= c->parts_cap) return AESGCM_OK;
-    if (c->parts) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->parts)); c->parts = nullptr; c->parts_cap = 0; }
+    if (c->parts) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(c->parts)); c->parts = nullptr; c->parts_cap = 0; }   // rare: first big message
     size_t n = need < 4096 ? 4096 : need;
     hipError_t e = hipMalloc(&c->parts, n * sizeof(uint4));
     if (e == hipErrorOutOfMemory) return AESGCM_ENOMEM;
@@ -502,7 +500,6 @@ static int enqueue_main(aesgcm_ctx *c, int mode, const uint8_t iv[12], const voi
     p.parts = c->parts;
     p.counter = c->d_counter;
     p.counter_base = c->counter_base;
-    p.flags = c->flags;
     u32 wgs = (C + AESGCM_WG / 64 - 1) / (AESGCM_WG / 64);          // one wave per chunk is enough for small inputs
     if (wgs > (u32)c->G) wgs = (u32)c->G;
     c->counter_base += C + wgs * (AESGCM_WG / 64);                 // every wave makes exactly one failing fetch
@@ -518,7 +515,14 @@ static int enqueue_main(aesgcm_ctx *c, int mode, const uint8_t iv[12], const voi
         else { HIPCHK(hipEventCreate(&evp.first)); HIPCHK(hipEventCreate(&evp.second)); }
         HIPCHK(hipEventRecord(evp.first, st));
     }
-    HIPCHK(launch_main(mode, c->nr, dim3(wgs), st, c->km, c->tables, p));
+    {
+        const hipError_t le = launch_main(mode, c->nr, dim3(wgs), st, c->km, c->tables, p);
+        if (le != hipSuccess) {                      // nothing ran: the dispenser was not advanced on the device
+            c->counter_base = p.counter_base;
+            if (c->timing) c->ev_pool.push_back(evp);
+            return hip_fail(le, "k_main launch");
+        }
+    }
     if (c->timing) { HIPCHK(hipEventRecord(evp.second, st)); c->ev.push_back(evp); }
     if (gh && po) {
         if (needs_weigh(C, p.Tw)) {
@@ -625,14 +629,13 @@ static int ctx_create_common(aesgcm_ctx **out, int device, const uint8_t *key, s
     c->nr = pre_nr ? pre_nr : (int)(key_len / 4 + 6);
     int per_cu = 2;
     if (const char *e = getenv("AESGCM_WGS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 2) per_cu = v; }
-    if (const char *e = getenv("AESGCM_FLAGS")) c->flags = (u32)strtoul(e, nullptr, 0);
     if (const char *e = getenv("AESGCM_TW")) c->tw_override = (u32)strtoul(e, nullptr, 0);
     int G = per_cu * ds->n_cu;
     if (G > AESGCM_GMAX) G = AESGCM_GMAX;
     if (G < 1) G = 1;
     c->G = G;
-    HIPCHK(hipSetDevice(device));
     hipError_t e;
+    if ((e = hipSetDevice(device)) != hipSuccess) { delete c; return hip_fail(e, "hipSetDevice"); }
     if ((e = hipStreamCreate(&c->stream)) != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate"); }
     if ((e = hipMalloc(&c->km, sizeof(KeyMaterial))) != hipSuccess ||
         (e = hipMalloc(&c->stage1, sizeof(uint4) * AESGCM_GMAX)) != hipSuccess ||
@@ -969,13 +972,14 @@ static int batch_launch(int device, int decrypt, size_t n_pkts, size_t key_len, 
     u32 wgs = (u32)((n_pkts + waves_per_wg - 1) / waves_per_wg);
     const u32 gmax = (u32)(2 * ds->n_cu > AESGCM_GMAX ? AESGCM_GMAX : 2 * ds->n_cu);
     if (wgs > gmax) wgs = gmax;
-    {
+    {   // a fresh dispenser per launch (zeroed on the launch stream), so launches on different streams may overlap
         std::lock_guard<std::mutex> lk(g_mu);
-        p.counter = ds->batch_counter; p.counter_base = ds->batch_base;
-        ds->batch_base += (u32)n_pkts + wgs * waves_per_wg;
+        p.counter = ds->batch_counter + (ds->batch_slot++ % BATCH_DISPENSERS);
+        p.counter_base = 0;
     }
     const int nr = (int)(key_len / 4 + 6);
     hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipMemsetAsync(p.counter, 0, 4, st));
 #define LB(NR, D) hipLaunchKernelGGL((k_batch<NR, D>), dim3(wgs), dim3(AESGCM_WG), BATCH_LDS_BYTES, st, ds->tables, p)
     if (decrypt) { if (nr == 10) LB(10, 1); else if (nr == 12) LB(12, 1); else LB(14, 1); }
     else         { if (nr == 10) LB(10, 0); else if (nr == 12) LB(12, 0); else LB(14, 0); }

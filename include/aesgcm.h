@@ -16,7 +16,9 @@
  *     kernels on the selected device.  There is no CPU fallback: without a usable HIP device every
  *     compute entry point fails with AESGCM_EHIP.
  *   - the caller owns every buffer it passes; the library owns only opaque contexts.
- *   - a context is not thread-safe; distinct contexts may be used from distinct threads.
+ *   - a context is not thread-safe; distinct contexts may be used from distinct threads.  Calls on ONE
+ *     context must be stream-ordered (same stream, or the caller synchronises between streams): a context
+ *     owns one set of scratch buffers.  The batch entry points have no context and may overlap freely.
  *   - IV is always 96 bits (src/gcm_pkg.vhd:15-17, tb/gcm_gctr.py:251); tag is the full 128 bits
  *     (src/gcm_ghash.vhd:293).
  *   - length rule: data <= 2^36 - 32 bytes (the 32-bit block counter stops at all-ones,
