@@ -320,6 +320,7 @@ struct MainParams {
     u32 Tw;                      // rows per chunk
     u32 C;                       // chunks = ceil(R / Tw); chunk 0 is the short one (R0 rows)
     u32 R0;                      // rows in chunk 0 = R - (C-1)*Tw
+    u32 row_lo, row_hi;          // rows [row_lo, row_hi) hold 64 full data blocks each (fast path)
     u32 counter_base;
     u32 ctr0;                    // counter of data block 0 (2 + first_block)
     u32 iv0, iv1, iv2;           // IV as memory-order words
@@ -423,6 +424,32 @@ HD uint4 mask_block(uint4 v, u32 nbytes) {
 // The hot loop: lane `lane` (0..63) of the wave that owns chunk `c`.  Rows of the chunk are consecutive
 // 64-block groups; the lane runs Horner with K = H^64 (its own blocks are 64 apart).  Returns the lane's
 // GHASH accumulator for the chunk: sum_r X[row_r, lane] * K^(rows-1-r).
+// Almost every row is a "pure data row" (64 full data blocks): those take the fast path, whose addresses are a
+// wave-uniform 64-bit base plus a 32-bit lane offset (scalar base + vector offset addressing, no 64-bit vector
+// arithmetic, no per-lane branches).  Rows that contain front padding, AAD blocks or the ragged last block take
+// the general path.
+template <int NR, int MODE>
+HD uint4 main_block(const u32 *__restrict__ rk, const unsigned char *smem, const CtrConsts &cc, u32 lb, uint4 x, u32 ctr) {
+    u32 s0, s1, s2, s3;
+    if (MODE == MODE_ECB) {
+        s0 = x.x ^ rk[0]; s1 = x.y ^ rk[1]; s2 = x.z ^ rk[2]; s3 = x.w ^ rk[3];
+        aes_rounds_lds<NR>(s0, s1, s2, s3, rk, smem, lb);
+        return make_uint4(s0, s1, s2, s3);
+    }
+    // counter block IV || cnt, cnt big-endian, low 32 bits only (aes_icb.vhd:97-100,118)
+    ctr_rounds_lds<NR>(bswap32(ctr), cc, s0, s1, s2, s3, rk, smem, lb);
+    return make_uint4(x.x ^ s0, x.y ^ s1, x.z ^ s2, x.w ^ s3);                  // gcm_gctr.vhd:150
+}
+
+// make a wave-uniform 64-bit value visibly scalar to the compiler (host: identity)
+HD u64 uniform64(u64 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return ((u64)(u32)__builtin_amdgcn_readfirstlane((u32)(x >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((u32)x);
+#else
+    return x;
+#endif
+}
+
 template <int NR, int MODE>
 HD uint4 main_chunk_lane(const KeyMaterial *__restrict__ km, const MainParams &p, const unsigned char *smem, const CtrConsts &cc, u32 c, u32 lane) {
     constexpr bool GH = (MODE == MODE_ENC || MODE == MODE_DEC);
@@ -431,12 +458,28 @@ HD uint4 main_chunk_lane(const KeyMaterial *__restrict__ km, const MainParams &p
     const u64 n_data_blocks = p.n_seq - p.n_aad;
     const u32 tail_bytes = (u32)(p.len & 15);          // 0 = last data block is full
     const u32 aad_tail = (u32)(p.aad_len & 15);
-    const u64 row0 = c ? (u64)p.R0 + (u64)(c - 1) * p.Tw : 0;
+    const u32 row0 = c ? p.R0 + (c - 1) * p.Tw : 0;                       // rows fit 32 bits (R <= 2^30)
     const u32 nrows = c ? p.Tw : p.R0;
+    const u64 first_data_slot = (u64)p.pad + p.n_aad;                     // virtual slot of data block 0
+    const u32 lane16 = lane * 16u;
     uint4 acc = make_uint4(0, 0, 0, 0);
-    u64 v = row0 * 64 + lane;                          // virtual slot (front padding included)
-    for (u32 r = 0; r < nrows; ++r, v += 64) {
+    for (u32 r = 0; r < nrows; ++r) {
+        const u32 row = row0 + r;                                          // wave-uniform
         if (GH && r > 0) acc = ghash_mul_const_lds(acc, smem);
+        if (row >= p.row_lo && row < p.row_hi) {
+            // ---- fast path: 64 full data blocks; uniform 64-bit base + 32-bit lane offset
+            const u64 i0 = (u64)row * 64 - first_data_slot;                // data block index of lane 0
+            const unsigned char *src = reinterpret_cast<const unsigned char *>(uniform64((u64)(uintptr_t)p.in + 16 * i0));
+            unsigned char *dst = reinterpret_cast<unsigned char *>(uniform64((u64)(uintptr_t)p.out + 16 * i0));
+            uint4 x = make_uint4(0, 0, 0, 0);
+            if (MODE != MODE_KS) x = *reinterpret_cast<const uint4 *>(src + lane16);
+            const uint4 y = main_block<NR, MODE>(rk, smem, cc, lb, x, p.ctr0 + (u32)i0 + lane);
+            *reinterpret_cast<uint4 *>(dst + lane16) = y;
+            if (GH) acc = xor4(acc, (MODE == MODE_DEC) ? x : y);          // aes_gcm.vhd:207-211
+            continue;
+        }
+        // ---- general path
+        const u64 v = (u64)row * 64 + lane;
         if (v < p.pad) continue;                       // front padding: contributes zero
         const u64 j = v - p.pad;                       // index in the GHASH sequence (AAD blocks then data blocks)
         uint4 gin;
@@ -453,17 +496,7 @@ HD uint4 main_chunk_lane(const KeyMaterial *__restrict__ km, const MainParams &p
                 if (ragged) x = load_block_bytes(p.in + 16 * i, tail_bytes);
                 else x = *reinterpret_cast<const uint4 *>(p.in + 16 * i);
             }
-            u32 s0, s1, s2, s3;
-            if (MODE == MODE_ECB) {
-                s0 = x.x ^ rk[0]; s1 = x.y ^ rk[1]; s2 = x.z ^ rk[2]; s3 = x.w ^ rk[3];
-                aes_rounds_lds<NR>(s0, s1, s2, s3, rk, smem, lb);
-            } else {
-                // counter block IV || cnt, cnt big-endian, low 32 bits only (aes_icb.vhd:97-100,118)
-                ctr_rounds_lds<NR>(bswap32(p.ctr0 + (u32)i), cc, s0, s1, s2, s3, rk, smem, lb);
-            }
-            uint4 y;
-            if (MODE == MODE_ECB) y = make_uint4(s0, s1, s2, s3);
-            else y = make_uint4(x.x ^ s0, x.y ^ s1, x.z ^ s2, x.w ^ s3);        // gcm_gctr.vhd:150
+            uint4 y = main_block<NR, MODE>(rk, smem, cc, lb, x, p.ctr0 + (u32)i);
             if (ragged) { y = mask_block(y, tail_bytes); store_block_bytes(p.out + 16 * i, y, tail_bytes); }
             else *reinterpret_cast<uint4 *>(p.out + 16 * i) = y;
             gin = (MODE == MODE_DEC) ? x : y;           // aes_gcm.vhd:207-211
@@ -552,6 +585,12 @@ static inline u32 plan_main(MainParams &p, int mode, u32 tw_override, const uint
     p.parts = parts;
     p.aad_len = gh ? aad_len : 0; p.n_aad = n_aad; p.len = len; p.n_seq = n_seq;
     p.rows = R; p.pad = (u32)(64 * R - n_seq); p.Tw = Tw; p.C = C; p.R0 = (u32)(R - (u64)(C - 1) * Tw);
+    {
+        const u64 fds = (u64)p.pad + n_aad;                            // virtual slot of data block 0
+        const u64 full = (len / 16);                                     // data blocks that are 16 bytes long
+        const u64 lo = (fds + 63) / 64, hi = (fds + full) / 64;
+        p.row_lo = (u32)lo; p.row_hi = (u32)(hi > lo ? hi : lo);
+    }
     p.ctr0 = (u32)(2 + first_block);
     u32 w[3] = {0, 0, 0};
     if (iv) iv_to_words(iv, w);

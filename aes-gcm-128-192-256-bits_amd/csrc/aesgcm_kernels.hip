@@ -116,9 +116,11 @@ __global__ __launch_bounds__(AESGCM_WG, AESGCM_WAVES_PER_SIMD) void k_main(const
     const u64 cyc0 = p.trace ? clock64() : 0;
     main_fill_lds(smem, km, tb, tid, GH);
     __syncthreads();
-    const CtrConsts cc = main_lane_consts<MODE>(km, p, smem, lane);
-    G128 tailpow;
-    if (GH) tailpow = main_lane_tailpow(km, lane);
+    // round-1 constants depend on key and IV only (the lane merely picks which table replica it reads), so they
+    // are wave-uniform: keep them in scalar registers, the vector file is full at 8 waves per SIMD
+    CtrConsts cc = main_lane_consts<MODE>(km, p, smem, lane);
+    cc.c0 = __builtin_amdgcn_readfirstlane(cc.c0); cc.c1 = __builtin_amdgcn_readfirstlane(cc.c1);
+    cc.c2 = __builtin_amdgcn_readfirstlane(cc.c2); cc.c3 = __builtin_amdgcn_readfirstlane(cc.c3);
     u32 done = 0;
     for (;;) {
         u32 c = 0;
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(AESGCM_WG, AESGCM_WAVES_PER_SIMD) void k_main(const
         if (c >= p.C) break;
         const uint4 acc = main_chunk_lane<NR, MODE>(km, p, smem, cc, c, lane);
         if (GH) {
-            const G128 z = wave_xor_fold(main_lane_tail(acc, tailpow));
+            const G128 z = wave_xor_fold(main_lane_tail(acc, main_lane_tailpow(km, lane)));   // H^(63-lane), loaded per chunk
             if (lane == 0) p.parts[c] = be_to_mo(z);
         }
         ++done;
