@@ -24,6 +24,9 @@ typedef uint64_t u64;
 #endif
 #define AESGCM_WG (1 << AESGCM_LOG_WG)   /* lanes per workgroup = GHASH lane stride S = radix of the H-power tables */
 #define AESGCM_GMAX 512        /* max workgroups per launch (2 per CU on 256 CUs) */
+#ifndef AESGCM_MAIN_WG
+#define AESGCM_MAIN_WG AESGCM_WG          /* lanes per k_main workgroup (waves are autonomous: any multiple of 64) */
+#endif
 #define AESGCM_NPW (AESGCM_WG + 1)       /* entries per power table: exponent digits 0..WG */
 #define AESGCM_LDS_GH 8192     /* bytes: 32 nibble positions x 16 entries x 16 B */
 #define AESGCM_LDS_AES 65536   /* bytes: 256 entries x (32 replicas of T0 | 32 replicas of T2) */
@@ -389,11 +392,11 @@ HD void setup_beta_lane(KeyMaterial *km, const uint4 *tab, int tid) {
 }
 
 // ---- k_main pieces -----------------------------------------------------------------------------
-// LDS image of one workgroup: what thread `tid` of AESGCM_WG writes
-HD void main_fill_lds(unsigned char *smem, const KeyMaterial *km, const DevTables *tb, u32 tid, bool gh) {
-    if (gh && tid < 512) reinterpret_cast<uint4 *>(smem + AESGCM_LDS_GH_OFF)[tid] = km->ktab[tid];
+// LDS image of one workgroup: what thread `tid` of AESGCM_MAIN_WG writes
+HD void main_fill_lds(unsigned char *smem, const KeyMaterial *km, const DevTables *tb, u32 tid, bool gh, u32 nthreads = AESGCM_MAIN_WG) {
+    if (gh) for (u32 q = tid; q < 512; q += nthreads) reinterpret_cast<uint4 *>(smem + AESGCM_LDS_GH_OFF)[q] = km->ktab[q];
     uint4 *dst = reinterpret_cast<uint4 *>(smem + AESGCM_LDS_AES_OFF);
-    for (u32 q = tid; q < AESGCM_LDS_AES / 16; q += AESGCM_WG) {
+    for (u32 q = tid; q < AESGCM_LDS_AES / 16; q += nthreads) {
         const u32 t0 = tb->te0[q >> 4];
         const u32 v = ((q >> 3) & 1) ? rotl32(t0, 16) : t0;
         dst[q] = make_uint4(v, v, v, v);

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(AESGCM_WG) void k_setup(KeyMaterial *km, const DevT
 // of the CU (older waves first) only changes WHO does the work, never how long the kernel's tail is.
 // ------------------------------------------------------------------------------------------------
 #ifndef AESGCM_WAVES_PER_SIMD
-#define AESGCM_WAVES_PER_SIMD (2 * AESGCM_WG / 256)   /* two workgroups per CU */
+#define AESGCM_WAVES_PER_SIMD (2 * AESGCM_MAIN_WG / 256)   /* two workgroups per CU */
 #endif
 __device__ __forceinline__ G128 wave_xor_fold(G128 z) {
 #pragma unroll
@@ -104,7 +104,7 @@ __device__ __forceinline__ G128 wave_xor_fold(G128 z) {
     return z;
 }
 template <int NR, int MODE>
-__global__ __launch_bounds__(AESGCM_WG, AESGCM_WAVES_PER_SIMD) void k_main(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const MainParams p) {
+__global__ __launch_bounds__(AESGCM_MAIN_WG, AESGCM_WAVES_PER_SIMD) void k_main(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const MainParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr bool GH = (MODE == MODE_ENC || MODE == MODE_DEC);
     const u32 tid = threadIdx.x, lane = tid & 63u;
@@ -241,10 +241,10 @@ __device__ __forceinline__ G128 batch_seq_block(bool aligned, u32 aad_len, u32 p
 }
 
 template <int NR, int DEC>
-__global__ __launch_bounds__(AESGCM_WG, AESGCM_WAVES_PER_SIMD) void k_batch(const DevTables *__restrict__ tb, const BatchParams p) {
+__global__ __launch_bounds__(AESGCM_WG, 2 * AESGCM_WG / 256) void k_batch(const DevTables *__restrict__ tb, const BatchParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    main_fill_lds(smem, nullptr, tb, tid, false);
+    main_fill_lds(smem, nullptr, tb, tid, false, AESGCM_WG);
     if (tid < 16) *reinterpret_cast<u32 *>(smem + BATCH_LDS_RTAB_OFF + 4 * tid) = shoup_rem_calc(tid);
     __syncthreads();
     const u32 lb = (lane & 31u) << 2;
@@ -439,9 +439,9 @@ static const u64 MAX_SEQ_BLOCKS = ((u64)1) << 36;
 template <int MODE>
 static hipError_t launch_main_nr(int nr, dim3 grid, hipStream_t st, const KeyMaterial *km, const DevTables *tb, const MainParams &p) {
     switch (nr) {
-    case 10: hipLaunchKernelGGL((k_main<10, MODE>), grid, dim3(AESGCM_WG), AESGCM_LDS_BYTES, st, km, tb, p); break;
-    case 12: hipLaunchKernelGGL((k_main<12, MODE>), grid, dim3(AESGCM_WG), AESGCM_LDS_BYTES, st, km, tb, p); break;
-    default: hipLaunchKernelGGL((k_main<14, MODE>), grid, dim3(AESGCM_WG), AESGCM_LDS_BYTES, st, km, tb, p); break;
+    case 10: hipLaunchKernelGGL((k_main<10, MODE>), grid, dim3(AESGCM_MAIN_WG), AESGCM_LDS_BYTES, st, km, tb, p); break;
+    case 12: hipLaunchKernelGGL((k_main<12, MODE>), grid, dim3(AESGCM_MAIN_WG), AESGCM_LDS_BYTES, st, km, tb, p); break;
+    default: hipLaunchKernelGGL((k_main<14, MODE>), grid, dim3(AESGCM_MAIN_WG), AESGCM_LDS_BYTES, st, km, tb, p); break;
     }
     return hipGetLastError();
 }
@@ -502,9 +502,9 @@ static int enqueue_main(aesgcm_ctx *c, int mode, const uint8_t iv[12], const voi
     p.parts = c->parts;
     p.counter = c->d_counter;
     p.counter_base = c->counter_base;
-    u32 wgs = (C + AESGCM_WG / 64 - 1) / (AESGCM_WG / 64);          // one wave per chunk is enough for small inputs
+    u32 wgs = (C + AESGCM_MAIN_WG / 64 - 1) / (AESGCM_MAIN_WG / 64);          // one wave per chunk is enough for small inputs
     if (wgs > (u32)c->G) wgs = (u32)c->G;
-    c->counter_base += C + wgs * (AESGCM_WG / 64);                 // every wave makes exactly one failing fetch
+    c->counter_base += C + wgs * (AESGCM_MAIN_WG / 64);            // every wave makes exactly one failing fetch
     p.trace = nullptr;
     if (c->timing) {
         p.trace = c->d_trace;
@@ -700,7 +700,7 @@ int aesgcm_ctx_device(const aesgcm_ctx *c) { return c ? c->device : AESGCM_EARG;
 int aesgcm_ctx_geometry(const aesgcm_ctx *c, int *n_wg, int *wg_lanes, int *lds_bytes) {
     if (!c) return AESGCM_EARG;
     if (n_wg) *n_wg = c->G;
-    if (wg_lanes) *wg_lanes = AESGCM_WG;
+    if (wg_lanes) *wg_lanes = AESGCM_MAIN_WG;
     if (lds_bytes) *lds_bytes = AESGCM_LDS_BYTES;
     return AESGCM_OK;
 }

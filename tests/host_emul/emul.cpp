@@ -48,7 +48,7 @@ template <int NR, int MODE>
 static void emu_main_nr(const KeyMaterial *km, const MainParams &p) {
     static unsigned char smem[AESGCM_LDS_BYTES] __attribute__((aligned(16)));
     constexpr bool GH = (MODE == MODE_ENC || MODE == MODE_DEC);
-    for (u32 tid = 0; tid < AESGCM_WG; tid++) main_fill_lds(smem, km, &g_tb, tid, GH);   // image is workgroup independent
+    for (u32 tid = 0; tid < AESGCM_MAIN_WG; tid++) main_fill_lds(smem, km, &g_tb, tid, GH);   // image is workgroup independent
     // the dispenser hands chunk c to whichever wave asks next; results do not depend on who that is, so the
     // harness walks the chunks in a scrambled order to make any accidental order dependence visible
     for (u32 k = 0; k < p.C; k++) {
@@ -141,7 +141,7 @@ static void test_units() {
 // batch-path pieces: Shoup 4-bit multiply against the bit-serial multiply, in-kernel key schedule against the oracle
 static void test_batch_pieces() {
     static unsigned char smem[BATCH_LDS_BYTES] __attribute__((aligned(16)));
-    for (u32 tid = 0; tid < AESGCM_WG; tid++) main_fill_lds(smem, nullptr, &g_tb, tid, false);
+    for (u32 tid = 0; tid < AESGCM_WG; tid++) main_fill_lds(smem, nullptr, &g_tb, tid, false, AESGCM_WG);
     for (u32 v = 0; v < 16; v++) *reinterpret_cast<u32 *>(smem + BATCH_LDS_RTAB_OFF + 4 * v) = shoup_rem_calc(v);
     for (int it = 0; it < 50; it++) {
         auto cb = rnd(16, 7000 + it), yb = rnd(16, 8000 + it);
