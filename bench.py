@@ -208,7 +208,10 @@ def main():
 
     stream = None
     if dist is not None:
-        stream = torch.cuda.current_stream().cuda_stream
+        # one explicit (non-default) stream for the kernels, the partial tensors and the collective's stream sync
+        tstream = torch.cuda.Stream()
+        torch.cuda.set_stream(tstream)
+        stream = tstream.cuda_stream
         local_parts = torch.zeros((len(msgs), 16), dtype=torch.uint8, device="cuda")
         gathered = torch.zeros((world, len(msgs), 16), dtype=torch.uint8, device="cuda")
 
