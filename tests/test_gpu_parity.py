@@ -244,3 +244,32 @@ def test_sharded_message_equals_single_launch(hip, orc):
             first = end
         assert c.shard_finalize_dev(iv, parts.ptr, ranks, al, n) == want_tag
         assert bytes(dout.download(n)) == want_ct
+
+
+def test_distinct_contexts_from_distinct_threads(hip, orc):
+    """The ABI's threading contract: a context is not thread-safe, distinct contexts may run concurrently."""
+    import threading
+    errs = []
+
+    def worker(t):
+        try:
+            key, iv = splitmix_bytes(900 + t, (16, 24, 32)[t % 3]), splitmix_bytes(950 + t, 12)
+            c = hip.Context(key)
+            f = orc.Fast(key)
+            for it in range(6):
+                n = (1 << 20) * (1 + (t + it) % 3) + 17 * t + it
+                aad, pt = splitmix_bytes(1000 + 10 * t + it, 13 * it), splitmix_bytes(2000 + 10 * t + it, n)
+                want = f.encrypt(iv, aad, pt)
+                if c.encrypt(iv, aad, pt) != want:
+                    errs.append((t, it, "enc"))
+                if c.decrypt(iv, aad, want[0], tag=want[1])[0] != pt:
+                    errs.append((t, it, "dec"))
+        except Exception as e:          # noqa: BLE001
+            errs.append((t, repr(e)))
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errs, errs
