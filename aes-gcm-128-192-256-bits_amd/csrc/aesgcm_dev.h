@@ -444,7 +444,14 @@ HD uint4 main_block(const u32 *__restrict__ rk, const unsigned char *smem, const
     return make_uint4(x.x ^ s0, x.y ^ s1, x.z ^ s2, x.w ^ s3);                  // gcm_gctr.vhd:150
 }
 
-// make a wave-uniform 64-bit value visibly scalar to the compiler (host: identity)
+// make wave-uniform values visibly scalar to the compiler (host: identity)
+HD u32 uniform32(u32 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (u32)__builtin_amdgcn_readfirstlane(x);
+#else
+    return x;
+#endif
+}
 HD u64 uniform64(u64 x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return ((u64)(u32)__builtin_amdgcn_readfirstlane((u32)(x >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((u32)x);
@@ -744,6 +751,99 @@ HD void batch_key_expand(const unsigned char *key, u32 *rk, const unsigned char 
         rk[w] = rk[w - NK] ^ t;
     }
 }
+
+// ================================================================================================
+// Packets under ONE key (the RTL keeps H while no new key is loaded, src/gcm_gctr.vhd:142-144): per-packet IV,
+// AAD and length; key schedule, H and the K = H^64 table come from the context.  One wave per packet.  The
+// packet's GHASH sequence is AAD blocks, data blocks AND the length block, right-aligned into rows; lane L ends
+// with H^(64-L), so the wave fold is already (P*H ^ L)*H.  The lane that holds the length block (always lane
+// 63 of the last row) has no data block to encrypt and computes E_K(IV || 1) in the same instruction stream.
+// ================================================================================================
+struct PktParams {
+    const unsigned char *ivs;    // n_pkts * 12 bytes
+    const unsigned char *aad;    // AAD bytes or NULL
+    const unsigned char *in;
+    unsigned char *out;
+    unsigned char *tags;         // n_pkts * 16 (computed tags)
+    const unsigned char *expect; // dec: expected tags or NULL
+    int *auth;                   // dec: per-packet 1/0 or NULL
+    const u64 *data_off;         // n_pkts + 1 offsets, or NULL = fixed pkt_len records
+    const u64 *aad_off;          // n_pkts + 1 offsets, or NULL = fixed aad_len records
+    u32 *counter; u32 counter_base;
+    u32 n_pkts, pkt_len, aad_len;
+    u32 aligned;                 // in/out base pointers 16-byte aligned
+};
+
+// per-packet geometry and constants: everything here is wave-uniform
+struct PktInfo { u64 doff, aoff; u32 pkt_len, aad_len, iv0, iv1, iv2, aligned; };
+HD PktInfo pkt_info(const PktParams &p, u32 pkt) {
+    PktInfo q;
+    q.pkt_len = p.pkt_len; q.aad_len = p.aad_len;
+    q.doff = (u64)pkt * p.pkt_len; q.aoff = (u64)pkt * p.aad_len;
+    if (p.data_off) { q.doff = p.data_off[pkt]; q.pkt_len = (u32)(p.data_off[pkt + 1] - q.doff); }
+    if (p.aad_off) { q.aoff = p.aad_off[pkt]; q.aad_len = (u32)(p.aad_off[pkt + 1] - q.aoff); }
+    q.aligned = (p.aligned && ((q.doff & 15) == 0)) ? 1u : 0u;
+    const unsigned char *ivp = p.ivs + (size_t)pkt * 12;
+    q.iv0 = load_le32(ivp); q.iv1 = load_le32(ivp + 4); q.iv2 = load_le32(ivp + 8);
+    // say "uniform" out loud: the values came through vector loads
+    q.pkt_len = uniform32(q.pkt_len); q.aad_len = uniform32(q.aad_len); q.aligned = uniform32(q.aligned);
+    q.iv0 = uniform32(q.iv0); q.iv1 = uniform32(q.iv1); q.iv2 = uniform32(q.iv2);
+    q.doff = uniform64(q.doff); q.aoff = uniform64(q.aoff);
+    return q;
+}
+
+// lane body for one packet; returns the lane's accumulator, *ej0 is meaningful on lane 63 only
+template <int NR, int DEC>
+HD uint4 pkt_lane(const KeyMaterial *__restrict__ km, const PktParams &p, const unsigned char *smem, u32 pkt, u32 lane, uint4 *ej0) {
+    const u32 *__restrict__ rk = km->rk;
+    const u32 lb = (lane & 31u) << 2;
+    const PktInfo q = pkt_info(p, pkt);
+    const u32 pkt_len = q.pkt_len, aad_len = q.aad_len;
+    const u64 doff = q.doff, aoff = q.aoff;
+    const bool aligned = q.aligned != 0;
+    CtrConsts cc = ctr_round1_consts(q.iv0, q.iv1, q.iv2, rk, smem, lb);      // key/IV only: wave-uniform -> scalar registers
+    cc.c0 = uniform32(cc.c0); cc.c1 = uniform32(cc.c1); cc.c2 = uniform32(cc.c2); cc.c3 = uniform32(cc.c3);
+    const u32 n_aad = (aad_len + 15) / 16, n_ct = (pkt_len + 15) / 16, n_seq = n_aad + n_ct + 1;
+    const u32 rows = (n_seq + 63) / 64, pad = 64 * rows - n_seq;
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    *ej0 = make_uint4(0, 0, 0, 0);
+    for (u32 r = 0; r < rows; r++) {
+        if (r) acc = ghash_mul_const_lds(acc, smem);
+        const u32 v = r * 64 + lane;
+        if (v < pad) continue;
+        const u32 j = v - pad;
+        uint4 gin;
+        if (j < n_aad) {
+            const u32 off = 16 * j, rem = aad_len - off;
+            gin = load_block_bytes(p.aad + aoff + off, rem < 16 ? rem : 16);
+        } else {
+            // data block i, or (last slot of the sequence) the length block, whose lane encrypts IV || 1 instead:
+            // one AES instance serves both roles
+            const bool is_len = (j == n_aad + n_ct);
+            const u32 i = j - n_aad, off = 16 * i, rem = is_len ? 0u : pkt_len - off;
+            const bool full = aligned && rem >= 16;
+            uint4 x = make_uint4(0, 0, 0, 0);
+            if (full) x = *reinterpret_cast<const uint4 *>(p.in + doff + off);
+            else if (rem) x = load_block_bytes(p.in + doff + off, rem < 16 ? rem : 16);
+            u32 s0, s1, s2, s3;
+            ctr_rounds_lds<NR>(bswap32(is_len ? 1u : 2u + i), cc, s0, s1, s2, s3, rk, smem, lb);
+            if (is_len) {
+                *ej0 = make_uint4(s0, s1, s2, s3);
+                // [8*len(A)]_64 || [8*len(C)]_64 (gcm_ghash.vhd:257) in memory order
+                gin = make_uint4(0u, bswap32(aad_len * 8u), 0u, bswap32(pkt_len * 8u));
+            } else {
+                uint4 y = make_uint4(x.x ^ s0, x.y ^ s1, x.z ^ s2, x.w ^ s3);
+                if (full) *reinterpret_cast<uint4 *>(p.out + doff + off) = y;
+                else { y = mask_block(y, rem < 16 ? rem : 16); store_block_bytes(p.out + doff + off, y, rem < 16 ? rem : 16); }
+                gin = DEC ? x : y;
+            }
+        }
+        acc = xor4(acc, gin);
+    }
+    return acc;
+}
+// lane L carries H^(64-L): the fold of these is (P*H ^ L)*H
+HD G128 pkt_lane_tail(const KeyMaterial *__restrict__ km, uint4 acc, u32 lane) { return gf_mul(mo_to_be(acc), mo_to_be(km->pw[0][64 - lane])); }
 
 // SplitMix64 at word position w; shared with oracle/aesgcm_oracle.c by definition.
 HD u64 splitmix64_at(u64 seed, u64 w) {

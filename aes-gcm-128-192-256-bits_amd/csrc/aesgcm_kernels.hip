@@ -356,6 +356,39 @@ __global__ __launch_bounds__(AESGCM_WG, 2 * AESGCM_WG / 256) void k_batch(const 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_pkt: many packets under the context's key, one wave per packet (lane body: pkt_lane()).
+// ------------------------------------------------------------------------------------------------
+template <int NR, int DEC>
+__global__ __launch_bounds__(AESGCM_MAIN_WG, AESGCM_WAVES_PER_SIMD) void k_pkt(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const PktParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const u32 tid = threadIdx.x, lane = tid & 63u;
+    main_fill_lds(smem, km, tb, tid, true);
+    __syncthreads();
+    // packets are dealt round-robin to the waves of the grid (they are small and many; a static deal keeps the
+    // loop wave-uniform by construction)
+    const u32 wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (AESGCM_MAIN_WG / 64) + (tid >> 6));
+    const u32 n_waves = gridDim.x * (AESGCM_MAIN_WG / 64);
+    for (u32 pkt = wave0; pkt < p.n_pkts; pkt += n_waves) {
+        uint4 ej0;
+        const uint4 acc = pkt_lane<NR, DEC>(km, p, smem, pkt, lane, &ej0);
+        const G128 z = wave_xor_fold(pkt_lane_tail(km, acc, lane));
+        if (lane == 63) {
+            const uint4 t = be_to_mo(z);
+            const uint4 tag = make_uint4(t.x ^ ej0.x, t.y ^ ej0.y, t.z ^ ej0.z, t.w ^ ej0.w);      // gcm_ghash.vhd:293
+            store_block_bytes(p.tags + (size_t)pkt * 16, tag, 16);
+            if (DEC && p.auth) {
+                int ok = 1;
+                if (p.expect) {
+                    const uint4 e = load_block_bytes(p.expect + (size_t)pkt * 16, 16);
+                    ok = ((e.x ^ tag.x) | (e.y ^ tag.y) | (e.z ^ tag.z) | (e.w ^ tag.w)) == 0;
+                }
+                p.auth[pkt] = ok;
+            }
+        }
+    }
+}
+
 // ================================================================================================
 // host side
 // ================================================================================================
@@ -465,7 +498,8 @@ static int set_lds_attrs(int device, DeviceState *ds) {
     SETATTR(10, MODE_KS);  SETATTR(12, MODE_KS);  SETATTR(14, MODE_KS);
     SETATTR(10, MODE_ECB); SETATTR(12, MODE_ECB); SETATTR(14, MODE_ECB);
 #undef SETATTR
-#define SETATTRB(NR, D) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch<NR, D>), hipFuncAttributeMaxDynamicSharedMemorySize, BATCH_LDS_BYTES))
+#define SETATTRB(NR, D) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch<NR, D>), hipFuncAttributeMaxDynamicSharedMemorySize, BATCH_LDS_BYTES)); \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pkt<NR, D>), hipFuncAttributeMaxDynamicSharedMemorySize, AESGCM_LDS_BYTES))
     SETATTRB(10, 0); SETATTRB(12, 0); SETATTRB(14, 0); SETATTRB(10, 1); SETATTRB(12, 1); SETATTRB(14, 1);
 #undef SETATTRB
     ds->attrs = true;
@@ -957,6 +991,36 @@ int aesgcm_stream_final(aesgcm_ctx *c, uint8_t tag[16]) {
     HIPCHK(hipMemcpyAsync(tag, c->d_tag, 16, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->s_active = false;
+    return AESGCM_OK;
+}
+
+// ---------------------------------------------------------------- packets under the context's key
+int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const void *d_ivs,
+                             const void *d_aad, size_t aad_len, const uint64_t *d_aad_off,
+                             const void *d_in, size_t pkt_len, const uint64_t *d_data_off, void *d_out,
+                             void *d_tags, const void *d_expect_tags, int *d_auth, void *stream) {
+    if (!c) return AESGCM_EARG;
+    if (!n_pkts) return AESGCM_OK;
+    if (!d_ivs || !d_tags || ((aad_len || d_aad_off) && !d_aad) || ((pkt_len || d_data_off) && (!d_in || !d_out))) return AESGCM_EARG;
+    if (n_pkts >= (((size_t)1) << 31) || pkt_len >= (((size_t)1) << 28) || aad_len >= (((size_t)1) << 28)) return AESGCM_ETOOLONG;
+    HIPCHK(hipSetDevice(c->device));
+    PktParams p;
+    memset(&p, 0, sizeof p);
+    p.ivs = (const unsigned char *)d_ivs; p.aad = (const unsigned char *)d_aad; p.in = (const unsigned char *)d_in;
+    p.out = (unsigned char *)d_out; p.tags = (unsigned char *)d_tags; p.expect = (const unsigned char *)d_expect_tags; p.auth = d_auth;
+    p.data_off = (const u64 *)d_data_off; p.aad_off = (const u64 *)d_aad_off;
+    p.n_pkts = (u32)n_pkts; p.pkt_len = (u32)pkt_len; p.aad_len = (u32)aad_len;
+    p.aligned = (((uintptr_t)d_in | (uintptr_t)d_out) & 15) == 0 && (d_data_off || pkt_len % 16 == 0);
+    const u32 waves_per_wg = AESGCM_MAIN_WG / 64;
+    u32 wgs = (u32)((n_pkts + waves_per_wg - 1) / waves_per_wg);
+    if (wgs > (u32)c->G) wgs = (u32)c->G;
+    hipStream_t st = pick_stream(c, stream);
+#define LP(NR, D) hipLaunchKernelGGL((k_pkt<NR, D>), dim3(wgs), dim3(AESGCM_MAIN_WG), AESGCM_LDS_BYTES, st, c->km, c->tables, p)
+    if (decrypt) { if (c->nr == 10) LP(10, 1); else if (c->nr == 12) LP(12, 1); else LP(14, 1); }
+    else         { if (c->nr == 10) LP(10, 0); else if (c->nr == 12) LP(12, 0); else LP(14, 0); }
+#undef LP
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return hip_fail(le, "k_pkt launch");
     return AESGCM_OK;
 }
 

@@ -20,7 +20,7 @@ SYMBOLS = [
     "aesgcm_encrypt_pipelined", "aesgcm_decrypt_pipelined", "aesgcm_host_alloc", "aesgcm_host_free",
     "aesgcm_encrypt", "aesgcm_decrypt", "aesgcm_encrypt_dev", "aesgcm_decrypt_dev", "aesgcm_last_tag",
     "aesgcm_keystream", "aesgcm_keystream_dev",
-    "aesgcm_shard_crypt_dev", "aesgcm_shard_finalize_dev", "aesgcm_batch_crypt_dev", "aesgcm_batch_crypt_var_dev",
+    "aesgcm_shard_crypt_dev", "aesgcm_shard_finalize_dev", "aesgcm_batch_crypt_dev", "aesgcm_batch_crypt_var_dev", "aesgcm_packets_crypt_dev",
     "aesgcm_stream_begin", "aesgcm_stream_aad", "aesgcm_stream_update", "aesgcm_stream_final",
     "aesgcm_dev_alloc", "aesgcm_dev_free", "aesgcm_dev_upload", "aesgcm_dev_download", "aesgcm_dev_sync",
     "aesgcm_fill_splitmix64_dev",
@@ -83,6 +83,7 @@ def load():
     L.aesgcm_shard_finalize_dev.argtypes = [vp, vp, vp, sz, sz, u64, vp, vp]
     L.aesgcm_batch_crypt_dev.argtypes = [cint, cint, sz, sz, vp, vp, vp, sz, vp, sz, vp, vp, vp, vp, vp]
     L.aesgcm_batch_crypt_var_dev.argtypes = [cint, cint, sz, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.aesgcm_packets_crypt_dev.argtypes = [vp, cint, sz, vp, vp, sz, vp, vp, sz, vp, vp, vp, vp, vp, vp]
     L.aesgcm_stream_begin.argtypes = [vp, vp, cint]
     L.aesgcm_stream_aad.argtypes = [vp, vp, sz]
     L.aesgcm_stream_update.argtypes = [vp, vp, sz, vp]
@@ -383,6 +384,12 @@ class Context:
 
     def keystream_dev(self, iv, first_block, nblocks, d_out, stream=None):
         _chk(load().aesgcm_keystream_dev(self._c, _fixed(iv, 12, "iv"), first_block, nblocks, d_out, stream))
+
+    # many packets under this context's key
+    def packets_crypt_dev(self, decrypt, n_pkts, d_ivs, d_in, d_out, d_tags, pkt_len=0, d_data_off=None,
+                          d_aad=None, aad_len=0, d_aad_off=None, d_expect_tags=None, d_auth=None, stream=None):
+        _chk(load().aesgcm_packets_crypt_dev(self._c, int(bool(decrypt)), n_pkts, d_ivs, d_aad, aad_len, d_aad_off,
+                                             d_in, pkt_len, d_data_off, d_out, d_tags, d_expect_tags, d_auth, stream))
 
     # shards
     def shard_crypt_dev(self, decrypt, iv, d_in, nbytes, d_out, first_block, total_len, d_partial,

@@ -150,6 +150,18 @@ AESGCM_API int aesgcm_shard_crypt_dev(aesgcm_ctx *ctx, int decrypt, const uint8_
 AESGCM_API int aesgcm_shard_finalize_dev(aesgcm_ctx *ctx, const uint8_t iv[12], const void *d_partials, size_t n_partials,
                               size_t aad_len, uint64_t total_len, uint8_t tag[16], void *stream);
 
+/* ---------------------------------------------------------------- many packets under the context's key
+ * The RTL keeps H across packets while no new key is loaded (src/gcm_gctr.vhd:142-144) and takes a new IV per
+ * packet (src/aes_icb.vhd:60-70 "load IV"): this is that mode.  Per packet: ivs[p] (12 bytes), optional AAD
+ * and data either as fixed-size records (aad_len / pkt_len, offset arrays NULL) or delimited by uint64 offset
+ * arrays with n_pkts + 1 entries (then aad_len / pkt_len are ignored); tags[p] receives the computed tag; for
+ * decrypt d_auth[p] (optional) = 1 if it equals d_expect_tags[p].  One wave per packet, so it is meant for
+ * packets up to ~1 MiB; larger messages belong to aesgcm_encrypt_dev.  Asynchronous on `stream`. */
+AESGCM_API int aesgcm_packets_crypt_dev(aesgcm_ctx *ctx, int decrypt, size_t n_pkts, const void *d_ivs,
+                             const void *d_aad, size_t aad_len, const uint64_t *d_aad_off,
+                             const void *d_in, size_t pkt_len, const uint64_t *d_data_off, void *d_out,
+                             void *d_tags, const void *d_expect_tags, int *d_auth, void *stream);
+
 /* ---------------------------------------------------------------- batch: independent packets, per-packet key + IV
  * (BASELINE config 5; the RTL equivalent is reloading key and IV between packets, tb/gcm_gctr.py:144-175,
  * with aes_kexp run per packet, config/config_aes_kexp.py:113-159.)  All arrays are contiguous device memory:

@@ -168,6 +168,51 @@ static void test_batch_pieces() {
     }
 }
 
+// packets under one key: per-packet IV/AAD/length, tag = fold of lane tails xor E_K(J0) from lane 63
+static void test_packets(int key_len, u64 seed) {
+    auto key = rnd(key_len, seed);
+    Emu E(key.data(), key_len, 0);
+    static unsigned char smem[AESGCM_LDS_BYTES] __attribute__((aligned(16)));
+    for (u32 tid = 0; tid < AESGCM_MAIN_WG; tid++) main_fill_lds(smem, &E.km, &g_tb, tid, true);
+    const u32 lens[] = {0, 1, 15, 16, 17, 48, 1000, 1008, 1024, 4096, 4100, 70000};
+    const u32 aads[] = {0, 20, 28, 16, 0, 33, 68, 0, 5, 0, 12, 64};
+    const int n = 12;
+    std::vector<u64> doff(n + 1, 0), aoff(n + 1, 0);
+    for (int i = 0; i < n; i++) { doff[i + 1] = doff[i] + lens[i]; aoff[i + 1] = aoff[i] + aads[i]; }
+    ABuf in(doff[n]), out(doff[n]);
+    auto aad = rnd(aoff[n], seed + 1), ivs = rnd(12 * n, seed + 2);
+    orc_fill_splitmix64(in.p, doff[n], seed + 3, 0);
+    std::vector<uint8_t> tags(16 * n);
+    PktParams p; memset(&p, 0, sizeof p);
+    p.ivs = ivs.data(); p.aad = aad.data(); p.in = in.p; p.out = out.p; p.tags = tags.data();
+    p.data_off = doff.data(); p.aad_off = aoff.data(); p.n_pkts = n; p.aligned = 1;
+    for (int dec = 0; dec < 2; dec++) {
+        if (dec) { p.in = out.p; p.out = out.p; }           // decrypt in place
+        for (u32 pkt = 0; pkt < (u32)n; pkt++) {
+            G128 fold = {{0, 0, 0, 0}}; uint4 ej0 = make_uint4(0, 0, 0, 0);
+            for (u32 lane = 0; lane < 64; lane++) {
+                uint4 e;
+                uint4 acc = (E.km.nr == 10) ? (dec ? pkt_lane<10, 1>(&E.km, p, smem, pkt, lane, &e) : pkt_lane<10, 0>(&E.km, p, smem, pkt, lane, &e))
+                          : (E.km.nr == 12) ? (dec ? pkt_lane<12, 1>(&E.km, p, smem, pkt, lane, &e) : pkt_lane<12, 0>(&E.km, p, smem, pkt, lane, &e))
+                                            : (dec ? pkt_lane<14, 1>(&E.km, p, smem, pkt, lane, &e) : pkt_lane<14, 0>(&E.km, p, smem, pkt, lane, &e));
+                xor_g(fold, pkt_lane_tail(&E.km, acc, lane));
+                if (lane == 63) ej0 = e;
+            }
+            uint4 t = be_to_mo(fold); t = xor4(t, ej0);
+            std::vector<uint8_t> ref(lens[pkt] + 16); uint8_t rtag[16];
+            if (!dec) {
+                orc_gcm_crypt(0, key.data(), key_len, ivs.data() + 12 * pkt, aad.data() + aoff[pkt], aads[pkt], in.p + doff[pkt], lens[pkt], ref.data(), rtag);
+                CHECK(memcmp(ref.data(), out.p + doff[pkt], lens[pkt]) == 0, "pkt ct %u", pkt);
+                memcpy(tags.data() + 16 * pkt, &t, 16);
+            } else {
+                CHECK(memcmp(in.p + doff[pkt], out.p + doff[pkt], lens[pkt]) == 0, "pkt dec %u", pkt);
+                memcpy(rtag, tags.data() + 16 * pkt, 16);
+            }
+            CHECK(memcmp(&t, rtag, 16) == 0, "pkt tag %u len %u aad %u dec %d", pkt, lens[pkt], aads[pkt], dec);
+        }
+    }
+}
+
 static void test_key(int key_len, u32 G /* rows per chunk override, 0 = production rule */, u64 seed, const std::vector<std::pair<u64, u64>> &sizes) {
     auto key = rnd(key_len, seed);
     Emu E(key.data(), key_len, G);
@@ -316,6 +361,7 @@ int main(int argc, char **argv) {
     test_stream(24, 3, 16 * 40 + 3, 33, 16 * 8, 92);
     test_keystream_and_ghash(55);
     test_batch_pieces();
+    test_packets(16, 61); test_packets(24, 62); test_packets(32, 63);
     if (level > 1) {
         test_key(32, 1, 7, {{123, 16 * 64 * 1100 + 11}});     // 1100 chunks: two stage-1 workgroups
         test_key(16, 0, 8, {{0, 16 * W * 600}});              // production rule, > GMAX chunks of Tw = 16

@@ -131,3 +131,52 @@ def test_variable_length_packets_macsec_shaped(hip, orc):
     hip.dev_sync()
     assert bytes(d_out.download(len(data))) == data
     assert set(struct.unpack("<%di" % n, bytes(d_auth.download()))) == {1}
+
+
+def test_packets_under_one_key(hip, orc):
+    """aesgcm_packets_crypt_dev: one key (context), per-packet IV, AAD and length; fixed-size records and offset
+    arrays; decrypt in place with per-packet authentication."""
+    import struct
+    rng = random.Random(4242)
+    for klen in (16, 24, 32):
+        key = splitmix_bytes(300 + klen, klen)
+        ctx = hip.Context(key)
+        f = orc.Fast(key)
+        # fixed-size records (cfg5-shaped, but one key)
+        n, pkt, al = 300, 4096, 20
+        ivs, aad, pt = splitmix_bytes(31, 12 * n), splitmix_bytes(32, al * n), splitmix_bytes(33, pkt * n)
+        def up(b):
+            d = hip.DeviceBuffer(max(len(b), 16)); d.upload(b); return d
+        d_ivs, d_aad, d_in = up(ivs), up(aad), up(pt)
+        d_out, d_tags = hip.DeviceBuffer(pkt * n), hip.DeviceBuffer(16 * n)
+        ctx.packets_crypt_dev(False, n, d_ivs.ptr, d_in.ptr, d_out.ptr, d_tags.ptr, pkt_len=pkt, d_aad=d_aad.ptr, aad_len=al)
+        hip.dev_sync()
+        ct, tags = bytes(d_out.download()), bytes(d_tags.download())
+        for p in range(n):
+            want = f.encrypt(ivs[12 * p:12 * p + 12], aad[al * p:al * (p + 1)], pt[pkt * p:pkt * (p + 1)])
+            assert (ct[pkt * p:pkt * (p + 1)], tags[16 * p:16 * p + 16]) == want, (klen, p)
+        # variable lengths through offset arrays, incl. empty packets and empty AAD
+        lens = [rng.choice((0, 1, 15, 16, 17, 46, 64, 1000, 1024, 1500, 4096, 9000, 70000)) for _ in range(120)]
+        aads = [rng.choice((0, 0, 8, 20, 28, 40, 100)) for _ in range(120)]
+        m = len(lens)
+        doff, aoff = [0], [0]
+        for a, b in zip(lens, aads):
+            doff.append(doff[-1] + a); aoff.append(aoff[-1] + b)
+        ivs, aad, pt = splitmix_bytes(41, 12 * m), splitmix_bytes(42, aoff[-1]), splitmix_bytes(43, doff[-1])
+        d_ivs, d_aad, d_buf = up(ivs), up(aad), up(pt)
+        d_doff, d_aoff = up(struct.pack("<%dQ" % (m + 1), *doff)), up(struct.pack("<%dQ" % (m + 1), *aoff))
+        d_tags, d_auth = hip.DeviceBuffer(16 * m), hip.DeviceBuffer(4 * m)
+        ctx.packets_crypt_dev(False, m, d_ivs.ptr, d_buf.ptr, d_buf.ptr, d_tags.ptr, d_data_off=d_doff.ptr, d_aad=d_aad.ptr, d_aad_off=d_aoff.ptr)
+        hip.dev_sync()
+        ct, tags = bytes(d_buf.download(doff[-1])), bytes(d_tags.download())
+        for p in range(m):
+            want = f.encrypt(ivs[12 * p:12 * p + 12], aad[aoff[p]:aoff[p + 1]], pt[doff[p]:doff[p + 1]])
+            assert (ct[doff[p]:doff[p + 1]], tags[16 * p:16 * p + 16]) == want, (klen, p, lens[p], aads[p])
+        bad = bytearray(tags); bad[16 * 5 + 3] ^= 4
+        d_exp, d_t2 = up(bytes(bad)), hip.DeviceBuffer(16 * m)
+        ctx.packets_crypt_dev(True, m, d_ivs.ptr, d_buf.ptr, d_buf.ptr, d_t2.ptr, d_data_off=d_doff.ptr, d_aad=d_aad.ptr, d_aad_off=d_aoff.ptr,
+                              d_expect_tags=d_exp.ptr, d_auth=d_auth.ptr)
+        hip.dev_sync()
+        assert bytes(d_buf.download(doff[-1])) == pt
+        auth = struct.unpack("<%di" % m, bytes(d_auth.download()))
+        assert [i for i, a in enumerate(auth) if not a] == [5]
