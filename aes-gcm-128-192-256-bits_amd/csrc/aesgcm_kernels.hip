@@ -122,7 +122,8 @@ __global__ __launch_bounds__(AESGCM_MAIN_WG, AESGCM_WAVES_PER_SIMD) void k_main(
     cc.c0 = __builtin_amdgcn_readfirstlane(cc.c0); cc.c1 = __builtin_amdgcn_readfirstlane(cc.c1);
     cc.c2 = __builtin_amdgcn_readfirstlane(cc.c2); cc.c3 = __builtin_amdgcn_readfirstlane(cc.c3);
     u32 done = 0;
-    for (;;) {
+    // bounded on purpose: no wave can own more than C chunks, so a dispenser problem can never turn into a hang
+    for (u32 guard = 0; guard <= p.C; ++guard) {
         u32 c = 0;
         if (lane == 0) c = atomicAdd(p.counter, 1u) - p.counter_base;
         c = __builtin_amdgcn_readfirstlane(c);
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(AESGCM_WG, 2 * AESGCM_WG / 256) void k_batch(const 
     const u32 lb = (lane & 31u) << 2;
     const u32 tabH = BATCH_LDS_WAVE_OFF + wave * BATCH_WAVE_LDS, tabC = tabH + 256u;
     constexpr u32 KEYLEN = 4 * (NR - 6);
-    for (;;) {
+    for (u32 guard = 0; guard <= p.n_pkts; ++guard) {          // bounded: a wave can never own more than n_pkts packets
         u32 pkt = 0;
         if (lane == 0) pkt = atomicAdd(p.counter, 1u) - p.counter_base;
         pkt = __builtin_amdgcn_readfirstlane(pkt);
