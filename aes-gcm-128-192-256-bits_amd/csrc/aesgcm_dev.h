@@ -666,6 +666,7 @@ struct BatchParams {
     const unsigned char *expect; // dec: expected tags or NULL
     int *auth;                   // dec: per-packet 1 = tag ok, 0 = mismatch (NULL = skip)
     u32 *counter; u32 counter_base;
+    u32 deal;                    // packets per dispenser fetch
     u32 n_pkts, pkt_len, aad_len;
     u32 aligned;                 // in/out rows are 16-byte aligned for every packet
     // variable-length form (all NULL = fixed pkt_len / aad_len, packets back to back):
@@ -770,6 +771,7 @@ struct PktParams {
     const u64 *data_off;         // n_pkts + 1 offsets, or NULL = fixed pkt_len records
     const u64 *aad_off;          // n_pkts + 1 offsets, or NULL = fixed aad_len records
     u32 *counter; u32 counter_base;
+    u32 deal;                    // packets per dispenser fetch
     u32 n_pkts, pkt_len, aad_len;
     u32 aligned;                 // in/out base pointers 16-byte aligned
 };

@@ -251,11 +251,19 @@ __global__ __launch_bounds__(AESGCM_WG, 2 * AESGCM_WG / 256) void k_batch(const 
     const u32 lb = (lane & 31u) << 2;
     const u32 tabH = BATCH_LDS_WAVE_OFF + wave * BATCH_WAVE_LDS, tabC = tabH + 256u;
     constexpr u32 KEYLEN = 4 * (NR - 6);
-    for (u32 guard = 0; guard <= p.n_pkts; ++guard) {          // bounded: a wave can never own more than n_pkts packets
-        u32 pkt = 0;
-        if (lane == 0) pkt = atomicAdd(p.counter, 1u) - p.counter_base;
-        pkt = __builtin_amdgcn_readfirstlane(pkt);
-        if (pkt >= p.n_pkts) break;
+    // packets are dealt in blocks of p.deal per dispenser fetch (see k_pkt); the loop is bounded on purpose:
+    // a wave can never own more than n_pkts packets
+    const u32 K = p.deal, nb = (p.n_pkts + K - 1) / K;
+    u32 pkt = 0, pkt_end = 0;
+    for (u32 guard = 0; guard <= p.n_pkts; ++guard, ++pkt) {
+        if (pkt == pkt_end) {
+            u32 b = 0;
+            if (lane == 0) b = atomicAdd(p.counter, 1u) - p.counter_base;
+            b = __builtin_amdgcn_readfirstlane(b);
+            if (b >= nb) break;
+            pkt = b * K;
+            pkt_end = pkt + K < p.n_pkts ? pkt + K : p.n_pkts;
+        }
         const unsigned char *key = p.keys + (size_t)pkt * KEYLEN;
         const unsigned char *ivp = p.ivs + (size_t)pkt * 12;
         // packet geometry: fixed-size records, or per-packet extents from the offset arrays (MACsec-shaped traffic)
@@ -366,25 +374,32 @@ __global__ __launch_bounds__(AESGCM_MAIN_WG, AESGCM_WAVES_PER_SIMD) void k_pkt(c
     const u32 tid = threadIdx.x, lane = tid & 63u;
     main_fill_lds(smem, km, tb, tid, true);
     __syncthreads();
-    // packets are dealt round-robin to the waves of the grid (they are small and many; a static deal keeps the
-    // loop wave-uniform by construction)
-    const u32 wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (AESGCM_MAIN_WG / 64) + (tid >> 6));
-    const u32 n_waves = gridDim.x * (AESGCM_MAIN_WG / 64);
-    for (u32 pkt = wave0; pkt < p.n_pkts; pkt += n_waves) {
-        uint4 ej0;
-        const uint4 acc = pkt_lane<NR, DEC>(km, p, smem, pkt, lane, &ej0);
-        const G128 z = wave_xor_fold(pkt_lane_tail(km, acc, lane));
-        if (lane == 63) {
-            const uint4 t = be_to_mo(z);
-            const uint4 tag = make_uint4(t.x ^ ej0.x, t.y ^ ej0.y, t.z ^ ej0.z, t.w ^ ej0.w);      // gcm_ghash.vhd:293
-            store_block_bytes(p.tags + (size_t)pkt * 16, tag, 16);
-            if (DEC && p.auth) {
-                int ok = 1;
-                if (p.expect) {
-                    const uint4 e = load_block_bytes(p.expect + (size_t)pkt * 16, 16);
-                    ok = ((e.x ^ tag.x) | (e.y ^ tag.y) | (e.z ^ tag.z) | (e.w ^ tag.w)) == 0;
+    // packets are dealt to the waves in blocks of p.deal from a dispenser: one atomic per block keeps the single
+    // dispenser address far below its ~87 M fetches/s ceiling (measured), and late waves still level the tail.
+    // The loop is bounded on purpose (a wave can never own more than nb blocks).
+    const u32 K = p.deal, nb = (p.n_pkts + K - 1) / K;
+    for (u32 guard = 0; guard <= nb; ++guard) {
+        u32 b = 0;
+        if (lane == 0) b = atomicAdd(p.counter, 1u) - p.counter_base;
+        b = __builtin_amdgcn_readfirstlane(b);
+        if (b >= nb) break;
+        const u32 p0 = b * K, p1 = p0 + K < p.n_pkts ? p0 + K : p.n_pkts;
+        for (u32 pkt = p0; pkt < p1; ++pkt) {
+            uint4 ej0;
+            const uint4 acc = pkt_lane<NR, DEC>(km, p, smem, pkt, lane, &ej0);
+            const G128 z = wave_xor_fold(pkt_lane_tail(km, acc, lane));
+            if (lane == 63) {
+                const uint4 t = be_to_mo(z);
+                const uint4 tag = make_uint4(t.x ^ ej0.x, t.y ^ ej0.y, t.z ^ ej0.z, t.w ^ ej0.w);      // gcm_ghash.vhd:293
+                store_block_bytes(p.tags + (size_t)pkt * 16, tag, 16);
+                if (DEC && p.auth) {
+                    int ok = 1;
+                    if (p.expect) {
+                        const uint4 e = load_block_bytes(p.expect + (size_t)pkt * 16, 16);
+                        ok = ((e.x ^ tag.x) | (e.y ^ tag.y) | (e.z ^ tag.z) | (e.w ^ tag.w)) == 0;
+                    }
+                    p.auth[pkt] = ok;
                 }
-                p.auth[pkt] = ok;
             }
         }
     }
@@ -1015,13 +1030,20 @@ int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const vo
     const u32 waves_per_wg = AESGCM_MAIN_WG / 64;
     u32 wgs = (u32)((n_pkts + waves_per_wg - 1) / waves_per_wg);
     if (wgs > (u32)c->G) wgs = (u32)c->G;
+    // deal: about 16 dispenser fetches per wave, at most 16 packets per fetch
+    u32 deal = (u32)(n_pkts / ((size_t)wgs * waves_per_wg * 16));
+    deal = deal < 1 ? 1 : deal > 16 ? 16 : deal;
+    if (const char *e = getenv("AESGCM_PKT_DEAL")) { const long v = atol(e); if (v >= 1 && v <= 4096) deal = (u32)v; }
+    p.deal = deal;
+    p.counter = c->d_counter; p.counter_base = c->counter_base;
+    c->counter_base += (u32)((n_pkts + deal - 1) / deal) + wgs * waves_per_wg;     // every wave ends on one failing fetch
     hipStream_t st = pick_stream(c, stream);
 #define LP(NR, D) hipLaunchKernelGGL((k_pkt<NR, D>), dim3(wgs), dim3(AESGCM_MAIN_WG), AESGCM_LDS_BYTES, st, c->km, c->tables, p)
     if (decrypt) { if (c->nr == 10) LP(10, 1); else if (c->nr == 12) LP(12, 1); else LP(14, 1); }
     else         { if (c->nr == 10) LP(10, 0); else if (c->nr == 12) LP(12, 0); else LP(14, 0); }
 #undef LP
     const hipError_t le = hipGetLastError();
-    if (le != hipSuccess) return hip_fail(le, "k_pkt launch");
+    if (le != hipSuccess) { c->counter_base = p.counter_base; return hip_fail(le, "k_pkt launch"); }
     return AESGCM_OK;
 }
 
@@ -1043,6 +1065,12 @@ static int batch_launch(int device, int decrypt, size_t n_pkts, size_t key_len, 
         std::lock_guard<std::mutex> lk(g_mu);
         p.counter = ds->batch_counter + (ds->batch_slot++ % BATCH_DISPENSERS);
         p.counter_base = 0;
+    }
+    {   // deal: about 16 dispenser fetches per wave, at most 16 packets per fetch
+        u32 deal = (u32)(n_pkts / ((size_t)wgs * waves_per_wg * 16));
+        deal = deal < 1 ? 1 : deal > 16 ? 16 : deal;
+        if (const char *e = getenv("AESGCM_PKT_DEAL")) { const long v = atol(e); if (v >= 1 && v <= 4096) deal = (u32)v; }
+        p.deal = deal;
     }
     const int nr = (int)(key_len / 4 + 6);
     hipStream_t st = (hipStream_t)stream;
