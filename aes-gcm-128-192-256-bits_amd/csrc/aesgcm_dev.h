@@ -694,6 +694,30 @@ HD G128 gf_mulx(G128 v) {
     r.w[0] = (v.w[0] >> 1) ^ (lsb & 0xE1000000u);
     return r;
 }
+// squaring is linear over GF(2): spread the coefficients (x^i -> x^2i), then fold the upper 128 coefficients
+// back with x^128 = 1 + x + x^2 + x^7 (R = 0xE1 || 0^120, src/ghash_gfmul.vhd:37-64).  About a hundred VALU
+// operations and no table, against a full table multiply: used for the c_j = c_(j-1)^2 chain of k_batch.
+HD u32 gf_spread16(u32 x) {                                  // bit b -> bit 2b
+    x = (x | (x << 8)) & 0x00FF00FFu; x = (x | (x << 4)) & 0x0F0F0F0Fu;
+    x = (x | (x << 2)) & 0x33333333u; x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
+HD G128 gf_sqr(G128 a) {
+    // coefficient i sits in word i/32 at bit 31 - i%32; the upper half of word k spreads into product word 2k
+    u32 W[8];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { W[2 * k] = gf_spread16(a.w[k] >> 16) << 1; W[2 * k + 1] = gf_spread16(a.w[k] & 0xFFFFu) << 1; }
+    const u32 h0 = W[4], h1 = W[5], h2 = W[6], h3 = W[7];    // coefficients 128..255
+    // Hh * (1 + x + x^2 + x^7): plain right shifts, the bits that fall off the end are folded once more
+    u32 t0 = h0 ^ (h0 >> 1) ^ (h0 >> 2) ^ (h0 >> 7);
+    u32 t1 = h1 ^ ((h1 >> 1) | (h0 << 31)) ^ ((h1 >> 2) | (h0 << 30)) ^ ((h1 >> 7) | (h0 << 25));
+    u32 t2 = h2 ^ ((h2 >> 1) | (h1 << 31)) ^ ((h2 >> 2) | (h1 << 30)) ^ ((h2 >> 7) | (h1 << 25));
+    u32 t3 = h3 ^ ((h3 >> 1) | (h2 << 31)) ^ ((h3 >> 2) | (h2 << 30)) ^ ((h3 >> 7) | (h2 << 25));
+    const u32 v = (h3 << 31) ^ (h3 << 30) ^ (h3 << 25);       // overflow polynomial, degree <= 6
+    t0 ^= v ^ (v >> 1) ^ (v >> 2) ^ (v >> 7);
+    G128 r; r.w[0] = W[0] ^ t0; r.w[1] = W[1] ^ t1; r.w[2] = W[2] ^ t2; r.w[3] = W[3] ^ t3;
+    return r;
+}
 // entry v (0..15) of the Shoup table of constant c: (v as polynomial v3 + v2 x + v1 x^2 + v0 x^3, GCM bit order:
 // the nibble's MSB is x^0) times c
 HD G128 shoup_entry(G128 c, u32 v) {

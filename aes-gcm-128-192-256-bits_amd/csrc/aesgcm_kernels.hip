@@ -330,9 +330,14 @@ __global__ __launch_bounds__(AESGCM_WG, 2 * AESGCM_WG / 256) void k_batch(const 
             }
         }
 
-        // ---- cross-lane tree: c_0 = H^q, c_{j+1} = c_j^2
-        G128 cpow = h;
-        for (u32 k = 1; k < q; k++) cpow = shoup_mul(cpow, smem, tabH);
+        // ---- cross-lane tree: c_0 = H^q, c_{j+1} = c_j^2 (squaring is linear: gf_sqr, no table)
+        G128 cpow = h;                                      // H^q by square-and-multiply (q is wave-uniform)
+        if (q > 1) {
+            for (int b = 30 - (int)__builtin_clz(q); b >= 0; b--) {
+                cpow = gf_sqr(cpow);
+                if ((q >> b) & 1u) cpow = shoup_mul(cpow, smem, tabH);
+            }
+        }
         if (q) {
 #pragma unroll 1
             for (int j = 0; j < 6; j++) {
@@ -342,7 +347,7 @@ __global__ __launch_bounds__(AESGCM_WG, 2 * AESGCM_WG / 256) void k_batch(const 
                 o.w[0] = __shfl_xor(t.w[0], 1 << j); o.w[1] = __shfl_xor(t.w[1], 1 << j);
                 o.w[2] = __shfl_xor(t.w[2], 1 << j); o.w[3] = __shfl_xor(t.w[3], 1 << j);
                 if (lane & (1u << j)) { acc.w[0] ^= o.w[0]; acc.w[1] ^= o.w[1]; acc.w[2] ^= o.w[2]; acc.w[3] ^= o.w[3]; }
-                if (j < 5) cpow = shoup_mul(cpow, smem, tabC);
+                if (j < 5) cpow = gf_sqr(cpow);
             }
         }
         // ---- lane 63 holds P = sum X_i H^(n-1-i); tag = ((P*H) ^ L)*H ^ E_K(J0)

@@ -153,6 +153,8 @@ static void test_batch_pieces() {
         for (u32 v = 0; v < 16; v++) { G128 e = shoup_entry(c, v); *reinterpret_cast<uint4 *>(smem + tab + 16 * v) = make_uint4(e.w[0], e.w[1], e.w[2], e.w[3]); }
         const G128 z = shoup_mul(y, smem, tab), want = gf_mul(y, c);
         CHECK(memcmp(&z, &want, 16) == 0, "shoup_mul %d", it);
+        const G128 s1 = gf_sqr(y), s2 = gf_mul(y, y), s3 = gf_sqr(c), s4 = gf_mul(c, c);
+        CHECK(memcmp(&s1, &s2, 16) == 0 && memcmp(&s3, &s4, 16) == 0, "gf_sqr %d", it);
     }
     for (int klen : {16, 24, 32}) {
         auto key = rnd(klen, 9000 + klen);
