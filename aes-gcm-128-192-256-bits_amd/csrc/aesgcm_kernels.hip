@@ -410,6 +410,30 @@ __global__ __launch_bounds__(AESGCM_MAIN_WG, AESGCM_WAVES_PER_SIMD) void k_pkt(c
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_pktl: many packets under the context's key, one LANE per packet (lane body: pktl_lane()); waves take
+// blocks of 64 consecutive packets from the dispenser.
+// ------------------------------------------------------------------------------------------------
+#ifndef AESGCM_PKTL_WAVES
+#define AESGCM_PKTL_WAVES 4          // waves per SIMD the register budget is sized for
+#endif
+template <int NR, int DEC>
+__global__ __launch_bounds__(AESGCM_MAIN_WG, AESGCM_PKTL_WAVES) void k_pktl(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const PktParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const u32 tid = threadIdx.x, lane = tid & 63u;
+    main_fill_lds(smem, km, tb, tid, true, AESGCM_MAIN_WG, true);
+    __syncthreads();
+    const u32 nb = (p.n_pkts + 63u) / 64u;
+    for (u32 guard = 0; guard <= nb; ++guard) {                // bounded, as every dispenser loop here
+        u32 b = 0;
+        if (lane == 0) b = atomicAdd(p.counter, 1u) - p.counter_base;
+        b = __builtin_amdgcn_readfirstlane(b);
+        if (b >= nb) break;
+        const u32 pkt = b * 64u + lane;
+        if (pkt < p.n_pkts) pktl_lane<NR, DEC>(km, p, smem, pkt, lane);
+    }
+}
+
 // ================================================================================================
 // host side
 // ================================================================================================
@@ -1035,18 +1059,35 @@ int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const vo
     const u32 waves_per_wg = AESGCM_MAIN_WG / 64;
     u32 wgs = (u32)((n_pkts + waves_per_wg - 1) / waves_per_wg);
     if (wgs > (u32)c->G) wgs = (u32)c->G;
-    // deal: about 16 dispenser fetches per wave, at most 16 packets per fetch
-    u32 deal = (u32)(n_pkts / ((size_t)wgs * waves_per_wg * 16));
-    deal = deal < 1 ? 1 : deal > 16 ? 16 : deal;
-    if (const char *e = getenv("AESGCM_PKT_DEAL")) { const long v = atol(e); if (v >= 1 && v <= 4096) deal = (u32)v; }
-    p.deal = deal;
-    p.counter = c->d_counter; p.counter_base = c->counter_base;
-    c->counter_base += (u32)((n_pkts + deal - 1) / deal) + wgs * waves_per_wg;     // every wave ends on one failing fetch
+    // shape: one wave per packet (k_pkt) for large packets or few of them, one lane per packet (k_pktl) when there
+    // are enough packets to fill the machine with lanes.  Measured crossover (profiles/packets_sweep.py): the lane
+    // shape wins from about 24 packets per byte of packet length (256 B: 4 Ki packets, 4 KiB: 100 Ki packets);
+    // with offset arrays the host does not know the lengths and goes by count alone.
+    bool by_lane = d_data_off ? n_pkts >= 32768 : (n_pkts >= 2048 && n_pkts >= 24 * pkt_len);
+    if (const char *e = getenv("AESGCM_PKT_SHAPE")) by_lane = (e[0] == 'l');
     hipStream_t st = pick_stream(c, stream);
-#define LP(NR, D) hipLaunchKernelGGL((k_pkt<NR, D>), dim3(wgs), dim3(AESGCM_MAIN_WG), AESGCM_LDS_BYTES, st, c->km, c->tables, p)
-    if (decrypt) { if (c->nr == 10) LP(10, 1); else if (c->nr == 12) LP(12, 1); else LP(14, 1); }
-    else         { if (c->nr == 10) LP(10, 0); else if (c->nr == 12) LP(12, 0); else LP(14, 0); }
+    p.counter = c->d_counter; p.counter_base = c->counter_base;
+    if (by_lane) {
+        const u32 nb = (u32)((n_pkts + 63) / 64);
+        wgs = (nb + waves_per_wg - 1) / waves_per_wg;
+        if (wgs > (u32)c->G) wgs = (u32)c->G;
+        c->counter_base += nb + wgs * waves_per_wg;                                 // every wave ends on one failing fetch
+#define LP(NR, D) hipLaunchKernelGGL((k_pktl<NR, D>), dim3(wgs), dim3(AESGCM_MAIN_WG), AESGCM_LDS_BYTES, st, c->km, c->tables, p)
+        if (decrypt) { if (c->nr == 10) LP(10, 1); else if (c->nr == 12) LP(12, 1); else LP(14, 1); }
+        else         { if (c->nr == 10) LP(10, 0); else if (c->nr == 12) LP(12, 0); else LP(14, 0); }
 #undef LP
+    } else {
+        // deal: about 16 dispenser fetches per wave, at most 16 packets per fetch
+        u32 deal = (u32)(n_pkts / ((size_t)wgs * waves_per_wg * 16));
+        deal = deal < 1 ? 1 : deal > 16 ? 16 : deal;
+        if (const char *e = getenv("AESGCM_PKT_DEAL")) { const long v = atol(e); if (v >= 1 && v <= 4096) deal = (u32)v; }
+        p.deal = deal;
+        c->counter_base += (u32)((n_pkts + deal - 1) / deal) + wgs * waves_per_wg;  // every wave ends on one failing fetch
+#define LP(NR, D) hipLaunchKernelGGL((k_pkt<NR, D>), dim3(wgs), dim3(AESGCM_MAIN_WG), AESGCM_LDS_BYTES, st, c->km, c->tables, p)
+        if (decrypt) { if (c->nr == 10) LP(10, 1); else if (c->nr == 12) LP(12, 1); else LP(14, 1); }
+        else         { if (c->nr == 10) LP(10, 0); else if (c->nr == 12) LP(12, 0); else LP(14, 0); }
+#undef LP
+    }
     const hipError_t le = hipGetLastError();
     if (le != hipSuccess) { c->counter_base = p.counter_base; return hip_fail(le, "k_pkt launch"); }
     return AESGCM_OK;

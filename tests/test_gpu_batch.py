@@ -133,10 +133,13 @@ def test_variable_length_packets_macsec_shaped(hip, orc):
     assert set(struct.unpack("<%di" % n, bytes(d_auth.download()))) == {1}
 
 
-def test_packets_under_one_key(hip, orc):
+@pytest.mark.parametrize("shape", ["wave", "lane"])
+def test_packets_under_one_key(hip, orc, shape, monkeypatch):
     """aesgcm_packets_crypt_dev: one key (context), per-packet IV, AAD and length; fixed-size records and offset
-    arrays; decrypt in place with per-packet authentication."""
+    arrays; decrypt in place with per-packet authentication.  Both kernel shapes (one wave per packet, one lane
+    per packet) are forced in turn; the library picks between them by packet count and size otherwise."""
     import struct
+    monkeypatch.setenv("AESGCM_PKT_SHAPE", shape)
     rng = random.Random(4242)
     for klen in (16, 24, 32):
         key = splitmix_bytes(300 + klen, klen)
@@ -180,3 +183,40 @@ def test_packets_under_one_key(hip, orc):
         assert bytes(d_buf.download(doff[-1])) == pt
         auth = struct.unpack("<%di" % m, bytes(d_auth.download()))
         assert [i for i, a in enumerate(auth) if not a] == [5]
+
+
+@pytest.mark.gpu
+def test_many_small_packets_default_shape(hip, orc, monkeypatch):
+    """50 000 MACsec-sized frames (0..1514 B, AAD 0..32 B) under one key: the count makes the library choose the
+    lane-per-packet kernel by itself; every ciphertext and tag is compared with the oracle, then decrypted in place."""
+    import struct
+    monkeypatch.delenv("AESGCM_PKT_SHAPE", raising=False)
+    rng = random.Random(777)
+    m = 50000
+    lens = [rng.choice((0, 46, 64, 128, 256, 512, 1000, 1500, 1514, rng.randrange(0, 1515))) for _ in range(m)]
+    aads = [rng.choice((0, 8, 16, 20, 28, 32)) for _ in range(m)]
+    doff, aoff = [0], [0]
+    for a, b in zip(lens, aads):
+        doff.append(doff[-1] + a); aoff.append(aoff[-1] + b)
+    key = splitmix_bytes(901, 32)
+    ctx, f = hip.Context(key), orc.Fast(key)
+    ivs, aad, pt = splitmix_bytes(51, 12 * m), splitmix_bytes(52, aoff[-1]), splitmix_bytes(53, doff[-1])
+    def up(b):
+        d = hip.DeviceBuffer(max(len(b), 16)); d.upload(b); return d
+    d_ivs, d_aad, d_buf = up(ivs), up(aad), up(pt)
+    d_doff, d_aoff = up(struct.pack("<%dQ" % (m + 1), *doff)), up(struct.pack("<%dQ" % (m + 1), *aoff))
+    d_tags, d_auth = hip.DeviceBuffer(16 * m), hip.DeviceBuffer(4 * m)
+    ctx.packets_crypt_dev(False, m, d_ivs.ptr, d_buf.ptr, d_buf.ptr, d_tags.ptr, d_data_off=d_doff.ptr, d_aad=d_aad.ptr, d_aad_off=d_aoff.ptr)
+    hip.dev_sync()
+    ct, tags = bytes(d_buf.download(doff[-1])), bytes(d_tags.download())
+    for p in range(m):
+        want = f.encrypt(ivs[12 * p:12 * p + 12], aad[aoff[p]:aoff[p + 1]], pt[doff[p]:doff[p + 1]])
+        assert (ct[doff[p]:doff[p + 1]], tags[16 * p:16 * p + 16]) == want, (p, lens[p], aads[p])
+    bad = bytearray(tags); bad[16 * 4321] ^= 0x80; bad[16 * 49999 + 15] ^= 1
+    d_exp = up(bytes(bad))
+    ctx.packets_crypt_dev(True, m, d_ivs.ptr, d_buf.ptr, d_buf.ptr, d_tags.ptr, d_data_off=d_doff.ptr, d_aad=d_aad.ptr, d_aad_off=d_aoff.ptr,
+                          d_expect_tags=d_exp.ptr, d_auth=d_auth.ptr)
+    hip.dev_sync()
+    assert bytes(d_buf.download(doff[-1])) == pt
+    auth = struct.unpack("<%di" % m, bytes(d_auth.download()))
+    assert [i for i, a in enumerate(auth) if not a] == [4321, 49999]
