@@ -307,12 +307,12 @@ def main():
         avg_s = kernel_ms / 1e3 / max(n_launch, 1)
         achieved = alg_bytes / avg_s if avg_s > 0 else 0.0
         tag_name = "cfg3_n1" if N == 1 else "cfg4_n%d" % N
-        roofline = {"bound": "hbm", "kernel": "k_main<14,ENC> (fused AES-CTR + GHASH)", "achieved": round(achieved / 1e9, 2),
+        roofline = {"bound": "hbm", "kernel": "k_main<%d,ENC> (fused AES-CTR + GHASH)" % (args.key_bits // 32 + 6), "achieved": round(achieved / 1e9, 2),
                     "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_BYTES_PER_S, 4),
                     "traffic": pmc_traffic(tag_name), "alg_bytes_per_launch": alg_bytes, "launches": n_launch,
                     "avg_launch_ms": round(avg_s * 1e3, 4)}
         line = {
-            "metric": "GiB/s plaintext, AES-256-GCM 16 GiB stream, bit-exact tag",
+            "metric": "GiB/s plaintext, AES-%d-GCM %.3g GiB stream, bit-exact tag" % (args.key_bits, args.gib_per_gpu),
             "value": round(value, 3), "unit": "GiB/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
