@@ -41,6 +41,11 @@ __global__ void k_gfmul(const uint4 *h, const uint4 *x, uint4 *z, size_t n) {
     if (i < n) z[i] = gf_mul_mo(x[i], h[i]);
 }
 
+// plain copy, 16 bytes per lane, grid-stride: the measured HBM read+write rate bench.py prints beside the peak
+__global__ __launch_bounds__(256) void k_copy16(uint4 *__restrict__ dst, const uint4 *__restrict__ src, u64 n) {
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) dst[i] = src[i];
+}
+
 __global__ void k_fill_splitmix64(u64 *buf, size_t n_words, size_t tail_bytes, u64 seed, u64 first_word) {
     size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += stride)
@@ -1281,6 +1286,15 @@ int aesgcm_dev_download(int device, void *h, const void *d, size_t n) {
 int aesgcm_dev_sync(int device) {
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipDeviceSynchronize());
+    return AESGCM_OK;
+}
+int aesgcm_dev_copy(int device, void *d_dst, const void *d_src, size_t bytes, void *stream) {
+    if (bytes && (!d_dst || !d_src)) return AESGCM_EARG;
+    if (((uintptr_t)d_dst | (uintptr_t)d_src | bytes) & 15) return AESGCM_EALIGN;
+    if (!bytes) return AESGCM_OK;
+    HIPCHK(hipSetDevice(device));
+    hipLaunchKernelGGL(k_copy16, dim3(8192), dim3(256), 0, (hipStream_t)stream, (uint4 *)d_dst, (const uint4 *)d_src, (u64)(bytes / 16));
+    HIPCHK(hipGetLastError());
     return AESGCM_OK;
 }
 int aesgcm_fill_splitmix64_dev(int device, void *d_buf, size_t len, uint64_t seed, uint64_t first_word, void *stream) {

@@ -22,7 +22,7 @@ SYMBOLS = [
     "aesgcm_keystream", "aesgcm_keystream_dev",
     "aesgcm_shard_crypt_dev", "aesgcm_shard_finalize_dev", "aesgcm_batch_crypt_dev", "aesgcm_batch_crypt_var_dev", "aesgcm_packets_crypt_dev",
     "aesgcm_stream_begin", "aesgcm_stream_aad", "aesgcm_stream_update", "aesgcm_stream_final",
-    "aesgcm_dev_alloc", "aesgcm_dev_free", "aesgcm_dev_upload", "aesgcm_dev_download", "aesgcm_dev_sync",
+    "aesgcm_dev_alloc", "aesgcm_dev_free", "aesgcm_dev_upload", "aesgcm_dev_download", "aesgcm_dev_sync", "aesgcm_dev_copy",
     "aesgcm_fill_splitmix64_dev",
     "aesgcm_ctx_timing_enable", "aesgcm_ctx_timing_read", "aesgcm_ctx_geometry", "aesgcm_ctx_wg_trace",
 ]
@@ -93,6 +93,7 @@ def load():
     L.aesgcm_dev_upload.argtypes = [cint, vp, vp, sz]
     L.aesgcm_dev_download.argtypes = [cint, vp, vp, sz]
     L.aesgcm_dev_sync.argtypes = [cint]
+    L.aesgcm_dev_copy.argtypes = [cint, vp, vp, sz, vp]
     L.aesgcm_fill_splitmix64_dev.argtypes = [cint, vp, sz, u64, u64, vp]
     L.aesgcm_ctx_timing_enable.argtypes = [vp, cint]
     L.aesgcm_ctx_timing_read.argtypes = [vp, ctypes.POINTER(u64), ctypes.POINTER(ctypes.c_double), cint]
@@ -260,6 +261,11 @@ class PinnedBuffer:
 
 def dev_sync(device=0):
     _chk(load().aesgcm_dev_sync(device))
+
+
+def dev_copy(d_dst, d_src, nbytes, device=0, stream=None):
+    """asynchronous device-to-device copy by the library's plain copy kernel"""
+    _chk(load().aesgcm_dev_copy(device, d_dst, d_src, nbytes, stream))
 
 
 # ---------------------------------------------------------------- context

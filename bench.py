@@ -301,6 +301,24 @@ def main():
     total_bytes = per_gpu * N * args.steps
     value = total_bytes / dt / GiB
 
+    # measured HBM read+write rate of a plain copy kernel over the same two buffers (outside the timed region)
+    copy_gbps = None
+    if rank == 0:
+        try:
+            ct_keep = bytes(d_ct.download(64, 0))
+            best = None
+            for _ in range(3):
+                lib.dev_sync(dev)
+                c0 = time.perf_counter()
+                lib.dev_copy(d_ct.ptr, d_pt.ptr, per_gpu, device=dev)
+                lib.dev_sync(dev)
+                c1 = time.perf_counter() - c0
+                best = c1 if best is None or c1 < best else best
+            copy_gbps = round(2 * per_gpu / best / 1e9, 1)
+            del ct_keep
+        except Exception as e:                                 # never break the bench line
+            log("copy measurement failed: %r" % (e,))
+
     if rank == 0:
         blocks_per_launch = (per_gpu // len(msgs)) // 16
         alg_bytes = 32 * blocks_per_launch                     # 16 B read + 16 B written per block
@@ -310,7 +328,8 @@ def main():
         roofline = {"bound": "hbm", "kernel": "k_main<%d,ENC> (fused AES-CTR + GHASH)" % (args.key_bits // 32 + 6), "achieved": round(achieved / 1e9, 2),
                     "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_BYTES_PER_S, 4),
                     "traffic": pmc_traffic(tag_name), "alg_bytes_per_launch": alg_bytes, "launches": n_launch,
-                    "avg_launch_ms": round(avg_s * 1e3, 4)}
+                    "avg_launch_ms": round(avg_s * 1e3, 4),
+                    "measured_copy_kernel": {"value": copy_gbps, "unit": "GB/s read+write", "frac_of_copy": (round(achieved / 1e9 / copy_gbps, 4) if copy_gbps else None)}}
         line = {
             "metric": "GiB/s plaintext, AES-%d-GCM %.3g GiB stream, bit-exact tag" % (args.key_bits, args.gib_per_gpu),
             "value": round(value, 3), "unit": "GiB/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,

@@ -215,6 +215,9 @@ AESGCM_API int aesgcm_dev_free(int device, void *d_ptr);
 AESGCM_API int aesgcm_dev_upload(int device, void *d_dst, const void *h_src, size_t bytes);
 AESGCM_API int aesgcm_dev_download(int device, void *h_dst, const void *d_src, size_t bytes);
 AESGCM_API int aesgcm_dev_sync(int device);
+/* device-to-device copy by a plain 16-bytes-per-lane kernel (asynchronous on `stream`): the measured HBM
+ * read+write figure bench.py reports beside the datasheet peak (SURVEY.md 8(d) "measured copy-kernel figure"). */
+AESGCM_API int aesgcm_dev_copy(int device, void *d_dst, const void *d_src, size_t bytes, void *stream);
 /* SplitMix64 counter-based synthetic stream: little-endian 64-bit word w of stream
  * `seed` for w = first_word ..; bytes [0, len) of the buffer. */
 AESGCM_API int aesgcm_fill_splitmix64_dev(int device, void *d_buf, size_t len, uint64_t seed, uint64_t first_word, void *stream);

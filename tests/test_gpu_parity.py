@@ -273,3 +273,16 @@ def test_distinct_contexts_from_distinct_threads(hip, orc):
     for th in ths:
         th.join()
     assert not errs, errs
+
+
+@pytest.mark.gpu
+def test_dev_copy(hip):
+    """aesgcm_dev_copy: the plain copy kernel bench.py uses for its measured-bandwidth figure"""
+    n = (1 << 20) + 48
+    src, dst = hip.DeviceBuffer(n), hip.DeviceBuffer(n)
+    src.fill_splitmix64(99)
+    hip.dev_copy(dst.ptr, src.ptr, n)
+    hip.dev_sync()
+    assert bytes(dst.download()) == bytes(src.download())
+    with pytest.raises(hip.AesGcmError):
+        hip.dev_copy(dst.ptr, src.ptr + 1, 16)
