@@ -549,7 +549,8 @@ static int set_lds_attrs(int device, DeviceState *ds) {
     SETATTR(10, MODE_ECB); SETATTR(12, MODE_ECB); SETATTR(14, MODE_ECB);
 #undef SETATTR
 #define SETATTRB(NR, D) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch<NR, D>), hipFuncAttributeMaxDynamicSharedMemorySize, BATCH_LDS_BYTES)); \
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pkt<NR, D>), hipFuncAttributeMaxDynamicSharedMemorySize, AESGCM_LDS_BYTES))
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pkt<NR, D>), hipFuncAttributeMaxDynamicSharedMemorySize, AESGCM_LDS_BYTES)); \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktl<NR, D>), hipFuncAttributeMaxDynamicSharedMemorySize, AESGCM_LDS_BYTES))
     SETATTRB(10, 0); SETATTRB(12, 0); SETATTRB(14, 0); SETATTRB(10, 1); SETATTRB(12, 1); SETATTRB(14, 1);
 #undef SETATTRB
     ds->attrs = true;
