@@ -76,3 +76,16 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.replace("oracle/aesgcm_oracle.c by definition", ""), f
                 assert "libcrypto" not in txt and "Crypto.Cipher" not in txt.replace("from Crypto.Cipher import AES", ""), f
+
+
+def test_plain_c_caller_builds_and_fails_loudly_without_gpu():
+    """examples/kat.c links against the library with nothing but the header; on a box without a HIP device it
+    must report AESGCM_EHIP and exit non-zero (no CPU fallback anywhere)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "examples"), "-s"], check=True)
+    r = subprocess.run([os.path.join(root, "examples", "kat")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    if os.path.exists("/dev/kfd"):
+        assert r.returncode == 0 and "KAT OK" in r.stdout, r.stderr
+    else:
+        assert r.returncode != 0 and "-6" in r.stderr, (r.returncode, r.stderr)

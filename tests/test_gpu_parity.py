@@ -286,3 +286,13 @@ def test_dev_copy(hip):
     assert bytes(dst.download()) == bytes(src.download())
     with pytest.raises(hip.AesGcmError):
         hip.dev_copy(dst.ptr, src.ptr + 1, 16)
+
+
+@pytest.mark.gpu
+def test_plain_c_caller(hip):
+    """examples/kat.c: the reference's README vector through aesgcm_encrypt / aesgcm_decrypt / aesgcm_stream_* from C"""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "examples"), "-s"], check=True)
+    r = subprocess.run([os.path.join(root, "examples", "kat")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode == 0 and "KAT OK" in r.stdout, (r.stdout, r.stderr)
