@@ -127,14 +127,18 @@ def usable_cores():
     return max(1, n)
 
 
-def pmc_traffic(tag):
-    """HBM bytes per launch of the fused kernel from a committed rocprofv3 PMC summary, if one exists
-    for this workload (profiles/pmc_<tag>.json written by profiles/collect_pmc.py); else None."""
+def pmc_summary(tag):
+    """committed rocprofv3 PMC summary for this workload (profiles/pmc_<tag>.json), or {}"""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_%s.json" % tag)) as f:
-            return json.load(f).get("hbm_bytes_per_launch")
-    except OSError:
-        return None
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
+def pmc_traffic(tag):
+    """HBM bytes per launch of the fused kernel from the committed PMC summary, if one exists; else None."""
+    return pmc_summary(tag).get("hbm_bytes_per_launch")
 
 
 def main():
@@ -329,6 +333,7 @@ def main():
                     "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_BYTES_PER_S, 4),
                     "traffic": pmc_traffic(tag_name), "alg_bytes_per_launch": alg_bytes, "launches": n_launch,
                     "avg_launch_ms": round(avg_s * 1e3, 4),
+                    "lds_busy_frac": (pmc_summary(tag_name).get("lds") or {}).get("lds_busy_frac"),
                     "measured_copy_kernel": {"value": copy_gbps, "unit": "GB/s read+write", "frac_of_copy": (round(achieved / 1e9 / copy_gbps, 4) if copy_gbps else None)}}
         line = {
             "metric": "GiB/s plaintext, AES-%d-GCM %.3g GiB stream, bit-exact tag" % (args.key_bits, args.gib_per_gpu),
