@@ -293,6 +293,7 @@ HD uint4 ghash_mul_const_lds(uint4 y, const unsigned char *lds) {
 struct DevTables {           // per device
     uint8_t sbox[256];
     u32 te0[256];
+    u32 te1[256], te2[256], te3[256];   // te0 rotated left by 8, 16, 24: k_body's scalar-cache reads need no rotate
 };
 
 struct KeyMaterial {         // per context (device memory)
@@ -304,6 +305,7 @@ struct KeyMaterial {         // per context (device memory)
     uint4 bp2[AESGCM_GMAX + 1]; // bp2[k] = beta^k * H^2, beta = H^WG
     uint4 ktab[512];         // nibble tables of K = H^64 (lane stride of a wave): entry p*16+v
     uint4 htab[512];         // nibble tables of H itself (k_pktl: one lane per packet, serial Horner)
+    uint4 k4tab[512];        // nibble tables of H^256 (k_body: a wave takes every fourth row)
     uint8_t rk_bytes[240];   // expanded key as the byte string tb/key_exp.py produces
 };
 
@@ -391,12 +393,17 @@ HD void setup_beta_lane(KeyMaterial *km, const uint4 *tab, int tid) {
     for (int k = tid; k <= AESGCM_GMAX; k += AESGCM_WG) km->bp2[k] = gf_mul_mo(tab[k], h2);
     if (tid < 512) km->ktab[tid] = gf_mul_mo(nibble_elem_mo(tid >> 4, (u32)(tid & 15)), km->pw[0][64]);
     if (tid < 512) km->htab[tid] = gf_mul_mo(nibble_elem_mo(tid >> 4, (u32)(tid & 15)), km->h);
+    if (tid < 512) km->k4tab[tid] = gf_mul_mo(nibble_elem_mo(tid >> 4, (u32)(tid & 15)), km->pw[0][256]);
 }
 
 // ---- k_main pieces -----------------------------------------------------------------------------
 // LDS image of one workgroup: what thread `tid` of AESGCM_MAIN_WG writes
-HD void main_fill_lds(unsigned char *smem, const KeyMaterial *km, const DevTables *tb, u32 tid, bool gh, u32 nthreads = AESGCM_MAIN_WG, bool by_h = false) {
-    if (gh) for (u32 q = tid; q < 512; q += nthreads) reinterpret_cast<uint4 *>(smem + AESGCM_LDS_GH_OFF)[q] = by_h ? km->htab[q] : km->ktab[q];
+enum { GH_TAB_K64 = 0, GH_TAB_H = 1, GH_TAB_K256 = 2 };       // which constant's nibble tables go to LDS
+HD void main_fill_lds(unsigned char *smem, const KeyMaterial *km, const DevTables *tb, u32 tid, bool gh, u32 nthreads = AESGCM_MAIN_WG, int which = GH_TAB_K64) {
+    if (gh) {
+        const uint4 *src = which == GH_TAB_H ? km->htab : which == GH_TAB_K256 ? km->k4tab : km->ktab;
+        for (u32 q = tid; q < 512; q += nthreads) reinterpret_cast<uint4 *>(smem + AESGCM_LDS_GH_OFF)[q] = src[q];
+    }
     uint4 *dst = reinterpret_cast<uint4 *>(smem + AESGCM_LDS_AES_OFF);
     for (u32 q = tid; q < AESGCM_LDS_AES / 16; q += nthreads) {
         const u32 t0 = tb->te0[q >> 4];
@@ -530,10 +537,100 @@ HD G128 main_lane_tailpow(const KeyMaterial *__restrict__ km, u32 lane) { return
 
 // stage 1 of the two-stage fold: chunk partial c weighted to the end of the sequence, H^((C-1-c)*Bc)
 HD G128 gf_pow_h_serial(const KeyMaterial *km, u64 e);
-HD G128 weigh_lane(const KeyMaterial *__restrict__ km, const uint4 *parts, u32 C, u64 Bc, u32 c) {
+// (m, minor) describe interleaved chunks: chunk c lies (C-1-c)/m major steps of Bc blocks and (C-1-c)%m minor steps
+// of `minor` blocks before the end (k_body: m = 4 row phases 64 blocks apart inside a 256*T-block super-chunk).
+HD G128 weigh_lane(const KeyMaterial *__restrict__ km, const uint4 *parts, u32 C, u64 Bc, u32 c, u32 m = 1, u32 minor = 0) {
     G128 z; z.w[0] = z.w[1] = z.w[2] = z.w[3] = 0;
-    if (c < C) z = gf_mul(mo_to_be(parts[c]), gf_pow_h_serial(km, (u64)(C - 1 - c) * Bc));
+    if (c < C) {
+        const u32 back = C - 1 - c;
+        z = gf_mul(mo_to_be(parts[c]), gf_pow_h_serial(km, (u64)(back / m) * Bc + (u64)(back % m) * minor));
+    }
     return z;
+}
+
+// ---- k_body pieces -----------------------------------------------------------------------------
+// The aligned middle of a large message: data blocks whose counters start at a multiple of 256 and that fill
+// whole super-chunks of 4*T rows.  A wave owns one PHASE v of a super-chunk: rows 4q + v, q = s*T .. s*T + T-1.
+// Then (aes_icb.vhd:97-118: counter = IV || cnt, cnt in bytes 12..15 big-endian)
+//   byte 15 of a lane's counter is 64v + lane for the whole chunk,
+//   bytes 12..14 are the same for all lanes of a row,
+// so after round 1 only column 0 of the state differs between lanes (and is a per-chunk constant of the lane), and
+// every round-2 output column is  P_j(lane) ^ U_j(row):  P_j = the one table value that comes from column 0 (four
+// VGPRs, computed once per chunk), U_j = the three row-uniform table values, the round key and the round-1
+// constants (scalar: table reads with wave-uniform indices go through the scalar cache, not LDS).
+// Rounds 1 and 2 therefore cost no LDS lookup in the row loop: 192 instead of 212 per AES-256 block.
+// GHASH: the lane's blocks are 256 apart, Horner constant H^256 (main_fill_lds(GH_TAB_K256)).
+struct BodyParams {
+    const unsigned char *in;     // first body block (16-byte aligned)
+    unsigned char *out;
+    uint4 *parts;                // one GHASH partial per chunk, chunk c = 4*s + v
+    u32 *counter; u32 counter_base;
+    u32 T;                       // rows per chunk (iterations of a wave), super-chunk = 4*T rows = 256*T blocks
+    u32 C;                       // chunks = 4 * super-chunks
+    u32 ctr_hi0;                 // (counter of body block 0) >> 8; its low byte is 0 by construction
+    u32 iv0, iv1, iv2;
+    u64 *trace;
+};
+struct BodyLane { u32 p0, p1, p2, p3; };
+// wave-uniform table values (host: plain loads; device: scalar loads from the global T0 table)
+HD u32 tu0(const DevTables *__restrict__ tb, u32 x) { return tb->te0[x & 0xFFu]; }
+HD u32 tu1(const DevTables *__restrict__ tb, u32 x) { return tb->te1[x & 0xFFu]; }
+HD u32 tu2(const DevTables *__restrict__ tb, u32 x) { return tb->te2[x & 0xFFu]; }
+HD u32 tu3(const DevTables *__restrict__ tb, u32 x) { return tb->te3[x & 0xFFu]; }
+// per-chunk lane constants: column 0 after round 1, and its four round-2 table values
+HD BodyLane body_lane_consts(const u32 *__restrict__ rk, const CtrConsts &cc, const unsigned char *lds, u32 v, u32 lane) {
+    const u32 lb = (lane & 31u) << 2;
+    const u32 w3 = ((64u * v + lane) << 24) ^ rk[3];                   // only byte 3 (= counter byte 15) is used
+    const u32 s0 = cc.c0 ^ rotl32(T2_AT(lds, w3, 3, lb), 8);
+    BodyLane b;
+    b.p0 = T0_AT(lds, s0, 0, lb);
+    b.p1 = rotl32(T2_AT(lds, s0, 3, lb), 8);
+    b.p2 = T2_AT(lds, s0, 2, lb);
+    b.p3 = rotl32(T0_AT(lds, s0, 1, lb), 8);
+    return b;
+}
+// keystream block of (row-uniform counter bytes 12..14 = hi24, lane constants b): rounds 1-2 from P ^ U, then 3..NR
+template <int NR>
+HD void body_rounds(u32 hi24, const BodyLane &b, const CtrConsts &cc, u32 &s0, u32 &s1, u32 &s2, u32 &s3,
+                    const u32 *__restrict__ rk, const DevTables *__restrict__ tb, const unsigned char *lds, u32 lb) {
+    // counter bytes 12, 13, 14 = hi24 big-endian; memory-order word 3 holds them in bytes 0, 1, 2 (byte 3 is the lane's)
+    const u32 k3 = rk[3];
+    const u32 u1 = cc.c1 ^ tu2(tb, hi24 ^ (k3 >> 16));                 // columns 1..3 after round 1: row-uniform
+    const u32 u2 = cc.c2 ^ tu1(tb, (hi24 >> 8) ^ (k3 >> 8));
+    const u32 u3 = cc.c3 ^ tu0(tb, (hi24 >> 16) ^ k3);
+    const u32 *__restrict__ k2 = rk + 8;
+    const u32 U0 = tu2(tb, u2 >> 16) ^ k2[0] ^ tu1(tb, u1 >> 8) ^ tu3(tb, u3 >> 24);
+    const u32 U1 = tu0(tb, u1) ^ tu2(tb, u3 >> 16) ^ k2[1] ^ tu1(tb, u2 >> 8);
+    const u32 U2 = tu0(tb, u2) ^ k2[2] ^ tu1(tb, u3 >> 8) ^ tu3(tb, u1 >> 24);
+    const u32 U3 = tu0(tb, u3) ^ tu2(tb, u1 >> 16) ^ k2[3] ^ tu3(tb, u2 >> 24);
+    s0 = b.p0 ^ U0; s1 = b.p1 ^ U1; s2 = b.p2 ^ U2; s3 = b.p3 ^ U3;
+#pragma unroll
+    for (int r = 3; r < NR; r++) aes_round_lds(s0, s1, s2, s3, rk + 4 * r, lds, lb);
+    aes_final_lds(s0, s1, s2, s3, rk + 4 * NR, lds, lb);
+}
+// lane `lane` of the wave that owns chunk c = 4*s + v: returns sum_i X[row 4(sT+i)+v, lane] * (H^256)^(T-1-i)
+template <int NR, int MODE>
+HD uint4 body_chunk_lane(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const BodyParams &p,
+                         const unsigned char *smem, const CtrConsts &cc, u32 c, u32 lane) {
+    const u32 *__restrict__ rk = km->rk;
+    const u32 lb = (lane & 31u) << 2, lane16 = lane * 16u;
+    const u32 v = c & 3u, s = c >> 2;
+    const BodyLane b = body_lane_consts(rk, cc, smem, v, lane);
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    for (u32 i = 0; i < p.T; ++i) {
+        const u32 q = s * p.T + i;                                     // super-row: counters [256 q, 256 q + 255] of the body
+        if (i) acc = ghash_mul_const_lds(acc, smem);
+        const u64 off = ((u64)q * 4 + v) * 1024;                       // byte offset of the row in the body
+        const unsigned char *src = reinterpret_cast<const unsigned char *>(uniform64((u64)(uintptr_t)p.in + off));
+        unsigned char *dst = reinterpret_cast<unsigned char *>(uniform64((u64)(uintptr_t)p.out + off));
+        const uint4 x = *reinterpret_cast<const uint4 *>(src + lane16);
+        u32 s0, s1, s2, s3;
+        body_rounds<NR>(p.ctr_hi0 + q, b, cc, s0, s1, s2, s3, rk, tb, smem, lb);
+        const uint4 y = make_uint4(x.x ^ s0, x.y ^ s1, x.z ^ s2, x.w ^ s3);                  // gcm_gctr.vhd:150
+        *reinterpret_cast<uint4 *>(dst + lane16) = y;
+        acc = xor4(acc, (MODE == MODE_DEC) ? x : y);                  // aes_gcm.vhd:207-211
+    }
+    return acc;
 }
 
 // ---- k_combine pieces --------------------------------------------------------------------------
@@ -609,6 +706,31 @@ static inline u32 plan_main(MainParams &p, int mode, u32 tw_override, const uint
     p.iv0 = w[0]; p.iv1 = w[1]; p.iv2 = w[2];
     p.aad_aligned = (((uintptr_t)aad) & 15) == 0;
     return C;
+}
+// Split of a data range for k_body: [head blocks][body = S super-chunks of 256*T blocks][tail].  The body starts at
+// the first block whose counter (2 + first_block + i, aes_icb.vhd:97-100) is a multiple of 256 and holds only whole
+// 16-byte blocks.  Returns false when the range is too small to be worth three launches (min_bytes).
+struct BodySplit { u64 head_blocks, body_blocks; u32 T, S; };
+static inline bool plan_body_split(u64 len, u64 first_block, u32 tw_override, u64 min_bytes, BodySplit *b) {
+    const u64 nfull = len / 16;
+    const u64 head = (256 - ((2 + first_block) & 255)) & 255;
+    if (nfull <= head) return false;
+    const u64 rows = (nfull - head) / 64;
+    u64 R; u32 Tw, C;
+    main_geometry(rows * 64, tw_override, &R, &Tw, &C);
+    if (!Tw) return false;
+    const u64 S = rows / (4ull * Tw);
+    if (!S || S * 4 > 0xFFFFFFFFull / 2) return false;
+    const u64 body = S * 256ull * Tw;
+    if (body * 16 < min_bytes) return false;
+    b->head_blocks = head; b->body_blocks = body; b->T = Tw; b->S = (u32)S;
+    return true;
+}
+static inline void plan_body(BodyParams &p, const BodySplit &b, const uint8_t *iv, const void *in, void *out, u64 first_block, uint4 *parts) {
+    p.in = (const unsigned char *)in + 16 * b.head_blocks; p.out = (unsigned char *)out + 16 * b.head_blocks;
+    p.parts = parts; p.T = b.T; p.C = 4 * b.S;
+    p.ctr_hi0 = (u32)((2 + first_block + b.head_blocks) >> 8);
+    u32 w[3]; iv_to_words(iv, w); p.iv0 = w[0]; p.iv1 = w[1]; p.iv2 = w[2];
 }
 // chunk partials are spaced Bc = 64*Tw blocks apart.  If that equals the table radix (Tw = 16) and there are
 // at most GMAX of them, k_combine folds them directly with the beta tables; otherwise k_weigh runs first.
@@ -879,7 +1001,7 @@ HD G128 pkt_lane_tail(const KeyMaterial *__restrict__ km, uint4 acc, u32 lane) {
 // One LANE per packet (k_pktl): the shape for MACsec-sized frames, where a 64-block row per packet would leave
 // most lanes idle.  The lane runs the whole frame serially, as the reference core does (tb/gcm_test.py:76-85):
 // AAD blocks, data blocks (CTR from 2, aes_icb.vhd:97-118), the length block, Y = (Y ^ X) * H with the LDS
-// nibble tables of H (main_fill_lds(by_h)), tag = Y ^ E_K(IV || 1).  Nothing here is wave-uniform except the key.
+// nibble tables of H (main_fill_lds(GH_TAB_H)), tag = Y ^ E_K(IV || 1).  Nothing here is wave-uniform except the key.
 template <int NR, int DEC>
 HD void pktl_lane(const KeyMaterial *__restrict__ km, const PktParams &p, const unsigned char *smem, u32 pkt, u32 lane) {
     const u32 *__restrict__ rk = km->rk;

@@ -33,6 +33,7 @@ __global__ void k_init_tables(DevTables *t) {
     u32 s = sbox_calc(x);
     t->sbox[x] = (uint8_t)s;
     t->te0[x] = te0_calc(s);
+    t->te1[x] = rotl32(te0_calc(s), 8); t->te2[x] = rotl32(te0_calc(s), 16); t->te3[x] = rotl32(te0_calc(s), 24);
 }
 
 // one GF multiply per thread: z[i] = x[i] * h[i]   (aesgcm_gfmul; replaces src/ghash_gfmul.vhd:37-64)
@@ -147,11 +148,49 @@ __global__ __launch_bounds__(AESGCM_MAIN_WG, AESGCM_WAVES_PER_SIMD) void k_main(
     }
 }
 
-// k_weigh: one lane per chunk partial, z = P_c * H^((C-1-c)*Bc); workgroup XOR-fold -> out[blockIdx.x]
-__global__ __launch_bounds__(AESGCM_WG) void k_weigh(const KeyMaterial *__restrict__ km, const uint4 *__restrict__ parts, u32 C, u64 Bc, uint4 *out) {
+// ------------------------------------------------------------------------------------------------
+// k_body: the aligned middle of a large message (lane body: body_chunk_lane()); rounds 1-2 of every counter
+// block come from per-lane chunk constants and scalar-cache table reads, not from LDS.
+// ------------------------------------------------------------------------------------------------
+template <int NR, int MODE>
+__global__ __launch_bounds__(AESGCM_MAIN_WG, AESGCM_WAVES_PER_SIMD) void k_body(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const BodyParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const u32 tid = threadIdx.x, lane = tid & 63u;
+    if (p.trace && tid == 0) {
+        u64 *tr = p.trace + 4 * (u64)blockIdx.x;
+        tr[0] = wall_clock64();
+        tr[2] = (u64)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((u64)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xF) << 32);
+    }
+    const u64 cyc0 = p.trace ? clock64() : 0;
+    main_fill_lds(smem, km, tb, tid, true, AESGCM_MAIN_WG, GH_TAB_K256);
+    __syncthreads();
+    CtrConsts cc = ctr_round1_consts(p.iv0, p.iv1, p.iv2, km->rk, smem, (lane & 31u) << 2);   // key and IV only: wave-uniform
+    cc.c0 = __builtin_amdgcn_readfirstlane(cc.c0); cc.c1 = __builtin_amdgcn_readfirstlane(cc.c1);
+    cc.c2 = __builtin_amdgcn_readfirstlane(cc.c2); cc.c3 = __builtin_amdgcn_readfirstlane(cc.c3);
+    u32 done = 0;
+    for (u32 guard = 0; guard <= p.C; ++guard) {               // bounded, as every dispenser loop here
+        u32 c = 0;
+        if (lane == 0) c = atomicAdd(p.counter, 1u) - p.counter_base;
+        c = __builtin_amdgcn_readfirstlane(c);
+        if (c >= p.C) break;
+        const uint4 acc = body_chunk_lane<NR, MODE>(km, tb, p, smem, cc, c, lane);
+        const G128 z = wave_xor_fold(main_lane_tail(acc, main_lane_tailpow(km, lane)));      // H^(63-lane)
+        if (lane == 0) p.parts[c] = be_to_mo(z);
+        ++done;
+    }
+    if (p.trace && lane == 0) {
+        u64 *tr = p.trace + 4 * (u64)blockIdx.x;
+        atomicMax((unsigned long long *)&tr[1], (unsigned long long)wall_clock64());
+        atomicAdd((unsigned long long *)&tr[3], (unsigned long long)done | ((unsigned long long)((clock64() - cyc0) >> 10) << 32));
+    }
+}
+
+// k_weigh: one lane per chunk partial, z = P_c * H^(blocks between the chunk's end and the end of the launch's range):
+// (C-1-c)*Bc for consecutive chunks, major/minor steps for k_body's interleaved ones; workgroup XOR-fold -> out[blockIdx.x]
+__global__ __launch_bounds__(AESGCM_WG) void k_weigh(const KeyMaterial *__restrict__ km, const uint4 *__restrict__ parts, u32 C, u64 Bc, u32 m, u32 minor, uint4 *out) {
     __shared__ uint4 red[AESGCM_WG / 64];
     const u32 tid = threadIdx.x;
-    const G128 z = wave_xor_fold(weigh_lane(km, parts, C, Bc, blockIdx.x * AESGCM_WG + tid));
+    const G128 z = wave_xor_fold(weigh_lane(km, parts, C, Bc, blockIdx.x * AESGCM_WG + tid, m, minor));
     if ((tid & 63u) == 0) red[tid >> 6] = be_to_mo(z);
     __syncthreads();
     if (tid == 0) {
@@ -491,6 +530,7 @@ struct aesgcm_ctx {
     u32 *d_counter = nullptr;          // chunk dispenser
     u32 counter_base = 0;              // value the dispenser holds before the next launch
     u32 tw_override = 0;               // AESGCM_TW
+    u64 body_min = (u64)512 << 20;     // ranges with an aligned middle of at least this many bytes go through k_body (AESGCM_BODY_MIN)
     uint4 *d_tag = nullptr;            // [0] tag / poly result, [1] streaming state Y
     u64 *d_trace = nullptr;            // per-workgroup trace of the last k_main launch (timing mode only)
     u32 last_np = 0;
@@ -510,6 +550,7 @@ struct aesgcm_ctx {
     u64 s_aad_len = 0, s_len = 0, s_blocks = 0;   // s_blocks = GHASH blocks absorbed so far
     // timing
     bool timing = false;
+    bool timing_mute = false;          // head / tail launches beside k_body are not the measured kernel
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
 };
@@ -548,6 +589,9 @@ static int set_lds_attrs(int device, DeviceState *ds) {
     SETATTR(10, MODE_KS);  SETATTR(12, MODE_KS);  SETATTR(14, MODE_KS);
     SETATTR(10, MODE_ECB); SETATTR(12, MODE_ECB); SETATTR(14, MODE_ECB);
 #undef SETATTR
+#define SETATTRY(NR, MODE) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_body<NR, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, AESGCM_LDS_BYTES))
+    SETATTRY(10, MODE_ENC); SETATTRY(12, MODE_ENC); SETATTRY(14, MODE_ENC); SETATTRY(10, MODE_DEC); SETATTRY(12, MODE_DEC); SETATTRY(14, MODE_DEC);
+#undef SETATTRY
 #define SETATTRB(NR, D) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch<NR, D>), hipFuncAttributeMaxDynamicSharedMemorySize, BATCH_LDS_BYTES)); \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pkt<NR, D>), hipFuncAttributeMaxDynamicSharedMemorySize, AESGCM_LDS_BYTES)); \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktl<NR, D>), hipFuncAttributeMaxDynamicSharedMemorySize, AESGCM_LDS_BYTES))
@@ -591,13 +635,14 @@ static int enqueue_main(aesgcm_ctx *c, int mode, const uint8_t iv[12], const voi
     if (wgs > (u32)c->G) wgs = (u32)c->G;
     c->counter_base += C + wgs * (AESGCM_MAIN_WG / 64);            // every wave makes exactly one failing fetch
     p.trace = nullptr;
-    if (c->timing) {
+    const bool timed = c->timing && !c->timing_mute;
+    if (timed) {
         p.trace = c->d_trace;
         HIPCHK(hipMemsetAsync(c->d_trace, 0, sizeof(u64) * 4 * AESGCM_GMAX, st));
     }
-    c->last_np = wgs;
+    if (!c->timing_mute) c->last_np = wgs;
     std::pair<hipEvent_t, hipEvent_t> evp;
-    if (c->timing) {
+    if (timed) {
         if (!c->ev_pool.empty()) { evp = c->ev_pool.back(); c->ev_pool.pop_back(); }
         else { HIPCHK(hipEventCreate(&evp.first)); HIPCHK(hipEventCreate(&evp.second)); }
         HIPCHK(hipEventRecord(evp.first, st));
@@ -606,20 +651,96 @@ static int enqueue_main(aesgcm_ctx *c, int mode, const uint8_t iv[12], const voi
         const hipError_t le = launch_main(mode, c->nr, dim3(wgs), st, c->km, c->tables, p);
         if (le != hipSuccess) {                      // nothing ran: the dispenser was not advanced on the device
             c->counter_base = p.counter_base;
-            if (c->timing) c->ev_pool.push_back(evp);
+            if (timed) c->ev_pool.push_back(evp);
             return hip_fail(le, "k_main launch");
         }
     }
-    if (c->timing) { HIPCHK(hipEventRecord(evp.second, st)); c->ev.push_back(evp); }
+    if (timed) { HIPCHK(hipEventRecord(evp.second, st)); c->ev.push_back(evp); }
     if (gh && po) {
         if (needs_weigh(C, p.Tw)) {
             const u32 nw = (C + AESGCM_WG - 1) / AESGCM_WG;
-            hipLaunchKernelGGL(k_weigh, dim3(nw), dim3(AESGCM_WG), 0, st, c->km, c->parts, C, (u64)64 * p.Tw, c->stage1);
+            hipLaunchKernelGGL(k_weigh, dim3(nw), dim3(AESGCM_WG), 0, st, c->km, c->parts, C, (u64)64 * p.Tw, 1u, 0u, c->stage1);
             HIPCHK(hipGetLastError());
             po->ptr = c->stage1; po->np = nw; po->gathered = true;
         } else {
             po->ptr = c->parts; po->np = C; po->gathered = false;
         }
+    }
+    return AESGCM_OK;
+}
+
+static int enqueue_combine(aesgcm_ctx *c, const CombineParams &p, hipStream_t st);
+
+// k_body over the planned split + k_weigh (interleaved exponents): stage-1 partials for k_combine
+static int enqueue_body(aesgcm_ctx *c, int mode, const uint8_t iv[12], const BodySplit &b, const void *d_in, void *d_out,
+                        u64 first_block, hipStream_t st, Partials *po) {
+    BodyParams p;
+    memset(&p, 0, sizeof p);
+    int rc = grow_parts(c, (size_t)4 * b.S);
+    if (rc) return rc;
+    plan_body(p, b, iv, d_in, d_out, first_block, c->parts);
+    p.counter = c->d_counter; p.counter_base = c->counter_base;
+    const u32 waves_per_wg = AESGCM_MAIN_WG / 64;
+    u32 wgs = (p.C + waves_per_wg - 1) / waves_per_wg;
+    if (wgs > (u32)c->G) wgs = (u32)c->G;
+    c->counter_base += p.C + wgs * waves_per_wg;                   // every wave makes exactly one failing fetch
+    if (c->timing) { p.trace = c->d_trace; HIPCHK(hipMemsetAsync(c->d_trace, 0, sizeof(u64) * 4 * AESGCM_GMAX, st)); }
+    c->last_np = wgs;
+    std::pair<hipEvent_t, hipEvent_t> evp;
+    if (c->timing) {
+        if (!c->ev_pool.empty()) { evp = c->ev_pool.back(); c->ev_pool.pop_back(); }
+        else { HIPCHK(hipEventCreate(&evp.first)); HIPCHK(hipEventCreate(&evp.second)); }
+        HIPCHK(hipEventRecord(evp.first, st));
+    }
+#define LY(NR, M) hipLaunchKernelGGL((k_body<NR, M>), dim3(wgs), dim3(AESGCM_MAIN_WG), AESGCM_LDS_BYTES, st, c->km, c->tables, p)
+    if (mode == MODE_DEC) { if (c->nr == 10) LY(10, MODE_DEC); else if (c->nr == 12) LY(12, MODE_DEC); else LY(14, MODE_DEC); }
+    else                  { if (c->nr == 10) LY(10, MODE_ENC); else if (c->nr == 12) LY(12, MODE_ENC); else LY(14, MODE_ENC); }
+#undef LY
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess) {
+        c->counter_base = p.counter_base;
+        if (c->timing) c->ev_pool.push_back(evp);
+        return hip_fail(le, "k_body launch");
+    }
+    if (c->timing) { HIPCHK(hipEventRecord(evp.second, st)); c->ev.push_back(evp); }
+    const u32 nw = (p.C + AESGCM_WG - 1) / AESGCM_WG;
+    hipLaunchKernelGGL(k_weigh, dim3(nw), dim3(AESGCM_WG), 0, st, c->km, c->parts, p.C, (u64)256 * b.T, 4u, 64u, c->stage1);
+    HIPCHK(hipGetLastError());
+    po->ptr = c->stage1; po->np = nw; po->gathered = true;
+    return AESGCM_OK;
+}
+
+// Y' = Y * H^nb ^ P(aad, data) for a whole range, Y in *state (device).  Large ranges go head / k_body / tail,
+// each piece folded into the state in order; small ones are a single k_main launch.
+static int absorb_range(aesgcm_ctx *c, int mode, const uint8_t iv[12], const void *d_aad, u64 aad_len, const void *d_in, u64 len,
+                        void *d_out, u64 first_block, hipStream_t st, uint4 *state) {
+    BodySplit b;
+    Partials pp;
+    int rc;
+    if (!plan_body_split(len, first_block, c->tw_override, c->body_min, &b)) {
+        if ((rc = enqueue_main(c, mode, iv, d_aad, aad_len, d_in, len, d_out, first_block, st, &pp))) return rc;
+        const u64 nb = (aad_len + 15) / 16 + (len + 15) / 16;
+        return nb ? enqueue_combine(c, plan_combine_carry(pp.ptr, pp.np, pp.gathered, state, nb), st) : AESGCM_OK;
+    }
+    if (((uintptr_t)d_in & 15) || ((uintptr_t)d_out & 15)) return AESGCM_EALIGN;
+    const u64 n_aad = (aad_len + 15) / 16;
+    if (n_aad + b.head_blocks) {
+        c->timing_mute = true;
+        rc = enqueue_main(c, mode, iv, d_aad, aad_len, d_in, 16 * b.head_blocks, d_out, first_block, st, &pp);
+        c->timing_mute = false;
+        if (rc) return rc;
+        if ((rc = enqueue_combine(c, plan_combine_carry(pp.ptr, pp.np, pp.gathered, state, n_aad + b.head_blocks), st))) return rc;
+    }
+    if ((rc = enqueue_body(c, mode, iv, b, d_in, d_out, first_block, st, &pp))) return rc;
+    if ((rc = enqueue_combine(c, plan_combine_carry(pp.ptr, pp.np, pp.gathered, state, b.body_blocks), st))) return rc;
+    const u64 done = b.head_blocks + b.body_blocks, tail = len - 16 * done;
+    if (tail) {
+        c->timing_mute = true;
+        rc = enqueue_main(c, mode, iv, nullptr, 0, (const unsigned char *)d_in + 16 * done, tail, (unsigned char *)d_out + 16 * done,
+                          first_block + done, st, &pp);
+        c->timing_mute = false;
+        if (rc) return rc;
+        if ((rc = enqueue_combine(c, plan_combine_carry(pp.ptr, pp.np, pp.gathered, state, (tail + 15) / 16), st))) return rc;
     }
     return AESGCM_OK;
 }
@@ -644,6 +765,14 @@ static int crypt_dev(aesgcm_ctx *c, int dec, const uint8_t iv[12], const void *d
     if (aad_len && !d_aad) return AESGCM_EARG;
     if (len && (!d_in || !d_out)) return AESGCM_EARG;
     HIPCHK(hipSetDevice(c->device));
+    BodySplit b;
+    if (plan_body_split(len, 0, c->tw_override, c->body_min, &b)) {
+        // large message: head / k_body / tail folded into a device-side chaining value, then the tag from it
+        uint4 *state = c->d_tag + 2;
+        HIPCHK(hipMemsetAsync(state, 0, 16, st));
+        if ((rc = absorb_range(c, dec ? MODE_DEC : MODE_ENC, iv, d_aad, aad_len, d_in, len, d_out, 0, st, state))) return rc;
+        return enqueue_combine(c, plan_combine_final(state, iv, aad_len, len, c->d_tag), st);
+    }
     Partials pp;
     rc = enqueue_main(c, dec ? MODE_DEC : MODE_ENC, iv, d_aad, aad_len, d_in, len, d_out, 0, st, &pp);
     if (rc) return rc;
@@ -717,6 +846,7 @@ static int ctx_create_common(aesgcm_ctx **out, int device, const uint8_t *key, s
     int per_cu = 2;
     if (const char *e = getenv("AESGCM_WGS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 2) per_cu = v; }
     if (const char *e = getenv("AESGCM_TW")) c->tw_override = (u32)strtoul(e, nullptr, 0);
+    if (const char *e = getenv("AESGCM_BODY_MIN")) c->body_min = strtoull(e, nullptr, 0);
     int G = per_cu * ds->n_cu;
     if (G > AESGCM_GMAX) G = AESGCM_GMAX;
     if (G < 1) G = 1;
@@ -787,6 +917,15 @@ int aesgcm_ctx_geometry(const aesgcm_ctx *c, int *n_wg, int *wg_lanes, int *lds_
     if (n_wg) *n_wg = c->G;
     if (wg_lanes) *wg_lanes = AESGCM_MAIN_WG;
     if (lds_bytes) *lds_bytes = AESGCM_LDS_BYTES;
+    return AESGCM_OK;
+}
+
+int aesgcm_ctx_split(const aesgcm_ctx *c, size_t len, uint64_t first_block, uint64_t *head_blocks, uint64_t *body_blocks) {
+    if (!c) return AESGCM_EARG;
+    BodySplit b;
+    const bool split = plan_body_split(len, first_block, c->tw_override, c->body_min, &b);
+    if (head_blocks) *head_blocks = split ? b.head_blocks : 0;
+    if (body_blocks) *body_blocks = split ? b.body_blocks : 0;
     return AESGCM_OK;
 }
 
@@ -967,9 +1106,19 @@ int aesgcm_shard_crypt_dev(aesgcm_ctx *c, int decrypt, const uint8_t iv[12], con
     if (first_block != 0 && aad_len) return AESGCM_EARG;
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = pick_stream(c, stream);
+    const u64 after = total_blocks - (first_block + my_blocks);            // blocks of the message behind this shard
+    BodySplit b;
+    if (plan_body_split(len, first_block, c->tw_override, c->body_min, &b)) {
+        uint4 *state = c->d_tag + 2;
+        HIPCHK(hipMemsetAsync(state, 0, 16, st));
+        if ((rc = absorb_range(c, decrypt ? MODE_DEC : MODE_ENC, iv, d_aad, aad_len, d_in, len, d_out, first_block, st, state))) return rc;
+        CombineParams q = plan_combine_poly(nullptr, 0, false, 0, (uint4 *)d_partial);       // W = Y * H^after
+        q.carry = state; q.has_carry = 1; q.e_carry = after;
+        return enqueue_combine(c, q, st);
+    }
     Partials pp;
     if ((rc = enqueue_main(c, decrypt ? MODE_DEC : MODE_ENC, iv, d_aad, aad_len, d_in, len, d_out, first_block, st, &pp))) return rc;
-    return enqueue_combine(c, plan_combine_poly(pp.ptr, pp.np, pp.gathered, total_blocks - (first_block + my_blocks), (uint4 *)d_partial), st);
+    return enqueue_combine(c, plan_combine_poly(pp.ptr, pp.np, pp.gathered, after, (uint4 *)d_partial), st);
 }
 int aesgcm_shard_finalize_dev(aesgcm_ctx *c, const uint8_t iv[12], const void *d_partials, size_t n_partials,
                               size_t aad_len, uint64_t total_len, uint8_t tag[16], void *stream) {

@@ -24,7 +24,7 @@ SYMBOLS = [
     "aesgcm_stream_begin", "aesgcm_stream_aad", "aesgcm_stream_update", "aesgcm_stream_final",
     "aesgcm_dev_alloc", "aesgcm_dev_free", "aesgcm_dev_upload", "aesgcm_dev_download", "aesgcm_dev_sync", "aesgcm_dev_copy",
     "aesgcm_fill_splitmix64_dev",
-    "aesgcm_ctx_timing_enable", "aesgcm_ctx_timing_read", "aesgcm_ctx_geometry", "aesgcm_ctx_wg_trace",
+    "aesgcm_ctx_timing_enable", "aesgcm_ctx_timing_read", "aesgcm_ctx_geometry", "aesgcm_ctx_split", "aesgcm_ctx_wg_trace",
 ]
 
 
@@ -99,6 +99,7 @@ def load():
     L.aesgcm_ctx_timing_read.argtypes = [vp, ctypes.POINTER(u64), ctypes.POINTER(ctypes.c_double), cint]
     L.aesgcm_ctx_wg_trace.argtypes = [vp, vp, sz, ctypes.POINTER(sz)]
     L.aesgcm_ctx_geometry.argtypes = [vp, ctypes.POINTER(cint), ctypes.POINTER(cint), ctypes.POINTER(cint)]
+    L.aesgcm_ctx_split.argtypes = [vp, sz, u64, ctypes.POINTER(u64), ctypes.POINTER(u64)]
     if L.aesgcm_abi_version() != 1:
         raise ImportError("libaesgcm_hip.so ABI %d, expected 1" % L.aesgcm_abi_version())
     _L = L
@@ -448,3 +449,9 @@ class Context:
         a, b, c = cint(0), cint(0), cint(0)
         _chk(load().aesgcm_ctx_geometry(self._c, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
         return dict(workgroups=a.value, wg_lanes=b.value, lds_bytes=c.value)
+
+    def split(self, nbytes, first_block=0):
+        """(head_blocks, body_blocks) of the head / k_body / tail cut of a data range; body_blocks = 0: one k_main launch"""
+        h, b = u64(0), u64(0)
+        _chk(load().aesgcm_ctx_split(self._c, nbytes, first_block, ctypes.byref(h), ctypes.byref(b)))
+        return h.value, b.value

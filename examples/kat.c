@@ -20,8 +20,8 @@ int main(void) {
     unsigned char key[16], iv[12], aad[64], pt[64], want_ct[64], want_tag[16], ct[64], back[64], tag[16], tag2[16];
     unhex("AD7A2BD03EAC835A6F620FDCB506B345", key);
     unhex("12153524C0895E81B2C28465", iv);
-    const int al = unhex("D609B1F056637A0D46DF998D88E5222AB2C2846512153524C0895E81", aad);
-    const int n = unhex("08000F101112131415161718191A1B1C1D1E1F202122232425262728292A2B2C2D2E2F30313233340001", pt);
+    const int al = unhex("D609B1F056637A0D46DF998D88E52E00B2C2846512153524C0895E81", aad);
+    const int n = unhex("08000F101112131415161718191A1B1C1D1E1F202122232425262728292A2B2C2D2E2F303132333435363738393A0002", pt);
     unhex("701AFA1CC039C0D765128A665DAB69243899BF7318CCDC81C9931DA17FBE8EDD7D17CB8B4C26FC81E3284F2B7FBA713D", want_ct);
     unhex("4F8D55E7D3F06FD5A13C0C29B9D5B880", want_tag);
 

@@ -224,7 +224,7 @@ AESGCM_API int aesgcm_fill_splitmix64_dev(int device, void *d_buf, size_t len, u
 
 /* ---------------------------------------------------------------- measurement support
  * When enabled, every launch of the fused CTR+GHASH kernel on this context is bracketed with HIP
- * events on the stream it is launched on.  aesgcm_ctx_timing_read synchronises those events and
+ * events on the stream it is launched on (see aesgcm_ctx_split for split ranges).  aesgcm_ctx_timing_read synchronises those events and
  * returns the number of launches and their summed duration since the last reset. */
 AESGCM_API int aesgcm_ctx_timing_enable(aesgcm_ctx *ctx, int on);
 AESGCM_API int aesgcm_ctx_timing_read(aesgcm_ctx *ctx, uint64_t *n_launches, double *total_ms, int reset);
@@ -234,6 +234,11 @@ AESGCM_API int aesgcm_ctx_timing_read(aesgcm_ctx *ctx, uint64_t *n_launches, dou
 AESGCM_API int aesgcm_ctx_wg_trace(aesgcm_ctx *ctx, uint64_t *out, size_t max_wgs, size_t *n_wgs);
 /* geometry the context chose (workgroups, lanes per workgroup, LDS bytes per workgroup) */
 AESGCM_API int aesgcm_ctx_geometry(const aesgcm_ctx *ctx, int *n_workgroups, int *wg_lanes, int *lds_bytes);
+/* How a data range of `len` bytes starting at block `first_block` of its message is launched: large ranges are cut
+ * into head (k_main), an aligned middle whose counters start at a multiple of 256 (k_body: rounds 1-2 without LDS
+ * lookups) and tail (k_main).  *body_blocks = 0 means one k_main launch.  With timing enabled, only the k_body
+ * launch of a split range is timed and traced (it is the measured kernel). */
+AESGCM_API int aesgcm_ctx_split(const aesgcm_ctx *ctx, size_t len, uint64_t first_block, uint64_t *head_blocks, uint64_t *body_blocks);
 
 #ifdef __cplusplus
 }

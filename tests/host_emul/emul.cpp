@@ -24,7 +24,7 @@ static int g_fail = 0;
 #define CHECK(cond, ...) do { if (!(cond)) { g_fail++; printf("FAIL %s:%d: ", __FILE__, __LINE__); printf(__VA_ARGS__); printf("\n"); } } while (0)
 
 static DevTables g_tb;
-static void init_tables() { for (u32 x = 0; x < 256; x++) { u32 s = sbox_calc(x); g_tb.sbox[x] = (uint8_t)s; g_tb.te0[x] = te0_calc(s); } }
+static void init_tables() { for (u32 x = 0; x < 256; x++) { u32 s = sbox_calc(x); g_tb.sbox[x] = (uint8_t)s; g_tb.te0[x] = te0_calc(s); g_tb.te1[x] = rotl32(te0_calc(s), 8); g_tb.te2[x] = rotl32(te0_calc(s), 16); g_tb.te3[x] = rotl32(te0_calc(s), 24); } }
 
 // emulated k_setup (same barrier structure: compute every lane's product, then commit)
 static void emu_setup(KeyMaterial *km, const uint8_t *key, int key_len, int pre_nr, u32 G) {
@@ -68,6 +68,26 @@ static void emu_main(int mode, const KeyMaterial *km, const MainParams &p) {
     if (km->nr == 10) { D(10) } else if (km->nr == 12) { D(12) } else { D(14) }
 #undef D
 }
+template <int NR, int MODE>
+static void emu_body_nr(const KeyMaterial *km, const BodyParams &p) {
+    static unsigned char smem[AESGCM_LDS_BYTES] __attribute__((aligned(16)));
+    for (u32 tid = 0; tid < AESGCM_MAIN_WG; tid++) main_fill_lds(smem, km, &g_tb, tid, true, AESGCM_MAIN_WG, GH_TAB_K256);
+    for (u32 k = 0; k < p.C; k++) {
+        const u32 c = (k * 7 + 3) % p.C == k ? k : (p.C - 1) - k;      // scrambled order (any permutation will do)
+        G128 fold = {{0, 0, 0, 0}};
+        for (u32 lane = 0; lane < 64; lane++) {
+            const CtrConsts cc = ctr_round1_consts(p.iv0, p.iv1, p.iv2, km->rk, smem, (lane & 31u) << 2);
+            uint4 acc = body_chunk_lane<NR, MODE>(km, &g_tb, p, smem, cc, c, lane);
+            xor_g(fold, main_lane_tail(acc, main_lane_tailpow(km, lane)));
+        }
+        p.parts[c] = be_to_mo(fold);
+    }
+}
+static void emu_body(int mode, const KeyMaterial *km, const BodyParams &p) {
+#define D(NR) if (mode == MODE_DEC) emu_body_nr<NR, MODE_DEC>(km, p); else emu_body_nr<NR, MODE_ENC>(km, p);
+    if (km->nr == 10) { D(10) } else if (km->nr == 12) { D(12) } else { D(14) }
+#undef D
+}
 static G128 emu_pow_h(const KeyMaterial *km, u64 e) { return gf_pow_h_serial(km, e); }
 static void emu_combine(const KeyMaterial *km, const CombineParams &p) {
     G128 acc = {{0, 0, 0, 0}};
@@ -107,6 +127,52 @@ struct Emu {
             r.ptr = stage1.data(); r.np = nw; r.gathered = true;
         } else { r.ptr = parts.data(); r.np = C; r.gathered = false; }
         return r;
+    }
+    // mirrors enqueue_body(): k_body + k_weigh with interleaved exponents
+    Parts run_body(int mode, const uint8_t *iv, const BodySplit &b, const void *in, void *out, u64 first_block) {
+        BodyParams p; memset(&p, 0, sizeof p);
+        if (parts.size() < 4 * (size_t)b.S) parts.resize(4 * (size_t)b.S);
+        plan_body(p, b, iv, in, out, first_block, parts.data());
+        emu_body(mode, &km, p);
+        u32 nw = (p.C + AESGCM_WG - 1) / AESGCM_WG;
+        for (u32 w = 0; w < nw; w++) {
+            G128 fold = {{0, 0, 0, 0}};
+            for (u32 tid = 0; tid < AESGCM_WG; tid++) xor_g(fold, weigh_lane(&km, parts.data(), p.C, (u64)256 * b.T, w * AESGCM_WG + tid, 4, 64));
+            stage1[w] = be_to_mo(fold);
+        }
+        Parts r = {stage1.data(), nw, true};
+        return r;
+    }
+    // mirrors absorb_range()
+    bool absorb(int mode, const uint8_t *iv, const uint8_t *aad, u64 aad_len, const uint8_t *in, u64 len, uint8_t *out, u64 first_block, u64 body_min, uint4 *Y) {
+        BodySplit b;
+        if (!plan_body_split(len, first_block, tw, body_min, &b)) {
+            Parts pp = run(mode, iv, aad, aad_len, in, len, out, first_block);
+            const u64 nb = (aad_len + 15) / 16 + (len + 15) / 16;
+            if (nb) emu_combine(&km, plan_combine_carry(pp.ptr, pp.np, pp.gathered, Y, nb));
+            return false;
+        }
+        const u64 n_aad = (aad_len + 15) / 16;
+        if (n_aad + b.head_blocks) {
+            Parts pp = run(mode, iv, aad, aad_len, in, 16 * b.head_blocks, out, first_block);
+            emu_combine(&km, plan_combine_carry(pp.ptr, pp.np, pp.gathered, Y, n_aad + b.head_blocks));
+        }
+        Parts pb = run_body(mode, iv, b, in, out, first_block);
+        emu_combine(&km, plan_combine_carry(pb.ptr, pb.np, pb.gathered, Y, b.body_blocks));
+        const u64 done = b.head_blocks + b.body_blocks, tail = len - 16 * done;
+        if (tail) {
+            Parts pp = run(mode, iv, nullptr, 0, in + 16 * done, tail, out + 16 * done, first_block + done);
+            emu_combine(&km, plan_combine_carry(pp.ptr, pp.np, pp.gathered, Y, (tail + 15) / 16));
+        }
+        return true;
+    }
+    // mirrors crypt_dev() for a message that takes the split; returns whether the split applied
+    bool crypt_split(int dec, const uint8_t iv[12], const uint8_t *aad, u64 aad_len, const uint8_t *in, u64 len, uint8_t *out, uint8_t tag[16], u64 body_min) {
+        uint4 Y = make_uint4(0, 0, 0, 0), t;
+        const bool split = absorb(dec ? MODE_DEC : MODE_ENC, iv, aad, aad_len, in, len, out, 0, body_min, &Y);
+        emu_combine(&km, plan_combine_final(&Y, iv, aad_len, len, &t));
+        memcpy(tag, &t, 16);
+        return split;
     }
     void crypt(int dec, const uint8_t iv[12], const uint8_t *aad, u64 aad_len, const uint8_t *in, u64 len, uint8_t *out, uint8_t tag[16]) {
         Parts pp = run(dec ? MODE_DEC : MODE_ENC, iv, aad, aad_len, in, len, out, 0);
@@ -321,6 +387,44 @@ static void test_shards(int key_len, u32 G, u64 al, u64 n, int R, u64 seed) {
     CHECK(memcmp(&t, rtag, 16) == 0, "shard tag key %d G %u aad %llu len %llu R %d", key_len, G, (unsigned long long)al, (unsigned long long)n, R);
 }
 
+// head / k_body / tail split (absorb_range): whole messages and shards with arbitrary first blocks
+static void test_body(int key_len, u32 G, u64 al, u64 n, u64 seed) {
+    auto key = rnd(key_len, seed), iv = rnd(12, seed + 1), aad = rnd(al, seed + 2);
+    ABuf pt(n), ct(n), ref(n), back(n);
+    orc_fill_splitmix64(pt.p, n, seed + 3, 0);
+    uint8_t rtag[16], tag[16], dtag[16];
+    orc_gcm_crypt(0, key.data(), key_len, iv.data(), aad.data(), al, pt.p, n, ref.p, rtag);
+    Emu E(key.data(), key_len, G);
+    const bool split = E.crypt_split(0, iv.data(), aad.data(), al, pt.p, n, ct.p, tag, 4096);
+    CHECK(split, "body split did not apply: len %llu G %u", (unsigned long long)n, G);
+    CHECK(memcmp(ct.p, ref.p, n) == 0, "body ct key %d G %u aad %llu len %llu", key_len, G, (unsigned long long)al, (unsigned long long)n);
+    CHECK(memcmp(tag, rtag, 16) == 0, "body tag key %d G %u aad %llu len %llu", key_len, G, (unsigned long long)al, (unsigned long long)n);
+    CHECK(ct.p[n] == 0xA5, "body overrun");
+    E.crypt_split(1, iv.data(), aad.data(), al, ct.p, n, back.p, dtag, 4096);
+    CHECK(memcmp(back.p, pt.p, n) == 0 && memcmp(dtag, rtag, 16) == 0, "body dec key %d G %u", key_len, G);
+    // the same message as R shards, every shard through absorb() from its own first block
+    for (int R : {2, 3}) {
+        ABuf ct2(n);
+        const u64 total_blocks = (n + 15) / 16;
+        std::vector<uint4> gathered(R);
+        u64 first = 0; int nsplit = 0;
+        for (int r = 0; r < R; r++) {
+            u64 blocks = total_blocks / R + ((u64)r < total_blocks % R ? 1 : 0), end = first + blocks;
+            u64 len = (end == total_blocks ? n : 16 * end) - 16 * first;
+            uint4 Y = make_uint4(0, 0, 0, 0);
+            nsplit += E.absorb(MODE_ENC, iv.data(), r == 0 ? aad.data() : nullptr, r == 0 ? al : 0, pt.p + 16 * first, len, ct2.p + 16 * first, first, 4096, &Y);
+            CombineParams q = plan_combine_poly(nullptr, 0, false, 0, &gathered[r]);
+            q.carry = &Y; q.has_carry = 1; q.e_carry = total_blocks - end;
+            emu_combine(&E.km, q);
+            first = end;
+        }
+        uint4 t;
+        emu_combine(&E.km, plan_combine_tag(gathered.data(), R, true, iv.data(), al, n, &t));
+        CHECK(nsplit > 0, "no shard took the split");
+        CHECK(memcmp(ct2.p, ref.p, n) == 0 && memcmp(&t, rtag, 16) == 0, "body shards R %d key %d G %u", R, key_len, G);
+    }
+}
+
 // streaming: AAD in chunks, data in chunks, running state carried through combine
 static void test_stream(int key_len, u32 G, u64 al, u64 n, u64 chunk, u64 seed) {
     auto key = rnd(key_len, seed), iv = rnd(12, seed + 1), aad = rnd(al, seed + 2);
@@ -391,6 +495,11 @@ int main(int argc, char **argv) {
     test_stream(16, 0, 0, 16 * (W * 4 + 52) + 9, 16 * (W + 188), 91);
     test_stream(24, 3, 16 * 40 + 3, 33, 16 * 8, 92);
     test_keystream_and_ghash(55);
+    // k_body: T = 1, 2, 3 rows per chunk; lengths chosen so head, tail and ragged end are all non-trivial
+    test_body(16, 1, 0, 16 * 3000 + 5, 101);
+    test_body(24, 2, 20, 16 * (254 + 2048 * 3 + 777) + 11, 102);
+    test_body(32, 3, 37, 16 * 9000, 103);
+    test_body(32, 1, 16, 16 * 254 + 16 * 1024 * 2, 104);          // head = 254 blocks exactly, empty tail
     test_batch_pieces();
     test_packets(16, 61); test_packets(24, 62); test_packets(32, 63);
     if (level > 1) {

@@ -296,3 +296,42 @@ def test_plain_c_caller(hip):
     subprocess.run(["make", "-C", os.path.join(root, "examples"), "-s"], check=True)
     r = subprocess.run([os.path.join(root, "examples", "kat")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
     assert r.returncode == 0 and "KAT OK" in r.stdout, (r.stdout, r.stderr)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tw", ["", "1", "3"])
+def test_body_split_forced_on_small_messages(hip, orc, monkeypatch, tw):
+    """The head / k_body / tail cut (aesgcm_ctx_split) normally starts at 512 MiB; AESGCM_BODY_MIN brings it down so that
+    whole messages, decrypts and shards with odd first blocks run through k_body at sizes the oracle checks in full."""
+    monkeypatch.setenv("AESGCM_BODY_MIN", "4096")
+    if tw:
+        monkeypatch.setenv("AESGCM_TW", tw)
+    for klen in (16, 24, 32):
+        key, iv = splitmix_bytes(700 + klen, klen), splitmix_bytes(701, 12)
+        c, f = hip.Context(key), orc.Fast(key)
+        for n, al in ((16 * 3000 + 5, 0), (16 * (254 + 2048 * 3 + 777) + 11, 20), (1 << 20, 37), (16 * 254 + 16 * 1024 * 2, 16), (3 << 20 | 7, 0)):
+            head, body = c.split(n)
+            assert body > 0 and head == 254, (n, head, body)
+            aad, pt = splitmix_bytes(702 + al, al), splitmix_bytes(703 + n % 97, n)
+            want_ct, want_tag = f.encrypt(iv, aad, pt)
+            assert c.encrypt(iv, aad, pt) == (want_ct, want_tag), (klen, n, al, "enc")
+            assert c.decrypt(iv, aad, want_ct, tag=want_tag) == (pt, want_tag), (klen, n, al, "dec")
+        # shards: every rank's range has its own head (first block not a multiple of 256)
+        n, al, ranks = (5 << 20) + 9, 33, 3
+        aad, pt = splitmix_bytes(710, al), splitmix_bytes(711, n)
+        want_ct, want_tag = f.encrypt(iv, aad, pt)
+        din, dout = hip.DeviceBuffer(n + 16), hip.DeviceBuffer(n + 16)
+        din.upload(pt)
+        d_aad = hip.DeviceBuffer(al); d_aad.upload(aad)
+        parts = hip.DeviceBuffer(16 * ranks)
+        total_blocks, first = (n + 15) // 16, 0
+        for r in range(ranks):
+            blocks = total_blocks // ranks + (1 if r < total_blocks % ranks else 0)
+            end = first + blocks
+            ln = (n if end == total_blocks else 16 * end) - 16 * first
+            assert c.split(ln, first)[1] > 0
+            c.shard_crypt_dev(False, iv, din.ptr + 16 * first, ln, dout.ptr + 16 * first, first, n, parts.ptr + 16 * r,
+                              d_aad=d_aad.ptr if r == 0 else None, aad_len=al if r == 0 else 0)
+            first = end
+        assert c.shard_finalize_dev(iv, parts.ptr, ranks, al, n) == want_tag
+        assert bytes(dout.download(n)) == want_ct
