@@ -530,7 +530,8 @@ struct aesgcm_ctx {
     u32 *d_counter = nullptr;          // chunk dispenser
     u32 counter_base = 0;              // value the dispenser holds before the next launch
     u32 tw_override = 0;               // AESGCM_TW
-    u64 body_min = (u64)512 << 20;     // ranges with an aligned middle of at least this many bytes go through k_body (AESGCM_BODY_MIN)
+    u64 body_min = (u64)3 << 30;       // ranges with an aligned middle of at least this many bytes go through k_body (AESGCM_BODY_MIN):
+                                       // the cut costs ~110 us of extra launches, break-even measured at ~2.5 GiB (profiles/split_threshold.py)
     uint4 *d_tag = nullptr;            // [0] tag / poly result, [1] streaming state Y
     u64 *d_trace = nullptr;            // per-workgroup trace of the last k_main launch (timing mode only)
     u32 last_np = 0;

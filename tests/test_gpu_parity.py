@@ -301,7 +301,7 @@ def test_plain_c_caller(hip):
 @pytest.mark.gpu
 @pytest.mark.parametrize("tw", ["", "1", "3"])
 def test_body_split_forced_on_small_messages(hip, orc, monkeypatch, tw):
-    """The head / k_body / tail cut (aesgcm_ctx_split) normally starts at 512 MiB; AESGCM_BODY_MIN brings it down so that
+    """The head / k_body / tail cut (aesgcm_ctx_split) normally starts at 3 GiB; AESGCM_BODY_MIN brings it down so that
     whole messages, decrypts and shards with odd first blocks run through k_body at sizes the oracle checks in full."""
     monkeypatch.setenv("AESGCM_BODY_MIN", "4096")
     if tw:
