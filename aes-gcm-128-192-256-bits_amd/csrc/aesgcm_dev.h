@@ -267,7 +267,7 @@ HD void ctr_rounds_lds(u32 ctr_be_word, const CtrConsts &k, u32 &s0, u32 &s1, u3
 // lanes either read the same address (broadcast) or different 16-byte slots: conflict-free by
 // construction.
 // ------------------------------------------------------------------------------------------------
-HD uint4 ghash_mul_const_lds(uint4 y, const unsigned char *lds) {
+HD uint4 ghash_mul_const_lds_at(uint4 y, const unsigned char *lds, u32 base) {
     u32x4_t r = {0, 0, 0, 0};
     const u32 w[4] = {y.x, y.y, y.z, y.w};
 #pragma unroll
@@ -277,13 +277,14 @@ HD uint4 ghash_mul_const_lds(uint4 y, const unsigned char *lds) {
             const int b = 4 * wi + bb;
             const u32 hi = (bb == 0) ? (w[wi] & 0xF0u) : ((w[wi] >> (8 * bb)) & 0xF0u);
             const u32 lo = (bb == 0) ? ((w[wi] << 4) & 0xF0u) : ((w[wi] >> (8 * bb - 4)) & 0xF0u);
-            const u32x4_t a = LDS_LD128(lds, hi + (AESGCM_LDS_GH_OFF + (2 * b) * 256));
-            const u32x4_t c = LDS_LD128(lds, lo + (AESGCM_LDS_GH_OFF + (2 * b + 1) * 256));
+            const u32x4_t a = LDS_LD128(lds, hi + (base + (2 * b) * 256));
+            const u32x4_t c = LDS_LD128(lds, lo + (base + (2 * b + 1) * 256));
             r.x = xor3(r.x, a.x, c.x); r.y = xor3(r.y, a.y, c.y); r.z = xor3(r.z, a.z, c.z); r.w = xor3(r.w, a.w, c.w);
         }
     }
     return make_uint4(r.x, r.y, r.z, r.w);
 }
+HD uint4 ghash_mul_const_lds(uint4 y, const unsigned char *lds) { return ghash_mul_const_lds_at(y, lds, AESGCM_LDS_GH_OFF); }
 
 // ================================================================================================
 // Device-resident structures and the per-lane bodies of the kernels.  The __global__ wrappers in
@@ -296,27 +297,34 @@ struct DevTables {           // per device
     u32 te1[256], te2[256], te3[256];   // te0 rotated left by 8, 16, 24: k_body's scalar-cache reads need no rotate
 };
 
+#define AESGCM_NPTAB 26
 struct KeyMaterial {         // per context (device memory)
     u32 rk[60];              // expanded key, memory-order words
     u32 nr;
     u32 _pad[3];
     uint4 h;                 // H = E_K(0^128)
     uint4 pw[4][AESGCM_NPW]; // pw[d][k] = H^(k * WG^d)
-    uint4 bp2[AESGCM_GMAX + 1]; // bp2[k] = beta^k * H^2, beta = H^WG
     uint4 ktab[512];         // nibble tables of K = H^64 (lane stride of a wave): entry p*16+v
     uint4 htab[512];         // nibble tables of H itself (k_pktl: one lane per packet, serial Horner)
     uint4 k4tab[512];        // nibble tables of H^256 (k_body: a wave takes every fourth row)
+    uint4 ptab[AESGCM_NPTAB][512]; // nibble tables of H^(2^k), k = 6 .. 31: the Horner constants of k_fold when chunk sizes are powers of two
     uint8_t rk_bytes[240];   // expanded key as the byte string tb/key_exp.py produces
 };
 
 enum { MODE_ENC = 0, MODE_DEC = 1, MODE_KS = 2, MODE_ECB = 3 };
 
+// One atomic address serves ~87 M fetches/s on MI355X (measured): a single dispenser caps a launch at one chunk per
+// 11.5 ns, i.e. chunks shorter than ~10 rows run at the dispenser's speed, not the kernel's.  Chunks are therefore
+// dealt from AESGCM_NQ queues on separate cache lines; a wave starts at its home queue and walks on when one runs dry.
+#define AESGCM_NQ 16
 struct MainParams {
     const unsigned char *in;     // data in (16-byte aligned) or NULL (MODE_KS)
     unsigned char *out;
     const unsigned char *aad;    // AAD bytes or NULL
     uint4 *parts;                // one GHASH partial per chunk (GHASH modes)
-    u32 *counter;                // chunk dispenser (atomic); chunk index = fetched value - counter_base
+    u32 *counter;                // chunk dispensers: queue q is the u32 at counter[16 q] (one cache line each)
+    u32 nq, seg;                 // queue q hands out chunks [q seg, (q+1) seg); value fetched - qbase[q] = index in the queue
+    u32 qbase[AESGCM_NQ];        // what each queue held before this launch (queues are never reset)
     u64 aad_len;                 // bytes
     u64 n_aad;                   // AAD blocks
     u64 len;                     // data bytes
@@ -327,32 +335,31 @@ struct MainParams {
     u32 C;                       // chunks = ceil(R / Tw); chunk 0 is the short one (R0 rows)
     u32 R0;                      // rows in chunk 0 = R - (C-1)*Tw
     u32 row_lo, row_hi;          // rows [row_lo, row_hi) hold 64 full data blocks each (fast path)
-    u32 counter_base;
     u32 ctr0;                    // counter of data block 0 (2 + first_block)
     u32 iv0, iv1, iv2;           // IV as memory-order words
     u32 aad_aligned;             // AAD pointer 16-byte aligned
     u64 *trace;                  // optional per-workgroup {start, end, HW_ID | XCC_ID << 32, chunks done} (measurement support)
+    uint4 *ej0;                  // GHASH modes: where the wave that owns chunk 0 leaves E_K(IV || 1) for k_combine (or NULL)
 };
 
-#define AESGCM_MAX_CHUNKS (AESGCM_GMAX * AESGCM_WG)   /* two-stage combine capacity: GMAX stage-1 workgroups x WG lanes */
+#define AESGCM_MAX_CHUNKS (1u << 18)   /* 64 lane accumulators (1 KiB) per chunk: at most 256 MiB of them, three k_fold launches */
 
-// Chunking of a GHASH sequence of n_seq blocks: rows of 64 blocks, Tw rows per chunk.  Measured on MI355X
-// (profiles/overhead_probe.py): a chunk costs its rows plus ~2.4 rows for the tail multiply, a lone wave needs
-// ~10 us per row when the CU is full, and ~8k waves are resident.  Small inputs therefore want MANY short
-// chunks (parallelism), large ones long chunks (amortised tail) but still >= 16 per resident wave (balance),
-// and never more chunks than the two-stage fold can take.
+// Chunking of a GHASH sequence of n_seq blocks: rows of 64 blocks, Tw rows per chunk.  A chunk costs its rows, a
+// dispenser fetch and a 1 KiB item store; ~8k waves are resident and a lone wave needs ~10 us per row when the CU is
+// full.  Small inputs want MANY short chunks (parallelism); large ones enough chunks per resident wave for the
+// dynamic dealing to level the age-ordered issue arbitration, but not so many that the dispensers (16 queues x
+// ~87 M fetches/s) or k_fold show up.  Measured (profiles/tw_sweep.py): 16 MiB best at 8 rows, 64 MiB at 16,
+// 256 MiB .. 4 GiB at 32; never more than AESGCM_MAX_CHUNKS chunks.
 HD void main_geometry(u64 n_seq, u32 tw_override, u64 *rows, u32 *Tw, u32 *C) {
     const u64 R = (n_seq + 63) / 64;
     u64 t;
     if (tw_override) t = tw_override;
     else if (R <= 32768) { t = R / 2048; if (t < 1) t = 1; }      // <= 32 MiB: ~2k chunks
-    else {
-        t = R / 16384; if (t < 16) t = 16; if (t > 64) t = 64;       // ~16k chunks up to 1 GiB, 64-row chunks beyond
-        if (R / t > 65536) { t = R / 65536; if (t > 256) t = 256; }    // >= 8 chunks per resident wave, <= 256 rows
-    }
+    else t = R < (1u << 18) ? 16 : 32;
     const u64 tmin = (R + AESGCM_MAX_CHUNKS - 1) / AESGCM_MAX_CHUNKS;
     if (t < tmin) t = tmin;
     if (t < 1) t = 1;
+    if (!tw_override) { u64 p2 = 1; while (p2 < t) p2 <<= 1; t = p2; }      // powers of two: k_fold's constants are then precomputed tables
     *rows = R; *Tw = (u32)t; *C = (u32)((R + t - 1) / t);
 }
 
@@ -387,13 +394,18 @@ HD bool setup_level(const uint4 *tab, int j, int tid, uint4 *prod) {
     *prod = gf_mul_mo(tab[tid], tab[base]);
     return true;
 }
-// after the beta table (d == 1) is complete in tab: bp2 (beta^k * H^2) and the nibble table of K = H^64
+// after the beta table (d == 1) is complete: the nibble tables of the fixed Horner constants H^64, H, H^256
 HD void setup_beta_lane(KeyMaterial *km, const uint4 *tab, int tid) {
-    const uint4 h2 = km->pw[0][2];
-    for (int k = tid; k <= AESGCM_GMAX; k += AESGCM_WG) km->bp2[k] = gf_mul_mo(tab[k], h2);
+    (void)tab;
     if (tid < 512) km->ktab[tid] = gf_mul_mo(nibble_elem_mo(tid >> 4, (u32)(tid & 15)), km->pw[0][64]);
     if (tid < 512) km->htab[tid] = gf_mul_mo(nibble_elem_mo(tid >> 4, (u32)(tid & 15)), km->h);
     if (tid < 512) km->k4tab[tid] = gf_mul_mo(nibble_elem_mo(tid >> 4, (u32)(tid & 15)), km->pw[0][256]);
+}
+
+// after all four power tables exist: ptab[k] = nibble tables of H^(2^(k+6)); H^(2^j) = pw[j / LOG_WG][2^(j % LOG_WG)]
+HD void setup_ptab_lane(KeyMaterial *km, u32 k, u32 tid) {
+    const u32 j = k + 6;
+    if (tid < 512) km->ptab[k][tid] = gf_mul_mo(nibble_elem_mo((int)(tid >> 4), tid & 15u), km->pw[j / AESGCM_LOG_WG][1u << (j % AESGCM_LOG_WG)]);
 }
 
 // ---- k_main pieces -----------------------------------------------------------------------------
@@ -531,21 +543,98 @@ HD CtrConsts main_lane_consts(const KeyMaterial *__restrict__ km, const MainPara
     if (MODE != MODE_ECB) cc = ctr_round1_consts(p.iv0, p.iv1, p.iv2, km->rk, smem, (lane & 31u) << 2);
     return cc;
 }
-// lane L of a wave carries H^(63-L) into the wave fold -> P_chunk = sum_{i in chunk} X_i H^(end-1-i)
-HD G128 main_lane_tail(uint4 acc, G128 tailpow_be) { return gf_mul(mo_to_be(acc), tailpow_be); }
-HD G128 main_lane_tailpow(const KeyMaterial *__restrict__ km, u32 lane) { return mo_to_be(km->pw[0][63 - lane]); }
-
-// stage 1 of the two-stage fold: chunk partial c weighted to the end of the sequence, H^((C-1-c)*Bc)
+// ---- k_fold pieces -----------------------------------------------------------------------------
+// A chunk leaves its 64 raw lane accumulators behind (one ITEM = 64 x 16 B, lane L = sum_r X[r, L] * K^(rows-1-r));
+// nothing is multiplied per chunk any more (a per-lane bit-serial multiply per chunk used to cost ~2.4 rows).
+// The polynomial of the range is  sum_L H^(63-L) * B_L,  B_L = sum_i item_i[L] * H^(blocks between item i and the end),
+// and B_L is a Horner recurrence per lane with WAVE-UNIFORM constants, i.e. the cheap LDS-table multiply.
+// One k_fold launch reduces n items to ceil(n / 256): stage a, a wave folds 16 consecutive items (constant A);
+// stage b, wave 0 folds the workgroup's <= 16 results (constant C = A^16).  Groups are cut from the END, so the
+// first group / first wave is the short one and group ends stay equally spaced.  At most three launches reach
+// one item (one up to 256 chunks, two up to 65536); k_combine applies H^(63-L) to it and XOR-folds the lanes.
+// k_body's chunks are interleaved (item 4s+v, v = row phase, 64 blocks apart; super-chunks 256 T apart):
+// period = 4 folds the four phases with A = H^64 and the super-chunks with B = H^(256 T).
+// Constants that are H^(2^k) (chunk sizes are powers of two unless AESGCM_TW says otherwise) come from the
+// key's precomputed tables (tab* = device pointer); others are built in the kernel from the exponent.
+struct FoldParams {
+    const uint4 *in; uint4 *out;
+    u32 n;                       // items in
+    u32 period;                  // 1: plain Horner with A.  4: inner Horner with A over each 4 items, outer with B
+    u64 eA, eB, eC;              // exponents (blocks) of the three constants; eC = blocks between stage-a outputs
+    const uint4 *tabA, *tabB, *tabC;   // precomputed nibble tables or NULL
+};
+#define FOLD_GROUP 16u           /* items per wave */
+#define FOLD_WAVES 16u           /* waves per workgroup: 1024 items per workgroup */
+#define FOLD_WG (64u * FOLD_WAVES)
+#define FOLD_LDS_TAB 24576u      /* three 8 KiB tables */
+#define FOLD_LDS_BYTES (FOLD_LDS_TAB + FOLD_WAVES * 1024u)
 HD G128 gf_pow_h_serial(const KeyMaterial *km, u64 e);
-// (m, minor) describe interleaved chunks: chunk c lies (C-1-c)/m major steps of Bc blocks and (C-1-c)%m minor steps
-// of `minor` blocks before the end (k_body: m = 4 row phases 64 blocks apart inside a 256*T-block super-chunk).
-HD G128 weigh_lane(const KeyMaterial *__restrict__ km, const uint4 *parts, u32 C, u64 Bc, u32 c, u32 m = 1, u32 minor = 0) {
-    G128 z; z.w[0] = z.w[1] = z.w[2] = z.w[3] = 0;
-    if (c < C) {
-        const u32 back = C - 1 - c;
-        z = gf_mul(mo_to_be(parts[c]), gf_pow_h_serial(km, (u64)(back / m) * Bc + (u64)(back % m) * minor));
+// nibble tables of H^e at LDS byte offset `base` (what thread tid of nthreads writes): copied or built
+HD void fold_fill_lds(unsigned char *smem, const KeyMaterial *km, const uint4 *tab, u64 e, u32 base, u32 tid, u32 nthreads) {
+    if (tab) { for (u32 q = tid; q < 512; q += nthreads) reinterpret_cast<uint4 *>(smem + base)[q] = tab[q]; return; }
+    const uint4 c = be_to_mo(gf_pow_h_serial(km, e));
+    for (u32 q = tid; q < 512; q += nthreads) reinterpret_cast<uint4 *>(smem + base)[q] = gf_mul_mo(nibble_elem_mo((int)(q >> 4), q & 15u), c);
+}
+HD u32 fold_wgs(u32 n) { return (n + FOLD_GROUP * FOLD_WAVES - 1) / (FOLD_GROUP * FOLD_WAVES); }
+// the items [*start, *end) of workgroup g, and how many waves have work
+HD u32 fold_wg_range(u32 n, u32 g, u32 *start, u32 *end) {
+    const u32 per = FOLD_GROUP * FOLD_WAVES;
+    *end = n - per * (fold_wgs(n) - 1 - g);
+    *start = *end > per ? *end - per : 0;
+    return (*end - *start + FOLD_GROUP - 1) / FOLD_GROUP;
+}
+// stage a: lane `lane` of wave w (of J active waves) of the workgroup that owns items [start, end)
+HD uint4 fold_wave_lane(const FoldParams &p, const unsigned char *smem, u32 start, u32 end, u32 J, u32 w, u32 lane) {
+    const u32 e = end - FOLD_GROUP * (J - 1 - w);
+    const u32 s = e > start + FOLD_GROUP ? e - FOLD_GROUP : start;
+    // loads in batches of 8 ahead of their multiplies (they do not depend on the accumulator; the items come from
+    // HBM, ~1-2 us away)
+    const u32 cnt = e - s;
+    uint4 outer = make_uint4(0, 0, 0, 0), inner = make_uint4(0, 0, 0, 0);
+    for (u32 k0 = 0; k0 < cnt; k0 += 8) {
+        uint4 it[8];
+#pragma unroll
+        for (u32 k = 0; k < 8; ++k) it[k] = (k0 + k < cnt) ? p.in[(size_t)(s + k0 + k) * 64 + lane] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (u32 k = 0; k < 8; ++k) {
+            if (k0 + k < cnt) {
+                if (p.period <= 1) {
+                    if (k0 + k) outer = ghash_mul_const_lds_at(outer, smem, 0u);
+                    outer = xor4(outer, it[k]);
+                } else {
+                    const u32 ph = (k0 + k) % p.period;                // s is a multiple of the period
+                    if (ph) inner = ghash_mul_const_lds_at(inner, smem, 0u);
+                    inner = xor4(inner, it[k]);
+                    if (ph == p.period - 1) {
+                        if (k0 + k + 1 > p.period) outer = ghash_mul_const_lds_at(outer, smem, 8192u);
+                        outer = xor4(outer, inner);
+                        inner = make_uint4(0, 0, 0, 0);
+                    }
+                }
+            }
+        }
     }
-    return z;
+    return outer;
+}
+// stage b: lane `lane` of wave 0 folds the J wave results staged in LDS (item j at FOLD_LDS_TAB + 1024 j)
+HD uint4 fold_wg_lane(const unsigned char *smem, u32 J, u32 lane) {
+    uint4 acc = *reinterpret_cast<const uint4 *>(smem + FOLD_LDS_TAB + lane * 16u);
+    for (u32 j = 1; j < J; ++j) acc = xor4(ghash_mul_const_lds_at(acc, smem, 16384u), *reinterpret_cast<const uint4 *>(smem + FOLD_LDS_TAB + j * 1024u + lane * 16u));
+    return acc;
+}
+// blocks between the ends of consecutive output items of a launch
+static inline u64 fold_out_step(const FoldParams &p) { return FOLD_WAVES * p.eC; }
+// fill the constants of a level: items eA blocks apart (period 1), or phases eA apart and periods eB apart
+static inline void plan_fold(FoldParams &p, const uint4 *in, uint4 *out, u32 n, u32 period, u64 eA, u64 eB) {
+    p.in = in; p.out = out; p.n = n; p.period = period; p.eA = eA; p.eB = period > 1 ? eB : 0;
+    p.eC = period > 1 ? (FOLD_GROUP / period) * eB : FOLD_GROUP * eA;
+    p.tabA = p.tabB = p.tabC = nullptr;
+}
+// index into KeyMaterial::ptab of the table of H^e, or -1
+static inline int ptab_index(u64 e) {
+    if (!e || (e & (e - 1))) return -1;
+    int k = 0; while ((e >> k) != 1) k++;
+    return (k >= 6 && k < 6 + AESGCM_NPTAB) ? k - 6 : -1;
 }
 
 // ---- k_body pieces -----------------------------------------------------------------------------
@@ -564,7 +653,7 @@ struct BodyParams {
     const unsigned char *in;     // first body block (16-byte aligned)
     unsigned char *out;
     uint4 *parts;                // one GHASH partial per chunk, chunk c = 4*s + v
-    u32 *counter; u32 counter_base;
+    u32 *counter; u32 nq, seg; u32 qbase[AESGCM_NQ];      // as in MainParams
     u32 T;                       // rows per chunk (iterations of a wave), super-chunk = 4*T rows = 256*T blocks
     u32 C;                       // chunks = 4 * super-chunks
     u32 ctr_hi0;                 // (counter of body block 0) >> 8; its low byte is 0 by construction
@@ -635,24 +724,27 @@ HD uint4 body_chunk_lane(const KeyMaterial *__restrict__ km, const DevTables *__
 
 // ---- k_combine pieces --------------------------------------------------------------------------
 #define COMBINE_THREADS (AESGCM_GMAX + 64)   /* GMAX partial lanes + the length-block lane + the E_K(J0) lane, rounded to waves */
+enum { PARTS_NONE = 0, PARTS_GATHERED = 1, PARTS_ITEM = 2 };
 struct CombineParams {
-    const uint4 *parts; u32 np; u32 gathered;
+    const uint4 *parts; u32 np; u32 kind;   // GATHERED: np weighted 16-byte partials (shards); ITEM: one 64-lane item of k_fold
     u32 want_tag;                // 1 = TAG, 0 = POLY
     u64 e;                       // POLY: exponent applied to the folded partials
     const uint4 *carry; u64 e_carry; u32 has_carry;
     u64 aad_len, ct_len;         // bytes, for the length block
     u32 iv0, iv1, iv2;
+    const uint4 *ej0;            // E_K(IV || 1) left by k_main, or NULL: k_combine computes it (one lane, bytewise: ~15 us)
     uint4 *out;
 };
 // what lane `tid` contributes to the XOR fold
 HD G128 combine_lane(const KeyMaterial *__restrict__ km, const uint8_t *sbox, const CombineParams &p, u32 tid) {
     G128 z; z.w[0] = z.w[1] = z.w[2] = z.w[3] = 0;
     const bool tag = p.want_tag != 0;
-    if (tid < p.np) {
-        uint4 m;
-        if (p.gathered) m = tag ? km->bp2[0] : gf_one_mo();
-        else m = tag ? km->bp2[p.np - 1 - tid] : km->pw[1][p.np - 1 - tid];
-        z = gf_mul(mo_to_be(p.parts[tid]), mo_to_be(m));
+    if (p.kind == PARTS_ITEM && tid < 64) {
+        // lane L of the last item carries H^(63-L); TAG mode needs the polynomial times H^2 (tag = P*H^2 ^ L*H ^ E_K(J0))
+        z = gf_mul(mo_to_be(p.parts[tid]), mo_to_be(km->pw[0][63 - tid + (tag ? 2 : 0)]));
+    } else if (p.kind == PARTS_GATHERED && tid < p.np) {
+        z = mo_to_be(p.parts[tid]);
+        if (tag) z = gf_mul(z, mo_to_be(km->pw[0][2]));
     } else if (tag && tid == AESGCM_GMAX) {
         // length block [8*len(A)]_64 || [8*len(C)]_64 (gcm_ghash.vhd:257) times H
         G128 L; const u64 a = p.aad_len * 8, c = p.ct_len * 8;
@@ -660,6 +752,7 @@ HD G128 combine_lane(const KeyMaterial *__restrict__ km, const uint8_t *sbox, co
         z = gf_mul(L, mo_to_be(km->h));
     } else if (tag && tid == AESGCM_GMAX + 1) {
         // E_K(IV || 0^31 1): the J0 block the RTL latches first (gcm_ghash.vhd:158-169)
+        if (p.ej0) return mo_to_be(*p.ej0);
         uint8_t j0[16], o[16];
         const u32 ivw[3] = {p.iv0, p.iv1, p.iv2};
         for (int k = 0; k < 12; k++) j0[k] = (uint8_t)(ivw[k >> 2] >> (8 * (k & 3)));
@@ -681,6 +774,11 @@ HD G128 gf_pow_h_serial(const KeyMaterial *km, u64 e) {
 // ---- host-side planning (shared by the C ABI and the CPU harness) -------------------------------
 static inline void iv_to_words(const uint8_t iv[12], u32 w[3]) { for (int q = 0; q < 3; q++) w[q] = load_le32(iv + 4 * q); }
 
+// how many dispenser queues a launch of C chunks uses, and the chunks per queue
+static inline void plan_queues(u32 C, u32 *nq, u32 *seg) {
+    u32 n = C >= 4096 ? AESGCM_NQ : C >= 512 ? 4 : 1;
+    *nq = n; *seg = (C + n - 1) / n;
+}
 // Fill MainParams for one launch; returns the number of chunks (0 = nothing to launch).
 static inline u32 plan_main(MainParams &p, int mode, u32 tw_override, const uint8_t *iv, const void *aad, u64 aad_len,
                             const void *in, u64 len, void *out, u64 first_block, uint4 *parts) {
@@ -732,35 +830,31 @@ static inline void plan_body(BodyParams &p, const BodySplit &b, const uint8_t *i
     p.ctr_hi0 = (u32)((2 + first_block + b.head_blocks) >> 8);
     u32 w[3]; iv_to_words(iv, w); p.iv0 = w[0]; p.iv1 = w[1]; p.iv2 = w[2];
 }
-// chunk partials are spaced Bc = 64*Tw blocks apart.  If that equals the table radix (Tw = 16) and there are
-// at most GMAX of them, k_combine folds them directly with the beta tables; otherwise k_weigh runs first.
-static inline bool needs_weigh(u32 C, u32 Tw) { return !(C <= AESGCM_GMAX && 64u * Tw == (u32)AESGCM_WG); }
-
-// whole-message tag from local workgroup partials:  P*H^2 ^ L*H ^ E_K(J0)
-static inline CombineParams plan_combine_tag(const uint4 *parts, u32 np, bool gathered, const uint8_t iv[12],
+// whole-message tag from the folded item:  P*H^2 ^ L*H ^ E_K(J0)
+static inline CombineParams plan_combine_tag(const uint4 *parts, u32 np, u32 kind, const uint8_t iv[12],
                                              u64 aad_len, u64 ct_len, uint4 *out) {
     CombineParams q = {};
-    q.parts = parts; q.np = np; q.gathered = gathered ? 1u : 0u; q.want_tag = 1;
+    q.parts = parts; q.np = np; q.kind = np ? kind : (u32)PARTS_NONE; q.want_tag = 1;
     q.aad_len = aad_len; q.ct_len = ct_len;
     u32 w[3]; iv_to_words(iv, w); q.iv0 = w[0]; q.iv1 = w[1]; q.iv2 = w[2];
     q.out = out;
     return q;
 }
 // polynomial value of local partials times H^e (shard partial, aesgcm_ghash)
-static inline CombineParams plan_combine_poly(const uint4 *parts, u32 np, bool gathered, u64 e, uint4 *out) {
+static inline CombineParams plan_combine_poly(const uint4 *parts, u32 np, u32 kind, u64 e, uint4 *out) {
     CombineParams q = {};
-    q.parts = parts; q.np = np; q.gathered = gathered ? 1u : 0u; q.e = e; q.out = out;
+    q.parts = parts; q.np = np; q.kind = np ? kind : (u32)PARTS_NONE; q.e = e; q.out = out;
     return q;
 }
 // streaming: Y' = Y * H^nb ^ P(new blocks)
-static inline CombineParams plan_combine_carry(const uint4 *parts, u32 np, bool gathered, uint4 *state, u64 nb) {
+static inline CombineParams plan_combine_carry(const uint4 *parts, u32 np, u32 kind, uint4 *state, u64 nb) {
     CombineParams q = {};
-    q.parts = parts; q.np = np; q.gathered = gathered ? 1u : 0u; q.carry = state; q.has_carry = 1; q.e_carry = nb; q.out = state;
+    q.parts = parts; q.np = np; q.kind = np ? kind : (u32)PARTS_NONE; q.carry = state; q.has_carry = 1; q.e_carry = nb; q.out = state;
     return q;
 }
 // streaming final: tag = Y*H^2 ^ L*H ^ E_K(J0)
 static inline CombineParams plan_combine_final(uint4 *state, const uint8_t iv[12], u64 aad_len, u64 ct_len, uint4 *out) {
-    CombineParams q = plan_combine_tag(nullptr, 0, false, iv, aad_len, ct_len, out);
+    CombineParams q = plan_combine_tag(nullptr, 0, PARTS_NONE, iv, aad_len, ct_len, out);
     q.carry = state; q.has_carry = 1; q.e_carry = 0;
     return q;
 }

@@ -22,6 +22,7 @@
 
 #include <mutex>
 #include <new>
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -128,16 +129,27 @@ __global__ __launch_bounds__(AESGCM_MAIN_WG, AESGCM_WAVES_PER_SIMD) void k_main(
     cc.c0 = __builtin_amdgcn_readfirstlane(cc.c0); cc.c1 = __builtin_amdgcn_readfirstlane(cc.c1);
     cc.c2 = __builtin_amdgcn_readfirstlane(cc.c2); cc.c3 = __builtin_amdgcn_readfirstlane(cc.c3);
     u32 done = 0;
-    // bounded on purpose: no wave can own more than C chunks, so a dispenser problem can never turn into a hang
-    for (u32 guard = 0; guard <= p.C; ++guard) {
-        u32 c = 0;
-        if (lane == 0) c = atomicAdd(p.counter, 1u) - p.counter_base;
-        c = __builtin_amdgcn_readfirstlane(c);
-        if (c >= p.C) break;
+    // bounded on purpose: no wave can own more than C chunks (plus one dry fetch per queue), so a dispenser problem can
+    // never turn into a hang
+    u32 q = (blockIdx.x * (AESGCM_MAIN_WG / 64) + (tid >> 6)) % p.nq, dry = 0;       // home queue; queues found empty so far
+    q = __builtin_amdgcn_readfirstlane(q);
+    for (u32 guard = 0; guard <= p.C + 2 * AESGCM_NQ; ++guard) {
+        u32 v = 0;
+        if (lane == 0) v = atomicAdd(p.counter + 16 * q, 1u) - p.qbase[q];
+        v = __builtin_amdgcn_readfirstlane(v);
+        if (v >= p.seg) {                                       // this queue is dry: walk on, stop after a full round
+            if (++dry == p.nq) break;
+            q = q + 1 == p.nq ? 0 : q + 1;
+            continue;
+        }
+        const u32 c = q * p.seg + v;
+        if (c >= p.C) continue;                                 // the last queue is padded to seg
         const uint4 acc = main_chunk_lane<NR, MODE>(km, p, smem, cc, c, lane);
-        if (GH) {
-            const G128 z = wave_xor_fold(main_lane_tail(acc, main_lane_tailpow(km, lane)));   // H^(63-lane), loaded per chunk
-            if (lane == 0) p.parts[c] = be_to_mo(z);
+        if (GH) p.parts[(size_t)c * 64 + lane] = acc;          // the chunk's item: 64 raw lane accumulators (k_fold takes over)
+        if (GH && c == 0 && p.ej0) {                             // E_K(IV || 1) for the tag (gcm_ghash.vhd:158-169), once per launch
+            u32 s0, s1, s2, s3;
+            ctr_rounds_lds<NR>(bswap32(1u), cc, s0, s1, s2, s3, km->rk, smem, (lane & 31u) << 2);
+            if (lane == 0) *p.ej0 = make_uint4(s0, s1, s2, s3);
         }
         ++done;
     }
@@ -168,14 +180,21 @@ __global__ __launch_bounds__(AESGCM_MAIN_WG, AESGCM_WAVES_PER_SIMD) void k_body(
     cc.c0 = __builtin_amdgcn_readfirstlane(cc.c0); cc.c1 = __builtin_amdgcn_readfirstlane(cc.c1);
     cc.c2 = __builtin_amdgcn_readfirstlane(cc.c2); cc.c3 = __builtin_amdgcn_readfirstlane(cc.c3);
     u32 done = 0;
-    for (u32 guard = 0; guard <= p.C; ++guard) {               // bounded, as every dispenser loop here
-        u32 c = 0;
-        if (lane == 0) c = atomicAdd(p.counter, 1u) - p.counter_base;
-        c = __builtin_amdgcn_readfirstlane(c);
-        if (c >= p.C) break;
+    u32 q = (blockIdx.x * (AESGCM_MAIN_WG / 64) + (tid >> 6)) % p.nq, dry = 0;
+    q = __builtin_amdgcn_readfirstlane(q);
+    for (u32 guard = 0; guard <= p.C + 2 * AESGCM_NQ; ++guard) {            // bounded, as every dispenser loop here
+        u32 v = 0;
+        if (lane == 0) v = atomicAdd(p.counter + 16 * q, 1u) - p.qbase[q];
+        v = __builtin_amdgcn_readfirstlane(v);
+        if (v >= p.seg) {
+            if (++dry == p.nq) break;
+            q = q + 1 == p.nq ? 0 : q + 1;
+            continue;
+        }
+        const u32 c = q * p.seg + v;
+        if (c >= p.C) continue;
         const uint4 acc = body_chunk_lane<NR, MODE>(km, tb, p, smem, cc, c, lane);
-        const G128 z = wave_xor_fold(main_lane_tail(acc, main_lane_tailpow(km, lane)));      // H^(63-lane)
-        if (lane == 0) p.parts[c] = be_to_mo(z);
+        p.parts[(size_t)c * 64 + lane] = acc;
         ++done;
     }
     if (p.trace && lane == 0) {
@@ -185,20 +204,23 @@ __global__ __launch_bounds__(AESGCM_MAIN_WG, AESGCM_WAVES_PER_SIMD) void k_body(
     }
 }
 
-// k_weigh: one lane per chunk partial, z = P_c * H^(blocks between the chunk's end and the end of the launch's range):
-// (C-1-c)*Bc for consecutive chunks, major/minor steps for k_body's interleaved ones; workgroup XOR-fold -> out[blockIdx.x]
-__global__ __launch_bounds__(AESGCM_WG) void k_weigh(const KeyMaterial *__restrict__ km, const uint4 *__restrict__ parts, u32 C, u64 Bc, u32 m, u32 minor, uint4 *out) {
-    __shared__ uint4 red[AESGCM_WG / 64];
-    const u32 tid = threadIdx.x;
-    const G128 z = wave_xor_fold(weigh_lane(km, parts, C, Bc, blockIdx.x * AESGCM_WG + tid, m, minor));
-    if ((tid & 63u) == 0) red[tid >> 6] = be_to_mo(z);
+// k_fold: 256 items per workgroup (lane bodies: fold_wave_lane(), fold_wg_lane()).  No static LDS: table offsets
+// are absolute.
+__global__ __launch_bounds__(FOLD_WG) void k_fold(const KeyMaterial *__restrict__ km, const FoldParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    fold_fill_lds(smem, km, p.tabA, p.eA, 0u, tid, FOLD_WG);
+    if (p.period > 1) fold_fill_lds(smem, km, p.tabB, p.eB, 8192u, tid, FOLD_WG);
+    fold_fill_lds(smem, km, p.tabC, p.eC, 16384u, tid, FOLD_WG);
     __syncthreads();
-    if (tid == 0) {
-        uint4 r = red[0];
-        for (int k = 1; k < AESGCM_WG / 64; k++) r = xor4(r, red[k]);
-        out[blockIdx.x] = r;
-    }
+    u32 start, end;
+    const u32 J = fold_wg_range(p.n, blockIdx.x, &start, &end);
+    if (w < J) *reinterpret_cast<uint4 *>(smem + FOLD_LDS_TAB + w * 1024u + lane * 16u) = fold_wave_lane(p, smem, start, end, J, w, lane);
+    __syncthreads();
+    if (w == 0) p.out[(size_t)blockIdx.x * 64 + lane] = fold_wg_lane(smem, J, lane);
 }
+// nibble tables of H^(2^k), k = 6..31, once per key (after k_setup)
+__global__ __launch_bounds__(512) void k_setup_ptab(KeyMaterial *km) { setup_ptab_lane(km, blockIdx.x, threadIdx.x); }
 
 // ------------------------------------------------------------------------------------------------
 // k_combine: one workgroup, per message.
@@ -524,11 +546,12 @@ struct aesgcm_ctx {
     int G = 0;                         // workgroups per full launch
     DevTables *tables = nullptr;
     KeyMaterial *km = nullptr;
-    uint4 *parts = nullptr;            // one partial per chunk (grown on demand)
-    size_t parts_cap = 0;              // entries
-    uint4 *stage1 = nullptr;           // GMAX outputs of k_weigh
+    uint4 *parts = nullptr;            // one item (64 lane accumulators) per chunk, grown on demand
+    size_t parts_cap = 0;              // items
+    uint4 *fold_a = nullptr, *fold_b = nullptr;   // k_fold ping-pong: MAX_CHUNKS/256 items and MAX_CHUNKS/65536 items
     u32 *d_counter = nullptr;          // chunk dispenser
-    u32 counter_base = 0;              // value the dispenser holds before the next launch
+    u32 counter_base = 0;              // value the packet dispenser (d_counter[0]) holds before the next launch
+    u32 mq_base[AESGCM_NQ] = {0};      // the same for the chunk queues of k_main / k_body (d_counter[16 (1 + q)])
     u32 tw_override = 0;               // AESGCM_TW
     u64 body_min = (u64)3 << 30;       // ranges with an aligned middle of at least this many bytes go through k_body (AESGCM_BODY_MIN):
                                        // the cut costs ~110 us of extra launches, break-even measured at ~2.5 GiB (profiles/split_threshold.py)
@@ -603,21 +626,43 @@ static int set_lds_attrs(int device, DeviceState *ds) {
 }
 
 // What the fold stage needs to know about the partials a launch produced.
-struct Partials { const uint4 *ptr = nullptr; u32 np = 0; bool gathered = false; };
+struct Partials { const uint4 *ptr = nullptr; u32 np = 0; u32 kind = PARTS_NONE; const uint4 *ej0 = nullptr; };
 
 static int grow_parts(aesgcm_ctx *c, size_t need) {
     if (need <= c->parts_cap) return AESGCM_OK;
     if (c->parts) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(c->parts)); c->parts = nullptr; c->parts_cap = 0; }   // rare: first big message
     size_t n = need < 4096 ? 4096 : need;
-    hipError_t e = hipMalloc(&c->parts, n * sizeof(uint4));
+    hipError_t e = hipMalloc(&c->parts, n * 64 * sizeof(uint4));
     if (e == hipErrorOutOfMemory) return AESGCM_ENOMEM;
     if (e != hipSuccess) return hip_fail(e, "hipMalloc");
     c->parts_cap = n;
     return AESGCM_OK;
 }
 
-// Enqueue the fused kernel over (aad, data) (+ k_weigh when the chunk partials need generic weights) and
-// describe the partials for k_combine.  mode ENC/DEC: GHASH partials.  mode KS/ECB: no GHASH.
+// device address of the key's precomputed table of H^e, or NULL
+static const uint4 *ptab_ptr(const aesgcm_ctx *c, u64 e) {
+    const int k = ptab_index(e);
+    return k < 0 ? nullptr : reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(c->km) + offsetof(KeyMaterial, ptab)) + (size_t)k * 512;
+}
+// k_fold levels: n items (period, eA, eB as in FoldParams) -> one item (left in parts, fold_a or fold_b)
+static int enqueue_fold(aesgcm_ctx *c, const uint4 *items, u32 n, u32 period, u64 eA, u64 eB, hipStream_t st, Partials *po) {
+    const uint4 *cur = items;
+    int which = 0;
+    while (n > 1) {
+        FoldParams f;
+        plan_fold(f, cur, which ? c->fold_b : c->fold_a, n, period, eA, eB);
+        f.tabA = ptab_ptr(c, f.eA); f.tabB = ptab_ptr(c, f.eB); f.tabC = ptab_ptr(c, f.eC);
+        const u32 G = fold_wgs(n);
+        hipLaunchKernelGGL(k_fold, dim3(G), dim3(FOLD_WG), FOLD_LDS_BYTES, st, c->km, f);
+        HIPCHK(hipGetLastError());
+        eA = fold_out_step(f); eB = 0; period = 1;
+        cur = f.out; n = G; which ^= 1;
+    }
+    po->ptr = cur; po->np = 1; po->kind = PARTS_ITEM;
+    return AESGCM_OK;
+}
+
+// Enqueue the fused kernel over (aad, data) and the k_fold levels over its chunk items; describe the result for k_combine.  mode ENC/DEC: GHASH partials.  mode KS/ECB: no GHASH.
 static int enqueue_main(aesgcm_ctx *c, int mode, const uint8_t iv[12], const void *d_aad, u64 aad_len,
                         const void *d_in, u64 len, void *d_out, u64 first_block, hipStream_t st, Partials *po) {
     const bool gh = (mode == MODE_ENC || mode == MODE_DEC);
@@ -630,11 +675,13 @@ static int enqueue_main(aesgcm_ctx *c, int mode, const uint8_t iv[12], const voi
     int rc;
     if (gh && (rc = grow_parts(c, C))) return rc;
     p.parts = c->parts;
-    p.counter = c->d_counter;
-    p.counter_base = c->counter_base;
     u32 wgs = (C + AESGCM_MAIN_WG / 64 - 1) / (AESGCM_MAIN_WG / 64);          // one wave per chunk is enough for small inputs
     if (wgs > (u32)c->G) wgs = (u32)c->G;
-    c->counter_base += C + wgs * (AESGCM_MAIN_WG / 64);            // every wave makes exactly one failing fetch
+    p.counter = c->d_counter + 16;
+    plan_queues(C, &p.nq, &p.seg);
+    for (u32 q = 0; q < AESGCM_NQ; q++) p.qbase[q] = c->mq_base[q];
+    for (u32 q = 0; q < p.nq; q++) c->mq_base[q] += p.seg + wgs * (AESGCM_MAIN_WG / 64);   // every wave finds every queue dry exactly once
+    if (gh && po) { p.ej0 = c->d_tag + 3; po->ej0 = p.ej0; }
     p.trace = nullptr;
     const bool timed = c->timing && !c->timing_mute;
     if (timed) {
@@ -650,29 +697,20 @@ static int enqueue_main(aesgcm_ctx *c, int mode, const uint8_t iv[12], const voi
     }
     {
         const hipError_t le = launch_main(mode, c->nr, dim3(wgs), st, c->km, c->tables, p);
-        if (le != hipSuccess) {                      // nothing ran: the dispenser was not advanced on the device
-            c->counter_base = p.counter_base;
+        if (le != hipSuccess) {                      // nothing ran: the queues were not advanced on the device
+            for (u32 q = 0; q < AESGCM_NQ; q++) c->mq_base[q] = p.qbase[q];
             if (timed) c->ev_pool.push_back(evp);
             return hip_fail(le, "k_main launch");
         }
     }
     if (timed) { HIPCHK(hipEventRecord(evp.second, st)); c->ev.push_back(evp); }
-    if (gh && po) {
-        if (needs_weigh(C, p.Tw)) {
-            const u32 nw = (C + AESGCM_WG - 1) / AESGCM_WG;
-            hipLaunchKernelGGL(k_weigh, dim3(nw), dim3(AESGCM_WG), 0, st, c->km, c->parts, C, (u64)64 * p.Tw, 1u, 0u, c->stage1);
-            HIPCHK(hipGetLastError());
-            po->ptr = c->stage1; po->np = nw; po->gathered = true;
-        } else {
-            po->ptr = c->parts; po->np = C; po->gathered = false;
-        }
-    }
+    if (gh && po) return enqueue_fold(c, c->parts, C, 1, (u64)64 * p.Tw, 0, st, po);
     return AESGCM_OK;
 }
 
 static int enqueue_combine(aesgcm_ctx *c, const CombineParams &p, hipStream_t st);
 
-// k_body over the planned split + k_weigh (interleaved exponents): stage-1 partials for k_combine
+// k_body over the planned split + the k_fold levels over its interleaved chunk items
 static int enqueue_body(aesgcm_ctx *c, int mode, const uint8_t iv[12], const BodySplit &b, const void *d_in, void *d_out,
                         u64 first_block, hipStream_t st, Partials *po) {
     BodyParams p;
@@ -680,11 +718,13 @@ static int enqueue_body(aesgcm_ctx *c, int mode, const uint8_t iv[12], const Bod
     int rc = grow_parts(c, (size_t)4 * b.S);
     if (rc) return rc;
     plan_body(p, b, iv, d_in, d_out, first_block, c->parts);
-    p.counter = c->d_counter; p.counter_base = c->counter_base;
     const u32 waves_per_wg = AESGCM_MAIN_WG / 64;
     u32 wgs = (p.C + waves_per_wg - 1) / waves_per_wg;
     if (wgs > (u32)c->G) wgs = (u32)c->G;
-    c->counter_base += p.C + wgs * waves_per_wg;                   // every wave makes exactly one failing fetch
+    p.counter = c->d_counter + 16;
+    plan_queues(p.C, &p.nq, &p.seg);
+    for (u32 q = 0; q < AESGCM_NQ; q++) p.qbase[q] = c->mq_base[q];
+    for (u32 q = 0; q < p.nq; q++) c->mq_base[q] += p.seg + wgs * waves_per_wg;
     if (c->timing) { p.trace = c->d_trace; HIPCHK(hipMemsetAsync(c->d_trace, 0, sizeof(u64) * 4 * AESGCM_GMAX, st)); }
     c->last_np = wgs;
     std::pair<hipEvent_t, hipEvent_t> evp;
@@ -699,16 +739,13 @@ static int enqueue_body(aesgcm_ctx *c, int mode, const uint8_t iv[12], const Bod
 #undef LY
     const hipError_t le = hipGetLastError();
     if (le != hipSuccess) {
-        c->counter_base = p.counter_base;
+        for (u32 q = 0; q < AESGCM_NQ; q++) c->mq_base[q] = p.qbase[q];
         if (c->timing) c->ev_pool.push_back(evp);
         return hip_fail(le, "k_body launch");
     }
     if (c->timing) { HIPCHK(hipEventRecord(evp.second, st)); c->ev.push_back(evp); }
-    const u32 nw = (p.C + AESGCM_WG - 1) / AESGCM_WG;
-    hipLaunchKernelGGL(k_weigh, dim3(nw), dim3(AESGCM_WG), 0, st, c->km, c->parts, p.C, (u64)256 * b.T, 4u, 64u, c->stage1);
-    HIPCHK(hipGetLastError());
-    po->ptr = c->stage1; po->np = nw; po->gathered = true;
-    return AESGCM_OK;
+    // items 4s + v: phases 64 blocks apart inside a super-chunk, super-chunks 256 T blocks apart
+    return enqueue_fold(c, c->parts, p.C, 4, 64, (u64)256 * b.T, st, po);
 }
 
 // Y' = Y * H^nb ^ P(aad, data) for a whole range, Y in *state (device).  Large ranges go head / k_body / tail,
@@ -721,7 +758,7 @@ static int absorb_range(aesgcm_ctx *c, int mode, const uint8_t iv[12], const voi
     if (!plan_body_split(len, first_block, c->tw_override, c->body_min, &b)) {
         if ((rc = enqueue_main(c, mode, iv, d_aad, aad_len, d_in, len, d_out, first_block, st, &pp))) return rc;
         const u64 nb = (aad_len + 15) / 16 + (len + 15) / 16;
-        return nb ? enqueue_combine(c, plan_combine_carry(pp.ptr, pp.np, pp.gathered, state, nb), st) : AESGCM_OK;
+        return nb ? enqueue_combine(c, plan_combine_carry(pp.ptr, pp.np, pp.kind, state, nb), st) : AESGCM_OK;
     }
     if (((uintptr_t)d_in & 15) || ((uintptr_t)d_out & 15)) return AESGCM_EALIGN;
     const u64 n_aad = (aad_len + 15) / 16;
@@ -730,10 +767,10 @@ static int absorb_range(aesgcm_ctx *c, int mode, const uint8_t iv[12], const voi
         rc = enqueue_main(c, mode, iv, d_aad, aad_len, d_in, 16 * b.head_blocks, d_out, first_block, st, &pp);
         c->timing_mute = false;
         if (rc) return rc;
-        if ((rc = enqueue_combine(c, plan_combine_carry(pp.ptr, pp.np, pp.gathered, state, n_aad + b.head_blocks), st))) return rc;
+        if ((rc = enqueue_combine(c, plan_combine_carry(pp.ptr, pp.np, pp.kind, state, n_aad + b.head_blocks), st))) return rc;
     }
     if ((rc = enqueue_body(c, mode, iv, b, d_in, d_out, first_block, st, &pp))) return rc;
-    if ((rc = enqueue_combine(c, plan_combine_carry(pp.ptr, pp.np, pp.gathered, state, b.body_blocks), st))) return rc;
+    if ((rc = enqueue_combine(c, plan_combine_carry(pp.ptr, pp.np, pp.kind, state, b.body_blocks), st))) return rc;
     const u64 done = b.head_blocks + b.body_blocks, tail = len - 16 * done;
     if (tail) {
         c->timing_mute = true;
@@ -741,7 +778,7 @@ static int absorb_range(aesgcm_ctx *c, int mode, const uint8_t iv[12], const voi
                           first_block + done, st, &pp);
         c->timing_mute = false;
         if (rc) return rc;
-        if ((rc = enqueue_combine(c, plan_combine_carry(pp.ptr, pp.np, pp.gathered, state, (tail + 15) / 16), st))) return rc;
+        if ((rc = enqueue_combine(c, plan_combine_carry(pp.ptr, pp.np, pp.kind, state, (tail + 15) / 16), st))) return rc;
     }
     return AESGCM_OK;
 }
@@ -777,7 +814,9 @@ static int crypt_dev(aesgcm_ctx *c, int dec, const uint8_t iv[12], const void *d
     Partials pp;
     rc = enqueue_main(c, dec ? MODE_DEC : MODE_ENC, iv, d_aad, aad_len, d_in, len, d_out, 0, st, &pp);
     if (rc) return rc;
-    return enqueue_combine(c, plan_combine_tag(pp.ptr, pp.np, pp.gathered, iv, aad_len, len, c->d_tag), st);
+    CombineParams q = plan_combine_tag(pp.ptr, pp.np, pp.kind, iv, aad_len, len, c->d_tag);
+    q.ej0 = pp.ej0;                                              // same IV, same stream: k_main left E_K(IV || 1) behind
+    return enqueue_combine(c, q, st);
 }
 
 static int ct_compare16(const uint8_t *a, const uint8_t *b) {
@@ -856,9 +895,10 @@ static int ctx_create_common(aesgcm_ctx **out, int device, const uint8_t *key, s
     if ((e = hipSetDevice(device)) != hipSuccess) { delete c; return hip_fail(e, "hipSetDevice"); }
     if ((e = hipStreamCreate(&c->stream)) != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate"); }
     if ((e = hipMalloc(&c->km, sizeof(KeyMaterial))) != hipSuccess ||
-        (e = hipMalloc(&c->stage1, sizeof(uint4) * AESGCM_GMAX)) != hipSuccess ||
-        (e = hipMalloc(&c->d_counter, 64)) != hipSuccess ||
-        (e = hipMemset(c->d_counter, 0, 64)) != hipSuccess ||
+        (e = hipMalloc(&c->fold_a, sizeof(uint4) * 64 * (AESGCM_MAX_CHUNKS / (FOLD_GROUP * FOLD_WAVES)))) != hipSuccess ||
+        (e = hipMalloc(&c->fold_b, sizeof(uint4) * 64 * (AESGCM_MAX_CHUNKS / 65536 + 4))) != hipSuccess ||
+        (e = hipMalloc(&c->d_counter, 64 * (1 + AESGCM_NQ))) != hipSuccess ||
+        (e = hipMemset(c->d_counter, 0, 64 * (1 + AESGCM_NQ))) != hipSuccess ||
         (e = hipMalloc(&c->d_tag, sizeof(uint4) * 4)) != hipSuccess ||
         (e = hipMalloc(&c->d_trace, sizeof(u64) * 4 * AESGCM_GMAX)) != hipSuccess) { aesgcm_ctx_destroy(c); return hip_fail(e, "hipMalloc"); }
     uint8_t *d_key = nullptr;
@@ -867,6 +907,7 @@ static int ctx_create_common(aesgcm_ctx **out, int device, const uint8_t *key, s
     e = hipMemcpyAsync(d_key, key, kb, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_setup, dim3(1), dim3(AESGCM_WG), 0, c->stream, c->km, c->tables, d_key, (int)key_len, pre_nr, (u32)G);
+        hipLaunchKernelGGL(k_setup_ptab, dim3(AESGCM_NPTAB), dim3(512), 0, c->stream, c->km);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemsetAsync(d_key, 0, 256, c->stream);    // do not leave key bytes behind
@@ -893,7 +934,8 @@ int aesgcm_ctx_destroy(aesgcm_ctx *c) {
     for (auto &e : c->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     if (c->km) { hipMemset(c->km, 0, sizeof(KeyMaterial)); hipFree(c->km); }
     if (c->parts) hipFree(c->parts);
-    if (c->stage1) hipFree(c->stage1);
+    if (c->fold_a) hipFree(c->fold_a);
+    if (c->fold_b) hipFree(c->fold_b);
     if (c->d_counter) hipFree(c->d_counter);
     if (c->d_tag) hipFree(c->d_tag);
     if (c->d_trace) hipFree(c->d_trace);
@@ -1087,7 +1129,7 @@ int aesgcm_ghash(aesgcm_ctx *c, const uint8_t *data, size_t len, uint8_t y[16]) 
     uint8_t iv0[12] = {0};
     // the data rides in the AAD slot of the GHASH sequence (GHASH only, no AES)
     if ((rc = enqueue_main(c, MODE_ENC, iv0, c->st_aad, len, c->st_in, 0, c->st_out, 0, c->stream, &pp))) return rc;
-    if ((rc = enqueue_combine(c, plan_combine_poly(pp.ptr, pp.np, pp.gathered, 1, c->d_tag), c->stream))) return rc;   // Y = P * H
+    if ((rc = enqueue_combine(c, plan_combine_poly(pp.ptr, pp.np, pp.kind, 1, c->d_tag), c->stream))) return rc;   // Y = P * H
     HIPCHK(hipMemcpyAsync(y, c->d_tag, 16, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return AESGCM_OK;
@@ -1113,20 +1155,20 @@ int aesgcm_shard_crypt_dev(aesgcm_ctx *c, int decrypt, const uint8_t iv[12], con
         uint4 *state = c->d_tag + 2;
         HIPCHK(hipMemsetAsync(state, 0, 16, st));
         if ((rc = absorb_range(c, decrypt ? MODE_DEC : MODE_ENC, iv, d_aad, aad_len, d_in, len, d_out, first_block, st, state))) return rc;
-        CombineParams q = plan_combine_poly(nullptr, 0, false, 0, (uint4 *)d_partial);       // W = Y * H^after
+        CombineParams q = plan_combine_poly(nullptr, 0, PARTS_NONE, 0, (uint4 *)d_partial);       // W = Y * H^after
         q.carry = state; q.has_carry = 1; q.e_carry = after;
         return enqueue_combine(c, q, st);
     }
     Partials pp;
     if ((rc = enqueue_main(c, decrypt ? MODE_DEC : MODE_ENC, iv, d_aad, aad_len, d_in, len, d_out, first_block, st, &pp))) return rc;
-    return enqueue_combine(c, plan_combine_poly(pp.ptr, pp.np, pp.gathered, after, (uint4 *)d_partial), st);
+    return enqueue_combine(c, plan_combine_poly(pp.ptr, pp.np, pp.kind, after, (uint4 *)d_partial), st);
 }
 int aesgcm_shard_finalize_dev(aesgcm_ctx *c, const uint8_t iv[12], const void *d_partials, size_t n_partials,
                               size_t aad_len, uint64_t total_len, uint8_t tag[16], void *stream) {
     if (!c || !iv || (n_partials && !d_partials) || n_partials > AESGCM_GMAX) return AESGCM_EARG;
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = pick_stream(c, stream);
-    int rc = enqueue_combine(c, plan_combine_tag((const uint4 *)d_partials, (u32)n_partials, true, iv, aad_len, total_len, c->d_tag), st);
+    int rc = enqueue_combine(c, plan_combine_tag((const uint4 *)d_partials, (u32)n_partials, PARTS_GATHERED, iv, aad_len, total_len, c->d_tag), st);
     if (rc) return rc;
     if (tag) { HIPCHK(hipMemcpyAsync(tag, c->d_tag, 16, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st)); }
     return AESGCM_OK;
@@ -1149,7 +1191,7 @@ static int stream_absorb(aesgcm_ctx *c, const void *d_aad, u64 aad_len, const vo
     if (rc) return rc;
     const u64 nb = (aad_len + 15) / 16 + (len + 15) / 16;
     c->s_blocks += nb;
-    return enqueue_combine(c, plan_combine_carry(pp.ptr, pp.np, pp.gathered, c->d_tag + 1, nb), c->stream);       // Y' = Y * H^nb ^ P
+    return enqueue_combine(c, plan_combine_carry(pp.ptr, pp.np, pp.kind, c->d_tag + 1, nb), c->stream);       // Y' = Y * H^nb ^ P
 }
 int aesgcm_stream_aad(aesgcm_ctx *c, const uint8_t *aad, size_t len) {
     if (!c || (len && !aad)) return AESGCM_EARG;

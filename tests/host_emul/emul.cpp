@@ -40,6 +40,7 @@ static void emu_setup(KeyMaterial *km, const uint8_t *key, int key_len, int pre_
         if (d == 1) for (int tid = 0; tid < AESGCM_WG; tid++) setup_beta_lane(km, tab, tid);
         if (d < 3) { uint4 next = tab[AESGCM_WG]; tab[0] = gf_one_mo(); tab[1] = next; }
     }
+    for (u32 k = 0; k < AESGCM_NPTAB; k++) for (u32 tid = 0; tid < 512; tid++) setup_ptab_lane(km, k, tid);
 }
 
 static void xor_g(G128 &a, const G128 &b) { for (int k = 0; k < 4; k++) a.w[k] ^= b.w[k]; }
@@ -53,13 +54,11 @@ static void emu_main_nr(const KeyMaterial *km, const MainParams &p) {
     // harness walks the chunks in a scrambled order to make any accidental order dependence visible
     for (u32 k = 0; k < p.C; k++) {
         const u32 c = (p.C - 1) - k;      // reverse order
-        G128 fold = {{0, 0, 0, 0}};
         for (u32 lane = 0; lane < 64; lane++) {
             const CtrConsts cc = main_lane_consts<MODE>(km, p, smem, lane);
             uint4 acc = main_chunk_lane<NR, MODE>(km, p, smem, cc, c, lane);
-            if (GH) xor_g(fold, main_lane_tail(acc, main_lane_tailpow(km, lane)));
+            if (GH) p.parts[(size_t)c * 64 + lane] = acc;
         }
-        if (GH) p.parts[c] = be_to_mo(fold);
     }
 }
 static void emu_main(int mode, const KeyMaterial *km, const MainParams &p) {
@@ -74,13 +73,10 @@ static void emu_body_nr(const KeyMaterial *km, const BodyParams &p) {
     for (u32 tid = 0; tid < AESGCM_MAIN_WG; tid++) main_fill_lds(smem, km, &g_tb, tid, true, AESGCM_MAIN_WG, GH_TAB_K256);
     for (u32 k = 0; k < p.C; k++) {
         const u32 c = (k * 7 + 3) % p.C == k ? k : (p.C - 1) - k;      // scrambled order (any permutation will do)
-        G128 fold = {{0, 0, 0, 0}};
         for (u32 lane = 0; lane < 64; lane++) {
             const CtrConsts cc = ctr_round1_consts(p.iv0, p.iv1, p.iv2, km->rk, smem, (lane & 31u) << 2);
-            uint4 acc = body_chunk_lane<NR, MODE>(km, &g_tb, p, smem, cc, c, lane);
-            xor_g(fold, main_lane_tail(acc, main_lane_tailpow(km, lane)));
+            p.parts[(size_t)c * 64 + lane] = body_chunk_lane<NR, MODE>(km, &g_tb, p, smem, cc, c, lane);
         }
-        p.parts[c] = be_to_mo(fold);
     }
 }
 static void emu_body(int mode, const KeyMaterial *km, const BodyParams &p) {
@@ -103,45 +99,58 @@ static void emu_combine(const KeyMaterial *km, const CombineParams &p) {
     *p.out = be_to_mo(acc);
 }
 
-struct Parts { const uint4 *ptr; u32 np; bool gathered; };
+struct Parts { const uint4 *ptr; u32 np; u32 gathered; };   // gathered = PARTS_* kind
 struct Emu {
-    KeyMaterial km; u32 tw; std::vector<uint4> parts, stage1;
-    Emu(const uint8_t *key, int key_len, u32 tw_) : tw(tw_), parts(1 << 16), stage1(AESGCM_GMAX) { emu_setup(&km, key, key_len, 0, 512); }
+    KeyMaterial km; u32 tw; std::vector<uint4> parts, fold_a, fold_b;
+    Emu(const uint8_t *key, int key_len, u32 tw_) : tw(tw_), parts(1 << 16), fold_a(1 << 16), fold_b(1 << 12) { emu_setup(&km, key, key_len, 0, 512); }
+    // mirrors enqueue_fold(): k_fold launches until one item is left
+    Parts fold(const uint4 *items, u32 n, u32 period, u64 eA, u64 eB) {
+        static unsigned char smem[FOLD_LDS_BYTES] __attribute__((aligned(16)));
+        const uint4 *cur = items; int which = 0;
+        while (n > 1) {
+            std::vector<uint4> &ob = which ? fold_b : fold_a;
+            const u32 G = fold_wgs(n);
+            if (ob.size() < (size_t)G * 64) ob.resize((size_t)G * 64);
+            FoldParams f;
+            plan_fold(f, cur, ob.data(), n, period, eA, eB);
+            auto tp = [&](u64 e) -> const uint4 * { int k = ptab_index(e); return k < 0 ? nullptr : km.ptab[k]; };
+            f.tabA = tp(f.eA); f.tabB = tp(f.eB); f.tabC = tp(f.eC);
+            for (u32 tid = 0; tid < FOLD_WG; tid++) {
+                fold_fill_lds(smem, &km, f.tabA, f.eA, 0u, tid, FOLD_WG);
+                if (period > 1) fold_fill_lds(smem, &km, f.tabB, f.eB, 8192u, tid, FOLD_WG);
+                fold_fill_lds(smem, &km, f.tabC, f.eC, 16384u, tid, FOLD_WG);
+            }
+            for (u32 g = 0; g < G; g++) {
+                u32 start, end;
+                const u32 J = fold_wg_range(n, g, &start, &end);
+                for (u32 w = 0; w < J; w++) for (u32 lane = 0; lane < 64; lane++)
+                    *reinterpret_cast<uint4 *>(smem + FOLD_LDS_TAB + w * 1024u + lane * 16u) = fold_wave_lane(f, smem, start, end, J, w, lane);
+                for (u32 lane = 0; lane < 64; lane++) f.out[(size_t)g * 64 + lane] = fold_wg_lane(smem, J, lane);
+            }
+            eA = fold_out_step(f); eB = 0; period = 1; cur = f.out; n = G; which ^= 1;
+        }
+        Parts r = {cur, 1, PARTS_ITEM};
+        return r;
+    }
     // mirrors enqueue_main(): launch + optional k_weigh
     Parts run(int mode, const uint8_t *iv, const void *aad, u64 aad_len, const void *in, u64 len, void *out, u64 first_block) {
         MainParams p; memset(&p, 0, sizeof p);
         u32 C = plan_main(p, mode, tw, iv, aad, aad_len, in, len, out, first_block, nullptr);
         Parts r = {nullptr, 0, false};
         if (!C) return r;
-        if (parts.size() < C) parts.resize(C);
+        if (parts.size() < (size_t)C * 64) parts.resize((size_t)C * 64);
         p.parts = parts.data();
         emu_main(mode, &km, p);
         if (mode != MODE_ENC && mode != MODE_DEC) return r;
-        if (needs_weigh(C, p.Tw)) {
-            u32 nw = (C + AESGCM_WG - 1) / AESGCM_WG;
-            for (u32 w = 0; w < nw; w++) {
-                G128 fold = {{0, 0, 0, 0}};
-                for (u32 tid = 0; tid < AESGCM_WG; tid++) xor_g(fold, weigh_lane(&km, parts.data(), C, (u64)64 * p.Tw, w * AESGCM_WG + tid));
-                stage1[w] = be_to_mo(fold);
-            }
-            r.ptr = stage1.data(); r.np = nw; r.gathered = true;
-        } else { r.ptr = parts.data(); r.np = C; r.gathered = false; }
-        return r;
+        return fold(parts.data(), C, 1, (u64)64 * p.Tw, 0);
     }
-    // mirrors enqueue_body(): k_body + k_weigh with interleaved exponents
+    // mirrors enqueue_body(): k_body + k_fold with the interleaved first level
     Parts run_body(int mode, const uint8_t *iv, const BodySplit &b, const void *in, void *out, u64 first_block) {
         BodyParams p; memset(&p, 0, sizeof p);
-        if (parts.size() < 4 * (size_t)b.S) parts.resize(4 * (size_t)b.S);
+        if (parts.size() < 256 * (size_t)b.S) parts.resize(256 * (size_t)b.S);
         plan_body(p, b, iv, in, out, first_block, parts.data());
         emu_body(mode, &km, p);
-        u32 nw = (p.C + AESGCM_WG - 1) / AESGCM_WG;
-        for (u32 w = 0; w < nw; w++) {
-            G128 fold = {{0, 0, 0, 0}};
-            for (u32 tid = 0; tid < AESGCM_WG; tid++) xor_g(fold, weigh_lane(&km, parts.data(), p.C, (u64)256 * b.T, w * AESGCM_WG + tid, 4, 64));
-            stage1[w] = be_to_mo(fold);
-        }
-        Parts r = {stage1.data(), nw, true};
-        return r;
+        return fold(parts.data(), p.C, 4, 64, (u64)256 * b.T);
     }
     // mirrors absorb_range()
     bool absorb(int mode, const uint8_t *iv, const uint8_t *aad, u64 aad_len, const uint8_t *in, u64 len, uint8_t *out, u64 first_block, u64 body_min, uint4 *Y) {
@@ -382,7 +391,7 @@ static void test_shards(int key_len, u32 G, u64 al, u64 n, int R, u64 seed) {
         first = end;
     }
     uint4 t;
-    emu_combine(&E.km, plan_combine_tag(gathered.data(), R, true, iv.data(), al, n, &t));
+    emu_combine(&E.km, plan_combine_tag(gathered.data(), R, PARTS_GATHERED, iv.data(), al, n, &t));
     CHECK(memcmp(ct.p, ref.p, n) == 0, "shard ct R %d", R);
     CHECK(memcmp(&t, rtag, 16) == 0, "shard tag key %d G %u aad %llu len %llu R %d", key_len, G, (unsigned long long)al, (unsigned long long)n, R);
 }
@@ -413,13 +422,13 @@ static void test_body(int key_len, u32 G, u64 al, u64 n, u64 seed) {
             u64 len = (end == total_blocks ? n : 16 * end) - 16 * first;
             uint4 Y = make_uint4(0, 0, 0, 0);
             nsplit += E.absorb(MODE_ENC, iv.data(), r == 0 ? aad.data() : nullptr, r == 0 ? al : 0, pt.p + 16 * first, len, ct2.p + 16 * first, first, 4096, &Y);
-            CombineParams q = plan_combine_poly(nullptr, 0, false, 0, &gathered[r]);
+            CombineParams q = plan_combine_poly(nullptr, 0, PARTS_NONE, 0, &gathered[r]);
             q.carry = &Y; q.has_carry = 1; q.e_carry = total_blocks - end;
             emu_combine(&E.km, q);
             first = end;
         }
         uint4 t;
-        emu_combine(&E.km, plan_combine_tag(gathered.data(), R, true, iv.data(), al, n, &t));
+        emu_combine(&E.km, plan_combine_tag(gathered.data(), R, PARTS_GATHERED, iv.data(), al, n, &t));
         CHECK(nsplit > 0, "no shard took the split");
         CHECK(memcmp(ct2.p, ref.p, n) == 0 && memcmp(&t, rtag, 16) == 0, "body shards R %d key %d G %u", R, key_len, G);
     }
@@ -505,6 +514,8 @@ int main(int argc, char **argv) {
     if (level > 1) {
         test_key(32, 1, 7, {{123, 16 * 64 * 1100 + 11}});     // 1100 chunks: two stage-1 workgroups
         test_key(16, 0, 8, {{0, 16 * W * 600}});              // production rule, > GMAX chunks of Tw = 16
+        test_key(24, 1, 10, {{5, 16 * 64 * 4200 + 3}});        // 4200 one-row chunks: three k_fold levels
+        test_body(32, 1, 9, 16 * (200 + 256 * 1100) + 7, 105);  // 4400 body items: interleaved first level + two more
     }
     printf(g_fail ? "EMUL FAILED (%d)\n" : "EMUL OK\n", g_fail);
     return g_fail ? 1 : 0;
