@@ -4,18 +4,19 @@
 //   k_init_tables   per device, once: S-box (256 B) and T0 (1 KiB) computed from their definitions.
 //   k_setup         per key: aes_kexp (or pre-expanded load), H = E_K(0), H-power tables, nibble table of K.
 //   k_main<NR,MODE> the hot path: fused AES-CTR + GHASH partial evaluation (also ECB / keystream modes).
-//   k_weigh         large messages: weights every chunk partial to the end of the sequence (H^e, generic e).
-//   k_combine       per message: folds the workgroup partials with powers of beta = H^WG, optional
-//                   H^e weighting (shards / streaming), length block, E_K(J0) -> tag.
-//   k_gfmul, k_fill small utility kernels.
+//   k_body<NR,MODE> the aligned middle of very large ranges: rounds 1-2 without LDS lookups.
+//   k_fold          reduces the chunks' items (64 lane accumulators each) by Horner with wave-uniform constants.
+//   k_combine       per message: H^(63-L) on the last item, lane fold, optional H^e weighting / chaining value
+//                   (shards, streaming), length block, E_K(J0) -> tag.
+//   k_batch, k_pkt, k_pktl   packets: own key per packet / one key, one wave or one lane per packet.
+//   k_gfmul, k_fill, k_copy16 small utility kernels.
 //
 // GHASH re-association (DESIGN.md "GHASH as a polynomial"): the GHASH input sequence
 // A_0..A_{u-1}, C_0..C_{c-1} (n = u + c blocks) is right-aligned into rows of 64 slots (front padding =
-// zeros, which do not change a polynomial) and cut into chunks of Tw rows.  Waves pull chunks from an atomic
-// dispenser; inside a chunk lane L runs Horner over its column with the per-key constant K = H^64
-// (acc = acc*K ^ X), multiplies by H^(63-L) and the wave XOR-folds to the chunk partial
-// P_c = sum_{i in chunk} X_i H^(end_c-1-i).  Folding P = sum_c P_c H^(n-end_c) happens in k_combine
-// (directly when the chunk spacing equals the table radix, after k_weigh otherwise).
+// zeros, which do not change a polynomial) and cut into chunks of Tw rows.  Waves pull chunks from atomic
+// dispensers; inside a chunk lane L runs Horner over its column with the per-key constant K = H^64
+// (acc = acc*K ^ X) and the wave stores the 64 accumulators as the chunk's item.  k_fold folds the items
+// lane-wise (B_L = sum_i item_i[L] * H^(blocks to the end)), k_combine forms P = sum_L B_L * H^(63-L).
 // The tag is (P*H ^ L)*H ^ E_K(J0) = P*H^2 ^ L*H ^ E_K(J0).
 #include "aesgcm_dev.h"
 #include "../../include/aesgcm.h"
@@ -62,7 +63,7 @@ __global__ void k_fill_splitmix64(u64 *buf, size_t n_words, size_t tail_bytes, u
 // ------------------------------------------------------------------------------------------------
 // k_setup: one workgroup of 512 lanes, once per key.
 //   lane 0      : key schedule (aes_kexp) or pre-expanded copy, H = E_K(0)  (gcm_gctr.vhd:141-144)
-//   all lanes   : four 513-entry power tables by doubling (9 multiply levels each), bp2, nibble table of K.
+//   all lanes   : four 1025-entry power tables by doubling, nibble tables of H^64, H, H^256 (k_setup_ptab adds H^(2^k)).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(AESGCM_WG) void k_setup(KeyMaterial *km, const DevTables *tb, const uint8_t *key, int key_len,
                                                      int preexpanded_nr, u32 G) {
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(512) void k_setup_ptab(KeyMaterial *km) { setup_pta
 
 // ------------------------------------------------------------------------------------------------
 // k_combine: one workgroup, per message.
-//   acc = sum_g parts[g] * M_g  where M_g = beta^(np-1-g) (local partials) or 1 (gathered, already weighted)
+//   acc = sum_L item[L] * H^(63-L)  (the last k_fold item)  or  sum_g parts[g]  (gathered shard partials, already weighted)
 //   POLY: out = acc * H^e                                (shard partial W_g, streaming state, aesgcm_ghash)
 //   TAG : out = acc*H^2 ^ L*H ^ E_K(IV||1)               (gcm_ghash.vhd:257 length block, :293 tag)
 //   a previous chaining value `carry` (streaming) enters as carry * H^(e_carry).

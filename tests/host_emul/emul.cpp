@@ -132,7 +132,7 @@ struct Emu {
         Parts r = {cur, 1, PARTS_ITEM};
         return r;
     }
-    // mirrors enqueue_main(): launch + optional k_weigh
+    // mirrors enqueue_main(): launch + k_fold levels
     Parts run(int mode, const uint8_t *iv, const void *aad, u64 aad_len, const void *in, u64 len, void *out, u64 first_block) {
         MainParams p; memset(&p, 0, sizeof p);
         u32 C = plan_main(p, mode, tw, iv, aad, aad_len, in, len, out, first_block, nullptr);
@@ -489,8 +489,8 @@ int main(int argc, char **argv) {
     const u64 W = AESGCM_WG;     // blocks per chunk at the production Tw = 16
     const std::vector<std::pair<u64, u64>> small = {{0, 0}, {0, 1}, {0, 15}, {0, 16}, {0, 17}, {1, 0}, {20, 48}, {28, 48}, {68, 0}, {16, 63 * 16}, {17, 64 * 16}, {0, 65 * 16 + 5},
                                                     {16, (W - 1) * 16}, {17, W * 16}, {0, (W + 1) * 16 + 5}, {4095, 4097}};
-    test_key(16, 0, 1, small);          // production chunking rule (Tw = 16: direct fold with the beta tables)
-    test_key(24, 1, 2, small);          // Tw = 1: every row its own chunk -> k_weigh path, many chunks
+    test_key(16, 0, 1, small);          // production chunking rule
+    test_key(24, 1, 2, small);          // Tw = 1: every row its own chunk -> many items, in-kernel fold tables where 64*Tw*16^l is not in ptab
     test_key(32, 3, 3, small);          // Tw = 3: ragged first chunk
     // several rows per chunk (Horner with K = H^64), ragged tails, front padding, > GMAX chunks
     test_key(16, 0, 4, {{0, 16 * W * 3}, {5, 16 * W * 2 + 7}, {33, 16 * (W * 3 - 36) + 1}});
