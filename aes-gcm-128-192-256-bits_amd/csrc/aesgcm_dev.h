@@ -41,6 +41,23 @@ HD u32 rotl32(u32 x, int r) { return (x << r) | (x >> (32 - r)); }
 
 HD G128 mo_to_be(uint4 m) { G128 g; g.w[0] = bswap32(m.x); g.w[1] = bswap32(m.y); g.w[2] = bswap32(m.z); g.w[3] = bswap32(m.w); return g; }
 HD uint4 be_to_mo(G128 g) { return make_uint4(bswap32(g.w[0]), bswap32(g.w[1]), bswap32(g.w[2]), bswap32(g.w[3])); }
+// 16-byte accesses to device memory that is known to be global: the pointers reach the kernels inside parameter
+// structs as generic pointers, and a flat_load is served in 64-byte L2 requests where a global_load gets 128-byte
+// ones (TCC_READ per byte: 1/62 vs 1/91, profiles/pmc_tcc.sh)
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef u32 gvec4_t __attribute__((ext_vector_type(4)));
+HD uint4 gload16(const void *p) {
+    const gvec4_t v = *(const __attribute__((address_space(1))) gvec4_t *)(uintptr_t)p;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+HD void gstore16(void *p, uint4 v) {
+    gvec4_t w = {v.x, v.y, v.z, v.w};
+    *(__attribute__((address_space(1))) gvec4_t *)(uintptr_t)p = w;
+}
+#else
+HD uint4 gload16(const void *p) { return *reinterpret_cast<const uint4 *>(p); }
+HD void gstore16(void *p, uint4 v) { *reinterpret_cast<uint4 *>(p) = v; }
+#endif
 HD uint4 xor4(uint4 a, uint4 b) { return make_uint4(a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w); }
 
 // v_perm_b32: result byte i = pool[sel.byte[i]] with pool = {src1 bytes 0..3, src0 bytes 4..7},
@@ -342,7 +359,7 @@ struct MainParams {
     uint4 *ej0;                  // GHASH modes: where the wave that owns chunk 0 leaves E_K(IV || 1) for k_combine (or NULL)
 };
 
-#define AESGCM_MAX_CHUNKS (1u << 18)   /* 64 lane accumulators (1 KiB) per chunk: at most 256 MiB of them, three k_fold launches */
+#define AESGCM_MAX_CHUNKS (1u << 19)   /* 64 lane accumulators (1 KiB) per chunk: at most 512 MiB of them, three k_fold launches */
 
 // Chunking of a GHASH sequence of n_seq blocks: rows of 64 blocks, Tw rows per chunk.  A chunk costs its rows, a
 // dispenser fetch and a 1 KiB item store; ~8k waves are resident and a lone wave needs ~10 us per row when the CU is
@@ -503,9 +520,9 @@ HD uint4 main_chunk_lane(const KeyMaterial *__restrict__ km, const MainParams &p
             const unsigned char *src = reinterpret_cast<const unsigned char *>(uniform64((u64)(uintptr_t)p.in + 16 * i0));
             unsigned char *dst = reinterpret_cast<unsigned char *>(uniform64((u64)(uintptr_t)p.out + 16 * i0));
             uint4 x = make_uint4(0, 0, 0, 0);
-            if (MODE != MODE_KS) x = *reinterpret_cast<const uint4 *>(src + lane16);
+            if (MODE != MODE_KS) x = gload16(src + lane16);
             const uint4 y = main_block<NR, MODE>(rk, smem, cc, lb, x, p.ctr0 + (u32)i0 + lane);
-            *reinterpret_cast<uint4 *>(dst + lane16) = y;
+            gstore16(dst + lane16, y);
             if (GH) acc = xor4(acc, (MODE == MODE_DEC) ? x : y);          // aes_gcm.vhd:207-211
             continue;
         }
@@ -712,11 +729,11 @@ HD uint4 body_chunk_lane(const KeyMaterial *__restrict__ km, const DevTables *__
         const u64 off = ((u64)q * 4 + v) * 1024;                       // byte offset of the row in the body
         const unsigned char *src = reinterpret_cast<const unsigned char *>(uniform64((u64)(uintptr_t)p.in + off));
         unsigned char *dst = reinterpret_cast<unsigned char *>(uniform64((u64)(uintptr_t)p.out + off));
-        const uint4 x = *reinterpret_cast<const uint4 *>(src + lane16);
+        const uint4 x = gload16(src + lane16);
         u32 s0, s1, s2, s3;
         body_rounds<NR>(p.ctr_hi0 + q, b, cc, s0, s1, s2, s3, rk, tb, smem, lb);
         const uint4 y = make_uint4(x.x ^ s0, x.y ^ s1, x.z ^ s2, x.w ^ s3);                  // gcm_gctr.vhd:150
-        *reinterpret_cast<uint4 *>(dst + lane16) = y;
+        gstore16(dst + lane16, y);
         acc = xor4(acc, (MODE == MODE_DEC) ? x : y);                  // aes_gcm.vhd:207-211
     }
     return acc;

@@ -20,9 +20,12 @@ def main(out):
         print("== kernel stats", os.path.relpath(p, out))
         for r in rows(p):
             print("  %-70s calls %6s  avg %12s ns  total %14s ns  %6s%%" % (r.get("Name", "")[:70], r.get("Calls"), r.get("AverageNs"), r.get("TotalDurationNs"), r.get("Percentage")))
-            if "k_main" in r.get("Name", ""):
-                summ["k_main_avg_ns"] = float(r["AverageNs"])
-                summ["k_main_calls"] = int(r["Calls"])
+            # the fused kernel of the run: k_body for split ranges, else k_main -- whichever took most of the time
+            if ("k_main" in r.get("Name", "") or "k_body" in r.get("Name", "")) and float(r["TotalDurationNs"]) > summ.get("_hot_total", 0.0):
+                summ["_hot_total"] = float(r["TotalDurationNs"])
+                summ["hot_kernel"] = r["Name"].split("(")[0].replace("void ", "")
+                summ["hot_avg_ns"] = float(r["AverageNs"])
+                summ["hot_calls"] = int(r["Calls"])
     for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
         if not os.path.isdir(d):
             continue
@@ -39,8 +42,9 @@ def main(out):
             for r in rows(p):
                 disp[r.get("Kernel_Name", "")].add(r.get("Dispatch_Id"))
             print("== pmc", os.path.relpath(p, out))
+            hot = summ.get("hot_kernel", "k_main")
             for k in acc:
-                if "k_main" not in k:
+                if hot not in k:
                     continue
                 n = len(disp[k])
                 print("  %s  dispatches %d  vgpr/sgpr/lds/wg/grid %s" % (k[:60], n, info[k]))
