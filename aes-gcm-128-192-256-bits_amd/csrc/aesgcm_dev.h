@@ -655,16 +655,19 @@ static inline int ptab_index(u64 e) {
 }
 
 // ---- k_body pieces -----------------------------------------------------------------------------
-// The aligned middle of a large message: data blocks whose counters start at a multiple of 256 and that fill
-// whole super-chunks of 4*T rows.  A wave owns one PHASE v of a super-chunk: rows 4q + v, q = s*T .. s*T + T-1.
-// Then (aes_icb.vhd:97-118: counter = IV || cnt, cnt in bytes 12..15 big-endian)
-//   byte 15 of a lane's counter is 64v + lane for the whole chunk,
-//   bytes 12..14 are the same for all lanes of a row,
-// so after round 1 only column 0 of the state differs between lanes (and is a per-chunk constant of the lane), and
-// every round-2 output column is  P_j(lane) ^ U_j(row):  P_j = the one table value that comes from column 0 (four
-// VGPRs, computed once per chunk), U_j = the three row-uniform table values, the round key and the round-1
-// constants (scalar: table reads with wave-uniform indices go through the scalar cache, not LDS).
-// Rounds 1 and 2 therefore cost no LDS lookup in the row loop: 192 instead of 212 per AES-256 block.
+// The aligned middle of a large message: data blocks from a block index (within the message) that is a multiple
+// of 256, in whole super-chunks of 4*T rows; row m holds blocks [64 m, 64 m + 64) -- aligned in memory as well
+// as in the message.  A wave owns one PHASE v of a super-chunk: rows 4q + v, q = s*T .. s*T + T-1.
+// The counter of block i is i + 2 (aes_icb.vhd:97-118: IV || cnt, cnt in bytes 12..15 big-endian), so in a row
+//   lanes 0..61  have counter 256 q + 64 v + lane + 2:      byte 15 = 64 v + lane + 2,   bytes 12..14 = hi24(q)
+//   lanes 62, 63 have counter 256 q + 64 (v+1) + lane - 62:  byte 15 = 64 (v+1) + lane - 62 (mod 256),
+//                                                            bytes 12..14 = hi24(q), or hi24(q + 1) when v = 3.
+// Byte 15 of a lane is a constant of the chunk, bytes 12..14 are wave-uniform per row (two values in phase 3).
+// After round 1 only column 0 of the state depends on byte 15, and every round-2 output column is
+// P_j(lane) ^ U_j(row):  P_j = the one table value that comes from column 0 (four VGPRs, computed once per chunk),
+// U_j = the three row-uniform table values, the round key and the round-1 constants (scalar: table reads with
+// wave-uniform indices go through the scalar cache, not LDS).  Rounds 1 and 2 therefore cost no LDS lookup in the
+// row loop: 192 instead of 212 per AES-256 block.
 // GHASH: the lane's blocks are 256 apart, Horner constant H^256 (main_fill_lds(GH_TAB_K256)).
 struct BodyParams {
     const unsigned char *in;     // first body block (16-byte aligned)
@@ -673,7 +676,7 @@ struct BodyParams {
     u32 *counter; u32 nq, seg; u32 qbase[AESGCM_NQ];      // as in MainParams
     u32 T;                       // rows per chunk (iterations of a wave), super-chunk = 4*T rows = 256*T blocks
     u32 C;                       // chunks = 4 * super-chunks
-    u32 ctr_hi0;                 // (counter of body block 0) >> 8; its low byte is 0 by construction
+    u32 ctr_hi0;                 // (message block index of body block 0) >> 8; the index is a multiple of 256
     u32 iv0, iv1, iv2;
     u64 *trace;
 };
@@ -686,7 +689,8 @@ HD u32 tu3(const DevTables *__restrict__ tb, u32 x) { return tb->te3[x & 0xFFu];
 // per-chunk lane constants: column 0 after round 1, and its four round-2 table values
 HD BodyLane body_lane_consts(const u32 *__restrict__ rk, const CtrConsts &cc, const unsigned char *lds, u32 v, u32 lane) {
     const u32 lb = (lane & 31u) << 2;
-    const u32 w3 = ((64u * v + lane) << 24) ^ rk[3];                   // only byte 3 (= counter byte 15) is used
+    const u32 b15 = lane < 62 ? 64u * v + lane + 2u : (64u * (v + 1u) + lane - 62u) & 0xFFu;
+    const u32 w3 = (b15 << 24) ^ rk[3];                                // only byte 3 (= counter byte 15) is used
     const u32 s0 = cc.c0 ^ rotl32(T2_AT(lds, w3, 3, lb), 8);
     BodyLane b;
     b.p0 = T0_AT(lds, s0, 0, lb);
@@ -695,21 +699,25 @@ HD BodyLane body_lane_consts(const u32 *__restrict__ rk, const CtrConsts &cc, co
     b.p3 = rotl32(T0_AT(lds, s0, 1, lb), 8);
     return b;
 }
-// keystream block of (row-uniform counter bytes 12..14 = hi24, lane constants b): rounds 1-2 from P ^ U, then 3..NR
-template <int NR>
-HD void body_rounds(u32 hi24, const BodyLane &b, const CtrConsts &cc, u32 &s0, u32 &s1, u32 &s2, u32 &s3,
-                    const u32 *__restrict__ rk, const DevTables *__restrict__ tb, const unsigned char *lds, u32 lb) {
+// the row-uniform part of the state after round 2 for counter bytes 12..14 = hi24
+struct BodyRow { u32 U0, U1, U2, U3; };
+HD BodyRow body_uniform(u32 hi24, const CtrConsts &cc, const u32 *__restrict__ rk, const DevTables *__restrict__ tb) {
     // counter bytes 12, 13, 14 = hi24 big-endian; memory-order word 3 holds them in bytes 0, 1, 2 (byte 3 is the lane's)
     const u32 k3 = rk[3];
-    const u32 u1 = cc.c1 ^ tu2(tb, hi24 ^ (k3 >> 16));                 // columns 1..3 after round 1: row-uniform
+    const u32 u1 = cc.c1 ^ tu2(tb, hi24 ^ (k3 >> 16));                 // columns 1..3 after round 1
     const u32 u2 = cc.c2 ^ tu1(tb, (hi24 >> 8) ^ (k3 >> 8));
     const u32 u3 = cc.c3 ^ tu0(tb, (hi24 >> 16) ^ k3);
     const u32 *__restrict__ k2 = rk + 8;
-    const u32 U0 = tu2(tb, u2 >> 16) ^ k2[0] ^ tu1(tb, u1 >> 8) ^ tu3(tb, u3 >> 24);
-    const u32 U1 = tu0(tb, u1) ^ tu2(tb, u3 >> 16) ^ k2[1] ^ tu1(tb, u2 >> 8);
-    const u32 U2 = tu0(tb, u2) ^ k2[2] ^ tu1(tb, u3 >> 8) ^ tu3(tb, u1 >> 24);
-    const u32 U3 = tu0(tb, u3) ^ tu2(tb, u1 >> 16) ^ k2[3] ^ tu3(tb, u2 >> 24);
-    s0 = b.p0 ^ U0; s1 = b.p1 ^ U1; s2 = b.p2 ^ U2; s3 = b.p3 ^ U3;
+    BodyRow r;
+    r.U0 = tu2(tb, u2 >> 16) ^ k2[0] ^ tu1(tb, u1 >> 8) ^ tu3(tb, u3 >> 24);
+    r.U1 = tu0(tb, u1) ^ tu2(tb, u3 >> 16) ^ k2[1] ^ tu1(tb, u2 >> 8);
+    r.U2 = tu0(tb, u2) ^ k2[2] ^ tu1(tb, u3 >> 8) ^ tu3(tb, u1 >> 24);
+    r.U3 = tu0(tb, u3) ^ tu2(tb, u1 >> 16) ^ k2[3] ^ tu3(tb, u2 >> 24);
+    return r;
+}
+// rounds 3..NR from the state after round 2
+template <int NR>
+HD void body_rounds(u32 &s0, u32 &s1, u32 &s2, u32 &s3, const u32 *__restrict__ rk, const unsigned char *lds, u32 lb) {
 #pragma unroll
     for (int r = 3; r < NR; r++) aes_round_lds(s0, s1, s2, s3, rk + 4 * r, lds, lb);
     aes_final_lds(s0, s1, s2, s3, rk + 4 * NR, lds, lb);
@@ -730,8 +738,14 @@ HD uint4 body_chunk_lane(const KeyMaterial *__restrict__ km, const DevTables *__
         const unsigned char *src = reinterpret_cast<const unsigned char *>(uniform64((u64)(uintptr_t)p.in + off));
         unsigned char *dst = reinterpret_cast<unsigned char *>(uniform64((u64)(uintptr_t)p.out + off));
         const uint4 x = gload16(src + lane16);
-        u32 s0, s1, s2, s3;
-        body_rounds<NR>(p.ctr_hi0 + q, b, cc, s0, s1, s2, s3, rk, tb, smem, lb);
+        const BodyRow u = body_uniform(p.ctr_hi0 + q, cc, rk, tb);
+        u32 s0 = b.p0 ^ u.U0, s1 = b.p1 ^ u.U1, s2 = b.p2 ^ u.U2, s3 = b.p3 ^ u.U3;
+        if (v == 3) {                                                  // wave-uniform: lanes 62, 63 are already in the next 256-block
+            const BodyRow n = body_uniform(p.ctr_hi0 + q + 1, cc, rk, tb);
+            const u32 m = lane >= 62 ? 0xFFFFFFFFu : 0u;
+            s0 ^= m & (u.U0 ^ n.U0); s1 ^= m & (u.U1 ^ n.U1); s2 ^= m & (u.U2 ^ n.U2); s3 ^= m & (u.U3 ^ n.U3);
+        }
+        body_rounds<NR>(s0, s1, s2, s3, rk, smem, lb);
         const uint4 y = make_uint4(x.x ^ s0, x.y ^ s1, x.z ^ s2, x.w ^ s3);                  // gcm_gctr.vhd:150
         gstore16(dst + lane16, y);
         acc = xor4(acc, (MODE == MODE_DEC) ? x : y);                  // aes_gcm.vhd:207-211
@@ -823,12 +837,12 @@ static inline u32 plan_main(MainParams &p, int mode, u32 tw_override, const uint
     return C;
 }
 // Split of a data range for k_body: [head blocks][body = S super-chunks of 256*T blocks][tail].  The body starts at
-// the first block whose counter (2 + first_block + i, aes_icb.vhd:97-100) is a multiple of 256 and holds only whole
-// 16-byte blocks.  Returns false when the range is too small to be worth three launches (min_bytes).
+// the first block whose index in the message (first_block + i) is a multiple of 256 -- no head at all for a whole
+// message or a shard cut at such an index -- and holds only whole 16-byte blocks.  Returns false when the range is too small to be worth three launches (min_bytes).
 struct BodySplit { u64 head_blocks, body_blocks; u32 T, S; };
 static inline bool plan_body_split(u64 len, u64 first_block, u32 tw_override, u64 min_bytes, BodySplit *b) {
     const u64 nfull = len / 16;
-    const u64 head = (256 - ((2 + first_block) & 255)) & 255;
+    const u64 head = (256 - (first_block & 255)) & 255;                // to the next multiple of 256 of the message block index
     if (nfull <= head) return false;
     const u64 rows = (nfull - head) / 64;
     u64 R; u32 Tw, C;
@@ -844,7 +858,7 @@ static inline bool plan_body_split(u64 len, u64 first_block, u32 tw_override, u6
 static inline void plan_body(BodyParams &p, const BodySplit &b, const uint8_t *iv, const void *in, void *out, u64 first_block, uint4 *parts) {
     p.in = (const unsigned char *)in + 16 * b.head_blocks; p.out = (unsigned char *)out + 16 * b.head_blocks;
     p.parts = parts; p.T = b.T; p.C = 4 * b.S;
-    p.ctr_hi0 = (u32)((2 + first_block + b.head_blocks) >> 8);
+    p.ctr_hi0 = (u32)((first_block + b.head_blocks) >> 8);
     u32 w[3]; iv_to_words(iv, w); p.iv0 = w[0]; p.iv1 = w[1]; p.iv2 = w[2];
 }
 // whole-message tag from the folded item:  P*H^2 ^ L*H ^ E_K(J0)

@@ -554,8 +554,8 @@ struct aesgcm_ctx {
     u32 counter_base = 0;              // value the packet dispenser (d_counter[0]) holds before the next launch
     u32 mq_base[AESGCM_NQ] = {0};      // the same for the chunk queues of k_main / k_body (d_counter[16 (1 + q)])
     u32 tw_override = 0;               // AESGCM_TW
-    u64 body_min = (u64)3 << 30;       // ranges with an aligned middle of at least this many bytes go through k_body (AESGCM_BODY_MIN):
-                                       // the cut costs ~110 us of extra launches, break-even measured at ~2.5 GiB (profiles/split_threshold.py)
+    u64 body_min = (u64)1 << 30;       // ranges with an aligned middle of at least this many bytes go through k_body (AESGCM_BODY_MIN):
+                                       // the extra launches cost ~50 us, break-even measured near 0.7 GiB (profiles/split_threshold.py)
     uint4 *d_tag = nullptr;            // [0] tag / poly result, [1] streaming state Y
     u64 *d_trace = nullptr;            // per-workgroup trace of the last k_main launch (timing mode only)
     u32 last_np = 0;

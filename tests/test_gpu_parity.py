@@ -301,7 +301,7 @@ def test_plain_c_caller(hip):
 @pytest.mark.gpu
 @pytest.mark.parametrize("tw", ["", "1", "3"])
 def test_body_split_forced_on_small_messages(hip, orc, monkeypatch, tw):
-    """The head / k_body / tail cut (aesgcm_ctx_split) normally starts at 3 GiB; AESGCM_BODY_MIN brings it down so that
+    """The head / k_body / tail cut (aesgcm_ctx_split) normally starts at 1 GiB; AESGCM_BODY_MIN brings it down so that
     whole messages, decrypts and shards with odd first blocks run through k_body at sizes the oracle checks in full."""
     monkeypatch.setenv("AESGCM_BODY_MIN", "4096")
     if tw:
@@ -311,7 +311,7 @@ def test_body_split_forced_on_small_messages(hip, orc, monkeypatch, tw):
         c, f = hip.Context(key), orc.Fast(key)
         for n, al in ((16 * 3000 + 5, 0), (16 * (254 + 2048 * 3 + 777) + 11, 20), (1 << 20, 37), (16 * 254 + 16 * 1024 * 2, 16), (3 << 20 | 7, 0)):
             head, body = c.split(n)
-            assert body > 0 and head == 254, (n, head, body)
+            assert body > 0 and head == 0, (n, head, body)          # a whole message starts at block 0: no head
             aad, pt = splitmix_bytes(702 + al, al), splitmix_bytes(703 + n % 97, n)
             want_ct, want_tag = f.encrypt(iv, aad, pt)
             assert c.encrypt(iv, aad, pt) == (want_ct, want_tag), (klen, n, al, "enc")
@@ -329,7 +329,8 @@ def test_body_split_forced_on_small_messages(hip, orc, monkeypatch, tw):
             blocks = total_blocks // ranks + (1 if r < total_blocks % ranks else 0)
             end = first + blocks
             ln = (n if end == total_blocks else 16 * end) - 16 * first
-            assert c.split(ln, first)[1] > 0
+            sh, sb = c.split(ln, first)
+            assert sb > 0 and sh == (-first) % 256, (first, sh, sb)
             c.shard_crypt_dev(False, iv, din.ptr + 16 * first, ln, dout.ptr + 16 * first, first, n, parts.ptr + 16 * r,
                               d_aad=d_aad.ptr if r == 0 else None, aad_len=al if r == 0 else 0)
             first = end
