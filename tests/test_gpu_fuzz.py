@@ -88,3 +88,29 @@ def test_fuzz_random_shard_splits(hip, orc):
         tag = ctx.shard_finalize_dev(iv, parts.ptr, ranks, al, n)
         assert tag == want[1], (it, ranks, bounds, al, n)
         assert bytes(d_out.download(n)) == want[0]
+
+
+@pytest.mark.parametrize("body", [False, True])
+def test_fold_level_boundaries(hip, orc, monkeypatch, body):
+    """k_fold reduces 256 items per launch (16 per wave): chunk counts on both sides of 16, 256 and 65536, with
+    one-row chunks so that the count is the row count; once through k_main alone, once with the k_body cut forced
+    (interleaved items, period-4 first level)."""
+    monkeypatch.setenv("AESGCM_TW", "1")
+    monkeypatch.setenv("AESGCM_BODY_MIN", "4096" if body else str(1 << 60))
+    key, iv = splitmix_bytes(4201, 32), splitmix_bytes(4202, 12)
+    ctx, f = hip.Context(key), orc.Fast(key)
+    counts = (1, 2, 15, 16, 17, 255, 256, 257, 4095, 4096, 4097, 65535, 65536, 65537)
+    for rows in counts:
+        for extra, al in ((0, 0), (5, 20)):
+            n = rows * 1024 + extra - (1024 if extra else 0) + (16 if extra else 0)      # ragged variant: one block + 5 bytes less/more
+            n = max(n, 1)
+            aad = splitmix_bytes(4300 + rows, al)
+            d_in = hip.DeviceBuffer(n + 32); d_in.fill_splitmix64(4400 + rows, 0, nbytes=n)
+            pt = bytes(d_in.download(n))
+            want = f.encrypt(iv, aad, pt)
+            d_aad = hip.DeviceBuffer(max(al, 16)); d_aad.upload(aad)
+            tag = ctx.encrypt_dev(iv, d_in.ptr, n, d_in.ptr, d_aad=d_aad.ptr if al else None, aad_len=al)   # in place
+            assert tag == want[1], (rows, n, al, body)
+            assert bytes(d_in.download(n)) == want[0], (rows, n, al, body)
+            if body and n >= 16 * 256 * 4:
+                assert ctx.split(n)[1] > 0
