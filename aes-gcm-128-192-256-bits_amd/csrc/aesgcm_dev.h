@@ -679,6 +679,7 @@ struct BodyParams {
     u32 ctr_hi0;                 // (message block index of body block 0) >> 8; the index is a multiple of 256
     u32 iv0, iv1, iv2;
     u64 *trace;
+    uint4 *ej0;                  // where the wave that owns chunk 0 leaves E_K(IV || 1) for k_combine (or NULL)
 };
 struct BodyLane { u32 p0, p1, p2, p3; };
 // wave-uniform table values (host: plain loads; device: scalar loads from the global T0 table)

@@ -196,6 +196,11 @@ __global__ __launch_bounds__(AESGCM_MAIN_WG, AESGCM_WAVES_PER_SIMD) void k_body(
         if (c >= p.C) continue;
         const uint4 acc = body_chunk_lane<NR, MODE>(km, tb, p, smem, cc, c, lane);
         p.parts[(size_t)c * 64 + lane] = acc;
+        if (c == 0 && p.ej0) {                                  // E_K(IV || 1) for the tag, once per launch (as in k_main)
+            u32 s0, s1, s2, s3;
+            ctr_rounds_lds<NR>(bswap32(1u), cc, s0, s1, s2, s3, km->rk, smem, (lane & 31u) << 2);
+            if (lane == 0) *p.ej0 = make_uint4(s0, s1, s2, s3);
+        }
         ++done;
     }
     if (p.trace && lane == 0) {
@@ -719,6 +724,7 @@ static int enqueue_body(aesgcm_ctx *c, int mode, const uint8_t iv[12], const Bod
     int rc = grow_parts(c, (size_t)4 * b.S);
     if (rc) return rc;
     plan_body(p, b, iv, d_in, d_out, first_block, c->parts);
+    p.ej0 = c->d_tag + 3; po->ej0 = p.ej0;
     const u32 waves_per_wg = AESGCM_MAIN_WG / 64;
     u32 wgs = (p.C + waves_per_wg - 1) / waves_per_wg;
     if (wgs > (u32)c->G) wgs = (u32)c->G;
@@ -752,7 +758,7 @@ static int enqueue_body(aesgcm_ctx *c, int mode, const uint8_t iv[12], const Bod
 // Y' = Y * H^nb ^ P(aad, data) for a whole range, Y in *state (device).  Large ranges go head / k_body / tail,
 // each piece folded into the state in order; small ones are a single k_main launch.
 static int absorb_range(aesgcm_ctx *c, int mode, const uint8_t iv[12], const void *d_aad, u64 aad_len, const void *d_in, u64 len,
-                        void *d_out, u64 first_block, hipStream_t st, uint4 *state) {
+                        void *d_out, u64 first_block, hipStream_t st, uint4 *state, const uint4 **ej0 = nullptr) {
     BodySplit b;
     Partials pp;
     int rc;
@@ -771,6 +777,7 @@ static int absorb_range(aesgcm_ctx *c, int mode, const uint8_t iv[12], const voi
         if ((rc = enqueue_combine(c, plan_combine_carry(pp.ptr, pp.np, pp.kind, state, n_aad + b.head_blocks), st))) return rc;
     }
     if ((rc = enqueue_body(c, mode, iv, b, d_in, d_out, first_block, st, &pp))) return rc;
+    if (ej0) *ej0 = pp.ej0;                                      // valid until the next launch on this context overwrites the slot: consumed by the caller's final combine
     if ((rc = enqueue_combine(c, plan_combine_carry(pp.ptr, pp.np, pp.kind, state, b.body_blocks), st))) return rc;
     const u64 done = b.head_blocks + b.body_blocks, tail = len - 16 * done;
     if (tail) {
@@ -809,8 +816,11 @@ static int crypt_dev(aesgcm_ctx *c, int dec, const uint8_t iv[12], const void *d
         // large message: head / k_body / tail folded into a device-side chaining value, then the tag from it
         uint4 *state = c->d_tag + 2;
         HIPCHK(hipMemsetAsync(state, 0, 16, st));
-        if ((rc = absorb_range(c, dec ? MODE_DEC : MODE_ENC, iv, d_aad, aad_len, d_in, len, d_out, 0, st, state))) return rc;
-        return enqueue_combine(c, plan_combine_final(state, iv, aad_len, len, c->d_tag), st);
+        const uint4 *ej0 = nullptr;
+        if ((rc = absorb_range(c, dec ? MODE_DEC : MODE_ENC, iv, d_aad, aad_len, d_in, len, d_out, 0, st, state, &ej0))) return rc;
+        CombineParams q = plan_combine_final(state, iv, aad_len, len, c->d_tag);
+        q.ej0 = ej0;                                             // left by k_body (every piece of this message writes the same value)
+        return enqueue_combine(c, q, st);
     }
     Partials pp;
     rc = enqueue_main(c, dec ? MODE_DEC : MODE_ENC, iv, d_aad, aad_len, d_in, len, d_out, 0, st, &pp);
