@@ -1197,7 +1197,7 @@ HD void pktl_lane(const KeyMaterial *__restrict__ km, const PktParams &p, const 
     }
 }
 
-// SplitMix64 at word position w; shared with oracle/aesgcm_oracle.c by definition.
+// SplitMix64 at word position w: a definition, restated independently by the CPU checker.
 HD u64 splitmix64_at(u64 seed, u64 w) {
     u64 z = seed + (w + 1) * 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;

@@ -50,3 +50,19 @@ def tweak_iv(iv, tweak):
     b = bytearray(iv)
     b[11] = (b[11] + tweak) & 0xFF
     return bytes(b)
+
+
+def splitmix64_bytes(seed, nbytes, first_word=0):
+    """The synthetic stream of SURVEY.md 8(d) on the host (keys, IVs): 64-bit little-endian word w of stream `seed`
+    is SplitMix64 evaluated at position w.  Same definition as aesgcm_fill_splitmix64_dev."""
+    M = (1 << 64) - 1
+    out = bytearray()
+    w = first_word
+    while len(out) < nbytes:
+        z = (seed + (w + 1) * 0x9E3779B97F4A7C15) & M
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        z ^= z >> 31
+        out += z.to_bytes(8, "little")
+        w += 1
+    return bytes(out[:nbytes])

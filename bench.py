@@ -179,13 +179,12 @@ def main():
 
     import aesgcm_amd  # noqa: F401
     from aesgcm_amd import lib, sharding
-    from oracle import oracle as O          # cpu_baseline leg + fixture cross-check only
 
     dev = local
     per_gpu = int(args.gib_per_gpu * GiB) // (16 * 2 * N) * (16 * 2 * N)
     kbytes = args.key_bits // 8
-    key = bytes(O.fill_splitmix64(kbytes, KEY_SEED))
-    iv0 = bytes(O.fill_splitmix64(12, IV_SEED))
+    key = sharding.splitmix64_bytes(KEY_SEED, kbytes)           # key and IV from the synthetic streams
+    iv0 = sharding.splitmix64_bytes(IV_SEED, 12)
 
     ctx = lib.Context(key, device=dev)
     geo = ctx.geometry()

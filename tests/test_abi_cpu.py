@@ -89,3 +89,35 @@ def test_plain_c_caller_builds_and_fails_loudly_without_gpu():
         assert r.returncode == 0 and "KAT OK" in r.stdout, r.stderr
     else:
         assert r.returncode != 0 and "-6" in r.stderr, (r.returncode, r.stderr)
+
+
+def test_oracle_is_only_used_where_allowed():
+    """oracle/ is test infrastructure: besides tests/, only __graft_entry__ (build + smoke) and the cpu_baseline leg of
+    bench.py may touch it; the package, the examples and the profiling scripts never do."""
+    import ast
+    import glob
+    offenders = []
+    files = glob.glob(os.path.join(ROOT, "aes-gcm-128-192-256-bits_amd", "**", "*.py"), recursive=True)
+    files += glob.glob(os.path.join(ROOT, "profiles", "**", "*.py"), recursive=True) + [os.path.join(ROOT, "aesgcm_amd.py")]
+    for f in files:
+        if re.search(r"^\s*(from|import)\s+oracle", open(f).read(), re.M):
+            offenders.append(f)
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    for node in tree.body:
+        inside = node.name if isinstance(node, ast.FunctionDef) else None
+        for sub in ast.walk(node):
+            if isinstance(sub, (ast.Import, ast.ImportFrom)):
+                names = [a.name for a in sub.names] + [getattr(sub, "module", "") or ""]
+                if any(n.split(".")[0] == "oracle" for n in names) and inside != "cpu_baseline":
+                    offenders.append("bench.py:%s" % (inside or "<module>"))
+    for f in glob.glob(os.path.join(ROOT, "examples", "*")) + glob.glob(os.path.join(ROOT, "aes-gcm-128-192-256-bits_amd", "csrc", "*")):
+        if os.path.isfile(f) and not f.endswith((".so", ".s")) and b"oracle/" in open(f, "rb").read():
+            offenders.append(f)
+    assert not offenders, offenders
+
+
+def test_host_splitmix_matches_the_oracle_generator():
+    from aesgcm_amd import sharding
+    from oracle import oracle as O
+    for seed, n, w in ((0x4B4559, 32, 0), (0x4956, 12, 0), (7, 100, 0), (5, 24, 3)):
+        assert sharding.splitmix64_bytes(seed, n, w) == bytes(O.fill_splitmix64(n, seed, w))
