@@ -22,6 +22,21 @@ __global__ __launch_bounds__(1024) void k_rows_phase(const uint4 *__restrict__ s
         for (u64 i = 0; i < T; i++) { const u64 row = 4 * (s * T + i) + v; dst[row * 64 + lane] = src[row * 64 + lane]; }
     }
 }
+// the same two patterns at the fused kernels' pace (one row per ~8 us per wave) and with k_body's 2 x 1024-lane workgroups
+// per CU: do requests change size when the rows of a neighbourhood are touched far apart in time?
+template <int PHASE>
+__global__ __launch_bounds__(1024) void k_rows_slow(const uint4 *__restrict__ src, uint4 *__restrict__ dst, u64 chunks) {
+    const u64 wave = (u64)blockIdx.x * 16 + (threadIdx.x >> 6), nw = (u64)gridDim.x * 16, lane = threadIdx.x & 63;
+    for (u64 c = wave; c < chunks; c += nw) {
+        const u64 s = c >> 2, v = c & 3;
+        for (u64 i = 0; i < T; i++) {
+            const u64 row = PHASE ? 4 * (s * T + i) + v : c * T + i;
+            const uint4 x = src[row * 64 + lane];
+            __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127);
+            dst[row * 64 + lane] = x;
+        }
+    }
+}
 int main() {
     const u64 bytes = 4ull << 30, rows = bytes / 1024, chunks = rows / T;
     uint4 *a, *b;
@@ -31,6 +46,8 @@ int main() {
         hipLaunchKernelGGL(k_rows_contiguous, dim3(512), dim3(1024), 0, 0, a, b, chunks);
         hipLaunchKernelGGL(k_rows_phase, dim3(512), dim3(1024), 0, 0, a, b, chunks);
     }
+    hipLaunchKernelGGL(k_rows_slow<0>, dim3(512), dim3(1024), 0, 0, a, b, chunks);
+    hipLaunchKernelGGL(k_rows_slow<1>, dim3(512), dim3(1024), 0, 0, a, b, chunks);
     hipDeviceSynchronize();
     printf("copied %llu bytes per launch (read) + the same written\n", bytes);
     return 0;
