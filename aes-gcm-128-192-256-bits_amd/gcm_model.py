@@ -12,7 +12,7 @@ Additionally it exports the one-shot bulk entry points BASELINE.json's north_sta
 """
 import logging
 
-from . import lib
+from . import lib, sharding
 from .lib import AesGcmError, AuthenticationError   # noqa: F401
 
 try:                                    # tb/gcm_model.py:2
@@ -26,12 +26,15 @@ class gcm:
 
     gcm(key, icb, ed) with key = {'data': HEX, 'n_bytes': 16|24|32}, icb = {'data': HEX, 'n_bytes': 12},
     ed = 'enc' | 'dec'.  The harness feeds all AAD first (<= 16 bytes per call), then data (16 bytes per call,
-    only the last may be shorter).  Every load_plain_text / load_cipher_text call appends its output chunk to
+    only the last may be shorter); like pycryptodome, any chunking is accepted.  Every load_plain_text / load_cipher_text call appends its output chunk to
     `data_out` before returning; get_tag(dut_tag) appends exactly one 16-byte entry to `tag`:
       enc : the tag this model computed;
       dec : the received tag if it authenticates, otherwise its bitwise complement, which makes the
             scoreboard comparison fail (the reference's convention, tb/gcm_model.py:47-51).
     """
+
+    _FLUSH = 1 << 16            # bytes of data handed to the GPU per GHASH absorption
+    _KS_MIN, _KS_MAX = 1 << 16, 1 << 22
 
     def __init__(self, key, icb, ed, device=0):
         self.ed = ed
@@ -43,20 +46,37 @@ class gcm:
             raise ValueError("the IP core and this model support 96-bit IVs only (src/gcm_pkg.vhd:15-17)")
         self.model = lib.Context(key_bytes, device=device)      # key load: on-GPU key expansion + H tables
         self.model.stream_begin(iv_bytes, decrypt=(ed != 'enc'))
+        self._iv = iv_bytes
         self._final_tag = None
+        # The harness calls once per 16-byte beat and needs the output chunk before the call returns.  A GPU round
+        # trip per beat would cost ~60 us each, so the beats are answered from a keystream the GPU produced ahead
+        # (aesgcm_keystream: E_K(IV || 2+i) is data-independent, src/gcm_gctr.vhd:141-150) and the inputs are handed
+        # to the GPU for GHASH (and a re-check of the outputs) in blocks of _FLUSH bytes and at get_tag.
+        self._aad = bytearray()
+        self._aad_sent = False
+        self._pend_in = bytearray()
+        self._pend_out = bytearray()
+        self._pos = 0                       # bytes of data seen so far
+        self._ks = b""
+        self._ks_off = 0                    # byte position of self._ks[0] in the keystream
+        self._ks_next = self._KS_MIN
 
     # -- monitor callbacks (tb/gcm_test.py:76-85) ---------------------------------------------------
     def load_aad(self, aad):
-        self._call(self.model.stream_aad, aad)
+        if self._pos or self._final_tag is not None:
+            # pycryptodome raises TypeError when update() follows encrypt()/decrypt()
+            raise TypeError("AAD must precede data")
+        self._aad += bytes(aad)
 
     def load_plain_text(self, pt):
-        self.data_out.append(self._call(self.model.stream_update, pt))
+        self.data_out.append(self._crypt(bytes(pt)))
 
     def load_cipher_text(self, ct):
-        self.data_out.append(self._call(self.model.stream_update, ct))
+        self.data_out.append(self._crypt(bytes(ct)))
 
     def get_tag(self, tag):
         if self._final_tag is None:
+            self._flush(final=True)
             self._final_tag = self.model.stream_final()
         mine = self._final_tag
         if self.ed == 'enc':
@@ -76,13 +96,52 @@ class gcm:
             self.tag.append(flipped.to_bytes(16, 'big'))
 
     # -- helpers -----------------------------------------------------------------------------------
-    def _call(self, fn, data):
+    def _crypt(self, chunk):
+        if self._final_tag is not None:
+            raise TypeError("the message is already finalised")
+        n = len(chunk)
+        if self._pos + n > sharding.MAX_MESSAGE:
+            raise ValueError("message exceeds the GCM length limit")           # aes_icb.vhd:114
+        if not n:
+            return b""
+        lo = self._pos - self._ks_off
+        if lo < 0 or lo + n > len(self._ks):
+            first = self._pos // 16
+            nblocks = max(self._ks_next // 16, (self._pos + n + 15) // 16 - first)
+            nblocks = min(nblocks, (sharding.MAX_MESSAGE + 31) // 16 - first)
+            self._ks = self._call(self.model.keystream, self._iv, first, nblocks)
+            self._ks_off = 16 * first
+            self._ks_next = min(2 * self._ks_next, self._KS_MAX)
+            lo = self._pos - self._ks_off
+        out = (int.from_bytes(chunk, 'big') ^ int.from_bytes(self._ks[lo:lo + n], 'big')).to_bytes(n, 'big')
+        self._pend_in += chunk
+        self._pend_out += out
+        self._pos += n
+        if len(self._pend_in) >= self._FLUSH:
+            self._flush(final=False)
+        return out
+
+    def _flush(self, final):
+        """GHASH absorption on the GPU: the AAD once, then the buffered inputs in whole blocks (everything at the end).
+        The GPU recomputes the outputs as well; they must equal what the keystream produced."""
+        if not self._aad_sent:
+            if self._aad:
+                self._call(self.model.stream_aad, bytes(self._aad))
+            self._aad_sent = True
+        whole = len(self._pend_in) if final else len(self._pend_in) // 16 * 16
+        if whole:
+            out = self._call(self.model.stream_update, bytes(self._pend_in[:whole]))
+            if out != bytes(self._pend_out[:whole]):
+                raise RuntimeError("keystream path and fused path disagree")
+            del self._pend_in[:whole]
+            del self._pend_out[:whole]
+
+    def _call(self, fn, *args):
         try:
-            return fn(bytes(data))
+            return fn(*args)
         except AesGcmError as e:
             if e.code == lib.ESTATE:
-                # pycryptodome raises TypeError for out-of-order calls (update() after encrypt())
-                raise TypeError("AAD must precede data and only the last chunk may be ragged") from e
+                raise TypeError("calls out of order") from e
             if e.code == lib.ETOOLONG:
                 raise ValueError("message exceeds the GCM length limit") from e
             raise

@@ -70,10 +70,21 @@ def test_out_of_order_calls_raise_like_pycryptodome(hip):
     m.load_plain_text(bytes(16))
     with pytest.raises(TypeError):
         m.load_aad(b"late aad")
-    m2 = gcm_model.gcm(_hexdict(bytes(16)), _hexdict(bytes(12)), 'enc')
-    m2.load_plain_text(b"short")          # ragged chunk: must be the last one
+    # any chunking is legal, as with pycryptodome's encrypt(): ragged chunks in the middle included
+    key, iv, aad = splitmix_bytes(21, 24), splitmix_bytes(22, 12), splitmix_bytes(23, 37)
+    pt = splitmix_bytes(24, 200001)
+    m2 = gcm_model.gcm(_hexdict(key), _hexdict(iv), 'enc')
+    m2.load_aad(aad[:5]); m2.load_aad(aad[5:])
+    o, sizes = 0, (5, 16, 1, 31, 70000, 64, 3)
+    k = 0
+    while o < len(pt):
+        n = sizes[k % len(sizes)]; k += 1
+        m2.load_plain_text(pt[o:o + n]); o += n
+    m2.get_tag(bytes(16))
+    want = gcm_model.encrypt(key, iv, aad, pt)
+    assert (b"".join(m2.data_out), m2.tag[0]) == want
     with pytest.raises(TypeError):
-        m2.load_plain_text(bytes(16))
+        m2.load_plain_text(b"after the tag")
 
 
 def test_chunked_stream_large_chunks(hip, orc):
