@@ -11,5 +11,6 @@ is no CPU fallback: if the shared library or a GPU is missing the calls raise.
 from . import lib            # noqa: F401
 from . import gcm_model      # noqa: F401
 from . import sharding       # noqa: F401
+from . import comm           # noqa: F401
 from .gcm_model import gcm, encrypt, decrypt, AesGcmError, AuthenticationError   # noqa: F401
 from .build import build     # noqa: F401

@@ -12,7 +12,7 @@ def needs_build():
     if not os.path.exists(SO):
         return True
     t = os.path.getmtime(SO)
-    srcs = [os.path.join(CSRC, f) for f in ("aesgcm_kernels.hip", "aesgcm_dev.h", "Makefile")]
+    srcs = [os.path.join(CSRC, f) for f in ("aesgcm_kernels.hip", "aesgcm_comm.hip", "aesgcm_dev.h", "Makefile")]
     srcs.append(os.path.join(os.path.dirname(HERE), "include", "aesgcm.h"))
     return any(os.path.getmtime(s) > t for s in srcs)
 

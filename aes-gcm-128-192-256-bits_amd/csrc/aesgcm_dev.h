@@ -328,7 +328,7 @@ struct KeyMaterial {         // per context (device memory)
     uint8_t rk_bytes[240];   // expanded key as the byte string tb/key_exp.py produces
 };
 
-enum { MODE_ENC = 0, MODE_DEC = 1, MODE_KS = 2, MODE_ECB = 3 };
+enum { MODE_ENC = 0, MODE_DEC = 1, MODE_KS = 2, MODE_ECB = 3, MODE_PROBE = 4 };   // PROBE (k_body only): ENC without the global load and store
 
 // One atomic address serves ~87 M fetches/s on MI355X (measured): a single dispenser caps a launch at one chunk per
 // 11.5 ns, i.e. chunks shorter than ~10 rows run at the dispenser's speed, not the kernel's.  Chunks are therefore
@@ -738,7 +738,9 @@ HD uint4 body_chunk_lane(const KeyMaterial *__restrict__ km, const DevTables *__
         const u64 off = ((u64)q * 4 + v) * 1024;                       // byte offset of the row in the body
         const unsigned char *src = reinterpret_cast<const unsigned char *>(uniform64((u64)(uintptr_t)p.in + off));
         unsigned char *dst = reinterpret_cast<unsigned char *>(uniform64((u64)(uintptr_t)p.out + off));
-        const uint4 x = gload16(src + lane16);
+        // MODE_PROBE: the same instruction stream without HBM traffic -- the ceiling of the formulation itself
+        // (aesgcm_ctx_ceiling_probe); the "plaintext" is a lane/row pattern and the ciphertext only feeds GHASH
+        const uint4 x = (MODE == MODE_PROBE) ? make_uint4(lane, q, v, 0u) : gload16(src + lane16);
         const BodyRow u = body_uniform(p.ctr_hi0 + q, cc, rk, tb);
         u32 s0 = b.p0 ^ u.U0, s1 = b.p1 ^ u.U1, s2 = b.p2 ^ u.U2, s3 = b.p3 ^ u.U3;
         if (v == 3) {                                                  // wave-uniform: lanes 62, 63 are already in the next 256-block
@@ -748,7 +750,7 @@ HD uint4 body_chunk_lane(const KeyMaterial *__restrict__ km, const DevTables *__
         }
         body_rounds<NR>(s0, s1, s2, s3, rk, smem, lb);
         const uint4 y = make_uint4(x.x ^ s0, x.y ^ s1, x.z ^ s2, x.w ^ s3);                  // gcm_gctr.vhd:150
-        gstore16(dst + lane16, y);
+        if (MODE != MODE_PROBE) gstore16(dst + lane16, y);
         acc = xor4(acc, (MODE == MODE_DEC) ? x : y);                  // aes_gcm.vhd:207-211
     }
     return acc;
@@ -759,6 +761,7 @@ HD uint4 body_chunk_lane(const KeyMaterial *__restrict__ km, const DevTables *__
 enum { PARTS_NONE = 0, PARTS_GATHERED = 1, PARTS_ITEM = 2 };
 struct CombineParams {
     const uint4 *parts; u32 np; u32 kind;   // GATHERED: np weighted 16-byte partials (shards); ITEM: one 64-lane item of k_fold
+    u32 stride;                  // GATHERED: distance between consecutive partials in 16-byte units (0 = 1): an all-gather of M messages' partials leaves [rank][message]
     u32 want_tag;                // 1 = TAG, 0 = POLY
     u64 e;                       // POLY: exponent applied to the folded partials
     const uint4 *carry; u64 e_carry; u32 has_carry;
@@ -775,7 +778,7 @@ HD G128 combine_lane(const KeyMaterial *__restrict__ km, const uint8_t *sbox, co
         // lane L of the last item carries H^(63-L); TAG mode needs the polynomial times H^2 (tag = P*H^2 ^ L*H ^ E_K(J0))
         z = gf_mul(mo_to_be(p.parts[tid]), mo_to_be(km->pw[0][63 - tid + (tag ? 2 : 0)]));
     } else if (p.kind == PARTS_GATHERED && tid < p.np) {
-        z = mo_to_be(p.parts[tid]);
+        z = mo_to_be(p.parts[(size_t)tid * (p.stride ? p.stride : 1u)]);
         if (tag) z = gf_mul(z, mo_to_be(km->pw[0][2]));
     } else if (tag && tid == AESGCM_GMAX) {
         // length block [8*len(A)]_64 || [8*len(C)]_64 (gcm_ghash.vhd:257) times H

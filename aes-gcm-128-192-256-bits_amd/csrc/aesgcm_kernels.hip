@@ -585,6 +585,7 @@ struct aesgcm_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
 };
 
+static void pipeline_release(aesgcm_ctx *c);
 static inline hipStream_t pick_stream(aesgcm_ctx *c, void *s) { return s ? (hipStream_t)s : c->stream; }
 
 static const u64 MAX_DATA = (((u64)1) << 36) - 32;      // aes_icb.vhd:114
@@ -621,6 +622,7 @@ static int set_lds_attrs(int device, DeviceState *ds) {
 #undef SETATTR
 #define SETATTRY(NR, MODE) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_body<NR, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, AESGCM_LDS_BYTES))
     SETATTRY(10, MODE_ENC); SETATTRY(12, MODE_ENC); SETATTRY(14, MODE_ENC); SETATTRY(10, MODE_DEC); SETATTRY(12, MODE_DEC); SETATTRY(14, MODE_DEC);
+    SETATTRY(10, MODE_PROBE); SETATTRY(12, MODE_PROBE); SETATTRY(14, MODE_PROBE);
 #undef SETATTRY
 #define SETATTRB(NR, D) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch<NR, D>), hipFuncAttributeMaxDynamicSharedMemorySize, BATCH_LDS_BYTES)); \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pkt<NR, D>), hipFuncAttributeMaxDynamicSharedMemorySize, AESGCM_LDS_BYTES)); \
@@ -741,8 +743,9 @@ static int enqueue_body(aesgcm_ctx *c, int mode, const uint8_t iv[12], const Bod
         HIPCHK(hipEventRecord(evp.first, st));
     }
 #define LY(NR, M) hipLaunchKernelGGL((k_body<NR, M>), dim3(wgs), dim3(AESGCM_MAIN_WG), AESGCM_LDS_BYTES, st, c->km, c->tables, p)
-    if (mode == MODE_DEC) { if (c->nr == 10) LY(10, MODE_DEC); else if (c->nr == 12) LY(12, MODE_DEC); else LY(14, MODE_DEC); }
-    else                  { if (c->nr == 10) LY(10, MODE_ENC); else if (c->nr == 12) LY(12, MODE_ENC); else LY(14, MODE_ENC); }
+    if (mode == MODE_DEC)        { if (c->nr == 10) LY(10, MODE_DEC); else if (c->nr == 12) LY(12, MODE_DEC); else LY(14, MODE_DEC); }
+    else if (mode == MODE_PROBE) { if (c->nr == 10) LY(10, MODE_PROBE); else if (c->nr == 12) LY(12, MODE_PROBE); else LY(14, MODE_PROBE); }
+    else                         { if (c->nr == 10) LY(10, MODE_ENC); else if (c->nr == 12) LY(12, MODE_ENC); else LY(14, MODE_ENC); }
 #undef LY
     const hipError_t le = hipGetLastError();
     if (le != hipSuccess) {
@@ -950,14 +953,7 @@ int aesgcm_ctx_destroy(aesgcm_ctx *c) {
     if (c->d_counter) hipFree(c->d_counter);
     if (c->d_tag) hipFree(c->d_tag);
     if (c->d_trace) hipFree(c->d_trace);
-    for (int i = 0; i < 2; i++) {
-        if (c->pl_buf[i]) hipFree(c->pl_buf[i]);
-        if (c->pl_ev_h2d[i]) hipEventDestroy(c->pl_ev_h2d[i]);
-        if (c->pl_ev_k[i]) hipEventDestroy(c->pl_ev_k[i]);
-        if (c->pl_ev_d2h[i]) hipEventDestroy(c->pl_ev_d2h[i]);
-    }
-    if (c->pl_in) hipStreamDestroy(c->pl_in);
-    if (c->pl_out) hipStreamDestroy(c->pl_out);
+    pipeline_release(c);
     if (c->st_in) hipFree(c->st_in);
     if (c->st_out) hipFree(c->st_out);
     if (c->st_aad) hipFree(c->st_aad);
@@ -966,6 +962,11 @@ int aesgcm_ctx_destroy(aesgcm_ctx *c) {
     return AESGCM_OK;
 }
 int aesgcm_ctx_device(const aesgcm_ctx *c) { return c ? c->device : AESGCM_EARG; }
+int aesgcm_ctx_stream(const aesgcm_ctx *c, void **stream) {
+    if (!c || !stream) return AESGCM_EARG;
+    *stream = (void *)c->stream;
+    return AESGCM_OK;
+}
 int aesgcm_ctx_geometry(const aesgcm_ctx *c, int *n_wg, int *wg_lanes, int *lds_bytes) {
     if (!c) return AESGCM_EARG;
     if (n_wg) *n_wg = c->G;
@@ -1174,15 +1175,22 @@ int aesgcm_shard_crypt_dev(aesgcm_ctx *c, int decrypt, const uint8_t iv[12], con
     if ((rc = enqueue_main(c, decrypt ? MODE_DEC : MODE_ENC, iv, d_aad, aad_len, d_in, len, d_out, first_block, st, &pp))) return rc;
     return enqueue_combine(c, plan_combine_poly(pp.ptr, pp.np, pp.kind, after, (uint4 *)d_partial), st);
 }
-int aesgcm_shard_finalize_dev(aesgcm_ctx *c, const uint8_t iv[12], const void *d_partials, size_t n_partials,
-                              size_t aad_len, uint64_t total_len, uint8_t tag[16], void *stream) {
+int aesgcm_shard_finalize_strided_dev(aesgcm_ctx *c, const uint8_t iv[12], const void *d_partials, size_t n_partials, size_t stride_bytes,
+                                      size_t aad_len, uint64_t total_len, uint8_t tag[16], void *stream) {
     if (!c || !iv || (n_partials && !d_partials) || n_partials > AESGCM_GMAX) return AESGCM_EARG;
+    if (stride_bytes < 16 || (stride_bytes & 15) || stride_bytes / 16 > 0xFFFFFFFFull) return AESGCM_EARG;
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = pick_stream(c, stream);
-    int rc = enqueue_combine(c, plan_combine_tag((const uint4 *)d_partials, (u32)n_partials, PARTS_GATHERED, iv, aad_len, total_len, c->d_tag), st);
+    CombineParams q = plan_combine_tag((const uint4 *)d_partials, (u32)n_partials, PARTS_GATHERED, iv, aad_len, total_len, c->d_tag);
+    q.stride = (u32)(stride_bytes / 16);
+    int rc = enqueue_combine(c, q, st);
     if (rc) return rc;
     if (tag) { HIPCHK(hipMemcpyAsync(tag, c->d_tag, 16, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st)); }
     return AESGCM_OK;
+}
+int aesgcm_shard_finalize_dev(aesgcm_ctx *c, const uint8_t iv[12], const void *d_partials, size_t n_partials,
+                              size_t aad_len, uint64_t total_len, uint8_t tag[16], void *stream) {
+    return aesgcm_shard_finalize_strided_dev(c, iv, d_partials, n_partials, 16, aad_len, total_len, tag, stream);
 }
 
 // ---------------------------------------------------------------- streaming
@@ -1373,22 +1381,40 @@ int aesgcm_batch_crypt_var_dev(int device, int decrypt, size_t n_pkts, size_t ke
 // H2D of chunk k+1, the fused kernel on chunk k and D2H of chunk k-1 overlap on three streams; the GHASH
 // value is carried from chunk to chunk on the device (Y' = Y*H^blocks ^ P, the same combine the beat-by-beat
 // interface uses), so the result is bit-identical to one launch over the whole message.
+static void pipeline_release(aesgcm_ctx *c) {
+    for (int i = 0; i < 2; i++) {
+        if (c->pl_buf[i]) { hipFree(c->pl_buf[i]); c->pl_buf[i] = nullptr; }
+        if (c->pl_ev_h2d[i]) { hipEventDestroy(c->pl_ev_h2d[i]); c->pl_ev_h2d[i] = nullptr; }
+        if (c->pl_ev_k[i]) { hipEventDestroy(c->pl_ev_k[i]); c->pl_ev_k[i] = nullptr; }
+        if (c->pl_ev_d2h[i]) { hipEventDestroy(c->pl_ev_d2h[i]); c->pl_ev_d2h[i] = nullptr; }
+    }
+    if (c->pl_in) { hipStreamDestroy(c->pl_in); c->pl_in = nullptr; }
+    if (c->pl_out) { hipStreamDestroy(c->pl_out); c->pl_out = nullptr; }
+    c->pl_cap = 0;
+}
+// all or nothing: either both streams, all six events and both chunk slots of `chunk` bytes exist afterwards, or none
+// of them does (pl_in == NULL, pl_cap == 0) and the next call starts from scratch
 static int pipeline_prepare(aesgcm_ctx *c, size_t chunk) {
+    hipError_t e = hipSuccess;
     if (!c->pl_in) {
-        HIPCHK(hipStreamCreateWithFlags(&c->pl_in, hipStreamNonBlocking));
-        HIPCHK(hipStreamCreateWithFlags(&c->pl_out, hipStreamNonBlocking));
-        for (int i = 0; i < 2; i++) {
-            HIPCHK(hipEventCreateWithFlags(&c->pl_ev_h2d[i], hipEventDisableTiming));
-            HIPCHK(hipEventCreateWithFlags(&c->pl_ev_k[i], hipEventDisableTiming));
-            HIPCHK(hipEventCreateWithFlags(&c->pl_ev_d2h[i], hipEventDisableTiming));
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->pl_in, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->pl_out, hipStreamNonBlocking);
+        for (int i = 0; i < 2 && e == hipSuccess; i++) {
+            e = hipEventCreateWithFlags(&c->pl_ev_h2d[i], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&c->pl_ev_k[i], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&c->pl_ev_d2h[i], hipEventDisableTiming);
         }
+        if (e != hipSuccess) { pipeline_release(c); return hip_fail(e, "pipeline streams/events"); }
     }
     if (chunk > c->pl_cap) {
-        for (int i = 0; i < 2; i++) {
-            if (c->pl_buf[i]) { HIPCHK(hipFree(c->pl_buf[i])); c->pl_buf[i] = nullptr; }
-            hipError_t e = hipMalloc((void **)&c->pl_buf[i], chunk);
-            if (e == hipErrorOutOfMemory) { c->pl_cap = 0; return AESGCM_ENOMEM; }
-            if (e != hipSuccess) return hip_fail(e, "hipMalloc");
+        c->pl_cap = 0;
+        for (int i = 0; i < 2 && e == hipSuccess; i++) {
+            if (c->pl_buf[i]) { e = hipFree(c->pl_buf[i]); c->pl_buf[i] = nullptr; }
+            if (e == hipSuccess) e = hipMalloc((void **)&c->pl_buf[i], chunk);
+        }
+        if (e != hipSuccess) {
+            pipeline_release(c);
+            return e == hipErrorOutOfMemory ? AESGCM_ENOMEM : hip_fail(e, "pipeline chunk slots");
         }
         c->pl_cap = chunk;
     }
@@ -1399,6 +1425,9 @@ static int crypt_pipelined(aesgcm_ctx *c, int dec, const uint8_t iv[12], const u
                            const uint8_t *in, size_t len, uint8_t *out, uint8_t tag[16], size_t chunk) {
     int rc = check_lengths(aad_len, len);
     if (rc) return rc;
+    // the chunk-to-chunk GHASH value lives in the streaming slot (d_tag[1], s_iv, s_dec): refuse to run inside an open
+    // stream_begin .. stream_final session instead of silently corrupting its running GHASH
+    if (c->s_active) return AESGCM_ESTATE;
     if (!chunk) chunk = (size_t)64 << 20;
     chunk = (chunk + 1023) / 1024 * 1024;                    // whole rows, 16-byte aligned chunk starts
     if (chunk > len) chunk = (len + 1023) / 1024 * 1024;
@@ -1534,6 +1563,33 @@ int aesgcm_ctx_timing_read(aesgcm_ctx *c, uint64_t *n, double *total_ms, int res
     if (n) *n = c->ev.size();
     if (total_ms) *total_ms = tot;
     if (reset) { for (auto &e : c->ev) c->ev_pool.push_back(e); c->ev.clear(); }
+    return AESGCM_OK;
+}
+
+// The fused kernel's instruction stream WITHOUT its HBM traffic: k_body<NR, MODE_PROBE> over a virtual range of `nbytes`
+// (same chunking, same dispensers, same LDS tables, same scalar loads, same GHASH; no global load, no global store
+// except the chunk items).  Its time is the ceiling of the T-table formulation on this chip at this moment's clocks.
+int aesgcm_ctx_ceiling_probe(aesgcm_ctx *c, size_t nbytes, double *ms, uint64_t *blocks) {
+    if (!c || !ms) return AESGCM_EARG;
+    HIPCHK(hipSetDevice(c->device));
+    BodySplit b;
+    if (!plan_body_split(nbytes, 0, c->tw_override, 0, &b)) return AESGCM_EARG;
+    const uint8_t iv[12] = {0};
+    Partials pp;
+    const bool was = c->timing;
+    c->timing = true;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const size_t mark = c->ev.size();
+    int rc = enqueue_body(c, MODE_PROBE, iv, b, nullptr, nullptr, 0, c->stream, &pp);
+    c->timing = was;
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    float t = 0;
+    HIPCHK(hipEventElapsedTime(&t, c->ev[mark].first, c->ev[mark].second));
+    c->ev_pool.push_back(c->ev[mark]);
+    c->ev.erase(c->ev.begin() + (long)mark);
+    *ms = t;
+    if (blocks) *blocks = b.body_blocks;
     return AESGCM_OK;
 }
 

@@ -10,21 +10,25 @@ import os
 
 from .build import SO, build
 
-OK, EARG, EKEYLEN, EIVLEN, ETOOLONG, EAUTH, EHIP, ENOMEM, ESTATE, EALIGN = 0, -1, -2, -3, -4, -5, -6, -7, -8, -9
+OK, EARG, EKEYLEN, EIVLEN, ETOOLONG, EAUTH, EHIP, ENOMEM, ESTATE, EALIGN, ERCCL = 0, -1, -2, -3, -4, -5, -6, -7, -8, -9, -10
 
 # every symbol include/aesgcm.h declares (tests check the .so exports exactly these)
 SYMBOLS = [
     "aesgcm_abi_version", "aesgcm_strerror", "aesgcm_last_error", "aesgcm_device_count", "aesgcm_device_name",
     "aesgcm_key_expand", "aesgcm_ecb_encrypt", "aesgcm_gfmul", "aesgcm_ghash", "aesgcm_get_h",
-    "aesgcm_ctx_create", "aesgcm_ctx_create_preexpanded", "aesgcm_ctx_destroy", "aesgcm_ctx_device",
+    "aesgcm_ctx_create", "aesgcm_ctx_create_preexpanded", "aesgcm_ctx_destroy", "aesgcm_ctx_device", "aesgcm_ctx_stream",
     "aesgcm_encrypt_pipelined", "aesgcm_decrypt_pipelined", "aesgcm_host_alloc", "aesgcm_host_free",
     "aesgcm_encrypt", "aesgcm_decrypt", "aesgcm_encrypt_dev", "aesgcm_decrypt_dev", "aesgcm_last_tag",
     "aesgcm_keystream", "aesgcm_keystream_dev",
-    "aesgcm_shard_crypt_dev", "aesgcm_shard_finalize_dev", "aesgcm_batch_crypt_dev", "aesgcm_batch_crypt_var_dev", "aesgcm_packets_crypt_dev",
+    "aesgcm_shard_crypt_dev", "aesgcm_shard_finalize_dev", "aesgcm_shard_finalize_strided_dev", "aesgcm_batch_crypt_dev", "aesgcm_batch_crypt_var_dev", "aesgcm_packets_crypt_dev",
     "aesgcm_stream_begin", "aesgcm_stream_aad", "aesgcm_stream_update", "aesgcm_stream_final",
     "aesgcm_dev_alloc", "aesgcm_dev_free", "aesgcm_dev_upload", "aesgcm_dev_download", "aesgcm_dev_sync", "aesgcm_dev_copy",
     "aesgcm_fill_splitmix64_dev",
     "aesgcm_ctx_timing_enable", "aesgcm_ctx_timing_read", "aesgcm_ctx_geometry", "aesgcm_ctx_split", "aesgcm_ctx_wg_trace",
+    "aesgcm_ctx_ceiling_probe",
+    "aesgcm_comm_last_error", "aesgcm_comm_unique_id", "aesgcm_comm_create", "aesgcm_comm_ranks", "aesgcm_comm_allgather_dev",
+    "aesgcm_comm_allreduce_f64", "aesgcm_comm_barrier", "aesgcm_comm_destroy",
+    "aesgcm_mgpu_create", "aesgcm_mgpu_ranks", "aesgcm_mgpu_crypt_dev", "aesgcm_mgpu_destroy",
 ]
 
 
@@ -51,8 +55,7 @@ def load():
     global _L
     if _L is not None:
         return _L
-    if not os.path.exists(SO):
-        build()
+    build()                       # no-op when the .so is newer than csrc/ and include/aesgcm.h; tolerates a missing hipcc if a prebuilt .so exists
     L = ctypes.CDLL(SO)
     L.aesgcm_strerror.restype = cp
     L.aesgcm_strerror.argtypes = [cint]
@@ -68,6 +71,7 @@ def load():
     L.aesgcm_ctx_create_preexpanded.argtypes = [ctypes.POINTER(vp), cint, vp, cint]
     L.aesgcm_ctx_destroy.argtypes = [vp]
     L.aesgcm_ctx_device.argtypes = [vp]
+    L.aesgcm_ctx_stream.argtypes = [vp, ctypes.POINTER(vp)]
     L.aesgcm_encrypt.argtypes = [vp, vp, vp, sz, vp, sz, vp, vp]
     L.aesgcm_decrypt.argtypes = [vp, vp, vp, sz, vp, sz, vp, vp, vp]
     L.aesgcm_encrypt_pipelined.argtypes = [vp, vp, vp, sz, vp, sz, vp, vp, sz]
@@ -81,6 +85,7 @@ def load():
     L.aesgcm_keystream_dev.argtypes = [vp, vp, u64, u64, vp, vp]
     L.aesgcm_shard_crypt_dev.argtypes = [vp, cint, vp, vp, sz, vp, sz, vp, u64, u64, vp, vp]
     L.aesgcm_shard_finalize_dev.argtypes = [vp, vp, vp, sz, sz, u64, vp, vp]
+    L.aesgcm_shard_finalize_strided_dev.argtypes = [vp, vp, vp, sz, sz, sz, u64, vp, vp]
     L.aesgcm_batch_crypt_dev.argtypes = [cint, cint, sz, sz, vp, vp, vp, sz, vp, sz, vp, vp, vp, vp, vp]
     L.aesgcm_batch_crypt_var_dev.argtypes = [cint, cint, sz, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.aesgcm_packets_crypt_dev.argtypes = [vp, cint, sz, vp, vp, sz, vp, vp, sz, vp, vp, vp, vp, vp, vp]
@@ -100,6 +105,19 @@ def load():
     L.aesgcm_ctx_wg_trace.argtypes = [vp, vp, sz, ctypes.POINTER(sz)]
     L.aesgcm_ctx_geometry.argtypes = [vp, ctypes.POINTER(cint), ctypes.POINTER(cint), ctypes.POINTER(cint)]
     L.aesgcm_ctx_split.argtypes = [vp, sz, u64, ctypes.POINTER(u64), ctypes.POINTER(u64)]
+    L.aesgcm_ctx_ceiling_probe.argtypes = [vp, sz, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(u64)]
+    L.aesgcm_comm_last_error.restype = cp
+    L.aesgcm_comm_unique_id.argtypes = [vp]
+    L.aesgcm_comm_create.argtypes = [ctypes.POINTER(vp), cint, vp, cint, cint]
+    L.aesgcm_comm_ranks.argtypes = [vp, ctypes.POINTER(cint), ctypes.POINTER(cint)]
+    L.aesgcm_comm_allgather_dev.argtypes = [vp, vp, vp, sz, vp]
+    L.aesgcm_comm_allreduce_f64.argtypes = [vp, ctypes.POINTER(ctypes.c_double), cint]
+    L.aesgcm_comm_barrier.argtypes = [vp]
+    L.aesgcm_comm_destroy.argtypes = [vp]
+    L.aesgcm_mgpu_create.argtypes = [ctypes.POINTER(vp), cint, ctypes.POINTER(cint), vp, sz]
+    L.aesgcm_mgpu_ranks.argtypes = [vp, ctypes.POINTER(cint)]
+    L.aesgcm_mgpu_crypt_dev.argtypes = [vp, cint, vp, vp, sz, ctypes.POINTER(vp), ctypes.POINTER(sz), ctypes.POINTER(vp), vp]
+    L.aesgcm_mgpu_destroy.argtypes = [vp]
     if L.aesgcm_abi_version() != 1:
         raise ImportError("libaesgcm_hip.so ABI %d, expected 1" % L.aesgcm_abi_version())
     _L = L
@@ -117,6 +135,8 @@ def _chk(rc):
     if rc == OK:
         return
     detail = load().aesgcm_last_error().decode() if rc == EHIP else ""
+    if rc == ERCCL or (rc == EHIP and not detail):
+        detail = load().aesgcm_comm_last_error().decode()
     if rc == EAUTH:
         raise AuthenticationError(rc, "MAC check failed")
     raise AesGcmError(rc, detail)
@@ -135,6 +155,10 @@ class _Buf:
             self.n = len(obj)
             self.addr = ctypes.cast(ctypes.c_char_p(obj), vp).value if self.n else None
         elif hasattr(obj, "ctypes") and hasattr(obj, "nbytes"):          # numpy
+            if writable and not obj.flags.writeable:
+                raise TypeError("output buffer must be writable")
+            if not obj.flags.c_contiguous:
+                raise TypeError("buffer must be C-contiguous")
             self.n = obj.nbytes
             self.addr = obj.ctypes.data if self.n else None
         else:
@@ -202,20 +226,26 @@ class DeviceBuffer:
 
     def upload(self, data, offset=0):
         b = _Buf(data)
-        if offset + b.n > self.nbytes:
+        if offset < 0 or offset + b.n > self.nbytes:
             raise AesGcmError(EARG, "upload past end of buffer")
         _chk(load().aesgcm_dev_upload(self.device, self.ptr + offset, b.addr, b.n))
 
     def download(self, nbytes=None, offset=0, out=None):
         n = self.nbytes - offset if nbytes is None else nbytes
+        if offset < 0 or n < 0 or offset + n > self.nbytes:
+            raise AesGcmError(EARG, "download past end of buffer")
         if out is None:
             out = bytearray(n)
         b = _Buf(out, writable=True)
+        if b.n < n:
+            raise AesGcmError(EARG, "output buffer smaller than the %d bytes requested" % n)
         _chk(load().aesgcm_dev_download(self.device, b.addr, self.ptr + offset, n))
         return out
 
     def fill_splitmix64(self, seed, first_word=0, nbytes=None, offset=0, stream=None):
         n = self.nbytes - offset if nbytes is None else nbytes
+        if offset < 0 or n < 0 or offset + n > self.nbytes:
+            raise AesGcmError(EARG, "fill past end of buffer")
         _chk(load().aesgcm_fill_splitmix64_dev(self.device, self.ptr + offset, n, seed, first_word, stream))
 
     def free(self):
@@ -301,6 +331,12 @@ class Context:
 
     def __exit__(self, *a):
         self.close()
+
+    def stream(self):
+        """the context's own HIP stream as an integer handle (what stream=None means)"""
+        s = vp()
+        _chk(load().aesgcm_ctx_stream(self._c, ctypes.byref(s)))
+        return s.value
 
     # unit level
     def h(self):
@@ -404,9 +440,9 @@ class Context:
         _chk(load().aesgcm_shard_crypt_dev(self._c, int(bool(decrypt)), _fixed(iv, 12, "iv"), d_aad, aad_len,
                                            d_in, nbytes, d_out, first_block, total_len, d_partial, stream))
 
-    def shard_finalize_dev(self, iv, d_partials, n_partials, aad_len, total_len, stream=None, want_tag=True):
+    def shard_finalize_dev(self, iv, d_partials, n_partials, aad_len, total_len, stream=None, want_tag=True, stride_bytes=16):
         tag = ctypes.create_string_buffer(16) if want_tag else None
-        _chk(load().aesgcm_shard_finalize_dev(self._c, _fixed(iv, 12, "iv"), d_partials, n_partials, aad_len, total_len, tag, stream))
+        _chk(load().aesgcm_shard_finalize_strided_dev(self._c, _fixed(iv, 12, "iv"), d_partials, n_partials, stride_bytes, aad_len, total_len, tag, stream))
         return tag.raw if want_tag else None
 
     # streaming
@@ -450,8 +486,86 @@ class Context:
         _chk(load().aesgcm_ctx_geometry(self._c, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
         return dict(workgroups=a.value, wg_lanes=b.value, lds_bytes=c.value)
 
+    def ceiling_probe(self, nbytes):
+        """(ms, blocks) of the fused kernel's instruction stream without its HBM traffic (aesgcm_ctx_ceiling_probe)"""
+        ms, nb = ctypes.c_double(0), u64(0)
+        _chk(load().aesgcm_ctx_ceiling_probe(self._c, nbytes, ctypes.byref(ms), ctypes.byref(nb)))
+        return ms.value, nb.value
+
     def split(self, nbytes, first_block=0):
         """(head_blocks, body_blocks) of the head / k_body / tail cut of a data range; body_blocks = 0: one k_main launch"""
         h, b = u64(0), u64(0)
         _chk(load().aesgcm_ctx_split(self._c, nbytes, first_block, ctypes.byref(h), ctypes.byref(b)))
         return h.value, b.value
+
+
+# ---------------------------------------------------------------- the exchange step (RCCL inside the library)
+def comm_unique_id():
+    """128-byte RCCL unique id (rank 0 makes it, every rank passes it to Comm)."""
+    b = ctypes.create_string_buffer(128)
+    _chk(load().aesgcm_comm_unique_id(b))
+    return b.raw
+
+
+class Comm:
+    """aesgcm_comm: one rank of an RCCL communicator (ncclCommInitRank), one process per GPU."""
+
+    def __init__(self, unique_id, n_ranks, rank, device=0):
+        self._c = None
+        c = vp()
+        _chk(load().aesgcm_comm_create(ctypes.byref(c), device, _fixed(unique_id, 128, "unique id"), n_ranks, rank))
+        self._c = c.value
+        n, r = cint(0), cint(0)
+        _chk(load().aesgcm_comm_ranks(self._c, ctypes.byref(n), ctypes.byref(r)))
+        self.n_ranks, self.rank = n.value, r.value        # what RCCL reports
+
+    def allgather_dev(self, d_send, d_recv, bytes_per_rank, stream=None):
+        _chk(load().aesgcm_comm_allgather_dev(self._c, d_send, d_recv, bytes_per_rank, stream))
+
+    def allreduce(self, value, op="max"):
+        v = ctypes.c_double(value)
+        _chk(load().aesgcm_comm_allreduce_f64(self._c, ctypes.byref(v), {"max": 0, "min": 1, "sum": 2}[op]))
+        return v.value
+
+    def barrier(self):
+        _chk(load().aesgcm_comm_barrier(self._c))
+
+    def close(self):
+        if self._c:
+            load().aesgcm_comm_destroy(self._c)
+            self._c = None
+
+    __del__ = close
+
+
+class MultiGpu:
+    """aesgcm_mgpu: one process, ndev GPUs (ncclCommInitAll); one message sharded over them."""
+
+    def __init__(self, key, devices):
+        self._m = None
+        devices = list(devices)
+        arr = (cint * len(devices))(*devices)
+        m = vp()
+        key = bytes(key)
+        _chk(load().aesgcm_mgpu_create(ctypes.byref(m), len(devices), arr, key, len(key)))
+        self._m, self.devices = m.value, devices
+        n = cint(0)
+        _chk(load().aesgcm_mgpu_ranks(self._m, ctypes.byref(n)))
+        self.n_ranks = n.value                             # communicator size RCCL reports
+
+    def crypt_dev(self, decrypt, iv, d_in, shard_len, d_out, d_aad=None, aad_len=0):
+        """d_in / d_out / shard_len: one entry per device -> tag"""
+        g = len(self.devices)
+        if not (len(d_in) == len(d_out) == len(shard_len) == g):
+            raise AesGcmError(EARG, "one shard per device")
+        pin, pout, ln = (vp * g)(*d_in), (vp * g)(*d_out), (sz * g)(*shard_len)
+        tag = ctypes.create_string_buffer(16)
+        _chk(load().aesgcm_mgpu_crypt_dev(self._m, int(bool(decrypt)), _fixed(iv, 12, "iv"), d_aad, aad_len, pin, ln, pout, tag))
+        return tag.raw
+
+    def close(self):
+        if self._m:
+            load().aesgcm_mgpu_destroy(self._m)
+            self._m = None
+
+    __del__ = close

@@ -34,6 +34,8 @@ def plan_job(n_ranks, bytes_per_gpu, rank, msg_bytes=None):
     if msg_bytes > MAX_MESSAGE:
         raise ValueError("a GCM message cannot exceed 2^36 - 32 bytes")
     n_msgs = total // msg_bytes
+    if n_msgs > 256:
+        raise ValueError("plan_job: more than 256 messages per job (tweak_iv advances one IV byte)")
     if n_msgs * msg_bytes != total or msg_bytes % (16 * n_ranks):
         raise ValueError("job does not split evenly")
     out = []
@@ -47,8 +49,13 @@ def plan_job(n_ranks, bytes_per_gpu, rank, msg_bytes=None):
 
 
 def tweak_iv(iv, tweak):
+    """IV of message `tweak` of a bench job: the base IV with its last byte advanced by `tweak` (the rule the cfg4
+    fixtures were generated with, tests/golden/gen_golden.py).  Bench/test helper only: it refuses to wrap, because a
+    wrapped byte would silently reuse a (key, nonce) pair, which GCM does not survive."""
     b = bytearray(iv)
-    b[11] = (b[11] + tweak) & 0xFF
+    if len(b) != 12 or tweak < 0 or b[11] + tweak > 0xFF:
+        raise ValueError("tweak_iv: base IV byte 11 (0x%02x) + %d leaves the byte; pick another base IV or fewer messages" % (b[11] if len(b) == 12 else 0, tweak))
+    b[11] += tweak
     return bytes(b)
 
 

@@ -18,7 +18,10 @@
  *   - the caller owns every buffer it passes; the library owns only opaque contexts.
  *   - a context is not thread-safe; distinct contexts may be used from distinct threads.  Calls on ONE
  *     context must be stream-ordered (same stream, or the caller synchronises between streams): a context
- *     owns one set of scratch buffers.  The batch entry points have no context and may overlap freely.
+ *     owns one set of scratch buffers (two streams driving aesgcm_shard_crypt_dev on ONE context would corrupt
+ *     each other's GHASH scratch).  The batch entry points have no context; launches on different streams may
+ *     overlap, up to 256 of them in flight per device (each takes the next slot of a 256-entry ring of packet
+ *     dispensers, zeroed on its own stream).
  *   - IV is always 96 bits (src/gcm_pkg.vhd:15-17, tb/gcm_gctr.py:251); tag is the full 128 bits
  *     (src/gcm_ghash.vhd:293).
  *   - length rule: data <= 2^36 - 32 bytes (the 32-bit block counter stops at all-ones,
@@ -52,6 +55,7 @@ extern "C" {
 #define AESGCM_ENOMEM   (-7)
 #define AESGCM_ESTATE   (-8)   /* streaming call out of order (AAD after data, ragged chunk)     */
 #define AESGCM_EALIGN   (-9)   /* device data pointer not 16-byte aligned                        */
+#define AESGCM_ERCCL    (-10)  /* RCCL missing or a collective failed; see aesgcm_comm_last_error() */
 
 typedef struct aesgcm_ctx aesgcm_ctx;
 
@@ -99,6 +103,9 @@ AESGCM_API int aesgcm_ctx_create(aesgcm_ctx **out, int device, const uint8_t *ke
 AESGCM_API int aesgcm_ctx_create_preexpanded(aesgcm_ctx **out, int device, const uint8_t *rk, int nr);
 AESGCM_API int aesgcm_ctx_destroy(aesgcm_ctx *ctx);
 AESGCM_API int aesgcm_ctx_device(const aesgcm_ctx *ctx);
+/* the context's own HIP stream (what `stream = NULL` means everywhere): lets a caller order other work -- the
+ * aesgcm_comm_allgather_dev of the partials -- behind the context's kernels without a host synchronisation */
+AESGCM_API int aesgcm_ctx_stream(const aesgcm_ctx *ctx, void **stream);
 
 /* ---------------------------------------------------------------- whole messages, host pointers
  * Replaces the model's update/encrypt/digest sequence (tb/gcm_model.py:21-35) i.e. the aes_gcm
@@ -149,6 +156,46 @@ AESGCM_API int aesgcm_shard_crypt_dev(aesgcm_ctx *ctx, int decrypt, const uint8_
                            void *d_partial, void *stream);
 AESGCM_API int aesgcm_shard_finalize_dev(aesgcm_ctx *ctx, const uint8_t iv[12], const void *d_partials, size_t n_partials,
                               size_t aad_len, uint64_t total_len, uint8_t tag[16], void *stream);
+/* The same with the n_partials partials stride_bytes apart (a multiple of 16): ONE all-gather of M messages' partials
+ * leaves them as [rank][message][16]; message m is finalised from d_partials + 16 m with stride 16 M. */
+AESGCM_API int aesgcm_shard_finalize_strided_dev(aesgcm_ctx *ctx, const uint8_t iv[12], const void *d_partials, size_t n_partials,
+                              size_t stride_bytes, size_t aad_len, uint64_t total_len, uint8_t tag[16], void *stream);
+
+/* ---------------------------------------------------------------- the exchange step, in the library
+ * (BASELINE north_star "a single RCCL reduce of per-shard partial tags over xGMI".)  RCCL has
+ * no XOR reduction (rccl.h ncclRedOp_t), so the 16-byte partials are all-gathered and folded on the device by
+ * aesgcm_shard_finalize_dev.  RCCL is loaded with dlopen("librccl.so.1") on first use; without it these return
+ * AESGCM_ERCCL and everything else in the library still works.
+ *
+ * One PROCESS per GPU: rank 0 calls aesgcm_comm_unique_id and hands the 128 bytes to the other ranks by any means
+ * (bench.py: a file under /tmp keyed by the launcher's pid); every rank then calls aesgcm_comm_create, which is
+ * ncclCommInitRank on `device`.  aesgcm_comm_ranks returns what RCCL reports (ncclCommCount / ncclCommUserRank).
+ * aesgcm_comm_allgather_dev: d_recv[r * bytes_per_rank ..] = rank r's d_send, asynchronous on `stream`.
+ * aesgcm_comm_allreduce_f64: one host double, op 0 = max, 1 = min, 2 = sum, synchronous (bench timing);
+ * aesgcm_comm_barrier is the sum of ones. */
+#define AESGCM_COMM_ID_BYTES 128
+typedef struct aesgcm_comm aesgcm_comm;
+AESGCM_API const char *aesgcm_comm_last_error(void);
+AESGCM_API int aesgcm_comm_unique_id(uint8_t id[AESGCM_COMM_ID_BYTES]);
+AESGCM_API int aesgcm_comm_create(aesgcm_comm **out, int device, const uint8_t id[AESGCM_COMM_ID_BYTES], int n_ranks, int rank);
+AESGCM_API int aesgcm_comm_ranks(const aesgcm_comm *comm, int *n_ranks, int *rank);
+AESGCM_API int aesgcm_comm_allgather_dev(aesgcm_comm *comm, const void *d_send, void *d_recv, size_t bytes_per_rank, void *stream);
+AESGCM_API int aesgcm_comm_allreduce_f64(aesgcm_comm *comm, double *value, int op);
+AESGCM_API int aesgcm_comm_barrier(aesgcm_comm *comm);
+AESGCM_API int aesgcm_comm_destroy(aesgcm_comm *comm);
+
+/* One process driving ndev GPUs (ncclCommInitAll).  Shard g = d_in[g] / d_out[g] (device memory of devices[g]),
+ * shard_len[g] bytes, owning the message's blocks right after shard g-1's; every length but the last must be a
+ * multiple of 16.  Each device expands the key and builds H and its tables itself (nothing is broadcast); the AAD
+ * (device memory of devices[0]) is absorbed by shard 0.  The call en/decrypts all shards concurrently, performs ONE
+ * grouped ncclAllGather of 16 bytes per device, folds on devices[0] and returns the tag; all streams are
+ * synchronised on return.  aesgcm_mgpu_ranks returns the communicator size RCCL reports. */
+typedef struct aesgcm_mgpu aesgcm_mgpu;
+AESGCM_API int aesgcm_mgpu_create(aesgcm_mgpu **out, int ndev, const int *devices, const uint8_t *key, size_t key_len);
+AESGCM_API int aesgcm_mgpu_ranks(const aesgcm_mgpu *m, int *n_ranks);
+AESGCM_API int aesgcm_mgpu_crypt_dev(aesgcm_mgpu *m, int decrypt, const uint8_t iv[12], const void *d_aad_on_dev0, size_t aad_len,
+                          const void *const *d_in, const size_t *shard_len, void *const *d_out, uint8_t tag[16]);
+AESGCM_API int aesgcm_mgpu_destroy(aesgcm_mgpu *m);
 
 /* ---------------------------------------------------------------- many packets under the context's key
  * The RTL keeps H across packets while no new key is loaded (src/gcm_gctr.vhd:142-144) and takes a new IV per
@@ -199,7 +246,9 @@ AESGCM_API int aesgcm_stream_final(aesgcm_ctx *ctx, uint8_t tag[16]);
  * pieces (0 = 64 MiB); H2D of chunk k+1, the fused kernel on chunk k and D2H of chunk k-1 overlap on three
  * HIP streams, and the running GHASH value is carried between chunks on the device (state the RTL and the
  * pycryptodome model cannot export).  Results are bit-identical to aesgcm_encrypt/aesgcm_decrypt.  Buffers from
- * aesgcm_host_alloc (page-locked) make the copies true DMA; pageable buffers work but copy slower. */
+ * aesgcm_host_alloc (page-locked) make the copies true DMA; pageable buffers work but copy slower.  The chunk-to-
+ * chunk GHASH value uses the context's streaming slot: inside an open aesgcm_stream_begin .. aesgcm_stream_final
+ * session these calls return AESGCM_ESTATE. */
 AESGCM_API int aesgcm_encrypt_pipelined(aesgcm_ctx *ctx, const uint8_t iv[12], const uint8_t *aad, size_t aad_len,
                              const uint8_t *pt, size_t len, uint8_t *ct, uint8_t tag[16], size_t chunk_bytes);
 AESGCM_API int aesgcm_decrypt_pipelined(aesgcm_ctx *ctx, const uint8_t iv[12], const uint8_t *aad, size_t aad_len,
@@ -232,6 +281,11 @@ AESGCM_API int aesgcm_ctx_timing_read(aesgcm_ctx *ctx, uint64_t *n_launches, dou
  * the *n_wgs workgroups four uint64 {start, end of its last wave (100 MHz wall clock), HW_ID | XCC_ID << 32,
  * (chunks its waves processed) | (sum over its waves of shader-clock kilocycles resident) << 32}. */
 AESGCM_API int aesgcm_ctx_wg_trace(aesgcm_ctx *ctx, uint64_t *out, size_t max_wgs, size_t *n_wgs);
+/* Ceiling of the formulation (SURVEY.md 8(d) "measured LDS/VALU ceilings next to the result"): runs the fused kernel's
+ * instruction stream over a virtual range of `nbytes` with its global loads and stores removed (no buffer is touched)
+ * and returns its duration and the number of 16-byte blocks it covered.  bench.py prints 32 B x blocks / time beside
+ * the achieved figure, measured in the same process. */
+AESGCM_API int aesgcm_ctx_ceiling_probe(aesgcm_ctx *ctx, size_t nbytes, double *ms, uint64_t *blocks);
 /* geometry the context chose (workgroups, lanes per workgroup, LDS bytes per workgroup) */
 AESGCM_API int aesgcm_ctx_geometry(const aesgcm_ctx *ctx, int *n_workgroups, int *wg_lanes, int *lds_bytes);
 /* How a data range of `len` bytes starting at block `first_block` of its message is launched: large ranges are cut

@@ -1,0 +1,171 @@
+"""CPU baseline of bench.py: the reference's CPU path timed on the GPU box's host cores.
+
+TEST / MEASUREMENT INFRASTRUCTURE ONLY (lives under oracle/; the product never imports it).
+
+The reference's software path is `AES.new(key, AES.MODE_GCM, nonce=iv).encrypt(...)` from pycryptodome
+(/root/reference/tb/gcm_model.py:18,26).  Probe order: pycryptodome if importable -- that exact call -- else the
+system libcrypto `EVP_aes_256_gcm` through ctypes (oracle/libcrypto_ref.py), which is the substitution BASELINE.md
+section 2 prescribes when the wheel is absent.  What is timed: the cfg3 plaintext stream (SplitMix64 seed 0xAE5C0003)
+in 64 MiB chunks, (i) one core, one stream and (ii) all usable cores as worker PROCESSES, each encrypting its own
+slice of the stream under its own IV; wall clock around the encrypt calls only (plaintext generated beforehand),
+best and median of >= 3 repetitions.  A bounded sample (default <= 512 MiB per worker), so the whole thing takes
+seconds; AES-GCM timing is data independent.
+
+Must be called BEFORE the process initialises the GPU: the workers are forked.
+"""
+import multiprocessing as mp
+import os
+import statistics
+import time
+
+GiB = 1 << 30
+CHUNK = 64 << 20
+KEY_SEED, IV_SEED, PT_SEED = 0x4B4559, 0x4956, 0xAE5C0003
+
+
+def usable_cores():
+    """cores this process may really use: affinity mask capped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(p) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def cpu_info():
+    model, flags = "unknown", set()
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("flags") and not flags:
+                flags = set(line.split(":", 1)[1].split())
+                break
+    except OSError:
+        pass
+    keep = [f for f in ("aes", "vaes", "pclmulqdq", "vpclmulqdq", "avx2", "avx512f") if f in flags]
+    return model, keep
+
+
+def probe_library():
+    """-> (name, kind): pycryptodome (the reference's own dependency) if importable, else libcrypto"""
+    try:
+        import Crypto
+        from Crypto.Cipher import AES  # noqa: F401
+        return "pycryptodome %s (AES.new(key, AES.MODE_GCM, nonce=iv).encrypt -- tb/gcm_model.py:18,26)" % Crypto.__version__, "reference"
+    except Exception:
+        pass
+    from oracle import libcrypto_ref as R
+    if R.available():
+        return "libcrypto EVP_aes_256_gcm via ctypes (%s); stands in for pycryptodome, which is not installed (BASELINE.md 2)" % R.version(), "library"
+    return None, None
+
+
+def _worker(idx, key, iv, n_chunks, use_pycryptodome, reps, start, done, out_q):
+    import numpy as np
+    from oracle import oracle as O
+    from oracle import libcrypto_ref as R
+    # this worker's slice of the cfg3 stream, generated before the clock starts
+    pts = [np.frombuffer(O.fill_splitmix64(CHUNK, PT_SEED, (idx * n_chunks + c) * (CHUNK // 8)), dtype=np.uint8) for c in range(n_chunks)]
+    ct = np.empty(CHUNK, dtype=np.uint8)
+    my_iv = bytes(iv[:8]) + (int.from_bytes(iv[8:], "big") + idx & 0xFFFFFFFF).to_bytes(4, "big")     # own IV per worker
+    for _ in range(reps):
+        start.wait()
+        t0 = time.perf_counter()
+        if use_pycryptodome:
+            from Crypto.Cipher import AES
+            m = AES.new(key, AES.MODE_GCM, nonce=my_iv)
+            for p in pts:
+                m.encrypt(p.tobytes())
+            m.digest()
+        else:
+            s = R.Stream(key, my_iv)
+            for p in pts:
+                s.update(p, ct)
+            s.final()
+        dt = time.perf_counter() - t0
+        done.wait()
+        out_q.put((idx, dt))
+
+
+def _run(n_workers, n_chunks, key, iv, use_pycryptodome, reps):
+    ctx = mp.get_context("fork")
+    start, done, q = ctx.Barrier(n_workers + 1), ctx.Barrier(n_workers + 1), ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(i, key, iv, n_chunks, use_pycryptodome, reps, start, done, q), daemon=True) for i in range(n_workers)]
+    for p in ps:
+        p.start()
+    rates = []
+    for _ in range(reps):
+        start.wait(timeout=600)
+        t0 = time.perf_counter()
+        done.wait(timeout=600)
+        wall = time.perf_counter() - t0
+        for _ in range(n_workers):
+            q.get(timeout=60)
+        rates.append(n_workers * n_chunks * CHUNK / wall)
+    for p in ps:
+        p.join(timeout=30)
+    return rates
+
+
+def measure(reps=3, max_bytes_per_worker=512 << 20, max_total=12 * GiB, with_port=True):
+    """-> the `cpu_baseline` object of the bench line."""
+    from oracle import oracle as O
+    name, kind = probe_library()
+    cores = usable_cores()
+    model, flags = cpu_info()
+    if name is None:
+        return {"error": "neither pycryptodome nor libcrypto available", "cores": cores, "cpu_model": model}
+    key = bytes(O.fill_splitmix64(32, KEY_SEED))
+    iv = bytes(O.fill_splitmix64(12, IV_SEED))
+    pyc = kind == "reference"
+    n_chunks = max(1, min(max_bytes_per_worker, max_total // cores) // CHUNK)
+    r1 = _run(1, n_chunks, key, iv, pyc, reps)
+    rn = _run(cores, n_chunks, key, iv, pyc, reps)
+    out = {
+        "value": round(max(rn) / GiB, 3), "unit": "GiB/s", "cores": cores, "kind": kind, "lib": name,
+        "value_median": round(statistics.median(rn) / GiB, 3),
+        "value_1core": round(max(r1) / GiB, 3), "value_1core_median": round(statistics.median(r1) / GiB, 3),
+        "cpu_model": model, "cpu_flags": flags, "reps": reps,
+        "sample": "AES-256-GCM, cfg3 plaintext stream (SplitMix64 seed 0xAE5C0003) in 64 MiB chunks: %d worker process(es) x %d MiB, "
+                  "each slice its own message under its own IV; wall clock around the encrypt calls, best of %d (median beside it)"
+                  % (cores, n_chunks * CHUNK >> 20, reps),
+    }
+    if with_port:
+        try:
+            out["port"] = port_rate(cores)
+        except Exception as e:           # never break the bench line
+            out["port"] = {"error": repr(e)}
+    return out
+
+
+def port_rate(n_threads, per_thread=32 << 20):
+    """the oracle's own table-driven C restatement (oracle/aesgcm_oracle.c orc_fast_*), threads; a side note, not the baseline"""
+    import threading
+    import numpy as np
+    from oracle import oracle as O
+    key = bytes(O.fill_splitmix64(32, KEY_SEED))
+    iv = bytes(O.fill_splitmix64(12, IV_SEED))
+    bufs = [np.frombuffer(O.fill_splitmix64(per_thread, PT_SEED, t * per_thread // 8), dtype=np.uint8) for t in range(n_threads)]
+    outs = [np.empty_like(b) for b in bufs]
+
+    def run(t):
+        O.Fast(key).crypt(False, iv, b"", bufs[t], outs[t])
+
+    ths = [threading.Thread(target=run, args=(t,)) for t in range(n_threads)]
+    t0 = time.perf_counter()
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    dt = time.perf_counter() - t0
+    return {"value": round(n_threads * per_thread / dt / GiB, 3), "unit": "GiB/s", "threads": n_threads,
+            "what": "oracle/aesgcm_oracle.c orc_fast (plain C tables, no AES-NI): the checker's own speed, not the baseline"}
+
+
+if __name__ == "__main__":
+    import json
+    print(json.dumps(measure(), indent=1))

@@ -1,0 +1,87 @@
+"""Child process of tests/test_gpu_stress.py: N randomised packet-kernel launches, a sample verified against the oracle.
+Prints progress lines and one JSON result line.  usage: stress_child.py <launches> <seed>"""
+import json
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    n_launch, seed = int(sys.argv[1]), int(sys.argv[2])
+    import numpy as np
+    import aesgcm_amd  # noqa: F401
+    from aesgcm_amd import lib
+    from oracle import oracle as O
+    rng = random.Random(seed)
+    nprng = np.random.default_rng(seed)
+    MAXP, MAXB = 4200, 1 << 20                       # packets per launch, bytes per launch
+    d_in, d_out = lib.DeviceBuffer(MAXB + 4096), lib.DeviceBuffer(MAXB + 4096)
+    d_aad = lib.DeviceBuffer(MAXP * 32 + 64)
+    d_ivs, d_keys, d_tags = lib.DeviceBuffer(12 * MAXP), lib.DeviceBuffer(32 * MAXP), lib.DeviceBuffer(16 * MAXP)
+    d_doff, d_aoff = lib.DeviceBuffer(8 * (MAXP + 1)), lib.DeviceBuffer(8 * (MAXP + 1))
+    data = nprng.integers(0, 256, MAXB + 4096, dtype=np.uint8)
+    aadb = nprng.integers(0, 256, MAXP * 32 + 64, dtype=np.uint8)
+    d_in.upload(data); d_aad.upload(aadb)
+    keys = {kb: bytes(nprng.integers(0, 256, kb, dtype=np.uint8)) for kb in (16, 24, 32)}
+    ctxs = {kb: lib.Context(k) for kb, k in keys.items()}
+    orcs = {kb: O.Fast(k) for kb, k in keys.items()}
+    counts = [1, 2, 63, 64, 65, 127, 129, 1000, 4097, 4200]
+    launches = verified = mismatches = 0
+    t0 = time.time()
+    while launches < n_launch:
+        n = rng.choice(counts) if rng.random() < 0.5 else rng.randrange(1, 300)
+        kind = rng.choice(("pkt_w", "pkt_l", "batch"))
+        kb = rng.choice((16, 24, 32))
+        # packet lengths: many zero-length and tiny ones, a few long; total bounded by MAXB
+        mean = max(1, min(2000, MAXB // n))
+        lens = [0 if rng.random() < 0.08 else min(rng.randrange(0, 2 * mean), 60000) for _ in range(n)]
+        if rng.random() < 0.3:
+            lens = [(x + 15) // 16 * 16 for x in lens]                       # aligned packets take the fast path
+        alens = [rng.choice((0, 0, 1, 12, 16, 20, 28)) for _ in range(n)]
+        doff = np.zeros(n + 1, dtype=np.uint64); doff[1:] = np.cumsum(lens)
+        aoff = np.zeros(n + 1, dtype=np.uint64); aoff[1:] = np.cumsum(alens)
+        if int(doff[-1]) > MAXB:
+            continue
+        ivs = nprng.integers(0, 256, 12 * n, dtype=np.uint8)
+        d_ivs.upload(ivs); d_doff.upload(doff); d_aoff.upload(aoff)
+        os.environ.pop("AESGCM_PKT_SHAPE", None); os.environ.pop("AESGCM_PKT_DEAL", None)
+        if kind == "batch":
+            pk = nprng.integers(0, 256, kb * n, dtype=np.uint8)
+            d_keys.upload(pk)
+            lib.batch_crypt_var_dev(False, n, kb, d_keys.ptr, d_ivs.ptr, d_in.ptr, d_doff.ptr, d_out.ptr, d_tags.ptr,
+                                    d_aad=d_aad.ptr, d_aad_off=d_aoff.ptr)
+        else:
+            os.environ["AESGCM_PKT_SHAPE"] = "w" if kind == "pkt_w" else "l"
+            os.environ["AESGCM_PKT_DEAL"] = str(rng.choice((1, 3, 16)))
+            ctxs[kb].packets_crypt_dev(False, n, d_ivs.ptr, d_in.ptr, d_out.ptr, d_tags.ptr, d_aad=d_aad.ptr,
+                                       d_aad_off=d_aoff.ptr, d_data_off=d_doff.ptr)
+        launches += 1
+        if launches % 40 == 0 or launches == n_launch:                        # verify this launch: a few packets of it
+            lib.dev_sync(0)
+            tags = bytes(d_tags.download(16 * n))
+            for p in {0, n - 1, rng.randrange(n), rng.randrange(n)}:
+                a, b = int(doff[p]), int(doff[p + 1])
+                ct = bytes(d_out.download(b - a, a)) if b > a else b""
+                iv = bytes(ivs[12 * p:12 * p + 12])
+                aad = bytes(aadb[int(aoff[p]):int(aoff[p + 1])])
+                f = O.Fast(bytes(pk[kb * p:kb * (p + 1)])) if kind == "batch" else orcs[kb]
+                want_ct, want_tag = f.encrypt(iv, aad, bytes(data[a:b]))
+                verified += 1
+                if ct != want_ct or tags[16 * p:16 * p + 16] != want_tag:
+                    mismatches += 1
+                    print("MISMATCH launch %d kind %s kb %d n %d pkt %d len %d aad %d" % (launches, kind, kb, n, p, b - a, len(aad)), flush=True)
+        if launches % 1000 == 0:
+            lib.dev_sync(0)
+            print("progress %d launches, %d verified, %.0f s" % (launches, verified, time.time() - t0), flush=True)
+    lib.dev_sync(0)
+    print(json.dumps({"launches": launches, "verified": verified, "mismatches": mismatches, "seconds": round(time.time() - t0, 1)}), flush=True)
+    return 0 if mismatches == 0 else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

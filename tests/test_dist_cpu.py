@@ -102,3 +102,51 @@ def test_plan_job_shapes():
     assert sharding.shard_bounds(7, 8, 0) == (0, 1, 7) and sharding.shard_bounds(7, 8, 5) == (1, 1, 0)
     with pytest.raises(ValueError):
         sharding.plan_job(1, 1 << 37, 0)
+
+
+def _file_worker(rank, world, rdzv, q):
+    sys.path.insert(0, ROOT)
+    os.environ["AESGCM_RDZV_DIR"] = rdzv
+    import aesgcm_amd  # noqa: F401
+    from aesgcm_amd import comm
+    uid = comm.share_bytes("rccl_unique_id", bytes(range(128)) if rank == 0 else None, rank, 128)
+    ex = comm.FileExchange(rank, world, 0)
+    got = []
+    for k in range(5):                                   # several rounds: sequence numbers and file reuse
+        got.append(ex._allgather_bytes(bytes([rank, k])))
+    mx = ex.allreduce(float(10 + rank), "max")
+    mn = ex.allreduce(float(10 + rank), "min")
+    ex.barrier()
+    comm.finish(rank, world)
+    q.put((rank, uid == bytes(range(128)), got, mx, mn))
+
+
+def test_launcher_plumbing_without_torch_two_ranks(tmp_path):
+    """the torch-free rank plumbing bench.py uses for N > 1: unique-id hand-off through a file, the debug file exchange
+    (all-gather / all-reduce / barrier) and the goodbye protocol that removes the rendezvous directory"""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    rdzv = str(tmp_path / "rdzv")
+    procs = [ctx.Process(target=_file_worker, args=(r, 2, rdzv, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, uid_ok, got, mx, mn in res:
+        assert uid_ok and mx == 11.0 and mn == 10.0
+        assert got == [[bytes([0, k]), bytes([1, k])] for k in range(5)]
+    assert not os.path.exists(rdzv)                      # rank 0 removed it after every goodbye
+
+
+def test_tweak_iv_refuses_to_wrap():
+    import aesgcm_amd  # noqa: F401
+    from aesgcm_amd import sharding
+    iv = bytes(11) + b"\xfe"
+    assert sharding.tweak_iv(iv, 1)[11] == 0xFF
+    with pytest.raises(ValueError):
+        sharding.tweak_iv(iv, 2)
+    with pytest.raises(ValueError):
+        sharding.plan_job(8, 1 << 30, 0, msg_bytes=16 * 8 * 2)       # 2^22 messages: more than one IV byte can number

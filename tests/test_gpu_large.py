@@ -79,6 +79,35 @@ def test_sharded_16GiB_equals_fixture(hip):
     pt.free(); ct.free()
 
 
+@pytest.mark.parametrize("msg", [0, 1, 2, 3])
+def test_cfg4_messages_sharded_8_equal_fixtures(hip, msg):
+    """BASELINE config 4 at its own size on ONE GPU: the 128 GiB job is 4 messages x 32 GiB (one GCM message cannot
+    exceed 2^36 - 32 bytes, src/aes_icb.vhd:114), each cut into 8 shards of 4 GiB exactly as the 8 ranks would own
+    them (sharding.shard_bounds).  Here the 8 shards run one after the other, IN PLACE (32 GiB resident), through the
+    same aesgcm_shard_crypt_dev / aesgcm_shard_finalize_dev calls; tag, CT head/tail and SHA-256 of all 32 GiB of
+    ciphertext must equal the libcrypto fixture."""
+    c = _case("cfg4_aes256_msg%d_32GiB" % msg)
+    n = c["n_bytes"]
+    assert n == 32 << 30
+    key, iv = stream_key_iv(c)
+    import aesgcm_amd  # noqa: F401
+    from aesgcm_amd import sharding
+    assert iv == sharding.tweak_iv(sharding.splitmix64_bytes(c["iv_seed"], 12), msg)     # the IV rule bench.py uses for N > 1
+    ctx = hip.Context(key)
+    buf = hip.DeviceBuffer(n)
+    buf.fill_splitmix64(c["pt_seed"], c["first_word"])
+    ranks = 8
+    parts = hip.DeviceBuffer(16 * ranks)
+    for r in range(ranks):
+        first, end, ln = sharding.shard_bounds(n, ranks, r)
+        assert ln == 4 << 30
+        ctx.shard_crypt_dev(False, iv, buf.ptr + 16 * first, ln, buf.ptr + 16 * first, first, n, parts.ptr + 16 * r)
+    assert ctx.shard_finalize_dev(iv, parts.ptr, ranks, 0, n).hex() == c["tag"]
+    assert bytes(buf.download(64, 0)).hex() == c["ct_head"] and bytes(buf.download(64, n - 64)).hex() == c["ct_tail"]
+    assert _sha_device(buf, n) == c["ct_sha256"]
+    buf.free(); parts.free()
+
+
 def test_maximum_message_and_length_limit(hip, orc):
     """2^36 - 32 bytes: the largest message the 32-bit block counter allows (src/aes_icb.vhd:114), in place,
     with a 20-byte AAD; one byte more must be refused."""

@@ -1,0 +1,104 @@
+"""GPU: the multi-process orchestration of the PRODUCT shard path, and the in-library RCCL entry points.
+
+* two fresh child processes (subprocess; the parent never execs itself) run bench.py's N > 1 path -- every rank
+  aesgcm_shard_crypt_dev -> all-gather of the 16-byte partials -> aesgcm_shard_finalize_strided_dev -- both on GPU 0,
+  with the debug file exchange (RCCL refuses two ranks on one device).  Both ranks must derive the tag the oracle
+  computes for the whole message; rank 0 also compares against a single-launch encrypt (--selfcheck).
+* aesgcm_comm_* / aesgcm_mgpu_* with a ONE-rank RCCL communicator (the only size a one-GPU box can form): the calls the
+  8-GPU job makes, RCCL really loaded and driven, cfg3 fixture as the expected result.
+"""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import pytest
+
+from util import golden, stream_key_iv
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _case(name):
+    for c in golden("streams.json")["cases"]:
+        if c["name"] == name:
+            return c
+    pytest.skip("fixture %s not generated" % name)
+
+
+def test_two_processes_product_shard_path_one_gpu(hip, orc):
+    per_rank_gib = 0.5                                    # message = 2 ranks x 0.5 GiB = 1 GiB, AES-256, seed 0xAE5C0004
+    n = int(2 * per_rank_gib * (1 << 30))
+    with tempfile.TemporaryDirectory(prefix="aesgcm_mp_") as rdzv:
+        procs = []
+        for r in range(2):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), AESGCM_RDZV_DIR=rdzv,
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT="29555")
+            cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "file", "--one-device",
+                   "--gib-per-gpu", str(per_rank_gib), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--selfcheck"]
+            procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT))
+        outs = []
+        try:
+            for p in procs:
+                outs.append(p.communicate(timeout=420))
+        except subprocess.TimeoutExpired:
+            for p in procs:
+                p.kill()
+            pytest.fail("a rank did not finish within 420 s (killed)")
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    line = json.loads(outs[0][0].strip().splitlines()[-1])          # rank 0 prints the bench line
+    assert line["n_gpus"] == 2 and line["config"]["exchange"] == {"backend": "file", "ranks_seen": 2, "torch": "not imported"}
+    assert line["selfcheck"] is True and line["tag_ok"] is not False
+    # the oracle's tag for the whole 1 GiB message (same key / IV / plaintext stream as the ranks used)
+    import numpy as np
+    import aesgcm_amd  # noqa: F401
+    from aesgcm_amd import sharding
+    key = sharding.splitmix64_bytes(0x4B4559, 32)
+    iv = sharding.splitmix64_bytes(0x4956, 12)
+    pt = np.frombuffer(orc.fill_splitmix64(n, 0xAE5C0004), dtype=np.uint8)
+    ct = np.empty_like(pt)
+    _, want = orc.Fast(key).crypt(False, iv, b"", pt, ct)
+    assert line["tags"] == [want.hex()]
+
+
+def test_rccl_single_rank_communicator(hip):
+    """aesgcm_comm_*: ncclCommInitRank with one rank, a 32-byte all-gather, a max all-reduce, a barrier"""
+    uid = hip.comm_unique_id()
+    assert len(uid) == 128
+    c = hip.Comm(uid, 1, 0, device=0)
+    assert (c.n_ranks, c.rank) == (1, 0)
+    a, b = hip.DeviceBuffer(32), hip.DeviceBuffer(32)
+    a.upload(bytes(range(32)))
+    c.allgather_dev(a.ptr, b.ptr, 32)
+    c.barrier()
+    assert bytes(b.download()) == bytes(range(32))
+    assert c.allreduce(3.25, "max") == 3.25 and c.allreduce(3.25, "sum") == 3.25
+    c.close()
+
+
+def test_mgpu_one_device_equals_cfg3_fixture(hip):
+    """aesgcm_mgpu_* (ncclCommInitAll over this process's devices = one here): cfg3's 16 GiB message, in place"""
+    c = _case("cfg3_aes256_16GiB")
+    n = c["n_bytes"]
+    key, iv = stream_key_iv(c)
+    m = hip.MultiGpu(key, [0])
+    assert m.n_ranks == 1
+    buf = hip.DeviceBuffer(n)
+    buf.fill_splitmix64(c["pt_seed"], c["first_word"])
+    tag = m.crypt_dev(False, iv, [buf.ptr], [n], [buf.ptr])
+    assert tag.hex() == c["tag"]
+    assert bytes(buf.download(64, 0)).hex() == c["ct_head"] and bytes(buf.download(64, n - 64)).hex() == c["ct_tail"]
+    # and back, with a ragged tail and an AAD on device 0 (small message)
+    aad = bytes(range(37))
+    d_aad = hip.DeviceBuffer(len(aad)); d_aad.upload(aad)
+    small = hip.DeviceBuffer(4096)
+    pt = bytes((7 * i) & 0xFF for i in range(3005))
+    small.upload(pt)
+    t1 = m.crypt_dev(False, iv, [small.ptr], [3005], [small.ptr], d_aad=d_aad.ptr, aad_len=len(aad))
+    ctx = hip.Context(key)
+    want_ct, want_tag = ctx.encrypt(iv, aad, pt)
+    assert t1 == want_tag and bytes(small.download(3005)) == want_ct
+    m.close(); buf.free()
