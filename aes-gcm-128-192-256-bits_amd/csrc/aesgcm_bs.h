@@ -1,0 +1,153 @@
+// aesgcm_bs.h -- bitsliced AES for gfx950: the round pipeline (aes_round / aes_last_round, config/config_aes_round.py:120-126,
+// src/aes_last_round.vhd:76) evaluated as boolean circuits on 32 blocks per lane, with NO table lookup at all.
+//
+// Why: on MI355X every ds_read_b32 of the T-table formulation costs the issuing SIMD about 5 issue cycles and a VALU
+// instruction 2 (profiles/microbench/overlap.hip: LDS-lookup waves and VALU waves on one SIMD do not overlap, their
+// costs add), so a table lookup + its address + its share of the XOR tree is ~9 cycles per S-box, while the S-box as
+// a circuit of three-input boolean instructions (v_bitop3_b32, any 3-input function in one VALU op) is ~90 ops per 32
+// S-boxes = 5.6 cycles.
+//
+// Representation: lane register s[8*j + b] holds bit b (0 = LSB) of state byte j (j = 4*column + row, i.e. byte j of
+// the block in memory order, vec_to_state src/aes_func.vhd:85-103) for 32 blocks: bit i of the register = block i.
+//   SubBytes    16 x bs_sbox (aesgcm_bs_sbox.inc, generated and verified by tools/sbox_lut3.py; src/aes_func.vhd:228-301)
+//   ShiftRows   renaming of registers (src/aes_func.vhd:146-154): free
+//   MixColumns  XOR network on bit planes (src/aes_func.vhd:159-210): out_i = xtime(a_i ^ a_i+1) ^ a_i+1 ^ a_i+2 ^ a_i+3
+//   AddRoundKey a round-key bit is the same for all 32 blocks: XOR with an all-zeros / all-ones mask (wave-uniform ->
+//               scalar operand), folded into the MixColumns XOR3s
+// The same code runs on the CPU (tests/host_emul) with BS_LUT as a plain function.
+#pragma once
+#include "aesgcm_dev.h"
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BS_LUT(a, b, c, tt) __builtin_amdgcn_bitop3_b32((a), (b), (c), (tt))
+#else
+HD u32 bs_lut_host(u32 a, u32 b, u32 c, u32 tt) {
+    u32 r = 0;
+    for (u32 idx = 0; idx < 8; idx++)
+        if ((tt >> idx) & 1u) r |= ((idx & 4u) ? a : ~a) & ((idx & 2u) ? b : ~b) & ((idx & 1u) ? c : ~c);
+    return r;
+}
+#define BS_LUT(a, b, c, tt) bs_lut_host((a), (b), (c), (tt))
+#endif
+#define BS_FN HD
+#include "aesgcm_bs_sbox.inc"
+
+#define BS_XOR3(a, b, c) BS_LUT((a), (b), (c), 0x96)
+
+// round-key bit masks: rkm[128 * r + 8 * j + b] = all-ones if bit b of byte j of round key r is set, else 0
+HD void bs_key_masks(const uint8_t *rk_bytes, int nr, u32 *rkm) {
+    for (int r = 0; r <= nr; r++)
+        for (int j = 0; j < 16; j++)
+            for (int b = 0; b < 8; b++) rkm[128 * r + 8 * j + b] = 0u - (u32)((rk_bytes[16 * r + j] >> b) & 1u);
+}
+
+// SubBytes on all 16 state bytes, in place
+HD void bs_sub_bytes(u32 *s) {
+#pragma unroll
+    for (int j = 0; j < 16; j++) bs_sbox(s[8 * j + 0], s[8 * j + 1], s[8 * j + 2], s[8 * j + 3], s[8 * j + 4], s[8 * j + 5], s[8 * j + 6], s[8 * j + 7]);
+}
+
+// ShiftRows + MixColumns + AddRoundKey(k) from the SubBytes output `s` into `o`  (o may not alias s)
+HD void bs_shift_mix_ark(const u32 *s, u32 *o, const u32 *__restrict__ k) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        // a[i][b]: row i of column c after ShiftRows = SubBytes output byte (row i, column (c + i) & 3)
+        u32 t[4][8];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int ja = 4 * ((c + i) & 3) + i, jb = 4 * ((c + i + 1) & 3) + ((i + 1) & 3);
+#pragma unroll
+            for (int b = 0; b < 8; b++) t[i][b] = s[8 * ja + b] ^ s[8 * jb + b];          // a_i ^ a_(i+1)
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int i1 = (i + 1) & 3, i2 = (i + 2) & 3;
+            const int j1 = 4 * ((c + i1) & 3) + i1;
+            const int jo = 4 * c + i;
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const u32 v = BS_XOR3(s[8 * j1 + b], t[i2][b], k[8 * jo + b]);           // a_(i+1) ^ a_(i+2) ^ a_(i+3) ^ key
+                // xtime(t_i): bit 0 = t7, bit b = t(b-1), with t7 also into bits 1, 3, 4 (x^8 = x^4 + x^3 + x + 1)
+                if (b == 0) o[8 * jo + b] = v ^ t[i][7];
+                else if (b == 1 || b == 3 || b == 4) o[8 * jo + b] = BS_XOR3(v, t[i][b - 1], t[i][7]);
+                else o[8 * jo + b] = v ^ t[i][b - 1];
+            }
+        }
+    }
+}
+// last round: ShiftRows + AddRoundKey(k)
+HD void bs_shift_ark(const u32 *s, u32 *o, const u32 *__restrict__ k) {
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int ja = 4 * ((c + i) & 3) + i, jo = 4 * c + i;
+#pragma unroll
+            for (int b = 0; b < 8; b++) o[8 * jo + b] = s[8 * ja + b] ^ k[8 * jo + b];
+        }
+}
+
+// One output column of a full round: SubBytes on the four bytes ShiftRows brings into column c (each state byte feeds
+// exactly one column, so the old state dies as the new one is born and ~220 registers hold a round), MixColumns, key.
+HD void bs_round_column(const u32 *s, u32 *o, const u32 *__restrict__ k, int c, bool last) {
+    u32 a[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int j = 4 * ((c + i) & 3) + i;                       // ShiftRows: row i comes from column c + i
+#pragma unroll
+        for (int b = 0; b < 8; b++) a[i][b] = s[8 * j + b];
+        bs_sbox(a[i][0], a[i][1], a[i][2], a[i][3], a[i][4], a[i][5], a[i][6], a[i][7]);
+    }
+    if (last) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int b = 0; b < 8; b++) o[8 * (4 * c + i) + b] = a[i][b] ^ k[8 * (4 * c + i) + b];
+        return;
+    }
+    u32 t[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int b = 0; b < 8; b++) t[i][b] = a[i][b] ^ a[(i + 1) & 3][b];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int jo = 4 * c + i;
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const u32 v = BS_XOR3(a[(i + 1) & 3][b], t[(i + 2) & 3][b], k[8 * jo + b]);
+            if (b == 0) o[8 * jo + b] = v ^ t[i][7];
+            else if (b == 1 || b == 3 || b == 4) o[8 * jo + b] = BS_XOR3(v, t[i][b - 1], t[i][7]);
+            else o[8 * jo + b] = v ^ t[i][b - 1];
+        }
+    }
+}
+
+// rounds 1 .. nr on a state that already has round key 0 applied; result in s
+HD void bs_rounds(u32 *s, const u32 *__restrict__ rkm, int nr) {
+    u32 o[128];
+#pragma unroll 1
+    for (int r = 1; r <= nr; r++) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) bs_round_column(s, o, rkm + 128 * r, c, r == nr);
+#pragma unroll
+        for (int q = 0; q < 128; q++) s[q] = o[q];
+    }
+}
+
+// 32 x 32 bit-matrix transpose in place: on entry w[p] bit i = element (p, i); on exit w[i] bit p = element (p, i).
+// Stages with 16- and 8-bit granularity are byte permutes (one v_perm_b32 per output word), the rest shift + bit-select.
+HD void bs_transpose32(u32 *w) {
+#pragma unroll
+    for (int j = 16; j >= 1; j >>= 1) {
+        const u32 m = j == 16 ? 0x0000FFFFu : j == 8 ? 0x00FF00FFu : j == 4 ? 0x0F0F0F0Fu : j == 2 ? 0x33333333u : 0x55555555u;
+#pragma unroll
+        for (int k = 0; k < 32; k++) {
+            if (k & j) continue;
+            const u32 a = w[k], b = w[k + j];
+            // low halves stay in a, a's high halves go to b's low halves
+            w[k] = (a & m) | ((b << j) & ~m);
+            w[k + j] = ((a >> j) & m) | (b & ~m);
+        }
+    }
+}

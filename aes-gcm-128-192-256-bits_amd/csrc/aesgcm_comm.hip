@@ -187,7 +187,7 @@ int aesgcm_mgpu_create(aesgcm_mgpu **out, int ndev, const int *devices, const ui
         // every device derives round keys, H and its tables locally from the key: nothing is broadcast
         if ((rc = aesgcm_ctx_create(&m->ctx[g], devices[g], key, key_len))) { aesgcm_mgpu_destroy(m); return rc; }
         hipError_t e = hipSetDevice(devices[g]);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->st[g], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreate(&m->st[g]);     // a blocking stream, as a context's own: ordered behind work the caller left on the NULL stream
         if (e == hipSuccess) e = hipMalloc(&m->part[g], 16);
         if (e == hipSuccess) e = hipMalloc(&m->all[g], (size_t)16 * ndev);
         if (e != hipSuccess) { aesgcm_mgpu_destroy(m); return hip_fail(e, "mgpu buffers"); }

@@ -25,7 +25,14 @@ typedef uint64_t u64;
 #define AESGCM_WG (1 << AESGCM_LOG_WG)   /* lanes per workgroup = GHASH lane stride S = radix of the H-power tables */
 #define AESGCM_GMAX 512        /* max workgroups per launch (2 per CU on 256 CUs) */
 #ifndef AESGCM_MAIN_WG
-#define AESGCM_MAIN_WG AESGCM_WG          /* lanes per k_main workgroup (waves are autonomous: any multiple of 64) */
+/* lanes per k_main / k_body workgroup (waves are autonomous: any multiple of 64), two workgroups per CU.  768 = 6 waves
+   per SIMD = an 80-register budget: at 1024 (8 per SIMD, 64 registers) both kernels spilled lane constants to scratch
+   and reloaded them inside the row loop (round-1 ISA: ScratchSize 36/32, three scratch_load per row); at 768 and 896
+   ScratchSize is 0.  Measured on one box, 16 GiB AES-256: 1024 -> 18.22/18.29 ms, 896 -> 18.50/18.59, 768 -> 17.72/17.77. */
+#define AESGCM_MAIN_WG 768
+#endif
+#ifndef AESGCM_PKT_WG
+#define AESGCM_PKT_WG AESGCM_WG           /* lanes per k_pkt / k_pktl workgroup */
 #endif
 #define AESGCM_NPW (AESGCM_WG + 1)       /* entries per power table: exponent digits 0..WG */
 #define AESGCM_LDS_GH 8192     /* bytes: 32 nibble positions x 16 entries x 16 B */

@@ -446,10 +446,10 @@ __global__ __launch_bounds__(AESGCM_WG, 2 * AESGCM_WG / 256) void k_batch(const 
 // k_pkt: many packets under the context's key, one wave per packet (lane body: pkt_lane()).
 // ------------------------------------------------------------------------------------------------
 template <int NR, int DEC>
-__global__ __launch_bounds__(AESGCM_MAIN_WG, AESGCM_WAVES_PER_SIMD) void k_pkt(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const PktParams p) {
+__global__ __launch_bounds__(AESGCM_PKT_WG, 2 * AESGCM_PKT_WG / 256) void k_pkt(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const PktParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 tid = threadIdx.x, lane = tid & 63u;
-    main_fill_lds(smem, km, tb, tid, true);
+    main_fill_lds(smem, km, tb, tid, true, AESGCM_PKT_WG);
     __syncthreads();
     // packets are dealt to the waves in blocks of p.deal from a dispenser: one atomic per block keeps the single
     // dispenser address far below its ~87 M fetches/s ceiling (measured), and late waves still level the tail.
@@ -490,10 +490,10 @@ __global__ __launch_bounds__(AESGCM_MAIN_WG, AESGCM_WAVES_PER_SIMD) void k_pkt(c
 #define AESGCM_PKTL_WAVES 4          // waves per SIMD the register budget is sized for
 #endif
 template <int NR, int DEC>
-__global__ __launch_bounds__(AESGCM_MAIN_WG, AESGCM_PKTL_WAVES) void k_pktl(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const PktParams p) {
+__global__ __launch_bounds__(AESGCM_PKT_WG, AESGCM_PKTL_WAVES) void k_pktl(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const PktParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 tid = threadIdx.x, lane = tid & 63u;
-    main_fill_lds(smem, km, tb, tid, true, AESGCM_MAIN_WG, true);
+    main_fill_lds(smem, km, tb, tid, true, AESGCM_PKT_WG, GH_TAB_H);
     __syncthreads();
     const u32 nb = (p.n_pkts + 63u) / 64u;
     for (u32 guard = 0; guard <= nb; ++guard) {                // bounded, as every dispenser loop here
@@ -1273,7 +1273,7 @@ int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const vo
     p.data_off = (const u64 *)d_data_off; p.aad_off = (const u64 *)d_aad_off;
     p.n_pkts = (u32)n_pkts; p.pkt_len = (u32)pkt_len; p.aad_len = (u32)aad_len;
     p.aligned = (((uintptr_t)d_in | (uintptr_t)d_out) & 15) == 0 && (d_data_off || pkt_len % 16 == 0);
-    const u32 waves_per_wg = AESGCM_MAIN_WG / 64;
+    const u32 waves_per_wg = AESGCM_PKT_WG / 64;
     u32 wgs = (u32)((n_pkts + waves_per_wg - 1) / waves_per_wg);
     if (wgs > (u32)c->G) wgs = (u32)c->G;
     // shape: one wave per packet (k_pkt) for large packets or few of them, one lane per packet (k_pktl) when there
@@ -1289,7 +1289,7 @@ int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const vo
         wgs = (nb + waves_per_wg - 1) / waves_per_wg;
         if (wgs > (u32)c->G) wgs = (u32)c->G;
         c->counter_base += nb + wgs * waves_per_wg;                                 // every wave ends on one failing fetch
-#define LP(NR, D) hipLaunchKernelGGL((k_pktl<NR, D>), dim3(wgs), dim3(AESGCM_MAIN_WG), AESGCM_LDS_BYTES, st, c->km, c->tables, p)
+#define LP(NR, D) hipLaunchKernelGGL((k_pktl<NR, D>), dim3(wgs), dim3(AESGCM_PKT_WG), AESGCM_LDS_BYTES, st, c->km, c->tables, p)
         if (decrypt) { if (c->nr == 10) LP(10, 1); else if (c->nr == 12) LP(12, 1); else LP(14, 1); }
         else         { if (c->nr == 10) LP(10, 0); else if (c->nr == 12) LP(12, 0); else LP(14, 0); }
 #undef LP
@@ -1300,7 +1300,7 @@ int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const vo
         if (const char *e = getenv("AESGCM_PKT_DEAL")) { const long v = atol(e); if (v >= 1 && v <= 4096) deal = (u32)v; }
         p.deal = deal;
         c->counter_base += (u32)((n_pkts + deal - 1) / deal) + wgs * waves_per_wg;  // every wave ends on one failing fetch
-#define LP(NR, D) hipLaunchKernelGGL((k_pkt<NR, D>), dim3(wgs), dim3(AESGCM_MAIN_WG), AESGCM_LDS_BYTES, st, c->km, c->tables, p)
+#define LP(NR, D) hipLaunchKernelGGL((k_pkt<NR, D>), dim3(wgs), dim3(AESGCM_PKT_WG), AESGCM_LDS_BYTES, st, c->km, c->tables, p)
         if (decrypt) { if (c->nr == 10) LP(10, 1); else if (c->nr == 12) LP(12, 1); else LP(14, 1); }
         else         { if (c->nr == 10) LP(10, 0); else if (c->nr == 12) LP(12, 0); else LP(14, 0); }
 #undef LP

@@ -4,6 +4,7 @@
 // the oracle (oracle/aesgcm_oracle.c, linked in).  It exists because the build container has no GPU:
 // it pins the arithmetic and the index algebra before any GPU minute is spent.  Test infrastructure only.
 #include "../../aes-gcm-128-192-256-bits_amd/csrc/aesgcm_dev.h"
+#include "../../aes-gcm-128-192-256-bits_amd/csrc/aesgcm_bs.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -213,6 +214,49 @@ static void test_units() {
     }
 }
 
+// bitsliced AES (csrc/aesgcm_bs.h): the LUT3-mapped S-box on all 256 inputs, the transpose, and whole blocks (32 per
+// "lane") for the three key sizes against the oracle's literal cipher
+static void test_bitslice() {
+    {   // S-box: byte values 0..255 in 8 lanes-worth of 32 slots
+        for (u32 base = 0; base < 256; base += 32) {
+            u32 x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (u32 i = 0; i < 32; i++) for (u32 b = 0; b < 8; b++) x[b] |= (((base + i) >> b) & 1u) << i;
+            bs_sbox(x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]);
+            for (u32 i = 0; i < 32; i++) {
+                u32 y = 0;
+                for (u32 b = 0; b < 8; b++) y |= ((x[b] >> i) & 1u) << b;
+                CHECK(y == orc_sbox((uint8_t)(base + i)), "bs_sbox %u", base + i);
+            }
+        }
+    }
+    {   // transpose
+        u32 w[32], ref[32];
+        auto r = rnd(128, 4242);
+        memcpy(w, r.data(), 128); memcpy(ref, r.data(), 128);
+        bs_transpose32(w);
+        for (u32 p = 0; p < 32; p++) for (u32 i = 0; i < 32; i++) CHECK(((w[i] >> p) & 1u) == ((ref[p] >> i) & 1u), "transpose %u %u", p, i);
+    }
+    for (int kl : {16, 24, 32}) {
+        auto key = rnd((size_t)kl, 5000 + kl);
+        uint8_t rk[240]; int nr = 0;
+        orc_key_expand(key.data(), (size_t)kl, rk, &nr);
+        static u32 rkm[15 * 128];
+        bs_key_masks(rk, nr, rkm);
+        auto in = rnd(32 * 16, 6000 + kl);
+        u32 st[128];
+        for (int q = 0; q < 128; q++) st[q] = 0;
+        for (u32 i = 0; i < 32; i++) for (u32 j = 0; j < 16; j++) for (u32 b = 0; b < 8; b++) st[8 * j + b] |= (u32)((in[16 * i + j] >> b) & 1u) << i;
+        for (int q = 0; q < 128; q++) st[q] ^= rkm[q];                      // AddRoundKey 0
+        bs_rounds(st, rkm, nr);
+        for (u32 i = 0; i < 32; i++) {
+            uint8_t want[16], got[16];
+            orc_aes_encrypt_block(rk, nr, in.data() + 16 * i, want);
+            for (u32 j = 0; j < 16; j++) { got[j] = 0; for (u32 b = 0; b < 8; b++) got[j] |= (uint8_t)(((st[8 * j + b] >> i) & 1u) << b); }
+            CHECK(memcmp(want, got, 16) == 0, "bitsliced AES-%d block %u", 8 * kl, i);
+        }
+    }
+}
+
 // batch-path pieces: Shoup 4-bit multiply against the bit-serial multiply, in-kernel key schedule against the oracle
 static void test_batch_pieces() {
     static unsigned char smem[BATCH_LDS_BYTES] __attribute__((aligned(16)));
@@ -290,7 +334,7 @@ static void test_packets(int key_len, u64 seed) {
     }
     // the same packets, one lane per packet (k_pktl): tags must equal the ones above, decrypt restores the input
     static unsigned char smem_h[AESGCM_LDS_BYTES] __attribute__((aligned(16)));
-    for (u32 tid = 0; tid < AESGCM_MAIN_WG; tid++) main_fill_lds(smem_h, &E.km, &g_tb, tid, true, AESGCM_MAIN_WG, true);
+    for (u32 tid = 0; tid < AESGCM_MAIN_WG; tid++) main_fill_lds(smem_h, &E.km, &g_tb, tid, true, AESGCM_MAIN_WG, GH_TAB_H);
     ABuf out2(doff[n]);
     std::vector<uint8_t> tags2(16 * n + 16), tags3(16 * n + 16);
     std::vector<int> auth(n, -1);
@@ -486,6 +530,7 @@ int main(int argc, char **argv) {
     int level = argc > 1 ? atoi(argv[1]) : 1;
     init_tables();
     test_units();
+    test_bitslice();
     const u64 W = AESGCM_WG;     // blocks per chunk at the production Tw = 16
     const std::vector<std::pair<u64, u64>> small = {{0, 0}, {0, 1}, {0, 15}, {0, 16}, {0, 17}, {1, 0}, {20, 48}, {28, 48}, {68, 0}, {16, 63 * 16}, {17, 64 * 16}, {0, 65 * 16 + 5},
                                                     {16, (W - 1) * 16}, {17, W * 16}, {0, (W + 1) * 16 + 5}, {4095, 4097}};
