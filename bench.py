@@ -30,7 +30,6 @@ import hashlib
 import json
 import os
 import statistics
-import subprocess
 import sys
 import time
 
@@ -70,10 +69,16 @@ def sha256_file(path):
 
 
 def git_head():
+    """short commit hash without starting a process (this one has the GPU open): $GIT_HEAD, else .git/HEAD by hand"""
+    h = os.environ.get("GIT_HEAD")
+    if h:
+        return h[:7]
     try:
-        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
-                              text=True, timeout=10).stdout.strip() or None
-    except Exception:
+        head = open(os.path.join(ROOT, ".git", "HEAD")).read().strip()
+        if head.startswith("ref:"):
+            head = open(os.path.join(ROOT, ".git", head.split(None, 1)[1])).read().strip()
+        return head[:7] or None
+    except OSError:
         return None
 
 

@@ -1,11 +1,11 @@
 // aesgcm_bs.h -- bitsliced AES for gfx950: the round pipeline (aes_round / aes_last_round, config/config_aes_round.py:120-126,
 // src/aes_last_round.vhd:76) evaluated as boolean circuits on 32 blocks per lane, with NO table lookup at all.
 //
-// Why: on MI355X every ds_read_b32 of the T-table formulation costs the issuing SIMD about 5 issue cycles and a VALU
-// instruction 2 (profiles/microbench/overlap.hip: LDS-lookup waves and VALU waves on one SIMD do not overlap, their
-// costs add), so a table lookup + its address + its share of the XOR tree is ~9 cycles per S-box, while the S-box as
-// a circuit of three-input boolean instructions (v_bitop3_b32, any 3-input function in one VALU op) is ~90 ops per 32
-// S-boxes = 5.6 cycles.
+// EXPERIMENT, NOT PRODUCT (round 2, VERDICT item 9: "decide the 0.70 question with a measurement").  Measured on MI355X
+// (bs_ctr.hip, profiles/microbench/README.md): CTR-only AES-128 1103 GB/s of keystream against 1620 GB/s for the
+// T-table kernel k_main<10,KS>; AES-256 897 against 1232.  The bitsliced form loses by about a quarter with this 90-
+// instruction S-box, so the library keeps the LDS T-table formulation; this header, the S-box mapper
+// (tools/sbox_lut3.py), the CPU parity test (tests/host_emul) and the GPU microbenchmark stay as the evidence.
 //
 // Representation: lane register s[8*j + b] holds bit b (0 = LSB) of state byte j (j = 4*column + row, i.e. byte j of
 // the block in memory order, vec_to_state src/aes_func.vhd:85-103) for 32 blocks: bit i of the register = block i.
@@ -16,7 +16,7 @@
 //               scalar operand), folded into the MixColumns XOR3s
 // The same code runs on the CPU (tests/host_emul) with BS_LUT as a plain function.
 #pragma once
-#include "aesgcm_dev.h"
+#include "../../aes-gcm-128-192-256-bits_amd/csrc/aesgcm_dev.h"
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define BS_LUT(a, b, c, tt) __builtin_amdgcn_bitop3_b32((a), (b), (c), (tt))
@@ -136,18 +136,18 @@ HD void bs_rounds(u32 *s, const u32 *__restrict__ rkm, int nr) {
 }
 
 // 32 x 32 bit-matrix transpose in place: on entry w[p] bit i = element (p, i); on exit w[i] bit p = element (p, i).
-// Stages with 16- and 8-bit granularity are byte permutes (one v_perm_b32 per output word), the rest shift + bit-select.
-HD void bs_transpose32(u32 *w) {
+// Five butterfly stages with compile-time strides (every register index is static).
+template <int J>
+HD void bs_transpose_stage(u32 *w) {
+    constexpr u32 m = J == 16 ? 0x0000FFFFu : J == 8 ? 0x00FF00FFu : J == 4 ? 0x0F0F0F0Fu : J == 2 ? 0x33333333u : 0x55555555u;
 #pragma unroll
-    for (int j = 16; j >= 1; j >>= 1) {
-        const u32 m = j == 16 ? 0x0000FFFFu : j == 8 ? 0x00FF00FFu : j == 4 ? 0x0F0F0F0Fu : j == 2 ? 0x33333333u : 0x55555555u;
-#pragma unroll
-        for (int k = 0; k < 32; k++) {
-            if (k & j) continue;
-            const u32 a = w[k], b = w[k + j];
-            // low halves stay in a, a's high halves go to b's low halves
-            w[k] = (a & m) | ((b << j) & ~m);
-            w[k + j] = ((a >> j) & m) | (b & ~m);
-        }
+    for (int k = 0; k < 32; k++) {
+        if (k & J) continue;
+        const u32 a = w[k], b = w[k + J];
+        w[k] = (a & m) | ((b << J) & ~m);               // low parts stay, b's low parts move up beside them
+        w[k + J] = ((a >> J) & m) | (b & ~m);
     }
+}
+HD void bs_transpose32(u32 *w) {
+    bs_transpose_stage<16>(w); bs_transpose_stage<8>(w); bs_transpose_stage<4>(w); bs_transpose_stage<2>(w); bs_transpose_stage<1>(w);
 }

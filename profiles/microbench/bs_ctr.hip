@@ -2,7 +2,7 @@
 // v_bitop3_b32 (csrc/aesgcm_bs.h), no LDS, no GHASH.  Writes the keystream to HBM (16 B per block, coalesced) like
 // k_main<NR, MODE_KS> does, verifies sampled blocks against the literal byte-wise cipher on the host, and prints GB/s
 // of keystream and the shader clock it sustained -- to be put beside k_main<NR, KS> (profiles/ks_time.py).
-//   hipcc --offload-arch=gfx950 -O3 -I../../aes-gcm-128-192-256-bits_amd/csrc -o bs_ctr bs_ctr.hip && ./bs_ctr
+//   hipcc --offload-arch=gfx950 -O3 -o bs_ctr bs_ctr.hip && ./bs_ctr
 #include "aesgcm_bs.h"
 #include <stdio.h>
 #include <stdlib.h>
@@ -10,7 +10,6 @@
 #include <vector>
 
 struct BsParams {
-    const u32 *rkm;      // (nr + 1) x 128 round-key bit masks
     u32 iv0, iv1, iv2;   // IV, memory-order words
     u32 ctr0;            // counter of block 0
     u32 n_tiles;         // tiles of 2048 blocks (32 per lane x 64 lanes)
@@ -39,7 +38,7 @@ __device__ __forceinline__ void counter_planes(u32 A, u32 *P) {
 }
 
 template <int NR, int WPS>
-__global__ __launch_bounds__(256, WPS) void k_bs_ctr(const BsParams p) {
+__global__ __launch_bounds__(256, WPS) void k_bs_ctr(const u32 *__restrict__ rkm, const BsParams p) {   // rkm: (nr + 1) x 128 round-key bit masks, read through the scalar cache
     const u32 lane = threadIdx.x & 63u;
     const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
     const unsigned long long t0 = clock64(), wc0 = wall_clock64();
@@ -50,14 +49,14 @@ __global__ __launch_bounds__(256, WPS) void k_bs_ctr(const BsParams p) {
 #pragma unroll
         for (int j = 0; j < 12; j++)
 #pragma unroll
-            for (int b = 0; b < 8; b++) s[8 * j + b] = (0u - ((ivw[j >> 2] >> (8 * (j & 3) + b)) & 1u)) ^ p.rkm[8 * j + b];
+            for (int b = 0; b < 8; b++) s[8 * j + b] = (0u - ((ivw[j >> 2] >> (8 * (j & 3) + b)) & 1u)) ^ rkm[8 * j + b];
         u32 P[32];
         counter_planes(p.ctr0 + tile * 2048u + lane, P);
 #pragma unroll
         for (int j = 12; j < 16; j++)
 #pragma unroll
-            for (int b = 0; b < 8; b++) s[8 * j + b] = P[8 * (15 - j) + b] ^ p.rkm[8 * j + b];
-        bs_rounds(s, p.rkm, NR);
+            for (int b = 0; b < 8; b++) s[8 * j + b] = P[8 * (15 - j) + b] ^ rkm[8 * j + b];
+        bs_rounds(s, rkm, NR);
         // back to one block per (lane, i): dword d of block i = transposed plane group d
         u32 w0[32], w1[32], w2[32], w3[32];
 #pragma unroll
@@ -87,15 +86,15 @@ static void run(const char *name, int key_len, int n_cu, size_t bytes) {
     const int wgs = n_cu * WPS * 4 / 4;                       // WPS waves per SIMD: 4 x WPS waves per CU = WPS workgroups of 256
     hipMalloc(&d_cyc, 16 * (size_t)wgs * 4);
     hipMalloc(&p.out, bytes);
-    p.rkm = d_rkm; p.cyc = d_cyc;
+    p.cyc = d_cyc;
     p.iv0 = load_le32(iv); p.iv1 = load_le32(iv + 4); p.iv2 = load_le32(iv + 8);
     p.ctr0 = 2; p.n_tiles = (u32)(bytes / (2048 * 16));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL((k_bs_ctr<NR, WPS>), dim3(wgs), dim3(256), 0, 0, p);      // warm-up
+    hipLaunchKernelGGL((k_bs_ctr<NR, WPS>), dim3(wgs), dim3(256), 0, 0, d_rkm, p);      // warm-up
     float best = 1e30f;
     for (int rep = 0; rep < 3; rep++) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((k_bs_ctr<NR, WPS>), dim3(wgs), dim3(256), 0, 0, p);
+        hipLaunchKernelGGL((k_bs_ctr<NR, WPS>), dim3(wgs), dim3(256), 0, 0, d_rkm, p);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (ms < best) best = ms;

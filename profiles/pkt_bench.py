@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Packet-path workloads for profiling (GPU box):  python profiles/pkt_bench.py KIND [--n N] [--len L] [--key-bits B] [--steps K]
+  KIND = batch  BASELINE config 5: N packets of L bytes, per-packet key and IV (k_batch), SplitMix64 inputs of SURVEY 8(d)
+         pktw   N packets under ONE key, one wave per packet (k_pkt)
+         pktl   N packets under ONE key, one lane per packet (k_pktl)
+Prints one JSON line: ms per launch (median and best of K, HIP-synchronised wall time), packets/s, GiB/s and the
+algorithmic HBM bytes per launch (32 B per block + key/IV/tag traffic)."""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import aesgcm_amd  # noqa: E402,F401
+from aesgcm_amd import lib  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("kind", choices=("batch", "pktw", "pktl"))
+ap.add_argument("--n", type=int, default=1 << 20)
+ap.add_argument("--len", type=int, default=4096)
+ap.add_argument("--key-bits", type=int, default=128)
+ap.add_argument("--steps", type=int, default=5)
+a = ap.parse_args()
+n, pkt, kb = a.n, a.len, a.key_bits // 8
+d_ivs = lib.DeviceBuffer(16 * n)
+d_ivs.fill_splitmix64(0x4956)
+d_pt, d_ct, d_tags = lib.DeviceBuffer(pkt * n), lib.DeviceBuffer(pkt * n), lib.DeviceBuffer(16 * n)
+d_pt.fill_splitmix64(0xAE5C0005)
+if a.kind == "batch":
+    d_keys = lib.DeviceBuffer(kb * n)
+    d_keys.fill_splitmix64(0x4B4559)
+
+    def go():
+        lib.batch_crypt_dev(False, n, kb, d_keys.ptr, d_ivs.ptr, d_pt.ptr, pkt, d_ct.ptr, d_tags.ptr)
+else:
+    os.environ["AESGCM_PKT_SHAPE"] = "w" if a.kind == "pktw" else "l"
+    ctx = lib.Context(bytes(range(kb)))
+
+    def go():
+        ctx.packets_crypt_dev(False, n, d_ivs.ptr, d_pt.ptr, d_ct.ptr, d_tags.ptr, pkt_len=pkt)
+go(); lib.dev_sync()
+ts = []
+for _ in range(a.steps):
+    lib.dev_sync()
+    t0 = time.perf_counter()
+    go()
+    lib.dev_sync()
+    ts.append(time.perf_counter() - t0)
+med, best = statistics.median(ts), min(ts)
+alg = n * (2 * pkt + 16 + 12 + (kb if a.kind == "batch" else 0))
+print(json.dumps({"kind": a.kind, "n_pkts": n, "pkt_len": pkt, "key_bits": a.key_bits, "ms_median": round(med * 1e3, 4), "ms_best": round(best * 1e3, 4),
+                  "mpkt_per_s": round(n / med / 1e6, 2), "gib_per_s": round(n * pkt / med / 2**30, 1), "alg_bytes_per_launch": alg,
+                  "alg_gb_per_s": round(alg / med / 1e9, 1), "frac_of_hbm_peak": round(alg / med / 8e12, 4)}))

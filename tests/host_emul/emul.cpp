@@ -4,7 +4,7 @@
 // the oracle (oracle/aesgcm_oracle.c, linked in).  It exists because the build container has no GPU:
 // it pins the arithmetic and the index algebra before any GPU minute is spent.  Test infrastructure only.
 #include "../../aes-gcm-128-192-256-bits_amd/csrc/aesgcm_dev.h"
-#include "../../aes-gcm-128-192-256-bits_amd/csrc/aesgcm_bs.h"
+#include "../../profiles/microbench/aesgcm_bs.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
