@@ -451,11 +451,22 @@ HD void main_fill_lds(unsigned char *smem, const KeyMaterial *km, const DevTable
 // block loads/stores with the ragged last block handled bytewise (gcm_ghash.vhd:225-246 byte-valid
 // mask = zero padding on the right; gcm_gctr.vhd:184 byte-valid passthrough on the data output)
 HD uint4 load_block_bytes(const unsigned char *p, u32 nbytes) {
+    // a whole block at a 4-byte aligned address (1500-byte frames, 20/28-byte headers: packets that are not a multiple
+    // of 16 bytes apart) goes as four dwords instead of sixteen byte loads
+    if (nbytes == 16 && (((uintptr_t)p) & 3) == 0) {
+        const u32 *q = reinterpret_cast<const u32 *>(p);
+        return make_uint4(q[0], q[1], q[2], q[3]);
+    }
     u32 w[4] = {0, 0, 0, 0};
     for (u32 k = 0; k < nbytes; k++) w[k >> 2] |= (u32)p[k] << (8 * (k & 3));
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 HD void store_block_bytes(unsigned char *p, uint4 v, u32 nbytes) {
+    if (nbytes == 16 && (((uintptr_t)p) & 3) == 0) {
+        u32 *q = reinterpret_cast<u32 *>(p);
+        q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w;
+        return;
+    }
     const u32 w[4] = {v.x, v.y, v.z, v.w};
     for (u32 k = 0; k < nbytes; k++) p[k] = (unsigned char)(w[k >> 2] >> (8 * (k & 3)));
 }
@@ -1007,6 +1018,42 @@ HD G128 shoup_mul(G128 y, const unsigned char *lds, u32 tab) {
             const u32x4_t t = LDS_LD128(lds, nib16 + tab);
             z0 ^= t.x; z1 ^= t.y; z2 ^= t.z; z3 ^= t.w;
         }
+    }
+    G128 z; z.w[0] = z0; z.w[1] = z1; z.w[2] = z2; z.w[3] = z3;
+    return z;
+}
+
+// ---- k_batch2 pieces -----------------------------------------------------------------------------
+// Byte-wise variant of the same method: TWO 16-entry tables per constant c, Th[v] = v*c and Tl[v] = v*c*x^4, so that
+//     Y*c = Horner over Y's 16 bytes:  Z = Z*x^8 xor Th[high nibble] xor Tl[low nibble]
+// halves the shift-and-reduce steps, and the 8 bits shifted out are reduced arithmetically (x^128 = 1 + x + x^2 + x^7,
+// R = 0xE1 || 0^120, src/ghash_gfmul.vhd:37-64) instead of through a table: 16 steps of ~20 VALU + 2 ds_read_b128
+// against 31 steps of ~14 VALU + ds_read_b32 + ds_read_b128.  Measured: VALU instructions per packet 7627 -> see
+// profiles/README.md.
+#define BATCH2_GROUP_LDS 1024u                  /* per packet group: Th(H) | Tl(H) | Th(C) | Tl(C), 256 B each */
+#define BATCH2_LDS_TAB_OFF (AESGCM_LDS_AES_OFF + AESGCM_LDS_AES)
+#define BATCH2_LDS_BYTES(LG) (BATCH2_LDS_TAB_OFF + (AESGCM_WG / 64u) * (64u >> (LG)) * BATCH2_GROUP_LDS)
+// Z * x^8: shift right by one byte; the byte b that falls out (bit k of b = GCM bit 127 - k) comes back as
+// b * (1 + x + x^2 + x^7) at the top of word 0
+HD void gf_shift8(u32 &z0, u32 &z1, u32 &z2, u32 &z3) {
+    const u32 b = z3 & 0xFFu;
+    z3 = (z3 >> 8) | (z2 << 24); z2 = (z2 >> 8) | (z1 << 24); z1 = (z1 >> 8) | (z0 << 24);
+    z0 = xor3(z0 >> 8, b << 24, b << 23) ^ (b << 22) ^ (b << 17);
+}
+HD G128 gf_mulx4(G128 v) { return gf_mulx(gf_mulx(gf_mulx(gf_mulx(v)))); }
+// Y * c through the two tables at LDS byte offsets tab (Th) and tab + 256 (Tl), entries = 4 BE words
+HD G128 shoup2_mul(G128 y, const unsigned char *lds, u32 tab) {
+    u32 z0 = 0, z1 = 0, z2 = 0, z3 = 0;
+#pragma unroll
+    for (int bi = 15; bi >= 0; bi--) {
+        const u32 w = y.w[bi >> 2];
+        const int sh = 8 * (3 - (bi & 3));
+        const u32 hi = (sh ? (w >> sh) : w) & 0xF0u;
+        const u32 lo = (sh ? (w >> (sh - 4)) : (w << 4)) & 0xF0u;
+        if (bi != 15) gf_shift8(z0, z1, z2, z3);
+        const u32x4_t a = LDS_LD128(lds, hi + tab);
+        const u32x4_t c = LDS_LD128(lds, lo + (tab + 256u));
+        z0 = xor3(z0, a.x, c.x); z1 = xor3(z1, a.y, c.y); z2 = xor3(z2, a.z, c.z); z3 = xor3(z3, a.w, c.w);
     }
     G128 z; z.w[0] = z0; z.w[1] = z1; z.w[2] = z2; z.w[3] = z3;
     return z;

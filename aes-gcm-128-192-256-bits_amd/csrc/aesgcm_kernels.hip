@@ -443,6 +443,180 @@ __global__ __launch_bounds__(AESGCM_WG, 2 * AESGCM_WG / 256) void k_batch(const 
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_batch2: the same job with G = 2^LG lanes per packet, i.e. 64 / G packets per wave (LG = 4: four packets of 16 lanes).
+// What a packet pays besides its AES and one GHASH multiply per block is the cross-lane tree (LG levels), the H^q chain
+// and the two closing multiplies -- per WAVE: with four packets in a wave those ~12 table multiplies are shared by four
+// packets, and the tree is 4 levels instead of 6.  Round keys can no longer be scalar (each lane group has its own key):
+// they live in vector registers (4 waves per SIMD).  GHASH multiplies use the byte-wise two-table form (shoup2_mul).
+// LDS: T-tables as everywhere, then 1 KiB per packet group (tables of H and of the current tree constant).
+// ------------------------------------------------------------------------------------------------
+template <int LG>
+__device__ __forceinline__ G128 group_bcast(G128 v, u32 lane, u32 src_l) {
+    const int src = (int)((lane & ~((1u << LG) - 1u)) + src_l);
+    G128 r;
+    r.w[0] = __shfl(v.w[0], src); r.w[1] = __shfl(v.w[1], src); r.w[2] = __shfl(v.w[2], src); r.w[3] = __shfl(v.w[3], src);
+    return r;
+}
+template <int LG>
+__device__ __forceinline__ void shoup2_build(unsigned char *smem, u32 tab, G128 c, u32 l) {
+#pragma unroll
+    for (u32 v = l; v < 16; v += (1u << LG)) {               // 16 entries per table, built by the group's own lanes
+        const G128 e = shoup_entry(c, v), el = gf_mulx4(e);
+        *reinterpret_cast<uint4 *>(smem + tab + 16 * v) = make_uint4(e.w[0], e.w[1], e.w[2], e.w[3]);
+        *reinterpret_cast<uint4 *>(smem + tab + 256 + 16 * v) = make_uint4(el.w[0], el.w[1], el.w[2], el.w[3]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// the largest value of a group-uniform quantity over the wave's 64 >> LG packet groups (wave-uniform result)
+template <int LG>
+__device__ __forceinline__ u32 groups_max(u32 v) {
+    u32 m = 0;
+#pragma unroll
+    for (u32 g = 0; g < (64u >> LG); g++) { const u32 x = (u32)__builtin_amdgcn_readlane((int)v, (int)(g << LG)); m = x > m ? x : m; }
+    return m;
+}
+
+template <int NR, int DEC, int LG>
+__global__ __launch_bounds__(AESGCM_WG, 4) void k_batch2(const DevTables *__restrict__ tb, const BatchParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr u32 G = 1u << LG, P = 64u >> LG;
+    const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    main_fill_lds(smem, nullptr, tb, tid, false, AESGCM_WG);
+    __syncthreads();
+    const u32 lb = (lane & 31u) << 2;
+    const u32 grp = lane >> LG, l = lane & (G - 1u);
+    const u32 tabH = BATCH2_LDS_TAB_OFF + (wave * P + grp) * BATCH2_GROUP_LDS, tabC = tabH + 512u;
+    constexpr u32 KEYLEN = 4 * (NR - 6);
+    // packets are dealt in blocks of p.deal (a multiple of P) per dispenser fetch; bounded on purpose (as every dispenser loop)
+    const u32 K = p.deal, nb = (p.n_pkts + K - 1) / K;
+    u32 pk0 = 0, pk_end = 0;
+    for (u32 guard = 0; guard <= p.n_pkts; ++guard, pk0 += P) {
+        if (pk0 >= pk_end) {
+            u32 b = 0;
+            if (lane == 0) b = atomicAdd(p.counter, 1u) - p.counter_base;
+            b = __builtin_amdgcn_readfirstlane(b);
+            if (b >= nb) break;
+            pk0 = b * K;
+            pk_end = pk0 + K < p.n_pkts ? pk0 + K : p.n_pkts;
+        }
+        const bool act = pk0 + grp < pk_end;                 // groups past the end shadow the first packet; their stores are masked
+        const u32 pkt = act ? pk0 + grp : pk0;
+        const unsigned char *key = p.keys + (size_t)pkt * KEYLEN;
+        const unsigned char *ivp = p.ivs + (size_t)pkt * 12;
+        u32 pkt_len = p.pkt_len, aad_len = p.aad_len;
+        u64 doff = (u64)pkt * p.pkt_len, aoff = (u64)pkt * p.aad_len;
+        if (p.data_off) { doff = p.data_off[pkt]; pkt_len = (u32)(p.data_off[pkt + 1] - doff); }
+        if (p.aad_off) { aoff = p.aad_off[pkt]; aad_len = (u32)(p.aad_off[pkt + 1] - aoff); }
+        const bool aligned = p.aligned && ((doff & 15) == 0);
+        const unsigned char *aad = p.aad ? p.aad + aoff : nullptr;
+        const unsigned char *in = p.in + doff;
+        unsigned char *out = p.out + doff;
+        const u32 n_aad = (aad_len + 15) / 16, n_ct = (pkt_len + 15) / 16, n_seq = n_aad + n_ct;
+        const u32 q = (n_seq + G - 1) / G;                  // blocks per lane (0 for an empty packet)
+        const u32 pad = G * q - n_seq;                      // front padding slots
+        const u32 qmax = groups_max<LG>(q), nct_max = groups_max<LG>(n_ct);
+
+        // ---- aes_kexp for this lane's packet (config/config_aes_kexp.py:128-159); every lane of a group computes the same words
+        u32 rk[4 * (NR + 1)];
+        batch_key_expand<NR>(key, rk, smem, lb);
+        const u32 iv0 = load_le32(ivp), iv1 = load_le32(ivp + 4), iv2 = load_le32(ivp + 8);
+
+        // ---- H = E_K(0^128) on lane 0 and E_K(IV || 1) on lane 1 of the group (gcm_gctr.vhd:141-145), one pass for both
+        G128 h, ej0;
+        {
+            u32 s0 = (l == 0 ? 0u : iv0) ^ rk[0], s1 = (l == 0 ? 0u : iv1) ^ rk[1], s2 = (l == 0 ? 0u : iv2) ^ rk[2];
+            u32 s3 = (l == 0 ? 0u : 0x01000000u) ^ rk[3];
+            aes_rounds_lds<NR>(s0, s1, s2, s3, rk, smem, lb);
+            const G128 e = mo_to_be(make_uint4(s0, s1, s2, s3));
+            h = group_bcast<LG>(e, lane, 0);
+            ej0 = group_bcast<LG>(e, lane, 1);
+        }
+        shoup2_build<LG>(smem, tabH, h, l);
+
+        G128 acc; acc.w[0] = acc.w[1] = acc.w[2] = acc.w[3] = 0;
+        // GHASH over the input must precede the CTR pass when decrypting (in-place safe); after it when encrypting
+#pragma unroll
+        for (int phase = 0; phase < 2; phase++) {
+            const bool do_ghash = (phase == 0) == (DEC != 0);
+            if (do_ghash) {
+                if (!DEC) __threadfence_block();           // this wave's ciphertext stores are visible to its other lanes
+                for (u32 k = 0; k < qmax; k++) {
+                    if (k < q) {
+                        if (k) acc = shoup2_mul(acc, smem, tabH);
+                        const u32 v = l * q + k;
+                        if (v >= pad) {
+                            const G128 b = batch_seq_block(aligned, aad_len, pkt_len, aad, DEC ? in : out, n_aad, v - pad);
+                            acc.w[0] ^= b.w[0]; acc.w[1] ^= b.w[1]; acc.w[2] ^= b.w[2]; acc.w[3] ^= b.w[3];
+                        }
+                    }
+                }
+            } else {
+                const CtrConsts cc = ctr_round1_consts(iv0, iv1, iv2, rk, smem, lb);
+                for (u32 i = l; i < nct_max; i += G) {
+                    if (i < n_ct) {
+                        const u32 off = 16 * i, rem = pkt_len - off;
+                        uint4 x;
+                        const bool full = aligned && rem >= 16;
+                        if (full) x = *reinterpret_cast<const uint4 *>(in + off);
+                        else x = load_block_bytes(in + off, rem < 16 ? rem : 16);
+                        u32 s0, s1, s2, s3;
+                        ctr_rounds_lds<NR>(bswap32(2u + i), cc, s0, s1, s2, s3, rk, smem, lb);
+                        const uint4 y = make_uint4(x.x ^ s0, x.y ^ s1, x.z ^ s2, x.w ^ s3);
+                        if (act) {
+                            if (full) *reinterpret_cast<uint4 *>(out + off) = y;
+                            else store_block_bytes(out + off, y, rem < 16 ? rem : 16);
+                        }
+                    }
+                }
+            }
+        }
+
+        // ---- H^q per group by square-and-multiply (squaring is linear: gf_sqr, no table); q differs between groups
+        G128 cpow = h;
+        if (qmax > 1) {
+            bool started = false;
+            for (int b = 31 - (int)__builtin_clz(qmax); b >= 0; b--) {
+                if (started) cpow = gf_sqr(cpow);
+                if ((q >> b) & 1u) {
+                    if (started) cpow = shoup2_mul(cpow, smem, tabH);
+                    started = true;
+                }
+            }
+        }
+        // ---- cross-lane tree inside the group: c_0 = H^q, c_{j+1} = c_j^2
+#pragma unroll 1
+        for (int j = 0; j < LG; j++) {
+            shoup2_build<LG>(smem, tabC, cpow, l);
+            const G128 t = shoup2_mul(acc, smem, tabC);
+            G128 o;
+            o.w[0] = __shfl_xor(t.w[0], 1 << j); o.w[1] = __shfl_xor(t.w[1], 1 << j);
+            o.w[2] = __shfl_xor(t.w[2], 1 << j); o.w[3] = __shfl_xor(t.w[3], 1 << j);
+            if (l & (1u << j)) { acc.w[0] ^= o.w[0]; acc.w[1] ^= o.w[1]; acc.w[2] ^= o.w[2]; acc.w[3] ^= o.w[3]; }
+            if (j < LG - 1) cpow = gf_sqr(cpow);
+        }
+        // ---- the group's last lane holds P = sum X_i H^(n-1-i); tag = ((P*H) ^ L)*H ^ E_K(J0)  (gcm_ghash.vhd:257,293)
+        G128 y = shoup2_mul(acc, smem, tabH);
+        y.w[1] ^= aad_len * 8u; y.w[3] ^= pkt_len * 8u;           // both < 2^32 bits by the ABI's limits
+        y = shoup2_mul(y, smem, tabH);
+        y.w[0] ^= ej0.w[0]; y.w[1] ^= ej0.w[1]; y.w[2] ^= ej0.w[2]; y.w[3] ^= ej0.w[3];
+        if (l == G - 1u && act) {
+            const uint4 tag = be_to_mo(y);
+            store_block_bytes(p.tags + (size_t)pkt * 16, tag, 16);
+            if (DEC && p.auth) {
+                int ok = 1;
+                if (p.expect) {
+                    const uint4 e = load_block_bytes(p.expect + (size_t)pkt * 16, 16);
+                    ok = ((e.x ^ tag.x) | (e.y ^ tag.y) | (e.z ^ tag.z) | (e.w ^ tag.w)) == 0;
+                }
+                p.auth[pkt] = ok;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_pkt: many packets under the context's key, one wave per packet (lane body: pkt_lane()).
 // ------------------------------------------------------------------------------------------------
 template <int NR, int DEC>
@@ -629,6 +803,10 @@ static int set_lds_attrs(int device, DeviceState *ds) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktl<NR, D>), hipFuncAttributeMaxDynamicSharedMemorySize, AESGCM_LDS_BYTES))
     SETATTRB(10, 0); SETATTRB(12, 0); SETATTRB(14, 0); SETATTRB(10, 1); SETATTRB(12, 1); SETATTRB(14, 1);
 #undef SETATTRB
+#define SETATTRB2(NR, D, LG) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch2<NR, D, LG>), hipFuncAttributeMaxDynamicSharedMemorySize, BATCH2_LDS_BYTES(LG)))
+    SETATTRB2(10, 0, 4); SETATTRB2(12, 0, 4); SETATTRB2(14, 0, 4); SETATTRB2(10, 1, 4); SETATTRB2(12, 1, 4); SETATTRB2(14, 1, 4);
+
+#undef SETATTRB2
     ds->attrs = true;
     return AESGCM_OK;
 }
@@ -1338,6 +1516,27 @@ static int batch_launch(int device, int decrypt, size_t n_pkts, size_t key_len, 
     const int nr = (int)(key_len / 4 + 6);
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipMemsetAsync(p.counter, 0, 4, st));
+    // shape: 16 lanes per packet (k_batch2<.., 4>: four packets share a wave's tree and closing multiplies) once there are
+    // enough packets to fill the machine that way (one 1024-lane workgroup per CU = 64 packets per CU), else one wave
+    // per packet (k_batch).  AESGCM_BATCH_LG=4|6 forces one.  Measured, 2^20 packets AES-128 (profiles/r02c): 4 KiB 11.9 ->
+    // 6.6 ms, 1 KiB 7.8 -> 2.8 ms, 256 B (2^22 packets) 30.0 -> 5.7 ms; 32 lanes per packet was never better than 16.
+    int lg = n_pkts >= (size_t)64 * ds->n_cu ? 4 : 6;
+    if (const char *e = getenv("AESGCM_BATCH_LG")) { const int v = atoi(e); if (v == 4 || v == 6) lg = v; }
+    if (lg < 6) {
+        const u32 P = 64u >> lg, per_wg = waves_per_wg * P;
+        wgs = (u32)((n_pkts + per_wg - 1) / per_wg);
+        if (wgs > (u32)ds->n_cu) wgs = (u32)ds->n_cu;
+        u32 deal = (u32)(n_pkts / ((size_t)wgs * waves_per_wg * 16));
+        deal = deal < P ? P : deal > 8 * P ? 8 * P : (deal + P - 1) / P * P;
+        p.deal = deal;
+#define LB2(NR, D, LG) hipLaunchKernelGGL((k_batch2<NR, D, LG>), dim3(wgs), dim3(AESGCM_WG), BATCH2_LDS_BYTES(LG), st, ds->tables, p)
+#define LB2N(D, LG) do { if (nr == 10) LB2(10, D, LG); else if (nr == 12) LB2(12, D, LG); else LB2(14, D, LG); } while (0)
+        if (decrypt) LB2N(1, 4); else LB2N(0, 4);
+#undef LB2N
+#undef LB2
+        HIPCHK(hipGetLastError());
+        return AESGCM_OK;
+    }
 #define LB(NR, D) hipLaunchKernelGGL((k_batch<NR, D>), dim3(wgs), dim3(AESGCM_WG), BATCH_LDS_BYTES, st, ds->tables, p)
     if (decrypt) { if (nr == 10) LB(10, 1); else if (nr == 12) LB(12, 1); else LB(14, 1); }
     else         { if (nr == 10) LB(10, 0); else if (nr == 12) LB(12, 0); else LB(14, 0); }

@@ -272,6 +272,16 @@ static void test_batch_pieces() {
         for (u32 v = 0; v < 16; v++) { G128 e = shoup_entry(c, v); *reinterpret_cast<uint4 *>(smem + tab + 16 * v) = make_uint4(e.w[0], e.w[1], e.w[2], e.w[3]); }
         const G128 z = shoup_mul(y, smem, tab), want = gf_mul(y, c);
         CHECK(memcmp(&z, &want, 16) == 0, "shoup_mul %d", it);
+        {   // byte-wise variant with the two tables Th, Tl (k_batch2)
+            static unsigned char t2[512] __attribute__((aligned(16)));
+            for (u32 v = 0; v < 16; v++) {
+                const G128 e = shoup_entry(c, v), el = gf_mulx4(e);
+                *reinterpret_cast<uint4 *>(t2 + 16 * v) = make_uint4(e.w[0], e.w[1], e.w[2], e.w[3]);
+                *reinterpret_cast<uint4 *>(t2 + 256 + 16 * v) = make_uint4(el.w[0], el.w[1], el.w[2], el.w[3]);
+            }
+            const G128 z2 = shoup2_mul(y, t2, 0u);
+            CHECK(memcmp(&z2, &want, 16) == 0, "shoup2_mul %d", it);
+        }
         const G128 s1 = gf_sqr(y), s2 = gf_mul(y, y), s3 = gf_sqr(c), s4 = gf_mul(c, c);
         CHECK(memcmp(&s1, &s2, 16) == 0 && memcmp(&s3, &s4, 16) == 0, "gf_sqr %d", it);
     }

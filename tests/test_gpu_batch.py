@@ -9,6 +9,18 @@ from util import golden, batch_inputs, splitmix_bytes
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["default", "lanes16", "lanes64"], autouse=True)
+def batch_shape(request, monkeypatch):
+    """every test here runs with the host's own choice of kernel shape and with each shape forced: 16 lanes per packet
+    (k_batch2: four packets per wave) and 64 lanes per packet (k_batch) -- AESGCM_BATCH_LG is read at every launch"""
+    lg = {"lanes16": "4", "lanes64": "6"}.get(request.param)
+    if lg:
+        monkeypatch.setenv("AESGCM_BATCH_LG", lg)
+    else:
+        monkeypatch.delenv("AESGCM_BATCH_LG", raising=False)
+    return request.param
+
+
 def _run(hip, decrypt, keys, ivs, data, pkt_len, key_len, aad=b"", aad_len=0, expect=None, inplace=False):
     n = len(ivs) // 12
     d_keys, d_ivs = hip.DeviceBuffer(max(len(keys), 16)), hip.DeviceBuffer(max(len(ivs), 16))
