@@ -173,6 +173,15 @@ HD G128 gf_mul(G128 x, G128 v) {
     G128 z; z.w[0] = z0; z.w[1] = z1; z.w[2] = z2; z.w[3] = z3;
     return z;
 }
+// multiply a field element by x (one right shift with reduction)
+HD G128 gf_mulx(G128 v) {
+    const u32 lsb = 0u - (v.w[3] & 1u);
+    G128 r;
+    r.w[3] = (v.w[3] >> 1) | (v.w[2] << 31); r.w[2] = (v.w[2] >> 1) | (v.w[1] << 31); r.w[1] = (v.w[1] >> 1) | (v.w[0] << 31);
+    r.w[0] = (v.w[0] >> 1) ^ (lsb & 0xE1000000u);
+    return r;
+}
+HD G128 gf_mulx4(G128 v) { return gf_mulx(gf_mulx(gf_mulx(gf_mulx(v)))); }
 HD uint4 gf_mul_mo(uint4 a, uint4 b) { return be_to_mo(gf_mul(mo_to_be(a), mo_to_be(b))); }
 HD uint4 gf_one_mo() { return make_uint4(0x80u, 0u, 0u, 0u); }   // the field's 1: byte 0 = 0x80
 
@@ -206,6 +215,14 @@ HD u32 xor3(u32 a, u32 b, u32 c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0
 #define LDS_LD128(lds, off) (*(const u32x4_t *)((lds) + (off)))
 HD u32 xor3(u32 a, u32 b, u32 c) { return a ^ b ^ c; }
 #endif
+
+// Z * x^8: shift right by one byte; the byte b that falls out (bit k of b = GCM bit 127 - k) comes back as
+// b * (1 + x + x^2 + x^7) at the top of word 0
+HD void gf_shift8(u32 &z0, u32 &z1, u32 &z2, u32 &z3) {
+    const u32 b = z3 & 0xFFu;
+    z3 = (z3 >> 8) | (z2 << 24); z2 = (z2 >> 8) | (z1 << 24); z1 = (z1 >> 8) | (z0 << 24);
+    z0 = xor3(z0 >> 8, b << 24, b << 23) ^ (b << 22) ^ (b << 17);
+}
 
 // ------------------------------------------------------------------------------------------------
 // Hot loop piece 1: Nr AES rounds on one counter/ECB block per lane, T-table lookups from LDS.
@@ -364,7 +381,13 @@ struct MainParams {
     u32 aad_aligned;             // AAD pointer 16-byte aligned
     u64 *trace;                  // optional per-workgroup {start, end, HW_ID | XCC_ID << 32, chunks done} (measurement support)
     uint4 *ej0;                  // GHASH modes: where the wave that owns chunk 0 leaves E_K(IV || 1) for k_combine (or NULL)
+    u32 tail;                    // 1: single-chunk whole message -- the wave that owns chunk 0 also finishes the tag (no k_combine launch)
+    uint4 *tag_out, *tag_host;   // tail: where the tag goes (device slot, and the pinned host slot or NULL)
 };
+// LDS of a tail launch (one workgroup): the usual 72 KiB, then the nibble tables of H and the per-lane Shoup tables
+#define AESGCM_LDS_TAIL_H AESGCM_LDS_BYTES
+#define AESGCM_LDS_TAIL_LANE (AESGCM_LDS_BYTES + 8192u)
+#define AESGCM_LDS_TAIL_BYTES (AESGCM_LDS_BYTES + 8192u + 32768u)
 
 #define AESGCM_MAX_CHUNKS (1u << 18)   /* 64 lane accumulators (1 KiB) per chunk: at most 256 MiB of them; k_fold measured ~0.8 ns per chunk (about 3x its LDS-array floor of one table multiply per item) */
 
@@ -378,6 +401,8 @@ HD void main_geometry(u64 n_seq, u32 tw_override, u64 *rows, u32 *Tw, u32 *C) {
     const u64 R = (n_seq + 63) / 64;
     u64 t;
     if (tw_override) t = tw_override;
+    else if (R <= 4) t = R;                                        // <= 4 KiB: ONE chunk; its wave finishes the tag itself (k_main's tail: a single launch)
+    else if (R <= 256) t = (R + 63) / 64;                          // <= 256 KiB: at most 64 chunks, which k_combine folds itself (no k_fold launch)
     else if (R <= 32768) { t = R / 2048; if (t < 1) t = 1; }      // <= 32 MiB: ~2k chunks
     else t = R < (1u << 18) ? 16 : 32;
     const u64 tmin = (R + AESGCM_MAX_CHUNKS - 1) / AESGCM_MAX_CHUNKS;
@@ -775,11 +800,28 @@ HD uint4 body_chunk_lane(const KeyMaterial *__restrict__ km, const DevTables *__
 }
 
 // ---- k_combine pieces --------------------------------------------------------------------------
-#define COMBINE_THREADS (AESGCM_GMAX + 64)   /* GMAX partial lanes + the length-block lane + the E_K(J0) lane, rounded to waves */
+// One workgroup per message (or per shard / streaming step).  Round 2: the launch also folds up to 64 chunk items itself
+// (two Horner stages with the key's precomputed H^(2^k) tables, as k_fold does for more), multiplies lane L by its own
+// constant H^(63-L) through a per-lane two-table Shoup multiply in LDS instead of a 128-step bit-serial loop, and
+// closes the tag with two table multiplies by H:  tag = ((P*H) ^ L)*H ^ E_K(J0)  (gcm_ghash.vhd:257,293).
+// A 64 KiB message is now k_main + k_combine (it was k_main + k_fold + k_combine + a 16-byte copy kernel).
+#define COMBINE_THREADS (AESGCM_GMAX + 64)   /* GMAX gathered-partial lanes, rounded up to waves */
 enum { PARTS_NONE = 0, PARTS_GATHERED = 1, PARTS_ITEM = 2 };
+#define COMBINE_FOLD_GROUP 8u                /* items per wave in the in-launch fold */
+#define COMBINE_MAX_ITEMS 64u
+#define CMB_LDS_TABA 0u                      /* nibble tables of H^(eA): items are eA blocks apart */
+#define CMB_LDS_TABC 8192u                   /* ... of H^(8 eA): groups of 8 items */
+#define CMB_LDS_TABH 16384u                  /* ... of H: the two closing multiplies */
+#define CMB_LDS_STAGE 24576u                 /* 8 wave results x 1 KiB */
+#define CMB_LDS_LANE 32768u                  /* per-lane Shoup tables: Th at + v*1024 + lane*16, Tl 16 KiB further */
+#define CMB_LDS_SBOX 65536u
+#define CMB_LDS_RED 65792u                   /* one 16-byte slot per wave */
+#define CMB_LDS_BYTES (CMB_LDS_RED + 16u * (COMBINE_THREADS / 64u))
 struct CombineParams {
-    const uint4 *parts; u32 np; u32 kind;   // GATHERED: np weighted 16-byte partials (shards); ITEM: one 64-lane item of k_fold
+    const uint4 *parts; u32 np; u32 kind;   // GATHERED: np weighted 16-byte partials (shards); ITEM: np <= 64 chunk items of 64 lanes, eA blocks apart
     u32 stride;                  // GATHERED: distance between consecutive partials in 16-byte units (0 = 1): an all-gather of M messages' partials leaves [rank][message]
+    u64 eA;                      // ITEM, np > 1: blocks between the ends of consecutive items (a power of two: the tables come from KeyMaterial::ptab)
+    const uint4 *tabA, *tabC;    // device pointers to the nibble tables of H^eA and H^(8 eA) (filled in by the host side)
     u32 want_tag;                // 1 = TAG, 0 = POLY
     u64 e;                       // POLY: exponent applied to the folded partials
     const uint4 *carry; u64 e_carry; u32 has_carry;
@@ -787,33 +829,98 @@ struct CombineParams {
     u32 iv0, iv1, iv2;
     const uint4 *ej0;            // E_K(IV || 1) left by k_main, or NULL: k_combine computes it (one lane, bytewise: ~15 us)
     uint4 *out;
+    uint4 *out_host;             // optional second copy of the result in host-visible (pinned, mapped) memory: no copy kernel for the tag
 };
-// what lane `tid` contributes to the XOR fold
-HD G128 combine_lane(const KeyMaterial *__restrict__ km, const uint8_t *sbox, const CombineParams &p, u32 tid) {
-    G128 z; z.w[0] = z.w[1] = z.w[2] = z.w[3] = 0;
-    const bool tag = p.want_tag != 0;
-    if (p.kind == PARTS_ITEM && tid < 64) {
-        // lane L of the last item carries H^(63-L); TAG mode needs the polynomial times H^2 (tag = P*H^2 ^ L*H ^ E_K(J0))
-        z = gf_mul(mo_to_be(p.parts[tid]), mo_to_be(km->pw[0][63 - tid + (tag ? 2 : 0)]));
-    } else if (p.kind == PARTS_GATHERED && tid < p.np) {
-        z = mo_to_be(p.parts[(size_t)tid * (p.stride ? p.stride : 1u)]);
-        if (tag) z = gf_mul(z, mo_to_be(km->pw[0][2]));
-    } else if (tag && tid == AESGCM_GMAX) {
-        // length block [8*len(A)]_64 || [8*len(C)]_64 (gcm_ghash.vhd:257) times H
-        G128 L; const u64 a = p.aad_len * 8, c = p.ct_len * 8;
-        L.w[0] = (u32)(a >> 32); L.w[1] = (u32)a; L.w[2] = (u32)(c >> 32); L.w[3] = (u32)c;
-        z = gf_mul(L, mo_to_be(km->h));
-    } else if (tag && tid == AESGCM_GMAX + 1) {
-        // E_K(IV || 0^31 1): the J0 block the RTL latches first (gcm_ghash.vhd:158-169)
-        if (p.ej0) return mo_to_be(*p.ej0);
-        uint8_t j0[16], o[16];
-        const u32 ivw[3] = {p.iv0, p.iv1, p.iv2};
-        for (int k = 0; k < 12; k++) j0[k] = (uint8_t)(ivw[k >> 2] >> (8 * (k & 3)));
-        j0[12] = 0; j0[13] = 0; j0[14] = 0; j0[15] = 1;
-        aes_block_bytes(km->rk_bytes, (int)km->nr, sbox, j0, o);
-        z = mo_to_be(make_uint4(load_le32(o), load_le32(o + 4), load_le32(o + 8), load_le32(o + 12)));
+// in-launch fold, stage a: wave w of J = ceil(np / 8) folds its (up to) 8 consecutive items; groups are cut from the END,
+// so only the first one is short and group ends stay 8 eA apart
+HD uint4 combine_fold_wave_lane(const CombineParams &p, const unsigned char *smem, u32 w, u32 lane) {
+    const u32 J = (p.np + COMBINE_FOLD_GROUP - 1) / COMBINE_FOLD_GROUP;
+    const u32 e = p.np - COMBINE_FOLD_GROUP * (J - 1 - w);
+    const u32 s = w == 0 ? 0 : e - COMBINE_FOLD_GROUP;
+    // all (up to) 8 loads first: they do not depend on the accumulator and each is an L2 round trip
+    uint4 it[COMBINE_FOLD_GROUP];
+#pragma unroll
+    for (u32 k = 0; k < COMBINE_FOLD_GROUP; ++k) it[k] = (s + k < e) ? p.parts[(size_t)(s + k) * 64 + lane] : make_uint4(0, 0, 0, 0);
+    uint4 acc = it[0];
+#pragma unroll
+    for (u32 k = 1; k < COMBINE_FOLD_GROUP; ++k)
+        if (s + k < e) acc = xor4(ghash_mul_const_lds_at(acc, smem, CMB_LDS_TABA), it[k]);
+    return acc;
+}
+// stage b: one wave folds the J staged results (H^(8 eA) apart)
+HD uint4 combine_fold_final_lane(const unsigned char *smem, u32 J, u32 lane) {
+    uint4 acc = *reinterpret_cast<const uint4 *>(smem + CMB_LDS_STAGE + lane * 16u);
+    for (u32 j = 1; j < J; ++j) acc = xor4(ghash_mul_const_lds_at(acc, smem, CMB_LDS_TABC), *reinterpret_cast<const uint4 *>(smem + CMB_LDS_STAGE + j * 1024u + lane * 16u));
+    return acc;
+}
+// Per-lane constant multiply: every lane has its OWN multiplier c (lane L of the last item needs H^(63-L)), so the tables
+// are per lane: entry v of lane `lane` at tab + v*1024 + lane*16 (Th) and 16 KiB further (Tl = Th * x^4) -- consecutive
+// lanes read consecutive 16-byte slots, conflict-free.  ~0.5 us against ~5 us for the 128-step bit-serial gf_mul.
+HD void shoup2_lane_build(unsigned char *lds, u32 tab, G128 c, u32 lane) {
+    G128 b[4];                                     // b[k] = c * x^(3-k): the nibble's bit k (bit 3 <-> x^0)
+    b[3] = c; b[2] = gf_mulx(b[3]); b[1] = gf_mulx(b[2]); b[0] = gf_mulx(b[1]);
+    G128 bl[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) bl[k] = gf_mulx4(b[k]);
+#pragma unroll
+    for (u32 v = 0; v < 16; v++) {
+        u32 h0 = 0, h1 = 0, h2 = 0, h3 = 0, l0 = 0, l1 = 0, l2 = 0, l3 = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) if ((v >> k) & 1u) {
+            h0 ^= b[k].w[0]; h1 ^= b[k].w[1]; h2 ^= b[k].w[2]; h3 ^= b[k].w[3];
+            l0 ^= bl[k].w[0]; l1 ^= bl[k].w[1]; l2 ^= bl[k].w[2]; l3 ^= bl[k].w[3];
+        }
+        *reinterpret_cast<uint4 *>(lds + tab + v * 1024u + lane * 16u) = make_uint4(h0, h1, h2, h3);
+        *reinterpret_cast<uint4 *>(lds + tab + 16384u + v * 1024u + lane * 16u) = make_uint4(l0, l1, l2, l3);
     }
+}
+HD G128 shoup2_lane_mul(G128 y, const unsigned char *lds, u32 tab, u32 lane) {
+    u32 z0 = 0, z1 = 0, z2 = 0, z3 = 0;
+    const u32 base = tab + lane * 16u;
+#pragma unroll
+    for (int bi = 15; bi >= 0; bi--) {
+        const u32 w = y.w[bi >> 2];
+        const int sh = 8 * (3 - (bi & 3));
+        const u32 hi = (sh ? (w >> sh) : w) & 0xF0u;
+        const u32 lo = (sh ? (w >> (sh - 4)) : (w << 4)) & 0xF0u;
+        if (bi != 15) gf_shift8(z0, z1, z2, z3);
+        const u32x4_t a = LDS_LD128(lds, hi * 64u + base);
+        const u32x4_t c = LDS_LD128(lds, lo * 64u + (base + 16384u));
+        z0 = xor3(z0, a.x, c.x); z1 = xor3(z1, a.y, c.y); z2 = xor3(z2, a.z, c.z); z3 = xor3(z3, a.w, c.w);
+    }
+    G128 z; z.w[0] = z0; z.w[1] = z1; z.w[2] = z2; z.w[3] = z3;
     return z;
+}
+// tag = ((P*H) ^ L)*H ^ E_K(IV || 1)  (gcm_ghash.vhd:257,293): two multiplies by the uniform constant H through its nibble
+// tables at LDS offset tabH.  Shared by k_combine and by k_main's single-chunk tail.
+HD G128 close_tag_lds(G128 P, u64 aad_len, u64 ct_len, G128 ej0, const unsigned char *smem, u32 tabH) {
+    G128 L; const u64 a = aad_len * 8, c = ct_len * 8;
+    L.w[0] = (u32)(a >> 32); L.w[1] = (u32)a; L.w[2] = (u32)(c >> 32); L.w[3] = (u32)c;
+    G128 y = mo_to_be(ghash_mul_const_lds_at(be_to_mo(P), smem, tabH));
+    y.w[0] ^= L.w[0]; y.w[1] ^= L.w[1]; y.w[2] ^= L.w[2]; y.w[3] ^= L.w[3];
+    y = mo_to_be(ghash_mul_const_lds_at(be_to_mo(y), smem, tabH));
+    y.w[0] ^= ej0.w[0]; y.w[1] ^= ej0.w[1]; y.w[2] ^= ej0.w[2]; y.w[3] ^= ej0.w[3];
+    return y;
+}
+// k_main's tail, lane part: lane L of the single chunk's item times H^(63-L) (the wave then XOR-folds and closes the tag)
+HD G128 main_tail_lane(const KeyMaterial *__restrict__ km, unsigned char *smem, uint4 acc, u32 lane) {
+    shoup2_lane_build(smem, AESGCM_LDS_TAIL_LANE, mo_to_be(km->pw[0][63 - lane]), lane);
+    return shoup2_lane_mul(mo_to_be(acc), smem, AESGCM_LDS_TAIL_LANE, lane);
+}
+// E_K(IV || 0^31 1): the J0 block the RTL latches first (gcm_ghash.vhd:158-169), bytewise (only when k_main left none behind)
+HD G128 combine_ej0_bytes(const KeyMaterial *__restrict__ km, const uint8_t *sbox, const CombineParams &p) {
+    uint8_t j0[16], o[16];
+    const u32 ivw[3] = {p.iv0, p.iv1, p.iv2};
+    for (int k = 0; k < 12; k++) j0[k] = (uint8_t)(ivw[k >> 2] >> (8 * (k & 3)));
+    j0[12] = 0; j0[13] = 0; j0[14] = 0; j0[15] = 1;
+    aes_block_bytes(km->rk_bytes, (int)km->nr, sbox, j0, o);
+    return mo_to_be(make_uint4(load_le32(o), load_le32(o + 4), load_le32(o + 8), load_le32(o + 12)));
+}
+// length block [8*len(A)]_64 || [8*len(C)]_64 (gcm_ghash.vhd:257)
+HD G128 combine_len_block(const CombineParams &p) {
+    G128 L; const u64 a = p.aad_len * 8, c = p.ct_len * 8;
+    L.w[0] = (u32)(a >> 32); L.w[1] = (u32)a; L.w[2] = (u32)(c >> 32); L.w[3] = (u32)c;
+    return L;
 }
 // H^e as the product of its four radix-WG digit entries (e < WG^4 >= 2^36)
 HD G128 gf_pow_h_digit(const KeyMaterial *km, u64 e, u32 d) { return mo_to_be(km->pw[d][(e >> (AESGCM_LOG_WG * d)) & (u64)(AESGCM_WG - 1)]); }
@@ -893,6 +1000,8 @@ static inline CombineParams plan_combine_tag(const uint4 *parts, u32 np, u32 kin
     q.out = out;
     return q;
 }
+// chunk items handed to k_combine unfolded: their spacing (the host side adds the table pointers)
+static inline CombineParams combine_with_items(CombineParams q, u64 eA) { q.eA = eA; return q; }
 // polynomial value of local partials times H^e (shard partial, aesgcm_ghash)
 static inline CombineParams plan_combine_poly(const uint4 *parts, u32 np, u32 kind, u64 e, uint4 *out) {
     CombineParams q = {};
@@ -956,14 +1065,6 @@ HD u32 shoup_rem_calc(u32 v) {
         z.w[0] = (z.w[0] >> 1) ^ (lsb & 0xE1000000u);
     }
     return z.w[0];                                             // only the top 16 bits can be set
-}
-// multiply a field element by x (one right shift with reduction)
-HD G128 gf_mulx(G128 v) {
-    const u32 lsb = 0u - (v.w[3] & 1u);
-    G128 r;
-    r.w[3] = (v.w[3] >> 1) | (v.w[2] << 31); r.w[2] = (v.w[2] >> 1) | (v.w[1] << 31); r.w[1] = (v.w[1] >> 1) | (v.w[0] << 31);
-    r.w[0] = (v.w[0] >> 1) ^ (lsb & 0xE1000000u);
-    return r;
 }
 // squaring is linear over GF(2): spread the coefficients (x^i -> x^2i), then fold the upper 128 coefficients
 // back with x^128 = 1 + x + x^2 + x^7 (R = 0xE1 || 0^120, src/ghash_gfmul.vhd:37-64).  About a hundred VALU
@@ -1033,14 +1134,6 @@ HD G128 shoup_mul(G128 y, const unsigned char *lds, u32 tab) {
 #define BATCH2_GROUP_LDS 1024u                  /* per packet group: Th(H) | Tl(H) | Th(C) | Tl(C), 256 B each */
 #define BATCH2_LDS_TAB_OFF (AESGCM_LDS_AES_OFF + AESGCM_LDS_AES)
 #define BATCH2_LDS_BYTES(LG) (BATCH2_LDS_TAB_OFF + (AESGCM_WG / 64u) * (64u >> (LG)) * BATCH2_GROUP_LDS)
-// Z * x^8: shift right by one byte; the byte b that falls out (bit k of b = GCM bit 127 - k) comes back as
-// b * (1 + x + x^2 + x^7) at the top of word 0
-HD void gf_shift8(u32 &z0, u32 &z1, u32 &z2, u32 &z3) {
-    const u32 b = z3 & 0xFFu;
-    z3 = (z3 >> 8) | (z2 << 24); z2 = (z2 >> 8) | (z1 << 24); z1 = (z1 >> 8) | (z0 << 24);
-    z0 = xor3(z0 >> 8, b << 24, b << 23) ^ (b << 22) ^ (b << 17);
-}
-HD G128 gf_mulx4(G128 v) { return gf_mulx(gf_mulx(gf_mulx(gf_mulx(v)))); }
 // Y * c through the two tables at LDS byte offsets tab (Th) and tab + 256 (Tl), entries = 4 BE words
 HD G128 shoup2_mul(G128 y, const unsigned char *lds, u32 tab) {
     u32 z0 = 0, z1 = 0, z2 = 0, z3 = 0;

@@ -123,6 +123,7 @@ __global__ __launch_bounds__(AESGCM_MAIN_WG, AESGCM_WAVES_PER_SIMD) void k_main(
     }
     const u64 cyc0 = p.trace ? clock64() : 0;
     main_fill_lds(smem, km, tb, tid, GH);
+    if (GH && p.tail) for (u32 q = tid; q < 512; q += AESGCM_MAIN_WG) reinterpret_cast<uint4 *>(smem + AESGCM_LDS_TAIL_H)[q] = km->htab[q];
     __syncthreads();
     // round-1 constants depend on key and IV only (the lane merely picks which table replica it reads), so they
     // are wave-uniform: keep them in scalar registers, the vector file is full at 8 waves per SIMD
@@ -132,25 +133,41 @@ __global__ __launch_bounds__(AESGCM_MAIN_WG, AESGCM_WAVES_PER_SIMD) void k_main(
     u32 done = 0;
     // bounded on purpose: no wave can own more than C chunks (plus one dry fetch per queue), so a dispenser problem can
     // never turn into a hang
-    u32 q = (blockIdx.x * (AESGCM_MAIN_WG / 64) + (tid >> 6)) % p.nq, dry = 0;       // home queue; queues found empty so far
+    u32 q = p.nq ? (blockIdx.x * (AESGCM_MAIN_WG / 64) + (tid >> 6)) % p.nq : 0, dry = 0;       // home queue; queues found empty so far
     q = __builtin_amdgcn_readfirstlane(q);
+    const u32 wave_id = __builtin_amdgcn_readfirstlane(blockIdx.x * (AESGCM_MAIN_WG / 64) + (tid >> 6));
     for (u32 guard = 0; guard <= p.C + 2 * AESGCM_NQ; ++guard) {
-        u32 v = 0;
-        if (lane == 0) v = atomicAdd(p.counter + 16 * q, 1u) - p.qbase[q];
-        v = __builtin_amdgcn_readfirstlane(v);
-        if (v >= p.seg) {                                       // this queue is dry: walk on, stop after a full round
-            if (++dry == p.nq) break;
-            q = q + 1 == p.nq ? 0 : q + 1;
-            continue;
+        u32 c;
+        if (p.nq == 0) {
+            // small launch: at least as many waves as chunks, wave i owns chunk i -- no dispenser round trips on the
+            // latency path of a short message
+            if (guard || wave_id >= p.C) break;
+            c = wave_id;
+        } else {
+            u32 v = 0;
+            if (lane == 0) v = atomicAdd(p.counter + 16 * q, 1u) - p.qbase[q];
+            v = __builtin_amdgcn_readfirstlane(v);
+            if (v >= p.seg) {                                       // this queue is dry: walk on, stop after a full round
+                if (++dry == p.nq) break;
+                q = q + 1 == p.nq ? 0 : q + 1;
+                continue;
+            }
+            c = q * p.seg + v;
+            if (c >= p.C) continue;                                 // the last queue is padded to seg
         }
-        const u32 c = q * p.seg + v;
-        if (c >= p.C) continue;                                 // the last queue is padded to seg
         const uint4 acc = main_chunk_lane<NR, MODE>(km, p, smem, cc, c, lane);
-        if (GH) p.parts[(size_t)c * 64 + lane] = acc;          // the chunk's item: 64 raw lane accumulators (k_fold takes over)
-        if (GH && c == 0 && p.ej0) {                             // E_K(IV || 1) for the tag (gcm_ghash.vhd:158-169), once per launch
+        if (GH) p.parts[(size_t)c * 64 + lane] = acc;          // the chunk's item: 64 raw lane accumulators (k_fold / k_combine take over)
+        if (GH && c == 0 && (p.ej0 || p.tail)) {                 // E_K(IV || 1) for the tag (gcm_ghash.vhd:158-169), once per launch
             u32 s0, s1, s2, s3;
             ctr_rounds_lds<NR>(bswap32(1u), cc, s0, s1, s2, s3, km->rk, smem, (lane & 31u) << 2);
-            if (lane == 0) *p.ej0 = make_uint4(s0, s1, s2, s3);
+            if (lane == 0 && p.ej0) *p.ej0 = make_uint4(s0, s1, s2, s3);
+            if (p.tail) {
+                // single-chunk message: this wave holds the whole polynomial (lane L: B_L); finish the tag here instead of
+                // launching k_combine: B_L * H^(63-L) per lane, XOR fold, tag = ((P*H) ^ L)*H ^ E_K(IV || 1)
+                const G128 P = wave_xor_fold(main_tail_lane(km, smem, acc, lane));
+                const G128 t = close_tag_lds(P, p.aad_len, p.len, mo_to_be(make_uint4(s0, s1, s2, s3)), smem, AESGCM_LDS_TAIL_H);
+                if (lane == 0) { *p.tag_out = be_to_mo(t); if (p.tag_host) *p.tag_host = be_to_mo(t); }
+            }
         }
         ++done;
     }
@@ -249,33 +266,55 @@ __device__ __forceinline__ G128 gf_pow_h(const KeyMaterial *km, u64 e, u32 lane)
 }
 
 __global__ __launch_bounds__(COMBINE_THREADS) void k_combine(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const CombineParams p) {
-    __shared__ uint4 red[COMBINE_THREADS / 64];
-    __shared__ uint8_t s_sbox[256];
-    const u32 tid = threadIdx.x;
-    if (tid < 256) s_sbox[tid] = tb->sbox[tid];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // no static LDS: table offsets are absolute (CMB_LDS_*)
+    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    const bool tag = p.want_tag != 0, items = p.kind == PARTS_ITEM;
+    const u32 J = items ? (p.np + COMBINE_FOLD_GROUP - 1) / COMBINE_FOLD_GROUP : 0;
+    // ---- stage the tables this launch needs
+    if (items && p.np > 1) for (u32 q = tid; q < 512; q += COMBINE_THREADS) reinterpret_cast<uint4 *>(smem + CMB_LDS_TABA)[q] = p.tabA[q];
+    if (J > 1) for (u32 q = tid; q < 512; q += COMBINE_THREADS) reinterpret_cast<uint4 *>(smem + CMB_LDS_TABC)[q] = p.tabC[q];
+    if (tag) for (u32 q = tid; q < 512; q += COMBINE_THREADS) reinterpret_cast<uint4 *>(smem + CMB_LDS_TABH)[q] = km->htab[q];
+    if (tid < 256) smem[CMB_LDS_SBOX + tid] = tb->sbox[tid];
     __syncthreads();
-    G128 z = combine_lane(km, s_sbox, p, tid);
+    // ---- chunk items: Horner in two stages (8 items per wave, then the <= 8 wave results)
+    if (w < J) *reinterpret_cast<uint4 *>(smem + CMB_LDS_STAGE + w * 1024u + lane * 16u) = combine_fold_wave_lane(p, smem, w, lane);
+    __syncthreads();
+    G128 z; z.w[0] = z.w[1] = z.w[2] = z.w[3] = 0;
+    if (items && w == 0) {
+        // lane L of the folded item carries H^(63-L): per-lane constant, per-lane tables
+        const G128 b = mo_to_be(combine_fold_final_lane(smem, J, lane));
+        shoup2_lane_build(smem, CMB_LDS_LANE, mo_to_be(km->pw[0][63 - lane]), lane);
+        z = shoup2_lane_mul(b, smem, CMB_LDS_LANE, lane);
+    } else if (p.kind == PARTS_GATHERED && tid < p.np) {
+        z = mo_to_be(p.parts[(size_t)tid * (p.stride ? p.stride : 1u)]);
+    }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         z.w[0] ^= __shfl_xor(z.w[0], off); z.w[1] ^= __shfl_xor(z.w[1], off);
         z.w[2] ^= __shfl_xor(z.w[2], off); z.w[3] ^= __shfl_xor(z.w[3], off);
     }
-    if ((tid & 63u) == 0) red[tid >> 6] = be_to_mo(z);
+    if (lane == 0) *reinterpret_cast<uint4 *>(smem + CMB_LDS_RED + 16u * w) = be_to_mo(z);
     __syncthreads();
     if (tid < 64) {
-        uint4 r = red[0];
-        for (int k = 1; k < COMBINE_THREADS / 64; k++) r = xor4(r, red[k]);
-        G128 acc = mo_to_be(r);
-        const bool tag = p.want_tag != 0;
+        uint4 r = *reinterpret_cast<const uint4 *>(smem + CMB_LDS_RED);
+        for (u32 k = 1; k < COMBINE_THREADS / 64; k++) r = xor4(r, *reinterpret_cast<const uint4 *>(smem + CMB_LDS_RED + 16u * k));
+        G128 acc = mo_to_be(r);                                   // P = polynomial of this launch's partials (every lane holds it)
         if (!tag && p.e) acc = gf_mul(acc, gf_pow_h(km, p.e, tid));
         if (p.has_carry) {
             G128 c = mo_to_be(*p.carry);
             if (p.e_carry) c = gf_mul(c, gf_pow_h(km, p.e_carry, tid));
-            // TAG mode: the carried value is a plain polynomial prefix, it still needs * H^2
-            if (tag) c = gf_mul(c, mo_to_be(km->pw[0][2]));
             acc.w[0] ^= c.w[0]; acc.w[1] ^= c.w[1]; acc.w[2] ^= c.w[2]; acc.w[3] ^= c.w[3];
         }
-        if (tid == 0) *p.out = be_to_mo(acc);
+        if (tag) {
+            G128 ej0;
+            if (p.ej0) ej0 = mo_to_be(*p.ej0);
+            else ej0 = combine_ej0_bytes(km, smem + CMB_LDS_SBOX, p);
+            acc = close_tag_lds(acc, p.aad_len, p.ct_len, ej0, smem, CMB_LDS_TABH);
+        }
+        if (tid == 0) {
+            *p.out = be_to_mo(acc);
+            if (p.out_host) *p.out_host = be_to_mo(acc);
+        }
     }
 }
 
@@ -735,6 +774,8 @@ struct aesgcm_ctx {
     u32 tw_override = 0;               // AESGCM_TW
     u64 body_min = (u64)1 << 30;       // ranges with an aligned middle of at least this many bytes go through k_body (AESGCM_BODY_MIN):
                                        // the extra launches cost ~50 us, break-even measured near 0.7 GiB (profiles/split_threshold.py)
+    uint4 *h_tag = nullptr;            // 64 bytes of pinned, device-mapped host memory: k_combine leaves the tag here too, so fetching it
+    uint4 *h_tag_dev = nullptr;        //   is a stream synchronisation and a 16-byte host read -- no copy kernel (its device address)
     uint4 *d_tag = nullptr;            // [0] tag / poly result, [1] streaming state Y
     u64 *d_trace = nullptr;            // per-workgroup trace of the last k_main launch (timing mode only)
     u32 last_np = 0;
@@ -767,10 +808,11 @@ static const u64 MAX_SEQ_BLOCKS = ((u64)1) << 36;
 
 template <int MODE>
 static hipError_t launch_main_nr(int nr, dim3 grid, hipStream_t st, const KeyMaterial *km, const DevTables *tb, const MainParams &p) {
+    const unsigned lds = p.tail ? AESGCM_LDS_TAIL_BYTES : AESGCM_LDS_BYTES;
     switch (nr) {
-    case 10: hipLaunchKernelGGL((k_main<10, MODE>), grid, dim3(AESGCM_MAIN_WG), AESGCM_LDS_BYTES, st, km, tb, p); break;
-    case 12: hipLaunchKernelGGL((k_main<12, MODE>), grid, dim3(AESGCM_MAIN_WG), AESGCM_LDS_BYTES, st, km, tb, p); break;
-    default: hipLaunchKernelGGL((k_main<14, MODE>), grid, dim3(AESGCM_MAIN_WG), AESGCM_LDS_BYTES, st, km, tb, p); break;
+    case 10: hipLaunchKernelGGL((k_main<10, MODE>), grid, dim3(AESGCM_MAIN_WG), lds, st, km, tb, p); break;
+    case 12: hipLaunchKernelGGL((k_main<12, MODE>), grid, dim3(AESGCM_MAIN_WG), lds, st, km, tb, p); break;
+    default: hipLaunchKernelGGL((k_main<14, MODE>), grid, dim3(AESGCM_MAIN_WG), lds, st, km, tb, p); break;
     }
     return hipGetLastError();
 }
@@ -788,7 +830,7 @@ static int set_lds_attrs(int device, DeviceState *ds) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (ds->attrs) return AESGCM_OK;
     HIPCHK(hipSetDevice(device));
-#define SETATTR(NR, MODE) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_main<NR, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, AESGCM_LDS_BYTES))
+#define SETATTR(NR, MODE) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_main<NR, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, AESGCM_LDS_TAIL_BYTES))
     SETATTR(10, MODE_ENC); SETATTR(12, MODE_ENC); SETATTR(14, MODE_ENC);
     SETATTR(10, MODE_DEC); SETATTR(12, MODE_DEC); SETATTR(14, MODE_DEC);
     SETATTR(10, MODE_KS);  SETATTR(12, MODE_KS);  SETATTR(14, MODE_KS);
@@ -803,6 +845,7 @@ static int set_lds_attrs(int device, DeviceState *ds) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktl<NR, D>), hipFuncAttributeMaxDynamicSharedMemorySize, AESGCM_LDS_BYTES))
     SETATTRB(10, 0); SETATTRB(12, 0); SETATTRB(14, 0); SETATTRB(10, 1); SETATTRB(12, 1); SETATTRB(14, 1);
 #undef SETATTRB
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_combine), hipFuncAttributeMaxDynamicSharedMemorySize, CMB_LDS_BYTES));
 #define SETATTRB2(NR, D, LG) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch2<NR, D, LG>), hipFuncAttributeMaxDynamicSharedMemorySize, BATCH2_LDS_BYTES(LG)))
     SETATTRB2(10, 0, 4); SETATTRB2(12, 0, 4); SETATTRB2(14, 0, 4); SETATTRB2(10, 1, 4); SETATTRB2(12, 1, 4); SETATTRB2(14, 1, 4);
 
@@ -812,7 +855,7 @@ static int set_lds_attrs(int device, DeviceState *ds) {
 }
 
 // What the fold stage needs to know about the partials a launch produced.
-struct Partials { const uint4 *ptr = nullptr; u32 np = 0; u32 kind = PARTS_NONE; const uint4 *ej0 = nullptr; };
+struct Partials { const uint4 *ptr = nullptr; u32 np = 0; u32 kind = PARTS_NONE; const uint4 *ej0 = nullptr; u64 eA = 0; bool done = false; };   // eA: blocks between chunk items when k_combine folds them itself (np > 1)
 
 static int grow_parts(aesgcm_ctx *c, size_t need) {
     if (need <= c->parts_cap) return AESGCM_OK;
@@ -850,7 +893,7 @@ static int enqueue_fold(aesgcm_ctx *c, const uint4 *items, u32 n, u32 period, u6
 
 // Enqueue the fused kernel over (aad, data) and the k_fold levels over its chunk items; describe the result for k_combine.  mode ENC/DEC: GHASH partials.  mode KS/ECB: no GHASH.
 static int enqueue_main(aesgcm_ctx *c, int mode, const uint8_t iv[12], const void *d_aad, u64 aad_len,
-                        const void *d_in, u64 len, void *d_out, u64 first_block, hipStream_t st, Partials *po) {
+                        const void *d_in, u64 len, void *d_out, u64 first_block, hipStream_t st, Partials *po, bool want_tail = false) {
     const bool gh = (mode == MODE_ENC || mode == MODE_DEC);
     if (po) *po = Partials();
     if (((uintptr_t)d_in & 15) || ((uintptr_t)d_out & 15)) return AESGCM_EALIGN;
@@ -865,9 +908,11 @@ static int enqueue_main(aesgcm_ctx *c, int mode, const uint8_t iv[12], const voi
     if (wgs > (u32)c->G) wgs = (u32)c->G;
     p.counter = c->d_counter + 16;
     plan_queues(C, &p.nq, &p.seg);
+    if ((u64)wgs * (AESGCM_MAIN_WG / 64) >= C) p.nq = 0;        // a wave per chunk: static assignment, the dispensers are not touched
     for (u32 q = 0; q < AESGCM_NQ; q++) p.qbase[q] = c->mq_base[q];
     for (u32 q = 0; q < p.nq; q++) c->mq_base[q] += p.seg + wgs * (AESGCM_MAIN_WG / 64);   // every wave finds every queue dry exactly once
     if (gh && po) { p.ej0 = c->d_tag + 3; po->ej0 = p.ej0; }
+    if (gh && po && want_tail && C == 1) { p.tail = 1; p.tag_out = c->d_tag; p.tag_host = c->h_tag_dev; po->done = true; }
     p.trace = nullptr;
     const bool timed = c->timing && !c->timing_mute;
     if (timed) {
@@ -890,7 +935,15 @@ static int enqueue_main(aesgcm_ctx *c, int mode, const uint8_t iv[12], const voi
         }
     }
     if (timed) { HIPCHK(hipEventRecord(evp.second, st)); c->ev.push_back(evp); }
-    if (gh && po) return enqueue_fold(c, c->parts, C, 1, (u64)64 * p.Tw, 0, st, po);
+    if (gh && po && po->done) return AESGCM_OK;                   // the launch finished the tag itself
+    if (gh && po) {
+        const u64 eA = (u64)64 * p.Tw;
+        if (C <= COMBINE_MAX_ITEMS && (C == 1 || (ptab_ptr(c, eA) && (C <= COMBINE_FOLD_GROUP || ptab_ptr(c, COMBINE_FOLD_GROUP * eA))))) {
+            po->ptr = c->parts; po->np = C; po->kind = PARTS_ITEM; po->eA = eA;   // few chunks: k_combine folds them, no k_fold launch
+            return AESGCM_OK;
+        }
+        return enqueue_fold(c, c->parts, C, 1, eA, 0, st, po);
+    }
     return AESGCM_OK;
 }
 
@@ -946,7 +999,7 @@ static int absorb_range(aesgcm_ctx *c, int mode, const uint8_t iv[12], const voi
     if (!plan_body_split(len, first_block, c->tw_override, c->body_min, &b)) {
         if ((rc = enqueue_main(c, mode, iv, d_aad, aad_len, d_in, len, d_out, first_block, st, &pp))) return rc;
         const u64 nb = (aad_len + 15) / 16 + (len + 15) / 16;
-        return nb ? enqueue_combine(c, plan_combine_carry(pp.ptr, pp.np, pp.kind, state, nb), st) : AESGCM_OK;
+        return nb ? enqueue_combine(c, combine_with_items(plan_combine_carry(pp.ptr, pp.np, pp.kind, state, nb), pp.eA), st) : AESGCM_OK;
     }
     if (((uintptr_t)d_in & 15) || ((uintptr_t)d_out & 15)) return AESGCM_EALIGN;
     const u64 n_aad = (aad_len + 15) / 16;
@@ -955,11 +1008,11 @@ static int absorb_range(aesgcm_ctx *c, int mode, const uint8_t iv[12], const voi
         rc = enqueue_main(c, mode, iv, d_aad, aad_len, d_in, 16 * b.head_blocks, d_out, first_block, st, &pp);
         c->timing_mute = false;
         if (rc) return rc;
-        if ((rc = enqueue_combine(c, plan_combine_carry(pp.ptr, pp.np, pp.kind, state, n_aad + b.head_blocks), st))) return rc;
+        if ((rc = enqueue_combine(c, combine_with_items(plan_combine_carry(pp.ptr, pp.np, pp.kind, state, n_aad + b.head_blocks), pp.eA), st))) return rc;
     }
     if ((rc = enqueue_body(c, mode, iv, b, d_in, d_out, first_block, st, &pp))) return rc;
     if (ej0) *ej0 = pp.ej0;                                      // valid until the next launch on this context overwrites the slot: consumed by the caller's final combine
-    if ((rc = enqueue_combine(c, plan_combine_carry(pp.ptr, pp.np, pp.kind, state, b.body_blocks), st))) return rc;
+    if ((rc = enqueue_combine(c, combine_with_items(plan_combine_carry(pp.ptr, pp.np, pp.kind, state, b.body_blocks), pp.eA), st))) return rc;
     const u64 done = b.head_blocks + b.body_blocks, tail = len - 16 * done;
     if (tail) {
         c->timing_mute = true;
@@ -967,13 +1020,20 @@ static int absorb_range(aesgcm_ctx *c, int mode, const uint8_t iv[12], const voi
                           first_block + done, st, &pp);
         c->timing_mute = false;
         if (rc) return rc;
-        if ((rc = enqueue_combine(c, plan_combine_carry(pp.ptr, pp.np, pp.kind, state, (tail + 15) / 16), st))) return rc;
+        if ((rc = enqueue_combine(c, combine_with_items(plan_combine_carry(pp.ptr, pp.np, pp.kind, state, (tail + 15) / 16), pp.eA), st))) return rc;
     }
     return AESGCM_OK;
 }
 
-static int enqueue_combine(aesgcm_ctx *c, const CombineParams &p, hipStream_t st) {
-    hipLaunchKernelGGL(k_combine, dim3(1), dim3(COMBINE_THREADS), 0, st, c->km, c->tables, p);
+static int enqueue_combine(aesgcm_ctx *c, const CombineParams &p0, hipStream_t st) {
+    CombineParams p = p0;
+    if (p.out == c->d_tag) p.out_host = c->h_tag_dev;             // results that go to the tag slot are mirrored to the pinned host slot
+    if (p.kind == PARTS_ITEM && p.np > 1) {                       // the launch folds the items itself: tables of H^eA, H^(8 eA)
+        p.tabA = ptab_ptr(c, p.eA);
+        p.tabC = p.np > COMBINE_FOLD_GROUP ? ptab_ptr(c, COMBINE_FOLD_GROUP * p.eA) : nullptr;
+        if (p.np > COMBINE_MAX_ITEMS || !p.tabA || (p.np > COMBINE_FOLD_GROUP && !p.tabC)) { snprintf(g_err, sizeof g_err, "k_combine: %u items, spacing %llu not foldable in the launch", p.np, (unsigned long long)p.eA); return AESGCM_EHIP; }
+    }
+    hipLaunchKernelGGL(k_combine, dim3(1), dim3(COMBINE_THREADS), CMB_LDS_BYTES, st, c->km, c->tables, p);
     HIPCHK(hipGetLastError());
     return AESGCM_OK;
 }
@@ -1004,11 +1064,19 @@ static int crypt_dev(aesgcm_ctx *c, int dec, const uint8_t iv[12], const void *d
         return enqueue_combine(c, q, st);
     }
     Partials pp;
-    rc = enqueue_main(c, dec ? MODE_DEC : MODE_ENC, iv, d_aad, aad_len, d_in, len, d_out, 0, st, &pp);
+    rc = enqueue_main(c, dec ? MODE_DEC : MODE_ENC, iv, d_aad, aad_len, d_in, len, d_out, 0, st, &pp, true);
     if (rc) return rc;
-    CombineParams q = plan_combine_tag(pp.ptr, pp.np, pp.kind, iv, aad_len, len, c->d_tag);
+    if (pp.done) return AESGCM_OK;                               // single chunk: k_main's tail left the tag in d_tag and in the host slot
+    CombineParams q = combine_with_items(plan_combine_tag(pp.ptr, pp.np, pp.kind, iv, aad_len, len, c->d_tag), pp.eA);
     q.ej0 = pp.ej0;                                              // same IV, same stream: k_main left E_K(IV || 1) behind
     return enqueue_combine(c, q, st);
+}
+
+// the tag of the last combine on `st`: wait for the stream, read the pinned host slot k_combine wrote (no D2H copy launch)
+static int fetch_tag(aesgcm_ctx *c, hipStream_t st, uint8_t tag[16]) {
+    HIPCHK(hipStreamSynchronize(st));
+    memcpy(tag, c->h_tag, 16);
+    return AESGCM_OK;
 }
 
 static int ct_compare16(const uint8_t *a, const uint8_t *b) {
@@ -1092,6 +1160,8 @@ static int ctx_create_common(aesgcm_ctx **out, int device, const uint8_t *key, s
         (e = hipMalloc(&c->d_counter, 64 * (1 + AESGCM_NQ))) != hipSuccess ||
         (e = hipMemset(c->d_counter, 0, 64 * (1 + AESGCM_NQ))) != hipSuccess ||
         (e = hipMalloc(&c->d_tag, sizeof(uint4) * 4)) != hipSuccess ||
+        (e = hipHostMalloc((void **)&c->h_tag, 64, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess ||
+        (e = hipHostGetDevicePointer((void **)&c->h_tag_dev, c->h_tag, 0)) != hipSuccess ||
         (e = hipMalloc(&c->d_trace, sizeof(u64) * 4 * AESGCM_GMAX)) != hipSuccess) { aesgcm_ctx_destroy(c); return hip_fail(e, "hipMalloc"); }
     uint8_t *d_key = nullptr;
     size_t kb = pre_nr ? (size_t)16 * (pre_nr + 1) : key_len;
@@ -1130,6 +1200,7 @@ int aesgcm_ctx_destroy(aesgcm_ctx *c) {
     if (c->fold_b) hipFree(c->fold_b);
     if (c->d_counter) hipFree(c->d_counter);
     if (c->d_tag) hipFree(c->d_tag);
+    if (c->h_tag) hipHostFree(c->h_tag);
     if (c->d_trace) hipFree(c->d_trace);
     pipeline_release(c);
     if (c->st_in) hipFree(c->st_in);
@@ -1221,7 +1292,7 @@ int aesgcm_encrypt_dev(aesgcm_ctx *c, const uint8_t iv[12], const void *d_aad, s
     hipStream_t st = pick_stream(c, stream);
     int rc = crypt_dev(c, 0, iv, d_aad, aad_len, d_pt, len, d_ct, st);
     if (rc) return rc;
-    if (tag) { HIPCHK(hipMemcpyAsync(tag, c->d_tag, 16, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st)); }
+    if (tag) return fetch_tag(c, st, tag);
     return AESGCM_OK;
 }
 int aesgcm_decrypt_dev(aesgcm_ctx *c, const uint8_t iv[12], const void *d_aad, size_t aad_len,
@@ -1232,8 +1303,7 @@ int aesgcm_decrypt_dev(aesgcm_ctx *c, const uint8_t iv[12], const void *d_aad, s
     if (rc) return rc;
     if (tag_out || expect_tag) {
         uint8_t t[16];
-        HIPCHK(hipMemcpyAsync(t, c->d_tag, 16, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        if ((rc = fetch_tag(c, st, t))) return rc;
         if (tag_out) memcpy(tag_out, t, 16);
         if (expect_tag && !ct_compare16(t, expect_tag)) return AESGCM_EAUTH;
     }
@@ -1257,9 +1327,7 @@ int aesgcm_encrypt(aesgcm_ctx *c, const uint8_t iv[12], const uint8_t *aad, size
     if ((rc = stage_in(c, aad, aad_len, pt, len))) return rc;
     if ((rc = crypt_dev(c, 0, iv, c->st_aad, aad_len, c->st_in, len, c->st_out, c->stream))) return rc;
     if (len) HIPCHK(hipMemcpyAsync(ct, c->st_out, len, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(tag, c->d_tag, 16, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return AESGCM_OK;
+    return fetch_tag(c, c->stream, tag);
 }
 int aesgcm_decrypt(aesgcm_ctx *c, const uint8_t iv[12], const uint8_t *aad, size_t aad_len,
                    const uint8_t *ct, size_t len, uint8_t *pt, const uint8_t *expect_tag, uint8_t tag_out[16]) {
@@ -1271,8 +1339,7 @@ int aesgcm_decrypt(aesgcm_ctx *c, const uint8_t iv[12], const uint8_t *aad, size
     if ((rc = crypt_dev(c, 1, iv, c->st_aad, aad_len, c->st_in, len, c->st_out, c->stream))) return rc;
     uint8_t t[16];
     if (len) HIPCHK(hipMemcpyAsync(pt, c->st_out, len, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(t, c->d_tag, 16, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    if ((rc = fetch_tag(c, c->stream, t))) return rc;
     if (tag_out) memcpy(tag_out, t, 16);
     if (expect_tag && !ct_compare16(t, expect_tag)) return AESGCM_EAUTH;
     return AESGCM_OK;
@@ -1319,7 +1386,7 @@ int aesgcm_ghash(aesgcm_ctx *c, const uint8_t *data, size_t len, uint8_t y[16]) 
     uint8_t iv0[12] = {0};
     // the data rides in the AAD slot of the GHASH sequence (GHASH only, no AES)
     if ((rc = enqueue_main(c, MODE_ENC, iv0, c->st_aad, len, c->st_in, 0, c->st_out, 0, c->stream, &pp))) return rc;
-    if ((rc = enqueue_combine(c, plan_combine_poly(pp.ptr, pp.np, pp.kind, 1, c->d_tag), c->stream))) return rc;   // Y = P * H
+    if ((rc = enqueue_combine(c, combine_with_items(plan_combine_poly(pp.ptr, pp.np, pp.kind, 1, c->d_tag), pp.eA), c->stream))) return rc;   // Y = P * H
     HIPCHK(hipMemcpyAsync(y, c->d_tag, 16, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return AESGCM_OK;
@@ -1351,7 +1418,7 @@ int aesgcm_shard_crypt_dev(aesgcm_ctx *c, int decrypt, const uint8_t iv[12], con
     }
     Partials pp;
     if ((rc = enqueue_main(c, decrypt ? MODE_DEC : MODE_ENC, iv, d_aad, aad_len, d_in, len, d_out, first_block, st, &pp))) return rc;
-    return enqueue_combine(c, plan_combine_poly(pp.ptr, pp.np, pp.kind, after, (uint4 *)d_partial), st);
+    return enqueue_combine(c, combine_with_items(plan_combine_poly(pp.ptr, pp.np, pp.kind, after, (uint4 *)d_partial), pp.eA), st);
 }
 int aesgcm_shard_finalize_strided_dev(aesgcm_ctx *c, const uint8_t iv[12], const void *d_partials, size_t n_partials, size_t stride_bytes,
                                       size_t aad_len, uint64_t total_len, uint8_t tag[16], void *stream) {
@@ -1363,7 +1430,7 @@ int aesgcm_shard_finalize_strided_dev(aesgcm_ctx *c, const uint8_t iv[12], const
     q.stride = (u32)(stride_bytes / 16);
     int rc = enqueue_combine(c, q, st);
     if (rc) return rc;
-    if (tag) { HIPCHK(hipMemcpyAsync(tag, c->d_tag, 16, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st)); }
+    if (tag) return fetch_tag(c, st, tag);
     return AESGCM_OK;
 }
 int aesgcm_shard_finalize_dev(aesgcm_ctx *c, const uint8_t iv[12], const void *d_partials, size_t n_partials,
@@ -1388,7 +1455,7 @@ static int stream_absorb(aesgcm_ctx *c, const void *d_aad, u64 aad_len, const vo
     if (rc) return rc;
     const u64 nb = (aad_len + 15) / 16 + (len + 15) / 16;
     c->s_blocks += nb;
-    return enqueue_combine(c, plan_combine_carry(pp.ptr, pp.np, pp.kind, c->d_tag + 1, nb), c->stream);       // Y' = Y * H^nb ^ P
+    return enqueue_combine(c, combine_with_items(plan_combine_carry(pp.ptr, pp.np, pp.kind, c->d_tag + 1, nb), pp.eA), c->stream);       // Y' = Y * H^nb ^ P
 }
 int aesgcm_stream_aad(aesgcm_ctx *c, const uint8_t *aad, size_t len) {
     if (!c || (len && !aad)) return AESGCM_EARG;
@@ -1428,8 +1495,7 @@ int aesgcm_stream_final(aesgcm_ctx *c, uint8_t tag[16]) {
     HIPCHK(hipSetDevice(c->device));
     int rc = enqueue_combine(c, plan_combine_final(c->d_tag + 1, c->s_iv, c->s_aad_len, c->s_len, c->d_tag), c->stream);
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(tag, c->d_tag, 16, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    if ((rc = fetch_tag(c, c->stream, tag))) return rc;
     c->s_active = false;
     return AESGCM_OK;
 }
@@ -1656,8 +1722,7 @@ static int crypt_pipelined(aesgcm_ctx *c, int dec, const uint8_t iv[12], const u
         HIPCHK(hipEventRecord(c->pl_ev_d2h[s], c->pl_out));
     }
     if ((rc = enqueue_combine(c, plan_combine_final(c->d_tag + 1, iv, aad_len, len, c->d_tag), c->stream))) return rc;
-    HIPCHK(hipMemcpyAsync(tag, c->d_tag, 16, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    if ((rc = fetch_tag(c, c->stream, tag))) return rc;
     HIPCHK(hipStreamSynchronize(c->pl_out));
     return AESGCM_OK;
 }

@@ -86,21 +86,50 @@ static void emu_body(int mode, const KeyMaterial *km, const BodyParams &p) {
 #undef D
 }
 static G128 emu_pow_h(const KeyMaterial *km, u64 e) { return gf_pow_h_serial(km, e); }
-static void emu_combine(const KeyMaterial *km, const CombineParams &p) {
+// emulated k_combine: the same lane pieces (in-launch item fold, per-lane Shoup multiply, closing table multiplies by H)
+static void emu_combine(const KeyMaterial *km, const CombineParams &p0) {
+    static unsigned char smem[CMB_LDS_BYTES] __attribute__((aligned(16)));
+    CombineParams p = p0;
+    const bool tag = p.want_tag != 0, items = p.kind == PARTS_ITEM;
+    auto tp = [&](u64 e) -> const uint4 * { int k = ptab_index(e); return k < 0 ? nullptr : km->ptab[k]; };
+    if (items && p.np > 1) { p.tabA = tp(p.eA); p.tabC = p.np > COMBINE_FOLD_GROUP ? tp(COMBINE_FOLD_GROUP * p.eA) : nullptr; }
+    CHECK(!(items && p.np > 1) || (p.np <= COMBINE_MAX_ITEMS && p.tabA && (p.np <= COMBINE_FOLD_GROUP || p.tabC)), "emu_combine: %u items not foldable", p.np);
+    const u32 J = items ? (p.np + COMBINE_FOLD_GROUP - 1) / COMBINE_FOLD_GROUP : 0;
+    if (items && p.np > 1) memcpy(smem + CMB_LDS_TABA, p.tabA, 8192);
+    if (J > 1) memcpy(smem + CMB_LDS_TABC, p.tabC, 8192);
+    if (tag) memcpy(smem + CMB_LDS_TABH, km->htab, 8192);
+    memcpy(smem + CMB_LDS_SBOX, g_tb.sbox, 256);
+    for (u32 w = 0; w < J; w++) for (u32 lane = 0; lane < 64; lane++)
+        *reinterpret_cast<uint4 *>(smem + CMB_LDS_STAGE + w * 1024u + lane * 16u) = combine_fold_wave_lane(p, smem, w, lane);
     G128 acc = {{0, 0, 0, 0}};
-    for (u32 tid = 0; tid < COMBINE_THREADS; tid++) xor_g(acc, combine_lane(km, g_tb.sbox, p, tid));
-    const bool tag = p.want_tag != 0;
+    if (items) {
+        for (u32 lane = 0; lane < 64; lane++) {
+            const G128 b = mo_to_be(combine_fold_final_lane(smem, J, lane));
+            shoup2_lane_build(smem, CMB_LDS_LANE, mo_to_be(km->pw[0][63 - lane]), lane);
+            xor_g(acc, shoup2_lane_mul(b, smem, CMB_LDS_LANE, lane));
+        }
+    } else if (p.kind == PARTS_GATHERED) {
+        for (u32 tid = 0; tid < p.np; tid++) xor_g(acc, mo_to_be(p.parts[(size_t)tid * (p.stride ? p.stride : 1u)]));
+    }
     if (!tag && p.e) acc = gf_mul(acc, emu_pow_h(km, p.e));
     if (p.has_carry) {
         G128 c = mo_to_be(*p.carry);
         if (p.e_carry) c = gf_mul(c, emu_pow_h(km, p.e_carry));
-        if (tag) c = gf_mul(c, mo_to_be(km->pw[0][2]));
         xor_g(acc, c);
+    }
+    if (tag) {
+        const G128 L = combine_len_block(p);
+        const G128 ej0 = p.ej0 ? mo_to_be(*p.ej0) : combine_ej0_bytes(km, smem + CMB_LDS_SBOX, p);
+        G128 y = mo_to_be(ghash_mul_const_lds_at(be_to_mo(acc), smem, CMB_LDS_TABH));
+        xor_g(y, L);
+        y = mo_to_be(ghash_mul_const_lds_at(be_to_mo(y), smem, CMB_LDS_TABH));
+        xor_g(y, ej0);
+        acc = y;
     }
     *p.out = be_to_mo(acc);
 }
 
-struct Parts { const uint4 *ptr; u32 np; u32 gathered; };   // gathered = PARTS_* kind
+struct Parts { const uint4 *ptr; u32 np; u32 gathered; u64 eA; };   // gathered = PARTS_* kind; eA: item spacing when k_combine folds the items itself
 struct Emu {
     KeyMaterial km; u32 tw; std::vector<uint4> parts, fold_a, fold_b;
     Emu(const uint8_t *key, int key_len, u32 tw_) : tw(tw_), parts(1 << 16), fold_a(1 << 16), fold_b(1 << 12) { emu_setup(&km, key, key_len, 0, 512); }
@@ -130,20 +159,24 @@ struct Emu {
             }
             eA = fold_out_step(f); eB = 0; period = 1; cur = f.out; n = G; which ^= 1;
         }
-        Parts r = {cur, 1, PARTS_ITEM};
+        Parts r = {cur, 1, PARTS_ITEM, 0};
         return r;
     }
     // mirrors enqueue_main(): launch + k_fold levels
     Parts run(int mode, const uint8_t *iv, const void *aad, u64 aad_len, const void *in, u64 len, void *out, u64 first_block) {
         MainParams p; memset(&p, 0, sizeof p);
         u32 C = plan_main(p, mode, tw, iv, aad, aad_len, in, len, out, first_block, nullptr);
-        Parts r = {nullptr, 0, false};
+        Parts r = {nullptr, 0, PARTS_NONE, 0};
         if (!C) return r;
         if (parts.size() < (size_t)C * 64) parts.resize((size_t)C * 64);
         p.parts = parts.data();
         emu_main(mode, &km, p);
         if (mode != MODE_ENC && mode != MODE_DEC) return r;
-        return fold(parts.data(), C, 1, (u64)64 * p.Tw, 0);
+        // mirrors enqueue_main(): few chunks with table-backed spacing go to k_combine unfolded
+        const u64 eA = (u64)64 * p.Tw;
+        auto has = [&](u64 e) { return ptab_index(e) >= 0; };
+        if (C <= COMBINE_MAX_ITEMS && (C == 1 || (has(eA) && (C <= COMBINE_FOLD_GROUP || has(COMBINE_FOLD_GROUP * eA))))) { Parts q = {parts.data(), C, PARTS_ITEM, eA}; return q; }
+        return fold(parts.data(), C, 1, eA, 0);
     }
     // mirrors enqueue_body(): k_body + k_fold with the interleaved first level
     Parts run_body(int mode, const uint8_t *iv, const BodySplit &b, const void *in, void *out, u64 first_block) {
@@ -159,20 +192,20 @@ struct Emu {
         if (!plan_body_split(len, first_block, tw, body_min, &b)) {
             Parts pp = run(mode, iv, aad, aad_len, in, len, out, first_block);
             const u64 nb = (aad_len + 15) / 16 + (len + 15) / 16;
-            if (nb) emu_combine(&km, plan_combine_carry(pp.ptr, pp.np, pp.gathered, Y, nb));
+            if (nb) emu_combine(&km, combine_with_items(plan_combine_carry(pp.ptr, pp.np, pp.gathered, Y, nb), pp.eA));
             return false;
         }
         const u64 n_aad = (aad_len + 15) / 16;
         if (n_aad + b.head_blocks) {
             Parts pp = run(mode, iv, aad, aad_len, in, 16 * b.head_blocks, out, first_block);
-            emu_combine(&km, plan_combine_carry(pp.ptr, pp.np, pp.gathered, Y, n_aad + b.head_blocks));
+            emu_combine(&km, combine_with_items(plan_combine_carry(pp.ptr, pp.np, pp.gathered, Y, n_aad + b.head_blocks), pp.eA));
         }
         Parts pb = run_body(mode, iv, b, in, out, first_block);
-        emu_combine(&km, plan_combine_carry(pb.ptr, pb.np, pb.gathered, Y, b.body_blocks));
+        emu_combine(&km, combine_with_items(plan_combine_carry(pb.ptr, pb.np, pb.gathered, Y, b.body_blocks), pb.eA));
         const u64 done = b.head_blocks + b.body_blocks, tail = len - 16 * done;
         if (tail) {
             Parts pp = run(mode, iv, nullptr, 0, in + 16 * done, tail, out + 16 * done, first_block + done);
-            emu_combine(&km, plan_combine_carry(pp.ptr, pp.np, pp.gathered, Y, (tail + 15) / 16));
+            emu_combine(&km, combine_with_items(plan_combine_carry(pp.ptr, pp.np, pp.gathered, Y, (tail + 15) / 16), pp.eA));
         }
         return true;
     }
@@ -187,7 +220,18 @@ struct Emu {
     void crypt(int dec, const uint8_t iv[12], const uint8_t *aad, u64 aad_len, const uint8_t *in, u64 len, uint8_t *out, uint8_t tag[16]) {
         Parts pp = run(dec ? MODE_DEC : MODE_ENC, iv, aad, aad_len, in, len, out, 0);
         uint4 t;
-        emu_combine(&km, plan_combine_tag(pp.ptr, pp.np, pp.gathered, iv, aad_len, len, &t));
+        if (pp.np == 1 && pp.gathered == PARTS_ITEM) {
+            // mirrors k_main's tail (single-chunk message: no k_combine launch): lane multiplies, fold, closing multiplies
+            static unsigned char smem[AESGCM_LDS_TAIL_BYTES] __attribute__((aligned(16)));
+            memcpy(smem + AESGCM_LDS_TAIL_H, km.htab, 8192);
+            G128 P = {{0, 0, 0, 0}};
+            for (u32 lane = 0; lane < 64; lane++) xor_g(P, main_tail_lane(&km, smem, pp.ptr[lane], lane));
+            CombineParams q = plan_combine_tag(nullptr, 0, PARTS_NONE, iv, aad_len, len, &t);
+            const G128 ej0 = combine_ej0_bytes(&km, g_tb.sbox, q);
+            t = be_to_mo(close_tag_lds(P, aad_len, len, ej0, smem, AESGCM_LDS_TAIL_H));
+        } else {
+            emu_combine(&km, combine_with_items(plan_combine_tag(pp.ptr, pp.np, pp.gathered, iv, aad_len, len, &t), pp.eA));
+        }
         memcpy(tag, &t, 16);
     }
 };
@@ -441,7 +485,7 @@ static void test_shards(int key_len, u32 G, u64 al, u64 n, int R, u64 seed) {
         u64 end = first + blocks;
         u64 len = (end == total_blocks ? n : 16 * end) - 16 * first;
         Parts pp = E.run(MODE_ENC, iv.data(), r == 0 ? aad.data() : nullptr, r == 0 ? al : 0, pt.p + 16 * first, len, ct.p + 16 * first, first);
-        emu_combine(&E.km, plan_combine_poly(pp.ptr, pp.np, pp.gathered, total_blocks - end, &gathered[r]));
+        emu_combine(&E.km, combine_with_items(plan_combine_poly(pp.ptr, pp.np, pp.gathered, total_blocks - end, &gathered[r]), pp.eA));
         first = end;
     }
     uint4 t;
@@ -500,12 +544,12 @@ static void test_stream(int key_len, u32 G, u64 al, u64 n, u64 chunk, u64 seed) 
     for (u64 off = 0; off < al; off += chunk) {
         u64 m = al - off < chunk ? al - off : chunk;
         Parts pp = E.run(MODE_ENC, iv.data(), aad.data() + off, m, nullptr, 0, nullptr, 0);
-        emu_combine(&E.km, plan_combine_carry(pp.ptr, pp.np, pp.gathered, &Y, (m + 15) / 16));
+        emu_combine(&E.km, combine_with_items(plan_combine_carry(pp.ptr, pp.np, pp.gathered, &Y, (m + 15) / 16), pp.eA));
     }
     for (u64 off = 0; off < n; off += chunk) {
         u64 m = n - off < chunk ? n - off : chunk;
         Parts pp = E.run(MODE_ENC, iv.data(), nullptr, 0, pt.p + off, m, ct.p + off, off / 16);
-        emu_combine(&E.km, plan_combine_carry(pp.ptr, pp.np, pp.gathered, &Y, (m + 15) / 16));
+        emu_combine(&E.km, combine_with_items(plan_combine_carry(pp.ptr, pp.np, pp.gathered, &Y, (m + 15) / 16), pp.eA));
     }
     uint4 t;
     emu_combine(&E.km, plan_combine_final(&Y, iv.data(), al, n, &t));
@@ -530,7 +574,7 @@ static void test_keystream_and_ghash(u64 seed) {
     for (u64 n : {1ull, 16ull, 17ull, 8191ull, 20000ull}) {
         auto d = rnd(n, seed + n);
         Parts pp = E.run(MODE_ENC, iv.data(), d.data(), n, nullptr, 0, nullptr, 0);
-        uint4 y; emu_combine(&E.km, plan_combine_poly(pp.ptr, pp.np, pp.gathered, 1, &y));
+        uint4 y; emu_combine(&E.km, combine_with_items(plan_combine_poly(pp.ptr, pp.np, pp.gathered, 1, &y), pp.eA));
         uint8_t yo[16] = {0}; orc_ghash_update((const uint8_t *)&E.km.h, yo, d.data(), n);
         CHECK(memcmp(&y, yo, 16) == 0, "ghash len %llu", (unsigned long long)n);
     }
