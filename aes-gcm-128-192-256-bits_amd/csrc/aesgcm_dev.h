@@ -383,6 +383,7 @@ struct MainParams {
     uint4 *ej0;                  // GHASH modes: where the wave that owns chunk 0 leaves E_K(IV || 1) for k_combine (or NULL)
     u32 tail;                    // 1: single-chunk whole message -- the wave that owns chunk 0 also finishes the tag (no k_combine launch)
     uint4 *tag_out, *tag_host;   // tail: where the tag goes (device slot, and the pinned host slot or NULL)
+    u64 gen;                     // tail: generation number published behind the host copy (see CombineParams::gen)
 };
 // LDS of a tail launch (one workgroup): the usual 72 KiB, then the nibble tables of H and the per-lane Shoup tables
 #define AESGCM_LDS_TAIL_H AESGCM_LDS_BYTES
@@ -401,7 +402,7 @@ HD void main_geometry(u64 n_seq, u32 tw_override, u64 *rows, u32 *Tw, u32 *C) {
     const u64 R = (n_seq + 63) / 64;
     u64 t;
     if (tw_override) t = tw_override;
-    else if (R <= 4) t = R;                                        // <= 4 KiB: ONE chunk; its wave finishes the tag itself (k_main's tail: a single launch)
+    else if (R <= 2) t = R;                                        // <= 2 KiB: ONE chunk; its wave finishes the tag itself (k_main's tail: a single launch).  A lone wave needs ~2.2 us per row, so longer messages are faster as one row per wave + k_combine
     else if (R <= 256) t = (R + 63) / 64;                          // <= 256 KiB: at most 64 chunks, which k_combine folds itself (no k_fold launch)
     else if (R <= 32768) { t = R / 2048; if (t < 1) t = 1; }      // <= 32 MiB: ~2k chunks
     else t = R < (1u << 18) ? 16 : 32;
@@ -830,6 +831,7 @@ struct CombineParams {
     const uint4 *ej0;            // E_K(IV || 1) left by k_main, or NULL: k_combine computes it (one lane, bytewise: ~15 us)
     uint4 *out;
     uint4 *out_host;             // optional second copy of the result in host-visible (pinned, mapped) memory: no copy kernel for the tag
+    u64 gen;                     // written to out_host[1] AFTER the result (system-scope fence between): the host polls it
 };
 // in-launch fold, stage a: wave w of J = ceil(np / 8) folds its (up to) 8 consecutive items; groups are cut from the END,
 // so only the first one is short and group ends stay 8 eA apart

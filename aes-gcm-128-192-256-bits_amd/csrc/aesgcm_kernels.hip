@@ -111,6 +111,12 @@ __device__ __forceinline__ G128 wave_xor_fold(G128 z) {
     }
     return z;
 }
+// result -> pinned host slot, then (behind a system-scope fence) the generation number the host is polling for
+__device__ __forceinline__ void publish_host(uint4 *slot, uint4 v, u64 gen) {
+    *slot = v;
+    __threadfence_system();
+    __hip_atomic_store(reinterpret_cast<u64 *>(slot + 1), gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 template <int NR, int MODE>
 __global__ __launch_bounds__(AESGCM_MAIN_WG, AESGCM_WAVES_PER_SIMD) void k_main(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const MainParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -166,7 +172,7 @@ __global__ __launch_bounds__(AESGCM_MAIN_WG, AESGCM_WAVES_PER_SIMD) void k_main(
                 // launching k_combine: B_L * H^(63-L) per lane, XOR fold, tag = ((P*H) ^ L)*H ^ E_K(IV || 1)
                 const G128 P = wave_xor_fold(main_tail_lane(km, smem, acc, lane));
                 const G128 t = close_tag_lds(P, p.aad_len, p.len, mo_to_be(make_uint4(s0, s1, s2, s3)), smem, AESGCM_LDS_TAIL_H);
-                if (lane == 0) { *p.tag_out = be_to_mo(t); if (p.tag_host) *p.tag_host = be_to_mo(t); }
+                if (lane == 0) { *p.tag_out = be_to_mo(t); if (p.tag_host) publish_host(p.tag_host, be_to_mo(t), p.gen); }
             }
         }
         ++done;
@@ -313,7 +319,7 @@ __global__ __launch_bounds__(COMBINE_THREADS) void k_combine(const KeyMaterial *
         }
         if (tid == 0) {
             *p.out = be_to_mo(acc);
-            if (p.out_host) *p.out_host = be_to_mo(acc);
+            if (p.out_host) publish_host(p.out_host, be_to_mo(acc), p.gen);
         }
     }
 }
@@ -775,7 +781,8 @@ struct aesgcm_ctx {
     u64 body_min = (u64)1 << 30;       // ranges with an aligned middle of at least this many bytes go through k_body (AESGCM_BODY_MIN):
                                        // the extra launches cost ~50 us, break-even measured near 0.7 GiB (profiles/split_threshold.py)
     uint4 *h_tag = nullptr;            // 64 bytes of pinned, device-mapped host memory: k_combine leaves the tag here too, so fetching it
-    uint4 *h_tag_dev = nullptr;        //   is a stream synchronisation and a 16-byte host read -- no copy kernel (its device address)
+    uint4 *h_tag_dev = nullptr;        //   is a host read -- no copy kernel, no interrupt-driven stream wait (its device address)
+    u64 tag_gen = 0;                   // generation number of the last result sent to the host slot (the kernel publishes it behind the tag)
     uint4 *d_tag = nullptr;            // [0] tag / poly result, [1] streaming state Y
     u64 *d_trace = nullptr;            // per-workgroup trace of the last k_main launch (timing mode only)
     u32 last_np = 0;
@@ -912,7 +919,7 @@ static int enqueue_main(aesgcm_ctx *c, int mode, const uint8_t iv[12], const voi
     for (u32 q = 0; q < AESGCM_NQ; q++) p.qbase[q] = c->mq_base[q];
     for (u32 q = 0; q < p.nq; q++) c->mq_base[q] += p.seg + wgs * (AESGCM_MAIN_WG / 64);   // every wave finds every queue dry exactly once
     if (gh && po) { p.ej0 = c->d_tag + 3; po->ej0 = p.ej0; }
-    if (gh && po && want_tail && C == 1) { p.tail = 1; p.tag_out = c->d_tag; p.tag_host = c->h_tag_dev; po->done = true; }
+    if (gh && po && want_tail && C == 1) { p.tail = 1; p.tag_out = c->d_tag; p.tag_host = c->h_tag_dev; p.gen = ++c->tag_gen; po->done = true; }
     p.trace = nullptr;
     const bool timed = c->timing && !c->timing_mute;
     if (timed) {
@@ -1027,7 +1034,7 @@ static int absorb_range(aesgcm_ctx *c, int mode, const uint8_t iv[12], const voi
 
 static int enqueue_combine(aesgcm_ctx *c, const CombineParams &p0, hipStream_t st) {
     CombineParams p = p0;
-    if (p.out == c->d_tag) p.out_host = c->h_tag_dev;             // results that go to the tag slot are mirrored to the pinned host slot
+    if (p.out == c->d_tag) { p.out_host = c->h_tag_dev; p.gen = ++c->tag_gen; }   // results that go to the tag slot are mirrored to the pinned host slot
     if (p.kind == PARTS_ITEM && p.np > 1) {                       // the launch folds the items itself: tables of H^eA, H^(8 eA)
         p.tabA = ptab_ptr(c, p.eA);
         p.tabC = p.np > COMBINE_FOLD_GROUP ? ptab_ptr(c, COMBINE_FOLD_GROUP * p.eA) : nullptr;
@@ -1072,9 +1079,21 @@ static int crypt_dev(aesgcm_ctx *c, int dec, const uint8_t iv[12], const void *d
     return enqueue_combine(c, q, st);
 }
 
-// the tag of the last combine on `st`: wait for the stream, read the pinned host slot k_combine wrote (no D2H copy launch)
+// The tag of the last result enqueued for the host slot: the kernel stores it in pinned host memory and then publishes
+// the generation number; the host polls that number for a short while (a kernel-completion interrupt costs ~10 us on
+// this platform, a poll of coherent host memory well under one) and falls back to a stream synchronisation for long-
+// running work or if anything went wrong.  Either way the work that produced the tag has completed when this returns.
 static int fetch_tag(aesgcm_ctx *c, hipStream_t st, uint8_t tag[16]) {
-    HIPCHK(hipStreamSynchronize(st));
+    const u64 want = c->tag_gen;
+    volatile u64 *gen = reinterpret_cast<volatile u64 *>(c->h_tag + 1);
+    bool seen = false;
+    for (u32 spin = 0; spin < 400000u; ++spin) {                 // ~100-200 us of polling at most
+        if (__atomic_load_n(gen, __ATOMIC_ACQUIRE) == want) { seen = true; break; }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    if (!seen) HIPCHK(hipStreamSynchronize(st));
     memcpy(tag, c->h_tag, 16);
     return AESGCM_OK;
 }
@@ -1162,6 +1181,7 @@ static int ctx_create_common(aesgcm_ctx **out, int device, const uint8_t *key, s
         (e = hipMalloc(&c->d_tag, sizeof(uint4) * 4)) != hipSuccess ||
         (e = hipHostMalloc((void **)&c->h_tag, 64, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess ||
         (e = hipHostGetDevicePointer((void **)&c->h_tag_dev, c->h_tag, 0)) != hipSuccess ||
+        (memset(c->h_tag, 0, 64), false) ||
         (e = hipMalloc(&c->d_trace, sizeof(u64) * 4 * AESGCM_GMAX)) != hipSuccess) { aesgcm_ctx_destroy(c); return hip_fail(e, "hipMalloc"); }
     uint8_t *d_key = nullptr;
     size_t kb = pre_nr ? (size_t)16 * (pre_nr + 1) : key_len;
