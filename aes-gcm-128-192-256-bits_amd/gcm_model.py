@@ -10,7 +10,9 @@ GPU library.  `from cocotb import log` becomes a standard `logging` logger when 
 Additionally it exports the one-shot bulk entry points BASELINE.json's north_star names:
     encrypt(key, iv, aad, data) -> (ct, tag)        decrypt(key, iv, aad, data, tag=None) -> (pt, tag)
 """
+import hashlib
 import logging
+import os
 
 from . import lib, sharding
 from .lib import AesGcmError, AuthenticationError   # noqa: F401
@@ -158,16 +160,17 @@ def _ct_equal(a, b):
 
 # ======================================================================================
 # one-shot bulk surface (north_star: encrypt/decrypt(key, iv, aad, data) -> (ct, tag))
-_ctx_cache = {}
+_ctx_cache = {}          # at most 8 contexts, keyed by a keyed digest of the key (raw keys are not kept on the host)
+_ctx_salt = os.urandom(16)
 
 
 def _ctx(key, device):
-    k = (bytes(key), device)
+    k = (hashlib.blake2b(bytes(key), key=_ctx_salt, digest_size=16).digest(), len(key), device)
     c = _ctx_cache.get(k)
     if c is None:
         if len(_ctx_cache) >= 8:
             _ctx_cache.pop(next(iter(_ctx_cache))).close()
-        c = _ctx_cache[k] = lib.Context(k[0], device=device)
+        c = _ctx_cache[k] = lib.Context(bytes(key), device=device)
     return c
 
 
