@@ -312,6 +312,7 @@ def main():
                                "multiply, scalar loads, chunk dispensers) with its global loads and stores removed, same process, "
                                "same clocks -- the ceiling of the formulation, not of the chip" % (key_bits // 32 + 6)}
             ceiling["achieved_over_ceiling"] = round(achieved / 1e9 / ceiling["value"], 4) if ceiling["value"] else None
+            ceiling["sclk_mhz"] = sclk_from_trace(ctx.wg_trace(), geo["wg_lanes"] // 64)      # the clock the no-HBM stream sustains
         except Exception as e:
             ceiling = {"error": repr(e)}
 
