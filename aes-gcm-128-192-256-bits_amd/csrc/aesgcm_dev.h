@@ -266,6 +266,27 @@ HD void aes_final_lds(u32 &s0, u32 &s1, u32 &s2, u32 &s3, const u32 *__restrict_
     s2 = merge_rows(c0, c1, c2, c3) ^ rkr[2];
     s3 = merge_rows(d0, d1, d2, d3) ^ rkr[3];
 }
+#ifndef AESGCM_T4
+#define AESGCM_T4 1                      /* k_body uses four T-tables (136 KiB of LDS, one 1024-lane workgroup per CU); 0 = the two-table round */
+#endif
+// Four-table form of the same round (k_body with AESGCM_T4): T1 = rotl8(T0) and T3 = rotl8(T2) sit in a second 64 KiB
+// LDS region exactly 65536 bytes above the first, reached by the SAME single v_perm per address: `lb2` = lb | 0x10000 and
+// the selector also copies its byte 2.  A column is then two XOR3 -- no rotate (v_alignbit issues at about 0.6 of the plain
+// VALU rate on this part, profiles/microbench) and no extra XOR: 8 instructions per round less, 12 % of the row's cycles.
+#define SEL_B2(k) (0x0c020000u | ((4u + (k)) << 8))
+#define T1_AT(lds, s, k, lb2) LDS_LD32(lds, perm_b32(s, lb2, SEL_B2(k)) + AESGCM_LDS_AES_OFF)
+#define T3_AT(lds, s, k, lb2) LDS_LD32(lds, perm_b32(s, lb2, SEL_B2(k)) + (AESGCM_LDS_AES_OFF + 128u))
+#define AESGCM_LDS_BYTES_T4 (AESGCM_LDS_BYTES + AESGCM_LDS_AES)
+HD void aes_round_lds4(u32 &s0, u32 &s1, u32 &s2, u32 &s3, const u32 *__restrict__ rkr, const unsigned char *lds, u32 lb, u32 lb2) {
+    const u32 a0 = T0_AT(lds, s0, 0, lb), a1 = T1_AT(lds, s1, 1, lb2), a2 = T2_AT(lds, s2, 2, lb), a3 = T3_AT(lds, s3, 3, lb2);
+    const u32 b0 = T0_AT(lds, s1, 0, lb), b1 = T1_AT(lds, s2, 1, lb2), b2 = T2_AT(lds, s3, 2, lb), b3 = T3_AT(lds, s0, 3, lb2);
+    const u32 c0 = T0_AT(lds, s2, 0, lb), c1 = T1_AT(lds, s3, 1, lb2), c2 = T2_AT(lds, s0, 2, lb), c3 = T3_AT(lds, s1, 3, lb2);
+    const u32 d0 = T0_AT(lds, s3, 0, lb), d1 = T1_AT(lds, s0, 1, lb2), d2 = T2_AT(lds, s1, 2, lb), d3 = T3_AT(lds, s2, 3, lb2);
+    s0 = xor3(xor3(a0, a1, a2), a3, rkr[0]);
+    s1 = xor3(xor3(b0, b1, b2), b3, rkr[1]);
+    s2 = xor3(xor3(c0, c1, c2), c3, rkr[2]);
+    s3 = xor3(xor3(d0, d1, d2), d3, rkr[3]);
+}
 // generic: state already has rk[0..3] applied
 template <int NR>
 HD void aes_rounds_lds(u32 &s0, u32 &s1, u32 &s2, u32 &s3, const u32 *__restrict__ rk, const unsigned char *lds, u32 lb) {
@@ -474,6 +495,15 @@ HD void main_fill_lds(unsigned char *smem, const KeyMaterial *km, const DevTable
     }
 }
 
+// region B of the LDS image: what thread `tid` writes (row x: 32 replicas of rotl8(T0[x]) | 32 replicas of rotl8(T2[x]))
+HD void fill_lds_t4(unsigned char *smem, const DevTables *tb, u32 tid, u32 nthreads) {
+    uint4 *dst = reinterpret_cast<uint4 *>(smem + AESGCM_LDS_AES_OFF + AESGCM_LDS_AES);
+    for (u32 q = tid; q < AESGCM_LDS_AES / 16; q += nthreads) {
+        const u32 t0 = tb->te0[q >> 4];
+        const u32 v = ((q >> 3) & 1) ? rotl32(t0, 24) : rotl32(t0, 8);
+        dst[q] = make_uint4(v, v, v, v);
+    }
+}
 // block loads/stores with the ragged last block handled bytewise (gcm_ghash.vhd:225-246 byte-valid
 // mask = zero padding on the right; gcm_gctr.vhd:184 byte-valid passthrough on the data output)
 HD uint4 load_block_bytes(const unsigned char *p, u32 nbytes) {
@@ -764,7 +794,11 @@ HD BodyRow body_uniform(u32 hi24, const CtrConsts &cc, const u32 *__restrict__ r
 template <int NR>
 HD void body_rounds(u32 &s0, u32 &s1, u32 &s2, u32 &s3, const u32 *__restrict__ rk, const unsigned char *lds, u32 lb) {
 #pragma unroll
+#if AESGCM_T4
+    for (int r = 3; r < NR; r++) aes_round_lds4(s0, s1, s2, s3, rk + 4 * r, lds, lb, lb | 0x10000u);
+#else
     for (int r = 3; r < NR; r++) aes_round_lds(s0, s1, s2, s3, rk + 4 * r, lds, lb);
+#endif
     aes_final_lds(s0, s1, s2, s3, rk + 4 * NR, lds, lb);
 }
 // lane `lane` of the wave that owns chunk c = 4*s + v: returns sum_i X[row 4(sT+i)+v, lane] * (H^256)^(T-1-i)

@@ -188,8 +188,17 @@ __global__ __launch_bounds__(AESGCM_MAIN_WG, AESGCM_WAVES_PER_SIMD) void k_main(
 // k_body: the aligned middle of a large message (lane body: body_chunk_lane()); rounds 1-2 of every counter
 // block come from per-lane chunk constants and scalar-cache table reads, not from LDS.
 // ------------------------------------------------------------------------------------------------
+#if AESGCM_T4
+#define AESGCM_BODY_WG 1024                  /* one workgroup per CU (136 KiB of LDS), 4 waves per SIMD, 128 registers */
+#define AESGCM_BODY_WPS 4
+#define AESGCM_BODY_LDS AESGCM_LDS_BYTES_T4
+#else
+#define AESGCM_BODY_WG AESGCM_MAIN_WG
+#define AESGCM_BODY_WPS AESGCM_WAVES_PER_SIMD
+#define AESGCM_BODY_LDS AESGCM_LDS_BYTES
+#endif
 template <int NR, int MODE>
-__global__ __launch_bounds__(AESGCM_MAIN_WG, AESGCM_WAVES_PER_SIMD) void k_body(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const BodyParams p) {
+__global__ __launch_bounds__(AESGCM_BODY_WG, AESGCM_BODY_WPS) void k_body(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const BodyParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 tid = threadIdx.x, lane = tid & 63u;
     if (p.trace && tid == 0) {
@@ -198,13 +207,16 @@ __global__ __launch_bounds__(AESGCM_MAIN_WG, AESGCM_WAVES_PER_SIMD) void k_body(
         tr[2] = (u64)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((u64)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xF) << 32);
     }
     const u64 cyc0 = p.trace ? clock64() : 0;
-    main_fill_lds(smem, km, tb, tid, true, AESGCM_MAIN_WG, GH_TAB_K256);
+    main_fill_lds(smem, km, tb, tid, true, AESGCM_BODY_WG, GH_TAB_K256);
+#if AESGCM_T4
+    fill_lds_t4(smem, tb, tid, AESGCM_BODY_WG);
+#endif
     __syncthreads();
     CtrConsts cc = ctr_round1_consts(p.iv0, p.iv1, p.iv2, km->rk, smem, (lane & 31u) << 2);   // key and IV only: wave-uniform
     cc.c0 = __builtin_amdgcn_readfirstlane(cc.c0); cc.c1 = __builtin_amdgcn_readfirstlane(cc.c1);
     cc.c2 = __builtin_amdgcn_readfirstlane(cc.c2); cc.c3 = __builtin_amdgcn_readfirstlane(cc.c3);
     u32 done = 0;
-    u32 q = (blockIdx.x * (AESGCM_MAIN_WG / 64) + (tid >> 6)) % p.nq, dry = 0;
+    u32 q = (blockIdx.x * (AESGCM_BODY_WG / 64) + (tid >> 6)) % p.nq, dry = 0;
     q = __builtin_amdgcn_readfirstlane(q);
     for (u32 guard = 0; guard <= p.C + 2 * AESGCM_NQ; ++guard) {            // bounded, as every dispenser loop here
         u32 v = 0;
@@ -843,7 +855,7 @@ static int set_lds_attrs(int device, DeviceState *ds) {
     SETATTR(10, MODE_KS);  SETATTR(12, MODE_KS);  SETATTR(14, MODE_KS);
     SETATTR(10, MODE_ECB); SETATTR(12, MODE_ECB); SETATTR(14, MODE_ECB);
 #undef SETATTR
-#define SETATTRY(NR, MODE) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_body<NR, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, AESGCM_LDS_BYTES))
+#define SETATTRY(NR, MODE) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_body<NR, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, AESGCM_BODY_LDS))
     SETATTRY(10, MODE_ENC); SETATTRY(12, MODE_ENC); SETATTRY(14, MODE_ENC); SETATTRY(10, MODE_DEC); SETATTRY(12, MODE_DEC); SETATTRY(14, MODE_DEC);
     SETATTRY(10, MODE_PROBE); SETATTRY(12, MODE_PROBE); SETATTRY(14, MODE_PROBE);
 #undef SETATTRY
@@ -965,9 +977,13 @@ static int enqueue_body(aesgcm_ctx *c, int mode, const uint8_t iv[12], const Bod
     if (rc) return rc;
     plan_body(p, b, iv, d_in, d_out, first_block, c->parts);
     p.ej0 = c->d_tag + 3; po->ej0 = p.ej0;
-    const u32 waves_per_wg = AESGCM_MAIN_WG / 64;
+    const u32 waves_per_wg = AESGCM_BODY_WG / 64;
     u32 wgs = (p.C + waves_per_wg - 1) / waves_per_wg;
+#if AESGCM_T4
+    if (wgs > (u32)c->G / 2) wgs = (u32)c->G / 2;                 // one 136 KiB workgroup per CU
+#else
     if (wgs > (u32)c->G) wgs = (u32)c->G;
+#endif
     p.counter = c->d_counter + 16;
     plan_queues(p.C, &p.nq, &p.seg);
     for (u32 q = 0; q < AESGCM_NQ; q++) p.qbase[q] = c->mq_base[q];
@@ -980,7 +996,7 @@ static int enqueue_body(aesgcm_ctx *c, int mode, const uint8_t iv[12], const Bod
         else { HIPCHK(hipEventCreate(&evp.first)); HIPCHK(hipEventCreate(&evp.second)); }
         HIPCHK(hipEventRecord(evp.first, st));
     }
-#define LY(NR, M) hipLaunchKernelGGL((k_body<NR, M>), dim3(wgs), dim3(AESGCM_MAIN_WG), AESGCM_LDS_BYTES, st, c->km, c->tables, p)
+#define LY(NR, M) hipLaunchKernelGGL((k_body<NR, M>), dim3(wgs), dim3(AESGCM_BODY_WG), AESGCM_BODY_LDS, st, c->km, c->tables, p)
     if (mode == MODE_DEC)        { if (c->nr == 10) LY(10, MODE_DEC); else if (c->nr == 12) LY(12, MODE_DEC); else LY(14, MODE_DEC); }
     else if (mode == MODE_PROBE) { if (c->nr == 10) LY(10, MODE_PROBE); else if (c->nr == 12) LY(12, MODE_PROBE); else LY(14, MODE_PROBE); }
     else                         { if (c->nr == 10) LY(10, MODE_ENC); else if (c->nr == 12) LY(12, MODE_ENC); else LY(14, MODE_ENC); }
@@ -1241,6 +1257,18 @@ int aesgcm_ctx_geometry(const aesgcm_ctx *c, int *n_wg, int *wg_lanes, int *lds_
     if (n_wg) *n_wg = c->G;
     if (wg_lanes) *wg_lanes = AESGCM_MAIN_WG;
     if (lds_bytes) *lds_bytes = AESGCM_LDS_BYTES;
+    return AESGCM_OK;
+}
+
+int aesgcm_ctx_body_geometry(const aesgcm_ctx *c, int *n_wg, int *wg_lanes, int *lds_bytes) {
+    if (!c) return AESGCM_EARG;
+#if AESGCM_T4
+    if (n_wg) *n_wg = c->G / 2;
+#else
+    if (n_wg) *n_wg = c->G;
+#endif
+    if (wg_lanes) *wg_lanes = AESGCM_BODY_WG;
+    if (lds_bytes) *lds_bytes = AESGCM_BODY_LDS;
     return AESGCM_OK;
 }
 

@@ -24,7 +24,7 @@ SYMBOLS = [
     "aesgcm_stream_begin", "aesgcm_stream_aad", "aesgcm_stream_update", "aesgcm_stream_final",
     "aesgcm_dev_alloc", "aesgcm_dev_free", "aesgcm_dev_upload", "aesgcm_dev_download", "aesgcm_dev_sync", "aesgcm_dev_copy",
     "aesgcm_fill_splitmix64_dev",
-    "aesgcm_ctx_timing_enable", "aesgcm_ctx_timing_read", "aesgcm_ctx_geometry", "aesgcm_ctx_split", "aesgcm_ctx_wg_trace",
+    "aesgcm_ctx_timing_enable", "aesgcm_ctx_timing_read", "aesgcm_ctx_geometry", "aesgcm_ctx_body_geometry", "aesgcm_ctx_split", "aesgcm_ctx_wg_trace",
     "aesgcm_ctx_ceiling_probe",
     "aesgcm_comm_last_error", "aesgcm_comm_unique_id", "aesgcm_comm_create", "aesgcm_comm_ranks", "aesgcm_comm_allgather_dev",
     "aesgcm_comm_allreduce_f64", "aesgcm_comm_barrier", "aesgcm_comm_destroy",
@@ -104,6 +104,7 @@ def load():
     L.aesgcm_ctx_timing_read.argtypes = [vp, ctypes.POINTER(u64), ctypes.POINTER(ctypes.c_double), cint]
     L.aesgcm_ctx_wg_trace.argtypes = [vp, vp, sz, ctypes.POINTER(sz)]
     L.aesgcm_ctx_geometry.argtypes = [vp, ctypes.POINTER(cint), ctypes.POINTER(cint), ctypes.POINTER(cint)]
+    L.aesgcm_ctx_body_geometry.argtypes = [vp, ctypes.POINTER(cint), ctypes.POINTER(cint), ctypes.POINTER(cint)]
     L.aesgcm_ctx_split.argtypes = [vp, sz, u64, ctypes.POINTER(u64), ctypes.POINTER(u64)]
     L.aesgcm_ctx_ceiling_probe.argtypes = [vp, sz, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(u64)]
     L.aesgcm_comm_last_error.restype = cp
@@ -481,9 +482,11 @@ class Context:
         _chk(load().aesgcm_ctx_wg_trace(self._c, buf, max_wgs, ctypes.byref(n)))
         return [tuple(buf[4 * i:4 * i + 4]) for i in range(n.value)]
 
-    def geometry(self):
+    def geometry(self, body=False):
+        """launch geometry of k_main, or (body=True) of k_body, the kernel of the aligned middle of ranges >= 1 GiB"""
         a, b, c = cint(0), cint(0), cint(0)
-        _chk(load().aesgcm_ctx_geometry(self._c, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        fn = load().aesgcm_ctx_body_geometry if body else load().aesgcm_ctx_geometry
+        _chk(fn(self._c, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
         return dict(workgroups=a.value, wg_lanes=b.value, lds_bytes=c.value)
 
     def ceiling_probe(self, nbytes):

@@ -285,6 +285,8 @@ def main():
     lib.dev_sync(dev)
     n_launch, kernel_ms = ctx.timing_read(reset=True)
     sclk = None
+    if ctx.split(msgs[0]["len"], msgs[0]["first_block"])[1]:
+        geo = ctx.geometry(body=True)                              # the timed kernel is k_body: report ITS launch geometry
     if rank == 0:
         try:
             sclk = sclk_from_trace(ctx.wg_trace(), geo["wg_lanes"] // 64)

@@ -1,0 +1,13 @@
+#!/bin/bash
+O=gpurun_out/r02_run13; mkdir -p $O
+for rep in 1 2; do for v in "" _t4; do
+  AESGCM_LIB=$PWD/aes-gcm-128-192-256-bits_amd/libaesgcm_hip$v.so timeout 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline > $O/ab$v$rep.json 2> $O/ab$v$rep.err
+  python - $O/ab$v$rep.json <<'PY'
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r=d["roofline"]; c=r.get("formulation_ceiling") or {}
+print("%-24s %.1f GiB/s kernel %.3f ms sclk %s | ceiling %.3f ms sclk %s | tag_ok %s ct_ok %s" % (sys.argv[1].split("/")[-1], d["value"], r["avg_launch_ms"], r.get("sclk_mhz"), c.get("ms",0), c.get("sclk_mhz"), d["tag_ok"], d["ct_head_tail_ok"]))
+PY
+done; done
+for v in "" _t4; do AESGCM_LIB=$PWD/aes-gcm-128-192-256-bits_amd/libaesgcm_hip$v.so timeout 300 python bench.py --config cfg2 --steps 20 --warmup 3 --no-cpu-baseline | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print('cfg2 $v', d['value'], r['avg_launch_ms'], d['tag_ok'])"; done

@@ -70,8 +70,11 @@ static void emu_main(int mode, const KeyMaterial *km, const MainParams &p) {
 }
 template <int NR, int MODE>
 static void emu_body_nr(const KeyMaterial *km, const BodyParams &p) {
-    static unsigned char smem[AESGCM_LDS_BYTES] __attribute__((aligned(16)));
+    static unsigned char smem[AESGCM_LDS_BYTES_T4] __attribute__((aligned(16)));
     for (u32 tid = 0; tid < AESGCM_MAIN_WG; tid++) main_fill_lds(smem, km, &g_tb, tid, true, AESGCM_MAIN_WG, GH_TAB_K256);
+#if AESGCM_T4
+    for (u32 tid = 0; tid < AESGCM_MAIN_WG; tid++) fill_lds_t4(smem, &g_tb, tid, AESGCM_MAIN_WG);     // second table region (T1 | T3)
+#endif
     for (u32 k = 0; k < p.C; k++) {
         const u32 c = (k * 7 + 3) % p.C == k ? k : (p.C - 1) - k;      // scrambled order (any permutation will do)
         for (u32 lane = 0; lane < 64; lane++) {
