@@ -182,6 +182,18 @@ HD G128 gf_mulx(G128 v) {
     return r;
 }
 HD G128 gf_mulx4(G128 v) { return gf_mulx(gf_mulx(gf_mulx(gf_mulx(v)))); }
+// entry v (0..15) of the Shoup table of constant c: (v as polynomial v3 + v2 x + v1 x^2 + v0 x^3, GCM bit order:
+// the nibble's MSB is x^0) times c
+HD G128 shoup_entry(G128 c, u32 v) {
+    G128 r; r.w[0] = r.w[1] = r.w[2] = r.w[3] = 0;
+    G128 t = c;
+    for (int k = 3; k >= 0; k--) {                             // bit 3 of v <-> x^0, bit 0 <-> x^3
+        const u32 m = 0u - ((v >> k) & 1u);
+        r.w[0] ^= t.w[0] & m; r.w[1] ^= t.w[1] & m; r.w[2] ^= t.w[2] & m; r.w[3] ^= t.w[3] & m;
+        t = gf_mulx(t);
+    }
+    return r;
+}
 HD uint4 gf_mul_mo(uint4 a, uint4 b) { return be_to_mo(gf_mul(mo_to_be(a), mo_to_be(b))); }
 HD uint4 gf_one_mo() { return make_uint4(0x80u, 0u, 0u, 0u); }   // the field's 1: byte 0 = 0x80
 
@@ -360,6 +372,7 @@ struct DevTables {           // per device
 };
 
 #define AESGCM_NPTAB 26
+#define AESGCM_NLTAB 66
 struct KeyMaterial {         // per context (device memory)
     u32 rk[60];              // expanded key, memory-order words
     u32 nr;
@@ -370,10 +383,43 @@ struct KeyMaterial {         // per context (device memory)
     uint4 htab[512];         // nibble tables of H itself (k_pktl: one lane per packet, serial Horner)
     uint4 k4tab[512];        // nibble tables of H^256 (k_body: a wave takes every fourth row)
     uint4 ptab[AESGCM_NPTAB][512]; // nibble tables of H^(2^k), k = 6 .. 31: the Horner constants of k_fold when chunk sizes are powers of two
+    uint4 ltab[AESGCM_NLTAB][32];  // two-table Shoup form of H^e, e = 0 .. 65: [e][v] = v*H^e, [e][16 + v] = v*H^e*x^4 (per-lane constant multiplies of the closing steps)
     uint8_t rk_bytes[240];   // expanded key as the byte string tb/key_exp.py produces
 };
 
 enum { MODE_ENC = 0, MODE_DEC = 1, MODE_KS = 2, MODE_ECB = 3, MODE_PROBE = 4 };   // PROBE (k_body only): ENC without the global load and store
+
+// per key, once (k_setup_ptab): the two Shoup tables of H^e for e = 0 .. 65 in device memory.  The closing steps of a tag need
+// lane L's value times H^(65-L) (or H^(63-L) for a shard partial) -- 64 different constants at once; with these tables a
+// lane's multiply is 32 independent 16-byte loads (indices = the nibbles of ITS value, all known up front) and a 16-step
+// shift-and-xor chain, instead of building a table per launch or running 128 bit-serial steps.
+HD void setup_ltab_lane(KeyMaterial *km, u32 e, u32 tid) {
+    if (tid >= 32 || e >= AESGCM_NLTAB) return;
+    const G128 c = mo_to_be(km->pw[0][e]);
+    G128 t = shoup_entry(c, tid & 15u);
+    if (tid >= 16) t = gf_mulx4(t);
+    km->ltab[e][tid] = make_uint4(t.w[0], t.w[1], t.w[2], t.w[3]);
+}
+// y * H^e through km->ltab[e] (device / host memory, not LDS)
+HD G128 shoup2_gmul(G128 y, const uint4 *__restrict__ tab) {
+    uint4 a[16], c[16];
+#pragma unroll
+    for (int bi = 0; bi < 16; bi++) {
+        const u32 w = y.w[bi >> 2];
+        const int sh = 8 * (3 - (bi & 3));
+        const u32 byte = (w >> sh) & 0xFFu;
+        a[bi] = tab[byte >> 4];
+        c[bi] = tab[16u + (byte & 15u)];
+    }
+    u32 z0 = 0, z1 = 0, z2 = 0, z3 = 0;
+#pragma unroll
+    for (int bi = 15; bi >= 0; bi--) {
+        if (bi != 15) gf_shift8(z0, z1, z2, z3);
+        z0 = xor3(z0, a[bi].x, c[bi].x); z1 = xor3(z1, a[bi].y, c[bi].y); z2 = xor3(z2, a[bi].z, c[bi].z); z3 = xor3(z3, a[bi].w, c[bi].w);
+    }
+    G128 z; z.w[0] = z0; z.w[1] = z1; z.w[2] = z2; z.w[3] = z3;
+    return z;
+}
 
 // One atomic address serves ~87 M fetches/s on MI355X (measured): a single dispenser caps a launch at one chunk per
 // 11.5 ns, i.e. chunks shorter than ~10 rows run at the dispenser's speed, not the kernel's.  Chunks are therefore
@@ -406,10 +452,6 @@ struct MainParams {
     uint4 *tag_out, *tag_host;   // tail: where the tag goes (device slot, and the pinned host slot or NULL)
     u64 gen;                     // tail: generation number published behind the host copy (see CombineParams::gen)
 };
-// LDS of a tail launch (one workgroup): the usual 72 KiB, then the nibble tables of H and the per-lane Shoup tables
-#define AESGCM_LDS_TAIL_H AESGCM_LDS_BYTES
-#define AESGCM_LDS_TAIL_LANE (AESGCM_LDS_BYTES + 8192u)
-#define AESGCM_LDS_TAIL_BYTES (AESGCM_LDS_BYTES + 8192u + 32768u)
 
 #define AESGCM_MAX_CHUNKS (1u << 18)   /* 64 lane accumulators (1 KiB) per chunk: at most 256 MiB of them; k_fold measured ~0.8 ns per chunk (about 3x its LDS-array floor of one table multiply per item) */
 
@@ -836,27 +878,27 @@ HD uint4 body_chunk_lane(const KeyMaterial *__restrict__ km, const DevTables *__
 
 // ---- k_combine pieces --------------------------------------------------------------------------
 // One workgroup per message (or per shard / streaming step).  Round 2: the launch also folds up to 64 chunk items itself
-// (two Horner stages with the key's precomputed H^(2^k) tables, as k_fold does for more), multiplies lane L by its own
-// constant H^(63-L) through a per-lane two-table Shoup multiply in LDS instead of a 128-step bit-serial loop, and
-// closes the tag with two table multiplies by H:  tag = ((P*H) ^ L)*H ^ E_K(J0)  (gcm_ghash.vhd:257,293).
+// (two Horner stages with the key's precomputed H^(2^k) tables, as k_fold does for more) and then needs ONE level of
+// per-lane constant multiplies through the key's precomputed Shoup tables (KeyMaterial::ltab) instead of three 128-step
+// bit-serial multiplies in sequence:  tag = sum_L B_L*H^(65-L) ^ L*H ^ E_K(J0)  (gcm_ghash.vhd:257,293 re-associated).
 // A 64 KiB message is now k_main + k_combine (it was k_main + k_fold + k_combine + a 16-byte copy kernel).
-#define COMBINE_THREADS (AESGCM_GMAX + 64)   /* GMAX gathered-partial lanes, rounded up to waves */
+#define COMBINE_THREADS 1024u                /* 16 waves: GMAX gathered-partial lanes, 16 level-1 fold groups, the single-term wave */
 enum { PARTS_NONE = 0, PARTS_GATHERED = 1, PARTS_ITEM = 2 };
-#define COMBINE_FOLD_GROUP 8u                /* items per wave in the in-launch fold */
+#define COMBINE_FOLD_GROUP 4u                /* fan-in of every level of the in-launch fold: 64 -> 16 -> 4 -> 1, three multiplies deep each */
 #define COMBINE_MAX_ITEMS 64u
 #define CMB_LDS_TABA 0u                      /* nibble tables of H^(eA): items are eA blocks apart */
-#define CMB_LDS_TABC 8192u                   /* ... of H^(8 eA): groups of 8 items */
-#define CMB_LDS_TABH 16384u                  /* ... of H: the two closing multiplies */
-#define CMB_LDS_STAGE 24576u                 /* 8 wave results x 1 KiB */
-#define CMB_LDS_LANE 32768u                  /* per-lane Shoup tables: Th at + v*1024 + lane*16, Tl 16 KiB further */
-#define CMB_LDS_SBOX 65536u
-#define CMB_LDS_RED 65792u                   /* one 16-byte slot per wave */
+#define CMB_LDS_TABB 8192u                   /* ... of H^(4 eA): level-1 results */
+#define CMB_LDS_TABC 16384u                  /* ... of H^(16 eA): level-2 results */
+#define CMB_LDS_STAGE1 24576u                /* 16 level-1 results x 1 KiB */
+#define CMB_LDS_STAGE2 40960u                /* 4 level-2 results x 1 KiB */
+#define CMB_LDS_SBOX 45056u
+#define CMB_LDS_RED 45312u                   /* one 16-byte slot per wave */
 #define CMB_LDS_BYTES (CMB_LDS_RED + 16u * (COMBINE_THREADS / 64u))
 struct CombineParams {
     const uint4 *parts; u32 np; u32 kind;   // GATHERED: np weighted 16-byte partials (shards); ITEM: np <= 64 chunk items of 64 lanes, eA blocks apart
     u32 stride;                  // GATHERED: distance between consecutive partials in 16-byte units (0 = 1): an all-gather of M messages' partials leaves [rank][message]
     u64 eA;                      // ITEM, np > 1: blocks between the ends of consecutive items (a power of two: the tables come from KeyMaterial::ptab)
-    const uint4 *tabA, *tabC;    // device pointers to the nibble tables of H^eA and H^(8 eA) (filled in by the host side)
+    const uint4 *tabA, *tabB, *tabC;   // device pointers to the nibble tables of H^eA, H^(4 eA), H^(16 eA) (filled in by the host side)
     u32 want_tag;                // 1 = TAG, 0 = POLY
     u64 e;                       // POLY: exponent applied to the folded partials
     const uint4 *carry; u64 e_carry; u32 has_carry;
@@ -867,81 +909,52 @@ struct CombineParams {
     uint4 *out_host;             // optional second copy of the result in host-visible (pinned, mapped) memory: no copy kernel for the tag
     u64 gen;                     // written to out_host[1] AFTER the result (system-scope fence between): the host polls it
 };
-// in-launch fold, stage a: wave w of J = ceil(np / 8) folds its (up to) 8 consecutive items; groups are cut from the END,
-// so only the first one is short and group ends stay 8 eA apart
-HD uint4 combine_fold_wave_lane(const CombineParams &p, const unsigned char *smem, u32 w, u32 lane) {
-    const u32 J = (p.np + COMBINE_FOLD_GROUP - 1) / COMBINE_FOLD_GROUP;
-    const u32 e = p.np - COMBINE_FOLD_GROUP * (J - 1 - w);
-    const u32 s = w == 0 ? 0 : e - COMBINE_FOLD_GROUP;
-    // all (up to) 8 loads first: they do not depend on the accumulator and each is an L2 round trip
-    uint4 it[COMBINE_FOLD_GROUP];
+// In-launch fold of n <= 64 chunk items: three levels of fan-in 4 (64 -> 16 -> 4 -> 1), each level a Horner over at most four
+// values with a wave-uniform constant (three dependent table multiplies of ~0.6 us for a lone wave, where two levels of
+// fan-in 8 were fourteen).  At every level the groups are cut from the END, so only the first group is short and group ends
+// stay equally spaced: 4 eA after level 1, 16 eA after level 2.
+HD u32 fold4_groups(u32 n) { return (n + COMBINE_FOLD_GROUP - 1) / COMBINE_FOLD_GROUP; }
+HD void fold4_range(u32 n, u32 g, u32 *s, u32 *e) {        // the values [*s, *e) of group g of fold4_groups(n)
+    const u32 J = fold4_groups(n);
+    *e = n - COMBINE_FOLD_GROUP * (J - 1 - g);
+    *s = g == 0 ? 0 : *e - COMBINE_FOLD_GROUP;
+}
+// level 1 loads: they depend on nothing and each is an L2 round trip, so k_combine issues them before it stages its tables
+struct CombineItems { uint4 it[COMBINE_FOLD_GROUP]; u32 n; };
+HD CombineItems combine_fold_load(const CombineParams &p, u32 g, u32 lane) {
+    u32 s, e;
+    fold4_range(p.np, g, &s, &e);
+    CombineItems c;
+    c.n = e - s;
 #pragma unroll
-    for (u32 k = 0; k < COMBINE_FOLD_GROUP; ++k) it[k] = (s + k < e) ? p.parts[(size_t)(s + k) * 64 + lane] : make_uint4(0, 0, 0, 0);
-    uint4 acc = it[0];
+    for (u32 k = 0; k < COMBINE_FOLD_GROUP; ++k) c.it[k] = (s + k < e) ? p.parts[(size_t)(s + k) * 64 + lane] : make_uint4(0, 0, 0, 0);
+    return c;
+}
+HD uint4 combine_fold_items(const CombineItems &c, const unsigned char *smem, u32 tab) {
+    uint4 acc = c.it[0];
 #pragma unroll
     for (u32 k = 1; k < COMBINE_FOLD_GROUP; ++k)
-        if (s + k < e) acc = xor4(ghash_mul_const_lds_at(acc, smem, CMB_LDS_TABA), it[k]);
+        if (k < c.n) acc = xor4(ghash_mul_const_lds_at(acc, smem, tab), c.it[k]);
     return acc;
 }
-// stage b: one wave folds the J staged results (H^(8 eA) apart)
-HD uint4 combine_fold_final_lane(const unsigned char *smem, u32 J, u32 lane) {
-    uint4 acc = *reinterpret_cast<const uint4 *>(smem + CMB_LDS_STAGE + lane * 16u);
-    for (u32 j = 1; j < J; ++j) acc = xor4(ghash_mul_const_lds_at(acc, smem, CMB_LDS_TABC), *reinterpret_cast<const uint4 *>(smem + CMB_LDS_STAGE + j * 1024u + lane * 16u));
-    return acc;
+// levels 2 and 3: group g of the n values staged at `stage` (1 KiB each), constant table at `tab`
+HD uint4 combine_fold_staged(const unsigned char *smem, u32 stage, u32 n, u32 g, u32 tab, u32 lane) {
+    u32 s, e;
+    fold4_range(n, g, &s, &e);
+    CombineItems c;
+    c.n = e - s;
+#pragma unroll
+    for (u32 k = 0; k < COMBINE_FOLD_GROUP; ++k) c.it[k] = (s + k < e) ? *reinterpret_cast<const uint4 *>(smem + stage + (s + k) * 1024u + lane * 16u) : make_uint4(0, 0, 0, 0);
+    return combine_fold_items(c, smem, tab);
 }
-// Per-lane constant multiply: every lane has its OWN multiplier c (lane L of the last item needs H^(63-L)), so the tables
-// are per lane: entry v of lane `lane` at tab + v*1024 + lane*16 (Th) and 16 KiB further (Tl = Th * x^4) -- consecutive
-// lanes read consecutive 16-byte slots, conflict-free.  ~0.5 us against ~5 us for the 128-step bit-serial gf_mul.
-HD void shoup2_lane_build(unsigned char *lds, u32 tab, G128 c, u32 lane) {
-    G128 b[4];                                     // b[k] = c * x^(3-k): the nibble's bit k (bit 3 <-> x^0)
-    b[3] = c; b[2] = gf_mulx(b[3]); b[1] = gf_mulx(b[2]); b[0] = gf_mulx(b[1]);
-    G128 bl[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) bl[k] = gf_mulx4(b[k]);
-#pragma unroll
-    for (u32 v = 0; v < 16; v++) {
-        u32 h0 = 0, h1 = 0, h2 = 0, h3 = 0, l0 = 0, l1 = 0, l2 = 0, l3 = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) if ((v >> k) & 1u) {
-            h0 ^= b[k].w[0]; h1 ^= b[k].w[1]; h2 ^= b[k].w[2]; h3 ^= b[k].w[3];
-            l0 ^= bl[k].w[0]; l1 ^= bl[k].w[1]; l2 ^= bl[k].w[2]; l3 ^= bl[k].w[3];
-        }
-        *reinterpret_cast<uint4 *>(lds + tab + v * 1024u + lane * 16u) = make_uint4(h0, h1, h2, h3);
-        *reinterpret_cast<uint4 *>(lds + tab + 16384u + v * 1024u + lane * 16u) = make_uint4(l0, l1, l2, l3);
-    }
-}
-HD G128 shoup2_lane_mul(G128 y, const unsigned char *lds, u32 tab, u32 lane) {
-    u32 z0 = 0, z1 = 0, z2 = 0, z3 = 0;
-    const u32 base = tab + lane * 16u;
-#pragma unroll
-    for (int bi = 15; bi >= 0; bi--) {
-        const u32 w = y.w[bi >> 2];
-        const int sh = 8 * (3 - (bi & 3));
-        const u32 hi = (sh ? (w >> sh) : w) & 0xF0u;
-        const u32 lo = (sh ? (w >> (sh - 4)) : (w << 4)) & 0xF0u;
-        if (bi != 15) gf_shift8(z0, z1, z2, z3);
-        const u32x4_t a = LDS_LD128(lds, hi * 64u + base);
-        const u32x4_t c = LDS_LD128(lds, lo * 64u + (base + 16384u));
-        z0 = xor3(z0, a.x, c.x); z1 = xor3(z1, a.y, c.y); z2 = xor3(z2, a.z, c.z); z3 = xor3(z3, a.w, c.w);
-    }
-    G128 z; z.w[0] = z0; z.w[1] = z1; z.w[2] = z2; z.w[3] = z3;
-    return z;
-}
-// tag = ((P*H) ^ L)*H ^ E_K(IV || 1)  (gcm_ghash.vhd:257,293): two multiplies by the uniform constant H through its nibble
-// tables at LDS offset tabH.  Shared by k_combine and by k_main's single-chunk tail.
-HD G128 close_tag_lds(G128 P, u64 aad_len, u64 ct_len, G128 ej0, const unsigned char *smem, u32 tabH) {
+// The closing of a tag without closing multiplies: tag = P*H^2 ^ L*H ^ E_K(J0) with P = sum_L B_L * H^(63-L), so lane L
+// contributes B_L * H^(65-L) and the length block L contributes L * H^1 -- 65 per-lane constant multiplies in parallel through
+// the key's precomputed tables (km->ltab[e], shoup2_gmul), one multiply deep.  Shared by k_combine and k_main's tail.
+HD G128 tag_lane_term(const KeyMaterial *__restrict__ km, uint4 b, u32 lane) { return shoup2_gmul(mo_to_be(b), km->ltab[65 - lane]); }
+HD G128 tag_len_term(const KeyMaterial *__restrict__ km, u64 aad_len, u64 ct_len) {
     G128 L; const u64 a = aad_len * 8, c = ct_len * 8;
     L.w[0] = (u32)(a >> 32); L.w[1] = (u32)a; L.w[2] = (u32)(c >> 32); L.w[3] = (u32)c;
-    G128 y = mo_to_be(ghash_mul_const_lds_at(be_to_mo(P), smem, tabH));
-    y.w[0] ^= L.w[0]; y.w[1] ^= L.w[1]; y.w[2] ^= L.w[2]; y.w[3] ^= L.w[3];
-    y = mo_to_be(ghash_mul_const_lds_at(be_to_mo(y), smem, tabH));
-    y.w[0] ^= ej0.w[0]; y.w[1] ^= ej0.w[1]; y.w[2] ^= ej0.w[2]; y.w[3] ^= ej0.w[3];
-    return y;
-}
-// k_main's tail, lane part: lane L of the single chunk's item times H^(63-L) (the wave then XOR-folds and closes the tag)
-HD G128 main_tail_lane(const KeyMaterial *__restrict__ km, unsigned char *smem, uint4 acc, u32 lane) {
-    shoup2_lane_build(smem, AESGCM_LDS_TAIL_LANE, mo_to_be(km->pw[0][63 - lane]), lane);
-    return shoup2_lane_mul(mo_to_be(acc), smem, AESGCM_LDS_TAIL_LANE, lane);
+    return shoup2_gmul(L, km->ltab[1]);
 }
 // E_K(IV || 0^31 1): the J0 block the RTL latches first (gcm_ghash.vhd:158-169), bytewise (only when k_main left none behind)
 HD G128 combine_ej0_bytes(const KeyMaterial *__restrict__ km, const uint8_t *sbox, const CombineParams &p) {
@@ -1124,18 +1137,6 @@ HD G128 gf_sqr(G128 a) {
     const u32 v = (h3 << 31) ^ (h3 << 30) ^ (h3 << 25);       // overflow polynomial, degree <= 6
     t0 ^= v ^ (v >> 1) ^ (v >> 2) ^ (v >> 7);
     G128 r; r.w[0] = W[0] ^ t0; r.w[1] = W[1] ^ t1; r.w[2] = W[2] ^ t2; r.w[3] = W[3] ^ t3;
-    return r;
-}
-// entry v (0..15) of the Shoup table of constant c: (v as polynomial v3 + v2 x + v1 x^2 + v0 x^3, GCM bit order:
-// the nibble's MSB is x^0) times c
-HD G128 shoup_entry(G128 c, u32 v) {
-    G128 r; r.w[0] = r.w[1] = r.w[2] = r.w[3] = 0;
-    G128 t = c;
-    for (int k = 3; k >= 0; k--) {                             // bit 3 of v <-> x^0, bit 0 <-> x^3
-        const u32 m = 0u - ((v >> k) & 1u);
-        r.w[0] ^= t.w[0] & m; r.w[1] ^= t.w[1] & m; r.w[2] ^= t.w[2] & m; r.w[3] ^= t.w[3] & m;
-        t = gf_mulx(t);
-    }
     return r;
 }
 // Y * c through the table at LDS byte offset `tab` (16 entries x 4 BE words) and the reduction table

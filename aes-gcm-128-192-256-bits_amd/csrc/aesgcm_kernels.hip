@@ -27,6 +27,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <vector>
 
 // ------------------------------------------------------------------------------------------------
@@ -129,7 +130,6 @@ __global__ __launch_bounds__(AESGCM_MAIN_WG, AESGCM_WAVES_PER_SIMD) void k_main(
     }
     const u64 cyc0 = p.trace ? clock64() : 0;
     main_fill_lds(smem, km, tb, tid, GH);
-    if (GH && p.tail) for (u32 q = tid; q < 512; q += AESGCM_MAIN_WG) reinterpret_cast<uint4 *>(smem + AESGCM_LDS_TAIL_H)[q] = km->htab[q];
     __syncthreads();
     // round-1 constants depend on key and IV only (the lane merely picks which table replica it reads), so they
     // are wave-uniform: keep them in scalar registers, the vector file is full at 8 waves per SIMD
@@ -147,7 +147,16 @@ __global__ __launch_bounds__(AESGCM_MAIN_WG, AESGCM_WAVES_PER_SIMD) void k_main(
         if (p.nq == 0) {
             // small launch: at least as many waves as chunks, wave i owns chunk i -- no dispenser round trips on the
             // latency path of a short message
-            if (guard || wave_id >= p.C) break;
+            if (guard) break;
+            if (wave_id >= p.C) {
+                // a spare wave (the launch has at least C + 1 of them) computes E_K(IV || 1) off the critical path of chunk 0
+                if (GH && wave_id == p.C && p.ej0 && !p.tail) {
+                    u32 s0, s1, s2, s3;
+                    ctr_rounds_lds<NR>(bswap32(1u), cc, s0, s1, s2, s3, km->rk, smem, (lane & 31u) << 2);
+                    if (lane == 0) *p.ej0 = make_uint4(s0, s1, s2, s3);
+                }
+                break;
+            }
             c = wave_id;
         } else {
             u32 v = 0;
@@ -163,15 +172,19 @@ __global__ __launch_bounds__(AESGCM_MAIN_WG, AESGCM_WAVES_PER_SIMD) void k_main(
         }
         const uint4 acc = main_chunk_lane<NR, MODE>(km, p, smem, cc, c, lane);
         if (GH) p.parts[(size_t)c * 64 + lane] = acc;          // the chunk's item: 64 raw lane accumulators (k_fold / k_combine take over)
-        if (GH && c == 0 && (p.ej0 || p.tail)) {                 // E_K(IV || 1) for the tag (gcm_ghash.vhd:158-169), once per launch
+        if (GH && c == 0 && (p.ej0 || p.tail) && (p.nq != 0 || p.tail)) {   // E_K(IV || 1) for the tag (gcm_ghash.vhd:158-169), once per launch (static launches: a spare wave does it)
             u32 s0, s1, s2, s3;
             ctr_rounds_lds<NR>(bswap32(1u), cc, s0, s1, s2, s3, km->rk, smem, (lane & 31u) << 2);
             if (lane == 0 && p.ej0) *p.ej0 = make_uint4(s0, s1, s2, s3);
             if (p.tail) {
                 // single-chunk message: this wave holds the whole polynomial (lane L: B_L); finish the tag here instead of
-                // launching k_combine: B_L * H^(63-L) per lane, XOR fold, tag = ((P*H) ^ L)*H ^ E_K(IV || 1)
-                const G128 P = wave_xor_fold(main_tail_lane(km, smem, acc, lane));
-                const G128 t = close_tag_lds(P, p.aad_len, p.len, mo_to_be(make_uint4(s0, s1, s2, s3)), smem, AESGCM_LDS_TAIL_H);
+                // launching k_combine: tag = sum_L B_L*H^(65-L) ^ L*H ^ E_K(IV || 1), every term one table multiply deep
+                G128 term = tag_lane_term(km, acc, lane);
+                if (lane == 0) {
+                    const G128 lt = tag_len_term(km, p.aad_len, p.len);
+                    term.w[0] ^= lt.w[0] ^ bswap32(s0); term.w[1] ^= lt.w[1] ^ bswap32(s1); term.w[2] ^= lt.w[2] ^ bswap32(s2); term.w[3] ^= lt.w[3] ^ bswap32(s3);
+                }
+                const G128 t = wave_xor_fold(term);
                 if (lane == 0) { *p.tag_out = be_to_mo(t); if (p.tag_host) publish_host(p.tag_host, be_to_mo(t), p.gen); }
             }
         }
@@ -261,7 +274,10 @@ __global__ __launch_bounds__(FOLD_WG) void k_fold(const KeyMaterial *__restrict_
     if (w == 0) p.out[(size_t)blockIdx.x * 64 + lane] = fold_wg_lane(smem, J, lane);
 }
 // nibble tables of H^(2^k), k = 6..31, once per key (after k_setup)
-__global__ __launch_bounds__(512) void k_setup_ptab(KeyMaterial *km) { setup_ptab_lane(km, blockIdx.x, threadIdx.x); }
+__global__ __launch_bounds__(512) void k_setup_ptab(KeyMaterial *km) {
+    if (blockIdx.x < AESGCM_NPTAB) setup_ptab_lane(km, blockIdx.x, threadIdx.x);
+    else setup_ltab_lane(km, blockIdx.x - AESGCM_NPTAB, threadIdx.x);      // Shoup tables of H^e, e = 0 .. 65
+}
 
 // ------------------------------------------------------------------------------------------------
 // k_combine: one workgroup, per message.
@@ -287,24 +303,34 @@ __global__ __launch_bounds__(COMBINE_THREADS) void k_combine(const KeyMaterial *
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // no static LDS: table offsets are absolute (CMB_LDS_*)
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
     const bool tag = p.want_tag != 0, items = p.kind == PARTS_ITEM;
-    const u32 J = items ? (p.np + COMBINE_FOLD_GROUP - 1) / COMBINE_FOLD_GROUP : 0;
-    // ---- stage the tables this launch needs
+    const u32 J1 = items ? fold4_groups(p.np) : 0, J2 = items ? fold4_groups(J1) : 0;      // groups at level 1 (<= 16) and level 2 (<= 4)
+    // ---- the item loads first (L2 round trips that depend on nothing), then the tables this launch needs
+    CombineItems ci;
+    ci.n = 0;
+    if (w < J1) ci = combine_fold_load(p, w, lane);
     if (items && p.np > 1) for (u32 q = tid; q < 512; q += COMBINE_THREADS) reinterpret_cast<uint4 *>(smem + CMB_LDS_TABA)[q] = p.tabA[q];
-    if (J > 1) for (u32 q = tid; q < 512; q += COMBINE_THREADS) reinterpret_cast<uint4 *>(smem + CMB_LDS_TABC)[q] = p.tabC[q];
-    if (tag) for (u32 q = tid; q < 512; q += COMBINE_THREADS) reinterpret_cast<uint4 *>(smem + CMB_LDS_TABH)[q] = km->htab[q];
+    if (J1 > 1) for (u32 q = tid; q < 512; q += COMBINE_THREADS) reinterpret_cast<uint4 *>(smem + CMB_LDS_TABB)[q] = p.tabB[q];
+    if (J2 > 1) for (u32 q = tid; q < 512; q += COMBINE_THREADS) reinterpret_cast<uint4 *>(smem + CMB_LDS_TABC)[q] = p.tabC[q];
     if (tid < 256) smem[CMB_LDS_SBOX + tid] = tb->sbox[tid];
     __syncthreads();
-    // ---- chunk items: Horner in two stages (8 items per wave, then the <= 8 wave results)
-    if (w < J) *reinterpret_cast<uint4 *>(smem + CMB_LDS_STAGE + w * 1024u + lane * 16u) = combine_fold_wave_lane(p, smem, w, lane);
+    // ---- chunk items: three Horner levels of fan-in 4
+    if (w < J1) *reinterpret_cast<uint4 *>(smem + CMB_LDS_STAGE1 + w * 1024u + lane * 16u) = combine_fold_items(ci, smem, CMB_LDS_TABA);
     __syncthreads();
+    if (w < J2) *reinterpret_cast<uint4 *>(smem + CMB_LDS_STAGE2 + w * 1024u + lane * 16u) = combine_fold_staged(smem, CMB_LDS_STAGE1, J1, w, CMB_LDS_TABB, lane);
+    __syncthreads();
+    // ---- every lane's term of the result.  TAG: B_L*H^(65-L), gathered W_g*H^2, L*H, E_K(J0), carry*H^2 -- all one
+    // table multiply deep (km->ltab).  POLY: B_L*H^(63-L), W_g; the weighting by H^e and the carry follow below.
     G128 z; z.w[0] = z.w[1] = z.w[2] = z.w[3] = 0;
     if (items && w == 0) {
-        // lane L of the folded item carries H^(63-L): per-lane constant, per-lane tables
-        const G128 b = mo_to_be(combine_fold_final_lane(smem, J, lane));
-        shoup2_lane_build(smem, CMB_LDS_LANE, mo_to_be(km->pw[0][63 - lane]), lane);
-        z = shoup2_lane_mul(b, smem, CMB_LDS_LANE, lane);
+        const G128 b = mo_to_be(combine_fold_staged(smem, CMB_LDS_STAGE2, J2, 0, CMB_LDS_TABC, lane));
+        z = shoup2_gmul(b, km->ltab[(tag ? 65u : 63u) - lane]);
     } else if (p.kind == PARTS_GATHERED && tid < p.np) {
         z = mo_to_be(p.parts[(size_t)tid * (p.stride ? p.stride : 1u)]);
+        if (tag) z = shoup2_gmul(z, km->ltab[2]);
+    } else if (tag && w == COMBINE_THREADS / 64 - 1) {             // the last wave carries the three single terms of a tag
+        if (lane == 0) z = tag_len_term(km, p.aad_len, p.ct_len);
+        else if (lane == 1) z = p.ej0 ? mo_to_be(*p.ej0) : combine_ej0_bytes(km, smem + CMB_LDS_SBOX, p);
+        else if (lane == 2 && p.has_carry && !p.e_carry) z = shoup2_gmul(mo_to_be(*p.carry), km->ltab[2]);
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -316,18 +342,13 @@ __global__ __launch_bounds__(COMBINE_THREADS) void k_combine(const KeyMaterial *
     if (tid < 64) {
         uint4 r = *reinterpret_cast<const uint4 *>(smem + CMB_LDS_RED);
         for (u32 k = 1; k < COMBINE_THREADS / 64; k++) r = xor4(r, *reinterpret_cast<const uint4 *>(smem + CMB_LDS_RED + 16u * k));
-        G128 acc = mo_to_be(r);                                   // P = polynomial of this launch's partials (every lane holds it)
+        G128 acc = mo_to_be(r);                                   // TAG: the tag itself (unless a weighted carry is still due); POLY: the polynomial
         if (!tag && p.e) acc = gf_mul(acc, gf_pow_h(km, p.e, tid));
-        if (p.has_carry) {
+        if (p.has_carry && (!tag || p.e_carry)) {                 // bit-serial path: shard / streaming steps, off the one-shot latency path
             G128 c = mo_to_be(*p.carry);
             if (p.e_carry) c = gf_mul(c, gf_pow_h(km, p.e_carry, tid));
+            if (tag) c = gf_mul(c, mo_to_be(km->pw[0][2]));
             acc.w[0] ^= c.w[0]; acc.w[1] ^= c.w[1]; acc.w[2] ^= c.w[2]; acc.w[3] ^= c.w[3];
-        }
-        if (tag) {
-            G128 ej0;
-            if (p.ej0) ej0 = mo_to_be(*p.ej0);
-            else ej0 = combine_ej0_bytes(km, smem + CMB_LDS_SBOX, p);
-            acc = close_tag_lds(acc, p.aad_len, p.ct_len, ej0, smem, CMB_LDS_TABH);
         }
         if (tid == 0) {
             *p.out = be_to_mo(acc);
@@ -827,7 +848,7 @@ static const u64 MAX_SEQ_BLOCKS = ((u64)1) << 36;
 
 template <int MODE>
 static hipError_t launch_main_nr(int nr, dim3 grid, hipStream_t st, const KeyMaterial *km, const DevTables *tb, const MainParams &p) {
-    const unsigned lds = p.tail ? AESGCM_LDS_TAIL_BYTES : AESGCM_LDS_BYTES;
+    const unsigned lds = AESGCM_LDS_BYTES;
     switch (nr) {
     case 10: hipLaunchKernelGGL((k_main<10, MODE>), grid, dim3(AESGCM_MAIN_WG), lds, st, km, tb, p); break;
     case 12: hipLaunchKernelGGL((k_main<12, MODE>), grid, dim3(AESGCM_MAIN_WG), lds, st, km, tb, p); break;
@@ -849,7 +870,7 @@ static int set_lds_attrs(int device, DeviceState *ds) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (ds->attrs) return AESGCM_OK;
     HIPCHK(hipSetDevice(device));
-#define SETATTR(NR, MODE) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_main<NR, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, AESGCM_LDS_TAIL_BYTES))
+#define SETATTR(NR, MODE) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_main<NR, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, AESGCM_LDS_BYTES))
     SETATTR(10, MODE_ENC); SETATTR(12, MODE_ENC); SETATTR(14, MODE_ENC);
     SETATTR(10, MODE_DEC); SETATTR(12, MODE_DEC); SETATTR(14, MODE_DEC);
     SETATTR(10, MODE_KS);  SETATTR(12, MODE_KS);  SETATTR(14, MODE_KS);
@@ -923,11 +944,11 @@ static int enqueue_main(aesgcm_ctx *c, int mode, const uint8_t iv[12], const voi
     int rc;
     if (gh && (rc = grow_parts(c, C))) return rc;
     p.parts = c->parts;
-    u32 wgs = (C + AESGCM_MAIN_WG / 64 - 1) / (AESGCM_MAIN_WG / 64);          // one wave per chunk is enough for small inputs
+    u32 wgs = (C + 1 + AESGCM_MAIN_WG / 64 - 1) / (AESGCM_MAIN_WG / 64);      // one wave per chunk is enough for small inputs (+ one spare for E_K(J0))
     if (wgs > (u32)c->G) wgs = (u32)c->G;
     p.counter = c->d_counter + 16;
     plan_queues(C, &p.nq, &p.seg);
-    if ((u64)wgs * (AESGCM_MAIN_WG / 64) >= C) p.nq = 0;        // a wave per chunk: static assignment, the dispensers are not touched
+    if ((u64)wgs * (AESGCM_MAIN_WG / 64) >= (u64)C + 1) p.nq = 0;   // a wave per chunk and a spare: static assignment, the dispensers are not touched
     for (u32 q = 0; q < AESGCM_NQ; q++) p.qbase[q] = c->mq_base[q];
     for (u32 q = 0; q < p.nq; q++) c->mq_base[q] += p.seg + wgs * (AESGCM_MAIN_WG / 64);   // every wave finds every queue dry exactly once
     if (gh && po) { p.ej0 = c->d_tag + 3; po->ej0 = p.ej0; }
@@ -957,7 +978,7 @@ static int enqueue_main(aesgcm_ctx *c, int mode, const uint8_t iv[12], const voi
     if (gh && po && po->done) return AESGCM_OK;                   // the launch finished the tag itself
     if (gh && po) {
         const u64 eA = (u64)64 * p.Tw;
-        if (C <= COMBINE_MAX_ITEMS && (C == 1 || (ptab_ptr(c, eA) && (C <= COMBINE_FOLD_GROUP || ptab_ptr(c, COMBINE_FOLD_GROUP * eA))))) {
+        if (C <= COMBINE_MAX_ITEMS && (C == 1 || (ptab_ptr(c, eA) && (C <= 4 || ptab_ptr(c, 4 * eA)) && (C <= 16 || ptab_ptr(c, 16 * eA))))) {
             po->ptr = c->parts; po->np = C; po->kind = PARTS_ITEM; po->eA = eA;   // few chunks: k_combine folds them, no k_fold launch
             return AESGCM_OK;
         }
@@ -1053,8 +1074,9 @@ static int enqueue_combine(aesgcm_ctx *c, const CombineParams &p0, hipStream_t s
     if (p.out == c->d_tag) { p.out_host = c->h_tag_dev; p.gen = ++c->tag_gen; }   // results that go to the tag slot are mirrored to the pinned host slot
     if (p.kind == PARTS_ITEM && p.np > 1) {                       // the launch folds the items itself: tables of H^eA, H^(8 eA)
         p.tabA = ptab_ptr(c, p.eA);
-        p.tabC = p.np > COMBINE_FOLD_GROUP ? ptab_ptr(c, COMBINE_FOLD_GROUP * p.eA) : nullptr;
-        if (p.np > COMBINE_MAX_ITEMS || !p.tabA || (p.np > COMBINE_FOLD_GROUP && !p.tabC)) { snprintf(g_err, sizeof g_err, "k_combine: %u items, spacing %llu not foldable in the launch", p.np, (unsigned long long)p.eA); return AESGCM_EHIP; }
+        p.tabB = p.np > 4 ? ptab_ptr(c, 4 * p.eA) : nullptr;
+        p.tabC = p.np > 16 ? ptab_ptr(c, 16 * p.eA) : nullptr;
+        if (p.np > COMBINE_MAX_ITEMS || !p.tabA || (p.np > 4 && !p.tabB) || (p.np > 16 && !p.tabC)) { snprintf(g_err, sizeof g_err, "k_combine: %u items, spacing %llu not foldable in the launch", p.np, (unsigned long long)p.eA); return AESGCM_EHIP; }
     }
     hipLaunchKernelGGL(k_combine, dim3(1), dim3(COMBINE_THREADS), CMB_LDS_BYTES, st, c->km, c->tables, p);
     HIPCHK(hipGetLastError());
@@ -1103,8 +1125,14 @@ static int fetch_tag(aesgcm_ctx *c, hipStream_t st, uint8_t tag[16]) {
     const u64 want = c->tag_gen;
     volatile u64 *gen = reinterpret_cast<volatile u64 *>(c->h_tag + 1);
     bool seen = false;
-    for (u32 spin = 0; spin < 400000u; ++spin) {                 // ~100-200 us of polling at most
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (u32 spin = 0;; ++spin) {                                 // poll for at most ~200 us, then block in the runtime
         if (__atomic_load_n(gen, __ATOMIC_ACQUIRE) == want) { seen = true; break; }
+        if ((spin & 63u) == 63u) {
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > 200000L) break;
+        }
 #if defined(__x86_64__)
         __builtin_ia32_pause();
 #endif
@@ -1205,7 +1233,7 @@ static int ctx_create_common(aesgcm_ctx **out, int device, const uint8_t *key, s
     e = hipMemcpyAsync(d_key, key, kb, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_setup, dim3(1), dim3(AESGCM_WG), 0, c->stream, c->km, c->tables, d_key, (int)key_len, pre_nr, (u32)G);
-        hipLaunchKernelGGL(k_setup_ptab, dim3(AESGCM_NPTAB), dim3(512), 0, c->stream, c->km);
+        hipLaunchKernelGGL(k_setup_ptab, dim3(AESGCM_NPTAB + AESGCM_NLTAB), dim3(512), 0, c->stream, c->km);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemsetAsync(d_key, 0, 256, c->stream);    // do not leave key bytes behind

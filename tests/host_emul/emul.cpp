@@ -42,6 +42,7 @@ static void emu_setup(KeyMaterial *km, const uint8_t *key, int key_len, int pre_
         if (d < 3) { uint4 next = tab[AESGCM_WG]; tab[0] = gf_one_mo(); tab[1] = next; }
     }
     for (u32 k = 0; k < AESGCM_NPTAB; k++) for (u32 tid = 0; tid < 512; tid++) setup_ptab_lane(km, k, tid);
+    for (u32 e = 0; e < AESGCM_NLTAB; e++) for (u32 tid = 0; tid < 32; tid++) setup_ltab_lane(km, e, tid);
 }
 
 static void xor_g(G128 &a, const G128 &b) { for (int k = 0; k < 4; k++) a.w[k] ^= b.w[k]; }
@@ -89,45 +90,44 @@ static void emu_body(int mode, const KeyMaterial *km, const BodyParams &p) {
 #undef D
 }
 static G128 emu_pow_h(const KeyMaterial *km, u64 e) { return gf_pow_h_serial(km, e); }
-// emulated k_combine: the same lane pieces (in-launch item fold, per-lane Shoup multiply, closing table multiplies by H)
+// emulated k_combine: the same lane pieces (in-launch item fold, one level of per-lane table multiplies through km->ltab)
 static void emu_combine(const KeyMaterial *km, const CombineParams &p0) {
     static unsigned char smem[CMB_LDS_BYTES] __attribute__((aligned(16)));
     CombineParams p = p0;
     const bool tag = p.want_tag != 0, items = p.kind == PARTS_ITEM;
     auto tp = [&](u64 e) -> const uint4 * { int k = ptab_index(e); return k < 0 ? nullptr : km->ptab[k]; };
-    if (items && p.np > 1) { p.tabA = tp(p.eA); p.tabC = p.np > COMBINE_FOLD_GROUP ? tp(COMBINE_FOLD_GROUP * p.eA) : nullptr; }
-    CHECK(!(items && p.np > 1) || (p.np <= COMBINE_MAX_ITEMS && p.tabA && (p.np <= COMBINE_FOLD_GROUP || p.tabC)), "emu_combine: %u items not foldable", p.np);
-    const u32 J = items ? (p.np + COMBINE_FOLD_GROUP - 1) / COMBINE_FOLD_GROUP : 0;
+    if (items && p.np > 1) { p.tabA = tp(p.eA); p.tabB = p.np > 4 ? tp(4 * p.eA) : nullptr; p.tabC = p.np > 16 ? tp(16 * p.eA) : nullptr; }
+    CHECK(!(items && p.np > 1) || (p.np <= COMBINE_MAX_ITEMS && p.tabA && (p.np <= 4 || p.tabB) && (p.np <= 16 || p.tabC)), "emu_combine: %u items not foldable", p.np);
+    const u32 J1 = items ? fold4_groups(p.np) : 0, J2 = items ? fold4_groups(J1) : 0;
     if (items && p.np > 1) memcpy(smem + CMB_LDS_TABA, p.tabA, 8192);
-    if (J > 1) memcpy(smem + CMB_LDS_TABC, p.tabC, 8192);
-    if (tag) memcpy(smem + CMB_LDS_TABH, km->htab, 8192);
+    if (J1 > 1) memcpy(smem + CMB_LDS_TABB, p.tabB, 8192);
+    if (J2 > 1) memcpy(smem + CMB_LDS_TABC, p.tabC, 8192);
     memcpy(smem + CMB_LDS_SBOX, g_tb.sbox, 256);
-    for (u32 w = 0; w < J; w++) for (u32 lane = 0; lane < 64; lane++)
-        *reinterpret_cast<uint4 *>(smem + CMB_LDS_STAGE + w * 1024u + lane * 16u) = combine_fold_wave_lane(p, smem, w, lane);
+    for (u32 w = 0; w < J1; w++) for (u32 lane = 0; lane < 64; lane++)
+        *reinterpret_cast<uint4 *>(smem + CMB_LDS_STAGE1 + w * 1024u + lane * 16u) = combine_fold_items(combine_fold_load(p, w, lane), smem, CMB_LDS_TABA);
+    for (u32 w = 0; w < J2; w++) for (u32 lane = 0; lane < 64; lane++)
+        *reinterpret_cast<uint4 *>(smem + CMB_LDS_STAGE2 + w * 1024u + lane * 16u) = combine_fold_staged(smem, CMB_LDS_STAGE1, J1, w, CMB_LDS_TABB, lane);
     G128 acc = {{0, 0, 0, 0}};
     if (items) {
-        for (u32 lane = 0; lane < 64; lane++) {
-            const G128 b = mo_to_be(combine_fold_final_lane(smem, J, lane));
-            shoup2_lane_build(smem, CMB_LDS_LANE, mo_to_be(km->pw[0][63 - lane]), lane);
-            xor_g(acc, shoup2_lane_mul(b, smem, CMB_LDS_LANE, lane));
-        }
+        for (u32 lane = 0; lane < 64; lane++) xor_g(acc, shoup2_gmul(mo_to_be(combine_fold_staged(smem, CMB_LDS_STAGE2, J2, 0, CMB_LDS_TABC, lane)), km->ltab[(tag ? 65u : 63u) - lane]));
     } else if (p.kind == PARTS_GATHERED) {
-        for (u32 tid = 0; tid < p.np; tid++) xor_g(acc, mo_to_be(p.parts[(size_t)tid * (p.stride ? p.stride : 1u)]));
-    }
-    if (!tag && p.e) acc = gf_mul(acc, emu_pow_h(km, p.e));
-    if (p.has_carry) {
-        G128 c = mo_to_be(*p.carry);
-        if (p.e_carry) c = gf_mul(c, emu_pow_h(km, p.e_carry));
-        xor_g(acc, c);
+        for (u32 tid = 0; tid < p.np; tid++) {
+            G128 z = mo_to_be(p.parts[(size_t)tid * (p.stride ? p.stride : 1u)]);
+            if (tag) z = shoup2_gmul(z, km->ltab[2]);
+            xor_g(acc, z);
+        }
     }
     if (tag) {
-        const G128 L = combine_len_block(p);
-        const G128 ej0 = p.ej0 ? mo_to_be(*p.ej0) : combine_ej0_bytes(km, smem + CMB_LDS_SBOX, p);
-        G128 y = mo_to_be(ghash_mul_const_lds_at(be_to_mo(acc), smem, CMB_LDS_TABH));
-        xor_g(y, L);
-        y = mo_to_be(ghash_mul_const_lds_at(be_to_mo(y), smem, CMB_LDS_TABH));
-        xor_g(y, ej0);
-        acc = y;
+        xor_g(acc, tag_len_term(km, p.aad_len, p.ct_len));
+        xor_g(acc, p.ej0 ? mo_to_be(*p.ej0) : combine_ej0_bytes(km, smem + CMB_LDS_SBOX, p));
+        if (p.has_carry && !p.e_carry) xor_g(acc, shoup2_gmul(mo_to_be(*p.carry), km->ltab[2]));
+    }
+    if (!tag && p.e) acc = gf_mul(acc, emu_pow_h(km, p.e));
+    if (p.has_carry && (!tag || p.e_carry)) {
+        G128 c = mo_to_be(*p.carry);
+        if (p.e_carry) c = gf_mul(c, emu_pow_h(km, p.e_carry));
+        if (tag) c = gf_mul(c, mo_to_be(km->pw[0][2]));
+        xor_g(acc, c);
     }
     *p.out = be_to_mo(acc);
 }
@@ -178,7 +178,7 @@ struct Emu {
         // mirrors enqueue_main(): few chunks with table-backed spacing go to k_combine unfolded
         const u64 eA = (u64)64 * p.Tw;
         auto has = [&](u64 e) { return ptab_index(e) >= 0; };
-        if (C <= COMBINE_MAX_ITEMS && (C == 1 || (has(eA) && (C <= COMBINE_FOLD_GROUP || has(COMBINE_FOLD_GROUP * eA))))) { Parts q = {parts.data(), C, PARTS_ITEM, eA}; return q; }
+        if (C <= COMBINE_MAX_ITEMS && (C == 1 || (has(eA) && (C <= 4 || has(4 * eA)) && (C <= 16 || has(16 * eA))))) { Parts q = {parts.data(), C, PARTS_ITEM, eA}; return q; }
         return fold(parts.data(), C, 1, eA, 0);
     }
     // mirrors enqueue_body(): k_body + k_fold with the interleaved first level
@@ -224,14 +224,13 @@ struct Emu {
         Parts pp = run(dec ? MODE_DEC : MODE_ENC, iv, aad, aad_len, in, len, out, 0);
         uint4 t;
         if (pp.np == 1 && pp.gathered == PARTS_ITEM) {
-            // mirrors k_main's tail (single-chunk message: no k_combine launch): lane multiplies, fold, closing multiplies
-            static unsigned char smem[AESGCM_LDS_TAIL_BYTES] __attribute__((aligned(16)));
-            memcpy(smem + AESGCM_LDS_TAIL_H, km.htab, 8192);
+            // mirrors k_main's tail (single-chunk message: no k_combine launch): every term one table multiply deep
             G128 P = {{0, 0, 0, 0}};
-            for (u32 lane = 0; lane < 64; lane++) xor_g(P, main_tail_lane(&km, smem, pp.ptr[lane], lane));
+            for (u32 lane = 0; lane < 64; lane++) xor_g(P, tag_lane_term(&km, pp.ptr[lane], lane));
+            xor_g(P, tag_len_term(&km, aad_len, len));
             CombineParams q = plan_combine_tag(nullptr, 0, PARTS_NONE, iv, aad_len, len, &t);
-            const G128 ej0 = combine_ej0_bytes(&km, g_tb.sbox, q);
-            t = be_to_mo(close_tag_lds(P, aad_len, len, ej0, smem, AESGCM_LDS_TAIL_H));
+            xor_g(P, combine_ej0_bytes(&km, g_tb.sbox, q));
+            t = be_to_mo(P);
         } else {
             emu_combine(&km, combine_with_items(plan_combine_tag(pp.ptr, pp.np, pp.gathered, iv, aad_len, len, &t), pp.eA));
         }
