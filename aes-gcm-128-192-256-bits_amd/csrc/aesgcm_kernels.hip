@@ -1175,6 +1175,7 @@ const char *aesgcm_strerror(int code) {
     case AESGCM_ENOMEM: return "out of device memory";
     case AESGCM_ESTATE: return "streaming call out of order";
     case AESGCM_EALIGN: return "device data pointer must be 16-byte aligned";
+    case AESGCM_ERCCL: return "RCCL unavailable or a collective failed (see aesgcm_comm_last_error)";
     default: return "unknown error";
     }
 }

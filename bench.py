@@ -160,7 +160,7 @@ def main():
     dev = 0 if args.one_device else local
     ex = None
     if world > 1:
-        ex = (comm.RcclExchange if args.backend in ("rccl", "nccl") else comm.FileExchange)(rank, world, dev)
+        ex = comm.make_exchange(rank, world, dev, prefer="rccl" if args.backend in ("rccl", "nccl") else "file")
 
     per_gpu = int(cfg["gib"] * GiB) // (16 * 2 * N) * (16 * 2 * N)
     key_bits = cfg["key_bits"]
