@@ -918,6 +918,11 @@ static int enqueue_fold(aesgcm_ctx *c, const uint4 *items, u32 n, u32 period, u6
     const uint4 *cur = items;
     int which = 0;
     while (n > 1) {
+        // the last level(s) can be k_combine's own: up to 64 items whose spacing has precomputed tables
+        if (period <= 1 && n <= COMBINE_MAX_ITEMS && ptab_ptr(c, eA) && (n <= 4 || ptab_ptr(c, 4 * eA)) && (n <= 16 || ptab_ptr(c, 16 * eA))) {
+            po->ptr = cur; po->np = n; po->kind = PARTS_ITEM; po->eA = eA;
+            return AESGCM_OK;
+        }
         FoldParams f;
         plan_fold(f, cur, which ? c->fold_b : c->fold_a, n, period, eA, eB);
         f.tabA = ptab_ptr(c, f.eA); f.tabB = ptab_ptr(c, f.eB); f.tabC = ptab_ptr(c, f.eC);
@@ -1099,6 +1104,15 @@ static int crypt_dev(aesgcm_ctx *c, int dec, const uint8_t iv[12], const void *d
     HIPCHK(hipSetDevice(c->device));
     BodySplit b;
     if (plan_body_split(len, 0, c->tw_override, c->body_min, &b)) {
+        if (!aad_len && !b.head_blocks && len == 16 * b.body_blocks) {
+            // the whole message is one aligned body (the benchmark's shape): no chaining value to carry, k_body's items go
+            // straight to the tag
+            Partials pb;
+            if ((rc = enqueue_body(c, dec ? MODE_DEC : MODE_ENC, iv, b, d_in, d_out, 0, st, &pb))) return rc;
+            CombineParams q = combine_with_items(plan_combine_tag(pb.ptr, pb.np, pb.kind, iv, 0, len, c->d_tag), pb.eA);
+            q.ej0 = pb.ej0;
+            return enqueue_combine(c, q, st);
+        }
         // large message: head / k_body / tail folded into a device-side chaining value, then the tag from it
         uint4 *state = c->d_tag + 2;
         HIPCHK(hipMemsetAsync(state, 0, 16, st));

@@ -141,6 +141,10 @@ struct Emu {
         static unsigned char smem[FOLD_LDS_BYTES] __attribute__((aligned(16)));
         const uint4 *cur = items; int which = 0;
         while (n > 1) {
+            {   // mirrors enqueue_fold(): the last level(s) belong to k_combine when the spacing has tables
+                auto has = [&](u64 e) { return ptab_index(e) >= 0; };
+                if (period <= 1 && n <= COMBINE_MAX_ITEMS && has(eA) && (n <= 4 || has(4 * eA)) && (n <= 16 || has(16 * eA))) { Parts q = {cur, n, PARTS_ITEM, eA}; return q; }
+            }
             std::vector<uint4> &ob = which ? fold_b : fold_a;
             const u32 G = fold_wgs(n);
             if (ob.size() < (size_t)G * 64) ob.resize((size_t)G * 64);
@@ -215,6 +219,14 @@ struct Emu {
     // mirrors crypt_dev() for a message that takes the split; returns whether the split applied
     bool crypt_split(int dec, const uint8_t iv[12], const uint8_t *aad, u64 aad_len, const uint8_t *in, u64 len, uint8_t *out, uint8_t tag[16], u64 body_min) {
         uint4 Y = make_uint4(0, 0, 0, 0), t;
+        BodySplit b0;
+        if (plan_body_split(len, 0, tw, body_min, &b0) && !aad_len && !b0.head_blocks && len == 16 * b0.body_blocks) {
+            // the whole message is one aligned body: k_body's items go straight to the tag (no chaining value)
+            Parts pb = run_body(dec ? MODE_DEC : MODE_ENC, iv, b0, in, out, 0);
+            emu_combine(&km, combine_with_items(plan_combine_tag(pb.ptr, pb.np, pb.gathered, iv, 0, len, &t), pb.eA));
+            memcpy(tag, &t, 16);
+            return true;
+        }
         const bool split = absorb(dec ? MODE_DEC : MODE_ENC, iv, aad, aad_len, in, len, out, 0, body_min, &Y);
         emu_combine(&km, plan_combine_final(&Y, iv, aad_len, len, &t));
         memcpy(tag, &t, 16);
@@ -610,6 +622,8 @@ int main(int argc, char **argv) {
     test_body(24, 2, 20, 16 * (254 + 2048 * 3 + 777) + 11, 102);
     test_body(32, 3, 37, 16 * 9000, 103);
     test_body(32, 1, 16, 16 * 254 + 16 * 1024 * 2, 104);          // head = 254 blocks exactly, empty tail
+    test_body(16, 2, 0, 16 * 256 * 2 * 6, 106);                     // no AAD, no head, no tail: the whole message is one body (direct tag path)
+    test_body(32, 1, 0, 16 * 256 * 300, 107);                       // ... with enough items for a k_fold level before k_combine's own fold
     test_batch_pieces();
     test_packets(16, 61); test_packets(24, 62); test_packets(32, 63);
     if (level > 1) {
