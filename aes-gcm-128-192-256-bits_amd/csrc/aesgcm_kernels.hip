@@ -811,8 +811,9 @@ struct aesgcm_ctx {
     u32 counter_base = 0;              // value the packet dispenser (d_counter[0]) holds before the next launch
     u32 mq_base[AESGCM_NQ] = {0};      // the same for the chunk queues of k_main / k_body (d_counter[16 (1 + q)])
     u32 tw_override = 0;               // AESGCM_TW
-    u64 body_min = (u64)1 << 30;       // ranges with an aligned middle of at least this many bytes go through k_body (AESGCM_BODY_MIN):
-                                       // the extra launches cost ~50 us, break-even measured near 0.7 GiB (profiles/split_threshold.py)
+    u64 body_min = (u64)128 << 20;     // ranges with an aligned middle of at least this many bytes go through k_body (AESGCM_BODY_MIN): with the
+                                       // four-table k_body and the direct tag path the cut pays from 128 MiB (profiles/r02d/split_threshold.txt:
+                                       // 64 MiB -22 %, 128 MiB +8.6 %, 512 MiB +6 %, 1 GiB +8.4 %, 2 GiB +9.1 %); round 1's break-even was 0.7 GiB
     uint4 *h_tag = nullptr;            // 64 bytes of pinned, device-mapped host memory: k_combine leaves the tag here too, so fetching it
     uint4 *h_tag_dev = nullptr;        //   is a host read -- no copy kernel, no interrupt-driven stream wait (its device address)
     u64 tag_gen = 0;                   // generation number of the last result sent to the host slot (the kernel publishes it behind the tag)
