@@ -8,8 +8,8 @@ system libcrypto `EVP_aes_256_gcm` through ctypes (oracle/libcrypto_ref.py), whi
 section 2 prescribes when the wheel is absent.  What is timed: the cfg3 plaintext stream (SplitMix64 seed 0xAE5C0003)
 in 64 MiB chunks, (i) one core, one stream and (ii) all usable cores as worker PROCESSES, each encrypting its own
 slice of the stream under its own IV; wall clock around the encrypt calls only (plaintext generated beforehand),
-best and median of >= 3 repetitions.  A bounded sample (default <= 512 MiB per worker), so the whole thing takes
-seconds; AES-GCM timing is data independent.
+best and median of >= 3 repetitions.  A bounded sample (default <= 512 MiB resident per worker, passed over 8 times:
+about 20-30 core-seconds in all); AES-GCM timing is data independent.
 
 Must be called BEFORE the process initialises the GPU: the workers are forked.
 """
@@ -64,7 +64,7 @@ def probe_library():
     return None, None
 
 
-def _worker(idx, key, iv, n_chunks, use_pycryptodome, reps, start, done, out_q):
+def _worker(idx, key, iv, n_chunks, passes, use_pycryptodome, reps, start, done, out_q):
     import numpy as np
     from oracle import oracle as O
     from oracle import libcrypto_ref as R
@@ -78,23 +78,25 @@ def _worker(idx, key, iv, n_chunks, use_pycryptodome, reps, start, done, out_q):
         if use_pycryptodome:
             from Crypto.Cipher import AES
             m = AES.new(key, AES.MODE_GCM, nonce=my_iv)
-            for p in pts:
-                m.encrypt(p.tobytes())
+            for _ in range(passes):
+                for p in pts:
+                    m.encrypt(p.tobytes())
             m.digest()
         else:
             s = R.Stream(key, my_iv)
-            for p in pts:
-                s.update(p, ct)
+            for _ in range(passes):                 # one GCM stream: `passes` times over the resident chunks
+                for p in pts:
+                    s.update(p, ct)
             s.final()
         dt = time.perf_counter() - t0
         done.wait()
         out_q.put((idx, dt))
 
 
-def _run(n_workers, n_chunks, key, iv, use_pycryptodome, reps):
+def _run(n_workers, n_chunks, passes, key, iv, use_pycryptodome, reps):
     ctx = mp.get_context("fork")
     start, done, q = ctx.Barrier(n_workers + 1), ctx.Barrier(n_workers + 1), ctx.Queue()
-    ps = [ctx.Process(target=_worker, args=(i, key, iv, n_chunks, use_pycryptodome, reps, start, done, q), daemon=True) for i in range(n_workers)]
+    ps = [ctx.Process(target=_worker, args=(i, key, iv, n_chunks, passes, use_pycryptodome, reps, start, done, q), daemon=True) for i in range(n_workers)]
     for p in ps:
         p.start()
     rates = []
@@ -105,13 +107,13 @@ def _run(n_workers, n_chunks, key, iv, use_pycryptodome, reps):
         wall = time.perf_counter() - t0
         for _ in range(n_workers):
             q.get(timeout=60)
-        rates.append(n_workers * n_chunks * CHUNK / wall)
+        rates.append(n_workers * n_chunks * passes * CHUNK / wall)
     for p in ps:
         p.join(timeout=30)
     return rates
 
 
-def measure(reps=3, max_bytes_per_worker=512 << 20, max_total=12 * GiB, with_port=True):
+def measure(reps=3, max_bytes_per_worker=512 << 20, max_total=12 * GiB, passes=8, with_port=True):
     """-> the `cpu_baseline` object of the bench line."""
     from oracle import oracle as O
     name, kind = probe_library()
@@ -123,16 +125,16 @@ def measure(reps=3, max_bytes_per_worker=512 << 20, max_total=12 * GiB, with_por
     iv = bytes(O.fill_splitmix64(12, IV_SEED))
     pyc = kind == "reference"
     n_chunks = max(1, min(max_bytes_per_worker, max_total // cores) // CHUNK)
-    r1 = _run(1, n_chunks, key, iv, pyc, reps)
-    rn = _run(cores, n_chunks, key, iv, pyc, reps)
+    r1 = _run(1, n_chunks, passes, key, iv, pyc, reps)
+    rn = _run(cores, n_chunks, passes, key, iv, pyc, reps)
     out = {
         "value": round(max(rn) / GiB, 3), "unit": "GiB/s", "cores": cores, "kind": kind, "lib": name,
         "value_median": round(statistics.median(rn) / GiB, 3),
         "value_1core": round(max(r1) / GiB, 3), "value_1core_median": round(statistics.median(r1) / GiB, 3),
         "cpu_model": model, "cpu_flags": flags, "reps": reps,
-        "sample": "AES-256-GCM, cfg3 plaintext stream (SplitMix64 seed 0xAE5C0003) in 64 MiB chunks: %d worker process(es) x %d MiB, "
-                  "each slice its own message under its own IV; wall clock around the encrypt calls, best of %d (median beside it)"
-                  % (cores, n_chunks * CHUNK >> 20, reps),
+        "sample": "AES-256-GCM, cfg3 plaintext stream (SplitMix64 seed 0xAE5C0003) in 64 MiB chunks: %d worker process(es) x %d MiB resident, "
+                  "encrypted %d times over as one message per worker under its own IV (%.1f GiB per repetition in all); wall clock around "
+                  "the encrypt calls, best of %d (median beside it)" % (cores, n_chunks * CHUNK >> 20, passes, cores * n_chunks * passes * CHUNK / GiB, reps),
     }
     if with_port:
         try:
