@@ -99,15 +99,28 @@ def make_exchange(rank, world, device, prefer="rccl"):
     builder had no multi-GPU box: the first multi-rank RCCL run of this code is the driver's scaling run."""
     if prefer != "rccl":
         return FileExchange(rank, world, device)
-    ex, err = None, ""
-    try:
-        ex = RcclExchange(rank, world, device)
-    except Exception as e:                      # noqa: BLE001 -- any failure means "no RCCL on this rank"
-        err = repr(e)
     d = rendezvous_dir()
     os.makedirs(d, exist_ok=True)
-    _write_atomic(os.path.join(d, "rccl_ok_%d" % rank), b"\x01" if ex is not None else b"\x00")
-    oks = [_wait_read(os.path.join(d, "rccl_ok_%d" % r), 1, 300.0) == b"\x01" for r in range(world)]
+
+    def agree(name, ok):
+        """every rank publishes ok/not ok under `name`; -> the list of all ranks' answers"""
+        _write_atomic(os.path.join(d, "%s_%d" % (name, rank)), b"\x01" if ok else b"\x00")
+        return [_wait_read(os.path.join(d, "%s_%d" % (name, r)), 1, 900.0) == b"\x01" for r in range(world)]
+
+    # pre-flight: can every rank load RCCL at all?  (a rank that cannot must not leave the others blocked inside ncclCommInitRank)
+    ex, err = None, ""
+    try:
+        lib.comm_unique_id()
+        pre = True
+    except Exception as e:                      # noqa: BLE001
+        pre, err = False, repr(e)
+    oks = agree("rccl_pre", pre)
+    if all(oks):
+        try:
+            ex = RcclExchange(rank, world, device)
+        except Exception as e:                  # noqa: BLE001 -- any failure means "no RCCL on this rank"
+            err = repr(e)
+        oks = agree("rccl_ok", ex is not None)
     if all(oks):
         return ex
     if ex is not None:
