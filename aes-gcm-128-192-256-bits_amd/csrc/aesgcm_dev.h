@@ -35,7 +35,10 @@ typedef uint64_t u64;
 #define AESGCM_PKT_WG AESGCM_WG           /* lanes per k_pkt / k_pktl workgroup */
 #endif
 #define AESGCM_NPW (AESGCM_WG + 1)       /* entries per power table: exponent digits 0..WG */
-#define AESGCM_LDS_GH 8192     /* bytes: 32 nibble positions x 16 entries x 16 B */
+#define AESGCM_Q5_GROUPS 26     /* five-bit groups of a 128-bit value (the last has three bits) */
+#define AESGCM_Q5_HI_ROW (AESGCM_Q5_GROUPS + 1)
+#define AESGCM_Q5_ENTRIES (AESGCM_Q5_GROUPS * 32)
+#define AESGCM_LDS_GH ((AESGCM_Q5_HI_ROW + AESGCM_Q5_GROUPS) * 256)   /* bytes: 13568 = 53 LDS rows: the five-bit GHASH tables of the launch constant (ghash_mul_const_lds) */
 #define AESGCM_LDS_AES 65536   /* bytes: 256 entries x (32 replicas of T0 | 32 replicas of T2) */
 #define AESGCM_LDS_BYTES (AESGCM_LDS_AES + AESGCM_LDS_GH)
 
@@ -219,14 +222,15 @@ HD uint4 quint_elem_mo(int p, u32 v) {
 // ------------------------------------------------------------------------------------------------
 // LDS access.  The kernels' dynamic LDS segment starts at LDS address 0 (k_main has no static LDS), so
 // table addresses are plain integers: this lets the compiler put the table base into the 16-bit
-// `offset:` field of ds_read_* instead of spending a v_add per lookup.  Layout of the 72 KiB segment:
-//   [0, 8 KiB)        32 GHASH nibble tables of the launch constant K, 256 B (one LDS bank row) each
-//   [8 KiB, 72 KiB)   AES: entry for byte value x at 8192 + x*256 + sel*128 + (lane&31)*4
+// `offset:` field of ds_read_* instead of spending a v_add per lookup.  Layout of the 77.25 KiB segment:
+//   [0, 13568)        the 26 five-bit GHASH tables of the launch constant K in 8-byte halves, one 256 B LDS bank row
+//                     per table half (ghash_mul_const_lds)
+//   [13568, +64 KiB)  AES: entry for byte value x at 13568 + x*256 + sel*128 + (lane&31)*4
 //                     (sel 0 = T0, sel 1 = T2 = rotl16(T0)), 32 replicas so lane l always reads bank l&31
 // On the host (tests/host_emul) `lds` is an ordinary array with the same layout.
 // ------------------------------------------------------------------------------------------------
 #define AESGCM_LDS_GH_OFF 0u
-#define AESGCM_LDS_AES_OFF 8192u
+#define AESGCM_LDS_AES_OFF ((u32)AESGCM_LDS_GH)       /* 13568: a multiple of 128, so lane l still reads bank l&31 */
 typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
 typedef u32 u32x2_t __attribute__((ext_vector_type(2)));
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -234,13 +238,11 @@ typedef u32 u32x2_t __attribute__((ext_vector_type(2)));
 #define LDS_LD64(lds, off) (*(const __attribute__((address_space(3))) u32x2_t *)(uintptr_t)(off))
 #define LDS_LD128(lds, off) (*(const __attribute__((address_space(3))) u32x4_t *)(uintptr_t)(off))
 HD u32 xor3(u32 a, u32 b, u32 c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
-HD u32 and_or(u32 a, u32 b, u32 c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xEA); }      // (a & b) | c as one full-rate boolean op
 #else
 #define LDS_LD32(lds, off) (*(const u32 *)((lds) + (off)))
 #define LDS_LD64(lds, off) (*(const u32x2_t *)((lds) + (off)))
 #define LDS_LD128(lds, off) (*(const u32x4_t *)((lds) + (off)))
 HD u32 xor3(u32 a, u32 b, u32 c) { return a ^ b ^ c; }
-HD u32 and_or(u32 a, u32 b, u32 c) { return (a & b) | c; }
 #endif
 
 // Z * x^8: shift right by one byte; the byte b that falls out (bit k of b = GCM bit 127 - k) comes back as
@@ -304,9 +306,6 @@ HD void aes_final_lds(u32 &s0, u32 &s1, u32 &s2, u32 &s3, const u32 *__restrict_
 #define T1_AT(lds, s, k, lb2) LDS_LD32(lds, perm_b32(s, lb2, SEL_B2(k)) + AESGCM_LDS_AES_OFF)
 #define T3_AT(lds, s, k, lb2) LDS_LD32(lds, perm_b32(s, lb2, SEL_B2(k)) + (AESGCM_LDS_AES_OFF + 128u))
 #define AESGCM_LDS_BYTES_T4 (AESGCM_LDS_BYTES + AESGCM_LDS_AES)
-#ifndef AESGCM_GH5
-#define AESGCM_GH5 AESGCM_T4             /* k_body's GHASH multiply through five-bit tables and ds_read_b64 (ghash_mul_const_lds5); needs the T4 layout */
-#endif
 HD void aes_round_lds4(u32 &s0, u32 &s1, u32 &s2, u32 &s3, const u32 *__restrict__ rkr, const unsigned char *lds, u32 lb, u32 lb2) {
     const u32 a0 = T0_AT(lds, s0, 0, lb), a1 = T1_AT(lds, s1, 1, lb2), a2 = T2_AT(lds, s2, 2, lb), a3 = T3_AT(lds, s3, 3, lb2);
     const u32 b0 = T0_AT(lds, s1, 0, lb), b1 = T1_AT(lds, s2, 1, lb2), b2 = T2_AT(lds, s3, 2, lb), b3 = T3_AT(lds, s0, 3, lb2);
@@ -353,12 +352,52 @@ HD void ctr_rounds_lds(u32 ctr_be_word, const CtrConsts &k, u32 &s0, u32 &s1, u3
 
 // ------------------------------------------------------------------------------------------------
 // Hot loop piece 2: multiply the lane's GHASH accumulator by the launch constant K = H^(lane stride)
-// through 32 nibble tables in LDS: Y*K = xor_p T_p[nibble_p(Y)] (multiplication by a constant is
-// GF(2)-linear -- the generalisation of the RTL's 2-way split, src/gcm_ghash.vhd:317-333).
-// Table p is one 256-byte LDS bank row (16 entries x 16 B), so within a ds_read_b128 lane group two
-// lanes either read the same address (broadcast) or different 16-byte slots: conflict-free by
-// construction.
+// through tables in LDS: Y*K = xor_p T_p[group_p(Y)] (multiplication by a constant is GF(2)-linear -- the
+// generalisation of the RTL's 2-way split, src/gcm_ghash.vhd:317-333).
+//
+// ghash_mul_const_lds (the row loops of k_main, k_body, k_pkt, k_pktl): 26 FIVE-bit tables read with ds_read_b64.
+// The LDS array serves a wave64 ds_read_b64 in 2 cycles (32 lanes x 8 B = all 64 banks) and a ds_read_b128 in 4
+// (MI355X_MICROARCH LDS table), so a table position costs 2 x 2 cycles for 5 bits against 4 cycles for 4 bits with
+// 16-byte nibble-table entries: 104 array cycles per multiply instead of 128, in kernels whose binding unit is that
+// array (round 2, profiles/r02f/gh5_ab.txt: 886 -> 919 GiB/s on one box).  A five-bit table of 8-byte half entries is
+// 32 x 8 B = one 256-byte bank row: two lanes of a 32-lane group read either the same address (broadcast) or different
+// banks -- conflict-free by construction.  Groups are cut from the four memory-order dwords taken as one 128-bit integer
+// (quint_elem_mo; any partition of the coordinates serves a linear map); three groups straddle a dword boundary (one
+// v_alignbit each).  Layout from AESGCM_LDS_GH_OFF: row p = low halves (.x .y) of table p, row 27 + p = high halves
+// (.z .w); row 26 stays empty so that the two halves are 6912 bytes apart, NOT a multiple of 512: otherwise the compiler
+// fuses the pair into one ds_read2st64_b64, which the LDS serves as 2 x (4 x 16 lanes) = 8 cycles instead of 2 + 2.
 // ------------------------------------------------------------------------------------------------
+HD uint4 ghash_mul_const_lds(uint4 y, const unsigned char *lds) {
+    const u32 w[4] = {y.x, y.y, y.z, y.w};
+    u32 r[4] = {0, 0, 0, 0}, t[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int p = 0; p < AESGCM_Q5_GROUPS; p++) {
+        const int bit = 5 * p, wi = bit >> 5, sh = bit & 31;
+        u32 x;                                                            // the group's value at bits 3..7
+        if (sh > 27 && wi < 3) x = (u32)((((u64)w[wi + 1] << 32) | w[wi]) >> (sh - 3));
+        else x = sh >= 3 ? w[wi] >> (sh - 3) : w[wi] << (3 - sh);
+        const u32 a = x & 0xF8u;
+        const u32x2_t l = LDS_LD64(lds, a + (AESGCM_LDS_GH_OFF + (u32)p * 256u));
+        const u32x2_t h = LDS_LD64(lds, a + (AESGCM_LDS_GH_OFF + (u32)(AESGCM_Q5_HI_ROW + p) * 256u));
+        if (p & 1) { r[0] = xor3(r[0], t[0], l.x); r[1] = xor3(r[1], t[1], l.y); r[2] = xor3(r[2], t[2], h.x); r[3] = xor3(r[3], t[3], h.y); }
+        else { t[0] = l.x; t[1] = l.y; t[2] = h.x; t[3] = h.y; }
+    }
+    return make_uint4(r[0], r[1], r[2], r[3]);
+}
+// what thread `tid` of `nthreads` writes of the LDS image of a five-bit table set `src` (AESGCM_Q5_ENTRIES entries, p*32 + v)
+HD void fill_lds_q5(unsigned char *smem, const uint4 *src, u32 tid, u32 nthreads) {
+    for (u32 q = tid; q < AESGCM_Q5_ENTRIES; q += nthreads) {
+        const uint4 e = src[q];
+        const u32 p = q >> 5, v = q & 31u;
+        u32 *lo = reinterpret_cast<u32 *>(smem + AESGCM_LDS_GH_OFF + p * 256u + v * 8u);
+        u32 *hi = reinterpret_cast<u32 *>(smem + AESGCM_LDS_GH_OFF + (AESGCM_Q5_HI_ROW + p) * 256u + v * 8u);
+        lo[0] = e.x; lo[1] = e.y; hi[0] = e.z; hi[1] = e.w;
+    }
+}
+
+// The nibble-table form (k_fold, k_combine: constants that change per launch, tables of 512 x 16 B at any LDS offset):
+// table p is one 256-byte LDS bank row (16 entries x 16 B), so within a ds_read_b128 lane group two lanes either read the
+// same address (broadcast) or different 16-byte slots: conflict-free by construction.
 HD uint4 ghash_mul_const_lds_at(uint4 y, const unsigned char *lds, u32 base) {
     u32x4_t r = {0, 0, 0, 0};
     const u32 w[4] = {y.x, y.y, y.z, y.w};
@@ -375,41 +414,6 @@ HD uint4 ghash_mul_const_lds_at(uint4 y, const unsigned char *lds, u32 base) {
         }
     }
     return make_uint4(r.x, r.y, r.z, r.w);
-}
-HD uint4 ghash_mul_const_lds(uint4 y, const unsigned char *lds) { return ghash_mul_const_lds_at(y, lds, AESGCM_LDS_GH_OFF); }
-
-// The same product through 26 FIVE-bit tables read with ds_read_b64 (k_body with AESGCM_GH5).  The LDS array serves a
-// wave64 ds_read_b64 in 2 cycles (32 lanes x 8 B = all 64 banks) and a ds_read_b128 in 4 (MI355X_MICROARCH LDS table), so
-// a table position costs 2 x 2 cycles for 5 bits here against 4 cycles for 4 bits above: 104 array cycles per multiply
-// instead of 128, in a kernel whose binding unit is that array.  A 5-bit table of 8-byte half entries is 32 x 8 B = one
-// 256-byte bank row: two lanes of a 32-lane group read either the same address or different banks -- conflict-free by
-// construction, like the nibble tables.  Groups are cut from the four memory-order dwords taken as one 128-bit integer
-// (quint_elem_mo); three groups straddle a dword boundary (one v_alignbit each).  Layout from AESGCM_LDS_Q5_OFF: row p =
-// low halves (.x .y) of table p, row 27 + p = high halves (.z .w); row 26 stays empty so that the two halves are 6912 bytes
-// apart, NOT a multiple of 512: otherwise the compiler fuses the pair into one ds_read2st64_b64, which the LDS serves as
-// 2 x (4 x 16 lanes) = 8 cycles instead of 2 + 2.  The region lies above 64 KiB (beyond the T-tables), so bit 17 of the
-// address is OR-ed into the index by the same boolean op that masks it.
-#define AESGCM_Q5_GROUPS 26
-#define AESGCM_Q5_HI_ROW (AESGCM_Q5_GROUPS + 1)
-#define AESGCM_LDS_Q5 ((AESGCM_Q5_HI_ROW + AESGCM_Q5_GROUPS) * 256u)       /* 13568 bytes */
-#define AESGCM_LDS_Q5_OFF (AESGCM_LDS_AES_OFF + 2u * AESGCM_LDS_AES)       /* above T0|T2 and T1|T3: 139264 = 0x22000 */
-HD uint4 ghash_mul_const_lds5(uint4 y, const unsigned char *lds) {
-    const u32 w[4] = {y.x, y.y, y.z, y.w};
-    const u32 hi = AESGCM_LDS_Q5_OFF & ~0xFFFFu, lo = AESGCM_LDS_Q5_OFF & 0xFFFFu;       // VGPR part, offset-field part
-    u32 r[4] = {0, 0, 0, 0}, t[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int p = 0; p < AESGCM_Q5_GROUPS; p++) {
-        const int bit = 5 * p, wi = bit >> 5, sh = bit & 31;
-        u32 x;                                                            // the group's value at bits 3..7
-        if (sh > 27 && wi < 3) x = (u32)((((u64)w[wi + 1] << 32) | w[wi]) >> (sh - 3));
-        else x = sh >= 3 ? w[wi] >> (sh - 3) : w[wi] << (3 - sh);
-        const u32 a = and_or(x, 0xF8u, hi);
-        const u32x2_t l = LDS_LD64(lds, a + (lo + (u32)p * 256u));
-        const u32x2_t h = LDS_LD64(lds, a + (lo + (u32)(AESGCM_Q5_HI_ROW + p) * 256u));
-        if (p & 1) { r[0] = xor3(r[0], t[0], l.x); r[1] = xor3(r[1], t[1], l.y); r[2] = xor3(r[2], t[2], h.x); r[3] = xor3(r[3], t[3], h.y); }
-        else { t[0] = l.x; t[1] = l.y; t[2] = h.x; t[3] = h.y; }
-    }
-    return make_uint4(r[0], r[1], r[2], r[3]);
 }
 
 // ================================================================================================
@@ -431,10 +435,9 @@ struct KeyMaterial {         // per context (device memory)
     u32 _pad[3];
     uint4 h;                 // H = E_K(0^128)
     uint4 pw[4][AESGCM_NPW]; // pw[d][k] = H^(k * WG^d)
-    uint4 ktab[512];         // nibble tables of K = H^64 (lane stride of a wave): entry p*16+v
-    uint4 htab[512];         // nibble tables of H itself (k_pktl: one lane per packet, serial Horner)
-    uint4 k4tab[512];        // nibble tables of H^256 (k_body: a wave takes every fourth row)
-    uint4 k5tab[AESGCM_Q5_GROUPS * 32]; // five-bit tables of H^256 (k_body's row loop with AESGCM_GH5): entry p*32+v = quint_elem_mo(p, v) * H^256
+    uint4 ktab[AESGCM_Q5_ENTRIES];   // five-bit tables of K = H^64 (lane stride of a wave): entry p*32+v = quint_elem_mo(p, v) * K
+    uint4 htab[AESGCM_Q5_ENTRIES];   // ... of H itself (k_pktl: one lane per packet, serial Horner)
+    uint4 k4tab[AESGCM_Q5_ENTRIES];  // ... of H^256 (k_body: a wave takes every fourth row)
     uint4 ptab[AESGCM_NPTAB][512]; // nibble tables of H^(2^k), k = 6 .. 31: the Horner constants of k_fold when chunk sizes are powers of two
     uint4 ltab[AESGCM_NLTAB][32];  // two-table Shoup form of H^e, e = 0 .. 65: [e][v] = v*H^e, [e][16 + v] = v*H^e*x^4 (per-lane constant multiplies of the closing steps)
     uint8_t rk_bytes[240];   // expanded key as the byte string tb/key_exp.py produces
@@ -560,14 +563,14 @@ HD bool setup_level(const uint4 *tab, int j, int tid, uint4 *prod) {
     *prod = gf_mul_mo(tab[tid], tab[base]);
     return true;
 }
-// after the beta table (d == 1) is complete: the nibble tables of the fixed Horner constants H^64, H, H^256
+// after the beta table (d == 1) is complete: the five-bit tables of the fixed Horner constants H^64, H, H^256
 HD void setup_beta_lane(KeyMaterial *km, const uint4 *tab, int tid) {
     (void)tab;
-    if (tid < 512) km->ktab[tid] = gf_mul_mo(nibble_elem_mo(tid >> 4, (u32)(tid & 15)), km->pw[0][64]);
-    if (tid < 512) km->htab[tid] = gf_mul_mo(nibble_elem_mo(tid >> 4, (u32)(tid & 15)), km->h);
-    if (tid < 512) km->k4tab[tid] = gf_mul_mo(nibble_elem_mo(tid >> 4, (u32)(tid & 15)), km->pw[0][256]);
-    for (int q = tid - 512; q >= 0 && q < AESGCM_Q5_GROUPS * 32; q += 512)       // the upper half of the workgroup (idle above): at most two entries each
-        km->k5tab[q] = gf_mul_mo(quint_elem_mo(q >> 5, (u32)(q & 31)), km->pw[0][256]);
+    for (int q = tid; q < 3 * AESGCM_Q5_ENTRIES; q += AESGCM_WG) {              // 2496 entries over the workgroup: at most three each
+        const int which = q / AESGCM_Q5_ENTRIES, e = q % AESGCM_Q5_ENTRIES;
+        const uint4 c = which == 0 ? km->pw[0][64] : which == 1 ? km->h : km->pw[0][256];
+        (which == 0 ? km->ktab : which == 1 ? km->htab : km->k4tab)[e] = gf_mul_mo(quint_elem_mo(e >> 5, (u32)(e & 31)), c);
+    }
 }
 
 // after all four power tables exist: ptab[k] = nibble tables of H^(2^(k+6)); H^(2^j) = pw[j / LOG_WG][2^(j % LOG_WG)]
@@ -578,11 +581,10 @@ HD void setup_ptab_lane(KeyMaterial *km, u32 k, u32 tid) {
 
 // ---- k_main pieces -----------------------------------------------------------------------------
 // LDS image of one workgroup: what thread `tid` of AESGCM_MAIN_WG writes
-enum { GH_TAB_K64 = 0, GH_TAB_H = 1, GH_TAB_K256 = 2 };       // which constant's nibble tables go to LDS
+enum { GH_TAB_K64 = 0, GH_TAB_H = 1, GH_TAB_K256 = 2 };       // which constant's five-bit tables go to LDS
 HD void main_fill_lds(unsigned char *smem, const KeyMaterial *km, const DevTables *tb, u32 tid, bool gh, u32 nthreads = AESGCM_MAIN_WG, int which = GH_TAB_K64) {
     if (gh) {
-        const uint4 *src = which == GH_TAB_H ? km->htab : which == GH_TAB_K256 ? km->k4tab : km->ktab;
-        for (u32 q = tid; q < 512; q += nthreads) reinterpret_cast<uint4 *>(smem + AESGCM_LDS_GH_OFF)[q] = src[q];
+        fill_lds_q5(smem, which == GH_TAB_H ? km->htab : which == GH_TAB_K256 ? km->k4tab : km->ktab, tid, nthreads);
     }
     uint4 *dst = reinterpret_cast<uint4 *>(smem + AESGCM_LDS_AES_OFF);
     for (u32 q = tid; q < AESGCM_LDS_AES / 16; q += nthreads) {
@@ -599,16 +601,6 @@ HD void fill_lds_t4(unsigned char *smem, const DevTables *tb, u32 tid, u32 nthre
         const u32 t0 = tb->te0[q >> 4];
         const u32 v = ((q >> 3) & 1) ? rotl32(t0, 24) : rotl32(t0, 8);
         dst[q] = make_uint4(v, v, v, v);
-    }
-}
-// the five-bit tables of H^256 above the T-tables (ghash_mul_const_lds5): halves of entry q = p*32 + v
-HD void fill_lds_q5(unsigned char *smem, const KeyMaterial *km, u32 tid, u32 nthreads) {
-    for (u32 q = tid; q < AESGCM_Q5_GROUPS * 32u; q += nthreads) {
-        const uint4 e = km->k5tab[q];
-        const u32 p = q >> 5, v = q & 31u;
-        u32 *lo = reinterpret_cast<u32 *>(smem + AESGCM_LDS_Q5_OFF + p * 256u + v * 8u);
-        u32 *hi = reinterpret_cast<u32 *>(smem + AESGCM_LDS_Q5_OFF + (AESGCM_Q5_HI_ROW + p) * 256u + v * 8u);
-        lo[0] = e.x; lo[1] = e.y; hi[0] = e.z; hi[1] = e.w;
     }
 }
 // block loads/stores with the ragged last block handled bytewise (gcm_ghash.vhd:225-246 byte-valid
@@ -919,11 +911,7 @@ HD uint4 body_chunk_lane(const KeyMaterial *__restrict__ km, const DevTables *__
     uint4 acc = make_uint4(0, 0, 0, 0);
     for (u32 i = 0; i < p.T; ++i) {
         const u32 q = s * p.T + i;                                     // super-row: counters [256 q, 256 q + 255] of the body
-#if AESGCM_GH5
-        if (i) acc = ghash_mul_const_lds5(acc, smem);
-#else
         if (i) acc = ghash_mul_const_lds(acc, smem);
-#endif
         const u64 off = ((u64)q * 4 + v) * 1024;                       // byte offset of the row in the body
         const unsigned char *src = reinterpret_cast<const unsigned char *>(uniform64((u64)(uintptr_t)p.in + off));
         unsigned char *dst = reinterpret_cast<unsigned char *>(uniform64((u64)(uintptr_t)p.out + off));

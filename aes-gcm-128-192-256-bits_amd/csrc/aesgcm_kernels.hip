@@ -204,11 +204,7 @@ __global__ __launch_bounds__(AESGCM_MAIN_WG, AESGCM_WAVES_PER_SIMD) void k_main(
 #if AESGCM_T4
 #define AESGCM_BODY_WG 1024                  /* one workgroup per CU (136 KiB of LDS), 4 waves per SIMD, 128 registers */
 #define AESGCM_BODY_WPS 4
-#if AESGCM_GH5
-#define AESGCM_BODY_LDS (AESGCM_LDS_BYTES_T4 + AESGCM_LDS_Q5)         /* 149 KiB: nibble tables, T0|T2, T1|T3, five-bit GHASH tables */
-#else
 #define AESGCM_BODY_LDS AESGCM_LDS_BYTES_T4
-#endif
 #else
 #define AESGCM_BODY_WG AESGCM_MAIN_WG
 #define AESGCM_BODY_WPS AESGCM_WAVES_PER_SIMD
@@ -227,9 +223,6 @@ __global__ __launch_bounds__(AESGCM_BODY_WG, AESGCM_BODY_WPS) void k_body(const 
     main_fill_lds(smem, km, tb, tid, true, AESGCM_BODY_WG, GH_TAB_K256);
 #if AESGCM_T4
     fill_lds_t4(smem, tb, tid, AESGCM_BODY_WG);
-#endif
-#if AESGCM_GH5
-    fill_lds_q5(smem, km, tid, AESGCM_BODY_WG);
 #endif
     __syncthreads();
     CtrConsts cc = ctr_round1_consts(p.iv0, p.iv1, p.iv2, km->rk, smem, (lane & 31u) << 2);   // key and IV only: wave-uniform

@@ -71,13 +71,10 @@ static void emu_main(int mode, const KeyMaterial *km, const MainParams &p) {
 }
 template <int NR, int MODE>
 static void emu_body_nr(const KeyMaterial *km, const BodyParams &p) {
-    static unsigned char smem[AESGCM_LDS_BYTES_T4 + AESGCM_LDS_Q5] __attribute__((aligned(16)));
+    static unsigned char smem[AESGCM_LDS_BYTES_T4] __attribute__((aligned(16)));
     for (u32 tid = 0; tid < AESGCM_MAIN_WG; tid++) main_fill_lds(smem, km, &g_tb, tid, true, AESGCM_MAIN_WG, GH_TAB_K256);
 #if AESGCM_T4
     for (u32 tid = 0; tid < AESGCM_MAIN_WG; tid++) fill_lds_t4(smem, &g_tb, tid, AESGCM_MAIN_WG);     // second table region (T1 | T3)
-#endif
-#if AESGCM_GH5
-    for (u32 tid = 0; tid < AESGCM_MAIN_WG; tid++) fill_lds_q5(smem, km, tid, AESGCM_MAIN_WG);        // five-bit GHASH tables above them
 #endif
     for (u32 k = 0; k < p.C; k++) {
         const u32 c = (k * 7 + 3) % p.C == k ? k : (p.C - 1) - k;      // scrambled order (any permutation will do)
@@ -458,16 +455,18 @@ static void test_key(int key_len, u32 G /* rows per chunk override, 0 = producti
         CHECK(memcmp(&E.km.pw[2][3], &g3, 16) == 0, "gamma^3");
         CHECK(memcmp(&E.km.pw[3][1], &E.km.pw[2][AESGCM_WG], 16) == 0, "delta");
     }
-    {   // the five-bit GHASH tables of H^256 (k_body's row loop): Y * H^256 through ghash_mul_const_lds5 against the bit-serial product,
-        // on random values and on every single-bit value (each of the 26 groups, the three that straddle a dword included)
-        static unsigned char smem[AESGCM_LDS_BYTES_T4 + AESGCM_LDS_Q5] __attribute__((aligned(16)));
-        for (u32 tid = 0; tid < AESGCM_MAIN_WG; tid++) fill_lds_q5(smem, &E.km, tid, AESGCM_MAIN_WG);
+    // the five-bit GHASH tables of the three fixed Horner constants: Y * c through ghash_mul_const_lds against the bit-serial
+    // product, on every single-bit value (each of the 26 groups, the three that straddle a dword included) and random ones
+    for (int which = 0; which < 3; which++) {
+        static unsigned char smem[AESGCM_LDS_BYTES] __attribute__((aligned(16)));
+        for (u32 tid = 0; tid < AESGCM_MAIN_WG; tid++) main_fill_lds(smem, &E.km, &g_tb, tid, true, AESGCM_MAIN_WG, which);
+        const uint4 c = which == GH_TAB_K64 ? E.km.pw[0][64] : which == GH_TAB_H ? E.km.h : E.km.pw[0][256];
         for (int i = 0; i < 128 + 64; i++) {
             uint4 y;
             if (i < 128) { u32 w[4] = {0, 0, 0, 0}; w[i >> 5] = 1u << (i & 31); y = make_uint4(w[0], w[1], w[2], w[3]); }
             else { auto r = rnd(16, seed * 131 + i); memcpy(&y, r.data(), 16); }
-            const uint4 a = ghash_mul_const_lds5(y, smem), b = gf_mul_mo(y, E.km.pw[0][256]);
-            CHECK(memcmp(&a, &b, 16) == 0, "ghash_mul_const_lds5 case %d", i);
+            const uint4 a = ghash_mul_const_lds(y, smem), b = gf_mul_mo(y, c);
+            CHECK(memcmp(&a, &b, 16) == 0, "ghash_mul_const_lds table %d case %d", which, i);
         }
     }
     // ECB through the LDS round code
