@@ -738,10 +738,13 @@ HD CtrConsts main_lane_consts(const KeyMaterial *__restrict__ km, const MainPara
 // nothing is multiplied per chunk any more (a per-lane bit-serial multiply per chunk used to cost ~2.4 rows).
 // The polynomial of the range is  sum_L H^(63-L) * B_L,  B_L = sum_i item_i[L] * H^(blocks between item i and the end),
 // and B_L is a Horner recurrence per lane with WAVE-UNIFORM constants, i.e. the cheap LDS-table multiply.
-// One k_fold launch reduces n items to ceil(n / 256): stage a, a wave folds 16 consecutive items (constant A);
-// stage b, wave 0 folds the workgroup's <= 16 results (constant C = A^16).  Groups are cut from the END, so the
-// first group / first wave is the short one and group ends stay equally spaced.  At most three launches reach
-// one item (one up to 256 chunks, two up to 65536); k_combine applies H^(63-L) to it and XOR-folds the lanes.
+// One k_fold launch reduces n items to ceil(n / (16 g)): stage a, a wave folds g consecutive items (constant A);
+// stage b, wave 0 folds the workgroup's <= 16 results (constant C = A^g).  Groups are cut from the END, so the
+// first group / first wave is the short one and group ends stay equally spaced.  g = 16 for long inputs; for up
+// to 16384 items g is the smallest power of two that leaves k_combine at most 64 items (fold_group): a workgroup's
+// multiplies all go through one CU's LDS array (16 waves x 128 array cycles each), so 256 items per workgroup cost
+// ~16 us however few workgroups there are -- with g = 1 .. 8 a mid-size message spreads over up to 64 CUs instead of 4
+// (round 2: k_fold 32 us -> see profiles/README.md).  k_combine applies H^(63-L) to the last item and XOR-folds the lanes.
 // k_body's chunks are interleaved (item 4s+v, v = row phase, 64 blocks apart; super-chunks 256 T apart):
 // period = 4 folds the four phases with A = H^64 and the super-chunks with B = H^(256 T).
 // Constants that are H^(2^k) (chunk sizes are powers of two unless AESGCM_TW says otherwise) come from the
@@ -750,11 +753,13 @@ struct FoldParams {
     const uint4 *in; uint4 *out;
     u32 n;                       // items in
     u32 period;                  // 1: plain Horner with A.  4: inner Horner with A over each 4 items, outer with B
+    u32 group;                   // items per wave (1, 2, 4, 8 or FOLD_GROUP; a multiple of the period)
     u64 eA, eB, eC;              // exponents (blocks) of the three constants; eC = blocks between stage-a outputs
     const uint4 *tabA, *tabB, *tabC;   // precomputed nibble tables or NULL
 };
-#define FOLD_GROUP 16u           /* items per wave */
-#define FOLD_WAVES 16u           /* waves per workgroup: 1024 items per workgroup */
+#define COMBINE_MAX_ITEMS 64u
+#define FOLD_GROUP 16u           /* most items per wave */
+#define FOLD_WAVES 16u           /* waves per workgroup: at most 256 items per workgroup */
 #define FOLD_WG (64u * FOLD_WAVES)
 #define FOLD_LDS_TAB 24576u      /* three 8 KiB tables */
 #define FOLD_LDS_BYTES (FOLD_LDS_TAB + FOLD_WAVES * 1024u)
@@ -765,18 +770,25 @@ HD void fold_fill_lds(unsigned char *smem, const KeyMaterial *km, const uint4 *t
     const uint4 c = be_to_mo(gf_pow_h_serial(km, e));
     for (u32 q = tid; q < 512; q += nthreads) reinterpret_cast<uint4 *>(smem + base)[q] = gf_mul_mo(nibble_elem_mo((int)(q >> 4), q & 15u), c);
 }
-HD u32 fold_wgs(u32 n) { return (n + FOLD_GROUP * FOLD_WAVES - 1) / (FOLD_GROUP * FOLD_WAVES); }
+// items per wave of a level over n items
+HD u32 fold_group(u32 n, u32 period) {
+    if (period > 1) return FOLD_GROUP;
+    u32 g = 1;
+    while (g < FOLD_GROUP && n > COMBINE_MAX_ITEMS * FOLD_WAVES * g) g <<= 1;
+    return g;
+}
+HD u32 fold_wgs(u32 n, u32 group) { return (n + group * FOLD_WAVES - 1) / (group * FOLD_WAVES); }
 // the items [*start, *end) of workgroup g, and how many waves have work
-HD u32 fold_wg_range(u32 n, u32 g, u32 *start, u32 *end) {
-    const u32 per = FOLD_GROUP * FOLD_WAVES;
-    *end = n - per * (fold_wgs(n) - 1 - g);
+HD u32 fold_wg_range(u32 n, u32 group, u32 g, u32 *start, u32 *end) {
+    const u32 per = group * FOLD_WAVES;
+    *end = n - per * (fold_wgs(n, group) - 1 - g);
     *start = *end > per ? *end - per : 0;
-    return (*end - *start + FOLD_GROUP - 1) / FOLD_GROUP;
+    return (*end - *start + group - 1) / group;
 }
 // stage a: lane `lane` of wave w (of J active waves) of the workgroup that owns items [start, end)
 HD uint4 fold_wave_lane(const FoldParams &p, const unsigned char *smem, u32 start, u32 end, u32 J, u32 w, u32 lane) {
-    const u32 e = end - FOLD_GROUP * (J - 1 - w);
-    const u32 s = e > start + FOLD_GROUP ? e - FOLD_GROUP : start;
+    const u32 e = end - p.group * (J - 1 - w);
+    const u32 s = e > start + p.group ? e - p.group : start;
     // loads in batches of 8 ahead of their multiplies (they do not depend on the accumulator; the items come from
     // HBM, ~1-2 us away)
     const u32 cnt = e - s;
@@ -817,7 +829,8 @@ static inline u64 fold_out_step(const FoldParams &p) { return FOLD_WAVES * p.eC;
 // fill the constants of a level: items eA blocks apart (period 1), or phases eA apart and periods eB apart
 static inline void plan_fold(FoldParams &p, const uint4 *in, uint4 *out, u32 n, u32 period, u64 eA, u64 eB) {
     p.in = in; p.out = out; p.n = n; p.period = period; p.eA = eA; p.eB = period > 1 ? eB : 0;
-    p.eC = period > 1 ? (FOLD_GROUP / period) * eB : FOLD_GROUP * eA;
+    p.group = fold_group(n, period);
+    p.eC = period > 1 ? (p.group / period) * eB : p.group * eA;
     p.tabA = p.tabB = p.tabC = nullptr;
 }
 // index into KeyMaterial::ptab of the table of H^e, or -1
@@ -942,7 +955,6 @@ HD uint4 body_chunk_lane(const KeyMaterial *__restrict__ km, const DevTables *__
 #define COMBINE_THREADS 1024u                /* 16 waves: GMAX gathered-partial lanes, 16 level-1 fold groups, the single-term wave */
 enum { PARTS_NONE = 0, PARTS_GATHERED = 1, PARTS_ITEM = 2 };
 #define COMBINE_FOLD_GROUP 4u                /* fan-in of every level of the in-launch fold: 64 -> 16 -> 4 -> 1, three multiplies deep each */
-#define COMBINE_MAX_ITEMS 64u
 #define CMB_LDS_TABA 0u                      /* nibble tables of H^(eA): items are eA blocks apart */
 #define CMB_LDS_TABB 8192u                   /* ... of H^(4 eA): level-1 results */
 #define CMB_LDS_TABC 16384u                  /* ... of H^(16 eA): level-2 results */

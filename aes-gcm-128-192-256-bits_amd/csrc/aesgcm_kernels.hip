@@ -258,7 +258,7 @@ __global__ __launch_bounds__(AESGCM_BODY_WG, AESGCM_BODY_WPS) void k_body(const 
     }
 }
 
-// k_fold: 256 items per workgroup (lane bodies: fold_wave_lane(), fold_wg_lane()).  No static LDS: table offsets
+// k_fold: up to 256 items per workgroup (lane bodies: fold_wave_lane(), fold_wg_lane()).  No static LDS: table offsets
 // are absolute.
 __global__ __launch_bounds__(FOLD_WG) void k_fold(const KeyMaterial *__restrict__ km, const FoldParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(FOLD_WG) void k_fold(const KeyMaterial *__restrict_
     fold_fill_lds(smem, km, p.tabC, p.eC, 16384u, tid, FOLD_WG);
     __syncthreads();
     u32 start, end;
-    const u32 J = fold_wg_range(p.n, blockIdx.x, &start, &end);
+    const u32 J = fold_wg_range(p.n, p.group, blockIdx.x, &start, &end);
     if (w < J) *reinterpret_cast<uint4 *>(smem + FOLD_LDS_TAB + w * 1024u + lane * 16u) = fold_wave_lane(p, smem, start, end, J, w, lane);
     __syncthreads();
     if (w == 0) p.out[(size_t)blockIdx.x * 64 + lane] = fold_wg_lane(smem, J, lane);
@@ -806,7 +806,7 @@ struct aesgcm_ctx {
     KeyMaterial *km = nullptr;
     uint4 *parts = nullptr;            // one item (64 lane accumulators) per chunk, grown on demand
     size_t parts_cap = 0;              // items
-    uint4 *fold_a = nullptr, *fold_b = nullptr;   // k_fold ping-pong: MAX_CHUNKS/256 items and MAX_CHUNKS/65536 items
+    uint4 *fold_a = nullptr, *fold_b = nullptr;   // k_fold ping-pong: MAX_CHUNKS/256 items; the second level leaves at most max(MAX_CHUNKS/65536, COMBINE_MAX_ITEMS) (fold_group)
     u32 *d_counter = nullptr;          // chunk dispenser
     u32 counter_base = 0;              // value the packet dispenser (d_counter[0]) holds before the next launch
     u32 mq_base[AESGCM_NQ] = {0};      // the same for the chunk queues of k_main / k_body (d_counter[16 (1 + q)])
@@ -914,6 +914,10 @@ static const uint4 *ptab_ptr(const aesgcm_ctx *c, u64 e) {
     const int k = ptab_index(e);
     return k < 0 ? nullptr : reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(c->km) + offsetof(KeyMaterial, ptab)) + (size_t)k * 512;
 }
+// capacity of the ping-pong buffers in items: a first level leaves at most MAX_CHUNKS/256, a second at most
+// max(MAX_CHUNKS/65536, COMBINE_MAX_ITEMS) (fold_group stops where k_combine can take over)
+#define FOLD_A_ITEMS (AESGCM_MAX_CHUNKS / (FOLD_GROUP * FOLD_WAVES))
+#define FOLD_B_ITEMS (AESGCM_MAX_CHUNKS / 65536u + COMBINE_MAX_ITEMS)
 // k_fold levels: n items (period, eA, eB as in FoldParams) -> one item (left in parts, fold_a or fold_b)
 static int enqueue_fold(aesgcm_ctx *c, const uint4 *items, u32 n, u32 period, u64 eA, u64 eB, hipStream_t st, Partials *po) {
     const uint4 *cur = items;
@@ -927,7 +931,8 @@ static int enqueue_fold(aesgcm_ctx *c, const uint4 *items, u32 n, u32 period, u6
         FoldParams f;
         plan_fold(f, cur, which ? c->fold_b : c->fold_a, n, period, eA, eB);
         f.tabA = ptab_ptr(c, f.eA); f.tabB = ptab_ptr(c, f.eB); f.tabC = ptab_ptr(c, f.eC);
-        const u32 G = fold_wgs(n);
+        const u32 G = fold_wgs(n, f.group);
+        if (G > (which ? FOLD_B_ITEMS : FOLD_A_ITEMS)) { snprintf(g_err, sizeof g_err, "k_fold: %u output items do not fit the level's buffer", G); return AESGCM_EHIP; }
         hipLaunchKernelGGL(k_fold, dim3(G), dim3(FOLD_WG), FOLD_LDS_BYTES, st, c->km, f);
         HIPCHK(hipGetLastError());
         eA = fold_out_step(f); eB = 0; period = 1;
@@ -1234,8 +1239,8 @@ static int ctx_create_common(aesgcm_ctx **out, int device, const uint8_t *key, s
     if ((e = hipSetDevice(device)) != hipSuccess) { delete c; return hip_fail(e, "hipSetDevice"); }
     if ((e = hipStreamCreate(&c->stream)) != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate"); }
     if ((e = hipMalloc(&c->km, sizeof(KeyMaterial))) != hipSuccess ||
-        (e = hipMalloc(&c->fold_a, sizeof(uint4) * 64 * (AESGCM_MAX_CHUNKS / (FOLD_GROUP * FOLD_WAVES)))) != hipSuccess ||
-        (e = hipMalloc(&c->fold_b, sizeof(uint4) * 64 * (AESGCM_MAX_CHUNKS / 65536 + 4))) != hipSuccess ||
+        (e = hipMalloc(&c->fold_a, sizeof(uint4) * 64 * FOLD_A_ITEMS)) != hipSuccess ||
+        (e = hipMalloc(&c->fold_b, sizeof(uint4) * 64 * FOLD_B_ITEMS)) != hipSuccess ||
         (e = hipMalloc(&c->d_counter, 64 * (1 + AESGCM_NQ))) != hipSuccess ||
         (e = hipMemset(c->d_counter, 0, 64 * (1 + AESGCM_NQ))) != hipSuccess ||
         (e = hipMalloc(&c->d_tag, sizeof(uint4) * 4)) != hipSuccess ||

@@ -146,7 +146,7 @@ struct Emu {
                 if (period <= 1 && n <= COMBINE_MAX_ITEMS && has(eA) && (n <= 4 || has(4 * eA)) && (n <= 16 || has(16 * eA))) { Parts q = {cur, n, PARTS_ITEM, eA}; return q; }
             }
             std::vector<uint4> &ob = which ? fold_b : fold_a;
-            const u32 G = fold_wgs(n);
+            const u32 G = fold_wgs(n, fold_group(n, period));
             if (ob.size() < (size_t)G * 64) ob.resize((size_t)G * 64);
             FoldParams f;
             plan_fold(f, cur, ob.data(), n, period, eA, eB);
@@ -159,7 +159,7 @@ struct Emu {
             }
             for (u32 g = 0; g < G; g++) {
                 u32 start, end;
-                const u32 J = fold_wg_range(n, g, &start, &end);
+                const u32 J = fold_wg_range(n, f.group, g, &start, &end);
                 for (u32 w = 0; w < J; w++) for (u32 lane = 0; lane < 64; lane++)
                     *reinterpret_cast<uint4 *>(smem + FOLD_LDS_TAB + w * 1024u + lane * 16u) = fold_wave_lane(f, smem, start, end, J, w, lane);
                 for (u32 lane = 0; lane < 64; lane++) f.out[(size_t)g * 64 + lane] = fold_wg_lane(smem, J, lane);
@@ -623,6 +623,8 @@ int main(int argc, char **argv) {
     test_key(16, 0, 4, {{0, 16 * W * 3}, {5, 16 * W * 2 + 7}, {33, 16 * (W * 3 - 36) + 1}});
     test_key(32, 2, 5, {{0, 16 * 2048 * 2}, {16, 16 * 2048 * 2 - 16}, {40, 16 * 2048 * 3 + 13}, {1000 * 16, 16 * 6144}});
     test_key(24, 5, 6, {{7, 16 * 8192 + 9}});
+    test_key(16, 1, 10, {{0, 16 * 64 * 1500 + 3}, {5, 16 * 64 * 3000}, {16, 16 * 64 * 5000 + 9}});   // 1500 / 3000 / 5000 items: k_fold with 2, 4, 8 items per wave (fold_group)
+    if (level >= 3) test_key(32, 1, 11, {{0, 16ull * 64 * 65535}});
     test_key(32, 1, 9, {{3, 16 * 64 * 700 + 11}});      // 700+ chunks > GMAX -> two-stage fold with > 1 stage-1 lanes... one stage-1 workgroup
     test_shards(32, 2, 37, 203 * 16 + 5, 8, 77);
     test_shards(16, 0, 0, 16 * (W * 5 + 100) + 3, 3, 78);
