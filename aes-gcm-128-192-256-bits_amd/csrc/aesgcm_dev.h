@@ -39,6 +39,7 @@ typedef uint64_t u64;
 #define AESGCM_Q5_HI_ROW (AESGCM_Q5_GROUPS + 1)
 #define AESGCM_Q5_ENTRIES (AESGCM_Q5_GROUPS * 32)
 #define AESGCM_LDS_GH ((AESGCM_Q5_HI_ROW + AESGCM_Q5_GROUPS) * 256)   /* bytes: 13568 = 53 LDS rows: the five-bit GHASH tables of the launch constant (ghash_mul_const_lds) */
+#define AESGCM_LDS_DRY_OFF (AESGCM_Q5_GROUPS * 256)  /* the spare row between the table halves: one u32 there is the workgroup's dry-queue mask (k_main / k_body dispensers) */
 #define AESGCM_LDS_AES 65536   /* bytes: 256 entries x (32 replicas of T0 | 32 replicas of T2) */
 #define AESGCM_LDS_BYTES (AESGCM_LDS_AES + AESGCM_LDS_GH)
 
@@ -479,7 +480,12 @@ HD G128 shoup2_gmul(G128 y, const uint4 *__restrict__ tab) {
 
 // One atomic address serves ~87 M fetches/s on MI355X (measured): a single dispenser caps a launch at one chunk per
 // 11.5 ns, i.e. chunks shorter than ~10 rows run at the dispenser's speed, not the kernel's.  Chunks are therefore
-// dealt from AESGCM_NQ queues on separate cache lines; a wave starts at its home queue and walks on when one runs dry.
+// dealt from AESGCM_NQ queues on separate cache lines; a wave starts at its home queue and walks on when one runs dry;
+// dry queues are remembered per workgroup in LDS, so only the first wave of a workgroup to find one pays a failing fetch.
+// Round 1 never reset the queues: every wave made one FAILING fetch on every queue so that the next launch knew the base
+// values -- waves x queues serialized atomics (6144 x 16 at 11.5 ns per address = 70 - 100 us) at the end of every dynamic
+// launch, which is why chunk counts above the wave count cost mid-size messages +100 us (profiles/r02f/tw_sweep_before.txt).
+// Now there are two sets of queues: a launch uses one and zeroes the other for the next launch on the stream.
 #define AESGCM_NQ 16
 struct MainParams {
     const unsigned char *in;     // data in (16-byte aligned) or NULL (MODE_KS)
@@ -487,8 +493,8 @@ struct MainParams {
     const unsigned char *aad;    // AAD bytes or NULL
     uint4 *parts;                // one GHASH partial per chunk (GHASH modes)
     u32 *counter;                // chunk dispensers: queue q is the u32 at counter[16 q] (one cache line each)
-    u32 nq, seg;                 // queue q hands out chunks [q seg, (q+1) seg); value fetched - qbase[q] = index in the queue
-    u32 qbase[AESGCM_NQ];        // what each queue held before this launch (queues are never reset)
+    u32 nq, seg;                 // queue q hands out chunks [q seg, (q+1) seg); the value fetched is the index in the queue (queues start at 0)
+    u32 *counter_zero;           // the other set of queues: zeroed by this launch for the next one
     u64 aad_len;                 // bytes
     u64 n_aad;                   // AAD blocks
     u64 len;                     // data bytes
@@ -515,15 +521,17 @@ struct MainParams {
 // dispenser fetch and a 1 KiB item store; ~8k waves are resident and a lone wave needs ~10 us per row when the CU is
 // full.  Small inputs want MANY short chunks (parallelism); large ones enough chunks per resident wave for the
 // dynamic dealing to level the age-ordered issue arbitration, but not so many that the dispensers (16 queues x
-// ~87 M fetches/s) or k_fold show up.  Measured (profiles/tw_sweep.py): 16 MiB best at 8 rows, 64 MiB at 16,
-// 256 MiB .. 4 GiB at 32; never more than AESGCM_MAX_CHUNKS chunks.
+// ~87 M fetches/s) or k_fold show up.  Measured (profiles/tw_sweep.py; round 2 after the dispenser and k_fold changes:
+// profiles/r02f/tw_sweep_after.txt): 16 .. 64 MiB best at 8 rows, 100 .. 256 MiB at 16, beyond at 32; never more than
+// AESGCM_MAX_CHUNKS chunks.
 HD void main_geometry(u64 n_seq, u32 tw_override, u64 *rows, u32 *Tw, u32 *C) {
     const u64 R = (n_seq + 63) / 64;
     u64 t;
     if (tw_override) t = tw_override;
     else if (R <= 2) t = R;                                        // <= 2 KiB: ONE chunk; its wave finishes the tag itself (k_main's tail: a single launch).  A lone wave needs ~2.2 us per row, so longer messages are faster as one row per wave + k_combine
     else if (R <= 256) t = (R + 63) / 64;                          // <= 256 KiB: at most 64 chunks, which k_combine folds itself (no k_fold launch)
-    else if (R <= 32768) { t = R / 2048; if (t < 1) t = 1; }      // <= 32 MiB: ~2k chunks
+    else if (R <= 16384) { t = R / 2048; if (t < 1) t = 1; }      // <= 16 MiB: ~2k chunks, a wave each (static assignment)
+    else if (R <= 65536) t = 8;                                    // <= 64 MiB: measured best (profiles/r02f/tw_sweep_after.txt): 4096 static chunks at 32 MiB, 8192 dealt ones at 64 MiB
     else t = R < (1u << 18) ? 16 : 32;
     const u64 tmin = (R + AESGCM_MAX_CHUNKS - 1) / AESGCM_MAX_CHUNKS;
     if (t < tmin) t = tmin;
@@ -859,7 +867,7 @@ struct BodyParams {
     const unsigned char *in;     // first body block (16-byte aligned)
     unsigned char *out;
     uint4 *parts;                // one GHASH partial per chunk, chunk c = 4*s + v
-    u32 *counter; u32 nq, seg; u32 qbase[AESGCM_NQ];      // as in MainParams
+    u32 *counter; u32 nq, seg; u32 *counter_zero;         // as in MainParams
     u32 T;                       // rows per chunk (iterations of a wave), super-chunk = 4*T rows = 256*T blocks
     u32 C;                       // chunks = 4 * super-chunks
     u32 ctr_hi0;                 // (message block index of body block 0) >> 8; the index is a multiple of 256

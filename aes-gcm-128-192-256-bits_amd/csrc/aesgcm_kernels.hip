@@ -95,6 +95,37 @@ __global__ __launch_bounds__(AESGCM_WG) void k_setup(KeyMaterial *km, const DevT
     }
 }
 
+// Next chunk of a dynamic launch for the calling wave, or DISPENSER_DONE.  `q` is the wave's current queue (wave-uniform).
+// The common case is one atomicAdd on the wave's own queue.  A queue found dry is recorded in a per-WORKGROUP bit mask in
+// LDS (the spare row of the GHASH table region), so the workgroup's other waves skip it without touching memory: a launch
+// makes at most (workgroups x queues) failing fetches instead of (waves x queues).  (Reading the counters with plain
+// agent-scope loads instead was tried and is wrong for this part: such loads are served by the XCD's own L2, which is not
+// coherent with the memory-side atomics of other XCDs -- waves saw stale "work left" values and spun on dry queues; k_body
+// got 25 % slower.)  Every queue keeps its home waves until it is dry, so every chunk is handed out whatever the others do.
+#define DISPENSER_DONE 0xFFFFFFFFu
+__device__ __forceinline__ u32 next_chunk(u32 *counter, unsigned char *smem, u32 nq, u32 seg, u32 C, u32 &q, u32 lane) {
+    u32 *dry = reinterpret_cast<u32 *>(smem + AESGCM_LDS_DRY_OFF);
+    const u32 all = nq >= 32 ? 0xFFFFFFFFu : (1u << nq) - 1u;
+    for (u32 tries = 0; tries < 4 * AESGCM_NQ; ++tries) {
+        const u32 mask = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile u32 *>(dry));
+        if ((mask & all) == all) return DISPENSER_DONE;
+        if ((mask >> q) & 1u) {                                     // known dry: the next queue (cyclically) that is not
+            const u32 live = ~mask & all, above = live & ~((2u << q) - 1u);
+            q = (u32)__builtin_ctz(above ? above : live);
+        }
+        u32 v = 0;
+        if (lane == 0) v = atomicAdd(counter + 16 * q, 1u);
+        v = __builtin_amdgcn_readfirstlane(v);
+        if (v < seg) {
+            const u32 c = q * seg + v;
+            if (c < C) return c;
+            continue;                                               // the last queue is padded to seg (fewer than nq entries)
+        }
+        if (lane == 0) atomicOr(dry, 1u << q);
+    }
+    return DISPENSER_DONE;
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_main: the fused hot path.  Persistent workgroups; after the LDS tables are staged every WAVE is
 // autonomous: it pulls chunk indices from the dispenser and processes one 16-byte block per lane per row
@@ -130,6 +161,7 @@ __global__ __launch_bounds__(AESGCM_MAIN_WG, AESGCM_WAVES_PER_SIMD) void k_main(
     }
     const u64 cyc0 = p.trace ? clock64() : 0;
     main_fill_lds(smem, km, tb, tid, GH);
+    if (tid == 0) *reinterpret_cast<u32 *>(smem + AESGCM_LDS_DRY_OFF) = 0;                      // dry-queue mask of the workgroup (next_chunk)
     __syncthreads();
     // round-1 constants depend on key and IV only (the lane merely picks which table replica it reads), so they
     // are wave-uniform: keep them in scalar registers, the vector file is full at 8 waves per SIMD
@@ -139,10 +171,11 @@ __global__ __launch_bounds__(AESGCM_MAIN_WG, AESGCM_WAVES_PER_SIMD) void k_main(
     u32 done = 0;
     // bounded on purpose: no wave can own more than C chunks (plus one dry fetch per queue), so a dispenser problem can
     // never turn into a hang
-    u32 q = p.nq ? (blockIdx.x * (AESGCM_MAIN_WG / 64) + (tid >> 6)) % p.nq : 0, dry = 0;       // home queue; queues found empty so far
+    if (p.nq && blockIdx.x == 0 && tid < AESGCM_NQ) p.counter_zero[16 * tid] = 0;             // the next dynamic launch's queues
+    u32 q = p.nq ? (blockIdx.x * (AESGCM_MAIN_WG / 64) + (tid >> 6)) % p.nq : 0;                // home queue
     q = __builtin_amdgcn_readfirstlane(q);
     const u32 wave_id = __builtin_amdgcn_readfirstlane(blockIdx.x * (AESGCM_MAIN_WG / 64) + (tid >> 6));
-    for (u32 guard = 0; guard <= p.C + 2 * AESGCM_NQ; ++guard) {
+    for (u32 guard = 0; guard <= p.C; ++guard) {
         u32 c;
         if (p.nq == 0) {
             // small launch: at least as many waves as chunks, wave i owns chunk i -- no dispenser round trips on the
@@ -159,16 +192,8 @@ __global__ __launch_bounds__(AESGCM_MAIN_WG, AESGCM_WAVES_PER_SIMD) void k_main(
             }
             c = wave_id;
         } else {
-            u32 v = 0;
-            if (lane == 0) v = atomicAdd(p.counter + 16 * q, 1u) - p.qbase[q];
-            v = __builtin_amdgcn_readfirstlane(v);
-            if (v >= p.seg) {                                       // this queue is dry: walk on, stop after a full round
-                if (++dry == p.nq) break;
-                q = q + 1 == p.nq ? 0 : q + 1;
-                continue;
-            }
-            c = q * p.seg + v;
-            if (c >= p.C) continue;                                 // the last queue is padded to seg
+            c = next_chunk(p.counter, smem, p.nq, p.seg, p.C, q, lane);
+            if (c == DISPENSER_DONE) break;
         }
         const uint4 acc = main_chunk_lane<NR, MODE>(km, p, smem, cc, c, lane);
         if (GH) p.parts[(size_t)c * 64 + lane] = acc;          // the chunk's item: 64 raw lane accumulators (k_fold / k_combine take over)
@@ -224,24 +249,18 @@ __global__ __launch_bounds__(AESGCM_BODY_WG, AESGCM_BODY_WPS) void k_body(const 
 #if AESGCM_T4
     fill_lds_t4(smem, tb, tid, AESGCM_BODY_WG);
 #endif
+    if (tid == 0) *reinterpret_cast<u32 *>(smem + AESGCM_LDS_DRY_OFF) = 0;   // dry-queue mask of the workgroup (next_chunk)
     __syncthreads();
     CtrConsts cc = ctr_round1_consts(p.iv0, p.iv1, p.iv2, km->rk, smem, (lane & 31u) << 2);   // key and IV only: wave-uniform
     cc.c0 = __builtin_amdgcn_readfirstlane(cc.c0); cc.c1 = __builtin_amdgcn_readfirstlane(cc.c1);
     cc.c2 = __builtin_amdgcn_readfirstlane(cc.c2); cc.c3 = __builtin_amdgcn_readfirstlane(cc.c3);
     u32 done = 0;
-    u32 q = (blockIdx.x * (AESGCM_BODY_WG / 64) + (tid >> 6)) % p.nq, dry = 0;
+    if (blockIdx.x == 0 && tid < AESGCM_NQ) p.counter_zero[16 * tid] = 0;    // the next dynamic launch's queues
+    u32 q = (blockIdx.x * (AESGCM_BODY_WG / 64) + (tid >> 6)) % p.nq;
     q = __builtin_amdgcn_readfirstlane(q);
-    for (u32 guard = 0; guard <= p.C + 2 * AESGCM_NQ; ++guard) {            // bounded, as every dispenser loop here
-        u32 v = 0;
-        if (lane == 0) v = atomicAdd(p.counter + 16 * q, 1u) - p.qbase[q];
-        v = __builtin_amdgcn_readfirstlane(v);
-        if (v >= p.seg) {
-            if (++dry == p.nq) break;
-            q = q + 1 == p.nq ? 0 : q + 1;
-            continue;
-        }
-        const u32 c = q * p.seg + v;
-        if (c >= p.C) continue;
+    for (u32 guard = 0; guard <= p.C; ++guard) {                             // bounded, as every dispenser loop here
+        const u32 c = next_chunk(p.counter, smem, p.nq, p.seg, p.C, q, lane);
+        if (c == DISPENSER_DONE) break;
         const uint4 acc = body_chunk_lane<NR, MODE>(km, tb, p, smem, cc, c, lane);
         p.parts[(size_t)c * 64 + lane] = acc;
         if (c == 0 && p.ej0) {                                  // E_K(IV || 1) for the tag, once per launch (as in k_main)
@@ -809,11 +828,11 @@ struct aesgcm_ctx {
     uint4 *fold_a = nullptr, *fold_b = nullptr;   // k_fold ping-pong: MAX_CHUNKS/256 items; the second level leaves at most max(MAX_CHUNKS/65536, COMBINE_MAX_ITEMS) (fold_group)
     u32 *d_counter = nullptr;          // chunk dispenser
     u32 counter_base = 0;              // value the packet dispenser (d_counter[0]) holds before the next launch
-    u32 mq_base[AESGCM_NQ] = {0};      // the same for the chunk queues of k_main / k_body (d_counter[16 (1 + q)])
+    u32 qset = 0;                      // which of the two sets of chunk queues (d_counter[16 (1 + 16 set + q)]) the next dynamic launch of k_main / k_body uses; that launch zeroes the other set
     u32 tw_override = 0;               // AESGCM_TW
-    u64 body_min = (u64)128 << 20;     // ranges with an aligned middle of at least this many bytes go through k_body (AESGCM_BODY_MIN): with the
-                                       // four-table k_body and the direct tag path the cut pays from 128 MiB (profiles/r02d/split_threshold.txt:
-                                       // 64 MiB -22 %, 128 MiB +8.6 %, 512 MiB +6 %, 1 GiB +8.4 %, 2 GiB +9.1 %); round 1's break-even was 0.7 GiB
+    u64 body_min = (u64)256 << 20;     // ranges with an aligned middle of at least this many bytes go through k_body (AESGCM_BODY_MIN).  Since k_main
+                                       // got cheaper below 256 MiB (dispensers, k_fold: profiles/r02f/split_threshold.txt) the cut pays from 256 MiB:
+                                       // 128 MiB -16 %, 256 MiB +0.8 %, 512 MiB +4 %, 1 GiB +11 %, 2 GiB +7 %; it was 128 MiB before, 0.7 GiB in round 1
     uint4 *h_tag = nullptr;            // 64 bytes of pinned, device-mapped host memory: k_combine leaves the tag here too, so fetching it
     uint4 *h_tag_dev = nullptr;        //   is a host read -- no copy kernel, no interrupt-driven stream wait (its device address)
     u64 tag_gen = 0;                   // generation number of the last result sent to the host slot (the kernel publishes it behind the tag)
@@ -957,11 +976,10 @@ static int enqueue_main(aesgcm_ctx *c, int mode, const uint8_t iv[12], const voi
     p.parts = c->parts;
     u32 wgs = (C + 1 + AESGCM_MAIN_WG / 64 - 1) / (AESGCM_MAIN_WG / 64);      // one wave per chunk is enough for small inputs (+ one spare for E_K(J0))
     if (wgs > (u32)c->G) wgs = (u32)c->G;
-    p.counter = c->d_counter + 16;
     plan_queues(C, &p.nq, &p.seg);
     if ((u64)wgs * (AESGCM_MAIN_WG / 64) >= (u64)C + 1) p.nq = 0;   // a wave per chunk and a spare: static assignment, the dispensers are not touched
-    for (u32 q = 0; q < AESGCM_NQ; q++) p.qbase[q] = c->mq_base[q];
-    for (u32 q = 0; q < p.nq; q++) c->mq_base[q] += p.seg + wgs * (AESGCM_MAIN_WG / 64);   // every wave finds every queue dry exactly once
+    p.counter = c->d_counter + 16 * (1 + AESGCM_NQ * c->qset);
+    p.counter_zero = c->d_counter + 16 * (1 + AESGCM_NQ * (c->qset ^ 1u));
     if (gh && po) { p.ej0 = c->d_tag + 3; po->ej0 = p.ej0; }
     if (gh && po && want_tail && C == 1) { p.tail = 1; p.tag_out = c->d_tag; p.tag_host = c->h_tag_dev; p.gen = ++c->tag_gen; po->done = true; }
     p.trace = nullptr;
@@ -979,11 +997,11 @@ static int enqueue_main(aesgcm_ctx *c, int mode, const uint8_t iv[12], const voi
     }
     {
         const hipError_t le = launch_main(mode, c->nr, dim3(wgs), st, c->km, c->tables, p);
-        if (le != hipSuccess) {                      // nothing ran: the queues were not advanced on the device
-            for (u32 q = 0; q < AESGCM_NQ; q++) c->mq_base[q] = p.qbase[q];
+        if (le != hipSuccess) {                      // nothing ran: the queues were not touched on the device
             if (timed) c->ev_pool.push_back(evp);
             return hip_fail(le, "k_main launch");
         }
+        if (p.nq) c->qset ^= 1u;                      // the launch leaves the other set zeroed for the next dynamic one
     }
     if (timed) { HIPCHK(hipEventRecord(evp.second, st)); c->ev.push_back(evp); }
     if (gh && po && po->done) return AESGCM_OK;                   // the launch finished the tag itself
@@ -1016,10 +1034,9 @@ static int enqueue_body(aesgcm_ctx *c, int mode, const uint8_t iv[12], const Bod
 #else
     if (wgs > (u32)c->G) wgs = (u32)c->G;
 #endif
-    p.counter = c->d_counter + 16;
     plan_queues(p.C, &p.nq, &p.seg);
-    for (u32 q = 0; q < AESGCM_NQ; q++) p.qbase[q] = c->mq_base[q];
-    for (u32 q = 0; q < p.nq; q++) c->mq_base[q] += p.seg + wgs * waves_per_wg;
+    p.counter = c->d_counter + 16 * (1 + AESGCM_NQ * c->qset);
+    p.counter_zero = c->d_counter + 16 * (1 + AESGCM_NQ * (c->qset ^ 1u));
     if (c->timing) { p.trace = c->d_trace; HIPCHK(hipMemsetAsync(c->d_trace, 0, sizeof(u64) * 4 * AESGCM_GMAX, st)); }
     c->last_np = wgs;
     std::pair<hipEvent_t, hipEvent_t> evp;
@@ -1035,10 +1052,10 @@ static int enqueue_body(aesgcm_ctx *c, int mode, const uint8_t iv[12], const Bod
 #undef LY
     const hipError_t le = hipGetLastError();
     if (le != hipSuccess) {
-        for (u32 q = 0; q < AESGCM_NQ; q++) c->mq_base[q] = p.qbase[q];
         if (c->timing) c->ev_pool.push_back(evp);
         return hip_fail(le, "k_body launch");
     }
+    c->qset ^= 1u;
     if (c->timing) { HIPCHK(hipEventRecord(evp.second, st)); c->ev.push_back(evp); }
     // items 4s + v: phases 64 blocks apart inside a super-chunk, super-chunks 256 T blocks apart
     return enqueue_fold(c, c->parts, p.C, 4, 64, (u64)256 * b.T, st, po);
@@ -1241,8 +1258,8 @@ static int ctx_create_common(aesgcm_ctx **out, int device, const uint8_t *key, s
     if ((e = hipMalloc(&c->km, sizeof(KeyMaterial))) != hipSuccess ||
         (e = hipMalloc(&c->fold_a, sizeof(uint4) * 64 * FOLD_A_ITEMS)) != hipSuccess ||
         (e = hipMalloc(&c->fold_b, sizeof(uint4) * 64 * FOLD_B_ITEMS)) != hipSuccess ||
-        (e = hipMalloc(&c->d_counter, 64 * (1 + AESGCM_NQ))) != hipSuccess ||
-        (e = hipMemset(c->d_counter, 0, 64 * (1 + AESGCM_NQ))) != hipSuccess ||
+        (e = hipMalloc(&c->d_counter, 64 * (1 + 2 * AESGCM_NQ))) != hipSuccess ||
+        (e = hipMemset(c->d_counter, 0, 64 * (1 + 2 * AESGCM_NQ))) != hipSuccess ||
         (e = hipMalloc(&c->d_tag, sizeof(uint4) * 4)) != hipSuccess ||
         (e = hipHostMalloc((void **)&c->h_tag, 64, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess ||
         (e = hipHostGetDevicePointer((void **)&c->h_tag_dev, c->h_tag, 0)) != hipSuccess ||

@@ -483,7 +483,7 @@ class Context:
         return [tuple(buf[4 * i:4 * i + 4]) for i in range(n.value)]
 
     def geometry(self, body=False):
-        """launch geometry of k_main, or (body=True) of k_body, the kernel of the aligned middle of ranges >= 128 MiB"""
+        """launch geometry of k_main, or (body=True) of k_body, the kernel of the aligned middle of ranges >= 256 MiB"""
         a, b, c = cint(0), cint(0), cint(0)
         fn = load().aesgcm_ctx_body_geometry if body else load().aesgcm_ctx_geometry
         _chk(fn(self._c, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))

@@ -288,7 +288,7 @@ AESGCM_API int aesgcm_ctx_wg_trace(aesgcm_ctx *ctx, uint64_t *out, size_t max_wg
 AESGCM_API int aesgcm_ctx_ceiling_probe(aesgcm_ctx *ctx, size_t nbytes, double *ms, uint64_t *blocks);
 /* geometry the context chose (workgroups, lanes per workgroup, LDS bytes per workgroup) */
 AESGCM_API int aesgcm_ctx_geometry(const aesgcm_ctx *ctx, int *n_workgroups, int *wg_lanes, int *lds_bytes);
-/* the same for k_body, the kernel that runs the aligned middle of ranges >= 128 MiB (four T-tables: one 1024-lane workgroup per CU) */
+/* the same for k_body, the kernel that runs the aligned middle of ranges >= 256 MiB (four T-tables: one 1024-lane workgroup per CU) */
 AESGCM_API int aesgcm_ctx_body_geometry(const aesgcm_ctx *ctx, int *n_workgroups, int *wg_lanes, int *lds_bytes);
 /* How a data range of `len` bytes starting at block `first_block` of its message is launched: large ranges are cut
  * into head (k_main), an aligned middle whose counters start at a multiple of 256 (k_body: rounds 1-2 without LDS
