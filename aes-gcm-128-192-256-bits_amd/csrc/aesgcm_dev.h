@@ -746,12 +746,12 @@ HD CtrConsts main_lane_consts(const KeyMaterial *__restrict__ km, const MainPara
 // nothing is multiplied per chunk any more (a per-lane bit-serial multiply per chunk used to cost ~2.4 rows).
 // The polynomial of the range is  sum_L H^(63-L) * B_L,  B_L = sum_i item_i[L] * H^(blocks between item i and the end),
 // and B_L is a Horner recurrence per lane with WAVE-UNIFORM constants, i.e. the cheap LDS-table multiply.
-// One k_fold launch reduces n items to ceil(n / (16 g)): stage a, a wave folds g consecutive items (constant A);
-// stage b, wave 0 folds the workgroup's <= 16 results (constant C = A^g).  Groups are cut from the END, so the
+// One k_fold launch reduces n items to ceil(n / (8 g)): stage a, a wave folds g consecutive items (constant A);
+// stage b, wave 0 folds the workgroup's <= 8 results (constant C = A^g).  Groups are cut from the END, so the
 // first group / first wave is the short one and group ends stay equally spaced.  g = 16 for long inputs; for up
 // to 16384 items g is the smallest power of two that leaves k_combine at most 64 items (fold_group): a workgroup's
-// multiplies all go through one CU's LDS array (16 waves x 128 array cycles each), so 256 items per workgroup cost
-// ~16 us however few workgroups there are -- with g = 1 .. 8 a mid-size message spreads over up to 64 CUs instead of 4
+// multiplies all go through one CU's LDS array (128 array cycles each), so a full workgroup costs
+// ~10-16 us however few workgroups there are -- with g = 1 .. 8 a mid-size message spreads over up to 64 CUs instead of 4
 // (round 2: k_fold 32 us -> see profiles/README.md).  k_combine applies H^(63-L) to the last item and XOR-folds the lanes.
 // k_body's chunks are interleaved (item 4s+v, v = row phase, 64 blocks apart; super-chunks 256 T apart):
 // period = 4 folds the four phases with A = H^64 and the super-chunks with B = H^(256 T).
@@ -767,7 +767,13 @@ struct FoldParams {
 };
 #define COMBINE_MAX_ITEMS 64u
 #define FOLD_GROUP 16u           /* most items per wave */
-#define FOLD_WAVES 16u           /* waves per workgroup: at most 256 items per workgroup */
+#ifndef FOLD_WAVES
+/* waves per workgroup: at most 128 items per workgroup.  The kernel needs 128 VGPRs (batches of 8 items in flight), i.e. 4 waves
+   per SIMD: with 8 waves per workgroup TWO workgroups share a CU and one's item loads hide behind the other's multiplies.
+   Measured per k_fold launch over a 16 GiB message's 2^18 items (profiles/r02f/fold_waves.txt): 16 waves 115 us, 8 waves 73 us,
+   4 waves 66 us; a rolled loop at 64 VGPRs with two 16-wave workgroups per CU: 172 us. */
+#define FOLD_WAVES 8u
+#endif
 #define FOLD_WG (64u * FOLD_WAVES)
 #define FOLD_LDS_TAB 24576u      /* three 8 KiB tables */
 #define FOLD_LDS_BYTES (FOLD_LDS_TAB + FOLD_WAVES * 1024u)

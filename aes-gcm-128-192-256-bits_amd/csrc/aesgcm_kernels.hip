@@ -277,7 +277,7 @@ __global__ __launch_bounds__(AESGCM_BODY_WG, AESGCM_BODY_WPS) void k_body(const 
     }
 }
 
-// k_fold: up to 256 items per workgroup (lane bodies: fold_wave_lane(), fold_wg_lane()).  No static LDS: table offsets
+// k_fold: up to FOLD_GROUP x FOLD_WAVES = 128 items per workgroup (lane bodies: fold_wave_lane(), fold_wg_lane()).  No static LDS: table offsets
 // are absolute.
 __global__ __launch_bounds__(FOLD_WG) void k_fold(const KeyMaterial *__restrict__ km, const FoldParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -825,7 +825,7 @@ struct aesgcm_ctx {
     KeyMaterial *km = nullptr;
     uint4 *parts = nullptr;            // one item (64 lane accumulators) per chunk, grown on demand
     size_t parts_cap = 0;              // items
-    uint4 *fold_a = nullptr, *fold_b = nullptr;   // k_fold ping-pong: MAX_CHUNKS/256 items; the second level leaves at most max(MAX_CHUNKS/65536, COMBINE_MAX_ITEMS) (fold_group)
+    uint4 *fold_a = nullptr, *fold_b = nullptr;   // k_fold ping-pong: MAX_CHUNKS/128 items; the second level leaves at most max(MAX_CHUNKS/65536, COMBINE_MAX_ITEMS) (fold_group)
     u32 *d_counter = nullptr;          // chunk dispenser
     u32 counter_base = 0;              // value the packet dispenser (d_counter[0]) holds before the next launch
     u32 qset = 0;                      // which of the two sets of chunk queues (d_counter[16 (1 + 16 set + q)]) the next dynamic launch of k_main / k_body uses; that launch zeroes the other set
@@ -933,7 +933,7 @@ static const uint4 *ptab_ptr(const aesgcm_ctx *c, u64 e) {
     const int k = ptab_index(e);
     return k < 0 ? nullptr : reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(c->km) + offsetof(KeyMaterial, ptab)) + (size_t)k * 512;
 }
-// capacity of the ping-pong buffers in items: a first level leaves at most MAX_CHUNKS/256, a second at most
+// capacity of the ping-pong buffers in items: a first level leaves at most MAX_CHUNKS/(FOLD_GROUP FOLD_WAVES), a second at most
 // max(MAX_CHUNKS/65536, COMBINE_MAX_ITEMS) (fold_group stops where k_combine can take over)
 #define FOLD_A_ITEMS (AESGCM_MAX_CHUNKS / (FOLD_GROUP * FOLD_WAVES))
 #define FOLD_B_ITEMS (AESGCM_MAX_CHUNKS / 65536u + COMBINE_MAX_ITEMS)

@@ -92,14 +92,16 @@ def test_fuzz_random_shard_splits(hip, orc):
 
 @pytest.mark.parametrize("body", [False, True])
 def test_fold_level_boundaries(hip, orc, monkeypatch, body):
-    """k_fold reduces 256 items per launch (16 per wave): chunk counts on both sides of 16, 256 and 65536, with
+    """k_fold reduces up to 128 items per workgroup (8 waves x 1..16 items, fold_group) and k_combine folds the last 64:
+    chunk counts on both sides of every boundary of that scheme (64, 128, 512 g for g = 1..16, 16 x 8192, 65536), with
     one-row chunks so that the count is the row count; once through k_main alone, once with the k_body cut forced
     (interleaved items, period-4 first level)."""
     monkeypatch.setenv("AESGCM_TW", "1")
     monkeypatch.setenv("AESGCM_BODY_MIN", "4096" if body else str(1 << 60))
     key, iv = splitmix_bytes(4201, 32), splitmix_bytes(4202, 12)
     ctx, f = hip.Context(key), orc.Fast(key)
-    counts = (1, 2, 15, 16, 17, 255, 256, 257, 4095, 4096, 4097, 65535, 65536, 65537)
+    counts = (1, 2, 15, 16, 17, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 2047, 2048, 2049, 4095, 4096, 4097, 8191, 8192, 8193,
+              16383, 16384, 16385, 65535, 65536, 65537)
     for rows in counts:
         for extra, al in ((0, 0), (5, 20)):
             n = rows * 1024 + extra - (1024 if extra else 0) + (16 if extra else 0)      # ragged variant: one block + 5 bytes less/more
