@@ -792,6 +792,11 @@ HD u32 fold_group(u32 n, u32 period) {
     return g;
 }
 HD u32 fold_wgs(u32 n, u32 group) { return (n + group * FOLD_WAVES - 1) / (group * FOLD_WAVES); }
+// capacity of the two ping-pong buffers in items (levels alternate between them, the first writes A): a first level leaves at
+// most MAX_CHUNKS/(FOLD_GROUP FOLD_WAVES); from there on fold_group keeps a level's output at COMBINE_MAX_ITEMS or below, where
+// k_combine takes over (tests/host_emul checks every n)
+#define FOLD_A_ITEMS (AESGCM_MAX_CHUNKS / (FOLD_GROUP * FOLD_WAVES))
+#define FOLD_B_ITEMS (AESGCM_MAX_CHUNKS / 65536u + COMBINE_MAX_ITEMS)
 // the items [*start, *end) of workgroup g, and how many waves have work
 HD u32 fold_wg_range(u32 n, u32 group, u32 g, u32 *start, u32 *end) {
     const u32 per = group * FOLD_WAVES;

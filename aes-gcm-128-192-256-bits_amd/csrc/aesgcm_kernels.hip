@@ -933,10 +933,6 @@ static const uint4 *ptab_ptr(const aesgcm_ctx *c, u64 e) {
     const int k = ptab_index(e);
     return k < 0 ? nullptr : reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(c->km) + offsetof(KeyMaterial, ptab)) + (size_t)k * 512;
 }
-// capacity of the ping-pong buffers in items: a first level leaves at most MAX_CHUNKS/(FOLD_GROUP FOLD_WAVES), a second at most
-// max(MAX_CHUNKS/65536, COMBINE_MAX_ITEMS) (fold_group stops where k_combine can take over)
-#define FOLD_A_ITEMS (AESGCM_MAX_CHUNKS / (FOLD_GROUP * FOLD_WAVES))
-#define FOLD_B_ITEMS (AESGCM_MAX_CHUNKS / 65536u + COMBINE_MAX_ITEMS)
 // k_fold levels: n items (period, eA, eB as in FoldParams) -> one item (left in parts, fold_a or fold_b)
 static int enqueue_fold(aesgcm_ctx *c, const uint4 *items, u32 n, u32 period, u64 eA, u64 eB, hipStream_t st, Partials *po) {
     const uint4 *cur = items;

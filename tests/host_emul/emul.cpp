@@ -261,6 +261,19 @@ struct ABuf { uint8_t *p; size_t n; ABuf(size_t n_) : n(n_) { p = (uint8_t *)ali
 
 static void test_units() {
     for (u32 x = 0; x < 256; x++) CHECK(g_tb.sbox[x] == orc_sbox((uint8_t)x), "sbox[%u]", x);
+    // k_fold level plan for every item count and both first-level periods: each level's output fits the buffer it is written to
+    // (A, B, A, ...), the walk ends at <= COMBINE_MAX_ITEMS items, and the group is a power of two and a multiple of the period
+    for (u32 period : {1u, 4u}) for (u32 n0 = COMBINE_MAX_ITEMS + 1; n0 <= AESGCM_MAX_CHUNKS; n0 += (n0 < 70000 ? 1 : 4099)) {
+        u32 n = n0, per = period, which = 0, levels = 0;
+        while (n > COMBINE_MAX_ITEMS || per > 1) {
+            const u32 g = fold_group(n, per), G = fold_wgs(n, g);
+            CHECK(g >= 1 && g <= FOLD_GROUP && (g & (g - 1)) == 0 && g % per == 0, "fold_group(%u, %u) = %u", n, per, g);
+            CHECK(G <= (which ? FOLD_B_ITEMS : FOLD_A_ITEMS), "fold level %u of n0 = %u leaves %u items", levels, n0, G);
+            CHECK(G < n || n == 1, "fold level does not shrink: %u -> %u", n, G);
+            n = G; per = 1; which ^= 1; if (++levels > 4) break;
+        }
+        CHECK(levels <= 3, "n0 = %u needs %u k_fold levels", n0, levels);
+    }
     // gf_mul vs oracle
     for (int i = 0; i < 200; i++) {
         auto a = rnd(16, 100 + i), b = rnd(16, 900 + i);
