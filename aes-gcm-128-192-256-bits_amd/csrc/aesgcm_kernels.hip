@@ -235,6 +235,13 @@ __global__ __launch_bounds__(AESGCM_MAIN_WG, AESGCM_WAVES_PER_SIMD) void k_main(
 #define AESGCM_BODY_WPS AESGCM_WAVES_PER_SIMD
 #define AESGCM_BODY_LDS AESGCM_LDS_BYTES
 #endif
+// the layout assumptions the kernels rely on, checked where they are used
+static_assert(2u * AESGCM_LDS_BYTES <= 160u * 1024u, "k_main / k_pkt / k_pktl: two workgroups must share a CU's 160 KiB of LDS");
+static_assert(AESGCM_BODY_LDS <= 160u * 1024u, "k_body: one workgroup per CU");
+static_assert(AESGCM_LDS_AES_OFF % 128u == 0, "T-table replicas: lane l must read bank l & 31");
+static_assert(AESGCM_LDS_DRY_OFF >= AESGCM_Q5_GROUPS * 256u && AESGCM_LDS_DRY_OFF + 4u <= AESGCM_Q5_HI_ROW * 256u, "the dry-queue mask sits in the spare row between the table halves");
+static_assert((AESGCM_Q5_HI_ROW * 256u) % 512u != 0 && AESGCM_Q5_HI_ROW * 256u > 2040u, "the two halves of a five-bit table entry must not be fusable into one ds_read2[st64]_b64");
+static_assert(FOLD_B_ITEMS >= COMBINE_MAX_ITEMS && FOLD_A_ITEMS >= COMBINE_MAX_ITEMS, "k_fold ping-pong buffers");
 template <int NR, int MODE>
 __global__ __launch_bounds__(AESGCM_BODY_WG, AESGCM_BODY_WPS) void k_body(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const BodyParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
