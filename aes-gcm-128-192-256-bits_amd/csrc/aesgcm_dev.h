@@ -515,7 +515,7 @@ struct MainParams {
     u64 gen;                     // tail: generation number published behind the host copy (see CombineParams::gen)
 };
 
-#define AESGCM_MAX_CHUNKS (1u << 18)   /* 64 lane accumulators (1 KiB) per chunk: at most 256 MiB of them; k_fold measured ~0.8 ns per chunk (about 3x its LDS-array floor of one table multiply per item) */
+#define AESGCM_MAX_CHUNKS (1u << 18)   /* 64 lane accumulators (1 KiB) per chunk: at most 256 MiB of them; k_fold's first level measured ~0.5 ns per chunk (135 us for 2^18; about 2x its LDS-array floor of 1.25 table multiplies per item) */
 
 // Chunking of a GHASH sequence of n_seq blocks: rows of 64 blocks, Tw rows per chunk.  A chunk costs its rows, a
 // dispenser fetch and a 1 KiB item store; ~8k waves are resident and a lone wave needs ~10 us per row when the CU is
