@@ -847,6 +847,7 @@ struct aesgcm_ctx {
     u64 *d_trace = nullptr;            // per-workgroup trace of the last k_main launch (timing mode only)
     u32 last_np = 0;
     hipStream_t stream = nullptr;
+    hipEvent_t ev_sync = nullptr;      // aesgcm_ctx_wait: marks "everything enqueued so far on this context's stream"
     // host-API staging
     unsigned char *st_in = nullptr, *st_out = nullptr, *st_aad = nullptr;
     size_t st_in_cap = 0, st_out_cap = 0, st_aad_cap = 0;
@@ -1311,6 +1312,7 @@ int aesgcm_ctx_destroy(aesgcm_ctx *c) {
     if (c->st_in) hipFree(c->st_in);
     if (c->st_out) hipFree(c->st_out);
     if (c->st_aad) hipFree(c->st_aad);
+    if (c->ev_sync) hipEventDestroy(c->ev_sync);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
     return AESGCM_OK;
@@ -1319,6 +1321,20 @@ int aesgcm_ctx_device(const aesgcm_ctx *c) { return c ? c->device : AESGCM_EARG;
 int aesgcm_ctx_stream(const aesgcm_ctx *c, void **stream) {
     if (!c || !stream) return AESGCM_EARG;
     *stream = (void *)c->stream;
+    return AESGCM_OK;
+}
+// Everything enqueued from now on on `c`'s own stream starts only after everything enqueued so far on `other`'s own stream
+// has completed (one event record + one stream wait; no host synchronisation).  Two contexts of one key on one device
+// have separate scratch sets and streams, so consecutive messages can alternate between them and message m+1's fused
+// kernel starts while message m's k_fold / k_combine drain; this call orders the step that needs both (the all-gather).
+int aesgcm_ctx_wait(aesgcm_ctx *c, aesgcm_ctx *other) {
+    if (!c || !other) return AESGCM_EARG;
+    if (c == other) return AESGCM_OK;
+    if (c->device != other->device) return AESGCM_EARG;
+    HIPCHK(hipSetDevice(c->device));
+    if (!other->ev_sync) HIPCHK(hipEventCreateWithFlags(&other->ev_sync, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(other->ev_sync, other->stream));
+    HIPCHK(hipStreamWaitEvent(c->stream, other->ev_sync, 0));
     return AESGCM_OK;
 }
 int aesgcm_ctx_geometry(const aesgcm_ctx *c, int *n_wg, int *wg_lanes, int *lds_bytes) {
@@ -1443,7 +1459,10 @@ int aesgcm_encrypt(aesgcm_ctx *c, const uint8_t iv[12], const uint8_t *aad, size
     HIPCHK(hipSetDevice(c->device));
     if ((rc = stage_in(c, aad, aad_len, pt, len))) return rc;
     if ((rc = crypt_dev(c, 0, iv, c->st_aad, aad_len, c->st_in, len, c->st_out, c->stream))) return rc;
-    if (len) HIPCHK(hipMemcpyAsync(ct, c->st_out, len, hipMemcpyDeviceToHost, c->stream));
+    // the call returns data synchronously (tb/gcm_model.py:26): the tag's generation number is published by k_combine BEFORE
+    // this copy starts, and with a page-locked `ct` (aesgcm_host_alloc) the copy is truly asynchronous -- wait for it.  With
+    // len == 0 nothing is copied and the tag alone is polled for.
+    if (len) { HIPCHK(hipMemcpyAsync(ct, c->st_out, len, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); }
     return fetch_tag(c, c->stream, tag);
 }
 int aesgcm_decrypt(aesgcm_ctx *c, const uint8_t iv[12], const uint8_t *aad, size_t aad_len,
@@ -1455,7 +1474,7 @@ int aesgcm_decrypt(aesgcm_ctx *c, const uint8_t iv[12], const uint8_t *aad, size
     if ((rc = stage_in(c, aad, aad_len, ct, len))) return rc;
     if ((rc = crypt_dev(c, 1, iv, c->st_aad, aad_len, c->st_in, len, c->st_out, c->stream))) return rc;
     uint8_t t[16];
-    if (len) HIPCHK(hipMemcpyAsync(pt, c->st_out, len, hipMemcpyDeviceToHost, c->stream));
+    if (len) { HIPCHK(hipMemcpyAsync(pt, c->st_out, len, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); }   // as aesgcm_encrypt: never return while `pt` is still landing
     if ((rc = fetch_tag(c, c->stream, t))) return rc;
     if (tag_out) memcpy(tag_out, t, 16);
     if (expect_tag && !ct_compare16(t, expect_tag)) return AESGCM_EAUTH;
@@ -1926,6 +1945,40 @@ int aesgcm_fill_splitmix64_dev(int device, void *d_buf, size_t len, uint64_t see
 }
 
 // ---------------------------------------------------------------- timing
+// a pair of HIP events for callers that time launches of the context-free entry points (batch) on the stream they use
+struct aesgcm_timer { int device; hipEvent_t a, b; };
+int aesgcm_timer_create(aesgcm_timer **out, int device) {
+    if (!out) return AESGCM_EARG;
+    *out = nullptr;
+    HIPCHK(hipSetDevice(device));
+    aesgcm_timer *t = new (std::nothrow) aesgcm_timer();
+    if (!t) return AESGCM_ENOMEM;
+    t->device = device; t->a = t->b = nullptr;
+    hipError_t e = hipEventCreate(&t->a);
+    if (e == hipSuccess) e = hipEventCreate(&t->b);
+    if (e != hipSuccess) { if (t->a) hipEventDestroy(t->a); delete t; return hip_fail(e, "hipEventCreate"); }
+    *out = t;
+    return AESGCM_OK;
+}
+int aesgcm_timer_start(aesgcm_timer *t, void *stream) { if (!t) return AESGCM_EARG; HIPCHK(hipSetDevice(t->device)); HIPCHK(hipEventRecord(t->a, (hipStream_t)stream)); return AESGCM_OK; }
+int aesgcm_timer_stop(aesgcm_timer *t, void *stream) { if (!t) return AESGCM_EARG; HIPCHK(hipSetDevice(t->device)); HIPCHK(hipEventRecord(t->b, (hipStream_t)stream)); return AESGCM_OK; }
+int aesgcm_timer_ms(aesgcm_timer *t, double *ms) {
+    if (!t || !ms) return AESGCM_EARG;
+    HIPCHK(hipSetDevice(t->device));
+    HIPCHK(hipEventSynchronize(t->b));
+    float f = 0;
+    HIPCHK(hipEventElapsedTime(&f, t->a, t->b));
+    *ms = f;
+    return AESGCM_OK;
+}
+int aesgcm_timer_destroy(aesgcm_timer *t) {
+    if (!t) return AESGCM_OK;
+    hipSetDevice(t->device);
+    hipEventDestroy(t->a); hipEventDestroy(t->b);
+    delete t;
+    return AESGCM_OK;
+}
+
 int aesgcm_ctx_timing_enable(aesgcm_ctx *c, int on) {
     if (!c) return AESGCM_EARG;
     c->timing = on != 0;

@@ -12,11 +12,13 @@ from .build import SO, build
 
 OK, EARG, EKEYLEN, EIVLEN, ETOOLONG, EAUTH, EHIP, ENOMEM, ESTATE, EALIGN, ERCCL = 0, -1, -2, -3, -4, -5, -6, -7, -8, -9, -10
 
+ABI_VERSION = 2         # AESGCM_ABI_VERSION of include/aesgcm.h this binding was written against
+
 # every symbol include/aesgcm.h declares (tests check the .so exports exactly these)
 SYMBOLS = [
     "aesgcm_abi_version", "aesgcm_strerror", "aesgcm_last_error", "aesgcm_device_count", "aesgcm_device_name",
     "aesgcm_key_expand", "aesgcm_ecb_encrypt", "aesgcm_gfmul", "aesgcm_ghash", "aesgcm_get_h",
-    "aesgcm_ctx_create", "aesgcm_ctx_create_preexpanded", "aesgcm_ctx_destroy", "aesgcm_ctx_device", "aesgcm_ctx_stream",
+    "aesgcm_ctx_create", "aesgcm_ctx_create_preexpanded", "aesgcm_ctx_destroy", "aesgcm_ctx_device", "aesgcm_ctx_stream", "aesgcm_ctx_wait",
     "aesgcm_encrypt_pipelined", "aesgcm_decrypt_pipelined", "aesgcm_host_alloc", "aesgcm_host_free",
     "aesgcm_encrypt", "aesgcm_decrypt", "aesgcm_encrypt_dev", "aesgcm_decrypt_dev", "aesgcm_last_tag",
     "aesgcm_keystream", "aesgcm_keystream_dev",
@@ -26,6 +28,7 @@ SYMBOLS = [
     "aesgcm_fill_splitmix64_dev",
     "aesgcm_ctx_timing_enable", "aesgcm_ctx_timing_read", "aesgcm_ctx_geometry", "aesgcm_ctx_body_geometry", "aesgcm_ctx_split", "aesgcm_ctx_wg_trace",
     "aesgcm_ctx_ceiling_probe",
+    "aesgcm_timer_create", "aesgcm_timer_start", "aesgcm_timer_stop", "aesgcm_timer_ms", "aesgcm_timer_destroy",
     "aesgcm_comm_last_error", "aesgcm_comm_unique_id", "aesgcm_comm_create", "aesgcm_comm_ranks", "aesgcm_comm_allgather_dev",
     "aesgcm_comm_allreduce_f64", "aesgcm_comm_barrier", "aesgcm_comm_destroy",
     "aesgcm_mgpu_create", "aesgcm_mgpu_ranks", "aesgcm_mgpu_crypt_dev", "aesgcm_mgpu_destroy",
@@ -72,6 +75,7 @@ def load():
     L.aesgcm_ctx_destroy.argtypes = [vp]
     L.aesgcm_ctx_device.argtypes = [vp]
     L.aesgcm_ctx_stream.argtypes = [vp, ctypes.POINTER(vp)]
+    L.aesgcm_ctx_wait.argtypes = [vp, vp]
     L.aesgcm_encrypt.argtypes = [vp, vp, vp, sz, vp, sz, vp, vp]
     L.aesgcm_decrypt.argtypes = [vp, vp, vp, sz, vp, sz, vp, vp, vp]
     L.aesgcm_encrypt_pipelined.argtypes = [vp, vp, vp, sz, vp, sz, vp, vp, sz]
@@ -107,6 +111,11 @@ def load():
     L.aesgcm_ctx_body_geometry.argtypes = [vp, ctypes.POINTER(cint), ctypes.POINTER(cint), ctypes.POINTER(cint)]
     L.aesgcm_ctx_split.argtypes = [vp, sz, u64, ctypes.POINTER(u64), ctypes.POINTER(u64)]
     L.aesgcm_ctx_ceiling_probe.argtypes = [vp, sz, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(u64)]
+    L.aesgcm_timer_create.argtypes = [ctypes.POINTER(vp), cint]
+    L.aesgcm_timer_start.argtypes = [vp, vp]
+    L.aesgcm_timer_stop.argtypes = [vp, vp]
+    L.aesgcm_timer_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
+    L.aesgcm_timer_destroy.argtypes = [vp]
     L.aesgcm_comm_last_error.restype = cp
     L.aesgcm_comm_unique_id.argtypes = [vp]
     L.aesgcm_comm_create.argtypes = [ctypes.POINTER(vp), cint, vp, cint, cint]
@@ -119,8 +128,8 @@ def load():
     L.aesgcm_mgpu_ranks.argtypes = [vp, ctypes.POINTER(cint)]
     L.aesgcm_mgpu_crypt_dev.argtypes = [vp, cint, vp, vp, sz, ctypes.POINTER(vp), ctypes.POINTER(sz), ctypes.POINTER(vp), vp]
     L.aesgcm_mgpu_destroy.argtypes = [vp]
-    if L.aesgcm_abi_version() != 1:
-        raise ImportError("libaesgcm_hip.so ABI %d, expected 1" % L.aesgcm_abi_version())
+    if L.aesgcm_abi_version() != ABI_VERSION:
+        raise ImportError("libaesgcm_hip.so ABI %d, expected %d (stale build? rebuild with `make -C csrc`)" % (L.aesgcm_abi_version(), ABI_VERSION))
     _L = L
     return L
 
@@ -300,6 +309,34 @@ def dev_copy(d_dst, d_src, nbytes, device=0, stream=None):
     _chk(load().aesgcm_dev_copy(device, d_dst, d_src, nbytes, stream))
 
 
+class Timer:
+    """aesgcm_timer: two HIP events recorded on the stream the timed launches run on."""
+
+    def __init__(self, device=0):
+        self._t = None
+        t = vp()
+        _chk(load().aesgcm_timer_create(ctypes.byref(t), device))
+        self._t = t.value
+
+    def start(self, stream=None):
+        _chk(load().aesgcm_timer_start(self._t, stream))
+
+    def stop(self, stream=None):
+        _chk(load().aesgcm_timer_stop(self._t, stream))
+
+    def ms(self):
+        v = ctypes.c_double(0)
+        _chk(load().aesgcm_timer_ms(self._t, ctypes.byref(v)))
+        return v.value
+
+    def close(self):
+        if self._t:
+            load().aesgcm_timer_destroy(self._t)
+            self._t = None
+
+    __del__ = close
+
+
 # ---------------------------------------------------------------- context
 class Context:
     """aesgcm_ctx: (device, expanded key, H, H-power tables).  One per key."""
@@ -338,6 +375,10 @@ class Context:
         s = vp()
         _chk(load().aesgcm_ctx_stream(self._c, ctypes.byref(s)))
         return s.value
+
+    def wait(self, other):
+        """what is enqueued on this context's stream from now on starts after everything enqueued so far on `other`'s"""
+        _chk(load().aesgcm_ctx_wait(self._c, other._c))
 
     # unit level
     def h(self):

@@ -19,7 +19,22 @@ host) over the whole resident workload.
           0xAE5C0004), message m = bytes [m*32 GiB, (m+1)*32 GiB), IV last byte + m.  Every message is sharded over
           ALL ranks (rank r owns the r-th 1/N of its blocks); per message each rank produces a 16-byte weighted
           GHASH partial; ONE RCCL all-gather per step moves N x M x 16 bytes; every rank folds and finalises the
-          tags.  There is no other inter-GPU traffic.  Tags are checked against the cfg4 fixtures.
+          tags.  There is no other inter-GPU traffic.  Tags are checked against the cfg4 fixtures.  A rank's messages
+          run on separate contexts (own stream + scratch each, --contexts) so that one message's fold / combine tail
+          hides behind the next message's fused kernel.
+  --config cfg5   configs[4]: 2^20 independent 4 KiB packets, AES-128-GCM, per-packet key and IV (on-GPU aes_kexp),
+          keys / IVs / plaintext from the SURVEY 8(d) streams; N > 1 = replicas of 2^20 / N packets, no collective.
+          Tags are checked by SHA-256 against tests/golden/batch.json.
+  --emulate-rank R --of W   on ONE GPU: exactly rank R's step of the W-GPU job (its shard of every message at the
+          real first_block, a device copy in place of the all-gather, the finalizes), with the other ranks' partials
+          computed beforehand so that the tags are the real ones.  The scaling prediction while no W-GPU node exists.
+
+`python bench.py --gpus N` WITHOUT a launcher (no RANK in the environment) starts the N ranks itself: N fresh child
+processes (RANK / LOCAL_RANK / WORLD_SIZE / rendezvous directory in their environment) created before this process makes
+any GPU call; rank 0's JSON line is relayed, the exit code is the worst child's, a hung child is killed and fails the run.
+
+If the exchange that comes up is not RCCL the line still says so (config.exchange.backend) but the run EXITS NON-ZERO
+unless --allow-file-exchange is given: a number produced through the debug file exchange is not an RCCL number.
 
 No PyTorch anywhere: torch.distributed.run only LAUNCHES the ranks (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
 environment); the collective is RCCL inside libaesgcm_hip.so (aesgcm_comm_*, include/aesgcm.h), the unique id travels
@@ -30,7 +45,9 @@ import hashlib
 import json
 import os
 import statistics
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -42,7 +59,9 @@ KEY_SEED, IV_SEED = 0x4B4559, 0x4956
 CONFIGS = {                            # BASELINE.json configs that fit one GPU
     "cfg3": dict(key_bits=256, gib=16.0, pt_seed=0xAE5C0003, fixture="cfg3_aes256_16GiB"),
     "cfg2": dict(key_bits=128, gib=1.0, pt_seed=0xAE5C0002, fixture="cfg2_aes128_1GiB"),
+    "cfg5": dict(key_bits=128, n_pkts=1 << 20, pkt_len=4096, pt_seed=0xAE5C0005),
 }
+EXIT_NOT_RCCL = 3                      # the exchange that came up is not RCCL and --allow-file-exchange was not given
 
 
 def log(*a):
@@ -91,11 +110,11 @@ def pmc_summary(tag):
         return {}
 
 
-def cpu_baseline():
+def cpu_baseline(config):
     """The reference's CPU path timed on this box's host cores (oracle/cpu_baseline.py: pycryptodome if importable, else
     libcrypto; 1 core and all cores as worker processes).  The ONLY place bench.py touches oracle/."""
     from oracle import cpu_baseline as cb
-    return cb.measure()
+    return cb.measure_cfg5() if config == "cfg5" else cb.measure()
 
 
 def sclk_from_trace(trace, waves_per_wg):
@@ -110,46 +129,290 @@ def sclk_from_trace(trace, waves_per_wg):
     return round(statistics.median(v), 0) if v else None
 
 
-def main():
+# ------------------------------------------------------------------------------------------------ self-launch
+def visible_gpus():
+    """GPUs the kernel driver exposes, counted WITHOUT any HIP call (this process must stay GPU-free: its children own
+    the devices).  /sys/class/kfd topology nodes with SIMDs are GPUs; honours a *_VISIBLE_DEVICES list.  None = unknown."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and v.strip() != "":
+            return len([x for x in v.split(",") if x.strip() != ""])
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for d in os.listdir(base):
+            try:
+                props = dict(line.split(None, 1) for line in open(os.path.join(base, d, "properties")) if " " in line)
+            except OSError:
+                continue
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+        return n or None                                   # nothing readable: unknown, let the ranks find out
+    except OSError:
+        return None
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args, argv):
+    """--gpus N without a launcher: start the N ranks as fresh child processes and relay rank 0's line.  Nothing here
+    touches the GPU (no library load, no HIP call) -- the children initialise their own devices."""
+    N = args.gpus
+    have = visible_gpus()
+    if have is not None and have < N and not args.one_device:
+        log("bench.py: --gpus %d but only %d GPU(s) visible on this node; refusing to measure fewer GPUs than asked for "
+            "(--one-device puts every rank on GPU 0 for debugging)" % (N, have))
+        return 2
+    rdzv = tempfile.mkdtemp(prefix="aesgcm_rdzv_self_", dir="/dev/shm" if os.access("/dev/shm", os.W_OK) else None)
+    port = free_port()
+    procs = []
+    for r in range(N):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(N), LOCAL_WORLD_SIZE=str(N),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AESGCM_RDZV_DIR=rdzv, AESGCM_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL across processes needs it on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    deadline = time.monotonic() + args.launch_timeout
+    out0 = b""
+    failed_at = None
+    rcs = [None] * N
+    import threading
+    box = {}
+
+    def drain():                                       # rank 0's stdout (the JSON line) -- read it so the pipe never fills
+        box["out"] = procs[0].stdout.read()
+    th = threading.Thread(target=drain, daemon=True)
+    th.start()
+    while any(rc is None for rc in rcs):
+        for i, p in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = p.poll()
+        now = time.monotonic()
+        if failed_at is None and any(rc not in (None, 0) for rc in rcs):
+            failed_at = now                            # the others may be blocked in a rendezvous or a collective with the dead rank
+        if now > deadline or (failed_at is not None and now - failed_at > 20.0):
+            for i, p in enumerate(procs):
+                if rcs[i] is None:
+                    log("bench.py: killing rank %d (pid %d): %s" % (i, p.pid, "launch timeout" if now > deadline else "another rank failed"))
+                    p.kill()                           # exact pid of a child this process started
+                    rcs[i] = p.wait()
+            break
+        time.sleep(0.05)
+    th.join(timeout=10)
+    out0 = box.get("out", b"") or b""
+    sys.stdout.write(out0.decode(errors="replace"))
+    sys.stdout.flush()
+    try:
+        for f in os.listdir(rdzv):
+            os.unlink(os.path.join(rdzv, f))
+        os.rmdir(rdzv)
+    except OSError:
+        pass
+    worst = max((rc if rc > 0 else 1) if rc else 0 for rc in rcs)      # killed (negative) counts as 1
+    if worst:
+        log("bench.py: rank exit codes %s" % (rcs,))
+    return worst
+
+
+# ------------------------------------------------------------------------------------------------ exchanges
+class EmulatedExchange:
+    """--emulate-rank: one GPU plays rank `rank` of `world`; the all-gather is a device copy of this rank's partials into
+    their slot of a gathered buffer that already holds the other ranks' (real) partials."""
+    def __init__(self, lib, rank, world, device):
+        self.lib, self.rank, self.world, self.device = lib, rank, world, device
+        self.name = "emulated (device copy; rank %d of %d on one GPU)" % (rank, world)
+
+    def allgather_dev(self, d_send, d_recv, bytes_per_rank, stream=None):
+        self.lib.dev_copy(d_recv + self.rank * bytes_per_rank, d_send, bytes_per_rank, device=self.device, stream=stream)
+
+    def allreduce(self, value, op="max"):
+        return value
+
+    def barrier(self):
+        pass
+
+    def close(self):
+        pass
+
+
+# ------------------------------------------------------------------------------------------------ cfg5
+def run_cfg5(args, rank, world, dev, ex, cpu_base):
+    """BASELINE config 5: independent packets, per-packet key and IV; replicas for N > 1 (no collective on the data path)"""
+    import aesgcm_amd  # noqa: F401
+    from aesgcm_amd import comm, lib
+    from aesgcm_amd.build import SO
+    cfg = CONFIGS["cfg5"]
+    N = world
+    n_all = args.n_pkts if args.n_pkts else cfg["n_pkts"]
+    pkt = args.pkt_len if args.pkt_len else cfg["pkt_len"]
+    key_bits = args.key_bits or cfg["key_bits"]
+    kb = key_bits // 8
+    standard = (n_all, pkt, key_bits) == (cfg["n_pkts"], cfg["pkt_len"], cfg["key_bits"])
+    n = n_all // N                                               # this replica's packets [rank * n, (rank + 1) * n)
+    first = rank * n
+    # keys: stream 0x4B4559, kb bytes per packet; IVs: the first 12 bytes of every 16 of stream 0x4956; plaintext 0xAE5C0005
+    d_keys, d_ivw, d_ivs = lib.DeviceBuffer(kb * n, device=dev), lib.DeviceBuffer(16 * n, device=dev), lib.DeviceBuffer(12 * n, device=dev)
+    d_keys.fill_splitmix64(KEY_SEED, first * kb // 8)
+    d_ivw.fill_splitmix64(IV_SEED, first * 2)
+    ivw = bytes(d_ivw.download())
+    d_ivs.upload(b"".join(ivw[16 * p:16 * p + 12] for p in range(n)))
+    d_ivw.free()
+    d_pt, d_ct, d_tags = lib.DeviceBuffer(pkt * n, device=dev), lib.DeviceBuffer(pkt * n, device=dev), lib.DeviceBuffer(16 * n, device=dev)
+    d_pt.fill_splitmix64(cfg["pt_seed"], first * pkt // 8)
+    lib.dev_sync(dev)
+
+    def step(stream=None):
+        lib.batch_crypt_dev(args.decrypt, n, kb, d_keys.ptr, d_ivs.ptr, d_ct.ptr if args.decrypt else d_pt.ptr, pkt,
+                            d_pt.ptr if args.decrypt else d_ct.ptr, d_tags.ptr, device=dev, stream=stream)
+
+    def barrier():
+        lib.dev_sync(dev)
+        if ex is not None:
+            ex.barrier()
+            lib.dev_sync(dev)
+
+    if args.decrypt:
+        lib.batch_crypt_dev(False, n, kb, d_keys.ptr, d_ivs.ptr, d_pt.ptr, pkt, d_ct.ptr, d_tags.ptr, device=dev)
+        lib.dev_sync(dev)
+    for _ in range(max(args.warmup, 1)):
+        step()
+    lib.dev_sync(dev)
+    # ---- parity: SHA-256 over all tags (and the first 64 tags literally) against the committed libcrypto fixture
+    tags = bytes(d_tags.download())
+    tag_ok = None
+    fx = None
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "batch.json")) as f:
+            fx = json.load(f)
+    except (OSError, ValueError):
+        pass
+    all_tags = tags
+    if ex is not None:                                          # replicas: rank 0 hashes the concatenation of every rank's tags
+        d = comm.rendezvous_dir()
+        comm._write_atomic(os.path.join(d, "cfg5_tags_%d" % rank), tags)
+        if rank == 0:
+            all_tags = b"".join(comm._wait_read(os.path.join(d, "cfg5_tags_%d" % r), 16 * n, 300.0) for r in range(world))
+    tags_sha = hashlib.sha256(all_tags).hexdigest() if rank == 0 else None
+    if fx is not None and standard and rank == 0:
+        tag_ok = (tags_sha == fx.get("full_tags_sha256")) and [tags[16 * p:16 * p + 16].hex() for p in range(64)] == fx["first64_tags"]
+        if not tag_ok:
+            log("PARITY FAILURE cfg5: tags sha %s, fixture %s" % (tags_sha, fx.get("full_tags_sha256")))
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if ex is not None:
+        dt = ex.allreduce(dt, "max")
+        ok = ex.allreduce(0.0 if tag_ok is False else 1.0, "min")
+        if tag_ok is not None:
+            tag_ok = bool(ok)
+    value = n * N * pkt * args.steps / dt / GiB
+
+    # ---- the kernel's own duration: HIP events on the stream it is launched on (the NULL stream), separate short pass
+    tm = lib.Timer(device=dev)
+    k_ms = []
+    for _ in range(min(5, max(1, args.steps))):
+        tm.start(None)
+        step()
+        tm.stop(None)
+        k_ms.append(tm.ms())
+    tm.close()
+    if rank == 0:
+        avg_s = statistics.mean(k_ms) / 1e3
+        alg_bytes = n * (2 * pkt + kb + 12 + 16)                  # per packet: data read + written, key, IV, tag
+        achieved = alg_bytes / avg_s
+        so_sha = sha256_file(SO)
+        pm = pmc_summary("cfg5_n1") if standard and not args.decrypt and N == 1 else {}
+        same_build = bool(pm) and pm.get("so_sha256") == so_sha
+        nr = key_bits // 32 + 6
+        roofline = {"bound": "hbm", "kernel": pm.get("kernel") or "k_batch2<%d,%d,4> (per-packet aes_kexp + AES-CTR + GHASH)" % (nr, int(args.decrypt)),
+                    "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_BYTES_PER_S, 4), "traffic": pm.get("hbm_bytes_per_launch") if same_build else None,
+                    "traffic_source": "profiles/pmc_cfg5_n1.json" if pm else None,
+                    "traffic_build": {"pmc_so_sha256": pm.get("so_sha256"), "pmc_git": pm.get("git"), "running_so_sha256": so_sha,
+                                      "running_git": git_head(), "match": same_build},
+                    "alg_bytes_per_launch": alg_bytes, "launches_timed": len(k_ms), "avg_launch_ms": round(avg_s * 1e3, 4),
+                    "timing": "HIP events on the launch stream around each launch in a separate %d-step pass after the timed region" % len(k_ms),
+                    "lds_busy_frac": (pm.get("lds") or {}).get("lds_busy_frac") if same_build else None}
+        line = {
+            "metric": "GiB/s plaintext, AES-%d-GCM, %d independent %d-byte packets, per-packet key/IV, bit-exact tags" % (key_bits, n * N, pkt),
+            "value": round(value, 3), "unit": "GiB/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if N > 1 else "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "cfg5%s: %d packets x %d B, AES-%d-GCM, per-packet key (stream 0x4B4559) and IV (stream 0x4956), on-GPU aes_kexp, "
+                                   "plaintext stream 0xAE5C0005%s%s" % ("" if standard else " (custom size)", n * N, pkt, key_bits,
+                                                                       ", DECRYPT + authenticate" if args.decrypt else "",
+                                                                       "; %d replicas of %d packets, no collective" % (N, n) if N > 1 else ""),
+                       "packets_per_gpu": n, "pkt_len": pkt, "key_bits": key_bits, "mpkt_per_s": round(n * N * args.steps / dt / 1e6, 2),
+                       "parallelism": "single" if N == 1 else "replicas%d" % N,
+                       "exchange": None if ex is None else {"backend": ex.name, "ranks_seen": ex.world, "use": "barrier and max-over-ranks timing only", "torch": "not imported"}},
+            "tag_ok": tag_ok, "tags_sha256": tags_sha, "roofline": roofline,
+        }
+        if cpu_base is not None:
+            line["cpu_baseline"] = cpu_base
+        print(json.dumps(line), flush=True)
+    return tag_ok
+
+
+# ------------------------------------------------------------------------------------------------ main
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS), help="N = 1 workload (default: the metric's cfg3)")
+    ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS), help="workload (default: the metric's cfg3; N > 1 stream runs are cfg4)")
     ap.add_argument("--gib-per-gpu", type=float, default=None, help="override: resident plaintext per GPU (no fixture check)")
     ap.add_argument("--key-bits", type=int, default=None, choices=(128, 192, 256), help="override (no fixture check)")
+    ap.add_argument("--n-pkts", type=int, default=None, help="cfg5 override: packets in all (no fixture check)")
+    ap.add_argument("--pkt-len", type=int, default=None, help="cfg5 override: bytes per packet (no fixture check)")
     ap.add_argument("--decrypt", action="store_true", help="time decrypt + authenticate instead of encrypt (N = 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="rccl", choices=("rccl", "nccl", "file", "gloo"),
                     help="exchange for N > 1: rccl (= nccl, the product: RCCL inside the library) or file (= gloo of round 1: "
-                         "debug, partials through the host, for several ranks on ONE GPU)")
-    ap.add_argument("--one-device", action="store_true", help="debug: every rank uses GPU 0 (with --backend file)")
+                         "debug, partials through the host, for several ranks on ONE GPU; needs --allow-file-exchange)")
+    ap.add_argument("--allow-file-exchange", action="store_true",
+                    help="accept a run whose exchange is not RCCL (debug); without it such a run prints its line and exits %d" % EXIT_NOT_RCCL)
+    ap.add_argument("--one-device", action="store_true", help="debug: every rank uses GPU 0 (RCCL refuses that: the file exchange comes up)")
     ap.add_argument("--selfcheck", action="store_true",
                     help="rank 0 also encrypts every whole message alone and compares tags (needs the extra memory)")
-    args = ap.parse_args()
+    ap.add_argument("--contexts", type=int, default=0,
+                    help="N > 1 / --emulate-rank: contexts (stream + scratch set each) a rank's messages rotate over; 0 = one per message, at most 4")
+    ap.add_argument("--emulate-rank", type=int, default=None, help="on ONE GPU, run exactly this rank's step of the --of W job")
+    ap.add_argument("--of", type=int, default=8, help="world size emulated by --emulate-rank")
+    ap.add_argument("--launch-timeout", type=float, default=3000.0, help="self-launch: seconds before hung ranks are killed")
+    args = ap.parse_args(argv)
+
+    if "RANK" not in os.environ and args.gpus > 1 and args.emulate_rank is None:
+        return self_launch(args, argv)                           # before anything touches the GPU
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     N = args.gpus
-    if world != N and not (N == 1 and world == 1):
-        log("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (N, world))
-        N = world
-
-    cfg = dict(CONFIGS[args.config])
-    standard = args.gib_per_gpu is None and args.key_bits is None
-    if N > 1:
-        cfg = dict(key_bits=256, gib=16.0, pt_seed=0xAE5C0004, fixture=None)
-    if args.gib_per_gpu is not None:
-        cfg["gib"] = args.gib_per_gpu
-    if args.key_bits is not None:
-        cfg["key_bits"] = args.key_bits
+    if world != N:
+        log("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to print a line for a different GPU count than asked for" % (N, world))
+        return 2
+    emu = args.emulate_rank
+    if emu is not None and (N != 1 or not (0 <= emu < args.of) or args.config == "cfg5"):
+        log("bench.py: --emulate-rank R --of W runs on one GPU (--gpus 1), 0 <= R < W, stream configs only")
+        return 2
 
     # ---- CPU baseline FIRST: its worker processes are forked before this process touches the GPU
     cpu_base = None
-    if N == 1 and rank == 0 and not args.no_cpu_baseline:
+    if N == 1 and rank == 0 and not args.no_cpu_baseline and emu is None:
         try:
-            cpu_base = cpu_baseline()
+            cpu_base = cpu_baseline(args.config)
         except Exception as e:                                  # the baseline must never break the bench line
             cpu_base = {"error": repr(e)}
 
@@ -161,54 +424,102 @@ def main():
     ex = None
     if world > 1:
         ex = comm.make_exchange(rank, world, dev, prefer="rccl" if args.backend in ("rccl", "nccl") else "file")
+    not_rccl = ex is not None and ex.name != "rccl"
+    if not_rccl and not args.allow_file_exchange and rank == 0:
+        log("bench.py: the exchange is '%s', not RCCL -- the line below is NOT a multi-GPU RCCL measurement; exiting %d "
+            "(--allow-file-exchange accepts it for debugging)" % (ex.name, EXIT_NOT_RCCL))
 
-    per_gpu = int(cfg["gib"] * GiB) // (16 * 2 * N) * (16 * 2 * N)
+    def finish(ok):
+        if ex is not None:
+            ex.barrier()
+            ex.close()
+            comm.finish(rank, world)
+        if ok is False:
+            return 1
+        return EXIT_NOT_RCCL if (not_rccl and not args.allow_file_exchange) else 0
+
+    if args.config == "cfg5":
+        return finish(run_cfg5(args, rank, world, dev, ex, cpu_base))
+
+    cfg = dict(CONFIGS[args.config])
+    standard = args.gib_per_gpu is None and args.key_bits is None
+    W = args.of if emu is not None else N                       # ranks of the job whose step this process runs
+    R = emu if emu is not None else rank
+    if W > 1:
+        cfg = dict(key_bits=256, gib=16.0, pt_seed=0xAE5C0004, fixture=None)
+    if args.gib_per_gpu is not None:
+        cfg["gib"] = args.gib_per_gpu
+    if args.key_bits is not None:
+        cfg["key_bits"] = args.key_bits
+
+    per_gpu = int(cfg["gib"] * GiB) // (16 * 2 * W) * (16 * 2 * W)
     key_bits = cfg["key_bits"]
     key = sharding.splitmix64_bytes(KEY_SEED, key_bits // 8)     # key and IV from the synthetic streams
     iv0 = sharding.splitmix64_bytes(IV_SEED, 12)
 
-    ctx = lib.Context(key, device=dev)
+    plan = sharding.plan_job(W, per_gpu, R)
+    M = len(plan)
+    n_ctx = 1 if W == 1 else max(1, min(args.contexts if args.contexts > 0 else 4, M))
+    ctxs = [lib.Context(key, device=dev) for _ in range(n_ctx)]
+    ctx = ctxs[0]
     geo = ctx.geometry()
     d_pt = lib.DeviceBuffer(per_gpu, device=dev)
     d_ct = lib.DeviceBuffer(per_gpu, device=dev)
 
-    plan = sharding.plan_job(N, per_gpu, rank)
+    def fixture_name(m):
+        if not standard:
+            return None
+        return cfg["fixture"] if W == 1 else ("cfg4_aes256_msg%d_32GiB" % m["msg"] if m["total"] == 32 * GiB else None)
+
     msgs = []
     for m in plan:
-        fixture = None
-        if standard:
-            fixture = cfg["fixture"] if N == 1 else ("cfg4_aes256_msg%d_32GiB" % m["msg"] if m["total"] == 32 * GiB else None)
         msgs.append(dict(iv=sharding.tweak_iv(iv0, m["iv_tweak"]), total=m["total"], first_block=m["first_block"],
-                         off=m["off"], len=m["len"], fixture=fixture))
+                         off=m["off"], len=m["len"], fixture=fixture_name(m)))
         d_pt.fill_splitmix64(cfg["pt_seed"], m["stream_word"], nbytes=m["len"], offset=m["off"])
-    M = len(msgs)
-    if N == 1:
+    if W == 1:
         workload = "%s: AES-%d-GCM, one %.3g GiB message, SplitMix64 PT seed 0x%X, empty AAD%s" % (
             args.config if standard else "custom", key_bits, per_gpu / GiB, cfg["pt_seed"], ", DECRYPT + authenticate" if args.decrypt else "")
-    else:
-        workload = ("cfg4 cut to %d ranks: %d AES-%d-GCM message(s) of %.3g GiB (SplitMix64 seed 0xAE5C0004), each sharded over "
-                    "all %d ranks, one 16 B x %d x %d all-gather per step (%s)" % (N, M, key_bits, msgs[0]["total"] / GiB, N, N, M, ex.name))
     lib.dev_sync(dev)
 
-    if ex is not None:
+    if W > 1:
         local_parts = lib.DeviceBuffer(16 * M, device=dev)
-        gathered = lib.DeviceBuffer(16 * M * world, device=dev)     # [rank][message][16] after the all-gather
+        gathered = lib.DeviceBuffer(16 * M * W, device=dev)         # [rank][message][16] after the all-gather
+    if emu is not None:
+        # the other ranks' REAL partials, computed here one shard at a time (untimed), so that the finalizes of the timed
+        # step produce the job's real tags and can be checked against the cfg4 fixtures
+        ex = EmulatedExchange(lib, R, W, dev)
+        scratch = lib.DeviceBuffer(max(m["len"] for m in plan), device=dev)
+        for rr in range(W):
+            if rr == R:
+                continue
+            for i, m in enumerate(sharding.plan_job(W, per_gpu, rr)):
+                scratch.fill_splitmix64(cfg["pt_seed"], m["stream_word"], nbytes=m["len"])
+                ctx.shard_crypt_dev(False, sharding.tweak_iv(iv0, m["iv_tweak"]), scratch.ptr, m["len"], scratch.ptr, m["first_block"], m["total"],
+                                    gathered.ptr + 16 * (rr * M + i))
+            lib.dev_sync(dev)
+        scratch.free()
+    if W > 1:
+        workload = ("%scfg4 cut to %d ranks: %d AES-%d-GCM message(s) of %.3g GiB (SplitMix64 seed 0xAE5C0004), each sharded over "
+                    "all %d ranks, one 16 B x %d x %d all-gather per step (%s), %d context(s) per rank" % (
+                        "rank %d of " % R if emu is not None else "", W, M, key_bits, msgs[0]["total"] / GiB, W, W, M, ex.name, n_ctx))
 
     expect_tag = None
-    cstream = ctx.stream()
 
-    def step():
+    def step(cs=None):
         """one pass over the resident workload; returns the list of tags (bytes) -- fetching a tag syncs the stream"""
-        if ex is None:
+        cs = ctxs if cs is None else cs
+        if W == 1:
             m = msgs[0]
             if args.decrypt:
                 return [ctx.decrypt_dev(m["iv"], d_ct.ptr, m["len"], d_pt.ptr, tag=expect_tag)]
             return [ctx.encrypt_dev(m["iv"], d_pt.ptr, m["len"], d_ct.ptr)]
-        for i, m in enumerate(msgs):
-            ctx.shard_crypt_dev(False, m["iv"], d_pt.ptr + m["off"], m["len"], d_ct.ptr + m["off"], m["first_block"], m["total"],
-                                local_parts.ptr + 16 * i, stream=cstream)
-        ex.allgather_dev(local_parts.ptr, gathered.ptr, 16 * M, stream=cstream)    # the context's stream: ordered after the partials
-        return [ctx.shard_finalize_dev(m["iv"], gathered.ptr + 16 * i, world, 0, m["total"], stride_bytes=16 * M, stream=cstream)
+        for i, m in enumerate(msgs):                                 # message i on context i mod K: own stream, own scratch
+            cs[i % len(cs)].shard_crypt_dev(False, m["iv"], d_pt.ptr + m["off"], m["len"], d_ct.ptr + m["off"], m["first_block"], m["total"],
+                                            local_parts.ptr + 16 * i)
+        for c in cs[1:]:
+            cs[0].wait(c)                                            # the all-gather needs every context's partials: stream-ordered, no host sync
+        ex.allgather_dev(local_parts.ptr, gathered.ptr, 16 * M, stream=cs[0].stream())
+        return [cs[0].shard_finalize_dev(m["iv"], gathered.ptr + 16 * i, W, 0, m["total"], stride_bytes=16 * M)
                 for i, m in enumerate(msgs)]
 
     def barrier():
@@ -233,14 +544,14 @@ def main():
     if checked:
         tag_ok = all(checked)
     ct_ok = None
-    if N == 1 and msgs[0]["fixture"]:
+    if W == 1 and msgs[0]["fixture"]:
         fx = load_fixture(msgs[0]["fixture"])
         if fx is not None:
             head = bytes(d_ct.download(64, 0))
             tail = bytes(d_ct.download(64, per_gpu - 64))
             ct_ok = (head.hex() == fx["ct_head"] and tail.hex() == fx["ct_tail"])
     selfcheck = None
-    if args.selfcheck and ex is not None and rank == 0:
+    if args.selfcheck and W > 1 and emu is None and rank == 0:
         selfcheck = True
         for m, t in zip(plan, tags):
             whole_pt, whole_ct = lib.DeviceBuffer(m["total"], device=dev), lib.DeviceBuffer(m["total"], device=dev)
@@ -259,7 +570,8 @@ def main():
 
     # ---- timed region: exactly K steps between barrier + synchronize on both sides; timing mode OFF (no event
     # records, no trace memset, no in-kernel trace atomics inside it)
-    ctx.timing_enable(False)
+    for c in ctxs:
+        c.timing_enable(False)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -277,11 +589,12 @@ def main():
     value = total_bytes / dt / GiB
 
     # ---- separate short pass with timing mode ON: HIP events around each launch of the fused kernel on its own
-    # stream, the per-workgroup trace (shader clock), then the same instruction stream without HBM traffic
+    # stream (ONE context, so the launches do not overlap), the per-workgroup trace (shader clock), then the same
+    # instruction stream without HBM traffic
     ctx.timing_enable(True)
     ctx.timing_read(reset=True)
     for _ in range(min(3, max(1, args.steps))):
-        step()
+        step([ctx])
     lib.dev_sync(dev)
     n_launch, kernel_ms = ctx.timing_read(reset=True)
     sclk = None
@@ -335,7 +648,7 @@ def main():
 
         # HBM traffic from the committed PMC summary -- only when it was measured on THIS build of the library
         so_sha = sha256_file(SO)
-        tag_name = ("%s_n1" % args.config) if N == 1 else "cfg4_n%d" % N
+        tag_name = ("%s_n1" % args.config) if W == 1 else "cfg4_n%d" % W
         pm = pmc_summary(tag_name) if standard and not args.decrypt else {}
         same_build = bool(pm) and pm.get("so_sha256") == so_sha
         traffic = pm.get("hbm_bytes_per_launch") if same_build else None
@@ -346,7 +659,7 @@ def main():
                     "traffic_build": {"pmc_so_sha256": pm.get("so_sha256"), "pmc_git": pm.get("git"), "running_so_sha256": so_sha,
                                       "running_git": git_head(), "match": same_build},
                     "alg_bytes_per_launch": alg_bytes, "launches_timed": n_launch, "avg_launch_ms": round(avg_s * 1e3, 4),
-                    "timing": "HIP events on the launch stream in a separate %d-step pass after the timed region (timing mode is off inside it)" % min(3, max(1, args.steps)),
+                    "timing": "HIP events on the launch stream in a separate %d-step pass after the timed region (timing mode is off inside it; one context, launches back to back)" % min(3, max(1, args.steps)),
                     "sclk_mhz": sclk,
                     "lds_busy_frac": (pm.get("lds") or {}).get("lds_busy_frac") if same_build else None,
                     "formulation_ceiling": ceiling,
@@ -356,22 +669,24 @@ def main():
             "value": round(value, 3), "unit": "GiB/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": workload, "bytes_per_gpu": per_gpu, "messages_per_step": M,
-                       "parallelism": "single" if N == 1 else "shard%d" % N, "key_bits": key_bits,
+            "config": {"workload": workload, "bytes_per_gpu": per_gpu, "messages_per_step": M, "contexts_per_rank": n_ctx,
+                       "parallelism": "single" if W == 1 else "shard%d" % W, "key_bits": key_bits,
                        "workgroups": geo["workgroups"], "wg_lanes": geo["wg_lanes"], "lds_bytes_per_wg": geo["lds_bytes"],
                        "exchange": None if ex is None else {"backend": ex.name, "ranks_seen": ex.world, "torch": "not imported"}},
             "tag_ok": tag_ok, "ct_head_tail_ok": ct_ok, "selfcheck": selfcheck, "tags": [t.hex() for t in tags],
             "roofline": roofline,
         }
+        if emu is not None:
+            line["emulated"] = {"rank": R, "of": W, "what": "ONE GPU runs rank %d's step of the %d-GPU cfg4 job: its shard of every message at the real "
+                                "first_block, a device copy in place of the RCCL all-gather, every finalize; `value` is this one rank's GiB/s "
+                                "(the %d-GPU aggregate would be %d x the slowest rank, less the all-gather latency)" % (R, W, W, W)}
         if cpu_base is not None:
             line["cpu_baseline"] = cpu_base
         print(json.dumps(line), flush=True)
 
-    if ex is not None:
-        ex.barrier()
-        ex.close()
-        comm.finish(rank, world)
-    return 0 if tag_ok is not False else 1
+    if emu is not None:
+        ex = None
+    return finish(tag_ok)
 
 
 if __name__ == "__main__":

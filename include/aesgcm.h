@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define AESGCM_ABI_VERSION 1
+#define AESGCM_ABI_VERSION 2   /* 2: aesgcm_ctx_wait, aesgcm_comm_* / aesgcm_mgpu_*, packet and batch entry points as listed below */
 
 #if defined(__GNUC__)
 #define AESGCM_API __attribute__((visibility("default")))
@@ -106,6 +106,12 @@ AESGCM_API int aesgcm_ctx_device(const aesgcm_ctx *ctx);
 /* the context's own HIP stream (what `stream = NULL` means everywhere): lets a caller order other work -- the
  * aesgcm_comm_allgather_dev of the partials -- behind the context's kernels without a host synchronisation */
 AESGCM_API int aesgcm_ctx_stream(const aesgcm_ctx *ctx, void **stream);
+/* Stream-order two contexts of one device without a host synchronisation: what is enqueued on ctx's own stream AFTER this call
+ * starts only when everything enqueued on other's own stream BEFORE it has completed.  A context owns one scratch set, so
+ * back-to-back messages (the shards of bench.py's N > 1 step) alternate between two contexts of the same key: message m+1's
+ * fused kernel then runs while message m's fold / combine kernels drain; the step that consumes both (the all-gather of the
+ * partials) is ordered with this call.  No reference counterpart (the RTL has one pipeline, src/aes_gcm.vhd). */
+AESGCM_API int aesgcm_ctx_wait(aesgcm_ctx *ctx, aesgcm_ctx *other);
 
 /* ---------------------------------------------------------------- whole messages, host pointers
  * Replaces the model's update/encrypt/digest sequence (tb/gcm_model.py:21-35) i.e. the aes_gcm
@@ -270,6 +276,16 @@ AESGCM_API int aesgcm_dev_copy(int device, void *d_dst, const void *d_src, size_
 /* SplitMix64 counter-based synthetic stream: little-endian 64-bit word w of stream
  * `seed` for w = first_word ..; bytes [0, len) of the buffer. */
 AESGCM_API int aesgcm_fill_splitmix64_dev(int device, void *d_buf, size_t len, uint64_t seed, uint64_t first_word, void *stream);
+
+/* A pair of HIP events: aesgcm_timer_start / _stop record them on `stream` (NULL = the default stream) around whatever the
+ * caller enqueues there; aesgcm_timer_ms waits for the second and returns the elapsed device time.  For timing launches
+ * of the context-free entry points (bench.py --config cfg5: aesgcm_batch_crypt_dev) on the stream they run on. */
+typedef struct aesgcm_timer aesgcm_timer;
+AESGCM_API int aesgcm_timer_create(aesgcm_timer **out, int device);
+AESGCM_API int aesgcm_timer_start(aesgcm_timer *t, void *stream);
+AESGCM_API int aesgcm_timer_stop(aesgcm_timer *t, void *stream);
+AESGCM_API int aesgcm_timer_ms(aesgcm_timer *t, double *ms);
+AESGCM_API int aesgcm_timer_destroy(aesgcm_timer *t);
 
 /* ---------------------------------------------------------------- measurement support
  * When enabled, every launch of the fused CTR+GHASH kernel on this context is bracketed with HIP

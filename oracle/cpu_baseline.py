@@ -168,6 +168,96 @@ def port_rate(n_threads, per_thread=32 << 20):
             "what": "oracle/aesgcm_oracle.c orc_fast (plain C tables, no AES-NI): the checker's own speed, not the baseline"}
 
 
+# ---------------------------------------------------------------- BASELINE config 5: per-packet key and IV
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def evp_batch_lib():
+    """oracle/libevpbatch.so (oracle/evp_batch.c: the per-packet EVP loop in C, linked against the system libcrypto)"""
+    import ctypes
+    import subprocess
+    so = os.path.join(_HERE, "libevpbatch.so")
+    src = os.path.join(_HERE, "evp_batch.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "evp"])
+    L = ctypes.CDLL(so)
+    vp, sz = ctypes.c_void_p, ctypes.c_size_t
+    L.evp_batch_encrypt.argtypes = [sz, sz, vp, vp, vp, sz, vp, vp]
+    return L
+
+
+def cfg5_inputs(first, n, pkt_len=4096, key_len=16):
+    """packets [first, first + n) of the cfg5 streams as numpy arrays: keys (stream 0x4B4559, key_len bytes each), IVs (the
+    first 12 bytes of every 16 of stream 0x4956), plaintext (stream 0xAE5C0005)"""
+    import numpy as np
+    from oracle import oracle as O
+    keys = np.frombuffer(O.fill_splitmix64(key_len * n, KEY_SEED, first * key_len // 8), dtype=np.uint8)
+    ivw = np.frombuffer(O.fill_splitmix64(16 * n, IV_SEED, first * 2), dtype=np.uint8).reshape(n, 16)
+    ivs = np.ascontiguousarray(ivw[:, :12]).reshape(-1)
+    pt = np.frombuffer(O.fill_splitmix64(pkt_len * n, 0xAE5C0005, first * pkt_len // 8), dtype=np.uint8)
+    return keys, ivs, pt
+
+
+def _worker5(idx, n, pkt_len, key_len, passes, reps, start, done, out_q):
+    import numpy as np
+    L = evp_batch_lib()
+    keys, ivs, pt = cfg5_inputs(idx * n, n, pkt_len, key_len)
+    ct, tags = np.empty(pkt_len * n, dtype=np.uint8), np.empty(16 * n, dtype=np.uint8)
+    for _ in range(reps):
+        start.wait()
+        t0 = time.perf_counter()
+        for _ in range(passes):
+            rc = L.evp_batch_encrypt(n, key_len, keys.ctypes.data, ivs.ctypes.data, pt.ctypes.data, pkt_len, ct.ctypes.data, tags.ctypes.data)
+        dt = time.perf_counter() - t0
+        done.wait()
+        out_q.put((idx, dt, rc))
+
+
+def _run5(n_workers, n, pkt_len, key_len, passes, reps):
+    ctx = mp.get_context("fork")
+    start, done, q = ctx.Barrier(n_workers + 1), ctx.Barrier(n_workers + 1), ctx.Queue()
+    ps = [ctx.Process(target=_worker5, args=(i, n, pkt_len, key_len, passes, reps, start, done, q), daemon=True) for i in range(n_workers)]
+    for p in ps:
+        p.start()
+    rates = []
+    for _ in range(reps):
+        start.wait(timeout=600)
+        t0 = time.perf_counter()
+        done.wait(timeout=600)
+        wall = time.perf_counter() - t0
+        for _ in range(n_workers):
+            if q.get(timeout=60)[2] != 0:
+                raise RuntimeError("evp_batch_encrypt failed")
+        rates.append(n_workers * n * passes / wall)            # packets per second
+    for p in ps:
+        p.join(timeout=30)
+    return rates
+
+
+def measure_cfg5(reps=3, pkts_per_worker=1 << 15, passes=32, pkt_len=4096, key_len=16):
+    """-> the `cpu_baseline` object of the cfg5 bench line: libcrypto, one EVP init (key + IV) per packet, the loop in C.
+    A bounded sample: every worker encrypts `pkts_per_worker` packets of the cfg5 streams `passes` times per repetition."""
+    from oracle import libcrypto_ref as R
+    cores = usable_cores()
+    model, flags = cpu_info()
+    if not R.available():
+        return {"error": "libcrypto not available", "cores": cores, "cpu_model": model}
+    r1 = _run5(1, pkts_per_worker, pkt_len, key_len, passes, reps)
+    rn = _run5(cores, pkts_per_worker, pkt_len, key_len, passes, reps)
+    to_gib = pkt_len / GiB
+    return {
+        "value": round(max(rn) * to_gib, 3), "unit": "GiB/s", "cores": cores, "kind": "library",
+        "lib": "libcrypto EVP_aes_%d_gcm (%s), one EVP_EncryptInit_ex(key, iv) per packet, per-packet loop in C (oracle/evp_batch.c); stands in for "
+               "pycryptodome, which is not installed (BASELINE.md 2)" % (8 * key_len, R.version()),
+        "value_median": round(statistics.median(rn) * to_gib, 3), "mpkt_per_s": round(max(rn) / 1e6, 3),
+        "value_1core": round(max(r1) * to_gib, 3), "value_1core_median": round(statistics.median(r1) * to_gib, 3), "mpkt_per_s_1core": round(max(r1) / 1e6, 3),
+        "cpu_model": model, "cpu_flags": flags, "reps": reps,
+        "sample": "AES-%d-GCM, cfg5 streams (keys 0x4B4559, IVs 0x4956, plaintext 0xAE5C0005): %d worker process(es) x %d packets of %d B, each packet "
+                  "under its own key and IV, encrypted %d times over per repetition (%.2f GiB per repetition in all); wall clock around the calls, "
+                  "best of %d (median beside it)" % (8 * key_len, cores, pkts_per_worker, pkt_len, passes, cores * pkts_per_worker * passes * pkt_len / GiB, reps),
+    }
+
+
 if __name__ == "__main__":
     import json
     print(json.dumps(measure(), indent=1))

@@ -3,6 +3,7 @@ and refuses to compute without a GPU (no CPU fallback)."""
 import os
 import re
 import subprocess
+import sys
 
 import pytest
 
@@ -29,7 +30,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     exported = set(re.findall(r" T (aesgcm_\w+)", out))
     assert exported == set(declared_symbols())
     L = lib.load()
-    assert L.aesgcm_abi_version() == 1
+    assert L.aesgcm_abi_version() == lib.ABI_VERSION == 2
     for s in declared_symbols():
         assert hasattr(L, s)
 
@@ -51,7 +52,7 @@ def test_strerror_covers_all_codes():
 
 def test_header_compiles_as_plain_c():
     # the boundary is a C ABI: the header must be consumable by gcc -std=c99 with no HIP/C++ types
-    code = '#include "aesgcm.h"\nint main(void){return AESGCM_ABI_VERSION==1?0:1;}\n'
+    code = '#include "aesgcm.h"\nint main(void){return AESGCM_ABI_VERSION==2?0:1;}\n'
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-x", "c", "-", "-fsyntax-only"],
                    input=code.encode(), check=True)
 
@@ -121,3 +122,16 @@ def test_host_splitmix_matches_the_oracle_generator():
     from oracle import oracle as O
     for seed, n, w in ((0x4B4559, 32, 0), (0x4956, 12, 0), (7, 100, 0), (5, 24, 3)):
         assert sharding.splitmix64_bytes(seed, n, w) == bytes(O.fill_splitmix64(n, seed, w))
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
+def test_bench_self_launch_fails_loudly_without_gpu():
+    """`python bench.py --gpus 2` with no launcher starts two rank processes itself; without a device every rank fails, and the
+    parent must exit non-zero and print no bench line (never a silent 1-GPU measurement)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
+                        "--gib-per-gpu", "0.01", "--launch-timeout", "120"], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=300)
+    assert p.returncode != 0
+    assert "{" not in p.stdout
+    assert "rank exit codes" in p.stderr

@@ -37,7 +37,7 @@ def test_two_processes_product_shard_path_one_gpu(hip, orc):
             env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), AESGCM_RDZV_DIR=rdzv,
                        MASTER_ADDR="127.0.0.1", MASTER_PORT="29555")
             cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "file", "--one-device",
-                   "--gib-per-gpu", str(per_rank_gib), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--selfcheck"]
+                   "--gib-per-gpu", str(per_rank_gib), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--selfcheck", "--allow-file-exchange"]
             procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT))
         outs = []
         try:
