@@ -368,7 +368,7 @@ HD void ctr_rounds_lds(u32 ctr_be_word, const CtrConsts &k, u32 &s0, u32 &s1, u3
 // (.z .w); row 26 stays empty so that the two halves are 6912 bytes apart, NOT a multiple of 512: otherwise the compiler
 // fuses the pair into one ds_read2st64_b64, which the LDS serves as 2 x (4 x 16 lanes) = 8 cycles instead of 2 + 2.
 // ------------------------------------------------------------------------------------------------
-HD uint4 ghash_mul_const_lds(uint4 y, const unsigned char *lds) {
+HD uint4 ghash_mul_q5_lds(uint4 y, const unsigned char *lds, const u32 base) {
     const u32 w[4] = {y.x, y.y, y.z, y.w};
     u32 r[4] = {0, 0, 0, 0}, t[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -378,20 +378,22 @@ HD uint4 ghash_mul_const_lds(uint4 y, const unsigned char *lds) {
         if (sh > 27 && wi < 3) x = (u32)((((u64)w[wi + 1] << 32) | w[wi]) >> (sh - 3));
         else x = sh >= 3 ? w[wi] >> (sh - 3) : w[wi] << (3 - sh);
         const u32 a = x & 0xF8u;
-        const u32x2_t l = LDS_LD64(lds, a + (AESGCM_LDS_GH_OFF + (u32)p * 256u));
-        const u32x2_t h = LDS_LD64(lds, a + (AESGCM_LDS_GH_OFF + (u32)(AESGCM_Q5_HI_ROW + p) * 256u));
+        const u32x2_t l = LDS_LD64(lds, a + (base + (u32)p * 256u));
+        const u32x2_t h = LDS_LD64(lds, a + (base + (u32)(AESGCM_Q5_HI_ROW + p) * 256u));
         if (p & 1) { r[0] = xor3(r[0], t[0], l.x); r[1] = xor3(r[1], t[1], l.y); r[2] = xor3(r[2], t[2], h.x); r[3] = xor3(r[3], t[3], h.y); }
         else { t[0] = l.x; t[1] = l.y; t[2] = h.x; t[3] = h.y; }
     }
     return make_uint4(r[0], r[1], r[2], r[3]);
 }
+// the launch constant's tables at LDS offset 0 (the row loops): the table base rides in the ds_read offset field
+HD uint4 ghash_mul_const_lds(uint4 y, const unsigned char *lds) { return ghash_mul_q5_lds(y, lds, AESGCM_LDS_GH_OFF); }
 // what thread `tid` of `nthreads` writes of the LDS image of a five-bit table set `src` (AESGCM_Q5_ENTRIES entries, p*32 + v)
-HD void fill_lds_q5(unsigned char *smem, const uint4 *src, u32 tid, u32 nthreads) {
+HD void fill_lds_q5(unsigned char *smem, const uint4 *src, u32 tid, u32 nthreads, u32 base = AESGCM_LDS_GH_OFF) {
     for (u32 q = tid; q < AESGCM_Q5_ENTRIES; q += nthreads) {
         const uint4 e = src[q];
         const u32 p = q >> 5, v = q & 31u;
-        u32 *lo = reinterpret_cast<u32 *>(smem + AESGCM_LDS_GH_OFF + p * 256u + v * 8u);
-        u32 *hi = reinterpret_cast<u32 *>(smem + AESGCM_LDS_GH_OFF + (AESGCM_Q5_HI_ROW + p) * 256u + v * 8u);
+        u32 *lo = reinterpret_cast<u32 *>(smem + base + p * 256u + v * 8u);
+        u32 *hi = reinterpret_cast<u32 *>(smem + base + (AESGCM_Q5_HI_ROW + p) * 256u + v * 8u);
         lo[0] = e.x; lo[1] = e.y; hi[0] = e.z; hi[1] = e.w;
     }
 }
@@ -430,14 +432,16 @@ struct DevTables {           // per device
 
 #define AESGCM_NPTAB 26
 #define AESGCM_NLTAB 66
+#define AESGCM_NQ5POW 7
 struct KeyMaterial {         // per context (device memory)
     u32 rk[60];              // expanded key, memory-order words
     u32 nr;
     u32 _pad[3];
     uint4 h;                 // H = E_K(0^128)
     uint4 pw[4][AESGCM_NPW]; // pw[d][k] = H^(k * WG^d)
-    uint4 ktab[AESGCM_Q5_ENTRIES];   // five-bit tables of K = H^64 (lane stride of a wave): entry p*32+v = quint_elem_mo(p, v) * K
-    uint4 htab[AESGCM_Q5_ENTRIES];   // ... of H itself (k_pktl: one lane per packet, serial Horner)
+    uint4 q5pow[AESGCM_NQ5POW][AESGCM_Q5_ENTRIES];   // five-bit tables of H^(2^j), j = 0 .. 6: entry p*32+v = quint_elem_mo(p, v) * H^(2^j).  [6] = K = H^64, the lane
+                                     // stride of a wave (k_main); [0] = H itself (k_pktl: one lane per packet, serial Horner); k_pktg: Horner stride H^(lanes per packet)
+                                     // and the constants of the cross-lane tree H, H^2, H^4, ...
     uint4 k4tab[AESGCM_Q5_ENTRIES];  // ... of H^256 (k_body: a wave takes every fourth row)
     uint4 ptab[AESGCM_NPTAB][512]; // nibble tables of H^(2^k), k = 6 .. 31: the Horner constants of k_fold when chunk sizes are powers of two
     uint4 ltab[AESGCM_NLTAB][32];  // two-table Shoup form of H^e, e = 0 .. 65: [e][v] = v*H^e, [e][16 + v] = v*H^e*x^4 (per-lane constant multiplies of the closing steps)
@@ -571,13 +575,13 @@ HD bool setup_level(const uint4 *tab, int j, int tid, uint4 *prod) {
     *prod = gf_mul_mo(tab[tid], tab[base]);
     return true;
 }
-// after the beta table (d == 1) is complete: the five-bit tables of the fixed Horner constants H^64, H, H^256
+// after the beta table (d == 1) is complete: the five-bit tables of the fixed Horner / tree constants H^(2^j) (j = 0 .. 6) and H^256
 HD void setup_beta_lane(KeyMaterial *km, const uint4 *tab, int tid) {
     (void)tab;
-    for (int q = tid; q < 3 * AESGCM_Q5_ENTRIES; q += AESGCM_WG) {              // 2496 entries over the workgroup: at most three each
+    for (int q = tid; q < (AESGCM_NQ5POW + 1) * AESGCM_Q5_ENTRIES; q += AESGCM_WG) {     // 6656 entries over the workgroup: at most seven each
         const int which = q / AESGCM_Q5_ENTRIES, e = q % AESGCM_Q5_ENTRIES;
-        const uint4 c = which == 0 ? km->pw[0][64] : which == 1 ? km->h : km->pw[0][256];
-        (which == 0 ? km->ktab : which == 1 ? km->htab : km->k4tab)[e] = gf_mul_mo(quint_elem_mo(e >> 5, (u32)(e & 31)), c);
+        const uint4 c = which < AESGCM_NQ5POW ? km->pw[0][1u << which] : km->pw[0][256];
+        (which < AESGCM_NQ5POW ? km->q5pow[which] : km->k4tab)[e] = gf_mul_mo(quint_elem_mo(e >> 5, (u32)(e & 31)), c);
     }
 }
 
@@ -592,7 +596,7 @@ HD void setup_ptab_lane(KeyMaterial *km, u32 k, u32 tid) {
 enum { GH_TAB_K64 = 0, GH_TAB_H = 1, GH_TAB_K256 = 2 };       // which constant's five-bit tables go to LDS
 HD void main_fill_lds(unsigned char *smem, const KeyMaterial *km, const DevTables *tb, u32 tid, bool gh, u32 nthreads = AESGCM_MAIN_WG, int which = GH_TAB_K64) {
     if (gh) {
-        fill_lds_q5(smem, which == GH_TAB_H ? km->htab : which == GH_TAB_K256 ? km->k4tab : km->ktab, tid, nthreads);
+        fill_lds_q5(smem, which == GH_TAB_H ? km->q5pow[0] : which == GH_TAB_K256 ? km->k4tab : km->q5pow[6], tid, nthreads);
     }
     uint4 *dst = reinterpret_cast<uint4 *>(smem + AESGCM_LDS_AES_OFF);
     for (u32 q = tid; q < AESGCM_LDS_AES / 16; q += nthreads) {
@@ -620,9 +624,17 @@ HD uint4 load_block_bytes(const unsigned char *p, u32 nbytes) {
         const u32 *q = reinterpret_cast<const u32 *>(p);
         return make_uint4(q[0], q[1], q[2], q[3]);
     }
-    u32 w[4] = {0, 0, 0, 0};
-    for (u32 k = 0; k < nbytes; k++) w[k >> 2] |= (u32)p[k] << (8 * (k & 3));
-    return make_uint4(w[0], w[1], w[2], w[3]);
+    // fully unrolled with constant word indices: a loop over w[k >> 2] with a run-time trip count made the compiler keep the
+    // four words in scratch memory (round-2 ISA: scratch_* inside the packet kernels' row loops)
+    u32 w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+#pragma unroll
+    for (u32 k = 0; k < 16; k++) {
+        if (k < nbytes) {
+            const u32 b = (u32)p[k] << (8 * (k & 3));
+            if (k < 4) w0 |= b; else if (k < 8) w1 |= b; else if (k < 12) w2 |= b; else w3 |= b;
+        }
+    }
+    return make_uint4(w0, w1, w2, w3);
 }
 HD void store_block_bytes(unsigned char *p, uint4 v, u32 nbytes) {
     if (nbytes == 16 && (((uintptr_t)p) & 3) == 0) {
@@ -630,17 +642,17 @@ HD void store_block_bytes(unsigned char *p, uint4 v, u32 nbytes) {
         q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w;
         return;
     }
-    const u32 w[4] = {v.x, v.y, v.z, v.w};
-    for (u32 k = 0; k < nbytes; k++) p[k] = (unsigned char)(w[k >> 2] >> (8 * (k & 3)));
-}
-HD uint4 mask_block(uint4 v, u32 nbytes) {
-    u32 w[4] = {v.x, v.y, v.z, v.w};
-    for (u32 k = 0; k < 4; k++) {
-        int keep = (int)nbytes - 4 * (int)k;           // bytes of word k that are valid
-        if (keep <= 0) w[k] = 0;
-        else if (keep < 4) w[k] &= (1u << (8 * keep)) - 1u;
+#pragma unroll
+    for (u32 k = 0; k < 16; k++) {
+        if (k < nbytes) {
+            const u32 w = k < 4 ? v.x : k < 8 ? v.y : k < 12 ? v.z : v.w;
+            p[k] = (unsigned char)(w >> (8 * (k & 3)));
+        }
     }
-    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+HD u32 mask_word(u32 w, int keep) { return keep <= 0 ? 0u : keep < 4 ? (w & ((1u << (8 * keep)) - 1u)) : w; }   // keep = valid bytes of the word
+HD uint4 mask_block(uint4 v, u32 nbytes) {
+    return make_uint4(mask_word(v.x, (int)nbytes), mask_word(v.y, (int)nbytes - 4), mask_word(v.z, (int)nbytes - 8), mask_word(v.w, (int)nbytes - 12));
 }
 
 // The hot loop: lane `lane` (0..63) of the wave that owns chunk `c`.  Rows of the chunk are consecutive
@@ -1304,10 +1316,26 @@ HD void batch_key_expand(const unsigned char *key, u32 *rk, const unsigned char 
 
 // ================================================================================================
 // Packets under ONE key (the RTL keeps H while no new key is loaded, src/gcm_gctr.vhd:142-144): per-packet IV,
-// AAD and length; key schedule, H and the K = H^64 table come from the context.  One wave per packet.  The
-// packet's GHASH sequence is AAD blocks, data blocks AND the length block, right-aligned into rows; lane L ends
-// with H^(64-L), so the wave fold is already (P*H ^ L)*H.  The lane that holds the length block (always lane
-// 63 of the last row) has no data block to encrypt and computes E_K(IV || 1) in the same instruction stream.
+// AAD and length; key schedule, H and every GHASH table come from the context.
+//
+// k_pktg<NR, DEC, LG>: G = 2^LG lanes per packet, 64 / G packets per wave (LG = 4: four packets of 16 lanes; LG = 6: one
+// packet per wave).  Round 3 rework of k_pkt (one wave per packet), whose counters said (profiles/r02g/pktw_1k: frac 0.05,
+// 2.5 x its algorithmic traffic, LDS busy 0.37): the length block took a slot of the row structure (a 1 KiB packet was two
+// rows, one of them 63/64 empty), the closing was a 128-step bit-serial multiply per lane per packet (~1300 VALU, three AES
+// rows' worth), and the byte loops spilled to scratch inside the row loop.  Now:
+//   * the packet's GHASH sequence (AAD blocks, then data blocks -- NOT the length block) is right-aligned into iterations of
+//     G slots; lane l of the group takes slots l, l + G, ...: Horner with the key's five-bit LDS table of H^G (acc = acc *
+//     H^G ^ X, ghash_mul_const_lds), the same row loop as k_main.  A 1 KiB packet is four iterations of its 16 lanes.
+//   * closing without a slot and without a bit-serial step: P = sum_l B_l H^(G-1-l) and tag = P H^2 ^ L H ^ E_K(J0)
+//     (gcm_ghash.vhd:257,293).  Every lane multiplies by H^2 (table); the length block L is XORed into lane G-2; then a
+//     cross-lane tree of LG levels with WAVE-UNIFORM constants H, H^2, H^4, ... (level j: the lane with bit j set takes
+//     partner * H^(2^j) ^ own).  Lane G-2's value meets exactly one more H on its way (level 0), every other path to lane G-1
+//     carries the weights of P: lane G-1 ends with P H^2 ^ L H.  LG + 1 table multiplies per wave-iteration, shared by the
+//     64 / G packets of the wave; the tables (H^(2^j), j < LG, five-bit form, 13.25 KiB each) sit behind the AES tables in LDS.
+//   * E_K(IV || 1) of up to 64 packets comes from ONE extra AES pass per dispenser fetch: lane j encrypts packet j's J0 block
+//     (gcm_ghash.vhd:158-169); the group's last lane picks its packet's value up with a lane shuffle.
+// LDS: [0, 13568) five-bit table of H^G | [13568, +64 KiB) T0 | T2 | [79104 + j * 13568) tree table j.  One 1024-lane workgroup
+// per CU (LG = 4: 130.25 KiB, LG = 6: 156.75 KiB).
 // ================================================================================================
 struct PktParams {
     const unsigned char *ivs;    // n_pkts * 12 bytes
@@ -1320,12 +1348,22 @@ struct PktParams {
     const u64 *data_off;         // n_pkts + 1 offsets, or NULL = fixed pkt_len records
     const u64 *aad_off;          // n_pkts + 1 offsets, or NULL = fixed aad_len records
     u32 *counter; u32 counter_base;
-    u32 deal;                    // packets per dispenser fetch
+    u32 deal;                    // packets per dispenser fetch (k_pktg: a multiple of the packets per wave, at most 64)
     u32 n_pkts, pkt_len, aad_len;
     u32 aligned;                 // in/out base pointers 16-byte aligned
 };
+#define PKTG_LDS_TREE_OFF (AESGCM_LDS_AES_OFF + AESGCM_LDS_AES)                       /* 79104 */
+#define PKTG_LDS_BYTES(LG) (PKTG_LDS_TREE_OFF + (u32)(LG) * (u32)AESGCM_LDS_GH)
+#define PKTG_MAX_DEAL 64u
 
-// per-packet geometry and constants: everything here is wave-uniform
+// what thread `tid` of `nthreads` writes of k_pktg's LDS image
+HD void pktg_fill_lds(unsigned char *smem, const KeyMaterial *km, const DevTables *tb, u32 tid, u32 nthreads, int lg) {
+    main_fill_lds(smem, nullptr, tb, tid, false, nthreads);                                    // T0 | T2
+    fill_lds_q5(smem, km->q5pow[lg], tid, nthreads, AESGCM_LDS_GH_OFF);                        // Horner stride H^G
+    for (int j = 0; j < lg; j++) fill_lds_q5(smem, km->q5pow[j], tid, nthreads, PKTG_LDS_TREE_OFF + (u32)j * (u32)AESGCM_LDS_GH);
+}
+
+// per-packet geometry and constants: uniform over the packet's lane group
 struct PktInfo { u64 doff, aoff; u32 pkt_len, aad_len, iv0, iv1, iv2, aligned; };
 HD PktInfo pkt_info(const PktParams &p, u32 pkt) {
     PktInfo q;
@@ -1336,67 +1374,75 @@ HD PktInfo pkt_info(const PktParams &p, u32 pkt) {
     q.aligned = (p.aligned && ((q.doff & 15) == 0)) ? 1u : 0u;
     const unsigned char *ivp = p.ivs + (size_t)pkt * 12;
     q.iv0 = load_le32(ivp); q.iv1 = load_le32(ivp + 4); q.iv2 = load_le32(ivp + 8);
-    // say "uniform" out loud: the values came through vector loads
-    q.pkt_len = uniform32(q.pkt_len); q.aad_len = uniform32(q.aad_len); q.aligned = uniform32(q.aligned);
-    q.iv0 = uniform32(q.iv0); q.iv1 = uniform32(q.iv1); q.iv2 = uniform32(q.iv2);
-    q.doff = uniform64(q.doff); q.aoff = uniform64(q.aoff);
     return q;
 }
+// iterations of a packet's lane group: its GHASH sequence (AAD blocks + data blocks) in slots of G
+HD u32 pktg_iters(const PktInfo &q, u32 G) { return ((q.aad_len + 15) / 16 + (q.pkt_len + 15) / 16 + G - 1) / G; }
 
-// lane body for one packet; returns the lane's accumulator, *ej0 is meaningful on lane 63 only
-template <int NR, int DEC>
-HD uint4 pkt_lane(const KeyMaterial *__restrict__ km, const PktParams &p, const unsigned char *smem, u32 pkt, u32 lane, uint4 *ej0) {
+// E_K(IV || 0^31 1) of packet `pkt` (gcm_ghash.vhd:158-169), whole cipher from the IV: one lane per packet of a dispenser block
+template <int NR>
+HD uint4 pktg_ej0_lane(const KeyMaterial *__restrict__ km, const PktParams &p, const unsigned char *smem, u32 pkt, u32 lane) {
+    const u32 *__restrict__ rk = km->rk;
+    const unsigned char *ivp = p.ivs + (size_t)pkt * 12;
+    u32 s0 = load_le32(ivp) ^ rk[0], s1 = load_le32(ivp + 4) ^ rk[1], s2 = load_le32(ivp + 8) ^ rk[2], s3 = 0x01000000u ^ rk[3];
+    aes_rounds_lds<NR>(s0, s1, s2, s3, rk, smem, (lane & 31u) << 2);
+    return make_uint4(s0, s1, s2, s3);
+}
+
+// lane l (0 .. G-1) of the group that owns packet `pkt`: CTR over its data blocks and the lane's Horner accumulator
+// B_l = sum_k X[slot G k + l] (H^G)^(q-1-k) over the right-aligned sequence.  `iters` >= the packet's own q: the wave runs to
+// the largest q of its groups under per-lane predicates (iterations beyond a packet's own come FIRST, as front padding).
+template <int NR, int DEC, int LG>
+HD uint4 pktg_lane(const KeyMaterial *__restrict__ km, const PktParams &p, const PktInfo &q, const unsigned char *smem, u32 l, u32 lane, u32 iters, bool act) {
+    constexpr u32 G = 1u << LG;
     const u32 *__restrict__ rk = km->rk;
     const u32 lb = (lane & 31u) << 2;
-    const PktInfo q = pkt_info(p, pkt);
-    const u32 pkt_len = q.pkt_len, aad_len = q.aad_len;
-    const u64 doff = q.doff, aoff = q.aoff;
+    const CtrConsts cc = ctr_round1_consts(q.iv0, q.iv1, q.iv2, rk, smem, lb);      // key and IV only: uniform over the group
+    const u32 n_aad = (q.aad_len + 15) / 16, n_ct = (q.pkt_len + 15) / 16, n_seq = n_aad + n_ct;
+    const u32 pad = G * iters - n_seq;                                              // front padding slots (whole idle iterations included)
+    const unsigned char *src = p.in + q.doff;
+    unsigned char *dst = p.out + q.doff;
     const bool aligned = q.aligned != 0;
-    CtrConsts cc = ctr_round1_consts(q.iv0, q.iv1, q.iv2, rk, smem, lb);      // key/IV only: wave-uniform -> scalar registers
-    cc.c0 = uniform32(cc.c0); cc.c1 = uniform32(cc.c1); cc.c2 = uniform32(cc.c2); cc.c3 = uniform32(cc.c3);
-    const u32 n_aad = (aad_len + 15) / 16, n_ct = (pkt_len + 15) / 16, n_seq = n_aad + n_ct + 1;
-    const u32 rows = (n_seq + 63) / 64, pad = 64 * rows - n_seq;
     uint4 acc = make_uint4(0, 0, 0, 0);
-    *ej0 = make_uint4(0, 0, 0, 0);
-    for (u32 r = 0; r < rows; r++) {
-        if (r) acc = ghash_mul_const_lds(acc, smem);
-        const u32 v = r * 64 + lane;
+    for (u32 k = 0; k < iters; k++) {
+        if (k) acc = ghash_mul_const_lds(acc, smem);
+        const u32 v = k * G + l;
         if (v < pad) continue;
         const u32 j = v - pad;
         uint4 gin;
         if (j < n_aad) {
-            const u32 off = 16 * j, rem = aad_len - off;
-            gin = load_block_bytes(p.aad + aoff + off, rem < 16 ? rem : 16);
+            const u32 off = 16 * j, rem = q.aad_len - off;
+            gin = load_block_bytes(p.aad + q.aoff + off, rem < 16 ? rem : 16);
         } else {
-            // data block i, or (last slot of the sequence) the length block, whose lane encrypts IV || 1 instead:
-            // one AES instance serves both roles
-            const bool is_len = (j == n_aad + n_ct);
-            const u32 i = j - n_aad, off = 16 * i, rem = is_len ? 0u : pkt_len - off;
+            const u32 i = j - n_aad, off = 16 * i, rem = q.pkt_len - off;
             const bool full = aligned && rem >= 16;
-            uint4 x = make_uint4(0, 0, 0, 0);
-            if (full) x = *reinterpret_cast<const uint4 *>(p.in + doff + off);
-            else if (rem) x = load_block_bytes(p.in + doff + off, rem < 16 ? rem : 16);
+            uint4 x;
+            if (full) x = gload16(src + off);
+            else x = load_block_bytes(src + off, rem < 16 ? rem : 16);
             u32 s0, s1, s2, s3;
-            ctr_rounds_lds<NR>(bswap32(is_len ? 1u : 2u + i), cc, s0, s1, s2, s3, rk, smem, lb);
-            if (is_len) {
-                *ej0 = make_uint4(s0, s1, s2, s3);
-                // [8*len(A)]_64 || [8*len(C)]_64 (gcm_ghash.vhd:257) in memory order
-                gin = make_uint4(0u, bswap32(aad_len * 8u), 0u, bswap32(pkt_len * 8u));
-            } else {
-                uint4 y = make_uint4(x.x ^ s0, x.y ^ s1, x.z ^ s2, x.w ^ s3);
-                if (full) *reinterpret_cast<uint4 *>(p.out + doff + off) = y;
-                else { y = mask_block(y, rem < 16 ? rem : 16); store_block_bytes(p.out + doff + off, y, rem < 16 ? rem : 16); }
-                gin = DEC ? x : y;
+            ctr_rounds_lds<NR>(bswap32(2u + i), cc, s0, s1, s2, s3, rk, smem, lb);     // aes_icb.vhd:97-118: counter 2 + i
+            uint4 y = make_uint4(x.x ^ s0, x.y ^ s1, x.z ^ s2, x.w ^ s3);                // gcm_gctr.vhd:150
+            if (rem < 16) y = mask_block(y, rem);
+            if (act) {
+                if (full) gstore16(dst + off, y);
+                else store_block_bytes(dst + off, y, rem < 16 ? rem : 16);
             }
+            gin = DEC ? x : y;                                                          // aes_gcm.vhd:207-211
         }
         acc = xor4(acc, gin);
     }
     return acc;
 }
-// lane L carries H^(64-L): the fold of these is (P*H ^ L)*H
-// (bit-serial on purpose: the same multiply through the key's Shoup tables, km->ltab[64 - lane], is a 32 KiB gather from L2
-// per packet and measured slower at every packet size -- 1 KiB 5.2 -> 7.5 ms, 4 KiB 8.6 -> 11.9 ms for 2^20 packets)
-HD G128 pkt_lane_tail(const KeyMaterial *__restrict__ km, uint4 acc, u32 lane) { return gf_mul(mo_to_be(acc), mo_to_be(km->pw[0][64 - lane])); }
+// closing, step 1 (every lane): B_l * H^2, and the length block [8 len(A)]_64 || [8 len(C)]_64 (gcm_ghash.vhd:257) into lane G-2
+template <int LG>
+HD uint4 pktg_close_lane(uint4 acc, const PktInfo &q, const unsigned char *smem, u32 l) {
+    constexpr u32 G = 1u << LG;
+    acc = ghash_mul_q5_lds(acc, smem, PKTG_LDS_TREE_OFF + 1u * (u32)AESGCM_LDS_GH);
+    if (l == G - 2u) acc = xor4(acc, make_uint4(0u, bswap32(q.aad_len * 8u), 0u, bswap32(q.pkt_len * 8u)));       // both < 2^32 bits by the ABI's limits
+    return acc;
+}
+// closing, tree level j (every lane): the value offered to the partner lane l ^ 2^j, which takes it if its bit j is set
+HD uint4 pktg_tree_offer(uint4 acc, const unsigned char *smem, int j) { return ghash_mul_q5_lds(acc, smem, PKTG_LDS_TREE_OFF + (u32)j * (u32)AESGCM_LDS_GH); }
 
 #ifndef AESGCM_PKTL_GROUP
 #define AESGCM_PKTL_GROUP 4

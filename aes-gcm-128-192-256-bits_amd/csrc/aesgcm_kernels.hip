@@ -45,9 +45,13 @@ __global__ void k_gfmul(const uint4 *h, const uint4 *x, uint4 *z, size_t n) {
     if (i < n) z[i] = gf_mul_mo(x[i], h[i]);
 }
 
-// plain copy, 16 bytes per lane, grid-stride: the measured HBM read+write rate bench.py prints beside the peak
+// plain copy, 16 bytes per lane, ONE element per thread and no loop: the measured HBM read+write rate bench.py prints beside
+// the peak.  Round 2's grid-stride form (8192 x 256 threads looping) reached 4.9 TB/s; this form 6.16 TB/s over the same two
+// 16 GiB buffers on the same box (profiles/r03/copy_variants.txt: tiles of 4 .. 16 loads in flight per lane, nontemporal
+// accesses and hipMemcpyAsync all sit between 4.6 and 5.6) -- the guide's float4-copy figure is 6.29.
 __global__ __launch_bounds__(256) void k_copy16(uint4 *__restrict__ dst, const uint4 *__restrict__ src, u64 n) {
-    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) dst[i] = src[i];
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) gstore16(dst + i, gload16(src + i));
 }
 
 __global__ void k_fill_splitmix64(u64 *buf, size_t n_words, size_t tail_bytes, u64 seed, u64 first_word) {
@@ -236,7 +240,8 @@ __global__ __launch_bounds__(AESGCM_MAIN_WG, AESGCM_WAVES_PER_SIMD) void k_main(
 #define AESGCM_BODY_LDS AESGCM_LDS_BYTES
 #endif
 // the layout assumptions the kernels rely on, checked where they are used
-static_assert(2u * AESGCM_LDS_BYTES <= 160u * 1024u, "k_main / k_pkt / k_pktl: two workgroups must share a CU's 160 KiB of LDS");
+static_assert(2u * AESGCM_LDS_BYTES <= 160u * 1024u, "k_main / k_pktl: two workgroups must share a CU's 160 KiB of LDS");
+static_assert(PKTG_LDS_BYTES(6) <= 160u * 1024u && AESGCM_NQ5POW >= 7, "k_pktg<.., 6>: Horner table, T0 | T2 and six tree tables in one CU's LDS");
 static_assert(AESGCM_BODY_LDS <= 160u * 1024u, "k_body: one workgroup per CU");
 static_assert(AESGCM_LDS_AES_OFF % 128u == 0, "T-table replicas: lane l must read bank l & 31");
 static_assert(AESGCM_LDS_DRY_OFF >= AESGCM_Q5_GROUPS * 256u && AESGCM_LDS_DRY_OFF + 4u <= AESGCM_Q5_HI_ROW * 256u, "the dry-queue mask sits in the spare row between the table halves");
@@ -721,37 +726,61 @@ __global__ __launch_bounds__(AESGCM_WG, 4) void k_batch2(const DevTables *__rest
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_pkt: many packets under the context's key, one wave per packet (lane body: pkt_lane()).
+// k_pktg: many packets under the context's key, 2^LG lanes per packet (lane bodies: pktg_lane(), pktg_close_lane(),
+// pktg_tree_offer(); see "Packets under ONE key" in aesgcm_dev.h).  One 1024-lane workgroup per CU.
 // ------------------------------------------------------------------------------------------------
-template <int NR, int DEC>
-__global__ __launch_bounds__(AESGCM_PKT_WG, 2 * AESGCM_PKT_WG / 256) void k_pkt(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const PktParams p) {
+template <int NR, int DEC, int LG>
+__global__ __launch_bounds__(AESGCM_PKT_WG, AESGCM_PKT_WG / 256) void k_pktg(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const PktParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr u32 G = 1u << LG, P = 64u >> LG;
     const u32 tid = threadIdx.x, lane = tid & 63u;
-    main_fill_lds(smem, km, tb, tid, true, AESGCM_PKT_WG);
+    pktg_fill_lds(smem, km, tb, tid, AESGCM_PKT_WG, LG);
     __syncthreads();
-    // packets are dealt to the waves in blocks of p.deal from a dispenser: one atomic per block keeps the single
-    // dispenser address far below its ~87 M fetches/s ceiling (measured), and late waves still level the tail.
-    // The loop is bounded on purpose (a wave can never own more than nb blocks).
+    const u32 grp = lane >> LG, l = lane & (G - 1u);
+    // packets are dealt to the waves in blocks of p.deal (a multiple of P, at most 64) from a dispenser: one atomic per block
+    // keeps the single dispenser address far below its ~87 M fetches/s ceiling (measured), and late waves still level the
+    // tail.  The loop is bounded on purpose (a wave can never own more than nb blocks).
     const u32 K = p.deal, nb = (p.n_pkts + K - 1) / K;
     for (u32 guard = 0; guard <= nb; ++guard) {
         u32 b = 0;
         if (lane == 0) b = atomicAdd(p.counter, 1u) - p.counter_base;
         b = __builtin_amdgcn_readfirstlane(b);
         if (b >= nb) break;
-        const u32 p0 = b * K, p1 = p0 + K < p.n_pkts ? p0 + K : p.n_pkts;
-        for (u32 pkt = p0; pkt < p1; ++pkt) {
-            uint4 ej0;
-            const uint4 acc = pkt_lane<NR, DEC>(km, p, smem, pkt, lane, &ej0);
-            const G128 z = wave_xor_fold(pkt_lane_tail(km, acc, lane));
-            if (lane == 63) {
-                const uint4 t = be_to_mo(z);
-                const uint4 tag = make_uint4(t.x ^ ej0.x, t.y ^ ej0.y, t.z ^ ej0.z, t.w ^ ej0.w);      // gcm_ghash.vhd:293
+        const u32 p0 = b * K, cnt = (p0 + K < p.n_pkts ? p0 + K : p.n_pkts) - p0;
+        // E_K(IV || 1) of the block's packets, one lane each, in ONE AES pass
+        const uint4 ej = pktg_ej0_lane<NR>(km, p, smem, p0 + (lane < cnt ? lane : 0u), lane);
+        for (u32 t = 0; t * P < cnt; ++t) {
+            const u32 idx = t * P + grp;
+            const bool act = idx < cnt;                          // groups past the end shadow the block's first packet; their stores are masked
+            const u32 pkt = p0 + (act ? idx : 0u);
+            const PktInfo q = pkt_info(p, pkt);
+            // the wave runs to the longest packet of its groups
+            u32 iters = pktg_iters(q, G);
+            if (P > 1) {
+#pragma unroll
+                for (u32 g = 1; g < P; g <<= 1) { const u32 o = (u32)__shfl_xor((int)iters, (int)(g << LG)); iters = o > iters ? o : iters; }
+            }
+            iters = __builtin_amdgcn_readfirstlane(iters);
+            uint4 acc = pktg_lane<NR, DEC, LG>(km, p, q, smem, l, lane, iters, act);
+            acc = pktg_close_lane<LG>(acc, q, smem, l);
+#pragma unroll
+            for (int j = 0; j < LG; j++) {
+                const uint4 o = pktg_tree_offer(acc, smem, j);
+                const u32 ox = (u32)__shfl_xor((int)o.x, 1 << j), oy = (u32)__shfl_xor((int)o.y, 1 << j);
+                const u32 oz = (u32)__shfl_xor((int)o.z, 1 << j), ow = (u32)__shfl_xor((int)o.w, 1 << j);
+                if (l & (1u << j)) { acc.x ^= ox; acc.y ^= oy; acc.z ^= oz; acc.w ^= ow; }
+            }
+            // lane G-1 of the group holds P H^2 ^ L H; its packet's E_K(IV || 1) sits in lane idx of `ej`
+            const int srcl = (int)(act ? idx : 0u);
+            const uint4 e = make_uint4((u32)__shfl((int)ej.x, srcl), (u32)__shfl((int)ej.y, srcl), (u32)__shfl((int)ej.z, srcl), (u32)__shfl((int)ej.w, srcl));
+            if (l == G - 1u && act) {
+                const uint4 tag = xor4(acc, e);                  // gcm_ghash.vhd:293
                 store_block_bytes(p.tags + (size_t)pkt * 16, tag, 16);
                 if (DEC && p.auth) {
                     int ok = 1;
                     if (p.expect) {
-                        const uint4 e = load_block_bytes(p.expect + (size_t)pkt * 16, 16);
-                        ok = ((e.x ^ tag.x) | (e.y ^ tag.y) | (e.z ^ tag.z) | (e.w ^ tag.w)) == 0;
+                        const uint4 x = load_block_bytes(p.expect + (size_t)pkt * 16, 16);
+                        ok = ((x.x ^ tag.x) | (x.y ^ tag.y) | (x.z ^ tag.z) | (x.w ^ tag.w)) == 0;
                     }
                     p.auth[pkt] = ok;
                 }
@@ -848,6 +877,7 @@ struct aesgcm_ctx {
     u32 last_np = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev_sync = nullptr;      // aesgcm_ctx_wait: marks "everything enqueued so far on this context's stream"
+    hipEvent_t ev_fused = nullptr;     // aesgcm_ctx_wait_fused: recorded behind every fused-kernel launch once somebody has asked for it
     // host-API staging
     unsigned char *st_in = nullptr, *st_out = nullptr, *st_aad = nullptr;
     size_t st_in_cap = 0, st_out_cap = 0, st_aad_cap = 0;
@@ -909,7 +939,8 @@ static int set_lds_attrs(int device, DeviceState *ds) {
     SETATTRY(10, MODE_PROBE); SETATTRY(12, MODE_PROBE); SETATTRY(14, MODE_PROBE);
 #undef SETATTRY
 #define SETATTRB(NR, D) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch<NR, D>), hipFuncAttributeMaxDynamicSharedMemorySize, BATCH_LDS_BYTES)); \
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pkt<NR, D>), hipFuncAttributeMaxDynamicSharedMemorySize, AESGCM_LDS_BYTES)); \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktg<NR, D, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, PKTG_LDS_BYTES(4))); \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktg<NR, D, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, PKTG_LDS_BYTES(6))); \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktl<NR, D>), hipFuncAttributeMaxDynamicSharedMemorySize, AESGCM_LDS_BYTES))
     SETATTRB(10, 0); SETATTRB(12, 0); SETATTRB(14, 0); SETATTRB(10, 1); SETATTRB(12, 1); SETATTRB(14, 1);
 #undef SETATTRB
@@ -1006,6 +1037,7 @@ static int enqueue_main(aesgcm_ctx *c, int mode, const uint8_t iv[12], const voi
             return hip_fail(le, "k_main launch");
         }
         if (p.nq) c->qset ^= 1u;                      // the launch leaves the other set zeroed for the next dynamic one
+        if (c->ev_fused) HIPCHK(hipEventRecord(c->ev_fused, st));
     }
     if (timed) { HIPCHK(hipEventRecord(evp.second, st)); c->ev.push_back(evp); }
     if (gh && po && po->done) return AESGCM_OK;                   // the launch finished the tag itself
@@ -1061,6 +1093,7 @@ static int enqueue_body(aesgcm_ctx *c, int mode, const uint8_t iv[12], const Bod
     }
     c->qset ^= 1u;
     if (c->timing) { HIPCHK(hipEventRecord(evp.second, st)); c->ev.push_back(evp); }
+    if (c->ev_fused) HIPCHK(hipEventRecord(c->ev_fused, st));
     // items 4s + v: phases 64 blocks apart inside a super-chunk, super-chunks 256 T blocks apart
     return enqueue_fold(c, c->parts, p.C, 4, 64, (u64)256 * b.T, st, po);
 }
@@ -1313,6 +1346,7 @@ int aesgcm_ctx_destroy(aesgcm_ctx *c) {
     if (c->st_out) hipFree(c->st_out);
     if (c->st_aad) hipFree(c->st_aad);
     if (c->ev_sync) hipEventDestroy(c->ev_sync);
+    if (c->ev_fused) hipEventDestroy(c->ev_fused);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
     return AESGCM_OK;
@@ -1335,6 +1369,20 @@ int aesgcm_ctx_wait(aesgcm_ctx *c, aesgcm_ctx *other) {
     if (!other->ev_sync) HIPCHK(hipEventCreateWithFlags(&other->ev_sync, hipEventDisableTiming));
     HIPCHK(hipEventRecord(other->ev_sync, other->stream));
     HIPCHK(hipStreamWaitEvent(c->stream, other->ev_sync, 0));
+    return AESGCM_OK;
+}
+// As aesgcm_ctx_wait, but only up to `other`'s most recently enqueued FUSED kernel (k_body / k_main), not its fold / combine
+// tail: message m+1's fused kernel (on `c`) then follows message m's (on `other`) back to back, and m's k_fold / k_combine
+// launches run beside it.  (Two contexts that simply start together share the CUs -- k_body is one 141 KiB workgroup per CU --
+// and finish together: that hides one tail in two; chained, all tails but the last hide.)  The event is recorded from the
+// first call on; a wait issued before `other` has launched anything is a no-op.
+int aesgcm_ctx_wait_fused(aesgcm_ctx *c, aesgcm_ctx *other) {
+    if (!c || !other) return AESGCM_EARG;
+    if (c == other) return AESGCM_OK;
+    if (c->device != other->device) return AESGCM_EARG;
+    HIPCHK(hipSetDevice(c->device));
+    if (!other->ev_fused) { HIPCHK(hipEventCreateWithFlags(&other->ev_fused, hipEventDisableTiming)); return AESGCM_OK; }
+    HIPCHK(hipStreamWaitEvent(c->stream, other->ev_fused, 0));
     return AESGCM_OK;
 }
 int aesgcm_ctx_geometry(const aesgcm_ctx *c, int *n_wg, int *wg_lanes, int *lds_bytes) {
@@ -1654,19 +1702,20 @@ int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const vo
     p.n_pkts = (u32)n_pkts; p.pkt_len = (u32)pkt_len; p.aad_len = (u32)aad_len;
     p.aligned = (((uintptr_t)d_in | (uintptr_t)d_out) & 15) == 0 && (d_data_off || pkt_len % 16 == 0);
     const u32 waves_per_wg = AESGCM_PKT_WG / 64;
-    u32 wgs = (u32)((n_pkts + waves_per_wg - 1) / waves_per_wg);
-    if (wgs > (u32)c->G) wgs = (u32)c->G;
-    // shape: one wave per packet (k_pkt) for large packets or few of them, one lane per packet (k_pktl) when there
-    // are enough packets to fill the machine with lanes.  Measured crossover (profiles/packets_sweep.py): the lane
-    // shape wins from about 24 packets per byte of packet length (256 B: 4 Ki packets, 4 KiB: 100 Ki packets);
-    // with offset arrays the host does not know the lengths and goes by count alone.
-    bool by_lane = d_data_off ? n_pkts >= 32768 : (n_pkts >= 2048 && n_pkts >= 24 * pkt_len);
-    if (const char *e = getenv("AESGCM_PKT_SHAPE")) by_lane = (e[0] == 'l');
+    const u32 n_cu = (u32)c->G / 2;                                                 // c->G = two workgroups per CU
+    // shape.  One LANE per packet (k_pktl) when there are enough packets to fill the machine with lanes: measured crossover
+    // (profiles/packets_sweep.py) from about 24 packets per byte of packet length (256 B: 4 Ki packets, 4 KiB: 100 Ki packets);
+    // with offset arrays the host does not know the lengths and goes by count alone.  Otherwise lane GROUPS (k_pktg): 16 lanes per
+    // packet (four packets per wave) once four packets per resident wave exist or the packets are short, else one packet per
+    // wave.  AESGCM_PKT_SHAPE=l|g|w forces lane / 16-lane group / wave.
+    int shape = (d_data_off ? n_pkts >= 32768 : (n_pkts >= 2048 && n_pkts >= 24 * pkt_len)) ? 'l'
+              : (n_pkts >= (size_t)4 * n_cu * waves_per_wg || (!d_data_off && pkt_len <= 1024)) ? 'g' : 'w';
+    if (const char *e = getenv("AESGCM_PKT_SHAPE")) { if (e[0] == 'l' || e[0] == 'g' || e[0] == 'w') shape = e[0]; }
     hipStream_t st = pick_stream(c, stream);
     p.counter = c->d_counter; p.counter_base = c->counter_base;
-    if (by_lane) {
+    if (shape == 'l') {
         const u32 nb = (u32)((n_pkts + 63) / 64);
-        wgs = (nb + waves_per_wg - 1) / waves_per_wg;
+        u32 wgs = (nb + waves_per_wg - 1) / waves_per_wg;
         if (wgs > (u32)c->G) wgs = (u32)c->G;
         c->counter_base += nb + wgs * waves_per_wg;                                 // every wave ends on one failing fetch
 #define LP(NR, D) hipLaunchKernelGGL((k_pktl<NR, D>), dim3(wgs), dim3(AESGCM_PKT_WG), AESGCM_LDS_BYTES, st, c->km, c->tables, p)
@@ -1674,13 +1723,20 @@ int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const vo
         else         { if (c->nr == 10) LP(10, 0); else if (c->nr == 12) LP(12, 0); else LP(14, 0); }
 #undef LP
     } else {
-        // deal: about 16 dispenser fetches per wave, at most 16 packets per fetch
-        u32 deal = (u32)(n_pkts / ((size_t)wgs * waves_per_wg * 16));
-        deal = deal < 1 ? 1 : deal > 16 ? 16 : deal;
-        if (const char *e = getenv("AESGCM_PKT_DEAL")) { const long v = atol(e); if (v >= 1 && v <= 4096) deal = (u32)v; }
+        const int lg = shape == 'g' ? 4 : 6;
+        const u32 P = 64u >> lg;                                                    // packets per wave-iteration
+        // deal: about 4 dispenser fetches per resident wave, a multiple of P, at most 64 packets (one E_K(J0) pass per fetch)
+        u32 deal = (u32)(n_pkts / ((size_t)n_cu * waves_per_wg * 4));
+        deal = deal / P * P;
+        deal = deal < P ? P : deal > PKTG_MAX_DEAL ? PKTG_MAX_DEAL : deal;
+        if (const char *e = getenv("AESGCM_PKT_DEAL")) { const long v = atol(e); if (v >= 1 && v <= (long)PKTG_MAX_DEAL) deal = ((u32)v + P - 1) / P * P; }
         p.deal = deal;
-        c->counter_base += (u32)((n_pkts + deal - 1) / deal) + wgs * waves_per_wg;  // every wave ends on one failing fetch
-#define LP(NR, D) hipLaunchKernelGGL((k_pkt<NR, D>), dim3(wgs), dim3(AESGCM_PKT_WG), AESGCM_LDS_BYTES, st, c->km, c->tables, p)
+        const u32 nb = (u32)((n_pkts + deal - 1) / deal);
+        u32 wgs = (nb + waves_per_wg - 1) / waves_per_wg;
+        if (wgs > n_cu) wgs = n_cu;                                                  // one workgroup per CU (LDS)
+        c->counter_base += nb + wgs * waves_per_wg;                                 // every wave ends on one failing fetch
+#define LP(NR, D) do { if (lg == 4) hipLaunchKernelGGL((k_pktg<NR, D, 4>), dim3(wgs), dim3(AESGCM_PKT_WG), PKTG_LDS_BYTES(4), st, c->km, c->tables, p); \
+                       else hipLaunchKernelGGL((k_pktg<NR, D, 6>), dim3(wgs), dim3(AESGCM_PKT_WG), PKTG_LDS_BYTES(6), st, c->km, c->tables, p); } while (0)
         if (decrypt) { if (c->nr == 10) LP(10, 1); else if (c->nr == 12) LP(12, 1); else LP(14, 1); }
         else         { if (c->nr == 10) LP(10, 0); else if (c->nr == 12) LP(12, 0); else LP(14, 0); }
 #undef LP
@@ -1926,7 +1982,9 @@ int aesgcm_dev_copy(int device, void *d_dst, const void *d_src, size_t bytes, vo
     if (((uintptr_t)d_dst | (uintptr_t)d_src | bytes) & 15) return AESGCM_EALIGN;
     if (!bytes) return AESGCM_OK;
     HIPCHK(hipSetDevice(device));
-    hipLaunchKernelGGL(k_copy16, dim3(8192), dim3(256), 0, (hipStream_t)stream, (uint4 *)d_dst, (const uint4 *)d_src, (u64)(bytes / 16));
+    const u64 n16 = bytes / 16;
+    if ((n16 + 255) / 256 > 0x7FFFFFFFull) return AESGCM_ETOOLONG;
+    hipLaunchKernelGGL(k_copy16, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (uint4 *)d_dst, (const uint4 *)d_src, n16);
     HIPCHK(hipGetLastError());
     return AESGCM_OK;
 }

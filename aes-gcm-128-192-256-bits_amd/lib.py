@@ -18,7 +18,7 @@ ABI_VERSION = 2         # AESGCM_ABI_VERSION of include/aesgcm.h this binding wa
 SYMBOLS = [
     "aesgcm_abi_version", "aesgcm_strerror", "aesgcm_last_error", "aesgcm_device_count", "aesgcm_device_name",
     "aesgcm_key_expand", "aesgcm_ecb_encrypt", "aesgcm_gfmul", "aesgcm_ghash", "aesgcm_get_h",
-    "aesgcm_ctx_create", "aesgcm_ctx_create_preexpanded", "aesgcm_ctx_destroy", "aesgcm_ctx_device", "aesgcm_ctx_stream", "aesgcm_ctx_wait",
+    "aesgcm_ctx_create", "aesgcm_ctx_create_preexpanded", "aesgcm_ctx_destroy", "aesgcm_ctx_device", "aesgcm_ctx_stream", "aesgcm_ctx_wait", "aesgcm_ctx_wait_fused",
     "aesgcm_encrypt_pipelined", "aesgcm_decrypt_pipelined", "aesgcm_host_alloc", "aesgcm_host_free",
     "aesgcm_encrypt", "aesgcm_decrypt", "aesgcm_encrypt_dev", "aesgcm_decrypt_dev", "aesgcm_last_tag",
     "aesgcm_keystream", "aesgcm_keystream_dev",
@@ -76,6 +76,7 @@ def load():
     L.aesgcm_ctx_device.argtypes = [vp]
     L.aesgcm_ctx_stream.argtypes = [vp, ctypes.POINTER(vp)]
     L.aesgcm_ctx_wait.argtypes = [vp, vp]
+    L.aesgcm_ctx_wait_fused.argtypes = [vp, vp]
     L.aesgcm_encrypt.argtypes = [vp, vp, vp, sz, vp, sz, vp, vp]
     L.aesgcm_decrypt.argtypes = [vp, vp, vp, sz, vp, sz, vp, vp, vp]
     L.aesgcm_encrypt_pipelined.argtypes = [vp, vp, vp, sz, vp, sz, vp, vp, sz]
@@ -379,6 +380,10 @@ class Context:
     def wait(self, other):
         """what is enqueued on this context's stream from now on starts after everything enqueued so far on `other`'s"""
         _chk(load().aesgcm_ctx_wait(self._c, other._c))
+
+    def wait_fused(self, other):
+        """... starts after `other`'s most recently enqueued fused kernel (not its fold / combine tail)"""
+        _chk(load().aesgcm_ctx_wait_fused(self._c, other._c))
 
     # unit level
     def h(self):

@@ -388,6 +388,7 @@ def main(argv=None):
                     help="rank 0 also encrypts every whole message alone and compares tags (needs the extra memory)")
     ap.add_argument("--contexts", type=int, default=0,
                     help="N > 1 / --emulate-rank: contexts (stream + scratch set each) a rank's messages rotate over; 0 = one per message, at most 4")
+    ap.add_argument("--no-chain", action="store_true", help="debug: do not chain message i's fused kernel behind message i-1's (the contexts start together)")
     ap.add_argument("--emulate-rank", type=int, default=None, help="on ONE GPU, run exactly this rank's step of the --of W job")
     ap.add_argument("--of", type=int, default=8, help="world size emulated by --emulate-rank")
     ap.add_argument("--launch-timeout", type=float, default=3000.0, help="self-launch: seconds before hung ranks are killed")
@@ -514,6 +515,8 @@ def main(argv=None):
                 return [ctx.decrypt_dev(m["iv"], d_ct.ptr, m["len"], d_pt.ptr, tag=expect_tag)]
             return [ctx.encrypt_dev(m["iv"], d_pt.ptr, m["len"], d_ct.ptr)]
         for i, m in enumerate(msgs):                                 # message i on context i mod K: own stream, own scratch
+            if len(cs) > 1 and i > 0 and not args.no_chain:
+                cs[i % len(cs)].wait_fused(cs[(i - 1) % len(cs)])   # fused kernels back to back; message i-1's fold / combine run beside message i
             cs[i % len(cs)].shard_crypt_dev(False, m["iv"], d_pt.ptr + m["off"], m["len"], d_ct.ptr + m["off"], m["first_block"], m["total"],
                                             local_parts.ptr + 16 * i)
         for c in cs[1:]:

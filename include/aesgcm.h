@@ -112,6 +112,11 @@ AESGCM_API int aesgcm_ctx_stream(const aesgcm_ctx *ctx, void **stream);
  * fused kernel then runs while message m's fold / combine kernels drain; the step that consumes both (the all-gather of the
  * partials) is ordered with this call.  No reference counterpart (the RTL has one pipeline, src/aes_gcm.vhd). */
 AESGCM_API int aesgcm_ctx_wait(aesgcm_ctx *ctx, aesgcm_ctx *other);
+/* The same, but only up to other's most recently enqueued FUSED kernel (the AES-CTR + GHASH launch), not the fold / combine
+ * launches behind it: chaining message m+1 (on ctx) to message m (on other) this way runs the fused kernels back to back and
+ * lets every fold / combine tail but the last hide behind the next message.  Tracking starts with the first call (which,
+ * like any call made before other has launched a fused kernel, waits for nothing). */
+AESGCM_API int aesgcm_ctx_wait_fused(aesgcm_ctx *ctx, aesgcm_ctx *other);
 
 /* ---------------------------------------------------------------- whole messages, host pointers
  * Replaces the model's update/encrypt/digest sequence (tb/gcm_model.py:21-35) i.e. the aes_gcm

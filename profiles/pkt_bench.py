@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Packet-path workloads for profiling (GPU box):  python profiles/pkt_bench.py KIND [--n N] [--len L] [--key-bits B] [--steps K]
   KIND = batch  BASELINE config 5: N packets of L bytes, per-packet key and IV (k_batch), SplitMix64 inputs of SURVEY 8(d)
-         pktw   N packets under ONE key, one wave per packet (k_pkt)
+         pktw   N packets under ONE key, one wave per packet (k_pktg<.., 6>)
+         pktg   N packets under ONE key, 16 lanes per packet (k_pktg<.., 4>)
          pktl   N packets under ONE key, one lane per packet (k_pktl)
 Prints one JSON line: ms per launch (median and best of K, HIP-synchronised wall time), packets/s, GiB/s and the
 algorithmic HBM bytes per launch (32 B per block + key/IV/tag traffic)."""
@@ -16,7 +17,7 @@ import aesgcm_amd  # noqa: E402,F401
 from aesgcm_amd import lib  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("kind", choices=("batch", "pktw", "pktl"))
+ap.add_argument("kind", choices=("batch", "pktw", "pktg", "pktl"))
 ap.add_argument("--n", type=int, default=1 << 20)
 ap.add_argument("--len", type=int, default=4096)
 ap.add_argument("--key-bits", type=int, default=128)
@@ -34,7 +35,7 @@ if a.kind == "batch":
     def go():
         lib.batch_crypt_dev(False, n, kb, d_keys.ptr, d_ivs.ptr, d_pt.ptr, pkt, d_ct.ptr, d_tags.ptr)
 else:
-    os.environ["AESGCM_PKT_SHAPE"] = "w" if a.kind == "pktw" else "l"
+    os.environ["AESGCM_PKT_SHAPE"] = {"pktw": "w", "pktg": "g", "pktl": "l"}[a.kind]
     ctx = lib.Context(bytes(range(kb)))
 
     def go():

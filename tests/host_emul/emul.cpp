@@ -370,15 +370,34 @@ static void test_batch_pieces() {
     }
 }
 
-// packets under one key: per-packet IV/AAD/length, tag = fold of lane tails xor E_K(J0) from lane 63
+// packets under one key, 2^LG lanes per packet (k_pktg): per-packet IV/AAD/length; lane accumulators, the H^2 step with the
+// length block in lane G-2, the cross-lane tree with wave-uniform constants, E_K(J0) from the one-lane-per-packet pass
+template <int NR, int DEC, int LG>
+static uint4 emu_pktg_packet(const KeyMaterial *km, const PktParams &p, const unsigned char *smem, u32 pkt, u32 extra_iters, u32 grp) {
+    constexpr u32 G = 1u << LG;
+    const PktInfo q = pkt_info(p, pkt);
+    const u32 iters = pktg_iters(q, G) + extra_iters;             // a wave runs to the longest packet of its groups
+    uint4 acc[G];
+    for (u32 l = 0; l < G; l++) acc[l] = pktg_close_lane<LG>(pktg_lane<NR, DEC, LG>(km, p, q, smem, l, grp * G + l, iters, true), q, smem, l);
+    for (int j = 0; j < LG; j++) {
+        uint4 o[G];
+        for (u32 l = 0; l < G; l++) o[l] = pktg_tree_offer(acc[l], smem, j);
+        for (u32 l = 0; l < G; l++) if (l & (1u << j)) acc[l] = xor4(acc[l], o[l ^ (1u << j)]);
+    }
+    return xor4(acc[G - 1], pktg_ej0_lane<NR>(km, p, smem, pkt, (pkt * 5 + 3) % 64));
+}
+template <int LG>
+static uint4 emu_pktg(const KeyMaterial *km, int dec, const PktParams &p, const unsigned char *smem, u32 pkt, u32 extra, u32 grp) {
+    if (km->nr == 10) return dec ? emu_pktg_packet<10, 1, LG>(km, p, smem, pkt, extra, grp) : emu_pktg_packet<10, 0, LG>(km, p, smem, pkt, extra, grp);
+    if (km->nr == 12) return dec ? emu_pktg_packet<12, 1, LG>(km, p, smem, pkt, extra, grp) : emu_pktg_packet<12, 0, LG>(km, p, smem, pkt, extra, grp);
+    return dec ? emu_pktg_packet<14, 1, LG>(km, p, smem, pkt, extra, grp) : emu_pktg_packet<14, 0, LG>(km, p, smem, pkt, extra, grp);
+}
 static void test_packets(int key_len, u64 seed) {
     auto key = rnd(key_len, seed);
     Emu E(key.data(), key_len, 0);
-    static unsigned char smem[AESGCM_LDS_BYTES] __attribute__((aligned(16)));
-    for (u32 tid = 0; tid < AESGCM_MAIN_WG; tid++) main_fill_lds(smem, &E.km, &g_tb, tid, true);
-    const u32 lens[] = {0, 1, 15, 16, 17, 48, 1000, 1008, 1024, 4096, 4100, 70000};
-    const u32 aads[] = {0, 20, 28, 16, 0, 33, 68, 0, 5, 0, 12, 64};
-    const int n = 12;
+    const u32 lens[] = {0, 1, 15, 16, 17, 48, 1000, 1008, 1024, 4096, 4100, 70000, 0, 256, 240};
+    const u32 aads[] = {0, 20, 28, 16, 0, 33, 68, 0, 5, 0, 12, 64, 16, 0, 16};
+    const int n = 15;
     std::vector<u64> doff(n + 1, 0), aoff(n + 1, 0);
     for (int i = 0; i < n; i++) { doff[i + 1] = doff[i] + lens[i]; aoff[i + 1] = aoff[i] + aads[i]; }
     ABuf in(doff[n]), out(doff[n]);
@@ -388,29 +407,26 @@ static void test_packets(int key_len, u64 seed) {
     PktParams p; memset(&p, 0, sizeof p);
     p.ivs = ivs.data(); p.aad = aad.data(); p.in = in.p; p.out = out.p; p.tags = tags.data();
     p.data_off = doff.data(); p.aad_off = aoff.data(); p.n_pkts = n; p.aligned = 1;
-    for (int dec = 0; dec < 2; dec++) {
-        if (dec) { p.in = out.p; p.out = out.p; }           // decrypt in place
-        for (u32 pkt = 0; pkt < (u32)n; pkt++) {
-            G128 fold = {{0, 0, 0, 0}}; uint4 ej0 = make_uint4(0, 0, 0, 0);
-            for (u32 lane = 0; lane < 64; lane++) {
-                uint4 e;
-                uint4 acc = (E.km.nr == 10) ? (dec ? pkt_lane<10, 1>(&E.km, p, smem, pkt, lane, &e) : pkt_lane<10, 0>(&E.km, p, smem, pkt, lane, &e))
-                          : (E.km.nr == 12) ? (dec ? pkt_lane<12, 1>(&E.km, p, smem, pkt, lane, &e) : pkt_lane<12, 0>(&E.km, p, smem, pkt, lane, &e))
-                                            : (dec ? pkt_lane<14, 1>(&E.km, p, smem, pkt, lane, &e) : pkt_lane<14, 0>(&E.km, p, smem, pkt, lane, &e));
-                xor_g(fold, pkt_lane_tail(&E.km, acc, lane));
-                if (lane == 63) ej0 = e;
+    static unsigned char smem[PKTG_LDS_BYTES(6)] __attribute__((aligned(16)));
+    for (int lg = 4; lg <= 6; lg += 2) {
+        memset(smem, 0xEE, sizeof smem);
+        for (u32 tid = 0; tid < AESGCM_PKT_WG; tid++) pktg_fill_lds(smem, &E.km, &g_tb, tid, AESGCM_PKT_WG, lg);
+        for (int dec = 0; dec < 2; dec++) {
+            p.in = dec ? out.p : in.p; p.out = out.p;           // decrypt in place
+            for (u32 pkt = 0; pkt < (u32)n; pkt++) {
+                const u32 extra = (pkt % 3 == 1) ? 2 : 0, grp = lg == 4 ? pkt & 3 : 0;
+                const uint4 t = lg == 4 ? emu_pktg<4>(&E.km, dec, p, smem, pkt, extra, grp) : emu_pktg<6>(&E.km, dec, p, smem, pkt, extra, grp);
+                std::vector<uint8_t> ref(lens[pkt] + 16); uint8_t rtag[16];
+                if (!dec) {
+                    orc_gcm_crypt(0, key.data(), key_len, ivs.data() + 12 * pkt, aad.data() + aoff[pkt], aads[pkt], in.p + doff[pkt], lens[pkt], ref.data(), rtag);
+                    CHECK(memcmp(ref.data(), out.p + doff[pkt], lens[pkt]) == 0, "pktg ct %u lg %d", pkt, lg);
+                    memcpy(tags.data() + 16 * pkt, &t, 16);
+                } else {
+                    CHECK(memcmp(in.p + doff[pkt], out.p + doff[pkt], lens[pkt]) == 0, "pktg dec %u lg %d", pkt, lg);
+                    memcpy(rtag, tags.data() + 16 * pkt, 16);
+                }
+                CHECK(memcmp(&t, rtag, 16) == 0, "pktg tag %u len %u aad %u dec %d lg %d", pkt, lens[pkt], aads[pkt], dec, lg);
             }
-            uint4 t = be_to_mo(fold); t = xor4(t, ej0);
-            std::vector<uint8_t> ref(lens[pkt] + 16); uint8_t rtag[16];
-            if (!dec) {
-                orc_gcm_crypt(0, key.data(), key_len, ivs.data() + 12 * pkt, aad.data() + aoff[pkt], aads[pkt], in.p + doff[pkt], lens[pkt], ref.data(), rtag);
-                CHECK(memcmp(ref.data(), out.p + doff[pkt], lens[pkt]) == 0, "pkt ct %u", pkt);
-                memcpy(tags.data() + 16 * pkt, &t, 16);
-            } else {
-                CHECK(memcmp(in.p + doff[pkt], out.p + doff[pkt], lens[pkt]) == 0, "pkt dec %u", pkt);
-                memcpy(rtag, tags.data() + 16 * pkt, 16);
-            }
-            CHECK(memcmp(&t, rtag, 16) == 0, "pkt tag %u len %u aad %u dec %d", pkt, lens[pkt], aads[pkt], dec);
         }
     }
     // the same packets, one lane per packet (k_pktl): tags must equal the ones above, decrypt restores the input

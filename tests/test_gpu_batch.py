@@ -145,11 +145,12 @@ def test_variable_length_packets_macsec_shaped(hip, orc):
     assert set(struct.unpack("<%di" % n, bytes(d_auth.download()))) == {1}
 
 
-@pytest.mark.parametrize("shape", ["wave", "lane"])
+@pytest.mark.parametrize("shape", ["wave", "group16", "lane"])
 def test_packets_under_one_key(hip, orc, shape, monkeypatch):
     """aesgcm_packets_crypt_dev: one key (context), per-packet IV, AAD and length; fixed-size records and offset
-    arrays; decrypt in place with per-packet authentication.  Both kernel shapes (one wave per packet, one lane
-    per packet) are forced in turn; the library picks between them by packet count and size otherwise."""
+    arrays; decrypt in place with per-packet authentication.  The three kernel shapes (one wave per packet and 16 lanes per
+    packet: k_pktg<.., 6> / k_pktg<.., 4>; one lane per packet: k_pktl) are forced in turn; the library picks between them by
+    packet count and size otherwise."""
     import struct
     monkeypatch.setenv("AESGCM_PKT_SHAPE", shape)
     rng = random.Random(4242)
