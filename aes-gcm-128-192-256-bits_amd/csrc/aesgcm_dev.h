@@ -944,6 +944,36 @@ HD void body_rounds(u32 &s0, u32 &s1, u32 &s2, u32 &s3, const u32 *__restrict__ 
 #endif
     aes_final_lds(s0, s1, s2, s3, rk + 4 * NR, lds, lb);
 }
+#ifndef AESGCM_BODY_ILP
+#define AESGCM_BODY_ILP 1                /* 2: two rows of a chunk in flight per lane (round-3 experiment, profiles/r03/body_ilp2.txt) */
+#endif
+// rounds 3..NR on TWO independent states, round by round (AESGCM_BODY_ILP == 2): adjacent independent lookup chains for the scheduler
+template <int NR>
+HD void body_rounds2(u32 &a0, u32 &a1, u32 &a2, u32 &a3, u32 &b0, u32 &b1, u32 &b2, u32 &b3, const u32 *__restrict__ rk, const unsigned char *lds, u32 lb) {
+#pragma unroll
+    for (int r = 3; r < NR; r++) {
+#if AESGCM_T4
+        aes_round_lds4(a0, a1, a2, a3, rk + 4 * r, lds, lb, lb | 0x10000u);
+        aes_round_lds4(b0, b1, b2, b3, rk + 4 * r, lds, lb, lb | 0x10000u);
+#else
+        aes_round_lds(a0, a1, a2, a3, rk + 4 * r, lds, lb);
+        aes_round_lds(b0, b1, b2, b3, rk + 4 * r, lds, lb);
+#endif
+    }
+    aes_final_lds(a0, a1, a2, a3, rk + 4 * NR, lds, lb);
+    aes_final_lds(b0, b1, b2, b3, rk + 4 * NR, lds, lb);
+}
+// the state of super-row q after round 2: per-chunk lane constants xor the row-uniform part (two values in phase 3)
+HD void body_state(u32 &s0, u32 &s1, u32 &s2, u32 &s3, const BodyLane &b, u32 hi24, u32 v, u32 lane, const CtrConsts &cc,
+                   const u32 *__restrict__ rk, const DevTables *__restrict__ tb) {
+    const BodyRow u = body_uniform(hi24, cc, rk, tb);
+    s0 = b.p0 ^ u.U0; s1 = b.p1 ^ u.U1; s2 = b.p2 ^ u.U2; s3 = b.p3 ^ u.U3;
+    if (v == 3) {                                                  // wave-uniform: lanes 62, 63 are already in the next 256-block
+        const BodyRow n = body_uniform(hi24 + 1, cc, rk, tb);
+        const u32 m = lane >= 62 ? 0xFFFFFFFFu : 0u;
+        s0 ^= m & (u.U0 ^ n.U0); s1 ^= m & (u.U1 ^ n.U1); s2 ^= m & (u.U2 ^ n.U2); s3 ^= m & (u.U3 ^ n.U3);
+    }
+}
 // lane `lane` of the wave that owns chunk c = 4*s + v: returns sum_i X[row 4(sT+i)+v, lane] * (H^256)^(T-1-i)
 template <int NR, int MODE>
 HD uint4 body_chunk_lane(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const BodyParams &p,
@@ -953,7 +983,27 @@ HD uint4 body_chunk_lane(const KeyMaterial *__restrict__ km, const DevTables *__
     const u32 v = c & 3u, s = c >> 2;
     const BodyLane b = body_lane_consts(rk, cc, smem, v, lane);
     uint4 acc = make_uint4(0, 0, 0, 0);
-    for (u32 i = 0; i < p.T; ++i) {
+    u32 i = 0;
+#if AESGCM_BODY_ILP == 2
+    for (; i + 1 < p.T; i += 2) {
+        const u32 q = s * p.T + i;
+        const u64 off = ((u64)q * 4 + v) * 1024;
+        const unsigned char *src = reinterpret_cast<const unsigned char *>(uniform64((u64)(uintptr_t)p.in + off));
+        unsigned char *dst = reinterpret_cast<unsigned char *>(uniform64((u64)(uintptr_t)p.out + off));
+        const uint4 xa = (MODE == MODE_PROBE) ? make_uint4(lane, q, v, 0u) : gload16(src + lane16);
+        const uint4 xb = (MODE == MODE_PROBE) ? make_uint4(lane, q + 1, v, 0u) : gload16(src + 4096 + lane16);
+        u32 a0, a1, a2, a3, b0, b1, b2, b3;
+        body_state(a0, a1, a2, a3, b, p.ctr_hi0 + q, v, lane, cc, rk, tb);
+        body_state(b0, b1, b2, b3, b, p.ctr_hi0 + q + 1, v, lane, cc, rk, tb);
+        body_rounds2<NR>(a0, a1, a2, a3, b0, b1, b2, b3, rk, smem, lb);
+        const uint4 ya = make_uint4(xa.x ^ a0, xa.y ^ a1, xa.z ^ a2, xa.w ^ a3), yb = make_uint4(xb.x ^ b0, xb.y ^ b1, xb.z ^ b2, xb.w ^ b3);
+        if (MODE != MODE_PROBE) { gstore16(dst + lane16, ya); gstore16(dst + 4096 + lane16, yb); }
+        if (i) acc = ghash_mul_const_lds(acc, smem);
+        acc = xor4(acc, (MODE == MODE_DEC) ? xa : ya);
+        acc = xor4(ghash_mul_const_lds(acc, smem), (MODE == MODE_DEC) ? xb : yb);
+    }
+#endif
+    for (; i < p.T; ++i) {
         const u32 q = s * p.T + i;                                     // super-row: counters [256 q, 256 q + 255] of the body
         if (i) acc = ghash_mul_const_lds(acc, smem);
         const u64 off = ((u64)q * 4 + v) * 1024;                       // byte offset of the row in the body
@@ -962,13 +1012,8 @@ HD uint4 body_chunk_lane(const KeyMaterial *__restrict__ km, const DevTables *__
         // MODE_PROBE: the same instruction stream without HBM traffic -- the ceiling of the formulation itself
         // (aesgcm_ctx_ceiling_probe); the "plaintext" is a lane/row pattern and the ciphertext only feeds GHASH
         const uint4 x = (MODE == MODE_PROBE) ? make_uint4(lane, q, v, 0u) : gload16(src + lane16);
-        const BodyRow u = body_uniform(p.ctr_hi0 + q, cc, rk, tb);
-        u32 s0 = b.p0 ^ u.U0, s1 = b.p1 ^ u.U1, s2 = b.p2 ^ u.U2, s3 = b.p3 ^ u.U3;
-        if (v == 3) {                                                  // wave-uniform: lanes 62, 63 are already in the next 256-block
-            const BodyRow n = body_uniform(p.ctr_hi0 + q + 1, cc, rk, tb);
-            const u32 m = lane >= 62 ? 0xFFFFFFFFu : 0u;
-            s0 ^= m & (u.U0 ^ n.U0); s1 ^= m & (u.U1 ^ n.U1); s2 ^= m & (u.U2 ^ n.U2); s3 ^= m & (u.U3 ^ n.U3);
-        }
+        u32 s0, s1, s2, s3;
+        body_state(s0, s1, s2, s3, b, p.ctr_hi0 + q, v, lane, cc, rk, tb);
         body_rounds<NR>(s0, s1, s2, s3, rk, smem, lb);
         const uint4 y = make_uint4(x.x ^ s0, x.y ^ s1, x.z ^ s2, x.w ^ s3);                  // gcm_gctr.vhd:150
         if (MODE != MODE_PROBE) gstore16(dst + lane16, y);

@@ -726,6 +726,135 @@ __global__ __launch_bounds__(AESGCM_WG, 4) void k_batch2(const DevTables *__rest
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_batch3: k_batch2's job in ONE pass over the data (round 3).  k_batch2 encrypts a packet, fences, and reads the ciphertext
+// back for GHASH because its lanes own CONSECUTIVE blocks in the GHASH phase and interleaved ones in the CTR phase: 1.57 x the
+// algorithmic HBM traffic (profiles/r02g/cfg5_batch).  Here lane l of the packet's 16-lane group owns slots l, l + 16, ... of the
+// right-aligned GHASH sequence in both roles: one loop does AES-CTR on the block and acc = acc * H^16 ^ block (Shoup tables of
+// the per-packet constant H^16 = (((H^2)^2)^2)^2, four linear squarings).  The closing is k_pktg's: every lane times H^2, the
+// length block into lane 14, a four-level tree with the group-uniform constants H, H^2, H^4, H^8 -- q + 5 table multiplies per
+// wave-iteration where k_batch2 makes q + 6 plus the H^q square-and-multiply chain, no ciphertext read-back, no fence.
+// Decrypt is the same pass (the lane reads its ciphertext block before it writes the plaintext: in place is safe).
+// ------------------------------------------------------------------------------------------------
+template <int NR, int DEC>
+__global__ __launch_bounds__(AESGCM_WG, 4) void k_batch3(const DevTables *__restrict__ tb, const BatchParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int LG = 4;
+    constexpr u32 G = 1u << LG, P = 64u >> LG;
+    const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    main_fill_lds(smem, nullptr, tb, tid, false, AESGCM_WG);
+    __syncthreads();
+    const u32 lb = (lane & 31u) << 2;
+    const u32 grp = lane >> LG, l = lane & (G - 1u);
+    const u32 tabA = BATCH2_LDS_TAB_OFF + (wave * P + grp) * BATCH2_GROUP_LDS, tabB = tabA + 512u;
+    constexpr u32 KEYLEN = 4 * (NR - 6);
+    const u32 K = p.deal, nb = (p.n_pkts + K - 1) / K;
+    u32 pk0 = 0, pk_end = 0;
+    for (u32 guard = 0; guard <= p.n_pkts; ++guard, pk0 += P) {      // bounded on purpose (as every dispenser loop)
+        if (pk0 >= pk_end) {
+            u32 b = 0;
+            if (lane == 0) b = atomicAdd(p.counter, 1u) - p.counter_base;
+            b = __builtin_amdgcn_readfirstlane(b);
+            if (b >= nb) break;
+            pk0 = b * K;
+            pk_end = pk0 + K < p.n_pkts ? pk0 + K : p.n_pkts;
+        }
+        const bool act = pk0 + grp < pk_end;                 // groups past the end shadow the first packet; their stores are masked
+        const u32 pkt = act ? pk0 + grp : pk0;
+        const unsigned char *key = p.keys + (size_t)pkt * KEYLEN;
+        const unsigned char *ivp = p.ivs + (size_t)pkt * 12;
+        u32 pkt_len = p.pkt_len, aad_len = p.aad_len;
+        u64 doff = (u64)pkt * p.pkt_len, aoff = (u64)pkt * p.aad_len;
+        if (p.data_off) { doff = p.data_off[pkt]; pkt_len = (u32)(p.data_off[pkt + 1] - doff); }
+        if (p.aad_off) { aoff = p.aad_off[pkt]; aad_len = (u32)(p.aad_off[pkt + 1] - aoff); }
+        const bool aligned = p.aligned && ((doff & 15) == 0);
+        const unsigned char *aad = p.aad ? p.aad + aoff : nullptr;
+        const unsigned char *in = p.in + doff;
+        unsigned char *out = p.out + doff;
+        const u32 n_aad = (aad_len + 15) / 16, n_ct = (pkt_len + 15) / 16, n_seq = n_aad + n_ct;
+        const u32 iters = groups_max<LG>((n_seq + G - 1) / G);          // the wave runs to its longest packet; shorter ones idle FIRST (front padding)
+        const u32 pad = G * iters - n_seq;
+
+        // ---- aes_kexp for this lane's packet (config/config_aes_kexp.py:128-159); every lane of a group computes the same words
+        u32 rk[4 * (NR + 1)];
+        batch_key_expand<NR>(key, rk, smem, lb);
+        const u32 iv0 = load_le32(ivp), iv1 = load_le32(ivp + 4), iv2 = load_le32(ivp + 8);
+        // ---- H = E_K(0^128) on lane 0 and E_K(IV || 1) on lane 1 of the group (gcm_gctr.vhd:141-145), one pass for both
+        G128 h, ej0;
+        {
+            u32 s0 = (l == 0 ? 0u : iv0) ^ rk[0], s1 = (l == 0 ? 0u : iv1) ^ rk[1], s2 = (l == 0 ? 0u : iv2) ^ rk[2];
+            u32 s3 = (l == 0 ? 0u : 0x01000000u) ^ rk[3];
+            aes_rounds_lds<NR>(s0, s1, s2, s3, rk, smem, lb);
+            const G128 e = mo_to_be(make_uint4(s0, s1, s2, s3));
+            h = group_bcast<LG>(e, lane, 0);
+            ej0 = group_bcast<LG>(e, lane, 1);
+        }
+        shoup2_build<LG>(smem, tabA, gf_sqr(gf_sqr(gf_sqr(gf_sqr(h)))), l);            // Horner stride H^16 (squaring is linear: gf_sqr, no table)
+
+        // ---- one pass: CTR on the lane's blocks and Horner over its slots
+        G128 acc; acc.w[0] = acc.w[1] = acc.w[2] = acc.w[3] = 0;
+        const CtrConsts cc = ctr_round1_consts(iv0, iv1, iv2, rk, smem, lb);
+        for (u32 k = 0; k < iters; k++) {
+            if (k) acc = shoup2_mul(acc, smem, tabA);
+            const u32 v = k * G + l;
+            if (v < pad) continue;
+            const u32 j = v - pad;
+            uint4 gin;
+            if (j < n_aad) {
+                const u32 off = 16 * j, rem = aad_len - off;
+                gin = load_block_bytes(aad + off, rem < 16 ? rem : 16);
+            } else {
+                const u32 i = j - n_aad, off = 16 * i, rem = pkt_len - off;
+                const bool full = aligned && rem >= 16;
+                uint4 x;
+                if (full) x = gload16(in + off);
+                else x = load_block_bytes(in + off, rem < 16 ? rem : 16);
+                u32 s0, s1, s2, s3;
+                ctr_rounds_lds<NR>(bswap32(2u + i), cc, s0, s1, s2, s3, rk, smem, lb);
+                uint4 y = make_uint4(x.x ^ s0, x.y ^ s1, x.z ^ s2, x.w ^ s3);
+                if (rem < 16) y = mask_block(y, rem);
+                if (act) {
+                    if (full) gstore16(out + off, y);
+                    else store_block_bytes(out + off, y, rem < 16 ? rem : 16);
+                }
+                gin = DEC ? x : y;                               // aes_gcm.vhd:207-211
+            }
+            const G128 b = mo_to_be(gin);
+            acc.w[0] ^= b.w[0]; acc.w[1] ^= b.w[1]; acc.w[2] ^= b.w[2]; acc.w[3] ^= b.w[3];
+        }
+
+        // ---- closing: P = sum_l B_l H^(15-l);  tag = P H^2 ^ L H ^ E_K(J0)  (gcm_ghash.vhd:257,293), as in k_pktg
+        G128 c = gf_sqr(h);                                     // H^2
+        shoup2_build<LG>(smem, tabB, c, l);
+        acc = shoup2_mul(acc, smem, tabB);
+        if (l == G - 2u) { acc.w[1] ^= aad_len * 8u; acc.w[3] ^= pkt_len * 8u; }     // the length block: both < 2^32 bits by the ABI's limits
+        shoup2_build<LG>(smem, tabA, h, l);                     // the Horner table is no longer needed
+#pragma unroll
+        for (int j = 0; j < LG; j++) {
+            // level j: constant H^(2^j); H in tabA, H^2 in tabB, then H^4 -> tabA, H^8 -> tabB
+            if (j >= 2) { c = gf_sqr(c); shoup2_build<LG>(smem, (j & 1) ? tabB : tabA, c, l); }
+            const G128 t = shoup2_mul(acc, smem, (j & 1) ? tabB : tabA);
+            G128 o;
+            o.w[0] = __shfl_xor(t.w[0], 1 << j); o.w[1] = __shfl_xor(t.w[1], 1 << j);
+            o.w[2] = __shfl_xor(t.w[2], 1 << j); o.w[3] = __shfl_xor(t.w[3], 1 << j);
+            if (l & (1u << j)) { acc.w[0] ^= o.w[0]; acc.w[1] ^= o.w[1]; acc.w[2] ^= o.w[2]; acc.w[3] ^= o.w[3]; }
+        }
+        acc.w[0] ^= ej0.w[0]; acc.w[1] ^= ej0.w[1]; acc.w[2] ^= ej0.w[2]; acc.w[3] ^= ej0.w[3];
+        if (l == G - 1u && act) {
+            const uint4 tag = be_to_mo(acc);
+            store_block_bytes(p.tags + (size_t)pkt * 16, tag, 16);
+            if (DEC && p.auth) {
+                int ok = 1;
+                if (p.expect) {
+                    const uint4 e = load_block_bytes(p.expect + (size_t)pkt * 16, 16);
+                    ok = ((e.x ^ tag.x) | (e.y ^ tag.y) | (e.z ^ tag.z) | (e.w ^ tag.w)) == 0;
+                }
+                p.auth[pkt] = ok;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_pktg: many packets under the context's key, 2^LG lanes per packet (lane bodies: pktg_lane(), pktg_close_lane(),
 // pktg_tree_offer(); see "Packets under ONE key" in aesgcm_dev.h).  One 1024-lane workgroup per CU.
 // ------------------------------------------------------------------------------------------------
@@ -947,6 +1076,9 @@ static int set_lds_attrs(int device, DeviceState *ds) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_combine), hipFuncAttributeMaxDynamicSharedMemorySize, CMB_LDS_BYTES));
 #define SETATTRB2(NR, D, LG) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch2<NR, D, LG>), hipFuncAttributeMaxDynamicSharedMemorySize, BATCH2_LDS_BYTES(LG)))
     SETATTRB2(10, 0, 4); SETATTRB2(12, 0, 4); SETATTRB2(14, 0, 4); SETATTRB2(10, 1, 4); SETATTRB2(12, 1, 4); SETATTRB2(14, 1, 4);
+#define SETATTRB3(NR, D) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch3<NR, D>), hipFuncAttributeMaxDynamicSharedMemorySize, BATCH2_LDS_BYTES(4)))
+    SETATTRB3(10, 0); SETATTRB3(12, 0); SETATTRB3(14, 0); SETATTRB3(10, 1); SETATTRB3(12, 1); SETATTRB3(14, 1);
+#undef SETATTRB3
 
 #undef SETATTRB2
     ds->attrs = true;
@@ -1703,12 +1835,13 @@ int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const vo
     p.aligned = (((uintptr_t)d_in | (uintptr_t)d_out) & 15) == 0 && (d_data_off || pkt_len % 16 == 0);
     const u32 waves_per_wg = AESGCM_PKT_WG / 64;
     const u32 n_cu = (u32)c->G / 2;                                                 // c->G = two workgroups per CU
-    // shape.  One LANE per packet (k_pktl) when there are enough packets to fill the machine with lanes: measured crossover
-    // (profiles/packets_sweep.py) from about 24 packets per byte of packet length (256 B: 4 Ki packets, 4 KiB: 100 Ki packets);
-    // with offset arrays the host does not know the lengths and goes by count alone.  Otherwise lane GROUPS (k_pktg): 16 lanes per
-    // packet (four packets per wave) once four packets per resident wave exist or the packets are short, else one packet per
-    // wave.  AESGCM_PKT_SHAPE=l|g|w forces lane / 16-lane group / wave.
-    int shape = (d_data_off ? n_pkts >= 32768 : (n_pkts >= 2048 && n_pkts >= 24 * pkt_len)) ? 'l'
+    // shape.  One LANE per packet (k_pktl) when there are enough packets to fill the machine with lanes; otherwise lane GROUPS
+    // (k_pktg): 16 lanes per packet (four packets per wave) once four packets per resident wave exist or the packets are short,
+    // else one packet per wave.  Measured crossovers (profiles/r03/packets_sweep_aes256.txt, AES-256, GiB/s group16 / lane):
+    // 65536 x 1 KiB 231 / 195, 262144 x 1 KiB 491 / 628, 262144 x 4 KiB 649 / 709, 16384 x 256 B 35 / 41, 4096 x 256 B 23 / 11;
+    // wave / group16: 4096 x 4 KiB 126 / 130, 1024 x 4 KiB 65 / 37, 4096 x 16 KiB 363 / 172.  With offset arrays the host does
+    // not know the lengths and goes by count alone.  AESGCM_PKT_SHAPE=l|g|w forces lane / 16-lane group / wave.
+    int shape = (d_data_off ? n_pkts >= 32768 : (n_pkts >= 131072 || (pkt_len <= 256 && n_pkts >= 8192))) ? 'l'
               : (n_pkts >= (size_t)4 * n_cu * waves_per_wg || (!d_data_off && pkt_len <= 1024)) ? 'g' : 'w';
     if (const char *e = getenv("AESGCM_PKT_SHAPE")) { if (e[0] == 'l' || e[0] == 'g' || e[0] == 'w') shape = e[0]; }
     hipStream_t st = pick_stream(c, stream);
@@ -1787,10 +1920,16 @@ static int batch_launch(int device, int decrypt, size_t n_pkts, size_t key_len, 
         u32 deal = (u32)(n_pkts / ((size_t)wgs * waves_per_wg * 16));
         deal = deal < P ? P : deal > 8 * P ? 8 * P : (deal + P - 1) / P * P;
         p.deal = deal;
+        // AESGCM_BATCH_FUSED=0 selects the two-phase k_batch2 (encrypt, fence, read the ciphertext back) for A/B runs
+        bool fused = true;
+        if (const char *e = getenv("AESGCM_BATCH_FUSED")) fused = atoi(e) != 0;
 #define LB2(NR, D, LG) hipLaunchKernelGGL((k_batch2<NR, D, LG>), dim3(wgs), dim3(AESGCM_WG), BATCH2_LDS_BYTES(LG), st, ds->tables, p)
-#define LB2N(D, LG) do { if (nr == 10) LB2(10, D, LG); else if (nr == 12) LB2(12, D, LG); else LB2(14, D, LG); } while (0)
+#define LB3(NR, D) hipLaunchKernelGGL((k_batch3<NR, D>), dim3(wgs), dim3(AESGCM_WG), BATCH2_LDS_BYTES(4), st, ds->tables, p)
+#define LB2N(D, LG) do { if (fused) { if (nr == 10) LB3(10, D); else if (nr == 12) LB3(12, D); else LB3(14, D); } \
+                         else { if (nr == 10) LB2(10, D, LG); else if (nr == 12) LB2(12, D, LG); else LB2(14, D, LG); } } while (0)
         if (decrypt) LB2N(1, 4); else LB2N(0, 4);
 #undef LB2N
+#undef LB3
 #undef LB2
         HIPCHK(hipGetLastError());
         return AESGCM_OK;

@@ -387,7 +387,7 @@ def main(argv=None):
     ap.add_argument("--selfcheck", action="store_true",
                     help="rank 0 also encrypts every whole message alone and compares tags (needs the extra memory)")
     ap.add_argument("--contexts", type=int, default=0,
-                    help="N > 1 / --emulate-rank: contexts (stream + scratch set each) a rank's messages rotate over; 0 = one per message, at most 4")
+                    help="N > 1 / --emulate-rank: contexts (stream + scratch set each) a rank's messages rotate over; 0 = the default, 2 (measured best of 1 / 2 / 4, profiles/r03/emulate_rank.txt)")
     ap.add_argument("--no-chain", action="store_true", help="debug: do not chain message i's fused kernel behind message i-1's (the contexts start together)")
     ap.add_argument("--emulate-rank", type=int, default=None, help="on ONE GPU, run exactly this rank's step of the --of W job")
     ap.add_argument("--of", type=int, default=8, help="world size emulated by --emulate-rank")
@@ -460,7 +460,7 @@ def main(argv=None):
 
     plan = sharding.plan_job(W, per_gpu, R)
     M = len(plan)
-    n_ctx = 1 if W == 1 else max(1, min(args.contexts if args.contexts > 0 else 4, M))
+    n_ctx = 1 if W == 1 else max(1, min(args.contexts if args.contexts > 0 else 2, M))
     ctxs = [lib.Context(key, device=dev) for _ in range(n_ctx)]
     ctx = ctxs[0]
     geo = ctx.geometry()

@@ -15,6 +15,9 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -- python3 $REPO/"$@" > $OUT/pmc_$C.json 2> $OUT/pmc_$C.err
 done
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq -- python3 $REPO/"$@" > $OUT/pmc_sq.json 2> $OUT/pmc_sq.err
+# second SQ pass (round 3, what binds the fused kernel): cycles with an instruction of each class in flight, wave and busy cycles
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INST_CYCLES_VMEM_RD --output-format csv -d $OUT/pmc_sq2 -- python3 $REPO/"$@" > $OUT/pmc_sq2.json 2> $OUT/pmc_sq2.err
+rocprofv3 --pmc SQ_INST_CYCLES_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INST_CYCLES_SMEM SQ_INST_CYCLES_SALU SQ_BUSY_CU_CYCLES SQ_INST_LEVEL_LDS --output-format csv -d $OUT/pmc_sq3 -- python3 $REPO/"$@" > $OUT/pmc_sq3.json 2> $OUT/pmc_sq3.err
 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_grbm -- python3 $REPO/"$@" > $OUT/pmc_grbm.json 2> $OUT/pmc_grbm.err
 cd $REPO
 python3 profiles/summarize.py $OUT "$TAG" "$HOT" > $OUT/summary.txt 2>&1

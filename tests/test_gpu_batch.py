@@ -9,15 +9,18 @@ from util import golden, batch_inputs, splitmix_bytes
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["default", "lanes16", "lanes64"], autouse=True)
+@pytest.fixture(params=["default", "lanes16", "lanes16_twophase", "lanes64"], autouse=True)
 def batch_shape(request, monkeypatch):
-    """every test here runs with the host's own choice of kernel shape and with each shape forced: 16 lanes per packet
-    (k_batch2: four packets per wave) and 64 lanes per packet (k_batch) -- AESGCM_BATCH_LG is read at every launch"""
-    lg = {"lanes16": "4", "lanes64": "6"}.get(request.param)
-    if lg:
-        monkeypatch.setenv("AESGCM_BATCH_LG", lg)
-    else:
-        monkeypatch.delenv("AESGCM_BATCH_LG", raising=False)
+    """every test here runs with the host's own choice of kernel shape and with each shape forced: 16 lanes per packet in one
+    pass (k_batch3: four packets per wave, GHASH fused into the CTR loop), the same in two phases (k_batch2: encrypt, read the
+    ciphertext back) and 64 lanes per packet (k_batch) -- AESGCM_BATCH_LG / AESGCM_BATCH_FUSED are read at every launch"""
+    env = {"lanes16": {"AESGCM_BATCH_LG": "4", "AESGCM_BATCH_FUSED": "1"}, "lanes16_twophase": {"AESGCM_BATCH_LG": "4", "AESGCM_BATCH_FUSED": "0"},
+           "lanes64": {"AESGCM_BATCH_LG": "6"}}.get(request.param, {})
+    for k in ("AESGCM_BATCH_LG", "AESGCM_BATCH_FUSED"):
+        if k in env:
+            monkeypatch.setenv(k, env[k])
+        else:
+            monkeypatch.delenv(k, raising=False)
     return request.param
 
 
