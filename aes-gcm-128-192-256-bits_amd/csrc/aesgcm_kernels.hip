@@ -107,7 +107,9 @@ __global__ __launch_bounds__(AESGCM_WG) void k_setup(KeyMaterial *km, const DevT
 // coherent with the memory-side atomics of other XCDs -- waves saw stale "work left" values and spun on dry queues; k_body
 // got 25 % slower.)  Every queue keeps its home waves until it is dry, so every chunk is handed out whatever the others do.
 #define DISPENSER_DONE 0xFFFFFFFFu
-__device__ __forceinline__ u32 next_chunk(u32 *counter, unsigned char *smem, u32 nq, u32 seg, u32 C, u32 &q, u32 lane) {
+// `strided`: queue q hands out chunks q, q + nq, q + 2 nq, ... instead of the contiguous [q seg, (q + 1) seg): all queues then walk
+// the index space together and the highest indices are dealt LAST (k_body's region B, plan_body_tail).
+__device__ __forceinline__ u32 next_chunk(u32 *counter, unsigned char *smem, u32 nq, u32 seg, u32 C, u32 &q, u32 lane, bool strided = false) {
     u32 *dry = reinterpret_cast<u32 *>(smem + AESGCM_LDS_DRY_OFF);
     const u32 all = nq >= 32 ? 0xFFFFFFFFu : (1u << nq) - 1u;
     for (u32 tries = 0; tries < 4 * AESGCM_NQ; ++tries) {
@@ -121,7 +123,7 @@ __device__ __forceinline__ u32 next_chunk(u32 *counter, unsigned char *smem, u32
         if (lane == 0) v = atomicAdd(counter + 16 * q, 1u);
         v = __builtin_amdgcn_readfirstlane(v);
         if (v < seg) {
-            const u32 c = q * seg + v;
+            const u32 c = strided ? v * nq + q : q * seg + v;
             if (c < C) return c;
             continue;                                               // the last queue is padded to seg (fewer than nq entries)
         }
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(AESGCM_BODY_WG, AESGCM_BODY_WPS) void k_body(const 
     u32 q = (blockIdx.x * (AESGCM_BODY_WG / 64) + (tid >> 6)) % p.nq;
     q = __builtin_amdgcn_readfirstlane(q);
     for (u32 guard = 0; guard <= p.C; ++guard) {                             // bounded, as every dispenser loop here
-        const u32 c = next_chunk(p.counter, smem, p.nq, p.seg, p.C, q, lane);
+        const u32 c = next_chunk(p.counter, smem, p.nq, p.seg, p.C, q, lane, true);
         if (c == DISPENSER_DONE) break;
         const uint4 acc = body_chunk_lane<NR, MODE>(km, tb, p, smem, cc, c, lane);
         p.parts[(size_t)c * 64 + lane] = acc;
@@ -995,6 +997,8 @@ struct aesgcm_ctx {
     u32 counter_base = 0;              // value the packet dispenser (d_counter[0]) holds before the next launch
     u32 qset = 0;                      // which of the two sets of chunk queues (d_counter[16 (1 + 16 set + q)]) the next dynamic launch of k_main / k_body uses; that launch zeroes the other set
     u32 tw_override = 0;               // AESGCM_TW
+    u64 tail_min = (u64)1 << 30;       // bodies of at least this many bytes get a region B (AESGCM_TAIL_MIN)
+    u32 tail_waves = 0;                // k_body: waves whose last chunk the finer region B is sized for (plan_body_tail); 0 = one region (AESGCM_BODY_TAIL=0)
     u64 body_min = (u64)256 << 20;     // ranges with an aligned middle of at least this many bytes go through k_body (AESGCM_BODY_MIN).  Since k_main
                                        // got cheaper below 256 MiB (dispensers, k_fold: profiles/r02f/split_threshold.txt) the cut pays from 256 MiB:
                                        // 128 MiB -16 %, 256 MiB +0.8 %, 512 MiB +4 %, 1 GiB +11 %, 2 GiB +7 %; it was 128 MiB before, 0.7 GiB in round 1
@@ -1186,12 +1190,17 @@ static int enqueue_main(aesgcm_ctx *c, int mode, const uint8_t iv[12], const voi
 
 static int enqueue_combine(aesgcm_ctx *c, const CombineParams &p, hipStream_t st);
 
-// k_body over the planned split + the k_fold levels over its interleaved chunk items
-static int enqueue_body(aesgcm_ctx *c, int mode, const uint8_t iv[12], const BodySplit &b, const void *d_in, void *d_out,
-                        u64 first_block, hipStream_t st, Partials *po) {
+// k_body over the planned split + the k_fold levels over its interleaved chunk items.  *po describes the partials of the LAST
+// region and *nb_out the blocks they cover; with a region B (plan_body_tail) region A has already been folded into the device
+// chaining value `state` (Y <- Y H^blocks(A) ^ P_A, the streaming step) when this returns, so the caller's own step -- carry
+// combine or tag -- is the same as for a one-region body, over nb_out blocks.
+static int enqueue_body(aesgcm_ctx *c, int mode, const uint8_t iv[12], const BodySplit &b0, const void *d_in, void *d_out,
+                        u64 first_block, hipStream_t st, Partials *po, uint4 *state, u64 *nb_out) {
+    BodySplit b = b0;
+    if (state && b.body_blocks * 16 >= c->tail_min) plan_body_tail(&b, c->tail_waves);
     BodyParams p;
     memset(&p, 0, sizeof p);
-    int rc = grow_parts(c, (size_t)4 * b.S);
+    int rc = grow_parts(c, (size_t)4 * (b.S + b.Sb));
     if (rc) return rc;
     plan_body(p, b, iv, d_in, d_out, first_block, c->parts);
     p.ej0 = c->d_tag + 3; po->ej0 = p.ej0;
@@ -1227,7 +1236,19 @@ static int enqueue_body(aesgcm_ctx *c, int mode, const uint8_t iv[12], const Bod
     if (c->timing) { HIPCHK(hipEventRecord(evp.second, st)); c->ev.push_back(evp); }
     if (c->ev_fused) HIPCHK(hipEventRecord(c->ev_fused, st));
     // items 4s + v: phases 64 blocks apart inside a super-chunk, super-chunks 256 T blocks apart
-    return enqueue_fold(c, c->parts, p.C, 4, 64, (u64)256 * b.T, st, po);
+    if (!b.Sb) {
+        if (nb_out) *nb_out = b.body_blocks;
+        return enqueue_fold(c, c->parts, p.C, 4, 64, (u64)256 * b.T, st, po);
+    }
+    const u64 nbA = (u64)256 * b.T * b.S, nbB = (u64)256 * b.Tb * b.Sb;
+    Partials pa;
+    if ((rc = enqueue_fold(c, c->parts, p.Ca, 4, 64, (u64)256 * b.T, st, &pa))) return rc;
+    if ((rc = enqueue_combine(c, combine_with_items(plan_combine_carry(pa.ptr, pa.np, pa.kind, state, nbA), pa.eA), st))) return rc;
+    const uint4 *ej0 = po->ej0;
+    rc = enqueue_fold(c, c->parts + (size_t)p.Ca * 64, p.C - p.Ca, 4, 64, (u64)256 * b.Tb, st, po);
+    po->ej0 = ej0;
+    if (nb_out) *nb_out = nbB;
+    return rc;
 }
 
 // Y' = Y * H^nb ^ P(aad, data) for a whole range, Y in *state (device).  Large ranges go head / k_body / tail,
@@ -1251,9 +1272,10 @@ static int absorb_range(aesgcm_ctx *c, int mode, const uint8_t iv[12], const voi
         if (rc) return rc;
         if ((rc = enqueue_combine(c, combine_with_items(plan_combine_carry(pp.ptr, pp.np, pp.kind, state, n_aad + b.head_blocks), pp.eA), st))) return rc;
     }
-    if ((rc = enqueue_body(c, mode, iv, b, d_in, d_out, first_block, st, &pp))) return rc;
+    u64 nb_last = 0;
+    if ((rc = enqueue_body(c, mode, iv, b, d_in, d_out, first_block, st, &pp, state, &nb_last))) return rc;
     if (ej0) *ej0 = pp.ej0;                                      // valid until the next launch on this context overwrites the slot: consumed by the caller's final combine
-    if ((rc = enqueue_combine(c, combine_with_items(plan_combine_carry(pp.ptr, pp.np, pp.kind, state, b.body_blocks), pp.eA), st))) return rc;
+    if ((rc = enqueue_combine(c, combine_with_items(plan_combine_carry(pp.ptr, pp.np, pp.kind, state, nb_last), pp.eA), st))) return rc;
     const u64 done = b.head_blocks + b.body_blocks, tail = len - 16 * done;
     if (tail) {
         c->timing_mute = true;
@@ -1300,9 +1322,13 @@ static int crypt_dev(aesgcm_ctx *c, int dec, const uint8_t iv[12], const void *d
             // the whole message is one aligned body (the benchmark's shape): no chaining value to carry, k_body's items go
             // straight to the tag
             Partials pb;
-            if ((rc = enqueue_body(c, dec ? MODE_DEC : MODE_ENC, iv, b, d_in, d_out, 0, st, &pb))) return rc;
+            uint4 *state = c->d_tag + 2;                         // used only when the body has a region B: region A's polynomial waits there
+            u64 nb_last = 0;
+            HIPCHK(hipMemsetAsync(state, 0, 16, st));
+            if ((rc = enqueue_body(c, dec ? MODE_DEC : MODE_ENC, iv, b, d_in, d_out, 0, st, &pb, state, &nb_last))) return rc;
             CombineParams q = combine_with_items(plan_combine_tag(pb.ptr, pb.np, pb.kind, iv, 0, len, c->d_tag), pb.eA);
             q.ej0 = pb.ej0;
+            if (nb_last != b.body_blocks) { q.carry = state; q.has_carry = 1; q.e_carry = nb_last; }    // tag = (Y H^nb ^ P_B) H^2 ^ L H ^ E_K(J0)
             return enqueue_combine(c, q, st);
         }
         // large message: head / k_body / tail folded into a device-side chaining value, then the tag from it
@@ -1417,6 +1443,9 @@ static int ctx_create_common(aesgcm_ctx **out, int device, const uint8_t *key, s
     if (const char *e = getenv("AESGCM_WGS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 2) per_cu = v; }
     if (const char *e = getenv("AESGCM_TW")) c->tw_override = (u32)strtoul(e, nullptr, 0);
     if (const char *e = getenv("AESGCM_BODY_MIN")) c->body_min = strtoull(e, nullptr, 0);
+    c->tail_waves = (u32)(per_cu * ds->n_cu / 2) * (AESGCM_BODY_WG / 64);                 // k_body's resident waves
+    if (const char *e = getenv("AESGCM_BODY_TAIL")) c->tail_waves = (u32)strtoul(e, nullptr, 0);
+    if (const char *e = getenv("AESGCM_TAIL_MIN")) c->tail_min = strtoull(e, nullptr, 0);
     int G = per_cu * ds->n_cu;
     if (G > AESGCM_GMAX) G = AESGCM_GMAX;
     if (G < 1) G = 1;
@@ -2211,7 +2240,7 @@ int aesgcm_ctx_ceiling_probe(aesgcm_ctx *c, size_t nbytes, double *ms, uint64_t 
     c->timing = true;
     HIPCHK(hipStreamSynchronize(c->stream));
     const size_t mark = c->ev.size();
-    int rc = enqueue_body(c, MODE_PROBE, iv, b, nullptr, nullptr, 0, c->stream, &pp);
+    int rc = enqueue_body(c, MODE_PROBE, iv, b, nullptr, nullptr, 0, c->stream, &pp, c->d_tag + 2, nullptr);
     c->timing = was;
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));

@@ -80,6 +80,14 @@ def main(out, tag, hot_re):
         pj.update({"FETCH_SIZE_KiB": pm.get("FETCH_SIZE"), "WRITE_SIZE_KiB": pm.get("WRITE_SIZE"),
                    "correction": "FETCH_SIZE x2 (gfx950 tallies 128-byte read requests at 64 B); WRITE_SIZE raw",
                    "hbm_read_bytes_per_launch": f, "hbm_write_bytes_per_launch": w, "hbm_bytes_per_launch": f + w})
+    if "TCC_EA0_RDREQ_sum" in pm:
+        # read requests at the L2's memory side by size; what is not 32 / 64 / 128 B is taken as 64 B
+        n, n32, n64, n128 = pm["TCC_EA0_RDREQ_sum"], pm.get("TCC_EA0_RDREQ_32B_sum", 0.0), pm.get("TCC_EA0_RDREQ_64B_sum", 0.0), pm.get("TCC_EA0_RDREQ_128B_sum", 0.0)
+        pj["tcc_read"] = {"requests": n, "32B": n32, "64B": n64, "128B": n128, "bytes_by_request_size": 32 * n32 + 64 * n64 + 128 * n128 + 64 * max(0.0, n - n32 - n64 - n128)}
+    if "TCC_EA0_WRREQ_sum" in pm:
+        n, n64 = pm["TCC_EA0_WRREQ_sum"], pm.get("TCC_EA0_WRREQ_64B_sum", 0.0)
+        pj["tcc_write"] = {"requests": n, "64B": n64, "bytes_64B_full_else_32B": 64 * n64 + 32 * max(0.0, n - n64),
+                           "l2_hit_frac": round(pm["TCC_HIT_sum"] / (pm["TCC_HIT_sum"] + pm["TCC_MISS_sum"]), 4) if pm.get("TCC_HIT_sum") is not None and (pm.get("TCC_HIT_sum", 0) + pm.get("TCC_MISS_sum", 0)) else None}
     if "SQ_LDS_IDX_ACTIVE" in pm and "GRBM_GUI_ACTIVE" in pm:
         cu = 256
         pj["lds"] = {"SQ_LDS_IDX_ACTIVE_per_launch": pm["SQ_LDS_IDX_ACTIVE"], "SQ_INSTS_LDS_per_launch": pm.get("SQ_INSTS_LDS"),
