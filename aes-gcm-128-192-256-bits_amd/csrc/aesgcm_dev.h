@@ -892,9 +892,7 @@ struct BodyParams {
     uint4 *parts;                // one GHASH partial per chunk, chunk c = 4*s + v
     u32 *counter; u32 nq, seg; u32 *counter_zero;         // as in MainParams
     u32 T;                       // rows per chunk (iterations of a wave), super-chunk = 4*T rows = 256*T blocks
-    u32 C;                       // chunks = 4 * super-chunks (both regions)
-    u32 Ca, Tb;                  // chunks [0, Ca) are region A (T rows each); chunks [Ca, C) are region B, the END of the body in finer chunks of Tb
-                                 // rows, dealt last: a wave's final chunk then lasts Tb rows instead of T (the launch's tail, plan_body_tail).  Ca = C: no region B
+    u32 C;                       // chunks = 4 * super-chunks
     u32 ctr_hi0;                 // (message block index of body block 0) >> 8; the index is a multiple of 256
     u32 iv0, iv1, iv2;
     u64 *trace;
@@ -982,16 +980,13 @@ HD uint4 body_chunk_lane(const KeyMaterial *__restrict__ km, const DevTables *__
                          const unsigned char *smem, const CtrConsts &cc, u32 c, u32 lane) {
     const u32 *__restrict__ rk = km->rk;
     const u32 lb = (lane & 31u) << 2, lane16 = lane * 16u;
-    const bool regB = c >= p.Ca;                                       // wave-uniform
-    const u32 cr = regB ? c - p.Ca : c;
-    const u32 v = cr & 3u, T = regB ? p.Tb : p.T;
-    const u32 q0 = regB ? (p.Ca >> 2) * p.T + (cr >> 2) * p.Tb : (cr >> 2) * p.T;      // first super-row of the chunk
+    const u32 v = c & 3u, s = c >> 2;
     const BodyLane b = body_lane_consts(rk, cc, smem, v, lane);
     uint4 acc = make_uint4(0, 0, 0, 0);
     u32 i = 0;
 #if AESGCM_BODY_ILP == 2
-    for (; i + 1 < T; i += 2) {
-        const u32 q = q0 + i;
+    for (; i + 1 < p.T; i += 2) {
+        const u32 q = s * p.T + i;
         const u64 off = ((u64)q * 4 + v) * 1024;
         const unsigned char *src = reinterpret_cast<const unsigned char *>(uniform64((u64)(uintptr_t)p.in + off));
         unsigned char *dst = reinterpret_cast<unsigned char *>(uniform64((u64)(uintptr_t)p.out + off));
@@ -1008,8 +1003,8 @@ HD uint4 body_chunk_lane(const KeyMaterial *__restrict__ km, const DevTables *__
         acc = xor4(ghash_mul_const_lds(acc, smem), (MODE == MODE_DEC) ? xb : yb);
     }
 #endif
-    for (; i < T; ++i) {
-        const u32 q = q0 + i;                                          // super-row: counters [256 q, 256 q + 255] of the body
+    for (; i < p.T; ++i) {
+        const u32 q = s * p.T + i;                                     // super-row: counters [256 q, 256 q + 255] of the body
         if (i) acc = ghash_mul_const_lds(acc, smem);
         const u64 off = ((u64)q * 4 + v) * 1024;                       // byte offset of the row in the body
         const unsigned char *src = reinterpret_cast<const unsigned char *>(uniform64((u64)(uintptr_t)p.in + off));
@@ -1167,7 +1162,7 @@ static inline u32 plan_main(MainParams &p, int mode, u32 tw_override, const uint
 // Split of a data range for k_body: [head blocks][body = S super-chunks of 256*T blocks][tail].  The body starts at
 // the first block whose index in the message (first_block + i) is a multiple of 256 -- no head at all for a whole
 // message or a shard cut at such an index -- and holds only whole 16-byte blocks.  Returns false when the range is too small to be worth three launches (min_bytes).
-struct BodySplit { u64 head_blocks, body_blocks; u32 T, S; u32 Tb, Sb; };   // region A: S super-chunks of 4 T rows; region B (plan_body_tail): Sb of 4 Tb rows
+struct BodySplit { u64 head_blocks, body_blocks; u32 T, S; };
 static inline bool plan_body_split(u64 len, u64 first_block, u32 tw_override, u64 min_bytes, BodySplit *b) {
     const u64 nfull = len / 16;
     const u64 head = (256 - (first_block & 255)) & 255;                // to the next multiple of 256 of the message block index
@@ -1180,27 +1175,12 @@ static inline bool plan_body_split(u64 len, u64 first_block, u32 tw_override, u6
     if (!S || S * 4 > 0xFFFFFFFFull / 2) return false;
     const u64 body = S * 256ull * Tw;
     if (body * 16 < min_bytes) return false;
-    b->head_blocks = head; b->body_blocks = body; b->T = Tw; b->S = (u32)S; b->Tb = 0; b->Sb = 0;
+    b->head_blocks = head; b->body_blocks = body; b->T = Tw; b->S = (u32)S;
     return true;
-}
-// The tail of a k_body launch.  Waves take chunks dynamically, so they finish their LAST chunk at different times: with T rows
-// per chunk a wave sits idle for half a chunk on average while the launch drains -- ~128 us of a 16.3 ms launch at 16 GiB
-// (T = 64), ~64 us of every 4.1 ms launch at 4 GiB (T = 32; profiles/r03/emulate_rank.txt: four such launches cost 1.9 % more than
-// one of 16 GiB).  Shorter chunks everywhere would mean more items to fold (the cap is 2^18).  Instead the END of the body -- about
-// one region-A chunk per resident wave -- is cut into chunks of T / 8 rows (region B) that the dispensers hand out last
-// (next_chunk deals chunk indices in increasing order across its queues): the idle tail shrinks eightfold, and region B's
-// 8 x fewer rows per item cost one more fold sequence over 2^15 items.  No region B for short bodies (fewer than 4 x the
-// converted super-chunks) or T < 8.
-static inline void plan_body_tail(BodySplit *b, u32 tail_waves) {
-    b->Tb = 0; b->Sb = 0;
-    if (!tail_waves || b->T < 8 || (b->T & 7)) return;
-    u32 conv = (tail_waves + 3) / 4;                                    // region-A super-chunks turned into region B: one A chunk per wave
-    if (b->S < 4 * conv) return;
-    b->S -= conv; b->Tb = b->T / 8; b->Sb = conv * 8;
 }
 static inline void plan_body(BodyParams &p, const BodySplit &b, const uint8_t *iv, const void *in, void *out, u64 first_block, uint4 *parts) {
     p.in = (const unsigned char *)in + 16 * b.head_blocks; p.out = (unsigned char *)out + 16 * b.head_blocks;
-    p.parts = parts; p.T = b.T; p.Ca = 4 * b.S; p.Tb = b.Tb; p.C = 4 * (b.S + b.Sb);
+    p.parts = parts; p.T = b.T; p.C = 4 * b.S;
     p.ctr_hi0 = (u32)((first_block + b.head_blocks) >> 8);
     u32 w[3]; iv_to_words(iv, w); p.iv0 = w[0]; p.iv1 = w[1]; p.iv2 = w[2];
 }

@@ -107,9 +107,7 @@ __global__ __launch_bounds__(AESGCM_WG) void k_setup(KeyMaterial *km, const DevT
 // coherent with the memory-side atomics of other XCDs -- waves saw stale "work left" values and spun on dry queues; k_body
 // got 25 % slower.)  Every queue keeps its home waves until it is dry, so every chunk is handed out whatever the others do.
 #define DISPENSER_DONE 0xFFFFFFFFu
-// `strided`: queue q hands out chunks q, q + nq, q + 2 nq, ... instead of the contiguous [q seg, (q + 1) seg): all queues then walk
-// the index space together and the highest indices are dealt LAST (k_body's region B, plan_body_tail).
-__device__ __forceinline__ u32 next_chunk(u32 *counter, unsigned char *smem, u32 nq, u32 seg, u32 C, u32 &q, u32 lane, bool strided = false) {
+__device__ __forceinline__ u32 next_chunk(u32 *counter, unsigned char *smem, u32 nq, u32 seg, u32 C, u32 &q, u32 lane) {
     u32 *dry = reinterpret_cast<u32 *>(smem + AESGCM_LDS_DRY_OFF);
     const u32 all = nq >= 32 ? 0xFFFFFFFFu : (1u << nq) - 1u;
     for (u32 tries = 0; tries < 4 * AESGCM_NQ; ++tries) {
@@ -123,7 +121,7 @@ __device__ __forceinline__ u32 next_chunk(u32 *counter, unsigned char *smem, u32
         if (lane == 0) v = atomicAdd(counter + 16 * q, 1u);
         v = __builtin_amdgcn_readfirstlane(v);
         if (v < seg) {
-            const u32 c = strided ? v * nq + q : q * seg + v;
+            const u32 c = q * seg + v;
             if (c < C) return c;
             continue;                                               // the last queue is padded to seg (fewer than nq entries)
         }
@@ -273,7 +271,7 @@ __global__ __launch_bounds__(AESGCM_BODY_WG, AESGCM_BODY_WPS) void k_body(const 
     u32 q = (blockIdx.x * (AESGCM_BODY_WG / 64) + (tid >> 6)) % p.nq;
     q = __builtin_amdgcn_readfirstlane(q);
     for (u32 guard = 0; guard <= p.C; ++guard) {                             // bounded, as every dispenser loop here
-        const u32 c = next_chunk(p.counter, smem, p.nq, p.seg, p.C, q, lane, true);
+        const u32 c = next_chunk(p.counter, smem, p.nq, p.seg, p.C, q, lane);
         if (c == DISPENSER_DONE) break;
         const uint4 acc = body_chunk_lane<NR, MODE>(km, tb, p, smem, cc, c, lane);
         p.parts[(size_t)c * 64 + lane] = acc;
@@ -997,8 +995,6 @@ struct aesgcm_ctx {
     u32 counter_base = 0;              // value the packet dispenser (d_counter[0]) holds before the next launch
     u32 qset = 0;                      // which of the two sets of chunk queues (d_counter[16 (1 + 16 set + q)]) the next dynamic launch of k_main / k_body uses; that launch zeroes the other set
     u32 tw_override = 0;               // AESGCM_TW
-    u64 tail_min = (u64)1 << 30;       // bodies of at least this many bytes get a region B (AESGCM_TAIL_MIN)
-    u32 tail_waves = 0;                // k_body: waves whose last chunk the finer region B is sized for (plan_body_tail); 0 = one region (AESGCM_BODY_TAIL=0)
     u64 body_min = (u64)256 << 20;     // ranges with an aligned middle of at least this many bytes go through k_body (AESGCM_BODY_MIN).  Since k_main
                                        // got cheaper below 256 MiB (dispensers, k_fold: profiles/r02f/split_threshold.txt) the cut pays from 256 MiB:
                                        // 128 MiB -16 %, 256 MiB +0.8 %, 512 MiB +4 %, 1 GiB +11 %, 2 GiB +7 %; it was 128 MiB before, 0.7 GiB in round 1
@@ -1072,6 +1068,8 @@ static int set_lds_attrs(int device, DeviceState *ds) {
     SETATTRY(10, MODE_PROBE); SETATTRY(12, MODE_PROBE); SETATTRY(14, MODE_PROBE);
 #undef SETATTRY
 #define SETATTRB(NR, D) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch<NR, D>), hipFuncAttributeMaxDynamicSharedMemorySize, BATCH_LDS_BYTES)); \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktg<NR, D, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, PKTG_LDS_BYTES(2))); \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktg<NR, D, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, PKTG_LDS_BYTES(3))); \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktg<NR, D, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, PKTG_LDS_BYTES(4))); \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktg<NR, D, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, PKTG_LDS_BYTES(6))); \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktl<NR, D>), hipFuncAttributeMaxDynamicSharedMemorySize, AESGCM_LDS_BYTES))
@@ -1190,17 +1188,12 @@ static int enqueue_main(aesgcm_ctx *c, int mode, const uint8_t iv[12], const voi
 
 static int enqueue_combine(aesgcm_ctx *c, const CombineParams &p, hipStream_t st);
 
-// k_body over the planned split + the k_fold levels over its interleaved chunk items.  *po describes the partials of the LAST
-// region and *nb_out the blocks they cover; with a region B (plan_body_tail) region A has already been folded into the device
-// chaining value `state` (Y <- Y H^blocks(A) ^ P_A, the streaming step) when this returns, so the caller's own step -- carry
-// combine or tag -- is the same as for a one-region body, over nb_out blocks.
-static int enqueue_body(aesgcm_ctx *c, int mode, const uint8_t iv[12], const BodySplit &b0, const void *d_in, void *d_out,
-                        u64 first_block, hipStream_t st, Partials *po, uint4 *state, u64 *nb_out) {
-    BodySplit b = b0;
-    if (state && b.body_blocks * 16 >= c->tail_min) plan_body_tail(&b, c->tail_waves);
+// k_body over the planned split + the k_fold levels over its interleaved chunk items
+static int enqueue_body(aesgcm_ctx *c, int mode, const uint8_t iv[12], const BodySplit &b, const void *d_in, void *d_out,
+                        u64 first_block, hipStream_t st, Partials *po) {
     BodyParams p;
     memset(&p, 0, sizeof p);
-    int rc = grow_parts(c, (size_t)4 * (b.S + b.Sb));
+    int rc = grow_parts(c, (size_t)4 * b.S);
     if (rc) return rc;
     plan_body(p, b, iv, d_in, d_out, first_block, c->parts);
     p.ej0 = c->d_tag + 3; po->ej0 = p.ej0;
@@ -1236,19 +1229,7 @@ static int enqueue_body(aesgcm_ctx *c, int mode, const uint8_t iv[12], const Bod
     if (c->timing) { HIPCHK(hipEventRecord(evp.second, st)); c->ev.push_back(evp); }
     if (c->ev_fused) HIPCHK(hipEventRecord(c->ev_fused, st));
     // items 4s + v: phases 64 blocks apart inside a super-chunk, super-chunks 256 T blocks apart
-    if (!b.Sb) {
-        if (nb_out) *nb_out = b.body_blocks;
-        return enqueue_fold(c, c->parts, p.C, 4, 64, (u64)256 * b.T, st, po);
-    }
-    const u64 nbA = (u64)256 * b.T * b.S, nbB = (u64)256 * b.Tb * b.Sb;
-    Partials pa;
-    if ((rc = enqueue_fold(c, c->parts, p.Ca, 4, 64, (u64)256 * b.T, st, &pa))) return rc;
-    if ((rc = enqueue_combine(c, combine_with_items(plan_combine_carry(pa.ptr, pa.np, pa.kind, state, nbA), pa.eA), st))) return rc;
-    const uint4 *ej0 = po->ej0;
-    rc = enqueue_fold(c, c->parts + (size_t)p.Ca * 64, p.C - p.Ca, 4, 64, (u64)256 * b.Tb, st, po);
-    po->ej0 = ej0;
-    if (nb_out) *nb_out = nbB;
-    return rc;
+    return enqueue_fold(c, c->parts, p.C, 4, 64, (u64)256 * b.T, st, po);
 }
 
 // Y' = Y * H^nb ^ P(aad, data) for a whole range, Y in *state (device).  Large ranges go head / k_body / tail,
@@ -1272,10 +1253,9 @@ static int absorb_range(aesgcm_ctx *c, int mode, const uint8_t iv[12], const voi
         if (rc) return rc;
         if ((rc = enqueue_combine(c, combine_with_items(plan_combine_carry(pp.ptr, pp.np, pp.kind, state, n_aad + b.head_blocks), pp.eA), st))) return rc;
     }
-    u64 nb_last = 0;
-    if ((rc = enqueue_body(c, mode, iv, b, d_in, d_out, first_block, st, &pp, state, &nb_last))) return rc;
+    if ((rc = enqueue_body(c, mode, iv, b, d_in, d_out, first_block, st, &pp))) return rc;
     if (ej0) *ej0 = pp.ej0;                                      // valid until the next launch on this context overwrites the slot: consumed by the caller's final combine
-    if ((rc = enqueue_combine(c, combine_with_items(plan_combine_carry(pp.ptr, pp.np, pp.kind, state, nb_last), pp.eA), st))) return rc;
+    if ((rc = enqueue_combine(c, combine_with_items(plan_combine_carry(pp.ptr, pp.np, pp.kind, state, b.body_blocks), pp.eA), st))) return rc;
     const u64 done = b.head_blocks + b.body_blocks, tail = len - 16 * done;
     if (tail) {
         c->timing_mute = true;
@@ -1322,13 +1302,9 @@ static int crypt_dev(aesgcm_ctx *c, int dec, const uint8_t iv[12], const void *d
             // the whole message is one aligned body (the benchmark's shape): no chaining value to carry, k_body's items go
             // straight to the tag
             Partials pb;
-            uint4 *state = c->d_tag + 2;                         // used only when the body has a region B: region A's polynomial waits there
-            u64 nb_last = 0;
-            HIPCHK(hipMemsetAsync(state, 0, 16, st));
-            if ((rc = enqueue_body(c, dec ? MODE_DEC : MODE_ENC, iv, b, d_in, d_out, 0, st, &pb, state, &nb_last))) return rc;
+            if ((rc = enqueue_body(c, dec ? MODE_DEC : MODE_ENC, iv, b, d_in, d_out, 0, st, &pb))) return rc;
             CombineParams q = combine_with_items(plan_combine_tag(pb.ptr, pb.np, pb.kind, iv, 0, len, c->d_tag), pb.eA);
             q.ej0 = pb.ej0;
-            if (nb_last != b.body_blocks) { q.carry = state; q.has_carry = 1; q.e_carry = nb_last; }    // tag = (Y H^nb ^ P_B) H^2 ^ L H ^ E_K(J0)
             return enqueue_combine(c, q, st);
         }
         // large message: head / k_body / tail folded into a device-side chaining value, then the tag from it
@@ -1443,9 +1419,6 @@ static int ctx_create_common(aesgcm_ctx **out, int device, const uint8_t *key, s
     if (const char *e = getenv("AESGCM_WGS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 2) per_cu = v; }
     if (const char *e = getenv("AESGCM_TW")) c->tw_override = (u32)strtoul(e, nullptr, 0);
     if (const char *e = getenv("AESGCM_BODY_MIN")) c->body_min = strtoull(e, nullptr, 0);
-    c->tail_waves = (u32)(per_cu * ds->n_cu / 2) * (AESGCM_BODY_WG / 64);                 // k_body's resident waves
-    if (const char *e = getenv("AESGCM_BODY_TAIL")) c->tail_waves = (u32)strtoul(e, nullptr, 0);
-    if (const char *e = getenv("AESGCM_TAIL_MIN")) c->tail_min = strtoull(e, nullptr, 0);
     int G = per_cu * ds->n_cu;
     if (G > AESGCM_GMAX) G = AESGCM_GMAX;
     if (G < 1) G = 1;
@@ -1872,7 +1845,11 @@ int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const vo
     // not know the lengths and goes by count alone.  AESGCM_PKT_SHAPE=l|g|w forces lane / 16-lane group / wave.
     int shape = (d_data_off ? n_pkts >= 32768 : (n_pkts >= 131072 || (pkt_len <= 256 && n_pkts >= 8192))) ? 'l'
               : (n_pkts >= (size_t)4 * n_cu * waves_per_wg || (!d_data_off && pkt_len <= 1024)) ? 'g' : 'w';
-    if (const char *e = getenv("AESGCM_PKT_SHAPE")) { if (e[0] == 'l' || e[0] == 'g' || e[0] == 'w') shape = e[0]; }
+    int lg = shape == 'g' ? 4 : 6;
+    if (const char *e = getenv("AESGCM_PKT_SHAPE")) {                                // l | w | g (= g16) | g8 | g4
+        if (e[0] == 'l' || e[0] == 'g' || e[0] == 'w') shape = e[0];
+        lg = shape == 'g' ? (e[1] == '8' ? 3 : e[1] == '4' ? 2 : 4) : 6;
+    }
     hipStream_t st = pick_stream(c, stream);
     p.counter = c->d_counter; p.counter_base = c->counter_base;
     if (shape == 'l') {
@@ -1885,7 +1862,6 @@ int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const vo
         else         { if (c->nr == 10) LP(10, 0); else if (c->nr == 12) LP(12, 0); else LP(14, 0); }
 #undef LP
     } else {
-        const int lg = shape == 'g' ? 4 : 6;
         const u32 P = 64u >> lg;                                                    // packets per wave-iteration
         // deal: about 4 dispenser fetches per resident wave, a multiple of P, at most 64 packets (one E_K(J0) pass per fetch)
         u32 deal = (u32)(n_pkts / ((size_t)n_cu * waves_per_wg * 4));
@@ -1897,11 +1873,12 @@ int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const vo
         u32 wgs = (nb + waves_per_wg - 1) / waves_per_wg;
         if (wgs > n_cu) wgs = n_cu;                                                  // one workgroup per CU (LDS)
         c->counter_base += nb + wgs * waves_per_wg;                                 // every wave ends on one failing fetch
-#define LP(NR, D) do { if (lg == 4) hipLaunchKernelGGL((k_pktg<NR, D, 4>), dim3(wgs), dim3(AESGCM_PKT_WG), PKTG_LDS_BYTES(4), st, c->km, c->tables, p); \
-                       else hipLaunchKernelGGL((k_pktg<NR, D, 6>), dim3(wgs), dim3(AESGCM_PKT_WG), PKTG_LDS_BYTES(6), st, c->km, c->tables, p); } while (0)
+#define LPG(NR, D, LG) hipLaunchKernelGGL((k_pktg<NR, D, LG>), dim3(wgs), dim3(AESGCM_PKT_WG), PKTG_LDS_BYTES(LG), st, c->km, c->tables, p)
+#define LP(NR, D) do { if (lg == 2) LPG(NR, D, 2); else if (lg == 3) LPG(NR, D, 3); else if (lg == 4) LPG(NR, D, 4); else LPG(NR, D, 6); } while (0)
         if (decrypt) { if (c->nr == 10) LP(10, 1); else if (c->nr == 12) LP(12, 1); else LP(14, 1); }
         else         { if (c->nr == 10) LP(10, 0); else if (c->nr == 12) LP(12, 0); else LP(14, 0); }
 #undef LP
+#undef LPG
     }
     const hipError_t le = hipGetLastError();
     if (le != hipSuccess) { c->counter_base = p.counter_base; return hip_fail(le, "k_pkt launch"); }
@@ -1936,11 +1913,12 @@ static int batch_launch(int device, int decrypt, size_t n_pkts, size_t key_len, 
     const int nr = (int)(key_len / 4 + 6);
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipMemsetAsync(p.counter, 0, 4, st));
-    // shape: 16 lanes per packet (k_batch2<.., 4>: four packets share a wave's tree and closing multiplies) once there are
-    // enough packets to fill the machine that way (one 1024-lane workgroup per CU = 64 packets per CU), else one wave
-    // per packet (k_batch).  AESGCM_BATCH_LG=4|6 forces one.  Measured, 2^20 packets AES-128 (profiles/r02c): 4 KiB 11.9 ->
-    // 6.6 ms, 1 KiB 7.8 -> 2.8 ms, 256 B (2^22 packets) 30.0 -> 5.7 ms; 32 lanes per packet was never better than 16.
-    int lg = n_pkts >= (size_t)64 * ds->n_cu ? 4 : 6;
+    // shape: 16 lanes per packet in one pass (k_batch3: four packets share a wave's tree and closing multiplies) once there are
+    // enough packets to fill the machine that way (one 1024-lane workgroup per CU = 64 packets per CU) or the packets are short,
+    // else one wave per packet (k_batch).  AESGCM_BATCH_LG=4|6 forces one.  Measured, AES-128, GiB/s k_batch / k_batch3
+    // (profiles/r03/batch_sweep_aes128.txt): 4096 x 1 KiB 30 / 56, 4096 x 256 B 7.5 / 17, 1024 x 1 KiB 14 / 16.5; 1024 x 4 KiB
+    // 45 / 33, 4096 x 4 KiB 108 / 120, 4096 x 16 KiB 286 / 168; from 16384 packets k_batch3 wins at every size (4 KiB 179 / 350).
+    int lg = (n_pkts >= (size_t)64 * ds->n_cu || (!p.data_off && p.pkt_len <= 2048)) ? 4 : 6;
     if (const char *e = getenv("AESGCM_BATCH_LG")) { const int v = atoi(e); if (v == 4 || v == 6) lg = v; }
     if (lg < 6) {
         const u32 P = 64u >> lg, per_wg = waves_per_wg * P;
@@ -2240,7 +2218,7 @@ int aesgcm_ctx_ceiling_probe(aesgcm_ctx *c, size_t nbytes, double *ms, uint64_t 
     c->timing = true;
     HIPCHK(hipStreamSynchronize(c->stream));
     const size_t mark = c->ev.size();
-    int rc = enqueue_body(c, MODE_PROBE, iv, b, nullptr, nullptr, 0, c->stream, &pp, c->d_tag + 2, nullptr);
+    int rc = enqueue_body(c, MODE_PROBE, iv, b, nullptr, nullptr, 0, c->stream, &pp);
     c->timing = was;
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Packets under one key: the three kernel shapes (one wave / 16 lanes / one lane per packet) over packet count and size (GPU box).
+"""Packets under one key: the kernel shapes (one wave / 16, 8, 4 lanes / one lane per packet) over packet count and size (GPU box).
 Prints GiB/s; the library's own choice (AESGCM_PKT_SHAPE unset) is the last column."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,7 +10,7 @@ ctx = lib.Context(bytes(range(kb)))
 nmax = 1 << 20
 d_ivs = lib.DeviceBuffer(12 * nmax); d_ivs.fill_splitmix64(2, nbytes=12 * nmax // 8 * 8)
 d_tags = lib.DeviceBuffer(16 * nmax)
-print("AES-%d   n_pkts  pkt_B     wave  group16     lane     auto   (GiB/s)" % (kb * 8))
+print("AES-%d   n_pkts  pkt_B     wave  group16   group8   group4     lane     auto   (GiB/s)" % (kb * 8))
 for pkt in (64, 256, 1024, 4096, 16384):
     nm = min(nmax, (1 << 32) // pkt)
     d_pt, d_ct = lib.DeviceBuffer(pkt * nm), lib.DeviceBuffer(pkt * nm)
@@ -19,7 +19,7 @@ for pkt in (64, 256, 1024, 4096, 16384):
         n = 1 << ln
         if n > nm: break
         row = []
-        for shape in ("w", "g", "l", None):
+        for shape in ("w", "g", "g8", "g4", "l", None):
             if shape: os.environ["AESGCM_PKT_SHAPE"] = shape
             else: os.environ.pop("AESGCM_PKT_SHAPE", None)
             best = 1e9
@@ -28,5 +28,5 @@ for pkt in (64, 256, 1024, 4096, 16384):
                 ctx.packets_crypt_dev(False, n, d_ivs.ptr, d_pt.ptr, d_ct.ptr, d_tags.ptr, pkt_len=pkt)
                 lib.dev_sync(); best = min(best, time.perf_counter() - t0)
             row.append(n * pkt / best / (1 << 30))
-        print("        %8d %6d %8.1f %8.1f %8.1f %8.1f" % (n, pkt, *row), flush=True)
+        print("        %8d %6d %8.1f %8.1f %8.1f %8.1f %8.1f %8.1f" % (n, pkt, *row), flush=True)
     del d_pt, d_ct

@@ -17,17 +17,20 @@ import aesgcm_amd  # noqa: E402,F401
 from aesgcm_amd import lib  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("kind", choices=("batch", "pktw", "pktg", "pktl"))
+ap.add_argument("kind", choices=("batch", "pktw", "pktg", "pktg8", "pktg4", "pktl"))
 ap.add_argument("--n", type=int, default=1 << 20)
 ap.add_argument("--len", type=int, default=4096)
 ap.add_argument("--key-bits", type=int, default=128)
 ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--inplace", action="store_true", help="write the output over the input (traffic probe: no separate output lines)")
 a = ap.parse_args()
 n, pkt, kb = a.n, a.len, a.key_bits // 8
 d_ivs = lib.DeviceBuffer(16 * n)
 d_ivs.fill_splitmix64(0x4956)
 d_pt, d_ct, d_tags = lib.DeviceBuffer(pkt * n), lib.DeviceBuffer(pkt * n), lib.DeviceBuffer(16 * n)
 d_pt.fill_splitmix64(0xAE5C0005)
+if a.inplace:
+    d_ct = d_pt
 if a.kind == "batch":
     d_keys = lib.DeviceBuffer(kb * n)
     d_keys.fill_splitmix64(0x4B4559)
@@ -35,7 +38,7 @@ if a.kind == "batch":
     def go():
         lib.batch_crypt_dev(False, n, kb, d_keys.ptr, d_ivs.ptr, d_pt.ptr, pkt, d_ct.ptr, d_tags.ptr)
 else:
-    os.environ["AESGCM_PKT_SHAPE"] = {"pktw": "w", "pktg": "g", "pktl": "l"}[a.kind]
+    os.environ["AESGCM_PKT_SHAPE"] = {"pktw": "w", "pktg": "g", "pktg8": "g8", "pktg4": "g4", "pktl": "l"}[a.kind]
     ctx = lib.Context(bytes(range(kb)))
 
     def go():

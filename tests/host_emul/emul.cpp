@@ -134,7 +134,7 @@ static void emu_combine(const KeyMaterial *km, const CombineParams &p0) {
 
 struct Parts { const uint4 *ptr; u32 np; u32 gathered; u64 eA; };   // gathered = PARTS_* kind; eA: item spacing when k_combine folds the items itself
 struct Emu {
-    KeyMaterial km; u32 tw; u32 tail_waves = 0; std::vector<uint4> parts, fold_a, fold_b;
+    KeyMaterial km; u32 tw; std::vector<uint4> parts, fold_a, fold_b;
     Emu(const uint8_t *key, int key_len, u32 tw_) : tw(tw_), parts(1 << 16), fold_a(1 << 16), fold_b(1 << 12) { emu_setup(&km, key, key_len, 0, 512); }
     // mirrors enqueue_fold(): k_fold launches until one item is left
     Parts fold(const uint4 *items, u32 n, u32 period, u64 eA, u64 eB) {
@@ -186,19 +186,12 @@ struct Emu {
         return fold(parts.data(), C, 1, eA, 0);
     }
     // mirrors enqueue_body(): k_body + k_fold with the interleaved first level
-    Parts run_body(int mode, const uint8_t *iv, const BodySplit &b0, const void *in, void *out, u64 first_block, uint4 *state, u64 *nb_out) {
-        BodySplit b = b0;
-        plan_body_tail(&b, tail_waves);
+    Parts run_body(int mode, const uint8_t *iv, const BodySplit &b, const void *in, void *out, u64 first_block) {
         BodyParams p; memset(&p, 0, sizeof p);
-        if (parts.size() < 256 * (size_t)(b.S + b.Sb)) parts.resize(256 * (size_t)(b.S + b.Sb));
+        if (parts.size() < 256 * (size_t)b.S) parts.resize(256 * (size_t)b.S);
         plan_body(p, b, iv, in, out, first_block, parts.data());
         emu_body(mode, &km, p);
-        if (!b.Sb) { *nb_out = b.body_blocks; return fold(parts.data(), p.C, 4, 64, (u64)256 * b.T); }
-        // region A goes into the chaining value first (the streaming step), region B is what the caller combines
-        const Parts pa = fold(parts.data(), p.Ca, 4, 64, (u64)256 * b.T);
-        emu_combine(&km, combine_with_items(plan_combine_carry(pa.ptr, pa.np, pa.gathered, state, (u64)256 * b.T * b.S), pa.eA));
-        *nb_out = (u64)256 * b.Tb * b.Sb;
-        return fold(parts.data() + (size_t)p.Ca * 64, p.C - p.Ca, 4, 64, (u64)256 * b.Tb);
+        return fold(parts.data(), p.C, 4, 64, (u64)256 * b.T);
     }
     // mirrors absorb_range()
     bool absorb(int mode, const uint8_t *iv, const uint8_t *aad, u64 aad_len, const uint8_t *in, u64 len, uint8_t *out, u64 first_block, u64 body_min, uint4 *Y) {
@@ -214,9 +207,8 @@ struct Emu {
             Parts pp = run(mode, iv, aad, aad_len, in, 16 * b.head_blocks, out, first_block);
             emu_combine(&km, combine_with_items(plan_combine_carry(pp.ptr, pp.np, pp.gathered, Y, n_aad + b.head_blocks), pp.eA));
         }
-        u64 nb_last = 0;
-        Parts pb = run_body(mode, iv, b, in, out, first_block, Y, &nb_last);
-        emu_combine(&km, combine_with_items(plan_combine_carry(pb.ptr, pb.np, pb.gathered, Y, nb_last), pb.eA));
+        Parts pb = run_body(mode, iv, b, in, out, first_block);
+        emu_combine(&km, combine_with_items(plan_combine_carry(pb.ptr, pb.np, pb.gathered, Y, b.body_blocks), pb.eA));
         const u64 done = b.head_blocks + b.body_blocks, tail = len - 16 * done;
         if (tail) {
             Parts pp = run(mode, iv, nullptr, 0, in + 16 * done, tail, out + 16 * done, first_block + done);
@@ -230,11 +222,8 @@ struct Emu {
         BodySplit b0;
         if (plan_body_split(len, 0, tw, body_min, &b0) && !aad_len && !b0.head_blocks && len == 16 * b0.body_blocks) {
             // the whole message is one aligned body: k_body's items go straight to the tag (no chaining value)
-            u64 nb_last = 0;
-            Parts pb = run_body(dec ? MODE_DEC : MODE_ENC, iv, b0, in, out, 0, &Y, &nb_last);
-            CombineParams q = combine_with_items(plan_combine_tag(pb.ptr, pb.np, pb.gathered, iv, 0, len, &t), pb.eA);
-            if (nb_last != b0.body_blocks) { q.carry = &Y; q.has_carry = 1; q.e_carry = nb_last; }      // region A waits in Y
-            emu_combine(&km, q);
+            Parts pb = run_body(dec ? MODE_DEC : MODE_ENC, iv, b0, in, out, 0);
+            emu_combine(&km, combine_with_items(plan_combine_tag(pb.ptr, pb.np, pb.gathered, iv, 0, len, &t), pb.eA));
             memcpy(tag, &t, 16);
             return true;
         }
@@ -419,14 +408,15 @@ static void test_packets(int key_len, u64 seed) {
     p.ivs = ivs.data(); p.aad = aad.data(); p.in = in.p; p.out = out.p; p.tags = tags.data();
     p.data_off = doff.data(); p.aad_off = aoff.data(); p.n_pkts = n; p.aligned = 1;
     static unsigned char smem[PKTG_LDS_BYTES(6)] __attribute__((aligned(16)));
-    for (int lg = 4; lg <= 6; lg += 2) {
+    for (int lg : {2, 3, 4, 6}) {
         memset(smem, 0xEE, sizeof smem);
         for (u32 tid = 0; tid < AESGCM_PKT_WG; tid++) pktg_fill_lds(smem, &E.km, &g_tb, tid, AESGCM_PKT_WG, lg);
         for (int dec = 0; dec < 2; dec++) {
             p.in = dec ? out.p : in.p; p.out = out.p;           // decrypt in place
             for (u32 pkt = 0; pkt < (u32)n; pkt++) {
-                const u32 extra = (pkt % 3 == 1) ? 2 : 0, grp = lg == 4 ? pkt & 3 : 0;
-                const uint4 t = lg == 4 ? emu_pktg<4>(&E.km, dec, p, smem, pkt, extra, grp) : emu_pktg<6>(&E.km, dec, p, smem, pkt, extra, grp);
+                const u32 extra = (pkt % 3 == 1) ? 2 : 0, grp = pkt & ((64u >> lg) - 1u);
+                const uint4 t = lg == 2 ? emu_pktg<2>(&E.km, dec, p, smem, pkt, extra, grp) : lg == 3 ? emu_pktg<3>(&E.km, dec, p, smem, pkt, extra, grp)
+                              : lg == 4 ? emu_pktg<4>(&E.km, dec, p, smem, pkt, extra, grp) : emu_pktg<6>(&E.km, dec, p, smem, pkt, extra, grp);
                 std::vector<uint8_t> ref(lens[pkt] + 16); uint8_t rtag[16];
                 if (!dec) {
                     orc_gcm_crypt(0, key.data(), key_len, ivs.data() + 12 * pkt, aad.data() + aoff[pkt], aads[pkt], in.p + doff[pkt], lens[pkt], ref.data(), rtag);
@@ -563,20 +553,13 @@ static void test_shards(int key_len, u32 G, u64 al, u64 n, int R, u64 seed) {
 }
 
 // head / k_body / tail split (absorb_range): whole messages and shards with arbitrary first blocks
-static void test_body(int key_len, u32 G, u64 al, u64 n, u64 seed, u32 tail_waves = 0) {
+static void test_body(int key_len, u32 G, u64 al, u64 n, u64 seed) {
     auto key = rnd(key_len, seed), iv = rnd(12, seed + 1), aad = rnd(al, seed + 2);
     ABuf pt(n), ct(n), ref(n), back(n);
     orc_fill_splitmix64(pt.p, n, seed + 3, 0);
     uint8_t rtag[16], tag[16], dtag[16];
     orc_gcm_crypt(0, key.data(), key_len, iv.data(), aad.data(), al, pt.p, n, ref.p, rtag);
     Emu E(key.data(), key_len, G);
-    E.tail_waves = tail_waves;                   // > 0: the end of every body is cut into chunks of T / 8 rows (region B, plan_body_tail)
-    if (tail_waves) {
-        BodySplit bs;
-        CHECK(plan_body_split(n, 0, G, 4096, &bs), "tail case does not split");
-        plan_body_tail(&bs, tail_waves);
-        CHECK(bs.Sb > 0, "tail case has no region B: T %u S %u", bs.T, bs.S);
-    }
     const bool split = E.crypt_split(0, iv.data(), aad.data(), al, pt.p, n, ct.p, tag, 4096);
     CHECK(split, "body split did not apply: len %llu G %u", (unsigned long long)n, G);
     CHECK(memcmp(ct.p, ref.p, n) == 0, "body ct key %d G %u aad %llu len %llu", key_len, G, (unsigned long long)al, (unsigned long long)n);
@@ -687,10 +670,6 @@ int main(int argc, char **argv) {
     test_body(32, 1, 16, 16 * 254 + 16 * 1024 * 2, 104);          // head = 254 blocks exactly, empty tail
     test_body(16, 2, 0, 16 * 256 * 2 * 6, 106);                     // no AAD, no head, no tail: the whole message is one body (direct tag path)
     test_body(32, 1, 0, 16 * 256 * 300, 107);                       // ... with enough items for a k_fold level before k_combine's own fold
-    // region B (the finer chunks at the end of a body): direct tag path, AAD + head + tail, shards whose bodies have one too
-    test_body(16, 8, 0, 16 * 256 * 8 * 9, 108, 4);                  // T = 8, Tb = 1: 9 super-chunks, 1 converted
-    test_body(32, 8, 20, 16 * (100 + 256 * 8 * 13 + 77) + 5, 109, 7);
-    test_body(24, 16, 0, 16 * 256 * 16 * 12, 110, 9);               // T = 16, Tb = 2, 3 super-chunks converted
     test_batch_pieces();
     test_packets(16, 61); test_packets(24, 62); test_packets(32, 63);
     if (level > 1) {

@@ -35,7 +35,7 @@ def main():
     t0 = time.time()
     while launches < n_launch:
         n = rng.choice(counts) if rng.random() < 0.5 else rng.randrange(1, 300)
-        kind = rng.choice(("pkt_w", "pkt_g", "pkt_l", "batch"))
+        kind = rng.choice(("pkt_w", "pkt_g", "pkt_g8", "pkt_g4", "pkt_l", "batch"))
         kb = rng.choice((16, 24, 32))
         # packet lengths: many zero-length and tiny ones, a few long; total bounded by MAXB
         mean = max(1, min(2000, MAXB // n))
@@ -56,7 +56,7 @@ def main():
             lib.batch_crypt_var_dev(False, n, kb, d_keys.ptr, d_ivs.ptr, d_in.ptr, d_doff.ptr, d_out.ptr, d_tags.ptr,
                                     d_aad=d_aad.ptr, d_aad_off=d_aoff.ptr)
         else:
-            os.environ["AESGCM_PKT_SHAPE"] = {"pkt_w": "w", "pkt_g": "g", "pkt_l": "l"}[kind]
+            os.environ["AESGCM_PKT_SHAPE"] = {"pkt_w": "w", "pkt_g": "g", "pkt_g8": "g8", "pkt_g4": "g4", "pkt_l": "l"}[kind]
             os.environ["AESGCM_PKT_DEAL"] = str(rng.choice((1, 3, 16, 64)))
             ctxs[kb].packets_crypt_dev(False, n, d_ivs.ptr, d_in.ptr, d_out.ptr, d_tags.ptr, d_aad=d_aad.ptr,
                                        d_aad_off=d_aoff.ptr, d_data_off=d_doff.ptr)

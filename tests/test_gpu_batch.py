@@ -148,7 +148,7 @@ def test_variable_length_packets_macsec_shaped(hip, orc):
     assert set(struct.unpack("<%di" % n, bytes(d_auth.download()))) == {1}
 
 
-@pytest.mark.parametrize("shape", ["wave", "group16", "lane"])
+@pytest.mark.parametrize("shape", ["wave", "group16", "g8", "g4", "lane"])
 def test_packets_under_one_key(hip, orc, shape, monkeypatch):
     """aesgcm_packets_crypt_dev: one key (context), per-packet IV, AAD and length; fixed-size records and offset
     arrays; decrypt in place with per-packet authentication.  The three kernel shapes (one wave per packet and 16 lanes per
