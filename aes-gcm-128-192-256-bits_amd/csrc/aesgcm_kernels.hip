@@ -1837,18 +1837,31 @@ int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const vo
     p.aligned = (((uintptr_t)d_in | (uintptr_t)d_out) & 15) == 0 && (d_data_off || pkt_len % 16 == 0);
     const u32 waves_per_wg = AESGCM_PKT_WG / 64;
     const u32 n_cu = (u32)c->G / 2;                                                 // c->G = two workgroups per CU
-    // shape.  One LANE per packet (k_pktl) when there are enough packets to fill the machine with lanes; otherwise lane GROUPS
-    // (k_pktg): 16 lanes per packet (four packets per wave) once four packets per resident wave exist or the packets are short,
-    // else one packet per wave.  Measured crossovers (profiles/r03/packets_sweep_aes256.txt, AES-256, GiB/s group16 / lane):
-    // 65536 x 1 KiB 231 / 195, 262144 x 1 KiB 491 / 628, 262144 x 4 KiB 649 / 709, 16384 x 256 B 35 / 41, 4096 x 256 B 23 / 11;
-    // wave / group16: 4096 x 4 KiB 126 / 130, 1024 x 4 KiB 65 / 37, 4096 x 16 KiB 363 / 172.  With offset arrays the host does
-    // not know the lengths and goes by count alone.  AESGCM_PKT_SHAPE=l|g|w forces lane / 16-lane group / wave.
-    int shape = (d_data_off ? n_pkts >= 32768 : (n_pkts >= 131072 || (pkt_len <= 256 && n_pkts >= 8192))) ? 'l'
-              : (n_pkts >= (size_t)4 * n_cu * waves_per_wg || (!d_data_off && pkt_len <= 1024)) ? 'g' : 'w';
-    int lg = shape == 'g' ? 4 : 6;
+    // shape: how many lanes work on one packet.  One LANE per packet (k_pktl) when the packets alone fill the machine's lanes;
+    // otherwise a lane GROUP per packet (k_pktg: 4, 8 or 16 lanes, 16 / 8 / 4 packets per wave) or a whole wave (k_pktg<.., 6>).
+    // Measured (profiles/r03/packets_sweep_aes256.txt, GiB/s wave / g16 / g8 / g4 / lane): the best shape is the one that just
+    // fills the resident lanes (256 CUs x 16 waves x 64) -- 65536 x 1 KiB 203 / 232 / 340 / 384 / 194, 16384 x 4 KiB 235 / 367 /
+    // 290 / 177 / 53, 4096 x 16 KiB 362 / 172 / 95 / 49 / 13 -- but never more lanes than an eighth of the packet's blocks once
+    // the machine is full (closing cost per byte: 16384 x 1 KiB 62 / 128 / 176 / 138 / 50, 16384 x 256 B 16 / 35 / 58 / 72 / 41), a
+    // quarter when it is not (4096 x 1 KiB 34 / 69 / 57 / 38 / 13).  Lanes win from 131072 packets (2^20 x 1 KiB 303 / 592 / 657 /
+    // 742 / 767; 262144 x 4 KiB 496 / 656 / 704 / 722 / 724), short packets from 32768 (65536 x 256 B 51 / 61 / 95 / 129 / 148).
+    // With offset arrays the host does not know the lengths: it goes by count and assumes 1 KiB.
+    // AESGCM_PKT_SHAPE=l|w|g|g8|g4 forces lane / wave / 16- / 8- / 4-lane groups.
+    const size_t lanes_total = (size_t)n_cu * waves_per_wg * 64;
+    const size_t blocks = d_data_off ? 64 : (pkt_len + 15) / 16;
+    int shape, lg = 6;
+    if (d_data_off ? n_pkts >= 32768 : (n_pkts >= 131072 || (pkt_len <= 256 && n_pkts >= 32768))) shape = 'l';
+    else {
+        const size_t fill = lanes_total / n_pkts, cap = n_pkts >= 16384 ? blocks / 8 : blocks / 4;
+        const size_t g = fill < cap ? fill : cap;
+        lg = g >= 64 ? 6 : g >= 16 ? 4 : g >= 8 ? 3 : 2;
+        shape = lg == 6 ? 'w' : 'g';
+    }
     if (const char *e = getenv("AESGCM_PKT_SHAPE")) {                                // l | w | g (= g16) | g8 | g4
-        if (e[0] == 'l' || e[0] == 'g' || e[0] == 'w') shape = e[0];
-        lg = shape == 'g' ? (e[1] == '8' ? 3 : e[1] == '4' ? 2 : 4) : 6;
+        if (e[0] == 'l' || e[0] == 'g' || e[0] == 'w') {
+            shape = e[0];
+            lg = shape == 'g' ? (e[1] == '8' ? 3 : e[1] == '4' ? 2 : 4) : 6;
+        }
     }
     hipStream_t st = pick_stream(c, stream);
     p.counter = c->d_counter; p.counter_base = c->counter_base;
