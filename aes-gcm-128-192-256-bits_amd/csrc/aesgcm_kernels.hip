@@ -330,8 +330,7 @@ __device__ __forceinline__ G128 gf_pow_h(const KeyMaterial *km, u64 e, u32 lane)
     return v;       // lanes 0..3 all hold the product
 }
 
-__global__ __launch_bounds__(COMBINE_THREADS) void k_combine(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const CombineParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // no static LDS: table offsets are absolute (CMB_LDS_*)
+__device__ __forceinline__ void combine_body(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const CombineParams &p, unsigned char *smem) {
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
     const bool tag = p.want_tag != 0, items = p.kind == PARTS_ITEM;
     const u32 J1 = items ? fold4_groups(p.np) : 0, J2 = items ? fold4_groups(J1) : 0;      // groups at level 1 (<= 16) and level 2 (<= 4)
@@ -386,6 +385,18 @@ __global__ __launch_bounds__(COMBINE_THREADS) void k_combine(const KeyMaterial *
             if (p.out_host) publish_host(p.out_host, be_to_mo(acc), p.gen);
         }
     }
+}
+
+__global__ __launch_bounds__(COMBINE_THREADS) void k_combine(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const CombineParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // no static LDS: table offsets are absolute (CMB_LDS_*)
+    combine_body(km, tb, p, smem);
+}
+// several independent messages in ONE launch, one workgroup each (aesgcm_shard_finalize_batch_dev: the M tags of a multi-GPU step)
+#define COMBINE_BATCH_MAX 8
+struct CombineBatch { CombineParams p[COMBINE_BATCH_MAX]; };
+__global__ __launch_bounds__(COMBINE_THREADS) void k_combine_batch(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const CombineBatch b) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    combine_body(km, tb, b.p[blockIdx.x], smem);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1001,6 +1012,8 @@ struct aesgcm_ctx {
     uint4 *h_tag = nullptr;            // 64 bytes of pinned, device-mapped host memory: k_combine leaves the tag here too, so fetching it
     uint4 *h_tag_dev = nullptr;        //   is a host read -- no copy kernel, no interrupt-driven stream wait (its device address)
     u64 tag_gen = 0;                   // generation number of the last result sent to the host slot (the kernel publishes it behind the tag)
+    uint4 *h_mtag = nullptr, *h_mtag_dev = nullptr;   // COMBINE_BATCH_MAX slots of {tag, generation} in pinned host memory (batched finalize); created on first use
+    uint4 *d_mtag = nullptr;
     uint4 *d_tag = nullptr;            // [0] tag / poly result, [1] streaming state Y
     u64 *d_trace = nullptr;            // per-workgroup trace of the last k_main launch (timing mode only)
     u32 last_np = 0;
@@ -1076,6 +1089,7 @@ static int set_lds_attrs(int device, DeviceState *ds) {
     SETATTRB(10, 0); SETATTRB(12, 0); SETATTRB(14, 0); SETATTRB(10, 1); SETATTRB(12, 1); SETATTRB(14, 1);
 #undef SETATTRB
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_combine), hipFuncAttributeMaxDynamicSharedMemorySize, CMB_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_combine_batch), hipFuncAttributeMaxDynamicSharedMemorySize, CMB_LDS_BYTES));
 #define SETATTRB2(NR, D, LG) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch2<NR, D, LG>), hipFuncAttributeMaxDynamicSharedMemorySize, BATCH2_LDS_BYTES(LG)))
     SETATTRB2(10, 0, 4); SETATTRB2(12, 0, 4); SETATTRB2(14, 0, 4); SETATTRB2(10, 1, 4); SETATTRB2(12, 1, 4); SETATTRB2(14, 1, 4);
 #define SETATTRB3(NR, D) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch3<NR, D>), hipFuncAttributeMaxDynamicSharedMemorySize, BATCH2_LDS_BYTES(4)))
@@ -1474,6 +1488,8 @@ int aesgcm_ctx_destroy(aesgcm_ctx *c) {
     if (c->d_counter) hipFree(c->d_counter);
     if (c->d_tag) hipFree(c->d_tag);
     if (c->h_tag) hipHostFree(c->h_tag);
+    if (c->h_mtag) hipHostFree(c->h_mtag);
+    if (c->d_mtag) hipFree(c->d_mtag);
     if (c->d_trace) hipFree(c->d_trace);
     pipeline_release(c);
     if (c->st_in) hipFree(c->st_in);
@@ -1727,6 +1743,13 @@ int aesgcm_shard_crypt_dev(aesgcm_ctx *c, int decrypt, const uint8_t iv[12], con
     const u64 after = total_blocks - (first_block + my_blocks);            // blocks of the message behind this shard
     BodySplit b;
     if (plan_body_split(len, first_block, c->tw_override, c->body_min, &b)) {
+        if (!aad_len && !b.head_blocks && len == 16 * b.body_blocks) {
+            // the shard is one aligned body (the 8-GPU job's shape: 4 GiB at a multiple of 256 blocks): its items go straight to the
+            // weighted partial W = P H^after -- no chaining value, one k_combine instead of memset + carry combine + weighting combine
+            Partials pb;
+            if ((rc = enqueue_body(c, decrypt ? MODE_DEC : MODE_ENC, iv, b, d_in, d_out, first_block, st, &pb))) return rc;
+            return enqueue_combine(c, combine_with_items(plan_combine_poly(pb.ptr, pb.np, pb.kind, after, (uint4 *)d_partial), pb.eA), st);
+        }
         uint4 *state = c->d_tag + 2;
         HIPCHK(hipMemsetAsync(state, 0, 16, st));
         if ((rc = absorb_range(c, decrypt ? MODE_DEC : MODE_ENC, iv, d_aad, aad_len, d_in, len, d_out, first_block, st, state))) return rc;
@@ -1749,6 +1772,57 @@ int aesgcm_shard_finalize_strided_dev(aesgcm_ctx *c, const uint8_t iv[12], const
     int rc = enqueue_combine(c, q, st);
     if (rc) return rc;
     if (tag) return fetch_tag(c, st, tag);
+    return AESGCM_OK;
+}
+// The tags of n_msgs messages in ONE launch (one workgroup per message) and one wait: what a multi-GPU step does after its single
+// all-gather.  Per message a k_combine launch costs ~15 us (E_K(IV || 1) bytewise on one lane) plus a host round trip for its tag;
+// four of them were ~140 us of a 17 ms rank step (profiles/r03/rank_step_trace.txt).
+int aesgcm_shard_finalize_batch_dev(aesgcm_ctx *c, size_t n_msgs, const uint8_t *ivs, const void *d_partials, size_t n_partials,
+                                    size_t stride_bytes, size_t msg_stride_bytes, const size_t *aad_lens, const uint64_t *total_lens,
+                                    uint8_t *tags, void *stream) {
+    if (!c || !ivs || !total_lens || !tags || (n_partials && !d_partials) || n_partials > AESGCM_GMAX) return AESGCM_EARG;
+    if (!n_msgs) return AESGCM_OK;
+    if (n_msgs > COMBINE_BATCH_MAX) return AESGCM_EARG;
+    if (stride_bytes < 16 || (stride_bytes & 15) || stride_bytes / 16 > 0xFFFFFFFFull || (msg_stride_bytes & 15)) return AESGCM_EARG;
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->h_mtag) {
+        HIPCHK(hipHostMalloc((void **)&c->h_mtag, 32 * COMBINE_BATCH_MAX, hipHostMallocMapped | hipHostMallocCoherent));
+        memset(c->h_mtag, 0, 32 * COMBINE_BATCH_MAX);
+        HIPCHK(hipHostGetDevicePointer((void **)&c->h_mtag_dev, c->h_mtag, 0));
+        HIPCHK(hipMalloc(&c->d_mtag, 16 * COMBINE_BATCH_MAX));
+    }
+    hipStream_t st = pick_stream(c, stream);
+    CombineBatch b;
+    memset(&b, 0, sizeof b);
+    const u64 gen = ++c->tag_gen;
+    for (size_t m = 0; m < n_msgs; m++) {
+        CombineParams q = plan_combine_tag((const uint4 *)((const unsigned char *)d_partials + m * msg_stride_bytes), (u32)n_partials, PARTS_GATHERED,
+                                           ivs + 12 * m, aad_lens ? aad_lens[m] : 0, total_lens[m], c->d_mtag + m);
+        q.stride = (u32)(stride_bytes / 16);
+        q.out_host = c->h_mtag_dev + 2 * m; q.gen = gen;
+        b.p[m] = q;
+    }
+    hipLaunchKernelGGL(k_combine_batch, dim3((unsigned)n_msgs), dim3(COMBINE_THREADS), CMB_LDS_BYTES, st, c->km, c->tables, b);
+    HIPCHK(hipGetLastError());
+    // every workgroup publishes its own generation word behind its tag: poll them all (short), then fall back to the stream
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    bool seen = false;
+    for (u32 spin = 0; !seen; ++spin) {
+        seen = true;
+        for (size_t m = 0; m < n_msgs; m++)
+            if (__atomic_load_n(reinterpret_cast<volatile u64 *>(c->h_mtag + 2 * m + 1), __ATOMIC_ACQUIRE) != gen) { seen = false; break; }
+        if (seen) break;
+        if ((spin & 63u) == 63u) {
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > 200000L) break;
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    if (!seen) HIPCHK(hipStreamSynchronize(st));
+    for (size_t m = 0; m < n_msgs; m++) memcpy(tags + 16 * m, c->h_mtag + 2 * m, 16);
     return AESGCM_OK;
 }
 int aesgcm_shard_finalize_dev(aesgcm_ctx *c, const uint8_t iv[12], const void *d_partials, size_t n_partials,

@@ -22,7 +22,7 @@ SYMBOLS = [
     "aesgcm_encrypt_pipelined", "aesgcm_decrypt_pipelined", "aesgcm_host_alloc", "aesgcm_host_free",
     "aesgcm_encrypt", "aesgcm_decrypt", "aesgcm_encrypt_dev", "aesgcm_decrypt_dev", "aesgcm_last_tag",
     "aesgcm_keystream", "aesgcm_keystream_dev",
-    "aesgcm_shard_crypt_dev", "aesgcm_shard_finalize_dev", "aesgcm_shard_finalize_strided_dev", "aesgcm_batch_crypt_dev", "aesgcm_batch_crypt_var_dev", "aesgcm_packets_crypt_dev",
+    "aesgcm_shard_crypt_dev", "aesgcm_shard_finalize_dev", "aesgcm_shard_finalize_strided_dev", "aesgcm_shard_finalize_batch_dev", "aesgcm_batch_crypt_dev", "aesgcm_batch_crypt_var_dev", "aesgcm_packets_crypt_dev",
     "aesgcm_stream_begin", "aesgcm_stream_aad", "aesgcm_stream_update", "aesgcm_stream_final",
     "aesgcm_dev_alloc", "aesgcm_dev_free", "aesgcm_dev_upload", "aesgcm_dev_download", "aesgcm_dev_sync", "aesgcm_dev_copy",
     "aesgcm_fill_splitmix64_dev",
@@ -91,6 +91,7 @@ def load():
     L.aesgcm_shard_crypt_dev.argtypes = [vp, cint, vp, vp, sz, vp, sz, vp, u64, u64, vp, vp]
     L.aesgcm_shard_finalize_dev.argtypes = [vp, vp, vp, sz, sz, u64, vp, vp]
     L.aesgcm_shard_finalize_strided_dev.argtypes = [vp, vp, vp, sz, sz, sz, u64, vp, vp]
+    L.aesgcm_shard_finalize_batch_dev.argtypes = [vp, sz, vp, vp, sz, sz, sz, ctypes.POINTER(sz), ctypes.POINTER(u64), vp, vp]
     L.aesgcm_batch_crypt_dev.argtypes = [cint, cint, sz, sz, vp, vp, vp, sz, vp, sz, vp, vp, vp, vp, vp]
     L.aesgcm_batch_crypt_var_dev.argtypes = [cint, cint, sz, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.aesgcm_packets_crypt_dev.argtypes = [vp, cint, sz, vp, vp, sz, vp, vp, sz, vp, vp, vp, vp, vp, vp]
@@ -491,6 +492,17 @@ class Context:
         tag = ctypes.create_string_buffer(16) if want_tag else None
         _chk(load().aesgcm_shard_finalize_strided_dev(self._c, _fixed(iv, 12, "iv"), d_partials, n_partials, stride_bytes, aad_len, total_len, tag, stream))
         return tag.raw if want_tag else None
+
+    def shard_finalize_batch_dev(self, ivs, d_partials, n_partials, total_lens, aad_lens=None, stride_bytes=None, msg_stride_bytes=16, stream=None):
+        """the tags of len(ivs) messages in one launch and one wait (aesgcm_shard_finalize_batch_dev); default layout [rank][message][16]"""
+        n = len(ivs)
+        ivb = b"".join(_fixed(iv, 12, "iv") for iv in ivs)
+        tl = (u64 * n)(*total_lens)
+        al = (sz * n)(*aad_lens) if aad_lens is not None else None
+        tags = ctypes.create_string_buffer(16 * n)
+        _chk(load().aesgcm_shard_finalize_batch_dev(self._c, n, ivb, d_partials, n_partials, 16 * n if stride_bytes is None else stride_bytes,
+                                                    msg_stride_bytes, al, tl, tags, stream))
+        return [tags.raw[16 * m:16 * m + 16] for m in range(n)]
 
     # streaming
     def stream_begin(self, iv, decrypt=False):

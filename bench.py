@@ -388,6 +388,7 @@ def main(argv=None):
                     help="rank 0 also encrypts every whole message alone and compares tags (needs the extra memory)")
     ap.add_argument("--contexts", type=int, default=0,
                     help="N > 1 / --emulate-rank: contexts (stream + scratch set each) a rank's messages rotate over; 0 = the default, 2 (measured best of 1 / 2 / 4, profiles/r03/emulate_rank.txt)")
+    ap.add_argument("--no-batch-finalize", action="store_true", help="debug: one aesgcm_shard_finalize_strided_dev call per message instead of the batched one")
     ap.add_argument("--no-chain", action="store_true", help="debug: do not chain message i's fused kernel behind message i-1's (the contexts start together)")
     ap.add_argument("--emulate-rank", type=int, default=None, help="on ONE GPU, run exactly this rank's step of the --of W job")
     ap.add_argument("--of", type=int, default=8, help="world size emulated by --emulate-rank")
@@ -522,6 +523,8 @@ def main(argv=None):
         for c in cs[1:]:
             cs[0].wait(c)                                            # the all-gather needs every context's partials: stream-ordered, no host sync
         ex.allgather_dev(local_parts.ptr, gathered.ptr, 16 * M, stream=cs[0].stream())
+        if M <= 8 and not args.no_batch_finalize:                     # all M tags in one launch and one wait
+            return cs[0].shard_finalize_batch_dev([m["iv"] for m in msgs], gathered.ptr, W, [m["total"] for m in msgs])
         return [cs[0].shard_finalize_dev(m["iv"], gathered.ptr + 16 * i, W, 0, m["total"], stride_bytes=16 * M)
                 for i, m in enumerate(msgs)]
 

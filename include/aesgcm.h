@@ -172,6 +172,14 @@ AESGCM_API int aesgcm_shard_finalize_dev(aesgcm_ctx *ctx, const uint8_t iv[12], 
 AESGCM_API int aesgcm_shard_finalize_strided_dev(aesgcm_ctx *ctx, const uint8_t iv[12], const void *d_partials, size_t n_partials,
                               size_t stride_bytes, size_t aad_len, uint64_t total_len, uint8_t tag[16], void *stream);
 
+/* The tags of n_msgs (<= 8) messages after ONE all-gather, in one launch and one wait: message m has IV ivs + 12 m, lengths
+ * aad_lens[m] (NULL = all zero) / total_lens[m], its n_partials partials start at d_partials + m * msg_stride_bytes and lie
+ * stride_bytes apart; tags receives n_msgs * 16 bytes.  With the [rank][message][16] layout: msg_stride_bytes = 16,
+ * stride_bytes = 16 * n_msgs.  Same arithmetic as aesgcm_shard_finalize_strided_dev called n_msgs times. */
+AESGCM_API int aesgcm_shard_finalize_batch_dev(aesgcm_ctx *ctx, size_t n_msgs, const uint8_t *ivs, const void *d_partials, size_t n_partials,
+                              size_t stride_bytes, size_t msg_stride_bytes, const size_t *aad_lens, const uint64_t *total_lens,
+                              uint8_t *tags, void *stream);
+
 /* ---------------------------------------------------------------- the exchange step, in the library
  * (BASELINE north_star "a single RCCL reduce of per-shard partial tags over xGMI".)  RCCL has
  * no XOR reduction (rccl.h ncclRedOp_t), so the 16-byte partials are all-gathered and folded on the device by

@@ -246,6 +246,54 @@ def test_sharded_message_equals_single_launch(hip, orc):
         assert bytes(dout.download(n)) == want_ct
 
 
+def test_batched_finalize_equals_one_call_per_message(hip, orc):
+    """aesgcm_shard_finalize_batch_dev: the tags of M messages from ONE [rank][message][16] gather in one launch -- three messages
+    of different length / AAD, four shards each, the shards spread over two contexts whose fused kernels are chained
+    (aesgcm_ctx_wait_fused) and joined (aesgcm_ctx_wait) as in bench.py's N > 1 step; pure-body shards included (AESGCM_BODY_MIN
+    is read at context creation: 4096 forces the k_body cut so that the direct weighted-partial path runs at this size)."""
+    import os
+    os.environ["AESGCM_BODY_MIN"] = "4096"
+    try:
+        key = splitmix_bytes(90, 32)
+        cs = [hip.Context(key), hip.Context(key)]
+    finally:
+        os.environ.pop("AESGCM_BODY_MIN", None)
+    ranks = 4
+    msgs = [dict(n=4 * 256 * 16 * 8, al=0, iv=splitmix_bytes(91, 12)),          # four shards of 8 whole 256-block super-rows: pure bodies
+            dict(n=(3 << 20) + 5, al=20, iv=splitmix_bytes(92, 12)),
+            dict(n=16 * 11, al=0, iv=splitmix_bytes(93, 12))]
+    M = len(msgs)
+    gathered = hip.DeviceBuffer(16 * M * ranks)                                     # [rank][message][16]
+    bufs, want = [], []
+    for i, m in enumerate(msgs):
+        aad = splitmix_bytes(94 + i, m["al"])
+        din, dout = hip.DeviceBuffer(m["n"] + 16), hip.DeviceBuffer(m["n"] + 16)
+        din.fill_splitmix64(97 + i, 0, nbytes=m["n"])
+        want.append(orc.Fast(key).encrypt(m["iv"], aad, bytes(din.download(m["n"]))))
+        d_aad = hip.DeviceBuffer(max(m["al"], 1)); d_aad.upload(aad)
+        bufs.append((din, dout, d_aad))
+        total_blocks = (m["n"] + 15) // 16
+        first = 0
+        c = cs[i % 2]
+        if i:
+            c.wait_fused(cs[(i - 1) % 2])
+        for r in range(ranks):
+            blocks = total_blocks // ranks + (1 if r < total_blocks % ranks else 0)
+            end = first + blocks
+            ln = (m["n"] if end == total_blocks else 16 * end) - 16 * first
+            c.shard_crypt_dev(False, m["iv"], din.ptr + 16 * first, ln, dout.ptr + 16 * first, first, m["n"], gathered.ptr + 16 * (r * M + i),
+                              d_aad=d_aad.ptr if r == 0 else None, aad_len=m["al"] if r == 0 else 0)
+            first = end
+    cs[0].wait(cs[1])
+    tags = cs[0].shard_finalize_batch_dev([m["iv"] for m in msgs], gathered.ptr, ranks, [m["n"] for m in msgs], aad_lens=[m["al"] for m in msgs])
+    one_by_one = [cs[0].shard_finalize_dev(m["iv"], gathered.ptr + 16 * i, ranks, m["al"], m["n"], stride_bytes=16 * M) for i, m in enumerate(msgs)]
+    assert tags == one_by_one == [w[1] for w in want]
+    for (din, dout, _), m, w in zip(bufs, msgs, want):
+        assert bytes(dout.download(m["n"])) == w[0]
+    with pytest.raises(hip.AesGcmError):
+        cs[0].shard_finalize_batch_dev([msgs[0]["iv"]] * 9, gathered.ptr, ranks, [16] * 9)       # more than 8 messages per call
+
+
 def test_distinct_contexts_from_distinct_threads(hip, orc):
     """The ABI's threading contract: a context is not thread-safe, distinct contexts may run concurrently."""
     import threading
