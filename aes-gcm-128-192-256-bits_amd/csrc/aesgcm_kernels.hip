@@ -291,7 +291,10 @@ __global__ __launch_bounds__(AESGCM_BODY_WG, AESGCM_BODY_WPS) void k_body(const 
 
 // k_fold: up to FOLD_GROUP x FOLD_WAVES = 128 items per workgroup (lane bodies: fold_wave_lane(), fold_wg_lane()).  No static LDS: table offsets
 // are absolute.
-__global__ __launch_bounds__(FOLD_WG) void k_fold(const KeyMaterial *__restrict__ km, const FoldParams p) {
+#ifndef FOLD_WPS
+#define FOLD_WPS 2                       /* waves per SIMD the register budget is sized for (2 = one 8-wave workgroup per CU by registers) */
+#endif
+__global__ __launch_bounds__(FOLD_WG, FOLD_WPS) void k_fold(const KeyMaterial *__restrict__ km, const FoldParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
     fold_fill_lds(smem, km, p.tabA, p.eA, 0u, tid, FOLD_WG);

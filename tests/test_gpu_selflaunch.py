@@ -47,3 +47,32 @@ def test_gpus_mismatch_with_world_size_is_refused(hip):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--no-cpu-baseline"], env=env, cwd=ROOT,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
     assert p.returncode != 0 and "{" not in p.stdout
+
+
+def test_cfg5_replicas_produce_the_same_tags_as_one_gpu(hip):
+    """bench.py --config cfg5: N ranks are replicas of 2^k / N packets with no collective on the data path; the SHA-256 over all
+    tags (rank 0 concatenates every rank's) must equal the one-GPU run's over the same packets, and the first 64 tags the fixture's"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "AESGCM_RDZV_DIR")}
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "cfg5", "--n-pkts", "65536", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    one = subprocess.run(base, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run(base + ["--gpus", "2", "--one-device", "--backend", "file", "--allow-file-exchange"], env=env, cwd=ROOT,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert two.returncode == 0, two.stderr[-2000:]
+    l1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    l2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
+    assert l1["n_gpus"] == 1 and l2["n_gpus"] == 2 and l2["config"]["packets_per_gpu"] == 32768
+    assert l1["tags_sha256"] == l2["tags_sha256"]
+    assert l1["roofline"]["kernel"].startswith("k_batch3") and l1["roofline"]["frac"] > 0
+    import hashlib
+    from util import golden, batch_inputs
+    # the same 65536 packets start with the fixture's first 64
+    fx = golden("batch.json")
+    keys, ivs, pt = batch_inputs(0, 64, 4096)
+    d_keys, d_ivs, d_in = hip.DeviceBuffer(len(keys)), hip.DeviceBuffer(len(ivs)), hip.DeviceBuffer(len(pt))
+    d_keys.upload(keys); d_ivs.upload(ivs); d_in.upload(pt)
+    d_out, d_tags = hip.DeviceBuffer(len(pt)), hip.DeviceBuffer(16 * 64)
+    hip.batch_crypt_dev(False, 64, 16, d_keys.ptr, d_ivs.ptr, d_in.ptr, 4096, d_out.ptr, d_tags.ptr)
+    hip.dev_sync()
+    tags = bytes(d_tags.download())
+    assert [tags[16 * p:16 * p + 16].hex() for p in range(64)] == fx["first64_tags"]
