@@ -780,8 +780,9 @@ struct FoldParams {
 #define COMBINE_MAX_ITEMS 64u
 #define FOLD_GROUP 16u           /* most items per wave */
 #ifndef FOLD_WAVES
-/* waves per workgroup: at most 128 items per workgroup.  The kernel needs 128 VGPRs (batches of 8 items in flight), i.e. 4 waves
-   per SIMD: with 8 waves per workgroup TWO workgroups share a CU and one's item loads hide behind the other's multiplies.
+/* waves per workgroup: at most 128 items per workgroup.  With 512 lanes the compiler takes 176 VGPRs (batches of 8 items in flight):
+   two waves per SIMD, i.e. ONE such workgroup per CU (profiles/r03/isa_census.txt; forcing 128 registers, -DFOLD_WPS=4, spills 188 bytes into
+   the item loop) -- round 2's "two workgroups share a CU" was wrong, its measurement stands: half as many items behind one CU's LDS array.
    Measured per k_fold launch over a 16 GiB message's 2^18 items (profiles/r02f/fold_waves.txt): 16 waves 115 us, 8 waves 73 us,
    4 waves 66 us; a rolled loop at 64 VGPRs with two 16-wave workgroups per CU: 172 us. */
 #define FOLD_WAVES 8u
