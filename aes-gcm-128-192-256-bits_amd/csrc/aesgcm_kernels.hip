@@ -749,13 +749,22 @@ __global__ __launch_bounds__(AESGCM_WG, 4) void k_batch2(const DevTables *__rest
 // wave-iteration where k_batch2 makes q + 6 plus the H^q square-and-multiply chain, no ciphertext read-back, no fence.
 // Decrypt is the same pass (the lane reads its ciphertext block before it writes the plaintext: in place is safe).
 // ------------------------------------------------------------------------------------------------
+// Lanes per k_batch3 workgroup (one per CU).  At 1024 lanes (128 registers, the round keys live in VGPRs) the AES-128 instance spills 104 bytes around its
+// packet loop and the launch moves 11.1e9 bytes against 8.64e9 algorithmic; at 768 lanes (3 waves per SIMD, 160 registers, ScratchSize 0) it moves 8.68e9
+// (1.005 x: reads 4.37e9, writes 4.31e9) at the same speed -- 616 vs 618 GiB/s, the kernel is VALU-bound (profiles/r03/batch3_wg768_ab.txt).  AES-256 still
+// spills 48 bytes at 768 lanes and is 2 % slower there (521 vs 532 GiB/s): it keeps 1024.  BATCH3_WG forces one geometry for all key sizes.
+#ifdef BATCH3_WG
+#define BATCH3_LANES(NR) BATCH3_WG
+#else
+#define BATCH3_LANES(NR) ((NR) == 14 ? AESGCM_WG : 768)
+#endif
 template <int NR, int DEC>
-__global__ __launch_bounds__(AESGCM_WG, 4) void k_batch3(const DevTables *__restrict__ tb, const BatchParams p) {
+__global__ __launch_bounds__(BATCH3_LANES(NR), (BATCH3_LANES(NR) + 255) / 256) void k_batch3(const DevTables *__restrict__ tb, const BatchParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int LG = 4;
     constexpr u32 G = 1u << LG, P = 64u >> LG;
     const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    main_fill_lds(smem, nullptr, tb, tid, false, AESGCM_WG);
+    main_fill_lds(smem, nullptr, tb, tid, false, BATCH3_LANES(NR));
     __syncthreads();
     const u32 lb = (lane & 31u) << 2;
     const u32 grp = lane >> LG, l = lane & (G - 1u);
@@ -872,12 +881,23 @@ __global__ __launch_bounds__(AESGCM_WG, 4) void k_batch3(const DevTables *__rest
 // k_pktg: many packets under the context's key, 2^LG lanes per packet (lane bodies: pktg_lane(), pktg_close_lane(),
 // pktg_tree_offer(); see "Packets under ONE key" in aesgcm_dev.h).  One 1024-lane workgroup per CU.
 // ------------------------------------------------------------------------------------------------
+// Lanes per k_pktg workgroup (one workgroup per CU).  At 1024 lanes (4 waves per SIMD, 128 registers) every instance spills 68 - 88 bytes around
+// its packet loop, and that scratch is what k_pktg's extra HBM traffic was: 2^20 x 1 KiB at 16 lanes per packet read 1.658e9 bytes against 1.086e9
+// algorithmic, all 128-byte requests; at 768 lanes (3 waves per SIMD, 148 - 165 registers, ScratchSize 0) 1.104e9, and writes fall from 1.20e9 to
+// 1.10e9 (profiles/r03/pktg_wg768_ab.txt).  In time the two are within 3 % of each other -- the kernel is bound by VALU issue and latency, not by
+// HBM: 768 lanes win at 16 and 64 lanes per packet (1 KiB 510 -> 523, 287 -> 290; 4 KiB 695 -> 693, 514 -> 559 GiB/s), 1024 lanes at 8 and 4
+// (4 KiB 730 -> 713, 740 -> 717).  Each group size gets the faster geometry; AESGCM_PKTG_WG forces one for all.
+#ifdef AESGCM_PKTG_WG
+#define PKTG_WG(LG) AESGCM_PKTG_WG
+#else
+#define PKTG_WG(LG) ((LG) >= 4 ? 768 : AESGCM_PKT_WG)
+#endif
 template <int NR, int DEC, int LG>
-__global__ __launch_bounds__(AESGCM_PKT_WG, AESGCM_PKT_WG / 256) void k_pktg(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const PktParams p) {
+__global__ __launch_bounds__(PKTG_WG(LG), (PKTG_WG(LG) + 255) / 256) void k_pktg(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const PktParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr u32 G = 1u << LG, P = 64u >> LG;
     const u32 tid = threadIdx.x, lane = tid & 63u;
-    pktg_fill_lds(smem, km, tb, tid, AESGCM_PKT_WG, LG);
+    pktg_fill_lds(smem, km, tb, tid, PKTG_WG(LG), LG);
     __syncthreads();
     const u32 grp = lane >> LG, l = lane & (G - 1u);
     // packets are dealt to the waves in blocks of p.deal (a multiple of P, at most 64) from a dispenser: one atomic per block
@@ -1953,6 +1973,7 @@ int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const vo
 #undef LP
     } else {
         const u32 P = 64u >> lg;                                                    // packets per wave-iteration
+        const u32 waves_per_wg = (u32)PKTG_WG(lg) / 64;
         // deal: about 4 dispenser fetches per resident wave, a multiple of P, at most 64 packets (one E_K(J0) pass per fetch)
         u32 deal = (u32)(n_pkts / ((size_t)n_cu * waves_per_wg * 4));
         deal = deal / P * P;
@@ -1963,7 +1984,7 @@ int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const vo
         u32 wgs = (nb + waves_per_wg - 1) / waves_per_wg;
         if (wgs > n_cu) wgs = n_cu;                                                  // one workgroup per CU (LDS)
         c->counter_base += nb + wgs * waves_per_wg;                                 // every wave ends on one failing fetch
-#define LPG(NR, D, LG) hipLaunchKernelGGL((k_pktg<NR, D, LG>), dim3(wgs), dim3(AESGCM_PKT_WG), PKTG_LDS_BYTES(LG), st, c->km, c->tables, p)
+#define LPG(NR, D, LG) hipLaunchKernelGGL((k_pktg<NR, D, LG>), dim3(wgs), dim3(PKTG_WG(LG)), PKTG_LDS_BYTES(LG), st, c->km, c->tables, p)
 #define LP(NR, D) do { if (lg == 2) LPG(NR, D, 2); else if (lg == 3) LPG(NR, D, 3); else if (lg == 4) LPG(NR, D, 4); else LPG(NR, D, 6); } while (0)
         if (decrypt) { if (c->nr == 10) LP(10, 1); else if (c->nr == 12) LP(12, 1); else LP(14, 1); }
         else         { if (c->nr == 10) LP(10, 0); else if (c->nr == 12) LP(12, 0); else LP(14, 0); }
@@ -1976,6 +1997,11 @@ int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const vo
 }
 
 // ---------------------------------------------------------------- batch (per-packet key and IV)
+// AESGCM_BATCH_FUSED=0 selects the two-phase k_batch2 (encrypt, fence, read the ciphertext back) instead of k_batch3, for A/B runs
+static bool fused_default() {
+    if (const char *e = getenv("AESGCM_BATCH_FUSED")) return atoi(e) != 0;
+    return true;
+}
 static int batch_launch(int device, int decrypt, size_t n_pkts, size_t key_len, BatchParams &p, void *stream) {
     if (key_len != 16 && key_len != 24 && key_len != 32) return AESGCM_EKEYLEN;
     if (n_pkts >= (((size_t)1) << 31)) return AESGCM_ETOOLONG;
@@ -2011,17 +2037,16 @@ static int batch_launch(int device, int decrypt, size_t n_pkts, size_t key_len, 
     int lg = (n_pkts >= (size_t)64 * ds->n_cu || (!p.data_off && p.pkt_len <= 2048)) ? 4 : 6;
     if (const char *e = getenv("AESGCM_BATCH_LG")) { const int v = atoi(e); if (v == 4 || v == 6) lg = v; }
     if (lg < 6) {
+        const u32 waves_per_wg = (u32)(fused_default() ? BATCH3_LANES(nr) : AESGCM_WG) / 64;
         const u32 P = 64u >> lg, per_wg = waves_per_wg * P;
         wgs = (u32)((n_pkts + per_wg - 1) / per_wg);
         if (wgs > (u32)ds->n_cu) wgs = (u32)ds->n_cu;
         u32 deal = (u32)(n_pkts / ((size_t)wgs * waves_per_wg * 16));
         deal = deal < P ? P : deal > 8 * P ? 8 * P : (deal + P - 1) / P * P;
         p.deal = deal;
-        // AESGCM_BATCH_FUSED=0 selects the two-phase k_batch2 (encrypt, fence, read the ciphertext back) for A/B runs
-        bool fused = true;
-        if (const char *e = getenv("AESGCM_BATCH_FUSED")) fused = atoi(e) != 0;
+        const bool fused = fused_default();
 #define LB2(NR, D, LG) hipLaunchKernelGGL((k_batch2<NR, D, LG>), dim3(wgs), dim3(AESGCM_WG), BATCH2_LDS_BYTES(LG), st, ds->tables, p)
-#define LB3(NR, D) hipLaunchKernelGGL((k_batch3<NR, D>), dim3(wgs), dim3(AESGCM_WG), BATCH2_LDS_BYTES(4), st, ds->tables, p)
+#define LB3(NR, D) hipLaunchKernelGGL((k_batch3<NR, D>), dim3(wgs), dim3(BATCH3_LANES(NR)), BATCH2_LDS_BYTES(4), st, ds->tables, p)
 #define LB2N(D, LG) do { if (fused) { if (nr == 10) LB3(10, D); else if (nr == 12) LB3(12, D); else LB3(14, D); } \
                          else { if (nr == 10) LB2(10, D, LG); else if (nr == 12) LB2(12, D, LG); else LB2(14, D, LG); } } while (0)
         if (decrypt) LB2N(1, 4); else LB2N(0, 4);
