@@ -1317,6 +1317,8 @@ HD G128 shoup_mul(G128 y, const unsigned char *lds, u32 tab) {
 #define BATCH2_GROUP_LDS 1024u                  /* per packet group: Th(H) | Tl(H) | Th(C) | Tl(C), 256 B each */
 #define BATCH2_LDS_TAB_OFF (AESGCM_LDS_AES_OFF + AESGCM_LDS_AES)
 #define BATCH2_LDS_BYTES(LG) (BATCH2_LDS_TAB_OFF + (AESGCM_WG / 64u) * (64u >> (LG)) * BATCH2_GROUP_LDS)
+#define BATCH3_GROUP_LDS 1056u                  /* k_batch3: the same two table pairs, then the packet's H and E_K(J0) (16 bytes each) */
+#define BATCH3_LDS_BYTES (BATCH2_LDS_TAB_OFF + (AESGCM_WG / 64u) * 4u * BATCH3_GROUP_LDS)
 // Y * c through the two tables at LDS byte offsets tab (Th) and tab + 256 (Tl), entries = 4 BE words
 HD G128 shoup2_mul(G128 y, const unsigned char *lds, u32 tab) {
     u32 z0 = 0, z1 = 0, z2 = 0, z3 = 0;

@@ -147,6 +147,30 @@ __device__ __forceinline__ G128 wave_xor_fold(G128 z) {
     }
     return z;
 }
+// value of lane (lane ^ MASK).  For MASK < 32 this is ds_swizzle in bit mode (and 0x1F, or 0, xor MASK: no address register);
+// __shfl_xor lowers to ds_bpermute with a per-lane index, and the compiler hoists those index registers out of the packet
+// loops -- in k_pktg at 128 registers they were 7 of the ~20 dwords it then spilled to scratch (round-3 ISA).
+template <int MASK>
+__device__ __forceinline__ u32 lane_xor(u32 x) {
+    if constexpr (MASK < 32) return (u32)__builtin_amdgcn_ds_swizzle((int)x, (MASK << 10) | 0x1F);
+    else return (u32)__shfl_xor((int)x, MASK);
+}
+// the lane's index in its wave from nothing but the execution mask (no input register, opaque to common-subexpression elimination)
+__device__ __forceinline__ u32 lane_id_fresh() {
+    u32 x;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(x));
+    return x;
+}
+__device__ __forceinline__ u32 lane_xor_pow2(u32 x, int j) {           // lane ^ (1 << j); j is a constant after unrolling
+    switch (j) {
+    case 0: return lane_xor<1>(x);
+    case 1: return lane_xor<2>(x);
+    case 2: return lane_xor<4>(x);
+    case 3: return lane_xor<8>(x);
+    case 4: return lane_xor<16>(x);
+    default: return lane_xor<32>(x);
+    }
+}
 // result -> pinned host slot, then (behind a system-scope fence) the generation number the host is polling for
 __device__ __forceinline__ void publish_host(uint4 *slot, uint4 v, u64 gen) {
     *slot = v;
@@ -241,7 +265,7 @@ __global__ __launch_bounds__(AESGCM_MAIN_WG, AESGCM_WAVES_PER_SIMD) void k_main(
 #endif
 // the layout assumptions the kernels rely on, checked where they are used
 static_assert(2u * AESGCM_LDS_BYTES <= 160u * 1024u, "k_main / k_pktl: two workgroups must share a CU's 160 KiB of LDS");
-static_assert(PKTG_LDS_BYTES(6) <= 160u * 1024u && AESGCM_NQ5POW >= 7, "k_pktg<.., 6>: Horner table, T0 | T2 and six tree tables in one CU's LDS");
+static_assert(PKTG_LDS_BYTES(6) <= 160u * 1024u && PKTG_LDS_BYTES(4) + 16u * 1024u <= 160u * 1024u && AESGCM_NQ5POW >= 7, "k_pktg: Horner table, T0 | T2, the tree tables (and the E_K(J0) slots of up to 16 waves at 16 lanes per packet) in one CU's LDS");
 static_assert(AESGCM_BODY_LDS <= 160u * 1024u, "k_body: one workgroup per CU");
 static_assert(AESGCM_LDS_AES_OFF % 128u == 0, "T-table replicas: lane l must read bank l & 31");
 static_assert(AESGCM_LDS_DRY_OFF >= AESGCM_Q5_GROUPS * 256u && AESGCM_LDS_DRY_OFF + 4u <= AESGCM_Q5_HI_ROW * 256u, "the dry-queue mask sits in the spare row between the table halves");
@@ -436,8 +460,11 @@ __device__ __forceinline__ G128 batch_seq_block(bool aligned, u32 aad_len, u32 p
     return mo_to_be(m);
 }
 
+#ifndef BATCH1_WPS
+#define BATCH1_WPS (AESGCM_WG / 256)      /* waves per SIMD the register budget is sized for: 4 = 128 registers (8 = 64 registers spilled 92 - 116 bytes into the packet loop) */
+#endif
 template <int NR, int DEC>
-__global__ __launch_bounds__(AESGCM_WG, 2 * AESGCM_WG / 256) void k_batch(const DevTables *__restrict__ tb, const BatchParams p) {
+__global__ __launch_bounds__(AESGCM_WG, BATCH1_WPS) void k_batch(const DevTables *__restrict__ tb, const BatchParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     main_fill_lds(smem, nullptr, tb, tid, false, AESGCM_WG);
@@ -534,13 +561,13 @@ __global__ __launch_bounds__(AESGCM_WG, 2 * AESGCM_WG / 256) void k_batch(const 
             }
         }
         if (q) {
-#pragma unroll 1
+#pragma unroll
             for (int j = 0; j < 6; j++) {
                 shoup_build(smem, tabC, cpow, lane);
                 const G128 t = shoup_mul(acc, smem, tabC);
                 G128 o;
-                o.w[0] = __shfl_xor(t.w[0], 1 << j); o.w[1] = __shfl_xor(t.w[1], 1 << j);
-                o.w[2] = __shfl_xor(t.w[2], 1 << j); o.w[3] = __shfl_xor(t.w[3], 1 << j);
+                o.w[0] = lane_xor_pow2(t.w[0], j); o.w[1] = lane_xor_pow2(t.w[1], j);
+                o.w[2] = lane_xor_pow2(t.w[2], j); o.w[3] = lane_xor_pow2(t.w[3], j);
                 if (lane & (1u << j)) { acc.w[0] ^= o.w[0]; acc.w[1] ^= o.w[1]; acc.w[2] ^= o.w[2]; acc.w[3] ^= o.w[3]; }
                 if (j < 5) cpow = gf_sqr(cpow);
             }
@@ -749,26 +776,26 @@ __global__ __launch_bounds__(AESGCM_WG, 4) void k_batch2(const DevTables *__rest
 // wave-iteration where k_batch2 makes q + 6 plus the H^q square-and-multiply chain, no ciphertext read-back, no fence.
 // Decrypt is the same pass (the lane reads its ciphertext block before it writes the plaintext: in place is safe).
 // ------------------------------------------------------------------------------------------------
-// Lanes per k_batch3 workgroup (one per CU).  At 1024 lanes (128 registers, the round keys live in VGPRs) the AES-128 instance spills 104 bytes around its
-// packet loop and the launch moves 11.1e9 bytes against 8.64e9 algorithmic; at 768 lanes (3 waves per SIMD, 160 registers, ScratchSize 0) it moves 8.68e9
-// (1.005 x: reads 4.37e9, writes 4.31e9) at the same speed -- 616 vs 618 GiB/s, the kernel is VALU-bound (profiles/r03/batch3_wg768_ab.txt).  AES-256 still
-// spills 48 bytes at 768 lanes and is 2 % slower there (521 vs 532 GiB/s): it keeps 1024.  BATCH3_WG forces one geometry for all key sizes.
+// Lanes per k_batch3 workgroup (one per CU).  The first round-3 build (1024 lanes, 128 registers, round keys in VGPRs) spilled 104 - 124 bytes around its
+// packet loop and moved 11.1e9 bytes against 8.64e9 algorithmic; with 768-lane workgroups (160 registers, no scratch) 8.68e9 at the same speed -- the
+// extra traffic was scratch (profiles/r03/batch3_wg768_ab.txt).  What was being spilled was bookkeeping, as in k_pktg: the packet's H and E_K(J0) held
+// across the block loop (now in the group's LDS slot), the lane's position (lane_id_fresh behind the loop), ds_bpermute index registers (ds_swizzle).
+// Without them every instance fits 98 - 115 registers at 1024 lanes with ScratchSize 0.  BATCH3_WG forces another geometry.
 #ifdef BATCH3_WG
 #define BATCH3_LANES(NR) BATCH3_WG
 #else
-#define BATCH3_LANES(NR) ((NR) == 14 ? AESGCM_WG : 768)
+#define BATCH3_LANES(NR) AESGCM_WG
 #endif
 template <int NR, int DEC>
 __global__ __launch_bounds__(BATCH3_LANES(NR), (BATCH3_LANES(NR) + 255) / 256) void k_batch3(const DevTables *__restrict__ tb, const BatchParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int LG = 4;
     constexpr u32 G = 1u << LG, P = 64u >> LG;
-    const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const u32 tid = threadIdx.x, lane = tid & 63u;
     main_fill_lds(smem, nullptr, tb, tid, false, BATCH3_LANES(NR));
     __syncthreads();
     const u32 lb = (lane & 31u) << 2;
-    const u32 grp = lane >> LG, l = lane & (G - 1u);
-    const u32 tabA = BATCH2_LDS_TAB_OFF + (wave * P + grp) * BATCH2_GROUP_LDS, tabB = tabA + 512u;
+    const u32 wave_tab = BATCH2_LDS_TAB_OFF + (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6)) * P * BATCH3_GROUP_LDS;     // scalar
     constexpr u32 KEYLEN = 4 * (NR - 6);
     const u32 K = p.deal, nb = (p.n_pkts + K - 1) / K;
     u32 pk0 = 0, pk_end = 0;
@@ -781,6 +808,9 @@ __global__ __launch_bounds__(BATCH3_LANES(NR), (BATCH3_LANES(NR) + 255) / 256) v
             pk0 = b * K;
             pk_end = pk0 + K < p.n_pkts ? pk0 + K : p.n_pkts;
         }
+        // the lane's position from a fresh lane id here and again behind the block loop (lane_id_fresh), so that none of it stays in a register across the loop
+        const u32 lane1 = lane_id_fresh(), grp = lane1 >> LG, l = lane1 & (G - 1u);
+        const u32 tabA = wave_tab + grp * BATCH3_GROUP_LDS;
         const bool act = pk0 + grp < pk_end;                 // groups past the end shadow the first packet; their stores are masked
         const u32 pkt = act ? pk0 + grp : pk0;
         const unsigned char *key = p.keys + (size_t)pkt * KEYLEN;
@@ -802,16 +832,23 @@ __global__ __launch_bounds__(BATCH3_LANES(NR), (BATCH3_LANES(NR) + 255) / 256) v
         batch_key_expand<NR>(key, rk, smem, lb);
         const u32 iv0 = load_le32(ivp), iv1 = load_le32(ivp + 4), iv2 = load_le32(ivp + 8);
         // ---- H = E_K(0^128) on lane 0 and E_K(IV || 1) on lane 1 of the group (gcm_gctr.vhd:141-145), one pass for both
-        G128 h, ej0;
+        // Both go to the group's LDS slot (32 bytes behind its tables) and are read back where they are needed: H now and at the closing, E_K(J0) at the very
+        // end -- held in registers across the block loop they were part of what the 128-register build spilled.
         {
             u32 s0 = (l == 0 ? 0u : iv0) ^ rk[0], s1 = (l == 0 ? 0u : iv1) ^ rk[1], s2 = (l == 0 ? 0u : iv2) ^ rk[2];
             u32 s3 = (l == 0 ? 0u : 0x01000000u) ^ rk[3];
             aes_rounds_lds<NR>(s0, s1, s2, s3, rk, smem, lb);
             const G128 e = mo_to_be(make_uint4(s0, s1, s2, s3));
-            h = group_bcast<LG>(e, lane, 0);
-            ej0 = group_bcast<LG>(e, lane, 1);
+            if (l < 2) *reinterpret_cast<uint4 *>(smem + tabA + 1024u + 16u * l) = make_uint4(e.w[0], e.w[1], e.w[2], e.w[3]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        shoup2_build<LG>(smem, tabA, gf_sqr(gf_sqr(gf_sqr(gf_sqr(h)))), l);            // Horner stride H^16 (squaring is linear: gf_sqr, no table)
+        {
+            const uint4 hv = *reinterpret_cast<const uint4 *>(smem + tabA + 1024u);
+            G128 h; h.w[0] = hv.x; h.w[1] = hv.y; h.w[2] = hv.z; h.w[3] = hv.w;
+            shoup2_build<LG>(smem, tabA, gf_sqr(gf_sqr(gf_sqr(gf_sqr(h)))), l);        // Horner stride H^16 (squaring is linear: gf_sqr, no table)
+        }
 
         // ---- one pass: CTR on the lane's blocks and Horner over its slots
         G128 acc; acc.w[0] = acc.w[1] = acc.w[2] = acc.w[3] = 0;
@@ -846,32 +883,38 @@ __global__ __launch_bounds__(BATCH3_LANES(NR), (BATCH3_LANES(NR) + 255) / 256) v
         }
 
         // ---- closing: P = sum_l B_l H^(15-l);  tag = P H^2 ^ L H ^ E_K(J0)  (gcm_ghash.vhd:257,293), as in k_pktg
+        const u32 lane2 = lane_id_fresh(), grp2 = lane2 >> LG, l2 = lane2 & (G - 1u);
+        const u32 tabA2 = wave_tab + grp2 * BATCH3_GROUP_LDS, tabB2 = tabA2 + 512u;
+        const bool act2 = pk0 + grp2 < pk_end;
+        const u32 pkt2 = act2 ? pk0 + grp2 : pk0;
+        G128 h;
+        { const uint4 hv = *reinterpret_cast<const uint4 *>(smem + tabA2 + 1024u); h.w[0] = hv.x; h.w[1] = hv.y; h.w[2] = hv.z; h.w[3] = hv.w; }
         G128 c = gf_sqr(h);                                     // H^2
-        shoup2_build<LG>(smem, tabB, c, l);
-        acc = shoup2_mul(acc, smem, tabB);
-        if (l == G - 2u) { acc.w[1] ^= aad_len * 8u; acc.w[3] ^= pkt_len * 8u; }     // the length block: both < 2^32 bits by the ABI's limits
-        shoup2_build<LG>(smem, tabA, h, l);                     // the Horner table is no longer needed
+        shoup2_build<LG>(smem, tabB2, c, l2);
+        acc = shoup2_mul(acc, smem, tabB2);
+        if (l2 == G - 2u) { acc.w[1] ^= aad_len * 8u; acc.w[3] ^= pkt_len * 8u; }     // the length block: both < 2^32 bits by the ABI's limits
+        shoup2_build<LG>(smem, tabA2, h, l2);                   // the Horner table is no longer needed
 #pragma unroll
         for (int j = 0; j < LG; j++) {
             // level j: constant H^(2^j); H in tabA, H^2 in tabB, then H^4 -> tabA, H^8 -> tabB
-            if (j >= 2) { c = gf_sqr(c); shoup2_build<LG>(smem, (j & 1) ? tabB : tabA, c, l); }
-            const G128 t = shoup2_mul(acc, smem, (j & 1) ? tabB : tabA);
+            if (j >= 2) { c = gf_sqr(c); shoup2_build<LG>(smem, (j & 1) ? tabB2 : tabA2, c, l2); }
+            const G128 t = shoup2_mul(acc, smem, (j & 1) ? tabB2 : tabA2);
             G128 o;
-            o.w[0] = __shfl_xor(t.w[0], 1 << j); o.w[1] = __shfl_xor(t.w[1], 1 << j);
-            o.w[2] = __shfl_xor(t.w[2], 1 << j); o.w[3] = __shfl_xor(t.w[3], 1 << j);
-            if (l & (1u << j)) { acc.w[0] ^= o.w[0]; acc.w[1] ^= o.w[1]; acc.w[2] ^= o.w[2]; acc.w[3] ^= o.w[3]; }
+            o.w[0] = lane_xor_pow2(t.w[0], j); o.w[1] = lane_xor_pow2(t.w[1], j);
+            o.w[2] = lane_xor_pow2(t.w[2], j); o.w[3] = lane_xor_pow2(t.w[3], j);
+            if (l2 & (1u << j)) { acc.w[0] ^= o.w[0]; acc.w[1] ^= o.w[1]; acc.w[2] ^= o.w[2]; acc.w[3] ^= o.w[3]; }
         }
-        acc.w[0] ^= ej0.w[0]; acc.w[1] ^= ej0.w[1]; acc.w[2] ^= ej0.w[2]; acc.w[3] ^= ej0.w[3];
-        if (l == G - 1u && act) {
+        { const uint4 ev = *reinterpret_cast<const uint4 *>(smem + tabA2 + 1040u); acc.w[0] ^= ev.x; acc.w[1] ^= ev.y; acc.w[2] ^= ev.z; acc.w[3] ^= ev.w; }
+        if (l2 == G - 1u && act2) {
             const uint4 tag = be_to_mo(acc);
-            store_block_bytes(p.tags + (size_t)pkt * 16, tag, 16);
+            store_block_bytes(p.tags + (size_t)pkt2 * 16, tag, 16);
             if (DEC && p.auth) {
                 int ok = 1;
                 if (p.expect) {
-                    const uint4 e = load_block_bytes(p.expect + (size_t)pkt * 16, 16);
+                    const uint4 e = load_block_bytes(p.expect + (size_t)pkt2 * 16, 16);
                     ok = ((e.x ^ tag.x) | (e.y ^ tag.y) | (e.z ^ tag.z) | (e.w ^ tag.w)) == 0;
                 }
-                p.auth[pkt] = ok;
+                p.auth[pkt2] = ok;
             }
         }
     }
@@ -881,16 +924,28 @@ __global__ __launch_bounds__(BATCH3_LANES(NR), (BATCH3_LANES(NR) + 255) / 256) v
 // k_pktg: many packets under the context's key, 2^LG lanes per packet (lane bodies: pktg_lane(), pktg_close_lane(),
 // pktg_tree_offer(); see "Packets under ONE key" in aesgcm_dev.h).  One 1024-lane workgroup per CU.
 // ------------------------------------------------------------------------------------------------
-// Lanes per k_pktg workgroup (one workgroup per CU).  At 1024 lanes (4 waves per SIMD, 128 registers) every instance spills 68 - 88 bytes around
-// its packet loop, and that scratch is what k_pktg's extra HBM traffic was: 2^20 x 1 KiB at 16 lanes per packet read 1.658e9 bytes against 1.086e9
-// algorithmic, all 128-byte requests; at 768 lanes (3 waves per SIMD, 148 - 165 registers, ScratchSize 0) 1.104e9, and writes fall from 1.20e9 to
-// 1.10e9 (profiles/r03/pktg_wg768_ab.txt).  In time the two are within 3 % of each other -- the kernel is bound by VALU issue and latency, not by
-// HBM: 768 lanes win at 16 and 64 lanes per packet (1 KiB 510 -> 523, 287 -> 290; 4 KiB 695 -> 693, 514 -> 559 GiB/s), 1024 lanes at 8 and 4
-// (4 KiB 730 -> 713, 740 -> 717).  Each group size gets the faster geometry; AESGCM_PKTG_WG forces one for all.
+#define PKTG_LDS_TOTAL(LG) (PKTG_LDS_BYTES(LG) + ((LG) <= 4 ? (u32)(PKTG_WG(LG) / 64) * 1024u : 0u))     /* + the waves' E_K(J0) slots */
+// the cross-lane tree of a packet's group, level J .. LG-1 (compile-time recursion: lane_xor needs its mask as a constant)
+template <int LG, int J>
+__device__ __forceinline__ void pktg_tree(uint4 &acc, const unsigned char *smem, u32 l) {
+    if constexpr (J < LG) {
+        const uint4 o = pktg_tree_offer(acc, smem, J);
+        const u32 ox = lane_xor<(1 << J)>(o.x), oy = lane_xor<(1 << J)>(o.y), oz = lane_xor<(1 << J)>(o.z), ow = lane_xor<(1 << J)>(o.w);
+        if (l & (1u << J)) { acc.x ^= ox; acc.y ^= oy; acc.z ^= oz; acc.w ^= ow; }
+        pktg_tree<LG, J + 1>(acc, smem, l);
+    }
+}
+// Lanes per k_pktg workgroup (one workgroup per CU).  The first round-3 build (1024 lanes, 128 registers) spilled 68 - 88 bytes around its packet
+// loop, and that scratch is what its extra HBM traffic was: 2^20 x 1 KiB at 16 lanes per packet read 1.658e9 bytes against 1.086e9 algorithmic, all
+// 128-byte requests; with 768-lane workgroups (148 - 165 registers, no scratch) 1.104e9 (profiles/r03/pktg_wg768_ab.txt).  What was being spilled was
+// bookkeeping, and it is gone at 1024 lanes too: the index registers of ds_bpermute exchanges (now ds_swizzle, lane_xor), the 64 E_K(J0) values held
+// across the packet loop (now in the wave's LDS slot) and the lane's position (recomputed from lane_id_fresh after the loop).  Lane groups therefore
+// run 1024-lane workgroups again (4 waves per SIMD: 16 lanes per packet 517 -> 530, 681 -> 700 GiB/s at 1 / 4 KiB against 768 lanes); one packet per
+// wave keeps its E_K(J0) values in registers and stays at 768 lanes, where it needs no scratch.  AESGCM_PKTG_WG forces one geometry for all.
 #ifdef AESGCM_PKTG_WG
 #define PKTG_WG(LG) AESGCM_PKTG_WG
 #else
-#define PKTG_WG(LG) ((LG) >= 4 ? 768 : AESGCM_PKT_WG)
+#define PKTG_WG(LG) ((LG) == 6 ? 768 : AESGCM_PKT_WG)
 #endif
 template <int NR, int DEC, int LG>
 __global__ __launch_bounds__(PKTG_WG(LG), (PKTG_WG(LG) + 255) / 256) void k_pktg(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const PktParams p) {
@@ -899,7 +954,7 @@ __global__ __launch_bounds__(PKTG_WG(LG), (PKTG_WG(LG) + 255) / 256) void k_pktg
     const u32 tid = threadIdx.x, lane = tid & 63u;
     pktg_fill_lds(smem, km, tb, tid, PKTG_WG(LG), LG);
     __syncthreads();
-    const u32 grp = lane >> LG, l = lane & (G - 1u);
+    const u32 wave_slot = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6)) * 1024u;       // scalar
     // packets are dealt to the waves in blocks of p.deal (a multiple of P, at most 64) from a dispenser: one atomic per block
     // keeps the single dispenser address far below its ~87 M fetches/s ceiling (measured), and late waves still level the
     // tail.  The loop is bounded on purpose (a wave can never own more than nb blocks).
@@ -910,42 +965,42 @@ __global__ __launch_bounds__(PKTG_WG(LG), (PKTG_WG(LG) + 255) / 256) void k_pktg
         b = __builtin_amdgcn_readfirstlane(b);
         if (b >= nb) break;
         const u32 p0 = b * K, cnt = (p0 + K < p.n_pkts ? p0 + K : p.n_pkts) - p0;
-        // E_K(IV || 1) of the block's packets, one lane each, in ONE AES pass
-        const uint4 ej = pktg_ej0_lane<NR>(km, p, smem, p0 + (lane < cnt ? lane : 0u), lane);
+        // E_K(IV || 1) of the block's packets, one lane each, in ONE AES pass.  Lane groups park the 64 values in the wave's own 1 KiB of LDS
+        // (behind the tree tables): held in registers across the packet loop they were spilled at 128 registers; one packet per wave keeps them.
+        constexpr bool EJ_LDS = LG <= 4;
+        unsigned char *ej_slot = smem + PKTG_LDS_BYTES(LG) + wave_slot;
+        uint4 ej = pktg_ej0_lane<NR>(km, p, smem, p0 + (lane < cnt ? lane : 0u), lane);
+        if (EJ_LDS) { *reinterpret_cast<uint4 *>(ej_slot + lane * 16u) = ej; ej = make_uint4(0, 0, 0, 0); }
         for (u32 t = 0; t * P < cnt; ++t) {
-            const u32 idx = t * P + grp;
+            const u32 lane1 = lane_id_fresh(), l = lane1 & (G - 1u), idx = t * P + (lane1 >> LG);
             const bool act = idx < cnt;                          // groups past the end shadow the block's first packet; their stores are masked
             const u32 pkt = p0 + (act ? idx : 0u);
             const PktInfo q = pkt_info(p, pkt);
             // the wave runs to the longest packet of its groups
             u32 iters = pktg_iters(q, G);
-            if (P > 1) {
-#pragma unroll
-                for (u32 g = 1; g < P; g <<= 1) { const u32 o = (u32)__shfl_xor((int)iters, (int)(g << LG)); iters = o > iters ? o : iters; }
-            }
-            iters = __builtin_amdgcn_readfirstlane(iters);
-            uint4 acc = pktg_lane<NR, DEC, LG>(km, p, q, smem, l, lane, iters, act);
-            acc = pktg_close_lane<LG>(acc, q, smem, l);
-#pragma unroll
-            for (int j = 0; j < LG; j++) {
-                const uint4 o = pktg_tree_offer(acc, smem, j);
-                const u32 ox = (u32)__shfl_xor((int)o.x, 1 << j), oy = (u32)__shfl_xor((int)o.y, 1 << j);
-                const u32 oz = (u32)__shfl_xor((int)o.z, 1 << j), ow = (u32)__shfl_xor((int)o.w, 1 << j);
-                if (l & (1u << j)) { acc.x ^= ox; acc.y ^= oy; acc.z ^= oz; acc.w ^= ow; }
-            }
+            iters = groups_max<LG>(iters);                      // wave-uniform: the first lane of every group, through scalar registers
+            uint4 acc = pktg_lane<NR, DEC, LG>(km, p, q, smem, l, lane1, iters, act);
+            // what follows needs the lane's position again.  Taken from a FRESH lane id (lane_id_fresh: the compiler cannot tie it to the one above), so that
+            // l / grp / idx / pkt need not stay in registers across the packet loop -- at 128 registers they were spilled there
+            const u32 lane2 = lane_id_fresh(), l2 = lane2 & (G - 1u), idx2 = t * P + (lane2 >> LG);
+            const bool act2 = idx2 < cnt;
+            const u32 pkt2 = p0 + (act2 ? idx2 : 0u);
+            acc = pktg_close_lane<LG>(acc, q, smem, l2);
+            pktg_tree<LG, 0>(acc, smem, l2);
             // lane G-1 of the group holds P H^2 ^ L H; its packet's E_K(IV || 1) sits in lane idx of `ej`
-            const int srcl = (int)(act ? idx : 0u);
-            const uint4 e = make_uint4((u32)__shfl((int)ej.x, srcl), (u32)__shfl((int)ej.y, srcl), (u32)__shfl((int)ej.z, srcl), (u32)__shfl((int)ej.w, srcl));
-            if (l == G - 1u && act) {
+            const int srcl = (int)(act2 ? idx2 : 0u);
+            const uint4 e = EJ_LDS ? *reinterpret_cast<const uint4 *>(ej_slot + (u32)srcl * 16u)
+                                   : make_uint4((u32)__shfl((int)ej.x, srcl), (u32)__shfl((int)ej.y, srcl), (u32)__shfl((int)ej.z, srcl), (u32)__shfl((int)ej.w, srcl));
+            if (l2 == G - 1u && act2) {
                 const uint4 tag = xor4(acc, e);                  // gcm_ghash.vhd:293
-                store_block_bytes(p.tags + (size_t)pkt * 16, tag, 16);
+                store_block_bytes(p.tags + (size_t)pkt2 * 16, tag, 16);
                 if (DEC && p.auth) {
                     int ok = 1;
                     if (p.expect) {
-                        const uint4 x = load_block_bytes(p.expect + (size_t)pkt * 16, 16);
+                        const uint4 x = load_block_bytes(p.expect + (size_t)pkt2 * 16, 16);
                         ok = ((x.x ^ tag.x) | (x.y ^ tag.y) | (x.z ^ tag.z) | (x.w ^ tag.w)) == 0;
                     }
-                    p.auth[pkt] = ok;
+                    p.auth[pkt2] = ok;
                 }
             }
         }
@@ -1104,10 +1159,10 @@ static int set_lds_attrs(int device, DeviceState *ds) {
     SETATTRY(10, MODE_PROBE); SETATTRY(12, MODE_PROBE); SETATTRY(14, MODE_PROBE);
 #undef SETATTRY
 #define SETATTRB(NR, D) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch<NR, D>), hipFuncAttributeMaxDynamicSharedMemorySize, BATCH_LDS_BYTES)); \
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktg<NR, D, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, PKTG_LDS_BYTES(2))); \
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktg<NR, D, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, PKTG_LDS_BYTES(3))); \
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktg<NR, D, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, PKTG_LDS_BYTES(4))); \
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktg<NR, D, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, PKTG_LDS_BYTES(6))); \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktg<NR, D, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, PKTG_LDS_TOTAL(2))); \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktg<NR, D, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, PKTG_LDS_TOTAL(3))); \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktg<NR, D, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, PKTG_LDS_TOTAL(4))); \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktg<NR, D, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, PKTG_LDS_TOTAL(6))); \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktl<NR, D>), hipFuncAttributeMaxDynamicSharedMemorySize, AESGCM_LDS_BYTES))
     SETATTRB(10, 0); SETATTRB(12, 0); SETATTRB(14, 0); SETATTRB(10, 1); SETATTRB(12, 1); SETATTRB(14, 1);
 #undef SETATTRB
@@ -1115,7 +1170,7 @@ static int set_lds_attrs(int device, DeviceState *ds) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_combine_batch), hipFuncAttributeMaxDynamicSharedMemorySize, CMB_LDS_BYTES));
 #define SETATTRB2(NR, D, LG) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch2<NR, D, LG>), hipFuncAttributeMaxDynamicSharedMemorySize, BATCH2_LDS_BYTES(LG)))
     SETATTRB2(10, 0, 4); SETATTRB2(12, 0, 4); SETATTRB2(14, 0, 4); SETATTRB2(10, 1, 4); SETATTRB2(12, 1, 4); SETATTRB2(14, 1, 4);
-#define SETATTRB3(NR, D) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch3<NR, D>), hipFuncAttributeMaxDynamicSharedMemorySize, BATCH2_LDS_BYTES(4)))
+#define SETATTRB3(NR, D) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch3<NR, D>), hipFuncAttributeMaxDynamicSharedMemorySize, BATCH3_LDS_BYTES))
     SETATTRB3(10, 0); SETATTRB3(12, 0); SETATTRB3(14, 0); SETATTRB3(10, 1); SETATTRB3(12, 1); SETATTRB3(14, 1);
 #undef SETATTRB3
 
@@ -1984,7 +2039,7 @@ int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const vo
         u32 wgs = (nb + waves_per_wg - 1) / waves_per_wg;
         if (wgs > n_cu) wgs = n_cu;                                                  // one workgroup per CU (LDS)
         c->counter_base += nb + wgs * waves_per_wg;                                 // every wave ends on one failing fetch
-#define LPG(NR, D, LG) hipLaunchKernelGGL((k_pktg<NR, D, LG>), dim3(wgs), dim3(PKTG_WG(LG)), PKTG_LDS_BYTES(LG), st, c->km, c->tables, p)
+#define LPG(NR, D, LG) hipLaunchKernelGGL((k_pktg<NR, D, LG>), dim3(wgs), dim3(PKTG_WG(LG)), PKTG_LDS_TOTAL(LG), st, c->km, c->tables, p)
 #define LP(NR, D) do { if (lg == 2) LPG(NR, D, 2); else if (lg == 3) LPG(NR, D, 3); else if (lg == 4) LPG(NR, D, 4); else LPG(NR, D, 6); } while (0)
         if (decrypt) { if (c->nr == 10) LP(10, 1); else if (c->nr == 12) LP(12, 1); else LP(14, 1); }
         else         { if (c->nr == 10) LP(10, 0); else if (c->nr == 12) LP(12, 0); else LP(14, 0); }
@@ -2046,7 +2101,7 @@ static int batch_launch(int device, int decrypt, size_t n_pkts, size_t key_len, 
         p.deal = deal;
         const bool fused = fused_default();
 #define LB2(NR, D, LG) hipLaunchKernelGGL((k_batch2<NR, D, LG>), dim3(wgs), dim3(AESGCM_WG), BATCH2_LDS_BYTES(LG), st, ds->tables, p)
-#define LB3(NR, D) hipLaunchKernelGGL((k_batch3<NR, D>), dim3(wgs), dim3(BATCH3_LANES(NR)), BATCH2_LDS_BYTES(4), st, ds->tables, p)
+#define LB3(NR, D) hipLaunchKernelGGL((k_batch3<NR, D>), dim3(wgs), dim3(BATCH3_LANES(NR)), BATCH3_LDS_BYTES, st, ds->tables, p)
 #define LB2N(D, LG) do { if (fused) { if (nr == 10) LB3(10, D); else if (nr == 12) LB3(12, D); else LB3(14, D); } \
                          else { if (nr == 10) LB2(10, D, LG); else if (nr == 12) LB2(12, D, LG); else LB2(14, D, LG); } } while (0)
         if (decrypt) LB2N(1, 4); else LB2N(0, 4);
