@@ -887,6 +887,18 @@ static inline int ptab_index(u64 e) {
 // wave-uniform indices go through the scalar cache, not LDS).  Rounds 1 and 2 therefore cost no LDS lookup in the
 // row loop: 192 instead of 212 per AES-256 block.
 // GHASH: the lane's blocks are 256 apart, Horner constant H^256 (main_fill_lds(GH_TAB_K256)).
+#ifndef AESGCM_BODY_RKV_FROM
+#define AESGCM_BODY_RKV_FROM(NR) ((NR) == 14 ? 28 : 4 * ((NR) + 1))     /* first round-key word k_body keeps in a vector register (none for AES-128 / 192) */
+#endif
+HD u32 pin_vgpr(u32 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u32 r;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(x));
+    return r;
+#else
+    return x;
+#endif
+}
 struct BodyParams {
     const unsigned char *in;     // first body block (16-byte aligned)
     unsigned char *out;
@@ -979,10 +991,17 @@ HD void body_state(u32 &s0, u32 &s1, u32 &s2, u32 &s3, const BodyLane &b, u32 hi
 template <int NR, int MODE>
 HD uint4 body_chunk_lane(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const BodyParams &p,
                          const unsigned char *smem, const CtrConsts &cc, u32 c, u32 lane) {
-    const u32 *__restrict__ rk = km->rk;
+    const u32 *__restrict__ rk0 = km->rk;
     const u32 lb = (lane & 31u) << 2, lane16 = lane * 16u;
     const u32 v = c & 3u, s = c >> 2;
-    const BodyLane b = body_lane_consts(rk, cc, smem, v, lane);
+    const BodyLane b = body_lane_consts(rk0, cc, smem, v, lane);
+    // AES-256 has 60 round-key words; all of them in scalar registers, with the row-uniform round-2 state, the pointers and the loop state, overflow the
+    // 102 SGPRs: the compiler parked 31 scalars in the lanes of a VGPR and fetched ten of them back with v_readlane in EVERY row (round-3 ISA census) --
+    // VALU issue slots in a loop that is bound by them.  The keys of the late rounds therefore live in VECTOR registers (a VALU operand either way; the
+    // kernel uses 85 of its 128): pin_vgpr hides the copy from the compiler so that it stays one.
+    u32 rk[4 * (NR + 1)];
+#pragma unroll
+    for (int w = 0; w < 4 * (NR + 1); w++) rk[w] = (w >= AESGCM_BODY_RKV_FROM(NR)) ? pin_vgpr(rk0[w]) : rk0[w];
     uint4 acc = make_uint4(0, 0, 0, 0);
     u32 i = 0;
 #if AESGCM_BODY_ILP == 2
