@@ -294,6 +294,32 @@ def test_batched_finalize_equals_one_call_per_message(hip, orc):
         cs[0].shard_finalize_batch_dev([msgs[0]["iv"]] * 9, gathered.ptr, ranks, [16] * 9)       # more than 8 messages per call
 
 
+def test_timer_and_context_ordering_entry_points(hip):
+    """aesgcm_timer_* brackets work on the stream it is recorded on; aesgcm_ctx_wait / _wait_fused accept two contexts of one device,
+    are no-ops on one context and reject NULL"""
+    key = splitmix_bytes(70, 16)
+    a, b = hip.Context(key), hip.Context(key)
+    n = 64 << 20
+    din, dout = hip.DeviceBuffer(n), hip.DeviceBuffer(n)
+    din.fill_splitmix64(71)
+    hip.dev_sync()
+    t = hip.Timer()
+    t.start(a.stream())
+    a.encrypt_dev(splitmix_bytes(72, 12), din.ptr, n, dout.ptr, want_tag=False)
+    t.stop(a.stream())
+    ms = t.ms()
+    assert 0.02 < ms < 50.0, ms                       # 64 MiB at ~0.2 - 1 TB/s
+    t.close()
+    a.wait(a); a.wait_fused(a)                        # same context: nothing to order
+    b.wait_fused(a); b.wait(a)                        # message on b ordered behind a's work: same tag as a alone
+    tag_b = b.encrypt_dev(splitmix_bytes(72, 12), din.ptr, n, dout.ptr)
+    tag_a = a.encrypt_dev(splitmix_bytes(72, 12), din.ptr, n, dout.ptr)
+    assert tag_a == tag_b
+    L = hip.load()
+    assert L.aesgcm_ctx_wait(None, a._c) == hip.EARG and L.aesgcm_ctx_wait_fused(a._c, None) == hip.EARG
+    assert L.aesgcm_timer_ms(None, None) == hip.EARG
+
+
 def test_distinct_contexts_from_distinct_threads(hip, orc):
     """The ABI's threading contract: a context is not thread-safe, distinct contexts may run concurrently."""
     import threading

@@ -128,3 +128,29 @@ def test_external_libcrypto_agrees_when_present(orc):
     for n in (0, 5, 16, 1000, 70000):
         key, iv, aad, pt = splitmix_bytes(9, 24), splitmix_bytes(10, 12), splitmix_bytes(11, 21), splitmix_bytes(12, n)
         assert R.encrypt(key, iv, aad, pt) == orc.Fast(key).encrypt(iv, aad, pt)
+
+
+def test_cfg5_cpu_baseline_loop_matches_the_batch_fixture():
+    """oracle/evp_batch.c (the per-packet EVP loop bench.py --config cfg5 times as its CPU baseline) over the first 64 cfg5 packets:
+    tags and ciphertext equal tests/golden/batch.json -- the baseline measures the same job the GPU does"""
+    import hashlib
+    import numpy as np
+    from oracle import cpu_baseline as cb
+    from oracle import libcrypto_ref as R
+    if not R.available():
+        pytest.skip("no libcrypto on this machine")
+    L = cb.evp_batch_lib()
+    keys, ivs, pt = cb.cfg5_inputs(0, 64)
+    ct, tags = np.empty(64 * 4096, dtype=np.uint8), np.empty(16 * 64, dtype=np.uint8)
+    assert L.evp_batch_encrypt(64, 16, keys.ctypes.data, ivs.ctypes.data, pt.ctypes.data, 4096, ct.ctypes.data, tags.ctypes.data) == 0
+    fx = golden("batch.json")
+    assert [bytes(tags[16 * p:16 * p + 16]).hex() for p in range(64)] == fx["first64_tags"]
+    assert hashlib.sha256(ct.tobytes()).hexdigest() == fx["first64_ct_sha256"]
+    # a later slice of the streams (worker 3 of the multi-process run) against the oracle's own cipher
+    keys, ivs, pt = cb.cfg5_inputs(3 * 32768, 4)
+    ct, tags = np.empty(4 * 4096, dtype=np.uint8), np.empty(16 * 4, dtype=np.uint8)
+    assert L.evp_batch_encrypt(4, 16, keys.ctypes.data, ivs.ctypes.data, pt.ctypes.data, 4096, ct.ctypes.data, tags.ctypes.data) == 0
+    from oracle import oracle as O
+    for p in range(4):
+        want_ct, want_tag = O.Fast(bytes(keys[16 * p:16 * p + 16])).encrypt(bytes(ivs[12 * p:12 * p + 12]), b"", bytes(pt[4096 * p:4096 * (p + 1)]))
+        assert bytes(ct[4096 * p:4096 * (p + 1)]) == want_ct and bytes(tags[16 * p:16 * p + 16]) == want_tag
