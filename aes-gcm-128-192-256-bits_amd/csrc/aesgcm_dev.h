@@ -1401,8 +1401,8 @@ HD void batch_key_expand(const unsigned char *key, u32 *rk, const unsigned char 
 //     64 / G packets of the wave; the tables (H^(2^j), j < LG, five-bit form, 13.25 KiB each) sit behind the AES tables in LDS.
 //   * E_K(IV || 1) of up to 64 packets comes from ONE extra AES pass per dispenser fetch: lane j encrypts packet j's J0 block
 //     (gcm_ghash.vhd:158-169); the group's last lane picks its packet's value up with a lane shuffle.
-// LDS: [0, 13568) five-bit table of H^G | [13568, +64 KiB) T0 | T2 | [79104 + j * 13568) tree table j.  One 1024-lane workgroup
-// per CU (LG = 4: 130.25 KiB, LG = 6: 156.75 KiB).
+// LDS: [0, 13568) five-bit table of H^G | [13568, +64 KiB) T0 | T2 | [79104 + j * 13568) tree table j | (lane groups) 1 KiB per wave for
+// the E_K(J0) values of a dispenser block.  One workgroup per CU (LG = 4: 130.25 + 16 KiB at 1024 lanes, LG = 6: 156.75 KiB at 768).
 // ================================================================================================
 struct PktParams {
     const unsigned char *ivs;    // n_pkts * 12 bytes
