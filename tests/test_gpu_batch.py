@@ -201,6 +201,37 @@ def test_packets_under_one_key(hip, orc, shape, monkeypatch):
         assert [i for i, a in enumerate(auth) if not a] == [5]
 
 
+@pytest.mark.parametrize("shape", [None, "wave", "group16", "g8", "g4", "lane"])
+def test_fixed_size_records_of_odd_lengths(hip, orc, shape, monkeypatch):
+    """aesgcm_packets_crypt_dev with fixed-size records that are empty, shorter than a block, ragged, or not a multiple of 4 bytes apart (the
+    byte-wise load / store paths), with and without AAD, in every kernel shape and in the host's own choice; decrypt in place"""
+    import struct
+    if shape:
+        monkeypatch.setenv("AESGCM_PKT_SHAPE", shape)
+    else:
+        monkeypatch.delenv("AESGCM_PKT_SHAPE", raising=False)
+    key = splitmix_bytes(610, 24)
+    ctx, f = hip.Context(key), orc.Fast(key)
+    def up(b):
+        d = hip.DeviceBuffer(max(len(b), 16)); d.upload(b); return d
+    for n, pkt, al in ((5, 0, 0), (70, 0, 12), (130, 1, 0), (67, 17, 20), (200, 1000, 0), (90, 1500, 28), (33, 4099, 1), (300, 64, 16)):
+        ivs, aad, pt = splitmix_bytes(611 + pkt, 12 * n), splitmix_bytes(612 + pkt, al * n), splitmix_bytes(613 + pkt, pkt * n)
+        d_ivs, d_aad, d_buf = up(ivs), up(aad), up(pt)
+        d_tags, d_auth = hip.DeviceBuffer(16 * n), hip.DeviceBuffer(4 * n)
+        ctx.packets_crypt_dev(False, n, d_ivs.ptr, d_buf.ptr, d_buf.ptr, d_tags.ptr, pkt_len=pkt, d_aad=d_aad.ptr if al else None, aad_len=al)
+        hip.dev_sync()
+        ct, tags = bytes(d_buf.download(pkt * n)) if pkt else b"", bytes(d_tags.download())
+        for p in range(n):
+            want = f.encrypt(ivs[12 * p:12 * p + 12], aad[al * p:al * (p + 1)], pt[pkt * p:pkt * (p + 1)])
+            assert (ct[pkt * p:pkt * (p + 1)], tags[16 * p:16 * p + 16]) == want, (shape, n, pkt, al, p)
+        d_exp = up(tags)
+        ctx.packets_crypt_dev(True, n, d_ivs.ptr, d_buf.ptr, d_buf.ptr, d_tags.ptr, pkt_len=pkt, d_aad=d_aad.ptr if al else None, aad_len=al,
+                              d_expect_tags=d_exp.ptr, d_auth=d_auth.ptr)
+        hip.dev_sync()
+        assert (bytes(d_buf.download(pkt * n)) if pkt else b"") == pt
+        assert set(struct.unpack("<%di" % n, bytes(d_auth.download()))) == {1}
+
+
 @pytest.mark.gpu
 def test_many_small_packets_default_shape(hip, orc, monkeypatch):
     """50 000 MACsec-sized frames (0..1514 B, AAD 0..32 B) under one key: the count makes the library choose the
