@@ -7,8 +7,9 @@
 //   k_body<NR,MODE> the aligned middle of very large ranges: rounds 1-2 without LDS lookups.
 //   k_fold          reduces the chunks' items (64 lane accumulators each) by Horner with wave-uniform constants.
 //   k_combine       per message: H^(63-L) on the last item, lane fold, optional H^e weighting / chaining value
-//                   (shards, streaming), length block, E_K(J0) -> tag.
-//   k_batch, k_pkt, k_pktl   packets: own key per packet / one key, one wave or one lane per packet.
+//                   (shards, streaming), length block, E_K(J0) -> tag.  k_combine_batch: up to 8 messages, one workgroup each.
+//   k_batch3, k_batch2, k_batch   packets with their OWN key: 16 lanes per packet in one pass / in two phases (A/B only) / one wave per packet.
+//   k_pktg<.., LG>, k_pktl        packets under the context's key: 2^LG lanes per packet (4, 8, 16, 64) / one lane per packet.
 //   k_gfmul, k_fill, k_copy16 small utility kernels.
 //
 // GHASH re-association (DESIGN.md "GHASH as a polynomial"): the GHASH input sequence
