@@ -443,6 +443,7 @@ struct KeyMaterial {         // per context (device memory)
                                      // stride of a wave (k_main); [0] = H itself (k_pktl: one lane per packet, serial Horner); k_pktg: Horner stride H^(lanes per packet)
                                      // and the constants of the cross-lane tree H, H^2, H^4, ...
     uint4 k4tab[AESGCM_Q5_ENTRIES];  // ... of H^256 (k_body: a wave takes every fourth row)
+    uint4 k18tab[AESGCM_Q5_ENTRIES]; // ... of H^(2^18) (k_body, cyclic rows: a wave takes every 4096th row)
     uint4 ptab[AESGCM_NPTAB][512]; // nibble tables of H^(2^k), k = 6 .. 31: the Horner constants of k_fold when chunk sizes are powers of two
     uint4 ltab[AESGCM_NLTAB][32];  // two-table Shoup form of H^e, e = 0 .. 65: [e][v] = v*H^e, [e][16 + v] = v*H^e*x^4 (per-lane constant multiplies of the closing steps)
     uint8_t rk_bytes[240];   // expanded key as the byte string tb/key_exp.py produces
@@ -575,13 +576,13 @@ HD bool setup_level(const uint4 *tab, int j, int tid, uint4 *prod) {
     *prod = gf_mul_mo(tab[tid], tab[base]);
     return true;
 }
-// after the beta table (d == 1) is complete: the five-bit tables of the fixed Horner / tree constants H^(2^j) (j = 0 .. 6) and H^256
+// after the beta table (d == 1) is complete: the five-bit tables of the fixed Horner / tree constants H^(2^j) (j = 0 .. 6), H^256 and H^(2^18)
 HD void setup_beta_lane(KeyMaterial *km, const uint4 *tab, int tid) {
     (void)tab;
-    for (int q = tid; q < (AESGCM_NQ5POW + 1) * AESGCM_Q5_ENTRIES; q += AESGCM_WG) {     // 6656 entries over the workgroup: at most seven each
+    for (int q = tid; q < (AESGCM_NQ5POW + 2) * AESGCM_Q5_ENTRIES; q += AESGCM_WG) {     // 7488 entries over the workgroup: at most eight each
         const int which = q / AESGCM_Q5_ENTRIES, e = q % AESGCM_Q5_ENTRIES;
-        const uint4 c = which < AESGCM_NQ5POW ? km->pw[0][1u << which] : km->pw[0][256];
-        (which < AESGCM_NQ5POW ? km->q5pow[which] : km->k4tab)[e] = gf_mul_mo(quint_elem_mo(e >> 5, (u32)(e & 31)), c);
+        const uint4 c = which < AESGCM_NQ5POW ? km->pw[0][1u << which] : which == AESGCM_NQ5POW ? km->pw[0][256] : km->pw[1][256];   // H^(2^18) = H^(256 * 1024)
+        (which < AESGCM_NQ5POW ? km->q5pow[which] : which == AESGCM_NQ5POW ? km->k4tab : km->k18tab)[e] = gf_mul_mo(quint_elem_mo(e >> 5, (u32)(e & 31)), c);
     }
 }
 
@@ -593,10 +594,10 @@ HD void setup_ptab_lane(KeyMaterial *km, u32 k, u32 tid) {
 
 // ---- k_main pieces -----------------------------------------------------------------------------
 // LDS image of one workgroup: what thread `tid` of AESGCM_MAIN_WG writes
-enum { GH_TAB_K64 = 0, GH_TAB_H = 1, GH_TAB_K256 = 2 };       // which constant's five-bit tables go to LDS
+enum { GH_TAB_K64 = 0, GH_TAB_H = 1, GH_TAB_K256 = 2, GH_TAB_K2P18 = 3 };       // which constant's five-bit tables go to LDS
 HD void main_fill_lds(unsigned char *smem, const KeyMaterial *km, const DevTables *tb, u32 tid, bool gh, u32 nthreads = AESGCM_MAIN_WG, int which = GH_TAB_K64) {
     if (gh) {
-        fill_lds_q5(smem, which == GH_TAB_H ? km->q5pow[0] : which == GH_TAB_K256 ? km->k4tab : km->q5pow[6], tid, nthreads);
+        fill_lds_q5(smem, which == GH_TAB_H ? km->q5pow[0] : which == GH_TAB_K256 ? km->k4tab : which == GH_TAB_K2P18 ? km->k18tab : km->q5pow[6], tid, nthreads);
     }
     uint4 *dst = reinterpret_cast<uint4 *>(smem + AESGCM_LDS_AES_OFF);
     for (u32 q = tid; q < AESGCM_LDS_AES / 16; q += nthreads) {
@@ -910,6 +911,7 @@ struct BodyParams {
     u32 iv0, iv1, iv2;
     u64 *trace;
     uint4 *ej0;                  // where the wave that owns chunk 0 leaves E_K(IV || 1) for k_combine (or NULL)
+    u32 cyc, Q;                  // cyc: cyclic rows (body_cyc_lane) over the Q super-rows of the body; T, C and the queues are unused
 };
 struct BodyLane { u32 p0, p1, p2, p3; };
 // wave-uniform table values (host: plain loads; device: scalar loads from the global T0 table)
@@ -987,13 +989,13 @@ HD void body_state(u32 &s0, u32 &s1, u32 &s2, u32 &s3, const BodyLane &b, u32 hi
         s0 ^= m & (u.U0 ^ n.U0); s1 ^= m & (u.U1 ^ n.U1); s2 ^= m & (u.U2 ^ n.U2); s3 ^= m & (u.U3 ^ n.U3);
     }
 }
-// lane `lane` of the wave that owns chunk c = 4*s + v: returns sum_i X[row 4(sT+i)+v, lane] * (H^256)^(T-1-i)
+// lane `lane` of a wave that takes the n super-rows q0, q0 + qstep, ... in row phase v: returns sum_i X[row 4(q0 + i qstep) + v, lane] * K^(n-1-i),
+// K = H^(256 qstep) = the constant whose tables the launch staged in LDS
 template <int NR, int MODE>
-HD uint4 body_chunk_lane(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const BodyParams &p,
-                         const unsigned char *smem, const CtrConsts &cc, u32 c, u32 lane) {
+HD uint4 body_strand_lane(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const BodyParams &p,
+                          const unsigned char *smem, const CtrConsts &cc, u32 q0, u32 qstep, u32 n, u32 v, u32 lane) {
     const u32 *__restrict__ rk0 = km->rk;
     const u32 lb = (lane & 31u) << 2, lane16 = lane * 16u;
-    const u32 v = c & 3u, s = c >> 2;
     const BodyLane b = body_lane_consts(rk0, cc, smem, v, lane);
     // AES-256 has 60 round-key words; all of them in scalar registers, with the row-uniform round-2 state, the pointers and the loop state, overflow the
     // 102 SGPRs: the compiler parked 31 scalars in the lanes of a VGPR and fetched ten of them back with v_readlane in EVERY row (round-3 ISA census) --
@@ -1005,26 +1007,26 @@ HD uint4 body_chunk_lane(const KeyMaterial *__restrict__ km, const DevTables *__
     uint4 acc = make_uint4(0, 0, 0, 0);
     u32 i = 0;
 #if AESGCM_BODY_ILP == 2
-    for (; i + 1 < p.T; i += 2) {
-        const u32 q = s * p.T + i;
-        const u64 off = ((u64)q * 4 + v) * 1024;
+    for (; i + 1 < n; i += 2) {
+        const u32 q = q0 + i * qstep;
+        const u64 off = ((u64)q * 4 + v) * 1024, off2 = (u64)qstep * 4096;
         const unsigned char *src = reinterpret_cast<const unsigned char *>(uniform64((u64)(uintptr_t)p.in + off));
         unsigned char *dst = reinterpret_cast<unsigned char *>(uniform64((u64)(uintptr_t)p.out + off));
         const uint4 xa = (MODE == MODE_PROBE) ? make_uint4(lane, q, v, 0u) : gload16(src + lane16);
-        const uint4 xb = (MODE == MODE_PROBE) ? make_uint4(lane, q + 1, v, 0u) : gload16(src + 4096 + lane16);
+        const uint4 xb = (MODE == MODE_PROBE) ? make_uint4(lane, q + qstep, v, 0u) : gload16(src + off2 + lane16);
         u32 a0, a1, a2, a3, b0, b1, b2, b3;
         body_state(a0, a1, a2, a3, b, p.ctr_hi0 + q, v, lane, cc, rk, tb);
-        body_state(b0, b1, b2, b3, b, p.ctr_hi0 + q + 1, v, lane, cc, rk, tb);
+        body_state(b0, b1, b2, b3, b, p.ctr_hi0 + q + qstep, v, lane, cc, rk, tb);
         body_rounds2<NR>(a0, a1, a2, a3, b0, b1, b2, b3, rk, smem, lb);
         const uint4 ya = make_uint4(xa.x ^ a0, xa.y ^ a1, xa.z ^ a2, xa.w ^ a3), yb = make_uint4(xb.x ^ b0, xb.y ^ b1, xb.z ^ b2, xb.w ^ b3);
-        if (MODE != MODE_PROBE) { gstore16(dst + lane16, ya); gstore16(dst + 4096 + lane16, yb); }
+        if (MODE != MODE_PROBE) { gstore16(dst + lane16, ya); gstore16(dst + off2 + lane16, yb); }
         if (i) acc = ghash_mul_const_lds(acc, smem);
         acc = xor4(acc, (MODE == MODE_DEC) ? xa : ya);
         acc = xor4(ghash_mul_const_lds(acc, smem), (MODE == MODE_DEC) ? xb : yb);
     }
 #endif
-    for (; i < p.T; ++i) {
-        const u32 q = s * p.T + i;                                     // super-row: counters [256 q, 256 q + 255] of the body
+    for (; i < n; ++i) {
+        const u32 q = q0 + i * qstep;                                  // super-row: counters [256 q, 256 q + 255] of the body
         if (i) acc = ghash_mul_const_lds(acc, smem);
         const u64 off = ((u64)q * 4 + v) * 1024;                       // byte offset of the row in the body
         const unsigned char *src = reinterpret_cast<const unsigned char *>(uniform64((u64)(uintptr_t)p.in + off));
@@ -1040,6 +1042,31 @@ HD uint4 body_chunk_lane(const KeyMaterial *__restrict__ km, const DevTables *__
         acc = xor4(acc, (MODE == MODE_DEC) ? x : y);                  // aes_gcm.vhd:207-211
     }
     return acc;
+}
+// dealt chunks: lane `lane` of the wave that owns chunk c = 4*s + v: returns sum_i X[row 4(sT+i)+v, lane] * (H^256)^(T-1-i)
+template <int NR, int MODE>
+HD uint4 body_chunk_lane(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const BodyParams &p,
+                         const unsigned char *smem, const CtrConsts &cc, u32 c, u32 lane) {
+    return body_strand_lane<NR, MODE>(km, tb, p, smem, cc, (c >> 2) * p.T, 1u, p.T, c & 3u, lane);
+}
+// Cyclic rows (mid-size bodies, BodyParams::cyc): no dispenser and no item per chunk.  Wave w of the launch's BODY_CYC_WAVES takes the rows
+// w, w + 4096, w + 8192, ... of the body -- phase v = w & 3 of the super-rows j, j + 1024, ... (j = w >> 2) -- as ONE Horner with the constant
+// H^(64 * 4096) = H^(2^18) (main_fill_lds(GH_TAB_K2P18)), and leaves ONE item.  The last rows of the 4096 strands are the last 4096 rows of the
+// body, in the order of the slots (j - Q) mod 1024: written there, the items are 64 blocks apart like the chunks of a k_main launch with one row
+// per chunk, whatever the body's length (strands without a row leave a zero item in front, which a Horner fold passes through) -- always 4096
+// items, one k_fold level, k_combine.  At any moment the waves of the launch work on 4096 consecutive rows (a 4 MiB window), and every wave has the
+// same number of rows to within one: nothing to balance as long as the launch is short against the drift of the issue arbitration (which is
+// what the dealt chunks of a long launch are for).
+#define BODY_CYC_QUADS 1024u             /* wave quads of the launch = 256 workgroups x 4: the stride of a strand in super-rows */
+#define BODY_CYC_WAVES (4u * BODY_CYC_QUADS)
+HD u32 body_cyc_rows(u32 Q, u32 j) { return j < Q ? (Q - j + BODY_CYC_QUADS - 1u) / BODY_CYC_QUADS : 0u; }      // super-rows of strand j of a body of Q
+HD u32 body_cyc_item(u32 Q, u32 w) { return 4u * (((w >> 2) + BODY_CYC_QUADS - (Q & (BODY_CYC_QUADS - 1u))) & (BODY_CYC_QUADS - 1u)) + (w & 3u); }
+template <int NR, int MODE>
+HD uint4 body_cyc_lane(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const BodyParams &p,
+                       const unsigned char *smem, const CtrConsts &cc, u32 w, u32 lane) {
+    const u32 n = body_cyc_rows(p.Q, w >> 2);
+    if (!n) return make_uint4(0, 0, 0, 0);
+    return body_strand_lane<NR, MODE>(km, tb, p, smem, cc, w >> 2, BODY_CYC_QUADS, n, w & 3u, lane);
 }
 
 // ---- k_combine pieces --------------------------------------------------------------------------
@@ -1182,12 +1209,19 @@ static inline u32 plan_main(MainParams &p, int mode, u32 tw_override, const uint
 // Split of a data range for k_body: [head blocks][body = S super-chunks of 256*T blocks][tail].  The body starts at
 // the first block whose index in the message (first_block + i) is a multiple of 256 -- no head at all for a whole
 // message or a shard cut at such an index -- and holds only whole 16-byte blocks.  Returns false when the range is too small to be worth three launches (min_bytes).
-struct BodySplit { u64 head_blocks, body_blocks; u32 T, S; };
-static inline bool plan_body_split(u64 len, u64 first_block, u32 tw_override, u64 min_bytes, BodySplit *b) {
+struct BodySplit { u64 head_blocks, body_blocks; u32 T, S; u32 cyc, Q; };
+// The aligned middle of a range for k_body, or false (k_main takes all of it).  Bodies of [cyc_min, cyc_max) bytes are every whole super-row behind the
+// head, taken as cyclic rows (body_cyc_lane); others are whole super-chunks of dealt chunks, from min_bytes.
+static inline bool plan_body_split(u64 len, u64 first_block, u32 tw_override, u64 min_bytes, BodySplit *b, u64 cyc_min = ~0ull, u64 cyc_max = 0) {
     const u64 nfull = len / 16;
     const u64 head = (256 - (first_block & 255)) & 255;                // to the next multiple of 256 of the message block index
     if (nfull <= head) return false;
     const u64 rows = (nfull - head) / 64;
+    b->cyc = 0; b->Q = 0;
+    if (rows / 4 && rows / 4 <= 0xFFFFFFFFull && (rows / 4) * 4096 >= cyc_min && (rows / 4) * 4096 < cyc_max) {
+        b->head_blocks = head; b->body_blocks = (rows / 4) * 256; b->T = 0; b->S = 0; b->cyc = 1; b->Q = (u32)(rows / 4);
+        return true;
+    }
     u64 R; u32 Tw, C;
     main_geometry(rows * 64, tw_override, &R, &Tw, &C);
     if (!Tw) return false;
@@ -1200,7 +1234,7 @@ static inline bool plan_body_split(u64 len, u64 first_block, u32 tw_override, u6
 }
 static inline void plan_body(BodyParams &p, const BodySplit &b, const uint8_t *iv, const void *in, void *out, u64 first_block, uint4 *parts) {
     p.in = (const unsigned char *)in + 16 * b.head_blocks; p.out = (unsigned char *)out + 16 * b.head_blocks;
-    p.parts = parts; p.T = b.T; p.C = 4 * b.S;
+    p.parts = parts; p.T = b.T; p.C = 4 * b.S; p.cyc = b.cyc; p.Q = b.Q;
     p.ctr_hi0 = (u32)((first_block + b.head_blocks) >> 8);
     u32 w[3]; iv_to_words(iv, w); p.iv0 = w[0]; p.iv1 = w[1]; p.iv2 = w[2];
 }

@@ -272,7 +272,7 @@ static_assert(AESGCM_LDS_AES_OFF % 128u == 0, "T-table replicas: lane l must rea
 static_assert(AESGCM_LDS_DRY_OFF >= AESGCM_Q5_GROUPS * 256u && AESGCM_LDS_DRY_OFF + 4u <= AESGCM_Q5_HI_ROW * 256u, "the dry-queue mask sits in the spare row between the table halves");
 static_assert((AESGCM_Q5_HI_ROW * 256u) % 512u != 0 && AESGCM_Q5_HI_ROW * 256u > 2040u, "the two halves of a five-bit table entry must not be fusable into one ds_read2[st64]_b64");
 static_assert(FOLD_B_ITEMS >= COMBINE_MAX_ITEMS && FOLD_A_ITEMS >= COMBINE_MAX_ITEMS, "k_fold ping-pong buffers");
-template <int NR, int MODE>
+template <int NR, int MODE, bool CYC>
 __global__ __launch_bounds__(AESGCM_BODY_WG, AESGCM_BODY_WPS) void k_body(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const BodyParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 tid = threadIdx.x, lane = tid & 63u;
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(AESGCM_BODY_WG, AESGCM_BODY_WPS) void k_body(const 
         tr[2] = (u64)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((u64)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xF) << 32);
     }
     const u64 cyc0 = p.trace ? clock64() : 0;
-    main_fill_lds(smem, km, tb, tid, true, AESGCM_BODY_WG, GH_TAB_K256);
+    main_fill_lds(smem, km, tb, tid, true, AESGCM_BODY_WG, CYC ? GH_TAB_K2P18 : GH_TAB_K256);
 #if AESGCM_T4
     fill_lds_t4(smem, tb, tid, AESGCM_BODY_WG);
 #endif
@@ -292,6 +292,22 @@ __global__ __launch_bounds__(AESGCM_BODY_WG, AESGCM_BODY_WPS) void k_body(const 
     cc.c0 = __builtin_amdgcn_readfirstlane(cc.c0); cc.c1 = __builtin_amdgcn_readfirstlane(cc.c1);
     cc.c2 = __builtin_amdgcn_readfirstlane(cc.c2); cc.c3 = __builtin_amdgcn_readfirstlane(cc.c3);
     u32 done = 0;
+    if (CYC) {                                                                // cyclic rows: one strand and one item per wave, no dispenser
+        const u32 w = __builtin_amdgcn_readfirstlane(blockIdx.x * (AESGCM_BODY_WG / 64) + (tid >> 6));
+        const uint4 acc = body_cyc_lane<NR, MODE>(km, tb, p, smem, cc, w, lane);
+        p.parts[(size_t)body_cyc_item(p.Q, w) * 64 + lane] = acc;
+        if (w == 0 && p.ej0) {
+            u32 s0, s1, s2, s3;
+            ctr_rounds_lds<NR>(bswap32(1u), cc, s0, s1, s2, s3, km->rk, smem, (lane & 31u) << 2);
+            if (lane == 0) *p.ej0 = make_uint4(s0, s1, s2, s3);
+        }
+        if (p.trace && lane == 0) {
+            u64 *tr = p.trace + 4 * (u64)blockIdx.x;
+            atomicMax((unsigned long long *)&tr[1], (unsigned long long)wall_clock64());
+            atomicAdd((unsigned long long *)&tr[3], (unsigned long long)body_cyc_rows(p.Q, w >> 2) | ((unsigned long long)((clock64() - cyc0) >> 10) << 32));
+        }
+        return;
+    }
     if (blockIdx.x == 0 && tid < AESGCM_NQ) p.counter_zero[16 * tid] = 0;    // the next dynamic launch's queues
     u32 q = (blockIdx.x * (AESGCM_BODY_WG / 64) + (tid >> 6)) % p.nq;
     q = __builtin_amdgcn_readfirstlane(q);
@@ -1088,6 +1104,10 @@ struct aesgcm_ctx {
     u64 body_min = (u64)256 << 20;     // ranges with an aligned middle of at least this many bytes go through k_body (AESGCM_BODY_MIN).  Since k_main
                                        // got cheaper below 256 MiB (dispensers, k_fold: profiles/r02f/split_threshold.txt) the cut pays from 256 MiB:
                                        // 128 MiB -16 %, 256 MiB +0.8 %, 512 MiB +4 %, 1 GiB +11 %, 2 GiB +7 %; it was 128 MiB before, 0.7 GiB in round 1
+    u64 cyc_min = (u64)4 << 20, cyc_max = (u64)384 << 20;   // aligned middles of [cyc_min, cyc_max) bytes go through k_body as cyclic rows (body_cyc_lane): no dispenser, 4096 items
+                                       // whatever the size.  AESGCM_BODY_CYC=min:max (bytes; 0:0 = never); needs one k_body workgroup per CU on 256 CUs.  Measured against
+                                       // k_main / dealt k_body (profiles/r03c/cyc_sweep_*.txt, AES-256, us per message): 2 MiB 35 -> 37, 4 MiB 39 -> 38, 16 MiB 66 -> 55,
+                                       // 64 MiB 137 -> 106, 128 MiB 188 -> 173, 256 MiB 326 -> 315, 512 MiB 548 -> 594 (equal shares end with the slowest wave), 4 GiB 4306 -> 4977
     uint4 *h_tag = nullptr;            // 64 bytes of pinned, device-mapped host memory: k_combine leaves the tag here too, so fetching it
     uint4 *h_tag_dev = nullptr;        //   is a host read -- no copy kernel, no interrupt-driven stream wait (its device address)
     u64 tag_gen = 0;                   // generation number of the last result sent to the host slot (the kernel publishes it behind the tag)
@@ -1155,9 +1175,10 @@ static int set_lds_attrs(int device, DeviceState *ds) {
     SETATTR(10, MODE_KS);  SETATTR(12, MODE_KS);  SETATTR(14, MODE_KS);
     SETATTR(10, MODE_ECB); SETATTR(12, MODE_ECB); SETATTR(14, MODE_ECB);
 #undef SETATTR
-#define SETATTRY(NR, MODE) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_body<NR, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, AESGCM_BODY_LDS))
-    SETATTRY(10, MODE_ENC); SETATTRY(12, MODE_ENC); SETATTRY(14, MODE_ENC); SETATTRY(10, MODE_DEC); SETATTRY(12, MODE_DEC); SETATTRY(14, MODE_DEC);
-    SETATTRY(10, MODE_PROBE); SETATTRY(12, MODE_PROBE); SETATTRY(14, MODE_PROBE);
+#define SETATTRY(NR, MODE, CYC) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_body<NR, MODE, CYC>), hipFuncAttributeMaxDynamicSharedMemorySize, AESGCM_BODY_LDS))
+    SETATTRY(10, MODE_ENC, false); SETATTRY(12, MODE_ENC, false); SETATTRY(14, MODE_ENC, false); SETATTRY(10, MODE_DEC, false); SETATTRY(12, MODE_DEC, false); SETATTRY(14, MODE_DEC, false);
+    SETATTRY(10, MODE_ENC, true); SETATTRY(12, MODE_ENC, true); SETATTRY(14, MODE_ENC, true); SETATTRY(10, MODE_DEC, true); SETATTRY(12, MODE_DEC, true); SETATTRY(14, MODE_DEC, true);
+    SETATTRY(10, MODE_PROBE, false); SETATTRY(12, MODE_PROBE, false); SETATTRY(14, MODE_PROBE, false);
 #undef SETATTRY
 #define SETATTRB(NR, D) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch<NR, D>), hipFuncAttributeMaxDynamicSharedMemorySize, BATCH_LDS_BYTES)); \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktg<NR, D, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, PKTG_LDS_TOTAL(2))); \
@@ -1223,6 +1244,15 @@ static int enqueue_fold(aesgcm_ctx *c, const uint4 *items, u32 n, u32 period, u6
     return AESGCM_OK;
 }
 
+// the context's cut of a range into head / k_body / tail (plan_body_split with its thresholds; cyclic rows only where the launch has its 4096 waves)
+static bool ctx_body_split(const aesgcm_ctx *c, u64 len, u64 first_block, BodySplit *b) {
+#if AESGCM_T4
+    const bool cyc_ok = (u32)c->G / 2 * (AESGCM_BODY_WG / 64) == BODY_CYC_WAVES;
+#else
+    const bool cyc_ok = false;
+#endif
+    return plan_body_split(len, first_block, c->tw_override, c->body_min, b, cyc_ok ? c->cyc_min : ~0ull, cyc_ok ? c->cyc_max : 0);
+}
 // Enqueue the fused kernel over (aad, data) and the k_fold levels over its chunk items; describe the result for k_combine.  mode ENC/DEC: GHASH partials.  mode KS/ECB: no GHASH.
 static int enqueue_main(aesgcm_ctx *c, int mode, const uint8_t iv[12], const void *d_aad, u64 aad_len,
                         const void *d_in, u64 len, void *d_out, u64 first_block, hipStream_t st, Partials *po, bool want_tail = false) {
@@ -1286,18 +1316,19 @@ static int enqueue_body(aesgcm_ctx *c, int mode, const uint8_t iv[12], const Bod
                         u64 first_block, hipStream_t st, Partials *po) {
     BodyParams p;
     memset(&p, 0, sizeof p);
-    int rc = grow_parts(c, (size_t)4 * b.S);
+    int rc = grow_parts(c, b.cyc ? (size_t)BODY_CYC_WAVES : (size_t)4 * b.S);
     if (rc) return rc;
     plan_body(p, b, iv, d_in, d_out, first_block, c->parts);
     p.ej0 = c->d_tag + 3; po->ej0 = p.ej0;
     const u32 waves_per_wg = AESGCM_BODY_WG / 64;
-    u32 wgs = (p.C + waves_per_wg - 1) / waves_per_wg;
+    u32 wgs = b.cyc ? BODY_CYC_WAVES / waves_per_wg : (p.C + waves_per_wg - 1) / waves_per_wg;
 #if AESGCM_T4
     if (wgs > (u32)c->G / 2) wgs = (u32)c->G / 2;                 // one 136 KiB workgroup per CU
 #else
     if (wgs > (u32)c->G) wgs = (u32)c->G;
 #endif
-    plan_queues(p.C, &p.nq, &p.seg);
+    if (b.cyc && wgs * waves_per_wg != BODY_CYC_WAVES) { snprintf(g_err, sizeof g_err, "k_body: cyclic rows need %u workgroups, the device takes %u", BODY_CYC_WAVES / waves_per_wg, wgs); return AESGCM_EHIP; }
+    if (!b.cyc) plan_queues(p.C, &p.nq, &p.seg);
     p.counter = c->d_counter + 16 * (1 + AESGCM_NQ * c->qset);
     p.counter_zero = c->d_counter + 16 * (1 + AESGCM_NQ * (c->qset ^ 1u));
     if (c->timing) { p.trace = c->d_trace; HIPCHK(hipMemsetAsync(c->d_trace, 0, sizeof(u64) * 4 * AESGCM_GMAX, st)); }
@@ -1308,19 +1339,26 @@ static int enqueue_body(aesgcm_ctx *c, int mode, const uint8_t iv[12], const Bod
         else { HIPCHK(hipEventCreate(&evp.first)); HIPCHK(hipEventCreate(&evp.second)); }
         HIPCHK(hipEventRecord(evp.first, st));
     }
-#define LY(NR, M) hipLaunchKernelGGL((k_body<NR, M>), dim3(wgs), dim3(AESGCM_BODY_WG), AESGCM_BODY_LDS, st, c->km, c->tables, p)
-    if (mode == MODE_DEC)        { if (c->nr == 10) LY(10, MODE_DEC); else if (c->nr == 12) LY(12, MODE_DEC); else LY(14, MODE_DEC); }
-    else if (mode == MODE_PROBE) { if (c->nr == 10) LY(10, MODE_PROBE); else if (c->nr == 12) LY(12, MODE_PROBE); else LY(14, MODE_PROBE); }
-    else                         { if (c->nr == 10) LY(10, MODE_ENC); else if (c->nr == 12) LY(12, MODE_ENC); else LY(14, MODE_ENC); }
+#define LY(NR, M, CYC) hipLaunchKernelGGL((k_body<NR, M, CYC>), dim3(wgs), dim3(AESGCM_BODY_WG), AESGCM_BODY_LDS, st, c->km, c->tables, p)
+    if (b.cyc && mode == MODE_PROBE) return AESGCM_EARG;
+    if (b.cyc) {
+        if (mode == MODE_DEC)    { if (c->nr == 10) LY(10, MODE_DEC, true); else if (c->nr == 12) LY(12, MODE_DEC, true); else LY(14, MODE_DEC, true); }
+        else                     { if (c->nr == 10) LY(10, MODE_ENC, true); else if (c->nr == 12) LY(12, MODE_ENC, true); else LY(14, MODE_ENC, true); }
+    }
+    else if (mode == MODE_DEC)   { if (c->nr == 10) LY(10, MODE_DEC, false); else if (c->nr == 12) LY(12, MODE_DEC, false); else LY(14, MODE_DEC, false); }
+    else if (mode == MODE_PROBE) { if (c->nr == 10) LY(10, MODE_PROBE, false); else if (c->nr == 12) LY(12, MODE_PROBE, false); else LY(14, MODE_PROBE, false); }
+    else                         { if (c->nr == 10) LY(10, MODE_ENC, false); else if (c->nr == 12) LY(12, MODE_ENC, false); else LY(14, MODE_ENC, false); }
 #undef LY
     const hipError_t le = hipGetLastError();
     if (le != hipSuccess) {
         if (c->timing) c->ev_pool.push_back(evp);
         return hip_fail(le, "k_body launch");
     }
-    c->qset ^= 1u;
+    if (!b.cyc) c->qset ^= 1u;
     if (c->timing) { HIPCHK(hipEventRecord(evp.second, st)); c->ev.push_back(evp); }
     if (c->ev_fused) HIPCHK(hipEventRecord(c->ev_fused, st));
+    // cyclic rows: always BODY_CYC_WAVES items, 64 blocks apart (body_cyc_item)
+    if (b.cyc) return enqueue_fold(c, c->parts, BODY_CYC_WAVES, 1, 64, 0, st, po);
     // items 4s + v: phases 64 blocks apart inside a super-chunk, super-chunks 256 T blocks apart
     return enqueue_fold(c, c->parts, p.C, 4, 64, (u64)256 * b.T, st, po);
 }
@@ -1332,7 +1370,7 @@ static int absorb_range(aesgcm_ctx *c, int mode, const uint8_t iv[12], const voi
     BodySplit b;
     Partials pp;
     int rc;
-    if (!plan_body_split(len, first_block, c->tw_override, c->body_min, &b)) {
+    if (!ctx_body_split(c, len, first_block, &b)) {
         if ((rc = enqueue_main(c, mode, iv, d_aad, aad_len, d_in, len, d_out, first_block, st, &pp))) return rc;
         const u64 nb = (aad_len + 15) / 16 + (len + 15) / 16;
         return nb ? enqueue_combine(c, combine_with_items(plan_combine_carry(pp.ptr, pp.np, pp.kind, state, nb), pp.eA), st) : AESGCM_OK;
@@ -1390,7 +1428,7 @@ static int crypt_dev(aesgcm_ctx *c, int dec, const uint8_t iv[12], const void *d
     if (len && (!d_in || !d_out)) return AESGCM_EARG;
     HIPCHK(hipSetDevice(c->device));
     BodySplit b;
-    if (plan_body_split(len, 0, c->tw_override, c->body_min, &b)) {
+    if (ctx_body_split(c, len, 0, &b)) {
         if (!aad_len && !b.head_blocks && len == 16 * b.body_blocks) {
             // the whole message is one aligned body (the benchmark's shape): no chaining value to carry, k_body's items go
             // straight to the tag
@@ -1511,7 +1549,12 @@ static int ctx_create_common(aesgcm_ctx **out, int device, const uint8_t *key, s
     int per_cu = 2;
     if (const char *e = getenv("AESGCM_WGS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 2) per_cu = v; }
     if (const char *e = getenv("AESGCM_TW")) c->tw_override = (u32)strtoul(e, nullptr, 0);
-    if (const char *e = getenv("AESGCM_BODY_MIN")) c->body_min = strtoull(e, nullptr, 0);
+    if (const char *e = getenv("AESGCM_BODY_MIN")) { c->body_min = strtoull(e, nullptr, 0); if (c->body_min >= (1ull << 60)) c->cyc_max = 0; }   // "never k_body" means it
+    if (const char *e = getenv("AESGCM_BODY_CYC")) {
+        char *end = nullptr;
+        const u64 lo = strtoull(e, &end, 0);
+        if (end && *end == ':') { c->cyc_min = lo; c->cyc_max = strtoull(end + 1, nullptr, 0); }
+    }
     int G = per_cu * ds->n_cu;
     if (G > AESGCM_GMAX) G = AESGCM_GMAX;
     if (G < 1) G = 1;
@@ -1637,7 +1680,7 @@ int aesgcm_ctx_body_geometry(const aesgcm_ctx *c, int *n_wg, int *wg_lanes, int 
 int aesgcm_ctx_split(const aesgcm_ctx *c, size_t len, uint64_t first_block, uint64_t *head_blocks, uint64_t *body_blocks) {
     if (!c) return AESGCM_EARG;
     BodySplit b;
-    const bool split = plan_body_split(len, first_block, c->tw_override, c->body_min, &b);
+    const bool split = ctx_body_split(c, len, first_block, &b);
     if (head_blocks) *head_blocks = split ? b.head_blocks : 0;
     if (body_blocks) *body_blocks = split ? b.body_blocks : 0;
     return AESGCM_OK;
@@ -1821,7 +1864,7 @@ int aesgcm_shard_crypt_dev(aesgcm_ctx *c, int decrypt, const uint8_t iv[12], con
     hipStream_t st = pick_stream(c, stream);
     const u64 after = total_blocks - (first_block + my_blocks);            // blocks of the message behind this shard
     BodySplit b;
-    if (plan_body_split(len, first_block, c->tw_override, c->body_min, &b)) {
+    if (ctx_body_split(c, len, first_block, &b)) {
         if (!aad_len && !b.head_blocks && len == 16 * b.body_blocks) {
             // the shard is one aligned body (the 8-GPU job's shape: 4 GiB at a multiple of 256 blocks): its items go straight to the
             // weighted partial W = P H^after -- no chaining value, one k_combine instead of memset + carry combine + weighting combine

@@ -72,10 +72,24 @@ static void emu_main(int mode, const KeyMaterial *km, const MainParams &p) {
 template <int NR, int MODE>
 static void emu_body_nr(const KeyMaterial *km, const BodyParams &p) {
     static unsigned char smem[AESGCM_LDS_BYTES_T4] __attribute__((aligned(16)));
-    for (u32 tid = 0; tid < AESGCM_MAIN_WG; tid++) main_fill_lds(smem, km, &g_tb, tid, true, AESGCM_MAIN_WG, GH_TAB_K256);
+    for (u32 tid = 0; tid < AESGCM_MAIN_WG; tid++) main_fill_lds(smem, km, &g_tb, tid, true, AESGCM_MAIN_WG, p.cyc ? GH_TAB_K2P18 : GH_TAB_K256);
 #if AESGCM_T4
     for (u32 tid = 0; tid < AESGCM_MAIN_WG; tid++) fill_lds_t4(smem, &g_tb, tid, AESGCM_MAIN_WG);     // second table region (T1 | T3)
 #endif
+    if (p.cyc) {                                                        // cyclic rows: one strand and one item per wave (k_body<.., true>)
+        std::vector<char> seen(BODY_CYC_WAVES, 0);
+        for (u32 k = 0; k < BODY_CYC_WAVES; k++) {
+            const u32 w = (k * 2741u + 17u) % BODY_CYC_WAVES;           // scrambled order (2741 is odd: a permutation)
+            const u32 item = body_cyc_item(p.Q, w);
+            CHECK(item < BODY_CYC_WAVES && !seen[item], "cyclic item %u of wave %u taken twice", item, w);
+            seen[item] = 1;
+            for (u32 lane = 0; lane < 64; lane++) {
+                const CtrConsts cc = ctr_round1_consts(p.iv0, p.iv1, p.iv2, km->rk, smem, (lane & 31u) << 2);
+                p.parts[(size_t)item * 64 + lane] = body_cyc_lane<NR, MODE>(km, &g_tb, p, smem, cc, w, lane);
+            }
+        }
+        return;
+    }
     for (u32 k = 0; k < p.C; k++) {
         const u32 c = (k * 7 + 3) % p.C == k ? k : (p.C - 1) - k;      // scrambled order (any permutation will do)
         for (u32 lane = 0; lane < 64; lane++) {
@@ -135,6 +149,7 @@ static void emu_combine(const KeyMaterial *km, const CombineParams &p0) {
 struct Parts { const uint4 *ptr; u32 np; u32 gathered; u64 eA; };   // gathered = PARTS_* kind; eA: item spacing when k_combine folds the items itself
 struct Emu {
     KeyMaterial km; u32 tw; std::vector<uint4> parts, fold_a, fold_b;
+    bool cyc = false;               // bodies as cyclic rows (every size) instead of dealt chunks
     Emu(const uint8_t *key, int key_len, u32 tw_) : tw(tw_), parts(1 << 16), fold_a(1 << 16), fold_b(1 << 12) { emu_setup(&km, key, key_len, 0, 512); }
     // mirrors enqueue_fold(): k_fold launches until one item is left
     Parts fold(const uint4 *items, u32 n, u32 period, u64 eA, u64 eB) {
@@ -188,15 +203,17 @@ struct Emu {
     // mirrors enqueue_body(): k_body + k_fold with the interleaved first level
     Parts run_body(int mode, const uint8_t *iv, const BodySplit &b, const void *in, void *out, u64 first_block) {
         BodyParams p; memset(&p, 0, sizeof p);
-        if (parts.size() < 256 * (size_t)b.S) parts.resize(256 * (size_t)b.S);
+        const size_t need = b.cyc ? (size_t)64 * BODY_CYC_WAVES : 256 * (size_t)b.S;
+        if (parts.size() < need) parts.resize(need);
         plan_body(p, b, iv, in, out, first_block, parts.data());
         emu_body(mode, &km, p);
+        if (b.cyc) return fold(parts.data(), BODY_CYC_WAVES, 1, 64, 0);
         return fold(parts.data(), p.C, 4, 64, (u64)256 * b.T);
     }
     // mirrors absorb_range()
     bool absorb(int mode, const uint8_t *iv, const uint8_t *aad, u64 aad_len, const uint8_t *in, u64 len, uint8_t *out, u64 first_block, u64 body_min, uint4 *Y) {
         BodySplit b;
-        if (!plan_body_split(len, first_block, tw, body_min, &b)) {
+        if (!plan_body_split(len, first_block, tw, body_min, &b, cyc ? 0 : ~0ull, cyc ? ~0ull : 0)) {
             Parts pp = run(mode, iv, aad, aad_len, in, len, out, first_block);
             const u64 nb = (aad_len + 15) / 16 + (len + 15) / 16;
             if (nb) emu_combine(&km, combine_with_items(plan_combine_carry(pp.ptr, pp.np, pp.gathered, Y, nb), pp.eA));
@@ -220,7 +237,7 @@ struct Emu {
     bool crypt_split(int dec, const uint8_t iv[12], const uint8_t *aad, u64 aad_len, const uint8_t *in, u64 len, uint8_t *out, uint8_t tag[16], u64 body_min) {
         uint4 Y = make_uint4(0, 0, 0, 0), t;
         BodySplit b0;
-        if (plan_body_split(len, 0, tw, body_min, &b0) && !aad_len && !b0.head_blocks && len == 16 * b0.body_blocks) {
+        if (plan_body_split(len, 0, tw, body_min, &b0, cyc ? 0 : ~0ull, cyc ? ~0ull : 0) && !aad_len && !b0.head_blocks && len == 16 * b0.body_blocks) {
             // the whole message is one aligned body: k_body's items go straight to the tag (no chaining value)
             Parts pb = run_body(dec ? MODE_DEC : MODE_ENC, iv, b0, in, out, 0);
             emu_combine(&km, combine_with_items(plan_combine_tag(pb.ptr, pb.np, pb.gathered, iv, 0, len, &t), pb.eA));
@@ -553,13 +570,14 @@ static void test_shards(int key_len, u32 G, u64 al, u64 n, int R, u64 seed) {
 }
 
 // head / k_body / tail split (absorb_range): whole messages and shards with arbitrary first blocks
-static void test_body(int key_len, u32 G, u64 al, u64 n, u64 seed) {
+static void test_body(int key_len, u32 G, u64 al, u64 n, u64 seed, bool cyc = false) {
     auto key = rnd(key_len, seed), iv = rnd(12, seed + 1), aad = rnd(al, seed + 2);
     ABuf pt(n), ct(n), ref(n), back(n);
     orc_fill_splitmix64(pt.p, n, seed + 3, 0);
     uint8_t rtag[16], tag[16], dtag[16];
     orc_gcm_crypt(0, key.data(), key_len, iv.data(), aad.data(), al, pt.p, n, ref.p, rtag);
     Emu E(key.data(), key_len, G);
+    E.cyc = cyc;
     const bool split = E.crypt_split(0, iv.data(), aad.data(), al, pt.p, n, ct.p, tag, 4096);
     CHECK(split, "body split did not apply: len %llu G %u", (unsigned long long)n, G);
     CHECK(memcmp(ct.p, ref.p, n) == 0, "body ct key %d G %u aad %llu len %llu", key_len, G, (unsigned long long)al, (unsigned long long)n);
@@ -670,6 +688,8 @@ int main(int argc, char **argv) {
     test_body(32, 1, 16, 16 * 254 + 16 * 1024 * 2, 104);          // head = 254 blocks exactly, empty tail
     test_body(16, 2, 0, 16 * 256 * 2 * 6, 106);                     // no AAD, no head, no tail: the whole message is one body (direct tag path)
     test_body(32, 1, 0, 16 * 256 * 300, 107);                       // ... with enough items for a k_fold level before k_combine's own fold
+    test_body(16, 1, 0, 16 * 256 * 7, 108, true);                   // cyclic rows: 7 super-rows, the other strands leave zero items; the whole message is the body
+    test_body(32, 2, 21, 16 * (100 + 256 * 40 + 70) + 3, 109, true); // ... with AAD, head and tail, and as shards from odd first blocks
     test_batch_pieces();
     test_packets(16, 61); test_packets(24, 62); test_packets(32, 63);
     if (level > 1) {
@@ -677,6 +697,8 @@ int main(int argc, char **argv) {
         test_key(16, 0, 8, {{0, 16 * W * 600}});              // production rule, > GMAX chunks of Tw = 16
         test_key(24, 1, 10, {{5, 16 * 64 * 4200 + 3}});        // 4200 one-row chunks: three k_fold levels
         test_body(32, 1, 9, 16 * (200 + 256 * 1100) + 7, 105);  // 4400 body items: interleaved first level + two more
+        test_body(24, 1, 0, 16 * 256 * 1024, 110, true);       // cyclic rows: every strand one super-row (4 MiB)
+        test_body(32, 1, 5, 16 * (31 + 256 * 1333 + 200) + 9, 111, true);   // 1333 super-rows: strands of two and of one, items rotated by 309 slots
     }
     printf(g_fail ? "EMUL FAILED (%d)\n" : "EMUL OK\n", g_fail);
     return g_fail ? 1 : 0;

@@ -90,14 +90,16 @@ def test_fuzz_random_shard_splits(hip, orc):
         assert bytes(d_out.download(n)) == want[0]
 
 
-@pytest.mark.parametrize("body", [False, True])
+@pytest.mark.parametrize("body", [False, True, "cyc"])
 def test_fold_level_boundaries(hip, orc, monkeypatch, body):
     """k_fold reduces up to 128 items per workgroup (8 waves x 1..16 items, fold_group) and k_combine folds the last 64:
     chunk counts on both sides of every boundary of that scheme (64, 128, 512 g for g = 1..16, 16 x 8192, 65536), with
     one-row chunks so that the count is the row count; once through k_main alone, once with the k_body cut forced
-    (interleaved items, period-4 first level)."""
+    (interleaved items, period-4 first level), once with the aligned middle as cyclic rows (k_body<.., true>: strands of 0 .. 17 rows,
+    always 4096 items, rotated by the row count)."""
     monkeypatch.setenv("AESGCM_TW", "1")
-    monkeypatch.setenv("AESGCM_BODY_MIN", "4096" if body else str(1 << 60))
+    monkeypatch.setenv("AESGCM_BODY_MIN", "4096" if body is True else str(1 << 59))
+    monkeypatch.setenv("AESGCM_BODY_CYC", "4096:%d" % (1 << 50) if body == "cyc" else "0:0")
     key, iv = splitmix_bytes(4201, 32), splitmix_bytes(4202, 12)
     ctx, f = hip.Context(key), orc.Fast(key)
     counts = (1, 2, 15, 16, 17, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 2047, 2048, 2049, 4095, 4096, 4097, 8191, 8192, 8193,

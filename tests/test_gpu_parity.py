@@ -373,12 +373,14 @@ def test_plain_c_caller(hip):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tw", ["", "1", "3"])
+@pytest.mark.parametrize("tw", ["", "1", "3", "cyc"])
 def test_body_split_forced_on_small_messages(hip, orc, monkeypatch, tw):
-    """The head / k_body / tail cut (aesgcm_ctx_split) normally starts at 1 GiB; AESGCM_BODY_MIN brings it down so that
-    whole messages, decrypts and shards with odd first blocks run through k_body at sizes the oracle checks in full."""
+    """The head / k_body / tail cut (aesgcm_ctx_split) normally starts at 8 MiB; AESGCM_BODY_MIN / AESGCM_BODY_CYC bring it down so that
+    whole messages, decrypts and shards with odd first blocks run through k_body -- dealt chunks, or cyclic rows -- at sizes the oracle
+    checks in full."""
     monkeypatch.setenv("AESGCM_BODY_MIN", "4096")
-    if tw:
+    monkeypatch.setenv("AESGCM_BODY_CYC", "4096:%d" % (1 << 50) if tw == "cyc" else "0:0")
+    if tw and tw != "cyc":
         monkeypatch.setenv("AESGCM_TW", tw)
     for klen in (16, 24, 32):
         key, iv = splitmix_bytes(700 + klen, klen), splitmix_bytes(701, 12)
