@@ -431,7 +431,7 @@ struct DevTables {           // per device
 };
 
 #define AESGCM_NPTAB 26
-#define AESGCM_NLTAB 66
+#define AESGCM_NLTAB 130
 #define AESGCM_NQ5POW 7
 struct KeyMaterial {         // per context (device memory)
     u32 rk[60];              // expanded key, memory-order words
@@ -445,7 +445,7 @@ struct KeyMaterial {         // per context (device memory)
     uint4 k4tab[AESGCM_Q5_ENTRIES];  // ... of H^256 (k_body: a wave takes every fourth row)
     uint4 k18tab[AESGCM_Q5_ENTRIES]; // ... of H^(2^18) (k_body, cyclic rows: a wave takes every 4096th row)
     uint4 ptab[AESGCM_NPTAB][512]; // nibble tables of H^(2^k), k = 6 .. 31: the Horner constants of k_fold when chunk sizes are powers of two
-    uint4 ltab[AESGCM_NLTAB][32];  // two-table Shoup form of H^e, e = 0 .. 65: [e][v] = v*H^e, [e][16 + v] = v*H^e*x^4 (per-lane constant multiplies of the closing steps)
+    uint4 ltab[AESGCM_NLTAB][32];  // two-table Shoup form of H^e, e = 0 .. 129 (65 - lane, plus up to 64 blocks of a separate last row behind the items: CombineParams::tail_blocks): [e][v] = v*H^e, [e][16 + v] = v*H^e*x^4 (per-lane constant multiplies of the closing steps)
     uint8_t rk_bytes[240];   // expanded key as the byte string tb/key_exp.py produces
 };
 
@@ -911,7 +911,11 @@ struct BodyParams {
     u32 iv0, iv1, iv2;
     u64 *trace;
     uint4 *ej0;                  // where the wave that owns chunk 0 leaves E_K(IV || 1) for k_combine (or NULL)
-    u32 cyc, Q;                  // cyc: cyclic rows (body_cyc_lane) over the Q super-rows of the body; T, C and the queues are unused
+    // cyclic rows (k_body<.., true>, body_cyc_lane): T, C and the queues are unused
+    u32 cyc;
+    u32 F, R;                    // rows in front of the body (AAD blocks and the data blocks up to the body, front-padded: `front`) and whole rows of the body
+    u32 tb;                      // blocks of the last, partial row behind the body (`last`; 0 = none): its item goes to parts[BODY_CYC_WAVES]
+    MainParams front, last;      // the two generic pieces as one-row chunks of main_chunk_lane
 };
 struct BodyLane { u32 p0, p1, p2, p3; };
 // wave-uniform table values (host: plain loads; device: scalar loads from the global T0 table)
@@ -993,7 +997,8 @@ HD void body_state(u32 &s0, u32 &s1, u32 &s2, u32 &s3, const BodyLane &b, u32 hi
 // K = H^(256 qstep) = the constant whose tables the launch staged in LDS
 template <int NR, int MODE>
 HD uint4 body_strand_lane(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const BodyParams &p,
-                          const unsigned char *smem, const CtrConsts &cc, u32 q0, u32 qstep, u32 n, u32 v, u32 lane) {
+                          const unsigned char *smem, const CtrConsts &cc, u32 q0, u32 qstep, u32 n, u32 v, u32 lane,
+                          uint4 acc_in = make_uint4(0, 0, 0, 0), bool continued = false) {      // continued: acc_in is the strand so far (one more multiply in front of the first row)
     const u32 *__restrict__ rk0 = km->rk;
     const u32 lb = (lane & 31u) << 2, lane16 = lane * 16u;
     const BodyLane b = body_lane_consts(rk0, cc, smem, v, lane);
@@ -1004,9 +1009,10 @@ HD uint4 body_strand_lane(const KeyMaterial *__restrict__ km, const DevTables *_
     u32 rk[4 * (NR + 1)];
 #pragma unroll
     for (int w = 0; w < 4 * (NR + 1); w++) rk[w] = (w >= AESGCM_BODY_RKV_FROM(NR)) ? pin_vgpr(rk0[w]) : rk0[w];
-    uint4 acc = make_uint4(0, 0, 0, 0);
+    uint4 acc = acc_in;
     u32 i = 0;
 #if AESGCM_BODY_ILP == 2
+    if (continued) acc = ghash_mul_const_lds(acc, smem);
     for (; i + 1 < n; i += 2) {
         const u32 q = q0 + i * qstep;
         const u64 off = ((u64)q * 4 + v) * 1024, off2 = (u64)qstep * 4096;
@@ -1027,7 +1033,11 @@ HD uint4 body_strand_lane(const KeyMaterial *__restrict__ km, const DevTables *_
 #endif
     for (; i < n; ++i) {
         const u32 q = q0 + i * qstep;                                  // super-row: counters [256 q, 256 q + 255] of the body
+#if AESGCM_BODY_ILP == 2
         if (i) acc = ghash_mul_const_lds(acc, smem);
+#else
+        if (i || continued) acc = ghash_mul_const_lds(acc, smem);
+#endif
         const u64 off = ((u64)q * 4 + v) * 1024;                       // byte offset of the row in the body
         const unsigned char *src = reinterpret_cast<const unsigned char *>(uniform64((u64)(uintptr_t)p.in + off));
         unsigned char *dst = reinterpret_cast<unsigned char *>(uniform64((u64)(uintptr_t)p.out + off));
@@ -1049,24 +1059,43 @@ HD uint4 body_chunk_lane(const KeyMaterial *__restrict__ km, const DevTables *__
                          const unsigned char *smem, const CtrConsts &cc, u32 c, u32 lane) {
     return body_strand_lane<NR, MODE>(km, tb, p, smem, cc, (c >> 2) * p.T, 1u, p.T, c & 3u, lane);
 }
-// Cyclic rows (mid-size bodies, BodyParams::cyc): no dispenser and no item per chunk.  Wave w of the launch's BODY_CYC_WAVES takes the rows
-// w, w + 4096, w + 8192, ... of the body -- phase v = w & 3 of the super-rows j, j + 1024, ... (j = w >> 2) -- as ONE Horner with the constant
-// H^(64 * 4096) = H^(2^18) (main_fill_lds(GH_TAB_K2P18)), and leaves ONE item.  The last rows of the 4096 strands are the last 4096 rows of the
-// body, in the order of the slots (j - Q) mod 1024: written there, the items are 64 blocks apart like the chunks of a k_main launch with one row
-// per chunk, whatever the body's length (strands without a row leave a zero item in front, which a Horner fold passes through) -- always 4096
-// items, one k_fold level, k_combine.  At any moment the waves of the launch work on 4096 consecutive rows (a 4 MiB window), and every wave has the
+// Cyclic rows (mid-size ranges, BodyParams::cyc): no dispenser, no item per chunk, and the whole range -- AAD, odd first block, ragged end -- in ONE launch.
+// The GHASH sequence of the range is laid on a grid of 64-block rows that is aligned to the BODY: F front rows (the AAD blocks and the data blocks up to the
+// first block whose message index is a multiple of 256, padded with zero blocks in FRONT, which GHASH does not see), R whole rows of the body, and behind them at
+// most one partial row of tb blocks.  Wave s of the launch's 4096 takes the rows  rho, rho + 4096, rho + 8192, ...  of the F + R grid rows
+// (rho = (s + F + R) mod 4096) as ONE Horner with the constant H^(64 * 4096) = H^(2^18) (main_fill_lds(GH_TAB_K2P18)) and leaves item s: the last
+// rows of the 4096 strands are the last 4096 rows of the grid in the order of s, so the items are 64 blocks apart like the chunks of a k_main
+// launch with one row per chunk, whatever the length (strands without a row leave a zero item in front, which a Horner fold passes through) --
+// always 4096 items, one k_fold level, k_combine.  A strand's front row, if it has one (F <= 4096: at most its first), goes through k_main's
+// general row code (main_chunk_lane on a one-row chunk); every other row is a body row with the round-1/2 shortcuts, and all body rows of a wave
+// have the same phase v = (rho - F) mod 4.  The partial row behind the body cannot sit on the grid (its end is the end of the sequence): wave 0
+// (a strand of the shorter kind) takes it as a front-padded row of its own and leaves item 4096, which k_combine weights separately
+// (CombineParams::tail_item).  At any moment the waves of the launch work on 4096 consecutive rows (a 4 MiB window), and every wave has the
 // same number of rows to within one: nothing to balance as long as the launch is short against the drift of the issue arbitration (which is
 // what the dealt chunks of a long launch are for).
-#define BODY_CYC_QUADS 1024u             /* wave quads of the launch = 256 workgroups x 4: the stride of a strand in super-rows */
-#define BODY_CYC_WAVES (4u * BODY_CYC_QUADS)
-HD u32 body_cyc_rows(u32 Q, u32 j) { return j < Q ? (Q - j + BODY_CYC_QUADS - 1u) / BODY_CYC_QUADS : 0u; }      // super-rows of strand j of a body of Q
-HD u32 body_cyc_item(u32 Q, u32 w) { return 4u * (((w >> 2) + BODY_CYC_QUADS - (Q & (BODY_CYC_QUADS - 1u))) & (BODY_CYC_QUADS - 1u)) + (w & 3u); }
+#define BODY_CYC_WAVES 4096u             /* waves of the launch = 256 workgroups x 16: the stride of a strand in rows */
+#define BODY_CYC_MAX_FRONT BODY_CYC_WAVES /* front rows the layout admits (4 MiB of AAD): one per strand */
+HD u32 body_cyc_residue(const BodyParams &p, u32 s) { return (s + p.F + p.R) & (BODY_CYC_WAVES - 1u); }
 template <int NR, int MODE>
 HD uint4 body_cyc_lane(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const BodyParams &p,
-                       const unsigned char *smem, const CtrConsts &cc, u32 w, u32 lane) {
-    const u32 n = body_cyc_rows(p.Q, w >> 2);
-    if (!n) return make_uint4(0, 0, 0, 0);
-    return body_strand_lane<NR, MODE>(km, tb, p, smem, cc, w >> 2, BODY_CYC_QUADS, n, w & 3u, lane);
+                       const unsigned char *smem, const CtrConsts &cc, u32 s, u32 lane) {
+    const u32 Rt = p.F + p.R;
+    u32 u = body_cyc_residue(p, s);
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    bool started = false;
+    if (u < p.F) {                                                     // wave-uniform
+        acc = main_chunk_lane<NR, MODE>(km, p.front, smem, cc, u, lane);
+        started = true;
+        u += BODY_CYC_WAVES;
+    }
+    if (u >= Rt) return acc;
+    const u32 r0 = u - p.F, n = (Rt - u + BODY_CYC_WAVES - 1u) / BODY_CYC_WAVES;
+    return body_strand_lane<NR, MODE>(km, tb, p, smem, cc, r0 >> 2, BODY_CYC_WAVES / 4u, n, r0 & 3u, lane, acc, started);
+}
+// the partial row behind the body (lane values = one-row item, right-aligned)
+template <int NR, int MODE>
+HD uint4 body_cyc_last_lane(const KeyMaterial *__restrict__ km, const BodyParams &p, const unsigned char *smem, const CtrConsts &cc, u32 lane) {
+    return main_chunk_lane<NR, MODE>(km, p.last, smem, cc, 0u, lane);
 }
 
 // ---- k_combine pieces --------------------------------------------------------------------------
@@ -1090,6 +1119,7 @@ struct CombineParams {
     const uint4 *parts; u32 np; u32 kind;   // GATHERED: np weighted 16-byte partials (shards); ITEM: np <= 64 chunk items of 64 lanes, eA blocks apart
     u32 stride;                  // GATHERED: distance between consecutive partials in 16-byte units (0 = 1): an all-gather of M messages' partials leaves [rank][message]
     u64 eA;                      // ITEM, np > 1: blocks between the ends of consecutive items (a power of two: the tables come from KeyMaterial::ptab)
+    const uint4 *tail_item; u32 tail_blocks;   // ITEM: one more item of 64 lanes whose end is the end of the sequence, tail_blocks (<= 64) blocks behind the end of the others (k_body's cyclic rows: the partial last row)
     const uint4 *tabA, *tabB, *tabC;   // device pointers to the nibble tables of H^eA, H^(4 eA), H^(16 eA) (filled in by the host side)
     u32 want_tag;                // 1 = TAG, 0 = POLY
     u64 e;                       // POLY: exponent applied to the folded partials
@@ -1209,19 +1239,12 @@ static inline u32 plan_main(MainParams &p, int mode, u32 tw_override, const uint
 // Split of a data range for k_body: [head blocks][body = S super-chunks of 256*T blocks][tail].  The body starts at
 // the first block whose index in the message (first_block + i) is a multiple of 256 -- no head at all for a whole
 // message or a shard cut at such an index -- and holds only whole 16-byte blocks.  Returns false when the range is too small to be worth three launches (min_bytes).
-struct BodySplit { u64 head_blocks, body_blocks; u32 T, S; u32 cyc, Q; };
-// The aligned middle of a range for k_body, or false (k_main takes all of it).  Bodies of [cyc_min, cyc_max) bytes are every whole super-row behind the
-// head, taken as cyclic rows (body_cyc_lane); others are whole super-chunks of dealt chunks, from min_bytes.
-static inline bool plan_body_split(u64 len, u64 first_block, u32 tw_override, u64 min_bytes, BodySplit *b, u64 cyc_min = ~0ull, u64 cyc_max = 0) {
+struct BodySplit { u64 head_blocks, body_blocks; u32 T, S; };
+static inline bool plan_body_split(u64 len, u64 first_block, u32 tw_override, u64 min_bytes, BodySplit *b) {
     const u64 nfull = len / 16;
     const u64 head = (256 - (first_block & 255)) & 255;                // to the next multiple of 256 of the message block index
     if (nfull <= head) return false;
     const u64 rows = (nfull - head) / 64;
-    b->cyc = 0; b->Q = 0;
-    if (rows / 4 && rows / 4 <= 0xFFFFFFFFull && (rows / 4) * 4096 >= cyc_min && (rows / 4) * 4096 < cyc_max) {
-        b->head_blocks = head; b->body_blocks = (rows / 4) * 256; b->T = 0; b->S = 0; b->cyc = 1; b->Q = (u32)(rows / 4);
-        return true;
-    }
     u64 R; u32 Tw, C;
     main_geometry(rows * 64, tw_override, &R, &Tw, &C);
     if (!Tw) return false;
@@ -1234,9 +1257,36 @@ static inline bool plan_body_split(u64 len, u64 first_block, u32 tw_override, u6
 }
 static inline void plan_body(BodyParams &p, const BodySplit &b, const uint8_t *iv, const void *in, void *out, u64 first_block, uint4 *parts) {
     p.in = (const unsigned char *)in + 16 * b.head_blocks; p.out = (unsigned char *)out + 16 * b.head_blocks;
-    p.parts = parts; p.T = b.T; p.C = 4 * b.S; p.cyc = b.cyc; p.Q = b.Q;
+    p.parts = parts; p.T = b.T; p.C = 4 * b.S;
     p.ctr_hi0 = (u32)((first_block + b.head_blocks) >> 8);
     u32 w[3]; iv_to_words(iv, w); p.iv0 = w[0]; p.iv1 = w[1]; p.iv2 = w[2];
+}
+// A whole range (AAD, data from any first block, ragged end) as ONE k_body launch of cyclic rows (body_cyc_lane), when its body -- the whole 64-block
+// rows from the first block whose message index is a multiple of 256 -- has [min_bytes, max_bytes) bytes and the blocks in front of it fit one front
+// row per strand.  Fills p (parts: BODY_CYC_WAVES + 1 items) and returns true; `tail_blocks` = blocks of the partial row behind the body.
+static inline bool plan_body_cyc(BodyParams &p, int mode, const uint8_t *iv, const void *aad, u64 aad_len, const void *in, u64 len, void *out,
+                                 u64 first_block, uint4 *parts, u64 min_bytes, u64 max_bytes) {
+    const u64 nfull = len / 16;
+    const u64 head = (256 - (first_block & 255)) & 255;
+    if (nfull <= head) return false;
+    const u64 R = (nfull - head) / 64;
+    if (!R || R * 1024 < min_bytes || R * 1024 >= max_bytes) return false;
+    const u64 n_aad = (aad_len + 15) / 16, F = (n_aad + head + 63) / 64;
+    if (F > BODY_CYC_MAX_FRONT || F + R > 0x7FFFFFFFull) return false;
+    { const BodyParams zero = {}; p = zero; }
+    const u64 done = head + 64 * R;                                    // data blocks in front of the partial row
+    p.cyc = 1; p.F = (u32)F; p.R = (u32)R;
+    p.in = (const unsigned char *)in + 16 * head; p.out = (unsigned char *)out + 16 * head;
+    p.parts = parts;
+    p.ctr_hi0 = (u32)((first_block + head) >> 8);
+    u32 w[3]; iv_to_words(iv, w); p.iv0 = w[0]; p.iv1 = w[1]; p.iv2 = w[2];
+    // the generic pieces as chunks of one row (tw_override = 1): chunk c of `front` is grid row c
+    const u32 Cf = plan_main(p.front, mode, 1, iv, aad, aad_len, in, 16 * head, out, first_block, nullptr);
+    const u32 Cl = plan_main(p.last, mode, 1, iv, nullptr, 0, (const unsigned char *)in + 16 * done, len - 16 * done,
+                             (unsigned char *)out + 16 * done, first_block + done, nullptr);
+    if (Cf != (u32)F || Cl > 1) return false;                          // cannot happen: the geometry above is plan_main's
+    p.tb = Cl ? (u32)p.last.n_seq : 0;
+    return true;
 }
 // whole-message tag from the folded item:  P*H^2 ^ L*H ^ E_K(J0)
 static inline CombineParams plan_combine_tag(const uint4 *parts, u32 np, u32 kind, const uint8_t iv[12],
@@ -1249,7 +1299,7 @@ static inline CombineParams plan_combine_tag(const uint4 *parts, u32 np, u32 kin
     return q;
 }
 // chunk items handed to k_combine unfolded: their spacing (the host side adds the table pointers)
-static inline CombineParams combine_with_items(CombineParams q, u64 eA) { q.eA = eA; return q; }
+static inline CombineParams combine_with_items(CombineParams q, u64 eA, const uint4 *tail_item = nullptr, u32 tail_blocks = 0) { q.eA = eA; q.tail_item = tail_item; q.tail_blocks = tail_blocks; return q; }
 // polynomial value of local partials times H^e (shard partial, aesgcm_ghash)
 static inline CombineParams plan_combine_poly(const uint4 *parts, u32 np, u32 kind, u64 e, uint4 *out) {
     CombineParams q = {};

@@ -295,16 +295,19 @@ __global__ __launch_bounds__(AESGCM_BODY_WG, AESGCM_BODY_WPS) void k_body(const 
     if (CYC) {                                                                // cyclic rows: one strand and one item per wave, no dispenser
         const u32 w = __builtin_amdgcn_readfirstlane(blockIdx.x * (AESGCM_BODY_WG / 64) + (tid >> 6));
         const uint4 acc = body_cyc_lane<NR, MODE>(km, tb, p, smem, cc, w, lane);
-        p.parts[(size_t)body_cyc_item(p.Q, w) * 64 + lane] = acc;
-        if (w == 0 && p.ej0) {
-            u32 s0, s1, s2, s3;
-            ctr_rounds_lds<NR>(bswap32(1u), cc, s0, s1, s2, s3, km->rk, smem, (lane & 31u) << 2);
-            if (lane == 0) *p.ej0 = make_uint4(s0, s1, s2, s3);
+        p.parts[(size_t)w * 64 + lane] = acc;
+        if (w == 0) {                                                         // a strand of the shorter kind: the partial last row and E_K(IV || 1)
+            if (p.tb) p.parts[(size_t)BODY_CYC_WAVES * 64 + lane] = body_cyc_last_lane<NR, MODE>(km, p, smem, cc, lane);
+            if (p.ej0) {
+                u32 s0, s1, s2, s3;
+                ctr_rounds_lds<NR>(bswap32(1u), cc, s0, s1, s2, s3, km->rk, smem, (lane & 31u) << 2);
+                if (lane == 0) *p.ej0 = make_uint4(s0, s1, s2, s3);
+            }
         }
         if (p.trace && lane == 0) {
             u64 *tr = p.trace + 4 * (u64)blockIdx.x;
             atomicMax((unsigned long long *)&tr[1], (unsigned long long)wall_clock64());
-            atomicAdd((unsigned long long *)&tr[3], (unsigned long long)body_cyc_rows(p.Q, w >> 2) | ((unsigned long long)((clock64() - cyc0) >> 10) << 32));
+            atomicAdd((unsigned long long *)&tr[3], (unsigned long long)((p.F + p.R) / BODY_CYC_WAVES) | ((unsigned long long)((clock64() - cyc0) >> 10) << 32));
         }
         return;
     }
@@ -397,7 +400,9 @@ __device__ __forceinline__ void combine_body(const KeyMaterial *__restrict__ km,
     G128 z; z.w[0] = z.w[1] = z.w[2] = z.w[3] = 0;
     if (items && w == 0) {
         const G128 b = mo_to_be(combine_fold_staged(smem, CMB_LDS_STAGE2, J2, 0, CMB_LDS_TABC, lane));
-        z = shoup2_gmul(b, km->ltab[(tag ? 65u : 63u) - lane]);
+        z = shoup2_gmul(b, km->ltab[(tag ? 65u : 63u) - lane + (p.tail_item ? p.tail_blocks : 0u)]);
+    } else if (items && w == 1 && p.tail_item) {                   // the partial last row of k_body's cyclic rows: it ends where the sequence ends
+        z = shoup2_gmul(mo_to_be(p.tail_item[lane]), km->ltab[(tag ? 65u : 63u) - lane]);
     } else if (p.kind == PARTS_GATHERED && tid < p.np) {
         z = mo_to_be(p.parts[(size_t)tid * (p.stride ? p.stride : 1u)]);
         if (tag) z = shoup2_gmul(z, km->ltab[2]);
@@ -1104,7 +1109,8 @@ struct aesgcm_ctx {
     u64 body_min = (u64)256 << 20;     // ranges with an aligned middle of at least this many bytes go through k_body (AESGCM_BODY_MIN).  Since k_main
                                        // got cheaper below 256 MiB (dispensers, k_fold: profiles/r02f/split_threshold.txt) the cut pays from 256 MiB:
                                        // 128 MiB -16 %, 256 MiB +0.8 %, 512 MiB +4 %, 1 GiB +11 %, 2 GiB +7 %; it was 128 MiB before, 0.7 GiB in round 1
-    u64 cyc_min = (u64)4 << 20, cyc_max = (u64)384 << 20;   // aligned middles of [cyc_min, cyc_max) bytes go through k_body as cyclic rows (body_cyc_lane): no dispenser, 4096 items
+    u64 cyc_max_pieces = (u64)640 << 20;   // ... for ranges with AAD, an odd first block or a ragged end
+    u64 cyc_min = (u64)4 << 20, cyc_max = (u64)384 << 20;   // ranges whose whole rows are [cyc_min, cyc_max) bytes go through k_body as cyclic rows (body_cyc_lane): no dispenser, 4096 items
                                        // whatever the size.  AESGCM_BODY_CYC=min:max (bytes; 0:0 = never); needs one k_body workgroup per CU on 256 CUs.  Measured against
                                        // k_main / dealt k_body (profiles/r03c/cyc_sweep_*.txt, AES-256, us per message): 2 MiB 35 -> 37, 4 MiB 39 -> 38, 16 MiB 66 -> 55,
                                        // 64 MiB 137 -> 106, 128 MiB 188 -> 173, 256 MiB 326 -> 315, 512 MiB 548 -> 594 (equal shares end with the slowest wave), 4 GiB 4306 -> 4977
@@ -1202,7 +1208,7 @@ static int set_lds_attrs(int device, DeviceState *ds) {
 }
 
 // What the fold stage needs to know about the partials a launch produced.
-struct Partials { const uint4 *ptr = nullptr; u32 np = 0; u32 kind = PARTS_NONE; const uint4 *ej0 = nullptr; u64 eA = 0; bool done = false; };   // eA: blocks between chunk items when k_combine folds them itself (np > 1)
+struct Partials { const uint4 *ptr = nullptr; u32 np = 0; u32 kind = PARTS_NONE; const uint4 *ej0 = nullptr; u64 eA = 0; bool done = false; const uint4 *tail_item = nullptr; u32 tail_blocks = 0; };   // eA: blocks between chunk items when k_combine folds them itself (np > 1)
 
 static int grow_parts(aesgcm_ctx *c, size_t need) {
     if (need <= c->parts_cap) return AESGCM_OK;
@@ -1244,14 +1250,9 @@ static int enqueue_fold(aesgcm_ctx *c, const uint4 *items, u32 n, u32 period, u6
     return AESGCM_OK;
 }
 
-// the context's cut of a range into head / k_body / tail (plan_body_split with its thresholds; cyclic rows only where the launch has its 4096 waves)
+// the context's cut of a range into head / k_body (dealt chunks) / tail
 static bool ctx_body_split(const aesgcm_ctx *c, u64 len, u64 first_block, BodySplit *b) {
-#if AESGCM_T4
-    const bool cyc_ok = (u32)c->G / 2 * (AESGCM_BODY_WG / 64) == BODY_CYC_WAVES;
-#else
-    const bool cyc_ok = false;
-#endif
-    return plan_body_split(len, first_block, c->tw_override, c->body_min, b, cyc_ok ? c->cyc_min : ~0ull, cyc_ok ? c->cyc_max : 0);
+    return plan_body_split(len, first_block, c->tw_override, c->body_min, b);
 }
 // Enqueue the fused kernel over (aad, data) and the k_fold levels over its chunk items; describe the result for k_combine.  mode ENC/DEC: GHASH partials.  mode KS/ECB: no GHASH.
 static int enqueue_main(aesgcm_ctx *c, int mode, const uint8_t iv[12], const void *d_aad, u64 aad_len,
@@ -1311,26 +1312,10 @@ static int enqueue_main(aesgcm_ctx *c, int mode, const uint8_t iv[12], const voi
 
 static int enqueue_combine(aesgcm_ctx *c, const CombineParams &p, hipStream_t st);
 
-// k_body over the planned split + the k_fold levels over its interleaved chunk items
-static int enqueue_body(aesgcm_ctx *c, int mode, const uint8_t iv[12], const BodySplit &b, const void *d_in, void *d_out,
-                        u64 first_block, hipStream_t st, Partials *po) {
-    BodyParams p;
-    memset(&p, 0, sizeof p);
-    int rc = grow_parts(c, b.cyc ? (size_t)BODY_CYC_WAVES : (size_t)4 * b.S);
-    if (rc) return rc;
-    plan_body(p, b, iv, d_in, d_out, first_block, c->parts);
-    p.ej0 = c->d_tag + 3; po->ej0 = p.ej0;
-    const u32 waves_per_wg = AESGCM_BODY_WG / 64;
-    u32 wgs = b.cyc ? BODY_CYC_WAVES / waves_per_wg : (p.C + waves_per_wg - 1) / waves_per_wg;
-#if AESGCM_T4
-    if (wgs > (u32)c->G / 2) wgs = (u32)c->G / 2;                 // one 136 KiB workgroup per CU
-#else
-    if (wgs > (u32)c->G) wgs = (u32)c->G;
-#endif
-    if (b.cyc && wgs * waves_per_wg != BODY_CYC_WAVES) { snprintf(g_err, sizeof g_err, "k_body: cyclic rows need %u workgroups, the device takes %u", BODY_CYC_WAVES / waves_per_wg, wgs); return AESGCM_EHIP; }
-    if (!b.cyc) plan_queues(p.C, &p.nq, &p.seg);
-    p.counter = c->d_counter + 16 * (1 + AESGCM_NQ * c->qset);
-    p.counter_zero = c->d_counter + 16 * (1 + AESGCM_NQ * (c->qset ^ 1u));
+// one k_body launch (dealt chunks or cyclic rows) with the context's timing and event bookkeeping
+static int launch_body(aesgcm_ctx *c, int mode, BodyParams &p, u32 wgs, hipStream_t st) {
+    const bool cyc = p.cyc != 0;
+    if (cyc && mode == MODE_PROBE) return AESGCM_EARG;
     if (c->timing) { p.trace = c->d_trace; HIPCHK(hipMemsetAsync(c->d_trace, 0, sizeof(u64) * 4 * AESGCM_GMAX, st)); }
     c->last_np = wgs;
     std::pair<hipEvent_t, hipEvent_t> evp;
@@ -1340,8 +1325,7 @@ static int enqueue_body(aesgcm_ctx *c, int mode, const uint8_t iv[12], const Bod
         HIPCHK(hipEventRecord(evp.first, st));
     }
 #define LY(NR, M, CYC) hipLaunchKernelGGL((k_body<NR, M, CYC>), dim3(wgs), dim3(AESGCM_BODY_WG), AESGCM_BODY_LDS, st, c->km, c->tables, p)
-    if (b.cyc && mode == MODE_PROBE) return AESGCM_EARG;
-    if (b.cyc) {
+    if (cyc) {
         if (mode == MODE_DEC)    { if (c->nr == 10) LY(10, MODE_DEC, true); else if (c->nr == 12) LY(12, MODE_DEC, true); else LY(14, MODE_DEC, true); }
         else                     { if (c->nr == 10) LY(10, MODE_ENC, true); else if (c->nr == 12) LY(12, MODE_ENC, true); else LY(14, MODE_ENC, true); }
     }
@@ -1354,13 +1338,62 @@ static int enqueue_body(aesgcm_ctx *c, int mode, const uint8_t iv[12], const Bod
         if (c->timing) c->ev_pool.push_back(evp);
         return hip_fail(le, "k_body launch");
     }
-    if (!b.cyc) c->qset ^= 1u;
+    if (!cyc) c->qset ^= 1u;
     if (c->timing) { HIPCHK(hipEventRecord(evp.second, st)); c->ev.push_back(evp); }
     if (c->ev_fused) HIPCHK(hipEventRecord(c->ev_fused, st));
-    // cyclic rows: always BODY_CYC_WAVES items, 64 blocks apart (body_cyc_item)
-    if (b.cyc) return enqueue_fold(c, c->parts, BODY_CYC_WAVES, 1, 64, 0, st, po);
+    return AESGCM_OK;
+}
+// k_body over the planned split + the k_fold levels over its interleaved chunk items
+static int enqueue_body(aesgcm_ctx *c, int mode, const uint8_t iv[12], const BodySplit &b, const void *d_in, void *d_out,
+                        u64 first_block, hipStream_t st, Partials *po) {
+    BodyParams p;
+    memset(&p, 0, sizeof p);
+    int rc = grow_parts(c, (size_t)4 * b.S);
+    if (rc) return rc;
+    plan_body(p, b, iv, d_in, d_out, first_block, c->parts);
+    p.ej0 = c->d_tag + 3; po->ej0 = p.ej0;
+    const u32 waves_per_wg = AESGCM_BODY_WG / 64;
+    u32 wgs = (p.C + waves_per_wg - 1) / waves_per_wg;
+#if AESGCM_T4
+    if (wgs > (u32)c->G / 2) wgs = (u32)c->G / 2;                 // one 136 KiB workgroup per CU
+#else
+    if (wgs > (u32)c->G) wgs = (u32)c->G;
+#endif
+    plan_queues(p.C, &p.nq, &p.seg);
+    p.counter = c->d_counter + 16 * (1 + AESGCM_NQ * c->qset);
+    p.counter_zero = c->d_counter + 16 * (1 + AESGCM_NQ * (c->qset ^ 1u));
+    if ((rc = launch_body(c, mode, p, wgs, st))) return rc;
     // items 4s + v: phases 64 blocks apart inside a super-chunk, super-chunks 256 T blocks apart
     return enqueue_fold(c, c->parts, p.C, 4, 64, (u64)256 * b.T, st, po);
+}
+// A whole range -- AAD, data from any first block, ragged end -- as ONE k_body launch of cyclic rows (plan_body_cyc) and the k_fold level over its
+// 4096 items, when the range is of that size (*took says whether it was).  po describes the items and the partial last row for k_combine.
+static bool cyc_capable(const aesgcm_ctx *c) {
+#if AESGCM_T4
+    return (u32)c->G / 2 * (AESGCM_BODY_WG / 64) == BODY_CYC_WAVES && c->cyc_max_pieces > c->cyc_min;
+#else
+    return false;
+#endif
+}
+static int enqueue_cyc(aesgcm_ctx *c, int mode, const uint8_t iv[12], const void *d_aad, u64 aad_len, const void *d_in, u64 len, void *d_out,
+                       u64 first_block, hipStream_t st, Partials *po, bool *took) {
+    *took = false;
+    if (!cyc_capable(c) || len < c->cyc_min) return AESGCM_OK;
+    if (((uintptr_t)d_in & 15) || ((uintptr_t)d_out & 15)) return AESGCM_OK;     // the caller's other path reports the alignment
+    int rc = grow_parts(c, (size_t)BODY_CYC_WAVES + 1);
+    if (rc) return rc;
+    BodyParams p;
+    // a range with pieces around its body (AAD, an odd first block, a ragged end) costs the other paths a launch pair per piece (+45 .. 80 us,
+    // profiles/r03c/general_shape.txt): for those the cyclic launch stays ahead for longer
+    const bool pieces = aad_len || (first_block & 255) || (len & 1023);
+    if (!plan_body_cyc(p, mode, iv, d_aad, aad_len, d_in, len, d_out, first_block, c->parts, c->cyc_min, pieces ? c->cyc_max_pieces : c->cyc_max)) return AESGCM_OK;
+    *took = true;
+    *po = Partials();
+    p.ej0 = c->d_tag + 3; po->ej0 = p.ej0;
+    if ((rc = launch_body(c, mode, p, BODY_CYC_WAVES / (AESGCM_BODY_WG / 64), st))) return rc;
+    if ((rc = enqueue_fold(c, c->parts, BODY_CYC_WAVES, 1, 64, 0, st, po))) return rc;       // always BODY_CYC_WAVES items, 64 blocks apart
+    if (p.tb) { po->tail_item = c->parts + (size_t)BODY_CYC_WAVES * 64; po->tail_blocks = p.tb; }
+    return AESGCM_OK;
 }
 
 // Y' = Y * H^nb ^ P(aad, data) for a whole range, Y in *state (device).  Large ranges go head / k_body / tail,
@@ -1370,6 +1403,15 @@ static int absorb_range(aesgcm_ctx *c, int mode, const uint8_t iv[12], const voi
     BodySplit b;
     Partials pp;
     int rc;
+    {   // mid-size ranges: the whole range in one k_body launch of cyclic rows
+        bool took;
+        if ((rc = enqueue_cyc(c, mode, iv, d_aad, aad_len, d_in, len, d_out, first_block, st, &pp, &took))) return rc;
+        if (took) {
+            if (ej0) *ej0 = pp.ej0;
+            const u64 nb = (aad_len + 15) / 16 + (len + 15) / 16;
+            return enqueue_combine(c, combine_with_items(plan_combine_carry(pp.ptr, pp.np, pp.kind, state, nb), pp.eA, pp.tail_item, pp.tail_blocks), st);
+        }
+    }
     if (!ctx_body_split(c, len, first_block, &b)) {
         if ((rc = enqueue_main(c, mode, iv, d_aad, aad_len, d_in, len, d_out, first_block, st, &pp))) return rc;
         const u64 nb = (aad_len + 15) / 16 + (len + 15) / 16;
@@ -1427,6 +1469,16 @@ static int crypt_dev(aesgcm_ctx *c, int dec, const uint8_t iv[12], const void *d
     if (aad_len && !d_aad) return AESGCM_EARG;
     if (len && (!d_in || !d_out)) return AESGCM_EARG;
     HIPCHK(hipSetDevice(c->device));
+    {   // mid-size messages: k_body as cyclic rows takes AAD, data and the ragged end in one launch; its items go straight to the tag
+        Partials pc;
+        bool took;
+        if ((rc = enqueue_cyc(c, dec ? MODE_DEC : MODE_ENC, iv, d_aad, aad_len, d_in, len, d_out, 0, st, &pc, &took))) return rc;
+        if (took) {
+            CombineParams q = combine_with_items(plan_combine_tag(pc.ptr, pc.np, pc.kind, iv, aad_len, len, c->d_tag), pc.eA, pc.tail_item, pc.tail_blocks);
+            q.ej0 = pc.ej0;
+            return enqueue_combine(c, q, st);
+        }
+    }
     BodySplit b;
     if (ctx_body_split(c, len, 0, &b)) {
         if (!aad_len && !b.head_blocks && len == 16 * b.body_blocks) {
@@ -1549,11 +1601,11 @@ static int ctx_create_common(aesgcm_ctx **out, int device, const uint8_t *key, s
     int per_cu = 2;
     if (const char *e = getenv("AESGCM_WGS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 2) per_cu = v; }
     if (const char *e = getenv("AESGCM_TW")) c->tw_override = (u32)strtoul(e, nullptr, 0);
-    if (const char *e = getenv("AESGCM_BODY_MIN")) { c->body_min = strtoull(e, nullptr, 0); if (c->body_min >= (1ull << 60)) c->cyc_max = 0; }   // "never k_body" means it
+    if (const char *e = getenv("AESGCM_BODY_MIN")) { c->body_min = strtoull(e, nullptr, 0); if (c->body_min >= (1ull << 60)) c->cyc_max = c->cyc_max_pieces = 0; }   // "never k_body" means it
     if (const char *e = getenv("AESGCM_BODY_CYC")) {
         char *end = nullptr;
         const u64 lo = strtoull(e, &end, 0);
-        if (end && *end == ':') { c->cyc_min = lo; c->cyc_max = strtoull(end + 1, nullptr, 0); }
+        if (end && *end == ':') { c->cyc_min = lo; c->cyc_max = c->cyc_max_pieces = strtoull(end + 1, nullptr, 0); }
     }
     int G = per_cu * ds->n_cu;
     if (G > AESGCM_GMAX) G = AESGCM_GMAX;
@@ -1679,6 +1731,15 @@ int aesgcm_ctx_body_geometry(const aesgcm_ctx *c, int *n_wg, int *wg_lanes, int 
 
 int aesgcm_ctx_split(const aesgcm_ctx *c, size_t len, uint64_t first_block, uint64_t *head_blocks, uint64_t *body_blocks) {
     if (!c) return AESGCM_EARG;
+    if (cyc_capable(c)) {                                                  // cyclic rows: the body is every whole row behind the head
+        const u64 nfull = len / 16, head = (256 - (first_block & 255)) & 255;
+        const u64 R = nfull > head ? (nfull - head) / 64 : 0;
+        if (R && R * 1024 >= c->cyc_min && R * 1024 < (((first_block & 255) || (len & 1023)) ? c->cyc_max_pieces : c->cyc_max)) {
+            if (head_blocks) *head_blocks = head;
+            if (body_blocks) *body_blocks = 64 * R;
+            return AESGCM_OK;
+        }
+    }
     BodySplit b;
     const bool split = ctx_body_split(c, len, first_block, &b);
     if (head_blocks) *head_blocks = split ? b.head_blocks : 0;
@@ -1863,6 +1924,12 @@ int aesgcm_shard_crypt_dev(aesgcm_ctx *c, int decrypt, const uint8_t iv[12], con
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = pick_stream(c, stream);
     const u64 after = total_blocks - (first_block + my_blocks);            // blocks of the message behind this shard
+    {   // mid-size shards: one k_body launch of cyclic rows, its items straight to the weighted partial W = P H^after
+        Partials pc;
+        bool took;
+        if ((rc = enqueue_cyc(c, decrypt ? MODE_DEC : MODE_ENC, iv, d_aad, aad_len, d_in, len, d_out, first_block, st, &pc, &took))) return rc;
+        if (took) return enqueue_combine(c, combine_with_items(plan_combine_poly(pc.ptr, pc.np, pc.kind, after, (uint4 *)d_partial), pc.eA, pc.tail_item, pc.tail_blocks), st);
+    }
     BodySplit b;
     if (ctx_body_split(c, len, first_block, &b)) {
         if (!aad_len && !b.head_blocks && len == 16 * b.body_blocks) {

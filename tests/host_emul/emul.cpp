@@ -77,15 +77,12 @@ static void emu_body_nr(const KeyMaterial *km, const BodyParams &p) {
     for (u32 tid = 0; tid < AESGCM_MAIN_WG; tid++) fill_lds_t4(smem, &g_tb, tid, AESGCM_MAIN_WG);     // second table region (T1 | T3)
 #endif
     if (p.cyc) {                                                        // cyclic rows: one strand and one item per wave (k_body<.., true>)
-        std::vector<char> seen(BODY_CYC_WAVES, 0);
         for (u32 k = 0; k < BODY_CYC_WAVES; k++) {
             const u32 w = (k * 2741u + 17u) % BODY_CYC_WAVES;           // scrambled order (2741 is odd: a permutation)
-            const u32 item = body_cyc_item(p.Q, w);
-            CHECK(item < BODY_CYC_WAVES && !seen[item], "cyclic item %u of wave %u taken twice", item, w);
-            seen[item] = 1;
             for (u32 lane = 0; lane < 64; lane++) {
                 const CtrConsts cc = ctr_round1_consts(p.iv0, p.iv1, p.iv2, km->rk, smem, (lane & 31u) << 2);
-                p.parts[(size_t)item * 64 + lane] = body_cyc_lane<NR, MODE>(km, &g_tb, p, smem, cc, w, lane);
+                p.parts[(size_t)w * 64 + lane] = body_cyc_lane<NR, MODE>(km, &g_tb, p, smem, cc, w, lane);
+                if (w == 0 && p.tb) p.parts[(size_t)BODY_CYC_WAVES * 64 + lane] = body_cyc_last_lane<NR, MODE>(km, p, smem, cc, lane);
             }
         }
         return;
@@ -123,7 +120,8 @@ static void emu_combine(const KeyMaterial *km, const CombineParams &p0) {
         *reinterpret_cast<uint4 *>(smem + CMB_LDS_STAGE2 + w * 1024u + lane * 16u) = combine_fold_staged(smem, CMB_LDS_STAGE1, J1, w, CMB_LDS_TABB, lane);
     G128 acc = {{0, 0, 0, 0}};
     if (items) {
-        for (u32 lane = 0; lane < 64; lane++) xor_g(acc, shoup2_gmul(mo_to_be(combine_fold_staged(smem, CMB_LDS_STAGE2, J2, 0, CMB_LDS_TABC, lane)), km->ltab[(tag ? 65u : 63u) - lane]));
+        for (u32 lane = 0; lane < 64; lane++) xor_g(acc, shoup2_gmul(mo_to_be(combine_fold_staged(smem, CMB_LDS_STAGE2, J2, 0, CMB_LDS_TABC, lane)), km->ltab[(tag ? 65u : 63u) - lane + (p.tail_item ? p.tail_blocks : 0u)]));
+        if (p.tail_item) for (u32 lane = 0; lane < 64; lane++) xor_g(acc, shoup2_gmul(mo_to_be(p.tail_item[lane]), km->ltab[(tag ? 65u : 63u) - lane]));
     } else if (p.kind == PARTS_GATHERED) {
         for (u32 tid = 0; tid < p.np; tid++) {
             G128 z = mo_to_be(p.parts[(size_t)tid * (p.stride ? p.stride : 1u)]);
@@ -146,10 +144,11 @@ static void emu_combine(const KeyMaterial *km, const CombineParams &p0) {
     *p.out = be_to_mo(acc);
 }
 
-struct Parts { const uint4 *ptr; u32 np; u32 gathered; u64 eA; };   // gathered = PARTS_* kind; eA: item spacing when k_combine folds the items itself
+struct Parts { const uint4 *ptr; u32 np; u32 gathered; u64 eA; const uint4 *tail_item = nullptr; u32 tail_blocks = 0; };   // gathered = PARTS_* kind; eA: item spacing when k_combine folds the items itself
 struct Emu {
     KeyMaterial km; u32 tw; std::vector<uint4> parts, fold_a, fold_b;
-    bool cyc = false;               // bodies as cyclic rows (every size) instead of dealt chunks
+    u32 n_cyc = 0;                  // launches that went through run_cyc()
+    bool cyc = false; u64 cyc_min = 1024;   // ranges with at least one whole body row as cyclic rows of k_body (every size) instead of the pieces
     Emu(const uint8_t *key, int key_len, u32 tw_) : tw(tw_), parts(1 << 16), fold_a(1 << 16), fold_b(1 << 12) { emu_setup(&km, key, key_len, 0, 512); }
     // mirrors enqueue_fold(): k_fold launches until one item is left
     Parts fold(const uint4 *items, u32 n, u32 period, u64 eA, u64 eB) {
@@ -203,17 +202,35 @@ struct Emu {
     // mirrors enqueue_body(): k_body + k_fold with the interleaved first level
     Parts run_body(int mode, const uint8_t *iv, const BodySplit &b, const void *in, void *out, u64 first_block) {
         BodyParams p; memset(&p, 0, sizeof p);
-        const size_t need = b.cyc ? (size_t)64 * BODY_CYC_WAVES : 256 * (size_t)b.S;
-        if (parts.size() < need) parts.resize(need);
+        if (parts.size() < 256 * (size_t)b.S) parts.resize(256 * (size_t)b.S);
         plan_body(p, b, iv, in, out, first_block, parts.data());
         emu_body(mode, &km, p);
-        if (b.cyc) return fold(parts.data(), BODY_CYC_WAVES, 1, 64, 0);
         return fold(parts.data(), p.C, 4, 64, (u64)256 * b.T);
+    }
+    // mirrors enqueue_cyc(): the whole range as cyclic rows of k_body + one k_fold level; false = the range is not of that size
+    bool run_cyc(int mode, const uint8_t *iv, const void *aad, u64 aad_len, const void *in, u64 len, void *out, u64 first_block, Parts *po) {
+        if (!cyc) return false;
+        if (parts.size() < (size_t)64 * (BODY_CYC_WAVES + 1)) parts.resize((size_t)64 * (BODY_CYC_WAVES + 1));
+        BodyParams p;
+        if (!plan_body_cyc(p, mode, iv, aad, aad_len, in, len, out, first_block, parts.data(), cyc_min, ~0ull)) return false;
+        emu_body(mode, &km, p);
+        ++n_cyc;
+        *po = fold(parts.data(), BODY_CYC_WAVES, 1, 64, 0);
+        if (p.tb) { po->tail_item = parts.data() + (size_t)BODY_CYC_WAVES * 64; po->tail_blocks = p.tb; }
+        return true;
     }
     // mirrors absorb_range()
     bool absorb(int mode, const uint8_t *iv, const uint8_t *aad, u64 aad_len, const uint8_t *in, u64 len, uint8_t *out, u64 first_block, u64 body_min, uint4 *Y) {
         BodySplit b;
-        if (!plan_body_split(len, first_block, tw, body_min, &b, cyc ? 0 : ~0ull, cyc ? ~0ull : 0)) {
+        {   // mirrors absorb_range(): cyclic rows first
+            Parts pc = {nullptr, 0, PARTS_NONE, 0};
+            if (run_cyc(mode, iv, aad, aad_len, in, len, out, first_block, &pc)) {
+                const u64 nb = (aad_len + 15) / 16 + (len + 15) / 16;
+                emu_combine(&km, combine_with_items(plan_combine_carry(pc.ptr, pc.np, pc.gathered, Y, nb), pc.eA, pc.tail_item, pc.tail_blocks));
+                return true;
+            }
+        }
+        if (!plan_body_split(len, first_block, tw, body_min, &b)) {
             Parts pp = run(mode, iv, aad, aad_len, in, len, out, first_block);
             const u64 nb = (aad_len + 15) / 16 + (len + 15) / 16;
             if (nb) emu_combine(&km, combine_with_items(plan_combine_carry(pp.ptr, pp.np, pp.gathered, Y, nb), pp.eA));
@@ -236,8 +253,16 @@ struct Emu {
     // mirrors crypt_dev() for a message that takes the split; returns whether the split applied
     bool crypt_split(int dec, const uint8_t iv[12], const uint8_t *aad, u64 aad_len, const uint8_t *in, u64 len, uint8_t *out, uint8_t tag[16], u64 body_min) {
         uint4 Y = make_uint4(0, 0, 0, 0), t;
+        {   // mirrors crypt_dev(): cyclic rows first, items straight to the tag
+            Parts pc = {nullptr, 0, PARTS_NONE, 0};
+            if (run_cyc(dec ? MODE_DEC : MODE_ENC, iv, aad, aad_len, in, len, out, 0, &pc)) {
+                emu_combine(&km, combine_with_items(plan_combine_tag(pc.ptr, pc.np, pc.gathered, iv, aad_len, len, &t), pc.eA, pc.tail_item, pc.tail_blocks));
+                memcpy(tag, &t, 16);
+                return true;
+            }
+        }
         BodySplit b0;
-        if (plan_body_split(len, 0, tw, body_min, &b0, cyc ? 0 : ~0ull, cyc ? ~0ull : 0) && !aad_len && !b0.head_blocks && len == 16 * b0.body_blocks) {
+        if (plan_body_split(len, 0, tw, body_min, &b0) && !aad_len && !b0.head_blocks && len == 16 * b0.body_blocks) {
             // the whole message is one aligned body: k_body's items go straight to the tag (no chaining value)
             Parts pb = run_body(dec ? MODE_DEC : MODE_ENC, iv, b0, in, out, 0);
             emu_combine(&km, combine_with_items(plan_combine_tag(pb.ptr, pb.np, pb.gathered, iv, 0, len, &t), pb.eA));
@@ -580,6 +605,7 @@ static void test_body(int key_len, u32 G, u64 al, u64 n, u64 seed, bool cyc = fa
     E.cyc = cyc;
     const bool split = E.crypt_split(0, iv.data(), aad.data(), al, pt.p, n, ct.p, tag, 4096);
     CHECK(split, "body split did not apply: len %llu G %u", (unsigned long long)n, G);
+    CHECK(!cyc || E.n_cyc == 1, "cyclic rows did not take the message: len %llu", (unsigned long long)n);
     CHECK(memcmp(ct.p, ref.p, n) == 0, "body ct key %d G %u aad %llu len %llu", key_len, G, (unsigned long long)al, (unsigned long long)n);
     CHECK(memcmp(tag, rtag, 16) == 0, "body tag key %d G %u aad %llu len %llu", key_len, G, (unsigned long long)al, (unsigned long long)n);
     CHECK(ct.p[n] == 0xA5, "body overrun");
@@ -688,8 +714,11 @@ int main(int argc, char **argv) {
     test_body(32, 1, 16, 16 * 254 + 16 * 1024 * 2, 104);          // head = 254 blocks exactly, empty tail
     test_body(16, 2, 0, 16 * 256 * 2 * 6, 106);                     // no AAD, no head, no tail: the whole message is one body (direct tag path)
     test_body(32, 1, 0, 16 * 256 * 300, 107);                       // ... with enough items for a k_fold level before k_combine's own fold
-    test_body(16, 1, 0, 16 * 256 * 7, 108, true);                   // cyclic rows: 7 super-rows, the other strands leave zero items; the whole message is the body
-    test_body(32, 2, 21, 16 * (100 + 256 * 40 + 70) + 3, 109, true); // ... with AAD, head and tail, and as shards from odd first blocks
+    test_body(16, 1, 0, 16 * 256 * 7, 108, true);                   // cyclic rows: 28 rows, the other strands leave zero items; the whole message is the body
+    test_body(32, 2, 21, 16 * (100 + 256 * 40 + 70) + 3, 109, true); // ... with AAD (a front row), a ragged partial last row, and as shards from odd first blocks (head blocks in the front rows)
+    test_body(24, 1, 16 * 70 + 3, 16 * 64 * 9 + 1023, 112, true);   // two front rows of AAD, the longest last row there is (63 blocks + 15 bytes = 64 blocks)
+    test_body(16, 1, 16 * 64, 16 * 64 * 5 + 16, 113, true);         // AAD fills its row exactly (no front padding), one whole block behind the body
+    test_body(32, 1, 1, 16 * 64 * 3 + 1, 114, true);                 // one byte of AAD, one byte behind the body
     test_batch_pieces();
     test_packets(16, 61); test_packets(24, 62); test_packets(32, 63);
     if (level > 1) {
@@ -697,8 +726,9 @@ int main(int argc, char **argv) {
         test_key(16, 0, 8, {{0, 16 * W * 600}});              // production rule, > GMAX chunks of Tw = 16
         test_key(24, 1, 10, {{5, 16 * 64 * 4200 + 3}});        // 4200 one-row chunks: three k_fold levels
         test_body(32, 1, 9, 16 * (200 + 256 * 1100) + 7, 105);  // 4400 body items: interleaved first level + two more
-        test_body(24, 1, 0, 16 * 256 * 1024, 110, true);       // cyclic rows: every strand one super-row (4 MiB)
-        test_body(32, 1, 5, 16 * (31 + 256 * 1333 + 200) + 9, 111, true);   // 1333 super-rows: strands of two and of one, items rotated by 309 slots
+        test_body(24, 1, 0, 16 * 64 * 4096, 110, true);        // cyclic rows: every strand exactly one row (4 MiB)
+        test_body(32, 1, 5, 16 * (31 + 64 * 5333 + 50) + 9, 111, true);     // 5333 body rows + a front row: strands of two and of one, residues rotated
+        test_body(16, 1, 16 * 64 * 3 + 7, 16 * 64 * 4200, 115, true);       // four front rows, the first strands start with them and go on with body rows
     }
     printf(g_fail ? "EMUL FAILED (%d)\n" : "EMUL OK\n", g_fail);
     return g_fail ? 1 : 0;

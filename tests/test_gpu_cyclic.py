@@ -1,0 +1,102 @@
+"""GPU: k_body as cyclic rows at its production sizes (4 .. 384 MiB): ONE launch takes the AAD (front rows of the row grid), data that starts at
+any block (shards: head blocks in the front rows), the whole rows of the body and the partial last row -- against the oracle on the same inputs,
+bit for bit, through the C ABI; encrypt, decrypt, in place, shards from odd first blocks, streaming chunks, and the ranges the layout refuses
+(more AAD than one front row per strand) which must fall back to the other paths with the same result."""
+import pytest
+
+from util import splitmix_bytes
+
+pytestmark = pytest.mark.gpu
+MiB = 1 << 20
+
+
+def _check(hip, f, ctx, iv, n, al, seed, aad_off=0):
+    aad = splitmix_bytes(seed, al)
+    d_in = hip.DeviceBuffer(n + 64); d_in.fill_splitmix64(seed + 1, 0, nbytes=n)
+    d_out = hip.DeviceBuffer(n + 64)
+    d_aad = hip.DeviceBuffer(al + 64)
+    if al:
+        d_aad.upload(bytes(aad_off) + aad)
+    pt = bytes(d_in.download(n))
+    want_ct, want_tag = f.encrypt(iv, aad, pt)
+    tag = ctx.encrypt_dev(iv, d_in.ptr, n, d_out.ptr, d_aad=d_aad.ptr + aad_off if al else None, aad_len=al)
+    assert tag == want_tag, ("enc tag", n, al)
+    assert bytes(d_out.download(n)) == want_ct, ("enc ct", n, al)
+    # decrypt in place, expected tag checked by the library
+    tag2 = ctx.decrypt_dev(iv, d_out.ptr, n, d_out.ptr, d_aad=d_aad.ptr + aad_off if al else None, aad_len=al, tag=want_tag)
+    assert tag2 == want_tag, ("dec tag", n, al)
+    assert bytes(d_out.download(n)) == pt, ("dec pt", n, al)
+
+
+@pytest.mark.parametrize("klen", [16, 24, 32])
+def test_whole_messages_of_any_shape_take_the_cyclic_launch(hip, orc, klen):
+    key, iv = splitmix_bytes(9100 + klen, klen), splitmix_bytes(9101, 12)
+    ctx, f = hip.Context(key), orc.Fast(key)
+    shapes = [(4 * MiB, 0), (4 * MiB + 5, 20), (5 * MiB - 3, 1000), (6 * MiB + 1023, 16 * 64), (7 * MiB + 16, 1), (9 * MiB + 1008, 16 * 64 * 3 + 7)]
+    if klen == 32:
+        shapes += [(16 * MiB + 1, 13), (33 * MiB - 17, 68), (64 * MiB + 4096 + 15, 4095)]
+    for k, (n, al) in enumerate(shapes):
+        head, body = ctx.split(n)
+        assert head == 0 and body == (n // 1024) * 64, (n, head, body)           # every whole row is body: the cyclic launch took it
+        _check(hip, f, ctx, iv, n, al, 9200 + 10 * k, aad_off=(k % 3) * 4)      # AAD pointer 16-, 4- and 8-byte aligned
+
+
+def test_aad_longer_than_the_front_rows_falls_back(hip, orc):
+    """more than 4096 front rows (4 MiB of AAD) do not fit one per strand: the range goes the other way, with the same tag"""
+    key, iv = splitmix_bytes(9300, 32), splitmix_bytes(9301, 12)
+    ctx, f = hip.Context(key), orc.Fast(key)
+    _check(hip, f, ctx, iv, 4 * MiB + 100, 4 * MiB + 4096 + 9, 9310)
+    _check(hip, f, ctx, iv, 4 * MiB + 100, 4 * MiB - 64, 9320)                # 4095.9 front rows: still the cyclic launch
+
+
+def test_shards_and_streaming_chunks_from_odd_first_blocks(hip, orc):
+    key, iv = splitmix_bytes(9400, 32), splitmix_bytes(9401, 12)
+    ctx, f = hip.Context(key), orc.Fast(key)
+    n, al, ranks = 23 * MiB + 11, 33, 3
+    aad, pt = splitmix_bytes(9402, al), splitmix_bytes(9403, n)
+    want_ct, want_tag = f.encrypt(iv, aad, pt)
+    din, dout = hip.DeviceBuffer(n + 16), hip.DeviceBuffer(n + 16)
+    din.upload(pt)
+    d_aad = hip.DeviceBuffer(al); d_aad.upload(aad)
+    parts = hip.DeviceBuffer(16 * ranks)
+    total_blocks, first = (n + 15) // 16, 0
+    for r in range(ranks):
+        blocks = total_blocks // ranks + (1 if r < total_blocks % ranks else 0) + (7 if r == 0 else -7 if r == 1 else 0)     # odd cuts
+        end = first + blocks
+        ln = (n if end == total_blocks else 16 * end) - 16 * first
+        sh, sb = ctx.split(ln, first)
+        assert sb > 0 and sh == (-first) % 256, (first, sh, sb)
+        ctx.shard_crypt_dev(False, iv, din.ptr + 16 * first, ln, dout.ptr + 16 * first, first, n, parts.ptr + 16 * r,
+                            d_aad=d_aad.ptr if r == 0 else None, aad_len=al if r == 0 else 0)
+        first = end
+    assert ctx.shard_finalize_dev(iv, parts.ptr, ranks, al, n) == want_tag
+    assert bytes(dout.download(n)) == want_ct
+    # streaming: AAD, then data in chunks of 5 MiB + 48 (every chunk a cyclic launch with a carried state), decrypt direction too
+    for dec in (False, True):
+        src = want_ct if dec else pt
+        ctx.stream_begin(iv, decrypt=dec)
+        ctx.stream_aad(aad)
+        out, step = [], 5 * MiB + 48
+        for off in range(0, n, step):
+            out.append(ctx.stream_update(src[off:off + step]))
+        assert ctx.stream_final() == want_tag, dec
+        assert b"".join(out) == (pt if dec else want_ct), dec
+
+
+def test_back_to_back_messages_do_not_see_each_other(hip, orc):
+    """the 4097 item slots are reused by every launch: alternate two messages of different shapes many times"""
+    key = splitmix_bytes(9500, 16)
+    ctx, f = hip.Context(key), orc.Fast(key)
+    cases = []
+    for k, (n, al) in enumerate(((4 * MiB + 77, 5), (6 * MiB, 0))):
+        iv = splitmix_bytes(9501 + k, 12)
+        aad = splitmix_bytes(9510 + k, al)
+        d_in = hip.DeviceBuffer(n + 16); d_in.fill_splitmix64(9520 + k, 0, nbytes=n)
+        d_aad = hip.DeviceBuffer(al + 16); d_aad.upload(aad)
+        want = f.encrypt(iv, aad, bytes(d_in.download(n)))
+        cases.append((iv, n, al, d_in, d_aad, want))
+    d_out = hip.DeviceBuffer(6 * MiB + 64)
+    for it in range(60):
+        iv, n, al, d_in, d_aad, want = cases[it & 1]
+        assert ctx.encrypt_dev(iv, d_in.ptr, n, d_out.ptr, d_aad=d_aad.ptr if al else None, aad_len=al) == want[1], it
+    assert bytes(d_out.download(cases[1][1])) == cases[1][5][0]
