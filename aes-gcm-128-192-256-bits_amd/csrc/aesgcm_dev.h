@@ -455,12 +455,15 @@ enum { MODE_ENC = 0, MODE_DEC = 1, MODE_KS = 2, MODE_ECB = 3, MODE_PROBE = 4 }; 
 // lane L's value times H^(65-L) (or H^(63-L) for a shard partial) -- 64 different constants at once; with these tables a
 // lane's multiply is 32 independent 16-byte loads (indices = the nibbles of ITS value, all known up front) and a 16-step
 // shift-and-xor chain, instead of building a table per launch or running 128 bit-serial steps.
-HD void setup_ltab_lane(KeyMaterial *km, u32 e, u32 tid) {
-    if (tid >= 32 || e >= AESGCM_NLTAB) return;
-    const G128 c = mo_to_be(km->pw[0][e]);
+// entry tid (0 .. 31) of the two-table Shoup form of the constant c: [v] = v*c, [16 + v] = v*c*x^4
+HD uint4 shoup2_entry(G128 c, u32 tid) {
     G128 t = shoup_entry(c, tid & 15u);
     if (tid >= 16) t = gf_mulx4(t);
-    km->ltab[e][tid] = make_uint4(t.w[0], t.w[1], t.w[2], t.w[3]);
+    return make_uint4(t.w[0], t.w[1], t.w[2], t.w[3]);
+}
+HD void setup_ltab_lane(KeyMaterial *km, u32 e, u32 tid) {
+    if (tid >= 32 || e >= AESGCM_NLTAB) return;
+    km->ltab[e][tid] = shoup2_entry(mo_to_be(km->pw[0][e]), tid);
 }
 // y * H^e through km->ltab[e] (device / host memory, not LDS)
 HD G128 shoup2_gmul(G128 y, const uint4 *__restrict__ tab) {
@@ -478,6 +481,30 @@ HD G128 shoup2_gmul(G128 y, const uint4 *__restrict__ tab) {
     for (int bi = 15; bi >= 0; bi--) {
         if (bi != 15) gf_shift8(z0, z1, z2, z3);
         z0 = xor3(z0, a[bi].x, c[bi].x); z1 = xor3(z1, a[bi].y, c[bi].y); z2 = xor3(z2, a[bi].z, c[bi].z); z3 = xor3(z3, a[bi].w, c[bi].w);
+    }
+    G128 z; z.w[0] = z0; z.w[1] = z1; z.w[2] = z2; z.w[3] = z3;
+    return z;
+}
+
+// the same multiply with the table loads in four batches of eight (32 registers of entries in flight instead of 128): for tables in LDS, where a
+// load costs nothing to wait for, inside kernels that have no registers to spare (k_body's fused closing)
+HD G128 shoup2_gmul_lds(G128 y, const uint4 *__restrict__ tab) {
+    u32 z0 = 0, z1 = 0, z2 = 0, z3 = 0;
+#pragma unroll
+    for (int q = 3; q >= 0; q--) {
+        uint4 a[4], c[4];
+        const u32 w = y.w[q];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const u32 byte = (w >> (8 * (3 - k))) & 0xFFu;
+            a[k] = tab[byte >> 4];
+            c[k] = tab[16u + (byte & 15u)];
+        }
+#pragma unroll
+        for (int k = 3; k >= 0; k--) {
+            if (!(q == 3 && k == 3)) gf_shift8(z0, z1, z2, z3);
+            z0 = xor3(z0, a[k].x, c[k].x); z1 = xor3(z1, a[k].y, c[k].y); z2 = xor3(z2, a[k].z, c[k].z); z3 = xor3(z3, a[k].w, c[k].w);
+        }
     }
     G128 z; z.w[0] = z0; z.w[1] = z1; z.w[2] = z2; z.w[3] = z3;
     return z;
@@ -916,6 +943,12 @@ struct BodyParams {
     u32 F, R;                    // rows in front of the body (AAD blocks and the data blocks up to the body, front-padded: `front`) and whole rows of the body
     u32 tb;                      // blocks of the last, partial row behind the body (`last`; 0 = none): its item goes to parts[BODY_CYC_WAVES]
     MainParams front, last;      // the two generic pieces as one-row chunks of main_chunk_lane
+    // fused closing (whole messages, body_cyc_* below): the launch folds its own items and leaves the tag -- no k_fold, no k_combine
+    u32 fuse;
+    u64 aad_len, ct_len;         // bytes, for the length block
+    unsigned long long *acc;     // CYC_ACC_SLOTS x {hi, lo} XOR accumulators and the arrival counter behind them (device memory, zero between launches)
+    uint4 *tag_out, *tag_host;   // where the tag goes (device slot, and the pinned host slot or NULL)
+    u64 gen;                     // generation number published behind the host copy (see CombineParams::gen)
 };
 struct BodyLane { u32 p0, p1, p2, p3; };
 // wave-uniform table values (host: plain loads; device: scalar loads from the global T0 table)
@@ -1097,6 +1130,38 @@ template <int NR, int MODE>
 HD uint4 body_cyc_last_lane(const KeyMaterial *__restrict__ km, const BodyParams &p, const unsigned char *smem, const CtrConsts &cc, u32 lane) {
     return main_chunk_lane<NR, MODE>(km, p.last, smem, cc, 0u, lane);
 }
+
+// Fused closing of a cyclic launch (BodyParams::fuse: whole messages).  Every workgroup folds its own sixteen items -- they are consecutive,
+// 64 blocks apart -- in a binary tree, four table multiplies deep, with the constants H^64, H^128, H^256, H^512 (the key's nibble tables ptab[0 .. 3],
+// staged where the T-tables were): level k leaves  y = x_even * H^(64 * 2^k) ^ x_odd.  Wave 0 then closes the workgroup's item G the way k_combine
+// closes a message -- lane L contributes G_L * H^(65 - L + tb) through the per-lane Shoup tables, tb = blocks of the partial last row -- and weights
+// the sum with H^(1024 (255 - g)), the blocks between the end of its items and the end of the grid (pw[1][255 - g], as a two-table Shoup form built
+// in LDS).  Workgroup 0 adds the terms that occur once: the partial last row (lane L: T_L * H^(65 - L)), the length block times H and E_K(J0).  The
+// workgroup's 16 bytes are XORed into one of CYC_ACC_SLOTS accumulators with memory-side atomics; the workgroup that finds all others arrived XORs
+// the slots together, zeroes them for the next launch and publishes the tag.  Nothing but atomics crosses workgroups, which is what the dispensers
+// already rely on (the XCDs' L2s are not coherent with each other for plain loads).
+#define CYC_ACC_SLOTS 16u
+#define CYC_LDS_TREE_TAB 0u                  /* four nibble tables of 8 KiB: H^64, H^128, H^256, H^512 */
+#define CYC_LDS_STAGE 32768u                 /* 16 + 8 + 4 + 2 items of 1 KiB: the levels of the tree */
+#define CYC_LDS_WTAB (CYC_LDS_STAGE + 30u * 1024u)   /* two-table Shoup form of the workgroup's weight (512 B) */
+#define CYC_LDS_LTAB (CYC_LDS_WTAB + 512u)       /* lane L's Shoup tables of H^(65 - L + tb): 64 x 32 entries, 528 bytes apart (the 16 spare bytes spread the lanes over the banks) */
+#define CYC_LDS_LTAB_STRIDE 528u
+#define CYC_LDS_LTAB0 (CYC_LDS_LTAB + 64u * CYC_LDS_LTAB_STRIDE)   /* workgroup 0, when there is a partial last row: the same for H^(65 - L) */
+#define CYC_LDS_END (CYC_LDS_LTAB0 + 64u * CYC_LDS_LTAB_STRIDE)
+HD u32 cyc_stage_off(u32 level) { return CYC_LDS_STAGE + (level == 0 ? 0u : level == 1 ? 16384u : level == 2 ? 24576u : 28672u); }   // where the inputs of tree level `level` sit
+// tree level `level` (0 .. 3), pair k: lane `lane`
+HD uint4 cyc_tree_lane(const unsigned char *smem, u32 level, u32 k, u32 lane) {
+    const u32 in = cyc_stage_off(level);
+    const uint4 xe = *reinterpret_cast<const uint4 *>(smem + in + (2u * k) * 1024u + lane * 16u);
+    const uint4 xo = *reinterpret_cast<const uint4 *>(smem + in + (2u * k + 1u) * 1024u + lane * 16u);
+    return xor4(ghash_mul_const_lds_at(xe, smem, CYC_LDS_TREE_TAB + level * 8192u), xo);
+}
+// lane L's term of a workgroup item (tb = blocks behind the grid) or of the partial last row (tb = 0)
+HD G128 cyc_lane_term(const KeyMaterial *__restrict__ km, uint4 item, u32 lane, u32 tb) { return shoup2_gmul(mo_to_be(item), km->ltab[65u - lane + tb]); }
+// ... of a workgroup item, from the copy of the lanes' tables that the workgroup staged in LDS (entry k of 2048: lane k >> 5, entry k & 31)
+HD uint4 cyc_ltab_entry(const KeyMaterial *__restrict__ km, u32 k, u32 tb) { return km->ltab[65u - (k >> 5) + tb][k & 31u]; }
+HD u32 cyc_ltab_off(u32 k, u32 base = CYC_LDS_LTAB) { return base + (k >> 5) * CYC_LDS_LTAB_STRIDE + (k & 31u) * 16u; }
+HD G128 cyc_lane_term_lds(const unsigned char *smem, uint4 item, u32 lane, u32 base = CYC_LDS_LTAB) { return shoup2_gmul_lds(mo_to_be(item), reinterpret_cast<const uint4 *>(smem + base + lane * CYC_LDS_LTAB_STRIDE)); }
 
 // ---- k_combine pieces --------------------------------------------------------------------------
 // One workgroup per message (or per shard / streaming step).  Round 2: the launch also folds up to 64 chunk items itself

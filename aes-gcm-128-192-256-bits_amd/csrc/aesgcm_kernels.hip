@@ -272,6 +272,95 @@ static_assert(AESGCM_LDS_AES_OFF % 128u == 0, "T-table replicas: lane l must rea
 static_assert(AESGCM_LDS_DRY_OFF >= AESGCM_Q5_GROUPS * 256u && AESGCM_LDS_DRY_OFF + 4u <= AESGCM_Q5_HI_ROW * 256u, "the dry-queue mask sits in the spare row between the table halves");
 static_assert((AESGCM_Q5_HI_ROW * 256u) % 512u != 0 && AESGCM_Q5_HI_ROW * 256u > 2040u, "the two halves of a five-bit table entry must not be fusable into one ds_read2[st64]_b64");
 static_assert(FOLD_B_ITEMS >= COMBINE_MAX_ITEMS && FOLD_A_ITEMS >= COMBINE_MAX_ITEMS, "k_fold ping-pong buffers");
+// host-visible tag without a full fence: the slot is pinned host memory (stores go out over the fabric, not into L2), so ordering the generation
+// number behind the tag takes a wait for the tag's stores, not a write-back of the XCD's L2 -- which in a launch that has just streamed the message
+// through that L2 would be megabytes on the critical path
+__device__ __forceinline__ void publish_host_lean(uint4 *slot, uint4 v, u64 gen) {
+    unsigned long long *q = reinterpret_cast<unsigned long long *>(slot);
+    __hip_atomic_store(q, (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(q + 1, (unsigned long long)v.z | ((unsigned long long)v.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(q + 2, (unsigned long long)gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// XOR of a value over the lanes of the wave (all lanes get the sum)
+__device__ __forceinline__ G128 wave_xor(G128 z) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        z.w[0] ^= __shfl_xor(z.w[0], off); z.w[1] ^= __shfl_xor(z.w[1], off);
+        z.w[2] ^= __shfl_xor(z.w[2], off); z.w[3] ^= __shfl_xor(z.w[3], off);
+    }
+    return z;
+}
+// the fused closing of a cyclic launch (lane pieces and the algebra: aesgcm_dev.h, "Fused closing"); acc = the wave's item, last / ej0 = wave 0's
+// partial last row and E_K(IV || 1)
+__device__ __forceinline__ void cyc_close(const KeyMaterial *__restrict__ km, const BodyParams &p, unsigned char *smem, uint4 acc, uint4 last, uint4 ej0) {
+    const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6, g = blockIdx.x;
+    // the tree's tables and the weight, requested before the barrier so that they travel while the workgroup's last waves finish their rows
+    const uint4 *pt = &km->ptab[0][0];
+    const uint4 t0 = pt[tid], t1 = pt[1024u + tid];
+    const uint4 l0 = cyc_ltab_entry(km, tid, p.tb), l1 = cyc_ltab_entry(km, 1024u + tid, p.tb);
+    const uint4 wc = km->pw[1][gridDim.x - 1u - g];                            // H^(1024 (255 - g)); the launch has 256 workgroups (enqueue_cyc)
+    const bool once = g == 0 && p.tb;                                         // workgroup 0 closes the partial last row as well: H^(65 - L)
+    uint4 m0 = make_uint4(0, 0, 0, 0), m1 = m0;
+    if (once) { m0 = cyc_ltab_entry(km, tid, 0u); m1 = cyc_ltab_entry(km, 1024u + tid, 0u); }
+    __syncthreads();                                                          // every wave is done with the T-tables
+    if (once) { *reinterpret_cast<uint4 *>(smem + cyc_ltab_off(tid, CYC_LDS_LTAB0)) = m0; *reinterpret_cast<uint4 *>(smem + cyc_ltab_off(1024u + tid, CYC_LDS_LTAB0)) = m1; }
+    reinterpret_cast<uint4 *>(smem + CYC_LDS_TREE_TAB)[tid] = t0;
+    reinterpret_cast<uint4 *>(smem + CYC_LDS_TREE_TAB)[1024u + tid] = t1;
+    *reinterpret_cast<uint4 *>(smem + cyc_ltab_off(tid)) = l0;
+    *reinterpret_cast<uint4 *>(smem + cyc_ltab_off(1024u + tid)) = l1;
+    *reinterpret_cast<uint4 *>(smem + cyc_stage_off(0) + wv * 1024u + lane * 16u) = acc;
+    __syncthreads();
+    uint4 y = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (u32 level = 0; level < 4; ++level) {
+        if (wv < (8u >> level)) {
+            y = cyc_tree_lane(smem, level, wv, lane);
+            if (level < 3) *reinterpret_cast<uint4 *>(smem + cyc_stage_off(level + 1) + wv * 1024u + lane * 16u) = y;
+        }
+        if (level < 3) __syncthreads();
+    }
+    if (wv != 0) return;
+    G128 z = wave_xor(cyc_lane_term_lds(smem, y, lane));
+    if (g + 1u != gridDim.x) {                                                // weight H^(1024 (255 - g)) through a two-table Shoup form in LDS
+        if (lane < 32) *reinterpret_cast<uint4 *>(smem + CYC_LDS_WTAB + 16u * lane) = shoup2_entry(mo_to_be(wc), lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        z = shoup2_gmul_lds(z, reinterpret_cast<const uint4 *>(smem + CYC_LDS_WTAB));
+    }
+    if (g == 0) {                                                             // the terms that occur once
+        G128 x; x.w[0] = x.w[1] = x.w[2] = x.w[3] = 0;
+        if (p.tb) x = cyc_lane_term_lds(smem, last, lane, CYC_LDS_LTAB0);
+        if (lane == 0) {
+            G128 L; const u64 la = p.aad_len * 8, lc = p.ct_len * 8;       // the length block times H (tag_len_term with the batched multiply: no registers to spare here)
+            L.w[0] = (u32)(la >> 32); L.w[1] = (u32)la; L.w[2] = (u32)(lc >> 32); L.w[3] = (u32)lc;
+            L = shoup2_gmul_lds(L, km->ltab[1]);
+            const G128 e = mo_to_be(ej0);
+            x.w[0] ^= L.w[0] ^ e.w[0]; x.w[1] ^= L.w[1] ^ e.w[1]; x.w[2] ^= L.w[2] ^ e.w[2]; x.w[3] ^= L.w[3] ^ e.w[3];
+        }
+        x = wave_xor(x);
+        z.w[0] ^= x.w[0]; z.w[1] ^= x.w[1]; z.w[2] ^= x.w[2]; z.w[3] ^= x.w[3];
+    }
+    if (lane != 0) return;
+    // memory-side atomics only: the XORs return before the arrival is counted (the increment depends on their results), so the workgroup that
+    // counts the last arrival finds every contribution in the slots
+    const u32 slot = g & (CYC_ACC_SLOTS - 1u);
+    const unsigned long long ohi = atomicXor(p.acc + 2u * slot, ((unsigned long long)z.w[0] << 32) | z.w[1]);
+    const unsigned long long olo = atomicXor(p.acc + 2u * slot + 1u, ((unsigned long long)z.w[2] << 32) | z.w[3]);
+    u32 dep;
+    asm volatile("v_and_b32 %0, 0, %1" : "=v"(dep) : "v"((u32)(ohi ^ olo) | (u32)((ohi ^ olo) >> 32)));
+    const unsigned long long arrived = atomicAdd(p.acc + 2u * CYC_ACC_SLOTS, 1ull + dep);
+    if (arrived + 1ull != gridDim.x) return;
+    unsigned long long hi = 0, lo = 0;
+#pragma unroll
+    for (u32 k = 0; k < CYC_ACC_SLOTS; ++k) { hi ^= atomicExch(p.acc + 2u * k, 0ull); lo ^= atomicExch(p.acc + 2u * k + 1u, 0ull); }
+    atomicExch(p.acc + 2u * CYC_ACC_SLOTS, 0ull);                             // zero between launches
+    G128 t; t.w[0] = (u32)(hi >> 32); t.w[1] = (u32)hi; t.w[2] = (u32)(lo >> 32); t.w[3] = (u32)lo;
+    *p.tag_out = be_to_mo(t);
+    if (p.tag_host) publish_host_lean(p.tag_host, be_to_mo(t), p.gen);
+}
+
 template <int NR, int MODE, bool CYC>
 __global__ __launch_bounds__(AESGCM_BODY_WG, AESGCM_BODY_WPS) void k_body(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const BodyParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -295,13 +384,13 @@ __global__ __launch_bounds__(AESGCM_BODY_WG, AESGCM_BODY_WPS) void k_body(const 
     if (CYC) {                                                                // cyclic rows: one strand and one item per wave, no dispenser
         const u32 w = __builtin_amdgcn_readfirstlane(blockIdx.x * (AESGCM_BODY_WG / 64) + (tid >> 6));
         const uint4 acc = body_cyc_lane<NR, MODE>(km, tb, p, smem, cc, w, lane);
-        p.parts[(size_t)w * 64 + lane] = acc;
+        uint4 last = make_uint4(0, 0, 0, 0), ej0 = make_uint4(0, 0, 0, 0);
         if (w == 0) {                                                         // a strand of the shorter kind: the partial last row and E_K(IV || 1)
-            if (p.tb) p.parts[(size_t)BODY_CYC_WAVES * 64 + lane] = body_cyc_last_lane<NR, MODE>(km, p, smem, cc, lane);
-            if (p.ej0) {
+            if (p.tb) last = body_cyc_last_lane<NR, MODE>(km, p, smem, cc, lane);
+            if (p.ej0 || p.fuse) {
                 u32 s0, s1, s2, s3;
                 ctr_rounds_lds<NR>(bswap32(1u), cc, s0, s1, s2, s3, km->rk, smem, (lane & 31u) << 2);
-                if (lane == 0) *p.ej0 = make_uint4(s0, s1, s2, s3);
+                ej0 = make_uint4(s0, s1, s2, s3);
             }
         }
         if (p.trace && lane == 0) {
@@ -309,6 +398,15 @@ __global__ __launch_bounds__(AESGCM_BODY_WG, AESGCM_BODY_WPS) void k_body(const 
             atomicMax((unsigned long long *)&tr[1], (unsigned long long)wall_clock64());
             atomicAdd((unsigned long long *)&tr[3], (unsigned long long)((p.F + p.R) / BODY_CYC_WAVES) | ((unsigned long long)((clock64() - cyc0) >> 10) << 32));
         }
+        if (!p.fuse) {                                                        // items for k_fold / k_combine
+            p.parts[(size_t)w * 64 + lane] = acc;
+            if (w == 0) {
+                if (p.tb) p.parts[(size_t)BODY_CYC_WAVES * 64 + lane] = last;
+                if (p.ej0 && lane == 0) *p.ej0 = ej0;
+            }
+            return;
+        }
+        cyc_close(km, p, smem, acc, last, ej0);
         return;
     }
     if (blockIdx.x == 0 && tid < AESGCM_NQ) p.counter_zero[16 * tid] = 0;    // the next dynamic launch's queues
@@ -1109,6 +1207,8 @@ struct aesgcm_ctx {
     u64 body_min = (u64)256 << 20;     // ranges with an aligned middle of at least this many bytes go through k_body (AESGCM_BODY_MIN).  Since k_main
                                        // got cheaper below 256 MiB (dispensers, k_fold: profiles/r02f/split_threshold.txt) the cut pays from 256 MiB:
                                        // 128 MiB -16 %, 256 MiB +0.8 %, 512 MiB +4 %, 1 GiB +11 %, 2 GiB +7 %; it was 128 MiB before, 0.7 GiB in round 1
+    unsigned long long *d_cyc = nullptr;   // the accumulators and the arrival counter of the fused closing of a cyclic launch (zero between launches)
+    bool cyc_fuse = true;              // whole messages: the cyclic launch closes the tag itself (AESGCM_CYC_FUSE=0: k_fold + k_combine behind it)
     u64 cyc_max_pieces = (u64)640 << 20;   // ... for ranges with AAD, an odd first block or a ragged end
     u64 cyc_min = (u64)4 << 20, cyc_max = (u64)384 << 20;   // ranges whose whole rows are [cyc_min, cyc_max) bytes go through k_body as cyclic rows (body_cyc_lane): no dispenser, 4096 items
                                        // whatever the size.  AESGCM_BODY_CYC=min:max (bytes; 0:0 = never); needs one k_body workgroup per CU on 256 CUs.  Measured against
@@ -1376,7 +1476,7 @@ static bool cyc_capable(const aesgcm_ctx *c) {
 #endif
 }
 static int enqueue_cyc(aesgcm_ctx *c, int mode, const uint8_t iv[12], const void *d_aad, u64 aad_len, const void *d_in, u64 len, void *d_out,
-                       u64 first_block, hipStream_t st, Partials *po, bool *took) {
+                       u64 first_block, hipStream_t st, Partials *po, bool *took, bool whole_message_tag = false) {
     *took = false;
     if (!cyc_capable(c) || len < c->cyc_min) return AESGCM_OK;
     if (((uintptr_t)d_in & 15) || ((uintptr_t)d_out & 15)) return AESGCM_OK;     // the caller's other path reports the alignment
@@ -1389,6 +1489,12 @@ static int enqueue_cyc(aesgcm_ctx *c, int mode, const uint8_t iv[12], const void
     if (!plan_body_cyc(p, mode, iv, d_aad, aad_len, d_in, len, d_out, first_block, c->parts, c->cyc_min, pieces ? c->cyc_max_pieces : c->cyc_max)) return AESGCM_OK;
     *took = true;
     *po = Partials();
+    if (whole_message_tag && c->cyc_fuse) {                                     // the launch closes the tag itself (cyc_close): nothing behind it
+        p.fuse = 1; p.aad_len = aad_len; p.ct_len = len; p.acc = c->d_cyc;
+        p.tag_out = c->d_tag; p.tag_host = c->h_tag_dev; p.gen = ++c->tag_gen;
+        po->done = true;
+        return launch_body(c, mode, p, BODY_CYC_WAVES / (AESGCM_BODY_WG / 64), st);
+    }
     p.ej0 = c->d_tag + 3; po->ej0 = p.ej0;
     if ((rc = launch_body(c, mode, p, BODY_CYC_WAVES / (AESGCM_BODY_WG / 64), st))) return rc;
     if ((rc = enqueue_fold(c, c->parts, BODY_CYC_WAVES, 1, 64, 0, st, po))) return rc;       // always BODY_CYC_WAVES items, 64 blocks apart
@@ -1472,7 +1578,8 @@ static int crypt_dev(aesgcm_ctx *c, int dec, const uint8_t iv[12], const void *d
     {   // mid-size messages: k_body as cyclic rows takes AAD, data and the ragged end in one launch; its items go straight to the tag
         Partials pc;
         bool took;
-        if ((rc = enqueue_cyc(c, dec ? MODE_DEC : MODE_ENC, iv, d_aad, aad_len, d_in, len, d_out, 0, st, &pc, &took))) return rc;
+        if ((rc = enqueue_cyc(c, dec ? MODE_DEC : MODE_ENC, iv, d_aad, aad_len, d_in, len, d_out, 0, st, &pc, &took, true))) return rc;
+        if (took && pc.done) return AESGCM_OK;                   // the launch left the tag in d_tag and in the host slot
         if (took) {
             CombineParams q = combine_with_items(plan_combine_tag(pc.ptr, pc.np, pc.kind, iv, aad_len, len, c->d_tag), pc.eA, pc.tail_item, pc.tail_blocks);
             q.ej0 = pc.ej0;
@@ -1602,6 +1709,7 @@ static int ctx_create_common(aesgcm_ctx **out, int device, const uint8_t *key, s
     if (const char *e = getenv("AESGCM_WGS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 2) per_cu = v; }
     if (const char *e = getenv("AESGCM_TW")) c->tw_override = (u32)strtoul(e, nullptr, 0);
     if (const char *e = getenv("AESGCM_BODY_MIN")) { c->body_min = strtoull(e, nullptr, 0); if (c->body_min >= (1ull << 60)) c->cyc_max = c->cyc_max_pieces = 0; }   // "never k_body" means it
+    if (const char *e = getenv("AESGCM_CYC_FUSE")) c->cyc_fuse = atoi(e) != 0;
     if (const char *e = getenv("AESGCM_BODY_CYC")) {
         char *end = nullptr;
         const u64 lo = strtoull(e, &end, 0);
@@ -1619,6 +1727,8 @@ static int ctx_create_common(aesgcm_ctx **out, int device, const uint8_t *key, s
         (e = hipMalloc(&c->fold_b, sizeof(uint4) * 64 * FOLD_B_ITEMS)) != hipSuccess ||
         (e = hipMalloc(&c->d_counter, 64 * (1 + 2 * AESGCM_NQ))) != hipSuccess ||
         (e = hipMemset(c->d_counter, 0, 64 * (1 + 2 * AESGCM_NQ))) != hipSuccess ||
+        (e = hipMalloc(&c->d_cyc, 8 * (2 * CYC_ACC_SLOTS + 1))) != hipSuccess ||
+        (e = hipMemset(c->d_cyc, 0, 8 * (2 * CYC_ACC_SLOTS + 1))) != hipSuccess ||
         (e = hipMalloc(&c->d_tag, sizeof(uint4) * 4)) != hipSuccess ||
         (e = hipHostMalloc((void **)&c->h_tag, 64, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess ||
         (e = hipHostGetDevicePointer((void **)&c->h_tag_dev, c->h_tag, 0)) != hipSuccess ||
@@ -1660,6 +1770,7 @@ int aesgcm_ctx_destroy(aesgcm_ctx *c) {
     if (c->fold_a) hipFree(c->fold_a);
     if (c->fold_b) hipFree(c->fold_b);
     if (c->d_counter) hipFree(c->d_counter);
+    if (c->d_cyc) hipFree(c->d_cyc);
     if (c->d_tag) hipFree(c->d_tag);
     if (c->h_tag) hipHostFree(c->h_tag);
     if (c->h_mtag) hipHostFree(c->h_mtag);

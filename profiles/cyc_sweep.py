@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""k_body as cyclic rows against the round-2 paths (k_main below 256 MiB, dealt k_body from there), by message size (GPU box).
+"""k_body as cyclic rows (with k_fold + k_combine behind the launch, and with the fused closing) against the round-2 paths (k_main below 256 MiB, dealt k_body from there), by message size (GPU box).
 Device-resident encrypt_dev incl. the tag readback, median and best of N calls, alternating the two settings call by call
 group so that clock drift hits both.  Contexts read AESGCM_BODY_CYC at creation.
     python profiles/cyc_sweep.py [key_bytes]"""
@@ -16,19 +16,22 @@ iv = bytes(12)
 os.environ["AESGCM_BODY_CYC"] = "0:0"
 old = lib.Context(bytes(range(kb)))
 os.environ["AESGCM_BODY_CYC"] = "%d:%d" % (1 * MiB, 1 << 50)
+os.environ["AESGCM_CYC_FUSE"] = "0"
 cyc = lib.Context(bytes(range(kb)))
-os.environ.pop("AESGCM_BODY_CYC")
-print("AES-%d   MiB    old_med   old_best    cyc_med   cyc_best   (us)    cyc GiB/s   tags" % (kb * 8))
+os.environ["AESGCM_CYC_FUSE"] = "1"
+fus = lib.Context(bytes(range(kb)))
+os.environ.pop("AESGCM_BODY_CYC"); os.environ.pop("AESGCM_CYC_FUSE")
+print("AES-%d   MiB    old_med   old_best    cyc_med   cyc_best  fused_med fused_best  (us)   fused GiB/s   tags" % (kb * 8))
 for mib in (1, 2, 4, 8, 16, 32, 64, 100, 128, 256, 512, 1024, 2048, 4096):
     n = mib * MiB
-    ts = {"old": [], "cyc": []}
+    ts = {"old": [], "cyc": [], "fus": []}
     tags = {}
     for rep in range(4):
-        for name, ctx in (("old", old), ("cyc", cyc)):
+        for name, ctx in (("old", old), ("cyc", cyc), ("fus", fus)):
             for it in range(6):
                 t0 = time.perf_counter()
                 tags[name] = ctx.encrypt_dev(iv, a.ptr, n, b.ptr)
                 ts[name].append(time.perf_counter() - t0)
-    o, c = ts["old"], ts["cyc"]
-    print("       %6d  %9.1f  %9.1f  %9.1f  %9.1f           %8.1f   %s" % (mib, statistics.median(o) * 1e6, min(o) * 1e6, statistics.median(c) * 1e6, min(c) * 1e6,
-                                                                          n / statistics.median(c) / (1 << 30), "same" if tags["old"] == tags["cyc"] else "DIFFERENT"), flush=True)
+    o, c, f = ts["old"], ts["cyc"], ts["fus"]
+    print("       %6d  %9.1f  %9.1f  %9.1f  %9.1f  %9.1f  %9.1f          %8.1f   %s" % (mib, statistics.median(o) * 1e6, min(o) * 1e6, statistics.median(c) * 1e6, min(c) * 1e6,
+          statistics.median(f) * 1e6, min(f) * 1e6, n / statistics.median(f) / (1 << 30), "same" if tags["old"] == tags["cyc"] == tags["fus"] else "DIFFERENT"), flush=True)

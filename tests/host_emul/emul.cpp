@@ -69,6 +69,50 @@ static void emu_main(int mode, const KeyMaterial *km, const MainParams &p) {
     if (km->nr == 10) { D(10) } else if (km->nr == 12) { D(12) } else { D(14) }
 #undef D
 }
+// emulated cyc_close(): the fused closing of a cyclic launch, workgroup by workgroup with the same lane pieces (tree levels, lane terms from the staged
+// tables, the weight through a two-table Shoup form, the terms that occur once in workgroup 0); the accumulator slots are plain XORs here
+static void emu_cyc_close(const KeyMaterial *km, const BodyParams &p, const uint4 *items, const uint4 *last, uint4 ej0) {
+    static unsigned char smem[CYC_LDS_END] __attribute__((aligned(16)));
+    const u32 wgs = BODY_CYC_WAVES / 16;
+    G128 slots[CYC_ACC_SLOTS];
+    memset(slots, 0, sizeof slots);
+    u32 arrived = 0;
+    for (u32 gg = 0; gg < wgs; gg++) {
+        const u32 g = (gg * 37u + 5u) % wgs;                               // any arrival order
+        for (u32 tid = 0; tid < 1024; tid++) {
+            reinterpret_cast<uint4 *>(smem + CYC_LDS_TREE_TAB)[tid] = (&km->ptab[0][0])[tid];
+            reinterpret_cast<uint4 *>(smem + CYC_LDS_TREE_TAB)[1024u + tid] = (&km->ptab[0][0])[1024u + tid];
+            for (u32 k = tid; k < 2048; k += 1024) {
+                *reinterpret_cast<uint4 *>(smem + cyc_ltab_off(k)) = cyc_ltab_entry(km, k, p.tb);
+                if (g == 0 && p.tb) *reinterpret_cast<uint4 *>(smem + cyc_ltab_off(k, CYC_LDS_LTAB0)) = cyc_ltab_entry(km, k, 0u);
+            }
+            *reinterpret_cast<uint4 *>(smem + cyc_stage_off(0) + (tid >> 6) * 1024u + (tid & 63u) * 16u) = items[(size_t)(16 * g + (tid >> 6)) * 64 + (tid & 63u)];
+        }
+        uint4 y[64];
+        for (u32 level = 0; level < 4; level++)
+            for (u32 wv = 0; wv < (8u >> level); wv++) for (u32 lane = 0; lane < 64; lane++) {
+                const uint4 v = cyc_tree_lane(smem, level, wv, lane);
+                if (level < 3) *reinterpret_cast<uint4 *>(smem + cyc_stage_off(level + 1) + wv * 1024u + lane * 16u) = v; else y[lane] = v;
+            }
+        G128 z = {{0, 0, 0, 0}};
+        for (u32 lane = 0; lane < 64; lane++) xor_g(z, cyc_lane_term_lds(smem, y[lane], lane));
+        if (g + 1 != wgs) {
+            for (u32 lane = 0; lane < 32; lane++) *reinterpret_cast<uint4 *>(smem + CYC_LDS_WTAB + 16u * lane) = shoup2_entry(mo_to_be(km->pw[1][wgs - 1 - g]), lane);
+            z = shoup2_gmul_lds(z, reinterpret_cast<const uint4 *>(smem + CYC_LDS_WTAB));
+        }
+        if (g == 0) {
+            if (p.tb) for (u32 lane = 0; lane < 64; lane++) xor_g(z, cyc_lane_term_lds(smem, last[lane], lane, CYC_LDS_LTAB0));
+            xor_g(z, tag_len_term(km, p.aad_len, p.ct_len));
+            xor_g(z, mo_to_be(ej0));
+        }
+        xor_g(slots[g & (CYC_ACC_SLOTS - 1u)], z);
+        ++arrived;
+    }
+    CHECK(arrived == wgs, "cyc_close arrivals");
+    G128 t = {{0, 0, 0, 0}};
+    for (u32 k = 0; k < CYC_ACC_SLOTS; k++) xor_g(t, slots[k]);
+    *p.tag_out = be_to_mo(t);
+}
 template <int NR, int MODE>
 static void emu_body_nr(const KeyMaterial *km, const BodyParams &p) {
     static unsigned char smem[AESGCM_LDS_BYTES_T4] __attribute__((aligned(16)));
@@ -84,6 +128,12 @@ static void emu_body_nr(const KeyMaterial *km, const BodyParams &p) {
                 p.parts[(size_t)w * 64 + lane] = body_cyc_lane<NR, MODE>(km, &g_tb, p, smem, cc, w, lane);
                 if (w == 0 && p.tb) p.parts[(size_t)BODY_CYC_WAVES * 64 + lane] = body_cyc_last_lane<NR, MODE>(km, p, smem, cc, lane);
             }
+        }
+        if (p.fuse) {                                                   // the launch closes the tag itself
+            const CtrConsts cc = ctr_round1_consts(p.iv0, p.iv1, p.iv2, km->rk, smem, 0);
+            u32 s0, s1, s2, s3;
+            ctr_rounds_lds<NR>(bswap32(1u), cc, s0, s1, s2, s3, km->rk, smem, 0);
+            emu_cyc_close(km, p, p.parts, p.parts + (size_t)BODY_CYC_WAVES * 64, make_uint4(s0, s1, s2, s3));
         }
         return;
     }
@@ -148,6 +198,7 @@ struct Parts { const uint4 *ptr; u32 np; u32 gathered; u64 eA; const uint4 *tail
 struct Emu {
     KeyMaterial km; u32 tw; std::vector<uint4> parts, fold_a, fold_b;
     u32 n_cyc = 0;                  // launches that went through run_cyc()
+    bool fuse = true;               // whole messages: the cyclic launch closes the tag itself (cyc_close)
     bool cyc = false; u64 cyc_min = 1024;   // ranges with at least one whole body row as cyclic rows of k_body (every size) instead of the pieces
     Emu(const uint8_t *key, int key_len, u32 tw_) : tw(tw_), parts(1 << 16), fold_a(1 << 16), fold_b(1 << 12) { emu_setup(&km, key, key_len, 0, 512); }
     // mirrors enqueue_fold(): k_fold launches until one item is left
@@ -208,13 +259,15 @@ struct Emu {
         return fold(parts.data(), p.C, 4, 64, (u64)256 * b.T);
     }
     // mirrors enqueue_cyc(): the whole range as cyclic rows of k_body + one k_fold level; false = the range is not of that size
-    bool run_cyc(int mode, const uint8_t *iv, const void *aad, u64 aad_len, const void *in, u64 len, void *out, u64 first_block, Parts *po) {
+    bool run_cyc(int mode, const uint8_t *iv, const void *aad, u64 aad_len, const void *in, u64 len, void *out, u64 first_block, Parts *po, uint4 *fused_tag = nullptr) {
         if (!cyc) return false;
         if (parts.size() < (size_t)64 * (BODY_CYC_WAVES + 1)) parts.resize((size_t)64 * (BODY_CYC_WAVES + 1));
         BodyParams p;
         if (!plan_body_cyc(p, mode, iv, aad, aad_len, in, len, out, first_block, parts.data(), cyc_min, ~0ull)) return false;
+        if (fused_tag && fuse) { p.fuse = 1; p.aad_len = aad_len; p.ct_len = len; p.tag_out = fused_tag; }
         emu_body(mode, &km, p);
         ++n_cyc;
+        if (p.fuse) { po->np = 0; return true; }
         *po = fold(parts.data(), BODY_CYC_WAVES, 1, 64, 0);
         if (p.tb) { po->tail_item = parts.data() + (size_t)BODY_CYC_WAVES * 64; po->tail_blocks = p.tb; }
         return true;
@@ -255,8 +308,8 @@ struct Emu {
         uint4 Y = make_uint4(0, 0, 0, 0), t;
         {   // mirrors crypt_dev(): cyclic rows first, items straight to the tag
             Parts pc = {nullptr, 0, PARTS_NONE, 0};
-            if (run_cyc(dec ? MODE_DEC : MODE_ENC, iv, aad, aad_len, in, len, out, 0, &pc)) {
-                emu_combine(&km, combine_with_items(plan_combine_tag(pc.ptr, pc.np, pc.gathered, iv, aad_len, len, &t), pc.eA, pc.tail_item, pc.tail_blocks));
+            if (run_cyc(dec ? MODE_DEC : MODE_ENC, iv, aad, aad_len, in, len, out, 0, &pc, &t)) {
+                if (!fuse) emu_combine(&km, combine_with_items(plan_combine_tag(pc.ptr, pc.np, pc.gathered, iv, aad_len, len, &t), pc.eA, pc.tail_item, pc.tail_blocks));
                 memcpy(tag, &t, 16);
                 return true;
             }
@@ -603,6 +656,14 @@ static void test_body(int key_len, u32 G, u64 al, u64 n, u64 seed, bool cyc = fa
     orc_gcm_crypt(0, key.data(), key_len, iv.data(), aad.data(), al, pt.p, n, ref.p, rtag);
     Emu E(key.data(), key_len, G);
     E.cyc = cyc;
+    if (cyc) {                                                          // first with k_fold / k_combine behind the launch, then (below) with the fused closing
+        uint8_t utag[16];
+        E.fuse = false;
+        E.crypt_split(0, iv.data(), aad.data(), al, pt.p, n, ct.p, utag, 4096);
+        CHECK(memcmp(utag, rtag, 16) == 0, "cyclic unfused tag key %d aad %llu len %llu", key_len, (unsigned long long)al, (unsigned long long)n);
+        E.fuse = true; E.n_cyc = 0;
+        memset(ct.p, 0xA5, n);
+    }
     const bool split = E.crypt_split(0, iv.data(), aad.data(), al, pt.p, n, ct.p, tag, 4096);
     CHECK(split, "body split did not apply: len %llu G %u", (unsigned long long)n, G);
     CHECK(!cyc || E.n_cyc == 1, "cyclic rows did not take the message: len %llu", (unsigned long long)n);

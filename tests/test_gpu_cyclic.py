@@ -28,8 +28,10 @@ def _check(hip, f, ctx, iv, n, al, seed, aad_off=0):
     assert bytes(d_out.download(n)) == pt, ("dec pt", n, al)
 
 
-@pytest.mark.parametrize("klen", [16, 24, 32])
-def test_whole_messages_of_any_shape_take_the_cyclic_launch(hip, orc, klen):
+@pytest.mark.parametrize("klen,fuse", [(16, "1"), (24, "1"), (32, "1"), (16, "0"), (32, "0")])
+def test_whole_messages_of_any_shape_take_the_cyclic_launch(hip, orc, monkeypatch, klen, fuse):
+    """fuse = 1: the launch closes the tag itself (cyc_close: tree per workgroup, atomics across); 0: k_fold and k_combine behind it"""
+    monkeypatch.setenv("AESGCM_CYC_FUSE", fuse)
     key, iv = splitmix_bytes(9100 + klen, klen), splitmix_bytes(9101, 12)
     ctx, f = hip.Context(key), orc.Fast(key)
     shapes = [(4 * MiB, 0), (4 * MiB + 5, 20), (5 * MiB - 3, 1000), (6 * MiB + 1023, 16 * 64), (7 * MiB + 16, 1), (9 * MiB + 1008, 16 * 64 * 3 + 7)]
