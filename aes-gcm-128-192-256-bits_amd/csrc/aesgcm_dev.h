@@ -65,9 +65,27 @@ HD void gstore16(void *p, uint4 v) {
     gvec4_t w = {v.x, v.y, v.z, v.w};
     *(__attribute__((address_space(1))) gvec4_t *)(uintptr_t)p = w;
 }
+// ... written THROUGH the XCD's L2 to memory (sc0 sc1): the line does not stay dirty in the L2, so nothing of it is left for a write-back at the end
+// of the launch -- or, in a launch that publishes its result from inside (k_body's fused closing), before the result may be shown.  `base` is
+// wave-uniform, `off` the lane's byte offset.  The s_nop covers the store-data hazard the compiler cannot see inside the asm.
+HD void gstore16_wt(unsigned char *base, u32 off, uint4 v) {
+    gvec4_t w = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1\n\ts_nop 0" :: "v"(off), "v"(w), "s"(base) : "memory");
+}
+// ... at a per-lane address (the general rows of k_main's lane code), whole blocks, dwords and single bytes
+HD void gstore16_wt_at(void *p, uint4 v) {
+    gvec4_t w = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 0" :: "v"(p), "v"(w) : "memory");
+}
+HD void gstore4_wt_at(void *p, u32 v) { asm volatile("global_store_dword %0, %1, off sc0 sc1" :: "v"(p), "v"(v) : "memory"); }
+HD void gstore1_wt_at(void *p, u32 v) { asm volatile("global_store_byte %0, %1, off sc0 sc1" :: "v"(p), "v"(v) : "memory"); }
 #else
 HD uint4 gload16(const void *p) { return *reinterpret_cast<const uint4 *>(p); }
 HD void gstore16(void *p, uint4 v) { *reinterpret_cast<uint4 *>(p) = v; }
+HD void gstore16_wt(unsigned char *base, u32 off, uint4 v) { *reinterpret_cast<uint4 *>(base + off) = v; }
+HD void gstore16_wt_at(void *p, uint4 v) { *reinterpret_cast<uint4 *>(p) = v; }
+HD void gstore4_wt_at(void *p, u32 v) { *reinterpret_cast<u32 *>(p) = v; }
+HD void gstore1_wt_at(void *p, u32 v) { *reinterpret_cast<unsigned char *>(p) = (unsigned char)v; }
 #endif
 HD uint4 xor4(uint4 a, uint4 b) { return make_uint4(a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w); }
 
@@ -545,6 +563,7 @@ struct MainParams {
     u32 tail;                    // 1: single-chunk whole message -- the wave that owns chunk 0 also finishes the tag (no k_combine launch)
     uint4 *tag_out, *tag_host;   // tail: where the tag goes (device slot, and the pinned host slot or NULL)
     u64 gen;                     // tail: generation number published behind the host copy (see CombineParams::gen)
+    u32 wt;                      // stores through the L2 (gstore16_wt): the generic rows of a cyclic k_body launch that shows its tag from inside
 };
 
 #define AESGCM_MAX_CHUNKS (1u << 18)   /* 64 lane accumulators (1 KiB) per chunk: at most 256 MiB of them; k_fold's first level measured ~0.5 ns per chunk (135 us for 2^18; about 2x its LDS-array floor of 1.25 table multiplies per item) */
@@ -664,9 +683,10 @@ HD uint4 load_block_bytes(const unsigned char *p, u32 nbytes) {
     }
     return make_uint4(w0, w1, w2, w3);
 }
-HD void store_block_bytes(unsigned char *p, uint4 v, u32 nbytes) {
+HD void store_block_bytes(unsigned char *p, uint4 v, u32 nbytes, bool wt = false) {      // wt: through the L2 (gstore16_wt)
     if (nbytes == 16 && (((uintptr_t)p) & 3) == 0) {
         u32 *q = reinterpret_cast<u32 *>(p);
+        if (wt) { gstore4_wt_at(q, v.x); gstore4_wt_at(q + 1, v.y); gstore4_wt_at(q + 2, v.z); gstore4_wt_at(q + 3, v.w); return; }
         q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w;
         return;
     }
@@ -674,7 +694,8 @@ HD void store_block_bytes(unsigned char *p, uint4 v, u32 nbytes) {
     for (u32 k = 0; k < 16; k++) {
         if (k < nbytes) {
             const u32 w = k < 4 ? v.x : k < 8 ? v.y : k < 12 ? v.z : v.w;
-            p[k] = (unsigned char)(w >> (8 * (k & 3)));
+            if (wt) gstore1_wt_at(p + k, (w >> (8 * (k & 3))) & 0xFFu);
+            else p[k] = (unsigned char)(w >> (8 * (k & 3)));
         }
     }
 }
@@ -743,7 +764,7 @@ HD uint4 main_chunk_lane(const KeyMaterial *__restrict__ km, const MainParams &p
             uint4 x = make_uint4(0, 0, 0, 0);
             if (MODE != MODE_KS) x = gload16(src + lane16);
             const uint4 y = main_block<NR, MODE>(rk, smem, cc, lb, x, p.ctr0 + (u32)i0 + lane);
-            gstore16(dst + lane16, y);
+            if (p.wt) gstore16_wt(dst, lane16, y); else gstore16(dst + lane16, y);
             if (GH) acc = xor4(acc, (MODE == MODE_DEC) ? x : y);          // aes_gcm.vhd:207-211
             continue;
         }
@@ -766,7 +787,8 @@ HD uint4 main_chunk_lane(const KeyMaterial *__restrict__ km, const MainParams &p
                 else x = *reinterpret_cast<const uint4 *>(p.in + 16 * i);
             }
             uint4 y = main_block<NR, MODE>(rk, smem, cc, lb, x, p.ctr0 + (u32)i);
-            if (ragged) { y = mask_block(y, tail_bytes); store_block_bytes(p.out + 16 * i, y, tail_bytes); }
+            if (ragged) { y = mask_block(y, tail_bytes); store_block_bytes(p.out + 16 * i, y, tail_bytes, p.wt != 0); }
+            else if (p.wt) gstore16_wt_at(p.out + 16 * i, y);
             else *reinterpret_cast<uint4 *>(p.out + 16 * i) = y;
             gin = (MODE == MODE_DEC) ? x : y;           // aes_gcm.vhd:207-211
         }
@@ -944,7 +966,8 @@ struct BodyParams {
     u32 tb;                      // blocks of the last, partial row behind the body (`last`; 0 = none): its item goes to parts[BODY_CYC_WAVES]
     MainParams front, last;      // the two generic pieces as one-row chunks of main_chunk_lane
     // fused closing (whole messages, body_cyc_* below): the launch folds its own items and leaves the tag -- no k_fold, no k_combine
-    u32 fuse;
+    u32 fuse;                    // 1: closing in the launch; | 2: without the L2 write-back in front of the arrival (the host waits for the end of the launch); | 4: likewise, because the rows were stored through the L2 (wt)
+    u32 wt;                      // body rows store their ciphertext through the L2 (gstore16_wt)
     u64 aad_len, ct_len;         // bytes, for the length block
     unsigned long long *acc;     // CYC_ACC_SLOTS x {hi, lo} XOR accumulators and the arrival counter behind them (device memory, zero between launches)
     uint4 *tag_out, *tag_host;   // where the tag goes (device slot, and the pinned host slot or NULL)
@@ -1081,7 +1104,7 @@ HD uint4 body_strand_lane(const KeyMaterial *__restrict__ km, const DevTables *_
         body_state(s0, s1, s2, s3, b, p.ctr_hi0 + q, v, lane, cc, rk, tb);
         body_rounds<NR>(s0, s1, s2, s3, rk, smem, lb);
         const uint4 y = make_uint4(x.x ^ s0, x.y ^ s1, x.z ^ s2, x.w ^ s3);                  // gcm_gctr.vhd:150
-        if (MODE != MODE_PROBE) gstore16(dst + lane16, y);
+        if (MODE != MODE_PROBE) { if (p.wt) gstore16_wt(dst, lane16, y); else gstore16(dst + lane16, y); }
         acc = xor4(acc, (MODE == MODE_DEC) ? x : y);                  // aes_gcm.vhd:207-211
     }
     return acc;

@@ -300,6 +300,7 @@ __device__ __forceinline__ void cyc_close(const KeyMaterial *__restrict__ km, co
     const uint4 t0 = pt[tid], t1 = pt[1024u + tid];
     const uint4 l0 = cyc_ltab_entry(km, tid, p.tb), l1 = cyc_ltab_entry(km, 1024u + tid, p.tb);
     const uint4 wc = km->pw[1][gridDim.x - 1u - g];                            // H^(1024 (255 - g)); the launch has 256 workgroups (enqueue_cyc)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // the rows' stores (the compiler does not count those issued from asm) have been acknowledged
     const bool once = g == 0 && p.tb;                                         // workgroup 0 closes the partial last row as well: H^(65 - L)
     uint4 m0 = make_uint4(0, 0, 0, 0), m1 = m0;
     if (once) { m0 = cyc_ltab_entry(km, tid, 0u); m1 = cyc_ltab_entry(km, 1024u + tid, 0u); }
@@ -321,6 +322,10 @@ __device__ __forceinline__ void cyc_close(const KeyMaterial *__restrict__ km, co
         if (level < 3) __syncthreads();
     }
     if (wv != 0) return;
+    // The workgroup's ciphertext has reached its XCD's L2 (the barriers above waited for the stores); an agent-scope release writes that L2 back, so that
+    // when the last arrival publishes the tag every byte of the message is in memory -- for the copy engines, the other XCDs and the host -- although the
+    // launch itself retires a few microseconds later.  (p.fuse & 2: leave that to the end of the launch; the host then waits for it, fetch_tag.)
+    if (!(p.fuse & 6u)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     G128 z = wave_xor(cyc_lane_term_lds(smem, y, lane));
     if (g + 1u != gridDim.x) {                                                // weight H^(1024 (255 - g)) through a two-table Shoup form in LDS
         if (lane < 32) *reinterpret_cast<uint4 *>(smem + CYC_LDS_WTAB + 16u * lane) = shoup2_entry(mo_to_be(wc), lane);
@@ -1207,9 +1212,21 @@ struct aesgcm_ctx {
     u64 body_min = (u64)256 << 20;     // ranges with an aligned middle of at least this many bytes go through k_body (AESGCM_BODY_MIN).  Since k_main
                                        // got cheaper below 256 MiB (dispensers, k_fold: profiles/r02f/split_threshold.txt) the cut pays from 256 MiB:
                                        // 128 MiB -16 %, 256 MiB +0.8 %, 512 MiB +4 %, 1 GiB +11 %, 2 GiB +7 %; it was 128 MiB before, 0.7 GiB in round 1
+    bool tag_in_launch = false;        // the tag of the last message comes from inside its cyclic launch (fetch_tag waits for the launch's end behind it)
     unsigned long long *d_cyc = nullptr;   // the accumulators and the arrival counter of the fused closing of a cyclic launch (zero between launches)
+    // The tag of a fused cyclic launch appears while the launch is still running, and the call's contract is that the ciphertext is in memory by then.  Three ways,
+    // measured on 64 KiB .. 64 MiB (profiles/r03c/cyc_end.txt, us per message at 64 KiB / 16 MiB): the rows store THROUGH the L2 (sc0 sc1), so no line is left
+    // dirty -- 24 / 40, the default; every workgroup writes its XCD's L2 back before it counts itself arrived (AESGCM_CYC_FUSE=1) -- 29 / 46, the write-back costs 5 us
+    // however little is dirty; the host waits for the end of the launch behind the tag (AESGCM_CYC_FUSE=2) -- 38 / 54, the completion signal of a launch reaches the
+    // host 11 us after its last instruction.  (Three launches, AESGCM_CYC_FUSE=0: 26 (k_main) / 56.)
+    bool cyc_wt = true;
+    bool body_wt = true;               // the dealt k_body stores through the L2 as well: the end of a 16 GiB launch has less to write back (step 16.90 -> 16.79 ms, 1 GiB 1140 -> 1118 us;
+                                       // AESGCM_BODY_WT=0: plain stores)
+    bool cyc_wait_end = false;
     bool cyc_fuse = true;              // whole messages: the cyclic launch closes the tag itself (AESGCM_CYC_FUSE=0: k_fold + k_combine behind it)
     u64 cyc_max_pieces = (u64)640 << 20;   // ... for ranges with AAD, an odd first block or a ragged end
+    u64 cyc_min_fused = (u64)64 << 10, cyc_max_fused = (u64)512 << 20;   // whole messages, whose cyclic launch closes the tag itself (cyc_close): the launch is 24 us from 16 KiB
+                                       // to 2 MiB where k_main + k_fold + k_combine take 27 (64 KiB) .. 39 (256 KiB) .. 34 (1 MiB), profiles/r03c/cyc_small.txt; 512 MiB: 580 against 558
     u64 cyc_min = (u64)4 << 20, cyc_max = (u64)384 << 20;   // ranges whose whole rows are [cyc_min, cyc_max) bytes go through k_body as cyclic rows (body_cyc_lane): no dispenser, 4096 items
                                        // whatever the size.  AESGCM_BODY_CYC=min:max (bytes; 0:0 = never); needs one k_body workgroup per CU on 256 CUs.  Measured against
                                        // k_main / dealt k_body (profiles/r03c/cyc_sweep_*.txt, AES-256, us per message): 2 MiB 35 -> 37, 4 MiB 39 -> 38, 16 MiB 66 -> 55,
@@ -1374,7 +1391,7 @@ static int enqueue_main(aesgcm_ctx *c, int mode, const uint8_t iv[12], const voi
     p.counter = c->d_counter + 16 * (1 + AESGCM_NQ * c->qset);
     p.counter_zero = c->d_counter + 16 * (1 + AESGCM_NQ * (c->qset ^ 1u));
     if (gh && po) { p.ej0 = c->d_tag + 3; po->ej0 = p.ej0; }
-    if (gh && po && want_tail && C == 1) { p.tail = 1; p.tag_out = c->d_tag; p.tag_host = c->h_tag_dev; p.gen = ++c->tag_gen; po->done = true; }
+    if (gh && po && want_tail && C == 1) { p.tail = 1; p.tag_out = c->d_tag; p.tag_host = c->h_tag_dev; p.gen = ++c->tag_gen; po->done = true; c->tag_in_launch = false; }
     p.trace = nullptr;
     const bool timed = c->timing && !c->timing_mute;
     if (timed) {
@@ -1462,6 +1479,7 @@ static int enqueue_body(aesgcm_ctx *c, int mode, const uint8_t iv[12], const Bod
     plan_queues(p.C, &p.nq, &p.seg);
     p.counter = c->d_counter + 16 * (1 + AESGCM_NQ * c->qset);
     p.counter_zero = c->d_counter + 16 * (1 + AESGCM_NQ * (c->qset ^ 1u));
+    p.wt = c->body_wt;
     if ((rc = launch_body(c, mode, p, wgs, st))) return rc;
     // items 4s + v: phases 64 blocks apart inside a super-chunk, super-chunks 256 T blocks apart
     return enqueue_fold(c, c->parts, p.C, 4, 64, (u64)256 * b.T, st, po);
@@ -1470,7 +1488,7 @@ static int enqueue_body(aesgcm_ctx *c, int mode, const uint8_t iv[12], const Bod
 // 4096 items, when the range is of that size (*took says whether it was).  po describes the items and the partial last row for k_combine.
 static bool cyc_capable(const aesgcm_ctx *c) {
 #if AESGCM_T4
-    return (u32)c->G / 2 * (AESGCM_BODY_WG / 64) == BODY_CYC_WAVES && c->cyc_max_pieces > c->cyc_min;
+    return (u32)c->G / 2 * (AESGCM_BODY_WG / 64) == BODY_CYC_WAVES && c->cyc_max_pieces > c->cyc_min_fused;
 #else
     return false;
 #endif
@@ -1478,7 +1496,8 @@ static bool cyc_capable(const aesgcm_ctx *c) {
 static int enqueue_cyc(aesgcm_ctx *c, int mode, const uint8_t iv[12], const void *d_aad, u64 aad_len, const void *d_in, u64 len, void *d_out,
                        u64 first_block, hipStream_t st, Partials *po, bool *took, bool whole_message_tag = false) {
     *took = false;
-    if (!cyc_capable(c) || len < c->cyc_min) return AESGCM_OK;
+    const bool fused = whole_message_tag && c->cyc_fuse;
+    if (!cyc_capable(c) || len < (fused ? c->cyc_min_fused : c->cyc_min)) return AESGCM_OK;
     if (((uintptr_t)d_in & 15) || ((uintptr_t)d_out & 15)) return AESGCM_OK;     // the caller's other path reports the alignment
     int rc = grow_parts(c, (size_t)BODY_CYC_WAVES + 1);
     if (rc) return rc;
@@ -1486,13 +1505,15 @@ static int enqueue_cyc(aesgcm_ctx *c, int mode, const uint8_t iv[12], const void
     // a range with pieces around its body (AAD, an odd first block, a ragged end) costs the other paths a launch pair per piece (+45 .. 80 us,
     // profiles/r03c/general_shape.txt): for those the cyclic launch stays ahead for longer
     const bool pieces = aad_len || (first_block & 255) || (len & 1023);
-    if (!plan_body_cyc(p, mode, iv, d_aad, aad_len, d_in, len, d_out, first_block, c->parts, c->cyc_min, pieces ? c->cyc_max_pieces : c->cyc_max)) return AESGCM_OK;
+    const u64 lo = fused ? c->cyc_min_fused : c->cyc_min, hi = pieces ? c->cyc_max_pieces : fused ? c->cyc_max_fused : c->cyc_max;
+    if (!plan_body_cyc(p, mode, iv, d_aad, aad_len, d_in, len, d_out, first_block, c->parts, lo, hi)) return AESGCM_OK;
     *took = true;
     *po = Partials();
-    if (whole_message_tag && c->cyc_fuse) {                                     // the launch closes the tag itself (cyc_close): nothing behind it
-        p.fuse = 1; p.aad_len = aad_len; p.ct_len = len; p.acc = c->d_cyc;
+    if (fused) {                                                                // the launch closes the tag itself (cyc_close): nothing behind it
+        p.fuse = c->cyc_wait_end ? 3 : c->cyc_wt ? 5 : 1; p.wt = p.front.wt = p.last.wt = c->cyc_wt; p.aad_len = aad_len; p.ct_len = len; p.acc = c->d_cyc;
         p.tag_out = c->d_tag; p.tag_host = c->h_tag_dev; p.gen = ++c->tag_gen;
         po->done = true;
+        c->tag_in_launch = c->cyc_wait_end;
         return launch_body(c, mode, p, BODY_CYC_WAVES / (AESGCM_BODY_WG / 64), st);
     }
     p.ej0 = c->d_tag + 3; po->ej0 = p.ej0;
@@ -1549,7 +1570,7 @@ static int absorb_range(aesgcm_ctx *c, int mode, const uint8_t iv[12], const voi
 
 static int enqueue_combine(aesgcm_ctx *c, const CombineParams &p0, hipStream_t st) {
     CombineParams p = p0;
-    if (p.out == c->d_tag) { p.out_host = c->h_tag_dev; p.gen = ++c->tag_gen; }   // results that go to the tag slot are mirrored to the pinned host slot
+    if (p.out == c->d_tag) { p.out_host = c->h_tag_dev; p.gen = ++c->tag_gen; c->tag_in_launch = false; }   // results that go to the tag slot are mirrored to the pinned host slot
     if (p.kind == PARTS_ITEM && p.np > 1) {                       // the launch folds the items itself: tables of H^eA, H^(8 eA)
         p.tabA = ptab_ptr(c, p.eA);
         p.tabB = p.np > 4 ? ptab_ptr(c, 4 * p.eA) : nullptr;
@@ -1636,6 +1657,19 @@ static int fetch_tag(aesgcm_ctx *c, hipStream_t st, uint8_t tag[16]) {
 #endif
     }
     if (!seen) HIPCHK(hipStreamSynchronize(st));
+    else if (c->tag_in_launch) {
+        // the cyclic launch published the tag from inside: every workgroup has stored its ciphertext by then, but the launch -- and with it the write-back of
+        // the other XCDs' L2s -- ends a few microseconds later.  The call promises a synchronised stream, so wait for the end; polling the stream's
+        // completion is still far cheaper than the interrupt-driven wait
+        hipError_t q = hipErrorNotReady;
+        for (u32 spin = 0; spin < 4096 && (q = hipStreamQuery(st)) == hipErrorNotReady; ++spin) {
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        if (q == hipErrorNotReady) HIPCHK(hipStreamSynchronize(st));
+        else if (q != hipSuccess) return hip_fail(q, "hipStreamQuery");
+    }
     memcpy(tag, c->h_tag, 16);
     return AESGCM_OK;
 }
@@ -1708,12 +1742,13 @@ static int ctx_create_common(aesgcm_ctx **out, int device, const uint8_t *key, s
     int per_cu = 2;
     if (const char *e = getenv("AESGCM_WGS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 2) per_cu = v; }
     if (const char *e = getenv("AESGCM_TW")) c->tw_override = (u32)strtoul(e, nullptr, 0);
-    if (const char *e = getenv("AESGCM_BODY_MIN")) { c->body_min = strtoull(e, nullptr, 0); if (c->body_min >= (1ull << 60)) c->cyc_max = c->cyc_max_pieces = 0; }   // "never k_body" means it
-    if (const char *e = getenv("AESGCM_CYC_FUSE")) c->cyc_fuse = atoi(e) != 0;
+    if (const char *e = getenv("AESGCM_BODY_MIN")) { c->body_min = strtoull(e, nullptr, 0); if (c->body_min >= (1ull << 60)) c->cyc_max = c->cyc_max_pieces = c->cyc_max_fused = 0; }   // "never k_body" means it
+    if (const char *e = getenv("AESGCM_CYC_FUSE")) { c->cyc_fuse = atoi(e) != 0; c->cyc_wait_end = atoi(e) == 2; c->cyc_wt = atoi(e) == 4; }   // 0: k_fold + k_combine; 1: write-back; 2: wait for the end; 4 (default): stores through the L2
+    if (const char *e = getenv("AESGCM_BODY_WT")) c->body_wt = atoi(e) != 0;
     if (const char *e = getenv("AESGCM_BODY_CYC")) {
         char *end = nullptr;
         const u64 lo = strtoull(e, &end, 0);
-        if (end && *end == ':') { c->cyc_min = lo; c->cyc_max = c->cyc_max_pieces = strtoull(end + 1, nullptr, 0); }
+        if (end && *end == ':') { c->cyc_min = c->cyc_min_fused = lo; c->cyc_max = c->cyc_max_pieces = c->cyc_max_fused = strtoull(end + 1, nullptr, 0); }
     }
     int G = per_cu * ds->n_cu;
     if (G > AESGCM_GMAX) G = AESGCM_GMAX;

@@ -134,9 +134,14 @@ AESGCM_API int aesgcm_decrypt(aesgcm_ctx *ctx, const uint8_t iv[12], const uint8
 /* ---------------------------------------------------------------- whole messages, device pointers
  * The benchmarked path: d_in/d_out are device pointers (16-byte aligned, may alias for in-place),
  * d_aad a device pointer (any alignment) or NULL.  Work is enqueued on `stream` (a hipStream_t
- * passed as void*, NULL = context stream); the only host traffic is the 16-byte tag, whose copy
- * synchronises the stream.  Pass tag = NULL to skip the copy and the synchronisation; the tag then
- * stays in the context and can be fetched with aesgcm_last_tag(). */
+ * passed as void*, NULL = context stream); the only host traffic is the 16-byte tag.  When the call
+ * returns with a tag, the whole result is in device memory: the kernel that finishes the tag stores it
+ * in a pinned host slot behind the data (messages of 64 KiB .. 512 MiB: the one launch that encrypts
+ * the message, whose ciphertext stores go through the L2 for that), and the call returns when the
+ * slot shows it -- long work falls back to a stream synchronisation.  The launch itself may retire a
+ * few microseconds later; anything ordered behind it on `stream`, hipStreamSynchronize and blocking
+ * copies see it complete as always.  Pass tag = NULL to skip the wait; the tag then stays in the
+ * context and can be fetched with aesgcm_last_tag(). */
 AESGCM_API int aesgcm_encrypt_dev(aesgcm_ctx *ctx, const uint8_t iv[12], const void *d_aad, size_t aad_len,
                        const void *d_pt, size_t len, void *d_ct, uint8_t tag[16], void *stream);
 AESGCM_API int aesgcm_decrypt_dev(aesgcm_ctx *ctx, const uint8_t iv[12], const void *d_aad, size_t aad_len,

@@ -28,9 +28,10 @@ def _check(hip, f, ctx, iv, n, al, seed, aad_off=0):
     assert bytes(d_out.download(n)) == pt, ("dec pt", n, al)
 
 
-@pytest.mark.parametrize("klen,fuse", [(16, "1"), (24, "1"), (32, "1"), (16, "0"), (32, "0")])
+@pytest.mark.parametrize("klen,fuse", [(16, "1"), (24, "1"), (32, "1"), (16, "0"), (32, "0"), (16, "4"), (32, "4"), (24, "2")])
 def test_whole_messages_of_any_shape_take_the_cyclic_launch(hip, orc, monkeypatch, klen, fuse):
-    """fuse = 1: the launch closes the tag itself (cyc_close: tree per workgroup, atomics across); 0: k_fold and k_combine behind it"""
+    """fuse = 1: the launch closes the tag itself (cyc_close: tree per workgroup, atomics across); 0: k_fold and k_combine behind it;
+    4 / 2: the two other ways to have the ciphertext in memory when the tag appears (stores through the L2 / the host waits for the launch's end)"""
     monkeypatch.setenv("AESGCM_CYC_FUSE", fuse)
     key, iv = splitmix_bytes(9100 + klen, klen), splitmix_bytes(9101, 12)
     ctx, f = hip.Context(key), orc.Fast(key)

@@ -23,7 +23,7 @@ def _len(rng, cap):
 
 def test_fuzz_one_shot_and_device_paths(hip, orc):
     rng = random.Random(20260101)
-    old = os.environ.get("AESGCM_TW")
+    old, old_cyc = os.environ.get("AESGCM_TW"), os.environ.get("AESGCM_BODY_CYC")
     try:
         for it in range(220):
             klen = rng.choice((16, 24, 32))
@@ -32,6 +32,12 @@ def test_fuzz_one_shot_and_device_paths(hip, orc):
                 os.environ.pop("AESGCM_TW", None)
             else:
                 os.environ["AESGCM_TW"] = str(tw)
+            # every other context keeps to k_main / k_fold / k_combine (the paths of messages below 64 KiB and of long AAD); the others take the
+            # cyclic launch with its fused closing from 64 KiB
+            if it & 1:
+                os.environ["AESGCM_BODY_CYC"] = "0:0"
+            else:
+                os.environ.pop("AESGCM_BODY_CYC", None)
             key, iv = splitmix_bytes(9000 + it, klen), splitmix_bytes(9500 + it, 12)
             al = _len(rng, 1 << 16) if rng.random() < 0.7 else 0
             n = _len(rng, 6 << 20)
@@ -56,10 +62,11 @@ def test_fuzz_one_shot_and_device_paths(hip, orc):
             assert back == pt and t2 == want[1], (it, "dec")
             ctx.close()
     finally:
-        if old is None:
-            os.environ.pop("AESGCM_TW", None)
-        else:
-            os.environ["AESGCM_TW"] = old
+        for name, val in (("AESGCM_TW", old), ("AESGCM_BODY_CYC", old_cyc)):
+            if val is None:
+                os.environ.pop(name, None)
+            else:
+                os.environ[name] = val
 
 
 def test_fuzz_random_shard_splits(hip, orc):

@@ -43,7 +43,7 @@ def test_scratch_free_kernels(census):
         if name.startswith("k_body<") and name.endswith(", true>"):
             # cyclic rows: the fused closing behind the row loop (cyc_close, once per launch) parks E_K(J0) and the last-row item in scratch while its
             # table multiplies hold the register file; nothing inside a loop may
-            assert k["scratch"] <= 64 and all(ops.get("scratch", 0) == 0 for d, ops in k["depth"].items() if d >= 1), (name, k["scratch"], k["depth"])
+            assert k["scratch"] <= 128 and all(ops.get("scratch", 0) == 0 for d, ops in k["depth"].items() if d >= 1), (name, k["scratch"], k["depth"])
         elif name.startswith(("k_body<", "k_pktl<", "k_pktg<", "k_batch3<")) or name.startswith("k_main<") and name.endswith((", 2>", ", 3>")):
             assert k["scratch"] == 0, (name, k["scratch"])
 
