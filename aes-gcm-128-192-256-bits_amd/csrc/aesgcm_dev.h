@@ -67,15 +67,16 @@ HD void gstore16(void *p, uint4 v) {
 }
 // ... written THROUGH the XCD's L2 to memory (sc0 sc1): the line does not stay dirty in the L2, so nothing of it is left for a write-back at the end
 // of the launch -- or, in a launch that publishes its result from inside (k_body's fused closing), before the result may be shown.  `base` is
-// wave-uniform, `off` the lane's byte offset.  The s_nop covers the store-data hazard the compiler cannot see inside the asm.
+// wave-uniform, `off` the lane's byte offset.  The s_nop covers the store-data hazard the compiler cannot see inside
+// the asm (a VALU write of the data registers within two wait states of a store wider than 64 bits, gfx940 and later).
 HD void gstore16_wt(unsigned char *base, u32 off, uint4 v) {
     gvec4_t w = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1\n\ts_nop 0" :: "v"(off), "v"(w), "s"(base) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1\n\ts_nop 1" :: "v"(off), "v"(w), "s"(base) : "memory");
 }
 // ... at a per-lane address (the general rows of k_main's lane code), whole blocks, dwords and single bytes
 HD void gstore16_wt_at(void *p, uint4 v) {
     gvec4_t w = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 0" :: "v"(p), "v"(w) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(p), "v"(w) : "memory");
 }
 HD void gstore4_wt_at(void *p, u32 v) { asm volatile("global_store_dword %0, %1, off sc0 sc1" :: "v"(p), "v"(v) : "memory"); }
 HD void gstore1_wt_at(void *p, u32 v) { asm volatile("global_store_byte %0, %1, off sc0 sc1" :: "v"(p), "v"(v) : "memory"); }
@@ -563,7 +564,6 @@ struct MainParams {
     u32 tail;                    // 1: single-chunk whole message -- the wave that owns chunk 0 also finishes the tag (no k_combine launch)
     uint4 *tag_out, *tag_host;   // tail: where the tag goes (device slot, and the pinned host slot or NULL)
     u64 gen;                     // tail: generation number published behind the host copy (see CombineParams::gen)
-    u32 wt;                      // stores through the L2 (gstore16_wt): the generic rows of a cyclic k_body launch that shows its tag from inside
 };
 
 #define AESGCM_MAX_CHUNKS (1u << 18)   /* 64 lane accumulators (1 KiB) per chunk: at most 256 MiB of them; k_fold's first level measured ~0.5 ns per chunk (135 us for 2^18; about 2x its LDS-array floor of 1.25 table multiplies per item) */
@@ -740,7 +740,7 @@ HD u64 uniform64(u64 x) {
 #endif
 }
 
-template <int NR, int MODE>
+template <int NR, int MODE, bool WT = false>      // WT: stores through the L2 (the generic rows of a cyclic k_body launch)
 HD uint4 main_chunk_lane(const KeyMaterial *__restrict__ km, const MainParams &p, const unsigned char *smem, const CtrConsts &cc, u32 c, u32 lane) {
     constexpr bool GH = (MODE == MODE_ENC || MODE == MODE_DEC);
     const u32 *__restrict__ rk = km->rk;
@@ -764,7 +764,7 @@ HD uint4 main_chunk_lane(const KeyMaterial *__restrict__ km, const MainParams &p
             uint4 x = make_uint4(0, 0, 0, 0);
             if (MODE != MODE_KS) x = gload16(src + lane16);
             const uint4 y = main_block<NR, MODE>(rk, smem, cc, lb, x, p.ctr0 + (u32)i0 + lane);
-            if (p.wt) gstore16_wt(dst, lane16, y); else gstore16(dst + lane16, y);
+            if (WT) gstore16_wt(dst, lane16, y); else gstore16(dst + lane16, y);
             if (GH) acc = xor4(acc, (MODE == MODE_DEC) ? x : y);          // aes_gcm.vhd:207-211
             continue;
         }
@@ -787,8 +787,8 @@ HD uint4 main_chunk_lane(const KeyMaterial *__restrict__ km, const MainParams &p
                 else x = *reinterpret_cast<const uint4 *>(p.in + 16 * i);
             }
             uint4 y = main_block<NR, MODE>(rk, smem, cc, lb, x, p.ctr0 + (u32)i);
-            if (ragged) { y = mask_block(y, tail_bytes); store_block_bytes(p.out + 16 * i, y, tail_bytes, p.wt != 0); }
-            else if (p.wt) gstore16_wt_at(p.out + 16 * i, y);
+            if (ragged) { y = mask_block(y, tail_bytes); store_block_bytes(p.out + 16 * i, y, tail_bytes, WT); }
+            else if (WT) gstore16_wt_at(p.out + 16 * i, y);
             else *reinterpret_cast<uint4 *>(p.out + 16 * i) = y;
             gin = (MODE == MODE_DEC) ? x : y;           // aes_gcm.vhd:207-211
         }
@@ -966,8 +966,7 @@ struct BodyParams {
     u32 tb;                      // blocks of the last, partial row behind the body (`last`; 0 = none): its item goes to parts[BODY_CYC_WAVES]
     MainParams front, last;      // the two generic pieces as one-row chunks of main_chunk_lane
     // fused closing (whole messages, body_cyc_* below): the launch folds its own items and leaves the tag -- no k_fold, no k_combine
-    u32 fuse;                    // 1: closing in the launch; | 2: without the L2 write-back in front of the arrival (the host waits for the end of the launch); | 4: likewise, because the rows were stored through the L2 (wt)
-    u32 wt;                      // body rows store their ciphertext through the L2 (gstore16_wt)
+    u32 fuse;                    // 1: closing in the launch; | 2: no L2 write-back in front of the arrival because the host waits for the end of the launch; | 4: none because the rows were stored through the L2 (AESGCM_BODY_WT)
     u64 aad_len, ct_len;         // bytes, for the length block
     unsigned long long *acc;     // CYC_ACC_SLOTS x {hi, lo} XOR accumulators and the arrival counter behind them (device memory, zero between launches)
     uint4 *tag_out, *tag_host;   // where the tag goes (device slot, and the pinned host slot or NULL)
@@ -1019,6 +1018,11 @@ HD void body_rounds(u32 &s0, u32 &s1, u32 &s2, u32 &s3, const u32 *__restrict__ 
 #endif
     aes_final_lds(s0, s1, s2, s3, rk + 4 * NR, lds, lb);
 }
+#ifndef AESGCM_BODY_WT
+#define AESGCM_BODY_WT 1                 /* k_body's rows store their ciphertext through the L2 (gstore16_wt): nothing of it is left dirty for the end of the launch -- the cyclic launch shows
+                                            its tag from inside (cyc_close), and a dealt 16 GiB launch ends 0.1 ms sooner (profiles/r03c/body_wt_ab: step 16.90 -> 16.79 ms).  0: plain stores
+                                            (then cyc_close must write the L2 back: AESGCM_CYC_FUSE=1) */
+#endif
 #ifndef AESGCM_BODY_ILP
 #define AESGCM_BODY_ILP 1                /* 2: two rows of a chunk in flight per lane (round-3 experiment, profiles/r03/body_ilp2.txt) */
 #endif
@@ -1104,7 +1108,13 @@ HD uint4 body_strand_lane(const KeyMaterial *__restrict__ km, const DevTables *_
         body_state(s0, s1, s2, s3, b, p.ctr_hi0 + q, v, lane, cc, rk, tb);
         body_rounds<NR>(s0, s1, s2, s3, rk, smem, lb);
         const uint4 y = make_uint4(x.x ^ s0, x.y ^ s1, x.z ^ s2, x.w ^ s3);                  // gcm_gctr.vhd:150
-        if (MODE != MODE_PROBE) { if (p.wt) gstore16_wt(dst, lane16, y); else gstore16(dst + lane16, y); }
+        if (MODE != MODE_PROBE) {
+#if AESGCM_BODY_WT
+            gstore16_wt(dst, lane16, y);
+#else
+            gstore16(dst + lane16, y);
+#endif
+        }
         acc = xor4(acc, (MODE == MODE_DEC) ? x : y);                  // aes_gcm.vhd:207-211
     }
     return acc;
@@ -1140,7 +1150,7 @@ HD uint4 body_cyc_lane(const KeyMaterial *__restrict__ km, const DevTables *__re
     uint4 acc = make_uint4(0, 0, 0, 0);
     bool started = false;
     if (u < p.F) {                                                     // wave-uniform
-        acc = main_chunk_lane<NR, MODE>(km, p.front, smem, cc, u, lane);
+        acc = main_chunk_lane<NR, MODE, AESGCM_BODY_WT != 0>(km, p.front, smem, cc, u, lane);
         started = true;
         u += BODY_CYC_WAVES;
     }
@@ -1151,7 +1161,7 @@ HD uint4 body_cyc_lane(const KeyMaterial *__restrict__ km, const DevTables *__re
 // the partial row behind the body (lane values = one-row item, right-aligned)
 template <int NR, int MODE>
 HD uint4 body_cyc_last_lane(const KeyMaterial *__restrict__ km, const BodyParams &p, const unsigned char *smem, const CtrConsts &cc, u32 lane) {
-    return main_chunk_lane<NR, MODE>(km, p.last, smem, cc, 0u, lane);
+    return main_chunk_lane<NR, MODE, AESGCM_BODY_WT != 0>(km, p.last, smem, cc, 0u, lane);
 }
 
 // Fused closing of a cyclic launch (BodyParams::fuse: whole messages).  Every workgroup folds its own sixteen items -- they are consecutive,

@@ -1212,6 +1212,7 @@ struct aesgcm_ctx {
     u64 body_min = (u64)256 << 20;     // ranges with an aligned middle of at least this many bytes go through k_body (AESGCM_BODY_MIN).  Since k_main
                                        // got cheaper below 256 MiB (dispensers, k_fold: profiles/r02f/split_threshold.txt) the cut pays from 256 MiB:
                                        // 128 MiB -16 %, 256 MiB +0.8 %, 512 MiB +4 %, 1 GiB +11 %, 2 GiB +7 %; it was 128 MiB before, 0.7 GiB in round 1
+    long poll_ns = 200000L;            // how long fetch_tag polls the host slot before it blocks in the runtime (AESGCM_POLL_US)
     bool tag_in_launch = false;        // the tag of the last message comes from inside its cyclic launch (fetch_tag waits for the launch's end behind it)
     unsigned long long *d_cyc = nullptr;   // the accumulators and the arrival counter of the fused closing of a cyclic launch (zero between launches)
     // The tag of a fused cyclic launch appears while the launch is still running, and the call's contract is that the ciphertext is in memory by then.  Three ways,
@@ -1219,9 +1220,8 @@ struct aesgcm_ctx {
     // dirty -- 24 / 40, the default; every workgroup writes its XCD's L2 back before it counts itself arrived (AESGCM_CYC_FUSE=1) -- 29 / 46, the write-back costs 5 us
     // however little is dirty; the host waits for the end of the launch behind the tag (AESGCM_CYC_FUSE=2) -- 38 / 54, the completion signal of a launch reaches the
     // host 11 us after its last instruction.  (Three launches, AESGCM_CYC_FUSE=0: 26 (k_main) / 56.)
-    bool cyc_wt = true;
-    bool body_wt = true;               // the dealt k_body stores through the L2 as well: the end of a 16 GiB launch has less to write back (step 16.90 -> 16.79 ms, 1 GiB 1140 -> 1118 us;
-                                       // AESGCM_BODY_WT=0: plain stores)
+    bool cyc_wt = AESGCM_BODY_WT != 0; // (the dealt k_body stores through the L2 as well: the end of a 16 GiB launch has less to write back, step 16.90 -> 16.79 ms, 1 GiB 1140 -> 1118 us,
+                                       // profiles/r03c/body_wt_ab; compile-time: -DAESGCM_BODY_WT=0)
     bool cyc_wait_end = false;
     bool cyc_fuse = true;              // whole messages: the cyclic launch closes the tag itself (AESGCM_CYC_FUSE=0: k_fold + k_combine behind it)
     u64 cyc_max_pieces = (u64)640 << 20;   // ... for ranges with AAD, an odd first block or a ragged end
@@ -1479,7 +1479,6 @@ static int enqueue_body(aesgcm_ctx *c, int mode, const uint8_t iv[12], const Bod
     plan_queues(p.C, &p.nq, &p.seg);
     p.counter = c->d_counter + 16 * (1 + AESGCM_NQ * c->qset);
     p.counter_zero = c->d_counter + 16 * (1 + AESGCM_NQ * (c->qset ^ 1u));
-    p.wt = c->body_wt;
     if ((rc = launch_body(c, mode, p, wgs, st))) return rc;
     // items 4s + v: phases 64 blocks apart inside a super-chunk, super-chunks 256 T blocks apart
     return enqueue_fold(c, c->parts, p.C, 4, 64, (u64)256 * b.T, st, po);
@@ -1510,7 +1509,7 @@ static int enqueue_cyc(aesgcm_ctx *c, int mode, const uint8_t iv[12], const void
     *took = true;
     *po = Partials();
     if (fused) {                                                                // the launch closes the tag itself (cyc_close): nothing behind it
-        p.fuse = c->cyc_wait_end ? 3 : c->cyc_wt ? 5 : 1; p.wt = p.front.wt = p.last.wt = c->cyc_wt; p.aad_len = aad_len; p.ct_len = len; p.acc = c->d_cyc;
+        p.fuse = c->cyc_wait_end ? 3 : c->cyc_wt ? 5 : 1; p.aad_len = aad_len; p.ct_len = len; p.acc = c->d_cyc;
         p.tag_out = c->d_tag; p.tag_host = c->h_tag_dev; p.gen = ++c->tag_gen;
         po->done = true;
         c->tag_in_launch = c->cyc_wait_end;
@@ -1650,7 +1649,7 @@ static int fetch_tag(aesgcm_ctx *c, hipStream_t st, uint8_t tag[16]) {
         if (__atomic_load_n(gen, __ATOMIC_ACQUIRE) == want) { seen = true; break; }
         if ((spin & 63u) == 63u) {
             clock_gettime(CLOCK_MONOTONIC, &t1);
-            if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > 200000L) break;
+            if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > c->poll_ns) break;
         }
 #if defined(__x86_64__)
         __builtin_ia32_pause();
@@ -1743,8 +1742,8 @@ static int ctx_create_common(aesgcm_ctx **out, int device, const uint8_t *key, s
     if (const char *e = getenv("AESGCM_WGS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 2) per_cu = v; }
     if (const char *e = getenv("AESGCM_TW")) c->tw_override = (u32)strtoul(e, nullptr, 0);
     if (const char *e = getenv("AESGCM_BODY_MIN")) { c->body_min = strtoull(e, nullptr, 0); if (c->body_min >= (1ull << 60)) c->cyc_max = c->cyc_max_pieces = c->cyc_max_fused = 0; }   // "never k_body" means it
-    if (const char *e = getenv("AESGCM_CYC_FUSE")) { c->cyc_fuse = atoi(e) != 0; c->cyc_wait_end = atoi(e) == 2; c->cyc_wt = atoi(e) == 4; }   // 0: k_fold + k_combine; 1: write-back; 2: wait for the end; 4 (default): stores through the L2
-    if (const char *e = getenv("AESGCM_BODY_WT")) c->body_wt = atoi(e) != 0;
+    if (const char *e = getenv("AESGCM_CYC_FUSE")) { c->cyc_fuse = atoi(e) != 0; c->cyc_wait_end = atoi(e) == 2; c->cyc_wt = AESGCM_BODY_WT != 0 && atoi(e) != 1 && atoi(e) != 2; }   // 0: k_fold + k_combine; 1: + write-back; 2: wait for the end; default: nothing (the rows went through the L2)
+    if (const char *e = getenv("AESGCM_POLL_US")) c->poll_ns = 1000L * atol(e);
     if (const char *e = getenv("AESGCM_BODY_CYC")) {
         char *end = nullptr;
         const u64 lo = strtoull(e, &end, 0);
