@@ -103,3 +103,25 @@ def test_back_to_back_messages_do_not_see_each_other(hip, orc):
         iv, n, al, d_in, d_aad, want = cases[it & 1]
         assert ctx.encrypt_dev(iv, d_in.ptr, n, d_out.ptr, d_aad=d_aad.ptr if al else None, aad_len=al) == want[1], it
     assert bytes(d_out.download(cases[1][1])) == cases[1][5][0]
+
+
+def test_queued_launches_and_two_contexts(hip, orc):
+    """tag = NULL: the calls only enqueue -- cyclic launches queue up behind each other on the stream (each leaves the accumulators zeroed for the
+    next), two contexts on their own streams run side by side; the tags are read afterwards with aesgcm_last_tag"""
+    k1, k2 = splitmix_bytes(9600, 32), splitmix_bytes(9601, 16)
+    c1, c2 = hip.Context(k1), hip.Context(k2)
+    f1, f2 = orc.Fast(k1), orc.Fast(k2)
+    n = 3 * MiB + 4096 + 7
+    d_in = hip.DeviceBuffer(n + 16); d_in.fill_splitmix64(9610, 0, nbytes=n)
+    pt = bytes(d_in.download(n))
+    o1, o2 = hip.DeviceBuffer(n + 16), hip.DeviceBuffer(n + 16)
+    ivs = [splitmix_bytes(9620 + k, 12) for k in range(12)]
+    for k, iv in enumerate(ivs):                                    # 12 launches per context in flight, nothing waited for
+        c1.encrypt_dev(iv, d_in.ptr, n, o1.ptr, want_tag=False)
+        c2.encrypt_dev(iv, d_in.ptr, n - 4096 * (k & 1), o2.ptr, want_tag=False)
+    t1, t2 = c1.last_tag(), c2.last_tag()
+    w1, w2 = f1.encrypt(ivs[-1], b"", pt), f2.encrypt(ivs[-1], b"", pt[:n - 4096])
+    assert t1 == w1[1] and t2 == w2[1]
+    assert bytes(o1.download(n)) == w1[0] and bytes(o2.download(n - 4096)) == w2[0]
+    # and a waited call right behind them sees clean accumulators
+    assert c1.encrypt_dev(ivs[0], d_in.ptr, n, o1.ptr) == f1.encrypt(ivs[0], b"", pt)[1]
