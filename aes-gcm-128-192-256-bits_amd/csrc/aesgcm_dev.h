@@ -438,6 +438,28 @@ HD uint4 ghash_mul_const_lds_at(uint4 y, const unsigned char *lds, u32 base) {
     return make_uint4(r.x, r.y, r.z, r.w);
 }
 
+// the same multiply as a LOOP over the four words of y (not unrolled: eight table loads, 32 registers of entries, in flight instead of up to 128) --
+// for k_body's fused closing, which has 128 registers in all and must not spill: every wave of the launch runs it.  The words rotate through w0 so
+// that nothing is indexed by the loop counter.
+HD uint4 ghash_mul_const_lds_at_lean(uint4 y, const unsigned char *lds, u32 base) {
+    u32x4_t r = {0, 0, 0, 0};
+    u32 w0 = y.x, w1 = y.y, w2 = y.z, w3 = y.w;
+#pragma unroll 1
+    for (u32 wi = 0; wi < 4; wi++) {
+#pragma unroll
+        for (int bb = 0; bb < 4; bb++) {
+            const u32 hi = (bb == 0) ? (w0 & 0xF0u) : ((w0 >> (8 * bb)) & 0xF0u);
+            const u32 lo = (bb == 0) ? ((w0 << 4) & 0xF0u) : ((w0 >> (8 * bb - 4)) & 0xF0u);
+            const u32x4_t a = LDS_LD128(lds, hi + (base + (2 * bb) * 256));
+            const u32x4_t c = LDS_LD128(lds, lo + (base + (2 * bb + 1) * 256));
+            r.x = xor3(r.x, a.x, c.x); r.y = xor3(r.y, a.y, c.y); r.z = xor3(r.z, a.z, c.z); r.w = xor3(r.w, a.w, c.w);
+        }
+        base += 2048u;
+        w0 = w1; w1 = w2; w2 = w3;
+    }
+    return make_uint4(r.x, r.y, r.z, r.w);
+}
+
 // ================================================================================================
 // Device-resident structures and the per-lane bodies of the kernels.  The __global__ wrappers in
 // aesgcm_kernels.hip only add LDS staging, barriers and cross-lane reductions around these, so the
@@ -505,25 +527,27 @@ HD G128 shoup2_gmul(G128 y, const uint4 *__restrict__ tab) {
     return z;
 }
 
-// the same multiply with the table loads in four batches of eight (32 registers of entries in flight instead of 128): for tables in LDS, where a
-// load costs nothing to wait for, inside kernels that have no registers to spare (k_body's fused closing)
+// the same multiply as a LOOP over the four words of y, last word first (not unrolled: eight table loads in flight instead of 32 -- for tables in LDS,
+// where a load costs little to wait for, inside kernels that have no registers to spare: k_body's fused closing)
 HD G128 shoup2_gmul_lds(G128 y, const uint4 *__restrict__ tab) {
     u32 z0 = 0, z1 = 0, z2 = 0, z3 = 0;
-#pragma unroll
-    for (int q = 3; q >= 0; q--) {
+    u32 w0 = y.w[3], w1 = y.w[2], w2 = y.w[1], w3 = y.w[0];
+#pragma unroll 1
+    for (u32 q = 0; q < 4; q++) {
         uint4 a[4], c[4];
-        const u32 w = y.w[q];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const u32 byte = (w >> (8 * (3 - k))) & 0xFFu;
+            const u32 byte = (w0 >> (8 * (3 - k))) & 0xFFu;
             a[k] = tab[byte >> 4];
             c[k] = tab[16u + (byte & 15u)];
         }
 #pragma unroll
         for (int k = 3; k >= 0; k--) {
-            if (!(q == 3 && k == 3)) gf_shift8(z0, z1, z2, z3);
+            if (k != 3) gf_shift8(z0, z1, z2, z3);
+            else if (q) gf_shift8(z0, z1, z2, z3);
             z0 = xor3(z0, a[k].x, c[k].x); z1 = xor3(z1, a[k].y, c[k].y); z2 = xor3(z2, a[k].z, c[k].z); z3 = xor3(z3, a[k].w, c[k].w);
         }
+        w0 = w1; w1 = w2; w2 = w3;
     }
     G128 z; z.w[0] = z0; z.w[1] = z1; z.w[2] = z2; z.w[3] = z3;
     return z;
@@ -1181,13 +1205,15 @@ HD uint4 body_cyc_last_lane(const KeyMaterial *__restrict__ km, const BodyParams
 #define CYC_LDS_LTAB_STRIDE 528u
 #define CYC_LDS_LTAB0 (CYC_LDS_LTAB + 64u * CYC_LDS_LTAB_STRIDE)   /* workgroup 0, when there is a partial last row: the same for H^(65 - L) */
 #define CYC_LDS_END (CYC_LDS_LTAB0 + 64u * CYC_LDS_LTAB_STRIDE)
+#define CYC_LDS_PARK AESGCM_LDS_BYTES_T4      /* behind the row loop's tables: wave 0 of workgroup 0 parks its last-row item (64 x 16 B) and E_K(J0) here until the closing */
+#define CYC_LDS_PARK_BYTES 1040u
 HD u32 cyc_stage_off(u32 level) { return CYC_LDS_STAGE + (level == 0 ? 0u : level == 1 ? 16384u : level == 2 ? 24576u : 28672u); }   // where the inputs of tree level `level` sit
 // tree level `level` (0 .. 3), pair k: lane `lane`
 HD uint4 cyc_tree_lane(const unsigned char *smem, u32 level, u32 k, u32 lane) {
     const u32 in = cyc_stage_off(level);
     const uint4 xe = *reinterpret_cast<const uint4 *>(smem + in + (2u * k) * 1024u + lane * 16u);
     const uint4 xo = *reinterpret_cast<const uint4 *>(smem + in + (2u * k + 1u) * 1024u + lane * 16u);
-    return xor4(ghash_mul_const_lds_at(xe, smem, CYC_LDS_TREE_TAB + level * 8192u), xo);
+    return xor4(ghash_mul_const_lds_at_lean(xe, smem, CYC_LDS_TREE_TAB + level * 8192u), xo);
 }
 // lane L's term of a workgroup item (tb = blocks behind the grid) or of the partial last row (tb = 0)
 HD G128 cyc_lane_term(const KeyMaterial *__restrict__ km, uint4 item, u32 lane, u32 tb) { return shoup2_gmul(mo_to_be(item), km->ltab[65u - lane + tb]); }

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(AESGCM_MAIN_WG, AESGCM_WAVES_PER_SIMD) void k_main(
 // the layout assumptions the kernels rely on, checked where they are used
 static_assert(2u * AESGCM_LDS_BYTES <= 160u * 1024u, "k_main / k_pktl: two workgroups must share a CU's 160 KiB of LDS");
 static_assert(PKTG_LDS_BYTES(6) <= 160u * 1024u && PKTG_LDS_BYTES(4) + 16u * 1024u <= 160u * 1024u && AESGCM_NQ5POW >= 7, "k_pktg: Horner table, T0 | T2, the tree tables (and the E_K(J0) slots of up to 16 waves at 16 lanes per packet) in one CU's LDS");
-static_assert(AESGCM_BODY_LDS <= 160u * 1024u, "k_body: one workgroup per CU");
+static_assert(AESGCM_BODY_LDS + CYC_LDS_PARK_BYTES <= 160u * 1024u && CYC_LDS_END <= CYC_LDS_PARK, "k_body: one workgroup per CU; the fused closing's tables end in front of the parked items");
 static_assert(AESGCM_LDS_AES_OFF % 128u == 0, "T-table replicas: lane l must read bank l & 31");
 static_assert(AESGCM_LDS_DRY_OFF >= AESGCM_Q5_GROUPS * 256u && AESGCM_LDS_DRY_OFF + 4u <= AESGCM_Q5_HI_ROW * 256u, "the dry-queue mask sits in the spare row between the table halves");
 static_assert((AESGCM_Q5_HI_ROW * 256u) % 512u != 0 && AESGCM_Q5_HI_ROW * 256u > 2040u, "the two halves of a five-bit table entry must not be fusable into one ds_read2[st64]_b64");
@@ -291,9 +291,9 @@ __device__ __forceinline__ G128 wave_xor(G128 z) {
     }
     return z;
 }
-// the fused closing of a cyclic launch (lane pieces and the algebra: aesgcm_dev.h, "Fused closing"); acc = the wave's item, last / ej0 = wave 0's
-// partial last row and E_K(IV || 1)
-__device__ __forceinline__ void cyc_close(const KeyMaterial *__restrict__ km, const BodyParams &p, unsigned char *smem, uint4 acc, uint4 last, uint4 ej0) {
+// the fused closing of a cyclic launch (lane pieces and the algebra: aesgcm_dev.h, "Fused closing"); acc = the wave's item; wave 0 of workgroup 0 has left its
+// partial last row and E_K(IV || 1) at CYC_LDS_PARK
+__device__ __forceinline__ void cyc_close(const KeyMaterial *__restrict__ km, const BodyParams &p, unsigned char *smem, uint4 acc) {
     const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6, g = blockIdx.x;
     // the tree's tables and the weight, requested before the barrier so that they travel while the workgroup's last waves finish their rows
     const uint4 *pt = &km->ptab[0][0];
@@ -336,8 +336,9 @@ __device__ __forceinline__ void cyc_close(const KeyMaterial *__restrict__ km, co
     }
     if (g == 0) {                                                             // the terms that occur once
         G128 x; x.w[0] = x.w[1] = x.w[2] = x.w[3] = 0;
-        if (p.tb) x = cyc_lane_term_lds(smem, last, lane, CYC_LDS_LTAB0);
+        if (p.tb) x = cyc_lane_term_lds(smem, *reinterpret_cast<const uint4 *>(smem + CYC_LDS_PARK + lane * 16u), lane, CYC_LDS_LTAB0);
         if (lane == 0) {
+            const uint4 ej0 = *reinterpret_cast<const uint4 *>(smem + CYC_LDS_PARK + 1024u);
             G128 L; const u64 la = p.aad_len * 8, lc = p.ct_len * 8;       // the length block times H (tag_len_term with the batched multiply: no registers to spare here)
             L.w[0] = (u32)(la >> 32); L.w[1] = (u32)la; L.w[2] = (u32)(lc >> 32); L.w[3] = (u32)lc;
             L = shoup2_gmul_lds(L, km->ltab[1]);
@@ -411,7 +412,11 @@ __global__ __launch_bounds__(AESGCM_BODY_WG, AESGCM_BODY_WPS) void k_body(const 
             }
             return;
         }
-        cyc_close(km, p, smem, acc, last, ej0);
+        if (w == 0) {                                                         // parked in LDS (not in registers: the closing has none to spare) until workgroup 0's wave 0 closes
+            *reinterpret_cast<uint4 *>(smem + CYC_LDS_PARK + lane * 16u) = last;
+            if (lane == 0) *reinterpret_cast<uint4 *>(smem + CYC_LDS_PARK + 1024u) = ej0;
+        }
+        cyc_close(km, p, smem, acc);
         return;
     }
     if (blockIdx.x == 0 && tid < AESGCM_NQ) p.counter_zero[16 * tid] = 0;    // the next dynamic launch's queues
@@ -1298,7 +1303,7 @@ static int set_lds_attrs(int device, DeviceState *ds) {
     SETATTR(10, MODE_KS);  SETATTR(12, MODE_KS);  SETATTR(14, MODE_KS);
     SETATTR(10, MODE_ECB); SETATTR(12, MODE_ECB); SETATTR(14, MODE_ECB);
 #undef SETATTR
-#define SETATTRY(NR, MODE, CYC) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_body<NR, MODE, CYC>), hipFuncAttributeMaxDynamicSharedMemorySize, AESGCM_BODY_LDS))
+#define SETATTRY(NR, MODE, CYC) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_body<NR, MODE, CYC>), hipFuncAttributeMaxDynamicSharedMemorySize, AESGCM_BODY_LDS + (CYC ? CYC_LDS_PARK_BYTES : 0u)))
     SETATTRY(10, MODE_ENC, false); SETATTRY(12, MODE_ENC, false); SETATTRY(14, MODE_ENC, false); SETATTRY(10, MODE_DEC, false); SETATTRY(12, MODE_DEC, false); SETATTRY(14, MODE_DEC, false);
     SETATTRY(10, MODE_ENC, true); SETATTRY(12, MODE_ENC, true); SETATTRY(14, MODE_ENC, true); SETATTRY(10, MODE_DEC, true); SETATTRY(12, MODE_DEC, true); SETATTRY(14, MODE_DEC, true);
     SETATTRY(10, MODE_PROBE, false); SETATTRY(12, MODE_PROBE, false); SETATTRY(14, MODE_PROBE, false);
@@ -1441,7 +1446,7 @@ static int launch_body(aesgcm_ctx *c, int mode, BodyParams &p, u32 wgs, hipStrea
         else { HIPCHK(hipEventCreate(&evp.first)); HIPCHK(hipEventCreate(&evp.second)); }
         HIPCHK(hipEventRecord(evp.first, st));
     }
-#define LY(NR, M, CYC) hipLaunchKernelGGL((k_body<NR, M, CYC>), dim3(wgs), dim3(AESGCM_BODY_WG), AESGCM_BODY_LDS, st, c->km, c->tables, p)
+#define LY(NR, M, CYC) hipLaunchKernelGGL((k_body<NR, M, CYC>), dim3(wgs), dim3(AESGCM_BODY_WG), AESGCM_BODY_LDS + (CYC ? CYC_LDS_PARK_BYTES : 0u), st, c->km, c->tables, p)
     if (cyc) {
         if (mode == MODE_DEC)    { if (c->nr == 10) LY(10, MODE_DEC, true); else if (c->nr == 12) LY(12, MODE_DEC, true); else LY(14, MODE_DEC, true); }
         else                     { if (c->nr == 10) LY(10, MODE_ENC, true); else if (c->nr == 12) LY(12, MODE_ENC, true); else LY(14, MODE_ENC, true); }

@@ -125,3 +125,44 @@ def test_queued_launches_and_two_contexts(hip, orc):
     assert bytes(o1.download(n)) == w1[0] and bytes(o2.download(n - 4096)) == w2[0]
     # and a waited call right behind them sees clean accumulators
     assert c1.encrypt_dev(ivs[0], d_in.ptr, n, o1.ptr) == f1.encrypt(ivs[0], b"", pt)[1]
+
+
+def test_ciphertext_is_in_memory_when_the_tag_is(hip):
+    """examples/early_read: a copy ordered behind nothing (its own non-blocking stream), issued the moment aesgcm_encrypt_dev returns, reads the whole
+    ciphertext of the call -- the in-launch tag of the cyclic rows appears only after every row has gone through the L2 to memory"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "examples"), "-s", "early_read"], check=True)
+    r = subprocess.run([os.path.join(root, "examples", "early_read"), "40"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0 and "EARLY READ OK" in r.stdout, (r.stdout, r.stderr)
+
+
+def test_many_random_shapes_back_to_back(hip, orc):
+    """400 messages of random shape (64 KiB .. 6 MiB, any AAD up to 3 KiB, odd lengths) through two contexts in alternation: every tag against the oracle,
+    every tenth ciphertext in full -- the accumulator slots, the arrival counter and the generation number of the host slot turn over 400 times"""
+    import random
+    rng = random.Random(31337)
+    keys = [splitmix_bytes(9700, 16), splitmix_bytes(9701, 32)]
+    ctxs = [hip.Context(k) for k in keys]
+    fast = [orc.Fast(k) for k in keys]
+    nmax = 6 * MiB
+    d_in = hip.DeviceBuffer(nmax + 64); d_in.fill_splitmix64(9710, 0, nbytes=nmax)
+    pt_all = bytes(d_in.download(nmax))
+    d_out = hip.DeviceBuffer(nmax + 64)
+    d_aad = hip.DeviceBuffer(4096)
+    for it in range(400):
+        k = it & 1
+        n = rng.choice((rng.randint(64 << 10, nmax), rng.randint(64 << 10, 1 << 20), 1024 * rng.randint(64, 6144), 1024 * rng.randint(64, 6144) + rng.choice((1, 15, 16, 17, 1008, 1023))))
+        n = min(n, nmax)
+        al = rng.choice((0, 0, 1, 13, 16, 20, 64, 1000, 1024, rng.randint(1, 3072)))
+        off = rng.randrange(0, nmax - n + 1, 16)
+        aad = splitmix_bytes(9800 + it, al)
+        if al:
+            d_aad.upload(aad)
+        iv = splitmix_bytes(10800 + it, 12)
+        tag = ctxs[k].encrypt_dev(iv, d_in.ptr + off, n, d_out.ptr, d_aad=d_aad.ptr if al else None, aad_len=al)
+        want_ct, want_tag = fast[k].encrypt(iv, aad, pt_all[off:off + n])
+        assert tag == want_tag, (it, n, al, off)
+        if it % 10 == 0:
+            assert bytes(d_out.download(n)) == want_ct, (it, n, al, off)
