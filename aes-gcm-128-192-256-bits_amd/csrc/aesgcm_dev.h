@@ -990,6 +990,7 @@ struct BodyParams {
     u32 tb;                      // blocks of the last, partial row behind the body (`last`; 0 = none): its item goes to parts[BODY_CYC_WAVES]
     MainParams front, last;      // the two generic pieces as one-row chunks of main_chunk_lane
     // fused closing (whole messages, body_cyc_* below): the launch folds its own items and leaves the tag -- no k_fold, no k_combine
+    u32 prio_rows;               // rotate the waves' issue priorities every so many rows (0 = leave them alone)
     u32 fuse;                    // 1: closing in the launch; | 2: no L2 write-back in front of the arrival because the host waits for the end of the launch; | 4: none because the rows were stored through the L2 (AESGCM_BODY_WT)
     u64 aad_len, ct_len;         // bytes, for the length block
     unsigned long long *acc;     // CYC_ACC_SLOTS x {hi, lo} XOR accumulators and the arrival counter behind them (device memory, zero between launches)
@@ -1077,12 +1078,30 @@ HD void body_state(u32 &s0, u32 &s1, u32 &s2, u32 &s3, const BodyLane &b, u32 hi
         s0 ^= m & (u.U0 ^ n.U0); s1 ^= m & (u.U1 ^ n.U1); s2 ^= m & (u.U2 ^ n.U2); s3 ^= m & (u.U3 ^ n.U3);
     }
 }
+// The CU's issue arbitration is priority first, age second: with equal shares of rows the oldest wave of a SIMD runs ahead and the youngest is left to
+// finish alone (a launch of cyclic rows loses 8 % at 512 MiB and 16 % at 4 GiB that way).  Rotating the priorities -- every `rows` rows wave `slot` of
+// its SIMD (0 .. 3) takes priority (slot + i / rows) mod 4 -- gives every wave every rank for the same share of the time.
+HD void body_prio(u32 i, u32 rows, u32 slot) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (i % rows == 0) {
+        switch ((slot + i / rows) & 3u) {                              // s_setprio takes an immediate
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+        }
+    }
+#else
+    (void)i; (void)rows; (void)slot;
+#endif
+}
 // lane `lane` of a wave that takes the n super-rows q0, q0 + qstep, ... in row phase v: returns sum_i X[row 4(q0 + i qstep) + v, lane] * K^(n-1-i),
 // K = H^(256 qstep) = the constant whose tables the launch staged in LDS
 template <int NR, int MODE>
 HD uint4 body_strand_lane(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const BodyParams &p,
                           const unsigned char *smem, const CtrConsts &cc, u32 q0, u32 qstep, u32 n, u32 v, u32 lane,
-                          uint4 acc_in = make_uint4(0, 0, 0, 0), bool continued = false) {      // continued: acc_in is the strand so far (one more multiply in front of the first row)
+                          uint4 acc_in = make_uint4(0, 0, 0, 0), bool continued = false,        // continued: acc_in is the strand so far (one more multiply in front of the first row)
+                          u32 prio_rows = 0, u32 prio_slot = 0) {                               // prio_rows > 0: rotate the wave's issue priority every prio_rows rows (body_prio)
     const u32 *__restrict__ rk0 = km->rk;
     const u32 lb = (lane & 31u) << 2, lane16 = lane * 16u;
     const BodyLane b = body_lane_consts(rk0, cc, smem, v, lane);
@@ -1117,6 +1136,7 @@ HD uint4 body_strand_lane(const KeyMaterial *__restrict__ km, const DevTables *_
 #endif
     for (; i < n; ++i) {
         const u32 q = q0 + i * qstep;                                  // super-row: counters [256 q, 256 q + 255] of the body
+        if (prio_rows) body_prio(i, prio_rows, prio_slot);
 #if AESGCM_BODY_ILP == 2
         if (i) acc = ghash_mul_const_lds(acc, smem);
 #else
@@ -1180,7 +1200,7 @@ HD uint4 body_cyc_lane(const KeyMaterial *__restrict__ km, const DevTables *__re
     }
     if (u >= Rt) return acc;
     const u32 r0 = u - p.F, n = (Rt - u + BODY_CYC_WAVES - 1u) / BODY_CYC_WAVES;
-    return body_strand_lane<NR, MODE>(km, tb, p, smem, cc, r0 >> 2, BODY_CYC_WAVES / 4u, n, r0 & 3u, lane, acc, started);
+    return body_strand_lane<NR, MODE>(km, tb, p, smem, cc, r0 >> 2, BODY_CYC_WAVES / 4u, n, r0 & 3u, lane, acc, started, p.prio_rows, (s >> 2) & 3u);   // wave s of a workgroup sits on SIMD s & 3
 }
 // the partial row behind the body (lane values = one-row item, right-aligned)
 template <int NR, int MODE>

@@ -1227,15 +1227,18 @@ struct aesgcm_ctx {
     // host 11 us after its last instruction.  (Three launches, AESGCM_CYC_FUSE=0: 26 (k_main) / 56.)
     bool cyc_wt = AESGCM_BODY_WT != 0; // (the dealt k_body stores through the L2 as well: the end of a 16 GiB launch has less to write back, step 16.90 -> 16.79 ms, 1 GiB 1140 -> 1118 us,
                                        // profiles/r03c/body_wt_ab; compile-time: -DAESGCM_BODY_WT=0)
+    u32 cyc_prio = 2;                  // rows between rotations of the waves' issue priorities in a cyclic launch (body_prio; AESGCM_CYC_PRIO, 0 = off).  Without it the oldest wave of
+                                       // every SIMD runs ahead and the youngest finishes alone: 256 MiB 321 -> 291 us, 1 GiB 1238 -> 1105 (dealt chunks: 1090), profiles/r03c/cyc_prio_*.txt
     bool cyc_wait_end = false;
     bool cyc_fuse = true;              // whole messages: the cyclic launch closes the tag itself (AESGCM_CYC_FUSE=0: k_fold + k_combine behind it)
-    u64 cyc_max_pieces = (u64)640 << 20;   // ... for ranges with AAD, an odd first block or a ragged end
-    u64 cyc_min_fused = (u64)64 << 10, cyc_max_fused = (u64)512 << 20;   // whole messages, whose cyclic launch closes the tag itself (cyc_close): the launch is 24 us from 16 KiB
-                                       // to 2 MiB where k_main + k_fold + k_combine take 27 (64 KiB) .. 39 (256 KiB) .. 34 (1 MiB), profiles/r03c/cyc_small.txt; 512 MiB: 580 against 558
-    u64 cyc_min = (u64)4 << 20, cyc_max = (u64)384 << 20;   // ranges whose whole rows are [cyc_min, cyc_max) bytes go through k_body as cyclic rows (body_cyc_lane): no dispenser, 4096 items
-                                       // whatever the size.  AESGCM_BODY_CYC=min:max (bytes; 0:0 = never); needs one k_body workgroup per CU on 256 CUs.  Measured against
-                                       // k_main / dealt k_body (profiles/r03c/cyc_sweep_*.txt, AES-256, us per message): 2 MiB 35 -> 37, 4 MiB 39 -> 38, 16 MiB 66 -> 55,
-                                       // 64 MiB 137 -> 106, 128 MiB 188 -> 173, 256 MiB 326 -> 315, 512 MiB 548 -> 594 (equal shares end with the slowest wave), 4 GiB 4306 -> 4977
+    // Which ranges go through k_body as cyclic rows (body_cyc_lane: one launch for AAD, data and ragged end, no dispenser, 4096 items whatever the size).  AESGCM_BODY_CYC=min:max
+    // (bytes; 0:0 = never); needs one k_body workgroup per CU on 256 CUs.  Whole messages close their tag inside the launch (cyc_close): 24 us from 16 KiB to 2 MiB where
+    // k_main + k_fold + k_combine take 27 (64 KiB) .. 39 (256 KiB) .. 34 (1 MiB), profiles/r03c/cyc_small.txt -- from 64 KiB.  Shards and streaming chunks keep k_fold + k_combine
+    // behind the launch and start at 4 MiB (2 MiB: 35 -> 37 us, 4 MiB: 39 -> 38).  The upper end: with the waves' priorities rotating (cyc_prio) equal shares hold up to about
+    // 1 GiB -- AES-256, us per message, dealt chunks / cyclic rows: 512 MiB 577 / 555, 768 MiB 824 / 818, 896 MiB 970 / 932, 1 GiB 1069 / 1099, 1.25 GiB 1370 / 1381
+    // (profiles/r03c/cyc_prio_fine_*.txt); a range with pieces around its body costs the dealt form a launch pair per piece (+45 .. 80 us), so those stay cyclic a little longer.
+    u64 cyc_min_fused = (u64)64 << 10, cyc_min = (u64)4 << 20;
+    u64 cyc_max = (u64)1 << 30, cyc_max_fused = (u64)1 << 30, cyc_max_pieces = (u64)1280 << 20;
     uint4 *h_tag = nullptr;            // 64 bytes of pinned, device-mapped host memory: k_combine leaves the tag here too, so fetching it
     uint4 *h_tag_dev = nullptr;        //   is a host read -- no copy kernel, no interrupt-driven stream wait (its device address)
     u64 tag_gen = 0;                   // generation number of the last result sent to the host slot (the kernel publishes it behind the tag)
@@ -1513,6 +1516,7 @@ static int enqueue_cyc(aesgcm_ctx *c, int mode, const uint8_t iv[12], const void
     if (!plan_body_cyc(p, mode, iv, d_aad, aad_len, d_in, len, d_out, first_block, c->parts, lo, hi)) return AESGCM_OK;
     *took = true;
     *po = Partials();
+    p.prio_rows = c->cyc_prio;
     if (fused) {                                                                // the launch closes the tag itself (cyc_close): nothing behind it
         p.fuse = c->cyc_wait_end ? 3 : c->cyc_wt ? 5 : 1; p.aad_len = aad_len; p.ct_len = len; p.acc = c->d_cyc;
         p.tag_out = c->d_tag; p.tag_host = c->h_tag_dev; p.gen = ++c->tag_gen;
@@ -1749,6 +1753,7 @@ static int ctx_create_common(aesgcm_ctx **out, int device, const uint8_t *key, s
     if (const char *e = getenv("AESGCM_BODY_MIN")) { c->body_min = strtoull(e, nullptr, 0); if (c->body_min >= (1ull << 60)) c->cyc_max = c->cyc_max_pieces = c->cyc_max_fused = 0; }   // "never k_body" means it
     if (const char *e = getenv("AESGCM_CYC_FUSE")) { c->cyc_fuse = atoi(e) != 0; c->cyc_wait_end = atoi(e) == 2; c->cyc_wt = AESGCM_BODY_WT != 0 && atoi(e) != 1 && atoi(e) != 2; }   // 0: k_fold + k_combine; 1: + write-back; 2: wait for the end; default: nothing (the rows went through the L2)
     if (const char *e = getenv("AESGCM_POLL_US")) c->poll_ns = 1000L * atol(e);
+    if (const char *e = getenv("AESGCM_CYC_PRIO")) c->cyc_prio = (u32)strtoul(e, nullptr, 0);
     if (const char *e = getenv("AESGCM_BODY_CYC")) {
         char *end = nullptr;
         const u64 lo = strtoull(e, &end, 0);
