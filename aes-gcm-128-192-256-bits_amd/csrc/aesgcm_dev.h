@@ -1167,7 +1167,7 @@ HD uint4 body_strand_lane(const KeyMaterial *__restrict__ km, const DevTables *_
 template <int NR, int MODE>
 HD uint4 body_chunk_lane(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const BodyParams &p,
                          const unsigned char *smem, const CtrConsts &cc, u32 c, u32 lane) {
-    return body_strand_lane<NR, MODE>(km, tb, p, smem, cc, (c >> 2) * p.T, 1u, p.T, c & 3u, lane);
+    return body_strand_lane<NR, MODE>(km, tb, p, smem, cc, (c >> 2) * p.T, 1u, p.T, c & 3u, lane);      // (rotating priorities here was tried: nothing, profiles/r03c/body_prio_dealt.txt)
 }
 // Cyclic rows (mid-size ranges, BodyParams::cyc): no dispenser, no item per chunk, and the whole range -- AAD, odd first block, ragged end -- in ONE launch.
 // The GHASH sequence of the range is laid on a grid of 64-block rows that is aligned to the BODY: F front rows (the AAD blocks and the data blocks up to the

@@ -136,7 +136,7 @@ AESGCM_API int aesgcm_decrypt(aesgcm_ctx *ctx, const uint8_t iv[12], const uint8
  * d_aad a device pointer (any alignment) or NULL.  Work is enqueued on `stream` (a hipStream_t
  * passed as void*, NULL = context stream); the only host traffic is the 16-byte tag.  When the call
  * returns with a tag, the whole result is in device memory: the kernel that finishes the tag stores it
- * in a pinned host slot behind the data (messages of 64 KiB .. 512 MiB: the one launch that encrypts
+ * in a pinned host slot behind the data (messages of 64 KiB .. 1 GiB: the one launch that encrypts
  * the message, whose ciphertext stores go through the L2 for that), and the call returns when the
  * slot shows it -- long work falls back to a stream synchronisation.  The launch itself may retire a
  * few microseconds later; anything ordered behind it on `stream`, hipStreamSynchronize and blocking
