@@ -843,7 +843,23 @@ HD CtrConsts main_lane_consts(const KeyMaterial *__restrict__ km, const MainPara
 // period = 4 folds the four phases with A = H^64 and the super-chunks with B = H^(256 T).
 // Constants that are H^(2^k) (chunk sizes are powers of two unless AESGCM_TW says otherwise) come from the
 // key's precomputed tables (tab* = device pointer); others are built in the kernel from the exponent.
+// k_fold can close the message itself (whole messages whose dealt k_body launch is the whole range: BASELINE configs 2 and 3): the workgroups of the
+// FIRST level then do with their output items what cyc_close does with a workgroup's item -- lane terms H^(65 - L), the weight H^(step (G - 1 - g)) as the
+// product of its radix-1024 digit powers (pw[d][digit], one two-table Shoup multiply per non-zero digit), 16 bytes into the accumulator slots, the
+// last arrival publishes -- and the second level, k_combine and their two launch gaps disappear (1 GiB: 47 -> 28 us behind k_body).
+struct FoldClose {
+    u32 on;
+    u64 step;                    // blocks between the ends of consecutive output items (fold_out_step)
+    u64 aad_len, ct_len;         // bytes, for the length block
+    const uint4 *ej0;            // E_K(IV || 1), left by the k_body launch in front
+    unsigned long long *acc;     // accumulator slots + arrival counter (as BodyParams::acc)
+    uint4 *tag_out, *tag_host; u64 gen;
+};
+#define FOLD_LDS_LTAB 32768u                 /* closing: the lanes' Shoup tables of H^(65 - L), 64 x 528 bytes */
+#define FOLD_LDS_WTAB (FOLD_LDS_LTAB + 64u * 528u)   /* closing: the weight digit's two-table Shoup form */
+#define FOLD_LDS_CLOSE_BYTES (FOLD_LDS_WTAB + 512u)
 struct FoldParams {
+    FoldClose close;
     const uint4 *in; uint4 *out;
     u32 n;                       // items in
     u32 period;                  // 1: plain Horner with A.  4: inner Horner with A over each 4 items, outer with B
@@ -934,6 +950,7 @@ HD uint4 fold_wg_lane(const unsigned char *smem, u32 J, u32 lane) {
 static inline u64 fold_out_step(const FoldParams &p) { return FOLD_WAVES * p.eC; }
 // fill the constants of a level: items eA blocks apart (period 1), or phases eA apart and periods eB apart
 static inline void plan_fold(FoldParams &p, const uint4 *in, uint4 *out, u32 n, u32 period, u64 eA, u64 eB) {
+    p.close.on = 0;
     p.in = in; p.out = out; p.n = n; p.period = period; p.eA = eA; p.eB = period > 1 ? eB : 0;
     p.group = fold_group(n, period);
     p.eC = period > 1 ? (p.group / period) * eB : p.group * eA;

@@ -291,6 +291,25 @@ __device__ __forceinline__ G128 wave_xor(G128 z) {
     }
     return z;
 }
+// One workgroup's 16 bytes of a tag into the accumulator slots, and the tag out of them when this was the launch's last arrival (one lane calls this).
+// Memory-side atomics only: the XORs return before the arrival is counted (the increment depends on their results), so the workgroup that counts the
+// last arrival finds every contribution in the slots; it zeroes slots and counter for the next launch.
+__device__ __forceinline__ void acc_arrive(unsigned long long *acc, u32 g, G128 z, uint4 *tag_out, uint4 *tag_host, u64 gen) {
+    const u32 slot = g & (CYC_ACC_SLOTS - 1u);
+    const unsigned long long ohi = atomicXor(acc + 2u * slot, ((unsigned long long)z.w[0] << 32) | z.w[1]);
+    const unsigned long long olo = atomicXor(acc + 2u * slot + 1u, ((unsigned long long)z.w[2] << 32) | z.w[3]);
+    u32 dep;
+    asm volatile("v_and_b32 %0, 0, %1" : "=v"(dep) : "v"((u32)(ohi ^ olo) | (u32)((ohi ^ olo) >> 32)));
+    const unsigned long long arrived = atomicAdd(acc + 2u * CYC_ACC_SLOTS, 1ull + dep);
+    if (arrived + 1ull != gridDim.x) return;
+    unsigned long long hi = 0, lo = 0;
+#pragma unroll
+    for (u32 k = 0; k < CYC_ACC_SLOTS; ++k) { hi ^= atomicExch(acc + 2u * k, 0ull); lo ^= atomicExch(acc + 2u * k + 1u, 0ull); }
+    atomicExch(acc + 2u * CYC_ACC_SLOTS, 0ull);
+    G128 t; t.w[0] = (u32)(hi >> 32); t.w[1] = (u32)hi; t.w[2] = (u32)(lo >> 32); t.w[3] = (u32)lo;
+    *tag_out = be_to_mo(t);
+    if (tag_host) publish_host_lean(tag_host, be_to_mo(t), gen);
+}
 // the fused closing of a cyclic launch (lane pieces and the algebra: aesgcm_dev.h, "Fused closing"); acc = the wave's item; wave 0 of workgroup 0 has left its
 // partial last row and E_K(IV || 1) at CYC_LDS_PARK
 __device__ __forceinline__ void cyc_close(const KeyMaterial *__restrict__ km, const BodyParams &p, unsigned char *smem, uint4 acc) {
@@ -349,22 +368,7 @@ __device__ __forceinline__ void cyc_close(const KeyMaterial *__restrict__ km, co
         z.w[0] ^= x.w[0]; z.w[1] ^= x.w[1]; z.w[2] ^= x.w[2]; z.w[3] ^= x.w[3];
     }
     if (lane != 0) return;
-    // memory-side atomics only: the XORs return before the arrival is counted (the increment depends on their results), so the workgroup that
-    // counts the last arrival finds every contribution in the slots
-    const u32 slot = g & (CYC_ACC_SLOTS - 1u);
-    const unsigned long long ohi = atomicXor(p.acc + 2u * slot, ((unsigned long long)z.w[0] << 32) | z.w[1]);
-    const unsigned long long olo = atomicXor(p.acc + 2u * slot + 1u, ((unsigned long long)z.w[2] << 32) | z.w[3]);
-    u32 dep;
-    asm volatile("v_and_b32 %0, 0, %1" : "=v"(dep) : "v"((u32)(ohi ^ olo) | (u32)((ohi ^ olo) >> 32)));
-    const unsigned long long arrived = atomicAdd(p.acc + 2u * CYC_ACC_SLOTS, 1ull + dep);
-    if (arrived + 1ull != gridDim.x) return;
-    unsigned long long hi = 0, lo = 0;
-#pragma unroll
-    for (u32 k = 0; k < CYC_ACC_SLOTS; ++k) { hi ^= atomicExch(p.acc + 2u * k, 0ull); lo ^= atomicExch(p.acc + 2u * k + 1u, 0ull); }
-    atomicExch(p.acc + 2u * CYC_ACC_SLOTS, 0ull);                             // zero between launches
-    G128 t; t.w[0] = (u32)(hi >> 32); t.w[1] = (u32)hi; t.w[2] = (u32)(lo >> 32); t.w[3] = (u32)lo;
-    *p.tag_out = be_to_mo(t);
-    if (p.tag_host) publish_host_lean(p.tag_host, be_to_mo(t), p.gen);
+    acc_arrive(p.acc, g, z, p.tag_out, p.tag_host, p.gen);
 }
 
 template <int NR, int MODE, bool CYC>
@@ -452,12 +456,39 @@ __global__ __launch_bounds__(FOLD_WG, FOLD_WPS) void k_fold(const KeyMaterial *_
     fold_fill_lds(smem, km, p.tabA, p.eA, 0u, tid, FOLD_WG);
     if (p.period > 1) fold_fill_lds(smem, km, p.tabB, p.eB, 8192u, tid, FOLD_WG);
     fold_fill_lds(smem, km, p.tabC, p.eC, 16384u, tid, FOLD_WG);
+    if (p.close.on) for (u32 k = tid; k < 2048u; k += FOLD_WG) *reinterpret_cast<uint4 *>(smem + cyc_ltab_off(k, FOLD_LDS_LTAB)) = cyc_ltab_entry(km, k, 0u);   // the lanes' tables of H^(65 - L)
     __syncthreads();
     u32 start, end;
     const u32 J = fold_wg_range(p.n, p.group, blockIdx.x, &start, &end);
     if (w < J) *reinterpret_cast<uint4 *>(smem + FOLD_LDS_TAB + w * 1024u + lane * 16u) = fold_wave_lane(p, smem, start, end, J, w, lane);
     __syncthreads();
-    if (w == 0) p.out[(size_t)blockIdx.x * 64 + lane] = fold_wg_lane(smem, J, lane);
+    if (w != 0) return;
+    const uint4 item = fold_wg_lane(smem, J, lane);
+    if (!p.close.on) { p.out[(size_t)blockIdx.x * 64 + lane] = item; return; }
+    // closing (FoldClose): this workgroup's item ends step (G - 1 - g) blocks in front of the end of the message
+    const u32 g = blockIdx.x;
+    G128 z = wave_xor(cyc_lane_term_lds(smem, item, lane, FOLD_LDS_LTAB));
+    const u64 e = p.close.step * (u64)(gridDim.x - 1u - g);
+#pragma unroll 1
+    for (u32 d = 0; d < 4; ++d) {
+        const u32 dig = (u32)(e >> (AESGCM_LOG_WG * d)) & (u32)(AESGCM_WG - 1);
+        if (!dig) continue;                                                   // wave-uniform
+        if (lane < 32) *reinterpret_cast<uint4 *>(smem + FOLD_LDS_WTAB + 16u * lane) = shoup2_entry(mo_to_be(km->pw[d][dig]), lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        z = shoup2_gmul_lds(z, reinterpret_cast<const uint4 *>(smem + FOLD_LDS_WTAB));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                // the table is rewritten by the next digit
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (g + 1u == gridDim.x && lane == 0) {                                   // the terms that occur once: the length block times H, E_K(J0)
+        G128 L; const u64 la = p.close.aad_len * 8, lc = p.close.ct_len * 8;
+        L.w[0] = (u32)(la >> 32); L.w[1] = (u32)la; L.w[2] = (u32)(lc >> 32); L.w[3] = (u32)lc;
+        L = shoup2_gmul_lds(L, km->ltab[1]);
+        const G128 ej = mo_to_be(*p.close.ej0);
+        z.w[0] ^= L.w[0] ^ ej.w[0]; z.w[1] ^= L.w[1] ^ ej.w[1]; z.w[2] ^= L.w[2] ^ ej.w[2]; z.w[3] ^= L.w[3] ^ ej.w[3];
+    }
+    if (lane == 0) acc_arrive(p.close.acc, g, z, p.close.tag_out, p.close.tag_host, p.close.gen);
 }
 // nibble tables of H^(2^k), k = 6..31, once per key (after k_setup)
 __global__ __launch_bounds__(512) void k_setup_ptab(KeyMaterial *km) {
@@ -1227,6 +1258,7 @@ struct aesgcm_ctx {
     // host 11 us after its last instruction.  (Three launches, AESGCM_CYC_FUSE=0: 26 (k_main) / 56.)
     bool cyc_wt = AESGCM_BODY_WT != 0; // (the dealt k_body stores through the L2 as well: the end of a 16 GiB launch has less to write back, step 16.90 -> 16.79 ms, 1 GiB 1140 -> 1118 us,
                                        // profiles/r03c/body_wt_ab; compile-time: -DAESGCM_BODY_WT=0)
+    bool fold_close = true;            // whole messages through the dealt k_body: k_fold's first level closes the tag (FoldClose; AESGCM_FOLD_CLOSE=0: further levels and k_combine)
     u32 cyc_prio = 2;                  // rows between rotations of the waves' issue priorities in a cyclic launch (body_prio; AESGCM_CYC_PRIO, 0 = off).  Without it the oldest wave of
                                        // every SIMD runs ahead and the youngest finishes alone: 256 MiB 321 -> 291 us, 1 GiB 1238 -> 1105 (dealt chunks: 1090), profiles/r03c/cyc_prio_*.txt
     bool cyc_wait_end = false;
@@ -1311,6 +1343,7 @@ static int set_lds_attrs(int device, DeviceState *ds) {
     SETATTRY(10, MODE_ENC, true); SETATTRY(12, MODE_ENC, true); SETATTRY(14, MODE_ENC, true); SETATTRY(10, MODE_DEC, true); SETATTRY(12, MODE_DEC, true); SETATTRY(14, MODE_DEC, true);
     SETATTRY(10, MODE_PROBE, false); SETATTRY(12, MODE_PROBE, false); SETATTRY(14, MODE_PROBE, false);
 #undef SETATTRY
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fold), hipFuncAttributeMaxDynamicSharedMemorySize, FOLD_LDS_CLOSE_BYTES));
 #define SETATTRB(NR, D) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch<NR, D>), hipFuncAttributeMaxDynamicSharedMemorySize, BATCH_LDS_BYTES)); \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktg<NR, D, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, PKTG_LDS_TOTAL(2))); \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktg<NR, D, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, PKTG_LDS_TOTAL(3))); \
@@ -1352,9 +1385,25 @@ static const uint4 *ptab_ptr(const aesgcm_ctx *c, u64 e) {
     return k < 0 ? nullptr : reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(c->km) + offsetof(KeyMaterial, ptab)) + (size_t)k * 512;
 }
 // k_fold levels: n items (period, eA, eB as in FoldParams) -> one item (left in parts, fold_a or fold_b)
-static int enqueue_fold(aesgcm_ctx *c, const uint4 *items, u32 n, u32 period, u64 eA, u64 eB, hipStream_t st, Partials *po) {
+#define FOLD_CLOSE_MAX_WGS 512u
+static int enqueue_fold(aesgcm_ctx *c, const uint4 *items, u32 n, u32 period, u64 eA, u64 eB, hipStream_t st, Partials *po, const FoldClose *close = nullptr) {
     const uint4 *cur = items;
     int which = 0;
+    if (close && n > COMBINE_MAX_ITEMS && fold_wgs(n, fold_group(n, period)) <= FOLD_CLOSE_MAX_WGS) {
+        // a whole message: the first level closes the tag itself (FoldClose) -- one launch behind the fused kernel instead of two or three.  Every closing workgroup
+        // stages the lanes' tables (33 KB) and spends ~4 us: with the 256 workgroups of a 1 GiB message that is one round on the chip and the step gains 11 us
+        // (cfg2: 976 -> 963 us); with the 2048 of 16 GiB it is eight rounds and costs what the second level and k_combine did (profiles/r03c/fold_close_ab.txt)
+        FoldParams f;
+        plan_fold(f, cur, c->fold_a, n, period, eA, eB);
+        f.tabA = ptab_ptr(c, f.eA); f.tabB = ptab_ptr(c, f.eB); f.tabC = ptab_ptr(c, f.eC);
+        f.close = *close;
+        f.close.on = 1; f.close.step = fold_out_step(f);
+        const u32 G = fold_wgs(n, f.group);
+        hipLaunchKernelGGL(k_fold, dim3(G), dim3(FOLD_WG), FOLD_LDS_CLOSE_BYTES, st, c->km, f);
+        HIPCHK(hipGetLastError());
+        po->done = true;
+        return AESGCM_OK;
+    }
     while (n > 1) {
         // the last level(s) can be k_combine's own: up to 64 items whose spacing has precomputed tables
         if (period <= 1 && n <= COMBINE_MAX_ITEMS && ptab_ptr(c, eA) && (n <= 4 || ptab_ptr(c, 4 * eA)) && (n <= 16 || ptab_ptr(c, 16 * eA))) {
@@ -1470,7 +1519,7 @@ static int launch_body(aesgcm_ctx *c, int mode, BodyParams &p, u32 wgs, hipStrea
 }
 // k_body over the planned split + the k_fold levels over its interleaved chunk items
 static int enqueue_body(aesgcm_ctx *c, int mode, const uint8_t iv[12], const BodySplit &b, const void *d_in, void *d_out,
-                        u64 first_block, hipStream_t st, Partials *po) {
+                        u64 first_block, hipStream_t st, Partials *po, const FoldClose *close = nullptr) {
     BodyParams p;
     memset(&p, 0, sizeof p);
     int rc = grow_parts(c, (size_t)4 * b.S);
@@ -1489,7 +1538,7 @@ static int enqueue_body(aesgcm_ctx *c, int mode, const uint8_t iv[12], const Bod
     p.counter_zero = c->d_counter + 16 * (1 + AESGCM_NQ * (c->qset ^ 1u));
     if ((rc = launch_body(c, mode, p, wgs, st))) return rc;
     // items 4s + v: phases 64 blocks apart inside a super-chunk, super-chunks 256 T blocks apart
-    return enqueue_fold(c, c->parts, p.C, 4, 64, (u64)256 * b.T, st, po);
+    return enqueue_fold(c, c->parts, p.C, 4, 64, (u64)256 * b.T, st, po, close);
 }
 // A whole range -- AAD, data from any first block, ragged end -- as ONE k_body launch of cyclic rows (plan_body_cyc) and the k_fold level over its
 // 4096 items, when the range is of that size (*took says whether it was).  po describes the items and the partial last row for k_combine.
@@ -1621,7 +1670,13 @@ static int crypt_dev(aesgcm_ctx *c, int dec, const uint8_t iv[12], const void *d
             // the whole message is one aligned body (the benchmark's shape): no chaining value to carry, k_body's items go
             // straight to the tag
             Partials pb;
-            if ((rc = enqueue_body(c, dec ? MODE_DEC : MODE_ENC, iv, b, d_in, d_out, 0, st, &pb))) return rc;
+            FoldClose fc = {};
+            if (c->fold_close) {                                 // k_fold's first level closes the tag (when there is a k_fold launch at all)
+                fc.aad_len = 0; fc.ct_len = len; fc.ej0 = c->d_tag + 3; fc.acc = c->d_cyc;
+                fc.tag_out = c->d_tag; fc.tag_host = c->h_tag_dev; fc.gen = c->tag_gen + 1;
+            }
+            if ((rc = enqueue_body(c, dec ? MODE_DEC : MODE_ENC, iv, b, d_in, d_out, 0, st, &pb, c->fold_close ? &fc : nullptr))) return rc;
+            if (pb.done) { ++c->tag_gen; c->tag_in_launch = false; return AESGCM_OK; }
             CombineParams q = combine_with_items(plan_combine_tag(pb.ptr, pb.np, pb.kind, iv, 0, len, c->d_tag), pb.eA);
             q.ej0 = pb.ej0;
             return enqueue_combine(c, q, st);
@@ -1754,6 +1809,7 @@ static int ctx_create_common(aesgcm_ctx **out, int device, const uint8_t *key, s
     if (const char *e = getenv("AESGCM_CYC_FUSE")) { c->cyc_fuse = atoi(e) != 0; c->cyc_wait_end = atoi(e) == 2; c->cyc_wt = AESGCM_BODY_WT != 0 && atoi(e) != 1 && atoi(e) != 2; }   // 0: k_fold + k_combine; 1: + write-back; 2: wait for the end; default: nothing (the rows went through the L2)
     if (const char *e = getenv("AESGCM_POLL_US")) c->poll_ns = 1000L * atol(e);
     if (const char *e = getenv("AESGCM_CYC_PRIO")) c->cyc_prio = (u32)strtoul(e, nullptr, 0);
+    if (const char *e = getenv("AESGCM_FOLD_CLOSE")) c->fold_close = atoi(e) != 0;
     if (const char *e = getenv("AESGCM_BODY_CYC")) {
         char *end = nullptr;
         const u64 lo = strtoull(e, &end, 0);

@@ -198,13 +198,41 @@ struct Parts { const uint4 *ptr; u32 np; u32 gathered; u64 eA; const uint4 *tail
 struct Emu {
     KeyMaterial km; u32 tw; std::vector<uint4> parts, fold_a, fold_b;
     u32 n_cyc = 0;                  // launches that went through run_cyc()
+    u32 n_fold_close = 0;           // messages whose tag came out of k_fold's closing
     bool fuse = true;               // whole messages: the cyclic launch closes the tag itself (cyc_close)
     bool cyc = false; u64 cyc_min = 1024;   // ranges with at least one whole body row as cyclic rows of k_body (every size) instead of the pieces
     Emu(const uint8_t *key, int key_len, u32 tw_) : tw(tw_), parts(1 << 16), fold_a(1 << 16), fold_b(1 << 12) { emu_setup(&km, key, key_len, 0, 512); }
     // mirrors enqueue_fold(): k_fold launches until one item is left
-    Parts fold(const uint4 *items, u32 n, u32 period, u64 eA, u64 eB) {
+    // mirrors k_fold's closing (FoldClose): the workgroups of the first level turn their output items into the tag
+    bool fold_close = true;
+    void fold_closing(const FoldParams &f, u32 G, u64 aad_len, u64 ct_len, uint4 ej0, uint4 *tag_out) {
+        static unsigned char lds[FOLD_LDS_CLOSE_BYTES] __attribute__((aligned(16)));
+        for (u32 k = 0; k < 2048; k++) *reinterpret_cast<uint4 *>(lds + cyc_ltab_off(k, FOLD_LDS_LTAB)) = cyc_ltab_entry(&km, k, 0u);
+        const u64 step = fold_out_step(f);
+        G128 slots[CYC_ACC_SLOTS];
+        memset(slots, 0, sizeof slots);
+        for (u32 gg = 0; gg < G; gg++) {
+            const u32 g = (gg * 29u + 3u) % G == gg ? gg : G - 1 - gg;      // any arrival order
+            G128 z = {{0, 0, 0, 0}};
+            for (u32 lane = 0; lane < 64; lane++) xor_g(z, cyc_lane_term_lds(lds, f.out[(size_t)g * 64 + lane], lane, FOLD_LDS_LTAB));
+            const u64 e = step * (u64)(G - 1 - g);
+            for (u32 d = 0; d < 4; d++) {
+                const u32 dig = (u32)(e >> (AESGCM_LOG_WG * d)) & (u32)(AESGCM_WG - 1);
+                if (!dig) continue;
+                for (u32 lane = 0; lane < 32; lane++) *reinterpret_cast<uint4 *>(lds + FOLD_LDS_WTAB + 16u * lane) = shoup2_entry(mo_to_be(km.pw[d][dig]), lane);
+                z = shoup2_gmul_lds(z, reinterpret_cast<const uint4 *>(lds + FOLD_LDS_WTAB));
+            }
+            if (g + 1 == G) { xor_g(z, tag_len_term(&km, aad_len, ct_len)); xor_g(z, mo_to_be(ej0)); }
+            xor_g(slots[g & (CYC_ACC_SLOTS - 1u)], z);
+        }
+        G128 t = {{0, 0, 0, 0}};
+        for (u32 k = 0; k < CYC_ACC_SLOTS; k++) xor_g(t, slots[k]);
+        *tag_out = be_to_mo(t);
+    }
+    Parts fold(const uint4 *items, u32 n, u32 period, u64 eA, u64 eB, const CombineParams *close = nullptr, uint4 *close_tag = nullptr) {
         static unsigned char smem[FOLD_LDS_BYTES] __attribute__((aligned(16)));
         const uint4 *cur = items; int which = 0;
+        bool first = true;
         while (n > 1) {
             {   // mirrors enqueue_fold(): the last level(s) belong to k_combine when the spacing has tables
                 auto has = [&](u64 e) { return ptab_index(e) >= 0; };
@@ -229,6 +257,13 @@ struct Emu {
                     *reinterpret_cast<uint4 *>(smem + FOLD_LDS_TAB + w * 1024u + lane * 16u) = fold_wave_lane(f, smem, start, end, J, w, lane);
                 for (u32 lane = 0; lane < 64; lane++) f.out[(size_t)g * 64 + lane] = fold_wg_lane(smem, J, lane);
             }
+            if (first && close && fold_close && n > COMBINE_MAX_ITEMS && G <= 512) {      // mirrors enqueue_fold(): the first level closes a whole message itself
+                CHECK(close->ej0 != nullptr, "fold closing without E_K(J0)");
+                fold_closing(f, G, close->aad_len, close->ct_len, *close->ej0, close_tag);
+                Parts q = {nullptr, 0, PARTS_NONE, 0};
+                return q;
+            }
+            first = false;
             eA = fold_out_step(f); eB = 0; period = 1; cur = f.out; n = G; which ^= 1;
         }
         Parts r = {cur, 1, PARTS_ITEM, 0};
@@ -251,12 +286,12 @@ struct Emu {
         return fold(parts.data(), C, 1, eA, 0);
     }
     // mirrors enqueue_body(): k_body + k_fold with the interleaved first level
-    Parts run_body(int mode, const uint8_t *iv, const BodySplit &b, const void *in, void *out, u64 first_block) {
+    Parts run_body(int mode, const uint8_t *iv, const BodySplit &b, const void *in, void *out, u64 first_block, const CombineParams *close = nullptr, uint4 *close_tag = nullptr) {
         BodyParams p; memset(&p, 0, sizeof p);
         if (parts.size() < 256 * (size_t)b.S) parts.resize(256 * (size_t)b.S);
         plan_body(p, b, iv, in, out, first_block, parts.data());
         emu_body(mode, &km, p);
-        return fold(parts.data(), p.C, 4, 64, (u64)256 * b.T);
+        return fold(parts.data(), p.C, 4, 64, (u64)256 * b.T, close, close_tag);
     }
     // mirrors enqueue_cyc(): the whole range as cyclic rows of k_body + one k_fold level; false = the range is not of that size
     bool run_cyc(int mode, const uint8_t *iv, const void *aad, u64 aad_len, const void *in, u64 len, void *out, u64 first_block, Parts *po, uint4 *fused_tag = nullptr) {
@@ -317,8 +352,12 @@ struct Emu {
         BodySplit b0;
         if (plan_body_split(len, 0, tw, body_min, &b0) && !aad_len && !b0.head_blocks && len == 16 * b0.body_blocks) {
             // the whole message is one aligned body: k_body's items go straight to the tag (no chaining value)
-            Parts pb = run_body(dec ? MODE_DEC : MODE_ENC, iv, b0, in, out, 0);
-            emu_combine(&km, combine_with_items(plan_combine_tag(pb.ptr, pb.np, pb.gathered, iv, 0, len, &t), pb.eA));
+            CombineParams q0 = plan_combine_tag(nullptr, 0, PARTS_NONE, iv, 0, len, &t);
+            const uint4 ej0 = be_to_mo(combine_ej0_bytes(&km, g_tb.sbox, q0));      // what k_body's chunk-0 wave leaves behind
+            q0.ej0 = &ej0;
+            Parts pb = run_body(dec ? MODE_DEC : MODE_ENC, iv, b0, in, out, 0, &q0, &t);
+            if (pb.gathered != PARTS_NONE || pb.np) emu_combine(&km, combine_with_items(plan_combine_tag(pb.ptr, pb.np, pb.gathered, iv, 0, len, &t), pb.eA));
+            else ++n_fold_close;
             memcpy(tag, &t, 16);
             return true;
         }
@@ -667,6 +706,7 @@ static void test_body(int key_len, u32 G, u64 al, u64 n, u64 seed, bool cyc = fa
     const bool split = E.crypt_split(0, iv.data(), aad.data(), al, pt.p, n, ct.p, tag, 4096);
     CHECK(split, "body split did not apply: len %llu G %u", (unsigned long long)n, G);
     CHECK(!cyc || E.n_cyc == 1, "cyclic rows did not take the message: len %llu", (unsigned long long)n);
+    CHECK(cyc || al || (n % 4096) || n < 16 * 256 * 40 || E.n_fold_close == 1, "k_fold did not close the message: len %llu", (unsigned long long)n);
     CHECK(memcmp(ct.p, ref.p, n) == 0, "body ct key %d G %u aad %llu len %llu", key_len, G, (unsigned long long)al, (unsigned long long)n);
     CHECK(memcmp(tag, rtag, 16) == 0, "body tag key %d G %u aad %llu len %llu", key_len, G, (unsigned long long)al, (unsigned long long)n);
     CHECK(ct.p[n] == 0xA5, "body overrun");
@@ -774,7 +814,8 @@ int main(int argc, char **argv) {
     test_body(32, 3, 37, 16 * 9000, 103);
     test_body(32, 1, 16, 16 * 254 + 16 * 1024 * 2, 104);          // head = 254 blocks exactly, empty tail
     test_body(16, 2, 0, 16 * 256 * 2 * 6, 106);                     // no AAD, no head, no tail: the whole message is one body (direct tag path)
-    test_body(32, 1, 0, 16 * 256 * 300, 107);                       // ... with enough items for a k_fold level before k_combine's own fold
+    test_body(32, 1, 0, 16 * 256 * 300, 107);                       // ... with enough items for a k_fold level: its ten workgroups close the tag themselves (FoldClose)
+    test_body(24, 3, 0, 16 * 256 * 3 * 40, 116);                    // ... three rows per chunk: the weight of the first workgroup is H^(24576), digit 24 of radix 1024
     test_body(16, 1, 0, 16 * 256 * 7, 108, true);                   // cyclic rows: 28 rows, the other strands leave zero items; the whole message is the body
     test_body(32, 2, 21, 16 * (100 + 256 * 40 + 70) + 3, 109, true); // ... with AAD (a front row), a ragged partial last row, and as shards from odd first blocks (head blocks in the front rows)
     test_body(24, 1, 16 * 70 + 3, 16 * 64 * 9 + 1023, 112, true);   // two front rows of AAD, the longest last row there is (63 blocks + 15 bytes = 64 blocks)
