@@ -370,8 +370,9 @@ def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 20; cfg2, whose step is 1 ms: 100)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps in front (default 3; cfg2: 50 -- the chip takes 10 - 20 ms under load to reach its clock, "
+                    "profiles/r03c/cfg2_warmup.txt: 3 warmup + 20 timed steps of 1 ms measure the ramp, 1030 GiB/s against 1165)")
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS), help="workload (default: the metric's cfg3; N > 1 stream runs are cfg4)")
     ap.add_argument("--gib-per-gpu", type=float, default=None, help="override: resident plaintext per GPU (no fixture check)")
     ap.add_argument("--key-bits", type=int, default=None, choices=(128, 192, 256), help="override (no fixture check)")
@@ -395,6 +396,11 @@ def main(argv=None):
     ap.add_argument("--of", type=int, default=8, help="world size emulated by --emulate-rank")
     ap.add_argument("--launch-timeout", type=float, default=3000.0, help="self-launch: seconds before hung ranks are killed")
     args = ap.parse_args(argv)
+    short_steps = args.config == "cfg2" and args.gib_per_gpu is None      # 1 ms per step
+    if args.steps is None:
+        args.steps = 100 if short_steps else 20
+    if args.warmup is None:
+        args.warmup = 50 if short_steps else 3
 
     if "RANK" not in os.environ and args.gpus > 1 and args.emulate_rank is None:
         return self_launch(args, argv)                           # before anything touches the GPU
