@@ -1583,6 +1583,8 @@ HD G128 shoup_mul(G128 y, const unsigned char *lds, u32 tab) {
 #define BATCH2_LDS_BYTES(LG) (BATCH2_LDS_TAB_OFF + (AESGCM_WG / 64u) * (64u >> (LG)) * BATCH2_GROUP_LDS)
 #define BATCH3_GROUP_LDS 1056u                  /* k_batch3: the same two table pairs, then the packet's H and E_K(J0) (16 bytes each) */
 #define BATCH3_LDS_BYTES (BATCH2_LDS_TAB_OFF + (AESGCM_WG / 64u) * 4u * BATCH3_GROUP_LDS)
+#define BATCH3_GROUP_LDS_LG(LG) ((LG) >= 4 ? BATCH3_GROUP_LDS : 544u)      /* 8 lanes per packet: 128 packets per workgroup, ONE table slot each + H and E_K(J0) */
+#define BATCH3_LDS_BYTES_LG(LG) (BATCH2_LDS_TAB_OFF + (AESGCM_WG / 64u) * (64u >> (LG)) * BATCH3_GROUP_LDS_LG(LG))
 // Y * c through the two tables at LDS byte offsets tab (Th) and tab + 256 (Tl), entries = 4 BE words
 HD G128 shoup2_mul(G128 y, const unsigned char *lds, u32 tab) {
     u32 z0 = 0, z1 = 0, z2 = 0, z3 = 0;

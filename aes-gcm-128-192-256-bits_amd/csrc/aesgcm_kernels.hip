@@ -947,16 +947,20 @@ __global__ __launch_bounds__(AESGCM_WG, 4) void k_batch2(const DevTables *__rest
 #else
 #define BATCH3_LANES(NR) AESGCM_WG
 #endif
-template <int NR, int DEC>
+// LG = 4: 16 lanes per packet, four packets per wave, two table slots per packet (the closing alternates between them).  LG = 3: 8 lanes per packet, eight
+// packets per wave -- what a wave-iteration pays once (key schedule, H and E_K(J0), the H^8 table, the closing) now serves eight packets, and the tree is a
+// level shorter; 128 packets per workgroup leave LDS for ONE table slot each, so the closing rebuilds that slot between its multiplies.
+template <int NR, int DEC, int LG>
 __global__ __launch_bounds__(BATCH3_LANES(NR), (BATCH3_LANES(NR) + 255) / 256) void k_batch3(const DevTables *__restrict__ tb, const BatchParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int LG = 4;
     constexpr u32 G = 1u << LG, P = 64u >> LG;
+    constexpr u32 GRP_LDS = BATCH3_GROUP_LDS_LG(LG), SLOT = GRP_LDS - 32u;      // the packet's H and E_K(J0) sit behind its table slot(s)
+    constexpr bool ONE_TAB = LG < 4;
     const u32 tid = threadIdx.x, lane = tid & 63u;
     main_fill_lds(smem, nullptr, tb, tid, false, BATCH3_LANES(NR));
     __syncthreads();
     const u32 lb = (lane & 31u) << 2;
-    const u32 wave_tab = BATCH2_LDS_TAB_OFF + (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6)) * P * BATCH3_GROUP_LDS;     // scalar
+    const u32 wave_tab = BATCH2_LDS_TAB_OFF + (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6)) * P * GRP_LDS;     // scalar
     constexpr u32 KEYLEN = 4 * (NR - 6);
     const u32 K = p.deal, nb = (p.n_pkts + K - 1) / K;
     u32 pk0 = 0, pk_end = 0;
@@ -971,7 +975,7 @@ __global__ __launch_bounds__(BATCH3_LANES(NR), (BATCH3_LANES(NR) + 255) / 256) v
         }
         // the lane's position from a fresh lane id here and again behind the block loop (lane_id_fresh), so that none of it stays in a register across the loop
         const u32 lane1 = lane_id_fresh(), grp = lane1 >> LG, l = lane1 & (G - 1u);
-        const u32 tabA = wave_tab + grp * BATCH3_GROUP_LDS;
+        const u32 tabA = wave_tab + grp * GRP_LDS;
         const bool act = pk0 + grp < pk_end;                 // groups past the end shadow the first packet; their stores are masked
         const u32 pkt = act ? pk0 + grp : pk0;
         const unsigned char *key = p.keys + (size_t)pkt * KEYLEN;
@@ -1000,15 +1004,17 @@ __global__ __launch_bounds__(BATCH3_LANES(NR), (BATCH3_LANES(NR) + 255) / 256) v
             u32 s3 = (l == 0 ? 0u : 0x01000000u) ^ rk[3];
             aes_rounds_lds<NR>(s0, s1, s2, s3, rk, smem, lb);
             const G128 e = mo_to_be(make_uint4(s0, s1, s2, s3));
-            if (l < 2) *reinterpret_cast<uint4 *>(smem + tabA + 1024u + 16u * l) = make_uint4(e.w[0], e.w[1], e.w[2], e.w[3]);
+            if (l < 2) *reinterpret_cast<uint4 *>(smem + tabA + SLOT + 16u * l) = make_uint4(e.w[0], e.w[1], e.w[2], e.w[3]);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         {
-            const uint4 hv = *reinterpret_cast<const uint4 *>(smem + tabA + 1024u);
+            const uint4 hv = *reinterpret_cast<const uint4 *>(smem + tabA + SLOT);
             G128 h; h.w[0] = hv.x; h.w[1] = hv.y; h.w[2] = hv.z; h.w[3] = hv.w;
-            shoup2_build<LG>(smem, tabA, gf_sqr(gf_sqr(gf_sqr(gf_sqr(h)))), l);        // Horner stride H^16 (squaring is linear: gf_sqr, no table)
+            G128 hs = gf_sqr(gf_sqr(gf_sqr(h)));                                       // Horner stride H^(lanes per packet): LG squarings (linear: gf_sqr, no table)
+            if (LG == 4) hs = gf_sqr(hs);
+            shoup2_build<LG>(smem, tabA, hs, l);
         }
 
         // ---- one pass: CTR on the lane's blocks and Horner over its slots
@@ -1045,27 +1051,30 @@ __global__ __launch_bounds__(BATCH3_LANES(NR), (BATCH3_LANES(NR) + 255) / 256) v
 
         // ---- closing: P = sum_l B_l H^(15-l);  tag = P H^2 ^ L H ^ E_K(J0)  (gcm_ghash.vhd:257,293), as in k_pktg
         const u32 lane2 = lane_id_fresh(), grp2 = lane2 >> LG, l2 = lane2 & (G - 1u);
-        const u32 tabA2 = wave_tab + grp2 * BATCH3_GROUP_LDS, tabB2 = tabA2 + 512u;
+        const u32 tabA2 = wave_tab + grp2 * GRP_LDS, tabB2 = ONE_TAB ? tabA2 : tabA2 + 512u;
         const bool act2 = pk0 + grp2 < pk_end;
         const u32 pkt2 = act2 ? pk0 + grp2 : pk0;
         G128 h;
-        { const uint4 hv = *reinterpret_cast<const uint4 *>(smem + tabA2 + 1024u); h.w[0] = hv.x; h.w[1] = hv.y; h.w[2] = hv.z; h.w[3] = hv.w; }
+        { const uint4 hv = *reinterpret_cast<const uint4 *>(smem + tabA2 + SLOT); h.w[0] = hv.x; h.w[1] = hv.y; h.w[2] = hv.z; h.w[3] = hv.w; }
         G128 c = gf_sqr(h);                                     // H^2
+        if (ONE_TAB) __builtin_amdgcn_wave_barrier();           // every lane is done with the Horner table
         shoup2_build<LG>(smem, tabB2, c, l2);
         acc = shoup2_mul(acc, smem, tabB2);
         if (l2 == G - 2u) { acc.w[1] ^= aad_len * 8u; acc.w[3] ^= pkt_len * 8u; }     // the length block: both < 2^32 bits by the ABI's limits
+        if (ONE_TAB) __builtin_amdgcn_wave_barrier();
         shoup2_build<LG>(smem, tabA2, h, l2);                   // the Horner table is no longer needed
 #pragma unroll
         for (int j = 0; j < LG; j++) {
-            // level j: constant H^(2^j); H in tabA, H^2 in tabB, then H^4 -> tabA, H^8 -> tabB
-            if (j >= 2) { c = gf_sqr(c); shoup2_build<LG>(smem, (j & 1) ? tabB2 : tabA2, c, l2); }
+            // level j: constant H^(2^j); two slots: H in tabA, H^2 in tabB, then H^4 -> tabA, H^8 -> tabB; one slot: each level rebuilds it (c = H^2 is still at hand for level 1)
+            if (ONE_TAB) { if (j >= 1) { if (j >= 2) c = gf_sqr(c); __builtin_amdgcn_wave_barrier(); shoup2_build<LG>(smem, tabA2, c, l2); } }
+            else if (j >= 2) { c = gf_sqr(c); shoup2_build<LG>(smem, (j & 1) ? tabB2 : tabA2, c, l2); }
             const G128 t = shoup2_mul(acc, smem, (j & 1) ? tabB2 : tabA2);
             G128 o;
             o.w[0] = lane_xor_pow2(t.w[0], j); o.w[1] = lane_xor_pow2(t.w[1], j);
             o.w[2] = lane_xor_pow2(t.w[2], j); o.w[3] = lane_xor_pow2(t.w[3], j);
             if (l2 & (1u << j)) { acc.w[0] ^= o.w[0]; acc.w[1] ^= o.w[1]; acc.w[2] ^= o.w[2]; acc.w[3] ^= o.w[3]; }
         }
-        { const uint4 ev = *reinterpret_cast<const uint4 *>(smem + tabA2 + 1040u); acc.w[0] ^= ev.x; acc.w[1] ^= ev.y; acc.w[2] ^= ev.z; acc.w[3] ^= ev.w; }
+        { const uint4 ev = *reinterpret_cast<const uint4 *>(smem + tabA2 + SLOT + 16u); acc.w[0] ^= ev.x; acc.w[1] ^= ev.y; acc.w[2] ^= ev.z; acc.w[3] ^= ev.w; }
         if (l2 == G - 1u && act2) {
             const uint4 tag = be_to_mo(acc);
             store_block_bytes(p.tags + (size_t)pkt2 * 16, tag, 16);
@@ -1356,7 +1365,8 @@ static int set_lds_attrs(int device, DeviceState *ds) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_combine_batch), hipFuncAttributeMaxDynamicSharedMemorySize, CMB_LDS_BYTES));
 #define SETATTRB2(NR, D, LG) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch2<NR, D, LG>), hipFuncAttributeMaxDynamicSharedMemorySize, BATCH2_LDS_BYTES(LG)))
     SETATTRB2(10, 0, 4); SETATTRB2(12, 0, 4); SETATTRB2(14, 0, 4); SETATTRB2(10, 1, 4); SETATTRB2(12, 1, 4); SETATTRB2(14, 1, 4);
-#define SETATTRB3(NR, D) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch3<NR, D>), hipFuncAttributeMaxDynamicSharedMemorySize, BATCH3_LDS_BYTES))
+#define SETATTRB3(NR, D) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch3<NR, D, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, BATCH3_LDS_BYTES_LG(4))); \
+                         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch3<NR, D, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, BATCH3_LDS_BYTES_LG(3)))
     SETATTRB3(10, 0); SETATTRB3(12, 0); SETATTRB3(14, 0); SETATTRB3(10, 1); SETATTRB3(12, 1); SETATTRB3(14, 1);
 #undef SETATTRB3
 
@@ -2408,11 +2418,17 @@ static int batch_launch(int device, int decrypt, size_t n_pkts, size_t key_len, 
     HIPCHK(hipMemsetAsync(p.counter, 0, 4, st));
     // shape: 16 lanes per packet in one pass (k_batch3: four packets share a wave's tree and closing multiplies) once there are
     // enough packets to fill the machine that way (one 1024-lane workgroup per CU = 64 packets per CU) or the packets are short,
-    // else one wave per packet (k_batch).  AESGCM_BATCH_LG=4|6 forces one.  Measured, AES-128, GiB/s k_batch / k_batch3
+    // else one wave per packet (k_batch).  AESGCM_BATCH_LG=3|4|6 forces one (3 = 8 lanes per packet, below).  Measured, AES-128, GiB/s k_batch / k_batch3
     // (profiles/r03/batch_sweep_aes128.txt): 4096 x 1 KiB 30 / 56, 4096 x 256 B 7.5 / 17, 1024 x 1 KiB 14 / 16.5; 1024 x 4 KiB
     // 45 / 33, 4096 x 4 KiB 108 / 120, 4096 x 16 KiB 286 / 168; from 16384 packets k_batch3 wins at every size (4 KiB 179 / 350).
     int lg = (n_pkts >= (size_t)64 * ds->n_cu || (!p.data_off && p.pkt_len <= 2048)) ? 4 : 6;
-    if (const char *e = getenv("AESGCM_BATCH_LG")) { const int v = atoi(e); if (v == 4 || v == 6) lg = v; }
+    // 8 lanes per packet (eight packets per wave share what a wave-iteration pays once) when there are packets enough to fill the chip that way and they are
+    // not long: 2^20 packets of 64 B 42 -> 74 GiB/s, 256 B 163 -> 265, 1 KiB 424 -> 560, 1500 B 484 -> 598, 4 KiB 658 -> 706 (cfg5: 646 -> 685), 16 KiB 770 -> 736;
+    // 16384 packets: 1 KiB 125 -> 155, 4 KiB 352 -> 273 (profiles/r03c/batch_sweep_lanes8_aes128.txt).  Batches with per-packet lengths keep 16 lanes.
+    if (lg == 4 && fused_default() && !p.data_off &&
+        ((n_pkts >= (size_t)256 * ds->n_cu && p.pkt_len <= 8192) || (n_pkts >= (size_t)64 * ds->n_cu && p.pkt_len <= 2048))) lg = 3;
+    if (const char *e = getenv("AESGCM_BATCH_LG")) { const int v = atoi(e); if (v == 3 || v == 4 || v == 6) lg = v; }
+    if (lg == 3 && !fused_default()) lg = 4;                          // 8 lanes per packet exist in the one-pass kernel only
     if (lg < 6) {
         const u32 waves_per_wg = (u32)(fused_default() ? BATCH3_LANES(nr) : AESGCM_WG) / 64;
         const u32 P = 64u >> lg, per_wg = waves_per_wg * P;
@@ -2423,10 +2439,11 @@ static int batch_launch(int device, int decrypt, size_t n_pkts, size_t key_len, 
         p.deal = deal;
         const bool fused = fused_default();
 #define LB2(NR, D, LG) hipLaunchKernelGGL((k_batch2<NR, D, LG>), dim3(wgs), dim3(AESGCM_WG), BATCH2_LDS_BYTES(LG), st, ds->tables, p)
-#define LB3(NR, D) hipLaunchKernelGGL((k_batch3<NR, D>), dim3(wgs), dim3(BATCH3_LANES(NR)), BATCH3_LDS_BYTES, st, ds->tables, p)
-#define LB2N(D, LG) do { if (fused) { if (nr == 10) LB3(10, D); else if (nr == 12) LB3(12, D); else LB3(14, D); } \
-                         else { if (nr == 10) LB2(10, D, LG); else if (nr == 12) LB2(12, D, LG); else LB2(14, D, LG); } } while (0)
-        if (decrypt) LB2N(1, 4); else LB2N(0, 4);
+#define LB3(NR, D, LG) hipLaunchKernelGGL((k_batch3<NR, D, LG>), dim3(wgs), dim3(BATCH3_LANES(NR)), BATCH3_LDS_BYTES_LG(LG), st, ds->tables, p)
+#define LB2N(D, LG) do { if (fused) { if (nr == 10) LB3(10, D, LG); else if (nr == 12) LB3(12, D, LG); else LB3(14, D, LG); } \
+                         else { if (nr == 10) LB2(10, D, 4); else if (nr == 12) LB2(12, D, 4); else LB2(14, D, 4); } } while (0)
+        if (lg == 3) { if (decrypt) LB2N(1, 3); else LB2N(0, 3); }
+        else { if (decrypt) LB2N(1, 4); else LB2N(0, 4); }
 #undef LB2N
 #undef LB3
 #undef LB2

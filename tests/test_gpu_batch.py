@@ -9,12 +9,12 @@ from util import golden, batch_inputs, splitmix_bytes
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["default", "lanes16", "lanes16_twophase", "lanes64"], autouse=True)
+@pytest.fixture(params=["default", "lanes16", "lanes8", "lanes16_twophase", "lanes64"], autouse=True)
 def batch_shape(request, monkeypatch):
     """every test here runs with the host's own choice of kernel shape and with each shape forced: 16 lanes per packet in one
-    pass (k_batch3: four packets per wave, GHASH fused into the CTR loop), the same in two phases (k_batch2: encrypt, read the
+    pass (k_batch3: four packets per wave, GHASH fused into the CTR loop), 8 lanes per packet (eight packets per wave, one table slot each), 16 lanes in two phases (k_batch2: encrypt, read the
     ciphertext back) and 64 lanes per packet (k_batch) -- AESGCM_BATCH_LG / AESGCM_BATCH_FUSED are read at every launch"""
-    env = {"lanes16": {"AESGCM_BATCH_LG": "4", "AESGCM_BATCH_FUSED": "1"}, "lanes16_twophase": {"AESGCM_BATCH_LG": "4", "AESGCM_BATCH_FUSED": "0"},
+    env = {"lanes16": {"AESGCM_BATCH_LG": "4", "AESGCM_BATCH_FUSED": "1"}, "lanes8": {"AESGCM_BATCH_LG": "3", "AESGCM_BATCH_FUSED": "1"}, "lanes16_twophase": {"AESGCM_BATCH_LG": "4", "AESGCM_BATCH_FUSED": "0"},
            "lanes64": {"AESGCM_BATCH_LG": "6"}}.get(request.param, {})
     for k in ("AESGCM_BATCH_LG", "AESGCM_BATCH_FUSED"):
         if k in env:
