@@ -1399,21 +1399,6 @@ static const uint4 *ptab_ptr(const aesgcm_ctx *c, u64 e) {
 static int enqueue_fold(aesgcm_ctx *c, const uint4 *items, u32 n, u32 period, u64 eA, u64 eB, hipStream_t st, Partials *po, const FoldClose *close = nullptr) {
     const uint4 *cur = items;
     int which = 0;
-    if (close && n > COMBINE_MAX_ITEMS && fold_wgs(n, fold_group(n, period)) <= FOLD_CLOSE_MAX_WGS) {
-        // a whole message: the first level closes the tag itself (FoldClose) -- one launch behind the fused kernel instead of two or three.  Every closing workgroup
-        // stages the lanes' tables (33 KB) and spends ~4 us: with the 256 workgroups of a 1 GiB message that is one round on the chip and the step gains 11 us
-        // (cfg2: 976 -> 963 us); with the 2048 of 16 GiB it is eight rounds and costs what the second level and k_combine did (profiles/r03c/fold_close_ab.txt)
-        FoldParams f;
-        plan_fold(f, cur, c->fold_a, n, period, eA, eB);
-        f.tabA = ptab_ptr(c, f.eA); f.tabB = ptab_ptr(c, f.eB); f.tabC = ptab_ptr(c, f.eC);
-        f.close = *close;
-        f.close.on = 1; f.close.step = fold_out_step(f);
-        const u32 G = fold_wgs(n, f.group);
-        hipLaunchKernelGGL(k_fold, dim3(G), dim3(FOLD_WG), FOLD_LDS_CLOSE_BYTES, st, c->km, f);
-        HIPCHK(hipGetLastError());
-        po->done = true;
-        return AESGCM_OK;
-    }
     while (n > 1) {
         // the last level(s) can be k_combine's own: up to 64 items whose spacing has precomputed tables
         if (period <= 1 && n <= COMBINE_MAX_ITEMS && ptab_ptr(c, eA) && (n <= 4 || ptab_ptr(c, 4 * eA)) && (n <= 16 || ptab_ptr(c, 16 * eA))) {
@@ -1424,6 +1409,18 @@ static int enqueue_fold(aesgcm_ctx *c, const uint4 *items, u32 n, u32 period, u6
         plan_fold(f, cur, which ? c->fold_b : c->fold_a, n, period, eA, eB);
         f.tabA = ptab_ptr(c, f.eA); f.tabB = ptab_ptr(c, f.eB); f.tabC = ptab_ptr(c, f.eC);
         const u32 G = fold_wgs(n, f.group);
+        if (close && G <= FOLD_CLOSE_MAX_WGS) {
+            // a whole message: this level closes the tag itself (FoldClose) -- no further level, no k_combine.  Every closing workgroup stages the lanes' tables (33 KB)
+            // and spends ~4 us: the 256 workgroups of a 1 GiB message's first level are one round on the chip and the step gains 11 us (cfg2: 976 -> 963 us); the
+            // 2048 of 16 GiB would be eight rounds and cost what they save (profiles/r03c/fold_close_ab.txt), so there the first level stays plain and the second
+            // (64 workgroups) closes
+            f.close = *close;
+            f.close.on = 1; f.close.step = fold_out_step(f);
+            hipLaunchKernelGGL(k_fold, dim3(G), dim3(FOLD_WG), FOLD_LDS_CLOSE_BYTES, st, c->km, f);
+            HIPCHK(hipGetLastError());
+            po->done = true;
+            return AESGCM_OK;
+        }
         if (G > (which ? FOLD_B_ITEMS : FOLD_A_ITEMS)) { snprintf(g_err, sizeof g_err, "k_fold: %u output items do not fit the level's buffer", G); return AESGCM_EHIP; }
         hipLaunchKernelGGL(k_fold, dim3(G), dim3(FOLD_WG), FOLD_LDS_BYTES, st, c->km, f);
         HIPCHK(hipGetLastError());

@@ -257,7 +257,7 @@ struct Emu {
                     *reinterpret_cast<uint4 *>(smem + FOLD_LDS_TAB + w * 1024u + lane * 16u) = fold_wave_lane(f, smem, start, end, J, w, lane);
                 for (u32 lane = 0; lane < 64; lane++) f.out[(size_t)g * 64 + lane] = fold_wg_lane(smem, J, lane);
             }
-            if (first && close && fold_close && n > COMBINE_MAX_ITEMS && G <= 512) {      // mirrors enqueue_fold(): the first level closes a whole message itself
+            if (close && fold_close && G <= 512) {      // (first is kept for the bookkeeping below)      // mirrors enqueue_fold(): the first level closes a whole message itself
                 CHECK(close->ej0 != nullptr, "fold closing without E_K(J0)");
                 fold_closing(f, G, close->aad_len, close->ct_len, *close->ej0, close_tag);
                 Parts q = {nullptr, 0, PARTS_NONE, 0};
