@@ -396,11 +396,16 @@ def main(argv=None):
     ap.add_argument("--of", type=int, default=8, help="world size emulated by --emulate-rank")
     ap.add_argument("--launch-timeout", type=float, default=3000.0, help="self-launch: seconds before hung ranks are killed")
     args = ap.parse_args(argv)
-    short_steps = args.config == "cfg2" and args.gib_per_gpu is None      # 1 ms per step
+    # defaults: 3 warmup + 20 timed steps, except where a step is so short that those would sit inside the chip's clock ramp (10 - 20 ms under load): then about
+    # 50 ms of warmup and 100 ms timed (cfg2, 1 ms per step: 50 + 100; --gib-per-gpu 0.0625, 0.09 ms: 556 + 1112)
+    est_ms = None
+    if args.config != "cfg5":
+        est_ms = (args.gib_per_gpu if args.gib_per_gpu is not None else {"cfg2": 1.0, "cfg3": 16.0}.get(args.config, 16.0)) * 1.0
+    short_steps = est_ms is not None and est_ms < 5.0
     if args.steps is None:
-        args.steps = 100 if short_steps else 20
+        args.steps = min(5000, max(20, int(100.0 / est_ms + 0.999))) if short_steps else 20
     if args.warmup is None:
-        args.warmup = 50 if short_steps else 3
+        args.warmup = min(2500, max(3, int(50.0 / est_ms + 0.999))) if short_steps else 3
 
     if "RANK" not in os.environ and args.gpus > 1 and args.emulate_rank is None:
         return self_launch(args, argv)                           # before anything touches the GPU
