@@ -14,6 +14,7 @@ benchmarked path.
 """
 import os
 import struct
+import sys
 import tempfile
 import time
 
@@ -57,7 +58,15 @@ def _wait_read(path, nbytes, timeout):
         time.sleep(0.005)
 
 
-def share_bytes(name, data, rank, nbytes, timeout=180.0):
+# How long a rank waits for the others.  The first RCCL call of a process loads a 573 MB library: 5 s with the file cached, minutes on a
+# cold box (seen in round 3), and every rank of a node does it at the same time.  The waits below are upper bounds for that, sized to sit
+# together (pre-flight + unique id + communicator) inside the driver's 1800 s per command.
+WAIT_PREFLIGHT_S = 700.0      # every rank has loaded librccl and says so
+WAIT_UNIQUE_ID_S = 300.0      # rank 0 (its library already loaded) publishes the unique id
+WAIT_COMM_S = 600.0           # every rank is back from ncclCommInitRank
+
+
+def share_bytes(name, data, rank, nbytes, timeout=WAIT_UNIQUE_ID_S):
     """rank 0 publishes `data` (nbytes) under `name`; every rank returns it."""
     d = rendezvous_dir()
     path = os.path.join(d, name)
@@ -102,10 +111,26 @@ def make_exchange(rank, world, device, prefer="rccl"):
     d = rendezvous_dir()
     os.makedirs(d, exist_ok=True)
 
-    def agree(name, ok):
-        """every rank publishes ok/not ok under `name`; -> the list of all ranks' answers"""
+    def agree(name, ok, timeout):
+        """every rank publishes ok/not ok under `name`; -> the list of all ranks' answers (a rank that never answers counts as not ok)"""
         _write_atomic(os.path.join(d, "%s_%d" % (name, rank)), b"\x01" if ok else b"\x00")
-        return [_wait_read(os.path.join(d, "%s_%d" % (name, r)), 1, 900.0) == b"\x01" for r in range(world)]
+        out = []
+        for r in range(world):
+            try:
+                out.append(_wait_read(os.path.join(d, "%s_%d" % (name, r)), 1, timeout) == b"\x01")
+            except TimeoutError:
+                out.append(False)
+        return out
+
+    def complain(stage, err):
+        # the library's own words (aesgcm_comm_last_error: RCCL's error string) on EVERY rank's stderr; with NCCL_DEBUG=WARN in the
+        # environment (bench.py sets it for the ranks it starts) RCCL's warning lines are already there
+        try:
+            detail = lib.load().aesgcm_comm_last_error().decode()
+        except Exception:                       # noqa: BLE001
+            detail = ""
+        sys.stderr.write("aesgcm comm rank %d/%d device %d: %s failed: %s | %s\n" % (rank, world, device, stage, err, detail))
+        sys.stderr.flush()
 
     # pre-flight: can every rank load RCCL at all?  (a rank that cannot must not leave the others blocked inside ncclCommInitRank)
     ex, err = None, ""
@@ -114,13 +139,15 @@ def make_exchange(rank, world, device, prefer="rccl"):
         pre = True
     except Exception as e:                      # noqa: BLE001
         pre, err = False, repr(e)
-    oks = agree("rccl_pre", pre)
+        complain("loading RCCL (ncclGetUniqueId)", err)
+    oks = agree("rccl_pre", pre, WAIT_PREFLIGHT_S)
     if all(oks):
         try:
             ex = RcclExchange(rank, world, device)
         except Exception as e:                  # noqa: BLE001 -- any failure means "no RCCL on this rank"
             err = repr(e)
-        oks = agree("rccl_ok", ex is not None)
+            complain("ncclCommInitRank", err)
+        oks = agree("rccl_ok", ex is not None, WAIT_COMM_S)
     if all(oks):
         return ex
     if ex is not None:

@@ -206,6 +206,13 @@ int aesgcm_mgpu_ranks(const aesgcm_mgpu *m, int *n_ranks) {
     return AESGCM_OK;
 }
 
+// device g's context, borrowed (the bench's kernel timing and launch geometry; it stays the mgpu object's)
+int aesgcm_mgpu_ctx(aesgcm_mgpu *m, int g, aesgcm_ctx **out) {
+    if (!m || !out || g < 0 || g >= m->ndev) return AESGCM_EARG;
+    *out = m->ctx[g];
+    return AESGCM_OK;
+}
+
 int aesgcm_mgpu_crypt_dev(aesgcm_mgpu *m, int decrypt, const uint8_t iv[12], const void *d_aad_on_dev0, size_t aad_len,
                           const void *const *d_in, const size_t *shard_len, void *const *d_out, uint8_t tag[16]) {
     if (!m || !iv || !d_in || !shard_len || !d_out || (aad_len && !d_aad_on_dev0)) return AESGCM_EARG;

@@ -1533,11 +1533,8 @@ HD u32 gf_spread16(u32 x) {                                  // bit b -> bit 2b
     x = (x | (x << 2)) & 0x33333333u; x = (x | (x << 1)) & 0x55555555u;
     return x;
 }
-HD G128 gf_sqr(G128 a) {
-    // coefficient i sits in word i/32 at bit 31 - i%32; the upper half of word k spreads into product word 2k
-    u32 W[8];
-#pragma unroll
-    for (int k = 0; k < 4; k++) { W[2 * k] = gf_spread16(a.w[k] >> 16) << 1; W[2 * k + 1] = gf_spread16(a.w[k] & 0xFFFFu) << 1; }
+// a 256-coefficient polynomial (coefficient i in word i/32 at bit 31 - i%32) folded to 128: the upper half times x^128 = 1 + x + x^2 + x^7
+HD G128 gf_reduce256(const u32 *W) {
     const u32 h0 = W[4], h1 = W[5], h2 = W[6], h3 = W[7];    // coefficients 128..255
     // Hh * (1 + x + x^2 + x^7): plain right shifts, the bits that fall off the end are folded once more
     u32 t0 = h0 ^ (h0 >> 1) ^ (h0 >> 2) ^ (h0 >> 7);
@@ -1548,6 +1545,13 @@ HD G128 gf_sqr(G128 a) {
     t0 ^= v ^ (v >> 1) ^ (v >> 2) ^ (v >> 7);
     G128 r; r.w[0] = W[0] ^ t0; r.w[1] = W[1] ^ t1; r.w[2] = W[2] ^ t2; r.w[3] = W[3] ^ t3;
     return r;
+}
+HD G128 gf_sqr(G128 a) {
+    // the upper half of word k spreads into product word 2k
+    u32 W[8];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { W[2 * k] = gf_spread16(a.w[k] >> 16) << 1; W[2 * k + 1] = gf_spread16(a.w[k] & 0xFFFFu) << 1; }
+    return gf_reduce256(W);
 }
 // Y * c through the table at LDS byte offset `tab` (16 entries x 4 BE words) and the reduction table
 HD G128 shoup_mul(G128 y, const unsigned char *lds, u32 tab) {
@@ -1601,6 +1605,88 @@ HD G128 shoup2_mul(G128 y, const unsigned char *lds, u32 tab) {
     }
     G128 z; z.w[0] = z0; z.w[1] = z1; z.w[2] = z2; z.w[3] = z3;
     return z;
+}
+
+// The same product with the reduction DELAYED (round 4).  shoup2_mul shifts its 128-bit accumulator by a byte -- and reduces the
+// byte that falls out -- in front of every byte of y: 16 x 12 instructions that have nothing to do with the table.  Here byte
+// 4w + k of y contributes E = Th[hi] ^ Tl[lo] shifted by w WORDS (a register choice, no instruction) and 8k bits, so the bytes
+// are taken in the order k = 3..0, w = 0..3 into a 256-coefficient accumulator V that is shifted by a byte only between the four
+// k groups (3 x 8 v_alignbit) and folded to 128 coefficients once (gf_reduce256, the tail of gf_sqr).  Same 32 ds_read_b128,
+// ~180 VALU instead of ~320.  Degrees: E < 128, the largest shift is 120 -> V < 248 coefficients.
+HD G128 shoup2_mul_dr(G128 y, const unsigned char *lds, u32 tab) {      // tab: a multiple of 256
+    u32 V[8];
+    u32 y0 = y.w[0], y1 = y.w[1], y2 = y.w[2], y3 = y.w[3];
+    // tab is 256-byte aligned: the entry offset is ORed in (one v_and_or_b32 per address), Tl rides in the ds_read offset field
+#define SHOUP2_DR_LOADS \
+        const u32x4_t a0 = LDS_LD128(lds, (y0 & 0xF0u) | tab), c0 = LDS_LD128(lds, (((y0 << 4) & 0xF0u) | tab) + 256u); \
+        const u32x4_t a1 = LDS_LD128(lds, (y1 & 0xF0u) | tab), c1 = LDS_LD128(lds, (((y1 << 4) & 0xF0u) | tab) + 256u); \
+        const u32x4_t a2 = LDS_LD128(lds, (y2 & 0xF0u) | tab), c2 = LDS_LD128(lds, (((y2 << 4) & 0xF0u) | tab) + 256u); \
+        const u32x4_t a3 = LDS_LD128(lds, (y3 & 0xF0u) | tab), c3 = LDS_LD128(lds, (((y3 << 4) & 0xF0u) | tab) + 256u); \
+        y0 >>= 8; y1 >>= 8; y2 >>= 8; y3 >>= 8;
+    {   // k = 3, the lowest byte of every word: nothing to shift yet
+        SHOUP2_DR_LOADS
+        V[7] = 0;
+        V[6] = a3.w ^ c3.w;
+        V[5] = xor3(a3.z, c3.z, a2.w) ^ c2.w;
+        V[4] = xor3(xor3(a3.y, c3.y, a2.z), c2.z, a1.w) ^ c1.w;
+        V[3] = xor3(xor3(xor3(a3.x, c3.x, a2.y), c2.y, a1.z), c1.z, a0.w) ^ c0.w;
+        V[2] = xor3(xor3(a2.x, c2.x, a1.y), c1.y, a0.z) ^ c0.z;
+        V[1] = xor3(a1.x, c1.x, a0.y) ^ c0.y;
+        V[0] = a0.x ^ c0.x;
+    }
+    // a real loop over the other three k groups (eight table loads in flight, not 32: fully unrolled, the kernels that use it spilled)
+#pragma unroll 1
+    for (int t = 1; t < 4; t++) {
+        SHOUP2_DR_LOADS
+        // V >>= 8, then the group's eight entries at word offsets 0 .. 3
+        V[7] = (V[7] >> 8) | (V[6] << 24);
+        V[6] = xor3((V[6] >> 8) | (V[5] << 24), a3.w, c3.w);
+        V[5] = xor3((V[5] >> 8) | (V[4] << 24), a3.z, c3.z) ^ a2.w ^ c2.w;
+        V[4] = xor3(xor3((V[4] >> 8) | (V[3] << 24), a3.y, c3.y), a2.z, c2.z) ^ a1.w ^ c1.w;
+        V[3] = xor3(xor3(xor3((V[3] >> 8) | (V[2] << 24), a3.x, c3.x), a2.y, c2.y), a1.z, c1.z) ^ a0.w ^ c0.w;
+        V[2] = xor3(xor3((V[2] >> 8) | (V[1] << 24), a2.x, c2.x), a1.y, c1.y) ^ a0.z ^ c0.z;
+        V[1] = xor3((V[1] >> 8) | (V[0] << 24), a1.x, c1.x) ^ a0.y ^ c0.y;
+        V[0] = xor3(V[0] >> 8, a0.x, c0.x);
+    }
+#undef SHOUP2_DR_LOADS
+    return gf_reduce256(V);
+}
+
+// Half of that product, for the split of ONE multiply over TWO lanes (the reference's own trick, src/gcm_ghash.vhd:317-333:
+// X*H = (Xhi || 0)*H ^ (0 || Xlo)*H).  (s0, s1) are taken as words 0, 1 of the multiplicand: the owner of a value passes its words 0, 1,
+// the helper lane passes words 2, 3 and its partial then stands two WORDS further down (shoup2_pair_join).  16 table reads, unreduced
+// 6-word partial.  tab: a multiple of 256.
+HD void shoup2_half_dr(u32 s0, u32 s1, const unsigned char *lds, u32 tab, u32 *V) {
+#define SHOUP2_HALF_LOADS \
+        const u32x4_t a0 = LDS_LD128(lds, (s0 & 0xF0u) | tab), c0 = LDS_LD128(lds, (((s0 << 4) & 0xF0u) | tab) + 256u); \
+        const u32x4_t a1 = LDS_LD128(lds, (s1 & 0xF0u) | tab), c1 = LDS_LD128(lds, (((s1 << 4) & 0xF0u) | tab) + 256u); \
+        s0 >>= 8; s1 >>= 8;
+    {
+        SHOUP2_HALF_LOADS
+        V[5] = 0;
+        V[4] = a1.w ^ c1.w;
+        V[3] = xor3(a1.z, c1.z, a0.w) ^ c0.w;
+        V[2] = xor3(a1.y, c1.y, a0.z) ^ c0.z;
+        V[1] = xor3(a1.x, c1.x, a0.y) ^ c0.y;
+        V[0] = a0.x ^ c0.x;
+    }
+#pragma unroll 1
+    for (int t = 1; t < 4; t++) {
+        SHOUP2_HALF_LOADS
+        V[5] = (V[5] >> 8) | (V[4] << 24);
+        V[4] = xor3((V[4] >> 8) | (V[3] << 24), a1.w, c1.w);
+        V[3] = xor3((V[3] >> 8) | (V[2] << 24), a1.z, c1.z) ^ a0.w ^ c0.w;
+        V[2] = xor3((V[2] >> 8) | (V[1] << 24), a1.y, c1.y) ^ a0.z ^ c0.z;
+        V[1] = xor3((V[1] >> 8) | (V[0] << 24), a1.x, c1.x) ^ a0.y ^ c0.y;
+        V[0] = xor3(V[0] >> 8, a0.x, c0.x);
+    }
+#undef SHOUP2_HALF_LOADS
+}
+// owner's partial (words 0, 1 of the value) and helper's partial (words 2, 3): the product
+HD G128 shoup2_pair_join(const u32 *Vo, const u32 *Vh) {
+    u32 R[8];
+    R[0] = Vo[0]; R[1] = Vo[1]; R[2] = Vo[2] ^ Vh[0]; R[3] = Vo[3] ^ Vh[1]; R[4] = Vo[4] ^ Vh[2]; R[5] = Vo[5] ^ Vh[3]; R[6] = Vh[4]; R[7] = Vh[5];
+    return gf_reduce256(R);
 }
 
 // aes_kexp per packet (config/config_aes_kexp.py:128-159 / tb/key_exp.py:79-114) on memory-order words, S-box

@@ -31,7 +31,7 @@ SYMBOLS = [
     "aesgcm_timer_create", "aesgcm_timer_start", "aesgcm_timer_stop", "aesgcm_timer_ms", "aesgcm_timer_destroy",
     "aesgcm_comm_last_error", "aesgcm_comm_unique_id", "aesgcm_comm_create", "aesgcm_comm_ranks", "aesgcm_comm_allgather_dev",
     "aesgcm_comm_allreduce_f64", "aesgcm_comm_barrier", "aesgcm_comm_destroy",
-    "aesgcm_mgpu_create", "aesgcm_mgpu_ranks", "aesgcm_mgpu_crypt_dev", "aesgcm_mgpu_destroy",
+    "aesgcm_mgpu_create", "aesgcm_mgpu_ranks", "aesgcm_mgpu_ctx", "aesgcm_mgpu_crypt_dev", "aesgcm_mgpu_destroy",
 ]
 
 
@@ -128,6 +128,7 @@ def load():
     L.aesgcm_comm_destroy.argtypes = [vp]
     L.aesgcm_mgpu_create.argtypes = [ctypes.POINTER(vp), cint, ctypes.POINTER(cint), vp, sz]
     L.aesgcm_mgpu_ranks.argtypes = [vp, ctypes.POINTER(cint)]
+    L.aesgcm_mgpu_ctx.argtypes = [vp, cint, ctypes.POINTER(vp)]
     L.aesgcm_mgpu_crypt_dev.argtypes = [vp, cint, vp, vp, sz, ctypes.POINTER(vp), ctypes.POINTER(sz), ctypes.POINTER(vp), vp]
     L.aesgcm_mgpu_destroy.argtypes = [vp]
     if L.aesgcm_abi_version() != ABI_VERSION:
@@ -359,9 +360,12 @@ class Context:
         self._c = c.value
         self.device = device
 
+    _borrowed = False           # True for a view of a context another object owns (MultiGpu.context)
+
     def close(self):
         if self._c:
-            load().aesgcm_ctx_destroy(self._c)
+            if not self._borrowed:
+                load().aesgcm_ctx_destroy(self._c)
             self._c = None
 
     __del__ = close
@@ -623,6 +627,14 @@ class MultiGpu:
         tag = ctypes.create_string_buffer(16)
         _chk(load().aesgcm_mgpu_crypt_dev(self._m, int(bool(decrypt)), _fixed(iv, 12, "iv"), d_aad, aad_len, pin, ln, pout, tag))
         return tag.raw
+
+    def context(self, g):
+        """device g's Context, borrowed from the mgpu object (closing it is a no-op)"""
+        c = vp()
+        _chk(load().aesgcm_mgpu_ctx(self._m, g, ctypes.byref(c)))
+        ctx = Context.__new__(Context)
+        ctx._c, ctx.device, ctx._borrowed, ctx._owner = c.value, self.devices[g], True, self
+        return ctx
 
     def close(self):
         if self._m:

@@ -44,6 +44,7 @@ import argparse
 import hashlib
 import json
 import os
+import signal
 import statistics
 import subprocess
 import sys
@@ -161,9 +162,85 @@ def free_port():
     return p
 
 
+def _kill_group(p, why):
+    """end a child this process started, and whatever it started: the child is its own session / process group leader"""
+    if p.poll() is not None:
+        return p.returncode
+    log("bench.py: killing pid %d: %s" % (p.pid, why))
+    try:
+        os.killpg(p.pid, signal.SIGKILL)                   # exact process group of a child this process started
+    except (OSError, ProcessLookupError):
+        try:
+            p.kill()
+        except OSError:
+            pass
+    try:
+        return p.wait(timeout=30)
+    except subprocess.TimeoutExpired:
+        return -9
+
+
+def _run_children(cmds_envs, launch_timeout, grace=20.0):
+    """Start the given (argv, env) children, each in a session of its own, and wait for them: child 0's stdout is captured
+    (the JSON line), the others' goes to stderr.  A child that fails takes the others down after `grace` seconds (they may
+    be blocked in a rendezvous or a collective with the dead one); the deadline kills what is left.  Whatever ends this
+    function -- return, exception, SIGTERM / SIGINT / SIGHUP to this process -- no child outlives it: a rank blocked in an
+    RCCL rendezvous would otherwise hold its GPU indefinitely and poison the next run on the machine.
+    -> (exit codes, child 0's stdout bytes)"""
+    import threading
+    procs, box = [], {}
+    old = {}
+
+    def on_signal(signum, _frame):
+        raise KeyboardInterrupt("signal %d" % signum)
+    for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        try:
+            old[sg] = signal.signal(sg, on_signal)
+        except (ValueError, OSError):                      # not the main thread
+            pass
+    rcs = [None] * len(cmds_envs)
+    try:
+        for r, (cmd, env) in enumerate(cmds_envs):
+            procs.append(subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE if r == 0 else sys.stderr,
+                                          start_new_session=True))
+
+        def drain():                                       # child 0's stdout -- read it so the pipe never fills
+            box["out"] = procs[0].stdout.read()
+        th = threading.Thread(target=drain, daemon=True)
+        th.start()
+        deadline = time.monotonic() + launch_timeout
+        failed_at = None
+        while any(rc is None for rc in rcs):
+            for i, p in enumerate(procs):
+                if rcs[i] is None:
+                    rcs[i] = p.poll()
+            now = time.monotonic()
+            if failed_at is None and any(rc not in (None, 0) for rc in rcs):
+                failed_at = now
+            if now > deadline or (failed_at is not None and now - failed_at > grace):
+                for i, p in enumerate(procs):
+                    if rcs[i] is None:
+                        rcs[i] = _kill_group(p, "rank %d: %s" % (i, "launch timeout" if now > deadline else "another rank failed"))
+                break
+            time.sleep(0.05)
+        th.join(timeout=10)
+        return rcs, box.get("out", b"") or b""
+    finally:
+        for i, p in enumerate(procs):
+            if p.poll() is None:
+                _kill_group(p, "rank %d: the launcher is going away" % i)
+        for sg, h in old.items():
+            try:
+                signal.signal(sg, h)
+            except (ValueError, OSError):
+                pass
+
+
 def self_launch(args, argv):
     """--gpus N without a launcher: start the N ranks as fresh child processes and relay rank 0's line.  Nothing here
-    touches the GPU (no library load, no HIP call) -- the children initialise their own devices."""
+    touches the GPU (no library load, no HIP call) -- the children initialise their own devices.  If the ranks come back
+    saying that no RCCL communicator came up between the processes (exit code EXIT_NOT_RCCL), ONE fresh child drives all N
+    devices through the library's single-process path instead (aesgcm_mgpu_*: ncclCommInitAll) and the line says so."""
     N = args.gpus
     have = visible_gpus()
     if have is not None and have < N and not args.one_device:
@@ -172,50 +249,34 @@ def self_launch(args, argv):
         return 2
     rdzv = tempfile.mkdtemp(prefix="aesgcm_rdzv_self_", dir="/dev/shm" if os.access("/dev/shm", os.W_OK) else None)
     port = free_port()
-    procs = []
-    for r in range(N):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(N), LOCAL_WORLD_SIZE=str(N),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AESGCM_RDZV_DIR=rdzv, AESGCM_SELF_LAUNCHED="1")
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL across processes needs it on this driver
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, cwd=ROOT,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
-    deadline = time.monotonic() + args.launch_timeout
-    out0 = b""
-    failed_at = None
-    rcs = [None] * N
-    import threading
-    box = {}
-
-    def drain():                                       # rank 0's stdout (the JSON line) -- read it so the pipe never fills
-        box["out"] = procs[0].stdout.read()
-    th = threading.Thread(target=drain, daemon=True)
-    th.start()
-    while any(rc is None for rc in rcs):
-        for i, p in enumerate(procs):
-            if rcs[i] is None:
-                rcs[i] = p.poll()
-        now = time.monotonic()
-        if failed_at is None and any(rc not in (None, 0) for rc in rcs):
-            failed_at = now                            # the others may be blocked in a rendezvous or a collective with the dead rank
-        if now > deadline or (failed_at is not None and now - failed_at > 20.0):
-            for i, p in enumerate(procs):
-                if rcs[i] is None:
-                    log("bench.py: killing rank %d (pid %d): %s" % (i, p.pid, "launch timeout" if now > deadline else "another rank failed"))
-                    p.kill()                           # exact pid of a child this process started
-                    rcs[i] = p.wait()
-            break
-        time.sleep(0.05)
-    th.join(timeout=10)
-    out0 = box.get("out", b"") or b""
-    sys.stdout.write(out0.decode(errors="replace"))
-    sys.stdout.flush()
+    base_env = dict(os.environ)
+    base_env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL across processes needs it on this driver
+    base_env.setdefault("NCCL_DEBUG", "WARN")                    # if RCCL refuses, its own words reach stderr
+    me = [sys.executable, os.path.abspath(__file__)]
     try:
-        for f in os.listdir(rdzv):
-            os.unlink(os.path.join(rdzv, f))
-        os.rmdir(rdzv)
-    except OSError:
-        pass
-    worst = max((rc if rc > 0 else 1) if rc else 0 for rc in rcs)      # killed (negative) counts as 1
+        if args.single_process:
+            rcs, out0 = [EXIT_NOT_RCCL], b""
+        else:
+            rcs, out0 = _run_children([(me + argv, dict(base_env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(N), LOCAL_WORLD_SIZE=str(N),
+                                                        MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AESGCM_RDZV_DIR=rdzv, AESGCM_SELF_LAUNCHED="1"))
+                                       for r in range(N)], args.launch_timeout)
+        worst = max((rc if rc > 0 else 1) if rc else 0 for rc in rcs)      # killed (negative) counts as 1
+        if ((worst == EXIT_NOT_RCCL or args.single_process) and not args.allow_file_exchange and not args.one_device and args.config != "cfg5"
+                and args.backend in ("rccl", "nccl")):
+            if not args.single_process:
+                log("bench.py: no RCCL communicator between %d processes (rank exit codes %s); the line above is NOT the result.  "
+                    "Falling back to ONE process driving all %d devices (ncclCommInitAll)" % (N, rcs, N))
+            rcs, out0 = _run_children([(me + [a for a in argv if a != "--single-process"] + ["--sp-child"], dict(base_env, AESGCM_SELF_LAUNCHED="1"))], args.launch_timeout)
+            worst = max((rc if rc > 0 else 1) if rc else 0 for rc in rcs)
+        sys.stdout.write(out0.decode(errors="replace"))
+        sys.stdout.flush()
+    finally:
+        try:
+            for f in os.listdir(rdzv):
+                os.unlink(os.path.join(rdzv, f))
+            os.rmdir(rdzv)
+        except OSError:
+            pass
     if worst:
         log("bench.py: rank exit codes %s" % (rcs,))
     return worst
@@ -365,6 +426,203 @@ def run_cfg5(args, rank, world, dev, ex, cpu_base):
     return tag_ok
 
 
+# ------------------------------------------------------------------------------------------------ messages in flight
+def run_inflight(args, dev):
+    """Sustained rate of mid-size messages with K of them queued (the reference's back-to-back packets under one key,
+    src/gcm_gctr.vhd:142-144).  K contexts of the same key, each with its own stream, scratch and host tag slot, take the
+    messages in turn; a call is enqueued with tag = NULL and returns at once; when the context comes round again the tag of
+    its previous message is collected (aesgcm_last_tag: a poll of the pinned host slot) and compared with the tag a waited
+    call produced for the same buffer before the timed region.  K = 1 is therefore "enqueue, then wait for the tag", the
+    waited form the default bench line uses.  The messages rotate over a ring of distinct buffers (plaintext, ciphertext, IV)
+    whose total exceeds the Infinity Cache, so no step re-reads what the previous one left in it."""
+    import aesgcm_amd  # noqa: F401
+    from aesgcm_amd import lib, sharding
+    K = max(1, args.inflight)
+    key_bits = args.key_bits or 256
+    size = int(args.gib_per_gpu * GiB) // 16 * 16
+    R = max(K, 2, min(255, int(args.ring_gib * GiB + size - 1) // size))
+    key = sharding.splitmix64_bytes(KEY_SEED, key_bits // 8)
+    iv0 = sharding.splitmix64_bytes(IV_SEED, 12)
+    ivs = [iv0[:8] + r.to_bytes(4, "big") for r in range(R)]
+    ctxs = [lib.Context(key, device=dev) for _ in range(K)]
+    d_pt = lib.DeviceBuffer(size * R, device=dev)
+    d_ct = lib.DeviceBuffer(size * R, device=dev)
+    d_pt.fill_splitmix64(0xAE5C0003, 0)
+    lib.dev_sync(dev)
+    # the waited form, once per ring slot: the reference tags of the queued calls (and, for the standard 16 GiB / 1 GiB messages, nothing else is needed --
+    # the queued and the waited form run the same launches; tests/test_gpu_cyclic.py and tests/test_gpu_inflight.py hold both to the oracle)
+    ref = [ctxs[0].encrypt_dev(ivs[r], d_pt.ptr + r * size, size, d_ct.ptr + r * size) for r in range(R)]
+    pending = [None] * K
+    bad = [0]
+
+    def collect(j):
+        if pending[j] is not None:
+            if ctxs[j].last_tag() != ref[pending[j]]:
+                bad[0] += 1
+            pending[j] = None
+
+    def run(n, i0):
+        for i in range(i0, i0 + n):
+            j, r = i % K, i % R
+            collect(j)
+            ctxs[j].encrypt_dev(ivs[r], d_pt.ptr + r * size, size, d_ct.ptr + r * size, want_tag=False)
+            pending[j] = r
+        for j in range(K):
+            collect(j)
+        return i0 + n
+
+    est_ms = size / GiB + 0.022
+    steps = args.steps if args.steps_given else min(20000, max(20, int(300.0 / est_ms)))
+    warm = args.warmup if args.warmup_given else min(10000, max(3, int(100.0 / est_ms)))
+    i = run(warm, 0)
+    lib.dev_sync(dev)
+    t0 = time.perf_counter()
+    i = run(steps, i)
+    lib.dev_sync(dev)
+    dt = time.perf_counter() - t0
+    value = size * steps / dt / GiB
+    # the kernel alone: HIP events around each launch on its stream, ONE context, launches back to back, waited
+    c0 = ctxs[0]
+    c0.timing_enable(True)
+    c0.timing_read(reset=True)
+    for r in range(min(R, 8)):
+        c0.encrypt_dev(ivs[r], d_pt.ptr + r * size, size, d_ct.ptr + r * size)
+    lib.dev_sync(dev)
+    n_launch, kernel_ms = c0.timing_read(reset=True)
+    c0.timing_enable(False)
+    avg_s = kernel_ms / 1e3 / max(n_launch, 1)
+    _, body_blocks = c0.split(size, 0)
+    blocks = body_blocks if body_blocks else size // 16
+    achieved = 32 * blocks / avg_s if avg_s > 0 else 0.0
+    line = {
+        "metric": "GiB/s plaintext, AES-%d-GCM, %.6g MiB messages, %d in flight, bit-exact tags" % (key_bits, size / (1 << 20), K),
+        "value": round(value, 3), "unit": "GiB/s", "n_gpus": 1, "steps": steps, "warmup": warm,
+        "ms_per_step": round(dt / steps * 1e3, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "custom: AES-%d-GCM messages of %d bytes under one key, %d queued (contexts rotate, tag = NULL, tags collected one turn late through "
+                               "the host slot), ring of %d message buffers = %.3g GiB, SplitMix64 PT seed 0xAE5C0003, empty AAD" % (key_bits, size, K, R, size * R / GiB),
+                   "bytes_per_message": size, "inflight": K, "ring": R, "parallelism": "single", "key_bits": key_bits, "us_per_message": round(dt / steps * 1e6, 2)},
+        "tag_ok": bad[0] == 0, "tags_checked": steps + warm, "tags_wrong": bad[0],
+        "roofline": {"bound": "hbm", "kernel": "%s<%d,ENC> (fused AES-CTR + GHASH), one message at a time" % ("k_body" if body_blocks else "k_main", key_bits // 32 + 6),
+                     "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_BYTES_PER_S, 4),
+                     "traffic": None, "alg_bytes_per_launch": 32 * blocks, "launches_timed": n_launch, "avg_launch_ms": round(avg_s * 1e3, 5),
+                     "sustained_frac": round(2 * size * steps / dt / HBM_PEAK_BYTES_PER_S, 4),
+                     "timing": "HIP events on the launch stream, one context, waited calls, separate pass after the timed region"},
+    }
+    print(json.dumps(line), flush=True)
+    if bad[0]:
+        log("PARITY FAILURE: %d of %d queued tags differ from the waited call's" % (bad[0], steps + warm))
+    return bad[0] == 0
+
+
+# ------------------------------------------------------------------------------------------------ one process, N devices
+def run_single_process(args):
+    """The N-GPU stream job (cfg4 cut to N devices, as the N-rank launch runs it) from ONE process: aesgcm_mgpu_* --
+    ncclCommInitAll, one grouped 16-byte all-gather per message, every device's context derived from the key locally.
+    The fallback of self_launch when no RCCL communicator comes up between processes (and --single-process asks for it).
+    Messages run one after the other (aesgcm_mgpu_crypt_dev returns the tag), so this path has a host round trip per message
+    that the N-rank path does not; the line names the path it is (config.exchange.backend)."""
+    import aesgcm_amd  # noqa: F401
+    from aesgcm_amd import lib, sharding
+    from aesgcm_amd.build import SO
+    N = args.gpus
+    have = lib.device_count()
+    if have < N:
+        log("bench.py: --gpus %d but the library sees %d device(s)" % (N, have))
+        return 2
+    if args.config == "cfg5" or args.decrypt:
+        log("bench.py: the single-process path runs the stream configs, encrypt")
+        return 2
+    cfg = dict(key_bits=256, gib=16.0, pt_seed=0xAE5C0004)
+    standard = args.gib_per_gpu is None and args.key_bits is None
+    if args.gib_per_gpu is not None:
+        cfg["gib"] = args.gib_per_gpu
+    if args.key_bits is not None:
+        cfg["key_bits"] = args.key_bits
+    per_gpu = int(cfg["gib"] * GiB) // (16 * 2 * N) * (16 * 2 * N)
+    key_bits = cfg["key_bits"]
+    key = sharding.splitmix64_bytes(KEY_SEED, key_bits // 8)
+    iv0 = sharding.splitmix64_bytes(IV_SEED, 12)
+    plans = [sharding.plan_job(N, per_gpu, r) for r in range(N)]
+    M = len(plans[0])
+    try:
+        mg = lib.MultiGpu(key, list(range(N)))
+    except lib.AesGcmError as e:
+        log("bench.py: aesgcm_mgpu_create over %d devices failed: %r / %s" % (N, e, lib.load().aesgcm_comm_last_error().decode()))
+        return 1
+    d_pt = [lib.DeviceBuffer(per_gpu, device=r) for r in range(N)]
+    d_ct = [lib.DeviceBuffer(per_gpu, device=r) for r in range(N)]
+    for r in range(N):
+        for m in plans[r]:
+            d_pt[r].fill_splitmix64(cfg["pt_seed"], m["stream_word"], nbytes=m["len"], offset=m["off"])
+    for r in range(N):
+        lib.dev_sync(r)
+    ivs = [sharding.tweak_iv(iv0, m["iv_tweak"]) for m in plans[0]]
+
+    def step():
+        return [mg.crypt_dev(False, ivs[i], [d_pt[r].ptr + plans[r][i]["off"] for r in range(N)], [plans[r][i]["len"] for r in range(N)],
+                             [d_ct[r].ptr + plans[r][i]["off"] for r in range(N)]) for i in range(M)]
+
+    def sync_all():
+        for r in range(N):
+            lib.dev_sync(r)
+
+    tags = None
+    for _ in range(max(args.warmup, 1)):
+        tags = step()
+    checked = []
+    for m, t in zip(plans[0], tags):
+        fx = load_fixture("cfg4_aes256_msg%d_32GiB" % m["msg"]) if standard and m["total"] == 32 * GiB else None
+        if fx is not None:
+            checked.append(t.hex() == fx["tag"])
+    tag_ok = all(checked) if checked else None
+    if tag_ok is False:
+        log("PARITY FAILURE (single process): tags=%s" % [t.hex() for t in tags])
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    value = per_gpu * N * args.steps / dt / GiB
+
+    ctx0 = mg.context(0)                                          # device 0's fused kernel under HIP events, separate short pass
+    ctx0.timing_enable(True)
+    ctx0.timing_read(reset=True)
+    for _ in range(min(3, max(1, args.steps))):
+        step()
+    sync_all()
+    n_launch, kernel_ms = ctx0.timing_read(reset=True)
+    ctx0.timing_enable(False)
+    m0 = plans[0][0]
+    _, body_blocks = ctx0.split(m0["len"], m0["first_block"])
+    blocks_per_launch = body_blocks if body_blocks else m0["len"] // 16
+    avg_s = kernel_ms / 1e3 / max(n_launch, 1)
+    alg_bytes = 32 * blocks_per_launch
+    achieved = alg_bytes / avg_s if avg_s > 0 else 0.0
+    geo = ctx0.geometry(body=bool(body_blocks))
+    line = {
+        "metric": "GiB/s plaintext, AES-%d-GCM %.3g GiB stream, bit-exact tag" % (key_bits, cfg["gib"]),
+        "value": round(value, 3), "unit": "GiB/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "cfg4 cut to %d devices: %d AES-%d-GCM message(s) of %.3g GiB (SplitMix64 seed 0xAE5C0004), each sharded over all %d "
+                               "devices by ONE process (aesgcm_mgpu_*), one grouped 16 B all-gather per message" % (N, M, key_bits, plans[0][0]["total"] / GiB, N),
+                   "bytes_per_gpu": per_gpu, "messages_per_step": M, "parallelism": "shard%d" % N, "key_bits": key_bits,
+                   "workgroups": geo["workgroups"], "wg_lanes": geo["wg_lanes"], "lds_bytes_per_wg": geo["lds_bytes"],
+                   "exchange": {"backend": "rccl (single process)", "ranks_seen": mg.n_ranks, "init": "ncclCommInitAll", "torch": "not imported"}},
+        "tag_ok": tag_ok, "tags": [t.hex() for t in tags],
+        "roofline": {"bound": "hbm", "kernel": "%s<%d,ENC> (fused AES-CTR + GHASH), device 0" % ("k_body" if body_blocks else "k_main", key_bits // 32 + 6),
+                     "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_BYTES_PER_S, 4),
+                     "traffic": None, "alg_bytes_per_launch": alg_bytes, "launches_timed": n_launch, "avg_launch_ms": round(avg_s * 1e3, 4),
+                     "timing": "HIP events on device 0's launch stream in a separate pass after the timed region",
+                     "traffic_build": {"running_so_sha256": sha256_file(SO), "running_git": git_head()}},
+    }
+    print(json.dumps(line), flush=True)
+    ok = mg.n_ranks == N and tag_ok is not False
+    mg.close()
+    return 0 if ok else 1
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
@@ -395,18 +653,34 @@ def main(argv=None):
     ap.add_argument("--emulate-rank", type=int, default=None, help="on ONE GPU, run exactly this rank's step of the --of W job")
     ap.add_argument("--of", type=int, default=8, help="world size emulated by --emulate-rank")
     ap.add_argument("--launch-timeout", type=float, default=3000.0, help="self-launch: seconds before hung ranks are killed")
+    ap.add_argument("--inflight", type=int, default=0,
+                    help="N = 1, with --gib-per-gpu S: sustained rate of S-sized messages with K of them queued -- K contexts (stream + scratch each) "
+                         "rotate, every call is enqueued with tag = NULL and its tag is collected through the host slot when the context comes round "
+                         "again; the messages rotate over a ring of buffers larger than the 256 MB Infinity Cache (--ring-gib)")
+    ap.add_argument("--ring-gib", type=float, default=1.0, help="--inflight: total plaintext in the ring of message buffers")
+    ap.add_argument("--single-process", action="store_true",
+                    help="N > 1: skip the one-process-per-GPU launch and let ONE fresh child drive all N devices (aesgcm_mgpu_*: ncclCommInitAll) -- "
+                         "what the self-launch falls back to by itself when no RCCL communicator comes up between processes")
+    ap.add_argument("--sp-child", action="store_true", help=argparse.SUPPRESS)      # internal: this process IS that child
     args = ap.parse_args(argv)
     # defaults: 3 warmup + 20 timed steps, except where a step is so short that those would sit inside the chip's clock ramp (10 - 20 ms under load): then about
     # 50 ms of warmup and 100 ms timed (cfg2, 1 ms per step: 50 + 100; --gib-per-gpu 0.0625, 0.09 ms: 556 + 1112)
+    if args.gib_per_gpu is not None and not args.gib_per_gpu > 0:
+        log("bench.py: --gib-per-gpu must be positive")
+        return 2
     est_ms = None
-    if args.config != "cfg5":
-        est_ms = (args.gib_per_gpu if args.gib_per_gpu is not None else {"cfg2": 1.0, "cfg3": 16.0}.get(args.config, 16.0)) * 1.0
-    short_steps = est_ms is not None and est_ms < 5.0
+    if args.config != "cfg5":                                    # ~1 ms per GiB; N > 1 stream runs are the 16 GiB-per-GPU cfg4 job whatever --config says
+        est_ms = (args.gib_per_gpu if args.gib_per_gpu is not None else 16.0 if (args.gpus > 1 or args.emulate_rank is not None) else
+                  {"cfg2": 1.0, "cfg3": 16.0}.get(args.config, 16.0)) * 1.0
+    short_steps = est_ms is not None and 0.0 < est_ms < 5.0
+    args.steps_given, args.warmup_given = args.steps is not None, args.warmup is not None
     if args.steps is None:
         args.steps = min(5000, max(20, int(100.0 / est_ms + 0.999))) if short_steps else 20
     if args.warmup is None:
         args.warmup = min(2500, max(3, int(50.0 / est_ms + 0.999))) if short_steps else 3
 
+    if args.sp_child:
+        return run_single_process(args)
     if "RANK" not in os.environ and args.gpus > 1 and args.emulate_rank is None:
         return self_launch(args, argv)                           # before anything touches the GPU
 
@@ -442,6 +716,15 @@ def main(argv=None):
     if not_rccl and not args.allow_file_exchange and rank == 0:
         log("bench.py: the exchange is '%s', not RCCL -- the line below is NOT a multi-GPU RCCL measurement; exiting %d "
             "(--allow-file-exchange accepts it for debugging)" % (ex.name, EXIT_NOT_RCCL))
+    if (not_rccl and not args.allow_file_exchange and args.backend in ("rccl", "nccl") and os.environ.get("AESGCM_SELF_LAUNCHED") == "1"
+            and not args.one_device):
+        # RCCL was asked for and did not come up: do not spend minutes measuring through the file exchange -- the launching parent
+        # (self_launch) will start ONE process over all devices instead.  Every rank leaves the same way.
+        log("bench.py rank %d: no RCCL communicator (%s); leaving so that the launcher can fall back to the single-process path" % (rank, ex.name))
+        ex.barrier()
+        ex.close()
+        comm.finish(rank, world)
+        return EXIT_NOT_RCCL
 
     def finish(ok):
         if ex is not None:
@@ -454,6 +737,11 @@ def main(argv=None):
 
     if args.config == "cfg5":
         return finish(run_cfg5(args, rank, world, dev, ex, cpu_base))
+    if args.inflight:
+        if N != 1 or args.gib_per_gpu is None or emu is not None or args.decrypt:
+            log("bench.py: --inflight K needs --gib-per-gpu S, one GPU, encrypt")
+            return 2
+        return finish(run_inflight(args, dev))
 
     cfg = dict(CONFIGS[args.config])
     standard = args.gib_per_gpu is None and args.key_bits is None

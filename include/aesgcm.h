@@ -217,6 +217,7 @@ AESGCM_API int aesgcm_comm_destroy(aesgcm_comm *comm);
 typedef struct aesgcm_mgpu aesgcm_mgpu;
 AESGCM_API int aesgcm_mgpu_create(aesgcm_mgpu **out, int ndev, const int *devices, const uint8_t *key, size_t key_len);
 AESGCM_API int aesgcm_mgpu_ranks(const aesgcm_mgpu *m, int *n_ranks);
+AESGCM_API int aesgcm_mgpu_ctx(aesgcm_mgpu *m, int g, aesgcm_ctx **out);     /* device g's context, borrowed: never destroy it */
 AESGCM_API int aesgcm_mgpu_crypt_dev(aesgcm_mgpu *m, int decrypt, const uint8_t iv[12], const void *d_aad_on_dev0, size_t aad_len,
                           const void *const *d_in, const size_t *shard_len, void *const *d_out, uint8_t tag[16]);
 AESGCM_API int aesgcm_mgpu_destroy(aesgcm_mgpu *m);

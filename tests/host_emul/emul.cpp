@@ -486,6 +486,13 @@ static void test_batch_pieces() {
             }
             const G128 z2 = shoup2_mul(y, t2, 0u);
             CHECK(memcmp(&z2, &want, 16) == 0, "shoup2_mul %d", it);
+            const G128 z3 = shoup2_mul_dr(y, t2, 0u);                  // round 4: the same product with the reduction delayed
+            CHECK(memcmp(&z3, &want, 16) == 0, "shoup2_mul_dr %d", it);
+            u32 Vo[6], Vh[6];                                           // ... and split over an owner and a helper lane (k_batch3 at 8 lanes per packet)
+            shoup2_half_dr(y.w[0], y.w[1], t2, 0u, Vo);
+            shoup2_half_dr(y.w[2], y.w[3], t2, 0u, Vh);
+            const G128 z4 = shoup2_pair_join(Vo, Vh);
+            CHECK(memcmp(&z4, &want, 16) == 0, "shoup2_half_dr / pair_join %d", it);
         }
         const G128 s1 = gf_sqr(y), s2 = gf_mul(y, y), s3 = gf_sqr(c), s4 = gf_mul(c, c);
         CHECK(memcmp(&s1, &s2, 16) == 0 && memcmp(&s3, &s4, 16) == 0, "gf_sqr %d", it);
