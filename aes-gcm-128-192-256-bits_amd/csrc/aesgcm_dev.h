@@ -1008,7 +1008,7 @@ struct BodyParams {
     MainParams front, last;      // the two generic pieces as one-row chunks of main_chunk_lane
     // fused closing (whole messages, body_cyc_* below): the launch folds its own items and leaves the tag -- no k_fold, no k_combine
     u32 prio_rows;               // rotate the waves' issue priorities every so many rows (0 = leave them alone)
-    u32 fuse;                    // 1: closing in the launch; | 2: no L2 write-back in front of the arrival because the host waits for the end of the launch; | 4: none because the rows were stored through the L2 (AESGCM_BODY_WT)
+    u32 fuse;                    // 1: the launch closes the tag itself (cyc_close).  Its rows reach memory before the tag is shown: through-the-L2 stores (AESGCM_BODY_WT) or, without them, an L2 write-back
     u64 aad_len, ct_len;         // bytes, for the length block
     unsigned long long *acc;     // CYC_ACC_SLOTS x {hi, lo} XOR accumulators and the arrival counter behind them (device memory, zero between launches)
     uint4 *tag_out, *tag_host;   // where the tag goes (device slot, and the pinned host slot or NULL)
@@ -1062,28 +1062,9 @@ HD void body_rounds(u32 &s0, u32 &s1, u32 &s2, u32 &s3, const u32 *__restrict__ 
 }
 #ifndef AESGCM_BODY_WT
 #define AESGCM_BODY_WT 1                 /* k_body's rows store their ciphertext through the L2 (gstore16_wt): nothing of it is left dirty for the end of the launch -- the cyclic launch shows
-                                            its tag from inside (cyc_close), and a dealt 16 GiB launch ends 0.1 ms sooner (profiles/r03c/body_wt_ab: step 16.90 -> 16.79 ms).  0: plain stores
-                                            (then cyc_close must write the L2 back: AESGCM_CYC_FUSE=1) */
+                                            its tag from inside (cyc_close), and a dealt 16 GiB launch ends 0.1 ms sooner (profiles/r03c/body_wt_ab: step 16.90 -> 16.79 ms).  0: plain stores;
+                                            cyc_close then writes the XCD's L2 back (an agent-scope release, 5 us) before the workgroup counts itself arrived */
 #endif
-#ifndef AESGCM_BODY_ILP
-#define AESGCM_BODY_ILP 1                /* 2: two rows of a chunk in flight per lane (round-3 experiment, profiles/r03/body_ilp2.txt) */
-#endif
-// rounds 3..NR on TWO independent states, round by round (AESGCM_BODY_ILP == 2): adjacent independent lookup chains for the scheduler
-template <int NR>
-HD void body_rounds2(u32 &a0, u32 &a1, u32 &a2, u32 &a3, u32 &b0, u32 &b1, u32 &b2, u32 &b3, const u32 *__restrict__ rk, const unsigned char *lds, u32 lb) {
-#pragma unroll
-    for (int r = 3; r < NR; r++) {
-#if AESGCM_T4
-        aes_round_lds4(a0, a1, a2, a3, rk + 4 * r, lds, lb, lb | 0x10000u);
-        aes_round_lds4(b0, b1, b2, b3, rk + 4 * r, lds, lb, lb | 0x10000u);
-#else
-        aes_round_lds(a0, a1, a2, a3, rk + 4 * r, lds, lb);
-        aes_round_lds(b0, b1, b2, b3, rk + 4 * r, lds, lb);
-#endif
-    }
-    aes_final_lds(a0, a1, a2, a3, rk + 4 * NR, lds, lb);
-    aes_final_lds(b0, b1, b2, b3, rk + 4 * NR, lds, lb);
-}
 // the state of super-row q after round 2: per-chunk lane constants xor the row-uniform part (two values in phase 3)
 HD void body_state(u32 &s0, u32 &s1, u32 &s2, u32 &s3, const BodyLane &b, u32 hi24, u32 v, u32 lane, const CtrConsts &cc,
                    const u32 *__restrict__ rk, const DevTables *__restrict__ tb) {
@@ -1131,34 +1112,10 @@ HD uint4 body_strand_lane(const KeyMaterial *__restrict__ km, const DevTables *_
     for (int w = 0; w < 4 * (NR + 1); w++) rk[w] = (w >= AESGCM_BODY_RKV_FROM(NR)) ? pin_vgpr(rk0[w]) : rk0[w];
     uint4 acc = acc_in;
     u32 i = 0;
-#if AESGCM_BODY_ILP == 2
-    if (continued) acc = ghash_mul_const_lds(acc, smem);
-    for (; i + 1 < n; i += 2) {
-        const u32 q = q0 + i * qstep;
-        const u64 off = ((u64)q * 4 + v) * 1024, off2 = (u64)qstep * 4096;
-        const unsigned char *src = reinterpret_cast<const unsigned char *>(uniform64((u64)(uintptr_t)p.in + off));
-        unsigned char *dst = reinterpret_cast<unsigned char *>(uniform64((u64)(uintptr_t)p.out + off));
-        const uint4 xa = (MODE == MODE_PROBE) ? make_uint4(lane, q, v, 0u) : gload16(src + lane16);
-        const uint4 xb = (MODE == MODE_PROBE) ? make_uint4(lane, q + qstep, v, 0u) : gload16(src + off2 + lane16);
-        u32 a0, a1, a2, a3, b0, b1, b2, b3;
-        body_state(a0, a1, a2, a3, b, p.ctr_hi0 + q, v, lane, cc, rk, tb);
-        body_state(b0, b1, b2, b3, b, p.ctr_hi0 + q + qstep, v, lane, cc, rk, tb);
-        body_rounds2<NR>(a0, a1, a2, a3, b0, b1, b2, b3, rk, smem, lb);
-        const uint4 ya = make_uint4(xa.x ^ a0, xa.y ^ a1, xa.z ^ a2, xa.w ^ a3), yb = make_uint4(xb.x ^ b0, xb.y ^ b1, xb.z ^ b2, xb.w ^ b3);
-        if (MODE != MODE_PROBE) { gstore16(dst + lane16, ya); gstore16(dst + off2 + lane16, yb); }
-        if (i) acc = ghash_mul_const_lds(acc, smem);
-        acc = xor4(acc, (MODE == MODE_DEC) ? xa : ya);
-        acc = xor4(ghash_mul_const_lds(acc, smem), (MODE == MODE_DEC) ? xb : yb);
-    }
-#endif
     for (; i < n; ++i) {
         const u32 q = q0 + i * qstep;                                  // super-row: counters [256 q, 256 q + 255] of the body
         if (prio_rows) body_prio(i, prio_rows, prio_slot);
-#if AESGCM_BODY_ILP == 2
-        if (i) acc = ghash_mul_const_lds(acc, smem);
-#else
         if (i || continued) acc = ghash_mul_const_lds(acc, smem);
-#endif
         const u64 off = ((u64)q * 4 + v) * 1024;                       // byte offset of the row in the body
         const unsigned char *src = reinterpret_cast<const unsigned char *>(uniform64((u64)(uintptr_t)p.in + off));
         unsigned char *dst = reinterpret_cast<unsigned char *>(uniform64((u64)(uintptr_t)p.out + off));

@@ -8,7 +8,7 @@
 //   k_fold          reduces the chunks' items (64 lane accumulators each) by Horner with wave-uniform constants.
 //   k_combine       per message: H^(63-L) on the last item, lane fold, optional H^e weighting / chaining value
 //                   (shards, streaming), length block, E_K(J0) -> tag.  k_combine_batch: up to 8 messages, one workgroup each.
-//   k_batch3, k_batch2, k_batch   packets with their OWN key: 16 lanes per packet in one pass / in two phases (A/B only) / one wave per packet.
+//   k_batch3, k_batch   packets with their OWN key: 8 or 16 lanes per packet in one pass / one wave per packet.
 //   k_pktg<.., LG>, k_pktl        packets under the context's key: 2^LG lanes per packet (4, 8, 16, 64) / one lane per packet.
 //   k_gfmul, k_fill, k_copy16 small utility kernels.
 //
@@ -343,8 +343,10 @@ __device__ __forceinline__ void cyc_close(const KeyMaterial *__restrict__ km, co
     if (wv != 0) return;
     // The workgroup's ciphertext has reached its XCD's L2 (the barriers above waited for the stores); an agent-scope release writes that L2 back, so that
     // when the last arrival publishes the tag every byte of the message is in memory -- for the copy engines, the other XCDs and the host -- although the
-    // launch itself retires a few microseconds later.  (p.fuse & 2: leave that to the end of the launch; the host then waits for it, fetch_tag.)
-    if (!(p.fuse & 6u)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    // launch itself retires a few microseconds later.  With through-the-L2 row stores (AESGCM_BODY_WT, the default build) nothing is dirty and there is nothing to write back.
+#if !AESGCM_BODY_WT
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
     G128 z = wave_xor(cyc_lane_term_lds(smem, y, lane));
     if (g + 1u != gridDim.x) {                                                // weight H^(1024 (255 - g)) through a two-table Shoup form in LDS
         if (lane < 32) *reinterpret_cast<uint4 *>(smem + CYC_LDS_WTAB + 16u * lane) = shoup2_entry(mo_to_be(wc), lane);
@@ -754,20 +756,8 @@ __global__ __launch_bounds__(AESGCM_WG, BATCH1_WPS) void k_batch(const DevTables
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_batch2: the same job with G = 2^LG lanes per packet, i.e. 64 / G packets per wave (LG = 4: four packets of 16 lanes).
-// What a packet pays besides its AES and one GHASH multiply per block is the cross-lane tree (LG levels), the H^q chain
-// and the two closing multiplies -- per WAVE: with four packets in a wave those ~12 table multiplies are shared by four
-// packets, and the tree is 4 levels instead of 6.  Round keys can no longer be scalar (each lane group has its own key):
-// they live in vector registers (4 waves per SIMD).  GHASH multiplies use the byte-wise two-table form (shoup2_mul).
-// LDS: T-tables as everywhere, then 1 KiB per packet group (tables of H and of the current tree constant).
+// Lane-group helpers of the packet kernels (G = 2^LG lanes per packet, 64 / G packets per wave)
 // ------------------------------------------------------------------------------------------------
-template <int LG>
-__device__ __forceinline__ G128 group_bcast(G128 v, u32 lane, u32 src_l) {
-    const int src = (int)((lane & ~((1u << LG) - 1u)) + src_l);
-    G128 r;
-    r.w[0] = __shfl(v.w[0], src); r.w[1] = __shfl(v.w[1], src); r.w[2] = __shfl(v.w[2], src); r.w[3] = __shfl(v.w[3], src);
-    return r;
-}
 template <int LG>
 __device__ __forceinline__ void shoup2_build(unsigned char *smem, u32 tab, G128 c, u32 l) {
 #pragma unroll
@@ -789,153 +779,16 @@ __device__ __forceinline__ u32 groups_max(u32 v) {
     return m;
 }
 
-template <int NR, int DEC, int LG>
-__global__ __launch_bounds__(AESGCM_WG, 4) void k_batch2(const DevTables *__restrict__ tb, const BatchParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr u32 G = 1u << LG, P = 64u >> LG;
-    const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    main_fill_lds(smem, nullptr, tb, tid, false, AESGCM_WG);
-    __syncthreads();
-    const u32 lb = (lane & 31u) << 2;
-    const u32 grp = lane >> LG, l = lane & (G - 1u);
-    const u32 tabH = BATCH2_LDS_TAB_OFF + (wave * P + grp) * BATCH2_GROUP_LDS, tabC = tabH + 512u;
-    constexpr u32 KEYLEN = 4 * (NR - 6);
-    // packets are dealt in blocks of p.deal (a multiple of P) per dispenser fetch; bounded on purpose (as every dispenser loop)
-    const u32 K = p.deal, nb = (p.n_pkts + K - 1) / K;
-    u32 pk0 = 0, pk_end = 0;
-    for (u32 guard = 0; guard <= p.n_pkts; ++guard, pk0 += P) {
-        if (pk0 >= pk_end) {
-            u32 b = 0;
-            if (lane == 0) b = atomicAdd(p.counter, 1u) - p.counter_base;
-            b = __builtin_amdgcn_readfirstlane(b);
-            if (b >= nb) break;
-            pk0 = b * K;
-            pk_end = pk0 + K < p.n_pkts ? pk0 + K : p.n_pkts;
-        }
-        const bool act = pk0 + grp < pk_end;                 // groups past the end shadow the first packet; their stores are masked
-        const u32 pkt = act ? pk0 + grp : pk0;
-        const unsigned char *key = p.keys + (size_t)pkt * KEYLEN;
-        const unsigned char *ivp = p.ivs + (size_t)pkt * 12;
-        u32 pkt_len = p.pkt_len, aad_len = p.aad_len;
-        u64 doff = (u64)pkt * p.pkt_len, aoff = (u64)pkt * p.aad_len;
-        if (p.data_off) { doff = p.data_off[pkt]; pkt_len = (u32)(p.data_off[pkt + 1] - doff); }
-        if (p.aad_off) { aoff = p.aad_off[pkt]; aad_len = (u32)(p.aad_off[pkt + 1] - aoff); }
-        const bool aligned = p.aligned && ((doff & 15) == 0);
-        const unsigned char *aad = p.aad ? p.aad + aoff : nullptr;
-        const unsigned char *in = p.in + doff;
-        unsigned char *out = p.out + doff;
-        const u32 n_aad = (aad_len + 15) / 16, n_ct = (pkt_len + 15) / 16, n_seq = n_aad + n_ct;
-        const u32 q = (n_seq + G - 1) / G;                  // blocks per lane (0 for an empty packet)
-        const u32 pad = G * q - n_seq;                      // front padding slots
-        const u32 qmax = groups_max<LG>(q), nct_max = groups_max<LG>(n_ct);
-
-        // ---- aes_kexp for this lane's packet (config/config_aes_kexp.py:128-159); every lane of a group computes the same words
-        u32 rk[4 * (NR + 1)];
-        batch_key_expand<NR>(key, rk, smem, lb);
-        const u32 iv0 = load_le32(ivp), iv1 = load_le32(ivp + 4), iv2 = load_le32(ivp + 8);
-
-        // ---- H = E_K(0^128) on lane 0 and E_K(IV || 1) on lane 1 of the group (gcm_gctr.vhd:141-145), one pass for both
-        G128 h, ej0;
-        {
-            u32 s0 = (l == 0 ? 0u : iv0) ^ rk[0], s1 = (l == 0 ? 0u : iv1) ^ rk[1], s2 = (l == 0 ? 0u : iv2) ^ rk[2];
-            u32 s3 = (l == 0 ? 0u : 0x01000000u) ^ rk[3];
-            aes_rounds_lds<NR>(s0, s1, s2, s3, rk, smem, lb);
-            const G128 e = mo_to_be(make_uint4(s0, s1, s2, s3));
-            h = group_bcast<LG>(e, lane, 0);
-            ej0 = group_bcast<LG>(e, lane, 1);
-        }
-        shoup2_build<LG>(smem, tabH, h, l);
-
-        G128 acc; acc.w[0] = acc.w[1] = acc.w[2] = acc.w[3] = 0;
-        // GHASH over the input must precede the CTR pass when decrypting (in-place safe); after it when encrypting
-#pragma unroll
-        for (int phase = 0; phase < 2; phase++) {
-            const bool do_ghash = (phase == 0) == (DEC != 0);
-            if (do_ghash) {
-                if (!DEC) __threadfence_block();           // this wave's ciphertext stores are visible to its other lanes
-                for (u32 k = 0; k < qmax; k++) {
-                    if (k < q) {
-                        if (k) acc = shoup2_mul(acc, smem, tabH);
-                        const u32 v = l * q + k;
-                        if (v >= pad) {
-                            const G128 b = batch_seq_block(aligned, aad_len, pkt_len, aad, DEC ? in : out, n_aad, v - pad);
-                            acc.w[0] ^= b.w[0]; acc.w[1] ^= b.w[1]; acc.w[2] ^= b.w[2]; acc.w[3] ^= b.w[3];
-                        }
-                    }
-                }
-            } else {
-                const CtrConsts cc = ctr_round1_consts(iv0, iv1, iv2, rk, smem, lb);
-                for (u32 i = l; i < nct_max; i += G) {
-                    if (i < n_ct) {
-                        const u32 off = 16 * i, rem = pkt_len - off;
-                        uint4 x;
-                        const bool full = aligned && rem >= 16;
-                        if (full) x = *reinterpret_cast<const uint4 *>(in + off);
-                        else x = load_block_bytes(in + off, rem < 16 ? rem : 16);
-                        u32 s0, s1, s2, s3;
-                        ctr_rounds_lds<NR>(bswap32(2u + i), cc, s0, s1, s2, s3, rk, smem, lb);
-                        const uint4 y = make_uint4(x.x ^ s0, x.y ^ s1, x.z ^ s2, x.w ^ s3);
-                        if (act) {
-                            if (full) *reinterpret_cast<uint4 *>(out + off) = y;
-                            else store_block_bytes(out + off, y, rem < 16 ? rem : 16);
-                        }
-                    }
-                }
-            }
-        }
-
-        // ---- H^q per group by square-and-multiply (squaring is linear: gf_sqr, no table); q differs between groups
-        G128 cpow = h;
-        if (qmax > 1) {
-            bool started = false;
-            for (int b = 31 - (int)__builtin_clz(qmax); b >= 0; b--) {
-                if (started) cpow = gf_sqr(cpow);
-                if ((q >> b) & 1u) {
-                    if (started) cpow = shoup2_mul(cpow, smem, tabH);
-                    started = true;
-                }
-            }
-        }
-        // ---- cross-lane tree inside the group: c_0 = H^q, c_{j+1} = c_j^2
-#pragma unroll 1
-        for (int j = 0; j < LG; j++) {
-            shoup2_build<LG>(smem, tabC, cpow, l);
-            const G128 t = shoup2_mul(acc, smem, tabC);
-            G128 o;
-            o.w[0] = __shfl_xor(t.w[0], 1 << j); o.w[1] = __shfl_xor(t.w[1], 1 << j);
-            o.w[2] = __shfl_xor(t.w[2], 1 << j); o.w[3] = __shfl_xor(t.w[3], 1 << j);
-            if (l & (1u << j)) { acc.w[0] ^= o.w[0]; acc.w[1] ^= o.w[1]; acc.w[2] ^= o.w[2]; acc.w[3] ^= o.w[3]; }
-            if (j < LG - 1) cpow = gf_sqr(cpow);
-        }
-        // ---- the group's last lane holds P = sum X_i H^(n-1-i); tag = ((P*H) ^ L)*H ^ E_K(J0)  (gcm_ghash.vhd:257,293)
-        G128 y = shoup2_mul(acc, smem, tabH);
-        y.w[1] ^= aad_len * 8u; y.w[3] ^= pkt_len * 8u;           // both < 2^32 bits by the ABI's limits
-        y = shoup2_mul(y, smem, tabH);
-        y.w[0] ^= ej0.w[0]; y.w[1] ^= ej0.w[1]; y.w[2] ^= ej0.w[2]; y.w[3] ^= ej0.w[3];
-        if (l == G - 1u && act) {
-            const uint4 tag = be_to_mo(y);
-            store_block_bytes(p.tags + (size_t)pkt * 16, tag, 16);
-            if (DEC && p.auth) {
-                int ok = 1;
-                if (p.expect) {
-                    const uint4 e = load_block_bytes(p.expect + (size_t)pkt * 16, 16);
-                    ok = ((e.x ^ tag.x) | (e.y ^ tag.y) | (e.z ^ tag.z) | (e.w ^ tag.w)) == 0;
-                }
-                p.auth[pkt] = ok;
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
-// k_batch3: k_batch2's job in ONE pass over the data (round 3).  k_batch2 encrypts a packet, fences, and reads the ciphertext
-// back for GHASH because its lanes own CONSECUTIVE blocks in the GHASH phase and interleaved ones in the CTR phase: 1.57 x the
-// algorithmic HBM traffic (profiles/r02g/cfg5_batch).  Here lane l of the packet's 16-lane group owns slots l, l + 16, ... of the
-// right-aligned GHASH sequence in both roles: one loop does AES-CTR on the block and acc = acc * H^16 ^ block (Shoup tables of
-// the per-packet constant H^16 = (((H^2)^2)^2)^2, four linear squarings).  The closing is k_pktg's: every lane times H^2, the
-// length block into lane 14, a four-level tree with the group-uniform constants H, H^2, H^4, H^8 -- q + 5 table multiplies per
-// wave-iteration where k_batch2 makes q + 6 plus the H^q square-and-multiply chain, no ciphertext read-back, no fence.
-// Decrypt is the same pass (the lane reads its ciphertext block before it writes the plaintext: in place is safe).
+// k_batch3: BASELINE config 5 with G = 2^LG lanes per packet, i.e. 64 / G packets per wave (LG = 4: four packets of 16 lanes, LG = 3: eight of 8), ONE pass
+// over the data.  What a packet pays besides its AES and one GHASH multiply per block -- key schedule, H and E_K(J0), the table of the Horner stride, the
+// closing -- is paid per WAVE, so the more packets share a wave the cheaper it gets; each lane group has its own key, so round keys live in vector registers.
+// Lane l of the packet's group owns slots l, l + G, ... of the right-aligned GHASH sequence in both roles: one loop does AES-CTR on the block and
+// acc = acc * H^G ^ block (Shoup tables of the per-packet constant H^G, LG linear squarings of H).  The closing is k_pktg's: every lane times H^2, the
+// length block into lane G-2, an LG-level tree with the group-uniform constants H, H^2, H^4, (H^8) -- q + LG + 1 table multiplies per wave-iteration, no
+// ciphertext read-back, no fence.  Decrypt is the same pass (the lane reads its ciphertext block before it writes the plaintext: in place is safe).
+// (Rounds 2 and 3 kept a two-phase predecessor, k_batch2 -- encrypt, fence, read the ciphertext back for GHASH: 1.57 x the algorithmic HBM traffic,
+// profiles/r02g/cfg5_batch -- for A/B runs; round 4 deleted it.  HISTORY.md.)
 // ------------------------------------------------------------------------------------------------
 // Lanes per k_batch3 workgroup (one per CU).  The first round-3 build (1024 lanes, 128 registers, round keys in VGPRs) spilled 104 - 124 bytes around its
 // packet loop and moved 11.1e9 bytes against 8.64e9 algorithmic; with 768-lane workgroups (160 registers, no scratch) 8.68e9 at the same speed -- the
@@ -1332,27 +1185,22 @@ struct aesgcm_ctx {
     u32 *d_counter = nullptr;          // chunk dispenser
     u32 counter_base = 0;              // value the packet dispenser (d_counter[0]) holds before the next launch
     u32 qset = 0;                      // which of the two sets of chunk queues (d_counter[16 (1 + 16 set + q)]) the next dynamic launch of k_main / k_body uses; that launch zeroes the other set
-    u32 tw_override = 0;               // AESGCM_TW
-    u64 body_min = (u64)256 << 20;     // ranges with an aligned middle of at least this many bytes go through k_body (AESGCM_BODY_MIN).  Since k_main
+    u32 tw_override = 0;               // option "tw": rows per chunk of the dealt kernels, 0 = the library's rule (main_geometry)
+    u64 body_min = (u64)256 << 20;     // ranges with an aligned middle of at least this many bytes go through k_body (option "body_min").  Since k_main
                                        // got cheaper below 256 MiB (dispensers, k_fold: profiles/r02f/split_threshold.txt) the cut pays from 256 MiB:
                                        // 128 MiB -16 %, 256 MiB +0.8 %, 512 MiB +4 %, 1 GiB +11 %, 2 GiB +7 %; it was 128 MiB before, 0.7 GiB in round 1
-    long poll_ns = 200000L;            // how long fetch_tag polls the host slot before it blocks in the runtime (AESGCM_POLL_US)
-    bool tag_in_launch = false;        // the tag of the last message comes from inside its cyclic launch (fetch_tag waits for the launch's end behind it)
+    long poll_ns = 200000L;            // how long fetch_tag polls the host slot before it blocks in the runtime (option "poll_us")
     unsigned long long *d_cyc = nullptr;   // the accumulators and the arrival counter of the fused closing of a cyclic launch (zero between launches)
-    // The tag of a fused cyclic launch appears while the launch is still running, and the call's contract is that the ciphertext is in memory by then.  Three ways,
-    // measured on 64 KiB .. 64 MiB (profiles/r03c/cyc_end.txt, us per message at 64 KiB / 16 MiB): the rows store THROUGH the L2 (sc0 sc1), so no line is left
-    // dirty -- 24 / 40, the default; every workgroup writes its XCD's L2 back before it counts itself arrived (AESGCM_CYC_FUSE=1) -- 29 / 46, the write-back costs 5 us
-    // however little is dirty; the host waits for the end of the launch behind the tag (AESGCM_CYC_FUSE=2) -- 38 / 54, the completion signal of a launch reaches the
-    // host 11 us after its last instruction.  (Three launches, AESGCM_CYC_FUSE=0: 26 (k_main) / 56.)
-    bool cyc_wt = AESGCM_BODY_WT != 0; // (the dealt k_body stores through the L2 as well: the end of a 16 GiB launch has less to write back, step 16.90 -> 16.79 ms, 1 GiB 1140 -> 1118 us,
-                                       // profiles/r03c/body_wt_ab; compile-time: -DAESGCM_BODY_WT=0)
-    bool fold_close = true;            // whole messages through the dealt k_body: k_fold's first level closes the tag (FoldClose; AESGCM_FOLD_CLOSE=0: further levels and k_combine)
-    u32 cyc_prio = 2;                  // rows between rotations of the waves' issue priorities in a cyclic launch (body_prio; AESGCM_CYC_PRIO, 0 = off).  Without it the oldest wave of
+    // The tag of a fused cyclic launch appears while the launch is still running, and the call's contract is that the ciphertext is in memory by then.  Three ways were
+    // built and measured in round 3 (profiles/r03c/cyc_end.txt, us per message at 64 KiB / 16 MiB): the rows store THROUGH the L2 (sc0 sc1), so no line is left dirty --
+    // 24 / 40, what ships (AESGCM_BODY_WT); every workgroup writes its XCD's L2 back before it counts itself arrived -- 29 / 46 (what a -DAESGCM_BODY_WT=0 build does);
+    // the host waits for the end of the launch behind the tag -- 38 / 54 (deleted in round 4 with the run-time switch between the three).
+    bool fold_close = true;            // whole messages through the dealt k_body: k_fold's first level closes the tag (FoldClose; option "fold_close" 0: further levels and k_combine)
+    u32 cyc_prio = 2;                  // rows between rotations of the waves' issue priorities in a cyclic launch (body_prio; option "cyc_prio", 0 = off).  Without it the oldest wave of
                                        // every SIMD runs ahead and the youngest finishes alone: 256 MiB 321 -> 291 us, 1 GiB 1238 -> 1105 (dealt chunks: 1090), profiles/r03c/cyc_prio_*.txt
-    bool cyc_wait_end = false;
-    bool cyc_fuse = true;              // whole messages: the cyclic launch closes the tag itself (AESGCM_CYC_FUSE=0: k_fold + k_combine behind it)
-    // Which ranges go through k_body as cyclic rows (body_cyc_lane: one launch for AAD, data and ragged end, no dispenser, 4096 items whatever the size).  AESGCM_BODY_CYC=min:max
-    // (bytes; 0:0 = never); needs one k_body workgroup per CU on 256 CUs.  Whole messages close their tag inside the launch (cyc_close): 24 us from 16 KiB to 2 MiB where
+    bool cyc_fuse = true;              // whole messages: the cyclic launch closes the tag itself (option "cyc_close" 0: k_fold + k_combine behind it, as for shards and streaming chunks)
+    // Which ranges go through k_body as cyclic rows (body_cyc_lane: one launch for AAD, data and ragged end, no dispenser, 4096 items whatever the size).  options "cyc_min" / "cyc_max"
+    // (bytes; both 0 = never); needs one k_body workgroup per CU on 256 CUs.  Whole messages close their tag inside the launch (cyc_close): 24 us from 16 KiB to 2 MiB where
     // k_main + k_fold + k_combine take 27 (64 KiB) .. 39 (256 KiB) .. 34 (1 MiB), profiles/r03c/cyc_small.txt -- from 64 KiB.  Shards and streaming chunks keep k_fold + k_combine
     // behind the launch and start at 4 MiB (2 MiB: 35 -> 37 us, 4 MiB: 39 -> 38).  The upper end: with the waves' priorities rotating (cyc_prio) equal shares hold up to about
     // 1 GiB -- AES-256, us per message, dealt chunks / cyclic rows: 512 MiB 577 / 555, 768 MiB 824 / 818, 896 MiB 970 / 932, 1 GiB 1069 / 1099, 1.25 GiB 1370 / 1381
@@ -1442,14 +1290,10 @@ static int set_lds_attrs(int device, DeviceState *ds) {
 #undef SETATTRB
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_combine), hipFuncAttributeMaxDynamicSharedMemorySize, CMB_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_combine_batch), hipFuncAttributeMaxDynamicSharedMemorySize, CMB_LDS_BYTES));
-#define SETATTRB2(NR, D, LG) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch2<NR, D, LG>), hipFuncAttributeMaxDynamicSharedMemorySize, BATCH2_LDS_BYTES(LG)))
-    SETATTRB2(10, 0, 4); SETATTRB2(12, 0, 4); SETATTRB2(14, 0, 4); SETATTRB2(10, 1, 4); SETATTRB2(12, 1, 4); SETATTRB2(14, 1, 4);
 #define SETATTRB3(NR, D) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch3<NR, D, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, BATCH3_LDS_BYTES_LG(4))); \
                          HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch3<NR, D, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, BATCH3_LDS_BYTES_LG(3)))
     SETATTRB3(10, 0); SETATTRB3(12, 0); SETATTRB3(14, 0); SETATTRB3(10, 1); SETATTRB3(12, 1); SETATTRB3(14, 1);
 #undef SETATTRB3
-
-#undef SETATTRB2
     ds->attrs = true;
     return AESGCM_OK;
 }
@@ -1534,7 +1378,7 @@ static int enqueue_main(aesgcm_ctx *c, int mode, const uint8_t iv[12], const voi
     p.counter = c->d_counter + 16 * (1 + AESGCM_NQ * c->qset);
     p.counter_zero = c->d_counter + 16 * (1 + AESGCM_NQ * (c->qset ^ 1u));
     if (gh && po) { p.ej0 = c->d_tag + 3; po->ej0 = p.ej0; }
-    if (gh && po && want_tail && C == 1) { p.tail = 1; p.tag_out = c->d_tag; p.tag_host = c->h_tag_dev; p.gen = ++c->tag_gen; po->done = true; c->tag_in_launch = false; }
+    if (gh && po && want_tail && C == 1) { p.tail = 1; p.tag_out = c->d_tag; p.tag_host = c->h_tag_dev; p.gen = ++c->tag_gen; po->done = true; }
     p.trace = nullptr;
     const bool timed = c->timing && !c->timing_mute;
     if (timed) {
@@ -1653,10 +1497,9 @@ static int enqueue_cyc(aesgcm_ctx *c, int mode, const uint8_t iv[12], const void
     *po = Partials();
     p.prio_rows = c->cyc_prio;
     if (fused) {                                                                // the launch closes the tag itself (cyc_close): nothing behind it
-        p.fuse = c->cyc_wait_end ? 3 : c->cyc_wt ? 5 : 1; p.aad_len = aad_len; p.ct_len = len; p.acc = c->d_cyc;
+        p.fuse = 1; p.aad_len = aad_len; p.ct_len = len; p.acc = c->d_cyc;
         p.tag_out = c->d_tag; p.tag_host = c->h_tag_dev; p.gen = ++c->tag_gen;
         po->done = true;
-        c->tag_in_launch = c->cyc_wait_end;
         return launch_body(c, mode, p, BODY_CYC_WAVES / (AESGCM_BODY_WG / 64), st);
     }
     p.ej0 = c->d_tag + 3; po->ej0 = p.ej0;
@@ -1713,7 +1556,7 @@ static int absorb_range(aesgcm_ctx *c, int mode, const uint8_t iv[12], const voi
 
 static int enqueue_combine(aesgcm_ctx *c, const CombineParams &p0, hipStream_t st) {
     CombineParams p = p0;
-    if (p.out == c->d_tag) { p.out_host = c->h_tag_dev; p.gen = ++c->tag_gen; c->tag_in_launch = false; }   // results that go to the tag slot are mirrored to the pinned host slot
+    if (p.out == c->d_tag) { p.out_host = c->h_tag_dev; p.gen = ++c->tag_gen; }   // results that go to the tag slot are mirrored to the pinned host slot
     if (p.kind == PARTS_ITEM && p.np > 1) {                       // the launch folds the items itself: tables of H^eA, H^(8 eA)
         p.tabA = ptab_ptr(c, p.eA);
         p.tabB = p.np > 4 ? ptab_ptr(c, 4 * p.eA) : nullptr;
@@ -1762,7 +1605,7 @@ static int crypt_dev(aesgcm_ctx *c, int dec, const uint8_t iv[12], const void *d
                 fc.tag_out = c->d_tag; fc.tag_host = c->h_tag_dev; fc.gen = c->tag_gen + 1;
             }
             if ((rc = enqueue_body(c, dec ? MODE_DEC : MODE_ENC, iv, b, d_in, d_out, 0, st, &pb, c->fold_close ? &fc : nullptr))) return rc;
-            if (pb.done) { ++c->tag_gen; c->tag_in_launch = false; return AESGCM_OK; }
+            if (pb.done) { ++c->tag_gen; return AESGCM_OK; }
             CombineParams q = combine_with_items(plan_combine_tag(pb.ptr, pb.np, pb.kind, iv, 0, len, c->d_tag), pb.eA);
             q.ej0 = pb.ej0;
             return enqueue_combine(c, q, st);
@@ -1789,12 +1632,12 @@ static int crypt_dev(aesgcm_ctx *c, int dec, const uint8_t iv[12], const void *d
 // the generation number; the host polls that number for a short while (a kernel-completion interrupt costs ~10 us on
 // this platform, a poll of coherent host memory well under one) and falls back to a stream synchronisation for long-
 // running work or if anything went wrong.
-// What has happened when this returns: the stream is synchronised in every case but one -- a tag published from INSIDE a launch (k_body's cyclic rows,
-// cyc_close; k_fold's closing, acc_arrive) is seen while that launch is still running.  Every byte of the result is in device memory by then: the rows
-// store through the L2 (global_store ... sc0 sc1, gstore16_wt / gstore*_wt_at; AESGCM_BODY_WT, asserted where k_body is defined), each workgroup waits
-// for its own stores (s_waitcnt vmcnt(0)) before it counts itself arrived, and the tag is published by the workgroup that counts the last arrival.  For
-// the in-launch case this function then polls the stream's completion (hipStreamQuery) so that the call still returns with a synchronised stream;
-// examples/early_read.cpp is the standing check of the stronger claim (a copy ordered behind nothing reads the whole result the moment the tag is there).
+// What has happened when this returns: a tag published from INSIDE a launch (k_body's cyclic rows, cyc_close; k_fold's closing, acc_arrive) is seen while that
+// launch is still running, and this function does NOT wait for its end -- the stream is not synchronised.  Every byte of the result is in device memory all the
+// same: the rows store through the L2 (global_store ... sc0 sc1, gstore16_wt / gstore*_wt_at, AESGCM_BODY_WT), each workgroup waits for the acknowledgement of
+// its own stores (s_waitcnt vmcnt(0)) before it counts itself arrived, and the tag is published by the workgroup that counts the last arrival; the launch
+// retires a few microseconds later.  examples/early_read.cpp (tests/test_gpu_cyclic.py) is the standing check: a copy ordered behind nothing reads the whole
+// result the moment the tag is there.  Tags that come from k_combine or k_main's tail are published by the last kernel of the call.
 static int fetch_tag(aesgcm_ctx *c, hipStream_t st, uint8_t tag[16]) {
     const u64 want = c->tag_gen;
     volatile u64 *gen = reinterpret_cast<volatile u64 *>(c->h_tag + 1);
@@ -1812,19 +1655,6 @@ static int fetch_tag(aesgcm_ctx *c, hipStream_t st, uint8_t tag[16]) {
 #endif
     }
     if (!seen) HIPCHK(hipStreamSynchronize(st));
-    else if (c->tag_in_launch) {
-        // the cyclic launch published the tag from inside: every workgroup has stored its ciphertext by then, but the launch -- and with it the write-back of
-        // the other XCDs' L2s -- ends a few microseconds later.  The call promises a synchronised stream, so wait for the end; polling the stream's
-        // completion is still far cheaper than the interrupt-driven wait
-        hipError_t q = hipErrorNotReady;
-        for (u32 spin = 0; spin < 4096 && (q = hipStreamQuery(st)) == hipErrorNotReady; ++spin) {
-#if defined(__x86_64__)
-            __builtin_ia32_pause();
-#endif
-        }
-        if (q == hipErrorNotReady) HIPCHK(hipStreamSynchronize(st));
-        else if (q != hipSuccess) return hip_fail(q, "hipStreamQuery");
-    }
     memcpy(tag, c->h_tag, 16);
     return AESGCM_OK;
 }
@@ -1894,19 +1724,7 @@ static int ctx_create_common(aesgcm_ctx **out, int device, const uint8_t *key, s
     c->device = device;
     c->tables = ds->tables;
     c->nr = pre_nr ? pre_nr : (int)(key_len / 4 + 6);
-    int per_cu = 2;
-    if (const char *e = getenv("AESGCM_WGS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 2) per_cu = v; }
-    if (const char *e = getenv("AESGCM_TW")) c->tw_override = (u32)strtoul(e, nullptr, 0);
-    if (const char *e = getenv("AESGCM_BODY_MIN")) { c->body_min = strtoull(e, nullptr, 0); if (c->body_min >= (1ull << 60)) c->cyc_max = c->cyc_max_pieces = c->cyc_max_fused = 0; }   // "never k_body" means it
-    if (const char *e = getenv("AESGCM_CYC_FUSE")) { c->cyc_fuse = atoi(e) != 0; c->cyc_wait_end = atoi(e) == 2; c->cyc_wt = AESGCM_BODY_WT != 0 && atoi(e) != 1 && atoi(e) != 2; }   // 0: k_fold + k_combine; 1: + write-back; 2: wait for the end; default: nothing (the rows went through the L2)
-    if (const char *e = getenv("AESGCM_POLL_US")) c->poll_ns = 1000L * atol(e);
-    if (const char *e = getenv("AESGCM_CYC_PRIO")) c->cyc_prio = (u32)strtoul(e, nullptr, 0);
-    if (const char *e = getenv("AESGCM_FOLD_CLOSE")) c->fold_close = atoi(e) != 0;
-    if (const char *e = getenv("AESGCM_BODY_CYC")) {
-        char *end = nullptr;
-        const u64 lo = strtoull(e, &end, 0);
-        if (end && *end == ':') { c->cyc_min = c->cyc_min_fused = lo; c->cyc_max = c->cyc_max_pieces = c->cyc_max_fused = strtoull(end + 1, nullptr, 0); }
-    }
+    const int per_cu = 2;
     int G = per_cu * ds->n_cu;
     if (G > AESGCM_GMAX) G = AESGCM_GMAX;
     if (G < 1) G = 1;
@@ -1979,6 +1797,25 @@ int aesgcm_ctx_destroy(aesgcm_ctx *c) {
     return AESGCM_OK;
 }
 int aesgcm_ctx_device(const aesgcm_ctx *c) { return c ? c->device : AESGCM_EARG; }
+// Tunables of ONE context, for tests and profiling scripts (the defaults are the measured best; nothing in the library reads the environment).
+// Every value selects between paths that produce the same bytes; the parity tests use them to reach each path at sizes a CPU check finishes in seconds.
+int aesgcm_ctx_set_option(aesgcm_ctx *c, const char *key, int64_t value) {
+    if (!c || !key || value < 0) return AESGCM_EARG;
+    const u64 v = (u64)value;
+    if (!strcmp(key, "tw")) c->tw_override = (u32)v;                                   // rows per chunk of the dealt kernels (0 = the library's rule)
+    else if (!strcmp(key, "body_min")) {                                              // bytes from which a range's aligned middle goes through k_body
+        c->body_min = v;
+        if (v >= (1ull << 60)) c->cyc_max = c->cyc_max_pieces = c->cyc_max_fused = 0;  // "never k_body" means the cyclic rows too
+    }
+    else if (!strcmp(key, "cyc_min")) c->cyc_min = c->cyc_min_fused = v;               // bytes: ranges in [cyc_min, cyc_max) take k_body's cyclic rows; both 0 = never
+    else if (!strcmp(key, "cyc_max")) c->cyc_max = c->cyc_max_pieces = c->cyc_max_fused = v;
+    else if (!strcmp(key, "cyc_close")) c->cyc_fuse = v != 0;                          // 1: a whole message's cyclic launch closes the tag itself; 0: k_fold + k_combine behind it
+    else if (!strcmp(key, "fold_close")) c->fold_close = v != 0;                       // 1: behind the dealt k_body the first (or second) k_fold level closes the tag
+    else if (!strcmp(key, "cyc_prio")) c->cyc_prio = (u32)v;                           // rows between rotations of the waves' issue priorities in a cyclic launch (0 = off)
+    else if (!strcmp(key, "poll_us")) c->poll_ns = 1000L * (long)v;                    // how long a tag is polled for in the host slot before the call blocks in the runtime
+    else return AESGCM_EARG;
+    return AESGCM_OK;
+}
 int aesgcm_ctx_stream(const aesgcm_ctx *c, void **stream) {
     if (!c || !stream) return AESGCM_EARG;
     *stream = (void *)c->stream;
@@ -2306,7 +2143,7 @@ int aesgcm_shard_finalize_batch_dev(aesgcm_ctx *c, size_t n_msgs, const uint8_t 
         if (seen) break;
         if ((spin & 63u) == 63u) {
             clock_gettime(CLOCK_MONOTONIC, &t1);
-            if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > 200000L) break;
+            if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > c->poll_ns) break;
         }
 #if defined(__x86_64__)
         __builtin_ia32_pause();
@@ -2383,6 +2220,52 @@ int aesgcm_stream_final(aesgcm_ctx *c, uint8_t tag[16]) {
     return AESGCM_OK;
 }
 
+// ---------------------------------------------------------------- shapes of the packet kernels
+#ifdef AESGCM_DEBUG_KNOBS
+// Test / profiling builds only (libaesgcm_hip_dbg.so, -DAESGCM_DEBUG_KNOBS; include/aesgcm_debug.h): force the kernel shape the next launches take, so that every
+// shape can be checked on inputs the host's own rule would give to another.  The product library has no such switch and reads no environment.
+static struct { int pkt_lanes, pkt_deal, batch_lanes, batch_deal; } g_force = {0, 0, 0, 0};
+extern "C" __attribute__((visibility("default"))) int aesgcm_debug_force_shape(const char *what, int value) {
+    if (!what) return AESGCM_EARG;
+    if (!strcmp(what, "pkt_lanes")) { if (value != 0 && value != 1 && value != 4 && value != 8 && value != 16 && value != 64) return AESGCM_EARG; g_force.pkt_lanes = value; }
+    else if (!strcmp(what, "pkt_deal")) g_force.pkt_deal = value;
+    else if (!strcmp(what, "batch_lanes")) { if (value != 0 && value != 8 && value != 16 && value != 64) return AESGCM_EARG; g_force.batch_lanes = value; }
+    else if (!strcmp(what, "batch_deal")) g_force.batch_deal = value;
+    else return AESGCM_EARG;
+    return AESGCM_OK;
+}
+#endif
+// Packets under ONE key: how many lanes work on one packet, as log2 (0 = one LANE per packet, k_pktl; 2, 3, 4 = a lane GROUP of 4, 8, 16, k_pktg; 6 = a whole
+// wave, k_pktg<.., 6>).  Measured (profiles/r03/packets_sweep_aes256.txt, GiB/s wave / g16 / g8 / g4 / lane): the best shape is the one that just fills the
+// resident lanes (256 CUs x 16 waves x 64) -- 65536 x 1 KiB 203 / 232 / 340 / 384 / 194, 16384 x 4 KiB 235 / 367 / 290 / 177 / 53, 4096 x 16 KiB
+// 362 / 172 / 95 / 49 / 13 (the one regime where a whole wave per packet is right: at most 4096 packets of at least 4 KiB) -- but never more lanes than an
+// eighth of the packet's blocks once the machine is full (closing cost per byte: 16384 x 1 KiB 62 / 128 / 176 / 138 / 50, 16384 x 256 B 16 / 35 / 58 / 72 / 41),
+// a quarter when it is not (4096 x 1 KiB 34 / 69 / 57 / 38 / 13).  Lanes win from 131072 packets (2^20 x 1 KiB 303 / 592 / 657 / 742 / 767; 262144 x 4 KiB
+// 496 / 656 / 704 / 722 / 724), short packets from 32768 (65536 x 256 B 51 / 61 / 95 / 129 / 148).  With offset arrays the host does not know the lengths: it
+// goes by count and assumes 1 KiB.
+static int packets_pick_lg(u32 n_cu, size_t n_pkts, size_t pkt_len, bool var) {
+    const size_t lanes_total = (size_t)n_cu * (AESGCM_PKT_WG / 64) * 64;
+    const size_t blocks = var ? 64 : (pkt_len + 15) / 16;
+    if (var ? n_pkts >= 32768 : (n_pkts >= 131072 || (pkt_len <= 256 && n_pkts >= 32768))) return 0;
+    const size_t fill = lanes_total / n_pkts, cap = n_pkts >= 16384 ? blocks / 8 : blocks / 4;
+    const size_t g = fill < cap ? fill : cap;
+    return g >= 64 ? 6 : g >= 16 ? 4 : g >= 8 ? 3 : 2;
+}
+// Packets with their OWN key (k_batch3 / k_batch): lanes per packet as log2 (3, 4 = k_batch3 with 8 / 16 lanes, 6 = one wave per packet, k_batch).  16 lanes once
+// there are packets enough to fill the machine that way (one 1024-lane workgroup per CU = 64 packets per CU) or the packets are short, else one wave per packet.
+// Measured, AES-128, GiB/s k_batch / k_batch3 (profiles/r03/batch_sweep_aes128.txt): 4096 x 1 KiB 30 / 56, 4096 x 256 B 7.5 / 17, 1024 x 1 KiB 14 / 16.5; 1024 x 4 KiB
+// 45 / 33, 4096 x 4 KiB 108 / 120, 4096 x 16 KiB 286 / 168; from 16384 packets k_batch3 wins at every size (4 KiB 179 / 350).  8 lanes (eight packets per wave
+// share what a wave-iteration pays once) when there are packets enough to fill the chip that way and they are not long: 2^20 packets of 64 B 42 -> 74 GiB/s,
+// 256 B 163 -> 265, 1 KiB 424 -> 560, 1500 B 484 -> 598, 4 KiB 658 -> 706, 16 KiB 770 -> 736; 16384 packets: 1 KiB 125 -> 155, 4 KiB 352 -> 273
+// (profiles/r03c/batch_sweep_lanes8_aes128.txt).  Batches with per-packet lengths (offset arrays on the device: the host does not know the lengths) go by count
+// alone and assume frames of MACsec size, where 8 lanes gain most; a batch of frames beyond 8 KiB loses ~5 % by it.
+static int batch_pick_lg(int n_cu, size_t n_pkts, size_t pkt_len, bool var) {
+    int lg = (n_pkts >= (size_t)64 * n_cu || (!var && pkt_len <= 2048)) ? 4 : 6;
+    if (lg == 4 && (var ? n_pkts >= (size_t)64 * n_cu
+                        : ((n_pkts >= (size_t)256 * n_cu && pkt_len <= 8192) || (n_pkts >= (size_t)64 * n_cu && pkt_len <= 2048)))) lg = 3;
+    return lg;
+}
+
 // ---------------------------------------------------------------- packets under the context's key
 int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const void *d_ivs,
                              const void *d_aad, size_t aad_len, const uint64_t *d_aad_off,
@@ -2402,32 +2285,11 @@ int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const vo
     p.aligned = (((uintptr_t)d_in | (uintptr_t)d_out) & 15) == 0 && (d_data_off || pkt_len % 16 == 0);
     const u32 waves_per_wg = AESGCM_PKT_WG / 64;
     const u32 n_cu = (u32)c->G / 2;                                                 // c->G = two workgroups per CU
-    // shape: how many lanes work on one packet.  One LANE per packet (k_pktl) when the packets alone fill the machine's lanes;
-    // otherwise a lane GROUP per packet (k_pktg: 4, 8 or 16 lanes, 16 / 8 / 4 packets per wave) or a whole wave (k_pktg<.., 6>).
-    // Measured (profiles/r03/packets_sweep_aes256.txt, GiB/s wave / g16 / g8 / g4 / lane): the best shape is the one that just
-    // fills the resident lanes (256 CUs x 16 waves x 64) -- 65536 x 1 KiB 203 / 232 / 340 / 384 / 194, 16384 x 4 KiB 235 / 367 /
-    // 290 / 177 / 53, 4096 x 16 KiB 362 / 172 / 95 / 49 / 13 -- but never more lanes than an eighth of the packet's blocks once
-    // the machine is full (closing cost per byte: 16384 x 1 KiB 62 / 128 / 176 / 138 / 50, 16384 x 256 B 16 / 35 / 58 / 72 / 41), a
-    // quarter when it is not (4096 x 1 KiB 34 / 69 / 57 / 38 / 13).  Lanes win from 131072 packets (2^20 x 1 KiB 303 / 592 / 657 /
-    // 742 / 767; 262144 x 4 KiB 496 / 656 / 704 / 722 / 724), short packets from 32768 (65536 x 256 B 51 / 61 / 95 / 129 / 148).
-    // With offset arrays the host does not know the lengths: it goes by count and assumes 1 KiB.
-    // AESGCM_PKT_SHAPE=l|w|g|g8|g4 forces lane / wave / 16- / 8- / 4-lane groups.
-    const size_t lanes_total = (size_t)n_cu * waves_per_wg * 64;
-    const size_t blocks = d_data_off ? 64 : (pkt_len + 15) / 16;
-    int shape, lg = 6;
-    if (d_data_off ? n_pkts >= 32768 : (n_pkts >= 131072 || (pkt_len <= 256 && n_pkts >= 32768))) shape = 'l';
-    else {
-        const size_t fill = lanes_total / n_pkts, cap = n_pkts >= 16384 ? blocks / 8 : blocks / 4;
-        const size_t g = fill < cap ? fill : cap;
-        lg = g >= 64 ? 6 : g >= 16 ? 4 : g >= 8 ? 3 : 2;
-        shape = lg == 6 ? 'w' : 'g';
-    }
-    if (const char *e = getenv("AESGCM_PKT_SHAPE")) {                                // l | w | g (= g16) | g8 | g4
-        if (e[0] == 'l' || e[0] == 'g' || e[0] == 'w') {
-            shape = e[0];
-            lg = shape == 'g' ? (e[1] == '8' ? 3 : e[1] == '4' ? 2 : 4) : 6;
-        }
-    }
+    int lg = packets_pick_lg(n_cu, n_pkts, pkt_len, d_data_off != nullptr);
+#ifdef AESGCM_DEBUG_KNOBS
+    if (g_force.pkt_lanes) lg = g_force.pkt_lanes == 1 ? 0 : g_force.pkt_lanes == 64 ? 6 : g_force.pkt_lanes == 16 ? 4 : g_force.pkt_lanes == 8 ? 3 : 2;
+#endif
+    const int shape = lg == 0 ? 'l' : lg == 6 ? 'w' : 'g';
     hipStream_t st = pick_stream(c, stream);
     p.counter = c->d_counter; p.counter_base = c->counter_base;
     if (shape == 'l') {
@@ -2446,7 +2308,9 @@ int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const vo
         u32 deal = (u32)(n_pkts / ((size_t)n_cu * waves_per_wg * 4));
         deal = deal / P * P;
         deal = deal < P ? P : deal > PKTG_MAX_DEAL ? PKTG_MAX_DEAL : deal;
-        if (const char *e = getenv("AESGCM_PKT_DEAL")) { const long v = atol(e); if (v >= 1 && v <= (long)PKTG_MAX_DEAL) deal = ((u32)v + P - 1) / P * P; }
+#ifdef AESGCM_DEBUG_KNOBS
+        if (g_force.pkt_deal >= 1 && g_force.pkt_deal <= (int)PKTG_MAX_DEAL) deal = ((u32)g_force.pkt_deal + P - 1) / P * P;
+#endif
         p.deal = deal;
         const u32 nb = (u32)((n_pkts + deal - 1) / deal);
         u32 wgs = (nb + waves_per_wg - 1) / waves_per_wg;
@@ -2465,11 +2329,6 @@ int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const vo
 }
 
 // ---------------------------------------------------------------- batch (per-packet key and IV)
-// AESGCM_BATCH_FUSED=0 selects the two-phase k_batch2 (encrypt, fence, read the ciphertext back) instead of k_batch3, for A/B runs
-static bool fused_default() {
-    if (const char *e = getenv("AESGCM_BATCH_FUSED")) return atoi(e) != 0;
-    return true;
-}
 static int batch_launch(int device, int decrypt, size_t n_pkts, size_t key_len, BatchParams &p, void *stream) {
     if (key_len != 16 && key_len != 24 && key_len != 32) return AESGCM_EKEYLEN;
     if (n_pkts >= (((size_t)1) << 31)) return AESGCM_ETOOLONG;
@@ -2491,46 +2350,32 @@ static int batch_launch(int device, int decrypt, size_t n_pkts, size_t key_len, 
     {   // deal: about 16 dispenser fetches per wave, at most 16 packets per fetch
         u32 deal = (u32)(n_pkts / ((size_t)wgs * waves_per_wg * 16));
         deal = deal < 1 ? 1 : deal > 16 ? 16 : deal;
-        if (const char *e = getenv("AESGCM_PKT_DEAL")) { const long v = atol(e); if (v >= 1 && v <= 4096) deal = (u32)v; }
+#ifdef AESGCM_DEBUG_KNOBS
+        if (g_force.batch_deal >= 1 && g_force.batch_deal <= 4096) deal = (u32)g_force.batch_deal;
+#endif
         p.deal = deal;
     }
     const int nr = (int)(key_len / 4 + 6);
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipMemsetAsync(p.counter, 0, 4, st));
-    // shape: 16 lanes per packet in one pass (k_batch3: four packets share a wave's tree and closing multiplies) once there are
-    // enough packets to fill the machine that way (one 1024-lane workgroup per CU = 64 packets per CU) or the packets are short,
-    // else one wave per packet (k_batch).  AESGCM_BATCH_LG=3|4|6 forces one (3 = 8 lanes per packet, below).  Measured, AES-128, GiB/s k_batch / k_batch3
-    // (profiles/r03/batch_sweep_aes128.txt): 4096 x 1 KiB 30 / 56, 4096 x 256 B 7.5 / 17, 1024 x 1 KiB 14 / 16.5; 1024 x 4 KiB
-    // 45 / 33, 4096 x 4 KiB 108 / 120, 4096 x 16 KiB 286 / 168; from 16384 packets k_batch3 wins at every size (4 KiB 179 / 350).
-    int lg = (n_pkts >= (size_t)64 * ds->n_cu || (!p.data_off && p.pkt_len <= 2048)) ? 4 : 6;
-    // 8 lanes per packet (eight packets per wave share what a wave-iteration pays once) when there are packets enough to fill the chip that way and they are
-    // not long: 2^20 packets of 64 B 42 -> 74 GiB/s, 256 B 163 -> 265, 1 KiB 424 -> 560, 1500 B 484 -> 598, 4 KiB 658 -> 706 (cfg5: 646 -> 685), 16 KiB 770 -> 736;
-    // 16384 packets: 1 KiB 125 -> 155, 4 KiB 352 -> 273 (profiles/r03c/batch_sweep_lanes8_aes128.txt).  Batches with per-packet lengths keep 16 lanes.
-    // Batches with per-packet lengths (offset arrays on the device: the host does not know the lengths) go by count alone and assume frames of
-    // MACsec size, where 8 lanes gain most (round 3: 256 B +63 %, 1 KiB +32 %, 1500 B +24 %); a batch of frames beyond 8 KiB loses ~5 % by it.
-    if (lg == 4 && fused_default() &&
-        (p.data_off ? n_pkts >= (size_t)64 * ds->n_cu
-                    : ((n_pkts >= (size_t)256 * ds->n_cu && p.pkt_len <= 8192) || (n_pkts >= (size_t)64 * ds->n_cu && p.pkt_len <= 2048)))) lg = 3;
-    if (const char *e = getenv("AESGCM_BATCH_LG")) { const int v = atoi(e); if (v == 3 || v == 4 || v == 6) lg = v; }
-    if (lg == 3 && !fused_default()) lg = 4;                          // 8 lanes per packet exist in the one-pass kernel only
+    int lg = batch_pick_lg(ds->n_cu, n_pkts, p.pkt_len, p.data_off != nullptr);          // 3 / 4: k_batch3 with 8 / 16 lanes per packet; 6: k_batch
+#ifdef AESGCM_DEBUG_KNOBS
+    if (g_force.batch_lanes) lg = g_force.batch_lanes == 8 ? 3 : g_force.batch_lanes == 16 ? 4 : 6;
+#endif
     if (lg < 6) {
-        const u32 waves_per_wg = (u32)(fused_default() ? BATCH3_LANES(nr) : AESGCM_WG) / 64;
+        const u32 waves_per_wg = (u32)BATCH3_LANES(nr) / 64;
         const u32 P = 64u >> lg, per_wg = waves_per_wg * P;
         wgs = (u32)((n_pkts + per_wg - 1) / per_wg);
         if (wgs > (u32)ds->n_cu) wgs = (u32)ds->n_cu;
         u32 deal = (u32)(n_pkts / ((size_t)wgs * waves_per_wg * 16));
         deal = deal < P ? P : deal > 8 * P ? 8 * P : (deal + P - 1) / P * P;
         p.deal = deal;
-        const bool fused = fused_default();
-#define LB2(NR, D, LG) hipLaunchKernelGGL((k_batch2<NR, D, LG>), dim3(wgs), dim3(AESGCM_WG), BATCH2_LDS_BYTES(LG), st, ds->tables, p)
 #define LB3(NR, D, LG) hipLaunchKernelGGL((k_batch3<NR, D, LG>), dim3(wgs), dim3(BATCH3_LANES(NR)), BATCH3_LDS_BYTES_LG(LG), st, ds->tables, p)
-#define LB2N(D, LG) do { if (fused) { if (nr == 10) LB3(10, D, LG); else if (nr == 12) LB3(12, D, LG); else LB3(14, D, LG); } \
-                         else { if (nr == 10) LB2(10, D, 4); else if (nr == 12) LB2(12, D, 4); else LB2(14, D, 4); } } while (0)
-        if (lg == 3) { if (decrypt) LB2N(1, 3); else LB2N(0, 3); }
-        else { if (decrypt) LB2N(1, 4); else LB2N(0, 4); }
-#undef LB2N
+#define LB3N(D, LG) do { if (nr == 10) LB3(10, D, LG); else if (nr == 12) LB3(12, D, LG); else LB3(14, D, LG); } while (0)
+        if (lg == 3) { if (decrypt) LB3N(1, 3); else LB3N(0, 3); }
+        else { if (decrypt) LB3N(1, 4); else LB3N(0, 4); }
+#undef LB3N
 #undef LB3
-#undef LB2
         HIPCHK(hipGetLastError());
         return AESGCM_OK;
     }
@@ -2571,6 +2416,30 @@ int aesgcm_batch_crypt_var_dev(int device, int decrypt, size_t n_pkts, size_t ke
     p.data_off = (const u64 *)d_data_off; p.aad_off = (const u64 *)d_aad_off;
     p.aligned = (((uintptr_t)d_in | (uintptr_t)d_out) & 15) == 0;      // per packet: and its offset is a multiple of 16
     return batch_launch(device, decrypt, n_pkts, key_len, p, stream);
+}
+
+// Which kernel shape a call with these arguments takes (lanes per packet: 1 = one lane per packet, 4 / 8 / 16 = a lane group, 64 = a whole wave); pkt_len = 0
+// with var_len != 0 describes the offset-array forms.  What bench.py and the profiling scripts print beside their numbers.
+int aesgcm_batch_shape(int device, size_t n_pkts, size_t pkt_len, int var_len, int *lanes_per_packet) {
+    if (!lanes_per_packet || !n_pkts) return AESGCM_EARG;
+    DeviceState *ds;
+    int rc = device_state(device, &ds);
+    if (rc) return rc;
+    int lg = batch_pick_lg(ds->n_cu, n_pkts, pkt_len, var_len != 0);
+#ifdef AESGCM_DEBUG_KNOBS
+    if (g_force.batch_lanes) lg = g_force.batch_lanes == 8 ? 3 : g_force.batch_lanes == 16 ? 4 : 6;
+#endif
+    *lanes_per_packet = 1 << lg;
+    return AESGCM_OK;
+}
+int aesgcm_packets_shape(const aesgcm_ctx *c, size_t n_pkts, size_t pkt_len, int var_len, int *lanes_per_packet) {
+    if (!c || !lanes_per_packet || !n_pkts) return AESGCM_EARG;
+    int lg = packets_pick_lg((u32)c->G / 2, n_pkts, pkt_len, var_len != 0);
+#ifdef AESGCM_DEBUG_KNOBS
+    if (g_force.pkt_lanes) lg = g_force.pkt_lanes == 1 ? 0 : g_force.pkt_lanes == 64 ? 6 : g_force.pkt_lanes == 16 ? 4 : g_force.pkt_lanes == 8 ? 3 : 2;
+#endif
+    *lanes_per_packet = 1 << lg;
+    return AESGCM_OK;
 }
 
 // ---------------------------------------------------------------- pipelined host-buffer path

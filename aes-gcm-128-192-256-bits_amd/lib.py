@@ -8,21 +8,21 @@ buffers).  Loading fails loudly when the library is missing; compute calls fail 
 import ctypes
 import os
 
-from .build import SO, build
+from .build import SO, SO_DEBUG, build
 
 OK, EARG, EKEYLEN, EIVLEN, ETOOLONG, EAUTH, EHIP, ENOMEM, ESTATE, EALIGN, ERCCL = 0, -1, -2, -3, -4, -5, -6, -7, -8, -9, -10
 
-ABI_VERSION = 2         # AESGCM_ABI_VERSION of include/aesgcm.h this binding was written against
+ABI_VERSION = 3         # AESGCM_ABI_VERSION of include/aesgcm.h this binding was written against
 
 # every symbol include/aesgcm.h declares (tests check the .so exports exactly these)
 SYMBOLS = [
     "aesgcm_abi_version", "aesgcm_strerror", "aesgcm_last_error", "aesgcm_device_count", "aesgcm_device_name",
     "aesgcm_key_expand", "aesgcm_ecb_encrypt", "aesgcm_gfmul", "aesgcm_ghash", "aesgcm_get_h",
-    "aesgcm_ctx_create", "aesgcm_ctx_create_preexpanded", "aesgcm_ctx_destroy", "aesgcm_ctx_device", "aesgcm_ctx_stream", "aesgcm_ctx_wait", "aesgcm_ctx_wait_fused",
+    "aesgcm_ctx_create", "aesgcm_ctx_create_preexpanded", "aesgcm_ctx_destroy", "aesgcm_ctx_device", "aesgcm_ctx_set_option", "aesgcm_ctx_stream", "aesgcm_ctx_wait", "aesgcm_ctx_wait_fused",
     "aesgcm_encrypt_pipelined", "aesgcm_decrypt_pipelined", "aesgcm_host_alloc", "aesgcm_host_free",
     "aesgcm_encrypt", "aesgcm_decrypt", "aesgcm_encrypt_dev", "aesgcm_decrypt_dev", "aesgcm_last_tag",
     "aesgcm_keystream", "aesgcm_keystream_dev",
-    "aesgcm_shard_crypt_dev", "aesgcm_shard_finalize_dev", "aesgcm_shard_finalize_strided_dev", "aesgcm_shard_finalize_batch_dev", "aesgcm_batch_crypt_dev", "aesgcm_batch_crypt_var_dev", "aesgcm_packets_crypt_dev",
+    "aesgcm_shard_crypt_dev", "aesgcm_shard_finalize_dev", "aesgcm_shard_finalize_strided_dev", "aesgcm_shard_finalize_batch_dev", "aesgcm_batch_crypt_dev", "aesgcm_batch_crypt_var_dev", "aesgcm_packets_crypt_dev", "aesgcm_batch_shape", "aesgcm_packets_shape",
     "aesgcm_stream_begin", "aesgcm_stream_aad", "aesgcm_stream_update", "aesgcm_stream_final",
     "aesgcm_dev_alloc", "aesgcm_dev_free", "aesgcm_dev_upload", "aesgcm_dev_download", "aesgcm_dev_sync", "aesgcm_dev_copy",
     "aesgcm_fill_splitmix64_dev",
@@ -59,7 +59,41 @@ def load():
     if _L is not None:
         return _L
     build()                       # no-op when the .so is newer than csrc/ and include/aesgcm.h; tolerates a missing hipcc if a prebuilt .so exists
-    L = ctypes.CDLL(SO)
+    _L = _typed(ctypes.CDLL(SO))
+    return _L
+
+
+_DBG = None
+
+
+class debug_library:
+    """`with lib.debug_library() as dbg:` -- inside the block every function of this module goes to libaesgcm_hip_dbg.so, the
+    -DAESGCM_DEBUG_KNOBS build of the same sources, whose one extra export forces kernel shapes (include/aesgcm_debug.h):
+    `dbg.force(pkt_lanes=8)`, `dbg.force(batch_lanes=16)`, ...; leaving the block clears every force and switches back to the
+    product library.  Device memory is the process's (either library's allocations serve both); contexts belong to the library
+    that made them, so create them inside the block.  Tests and profiling scripts only."""
+
+    def __enter__(self):
+        global _L, _DBG
+        load()
+        if _DBG is None:
+            _DBG = _typed(ctypes.CDLL(SO_DEBUG))
+            _DBG.aesgcm_debug_force_shape.argtypes = [cp, cint]
+        self._prev, _L = _L, _DBG
+        return self
+
+    def force(self, **kw):
+        for k, v in kw.items():
+            _chk(_DBG.aesgcm_debug_force_shape(k.encode(), int(v)))
+
+    def __exit__(self, *a):
+        global _L
+        for k in ("pkt_lanes", "pkt_deal", "batch_lanes", "batch_deal"):
+            _DBG.aesgcm_debug_force_shape(k.encode(), 0)
+        _L = self._prev
+
+
+def _typed(L):
     L.aesgcm_strerror.restype = cp
     L.aesgcm_strerror.argtypes = [cint]
     L.aesgcm_last_error.restype = cp
@@ -74,6 +108,7 @@ def load():
     L.aesgcm_ctx_create_preexpanded.argtypes = [ctypes.POINTER(vp), cint, vp, cint]
     L.aesgcm_ctx_destroy.argtypes = [vp]
     L.aesgcm_ctx_device.argtypes = [vp]
+    L.aesgcm_ctx_set_option.argtypes = [vp, cp, ctypes.c_int64]
     L.aesgcm_ctx_stream.argtypes = [vp, ctypes.POINTER(vp)]
     L.aesgcm_ctx_wait.argtypes = [vp, vp]
     L.aesgcm_ctx_wait_fused.argtypes = [vp, vp]
@@ -95,6 +130,8 @@ def load():
     L.aesgcm_batch_crypt_dev.argtypes = [cint, cint, sz, sz, vp, vp, vp, sz, vp, sz, vp, vp, vp, vp, vp]
     L.aesgcm_batch_crypt_var_dev.argtypes = [cint, cint, sz, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.aesgcm_packets_crypt_dev.argtypes = [vp, cint, sz, vp, vp, sz, vp, vp, sz, vp, vp, vp, vp, vp, vp]
+    L.aesgcm_batch_shape.argtypes = [cint, sz, sz, cint, ctypes.POINTER(cint)]
+    L.aesgcm_packets_shape.argtypes = [vp, sz, sz, cint, ctypes.POINTER(cint)]
     L.aesgcm_stream_begin.argtypes = [vp, vp, cint]
     L.aesgcm_stream_aad.argtypes = [vp, vp, sz]
     L.aesgcm_stream_update.argtypes = [vp, vp, sz, vp]
@@ -133,7 +170,6 @@ def load():
     L.aesgcm_mgpu_destroy.argtypes = [vp]
     if L.aesgcm_abi_version() != ABI_VERSION:
         raise ImportError("libaesgcm_hip.so ABI %d, expected %d (stale build? rebuild with `make -C csrc`)" % (L.aesgcm_abi_version(), ABI_VERSION))
-    _L = L
     return L
 
 
@@ -283,6 +319,13 @@ def batch_crypt_var_dev(decrypt, n_pkts, key_len, d_keys, d_ivs, d_in, d_data_of
                                            d_in, d_data_off, d_out, d_tags, d_expect_tags, d_auth, stream))
 
 
+def batch_shape(n_pkts, pkt_len=0, var_len=False, device=0):
+    """lanes per packet the batch entry points take for such a call: 8 / 16 (k_batch3) or 64 (k_batch)"""
+    v = cint(0)
+    _chk(load().aesgcm_batch_shape(device, n_pkts, pkt_len, int(bool(var_len)), ctypes.byref(v)))
+    return v.value
+
+
 class PinnedBuffer:
     """Page-locked host memory (hipHostMalloc) exposed as a writable memoryview / numpy-compatible buffer."""
 
@@ -359,13 +402,15 @@ class Context:
             _chk(L.aesgcm_ctx_create(ctypes.byref(c), device, key, len(key)))
         self._c = c.value
         self.device = device
+        self._lib = L               # the library that made it destroys it (debug_library switches the module's library for a block)
 
     _borrowed = False           # True for a view of a context another object owns (MultiGpu.context)
+    _lib = None
 
     def close(self):
         if self._c:
             if not self._borrowed:
-                load().aesgcm_ctx_destroy(self._c)
+                (self._lib or load()).aesgcm_ctx_destroy(self._c)
             self._c = None
 
     __del__ = close
@@ -375,6 +420,17 @@ class Context:
 
     def __exit__(self, *a):
         self.close()
+
+    def set_option(self, key, value):
+        """aesgcm_ctx_set_option: "tw", "body_min", "cyc_min", "cyc_max", "cyc_close", "fold_close", "cyc_prio", "poll_us" (include/aesgcm.h)"""
+        _chk(load().aesgcm_ctx_set_option(self._c, key.encode(), int(value)))
+        return self
+
+    def packets_shape(self, n_pkts, pkt_len=0, var_len=False):
+        """lanes per packet packets_crypt_dev takes for such a call: 1 (k_pktl), 4 / 8 / 16 or 64 (k_pktg)"""
+        v = cint(0)
+        _chk(load().aesgcm_packets_shape(self._c, n_pkts, pkt_len, int(bool(var_len)), ctypes.byref(v)))
+        return v.value
 
     def stream(self):
         """the context's own HIP stream as an integer handle (what stream=None means)"""

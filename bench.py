@@ -396,8 +396,9 @@ def run_cfg5(args, rank, world, dev, ex, cpu_base):
         pm = pmc_summary("cfg5_n1") if standard and not args.decrypt and N == 1 else {}
         same_build = bool(pm) and pm.get("so_sha256") == so_sha
         nr = key_bits // 32 + 6
-        roofline = {"bound": "hbm", "kernel": pm.get("kernel") or "%s (per-packet aes_kexp + AES-CTR + GHASH)" % (
-                        "k_batch2<%d,%d,4>" % (nr, int(args.decrypt)) if os.environ.get("AESGCM_BATCH_FUSED", "1") == "0" else "k_batch3<%d,%d,%s>" % (nr, int(args.decrypt), os.environ.get("AESGCM_BATCH_LG", "3" if n >= 65536 and pkt <= 8192 else "4"))),
+        lanes = lib.batch_shape(n, pkt, device=dev)                # the shape the library's own rule gives this call (aesgcm_batch_shape)
+        kname = "k_batch<%d,%d>" % (nr, int(args.decrypt)) if lanes == 64 else "k_batch3<%d,%d,%d>" % (nr, int(args.decrypt), 3 if lanes == 8 else 4)
+        roofline = {"bound": "hbm", "kernel": "%s (%d lanes per packet: per-packet aes_kexp + AES-CTR + GHASH)" % (kname, lanes),
                     "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_BYTES_PER_S, 4), "traffic": pm.get("hbm_bytes_per_launch") if same_build else None,
                     "traffic_source": "profiles/pmc_cfg5_n1.json" if pm else None,

@@ -37,7 +37,8 @@
 extern "C" {
 #endif
 
-#define AESGCM_ABI_VERSION 2   /* 2: aesgcm_ctx_wait, aesgcm_comm_* / aesgcm_mgpu_*, packet and batch entry points as listed below */
+#define AESGCM_ABI_VERSION 3   /* 2: aesgcm_ctx_wait, aesgcm_comm_* / aesgcm_mgpu_*, packet and batch entry points; 3: aesgcm_ctx_set_option (the library no longer reads
+                                  any environment variable), aesgcm_batch_shape / aesgcm_packets_shape, aesgcm_mgpu_ctx, aesgcm_last_tag through the host slot */
 
 #if defined(__GNUC__)
 #define AESGCM_API __attribute__((visibility("default")))
@@ -103,6 +104,17 @@ AESGCM_API int aesgcm_ctx_create(aesgcm_ctx **out, int device, const uint8_t *ke
 AESGCM_API int aesgcm_ctx_create_preexpanded(aesgcm_ctx **out, int device, const uint8_t *rk, int nr);
 AESGCM_API int aesgcm_ctx_destroy(aesgcm_ctx *ctx);
 AESGCM_API int aesgcm_ctx_device(const aesgcm_ctx *ctx);
+/* Tunables of one context, for tests and profiling scripts; the library reads no environment variable and the defaults are the
+ * measured best.  Every value selects between paths that produce the same bytes.  Keys (value >= 0):
+ *   "tw"          rows of 64 blocks per chunk of the dealt kernels, 0 = the library's rule
+ *   "body_min"    bytes from which a range's aligned middle goes through k_body's dealt chunks (>= 2^60: never, nor cyclic rows)
+ *   "cyc_min", "cyc_max"   bytes: ranges in [cyc_min, cyc_max) take k_body's cyclic rows (one launch per message); both 0 = never
+ *   "cyc_close"   1: that launch closes the tag itself; 0: k_fold + k_combine behind it
+ *   "fold_close"  1: behind the dealt k_body a k_fold level closes the tag; 0: further levels and k_combine
+ *   "cyc_prio"    rows between rotations of the waves' issue priorities in a cyclic launch, 0 = off
+ *   "poll_us"     how long a tag is polled for in the pinned host slot before the call blocks in the runtime
+ * AESGCM_EARG for an unknown key. */
+AESGCM_API int aesgcm_ctx_set_option(aesgcm_ctx *ctx, const char *key, int64_t value);
 /* the context's own HIP stream (what `stream = NULL` means everywhere): lets a caller order other work -- the
  * aesgcm_comm_allgather_dev of the partials -- behind the context's kernels without a host synchronisation */
 AESGCM_API int aesgcm_ctx_stream(const aesgcm_ctx *ctx, void **stream);
@@ -140,8 +152,10 @@ AESGCM_API int aesgcm_decrypt(aesgcm_ctx *ctx, const uint8_t iv[12], const uint8
  * the message, whose ciphertext stores go through the L2 for that), and the call returns when the
  * slot shows it -- long work falls back to a stream synchronisation.  The launch itself may retire a
  * few microseconds later; anything ordered behind it on `stream`, hipStreamSynchronize and blocking
- * copies see it complete as always.  Pass tag = NULL to skip the wait; the tag then stays in the
- * context and can be fetched with aesgcm_last_tag(). */
+ * copies see it complete as always.  Pass tag = NULL to skip the wait: the call only enqueues, and
+ * aesgcm_last_tag() later collects the tag of the context's most recent message the same way (a poll of
+ * the host slot) -- several contexts of one key, each with its own stream, keep several messages in
+ * flight that way (bench.py --inflight). */
 AESGCM_API int aesgcm_encrypt_dev(aesgcm_ctx *ctx, const uint8_t iv[12], const void *d_aad, size_t aad_len,
                        const void *d_pt, size_t len, void *d_ct, uint8_t tag[16], void *stream);
 AESGCM_API int aesgcm_decrypt_dev(aesgcm_ctx *ctx, const uint8_t iv[12], const void *d_aad, size_t aad_len,
@@ -245,6 +259,11 @@ AESGCM_API int aesgcm_packets_crypt_dev(aesgcm_ctx *ctx, int decrypt, size_t n_p
 AESGCM_API int aesgcm_batch_crypt_dev(int device, int decrypt, size_t n_pkts, size_t key_len, const void *d_keys, const void *d_ivs,
                            const void *d_aad, size_t aad_len, const void *d_in, size_t pkt_len, void *d_out,
                            void *d_tags, const void *d_expect_tags, int *d_auth, void *stream);
+
+/* Which kernel shape a call with these arguments takes: lanes per packet (1 = one lane per packet, 4 / 8 / 16 = a lane group, 64 = a
+ * whole wave).  var_len != 0 describes the offset-array forms (pkt_len ignored: the host does not know the lengths and goes by count). */
+AESGCM_API int aesgcm_batch_shape(int device, size_t n_pkts, size_t pkt_len, int var_len, int *lanes_per_packet);
+AESGCM_API int aesgcm_packets_shape(const aesgcm_ctx *ctx, size_t n_pkts, size_t pkt_len, int var_len, int *lanes_per_packet);
 
 /* Variable-length form (MACsec-shaped traffic like the reference's README vectors: short frames with a
  * per-frame header as AAD, README.md:251-257): packet p occupies bytes [d_data_off[p], d_data_off[p+1]) of

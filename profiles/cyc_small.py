@@ -11,11 +11,8 @@ a.fill_splitmix64(1)
 d_aad = lib.DeviceBuffer(64); d_aad.upload(bytes(range(64)))
 iv = bytes(12)
 for kb in (32, 16):
-    os.environ["AESGCM_BODY_CYC"] = "0:0"
-    old = lib.Context(bytes(range(kb)))
-    os.environ["AESGCM_BODY_CYC"] = "%d:%d" % (16 * KiB, 1 << 50)
-    cyc = lib.Context(bytes(range(kb)))
-    os.environ.pop("AESGCM_BODY_CYC")
+    old = lib.Context(bytes(range(kb))).set_option("cyc_min", 0).set_option("cyc_max", 0)
+    cyc = lib.Context(bytes(range(kb))).set_option("cyc_min", 16 * KiB).set_option("cyc_max", 1 << 50)
     print("AES-%d   KiB   k_main   cyclic   k_main+pieces  cyclic+pieces  (us)" % (kb * 8))
     for kib in (16, 32, 64, 128, 192, 256, 384, 512, 768, 1024, 2048, 4096):
         row = []

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """k_body as cyclic rows (with k_fold + k_combine behind the launch, and with the fused closing) against the round-2 paths (k_main below 256 MiB, dealt k_body from there), by message size (GPU box).
 Device-resident encrypt_dev incl. the tag readback, median and best of N calls, alternating the two settings call by call
-group so that clock drift hits both.  Contexts read AESGCM_BODY_CYC at creation.
+group so that clock drift hits both.  The three contexts differ in their options (aesgcm_ctx_set_option).
     python profiles/cyc_sweep.py [key_bytes]"""
 import os, sys, time, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,14 +13,9 @@ nmax = 4096 * MiB
 a, b = lib.DeviceBuffer(nmax), lib.DeviceBuffer(nmax)
 a.fill_splitmix64(1)
 iv = bytes(12)
-os.environ["AESGCM_BODY_CYC"] = "0:0"
-old = lib.Context(bytes(range(kb)))
-os.environ["AESGCM_BODY_CYC"] = "%d:%d" % (1 * MiB, 1 << 50)
-os.environ["AESGCM_CYC_FUSE"] = "0"
-cyc = lib.Context(bytes(range(kb)))
-os.environ["AESGCM_CYC_FUSE"] = "1"
-fus = lib.Context(bytes(range(kb)))
-os.environ.pop("AESGCM_BODY_CYC"); os.environ.pop("AESGCM_CYC_FUSE")
+old = lib.Context(bytes(range(kb))).set_option("cyc_min", 0).set_option("cyc_max", 0)
+cyc = lib.Context(bytes(range(kb))).set_option("cyc_min", 1 * MiB).set_option("cyc_max", 1 << 50).set_option("cyc_close", 0)
+fus = lib.Context(bytes(range(kb))).set_option("cyc_min", 1 * MiB).set_option("cyc_max", 1 << 50).set_option("cyc_close", 1)
 print("AES-%d   MiB    old_med   old_best    cyc_med   cyc_best  fused_med fused_best  (us)   fused GiB/s   tags" % (kb * 8))
 for mib in (1, 2, 4, 8, 16, 32, 64, 100, 128, 256, 512, 1024, 2048, 4096):
     n = mib * MiB

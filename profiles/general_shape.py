@@ -23,9 +23,8 @@ for mib in (1, 4, 16, 64, 256, 320, 384, 448, 512):
             ts.append(time.perf_counter() - t0)
         row.append(statistics.median(ts[3:]) * 1e6)
     print("%6d  %9.1f %9.1f %9.1f %9.1f" % (mib, *row), flush=True)
-os.environ["AESGCM_BODY_CYC"] = "0:0"
-old = lib.Context(bytes(range(32)))
-print("round-2 paths (AESGCM_BODY_CYC=0:0)")
+old = lib.Context(bytes(range(32))).set_option("cyc_min", 0).set_option("cyc_max", 0)
+print("round-2 paths (options cyc_min = cyc_max = 0)")
 for mib in (256, 320, 384, 448, 512):
     row = []
     for al, extra in ((0, 0), (20, 5)):

@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """Packets under one key: the kernel shapes (one wave / 16, 8, 4 lanes / one lane per packet) over packet count and size (GPU box).
-Prints GiB/s; the library's own choice (AESGCM_PKT_SHAPE unset) is the last column."""
+Prints GiB/s; the library's own choice is the last column.  Shapes are forced through the debug build (libaesgcm_hip_dbg.so, include/aesgcm_debug.h)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import aesgcm_amd  # noqa
 from aesgcm_amd import lib
 kb = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+_dbg = lib.debug_library(); _dbg.__enter__()
 ctx = lib.Context(bytes(range(kb)))
 nmax = 1 << 20
 d_ivs = lib.DeviceBuffer(12 * nmax); d_ivs.fill_splitmix64(2, nbytes=12 * nmax // 8 * 8)
@@ -19,9 +20,8 @@ for pkt in (64, 256, 1024, 4096, 16384):
         n = 1 << ln
         if n > nm: break
         row = []
-        for shape in ("w", "g", "g8", "g4", "l", None):
-            if shape: os.environ["AESGCM_PKT_SHAPE"] = shape
-            else: os.environ.pop("AESGCM_PKT_SHAPE", None)
+        for lanes in (64, 16, 8, 4, 1, 0):
+            _dbg.force(pkt_lanes=lanes)
             best = 1e9
             for it in range(4):
                 lib.dev_sync(); t0 = time.perf_counter()

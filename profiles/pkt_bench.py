@@ -17,7 +17,7 @@ import aesgcm_amd  # noqa: E402,F401
 from aesgcm_amd import lib  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("kind", choices=("batch", "pktw", "pktg", "pktg8", "pktg4", "pktl"))
+ap.add_argument("kind", choices=("batch", "pkt", "pktw", "pktg", "pktg8", "pktg4", "pktl"))
 ap.add_argument("--n", type=int, default=1 << 20)
 ap.add_argument("--len", type=int, default=4096)
 ap.add_argument("--key-bits", type=int, default=128)
@@ -38,7 +38,12 @@ if a.kind == "batch":
     def go():
         lib.batch_crypt_dev(False, n, kb, d_keys.ptr, d_ivs.ptr, d_pt.ptr, pkt, d_ct.ptr, d_tags.ptr)
 else:
-    os.environ["AESGCM_PKT_SHAPE"] = {"pktw": "w", "pktg": "g", "pktg8": "g8", "pktg4": "g4", "pktl": "l"}[a.kind]
+    # a forced shape is a function of the debug build only (libaesgcm_hip_dbg.so, include/aesgcm_debug.h); "pkt" = the library's own choice, product build
+    _dbg = None
+    if a.kind != "pkt":
+        _dbg = lib.debug_library()
+        _dbg.__enter__()
+        _dbg.force(pkt_lanes={"pktw": 64, "pktg": 16, "pktg8": 8, "pktg4": 4, "pktl": 1}[a.kind])
     ctx = lib.Context(bytes(range(kb)))
 
     def go():

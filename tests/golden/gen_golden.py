@@ -343,6 +343,10 @@ def gen_streams(large, huge):
         want("cfg2_aes128_1GiB", 16, 0xAE5C0002, GiB)
         want("aes256_1GiB", 32, 0xAE5C0003, GiB)
         want("cfg3_aes256_16GiB", 32, 0xAE5C0003, 16 * GiB)
+        # round 4: AES-192 at a size where the production split engages by itself (the dealt k_body<12, *> and FoldClose from 1 GiB), and the general
+        # head / k_body / tail path with a carried state -- AAD in front, a ragged end -- at a size nobody forces (src/aes_pkg.vhd:31-33: three modes alike)
+        want("aes192_1GiB", 24, 0xAE5C0007, GiB)
+        want("aes256_4GiB_aad20_minus5", 32, 0xAE5C0008, 4 * GiB - 5, aad=splitmix_bytes(0x414144, 20))
     if huge:
         # cfg4: 128 GiB aggregate = 4 messages x 32 GiB of ONE SplitMix64 stream (seed 0xAE5C0004), IV last byte + m.
         for m in range(4):

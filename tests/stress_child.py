@@ -1,5 +1,7 @@
 """Child process of tests/test_gpu_stress.py: N randomised packet-kernel launches, a sample verified against the oracle.
-Prints progress lines and one JSON result line.  usage: stress_child.py <launches> <seed>"""
+Prints progress lines and one JSON result line.  usage: stress_child.py <launches> <seed>
+Runs on the debug build of the library (libaesgcm_hip_dbg.so: the same sources plus aesgcm_debug_force_shape), because it forces
+every packet-kernel shape and deal size on every input; "pkt_auto" and "batch" leave the choice to the library's own rule."""
 import json
 import os
 import random
@@ -19,6 +21,11 @@ def main():
     from oracle import oracle as O
     rng = random.Random(seed)
     nprng = np.random.default_rng(seed)
+    with lib.debug_library() as dbg:
+        return run(n_launch, rng, nprng, np, lib, O, dbg)
+
+
+def run(n_launch, rng, nprng, np, lib, O, dbg):
     MAXP, MAXB = 4200, 1 << 20                       # packets per launch, bytes per launch
     d_in, d_out = lib.DeviceBuffer(MAXB + 4096), lib.DeviceBuffer(MAXB + 4096)
     d_aad = lib.DeviceBuffer(MAXP * 32 + 64)
@@ -35,7 +42,7 @@ def main():
     t0 = time.time()
     while launches < n_launch:
         n = rng.choice(counts) if rng.random() < 0.5 else rng.randrange(1, 300)
-        kind = rng.choice(("pkt_w", "pkt_g", "pkt_g8", "pkt_g4", "pkt_l", "batch"))
+        kind = rng.choice(("pkt_w", "pkt_g", "pkt_g8", "pkt_g4", "pkt_l", "pkt_auto", "batch", "batch"))
         kb = rng.choice((16, 24, 32))
         # packet lengths: many zero-length and tiny ones, a few long; total bounded by MAXB
         mean = max(1, min(2000, MAXB // n))
@@ -49,15 +56,15 @@ def main():
             continue
         ivs = nprng.integers(0, 256, 12 * n, dtype=np.uint8)
         d_ivs.upload(ivs); d_doff.upload(doff); d_aoff.upload(aoff)
-        os.environ.pop("AESGCM_PKT_SHAPE", None); os.environ.pop("AESGCM_PKT_DEAL", None)
+        dbg.force(pkt_lanes=0, pkt_deal=0, batch_lanes=0)
         if kind == "batch":
             pk = nprng.integers(0, 256, kb * n, dtype=np.uint8)
             d_keys.upload(pk)
+            dbg.force(batch_lanes=rng.choice((0, 0, 8, 16, 64)))
             lib.batch_crypt_var_dev(False, n, kb, d_keys.ptr, d_ivs.ptr, d_in.ptr, d_doff.ptr, d_out.ptr, d_tags.ptr,
                                     d_aad=d_aad.ptr, d_aad_off=d_aoff.ptr)
         else:
-            os.environ["AESGCM_PKT_SHAPE"] = {"pkt_w": "w", "pkt_g": "g", "pkt_g8": "g8", "pkt_g4": "g4", "pkt_l": "l"}[kind]
-            os.environ["AESGCM_PKT_DEAL"] = str(rng.choice((1, 3, 16, 64)))
+            dbg.force(pkt_lanes={"pkt_w": 64, "pkt_g": 16, "pkt_g8": 8, "pkt_g4": 4, "pkt_l": 1, "pkt_auto": 0}[kind], pkt_deal=rng.choice((0, 1, 3, 16, 64)))
             ctxs[kb].packets_crypt_dev(False, n, d_ivs.ptr, d_in.ptr, d_out.ptr, d_tags.ptr, d_aad=d_aad.ptr,
                                        d_aad_off=d_aoff.ptr, d_data_off=d_doff.ptr)
         launches += 1

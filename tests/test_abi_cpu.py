@@ -30,9 +30,26 @@ def test_library_builds_and_exports_every_declared_symbol():
     exported = set(re.findall(r" T (aesgcm_\w+)", out))
     assert exported == set(declared_symbols())
     L = lib.load()
-    assert L.aesgcm_abi_version() == lib.ABI_VERSION == 2
+    assert L.aesgcm_abi_version() == lib.ABI_VERSION == 3
     for s in declared_symbols():
         assert hasattr(L, s)
+
+
+def test_debug_build_is_the_product_plus_one_symbol_and_the_product_reads_no_environment():
+    """libaesgcm_hip_dbg.so (-DAESGCM_DEBUG_KNOBS) exports aesgcm_debug_force_shape and nothing else beyond the product's symbols; the product library
+    imports no getenv: no environment variable can change which kernel a production caller runs (round-3 verdict, item 6)."""
+    from aesgcm_amd.build import build, SO, SO_DEBUG
+    build()
+    def exported(path):
+        return set(re.findall(r" T (aesgcm_\w+)", subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)))
+    assert exported(SO_DEBUG) == exported(SO) | {"aesgcm_debug_force_shape"}
+    hdr = open(os.path.join(ROOT, "include", "aesgcm_debug.h")).read()
+    assert re.findall(r"AESGCM_API\s+[\w \*]+?\b(aesgcm_\w+)\s*\(", hdr) == ["aesgcm_debug_force_shape"]
+    for path in (SO, SO_DEBUG):
+        undefined = subprocess.check_output(["nm", "-D", "--undefined-only", path], text=True)
+        assert not re.search(r"\b(secure_)?getenv\b", undefined), path
+    for src in ("aesgcm_kernels.hip", "aesgcm_comm.hip", "aesgcm_dev.h"):
+        assert "getenv" not in open(os.path.join(ROOT, "aes-gcm-128-192-256-bits_amd", "csrc", src)).read(), src
 
 
 def test_code_object_targets_gfx950_only():
@@ -52,7 +69,7 @@ def test_strerror_covers_all_codes():
 
 def test_header_compiles_as_plain_c():
     # the boundary is a C ABI: the header must be consumable by gcc -std=c99 with no HIP/C++ types
-    code = '#include "aesgcm.h"\nint main(void){return AESGCM_ABI_VERSION==2?0:1;}\n'
+    code = '#include "aesgcm.h"\nint main(void){return AESGCM_ABI_VERSION==3?0:1;}\n'
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-x", "c", "-", "-fsyntax-only"],
                    input=code.encode(), check=True)
 

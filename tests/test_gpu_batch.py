@@ -9,19 +9,21 @@ from util import golden, batch_inputs, splitmix_bytes
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["default", "lanes16", "lanes8", "lanes16_twophase", "lanes64"], autouse=True)
-def batch_shape(request, monkeypatch):
-    """every test here runs with the host's own choice of kernel shape and with each shape forced: 16 lanes per packet in one
-    pass (k_batch3: four packets per wave, GHASH fused into the CTR loop), 8 lanes per packet (eight packets per wave, one table slot each), 16 lanes in two phases (k_batch2: encrypt, read the
-    ciphertext back) and 64 lanes per packet (k_batch) -- AESGCM_BATCH_LG / AESGCM_BATCH_FUSED are read at every launch"""
-    env = {"lanes16": {"AESGCM_BATCH_LG": "4", "AESGCM_BATCH_FUSED": "1"}, "lanes8": {"AESGCM_BATCH_LG": "3", "AESGCM_BATCH_FUSED": "1"}, "lanes16_twophase": {"AESGCM_BATCH_LG": "4", "AESGCM_BATCH_FUSED": "0"},
-           "lanes64": {"AESGCM_BATCH_LG": "6"}}.get(request.param, {})
-    for k in ("AESGCM_BATCH_LG", "AESGCM_BATCH_FUSED"):
-        if k in env:
-            monkeypatch.setenv(k, env[k])
-        else:
-            monkeypatch.delenv(k, raising=False)
-    return request.param
+@pytest.fixture(params=["default", "lanes16", "lanes8", "lanes64"])
+def batch_shape(request, hip):
+    """the batch tests run with the host's own choice of kernel shape (the product library) and with each shape forced: 16 lanes per packet (k_batch3: four
+    packets per wave, GHASH fused into the CTR loop), 8 lanes per packet (eight packets per wave, one table slot each, every multiply split over a lane pair) and
+    64 lanes per packet (k_batch).  Forcing a shape is a function of the debug build only (libaesgcm_hip_dbg.so, include/aesgcm_debug.h)."""
+    lanes = {"lanes16": 16, "lanes8": 8, "lanes64": 64}.get(request.param)
+    if lanes is None:
+        yield request.param
+        return
+    with hip.debug_library() as dbg:
+        dbg.force(batch_lanes=lanes)
+        yield request.param
+
+
+PKT_LANES = {"wave": 64, "group16": 16, "g8": 8, "g4": 4, "lane": 1}
 
 
 def _run(hip, decrypt, keys, ivs, data, pkt_len, key_len, aad=b"", aad_len=0, expect=None, inplace=False):
@@ -51,7 +53,7 @@ def _run(hip, decrypt, keys, ivs, data, pkt_len, key_len, aad=b"", aad_len=0, ex
     return out, tags, auth
 
 
-def test_cfg5_first_64_packets_match_fixture(hip):
+def test_cfg5_first_64_packets_match_fixture(hip, batch_shape):
     fx = golden("batch.json")
     keys, ivs, pt = batch_inputs(0, 64, 4096)
     ct, tags, _ = _run(hip, False, keys, ivs, pt, 4096, 16)
@@ -62,7 +64,7 @@ def test_cfg5_first_64_packets_match_fixture(hip):
     assert back == pt and tags2 == tags and auth == [1] * 64
 
 
-def test_batch_shapes_vs_oracle(hip, orc):
+def test_batch_shapes_vs_oracle(hip, orc, batch_shape):
     rng = random.Random(5)
     for klen, pkt_len, aad_len, n in ((16, 0, 0, 3), (16, 1, 0, 5), (24, 15, 7, 9), (32, 16, 16, 17), (16, 48, 28, 33), (32, 1000, 20, 40),
                                       (24, 1024, 0, 70), (16, 4096, 13, 130), (32, 9001, 68, 21), (16, 65536, 0, 6)):
@@ -85,7 +87,7 @@ def test_batch_shapes_vs_oracle(hip, orc):
 
 
 @pytest.mark.slow
-def test_cfg5_full_million_packets(hip):
+def test_cfg5_full_million_packets(hip, batch_shape):
     fx = golden("batch.json")
     if "full_tags_sha256" not in fx:
         pytest.skip("full batch fixture not generated")
@@ -107,7 +109,7 @@ def test_cfg5_full_million_packets(hip):
     assert sha.hexdigest() == fx["full_ct_sha256"]
 
 
-def test_variable_length_packets_macsec_shaped(hip, orc):
+def test_variable_length_packets_macsec_shaped(hip, orc, batch_shape):
     """Per-packet lengths and AAD through offset arrays: frames of 0..1600 bytes with 0..40-byte headers,
     including the reference's two README vectors as packets 0 and 1."""
     import struct
@@ -149,13 +151,18 @@ def test_variable_length_packets_macsec_shaped(hip, orc):
 
 
 @pytest.mark.parametrize("shape", ["wave", "group16", "g8", "g4", "lane"])
-def test_packets_under_one_key(hip, orc, shape, monkeypatch):
+def test_packets_under_one_key(hip, orc, shape):
+    with hip.debug_library() as dbg:
+        dbg.force(pkt_lanes=PKT_LANES[shape])
+        _packets_under_one_key(hip, orc)
+
+
+def _packets_under_one_key(hip, orc):
     """aesgcm_packets_crypt_dev: one key (context), per-packet IV, AAD and length; fixed-size records and offset
     arrays; decrypt in place with per-packet authentication.  The three kernel shapes (one wave per packet and 16 lanes per
     packet: k_pktg<.., 6> / k_pktg<.., 4>; one lane per packet: k_pktl) are forced in turn; the library picks between them by
     packet count and size otherwise."""
     import struct
-    monkeypatch.setenv("AESGCM_PKT_SHAPE", shape)
     rng = random.Random(4242)
     for klen in (16, 24, 32):
         key = splitmix_bytes(300 + klen, klen)
@@ -202,14 +209,18 @@ def test_packets_under_one_key(hip, orc, shape, monkeypatch):
 
 
 @pytest.mark.parametrize("shape", [None, "wave", "group16", "g8", "g4", "lane"])
-def test_fixed_size_records_of_odd_lengths(hip, orc, shape, monkeypatch):
+def test_fixed_size_records_of_odd_lengths(hip, orc, shape):
+    if shape is None:
+        return _fixed_size_records_of_odd_lengths(hip, orc)
+    with hip.debug_library() as dbg:
+        dbg.force(pkt_lanes=PKT_LANES[shape])
+        _fixed_size_records_of_odd_lengths(hip, orc)
+
+
+def _fixed_size_records_of_odd_lengths(hip, orc):
     """aesgcm_packets_crypt_dev with fixed-size records that are empty, shorter than a block, ragged, or not a multiple of 4 bytes apart (the
     byte-wise load / store paths), with and without AAD, in every kernel shape and in the host's own choice; decrypt in place"""
     import struct
-    if shape:
-        monkeypatch.setenv("AESGCM_PKT_SHAPE", shape)
-    else:
-        monkeypatch.delenv("AESGCM_PKT_SHAPE", raising=False)
     key = splitmix_bytes(610, 24)
     ctx, f = hip.Context(key), orc.Fast(key)
     def up(b):
@@ -233,11 +244,10 @@ def test_fixed_size_records_of_odd_lengths(hip, orc, shape, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_many_small_packets_default_shape(hip, orc, monkeypatch):
+def test_many_small_packets_default_shape(hip, orc):
     """50 000 MACsec-sized frames (0..1514 B, AAD 0..32 B) under one key: the count makes the library choose the
     lane-per-packet kernel by itself; every ciphertext and tag is compared with the oracle, then decrypted in place."""
     import struct
-    monkeypatch.delenv("AESGCM_PKT_SHAPE", raising=False)
     rng = random.Random(777)
     m = 50000
     lens = [rng.choice((0, 46, 64, 128, 256, 512, 1000, 1500, 1514, rng.randrange(0, 1515))) for _ in range(m)]

@@ -28,13 +28,13 @@ def _check(hip, f, ctx, iv, n, al, seed, aad_off=0):
     assert bytes(d_out.download(n)) == pt, ("dec pt", n, al)
 
 
-@pytest.mark.parametrize("klen,fuse", [(16, "1"), (24, "1"), (32, "1"), (16, "0"), (32, "0"), (16, "4"), (32, "4"), (24, "2")])
-def test_whole_messages_of_any_shape_take_the_cyclic_launch(hip, orc, monkeypatch, klen, fuse):
-    """fuse = 1: the launch closes the tag itself (cyc_close: tree per workgroup, atomics across); 0: k_fold and k_combine behind it;
-    4 / 2: the two other ways to have the ciphertext in memory when the tag appears (stores through the L2 / the host waits for the launch's end)"""
-    monkeypatch.setenv("AESGCM_CYC_FUSE", fuse)
+@pytest.mark.parametrize("klen,close", [(16, 1), (24, 1), (32, 1), (16, 0), (24, 0), (32, 0)])
+def test_whole_messages_of_any_shape_take_the_cyclic_launch(hip, orc, klen, close):
+    """close = 1: the launch closes the tag itself (cyc_close: tree per workgroup, atomics across; what ships); 0: k_fold and k_combine behind it
+    (the context option "cyc_close"; the form shards and streaming chunks always take)"""
     key, iv = splitmix_bytes(9100 + klen, klen), splitmix_bytes(9101, 12)
     ctx, f = hip.Context(key), orc.Fast(key)
+    ctx.set_option("cyc_close", close)
     shapes = [(4 * MiB, 0), (4 * MiB + 5, 20), (5 * MiB - 3, 1000), (6 * MiB + 1023, 16 * 64), (7 * MiB + 16, 1), (9 * MiB + 1008, 16 * 64 * 3 + 7)]
     if klen == 32:
         shapes += [(16 * MiB + 1, 13), (33 * MiB - 17, 68), (64 * MiB + 4096 + 15, 4095)]
@@ -128,14 +128,16 @@ def test_queued_launches_and_two_contexts(hip, orc):
 
 
 def test_ciphertext_is_in_memory_when_the_tag_is(hip):
-    """examples/early_read: a copy ordered behind nothing (its own non-blocking stream), issued the moment aesgcm_encrypt_dev returns, reads the whole
-    ciphertext of the call -- the in-launch tag of the cyclic rows appears only after every row has gone through the L2 to memory"""
+    """examples/early_read: a copy ordered behind nothing (its own non-blocking stream), issued the moment aesgcm_encrypt_dev / aesgcm_decrypt_dev return,
+    reads the result of the call -- the in-launch tag of the cyclic rows appears only after every row has gone through the L2 to memory.  About 3000 calls:
+    encrypt and decrypt, in place and not, AAD front rows and ragged byte stores, 64 KiB .. 1.17 GiB (the top of the cyclic range)"""
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.run(["make", "-C", os.path.join(root, "examples"), "-s", "early_read"], check=True)
-    r = subprocess.run([os.path.join(root, "examples", "early_read"), "40"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    r = subprocess.run([os.path.join(root, "examples", "early_read"), "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0 and "EARLY READ OK" in r.stdout, (r.stdout, r.stderr)
+    assert r.stdout.count("0 of ") == 17, r.stdout
 
 
 def test_many_random_shapes_back_to_back(hip, orc):

@@ -23,28 +23,23 @@ def _len(rng, cap):
 
 def test_fuzz_one_shot_and_device_paths(hip, orc):
     rng = random.Random(20260101)
-    old, old_cyc = os.environ.get("AESGCM_TW"), os.environ.get("AESGCM_BODY_CYC")
-    try:
+    if True:
         for it in range(220):
             klen = rng.choice((16, 24, 32))
             tw = rng.choice((None, None, 1, 2, 3, 5, 16, 64))
-            if tw is None:
-                os.environ.pop("AESGCM_TW", None)
-            else:
-                os.environ["AESGCM_TW"] = str(tw)
-            # every other context keeps to k_main / k_fold / k_combine (the paths of messages below 64 KiB and of long AAD); the others take the
-            # cyclic launch with its fused closing from 64 KiB
-            if it & 1:
-                os.environ["AESGCM_BODY_CYC"] = "0:0"
-            else:
-                os.environ.pop("AESGCM_BODY_CYC", None)
             key, iv = splitmix_bytes(9000 + it, klen), splitmix_bytes(9500 + it, 12)
             al = _len(rng, 1 << 16) if rng.random() < 0.7 else 0
             n = _len(rng, 6 << 20)
             aad, pt = splitmix_bytes(10000 + it, al), splitmix_bytes(11000 + it, n)
             f = orc.Fast(key)
             want = f.encrypt(iv, aad, pt)
-            ctx = hip.Context(key)                                    # reads AESGCM_TW at creation
+            ctx = hip.Context(key)
+            if tw is not None:
+                ctx.set_option("tw", tw)                              # rows per chunk of the dealt kernels
+            # every other context keeps to k_main / k_fold / k_combine (the paths of messages below 64 KiB and of long AAD); the others take the
+            # cyclic launch with its fused closing from 64 KiB
+            if it & 1:
+                ctx.set_option("cyc_min", 0).set_option("cyc_max", 0)
             mode = rng.choice(("host", "dev", "inplace", "pipe"))
             if mode == "host":
                 got = ctx.encrypt(iv, aad, pt)
@@ -61,12 +56,6 @@ def test_fuzz_one_shot_and_device_paths(hip, orc):
             back, t2 = ctx.decrypt(iv, aad, want[0], tag=want[1])
             assert back == pt and t2 == want[1], (it, "dec")
             ctx.close()
-    finally:
-        for name, val in (("AESGCM_TW", old), ("AESGCM_BODY_CYC", old_cyc)):
-            if val is None:
-                os.environ.pop(name, None)
-            else:
-                os.environ[name] = val
 
 
 def test_fuzz_random_shard_splits(hip, orc):
@@ -98,17 +87,16 @@ def test_fuzz_random_shard_splits(hip, orc):
 
 
 @pytest.mark.parametrize("body", [False, True, "cyc"])
-def test_fold_level_boundaries(hip, orc, monkeypatch, body):
+def test_fold_level_boundaries(hip, orc, body):
     """k_fold reduces up to 128 items per workgroup (8 waves x 1..16 items, fold_group) and k_combine folds the last 64:
     chunk counts on both sides of every boundary of that scheme (64, 128, 512 g for g = 1..16, 16 x 8192, 65536), with
     one-row chunks so that the count is the row count; once through k_main alone, once with the k_body cut forced
     (interleaved items, period-4 first level), once with the aligned middle as cyclic rows (k_body<.., true>: strands of 0 .. 17 rows,
     always 4096 items, rotated by the row count)."""
-    monkeypatch.setenv("AESGCM_TW", "1")
-    monkeypatch.setenv("AESGCM_BODY_MIN", "4096" if body is True else str(1 << 59))
-    monkeypatch.setenv("AESGCM_BODY_CYC", "4096:%d" % (1 << 50) if body == "cyc" else "0:0")
     key, iv = splitmix_bytes(4201, 32), splitmix_bytes(4202, 12)
     ctx, f = hip.Context(key), orc.Fast(key)
+    ctx.set_option("tw", 1).set_option("body_min", 4096 if body is True else 1 << 59)
+    ctx.set_option("cyc_min", 4096 if body == "cyc" else 0).set_option("cyc_max", 1 << 50 if body == "cyc" else 0)
     counts = (1, 2, 15, 16, 17, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 2047, 2048, 2049, 4095, 4096, 4097, 8191, 8192, 8193,
               16383, 16384, 16385, 65535, 65536, 65537)
     for rows in counts:

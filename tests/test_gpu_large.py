@@ -32,12 +32,16 @@ def _sha_device(buf, n):
     return sha.hexdigest()
 
 
-@pytest.mark.parametrize("name", ["cfg2_aes128_1GiB", "aes256_1GiB", "cfg3_aes256_16GiB"])
+@pytest.mark.parametrize("name", ["cfg2_aes128_1GiB", "aes192_1GiB", "aes256_1GiB", "cfg3_aes256_16GiB"])
 def test_full_size_stream_bit_exact(hip, orc, name):
+    """AES-128 / 192 / 256 at sizes where the production split engages by itself (the dealt k_body<10 | 12 | 14, *> with FoldClose from 1 GiB:
+    src/aes_pkg.vhd:31-33 treats the three modes alike, so does this)"""
     c = _case(name)
     n = c["n_bytes"]
     key, iv = stream_key_iv(c)
     ctx = hip.Context(key)
+    head, body = ctx.split(n)
+    assert head == 0 and body == n // 16, (head, body)                      # nobody forced it: the library's own cut, whole message = one aligned body
     pt, ct = hip.DeviceBuffer(n), hip.DeviceBuffer(n)
     pt.fill_splitmix64(c["pt_seed"], c["first_word"])
     tag = ctx.encrypt_dev(iv, pt.ptr, n, ct.ptr)
@@ -57,6 +61,37 @@ def test_full_size_stream_bit_exact(hip, orc, name):
     for off in [0, n - win, (n // 2) // 16 * 16]:
         assert bytes(pt.download(win, off)) == bytes(ct.download(win, off))
     pt.free(); ct.free()
+
+
+def test_general_path_4GiB_with_aad_and_ragged_end(hip, orc):
+    """4 GiB - 5 bytes with 20 bytes of AAD: the general path of a large message -- head (AAD) through k_main, the aligned middle through the dealt
+    k_body, the ragged tail through k_main, the GHASH state carried between the pieces on the device -- at a size nobody forces; then decrypt in
+    place, authenticated, and the plaintext back against the generator"""
+    c = _case("aes256_4GiB_aad20_minus5")
+    n = c["n_bytes"]
+    assert n == (4 << 30) - 5
+    key, iv = stream_key_iv(c)
+    aad = bytes.fromhex(c["aad"])
+    ctx = hip.Context(key)
+    head, body = ctx.split(n)
+    assert body > 0 and 16 * body < n                                        # a middle and a tail
+    buf = hip.DeviceBuffer(n + 16)
+    buf.fill_splitmix64(c["pt_seed"], c["first_word"], nbytes=(n + 7) // 8 * 8)
+    d_aad = hip.DeviceBuffer(len(aad)); d_aad.upload(aad)
+    out = hip.DeviceBuffer(n + 16)
+    tag = ctx.encrypt_dev(iv, buf.ptr, n, out.ptr, d_aad=d_aad.ptr, aad_len=len(aad))
+    assert tag.hex() == c["tag"]
+    assert bytes(out.download(64, 0)).hex() == c["ct_head"] and bytes(out.download(64, n - 64)).hex() == c["ct_tail"]
+    assert _sha_device(out, n) == c["ct_sha256"]
+    t2 = ctx.decrypt_dev(iv, out.ptr, n, out.ptr, d_aad=d_aad.ptr, aad_len=len(aad), tag=bytes.fromhex(c["tag"]))     # in place
+    assert t2 == tag
+    win = 1 << 20
+    for off in (0, (n - win) // 16 * 16, (n // 3) // 16 * 16):
+        m = min(win, n - off)
+        assert bytes(out.download(m, off)) == bytes(orc.fill_splitmix64(m, c["pt_seed"], c["first_word"] + off // 8)), off
+    with pytest.raises(hip.AuthenticationError):
+        ctx.decrypt_dev(iv, buf.ptr, n, out.ptr, d_aad=d_aad.ptr, aad_len=len(aad), tag=bytes.fromhex(c["tag"]))      # the plaintext is not the ciphertext
+    buf.free(); out.free()
 
 
 def test_sharded_16GiB_equals_fixture(hip):

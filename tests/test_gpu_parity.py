@@ -249,15 +249,10 @@ def test_sharded_message_equals_single_launch(hip, orc):
 def test_batched_finalize_equals_one_call_per_message(hip, orc):
     """aesgcm_shard_finalize_batch_dev: the tags of M messages from ONE [rank][message][16] gather in one launch -- three messages
     of different length / AAD, four shards each, the shards spread over two contexts whose fused kernels are chained
-    (aesgcm_ctx_wait_fused) and joined (aesgcm_ctx_wait) as in bench.py's N > 1 step; pure-body shards included (AESGCM_BODY_MIN
-    is read at context creation: 4096 forces the k_body cut so that the direct weighted-partial path runs at this size)."""
-    import os
-    os.environ["AESGCM_BODY_MIN"] = "4096"
-    try:
-        key = splitmix_bytes(90, 32)
-        cs = [hip.Context(key), hip.Context(key)]
-    finally:
-        os.environ.pop("AESGCM_BODY_MIN", None)
+    (aesgcm_ctx_wait_fused) and joined (aesgcm_ctx_wait) as in bench.py's N > 1 step; pure-body shards included (the context option
+    "body_min" = 4096 forces the k_body cut so that the direct weighted-partial path runs at this size)."""
+    key = splitmix_bytes(90, 32)
+    cs = [hip.Context(key).set_option("body_min", 4096), hip.Context(key).set_option("body_min", 4096)]
     ranks = 4
     msgs = [dict(n=4 * 256 * 16 * 8, al=0, iv=splitmix_bytes(91, 12)),          # four shards of 8 whole 256-block super-rows: pure bodies
             dict(n=(3 << 20) + 5, al=20, iv=splitmix_bytes(92, 12)),
@@ -374,17 +369,20 @@ def test_plain_c_caller(hip):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("tw", ["", "1", "3", "cyc"])
-def test_body_split_forced_on_small_messages(hip, orc, monkeypatch, tw):
-    """The head / k_body / tail cut (aesgcm_ctx_split) normally starts at 8 MiB; AESGCM_BODY_MIN / AESGCM_BODY_CYC bring it down so that
-    whole messages, decrypts and shards with odd first blocks run through k_body -- dealt chunks, or cyclic rows -- at sizes the oracle
-    checks in full."""
-    monkeypatch.setenv("AESGCM_BODY_MIN", "4096")
-    monkeypatch.setenv("AESGCM_BODY_CYC", "4096:%d" % (1 << 50) if tw == "cyc" else "0:0")
-    if tw and tw != "cyc":
-        monkeypatch.setenv("AESGCM_TW", tw)
+def test_body_split_forced_on_small_messages(hip, orc, tw):
+    """The head / k_body / tail cut (aesgcm_ctx_split) normally starts at 256 MiB and the cyclic rows at 64 KiB; the context options
+    "body_min" / "cyc_min" / "cyc_max" / "tw" (aesgcm_ctx_set_option) bring them down so that whole messages, decrypts and shards with odd
+    first blocks run through k_body -- dealt chunks, or cyclic rows -- at sizes the oracle checks in full."""
+    def options(c):
+        c.set_option("body_min", 4096)
+        c.set_option("cyc_min", 4096 if tw == "cyc" else 0)
+        c.set_option("cyc_max", 1 << 50 if tw == "cyc" else 0)
+        if tw and tw != "cyc":
+            c.set_option("tw", int(tw))
+        return c
     for klen in (16, 24, 32):
         key, iv = splitmix_bytes(700 + klen, klen), splitmix_bytes(701, 12)
-        c, f = hip.Context(key), orc.Fast(key)
+        c, f = options(hip.Context(key)), orc.Fast(key)
         for n, al in ((16 * 3000 + 5, 0), (16 * (254 + 2048 * 3 + 777) + 11, 20), (1 << 20, 37), (16 * 254 + 16 * 1024 * 2, 16), (3 << 20 | 7, 0)):
             head, body = c.split(n)
             assert body > 0 and head == 0, (n, head, body)          # a whole message starts at block 0: no head

@@ -26,6 +26,38 @@ def demangle(names):
         return {n: n for n in names}
 
 
+def wt_store_hazards(path=None, need=5):
+    """The through-the-L2 stores (gstore16_wt / gstore*_wt_at in aesgcm_dev.h) are inline asm, so the compiler's hazard recognizer does not see that they read
+    an SGPR pair as their base: `VALU writes SGPR -> VMEM reads that SGPR` needs 5 wait states (gfx940 and later), and only instruction distance provides
+    them.  -> [(line number, store, writer, wait states)] for every `global_store ... sc0 sc1` whose base SGPR is written by a VALU instruction
+    (v_readfirstlane / v_readlane / v_cmp into an SGPR) fewer than `need` wait states earlier in the same basic block.  tests/test_isa_cpu.py wants []."""
+    lines = open(path or DEFAULT_S).read().split("\n")
+    bad = []
+    for i, ln in enumerate(lines):
+        m = re.match(r"\s*global_store_\w+\s+v\d+, v(?:\[[\d:]+\]|\d+), s\[(\d+):(\d+)\].*sc0 sc1", ln)
+        if not m:
+            continue
+        regs = {"s%s" % m.group(1), "s%s" % m.group(2)}
+        waits, j = 0, i - 1
+        while j >= 0 and waits < need:
+            t = lines[j].strip()
+            j -= 1
+            if not t or t.startswith((";", "//")) or t.startswith(".") and not t.endswith(":"):
+                continue
+            if t.endswith(":") or re.match(r"^\.?\w+:", t):          # a label: the block starts here, whatever came before is a branch away
+                break
+            op = t.split()[0]
+            dst = re.match(r"\S+\s+(s\d+|s\[(\d+):(\d+)\])", t)
+            if op.startswith("v_") and dst:
+                d = {dst.group(1)} if dst.group(2) is None else {"s%d" % k for k in range(int(dst.group(2)), int(dst.group(3)) + 1)}
+                if d & regs:
+                    bad.append((i + 1, ln.strip(), t, waits))
+                    break
+            nop = re.match(r"s_nop\s+(\d+)", t)
+            waits += int(nop.group(1)) + 1 if nop else 1
+    return bad
+
+
 def classify(op):
     if op.startswith("scratch_"):
         return "scratch"
