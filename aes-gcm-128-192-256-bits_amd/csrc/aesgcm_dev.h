@@ -1804,6 +1804,9 @@ HD uint4 pktg_tree_offer(uint4 acc, const unsigned char *smem, int j) { return g
 #ifndef AESGCM_PKTL_GROUP
 #define AESGCM_PKTL_GROUP 4
 #endif
+#ifndef AESGCM_PKTL_LINE
+#define AESGCM_PKTL_LINE 1               /* k_pktl: a lane fetches its packet's whole 128-byte line at once (round 4) */
+#endif
 // One LANE per packet (k_pktl): the shape for MACsec-sized frames, where a 64-block row per packet would leave
 // most lanes idle.  The lane runs the whole frame serially, as the reference core does (tb/gcm_test.py:76-85):
 // AAD blocks, data blocks (CTR from 2, aes_icb.vhd:97-118), the length block, Y = (Y ^ X) * H with the LDS
@@ -1832,6 +1835,47 @@ HD void pktl_lane(const KeyMaterial *__restrict__ km, const PktParams &p, const 
     // whole groups of AESGCM_PKTL_GROUP blocks: the lane reads and writes 64 contiguous bytes at a time, so a cache
     // line is touched twice and not eight times (lanes of a wave are a packet apart: nothing coalesces across lanes).
     // Measured, 2^20 x 1 KiB, AES-256: 436 GiB/s block by block, 537 GiB/s in groups of 4 (8: the same).
+#if AESGCM_PKTL_LINE
+    // Round 4, encrypt: the lane's whole 128-byte line at once.  With 64 bytes per step a line was touched twice, a few microseconds apart, and 1024 lanes per
+    // CU each with their own line overrun the 32 KiB L1 -- and, at 32 CUs per XCD, the 4 MiB L2 -- in between: 1.41 x the algorithmic traffic (reads 1.8 x,
+    // profiles/r03e/pktl_1k).  All eight loads are issued back to back; the second half waits in 16 registers while the first is worked on (the scheduling
+    // barrier keeps the compiler from interleaving all eight blocks, which spilled).  Measured, 2^20 x 1 KiB AES-256, same box (profiles/r04/pktl_line_ab_*.txt):
+    // HBM bytes 1.404 x -> 1.101 x algorithmic (reads 1.80e9 -> 1.09e9 = exactly the plaintext), 638 -> 657 GiB/s -- the kernel was never bound by that traffic.
+    // Decrypt keeps the 64-byte steps: its GHASH runs on the loaded ciphertext, the table multiply's 52 loads in flight beside eight held blocks do not fit 128
+    // registers (15 scratch ops in the loop however the two were ordered), and 768-lane workgroups, where it fits, run 4 % slower.
+    while (!DEC && aligned && left >= 128) {
+        uint4 xa[4], xb[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) xa[k] = gload16(src + 16 * k);
+#pragma unroll
+        for (int k = 0; k < 4; k++) xb[k] = gload16(src + 64 + 16 * k);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            u32 s0, s1, s2, s3;
+            ctr_rounds_lds<NR>(bswap32(ctr + k), cc, s0, s1, s2, s3, rk, smem, lb);
+            xa[k] = make_uint4(xa[k].x ^ s0, xa[k].y ^ s1, xa[k].z ^ s2, xa[k].w ^ s3);
+            acc = ghash_mul_const_lds(xor4(acc, xa[k]), smem);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) gstore16(dst + 16 * k, xa[k]);
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            u32 s0, s1, s2, s3;
+            ctr_rounds_lds<NR>(bswap32(ctr + 4 + k), cc, s0, s1, s2, s3, rk, smem, lb);
+            xb[k] = make_uint4(xb[k].x ^ s0, xb[k].y ^ s1, xb[k].z ^ s2, xb[k].w ^ s3);
+            acc = ghash_mul_const_lds(xor4(acc, xb[k]), smem);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) gstore16(dst + 64 + 16 * k, xb[k]);
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        src += 128; dst += 128; left -= 128; ctr += 8;
+    }
+#endif
     while (aligned && left >= 16 * AESGCM_PKTL_GROUP) {
         uint4 x[AESGCM_PKTL_GROUP];
 #pragma unroll

@@ -371,6 +371,12 @@ __device__ __forceinline__ void cyc_close(const KeyMaterial *__restrict__ km, co
     }
     if (lane != 0) return;
     acc_arrive(p.acc, g, z, p.tag_out, p.tag_host, p.gen);
+    if (p.trace) {                                                             // timing mode: how long the closing took behind the workgroup's last row, in 10 ns units, bits 52 .. 63 of word 2
+        unsigned long long *tr = reinterpret_cast<unsigned long long *>(p.trace + 4 * (u64)g);
+        const u64 rows_end = __hip_atomic_load(tr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const u64 dt = wall_clock64() - rows_end;
+        atomicOr(tr + 2, (unsigned long long)(dt > 0xFFFu ? 0xFFFu : dt) << 52);
+    }
 }
 
 template <int NR, int MODE, bool CYC>
@@ -389,6 +395,11 @@ __global__ __launch_bounds__(AESGCM_BODY_WG, AESGCM_BODY_WPS) void k_body(const 
 #endif
     if (tid == 0) *reinterpret_cast<u32 *>(smem + AESGCM_LDS_DRY_OFF) = 0;   // dry-queue mask of the workgroup (next_chunk)
     __syncthreads();
+    if (p.trace && tid == 0) {                                                // timing mode: when the tables were staged, 10 ns units behind the workgroup's start, bits 40 .. 51 of word 2
+        unsigned long long *tr = reinterpret_cast<unsigned long long *>(p.trace + 4 * (u64)blockIdx.x);
+        const u64 dt = wall_clock64() - tr[0];
+        atomicOr(tr + 2, (unsigned long long)(dt > 0xFFFu ? 0xFFFu : dt) << 40);
+    }
     CtrConsts cc = ctr_round1_consts(p.iv0, p.iv1, p.iv2, km->rk, smem, (lane & 31u) << 2);   // key and IV only: wave-uniform
     cc.c0 = __builtin_amdgcn_readfirstlane(cc.c0); cc.c1 = __builtin_amdgcn_readfirstlane(cc.c1);
     cc.c2 = __builtin_amdgcn_readfirstlane(cc.c2); cc.c3 = __builtin_amdgcn_readfirstlane(cc.c3);
@@ -1113,14 +1124,17 @@ __global__ __launch_bounds__(PKTG_WG(LG), (PKTG_WG(LG) + 255) / 256) void k_pktg
 // k_pktl: many packets under the context's key, one LANE per packet (lane body: pktl_lane()); waves take
 // blocks of 64 consecutive packets from the dispenser.
 // ------------------------------------------------------------------------------------------------
+#ifndef AESGCM_PKTL_WG
+#define AESGCM_PKTL_WG AESGCM_PKT_WG  // lanes per k_pktl workgroup
+#endif
 #ifndef AESGCM_PKTL_WAVES
-#define AESGCM_PKTL_WAVES 4          // waves per SIMD the register budget is sized for
+#define AESGCM_PKTL_WAVES ((AESGCM_PKTL_WG + 255) / 256)          // waves per SIMD the register budget is sized for (one workgroup per CU)
 #endif
 template <int NR, int DEC>
-__global__ __launch_bounds__(AESGCM_PKT_WG, AESGCM_PKTL_WAVES) void k_pktl(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const PktParams p) {
+__global__ __launch_bounds__(AESGCM_PKTL_WG, AESGCM_PKTL_WAVES) void k_pktl(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const PktParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 tid = threadIdx.x, lane = tid & 63u;
-    main_fill_lds(smem, km, tb, tid, true, AESGCM_PKT_WG, GH_TAB_H);
+    main_fill_lds(smem, km, tb, tid, true, AESGCM_PKTL_WG, GH_TAB_H);
     __syncthreads();
     const u32 nb = (p.n_pkts + 63u) / 64u;
     for (u32 guard = 0; guard <= nb; ++guard) {                // bounded, as every dispenser loop here
@@ -2294,10 +2308,11 @@ int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const vo
     p.counter = c->d_counter; p.counter_base = c->counter_base;
     if (shape == 'l') {
         const u32 nb = (u32)((n_pkts + 63) / 64);
+        const u32 waves_per_wg = AESGCM_PKTL_WG / 64;
         u32 wgs = (nb + waves_per_wg - 1) / waves_per_wg;
         if (wgs > (u32)c->G) wgs = (u32)c->G;
         c->counter_base += nb + wgs * waves_per_wg;                                 // every wave ends on one failing fetch
-#define LP(NR, D) hipLaunchKernelGGL((k_pktl<NR, D>), dim3(wgs), dim3(AESGCM_PKT_WG), AESGCM_LDS_BYTES, st, c->km, c->tables, p)
+#define LP(NR, D) hipLaunchKernelGGL((k_pktl<NR, D>), dim3(wgs), dim3(AESGCM_PKTL_WG), AESGCM_LDS_BYTES, st, c->km, c->tables, p)
         if (decrypt) { if (c->nr == 10) LP(10, 1); else if (c->nr == 12) LP(12, 1); else LP(14, 1); }
         else         { if (c->nr == 10) LP(10, 0); else if (c->nr == 12) LP(12, 0); else LP(14, 0); }
 #undef LP

@@ -9,7 +9,8 @@ the argument is partly empirical -- so it gets volume:
   lengths, random source offsets, encrypt and decrypt, in place and not) through a context with the in-launch closing; EVERY tag against the oracle
   (libcrypto over the same bytes; every 50th message also against the C restatement and, with the ciphertext, against a context that keeps k_fold + k_combine
   behind the launch);
-* 20 dealt whole messages of 1 GiB + k x 4 KiB, AES-128 / 192 / 256, with and without FoldClose: tag against the oracle, the two forms against each other.
+* 20 dealt whole messages of 1 GiB + k x 128 KiB (one aligned body: FoldClose closes the tag) or + k x 4 KiB (a tail behind the body: carried state),
+  AES-128 / 192 / 256, with and without FoldClose: tag against the oracle, the two forms against each other.
 """
 import random
 
@@ -90,10 +91,12 @@ def test_dealt_gib_messages_with_and_without_foldclose(hip, orc, kb):
     key = bytes(orc.fill_splitmix64(kb, 0xF0 + kb))
     fc, nofc = hip.Context(key), hip.Context(key).set_option("fold_close", 0)
     for it in range(7 if kb != 32 else 6):                                   # 20 messages over the three key sizes
-        n = GiB + 4096 * rng.randint(0, 4096)
+        # even turns: a whole number of 128 KiB super-chunks, so the message is ONE aligned body and the first k_fold level closes the tag (FoldClose);
+        # odd turns: 4 KiB granularity, i.e. a tail behind the body -- the general path with a carried state, where nothing closes in k_fold
+        n = GiB + (128 << 10) * rng.randint(0, 128) if it % 2 == 0 else GiB + 4096 * rng.randint(1, 4096)
         iv = bytes(rng.randrange(256) for _ in range(12))
         head, body = fc.split(n)
-        assert head == 0 and body == n // 16                                  # the dealt kernel by the library's own rule
+        assert head == 0 and body > 0 and (body == n // 16 or it % 2 == 1), (n, head, body)      # the dealt kernel by the library's own rule
         t1 = fc.encrypt_dev(iv, d_src.ptr, n, d_o1.ptr)
         t2 = nofc.encrypt_dev(iv, d_src.ptr, n, d_o2.ptr)
         want_ct, want_tag = R.encrypt(key, iv, b"", src[:n])
