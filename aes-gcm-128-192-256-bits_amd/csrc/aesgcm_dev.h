@@ -485,6 +485,8 @@ struct KeyMaterial {         // per context (device memory)
                                      // and the constants of the cross-lane tree H, H^2, H^4, ...
     uint4 k4tab[AESGCM_Q5_ENTRIES];  // ... of H^256 (k_body: a wave takes every fourth row)
     uint4 k18tab[AESGCM_Q5_ENTRIES]; // ... of H^(2^18) (k_body, cyclic rows: a wave takes every 4096th row)
+    uint4 k17tab[AESGCM_Q5_ENTRIES]; // ... of H^(2^17) (k_body, cyclic rows in the half shape: 2048 waves, round 4)
+    uint4 pwh[256];                  // H^(512 j), j = 0 .. 255: the weight of workgroup 255 - j's item in the closing of the half shape (cyc_close_half)
     uint4 ptab[AESGCM_NPTAB][512]; // nibble tables of H^(2^k), k = 6 .. 31: the Horner constants of k_fold when chunk sizes are powers of two
     uint4 ltab[AESGCM_NLTAB][32];  // two-table Shoup form of H^e, e = 0 .. 129 (65 - lane, plus up to 64 blocks of a separate last row behind the items: CombineParams::tail_blocks): [e][v] = v*H^e, [e][16 + v] = v*H^e*x^4 (per-lane constant multiplies of the closing steps)
     uint8_t rk_bytes[240];   // expanded key as the byte string tb/key_exp.py produces
@@ -649,11 +651,15 @@ HD bool setup_level(const uint4 *tab, int j, int tid, uint4 *prod) {
 // after the beta table (d == 1) is complete: the five-bit tables of the fixed Horner / tree constants H^(2^j) (j = 0 .. 6), H^256 and H^(2^18)
 HD void setup_beta_lane(KeyMaterial *km, const uint4 *tab, int tid) {
     (void)tab;
-    for (int q = tid; q < (AESGCM_NQ5POW + 2) * AESGCM_Q5_ENTRIES; q += AESGCM_WG) {     // 7488 entries over the workgroup: at most eight each
+    for (int q = tid; q < (AESGCM_NQ5POW + 3) * AESGCM_Q5_ENTRIES; q += AESGCM_WG) {     // 8320 entries over the workgroup: at most nine each
         const int which = q / AESGCM_Q5_ENTRIES, e = q % AESGCM_Q5_ENTRIES;
-        const uint4 c = which < AESGCM_NQ5POW ? km->pw[0][1u << which] : which == AESGCM_NQ5POW ? km->pw[0][256] : km->pw[1][256];   // H^(2^18) = H^(256 * 1024)
-        (which < AESGCM_NQ5POW ? km->q5pow[which] : which == AESGCM_NQ5POW ? km->k4tab : km->k18tab)[e] = gf_mul_mo(quint_elem_mo(e >> 5, (u32)(e & 31)), c);
+        const uint4 c = which < AESGCM_NQ5POW ? km->pw[0][1u << which] : which == AESGCM_NQ5POW ? km->pw[0][256] :
+                        which == AESGCM_NQ5POW + 1 ? km->pw[1][256] : km->pw[1][128];                            // H^(2^18) = H^(256 * 1024), H^(2^17) = H^(128 * 1024)
+        (which < AESGCM_NQ5POW ? km->q5pow[which] : which == AESGCM_NQ5POW ? km->k4tab : which == AESGCM_NQ5POW + 1 ? km->k18tab : km->k17tab)[e] =
+            gf_mul_mo(quint_elem_mo(e >> 5, (u32)(e & 31)), c);
     }
+    for (int j = tid; j < 256; j += AESGCM_WG)                        // H^(512 j) = H^(1024 (j >> 1)) * H^(512 (j & 1)); pw[0] and pw[1] are complete here (d == 1)
+        km->pwh[j] = (j & 1) ? gf_mul_mo(km->pw[1][j >> 1], km->pw[0][512]) : km->pw[1][j >> 1];
 }
 
 // after all four power tables exist: ptab[k] = nibble tables of H^(2^(k+6)); H^(2^j) = pw[j / LOG_WG][2^(j % LOG_WG)]
@@ -664,10 +670,10 @@ HD void setup_ptab_lane(KeyMaterial *km, u32 k, u32 tid) {
 
 // ---- k_main pieces -----------------------------------------------------------------------------
 // LDS image of one workgroup: what thread `tid` of AESGCM_MAIN_WG writes
-enum { GH_TAB_K64 = 0, GH_TAB_H = 1, GH_TAB_K256 = 2, GH_TAB_K2P18 = 3 };       // which constant's five-bit tables go to LDS
+enum { GH_TAB_K64 = 0, GH_TAB_H = 1, GH_TAB_K256 = 2, GH_TAB_K2P18 = 3, GH_TAB_K2P17 = 4 };       // which constant's five-bit tables go to LDS
 HD void main_fill_lds(unsigned char *smem, const KeyMaterial *km, const DevTables *tb, u32 tid, bool gh, u32 nthreads = AESGCM_MAIN_WG, int which = GH_TAB_K64) {
     if (gh) {
-        fill_lds_q5(smem, which == GH_TAB_H ? km->q5pow[0] : which == GH_TAB_K256 ? km->k4tab : which == GH_TAB_K2P18 ? km->k18tab : km->q5pow[6], tid, nthreads);
+        fill_lds_q5(smem, which == GH_TAB_H ? km->q5pow[0] : which == GH_TAB_K256 ? km->k4tab : which == GH_TAB_K2P18 ? km->k18tab : which == GH_TAB_K2P17 ? km->k17tab : km->q5pow[6], tid, nthreads);
     }
     uint4 *dst = reinterpret_cast<uint4 *>(smem + AESGCM_LDS_AES_OFF);
     for (u32 q = tid; q < AESGCM_LDS_AES / 16; q += nthreads) {
@@ -978,6 +984,9 @@ static inline int ptab_index(u64 e) {
 // wave-uniform indices go through the scalar cache, not LDS).  Rounds 1 and 2 therefore cost no LDS lookup in the
 // row loop: 192 instead of 212 per AES-256 block.
 // GHASH: the lane's blocks are 256 apart, Horner constant H^256 (main_fill_lds(GH_TAB_K256)).
+#ifndef AESGCM_BODY_RKV_FROM_HALF
+#define AESGCM_BODY_RKV_FROM_HALF(NR) (4 * ((NR) + 1))                    /* ... in the half shape (two-table round: more temporaries) */
+#endif
 #ifndef AESGCM_BODY_RKV_FROM
 #define AESGCM_BODY_RKV_FROM(NR) ((NR) == 14 ? 28 : 4 * ((NR) + 1))     /* first round-key word k_body keeps in a vector register (none for AES-128 / 192) */
 #endif
@@ -1003,6 +1012,7 @@ struct BodyParams {
     uint4 *ej0;                  // where the wave that owns chunk 0 leaves E_K(IV || 1) for k_combine (or NULL)
     // cyclic rows (k_body<.., true>, body_cyc_lane): T, C and the queues are unused
     u32 cyc;
+    u32 cw;                      // waves of the cyclic launch = the stride of a strand in rows: BODY_CYC_WAVES (4096), or BODY_CYC_WAVES_HALF (2048) in the half shape
     u32 F, R;                    // rows in front of the body (AAD blocks and the data blocks up to the body, front-padded: `front`) and whole rows of the body
     u32 tb;                      // blocks of the last, partial row behind the body (`last`; 0 = none): its item goes to parts[BODY_CYC_WAVES]
     MainParams front, last;      // the two generic pieces as one-row chunks of main_chunk_lane
@@ -1050,14 +1060,13 @@ HD BodyRow body_uniform(u32 hi24, const CtrConsts &cc, const u32 *__restrict__ r
     return r;
 }
 // rounds 3..NR from the state after round 2
-template <int NR>
+template <int NR, bool T4 = (AESGCM_T4 != 0)>                   // T4: four T-tables in LDS (136 KiB); else the two-table round (the half shape of the cyclic rows, 77 KiB)
 HD void body_rounds(u32 &s0, u32 &s1, u32 &s2, u32 &s3, const u32 *__restrict__ rk, const unsigned char *lds, u32 lb) {
 #pragma unroll
-#if AESGCM_T4
-    for (int r = 3; r < NR; r++) aes_round_lds4(s0, s1, s2, s3, rk + 4 * r, lds, lb, lb | 0x10000u);
-#else
-    for (int r = 3; r < NR; r++) aes_round_lds(s0, s1, s2, s3, rk + 4 * r, lds, lb);
-#endif
+    for (int r = 3; r < NR; r++) {
+        if (T4) aes_round_lds4(s0, s1, s2, s3, rk + 4 * r, lds, lb, lb | 0x10000u);
+        else aes_round_lds(s0, s1, s2, s3, rk + 4 * r, lds, lb);
+    }
     aes_final_lds(s0, s1, s2, s3, rk + 4 * NR, lds, lb);
 }
 #ifndef AESGCM_BODY_WT
@@ -1095,7 +1104,7 @@ HD void body_prio(u32 i, u32 rows, u32 slot) {
 }
 // lane `lane` of a wave that takes the n super-rows q0, q0 + qstep, ... in row phase v: returns sum_i X[row 4(q0 + i qstep) + v, lane] * K^(n-1-i),
 // K = H^(256 qstep) = the constant whose tables the launch staged in LDS
-template <int NR, int MODE>
+template <int NR, int MODE, bool T4 = (AESGCM_T4 != 0)>
 HD uint4 body_strand_lane(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const BodyParams &p,
                           const unsigned char *smem, const CtrConsts &cc, u32 q0, u32 qstep, u32 n, u32 v, u32 lane,
                           uint4 acc_in = make_uint4(0, 0, 0, 0), bool continued = false,        // continued: acc_in is the strand so far (one more multiply in front of the first row)
@@ -1109,7 +1118,7 @@ HD uint4 body_strand_lane(const KeyMaterial *__restrict__ km, const DevTables *_
     // kernel uses 85 of its 128): pin_vgpr hides the copy from the compiler so that it stays one.
     u32 rk[4 * (NR + 1)];
 #pragma unroll
-    for (int w = 0; w < 4 * (NR + 1); w++) rk[w] = (w >= AESGCM_BODY_RKV_FROM(NR)) ? pin_vgpr(rk0[w]) : rk0[w];
+    for (int w = 0; w < 4 * (NR + 1); w++) rk[w] = (w >= (T4 ? AESGCM_BODY_RKV_FROM(NR) : AESGCM_BODY_RKV_FROM_HALF(NR))) ? pin_vgpr(rk0[w]) : rk0[w];
     uint4 acc = acc_in;
     u32 i = 0;
     for (; i < n; ++i) {
@@ -1124,7 +1133,7 @@ HD uint4 body_strand_lane(const KeyMaterial *__restrict__ km, const DevTables *_
         const uint4 x = (MODE == MODE_PROBE) ? make_uint4(lane, q, v, 0u) : gload16(src + lane16);
         u32 s0, s1, s2, s3;
         body_state(s0, s1, s2, s3, b, p.ctr_hi0 + q, v, lane, cc, rk, tb);
-        body_rounds<NR>(s0, s1, s2, s3, rk, smem, lb);
+        body_rounds<NR, T4>(s0, s1, s2, s3, rk, smem, lb);
         const uint4 y = make_uint4(x.x ^ s0, x.y ^ s1, x.z ^ s2, x.w ^ s3);                  // gcm_gctr.vhd:150
         if (MODE != MODE_PROBE) {
 #if AESGCM_BODY_WT
@@ -1159,22 +1168,28 @@ HD uint4 body_chunk_lane(const KeyMaterial *__restrict__ km, const DevTables *__
 // what the dealt chunks of a long launch are for).
 #define BODY_CYC_WAVES 4096u             /* waves of the launch = 256 workgroups x 16: the stride of a strand in rows */
 #define BODY_CYC_MAX_FRONT BODY_CYC_WAVES /* front rows the layout admits (4 MiB of AAD): one per strand */
-HD u32 body_cyc_residue(const BodyParams &p, u32 s) { return (s + p.F + p.R) & (BODY_CYC_WAVES - 1u); }
-template <int NR, int MODE>
+// The HALF shape (round 4, for callers that keep several messages in flight): 256 workgroups of 512 lanes with the two-table round (77 KiB of LDS, 128
+// registers), i.e. 2048 strands with the stride H^(64 * 2048) = H^(2^17) -- half a CU's wave slots, registers and LDS, so that the workgroup of ANOTHER message
+// shares the CU: one's table staging and closing (10 us of a 32 us launch at 16 MiB, profiles/r04/cyc_timeline_*.txt) run beside the other's rows.  Alone on
+// the chip such a launch has two waves per SIMD and is slow; the library uses it only on request (context option "cyc_half").
+#define BODY_CYC_WAVES_HALF 2048u
+template <u32 W = BODY_CYC_WAVES>
+HD u32 body_cyc_residue(const BodyParams &p, u32 s) { return (s + p.F + p.R) & (W - 1u); }
+template <int NR, int MODE, bool T4 = (AESGCM_T4 != 0), u32 W = BODY_CYC_WAVES>      // W = waves of the launch (BodyParams::cw says the same to the host side)
 HD uint4 body_cyc_lane(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const BodyParams &p,
                        const unsigned char *smem, const CtrConsts &cc, u32 s, u32 lane) {
     const u32 Rt = p.F + p.R;
-    u32 u = body_cyc_residue(p, s);
+    u32 u = body_cyc_residue<W>(p, s);
     uint4 acc = make_uint4(0, 0, 0, 0);
     bool started = false;
     if (u < p.F) {                                                     // wave-uniform
         acc = main_chunk_lane<NR, MODE, AESGCM_BODY_WT != 0>(km, p.front, smem, cc, u, lane);
         started = true;
-        u += BODY_CYC_WAVES;
+        u += W;
     }
     if (u >= Rt) return acc;
-    const u32 r0 = u - p.F, n = (Rt - u + BODY_CYC_WAVES - 1u) / BODY_CYC_WAVES;
-    return body_strand_lane<NR, MODE>(km, tb, p, smem, cc, r0 >> 2, BODY_CYC_WAVES / 4u, n, r0 & 3u, lane, acc, started, p.prio_rows, (s >> 2) & 3u);   // wave s of a workgroup sits on SIMD s & 3
+    const u32 r0 = u - p.F, n = (Rt - u + W - 1u) / W;
+    return body_strand_lane<NR, MODE, T4>(km, tb, p, smem, cc, r0 >> 2, W / 4u, n, r0 & 3u, lane, acc, started, p.prio_rows, (s >> 2) & 3u);   // wave s of a workgroup sits on SIMD s & 3
 }
 // the partial row behind the body (lane values = one-row item, right-aligned)
 template <int NR, int MODE>
@@ -1201,6 +1216,15 @@ HD uint4 body_cyc_last_lane(const KeyMaterial *__restrict__ km, const BodyParams
 #define CYC_LDS_END (CYC_LDS_LTAB0 + 64u * CYC_LDS_LTAB_STRIDE)
 #define CYC_LDS_PARK AESGCM_LDS_BYTES_T4      /* behind the row loop's tables: wave 0 of workgroup 0 parks its last-row item (64 x 16 B) and E_K(J0) here until the closing */
 #define CYC_LDS_PARK_BYTES 1040u
+// ... and of the half shape (cyc_close_half: eight items per workgroup, 77 KiB of LDS in all): three tree tables, 8 + 4 + 2 staged items, the weight, the lanes' tables
+#define CYCH_LDS_TREE_TAB 0u                 /* three nibble tables of 8 KiB: H^64, H^128, H^256 */
+#define CYCH_LDS_STAGE 24576u
+#define CYCH_LDS_WTAB (CYCH_LDS_STAGE + 14u * 1024u)
+#define CYCH_LDS_LTAB (CYCH_LDS_WTAB + 512u)
+#define CYCH_LDS_END (CYCH_LDS_LTAB + 64u * CYC_LDS_LTAB_STRIDE)
+#define CYCH_LDS_PARK AESGCM_LDS_BYTES       /* behind the row loop's tables (T0 | T2 and the five-bit GHASH tables) */
+HD u32 cych_stage_off(u32 level) { return CYCH_LDS_STAGE + (level == 0 ? 0u : level == 1 ? 8192u : 12288u); }
+HD uint4 cych_tree_lane(const unsigned char *smem, u32 level, u32 k, u32 lane);
 HD u32 cyc_stage_off(u32 level) { return CYC_LDS_STAGE + (level == 0 ? 0u : level == 1 ? 16384u : level == 2 ? 24576u : 28672u); }   // where the inputs of tree level `level` sit
 // tree level `level` (0 .. 3), pair k: lane `lane`
 HD uint4 cyc_tree_lane(const unsigned char *smem, u32 level, u32 k, u32 lane) {
@@ -1208,6 +1232,12 @@ HD uint4 cyc_tree_lane(const unsigned char *smem, u32 level, u32 k, u32 lane) {
     const uint4 xe = *reinterpret_cast<const uint4 *>(smem + in + (2u * k) * 1024u + lane * 16u);
     const uint4 xo = *reinterpret_cast<const uint4 *>(smem + in + (2u * k + 1u) * 1024u + lane * 16u);
     return xor4(ghash_mul_const_lds_at_lean(xe, smem, CYC_LDS_TREE_TAB + level * 8192u), xo);
+}
+HD uint4 cych_tree_lane(const unsigned char *smem, u32 level, u32 k, u32 lane) {
+    const u32 in = cych_stage_off(level);
+    const uint4 xe = *reinterpret_cast<const uint4 *>(smem + in + (2u * k) * 1024u + lane * 16u);
+    const uint4 xo = *reinterpret_cast<const uint4 *>(smem + in + (2u * k + 1u) * 1024u + lane * 16u);
+    return xor4(ghash_mul_const_lds_at_lean(xe, smem, CYCH_LDS_TREE_TAB + level * 8192u), xo);
 }
 // lane L's term of a workgroup item (tb = blocks behind the grid) or of the partial last row (tb = 0)
 HD G128 cyc_lane_term(const KeyMaterial *__restrict__ km, uint4 item, u32 lane, u32 tb) { return shoup2_gmul(mo_to_be(item), km->ltab[65u - lane + tb]); }
@@ -1383,17 +1413,17 @@ static inline void plan_body(BodyParams &p, const BodySplit &b, const uint8_t *i
 // rows from the first block whose message index is a multiple of 256 -- has [min_bytes, max_bytes) bytes and the blocks in front of it fit one front
 // row per strand.  Fills p (parts: BODY_CYC_WAVES + 1 items) and returns true; `tail_blocks` = blocks of the partial row behind the body.
 static inline bool plan_body_cyc(BodyParams &p, int mode, const uint8_t *iv, const void *aad, u64 aad_len, const void *in, u64 len, void *out,
-                                 u64 first_block, uint4 *parts, u64 min_bytes, u64 max_bytes) {
+                                 u64 first_block, uint4 *parts, u64 min_bytes, u64 max_bytes, u32 waves = BODY_CYC_WAVES) {
     const u64 nfull = len / 16;
     const u64 head = (256 - (first_block & 255)) & 255;
     if (nfull <= head) return false;
     const u64 R = (nfull - head) / 64;
     if (!R || R * 1024 < min_bytes || R * 1024 >= max_bytes) return false;
     const u64 n_aad = (aad_len + 15) / 16, F = (n_aad + head + 63) / 64;
-    if (F > BODY_CYC_MAX_FRONT || F + R > 0x7FFFFFFFull) return false;
+    if (F > waves || F + R > 0x7FFFFFFFull) return false;             // one front row per strand at most
     { const BodyParams zero = {}; p = zero; }
     const u64 done = head + 64 * R;                                    // data blocks in front of the partial row
-    p.cyc = 1; p.F = (u32)F; p.R = (u32)R;
+    p.cyc = 1; p.cw = waves; p.F = (u32)F; p.R = (u32)R;
     p.in = (const unsigned char *)in + 16 * head; p.out = (unsigned char *)out + 16 * head;
     p.parts = parts;
     p.ctr_hi0 = (u32)((first_block + head) >> 8);

@@ -458,6 +458,124 @@ __global__ __launch_bounds__(AESGCM_BODY_WG, AESGCM_BODY_WPS) void k_body(const 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_bodyh: the cyclic rows in the HALF shape (round 4; aesgcm_dev.h, BODY_CYC_WAVES_HALF) -- 256 workgroups of 512 lanes, the two-table round, 77 KiB of LDS and
+// 128 registers, so that TWO workgroups share a CU: those of two messages in flight on two streams.  What one launch spends outside its row loop -- 1.8 us of
+// table staging, 8 us of closing (tree, lane terms, weight, two atomic round trips; profiles/r04/cyc_timeline_aes256.txt) -- leaves the CU's issue slots and its
+// LDS array to the other message's rows.  Whole messages with the tag closed in the launch only (cyc_close_half); same strands, same items, same algebra as
+// k_body<.., true> with 2048 waves instead of 4096.
+// ------------------------------------------------------------------------------------------------
+#define AESGCM_BODYH_WG 512
+static_assert(2u * (AESGCM_LDS_BYTES + CYC_LDS_PARK_BYTES) <= 160u * 1024u && CYCH_LDS_END <= CYCH_LDS_PARK, "k_bodyh: two workgroups per CU; the closing's tables end in front of the parked items");
+__device__ __forceinline__ void cyc_close_half(const KeyMaterial *__restrict__ km, const BodyParams &p, unsigned char *smem, uint4 acc) {
+    const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6, g = blockIdx.x;
+    const uint4 *pt = &km->ptab[0][0];                                        // ptab[0 .. 2]: nibble tables of H^64, H^128, H^256 (512 entries each)
+    const uint4 t0 = pt[tid], t1 = pt[512u + tid], t2 = pt[1024u + tid];
+    uint4 l[4];
+#pragma unroll
+    for (u32 k = 0; k < 4; ++k) l[k] = cyc_ltab_entry(km, k * 512u + tid, p.tb);
+    const uint4 wc = km->pwh[gridDim.x - 1u - g];                             // H^(512 (255 - g)): the blocks between the end of this workgroup's eight items and the end of the grid
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // the rows' stores (the compiler does not count those issued from asm) have been acknowledged
+    __syncthreads();                                                          // every wave is done with the T-tables
+    reinterpret_cast<uint4 *>(smem + CYCH_LDS_TREE_TAB)[tid] = t0;
+    reinterpret_cast<uint4 *>(smem + CYCH_LDS_TREE_TAB)[512u + tid] = t1;
+    reinterpret_cast<uint4 *>(smem + CYCH_LDS_TREE_TAB)[1024u + tid] = t2;
+#pragma unroll
+    for (u32 k = 0; k < 4; ++k) *reinterpret_cast<uint4 *>(smem + cyc_ltab_off(k * 512u + tid, CYCH_LDS_LTAB)) = l[k];
+    *reinterpret_cast<uint4 *>(smem + cych_stage_off(0) + wv * 1024u + lane * 16u) = acc;
+    __syncthreads();
+    uint4 y = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (u32 level = 0; level < 3; ++level) {
+        if (wv < (4u >> level)) {
+            y = cych_tree_lane(smem, level, wv, lane);
+            if (level < 2) *reinterpret_cast<uint4 *>(smem + cych_stage_off(level + 1) + wv * 1024u + lane * 16u) = y;
+        }
+        if (level < 2) __syncthreads();
+    }
+    if (wv != 0) return;
+#if !AESGCM_BODY_WT
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
+    G128 z = wave_xor(cyc_lane_term_lds(smem, y, lane, CYCH_LDS_LTAB));
+    if (g + 1u != gridDim.x) {                                                // the weight through a two-table Shoup form in LDS
+        if (lane < 32) *reinterpret_cast<uint4 *>(smem + CYCH_LDS_WTAB + 16u * lane) = shoup2_entry(mo_to_be(wc), lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        z = shoup2_gmul_lds(z, reinterpret_cast<const uint4 *>(smem + CYCH_LDS_WTAB));
+    }
+    if (g == 0) {                                                             // the terms that occur once
+        G128 x; x.w[0] = x.w[1] = x.w[2] = x.w[3] = 0;
+        if (p.tb) {
+            // the partial last row wants the lanes' tables of H^(65 - L): they go where the workgroup's own were -- this wave is the only one left, and it is done with them
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (u32 k = 0; k < 32u; ++k) *reinterpret_cast<uint4 *>(smem + cyc_ltab_off(k * 64u + lane, CYCH_LDS_LTAB)) = cyc_ltab_entry(km, k * 64u + lane, 0u);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            x = cyc_lane_term_lds(smem, *reinterpret_cast<const uint4 *>(smem + CYCH_LDS_PARK + lane * 16u), lane, CYCH_LDS_LTAB);
+        }
+        if (lane == 0) {
+            const uint4 ej0 = *reinterpret_cast<const uint4 *>(smem + CYCH_LDS_PARK + 1024u);
+            G128 L; const u64 la = p.aad_len * 8, lc = p.ct_len * 8;
+            L.w[0] = (u32)(la >> 32); L.w[1] = (u32)la; L.w[2] = (u32)(lc >> 32); L.w[3] = (u32)lc;
+            L = shoup2_gmul_lds(L, km->ltab[1]);
+            const G128 e = mo_to_be(ej0);
+            x.w[0] ^= L.w[0] ^ e.w[0]; x.w[1] ^= L.w[1] ^ e.w[1]; x.w[2] ^= L.w[2] ^ e.w[2]; x.w[3] ^= L.w[3] ^ e.w[3];
+        }
+        x = wave_xor(x);
+        z.w[0] ^= x.w[0]; z.w[1] ^= x.w[1]; z.w[2] ^= x.w[2]; z.w[3] ^= x.w[3];
+    }
+    if (lane != 0) return;
+    acc_arrive(p.acc, g, z, p.tag_out, p.tag_host, p.gen);
+    if (p.trace) {
+        unsigned long long *tr = reinterpret_cast<unsigned long long *>(p.trace + 4 * (u64)g);
+        const u64 rows_end = __hip_atomic_load(tr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const u64 dt = wall_clock64() - rows_end;
+        atomicOr(tr + 2, (unsigned long long)(dt > 0xFFFu ? 0xFFFu : dt) << 52);
+    }
+}
+
+template <int NR, int MODE>
+__global__ __launch_bounds__(AESGCM_BODYH_WG, 4) void k_bodyh(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const BodyParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const u32 tid = threadIdx.x, lane = tid & 63u;
+    if (p.trace && tid == 0) {
+        u64 *tr = p.trace + 4 * (u64)blockIdx.x;
+        tr[0] = wall_clock64();
+        tr[2] = (u64)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((u64)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xF) << 32);
+    }
+    const u64 cyc0 = p.trace ? clock64() : 0;
+    main_fill_lds(smem, km, tb, tid, true, AESGCM_BODYH_WG, GH_TAB_K2P17);    // T0 | T2 and the five-bit tables of the stride H^(2^17)
+    __syncthreads();
+    if (p.trace && tid == 0) {
+        unsigned long long *tr = reinterpret_cast<unsigned long long *>(p.trace + 4 * (u64)blockIdx.x);
+        const u64 dt = wall_clock64() - tr[0];
+        atomicOr(tr + 2, (unsigned long long)(dt > 0xFFFu ? 0xFFFu : dt) << 40);
+    }
+    CtrConsts cc = ctr_round1_consts(p.iv0, p.iv1, p.iv2, km->rk, smem, (lane & 31u) << 2);
+    cc.c0 = __builtin_amdgcn_readfirstlane(cc.c0); cc.c1 = __builtin_amdgcn_readfirstlane(cc.c1);
+    cc.c2 = __builtin_amdgcn_readfirstlane(cc.c2); cc.c3 = __builtin_amdgcn_readfirstlane(cc.c3);
+    const u32 w = __builtin_amdgcn_readfirstlane(blockIdx.x * (AESGCM_BODYH_WG / 64) + (tid >> 6));
+    const uint4 acc = body_cyc_lane<NR, MODE, false, BODY_CYC_WAVES_HALF>(km, tb, p, smem, cc, w, lane);
+    if (w == 0) {                                                             // a strand of the shorter kind: the partial last row and E_K(IV || 1), parked in LDS for the closing
+        uint4 last = make_uint4(0, 0, 0, 0);
+        if (p.tb) last = body_cyc_last_lane<NR, MODE>(km, p, smem, cc, lane);
+        u32 s0, s1, s2, s3;
+        ctr_rounds_lds<NR>(bswap32(1u), cc, s0, s1, s2, s3, km->rk, smem, (lane & 31u) << 2);
+        *reinterpret_cast<uint4 *>(smem + CYCH_LDS_PARK + lane * 16u) = last;
+        if (lane == 0) *reinterpret_cast<uint4 *>(smem + CYCH_LDS_PARK + 1024u) = make_uint4(s0, s1, s2, s3);
+    }
+    if (p.trace && lane == 0) {
+        u64 *tr = p.trace + 4 * (u64)blockIdx.x;
+        atomicMax((unsigned long long *)&tr[1], (unsigned long long)wall_clock64());
+        atomicAdd((unsigned long long *)&tr[3], (unsigned long long)((p.F + p.R) / BODY_CYC_WAVES_HALF) | ((unsigned long long)((clock64() - cyc0) >> 10) << 32));
+    }
+    cyc_close_half(km, p, smem, acc);
+}
+
 // k_fold: up to FOLD_GROUP x FOLD_WAVES = 128 items per workgroup (lane bodies: fold_wave_lane(), fold_wg_lane()).  No static LDS: table offsets
 // are absolute.
 #ifndef FOLD_WPS
@@ -1212,6 +1330,11 @@ struct aesgcm_ctx {
     bool fold_close = true;            // whole messages through the dealt k_body: k_fold's first level closes the tag (FoldClose; option "fold_close" 0: further levels and k_combine)
     u32 cyc_prio = 2;                  // rows between rotations of the waves' issue priorities in a cyclic launch (body_prio; option "cyc_prio", 0 = off).  Without it the oldest wave of
                                        // every SIMD runs ahead and the youngest finishes alone: 256 MiB 321 -> 291 us, 1 GiB 1238 -> 1105 (dealt chunks: 1090), profiles/r03c/cyc_prio_*.txt
+    bool cyc_half = false;             // option "cyc_half": whole messages of cyc_half_min .. cyc_half_max bytes take the HALF shape of the cyclic rows (k_bodyh: 256 workgroups of 512 lanes,
+                                       // two per CU) -- for callers that keep two or more messages in flight on contexts of their own, where one message's staging and closing
+                                       // then run beside another's rows; alone on the chip the half shape is slower than the full one
+    u64 cyc_half_max = (u64)80 << 20;  // sustained GiB/s, AES-256, full shape with 2 in flight / half shape with 3 (profiles/r04/inflight_threshold.txt): 8 MiB 409 / 562, 24 MiB 677 / 797,
+                                       // 32 MiB 730 / 816, 48 MiB 810 / 836, 64 MiB 828 / 846, 96 MiB 870 / 862, 128 MiB 877 / 867 -- the two-table round costs what the overlap buys from there
     bool cyc_fuse = true;              // whole messages: the cyclic launch closes the tag itself (option "cyc_close" 0: k_fold + k_combine behind it, as for shards and streaming chunks)
     // Which ranges go through k_body as cyclic rows (body_cyc_lane: one launch for AAD, data and ragged end, no dispenser, 4096 items whatever the size).  options "cyc_min" / "cyc_max"
     // (bytes; both 0 = never); needs one k_body workgroup per CU on 256 CUs.  Whole messages close their tag inside the launch (cyc_close): 24 us from 16 KiB to 2 MiB where
@@ -1293,6 +1416,9 @@ static int set_lds_attrs(int device, DeviceState *ds) {
     SETATTRY(10, MODE_ENC, true); SETATTRY(12, MODE_ENC, true); SETATTRY(14, MODE_ENC, true); SETATTRY(10, MODE_DEC, true); SETATTRY(12, MODE_DEC, true); SETATTRY(14, MODE_DEC, true);
     SETATTRY(10, MODE_PROBE, false); SETATTRY(12, MODE_PROBE, false); SETATTRY(14, MODE_PROBE, false);
 #undef SETATTRY
+#define SETATTRH(NR, MODE) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bodyh<NR, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, AESGCM_LDS_BYTES + CYC_LDS_PARK_BYTES))
+    SETATTRH(10, MODE_ENC); SETATTRH(12, MODE_ENC); SETATTRH(14, MODE_ENC); SETATTRH(10, MODE_DEC); SETATTRH(12, MODE_DEC); SETATTRH(14, MODE_DEC);
+#undef SETATTRH
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fold), hipFuncAttributeMaxDynamicSharedMemorySize, FOLD_LDS_CLOSE_BYTES));
 #define SETATTRB(NR, D) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch<NR, D>), hipFuncAttributeMaxDynamicSharedMemorySize, BATCH_LDS_BYTES)); \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktg<NR, D, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, PKTG_LDS_TOTAL(2))); \
@@ -1432,8 +1558,9 @@ static int enqueue_combine(aesgcm_ctx *c, const CombineParams &p, hipStream_t st
 
 // one k_body launch (dealt chunks or cyclic rows) with the context's timing and event bookkeeping
 static int launch_body(aesgcm_ctx *c, int mode, BodyParams &p, u32 wgs, hipStream_t st) {
-    const bool cyc = p.cyc != 0;
+    const bool cyc = p.cyc != 0, half = cyc && p.cw == BODY_CYC_WAVES_HALF;
     if (cyc && mode == MODE_PROBE) return AESGCM_EARG;
+    if (half && !p.fuse) return AESGCM_EARG;                    // the half shape exists with the in-launch closing only
     if (c->timing) { p.trace = c->d_trace; HIPCHK(hipMemsetAsync(c->d_trace, 0, sizeof(u64) * 4 * AESGCM_GMAX, st)); }
     c->last_np = wgs;
     std::pair<hipEvent_t, hipEvent_t> evp;
@@ -1443,7 +1570,12 @@ static int launch_body(aesgcm_ctx *c, int mode, BodyParams &p, u32 wgs, hipStrea
         HIPCHK(hipEventRecord(evp.first, st));
     }
 #define LY(NR, M, CYC) hipLaunchKernelGGL((k_body<NR, M, CYC>), dim3(wgs), dim3(AESGCM_BODY_WG), AESGCM_BODY_LDS + (CYC ? CYC_LDS_PARK_BYTES : 0u), st, c->km, c->tables, p)
-    if (cyc) {
+#define LH(NR, M) hipLaunchKernelGGL((k_bodyh<NR, M>), dim3(wgs), dim3(AESGCM_BODYH_WG), AESGCM_LDS_BYTES + CYC_LDS_PARK_BYTES, st, c->km, c->tables, p)
+    if (half) {
+        if (mode == MODE_DEC)    { if (c->nr == 10) LH(10, MODE_DEC); else if (c->nr == 12) LH(12, MODE_DEC); else LH(14, MODE_DEC); }
+        else                     { if (c->nr == 10) LH(10, MODE_ENC); else if (c->nr == 12) LH(12, MODE_ENC); else LH(14, MODE_ENC); }
+    }
+    else if (cyc) {
         if (mode == MODE_DEC)    { if (c->nr == 10) LY(10, MODE_DEC, true); else if (c->nr == 12) LY(12, MODE_DEC, true); else LY(14, MODE_DEC, true); }
         else                     { if (c->nr == 10) LY(10, MODE_ENC, true); else if (c->nr == 12) LY(12, MODE_ENC, true); else LY(14, MODE_ENC, true); }
     }
@@ -1451,6 +1583,7 @@ static int launch_body(aesgcm_ctx *c, int mode, BodyParams &p, u32 wgs, hipStrea
     else if (mode == MODE_PROBE) { if (c->nr == 10) LY(10, MODE_PROBE, false); else if (c->nr == 12) LY(12, MODE_PROBE, false); else LY(14, MODE_PROBE, false); }
     else                         { if (c->nr == 10) LY(10, MODE_ENC, false); else if (c->nr == 12) LY(12, MODE_ENC, false); else LY(14, MODE_ENC, false); }
 #undef LY
+#undef LH
     const hipError_t le = hipGetLastError();
     if (le != hipSuccess) {
         if (c->timing) c->ev_pool.push_back(evp);
@@ -1506,7 +1639,8 @@ static int enqueue_cyc(aesgcm_ctx *c, int mode, const uint8_t iv[12], const void
     // profiles/r03c/general_shape.txt): for those the cyclic launch stays ahead for longer
     const bool pieces = aad_len || (first_block & 255) || (len & 1023);
     const u64 lo = fused ? c->cyc_min_fused : c->cyc_min, hi = pieces ? c->cyc_max_pieces : fused ? c->cyc_max_fused : c->cyc_max;
-    if (!plan_body_cyc(p, mode, iv, d_aad, aad_len, d_in, len, d_out, first_block, c->parts, lo, hi)) return AESGCM_OK;
+    const bool half = fused && c->cyc_half && len < c->cyc_half_max;             // two workgroups per CU: for messages in flight beside each other
+    if (!plan_body_cyc(p, mode, iv, d_aad, aad_len, d_in, len, d_out, first_block, c->parts, lo, hi, half ? BODY_CYC_WAVES_HALF : BODY_CYC_WAVES)) return AESGCM_OK;
     *took = true;
     *po = Partials();
     p.prio_rows = c->cyc_prio;
@@ -1514,7 +1648,7 @@ static int enqueue_cyc(aesgcm_ctx *c, int mode, const uint8_t iv[12], const void
         p.fuse = 1; p.aad_len = aad_len; p.ct_len = len; p.acc = c->d_cyc;
         p.tag_out = c->d_tag; p.tag_host = c->h_tag_dev; p.gen = ++c->tag_gen;
         po->done = true;
-        return launch_body(c, mode, p, BODY_CYC_WAVES / (AESGCM_BODY_WG / 64), st);
+        return launch_body(c, mode, p, half ? BODY_CYC_WAVES_HALF / (AESGCM_BODYH_WG / 64) : BODY_CYC_WAVES / (AESGCM_BODY_WG / 64), st);
     }
     p.ej0 = c->d_tag + 3; po->ej0 = p.ej0;
     if ((rc = launch_body(c, mode, p, BODY_CYC_WAVES / (AESGCM_BODY_WG / 64), st))) return rc;
@@ -1823,6 +1957,7 @@ int aesgcm_ctx_set_option(aesgcm_ctx *c, const char *key, int64_t value) {
     }
     else if (!strcmp(key, "cyc_min")) c->cyc_min = c->cyc_min_fused = v;               // bytes: ranges in [cyc_min, cyc_max) take k_body's cyclic rows; both 0 = never
     else if (!strcmp(key, "cyc_max")) c->cyc_max = c->cyc_max_pieces = c->cyc_max_fused = v;
+    else if (!strcmp(key, "cyc_half")) c->cyc_half = v != 0;                           // 1: whole messages below 80 MiB as k_bodyh (two workgroups per CU: for several messages in flight)
     else if (!strcmp(key, "cyc_close")) c->cyc_fuse = v != 0;                          // 1: a whole message's cyclic launch closes the tag itself; 0: k_fold + k_combine behind it
     else if (!strcmp(key, "fold_close")) c->fold_close = v != 0;                       // 1: behind the dealt k_body the first (or second) k_fold level closes the tag
     else if (!strcmp(key, "cyc_prio")) c->cyc_prio = (u32)v;                           // rows between rotations of the waves' issue priorities in a cyclic launch (0 = off)

@@ -110,6 +110,9 @@ AESGCM_API int aesgcm_ctx_device(const aesgcm_ctx *ctx);
  *   "body_min"    bytes from which a range's aligned middle goes through k_body's dealt chunks (>= 2^60: never, nor cyclic rows)
  *   "cyc_min", "cyc_max"   bytes: ranges in [cyc_min, cyc_max) take k_body's cyclic rows (one launch per message); both 0 = never
  *   "cyc_close"   1: that launch closes the tag itself; 0: k_fold + k_combine behind it
+ *   "cyc_half"    1: whole messages below 80 MiB take the launch in its half shape (256 workgroups of 512 lanes, two per CU): for callers
+ *                 that keep two or more messages in flight on contexts of their own -- one message's table staging and closing then run
+ *                 beside another's rows; a single message alone on the chip is slower that way (default 0)
  *   "fold_close"  1: behind the dealt k_body a k_fold level closes the tag; 0: further levels and k_combine
  *   "cyc_prio"    rows between rotations of the waves' issue priorities in a cyclic launch, 0 = off
  *   "poll_us"     how long a tag is polled for in the pinned host slot before the call blocks in the runtime

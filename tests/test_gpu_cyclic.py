@@ -44,6 +44,36 @@ def test_whole_messages_of_any_shape_take_the_cyclic_launch(hip, orc, klen, clos
         _check(hip, f, ctx, iv, n, al, 9200 + 10 * k, aad_off=(k % 3) * 4)      # AAD pointer 16-, 4- and 8-byte aligned
 
 
+@pytest.mark.parametrize("klen", [16, 24, 32])
+def test_half_shape_of_the_cyclic_launch(hip, orc, klen):
+    """context option "cyc_half": whole messages as k_bodyh -- 256 workgroups of 512 lanes, 2048 strands with the stride H^(2^17), the two-table round, eight
+    items per workgroup in the closing (three tree levels, weights H^(512 (255 - g))) -- for callers with several messages in flight; every shape the full
+    launch is tested on, AAD front rows (up to one per strand: 2 MiB), ragged ends, decrypt in place, and two contexts side by side on their own streams"""
+    key, iv = splitmix_bytes(9150 + klen, klen), splitmix_bytes(9151, 12)
+    ctx, f = hip.Context(key), orc.Fast(key)
+    ctx.set_option("cyc_half", 1)
+    shapes = [(64 * 1024, 0), (64 * 1024 + 1, 20), (96 * 1024 + 1013, 4095), (MiB + 5, 0), (2 * MiB + 1024 * 3 + 16, 16), (4 * MiB + 5, 20), (5 * MiB - 3, 1000),
+              (6 * MiB + 1023, 16 * 64), (7 * MiB + 16, 1), (9 * MiB + 1008, 16 * 64 * 3 + 7), (3 * MiB, 2 * MiB - 64), (3 * MiB + 7, 2 * MiB + 4096)]
+    if klen == 32:
+        shapes += [(16 * MiB + 1, 13), (33 * MiB - 17, 68), (64 * MiB + 4096 + 15, 4095)]
+    for k, (n, al) in enumerate(shapes):
+        _check(hip, f, ctx, iv, n, al, 9250 + 10 * k, aad_off=(k % 3) * 4)
+    # two contexts on their own streams, queued (tag = NULL), four launches each in flight
+    c2 = hip.Context(key).set_option("cyc_half", 1)
+    n = 3 * MiB + 4096 + 7
+    d_in = hip.DeviceBuffer(n + 16); d_in.fill_splitmix64(9610 + klen, 0, nbytes=n)
+    pt = bytes(d_in.download(n))
+    o1, o2 = hip.DeviceBuffer(n + 16), hip.DeviceBuffer(n + 16)
+    ivs = [splitmix_bytes(9630 + k, 12) for k in range(4)]
+    for k, v in enumerate(ivs):
+        ctx.encrypt_dev(v, d_in.ptr, n, o1.ptr, want_tag=False)
+        c2.encrypt_dev(v, d_in.ptr, n - 4096 * (k & 1), o2.ptr, want_tag=False)
+    t1, t2 = ctx.last_tag(), c2.last_tag()
+    w1, w2 = f.encrypt(ivs[-1], b"", pt), f.encrypt(ivs[-1], b"", pt[:n - 4096])
+    assert t1 == w1[1] and t2 == w2[1]
+    assert bytes(o1.download(n)) == w1[0] and bytes(o2.download(n - 4096)) == w2[0]
+
+
 def test_aad_longer_than_the_front_rows_falls_back(hip, orc):
     """more than 4096 front rows (4 MiB of AAD) do not fit one per strand: the range goes the other way, with the same tag"""
     key, iv = splitmix_bytes(9300, 32), splitmix_bytes(9301, 12)

@@ -64,7 +64,7 @@ def test_register_budgets(census):
         wide_pktg = name.startswith("k_pktg<") and name.endswith(", 6>")                 # 768-lane workgroups: 3 waves per SIMD, 168 registers
         if wide_pktg:
             assert k["vgpr"] <= 168 and k["scratch"] == 0, (name, k["vgpr"], k["scratch"])
-        elif name.startswith(("k_body<", "k_pktg<", "k_pktl<", "k_batch<", "k_batch3<")):
+        elif name.startswith(("k_body<", "k_bodyh<", "k_pktg<", "k_pktl<", "k_batch<", "k_batch3<")):
             assert k["vgpr"] <= 128, (name, k["vgpr"])         # one 1024-lane workgroup per CU = 4 waves per SIMD
             if name.startswith(("k_pktg<", "k_batch3<")):
                 assert k["scratch"] == 0, (name, k["scratch"])  # nothing spilled (ds_swizzle exchanges, per-packet values parked in LDS, fresh lane id)
@@ -75,12 +75,27 @@ def test_kernel_set(census):
     fam = {}
     for name in census:
         fam.setdefault(name.split("<")[0], []).append(name)
-    assert sorted(fam) == ["k_batch", "k_batch3", "k_body", "k_combine", "k_combine_batch", "k_copy16", "k_fill_splitmix64", "k_fold", "k_gfmul", "k_init_tables",
+    assert sorted(fam) == ["k_batch", "k_batch3", "k_body", "k_bodyh", "k_combine", "k_combine_batch", "k_copy16", "k_fill_splitmix64", "k_fold", "k_gfmul", "k_init_tables",
                            "k_main", "k_pktg", "k_pktl", "k_setup", "k_setup_ptab"], sorted(fam)
-    assert (len(fam["k_main"]), len(fam["k_body"]), len(fam["k_pktg"]), len(fam["k_pktl"]), len(fam["k_batch"]), len(fam["k_batch3"])) == (12, 15, 24, 6, 6, 12)
+    assert (len(fam["k_main"]), len(fam["k_body"]), len(fam["k_bodyh"]), len(fam["k_pktg"]), len(fam["k_pktl"]), len(fam["k_batch"]), len(fam["k_batch3"])) == (12, 15, 6, 24, 6, 6, 12)
 
 
 def test_no_sgpr_hazard_in_front_of_the_write_through_stores(census):
     import isa_census
     bad = isa_census.wt_store_hazards(os.path.join(CSRC, "aesgcm_kernels.gfx950.s"))
     assert not bad, bad[:5]
+
+
+def test_half_shape_keeps_its_spills_out_of_the_row_loop(census):
+    """k_bodyh (128 registers, the two-table round) spills three to five dwords around the GENERAL row code -- the front row a strand runs at most once -- and
+    nothing in the body row loop: the basic blocks with the (NR - 2) x 16 T-table lookups of rounds 3 .. NR, or with the 52 reads of the GHASH table multiply,
+    hold no scratch op."""
+    import isa_loops
+    path = os.path.join(CSRC, "aesgcm_kernels.gfx950.s")
+    for nr in (10, 12, 14):
+        for dec in (0, 1):
+            k = census["k_bodyh<%d, %d>" % (nr, dec)]
+            assert k["scratch"] <= 32 and sum(ops.get("scratch", 0) for ops in k["depth"].values()) <= 6, k
+            blocks = isa_loops.census(path, "_Z7k_bodyhILi%dELi%dEE" % (nr, dec))
+            rows = [c for _, c in blocks if c["lds"] == 16 * (nr - 2) or c["lds"] == 52]
+            assert rows and all(c["scratch"] == 0 for c in rows), (nr, dec, [(c["lds"], c["scratch"]) for c in rows])
