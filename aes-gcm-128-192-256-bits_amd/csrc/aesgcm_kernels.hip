@@ -256,8 +256,11 @@ __global__ __launch_bounds__(AESGCM_MAIN_WG, AESGCM_WAVES_PER_SIMD) void k_main(
 // block come from per-lane chunk constants and scalar-cache table reads, not from LDS.
 // ------------------------------------------------------------------------------------------------
 #if AESGCM_T4
-#define AESGCM_BODY_WG 1024                  /* one workgroup per CU (136 KiB of LDS), 4 waves per SIMD, 128 registers */
-#define AESGCM_BODY_WPS 4
+#ifndef AESGCM_BODY_WG_T4
+#define AESGCM_BODY_WG_T4 1024               /* lanes of k_body's workgroup (the cyclic rows and their closing need 1024; 768 = 3 waves per SIMD was the round-4 energy A/B, profiles/r04/energy_ab.txt) */
+#endif
+#define AESGCM_BODY_WG AESGCM_BODY_WG_T4     /* one workgroup per CU (136 KiB of LDS), 4 waves per SIMD, 128 registers */
+#define AESGCM_BODY_WPS ((AESGCM_BODY_WG + 255) / 256)
 #define AESGCM_BODY_LDS AESGCM_LDS_BYTES_T4
 #else
 #define AESGCM_BODY_WG AESGCM_MAIN_WG
