@@ -19,7 +19,7 @@
 #define CHECK(call) do { int rc_ = (call); if (rc_) { fprintf(stderr, "%s -> %d (%s; %s)\n", #call, rc_, aesgcm_strerror(rc_), aesgcm_last_error()); return 1; } } while (0)
 #define HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fprintf(stderr, "%s -> %s\n", #call, hipGetErrorString(e_)); return 1; } } while (0)
 
-struct Shape { size_t n, aad; int dec, inplace, calls; };
+struct Shape { size_t n, aad; int dec, inplace, calls, half; };      /* half: the context option cyc_half (k_bodyh, two workgroups per CU; messages < 80 MiB) */
 
 int main(int argc, char **argv) {
     const double scale = argc > 1 ? atof(argv[1]) : 1.0;
@@ -34,14 +34,19 @@ int main(int argc, char **argv) {
         {64 * MiB - 1008, 0, 0, 0, 100}, {64 * MiB + 3, 68, 0, 1, 60}, {64 * MiB + 1023, 1, 1, 1, 60},
         {256 * MiB + 16, 20, 0, 0, 40}, {256 * MiB, 0, 1, 1, 30},
         {1008 * MiB + 5, 0, 0, 0, 20}, {1023 * MiB + 1019, 28, 1, 0, 20}, {1200 * MiB + 7, 20, 0, 1, 16},          /* the top of the cyclic range, with and without pieces */
+        /* the half shape of the launch: the same promise from k_bodyh's closing */
+        {64 * KiB, 0, 0, 0, 300, 1}, {96 * KiB + 1013, 4095, 1, 1, 200, 1}, {MiB + 5, 16, 0, 1, 200, 1}, {4 * MiB - 1008, 1000, 1, 0, 150, 1},
+        {16 * MiB + 17, 20, 0, 0, 150, 1}, {16 * MiB - 15, 0, 1, 1, 100, 1}, {64 * MiB + 1023, 1, 0, 1, 60, 1}, {79 * MiB + 5, 68, 1, 0, 40, 1},
     };
     size_t nmax = 0;
     for (const Shape &s : shapes) nmax = s.n > nmax ? s.n : nmax;
     const size_t window = 8 * MiB;                                     /* what is read early of a big message: its end */
-    aesgcm_ctx *ctx = NULL;
+    aesgcm_ctx *ctx = NULL, *ctx_full = NULL, *ctx_half = NULL;
     void *d_pt = NULL, *d_ct[2] = {NULL, NULL}, *d_work = NULL, *d_out = NULL, *d_aad = NULL;
     unsigned char *h_early = NULL;
-    CHECK(aesgcm_ctx_create(&ctx, 0, key, sizeof key));
+    CHECK(aesgcm_ctx_create(&ctx_full, 0, key, sizeof key));
+    CHECK(aesgcm_ctx_create(&ctx_half, 0, key, sizeof key));
+    CHECK(aesgcm_ctx_set_option(ctx_half, "cyc_half", 1));
     CHECK(aesgcm_dev_alloc(0, &d_pt, nmax + 64));
     CHECK(aesgcm_dev_alloc(0, &d_ct[0], nmax + 64));
     CHECK(aesgcm_dev_alloc(0, &d_ct[1], nmax + 64));
@@ -60,6 +65,7 @@ int main(int argc, char **argv) {
     for (const Shape &s : shapes) {
         const size_t n = s.n, w = n < window ? n : window, w0 = n - w;              /* early-read region [w0, n) */
         const void *a = s.aad ? d_aad : NULL;
+        ctx = s.half ? ctx_half : ctx_full;
         /* reference results, read after a full synchronisation: ciphertext k for encrypt, the plaintext for decrypt */
         for (int k = 0; k < 2; k++) {
             CHECK(aesgcm_encrypt_dev(ctx, iv[k], a, s.aad, d_pt, n, d_ct[k], tag_ref[k], NULL));
@@ -90,14 +96,15 @@ int main(int argc, char **argv) {
             }
         }
         HIP(hipDeviceSynchronize());
-        printf("%11zu bytes, aad %4zu, %s, %s: %d of %d early reads differ\n", n, s.aad, s.dec ? "decrypt" : "encrypt", s.inplace ? "in place    " : "out of place", bad, n_calls);
+        printf("%11zu bytes, aad %4zu, %s, %s, %s shape: %d of %d early reads differ\n", n, s.aad, s.dec ? "decrypt" : "encrypt", s.inplace ? "in place    " : "out of place",
+               s.half ? "half" : "full", bad, n_calls);
         bad_total += bad;
         calls_total += n_calls;
     }
     (void)hipStreamDestroy(side);
     (void)hipHostFree(h_early);
     aesgcm_dev_free(0, d_pt); aesgcm_dev_free(0, d_ct[0]); aesgcm_dev_free(0, d_ct[1]); aesgcm_dev_free(0, d_work); aesgcm_dev_free(0, d_out); aesgcm_dev_free(0, d_aad);
-    aesgcm_ctx_destroy(ctx);
+    aesgcm_ctx_destroy(ctx_full); aesgcm_ctx_destroy(ctx_half);
     if (bad_total) { printf("EARLY READ FAILED (%d of %ld)\n", bad_total, calls_total); return 1; }
     printf("EARLY READ OK (%ld calls)\n", calls_total);
     return 0;

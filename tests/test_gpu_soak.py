@@ -79,6 +79,48 @@ def test_three_thousand_cyclic_messages_every_tag_against_the_oracle(hip, orc):
     assert not bad, bad
 
 
+def test_half_shape_two_contexts_in_flight_every_tag_against_the_oracle(hip, orc):
+    """800 random messages of 64 KiB .. 40 MiB through TWO contexts in the half shape (k_bodyh), queued (tag = NULL) so that workgroups of two messages share
+    the CUs, tags collected one turn late through the host slot; every tag against libcrypto, every 40th ciphertext too"""
+    from oracle import libcrypto_ref as R
+    rng = random.Random(515151)
+    nmax, span = 40 * MiB + 1024, 32 * MiB
+    d_src = hip.DeviceBuffer(span + nmax + 64)
+    d_src.fill_splitmix64(17)
+    src = np.frombuffer(bytes(d_src.download()), dtype=np.uint8)
+    d_out = [hip.DeviceBuffer(nmax + 64), hip.DeviceBuffer(nmax + 64)]
+    aad_all = bytes(orc.fill_splitmix64(4096, 18))
+    d_aad = hip.DeviceBuffer(4096 + 64); d_aad.upload(aad_all)
+    key = bytes(orc.fill_splitmix64(32, 0x4A1F))
+    ctxs = [hip.Context(key).set_option("cyc_half", 1), hip.Context(key).set_option("cyc_half", 1)]
+    pending = [None, None]
+    checked = 0
+
+    def collect(j):
+        nonlocal checked
+        if pending[j] is None:
+            return
+        it, n, want_ct, want_tag = pending[j]
+        assert ctxs[j].last_tag() == want_tag, (it, n)
+        if it % 40 == 0:
+            assert bytes(d_out[j].download(n)) == want_ct, (it, n, "ciphertext")
+        checked += 1
+        pending[j] = None
+
+    for it in range(800):
+        j = it & 1
+        collect(j)
+        n = rng.choice((_u_len(rng, 64 << 10, 40 * MiB), _u_len(rng, 64 << 10, 4 * MiB), 1024 * rng.randint(64, 40960) + rng.choice((0, 1, 16, 1008, 1023))))
+        al = rng.choice((0, 0, 16, 20, 1000, rng.randint(1, 4000)))
+        off = rng.randrange(0, span, 16)
+        iv = bytes(rng.randrange(256) for _ in range(12))
+        want_ct, want_tag = R.encrypt(key, iv, aad_all[:al], src[off:off + n])
+        ctxs[j].encrypt_dev(iv, d_src.ptr + off, n, d_out[j].ptr, d_aad=d_aad.ptr if al else None, aad_len=al, want_tag=False)
+        pending[j] = (it, n, want_ct, want_tag)
+    collect(0); collect(1)
+    assert checked == 800
+
+
 @pytest.mark.parametrize("kb", [16, 24, 32])
 def test_dealt_gib_messages_with_and_without_foldclose(hip, orc, kb):
     from oracle import libcrypto_ref as R
