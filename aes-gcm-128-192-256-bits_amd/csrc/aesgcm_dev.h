@@ -1562,21 +1562,18 @@ HD G128 shoup_mul(G128 y, const unsigned char *lds, u32 tab) {
     return z;
 }
 
-// ---- k_batch2 pieces -----------------------------------------------------------------------------
+// ---- k_batch3 pieces -----------------------------------------------------------------------------
 // Byte-wise variant of the same method: TWO 16-entry tables per constant c, Th[v] = v*c and Tl[v] = v*c*x^4, so that
 //     Y*c = Horner over Y's 16 bytes:  Z = Z*x^8 xor Th[high nibble] xor Tl[low nibble]
 // halves the shift-and-reduce steps, and the 8 bits shifted out are reduced arithmetically (x^128 = 1 + x + x^2 + x^7,
 // R = 0xE1 || 0^120, src/ghash_gfmul.vhd:37-64) instead of through a table: 16 steps of ~20 VALU + 2 ds_read_b128
-// against 31 steps of ~14 VALU + ds_read_b32 + ds_read_b128.  Measured: VALU instructions per packet 7627 -> see
-// profiles/README.md.
-#define BATCH2_GROUP_LDS 1024u                  /* per packet group: Th(H) | Tl(H) | Th(C) | Tl(C), 256 B each */
-#define BATCH2_LDS_TAB_OFF (AESGCM_LDS_AES_OFF + AESGCM_LDS_AES)
-#define BATCH2_LDS_BYTES(LG) (BATCH2_LDS_TAB_OFF + (AESGCM_WG / 64u) * (64u >> (LG)) * BATCH2_GROUP_LDS)
-#define BATCH3_GROUP_LDS 1056u                  /* k_batch3: the same two table pairs, then the packet's H and E_K(J0) (16 bytes each) */
-#define BATCH3_LDS_BYTES (BATCH2_LDS_TAB_OFF + (AESGCM_WG / 64u) * 4u * BATCH3_GROUP_LDS)
-#define BATCH3_GROUP_LDS_LG(LG) ((LG) >= 4 ? BATCH3_GROUP_LDS : 544u)      /* 8 lanes per packet: 128 packets per workgroup, ONE table slot each + H and E_K(J0) */
-#define BATCH3_LDS_BYTES_LG(LG) (BATCH2_LDS_TAB_OFF + (AESGCM_WG / 64u) * (64u >> (LG)) * BATCH3_GROUP_LDS_LG(LG))
-// Y * c through the two tables at LDS byte offsets tab (Th) and tab + 256 (Tl), entries = 4 BE words
+// against 31 steps of ~14 VALU + ds_read_b32 + ds_read_b128 (round 2).  Round 4 delays the reduction (shoup2_mul_dr below).
+// LDS of k_batch3 behind the T-tables: per packet one (8 lanes per packet) or two 512-byte table slots Th | Tl, then 32 bytes per packet for H and E_K(J0)
+#define BATCH3_LDS_TAB_OFF (AESGCM_LDS_AES_OFF + AESGCM_LDS_AES)
+#define BATCH3_GROUP_LDS_LG(LG) ((LG) >= 4 ? 1056u : 544u)
+#define BATCH3_LDS_BYTES_LG(LG) (BATCH3_LDS_TAB_OFF + (AESGCM_WG / 64u) * (64u >> (LG)) * BATCH3_GROUP_LDS_LG(LG))
+// Y * c through the two tables at LDS byte offsets tab (Th) and tab + 256 (Tl), entries = 4 BE words (the form with a reduction per byte: kept as the
+// unit-tested reference of shoup2_mul_dr and for -DBATCH3_DR=0 builds)
 HD G128 shoup2_mul(G128 y, const unsigned char *lds, u32 tab) {
     u32 z0 = 0, z1 = 0, z2 = 0, z3 = 0;
 #pragma unroll

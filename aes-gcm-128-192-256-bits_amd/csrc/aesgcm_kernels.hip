@@ -1,16 +1,18 @@
 // aesgcm_kernels.hip -- HIP kernels (gfx950) + the C ABI of include/aesgcm.h.
 //
-// Kernels
+// Kernels (DESIGN.md section 5 says what binds each)
 //   k_init_tables   per device, once: S-box (256 B) and T0 (1 KiB) computed from their definitions.
-//   k_setup         per key: aes_kexp (or pre-expanded load), H = E_K(0), H-power tables, nibble table of K.
-//   k_main<NR,MODE> the hot path: fused AES-CTR + GHASH partial evaluation (also ECB / keystream modes).
-//   k_body<NR,MODE> the aligned middle of very large ranges: rounds 1-2 without LDS lookups.
-//   k_fold          reduces the chunks' items (64 lane accumulators each) by Horner with wave-uniform constants.
-//   k_combine       per message: H^(63-L) on the last item, lane fold, optional H^e weighting / chaining value
+//   k_setup, k_setup_ptab   per key: aes_kexp (or pre-expanded load), H = E_K(0), H-power tables, the five-bit / nibble / Shoup tables of the launch constants.
+//   k_main<NR,MODE> fused AES-CTR + GHASH over dealt or owned chunks: messages below 64 KiB, heads and tails of larger ones; ECB / keystream modes.
+//   k_body<NR,MODE,CYC>   rounds 1-2 without LDS lookups, four T-tables.  CYC = false: dealt chunks (messages and shards from 1 GiB); CYC = true: cyclic rows,
+//                   one launch per message of 64 KiB .. 1 GiB that closes the tag itself (cyc_close).
+//   k_bodyh<NR,MODE>      the cyclic rows in a half shape (512 lanes, two-table round, two workgroups per CU) for messages in flight beside each other.
+//   k_fold          reduces the chunks' items (64 lane accumulators each) by Horner with wave-uniform constants; its first level may close the tag (FoldClose).
+//   k_combine       per message: H^(65-L) on the last item, lane fold, optional H^e weighting / chaining value
 //                   (shards, streaming), length block, E_K(J0) -> tag.  k_combine_batch: up to 8 messages, one workgroup each.
-//   k_batch3, k_batch   packets with their OWN key: 8 or 16 lanes per packet in one pass / one wave per packet.
-//   k_pktg<.., LG>, k_pktl        packets under the context's key: 2^LG lanes per packet (4, 8, 16, 64) / one lane per packet.
-//   k_gfmul, k_fill, k_copy16 small utility kernels.
+//   k_batch3<NR,DEC,LG>, k_batch   packets with their OWN key: 8 or 16 lanes per packet in one pass / one wave per packet.
+//   k_pktg<NR,DEC,LG>, k_pktl      packets under the context's key: 2^LG lanes per packet (4, 8, 16, 64) / one lane per packet.
+//   k_gfmul, k_fill_splitmix64, k_copy16   small utility kernels.
 //
 // GHASH re-association (DESIGN.md "GHASH as a polynomial"): the GHASH input sequence
 // A_0..A_{u-1}, C_0..C_{c-1} (n = u + c blocks) is right-aligned into rows of 64 slots (front padding =
@@ -1009,8 +1011,8 @@ __global__ __launch_bounds__(BATCH3_LANES(NR), (BATCH3_LANES(NR) + 255) / 256) v
     constexpr u32 G = 1u << LG, P = 64u >> LG;
     // LDS behind the T-tables: one (8 lanes per packet) or two 512-byte table slots per packet, 256-byte aligned (shoup2_mul_dr ORs the entry offset into
     // the slot address), then 32 bytes per packet for its H and E_K(J0)
-    constexpr u32 GRP_TAB = BATCH3_GROUP_LDS_LG(LG) - 32u, WAVES = BATCH3_LANES(NR) / 64u, HSLOTS = BATCH2_LDS_TAB_OFF + WAVES * P * GRP_TAB;
-    static_assert(BATCH2_LDS_TAB_OFF % 256u == 0 && GRP_TAB % 256u == 0, "k_batch3: table slots are 256-byte aligned");
+    constexpr u32 GRP_TAB = BATCH3_GROUP_LDS_LG(LG) - 32u, WAVES = BATCH3_LANES(NR) / 64u, HSLOTS = BATCH3_LDS_TAB_OFF + WAVES * P * GRP_TAB;
+    static_assert(BATCH3_LDS_TAB_OFF % 256u == 0 && GRP_TAB % 256u == 0, "k_batch3: table slots are 256-byte aligned");
     constexpr bool ONE_TAB = LG < 4;
     constexpr bool PAIR = BATCH3_PAIR && BATCH3_PERM && BATCH3_DR && LG == 3;
     const u32 tid = threadIdx.x, lane = tid & 63u;
@@ -1018,7 +1020,7 @@ __global__ __launch_bounds__(BATCH3_LANES(NR), (BATCH3_LANES(NR) + 255) / 256) v
     __syncthreads();
     const u32 lb = (lane & 31u) << 2;
     const u32 wave_id = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));                                          // scalar
-    const u32 wave_tab = BATCH2_LDS_TAB_OFF + wave_id * P * GRP_TAB, wave_hs = HSLOTS + wave_id * P * 32u;
+    const u32 wave_tab = BATCH3_LDS_TAB_OFF + wave_id * P * GRP_TAB, wave_hs = HSLOTS + wave_id * P * 32u;
     constexpr u32 KEYLEN = 4 * (NR - 6);
     const u32 K = p.deal, nb = (p.n_pkts + K - 1) / K;
     u32 pk0 = 0, pk_end = 0;
@@ -2435,7 +2437,6 @@ int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const vo
     p.data_off = (const u64 *)d_data_off; p.aad_off = (const u64 *)d_aad_off;
     p.n_pkts = (u32)n_pkts; p.pkt_len = (u32)pkt_len; p.aad_len = (u32)aad_len;
     p.aligned = (((uintptr_t)d_in | (uintptr_t)d_out) & 15) == 0 && (d_data_off || pkt_len % 16 == 0);
-    const u32 waves_per_wg = AESGCM_PKT_WG / 64;
     const u32 n_cu = (u32)c->G / 2;                                                 // c->G = two workgroups per CU
     int lg = packets_pick_lg(n_cu, n_pkts, pkt_len, d_data_off != nullptr);
 #ifdef AESGCM_DEBUG_KNOBS

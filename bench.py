@@ -449,6 +449,9 @@ def run_inflight(args, dev):
     half = (K >= 2) if args.half < 0 else bool(args.half)
     for c in ctxs:
         c.set_option("cyc_half", int(half))
+        for kv in args.opt:
+            k, v = kv.split("=", 1)
+            c.set_option(k, int(v, 0))
     d_pt = lib.DeviceBuffer(size * R, device=dev)
     d_ct = lib.DeviceBuffer(size * R, device=dev)
     d_pt.fill_splitmix64(0xAE5C0003, 0)
@@ -504,7 +507,7 @@ def run_inflight(args, dev):
         "ms_per_step": round(dt / steps * 1e3, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": "custom: AES-%d-GCM messages of %d bytes under one key, %d queued (contexts rotate, tag = NULL, tags collected one turn late through "
                                "the host slot), ring of %d message buffers = %.3g GiB, SplitMix64 PT seed 0xAE5C0003, empty AAD" % (key_bits, size, K, R, size * R / GiB),
-                   "bytes_per_message": size, "inflight": K, "ring": R, "half_shape": half, "parallelism": "single", "key_bits": key_bits, "us_per_message": round(dt / steps * 1e6, 2)},
+                   "bytes_per_message": size, "inflight": K, "ring": R, "half_shape": half, "context_options": args.opt, "parallelism": "single", "key_bits": key_bits, "us_per_message": round(dt / steps * 1e6, 2)},
         "tag_ok": bad[0] == 0, "tags_checked": steps + warm, "tags_wrong": bad[0],
         "roofline": {"bound": "hbm", "kernel": "%s<%d,ENC> (fused AES-CTR + GHASH), one message at a time" % ("k_body" if body_blocks else "k_main", key_bits // 32 + 6),
                      "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_BYTES_PER_S, 4),
@@ -665,6 +668,8 @@ def main(argv=None):
     ap.add_argument("--half", type=int, default=-1, choices=(-1, 0, 1),
                     help="--inflight: the cyclic rows in their half shape (context option cyc_half: 256 workgroups of 512 lanes, two per CU, so that one message's "
                          "staging and closing run beside another's rows); -1 = on for K >= 2, off for K = 1")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
+                    help="--inflight: a context option for every context (aesgcm_ctx_set_option), e.g. --opt cyc_max=0 --opt body_min=16777216; repeatable")
     ap.add_argument("--single-process", action="store_true",
                     help="N > 1: skip the one-process-per-GPU launch and let ONE fresh child drive all N devices (aesgcm_mgpu_*: ncclCommInitAll) -- "
                          "what the self-launch falls back to by itself when no RCCL communicator comes up between processes")

@@ -477,7 +477,7 @@ static void test_batch_pieces() {
         for (u32 v = 0; v < 16; v++) { G128 e = shoup_entry(c, v); *reinterpret_cast<uint4 *>(smem + tab + 16 * v) = make_uint4(e.w[0], e.w[1], e.w[2], e.w[3]); }
         const G128 z = shoup_mul(y, smem, tab), want = gf_mul(y, c);
         CHECK(memcmp(&z, &want, 16) == 0, "shoup_mul %d", it);
-        {   // byte-wise variant with the two tables Th, Tl (k_batch2)
+        {   // byte-wise variant with the two tables Th, Tl (k_batch3)
             static unsigned char t2[512] __attribute__((aligned(16)));
             for (u32 v = 0; v < 16; v++) {
                 const G128 e = shoup_entry(c, v), el = gf_mulx4(e);
