@@ -847,7 +847,7 @@ HD CtrConsts main_lane_consts(const KeyMaterial *__restrict__ km, const MainPara
 // (round 2: k_fold 32 us -> see profiles/README.md).  k_combine applies H^(63-L) to the last item and XOR-folds the lanes.
 // k_body's chunks are interleaved (item 4s+v, v = row phase, 64 blocks apart; super-chunks 256 T apart):
 // period = 4 folds the four phases with A = H^64 and the super-chunks with B = H^(256 T).
-// Constants that are H^(2^k) (chunk sizes are powers of two unless AESGCM_TW says otherwise) come from the
+// Constants that are H^(2^k) (chunk sizes are powers of two unless the context option "tw" says otherwise) come from the
 // key's precomputed tables (tab* = device pointer); others are built in the kernel from the exponent.
 // k_fold can close the message itself (whole messages whose dealt k_body launch is the whole range: BASELINE configs 2 and 3): the workgroups of the
 // FIRST level then do with their output items what cyc_close does with a workgroup's item -- lane terms H^(65 - L), the weight H^(step (G - 1 - g)) as the

@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B of k_batch3 builds on ONE box (GPU box, from the repo root):  bash profiles/batch_ab.sh <out dir> <lib> [<lib> ...]
-# For each library (AESGCM_LIB) and each forced lane-group size (AESGCM_BATCH_LG = 3, 4): the cfg5 bench line (tags checked against the fixture),
+# Every <lib> is a -DAESGCM_DEBUG_KNOBS build of a variant (it serves as product and as debug library: AESGCM_LIB = AESGCM_LIB_DEBUG).  For each library and each
+# forced lane-group size (BATCH_AB_LGS, default "3 4" -> bench.py --batch-lanes 8 / 16): the cfg5 bench line (tags checked against the fixture),
 # then two counter passes of the same command (never combined with tracing): the LDS / instruction counters, and GRBM_GUI_ACTIVE.
 # Prints one row per variant: GiB/s, kernel ms, LDS-array cycles, conflict cycles, their ratio, LDS busy, VALU and LDS instructions.
 O=$1; shift
@@ -11,11 +12,11 @@ for LIB in "$@"; do
   N=$(basename $LIB .so)
   for LG in ${BATCH_AB_LGS:-3 4}; do
     T=${N}_lg$LG
-    ( cd $REPO && AESGCM_LIB=$LIB AESGCM_BATCH_LG=$LG timeout 300 python3 bench.py --config cfg5 --no-cpu-baseline $EXTRA > $O/bench_$T.json 2> $O/bench_$T.err )
+    ( cd $REPO && AESGCM_LIB=$LIB AESGCM_LIB_DEBUG=$LIB timeout 300 python3 bench.py --config cfg5 --batch-lanes $((1 << LG)) --no-cpu-baseline $EXTRA > $O/bench_$T.json 2> $O/bench_$T.err )
     ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/ab_$T && \
-      AESGCM_LIB=$LIB AESGCM_BATCH_LG=$LG timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d /tmp/ab_$T/sq -- python3 $REPO/bench.py --config cfg5 --steps 4 --warmup 1 --no-cpu-baseline $EXTRA > /dev/null 2> $O/pmc_$T.err; \
-      AESGCM_LIB=$LIB AESGCM_BATCH_LG=$LG timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d /tmp/ab_$T/grbm -- python3 $REPO/bench.py --config cfg5 --steps 4 --warmup 1 --no-cpu-baseline $EXTRA > /dev/null 2>> $O/pmc_$T.err; \
-      for C in FETCH_SIZE WRITE_SIZE; do AESGCM_LIB=$LIB AESGCM_BATCH_LG=$LG timeout 300 rocprofv3 --pmc $C --output-format csv -d /tmp/ab_$T/$C -- python3 $REPO/bench.py --config cfg5 --steps 4 --warmup 1 --no-cpu-baseline $EXTRA > /dev/null 2>> $O/pmc_$T.err; done )
+      AESGCM_LIB=$LIB AESGCM_LIB_DEBUG=$LIB timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d /tmp/ab_$T/sq -- python3 $REPO/bench.py --config cfg5 --batch-lanes $((1 << LG)) --steps 4 --warmup 1 --no-cpu-baseline $EXTRA > /dev/null 2> $O/pmc_$T.err; \
+      AESGCM_LIB=$LIB AESGCM_LIB_DEBUG=$LIB timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d /tmp/ab_$T/grbm -- python3 $REPO/bench.py --config cfg5 --batch-lanes $((1 << LG)) --steps 4 --warmup 1 --no-cpu-baseline $EXTRA > /dev/null 2>> $O/pmc_$T.err; \
+      for C in FETCH_SIZE WRITE_SIZE; do AESGCM_LIB=$LIB AESGCM_LIB_DEBUG=$LIB timeout 300 rocprofv3 --pmc $C --output-format csv -d /tmp/ab_$T/$C -- python3 $REPO/bench.py --config cfg5 --batch-lanes $((1 << LG)) --steps 4 --warmup 1 --no-cpu-baseline $EXTRA > /dev/null 2>> $O/pmc_$T.err; done )
     python3 - $O $T /tmp/ab_$T <<'PY'
 import csv, glob, json, sys
 from collections import defaultdict
