@@ -357,7 +357,7 @@ HD CtrConsts ctr_round1_consts(u32 iv0, u32 iv1, u32 iv2, const u32 *__restrict_
     k.c3 = xor3(T2_AT(lds, s1, 2, lb), rotl32(T0_AT(lds, s0, 1, lb) ^ T2_AT(lds, s2, 3, lb), 8), rk[7]);  // + T0[s3.b0]
     return k;
 }
-template <int NR>
+template <int NR, bool T4 = false>                                  // T4: rounds 2 .. NR-1 through four T-tables (aes_round_lds4: the kernel staged T1 | T3 as well)
 HD void ctr_rounds_lds(u32 ctr_be_word, const CtrConsts &k, u32 &s0, u32 &s1, u32 &s2, u32 &s3,
                        const u32 *__restrict__ rk, const unsigned char *lds, u32 lb) {
     const u32 w3 = ctr_be_word ^ rk[3];
@@ -366,7 +366,10 @@ HD void ctr_rounds_lds(u32 ctr_be_word, const CtrConsts &k, u32 &s0, u32 &s1, u3
     s2 = k.c2 ^ rotl32(T0_AT(lds, w3, 1, lb), 8);
     s3 = k.c3 ^ T0_AT(lds, w3, 0, lb);
 #pragma unroll
-    for (int r = 2; r < NR; r++) aes_round_lds(s0, s1, s2, s3, rk + 4 * r, lds, lb);
+    for (int r = 2; r < NR; r++) {
+        if (T4) aes_round_lds4(s0, s1, s2, s3, rk + 4 * r, lds, lb, lb | 0x10000u);
+        else aes_round_lds(s0, s1, s2, s3, rk + 4 * r, lds, lb);
+    }
     aes_final_lds(s0, s1, s2, s3, rk + 4 * NR, lds, lb);
 }
 
@@ -1831,6 +1834,9 @@ HD uint4 pktg_tree_offer(uint4 acc, const unsigned char *smem, int j) { return g
 #ifndef AESGCM_PKTL_GROUP
 #define AESGCM_PKTL_GROUP 4
 #endif
+#ifndef AESGCM_PKTL_T4
+#define AESGCM_PKTL_T4 1                 /* k_pktl: four T-tables in LDS (141 KiB; it is one workgroup per CU by its registers anyway), no rotates in rounds 2 .. NR-1 (round 4) */
+#endif
 #ifndef AESGCM_PKTL_LINE
 #define AESGCM_PKTL_LINE 1               /* k_pktl: a lane fetches its packet's whole 128-byte line at once (round 4) */
 #endif
@@ -1838,7 +1844,7 @@ HD uint4 pktg_tree_offer(uint4 acc, const unsigned char *smem, int j) { return g
 // most lanes idle.  The lane runs the whole frame serially, as the reference core does (tb/gcm_test.py:76-85):
 // AAD blocks, data blocks (CTR from 2, aes_icb.vhd:97-118), the length block, Y = (Y ^ X) * H with the LDS
 // nibble tables of H (main_fill_lds(GH_TAB_H)), tag = Y ^ E_K(IV || 1).  Nothing here is wave-uniform except the key.
-template <int NR, int DEC>
+template <int NR, int DEC, bool T4 = false>
 HD void pktl_lane(const KeyMaterial *__restrict__ km, const PktParams &p, const unsigned char *smem, u32 pkt, u32 lane) {
     const u32 *__restrict__ rk = km->rk;
     const u32 lb = (lane & 31u) << 2;
@@ -1879,24 +1885,22 @@ HD void pktl_lane(const KeyMaterial *__restrict__ km, const PktParams &p, const 
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             u32 s0, s1, s2, s3;
-            ctr_rounds_lds<NR>(bswap32(ctr + k), cc, s0, s1, s2, s3, rk, smem, lb);
+            ctr_rounds_lds<NR, T4>(bswap32(ctr + k), cc, s0, s1, s2, s3, rk, smem, lb);
             xa[k] = make_uint4(xa[k].x ^ s0, xa[k].y ^ s1, xa[k].z ^ s2, xa[k].w ^ s3);
+            gstore16(dst + 16 * k, xa[k]);                      // at once: the block's registers are free for the next one (held to the end of the half, AES-256 spilled)
             acc = ghash_mul_const_lds(xor4(acc, xa[k]), smem);
         }
-#pragma unroll
-        for (int k = 0; k < 4; k++) gstore16(dst + 16 * k, xa[k]);
 #if defined(__HIP_DEVICE_COMPILE__)
         __builtin_amdgcn_sched_barrier(0);
 #endif
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             u32 s0, s1, s2, s3;
-            ctr_rounds_lds<NR>(bswap32(ctr + 4 + k), cc, s0, s1, s2, s3, rk, smem, lb);
+            ctr_rounds_lds<NR, T4>(bswap32(ctr + 4 + k), cc, s0, s1, s2, s3, rk, smem, lb);
             xb[k] = make_uint4(xb[k].x ^ s0, xb[k].y ^ s1, xb[k].z ^ s2, xb[k].w ^ s3);
+            gstore16(dst + 64 + 16 * k, xb[k]);
             acc = ghash_mul_const_lds(xor4(acc, xb[k]), smem);
         }
-#pragma unroll
-        for (int k = 0; k < 4; k++) gstore16(dst + 64 + 16 * k, xb[k]);
 #if defined(__HIP_DEVICE_COMPILE__)
         __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -1910,7 +1914,7 @@ HD void pktl_lane(const KeyMaterial *__restrict__ km, const PktParams &p, const 
 #pragma unroll
         for (int k = 0; k < AESGCM_PKTL_GROUP; k++) {
             u32 s0, s1, s2, s3;
-            ctr_rounds_lds<NR>(bswap32(ctr + k), cc, s0, s1, s2, s3, rk, smem, lb);
+            ctr_rounds_lds<NR, T4>(bswap32(ctr + k), cc, s0, s1, s2, s3, rk, smem, lb);
             const uint4 y = make_uint4(x[k].x ^ s0, x[k].y ^ s1, x[k].z ^ s2, x[k].w ^ s3);
             acc = ghash_mul_const_lds(xor4(acc, DEC ? x[k] : y), smem);
             x[k] = y;
@@ -1924,7 +1928,7 @@ HD void pktl_lane(const KeyMaterial *__restrict__ km, const PktParams &p, const 
         const bool full = aligned && nb == 16;
         const uint4 x = full ? *reinterpret_cast<const uint4 *>(src) : load_block_bytes(src, nb);
         u32 s0, s1, s2, s3;
-        ctr_rounds_lds<NR>(bswap32(ctr), cc, s0, s1, s2, s3, rk, smem, lb);
+        ctr_rounds_lds<NR, T4>(bswap32(ctr), cc, s0, s1, s2, s3, rk, smem, lb);
         uint4 y = make_uint4(x.x ^ s0, x.y ^ s1, x.z ^ s2, x.w ^ s3);
         if (full) *reinterpret_cast<uint4 *>(dst) = y;
         else { y = mask_block(y, nb); store_block_bytes(dst, y, nb); }
@@ -1934,7 +1938,7 @@ HD void pktl_lane(const KeyMaterial *__restrict__ km, const PktParams &p, const 
     // [8*len(A)]_64 || [8*len(C)]_64 (gcm_ghash.vhd:257) in memory order
     acc = ghash_mul_const_lds(xor4(acc, make_uint4(0u, bswap32(aad_len * 8u), 0u, bswap32(pkt_len * 8u))), smem);
     u32 s0, s1, s2, s3;
-    ctr_rounds_lds<NR>(bswap32(1u), cc, s0, s1, s2, s3, rk, smem, lb);
+    ctr_rounds_lds<NR, T4>(bswap32(1u), cc, s0, s1, s2, s3, rk, smem, lb);
     const uint4 tag = make_uint4(acc.x ^ s0, acc.y ^ s1, acc.z ^ s2, acc.w ^ s3);       // gcm_ghash.vhd:293
     if ((((uintptr_t)p.tags) & 15) == 0) *reinterpret_cast<uint4 *>(p.tags + (size_t)pkt * 16) = tag;
     else store_block_bytes(p.tags + (size_t)pkt * 16, tag, 16);

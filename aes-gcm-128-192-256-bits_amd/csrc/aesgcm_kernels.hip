@@ -1250,6 +1250,7 @@ __global__ __launch_bounds__(PKTG_WG(LG), (PKTG_WG(LG) + 255) / 256) void k_pktg
 #ifndef AESGCM_PKTL_WG
 #define AESGCM_PKTL_WG AESGCM_PKT_WG  // lanes per k_pktl workgroup
 #endif
+#define AESGCM_PKTL_LDS (AESGCM_PKTL_T4 ? AESGCM_LDS_BYTES_T4 : AESGCM_LDS_BYTES)
 #ifndef AESGCM_PKTL_WAVES
 #define AESGCM_PKTL_WAVES ((AESGCM_PKTL_WG + 255) / 256)          // waves per SIMD the register budget is sized for (one workgroup per CU)
 #endif
@@ -1258,6 +1259,9 @@ __global__ __launch_bounds__(AESGCM_PKTL_WG, AESGCM_PKTL_WAVES) void k_pktl(cons
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 tid = threadIdx.x, lane = tid & 63u;
     main_fill_lds(smem, km, tb, tid, true, AESGCM_PKTL_WG, GH_TAB_H);
+#if AESGCM_PKTL_T4
+    fill_lds_t4(smem, tb, tid, AESGCM_PKTL_WG);
+#endif
     __syncthreads();
     const u32 nb = (p.n_pkts + 63u) / 64u;
     for (u32 guard = 0; guard <= nb; ++guard) {                // bounded, as every dispenser loop here
@@ -1266,7 +1270,7 @@ __global__ __launch_bounds__(AESGCM_PKTL_WG, AESGCM_PKTL_WAVES) void k_pktl(cons
         b = __builtin_amdgcn_readfirstlane(b);
         if (b >= nb) break;
         const u32 pkt = b * 64u + lane;
-        if (pkt < p.n_pkts) pktl_lane<NR, DEC>(km, p, smem, pkt, lane);
+        if (pkt < p.n_pkts) pktl_lane<NR, DEC, AESGCM_PKTL_T4 != 0>(km, p, smem, pkt, lane);
     }
 }
 
@@ -1430,7 +1434,7 @@ static int set_lds_attrs(int device, DeviceState *ds) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktg<NR, D, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, PKTG_LDS_TOTAL(3))); \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktg<NR, D, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, PKTG_LDS_TOTAL(4))); \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktg<NR, D, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, PKTG_LDS_TOTAL(6))); \
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktl<NR, D>), hipFuncAttributeMaxDynamicSharedMemorySize, AESGCM_LDS_BYTES))
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktl<NR, D>), hipFuncAttributeMaxDynamicSharedMemorySize, AESGCM_PKTL_LDS))
     SETATTRB(10, 0); SETATTRB(12, 0); SETATTRB(14, 0); SETATTRB(10, 1); SETATTRB(12, 1); SETATTRB(14, 1);
 #undef SETATTRB
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_combine), hipFuncAttributeMaxDynamicSharedMemorySize, CMB_LDS_BYTES));
@@ -2449,9 +2453,9 @@ int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const vo
         const u32 nb = (u32)((n_pkts + 63) / 64);
         const u32 waves_per_wg = AESGCM_PKTL_WG / 64;
         u32 wgs = (nb + waves_per_wg - 1) / waves_per_wg;
-        if (wgs > (u32)c->G) wgs = (u32)c->G;
+        if (wgs > n_cu) wgs = n_cu;                                                  // one workgroup per CU (registers, and with four T-tables the LDS)
         c->counter_base += nb + wgs * waves_per_wg;                                 // every wave ends on one failing fetch
-#define LP(NR, D) hipLaunchKernelGGL((k_pktl<NR, D>), dim3(wgs), dim3(AESGCM_PKTL_WG), AESGCM_LDS_BYTES, st, c->km, c->tables, p)
+#define LP(NR, D) hipLaunchKernelGGL((k_pktl<NR, D>), dim3(wgs), dim3(AESGCM_PKTL_WG), AESGCM_PKTL_LDS, st, c->km, c->tables, p)
         if (decrypt) { if (c->nr == 10) LP(10, 1); else if (c->nr == 12) LP(12, 1); else LP(14, 1); }
         else         { if (c->nr == 10) LP(10, 0); else if (c->nr == 12) LP(12, 0); else LP(14, 0); }
 #undef LP

@@ -43,6 +43,12 @@ def _inner_scratch(k):
 
 def test_scratch_free_kernels(census):
     for name, k in census.items():
+        if name == "k_pktl<14, 0>":
+            # AES-256 encrypt with the whole-line fetch AND four T-tables sits at exactly 128 registers and spills six dwords: four stores and four loads in
+            # the whole kernel, two of them per 128 bytes in the line loop (+1.7 % HBM traffic).  Either feature alone is clean and slower on the same box
+            # (profiles/r04/pktl_t4_ab.txt: 2^20 x 1 KiB 634 - 656 GiB/s with two tables, 656 without the line fetch, 689 - 707 with both): kept, bounded here.
+            assert k["scratch"] <= 24 and sum(ops.get("scratch", 0) for ops in k["depth"].values()) <= 8, (name, k)
+            continue
         if name.startswith(("k_body<", "k_pktl<", "k_pktg<", "k_batch3<")) or name.startswith("k_main<") and name.endswith((", 2>", ", 3>")):
             assert k["scratch"] == 0, (name, k["scratch"])
 
@@ -52,7 +58,7 @@ def test_no_scratch_in_the_hot_loops(census):
     for name, k in census.items():
         if name.startswith(("k_main<", "k_body<", "k_pktg<", "k_pktl<", "k_batch<", "k_batch3<")):
             n, depth = _inner_scratch(k)
-            assert n == 0, "%s: %d scratch ops at loop depth %d" % (name, n, depth)
+            assert n <= (2 if name == "k_pktl<14, 0>" else 0), "%s: %d scratch ops at loop depth %d" % (name, n, depth)
             seen += 1
     assert seen == 12 + 15 + 24 + 6 + 6 + 12            # k_main (3 key sizes x 4 modes), k_body (x ENC, DEC dealt and cyclic + the dealt probe), k_pktg (x 2 x 4 shapes), k_pktl, k_batch, k_batch3 (x 2 shapes)
 
