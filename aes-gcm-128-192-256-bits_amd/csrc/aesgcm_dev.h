@@ -1869,14 +1869,16 @@ HD void pktl_lane(const KeyMaterial *__restrict__ km, const PktParams &p, const 
     // line is touched twice and not eight times (lanes of a wave are a packet apart: nothing coalesces across lanes).
     // Measured, 2^20 x 1 KiB, AES-256: 436 GiB/s block by block, 537 GiB/s in groups of 4 (8: the same).
 #if AESGCM_PKTL_LINE
-    // Round 4, encrypt: the lane's whole 128-byte line at once.  With 64 bytes per step a line was touched twice, a few microseconds apart, and 1024 lanes per
-    // CU each with their own line overrun the 32 KiB L1 -- and, at 32 CUs per XCD, the 4 MiB L2 -- in between: 1.41 x the algorithmic traffic (reads 1.8 x,
-    // profiles/r03e/pktl_1k).  All eight loads are issued back to back; the second half waits in 16 registers while the first is worked on (the scheduling
-    // barrier keeps the compiler from interleaving all eight blocks, which spilled).  Measured, 2^20 x 1 KiB AES-256, same box (profiles/r04/pktl_line_ab_*.txt):
-    // HBM bytes 1.404 x -> 1.101 x algorithmic (reads 1.80e9 -> 1.09e9 = exactly the plaintext), 638 -> 657 GiB/s -- the kernel was never bound by that traffic.
-    // Decrypt keeps the 64-byte steps: its GHASH runs on the loaded ciphertext, the table multiply's 52 loads in flight beside eight held blocks do not fit 128
-    // registers (15 scratch ops in the loop however the two were ordered), and 768-lane workgroups, where it fits, run 4 % slower.
-    while (!DEC && aligned && left >= 128) {
+    // Round 4: the lane's whole 128-byte line at once, loads and stores.  With 64 bytes per step a line was touched twice, a tenth of a millisecond apart (a
+    // lane needs ~0.2 ms for 128 bytes: 768 lanes share the CU's LDS), and the lines of all lanes in flight -- 32 CUs x 768 x (128 in + 128 out) = 6 MiB per
+    // XCD -- turn the 4 MiB L2 over many times in between: the input was fetched 1.8 x (profiles/r03e/pktl_1k), and output stored in two 64-byte groups left
+    // the L2 as 1.22 x the ciphertext (block by block: 3.2 x; profiles/r04/pktl_store_ab.txt).  All eight loads are issued back to back, all eight stores
+    // too; the blocks wait in 32 registers in between, which is why the workgroup is 768 lanes (3 waves per SIMD, 168 registers: at 1024 lanes AES-256
+    // spilled, and decrypt -- whose GHASH runs on the loaded block while the plaintext waits -- did not fit at all).  The scheduling barrier keeps the
+    // compiler from interleaving all eight blocks.  Measured, 2^20 packets under one key, same box (profiles/r04/pktl_768_ab.txt): HBM bytes = 1.000 - 1.005 x
+    // algorithmic, encrypt and decrypt, 256 B ... 4 KiB (round 3: 1.41 x; decrypt until this change: 1.57 x); AES-256 encrypt 1 KiB 665 -> 679 GiB/s, 4 KiB 796
+    // -> 823; decrypt 1 KiB 645 -> 662, 4 KiB 781 -> 750 (its register budget is full: 168).
+    while (aligned && left >= 128) {
         uint4 xa[4], xb[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) xa[k] = gload16(src + 16 * k);
@@ -1886,9 +1888,9 @@ HD void pktl_lane(const KeyMaterial *__restrict__ km, const PktParams &p, const 
         for (int k = 0; k < 4; k++) {
             u32 s0, s1, s2, s3;
             ctr_rounds_lds<NR, T4>(bswap32(ctr + k), cc, s0, s1, s2, s3, rk, smem, lb);
+            if (DEC) acc = ghash_mul_const_lds(xor4(acc, xa[k]), smem);
             xa[k] = make_uint4(xa[k].x ^ s0, xa[k].y ^ s1, xa[k].z ^ s2, xa[k].w ^ s3);
-            gstore16(dst + 16 * k, xa[k]);                      // at once: the block's registers are free for the next one (held to the end of the half, AES-256 spilled)
-            acc = ghash_mul_const_lds(xor4(acc, xa[k]), smem);
+            if (!DEC) acc = ghash_mul_const_lds(xor4(acc, xa[k]), smem);
         }
 #if defined(__HIP_DEVICE_COMPILE__)
         __builtin_amdgcn_sched_barrier(0);
@@ -1897,10 +1899,17 @@ HD void pktl_lane(const KeyMaterial *__restrict__ km, const PktParams &p, const 
         for (int k = 0; k < 4; k++) {
             u32 s0, s1, s2, s3;
             ctr_rounds_lds<NR, T4>(bswap32(ctr + 4 + k), cc, s0, s1, s2, s3, rk, smem, lb);
+            if (DEC) acc = ghash_mul_const_lds(xor4(acc, xb[k]), smem);
             xb[k] = make_uint4(xb[k].x ^ s0, xb[k].y ^ s1, xb[k].z ^ s2, xb[k].w ^ s3);
-            gstore16(dst + 64 + 16 * k, xb[k]);
-            acc = ghash_mul_const_lds(xor4(acc, xb[k]), smem);
+            if (!DEC) acc = ghash_mul_const_lds(xor4(acc, xb[k]), smem);
         }
+        // all eight stores back to back: the 128 bytes meet in the L2 and leave it as one full line (WRITE_SIZE = the ciphertext, 1.00 x).  In two groups of
+        // four, a tenth of a millisecond apart, 1.22 x; block by block 3.2 x -- the L2 turns over many times while a lane works through its line
+        // (profiles/r04/pktl_store_ab.txt).
+#pragma unroll
+        for (int k = 0; k < 4; k++) gstore16(dst + 16 * k, xa[k]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) gstore16(dst + 64 + 16 * k, xb[k]);
 #if defined(__HIP_DEVICE_COMPILE__)
         __builtin_amdgcn_sched_barrier(0);
 #endif

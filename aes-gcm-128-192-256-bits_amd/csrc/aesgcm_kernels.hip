@@ -1248,7 +1248,7 @@ __global__ __launch_bounds__(PKTG_WG(LG), (PKTG_WG(LG) + 255) / 256) void k_pktg
 // blocks of 64 consecutive packets from the dispenser.
 // ------------------------------------------------------------------------------------------------
 #ifndef AESGCM_PKTL_WG
-#define AESGCM_PKTL_WG AESGCM_PKT_WG  // lanes per k_pktl workgroup
+#define AESGCM_PKTL_WG 768            // lanes per k_pktl workgroup: 3 waves per SIMD = 168 registers, what eight held blocks beside the table multiply need
 #endif
 #define AESGCM_PKTL_LDS (AESGCM_PKTL_T4 ? AESGCM_LDS_BYTES_T4 : AESGCM_LDS_BYTES)
 #ifndef AESGCM_PKTL_WAVES

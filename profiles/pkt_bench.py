@@ -22,6 +22,7 @@ ap.add_argument("--n", type=int, default=1 << 20)
 ap.add_argument("--len", type=int, default=4096)
 ap.add_argument("--key-bits", type=int, default=128)
 ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--dec", action="store_true", help="decrypt + tag (the launch of the decrypt instance over the same bytes; tags are computed, not compared)")
 ap.add_argument("--inplace", action="store_true", help="write the output over the input (traffic probe: no separate output lines)")
 a = ap.parse_args()
 n, pkt, kb = a.n, a.len, a.key_bits // 8
@@ -36,7 +37,7 @@ if a.kind == "batch":
     d_keys.fill_splitmix64(0x4B4559)
 
     def go():
-        lib.batch_crypt_dev(False, n, kb, d_keys.ptr, d_ivs.ptr, d_pt.ptr, pkt, d_ct.ptr, d_tags.ptr)
+        lib.batch_crypt_dev(a.dec, n, kb, d_keys.ptr, d_ivs.ptr, d_pt.ptr, pkt, d_ct.ptr, d_tags.ptr)
 else:
     # a forced shape is a function of the debug build only (libaesgcm_hip_dbg.so, include/aesgcm_debug.h); "pkt" = the library's own choice, product build
     _dbg = None
@@ -47,7 +48,7 @@ else:
     ctx = lib.Context(bytes(range(kb)))
 
     def go():
-        ctx.packets_crypt_dev(False, n, d_ivs.ptr, d_pt.ptr, d_ct.ptr, d_tags.ptr, pkt_len=pkt)
+        ctx.packets_crypt_dev(a.dec, n, d_ivs.ptr, d_pt.ptr, d_ct.ptr, d_tags.ptr, pkt_len=pkt)
 go(); lib.dev_sync()
 ts = []
 for _ in range(a.steps):

@@ -43,12 +43,6 @@ def _inner_scratch(k):
 
 def test_scratch_free_kernels(census):
     for name, k in census.items():
-        if name == "k_pktl<14, 0>":
-            # AES-256 encrypt with the whole-line fetch AND four T-tables sits at exactly 128 registers and spills six dwords: four stores and four loads in
-            # the whole kernel, two of them per 128 bytes in the line loop (+1.7 % HBM traffic).  Either feature alone is clean and slower on the same box
-            # (profiles/r04/pktl_t4_ab.txt: 2^20 x 1 KiB 634 - 656 GiB/s with two tables, 656 without the line fetch, 689 - 707 with both): kept, bounded here.
-            assert k["scratch"] <= 24 and sum(ops.get("scratch", 0) for ops in k["depth"].values()) <= 8, (name, k)
-            continue
         if name.startswith(("k_body<", "k_pktl<", "k_pktg<", "k_batch3<")) or name.startswith("k_main<") and name.endswith((", 2>", ", 3>")):
             assert k["scratch"] == 0, (name, k["scratch"])
 
@@ -58,7 +52,7 @@ def test_no_scratch_in_the_hot_loops(census):
     for name, k in census.items():
         if name.startswith(("k_main<", "k_body<", "k_pktg<", "k_pktl<", "k_batch<", "k_batch3<")):
             n, depth = _inner_scratch(k)
-            assert n <= (2 if name == "k_pktl<14, 0>" else 0), "%s: %d scratch ops at loop depth %d" % (name, n, depth)
+            assert n == 0, "%s: %d scratch ops at loop depth %d" % (name, n, depth)
             seen += 1
     assert seen == 12 + 15 + 24 + 6 + 6 + 12            # k_main (3 key sizes x 4 modes), k_body (x ENC, DEC dealt and cyclic + the dealt probe), k_pktg (x 2 x 4 shapes), k_pktl, k_batch, k_batch3 (x 2 shapes)
 
@@ -67,10 +61,10 @@ def test_register_budgets(census):
     for name, k in census.items():
         if name.startswith("k_main<"):
             assert k["vgpr"] <= 80, (name, k["vgpr"])          # 768 lanes x 2 workgroups per CU = 6 waves per SIMD
-        wide_pktg = name.startswith("k_pktg<") and name.endswith(", 6>")                 # 768-lane workgroups: 3 waves per SIMD, 168 registers
-        if wide_pktg:
+        wide = name.startswith("k_pktg<") and name.endswith(", 6>") or name.startswith("k_pktl<")      # 768-lane workgroups: 3 waves per SIMD, 168 registers
+        if wide:
             assert k["vgpr"] <= 168 and k["scratch"] == 0, (name, k["vgpr"], k["scratch"])
-        elif name.startswith(("k_body<", "k_bodyh<", "k_pktg<", "k_pktl<", "k_batch<", "k_batch3<")):
+        elif name.startswith(("k_body<", "k_bodyh<", "k_pktg<", "k_batch<", "k_batch3<")):
             assert k["vgpr"] <= 128, (name, k["vgpr"])         # one 1024-lane workgroup per CU = 4 waves per SIMD
             if name.startswith(("k_pktg<", "k_batch3<")):
                 assert k["scratch"] == 0, (name, k["scratch"])  # nothing spilled (ds_swizzle exchanges, per-packet values parked in LDS, fresh lane id)
