@@ -1600,18 +1600,23 @@ HD G128 shoup2_mul(G128 y, const unsigned char *lds, u32 tab) {
 // are taken in the order k = 3..0, w = 0..3 into a 256-coefficient accumulator V that is shifted by a byte only between the four
 // k groups (3 x 8 v_alignbit) and folded to 128 coefficients once (gf_reduce256, the tail of gf_sqr).  Same 32 ds_read_b128,
 // ~180 VALU instead of ~320.  Degrees: E < 128, the largest shift is 120 -> V < 248 coefficients.
+// Addresses: the entry offsets of all four bytes of a word at once -- hn = w & 0xF0F0F0F0 (high nibbles x 16), ln = (w << 4) & 0xF0F0F0F0 (low nibbles x 16) --
+// and then ONE v_perm_b32 per table read: byte k of hn / ln under bytes 1, 2 of the slot address (tab is a multiple of 256 below 2^24), the selector
+// SHOUP2_SEL(k) in a scalar register of the rolled loop; Tl rides in the ds_read offset field.  11 instructions per word instead of the 20 of shift / mask /
+// or per byte; and every accumulator word takes its (up to four) entries in whole xor3s.  Round 4, second pass over k_batch3's issue count: 240 -> 180 VALU
+// per multiply.
+#define SHOUP2_SEL(k) (0x0c020104u + (u32)(k))
 HD G128 shoup2_mul_dr(G128 y, const unsigned char *lds, u32 tab) {      // tab: a multiple of 256
     u32 V[8];
-    u32 y0 = y.w[0], y1 = y.w[1], y2 = y.w[2], y3 = y.w[3];
-    // tab is 256-byte aligned: the entry offset is ORed in (one v_and_or_b32 per address), Tl rides in the ds_read offset field
-#define SHOUP2_DR_LOADS \
-        const u32x4_t a0 = LDS_LD128(lds, (y0 & 0xF0u) | tab), c0 = LDS_LD128(lds, (((y0 << 4) & 0xF0u) | tab) + 256u); \
-        const u32x4_t a1 = LDS_LD128(lds, (y1 & 0xF0u) | tab), c1 = LDS_LD128(lds, (((y1 << 4) & 0xF0u) | tab) + 256u); \
-        const u32x4_t a2 = LDS_LD128(lds, (y2 & 0xF0u) | tab), c2 = LDS_LD128(lds, (((y2 << 4) & 0xF0u) | tab) + 256u); \
-        const u32x4_t a3 = LDS_LD128(lds, (y3 & 0xF0u) | tab), c3 = LDS_LD128(lds, (((y3 << 4) & 0xF0u) | tab) + 256u); \
-        y0 >>= 8; y1 >>= 8; y2 >>= 8; y3 >>= 8;
+    const u32 h0 = y.w[0] & 0xF0F0F0F0u, h1 = y.w[1] & 0xF0F0F0F0u, h2 = y.w[2] & 0xF0F0F0F0u, h3 = y.w[3] & 0xF0F0F0F0u;
+    const u32 l0 = (y.w[0] << 4) & 0xF0F0F0F0u, l1 = (y.w[1] << 4) & 0xF0F0F0F0u, l2 = (y.w[2] << 4) & 0xF0F0F0F0u, l3 = (y.w[3] << 4) & 0xF0F0F0F0u;
+#define SHOUP2_DR_LOADS(sel) \
+        const u32x4_t a0 = LDS_LD128(lds, perm_b32(h0, tab, sel)), c0 = LDS_LD128(lds, perm_b32(l0, tab, sel) + 256u); \
+        const u32x4_t a1 = LDS_LD128(lds, perm_b32(h1, tab, sel)), c1 = LDS_LD128(lds, perm_b32(l1, tab, sel) + 256u); \
+        const u32x4_t a2 = LDS_LD128(lds, perm_b32(h2, tab, sel)), c2 = LDS_LD128(lds, perm_b32(l2, tab, sel) + 256u); \
+        const u32x4_t a3 = LDS_LD128(lds, perm_b32(h3, tab, sel)), c3 = LDS_LD128(lds, perm_b32(l3, tab, sel) + 256u);
     {   // k = 3, the lowest byte of every word: nothing to shift yet
-        SHOUP2_DR_LOADS
+        SHOUP2_DR_LOADS(SHOUP2_SEL(0))
         V[7] = 0;
         V[6] = a3.w ^ c3.w;
         V[5] = xor3(a3.z, c3.z, a2.w) ^ c2.w;
@@ -1624,15 +1629,15 @@ HD G128 shoup2_mul_dr(G128 y, const unsigned char *lds, u32 tab) {      // tab: 
     // a real loop over the other three k groups (eight table loads in flight, not 32: fully unrolled, the kernels that use it spilled)
 #pragma unroll 1
     for (int t = 1; t < 4; t++) {
-        SHOUP2_DR_LOADS
+        SHOUP2_DR_LOADS(SHOUP2_SEL(t))
         // V >>= 8, then the group's eight entries at word offsets 0 .. 3
         V[7] = (V[7] >> 8) | (V[6] << 24);
         V[6] = xor3((V[6] >> 8) | (V[5] << 24), a3.w, c3.w);
-        V[5] = xor3((V[5] >> 8) | (V[4] << 24), a3.z, c3.z) ^ a2.w ^ c2.w;
-        V[4] = xor3(xor3((V[4] >> 8) | (V[3] << 24), a3.y, c3.y), a2.z, c2.z) ^ a1.w ^ c1.w;
-        V[3] = xor3(xor3(xor3((V[3] >> 8) | (V[2] << 24), a3.x, c3.x), a2.y, c2.y), a1.z, c1.z) ^ a0.w ^ c0.w;
-        V[2] = xor3(xor3((V[2] >> 8) | (V[1] << 24), a2.x, c2.x), a1.y, c1.y) ^ a0.z ^ c0.z;
-        V[1] = xor3((V[1] >> 8) | (V[0] << 24), a1.x, c1.x) ^ a0.y ^ c0.y;
+        V[5] = xor3(xor3((V[5] >> 8) | (V[4] << 24), a3.z, c3.z), a2.w, c2.w);
+        V[4] = xor3(xor3(xor3((V[4] >> 8) | (V[3] << 24), a3.y, c3.y), a2.z, c2.z), a1.w, c1.w);
+        V[3] = xor3(xor3(xor3(xor3((V[3] >> 8) | (V[2] << 24), a3.x, c3.x), a2.y, c2.y), a1.z, c1.z), a0.w, c0.w);
+        V[2] = xor3(xor3(xor3((V[2] >> 8) | (V[1] << 24), a2.x, c2.x), a1.y, c1.y), a0.z, c0.z);
+        V[1] = xor3(xor3((V[1] >> 8) | (V[0] << 24), a1.x, c1.x), a0.y, c0.y);
         V[0] = xor3(V[0] >> 8, a0.x, c0.x);
     }
 #undef SHOUP2_DR_LOADS
@@ -1644,12 +1649,12 @@ HD G128 shoup2_mul_dr(G128 y, const unsigned char *lds, u32 tab) {      // tab: 
 // the helper lane passes words 2, 3 and its partial then stands two WORDS further down (shoup2_pair_join).  16 table reads, unreduced
 // 6-word partial.  tab: a multiple of 256.
 HD void shoup2_half_dr(u32 s0, u32 s1, const unsigned char *lds, u32 tab, u32 *V) {
-#define SHOUP2_HALF_LOADS \
-        const u32x4_t a0 = LDS_LD128(lds, (s0 & 0xF0u) | tab), c0 = LDS_LD128(lds, (((s0 << 4) & 0xF0u) | tab) + 256u); \
-        const u32x4_t a1 = LDS_LD128(lds, (s1 & 0xF0u) | tab), c1 = LDS_LD128(lds, (((s1 << 4) & 0xF0u) | tab) + 256u); \
-        s0 >>= 8; s1 >>= 8;
+    const u32 h0 = s0 & 0xF0F0F0F0u, h1 = s1 & 0xF0F0F0F0u, l0 = (s0 << 4) & 0xF0F0F0F0u, l1 = (s1 << 4) & 0xF0F0F0F0u;
+#define SHOUP2_HALF_LOADS(sel) \
+        const u32x4_t a0 = LDS_LD128(lds, perm_b32(h0, tab, sel)), c0 = LDS_LD128(lds, perm_b32(l0, tab, sel) + 256u); \
+        const u32x4_t a1 = LDS_LD128(lds, perm_b32(h1, tab, sel)), c1 = LDS_LD128(lds, perm_b32(l1, tab, sel) + 256u);
     {
-        SHOUP2_HALF_LOADS
+        SHOUP2_HALF_LOADS(SHOUP2_SEL(0))
         V[5] = 0;
         V[4] = a1.w ^ c1.w;
         V[3] = xor3(a1.z, c1.z, a0.w) ^ c0.w;
@@ -1659,12 +1664,12 @@ HD void shoup2_half_dr(u32 s0, u32 s1, const unsigned char *lds, u32 tab, u32 *V
     }
 #pragma unroll 1
     for (int t = 1; t < 4; t++) {
-        SHOUP2_HALF_LOADS
+        SHOUP2_HALF_LOADS(SHOUP2_SEL(t))
         V[5] = (V[5] >> 8) | (V[4] << 24);
         V[4] = xor3((V[4] >> 8) | (V[3] << 24), a1.w, c1.w);
-        V[3] = xor3((V[3] >> 8) | (V[2] << 24), a1.z, c1.z) ^ a0.w ^ c0.w;
-        V[2] = xor3((V[2] >> 8) | (V[1] << 24), a1.y, c1.y) ^ a0.z ^ c0.z;
-        V[1] = xor3((V[1] >> 8) | (V[0] << 24), a1.x, c1.x) ^ a0.y ^ c0.y;
+        V[3] = xor3(xor3((V[3] >> 8) | (V[2] << 24), a1.z, c1.z), a0.w, c0.w);
+        V[2] = xor3(xor3((V[2] >> 8) | (V[1] << 24), a1.y, c1.y), a0.z, c0.z);
+        V[1] = xor3(xor3((V[1] >> 8) | (V[0] << 24), a1.x, c1.x), a0.y, c0.y);
         V[0] = xor3(V[0] >> 8, a0.x, c0.x);
     }
 #undef SHOUP2_HALF_LOADS
