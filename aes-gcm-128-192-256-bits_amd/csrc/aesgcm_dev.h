@@ -1501,7 +1501,9 @@ struct BatchParams {
     // variable-length form (all NULL = fixed pkt_len / aad_len, packets back to back):
     const u64 *data_off;         // n_pkts + 1 byte offsets into in/out: packet p = [data_off[p], data_off[p+1])
     const u64 *aad_off;          // n_pkts + 1 byte offsets into aad (or NULL = no AAD)
+    const u32 *perm;             // variable-length form: the order in which the launch takes the packets (by falling length class, k_len_*), or NULL = as they come
 };
+HD u32 batch_map(const BatchParams &p, u32 i) { return p.perm ? p.perm[i] : i; }
 
 // reduction of the 4 bits shifted out by Z*x^4: r(v) for v = Z's last nibble, as the top 16 bits of word 0.
 // (bit k of v is GCM bit 124+k; after the shift it is x^(128+k'), reduced with R = 0xE1 || 0^120.)
@@ -1743,7 +1745,16 @@ struct PktParams {
     u32 deal;                    // packets per dispenser fetch (k_pktg: a multiple of the packets per wave, at most 64)
     u32 n_pkts, pkt_len, aad_len;
     u32 aligned;                 // in/out base pointers 16-byte aligned
+    const u32 *perm;             // the order in which the launch takes the packets (k_len_*: by falling length), or NULL = as they come
 };
+HD u32 pkt_map(const PktParams &p, u32 i) { return p.perm ? p.perm[i] : i; }
+// Packets of mixed length (offset arrays).  The lanes (k_pktl) or lane groups (k_pktg, k_batch3) of a wave run to the longest packet among them: with frames
+// of 64 .. 1514 bytes in arrival order a wave's 64 packets average 700 bytes and the wave takes as long as 1514 -- less than half the lanes work
+// (profiles/r04/packets_sweep_mixed_*.txt: 2^20 frames 426 GiB/s against 854 for 2^20 x 1 KiB).  The launch therefore takes the packets in the order of a
+// counting sort by length class (64 bytes per class, 256 classes, longest first so that the tail of the launch is short work): three small launches on the
+// same stream in front of it -- histogram, scan, scatter; the order inside a class is whatever the atomics make it, results do not depend on it.
+#define PKT_LEN_CLASSES 256u
+HD u32 pkt_len_class(u64 len) { const u64 c = len >> 6; return c < PKT_LEN_CLASSES ? (u32)c : PKT_LEN_CLASSES - 1u; }
 #define PKTG_LDS_TREE_OFF (AESGCM_LDS_AES_OFF + AESGCM_LDS_AES)                       /* 79104 */
 #define PKTG_LDS_BYTES(LG) (PKTG_LDS_TREE_OFF + (u32)(LG) * (u32)AESGCM_LDS_GH)
 #define PKTG_MAX_DEAL 64u

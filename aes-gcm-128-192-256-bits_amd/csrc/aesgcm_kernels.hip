@@ -1040,7 +1040,7 @@ __global__ __launch_bounds__(BATCH3_LANES(NR), (BATCH3_LANES(NR) + 255) / 256) v
         const u32 tabAp = wave_tab + (grp ^ 3u) * GRP_TAB;             // PAIR: the table slot of the packet on lanes ^ 20
         const bool pair_first = (grp & 2u) == 0;                       // lane bit 4 clear
         const bool act = pk0 + grp < pk_end;                 // groups past the end shadow the first packet; their stores are masked
-        const u32 pkt = act ? pk0 + grp : pk0;
+        const u32 pkt = batch_map(p, act ? pk0 + grp : pk0);
         const unsigned char *key = p.keys + (size_t)pkt * KEYLEN;
         const unsigned char *ivp = p.ivs + (size_t)pkt * 12;
         u32 pkt_len = p.pkt_len, aad_len = p.aad_len;
@@ -1117,7 +1117,7 @@ __global__ __launch_bounds__(BATCH3_LANES(NR), (BATCH3_LANES(NR) + 255) / 256) v
         batch3_pos<LG>(lane_id_fresh(), grp2, l2);
         const u32 tabA2 = wave_tab + grp2 * GRP_TAB, tabB2 = ONE_TAB ? tabA2 : tabA2 + 512u, hsA2 = wave_hs + grp2 * 32u;
         const bool act2 = pk0 + grp2 < pk_end;
-        const u32 pkt2 = act2 ? pk0 + grp2 : pk0;
+        const u32 pkt2 = batch_map(p, act2 ? pk0 + grp2 : pk0);
         G128 h;
         { const uint4 hv = *reinterpret_cast<const uint4 *>(smem + hsA2); h.w[0] = hv.x; h.w[1] = hv.y; h.w[2] = hv.z; h.w[3] = hv.w; }
         G128 c = gf_sqr(h);                                     // H^2
@@ -1154,6 +1154,55 @@ __global__ __launch_bounds__(BATCH3_LANES(NR), (BATCH3_LANES(NR) + 255) / 256) v
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_len_hist / k_len_scan / k_len_scatter: the order in which a launch takes packets of mixed length (aesgcm_dev.h, pkt_len_class): a counting sort of the
+// packet numbers by falling length class.  LEN_SORT_WGS workgroups own a slice of the packets each; counts[(255 - class) * LEN_SORT_WGS + workgroup] holds a
+// workgroup's count of a class, then (after the scan over that array in its own order) the position of its first packet of that class.  Atomics only in LDS:
+// a first form with one global cursor per class spent milliseconds on 2^20 atomics to two dozen addresses (call 25).
+// ------------------------------------------------------------------------------------------------
+#define LEN_SORT_WGS 256u
+#define LEN_SORT_ENTRIES (PKT_LEN_CLASSES * LEN_SORT_WGS)
+__device__ __forceinline__ void len_sort_slice(u32 n, u32 &lo, u32 &hi) {
+    const u32 per = (n + LEN_SORT_WGS - 1u) / LEN_SORT_WGS;
+    lo = blockIdx.x * per < n ? blockIdx.x * per : n;
+    hi = lo + per < n ? lo + per : n;
+}
+__global__ __launch_bounds__(256) void k_len_hist(const u64 *__restrict__ off, u32 n, u32 *__restrict__ counts) {
+    __shared__ u32 h[PKT_LEN_CLASSES];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    u32 lo, hi;
+    len_sort_slice(n, lo, hi);
+    for (u32 i = lo + threadIdx.x; i < hi; i += 256u) atomicAdd(&h[pkt_len_class(off[i + 1] - off[i])], 1u);
+    __syncthreads();
+    counts[(PKT_LEN_CLASSES - 1u - threadIdx.x) * LEN_SORT_WGS + blockIdx.x] = h[threadIdx.x];
+}
+__global__ __launch_bounds__(1024) void k_len_scan(u32 *__restrict__ counts) {         // exclusive prefix sums over the 65536 entries, in place; one workgroup
+    __shared__ u32 part[1024];
+    constexpr u32 PER = LEN_SORT_ENTRIES / 1024u;
+    u32 *mine = counts + threadIdx.x * PER;
+    u32 s = 0;
+    for (u32 k = 0; k < PER; ++k) s += mine[k];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (u32 d = 1; d < 1024u; d <<= 1) {                                              // Hillis-Steele over the 1024 partial sums
+        const u32 v = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    u32 run = part[threadIdx.x] - s;
+    for (u32 k = 0; k < PER; ++k) { const u32 c = mine[k]; mine[k] = run; run += c; }
+}
+__global__ __launch_bounds__(256) void k_len_scatter(const u64 *__restrict__ off, u32 n, const u32 *__restrict__ base, u32 *__restrict__ perm) {
+    __shared__ u32 cur[PKT_LEN_CLASSES];
+    cur[threadIdx.x] = base[(PKT_LEN_CLASSES - 1u - threadIdx.x) * LEN_SORT_WGS + blockIdx.x];
+    __syncthreads();
+    u32 lo, hi;
+    len_sort_slice(n, lo, hi);
+    for (u32 i = lo + threadIdx.x; i < hi; i += 256u) perm[atomicAdd(&cur[pkt_len_class(off[i + 1] - off[i])], 1u)] = i;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1205,12 +1254,12 @@ __global__ __launch_bounds__(PKTG_WG(LG), (PKTG_WG(LG) + 255) / 256) void k_pktg
         // (behind the tree tables): held in registers across the packet loop they were spilled at 128 registers; one packet per wave keeps them.
         constexpr bool EJ_LDS = LG <= 4;
         unsigned char *ej_slot = smem + PKTG_LDS_BYTES(LG) + wave_slot;
-        uint4 ej = pktg_ej0_lane<NR>(km, p, smem, p0 + (lane < cnt ? lane : 0u), lane);
+        uint4 ej = pktg_ej0_lane<NR>(km, p, smem, pkt_map(p, p0 + (lane < cnt ? lane : 0u)), lane);
         if (EJ_LDS) { *reinterpret_cast<uint4 *>(ej_slot + lane * 16u) = ej; ej = make_uint4(0, 0, 0, 0); }
         for (u32 t = 0; t * P < cnt; ++t) {
             const u32 lane1 = lane_id_fresh(), l = lane1 & (G - 1u), idx = t * P + (lane1 >> LG);
             const bool act = idx < cnt;                          // groups past the end shadow the block's first packet; their stores are masked
-            const u32 pkt = p0 + (act ? idx : 0u);
+            const u32 pkt = pkt_map(p, p0 + (act ? idx : 0u));
             const PktInfo q = pkt_info(p, pkt);
             // the wave runs to the longest packet of its groups
             u32 iters = pktg_iters(q, G);
@@ -1220,7 +1269,7 @@ __global__ __launch_bounds__(PKTG_WG(LG), (PKTG_WG(LG) + 255) / 256) void k_pktg
             // l / grp / idx / pkt need not stay in registers across the packet loop -- at 128 registers they were spilled there
             const u32 lane2 = lane_id_fresh(), l2 = lane2 & (G - 1u), idx2 = t * P + (lane2 >> LG);
             const bool act2 = idx2 < cnt;
-            const u32 pkt2 = p0 + (act2 ? idx2 : 0u);
+            const u32 pkt2 = pkt_map(p, p0 + (act2 ? idx2 : 0u));
             acc = pktg_close_lane<LG>(acc, q, smem, l2);
             pktg_tree<LG, 0>(acc, smem, l2);
             // lane G-1 of the group holds P H^2 ^ L H; its packet's E_K(IV || 1) sits in lane idx of `ej`
@@ -1269,8 +1318,8 @@ __global__ __launch_bounds__(AESGCM_PKTL_WG, AESGCM_PKTL_WAVES) void k_pktl(cons
         if (lane == 0) b = atomicAdd(p.counter, 1u) - p.counter_base;
         b = __builtin_amdgcn_readfirstlane(b);
         if (b >= nb) break;
-        const u32 pkt = b * 64u + lane;
-        if (pkt < p.n_pkts) pktl_lane<NR, DEC, AESGCM_PKTL_T4 != 0>(km, p, smem, pkt, lane);
+        const u32 idx = b * 64u + lane;
+        if (idx < p.n_pkts) pktl_lane<NR, DEC, AESGCM_PKTL_T4 != 0>(km, p, smem, pkt_map(p, idx), lane);
     }
 }
 
@@ -1285,7 +1334,8 @@ static int hip_fail(hipError_t e, const char *what) {
 #define HIPCHK(call) do { hipError_t _e = (call); if (_e != hipSuccess) return hip_fail(_e, #call); } while (0)
 
 #define BATCH_DISPENSERS 256
-struct DeviceState { DevTables *tables = nullptr; int n_cu = 0; bool attrs = false; u32 *batch_counter = nullptr; u32 batch_slot = 0; };   // ring of dispensers: concurrent batch launches never share one
+struct OrderSlot { u32 *perm = nullptr; size_t cap = 0; u32 *bins = nullptr; };                                   // the launch order of packets of mixed length (k_len_*)
+struct DeviceState { DevTables *tables = nullptr; int n_cu = 0; bool attrs = false; u32 *batch_counter = nullptr; u32 batch_slot = 0; OrderSlot order[4]; unsigned order_next = 0; };   // ring of dispensers: concurrent batch launches never share one
 static std::mutex g_mu;
 static std::vector<DeviceState> g_dev;
 
@@ -1372,6 +1422,10 @@ struct aesgcm_ctx {
     size_t pl_cap = 0;
     hipStream_t pl_in = nullptr, pl_out = nullptr;
     hipEvent_t pl_ev_h2d[2] = {nullptr, nullptr}, pl_ev_k[2] = {nullptr, nullptr}, pl_ev_d2h[2] = {nullptr, nullptr};
+    // packets of mixed length: the launch order by length class (k_len_*).  A ring of slots, so that calls on different streams do not share one.
+    OrderSlot order[4];
+    unsigned order_next = 0;
+    size_t order_min = 98304;          // packets from which the order pays (context option "pkt_order"; 0 = never)
     // streaming state
     bool s_active = false, s_data = false, s_ragged = false;
     int s_dec = 0;
@@ -1944,6 +1998,7 @@ int aesgcm_ctx_destroy(aesgcm_ctx *c) {
     if (c->d_mtag) hipFree(c->d_mtag);
     if (c->d_trace) hipFree(c->d_trace);
     pipeline_release(c);
+    for (auto &o : c->order) { if (o.perm) hipFree(o.perm); if (o.bins) hipFree(o.bins); }
     if (c->st_in) hipFree(c->st_in);
     if (c->st_out) hipFree(c->st_out);
     if (c->st_aad) hipFree(c->st_aad);
@@ -1970,6 +2025,7 @@ int aesgcm_ctx_set_option(aesgcm_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "cyc_close")) c->cyc_fuse = v != 0;                          // 1: a whole message's cyclic launch closes the tag itself; 0: k_fold + k_combine behind it
     else if (!strcmp(key, "fold_close")) c->fold_close = v != 0;                       // 1: behind the dealt k_body the first (or second) k_fold level closes the tag
     else if (!strcmp(key, "cyc_prio")) c->cyc_prio = (u32)v;                           // rows between rotations of the waves' issue priorities in a cyclic launch (0 = off)
+    else if (!strcmp(key, "pkt_order")) c->order_min = (size_t)v;                      // packets from which a launch over packets of mixed length takes them by falling length class (k_len_*); 0 = never
     else if (!strcmp(key, "poll_us")) c->poll_ns = 1000L * (long)v;                    // how long a tag is polled for in the host slot before the call blocks in the runtime
     else return AESGCM_EARG;
     return AESGCM_OK;
@@ -2382,13 +2438,14 @@ int aesgcm_stream_final(aesgcm_ctx *c, uint8_t tag[16]) {
 #ifdef AESGCM_DEBUG_KNOBS
 // Test / profiling builds only (libaesgcm_hip_dbg.so, -DAESGCM_DEBUG_KNOBS; include/aesgcm_debug.h): force the kernel shape the next launches take, so that every
 // shape can be checked on inputs the host's own rule would give to another.  The product library has no such switch and reads no environment.
-static struct { int pkt_lanes, pkt_deal, batch_lanes, batch_deal; } g_force = {0, 0, 0, 0};
+static struct { int pkt_lanes, pkt_deal, batch_lanes, batch_deal, batch_order; } g_force = {0, 0, 0, 0, 0};
 extern "C" __attribute__((visibility("default"))) int aesgcm_debug_force_shape(const char *what, int value) {
     if (!what) return AESGCM_EARG;
     if (!strcmp(what, "pkt_lanes")) { if (value != 0 && value != 1 && value != 4 && value != 8 && value != 16 && value != 64) return AESGCM_EARG; g_force.pkt_lanes = value; }
     else if (!strcmp(what, "pkt_deal")) g_force.pkt_deal = value;
     else if (!strcmp(what, "batch_lanes")) { if (value != 0 && value != 8 && value != 16 && value != 64) return AESGCM_EARG; g_force.batch_lanes = value; }
     else if (!strcmp(what, "batch_deal")) g_force.batch_deal = value;
+    else if (!strcmp(what, "batch_order")) { if (value < 0 || value > 2) return AESGCM_EARG; g_force.batch_order = value; }      // variable-length batches by length class: 0 = the library's rule, 1 = always, 2 = never
     else return AESGCM_EARG;
     return AESGCM_OK;
 }
@@ -2401,11 +2458,21 @@ extern "C" __attribute__((visibility("default"))) int aesgcm_debug_force_shape(c
 // a quarter when it is not (4096 x 1 KiB 34 / 69 / 57 / 38 / 13).  Lanes win from 131072 packets (2^20 x 1 KiB 303 / 592 / 657 / 742 / 767; 262144 x 4 KiB
 // 496 / 656 / 704 / 722 / 724), short packets from 32768 (65536 x 256 B 51 / 61 / 95 / 129 / 148).  With offset arrays the host does not know the lengths: it
 // goes by count and assumes 1 KiB.
-static int packets_pick_lg(u32 n_cu, size_t n_pkts, size_t pkt_len, bool var) {
-    const size_t lanes_total = (size_t)n_cu * (AESGCM_PKT_WG / 64) * 64;
+static int packets_pick_lg(u32 n_cu, size_t n_pkts, size_t pkt_len, bool var, bool ordered = false) {
+    const size_t lanes_total = (size_t)n_cu * (AESGCM_PKT_WG / 64) * 64, lanes_l = (size_t)n_cu * AESGCM_PKTL_WG;
     const size_t blocks = var ? 64 : (pkt_len + 15) / 16;
-    if (var ? n_pkts >= 32768 : (n_pkts >= 131072 || (pkt_len <= 256 && n_pkts >= 32768))) return 0;
-    const size_t fill = lanes_total / n_pkts, cap = n_pkts >= 16384 ? blocks / 8 : blocks / 4;
+    // One lane per packet once the packets fill k_pktl's resident lanes (256 x 768); frames of up to 1 KiB from three quarters of that, short ones much earlier.
+    // Round 4 (profiles/r04/packets_sweep_aes256.txt, after k_pktl's rebuild): 131072 x 4 KiB 553 by lanes against 722 by groups of 4 (196608: 795 / 713),
+    // 131072 x 16 KiB 573 / 789, 131072 x 1 KiB 488 / 509 (196608: 677 / 577), 49152 x 256 B 142 / 124, 16384 x 64 B 28 / 23.
+    // Offset arrays (the host does not know the lengths): as 1 KiB frames in array order (mixed 64 .. 1514 bytes: 131072 frames 243 by lanes / 277 by groups of
+    // 4, 196608: 346 / 296); taken by length class the groups hold on longer (196608: 323 / 394, 262144: 421 / 429, 393216: 584 / 505).
+    if (var ? (ordered ? 3 * n_pkts >= 4 * lanes_l : 4 * n_pkts >= 3 * lanes_l)
+            : (n_pkts >= lanes_l || (pkt_len <= 1024 && 4 * n_pkts >= 3 * lanes_l) || (pkt_len <= 256 && n_pkts >= 32768) || (pkt_len <= 64 && n_pkts >= 16384))) return 0;
+    // Lane groups: the group that just fills the resident lanes.  Packets of 4 KiB and more round the fill UP to a power of two (half again as many lanes as
+    // are resident is cheaper than rows twice as long: 49152 x 4 KiB 474 with 4 lanes, 576 with 8; x 16 KiB 542 / 722), shorter ones down (49152 x 1 KiB 325 / 291).
+    size_t fill = lanes_total / n_pkts;
+    if (!var && pkt_len >= 4096 && (fill & (fill - 1))) { size_t f = 1; while (f < fill) f <<= 1; fill = f; }
+    const size_t cap = n_pkts >= 16384 ? blocks / 8 : blocks / 4;
     const size_t g = fill < cap ? fill : cap;
     return g >= 64 ? 6 : g >= 16 ? 4 : g >= 8 ? 3 : 2;
 }
@@ -2422,6 +2489,31 @@ static int batch_pick_lg(int n_cu, size_t n_pkts, size_t pkt_len, bool var) {
     if (lg == 4 && (var ? n_pkts >= (size_t)64 * n_cu
                         : ((n_pkts >= (size_t)256 * n_cu && pkt_len <= 8192) || (n_pkts >= (size_t)64 * n_cu && pkt_len <= 2048)))) lg = 3;
     return lg;
+}
+
+// The order in which a launch takes packets of mixed length: counting sort by falling length class on the launch's stream (k_len_hist, k_len_scan,
+// k_len_scatter).  *perm = NULL when it does not pay or is switched off.  Three launches of about 10 us in front of the packet kernel: mixed frames of
+// 64 .. 1514 bytes, AES-256, best shape each (profiles/r04/packets_sweep_mixed_*.txt): 16384 frames 101 GiB/s in array order, 79 by class; 65536 223 / 199; 98304
+// 256 / 271; 131072 284 / 320; 262144 382 / 429; 2^20 426 / 717 -- the order pays once the machine is full, and the default threshold is there.
+static bool packets_ordered(const aesgcm_ctx *c, size_t n_pkts, bool var) { return var && c->order_min && n_pkts >= c->order_min; }
+static int order_launch(OrderSlot &o, const u64 *d_off, size_t n_pkts, hipStream_t st, const u32 **perm) {
+    if (!o.bins) HIPCHK(hipMalloc((void **)&o.bins, LEN_SORT_ENTRIES * sizeof(u32)));
+    if (o.cap < n_pkts) {
+        if (o.perm) { HIPCHK(hipFree(o.perm)); o.perm = nullptr; o.cap = 0; }     // hipFree waits for the launches that may still read it
+        HIPCHK(hipMalloc((void **)&o.perm, n_pkts * sizeof(u32)));
+        o.cap = n_pkts;
+    }
+    hipLaunchKernelGGL(k_len_hist, dim3(LEN_SORT_WGS), dim3(256), 0, st, d_off, (u32)n_pkts, o.bins);
+    hipLaunchKernelGGL(k_len_scan, dim3(1), dim3(1024), 0, st, o.bins);
+    hipLaunchKernelGGL(k_len_scatter, dim3(LEN_SORT_WGS), dim3(256), 0, st, d_off, (u32)n_pkts, o.bins, o.perm);
+    HIPCHK(hipGetLastError());
+    *perm = o.perm;
+    return AESGCM_OK;
+}
+static int packets_order(aesgcm_ctx *c, const u64 *d_off, size_t n_pkts, hipStream_t st, const u32 **perm) {
+    *perm = nullptr;
+    if (!packets_ordered(c, n_pkts, true)) return AESGCM_OK;
+    return order_launch(c->order[c->order_next++ & 3u], d_off, n_pkts, st, perm);
 }
 
 // ---------------------------------------------------------------- packets under the context's key
@@ -2442,13 +2534,14 @@ int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const vo
     p.n_pkts = (u32)n_pkts; p.pkt_len = (u32)pkt_len; p.aad_len = (u32)aad_len;
     p.aligned = (((uintptr_t)d_in | (uintptr_t)d_out) & 15) == 0 && (d_data_off || pkt_len % 16 == 0);
     const u32 n_cu = (u32)c->G / 2;                                                 // c->G = two workgroups per CU
-    int lg = packets_pick_lg(n_cu, n_pkts, pkt_len, d_data_off != nullptr);
+    int lg = packets_pick_lg(n_cu, n_pkts, pkt_len, d_data_off != nullptr, packets_ordered(c, n_pkts, d_data_off != nullptr));
 #ifdef AESGCM_DEBUG_KNOBS
     if (g_force.pkt_lanes) lg = g_force.pkt_lanes == 1 ? 0 : g_force.pkt_lanes == 64 ? 6 : g_force.pkt_lanes == 16 ? 4 : g_force.pkt_lanes == 8 ? 3 : 2;
 #endif
     const int shape = lg == 0 ? 'l' : lg == 6 ? 'w' : 'g';
     hipStream_t st = pick_stream(c, stream);
     p.counter = c->d_counter; p.counter_base = c->counter_base;
+    if (d_data_off) { const int rc = packets_order(c, (const u64 *)d_data_off, n_pkts, st, &p.perm); if (rc) return rc; }
     if (shape == 'l') {
         const u32 nb = (u32)((n_pkts + 63) / 64);
         const u32 waves_per_wg = AESGCM_PKTL_WG / 64;
@@ -2487,6 +2580,9 @@ int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const vo
 }
 
 // ---------------------------------------------------------------- batch (per-packet key and IV)
+// Variable-length batches by length class: mixed frames of 64 .. 1514 bytes, GiB/s in array order / by class (profiles/r04/batch_mixed_*.txt): AES-128 65536 packets
+// 202 / 178, 262144 313 / 307, 393216 332 / 342, 2^20 362 / 493; AES-256 65536 177 / 167, 98304 205 / 213, 262144 266 / 290, 2^20 301 / 437.
+#define BATCH_ORDER_MIN(nr) ((nr) == 10 ? 262144u : 98304u)
 static int batch_launch(int device, int decrypt, size_t n_pkts, size_t key_len, BatchParams &p, void *stream) {
     if (key_len != 16 && key_len != 24 && key_len != 32) return AESGCM_EKEYLEN;
     if (n_pkts >= (((size_t)1) << 31)) return AESGCM_ETOOLONG;
@@ -2521,6 +2617,16 @@ static int batch_launch(int device, int decrypt, size_t n_pkts, size_t key_len, 
     if (g_force.batch_lanes) lg = g_force.batch_lanes == 8 ? 3 : g_force.batch_lanes == 16 ? 4 : 6;
 #endif
     if (lg < 6) {
+        // packets of mixed length: by falling length class once the batch fills the machine several times over (BATCH_ORDER_MIN; as aesgcm_packets_crypt_dev)
+        bool ordered = p.data_off && n_pkts >= BATCH_ORDER_MIN(nr);
+#ifdef AESGCM_DEBUG_KNOBS
+        if (g_force.batch_order) ordered = p.data_off && g_force.batch_order == 1;
+#endif
+        if (ordered) {
+            OrderSlot *o;
+            { std::lock_guard<std::mutex> lk(g_mu); o = &ds->order[ds->order_next++ & 3u]; }
+            if ((rc = order_launch(*o, p.data_off, n_pkts, st, &p.perm))) return rc;
+        }
         const u32 waves_per_wg = (u32)BATCH3_LANES(nr) / 64;
         const u32 P = 64u >> lg, per_wg = waves_per_wg * P;
         wgs = (u32)((n_pkts + per_wg - 1) / per_wg);
@@ -2592,7 +2698,7 @@ int aesgcm_batch_shape(int device, size_t n_pkts, size_t pkt_len, int var_len, i
 }
 int aesgcm_packets_shape(const aesgcm_ctx *c, size_t n_pkts, size_t pkt_len, int var_len, int *lanes_per_packet) {
     if (!c || !lanes_per_packet || !n_pkts) return AESGCM_EARG;
-    int lg = packets_pick_lg((u32)c->G / 2, n_pkts, pkt_len, var_len != 0);
+    int lg = packets_pick_lg((u32)c->G / 2, n_pkts, pkt_len, var_len != 0, packets_ordered(c, n_pkts, var_len != 0));
 #ifdef AESGCM_DEBUG_KNOBS
     if (g_force.pkt_lanes) lg = g_force.pkt_lanes == 1 ? 0 : g_force.pkt_lanes == 64 ? 6 : g_force.pkt_lanes == 16 ? 4 : g_force.pkt_lanes == 8 ? 3 : 2;
 #endif

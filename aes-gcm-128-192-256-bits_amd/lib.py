@@ -88,7 +88,7 @@ class debug_library:
 
     def __exit__(self, *a):
         global _L
-        for k in ("pkt_lanes", "pkt_deal", "batch_lanes", "batch_deal"):
+        for k in ("pkt_lanes", "pkt_deal", "batch_lanes", "batch_deal", "batch_order"):
             _DBG.aesgcm_debug_force_shape(k.encode(), 0)
         _L = self._prev
 
@@ -422,7 +422,7 @@ class Context:
         self.close()
 
     def set_option(self, key, value):
-        """aesgcm_ctx_set_option: "tw", "body_min", "cyc_min", "cyc_max", "cyc_close", "fold_close", "cyc_prio", "poll_us" (include/aesgcm.h)"""
+        """aesgcm_ctx_set_option: "tw", "body_min", "cyc_min", "cyc_max", "cyc_close", "fold_close", "cyc_prio", "pkt_order", "poll_us" (include/aesgcm.h)"""
         _chk(load().aesgcm_ctx_set_option(self._c, key.encode(), int(value)))
         return self
 

@@ -115,6 +115,8 @@ AESGCM_API int aesgcm_ctx_device(const aesgcm_ctx *ctx);
  *                 beside another's rows; a single message alone on the chip is slower that way (default 0)
  *   "fold_close"  1: behind the dealt k_body a k_fold level closes the tag; 0: further levels and k_combine
  *   "cyc_prio"    rows between rotations of the waves' issue priorities in a cyclic launch, 0 = off
+ *   "pkt_order"   packets from which aesgcm_packets_crypt_dev with offset arrays takes the packets by falling length class (a counting sort on the
+ *                 device in front of the launch; default 98304, where it starts to pay), 0 = never.  The results are the same bytes.
  *   "poll_us"     how long a tag is polled for in the pinned host slot before the call blocks in the runtime
  * AESGCM_EARG for an unknown key. */
 AESGCM_API int aesgcm_ctx_set_option(aesgcm_ctx *ctx, const char *key, int64_t value);
@@ -244,8 +246,12 @@ AESGCM_API int aesgcm_mgpu_destroy(aesgcm_mgpu *m);
  * packet (src/aes_icb.vhd:60-70 "load IV"): this is that mode.  Per packet: ivs[p] (12 bytes), optional AAD
  * and data either as fixed-size records (aad_len / pkt_len, offset arrays NULL) or delimited by uint64 offset
  * arrays with n_pkts + 1 entries (then aad_len / pkt_len are ignored); tags[p] receives the computed tag; for
- * decrypt d_auth[p] (optional) = 1 if it equals d_expect_tags[p].  One wave per packet, so it is meant for
- * packets up to ~1 MiB; larger messages belong to aesgcm_encrypt_dev.  Asynchronous on `stream`. */
+ * decrypt d_auth[p] (optional) = 1 if it equals d_expect_tags[p].  At most a wave per packet, so it is meant for
+ * packets up to ~1 MiB; larger messages belong to aesgcm_encrypt_dev.  Asynchronous on `stream`.
+ * With offset arrays and many packets (context option "pkt_order", default from 98304) the launch takes the packets in the order of a
+ * counting sort by length class, made on the device in front of it (three small launches on `stream`, 4 bytes per packet of scratch in
+ * the context): the lanes of a wave run to the longest packet among them, and frames of mixed length in arrival order leave half of
+ * them idle.  Which packet a lane takes never shows in the results. */
 AESGCM_API int aesgcm_packets_crypt_dev(aesgcm_ctx *ctx, int decrypt, size_t n_pkts, const void *d_ivs,
                              const void *d_aad, size_t aad_len, const uint64_t *d_aad_off,
                              const void *d_in, size_t pkt_len, const uint64_t *d_data_off, void *d_out,
@@ -272,7 +278,8 @@ AESGCM_API int aesgcm_packets_shape(const aesgcm_ctx *ctx, size_t n_pkts, size_t
  * per-frame header as AAD, README.md:251-257): packet p occupies bytes [d_data_off[p], d_data_off[p+1]) of
  * in/out and, when d_aad_off != NULL, bytes [d_aad_off[p], d_aad_off[p+1]) of aad.  Offset arrays have
  * n_pkts + 1 uint64 entries in device memory.  Each packet < 2^28 bytes.  Packets whose data offset is a
- * multiple of 16 take the aligned fast path. */
+ * multiple of 16 take the aligned fast path.  From 262144 packets (AES-128; 98304 for the longer keys) the launch takes them by falling
+ * length class, as aesgcm_packets_crypt_dev does (scratch: 4 bytes per packet, kept per device). */
 AESGCM_API int aesgcm_batch_crypt_var_dev(int device, int decrypt, size_t n_pkts, size_t key_len, const void *d_keys, const void *d_ivs,
                                const void *d_aad, const uint64_t *d_aad_off, const void *d_in, const uint64_t *d_data_off,
                                void *d_out, void *d_tags, const void *d_expect_tags, int *d_auth, void *stream);

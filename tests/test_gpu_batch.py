@@ -277,3 +277,91 @@ def test_many_small_packets_default_shape(hip, orc):
     assert bytes(d_buf.download(doff[-1])) == pt
     auth = struct.unpack("<%di" % m, bytes(d_auth.download()))
     assert [i for i, a in enumerate(auth) if not a] == [4321, 49999]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [None, "group16", "g8", "g4", "lane"])
+def test_mixed_length_packets_taken_by_length_class(hip, orc, shape):
+    """6 000 frames of 0 .. 9 KiB through offset arrays, taken in the order of a counting sort by length class (k_len_hist / k_len_scan / k_len_scatter;
+    the context option pkt_order is the packet count from which the library does that by itself: here 1) and in array order (0).  Every kernel shape, both orders: the same ciphertext and tags, all against the
+    oracle; then decrypt in place with two forged tags."""
+    import struct
+    rng = random.Random(20261)
+    m = 6000
+    lens = [rng.choice((0, 16, 46, 64, 64, 128, 500, 1000, 1500, 1514, 4096, 9000, rng.randrange(0, 1515), rng.randrange(0, 1515))) for _ in range(m)]
+    aads = [rng.choice((0, 0, 8, 20, 28)) for _ in range(m)]
+    doff, aoff = [0], [0]
+    for a, b in zip(lens, aads):
+        doff.append(doff[-1] + a); aoff.append(aoff[-1] + b)
+    key = splitmix_bytes(902, 32)
+    f = orc.Fast(key)
+    ivs, aad, pt = splitmix_bytes(61, 12 * m), splitmix_bytes(62, max(aoff[-1], 16)), splitmix_bytes(63, doff[-1])
+    want = [f.encrypt(ivs[12 * p:12 * p + 12], aad[aoff[p]:aoff[p + 1]], pt[doff[p]:doff[p + 1]]) for p in range(m)]
+
+    def up(b):
+        d = hip.DeviceBuffer(max(len(b), 16)); d.upload(b); return d
+
+    def run():
+        for order in (1, 0):
+            ctx = hip.Context(key).set_option("pkt_order", order)
+            d_ivs, d_aad, d_in, d_out = up(ivs), up(aad), up(pt), hip.DeviceBuffer(doff[-1] + 16)
+            d_doff, d_aoff = up(struct.pack("<%dQ" % (m + 1), *doff)), up(struct.pack("<%dQ" % (m + 1), *aoff))
+            d_tags, d_auth = hip.DeviceBuffer(16 * m), hip.DeviceBuffer(4 * m)
+            ctx.packets_crypt_dev(False, m, d_ivs.ptr, d_in.ptr, d_out.ptr, d_tags.ptr, d_data_off=d_doff.ptr, d_aad=d_aad.ptr, d_aad_off=d_aoff.ptr)
+            hip.dev_sync()
+            ct, tags = bytes(d_out.download(doff[-1])), bytes(d_tags.download())
+            for p in range(m):
+                assert (ct[doff[p]:doff[p + 1]], tags[16 * p:16 * p + 16]) == want[p], (shape, order, p, lens[p], aads[p])
+            bad = bytearray(tags); bad[16 * 17] ^= 1; bad[16 * 5999 + 15] ^= 0x80
+            d_exp = up(bytes(bad))
+            ctx.packets_crypt_dev(True, m, d_ivs.ptr, d_out.ptr, d_out.ptr, d_tags.ptr, d_data_off=d_doff.ptr, d_aad=d_aad.ptr, d_aad_off=d_aoff.ptr,
+                                  d_expect_tags=d_exp.ptr, d_auth=d_auth.ptr)
+            hip.dev_sync()
+            assert bytes(d_out.download(doff[-1])) == pt, (shape, order)
+            auth = struct.unpack("<%di" % m, bytes(d_auth.download()))
+            assert [i for i, a in enumerate(auth) if not a] == [17, 5999], (shape, order)
+
+    if shape is None:
+        return run()
+    with hip.debug_library() as dbg:
+        dbg.force(pkt_lanes=PKT_LANES[shape])
+        run()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lanes", [8, 16])
+def test_variable_length_batch_taken_by_length_class(hip, orc, lanes):
+    """3 000 packets with a key each and lengths of 0 .. 5 KiB through offset arrays: k_batch3 takes them in the order of the counting sort by length class
+    (forced: the library does it by itself from 262144 / 98304 packets) and in array order -- the same bytes, against the oracle; decrypt in place with a forged tag."""
+    import struct
+    rng = random.Random(31337)
+    n, klen = 3000, 16
+    lens = [rng.choice((0, 16, 64, 64, 100, 500, 1000, 1500, 1514, 4096, 5000, rng.randrange(0, 1515))) for _ in range(n)]
+    aads = [rng.choice((0, 0, 8, 20, 28)) for _ in range(n)]
+    doff, aoff = [0], [0]
+    for a, b in zip(lens, aads):
+        doff.append(doff[-1] + a); aoff.append(aoff[-1] + b)
+    keys, ivs, aad, pt = splitmix_bytes(71, klen * n), splitmix_bytes(72, 12 * n), splitmix_bytes(73, max(aoff[-1], 16)), splitmix_bytes(74, doff[-1])
+    want = [orc.Fast(keys[klen * p:klen * (p + 1)]).encrypt(ivs[12 * p:12 * p + 12], aad[aoff[p]:aoff[p + 1]], pt[doff[p]:doff[p + 1]]) for p in range(n)]
+
+    def up(b):
+        d = hip.DeviceBuffer(max(len(b), 16)); d.upload(b); return d
+    with hip.debug_library() as dbg:
+        for order in (1, 2):                                     # always / never
+            dbg.force(batch_lanes=lanes, batch_order=order)
+            d_keys, d_ivs, d_aad, d_in, d_out = up(keys), up(ivs), up(aad), up(pt), hip.DeviceBuffer(doff[-1] + 16)
+            d_doff, d_aoff = up(struct.pack("<%dQ" % (n + 1), *doff)), up(struct.pack("<%dQ" % (n + 1), *aoff))
+            d_tags, d_auth = hip.DeviceBuffer(16 * n), hip.DeviceBuffer(4 * n)
+            hip.batch_crypt_var_dev(False, n, klen, d_keys.ptr, d_ivs.ptr, d_in.ptr, d_doff.ptr, d_out.ptr, d_tags.ptr, d_aad=d_aad.ptr, d_aad_off=d_aoff.ptr)
+            hip.dev_sync()
+            ct, tags = bytes(d_out.download(doff[-1])), bytes(d_tags.download())
+            for p in range(n):
+                assert (ct[doff[p]:doff[p + 1]], tags[16 * p:16 * p + 16]) == want[p], (lanes, order, p, lens[p], aads[p])
+            bad = bytearray(tags); bad[16 * 2999 + 7] ^= 2
+            d_exp = up(bytes(bad))
+            hip.batch_crypt_var_dev(True, n, klen, d_keys.ptr, d_ivs.ptr, d_out.ptr, d_doff.ptr, d_out.ptr, d_tags.ptr, d_aad=d_aad.ptr, d_aad_off=d_aoff.ptr,
+                                    d_expect_tags=d_exp.ptr, d_auth=d_auth.ptr)
+            hip.dev_sync()
+            assert bytes(d_out.download(doff[-1])) == pt, (lanes, order)
+            auth = struct.unpack("<%di" % n, bytes(d_auth.download()))
+            assert [i for i, a in enumerate(auth) if not a] == [2999], (lanes, order)
