@@ -1209,7 +1209,8 @@ __global__ __launch_bounds__(256) void k_len_scatter(const u64 *__restrict__ off
 // k_pktg: many packets under the context's key, 2^LG lanes per packet (lane bodies: pktg_lane(), pktg_close_lane(),
 // pktg_tree_offer(); see "Packets under ONE key" in aesgcm_dev.h).  One 1024-lane workgroup per CU.
 // ------------------------------------------------------------------------------------------------
-#define PKTG_LDS_TOTAL(LG) (PKTG_LDS_BYTES(LG) + ((LG) <= 4 ? (u32)(PKTG_WG(LG) / 64) * 1024u : 0u))     /* + the waves' E_K(J0) slots */
+#define PKTG_WAVE_SLOT 1280u                                                                                /* per wave: 64 E_K(J0) values and the 64 packet numbers of its dispenser block */
+#define PKTG_LDS_TOTAL(LG) (PKTG_LDS_BYTES(LG) + ((LG) <= 4 ? (u32)(PKTG_WG(LG) / 64) * PKTG_WAVE_SLOT : 0u))
 // the cross-lane tree of a packet's group, level J .. LG-1 (compile-time recursion: lane_xor needs its mask as a constant)
 template <int LG, int J>
 __device__ __forceinline__ void pktg_tree(uint4 &acc, const unsigned char *smem, u32 l) {
@@ -1239,7 +1240,7 @@ __global__ __launch_bounds__(PKTG_WG(LG), (PKTG_WG(LG) + 255) / 256) void k_pktg
     const u32 tid = threadIdx.x, lane = tid & 63u;
     pktg_fill_lds(smem, km, tb, tid, PKTG_WG(LG), LG);
     __syncthreads();
-    const u32 wave_slot = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6)) * 1024u;       // scalar
+    const u32 wave_slot = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6)) * PKTG_WAVE_SLOT;       // scalar
     // packets are dealt to the waves in blocks of p.deal (a multiple of P, at most 64) from a dispenser: one atomic per block
     // keeps the single dispenser address far below its ~87 M fetches/s ceiling (measured), and late waves still level the
     // tail.  The loop is bounded on purpose (a wave can never own more than nb blocks).
@@ -1254,12 +1255,18 @@ __global__ __launch_bounds__(PKTG_WG(LG), (PKTG_WG(LG) + 255) / 256) void k_pktg
         // (behind the tree tables): held in registers across the packet loop they were spilled at 128 registers; one packet per wave keeps them.
         constexpr bool EJ_LDS = LG <= 4;
         unsigned char *ej_slot = smem + PKTG_LDS_BYTES(LG) + wave_slot;
-        uint4 ej = pktg_ej0_lane<NR>(km, p, smem, pkt_map(p, p0 + (lane < cnt ? lane : 0u)), lane);
-        if (EJ_LDS) { *reinterpret_cast<uint4 *>(ej_slot + lane * 16u) = ej; ej = make_uint4(0, 0, 0, 0); }
+        // the block's packet numbers (pkt_map: the launch order of packets of mixed length) beside them, read back per group: the pointer chase stays out of the packet loop
+        const u32 mine = pkt_map(p, p0 + (lane < cnt ? lane : 0u));
+        uint4 ej = pktg_ej0_lane<NR>(km, p, smem, mine, lane);
+        if (EJ_LDS) {                                           // addresses from a fresh lane id: hoisted out of the dispenser loop they were two more registers held across it (spilled at 128)
+            const u32 lf = lane_id_fresh();
+            *reinterpret_cast<uint4 *>(ej_slot + lf * 16u) = ej; ej = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<u32 *>(ej_slot + 1024u + lf * 4u) = mine;
+        }
         for (u32 t = 0; t * P < cnt; ++t) {
             const u32 lane1 = lane_id_fresh(), l = lane1 & (G - 1u), idx = t * P + (lane1 >> LG);
             const bool act = idx < cnt;                          // groups past the end shadow the block's first packet; their stores are masked
-            const u32 pkt = pkt_map(p, p0 + (act ? idx : 0u));
+            const u32 pkt = EJ_LDS ? *reinterpret_cast<const u32 *>(ej_slot + 1024u + (act ? idx : 0u) * 4u) : pkt_map(p, p0 + (act ? idx : 0u));
             const PktInfo q = pkt_info(p, pkt);
             // the wave runs to the longest packet of its groups
             u32 iters = pktg_iters(q, G);
@@ -1269,7 +1276,7 @@ __global__ __launch_bounds__(PKTG_WG(LG), (PKTG_WG(LG) + 255) / 256) void k_pktg
             // l / grp / idx / pkt need not stay in registers across the packet loop -- at 128 registers they were spilled there
             const u32 lane2 = lane_id_fresh(), l2 = lane2 & (G - 1u), idx2 = t * P + (lane2 >> LG);
             const bool act2 = idx2 < cnt;
-            const u32 pkt2 = pkt_map(p, p0 + (act2 ? idx2 : 0u));
+            const u32 pkt2 = EJ_LDS ? *reinterpret_cast<const u32 *>(ej_slot + 1024u + (act2 ? idx2 : 0u) * 4u) : pkt_map(p, p0 + (act2 ? idx2 : 0u));
             acc = pktg_close_lane<LG>(acc, q, smem, l2);
             pktg_tree<LG, 0>(acc, smem, l2);
             // lane G-1 of the group holds P H^2 ^ L H; its packet's E_K(IV || 1) sits in lane idx of `ej`

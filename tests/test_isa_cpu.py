@@ -76,7 +76,7 @@ def test_kernel_set(census):
     for name in census:
         fam.setdefault(name.split("<")[0], []).append(name)
     assert sorted(fam) == ["k_batch", "k_batch3", "k_body", "k_bodyh", "k_combine", "k_combine_batch", "k_copy16", "k_fill_splitmix64", "k_fold", "k_gfmul", "k_init_tables",
-                           "k_main", "k_pktg", "k_pktl", "k_setup", "k_setup_ptab"], sorted(fam)
+                           "k_len_hist", "k_len_scan", "k_len_scatter", "k_main", "k_pktg", "k_pktl", "k_setup", "k_setup_ptab"], sorted(fam)
     assert (len(fam["k_main"]), len(fam["k_body"]), len(fam["k_bodyh"]), len(fam["k_pktg"]), len(fam["k_pktl"]), len(fam["k_batch"]), len(fam["k_batch3"])) == (12, 15, 6, 24, 6, 6, 12)
 
 
