@@ -1341,7 +1341,9 @@ static int hip_fail(hipError_t e, const char *what) {
 #define HIPCHK(call) do { hipError_t _e = (call); if (_e != hipSuccess) return hip_fail(_e, #call); } while (0)
 
 #define BATCH_DISPENSERS 256
-struct OrderSlot { u32 *perm = nullptr; size_t cap = 0; u32 *bins = nullptr; };                                   // the launch order of packets of mixed length (k_len_*)
+// The launch order of packets of mixed length (k_len_*): scratch of one launch.  `done` is recorded behind the packet kernel that reads the order, and the next
+// user of the slot makes its stream wait for it: slots may be reused by launches on other streams at any rate.
+struct OrderSlot { u32 *perm = nullptr; size_t cap = 0; u32 *bins = nullptr; hipEvent_t done = nullptr; };
 struct DeviceState { DevTables *tables = nullptr; int n_cu = 0; bool attrs = false; u32 *batch_counter = nullptr; u32 batch_slot = 0; OrderSlot order[4]; unsigned order_next = 0; };   // ring of dispensers: concurrent batch launches never share one
 static std::mutex g_mu;
 static std::vector<DeviceState> g_dev;
@@ -2005,7 +2007,7 @@ int aesgcm_ctx_destroy(aesgcm_ctx *c) {
     if (c->d_mtag) hipFree(c->d_mtag);
     if (c->d_trace) hipFree(c->d_trace);
     pipeline_release(c);
-    for (auto &o : c->order) { if (o.perm) hipFree(o.perm); if (o.bins) hipFree(o.bins); }
+    for (auto &o : c->order) { if (o.perm) hipFree(o.perm); if (o.bins) hipFree(o.bins); if (o.done) hipEventDestroy(o.done); }
     if (c->st_in) hipFree(c->st_in);
     if (c->st_out) hipFree(c->st_out);
     if (c->st_aad) hipFree(c->st_aad);
@@ -2504,10 +2506,13 @@ static int batch_pick_lg(int n_cu, size_t n_pkts, size_t pkt_len, bool var) {
 // 256 / 271; 131072 284 / 320; 262144 382 / 429; 2^20 426 / 717 -- the order pays once the machine is full, and the default threshold is there.
 static bool packets_ordered(const aesgcm_ctx *c, size_t n_pkts, bool var) { return var && c->order_min && n_pkts >= c->order_min; }
 static int order_launch(OrderSlot &o, const u64 *d_off, size_t n_pkts, hipStream_t st, const u32 **perm) {
-    if (!o.bins) HIPCHK(hipMalloc((void **)&o.bins, LEN_SORT_ENTRIES * sizeof(u32)));
+    if (!o.done) HIPCHK(hipEventCreateWithFlags(&o.done, hipEventDisableTiming));
+    else HIPCHK(hipStreamWaitEvent(st, o.done, 0));                                // the slot's previous reader, on whatever stream it ran
+    // no memory for the scratch (4 bytes per packet): the launch takes the packets as they come -- slower, never wrong
+    if (!o.bins && hipMalloc((void **)&o.bins, LEN_SORT_ENTRIES * sizeof(u32)) != hipSuccess) { o.bins = nullptr; (void)hipGetLastError(); *perm = nullptr; return AESGCM_OK; }
     if (o.cap < n_pkts) {
         if (o.perm) { HIPCHK(hipFree(o.perm)); o.perm = nullptr; o.cap = 0; }     // hipFree waits for the launches that may still read it
-        HIPCHK(hipMalloc((void **)&o.perm, n_pkts * sizeof(u32)));
+        if (hipMalloc((void **)&o.perm, n_pkts * sizeof(u32)) != hipSuccess) { o.perm = nullptr; (void)hipGetLastError(); *perm = nullptr; return AESGCM_OK; }
         o.cap = n_pkts;
     }
     hipLaunchKernelGGL(k_len_hist, dim3(LEN_SORT_WGS), dim3(256), 0, st, d_off, (u32)n_pkts, o.bins);
@@ -2517,10 +2522,11 @@ static int order_launch(OrderSlot &o, const u64 *d_off, size_t n_pkts, hipStream
     *perm = o.perm;
     return AESGCM_OK;
 }
-static int packets_order(aesgcm_ctx *c, const u64 *d_off, size_t n_pkts, hipStream_t st, const u32 **perm) {
-    *perm = nullptr;
+static int packets_order(aesgcm_ctx *c, const u64 *d_off, size_t n_pkts, hipStream_t st, const u32 **perm, OrderSlot **slot) {
+    *perm = nullptr; *slot = nullptr;
     if (!packets_ordered(c, n_pkts, true)) return AESGCM_OK;
-    return order_launch(c->order[c->order_next++ & 3u], d_off, n_pkts, st, perm);
+    *slot = &c->order[c->order_next++ & 3u];
+    return order_launch(**slot, d_off, n_pkts, st, perm);
 }
 
 // ---------------------------------------------------------------- packets under the context's key
@@ -2548,7 +2554,8 @@ int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const vo
     const int shape = lg == 0 ? 'l' : lg == 6 ? 'w' : 'g';
     hipStream_t st = pick_stream(c, stream);
     p.counter = c->d_counter; p.counter_base = c->counter_base;
-    if (d_data_off) { const int rc = packets_order(c, (const u64 *)d_data_off, n_pkts, st, &p.perm); if (rc) return rc; }
+    OrderSlot *oslot = nullptr;
+    if (d_data_off) { const int rc = packets_order(c, (const u64 *)d_data_off, n_pkts, st, &p.perm, &oslot); if (rc) return rc; }
     if (shape == 'l') {
         const u32 nb = (u32)((n_pkts + 63) / 64);
         const u32 waves_per_wg = AESGCM_PKTL_WG / 64;
@@ -2583,6 +2590,7 @@ int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const vo
     }
     const hipError_t le = hipGetLastError();
     if (le != hipSuccess) { c->counter_base = p.counter_base; return hip_fail(le, "k_pkt launch"); }
+    if (oslot && p.perm) HIPCHK(hipEventRecord(oslot->done, st));
     return AESGCM_OK;
 }
 
@@ -2625,14 +2633,16 @@ static int batch_launch(int device, int decrypt, size_t n_pkts, size_t key_len, 
 #endif
     if (lg < 6) {
         // packets of mixed length: by falling length class once the batch fills the machine several times over (BATCH_ORDER_MIN; as aesgcm_packets_crypt_dev)
+        OrderSlot *oslot = nullptr;
         bool ordered = p.data_off && n_pkts >= BATCH_ORDER_MIN(nr);
 #ifdef AESGCM_DEBUG_KNOBS
         if (g_force.batch_order) ordered = p.data_off && g_force.batch_order == 1;
 #endif
+        std::unique_lock<std::mutex> order_lock(g_mu, std::defer_lock);             // held from the choice of the slot to the event behind its reader: callers on other threads queue up here
         if (ordered) {
-            OrderSlot *o;
-            { std::lock_guard<std::mutex> lk(g_mu); o = &ds->order[ds->order_next++ & 3u]; }
-            if ((rc = order_launch(*o, p.data_off, n_pkts, st, &p.perm))) return rc;
+            order_lock.lock();
+            oslot = &ds->order[ds->order_next++ & 3u];
+            if ((rc = order_launch(*oslot, p.data_off, n_pkts, st, &p.perm))) return rc;
         }
         const u32 waves_per_wg = (u32)BATCH3_LANES(nr) / 64;
         const u32 P = 64u >> lg, per_wg = waves_per_wg * P;
@@ -2648,6 +2658,7 @@ static int batch_launch(int device, int decrypt, size_t n_pkts, size_t key_len, 
 #undef LB3N
 #undef LB3
         HIPCHK(hipGetLastError());
+        if (oslot && p.perm) HIPCHK(hipEventRecord(oslot->done, st));
         return AESGCM_OK;
     }
 #define LB(NR, D) hipLaunchKernelGGL((k_batch<NR, D>), dim3(wgs), dim3(AESGCM_WG), BATCH_LDS_BYTES, st, ds->tables, p)

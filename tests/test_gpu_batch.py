@@ -365,3 +365,44 @@ def test_variable_length_batch_taken_by_length_class(hip, orc, lanes):
             assert bytes(d_out.download(doff[-1])) == pt, (lanes, order)
             auth = struct.unpack("<%di" % n, bytes(d_auth.download()))
             assert [i for i, a in enumerate(auth) if not a] == [2999], (lanes, order)
+
+
+@pytest.mark.gpu
+def test_ordered_launches_back_to_back_reuse_their_scratch(hip, orc):
+    """The four scratch slots of the launch order are reused while earlier launches may still be running: ten launches over packets of mixed length queued
+    without a wait in between, each with its own offsets -- through a context on its stream (launches of ONE context share its dispenser and must stay on one
+    stream), and through the context-free batch entry point on two streams in turn (a dispenser per launch: those may overlap).  Tags against the oracle."""
+    import struct
+    rng = random.Random(8086)
+    key = splitmix_bytes(903, 16)
+    ctx = hip.Context(key).set_option("pkt_order", 1)
+    s1, s2 = hip.Context(key), hip.Context(key)            # kept alive: their streams carry the batch launches
+    f = orc.Fast(key)
+    m = 3000
+    runs = []
+    for r in range(20):
+        lens = [rng.choice((0, 16, 64, 200, 700, 1500, 1514, 3000, rng.randrange(0, 1515))) for _ in range(m)]
+        doff = [0]
+        for a in lens:
+            doff.append(doff[-1] + a)
+        ivs, pt = splitmix_bytes(700 + r, 12 * m), splitmix_bytes(800 + r, doff[-1])
+        d = {"doff": doff, "ivs": ivs, "pt": pt}
+        for k, b in (("d_ivs", ivs), ("d_in", pt), ("d_doff", struct.pack("<%dQ" % (m + 1), *doff)), ("d_keys", key * m)):
+            d[k] = hip.DeviceBuffer(max(len(b), 16)); d[k].upload(b)
+        d["d_out"], d["d_tags"] = hip.DeviceBuffer(doff[-1] + 16), hip.DeviceBuffer(16 * m)
+        runs.append(d)
+    hip.dev_sync()
+    with hip.debug_library() as dbg:
+        dbg.force(batch_order=1)
+        for r, d in enumerate(runs):
+            if r < 10:
+                ctx.packets_crypt_dev(False, m, d["d_ivs"].ptr, d["d_in"].ptr, d["d_out"].ptr, d["d_tags"].ptr, d_data_off=d["d_doff"].ptr)
+            else:
+                hip.batch_crypt_var_dev(False, m, 16, d["d_keys"].ptr, d["d_ivs"].ptr, d["d_in"].ptr, d["d_doff"].ptr, d["d_out"].ptr, d["d_tags"].ptr,
+                                        stream=(s1 if r % 2 else s2).stream())
+        hip.dev_sync()
+    for r, d in enumerate(runs):
+        ct, tags, doff = bytes(d["d_out"].download(d["doff"][-1])), bytes(d["d_tags"].download()), d["doff"]
+        for p in range(0, m, 7):
+            want = f.encrypt(d["ivs"][12 * p:12 * p + 12], b"", d["pt"][doff[p]:doff[p + 1]])
+            assert (ct[doff[p]:doff[p + 1]], tags[16 * p:16 * p + 16]) == want, (r, p)
