@@ -69,6 +69,28 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+# The contract is ONE JSON line on stdout.  Libraries loaded into this process write there too -- RCCL prints a five-line version banner through C stdio at
+# its first communicator, and C stdio flushes it at exit, i.e. BEHIND the line.  A process that is going to measure therefore keeps the real stdout for the
+# line alone (claim_stdout) and points descriptor 1 at stderr for everything else.
+_LINE_FD = None
+
+
+def claim_stdout():
+    global _LINE_FD
+    if _LINE_FD is None:
+        sys.stdout.flush()
+        _LINE_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line):
+    data = (json.dumps(line) + "\n").encode()
+    if _LINE_FD is None:
+        sys.stdout.write(data.decode()); sys.stdout.flush()
+    else:
+        os.write(_LINE_FD, data)
+
+
 def load_fixture(name):
     try:
         with open(os.path.join(ROOT, "tests", "golden", "streams.json")) as f:
@@ -423,7 +445,7 @@ def run_cfg5(args, rank, world, dev, ex, cpu_base):
         }
         if cpu_base is not None:
             line["cpu_baseline"] = cpu_base
-        print(json.dumps(line), flush=True)
+        emit(line)
     return tag_ok
 
 
@@ -515,7 +537,7 @@ def run_inflight(args, dev):
                      "sustained_frac": round(2 * size * steps / dt / HBM_PEAK_BYTES_PER_S, 4),
                      "timing": "HIP events on the launch stream, one context, waited calls, separate pass after the timed region"},
     }
-    print(json.dumps(line), flush=True)
+    emit(line)
     if bad[0]:
         log("PARITY FAILURE: %d of %d queued tags differ from the waited call's" % (bad[0], steps + warm))
     return bad[0] == 0
@@ -624,7 +646,7 @@ def run_single_process(args):
                      "timing": "HIP events on device 0's launch stream in a separate pass after the timed region",
                      "traffic_build": {"running_so_sha256": sha256_file(SO), "running_git": git_head()}},
     }
-    print(json.dumps(line), flush=True)
+    emit(line)
     ok = mg.n_ranks == N and tag_ok is not False
     mg.close()
     return 0 if ok else 1
@@ -694,10 +716,11 @@ def main(argv=None):
     if args.warmup is None:
         args.warmup = min(2500, max(3, int(50.0 / est_ms + 0.999))) if short_steps else 3
 
+    if "RANK" not in os.environ and args.gpus > 1 and args.emulate_rank is None and not args.sp_child:
+        return self_launch(args, argv)                           # before anything touches the GPU
+    claim_stdout()                                               # this process measures: stdout is for the line, descriptor 1 for whatever libraries print
     if args.sp_child:
         return run_single_process(args)
-    if "RANK" not in os.environ and args.gpus > 1 and args.emulate_rank is None:
-        return self_launch(args, argv)                           # before anything touches the GPU
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -740,6 +763,27 @@ def main(argv=None):
         ex.close()
         comm.finish(rank, world)
         return EXIT_NOT_RCCL
+
+    if (not_rccl and not args.allow_file_exchange and args.backend in ("rccl", "nccl") and os.environ.get("AESGCM_SELF_LAUNCHED") != "1"
+            and not args.one_device and args.config != "cfg5"):
+        # The same under an outside launcher (torchrun starts one process per GPU): the ranks cannot measure an RCCL job, but ONE fresh process over all
+        # devices can (aesgcm_mgpu_*: ncclCommInitAll).  Ranks 1 .. N-1 leave (their devices are free again); rank 0 starts that process as a CHILD --
+        # a process that has touched the GPU is never replaced by another program -- relays its line and leaves with its exit code.
+        log("bench.py rank %d: no RCCL communicator between the %d processes (%s)" % (rank, world, ex.name))
+        ex.barrier()
+        ex.close()
+        comm.finish(rank, world)
+        if rank != 0:
+            return 0
+        log("bench.py: falling back to ONE process driving all %d devices (ncclCommInitAll); the line below says so" % N)
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
+        env.update(AESGCM_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("NCCL_DEBUG", "WARN")
+        rcs, out0 = _run_children([([sys.executable, os.path.abspath(__file__)] + [a for a in argv if a != "--single-process"] + ["--sp-child"], env)], args.launch_timeout)
+        if out0:
+            os.write(_LINE_FD, out0)                              # the child's stdout is its line and nothing else (it claims its stdout too)
+        return (rcs[0] if rcs[0] > 0 else 1) if rcs[0] else 0
 
     def finish(ok):
         if ex is not None:
@@ -1007,7 +1051,7 @@ def main(argv=None):
                                 "(the %d-GPU aggregate would be %d x the slowest rank, less the all-gather latency)" % (R, W, W, W)}
         if cpu_base is not None:
             line["cpu_baseline"] = cpu_base
-        print(json.dumps(line), flush=True)
+        emit(line)
 
     if emu is not None:
         ex = None

@@ -102,3 +102,34 @@ def test_mgpu_one_device_equals_cfg3_fixture(hip):
     want_ct, want_tag = ctx.encrypt(iv, aad, pt)
     assert t1 == want_tag and bytes(small.download(3005)) == want_ct
     m.close(); buf.free()
+
+
+def test_launcher_ranks_without_rccl_hand_over_to_one_process(hip):
+    """Two ranks as an outside launcher would start them (RANK / WORLD_SIZE in the environment, no --one-device), both landing on GPU 0, where RCCL refuses to form
+    a communicator: the ranks must not measure through the file exchange -- rank 1 leaves with 0, rank 0 starts ONE fresh child over both devices
+    (aesgcm_mgpu_*) and relays it.  On a one-GPU box that child refuses ("the library sees 1 device(s)", exit code 2): the hand-over itself is what is checked
+    here; tests/test_gpu_multidevice.py checks the result on a box with two."""
+    import aesgcm_amd  # noqa: F401
+    from aesgcm_amd import lib
+    if lib.device_count() >= 2:
+        pytest.skip("two devices: RCCL comes up between the ranks (covered by test_gpu_multidevice.py)")
+    with tempfile.TemporaryDirectory(prefix="aesgcm_mp_") as rdzv:
+        procs = []
+        for r in range(2):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", AESGCM_RDZV_DIR=rdzv, MASTER_ADDR="127.0.0.1", MASTER_PORT="29556")
+            env.pop("AESGCM_SELF_LAUNCHED", None)
+            cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--gib-per-gpu", "0.25", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+            procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT))
+        outs = []
+        try:
+            for p in procs:
+                outs.append(p.communicate(timeout=900))
+        except subprocess.TimeoutExpired:
+            for p in procs:
+                p.kill()
+            pytest.fail("a rank did not finish within 900 s (killed)")
+    (so0, se0), (so1, se1) = outs
+    assert procs[1].returncode == 0, se1[-2000:]
+    assert "no RCCL communicator between the 2 processes" in se0 and "falling back to ONE process driving all 2 devices" in se0, se0[-3000:]
+    assert "the library sees 1 device(s)" in se0 and procs[0].returncode == 2, (procs[0].returncode, se0[-3000:])
+    assert not so0.strip(), so0                                   # no bench line claimed
