@@ -113,3 +113,77 @@ def test_fold_level_boundaries(hip, orc, body):
             assert bytes(d_in.download(n)) == want[0], (rows, n, al, body)
             if body and n >= 16 * 256 * 4:
                 assert ctx.split(n)[1] > 0
+
+
+def test_fuzz_packets_and_batches(hip, orc):
+    """Randomized: many packets under one key (aesgcm_packets_crypt_dev) and with a key each (aesgcm_batch_crypt_var_dev) -- count, length mix (empty, ragged,
+    MACsec-sized, a few long ones), AAD, fixed records or offset arrays with aligned or arbitrary starts, every kernel shape (forced through the debug build) or
+    the library's own, taken in array order or by length class; encrypt, then decrypt in place with a few forged tags.  A sample of packets against the oracle."""
+    import struct
+    rng = random.Random(20260102)
+    shapes = {"wave": 64, "group16": 16, "g8": 8, "g4": 4, "lane": 1}
+
+    def up(b):
+        d = hip.DeviceBuffer(max(len(b), 16)); d.upload(b); return d
+    with hip.debug_library() as dbg:
+        for it in range(150):
+            per_key = it % 3 == 2
+            klen = rng.choice((16, 24, 32))
+            m = rng.choice((1, 7, 63, 64, 65, 300, 1000, 4097, 9000))
+            mix = rng.choice(("macsec", "tiny", "ragged", "long"))
+            def one():
+                if mix == "macsec":
+                    return rng.choice((0, 46, 64, 128, 500, 1000, 1500, 1514, rng.randrange(0, 1515)))
+                if mix == "tiny":
+                    return rng.choice((0, 1, 15, 16, 17, 31, 32, 48))
+                if mix == "ragged":
+                    return rng.randrange(0, 700)
+                return rng.choice((64, 1000, 4096, 9000, 70000 if m <= 300 else 5000))
+            align = rng.choice((True, False))
+            lens = [one() for _ in range(m)]
+            if align:
+                lens = [x // 16 * 16 for x in lens]
+            aads = [rng.choice((0, 0, 8, 20, 28, 41)) for _ in range(m)]
+            doff, aoff = [0], [0]
+            for a, b in zip(lens, aads):
+                doff.append(doff[-1] + a); aoff.append(aoff[-1] + b)
+            key = splitmix_bytes(30000 + it, klen)
+            keys = splitmix_bytes(31000 + it, klen * m) if per_key else key * m
+            ivs, aad, pt = splitmix_bytes(32000 + it, 12 * m), splitmix_bytes(33000 + it, max(aoff[-1], 16)), splitmix_bytes(34000 + it, max(doff[-1], 16))
+            order = rng.choice((0, 1))
+            shape = rng.choice((None,) + tuple(shapes))
+            d_ivs, d_aad, d_buf = up(ivs), up(aad), up(pt)
+            d_doff, d_aoff = up(struct.pack("<%dQ" % (m + 1), *doff)), up(struct.pack("<%dQ" % (m + 1), *aoff))
+            d_tags, d_auth = hip.DeviceBuffer(16 * m), hip.DeviceBuffer(4 * m)
+            if per_key:
+                d_keys = up(keys)
+                dbg.force(batch_lanes={None: 0, "wave": 64, "group16": 16, "g8": 8, "g4": 8, "lane": 16}[shape], batch_order=2 - order)
+
+                def crypt(dec, d_exp=None):
+                    hip.batch_crypt_var_dev(dec, m, klen, d_keys.ptr, d_ivs.ptr, d_buf.ptr, d_doff.ptr, d_buf.ptr, d_tags.ptr, d_aad=d_aad.ptr, d_aad_off=d_aoff.ptr,
+                                            d_expect_tags=d_exp.ptr if d_exp else None, d_auth=d_auth.ptr if d_exp else None)
+            else:
+                ctx = hip.Context(key).set_option("pkt_order", order)
+                dbg.force(pkt_lanes=shapes.get(shape, 0), batch_lanes=0, batch_order=0)
+
+                def crypt(dec, d_exp=None):
+                    ctx.packets_crypt_dev(dec, m, d_ivs.ptr, d_buf.ptr, d_buf.ptr, d_tags.ptr, d_data_off=d_doff.ptr, d_aad=d_aad.ptr, d_aad_off=d_aoff.ptr,
+                                          d_expect_tags=d_exp.ptr if d_exp else None, d_auth=d_auth.ptr if d_exp else None)
+            crypt(False)
+            hip.dev_sync()
+            ct, tags = bytes(d_buf.download(max(doff[-1], 16)))[:doff[-1]], bytes(d_tags.download())
+            what = (it, "key each" if per_key else "one key", klen, m, mix, align, order, shape)
+            for p in sorted(set(rng.sample(range(m), min(m, 120))) | {0, m - 1}):
+                f = orc.Fast(keys[klen * p:klen * (p + 1)])
+                want = f.encrypt(ivs[12 * p:12 * p + 12], aad[aoff[p]:aoff[p + 1]], pt[doff[p]:doff[p + 1]])
+                assert (ct[doff[p]:doff[p + 1]], tags[16 * p:16 * p + 16]) == want, what + (p, lens[p], aads[p])
+            forged = sorted(set(rng.sample(range(m), min(m, 3))))
+            bad = bytearray(tags)
+            for p in forged:
+                bad[16 * p + rng.randrange(16)] ^= 1 << rng.randrange(8)
+            d_exp = up(bytes(bad))
+            crypt(True, d_exp)
+            hip.dev_sync()
+            assert bytes(d_buf.download(max(doff[-1], 16)))[:doff[-1]] == pt[:doff[-1]], what
+            auth = struct.unpack("<%di" % m, bytes(d_auth.download()))
+            assert [i for i, a in enumerate(auth) if not a] == forged, what
