@@ -24,6 +24,7 @@
 #include "aesgcm_dev.h"
 #include "../../include/aesgcm.h"
 
+#include <algorithm>
 #include <mutex>
 #include <new>
 #include <stddef.h>
@@ -1398,9 +1399,10 @@ struct aesgcm_ctx {
     bool fold_close = true;            // whole messages through the dealt k_body: k_fold's first level closes the tag (FoldClose; option "fold_close" 0: further levels and k_combine)
     u32 cyc_prio = 2;                  // rows between rotations of the waves' issue priorities in a cyclic launch (body_prio; option "cyc_prio", 0 = off).  Without it the oldest wave of
                                        // every SIMD runs ahead and the youngest finishes alone: 256 MiB 321 -> 291 us, 1 GiB 1238 -> 1105 (dealt chunks: 1090), profiles/r03c/cyc_prio_*.txt
-    bool cyc_half = false;             // option "cyc_half": whole messages of cyc_half_min .. cyc_half_max bytes take the HALF shape of the cyclic rows (k_bodyh: 256 workgroups of 512 lanes,
-                                       // two per CU) -- for callers that keep two or more messages in flight on contexts of their own, where one message's staging and closing
-                                       // then run beside another's rows; alone on the chip the half shape is slower than the full one
+    int cyc_half = 2;                  // option "cyc_half": whole messages below cyc_half_max bytes take the HALF shape of the cyclic rows (k_bodyh: 256 workgroups of 512 lanes, two per
+                                       // CU) -- for callers that keep two or more messages in flight on contexts of their own, where one message's staging and closing then run
+                                       // beside another's rows; alone on the chip the half shape is slower than the full one.  0 = never, 1 = always, 2 (default) = when another
+                                       // context of the device has a message under way at the moment of the call (others_in_flight)
     u64 cyc_half_max = (u64)80 << 20;  // sustained GiB/s, AES-256, full shape with 2 in flight / half shape with 3 (profiles/r04/inflight_threshold.txt): 8 MiB 409 / 562, 24 MiB 677 / 797,
                                        // 32 MiB 730 / 816, 48 MiB 810 / 836, 64 MiB 828 / 846, 96 MiB 870 / 862, 128 MiB 877 / 867 -- the two-table round costs what the overlap buys from there
     bool cyc_fuse = true;              // whole messages: the cyclic launch closes the tag itself (option "cyc_close" 0: k_fold + k_combine behind it, as for shards and streaming chunks)
@@ -1698,6 +1700,19 @@ static bool cyc_capable(const aesgcm_ctx *c) {
     return false;
 #endif
 }
+// Is a message of ANOTHER context of this device under way right now?  Every result goes to its context's pinned host slot with the generation number of its
+// launch behind it, so "under way" is: the slot does not show the generation last launched.  What the half shape of the cyclic rows is for (two messages
+// share every CU); asked once per whole-message launch, a mutex and a few loads.  Contexts register in ctx_create_common and leave in aesgcm_ctx_destroy.
+static std::vector<aesgcm_ctx *> g_ctxs;
+static bool others_in_flight(const aesgcm_ctx *c) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (const aesgcm_ctx *o : g_ctxs) {
+        if (o == c || o->device != c->device || !o->h_tag) continue;
+        const u64 launched = __atomic_load_n(&o->tag_gen, __ATOMIC_RELAXED);
+        if (__atomic_load_n(reinterpret_cast<const u64 *>(o->h_tag + 1), __ATOMIC_RELAXED) != launched) return true;
+    }
+    return false;
+}
 static int enqueue_cyc(aesgcm_ctx *c, int mode, const uint8_t iv[12], const void *d_aad, u64 aad_len, const void *d_in, u64 len, void *d_out,
                        u64 first_block, hipStream_t st, Partials *po, bool *took, bool whole_message_tag = false) {
     *took = false;
@@ -1711,7 +1726,7 @@ static int enqueue_cyc(aesgcm_ctx *c, int mode, const uint8_t iv[12], const void
     // profiles/r03c/general_shape.txt): for those the cyclic launch stays ahead for longer
     const bool pieces = aad_len || (first_block & 255) || (len & 1023);
     const u64 lo = fused ? c->cyc_min_fused : c->cyc_min, hi = pieces ? c->cyc_max_pieces : fused ? c->cyc_max_fused : c->cyc_max;
-    const bool half = fused && c->cyc_half && len < c->cyc_half_max;             // two workgroups per CU: for messages in flight beside each other
+    const bool half = fused && len < c->cyc_half_max && (c->cyc_half == 1 || (c->cyc_half == 2 && others_in_flight(c)));   // two workgroups per CU: for messages in flight beside each other
     if (!plan_body_cyc(p, mode, iv, d_aad, aad_len, d_in, len, d_out, first_block, c->parts, lo, hi, half ? BODY_CYC_WAVES_HALF : BODY_CYC_WAVES)) return AESGCM_OK;
     *took = true;
     *po = Partials();
@@ -1977,6 +1992,7 @@ static int ctx_create_common(aesgcm_ctx **out, int device, const uint8_t *key, s
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     hipFree(d_key);
     if (e != hipSuccess) { aesgcm_ctx_destroy(c); return hip_fail(e, "k_setup"); }
+    { std::lock_guard<std::mutex> lk(g_mu); g_ctxs.push_back(c); }
     *out = c;
     return AESGCM_OK;
 }
@@ -1991,6 +2007,7 @@ int aesgcm_ctx_create_preexpanded(aesgcm_ctx **out, int device, const uint8_t *r
 }
 int aesgcm_ctx_destroy(aesgcm_ctx *c) {
     if (!c) return AESGCM_OK;
+    { std::lock_guard<std::mutex> lk(g_mu); g_ctxs.erase(std::remove(g_ctxs.begin(), g_ctxs.end(), c), g_ctxs.end()); }
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto &e : c->ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
@@ -2030,7 +2047,7 @@ int aesgcm_ctx_set_option(aesgcm_ctx *c, const char *key, int64_t value) {
     }
     else if (!strcmp(key, "cyc_min")) c->cyc_min = c->cyc_min_fused = v;               // bytes: ranges in [cyc_min, cyc_max) take k_body's cyclic rows; both 0 = never
     else if (!strcmp(key, "cyc_max")) c->cyc_max = c->cyc_max_pieces = c->cyc_max_fused = v;
-    else if (!strcmp(key, "cyc_half")) c->cyc_half = v != 0;                           // 1: whole messages below 80 MiB as k_bodyh (two workgroups per CU: for several messages in flight)
+    else if (!strcmp(key, "cyc_half")) { if (v > 2) return AESGCM_EARG; c->cyc_half = (int)v; }   // whole messages below 80 MiB as k_bodyh (two workgroups per CU): 0 never, 1 always, 2 when another context has a message under way
     else if (!strcmp(key, "cyc_close")) c->cyc_fuse = v != 0;                          // 1: a whole message's cyclic launch closes the tag itself; 0: k_fold + k_combine behind it
     else if (!strcmp(key, "fold_close")) c->fold_close = v != 0;                       // 1: behind the dealt k_body the first (or second) k_fold level closes the tag
     else if (!strcmp(key, "cyc_prio")) c->cyc_prio = (u32)v;                           // rows between rotations of the waves' issue priorities in a cyclic launch (0 = off)

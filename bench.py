@@ -468,9 +468,9 @@ def run_inflight(args, dev):
     iv0 = sharding.splitmix64_bytes(IV_SEED, 12)
     ivs = [iv0[:8] + r.to_bytes(4, "big") for r in range(R)]
     ctxs = [lib.Context(key, device=dev) for _ in range(K)]
-    half = (K >= 2) if args.half < 0 else bool(args.half)
     for c in ctxs:
-        c.set_option("cyc_half", int(half))
+        if args.half >= 0:
+            c.set_option("cyc_half", args.half)                  # 0 / 1: never / always; else the library's own rule (half when another context has a message under way)
         for kv in args.opt:
             k, v = kv.split("=", 1)
             c.set_option(k, int(v, 0))
@@ -529,7 +529,7 @@ def run_inflight(args, dev):
         "ms_per_step": round(dt / steps * 1e3, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": "custom: AES-%d-GCM messages of %d bytes under one key, %d queued (contexts rotate, tag = NULL, tags collected one turn late through "
                                "the host slot), ring of %d message buffers = %.3g GiB, SplitMix64 PT seed 0xAE5C0003, empty AAD" % (key_bits, size, K, R, size * R / GiB),
-                   "bytes_per_message": size, "inflight": K, "ring": R, "half_shape": half, "context_options": args.opt, "parallelism": "single", "key_bits": key_bits, "us_per_message": round(dt / steps * 1e6, 2)},
+                   "bytes_per_message": size, "inflight": K, "ring": R, "half_shape": {-1: "library rule (when another context has a message under way)", 0: "never", 1: "always"}[args.half], "context_options": args.opt, "parallelism": "single", "key_bits": key_bits, "us_per_message": round(dt / steps * 1e6, 2)},
         "tag_ok": bad[0] == 0, "tags_checked": steps + warm, "tags_wrong": bad[0],
         "roofline": {"bound": "hbm", "kernel": "%s<%d,ENC> (fused AES-CTR + GHASH), one message at a time" % ("k_body" if body_blocks else "k_main", key_bits // 32 + 6),
                      "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_BYTES_PER_S, 4),
@@ -689,7 +689,7 @@ def main(argv=None):
     ap.add_argument("--ring-gib", type=float, default=1.0, help="--inflight: total plaintext in the ring of message buffers")
     ap.add_argument("--half", type=int, default=-1, choices=(-1, 0, 1),
                     help="--inflight: the cyclic rows in their half shape (context option cyc_half: 256 workgroups of 512 lanes, two per CU, so that one message's "
-                         "staging and closing run beside another's rows); -1 = on for K >= 2, off for K = 1")
+                         "staging and closing run beside another's rows): 1 always, 0 never, -1 (default) the library's own rule -- half when another context has a message under way")
     ap.add_argument("--batch-lanes", type=int, default=0, choices=(0, 8, 16, 64),
                     help="cfg5, A/B runs only: force the lanes per packet (k_batch3 with 8 / 16, k_batch with 64) -- through the DEBUG build of the library "
                          "(libaesgcm_hip_dbg.so, include/aesgcm_debug.h); the line then says so and is not a product measurement")

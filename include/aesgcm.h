@@ -110,9 +110,10 @@ AESGCM_API int aesgcm_ctx_device(const aesgcm_ctx *ctx);
  *   "body_min"    bytes from which a range's aligned middle goes through k_body's dealt chunks (>= 2^60: never, nor cyclic rows)
  *   "cyc_min", "cyc_max"   bytes: ranges in [cyc_min, cyc_max) take k_body's cyclic rows (one launch per message); both 0 = never
  *   "cyc_close"   1: that launch closes the tag itself; 0: k_fold + k_combine behind it
- *   "cyc_half"    1: whole messages below 80 MiB take the launch in its half shape (256 workgroups of 512 lanes, two per CU): for callers
- *                 that keep two or more messages in flight on contexts of their own -- one message's table staging and closing then run
- *                 beside another's rows; a single message alone on the chip is slower that way (default 0)
+ *   "cyc_half"    whole messages below 80 MiB take the launch in its half shape (256 workgroups of 512 lanes, two per CU), in which one message's
+ *                 table staging and closing run beside another's rows: 0 never, 1 always, 2 (default) when another context of the device has a
+ *                 message under way at the moment of the call (its host slot does not yet show its last launch) -- i.e. for callers that keep
+ *                 messages in flight on contexts of their own; a single message alone on the chip is slower in that shape
  *   "fold_close"  1: behind the dealt k_body a k_fold level closes the tag; 0: further levels and k_combine
  *   "cyc_prio"    rows between rotations of the waves' issue priorities in a cyclic launch, 0 = off
  *   "pkt_order"   packets from which aesgcm_packets_crypt_dev with offset arrays takes the packets by falling length class (a counting sort on the
