@@ -1502,6 +1502,7 @@ struct BatchParams {
     const u64 *data_off;         // n_pkts + 1 byte offsets into in/out: packet p = [data_off[p], data_off[p+1])
     const u64 *aad_off;          // n_pkts + 1 byte offsets into aad (or NULL = no AAD)
     const u32 *perm;             // variable-length form: the order in which the launch takes the packets (by falling length class, k_len_*), or NULL = as they come
+    u32 plain;                   // k_batch3: fixed-size aligned records of a whole number of wave-iterations, no AAD: the loop without padding / AAD / ragged-block tests
 };
 HD u32 batch_map(const BatchParams &p, u32 i) { return p.perm ? p.perm[i] : i; }
 

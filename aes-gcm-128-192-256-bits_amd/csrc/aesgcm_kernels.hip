@@ -1084,6 +1084,23 @@ __global__ __launch_bounds__(BATCH3_LANES(NR), (BATCH3_LANES(NR) + 255) / 256) v
         // ---- one pass: CTR on the lane's blocks and Horner over its slots
         G128 acc; acc.w[0] = acc.w[1] = acc.w[2] = acc.w[3] = 0;
         const CtrConsts cc = ctr_round1_consts(iv0, iv1, iv2, rk, smem, lb);
+        // Records of one size that is a whole number of wave-iterations, no AAD, aligned (cfg5's shape): no padding slot, no AAD slot, no ragged block -- the
+        // same work without the per-iteration tests and masks of the general loop below (launch-uniform: BatchParams::plain)
+        if (p.plain) {
+            const unsigned char *src = in + 16u * l;
+            unsigned char *dst = out + 16u * l;
+            for (u32 k = 0; k < iters; k++) {
+                if (k) acc = PAIR ? batch3_mul_pair(acc, smem, tabA, tabAp, pair_first) : BATCH3_MUL(acc, smem, tabA);
+                const uint4 x = gload16(src);
+                u32 s0, s1, s2, s3;
+                ctr_rounds_lds<NR>(bswap32(2u + k * G + l), cc, s0, s1, s2, s3, rk, smem, lb);
+                const uint4 y = make_uint4(x.x ^ s0, x.y ^ s1, x.z ^ s2, x.w ^ s3);
+                if (act) gstore16(dst, y);
+                const G128 b = mo_to_be(DEC ? x : y);                // aes_gcm.vhd:207-211
+                acc.w[0] ^= b.w[0]; acc.w[1] ^= b.w[1]; acc.w[2] ^= b.w[2]; acc.w[3] ^= b.w[3];
+                src += 16u * G; dst += 16u * G;
+            }
+        } else
         for (u32 k = 0; k < iters; k++) {
             if (k) acc = PAIR ? batch3_mul_pair(acc, smem, tabA, tabAp, pair_first) : BATCH3_MUL(acc, smem, tabA);
             const u32 v = k * G + l;
@@ -2661,6 +2678,7 @@ static int batch_launch(int device, int decrypt, size_t n_pkts, size_t key_len, 
             oslot = &ds->order[ds->order_next++ & 3u];
             if ((rc = order_launch(*oslot, p.data_off, n_pkts, st, &p.perm))) return rc;
         }
+        p.plain = !p.data_off && !p.aad_off && !p.aad_len && p.aligned && p.pkt_len && p.pkt_len % (16u << lg) == 0;
         const u32 waves_per_wg = (u32)BATCH3_LANES(nr) / 64;
         const u32 P = 64u >> lg, per_wg = waves_per_wg * P;
         wgs = (u32)((n_pkts + per_wg - 1) / per_wg);
