@@ -81,7 +81,7 @@ pmc_<tag>.json, stats_run.json}`, the bench lines of the same call in `%s/bench_
 `profiles/adopt_collection.sh`, table by `profiles/collection_table.py`, these lines by `profiles/refresh_docs.py`;
 `profiles/pmc_cfg{2,3,5}_n1.json` are copies of this collection's, so `bench.py` reports `roofline.traffic` on this build).  Boxes
 differ by their clock under load: this one ran cfg3 at %.1f GiB/s (sclk %s MHz); the same kernel measured between 933 and
-980.5 on the boxes of this round's collections (calls 12, 16, 22, 29, 35, 39, 42; sclk 1981 .. 2104).  The last column is algorithmic bytes / kernel
+980.5 on the boxes of this round's collections (calls 12, 16, 22, 29, 35, 39, 42; sclk 1976 .. 2104).  The last column is algorithmic bytes / kernel
 time under the profiler / 8 TB/s.
 
 %s
