@@ -65,6 +65,19 @@ HD void gstore16(void *p, uint4 v) {
     gvec4_t w = {v.x, v.y, v.z, v.w};
     *(__attribute__((address_space(1))) gvec4_t *)(uintptr_t)p = w;
 }
+// ... at ANY byte address (packets packed back to back start wherever the previous one ended).  The target runs with unaligned access mode on (the compiler
+// itself emits global_load_dwordx4 for an align-1 vector), so a whole block is one access whatever its address; only what is shorter than a block goes
+// byte by byte.  Round 4: 2^20 packed frames under one key 133 -> 673 GiB/s (profiles/r04/packets_sweep_packed_*.txt) -- sixteen byte loads and sixteen byte
+// stores per block before.
+typedef u32 gvec4u_t __attribute__((ext_vector_type(4), aligned(1)));
+HD uint4 gload16_any(const void *p) {
+    const gvec4u_t v = *(const __attribute__((address_space(1))) gvec4u_t *)(uintptr_t)p;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+HD void gstore16_any(void *p, uint4 v) {
+    gvec4u_t w = {v.x, v.y, v.z, v.w};
+    *(__attribute__((address_space(1))) gvec4u_t *)(uintptr_t)p = w;
+}
 // ... written THROUGH the XCD's L2 to memory (sc0 sc1): the line does not stay dirty in the L2, so nothing of it is left for a write-back at the end
 // of the launch -- or, in a launch that publishes its result from inside (k_body's fused closing), before the result may be shown.  `base` is
 // wave-uniform, `off` the lane's byte offset.  The s_nop covers the store-data hazard the compiler cannot see inside
@@ -83,6 +96,8 @@ HD void gstore1_wt_at(void *p, u32 v) { asm volatile("global_store_byte %0, %1, 
 #else
 HD uint4 gload16(const void *p) { return *reinterpret_cast<const uint4 *>(p); }
 HD void gstore16(void *p, uint4 v) { *reinterpret_cast<uint4 *>(p) = v; }
+HD uint4 gload16_any(const void *p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }
+HD void gstore16_any(void *p, uint4 v) { __builtin_memcpy(p, &v, 16); }
 HD void gstore16_wt(unsigned char *base, u32 off, uint4 v) { *reinterpret_cast<uint4 *>(base + off) = v; }
 HD void gstore16_wt_at(void *p, uint4 v) { *reinterpret_cast<uint4 *>(p) = v; }
 HD void gstore4_wt_at(void *p, u32 v) { *reinterpret_cast<u32 *>(p) = v; }
@@ -1816,19 +1831,19 @@ HD uint4 pktg_lane(const KeyMaterial *__restrict__ km, const PktParams &p, const
         uint4 gin;
         if (j < n_aad) {
             const u32 off = 16 * j, rem = q.aad_len - off;
-            gin = load_block_bytes(p.aad + q.aoff + off, rem < 16 ? rem : 16);
+            gin = rem >= 16 ? gload16_any(p.aad + q.aoff + off) : load_block_bytes(p.aad + q.aoff + off, rem);
         } else {
             const u32 i = j - n_aad, off = 16 * i, rem = q.pkt_len - off;
-            const bool full = aligned && rem >= 16;
+            const bool full = rem >= 16;                                                // a whole block is one access at any address (gload16_any)
             uint4 x;
-            if (full) x = gload16(src + off);
+            if (full) x = aligned ? gload16(src + off) : gload16_any(src + off);
             else x = load_block_bytes(src + off, rem < 16 ? rem : 16);
             u32 s0, s1, s2, s3;
             ctr_rounds_lds<NR>(bswap32(2u + i), cc, s0, s1, s2, s3, rk, smem, lb);     // aes_icb.vhd:97-118: counter 2 + i
             uint4 y = make_uint4(x.x ^ s0, x.y ^ s1, x.z ^ s2, x.w ^ s3);                // gcm_gctr.vhd:150
             if (rem < 16) y = mask_block(y, rem);
             if (act) {
-                if (full) gstore16(dst + off, y);
+                if (full) { if (aligned) gstore16(dst + off, y); else gstore16_any(dst + off, y); }
                 else store_block_bytes(dst + off, y, rem < 16 ? rem : 16);
             }
             gin = DEC ? x : y;                                                          // aes_gcm.vhd:207-211
@@ -1859,7 +1874,7 @@ HD uint4 pktg_tree_offer(uint4 acc, const unsigned char *smem, int j) { return g
 #endif
 // One LANE per packet (k_pktl): the shape for MACsec-sized frames, where a 64-block row per packet would leave
 // most lanes idle.  The lane runs the whole frame serially, as the reference core does (tb/gcm_test.py:76-85):
-// AAD blocks, data blocks (CTR from 2, aes_icb.vhd:97-118), the length block, Y = (Y ^ X) * H with the LDS
+// AAD blocks, data blocks (CTR from 2, aes_icb.vhd:97-118; whole blocks as one access at whatever byte address the packet starts: gload16_any), the length block, Y = (Y ^ X) * H with the LDS
 // nibble tables of H (main_fill_lds(GH_TAB_H)), tag = Y ^ E_K(IV || 1).  Nothing here is wave-uniform except the key.
 template <int NR, int DEC, bool T4 = false>
 HD void pktl_lane(const KeyMaterial *__restrict__ km, const PktParams &p, const unsigned char *smem, u32 pkt, u32 lane) {
@@ -1869,14 +1884,13 @@ HD void pktl_lane(const KeyMaterial *__restrict__ km, const PktParams &p, const 
     u64 doff = (u64)pkt * p.pkt_len, aoff = (u64)pkt * p.aad_len;
     if (p.data_off) { doff = p.data_off[pkt]; pkt_len = (u32)(p.data_off[pkt + 1] - doff); }
     if (p.aad_off) { aoff = p.aad_off[pkt]; aad_len = (u32)(p.aad_off[pkt + 1] - aoff); }
-    const bool aligned = p.aligned && ((doff & 15) == 0);
     const unsigned char *ivp = p.ivs + (size_t)pkt * 12;
     const CtrConsts cc = ctr_round1_consts(load_le32(ivp), load_le32(ivp + 4), load_le32(ivp + 8), rk, smem, lb);
     uint4 acc = make_uint4(0, 0, 0, 0);
     const unsigned char *a = p.aad + aoff;
     for (u32 left = aad_len; left; ) {
         const u32 nb = left < 16 ? left : 16;
-        acc = ghash_mul_const_lds(xor4(acc, load_block_bytes(a, nb)), smem);
+        acc = ghash_mul_const_lds(xor4(acc, nb == 16 ? gload16_any(a) : load_block_bytes(a, nb)), smem);
         a += nb; left -= nb;
     }
     const unsigned char *src = p.in + doff;
@@ -1895,12 +1909,12 @@ HD void pktl_lane(const KeyMaterial *__restrict__ km, const PktParams &p, const 
     // compiler from interleaving all eight blocks.  Measured, 2^20 packets under one key, same box (profiles/r04/pktl_768_ab.txt): HBM bytes = 1.000 - 1.005 x
     // algorithmic, encrypt and decrypt, 256 B ... 4 KiB (round 3: 1.41 x; decrypt until this change: 1.57 x); AES-256 encrypt 1 KiB 665 -> 679 GiB/s, 4 KiB 796
     // -> 823; decrypt 1 KiB 645 -> 662, 4 KiB 781 -> 750 (its register budget is full: 168).
-    while (aligned && left >= 128) {
+    while (left >= 128) {
         uint4 xa[4], xb[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) xa[k] = gload16(src + 16 * k);
+        for (int k = 0; k < 4; k++) xa[k] = gload16_any(src + 16 * k);
 #pragma unroll
-        for (int k = 0; k < 4; k++) xb[k] = gload16(src + 64 + 16 * k);
+        for (int k = 0; k < 4; k++) xb[k] = gload16_any(src + 64 + 16 * k);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             u32 s0, s1, s2, s3;
@@ -1924,19 +1938,19 @@ HD void pktl_lane(const KeyMaterial *__restrict__ km, const PktParams &p, const 
         // four, a tenth of a millisecond apart, 1.22 x; block by block 3.2 x -- the L2 turns over many times while a lane works through its line
         // (profiles/r04/pktl_store_ab.txt).
 #pragma unroll
-        for (int k = 0; k < 4; k++) gstore16(dst + 16 * k, xa[k]);
+        for (int k = 0; k < 4; k++) gstore16_any(dst + 16 * k, xa[k]);
 #pragma unroll
-        for (int k = 0; k < 4; k++) gstore16(dst + 64 + 16 * k, xb[k]);
+        for (int k = 0; k < 4; k++) gstore16_any(dst + 64 + 16 * k, xb[k]);
 #if defined(__HIP_DEVICE_COMPILE__)
         __builtin_amdgcn_sched_barrier(0);
 #endif
         src += 128; dst += 128; left -= 128; ctr += 8;
     }
 #endif
-    while (aligned && left >= 16 * AESGCM_PKTL_GROUP) {
+    while (left >= 16 * AESGCM_PKTL_GROUP) {
         uint4 x[AESGCM_PKTL_GROUP];
 #pragma unroll
-        for (int k = 0; k < AESGCM_PKTL_GROUP; k++) x[k] = reinterpret_cast<const uint4 *>(src)[k];
+        for (int k = 0; k < AESGCM_PKTL_GROUP; k++) x[k] = gload16_any(src + 16 * k);
 #pragma unroll
         for (int k = 0; k < AESGCM_PKTL_GROUP; k++) {
             u32 s0, s1, s2, s3;
@@ -1946,17 +1960,17 @@ HD void pktl_lane(const KeyMaterial *__restrict__ km, const PktParams &p, const 
             x[k] = y;
         }
 #pragma unroll
-        for (int k = 0; k < AESGCM_PKTL_GROUP; k++) reinterpret_cast<uint4 *>(dst)[k] = x[k];
+        for (int k = 0; k < AESGCM_PKTL_GROUP; k++) gstore16_any(dst + 16 * k, x[k]);
         src += 16 * AESGCM_PKTL_GROUP; dst += 16 * AESGCM_PKTL_GROUP; left -= 16 * AESGCM_PKTL_GROUP; ctr += AESGCM_PKTL_GROUP;
     }
     for (; left; ctr++) {
         const u32 nb = left < 16 ? left : 16;
-        const bool full = aligned && nb == 16;
-        const uint4 x = full ? *reinterpret_cast<const uint4 *>(src) : load_block_bytes(src, nb);
+        const bool full = nb == 16;
+        const uint4 x = full ? gload16_any(src) : load_block_bytes(src, nb);
         u32 s0, s1, s2, s3;
         ctr_rounds_lds<NR, T4>(bswap32(ctr), cc, s0, s1, s2, s3, rk, smem, lb);
         uint4 y = make_uint4(x.x ^ s0, x.y ^ s1, x.z ^ s2, x.w ^ s3);
-        if (full) *reinterpret_cast<uint4 *>(dst) = y;
+        if (full) gstore16_any(dst, y);
         else { y = mask_block(y, nb); store_block_bytes(dst, y, nb); }
         acc = ghash_mul_const_lds(xor4(acc, DEC ? x : y), smem);
         src += nb; dst += nb; left -= nb;

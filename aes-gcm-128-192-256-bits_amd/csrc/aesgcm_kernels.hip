@@ -1109,19 +1109,19 @@ __global__ __launch_bounds__(BATCH3_LANES(NR), (BATCH3_LANES(NR) + 255) / 256) v
             uint4 gin;
             if (j < n_aad) {
                 const u32 off = 16 * j, rem = aad_len - off;
-                gin = load_block_bytes(aad + off, rem < 16 ? rem : 16);
+                gin = rem >= 16 ? gload16_any(aad + off) : load_block_bytes(aad + off, rem);
             } else {
                 const u32 i = j - n_aad, off = 16 * i, rem = pkt_len - off;
-                const bool full = aligned && rem >= 16;
+                const bool full = rem >= 16;                    // a whole block is one access at any address
                 uint4 x;
-                if (full) x = gload16(in + off);
+                if (full) x = aligned ? gload16(in + off) : gload16_any(in + off);
                 else x = load_block_bytes(in + off, rem < 16 ? rem : 16);
                 u32 s0, s1, s2, s3;
                 ctr_rounds_lds<NR>(bswap32(2u + i), cc, s0, s1, s2, s3, rk, smem, lb);
                 uint4 y = make_uint4(x.x ^ s0, x.y ^ s1, x.z ^ s2, x.w ^ s3);
                 if (rem < 16) y = mask_block(y, rem);
                 if (act) {
-                    if (full) gstore16(out + off, y);
+                    if (full) { if (aligned) gstore16(out + off, y); else gstore16_any(out + off, y); }
                     else store_block_bytes(out + off, y, rem < 16 ? rem : 16);
                 }
                 gin = DEC ? x : y;                               // aes_gcm.vhd:207-211

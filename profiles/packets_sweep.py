@@ -6,7 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import aesgcm_amd  # noqa
 from aesgcm_amd import lib
 kb = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-var = len(sys.argv) > 2 and sys.argv[2] == "var"       # frames of mixed length (MACsec-shaped: 64 .. 1514 bytes, 16-byte aligned starts) through offset arrays
+var = len(sys.argv) > 2 and sys.argv[2] in ("var", "packed")       # frames of mixed length (MACsec-shaped: 64 .. 1514 bytes) through offset arrays: starts rounded up to 16 bytes,
+packed = len(sys.argv) > 2 and sys.argv[2] == "packed"             # or back to back as they come (starts at any byte)
 _dbg = lib.debug_library(); _dbg.__enter__()
 ctx = lib.Context(bytes(range(kb)))
 if len(sys.argv) > 3:
@@ -23,7 +24,7 @@ if var:
     print("AES-%d   n_pkts  mixed     wave  group16   group8   group4     lane     auto   (GiB/s; frames of 64 .. 1514 bytes, mean ~ 700%s)" % (kb * 8, "; " + sys.argv[3] if len(sys.argv) > 3 else "; by length class from 98304 packets"))
     lens = [rng.choice((64, 128, 256, 512, 1000, 1500, 1514, rng.randrange(64, 1515))) for _ in range(nmax)]
     off = [0]
-    for x in lens: off.append(off[-1] + (x + 15) // 16 * 16)
+    for x in lens: off.append(off[-1] + (x if packed else (x + 15) // 16 * 16))
     d_off = lib.DeviceBuffer(8 * (nmax + 1)); d_off.upload(struct.pack("<%dQ" % (nmax + 1), *off))
     d_pt, d_ct = lib.DeviceBuffer(off[-1] + 64), lib.DeviceBuffer(off[-1] + 64)
     d_pt.fill_splitmix64(3)
