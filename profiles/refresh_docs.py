@@ -36,6 +36,7 @@ i16, i64 = inflight(16), inflight(64)
 lat = {int(l.split()[0]): float(l.split()[1]) for l in open(os.path.join(D, "latency_c.txt")) if l.split() and l.split()[0].isdigit() and len(l.split()) == 3}
 pipe = float(re.search(r"chunk\s+64 MiB:.*?([\d.]+) GiB/s", open(os.path.join(D, "pipeline_time.txt")).read()).group(1))
 mixed = last_row("packets_sweep_mixed_aes256.txt", 1)[0]
+packed = last_row("packets_sweep_packed_aes256.txt", 1)[0]
 bm = last_row("batch_mixed_aes128.txt", 4)                  # array order, by class, library, lanes
 pl, pld = pmc("pktl_1k"), pmc("pktl_1k_dec")
 ALG_PKTL = 2**20 * (2048 + 28)
@@ -58,7 +59,7 @@ status = """## Status (round 4; one MI355X; every number from `profiles/%s/`, li
 | 16 MiB messages: waited / 2 / 3 in flight | %.0f / %.0f / **%.0f** | -- | 1.03 x | `inflight_sweep.txt`, `half_16m/` |
 | 64 MiB messages: waited / 2 / 3 in flight | %.0f / %.0f / %.0f | -- | 1.008 x | `inflight_sweep.txt`, `cyc_64m/` |
 | 2^20 x 1 KiB packets under one key, AES-256 (`k_pktl`), encrypt / decrypt | %.0f / %.0f | %.3f / %.3f | **1.00 x** (round 3: 1.41 x) | `pktl_768_ab.txt`, `pktl_1k/`, `pktl_1k_dec/` |
-| 2^20 frames of 64 .. 1514 bytes (offset arrays), one key AES-256 / a key each AES-128 | %.0f / %.0f (array order: 426 / %.0f) | -- | -- | `packets_sweep_mixed_aes256*.txt`, `batch_mixed_aes128.txt` |
+| 2^20 frames of 64 .. 1514 bytes (offset arrays), one key AES-256 / a key each AES-128; one key, packed back to back | %.0f / %.0f (array order: 426 / %.0f); %.0f (byte-wise blocks: 133) | -- | -- | `packets_sweep_mixed_aes256*.txt`, `batch_mixed_aes128.txt`, `packets_sweep_packed_aes256*.txt` |
 | 64 KiB message, waited call from C | %.1f us | -- | -- | `latency_c.txt` |
 | host memory to host memory, pipelined (PCIe-inclusive; never the metric) | %.1f (0.97 of the link's two-way rate, `pcie_probe.txt`) | -- | -- | `pipeline_time.txt` |
 | CPU beside it (libcrypto on the box's 16 cores / 1 core; pycryptodome is absent) | %.0f - %.0f / %.1f | -- | -- | `cpu_baseline` of the bench lines |
@@ -66,7 +67,7 @@ status = """## Status (round 4; one MI355X; every number from `profiles/%s/`, li
 Parity: %s GPU tests green (%s more skip without a second GPU)""" % (
     R, sha, RUN, b3["value"], b3["roofline"]["frac"], bd["value"], bd["roofline"]["frac"], b2["value"], b2["roofline"]["frac"],
     e0["value"], e0["value"] / b3["value"], e0["roofline"]["frac"], b5["value"], b5["roofline"]["frac"], b5d["value"], b5a["value"], b5d["roofline"]["frac"], b5a["roofline"]["frac"],
-    i16[1], i16[2], i16[3], i64[1], i64[2], i64[3], rate(pl), rate(pld), frac(pl), frac(pld), mixed, bm[2], bm[0], lat[65536], pipe, min(cpus), max(cpus), cpu1, tests.group(1), tests.group(2))
+    i16[1], i16[2], i16[3], i64[1], i64[2], i64[3], rate(pl), rate(pld), frac(pl), frac(pld), mixed, bm[2], bm[0], packed, lat[65536], pipe, min(cpus), max(cpus), cpu1, tests.group(1), tests.group(2))
 p = os.path.join(ROOT, "README.md")
 s = open(p).read()
 a, b = s.index("## Status (round 4;"), s.index(", 41 CPU tests;")
