@@ -99,7 +99,7 @@ HD void gstore16(void *p, uint4 v) { *reinterpret_cast<uint4 *>(p) = v; }
 HD uint4 gload16_any(const void *p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }
 HD void gstore16_any(void *p, uint4 v) { __builtin_memcpy(p, &v, 16); }
 HD void gstore16_wt(unsigned char *base, u32 off, uint4 v) { *reinterpret_cast<uint4 *>(base + off) = v; }
-HD void gstore16_wt_at(void *p, uint4 v) { *reinterpret_cast<uint4 *>(p) = v; }
+HD void gstore16_wt_at(void *p, uint4 v) { __builtin_memcpy(p, &v, 16); }
 HD void gstore4_wt_at(void *p, u32 v) { *reinterpret_cast<u32 *>(p) = v; }
 HD void gstore1_wt_at(void *p, u32 v) { *reinterpret_cast<unsigned char *>(p) = (unsigned char)v; }
 #endif
@@ -713,12 +713,7 @@ HD void fill_lds_t4(unsigned char *smem, const DevTables *tb, u32 tid, u32 nthre
 // block loads/stores with the ragged last block handled bytewise (gcm_ghash.vhd:225-246 byte-valid
 // mask = zero padding on the right; gcm_gctr.vhd:184 byte-valid passthrough on the data output)
 HD uint4 load_block_bytes(const unsigned char *p, u32 nbytes) {
-    // a whole block at a 4-byte aligned address (1500-byte frames, 20/28-byte headers: packets that are not a multiple
-    // of 16 bytes apart) goes as four dwords instead of sixteen byte loads
-    if (nbytes == 16 && (((uintptr_t)p) & 3) == 0) {
-        const u32 *q = reinterpret_cast<const u32 *>(p);
-        return make_uint4(q[0], q[1], q[2], q[3]);
-    }
+    if (nbytes == 16) return gload16_any(p);                       // a whole block: one access at any byte address (unaligned access mode, gload16_any)
     // fully unrolled with constant word indices: a loop over w[k >> 2] with a run-time trip count made the compiler keep the
     // four words in scratch memory (round-2 ISA: scratch_* inside the packet kernels' row loops)
     u32 w0 = 0, w1 = 0, w2 = 0, w3 = 0;
@@ -732,10 +727,8 @@ HD uint4 load_block_bytes(const unsigned char *p, u32 nbytes) {
     return make_uint4(w0, w1, w2, w3);
 }
 HD void store_block_bytes(unsigned char *p, uint4 v, u32 nbytes, bool wt = false) {      // wt: through the L2 (gstore16_wt)
-    if (nbytes == 16 && (((uintptr_t)p) & 3) == 0) {
-        u32 *q = reinterpret_cast<u32 *>(p);
-        if (wt) { gstore4_wt_at(q, v.x); gstore4_wt_at(q + 1, v.y); gstore4_wt_at(q + 2, v.z); gstore4_wt_at(q + 3, v.w); return; }
-        q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w;
+    if (nbytes == 16) {                                            // a whole block: one access at any byte address
+        if (wt) gstore16_wt_at(p, v); else gstore16_any(p, v);
         return;
     }
 #pragma unroll

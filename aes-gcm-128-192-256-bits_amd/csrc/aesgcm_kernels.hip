@@ -1720,7 +1720,7 @@ static bool cyc_capable(const aesgcm_ctx *c) {
 // Is a message of ANOTHER context of this device under way right now?  Every result goes to its context's pinned host slot with the generation number of its
 // launch behind it, so "under way" is: the slot does not show the generation last launched.  What the half shape of the cyclic rows is for (two messages
 // share every CU); asked once per whole-message launch, a mutex and a few loads.  Contexts register in ctx_create_common and leave in aesgcm_ctx_destroy.
-static std::vector<aesgcm_ctx *> g_ctxs;
+static std::vector<aesgcm_ctx *> &g_ctxs = *new std::vector<aesgcm_ctx *>();          // never destroyed: contexts may be destroyed after this library's static destructors have run
 static bool others_in_flight(const aesgcm_ctx *c) {
     std::lock_guard<std::mutex> lk(g_mu);
     for (const aesgcm_ctx *o : g_ctxs) {
