@@ -368,6 +368,19 @@ def test_plain_c_caller(hip):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("frames", [300, 200000])
+def test_plain_c_caller_frames(hip, frames):
+    """examples/frames.c: MACsec-shaped frames packed back to back under one key through aesgcm_packets_crypt_dev from C -- frame 0 is the reference's README
+    vector, one frame is checked against aesgcm_encrypt, all are decrypted in place and authenticated, a forged tag is reported.  300 frames take a lane
+    group each in array order, 200 000 the lane kernel in the order of the length classes."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "examples"), "-s", "frames"], check=True)
+    r = subprocess.run([os.path.join(root, "examples", "frames"), str(frames)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0 and "FRAMES OK" in r.stdout, (r.stdout, r.stderr)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("tw", ["", "1", "3", "cyc"])
 def test_body_split_forced_on_small_messages(hip, orc, tw):
     """The head / k_body / tail cut (aesgcm_ctx_split) normally starts at 256 MiB and the cyclic rows at 64 KiB; the context options
