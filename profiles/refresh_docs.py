@@ -89,7 +89,7 @@ time under the profiler / 8 TB/s.
 
 Bench lines of that call: cfg3 %.1f GiB/s (frac %.3f), decrypt %.1f, cfg2 %.1f (%.3f), cfg5 %.1f (%.3f), cfg5 decrypt %.1f, cfg5
 AES-256 %.1f, emulated rank steps %.1f / %.1f (%.3f / %.3f of the N = 1 step); `inflight_sweep.txt` (K = 1 .. 4: 16 MiB
-%.0f / %.0f / %.0f / %.0f, 64 MiB %.0f / %.0f / %.0f / %.0f GiB/s -- three in flight is the most the four hardware queues take),
+%.0f / %.0f / %.0f / %.0f, 64 MiB %.0f / %.0f / %.0f / %.0f GiB/s -- K = 4 and 8 fall on the runtime's stream-to-queue mapping: with GPU_MAX_HW_QUEUES = 8 four are as fast as three, and six are either way, `inflight_hw_queues.txt`),
 `inflight_sweep_half.txt`, `latency_c.txt` (64 KiB %.1f us, 1 MiB %.1f, 4 MiB %.1f), `size_sweep.txt`, `pipeline_time.txt` (host memory
 to host memory through the pipelined path: %.1f GiB/s page-locked at 64 MiB chunks), `packets_sweep_aes256.txt`,
 `packets_sweep_mixed_aes256.txt`, `batch_mixed_aes128.txt` (the packet shapes over count and size; frames of mixed length: 2^20 frames
