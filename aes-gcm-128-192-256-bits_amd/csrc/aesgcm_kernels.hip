@@ -12,6 +12,7 @@
 //                   (shards, streaming), length block, E_K(J0) -> tag.  k_combine_batch: up to 8 messages, one workgroup each.
 //   k_batch3<NR,DEC,LG>, k_batch   packets with their OWN key: 8 or 16 lanes per packet in one pass / one wave per packet.
 //   k_pktg<NR,DEC,LG>, k_pktl      packets under the context's key: 2^LG lanes per packet (4, 8, 16, 64) / one lane per packet.
+//   k_len_hist, k_len_scan, k_len_scatter   the order in which a launch takes packets of mixed length: a counting sort by falling length class.
 //   k_gfmul, k_fill_splitmix64, k_copy16   small utility kernels.
 //
 // GHASH re-association (DESIGN.md "GHASH as a polynomial"): the GHASH input sequence
