@@ -388,6 +388,55 @@ HD void ctr_rounds_lds(u32 ctr_be_word, const CtrConsts &k, u32 &s0, u32 &s1, u3
     aes_final_lds(s0, s1, s2, s3, rk + 4 * NR, lds, lb);
 }
 
+// NB counter blocks of one key and IV at once, round by round: first the 16 lookups of every block, then the folds -- NB independent chains whose LDS latencies
+// overlap inside ONE wave.  For kernels that run with few waves per SIMD (k_pktl's ILP form): there a wave has to cover the latency itself.
+template <int NR, bool T4, int NB>
+HD void ctr_rounds_lds_n(u32 ctr0, const CtrConsts &k, uint4 *out, const u32 *__restrict__ rk, const unsigned char *lds, u32 lb) {
+    u32 s[NB][4];
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        const u32 w3 = bswap32(ctr0 + (u32)b) ^ rk[3];
+        s[b][0] = k.c0 ^ rotl32(T2_AT(lds, w3, 3, lb), 8);
+        s[b][1] = k.c1 ^ T2_AT(lds, w3, 2, lb);
+        s[b][2] = k.c2 ^ rotl32(T0_AT(lds, w3, 1, lb), 8);
+        s[b][3] = k.c3 ^ T0_AT(lds, w3, 0, lb);
+    }
+    const u32 lb2 = lb | 0x10000u;
+#pragma unroll
+    for (int r = 2; r < NR; r++) {
+        u32 t[NB][16];
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const u32 s0 = s[b][0], s1 = s[b][1], s2 = s[b][2], s3 = s[b][3];
+            if (T4) {
+                t[b][0] = T0_AT(lds, s0, 0, lb); t[b][1] = T1_AT(lds, s1, 1, lb2); t[b][2] = T2_AT(lds, s2, 2, lb); t[b][3] = T3_AT(lds, s3, 3, lb2);
+                t[b][4] = T0_AT(lds, s1, 0, lb); t[b][5] = T1_AT(lds, s2, 1, lb2); t[b][6] = T2_AT(lds, s3, 2, lb); t[b][7] = T3_AT(lds, s0, 3, lb2);
+                t[b][8] = T0_AT(lds, s2, 0, lb); t[b][9] = T1_AT(lds, s3, 1, lb2); t[b][10] = T2_AT(lds, s0, 2, lb); t[b][11] = T3_AT(lds, s1, 3, lb2);
+                t[b][12] = T0_AT(lds, s3, 0, lb); t[b][13] = T1_AT(lds, s0, 1, lb2); t[b][14] = T2_AT(lds, s1, 2, lb); t[b][15] = T3_AT(lds, s2, 3, lb2);
+            } else {
+                t[b][0] = T0_AT(lds, s0, 0, lb); t[b][1] = T0_AT(lds, s1, 1, lb); t[b][2] = T2_AT(lds, s2, 2, lb); t[b][3] = T2_AT(lds, s3, 3, lb);
+                t[b][4] = T0_AT(lds, s1, 0, lb); t[b][5] = T0_AT(lds, s2, 1, lb); t[b][6] = T2_AT(lds, s3, 2, lb); t[b][7] = T2_AT(lds, s0, 3, lb);
+                t[b][8] = T0_AT(lds, s2, 0, lb); t[b][9] = T0_AT(lds, s3, 1, lb); t[b][10] = T2_AT(lds, s0, 2, lb); t[b][11] = T2_AT(lds, s1, 3, lb);
+                t[b][12] = T0_AT(lds, s3, 0, lb); t[b][13] = T0_AT(lds, s0, 1, lb); t[b][14] = T2_AT(lds, s1, 2, lb); t[b][15] = T2_AT(lds, s2, 3, lb);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const u32 *q = &t[b][4 * c];
+                s[b][c] = T4 ? xor3(xor3(q[0], q[1], q[2]), q[3], rk[4 * r + c]) : (xor3(q[0], q[2], rk[4 * r + c]) ^ rotl32(q[1] ^ q[3], 8));
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        u32 s0 = s[b][0], s1 = s[b][1], s2 = s[b][2], s3 = s[b][3];
+        aes_final_lds(s0, s1, s2, s3, rk + 4 * NR, lds, lb);
+        out[b] = make_uint4(s0, s1, s2, s3);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Hot loop piece 2: multiply the lane's GHASH accumulator by the launch constant K = H^(lane stride)
 // through tables in LDS: Y*K = xor_p T_p[group_p(Y)] (multiplication by a constant is GF(2)-linear -- the
@@ -1862,6 +1911,9 @@ HD uint4 pktg_tree_offer(uint4 acc, const unsigned char *smem, int j) { return g
 #ifndef AESGCM_PKTL_T4
 #define AESGCM_PKTL_T4 1                 /* k_pktl: four T-tables in LDS (141 KiB; it is one workgroup per CU by its registers anyway), no rotates in rounds 2 .. NR-1 (round 4) */
 #endif
+#ifndef AESGCM_PKTL_CHAINS
+#define AESGCM_PKTL_CHAINS 4              /* k_pktl's ILP form: keystream blocks computed side by side (two passes of four per 128-byte line) */
+#endif
 #ifndef AESGCM_PKTL_LINE
 #define AESGCM_PKTL_LINE 1               /* k_pktl: a lane fetches its packet's whole 128-byte line at once (round 4) */
 #endif
@@ -1869,7 +1921,7 @@ HD uint4 pktg_tree_offer(uint4 acc, const unsigned char *smem, int j) { return g
 // most lanes idle.  The lane runs the whole frame serially, as the reference core does (tb/gcm_test.py:76-85):
 // AAD blocks, data blocks (CTR from 2, aes_icb.vhd:97-118; whole blocks as one access at whatever byte address the packet starts: gload16_any), the length block, Y = (Y ^ X) * H with the LDS
 // nibble tables of H (main_fill_lds(GH_TAB_H)), tag = Y ^ E_K(IV || 1).  Nothing here is wave-uniform except the key.
-template <int NR, int DEC, bool T4 = false>
+template <int NR, int DEC, bool T4 = false, bool ILP = false>
 HD void pktl_lane(const KeyMaterial *__restrict__ km, const PktParams &p, const unsigned char *smem, u32 pkt, u32 lane) {
     const u32 *__restrict__ rk = km->rk;
     const u32 lb = (lane & 31u) << 2;
@@ -1902,6 +1954,23 @@ HD void pktl_lane(const KeyMaterial *__restrict__ km, const PktParams &p, const 
     // compiler from interleaving all eight blocks.  Measured, 2^20 packets under one key, same box (profiles/r04/pktl_768_ab.txt): HBM bytes = 1.000 - 1.005 x
     // algorithmic, encrypt and decrypt, 256 B ... 4 KiB (round 3: 1.41 x; decrypt until this change: 1.57 x); AES-256 encrypt 1 KiB 665 -> 679 GiB/s, 4 KiB 796
     // -> 823; decrypt 1 KiB 645 -> 662, 4 KiB 781 -> 750 (its register budget is full: 168).
+    // ILP (k_pktl<.., 1>: 512-lane workgroups, 256 registers; what the host takes while the packets do not fill the chip): the eight keystream blocks of a line
+    // as eight independent chains the compiler is free to interleave, then the eight multiplies.  With few waves per SIMD the wave itself must cover its LDS
+    // latency -- one chain at a time it runs at the same 4 us per block whether 12 waves share the CU or 4 (65536 x 1 KiB: 256 GiB/s by lanes, 390 by groups of 4).
+    while (ILP && left >= 128) {
+        uint4 x[8], ks[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) x[k] = gload16_any(src + 16 * k);
+        ctr_rounds_lds_n<NR, T4, AESGCM_PKTL_CHAINS>(ctr, cc, ks, rk, smem, lb);
+        ctr_rounds_lds_n<NR, T4, AESGCM_PKTL_CHAINS>(ctr + AESGCM_PKTL_CHAINS, cc, ks + AESGCM_PKTL_CHAINS, rk, smem, lb);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint4 y = xor4(x[k], ks[k]);
+            gstore16_any(dst + 16 * k, y);
+            acc = ghash_mul_const_lds(xor4(acc, DEC ? x[k] : y), smem);
+        }
+        src += 128; dst += 128; left -= 128; ctr += 8;
+    }
     while (left >= 128) {
         uint4 xa[4], xb[4];
 #pragma unroll

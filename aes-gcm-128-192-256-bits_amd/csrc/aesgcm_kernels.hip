@@ -1329,13 +1329,17 @@ __global__ __launch_bounds__(PKTG_WG(LG), (PKTG_WG(LG) + 255) / 256) void k_pktg
 #ifndef AESGCM_PKTL_WAVES
 #define AESGCM_PKTL_WAVES ((AESGCM_PKTL_WG + 255) / 256)          // waves per SIMD the register budget is sized for (one workgroup per CU)
 #endif
-template <int NR, int DEC>
-__global__ __launch_bounds__(AESGCM_PKTL_WG, AESGCM_PKTL_WAVES) void k_pktl(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const PktParams p) {
+// ILP = 1: the same lane code compiled for 512-lane workgroups (two waves per SIMD, 256 registers) with the eight keystream blocks of a line as independent
+// chains: for batches that do not fill the chip, where a wave has to hide its own LDS latency (pktl_lane, AESGCM_PKTL_WG_ILP).
+#define AESGCM_PKTL_WG_ILP 512
+template <int NR, int DEC, int ILP>
+__global__ __launch_bounds__(ILP ? AESGCM_PKTL_WG_ILP : AESGCM_PKTL_WG, ILP ? 2 : AESGCM_PKTL_WAVES) void k_pktl(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const PktParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr u32 WG = ILP ? AESGCM_PKTL_WG_ILP : AESGCM_PKTL_WG;
     const u32 tid = threadIdx.x, lane = tid & 63u;
-    main_fill_lds(smem, km, tb, tid, true, AESGCM_PKTL_WG, GH_TAB_H);
+    main_fill_lds(smem, km, tb, tid, true, WG, GH_TAB_H);
 #if AESGCM_PKTL_T4
-    fill_lds_t4(smem, tb, tid, AESGCM_PKTL_WG);
+    fill_lds_t4(smem, tb, tid, WG);
 #endif
     __syncthreads();
     const u32 nb = (p.n_pkts + 63u) / 64u;
@@ -1345,7 +1349,7 @@ __global__ __launch_bounds__(AESGCM_PKTL_WG, AESGCM_PKTL_WAVES) void k_pktl(cons
         b = __builtin_amdgcn_readfirstlane(b);
         if (b >= nb) break;
         const u32 idx = b * 64u + lane;
-        if (idx < p.n_pkts) pktl_lane<NR, DEC, AESGCM_PKTL_T4 != 0>(km, p, smem, pkt_map(p, idx), lane);
+        if (idx < p.n_pkts) pktl_lane<NR, DEC, AESGCM_PKTL_T4 != 0, ILP != 0>(km, p, smem, pkt_map(p, idx), lane);
     }
 }
 
@@ -1517,7 +1521,8 @@ static int set_lds_attrs(int device, DeviceState *ds) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktg<NR, D, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, PKTG_LDS_TOTAL(3))); \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktg<NR, D, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, PKTG_LDS_TOTAL(4))); \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktg<NR, D, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, PKTG_LDS_TOTAL(6))); \
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktl<NR, D>), hipFuncAttributeMaxDynamicSharedMemorySize, AESGCM_PKTL_LDS))
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktl<NR, D, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, AESGCM_PKTL_LDS)); \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktl<NR, D, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, AESGCM_PKTL_LDS))
     SETATTRB(10, 0); SETATTRB(12, 0); SETATTRB(14, 0); SETATTRB(10, 1); SETATTRB(12, 1); SETATTRB(14, 1);
 #undef SETATTRB
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_combine), hipFuncAttributeMaxDynamicSharedMemorySize, CMB_LDS_BYTES));
@@ -2482,13 +2487,14 @@ int aesgcm_stream_final(aesgcm_ctx *c, uint8_t tag[16]) {
 #ifdef AESGCM_DEBUG_KNOBS
 // Test / profiling builds only (libaesgcm_hip_dbg.so, -DAESGCM_DEBUG_KNOBS; include/aesgcm_debug.h): force the kernel shape the next launches take, so that every
 // shape can be checked on inputs the host's own rule would give to another.  The product library has no such switch and reads no environment.
-static struct { int pkt_lanes, pkt_deal, batch_lanes, batch_deal, batch_order; } g_force = {0, 0, 0, 0, 0};
+static struct { int pkt_lanes, pkt_deal, batch_lanes, batch_deal, batch_order, pkt_ilp; } g_force = {0, 0, 0, 0, 0, 0};
 extern "C" __attribute__((visibility("default"))) int aesgcm_debug_force_shape(const char *what, int value) {
     if (!what) return AESGCM_EARG;
     if (!strcmp(what, "pkt_lanes")) { if (value != 0 && value != 1 && value != 4 && value != 8 && value != 16 && value != 64) return AESGCM_EARG; g_force.pkt_lanes = value; }
     else if (!strcmp(what, "pkt_deal")) g_force.pkt_deal = value;
     else if (!strcmp(what, "batch_lanes")) { if (value != 0 && value != 8 && value != 16 && value != 64) return AESGCM_EARG; g_force.batch_lanes = value; }
     else if (!strcmp(what, "batch_deal")) g_force.batch_deal = value;
+    else if (!strcmp(what, "pkt_ilp")) { if (value < 0 || value > 2) return AESGCM_EARG; g_force.pkt_ilp = value; }              // k_pktl's ILP form: 0 = the library's rule, 1 = always, 2 = never
     else if (!strcmp(what, "batch_order")) { if (value < 0 || value > 2) return AESGCM_EARG; g_force.batch_order = value; }      // variable-length batches by length class: 0 = the library's rule, 1 = always, 2 = never
     else return AESGCM_EARG;
     return AESGCM_OK;
@@ -2510,8 +2516,10 @@ static int packets_pick_lg(u32 n_cu, size_t n_pkts, size_t pkt_len, bool var, bo
     // 131072 x 16 KiB 573 / 789, 131072 x 1 KiB 488 / 509 (196608: 677 / 577), 49152 x 256 B 142 / 124, 16384 x 64 B 28 / 23.
     // Offset arrays (the host does not know the lengths): as 1 KiB frames in array order (mixed 64 .. 1514 bytes: 131072 frames 243 by lanes / 277 by groups of
     // 4, 196608: 346 / 296); taken by length class the groups hold on longer (196608: 323 / 394, 262144: 421 / 429, 393216: 584 / 505).
+    // k_pktl's ILP form (512-lane workgroups) moves the 1 KiB mark down: 131072 x 1 KiB 592 by lanes against 500 by groups of 4, 98304: 454 / 456.
+    const size_t lanes_ilp = (size_t)n_cu * AESGCM_PKTL_WG_ILP;
     if (var ? (ordered ? 3 * n_pkts >= 4 * lanes_l : 4 * n_pkts >= 3 * lanes_l)
-            : (n_pkts >= lanes_l || (pkt_len <= 1024 && 4 * n_pkts >= 3 * lanes_l) || (pkt_len <= 256 && n_pkts >= 32768) || (pkt_len <= 64 && n_pkts >= 16384))) return 0;
+            : (n_pkts >= lanes_l || (pkt_len <= 1024 && 8 * n_pkts >= 7 * lanes_ilp) || (pkt_len <= 256 && n_pkts >= 32768) || (pkt_len <= 64 && n_pkts >= 16384))) return 0;
     // Lane groups: the group that just fills the resident lanes.  Packets of 4 KiB and more round the fill UP to a power of two (half again as many lanes as
     // are resident is cheaper than rows twice as long: 49152 x 4 KiB 474 with 4 lanes, 576 with 8; x 16 KiB 542 / 722), shorter ones down (49152 x 1 KiB 325 / 291).
     size_t fill = lanes_total / n_pkts;
@@ -2593,13 +2601,23 @@ int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const vo
     if (d_data_off) { const int rc = packets_order(c, (const u64 *)d_data_off, n_pkts, st, &p.perm, &oslot); if (rc) return rc; }
     if (shape == 'l') {
         const u32 nb = (u32)((n_pkts + 63) / 64);
-        const u32 waves_per_wg = AESGCM_PKTL_WG / 64;
-        u32 wgs = (nb + waves_per_wg - 1) / waves_per_wg;
+        // the ILP form (512-lane workgroups, eight independent keystream chains per line) while the packets fit one round of it; its workgroups are spread over
+        // all CUs, a wave of 64 packets each first
+        // Measured, AES-256, GiB/s 768-lane form / ILP form (profiles/r04/packets_sweep_ilp_aes256.txt): 1 KiB packets 16384 66 / 78, 65536 255 / 306, 131072 481 / 592;
+        // 256 B 32768 99 / 95, 98304 245 / 266, 131072 295 / 330; 64 B (no whole line to work on) 16384 27 / 19.
+        bool ilp = n_pkts <= (size_t)n_cu * AESGCM_PKTL_WG_ILP && (d_data_off || pkt_len >= 512 || (pkt_len >= 256 && n_pkts >= 49152));
+#ifdef AESGCM_DEBUG_KNOBS
+        if (g_force.pkt_ilp) ilp = g_force.pkt_ilp == 1;
+#endif
+        const u32 waves_per_wg = (ilp ? AESGCM_PKTL_WG_ILP : AESGCM_PKTL_WG) / 64;
+        u32 wgs = ilp ? nb : (nb + waves_per_wg - 1) / waves_per_wg;
         if (wgs > n_cu) wgs = n_cu;                                                  // one workgroup per CU (registers, and with four T-tables the LDS)
         c->counter_base += nb + wgs * waves_per_wg;                                 // every wave ends on one failing fetch
-#define LP(NR, D) hipLaunchKernelGGL((k_pktl<NR, D>), dim3(wgs), dim3(AESGCM_PKTL_WG), AESGCM_PKTL_LDS, st, c->km, c->tables, p)
+#define LPI(NR, D, I) hipLaunchKernelGGL((k_pktl<NR, D, I>), dim3(wgs), dim3(I ? AESGCM_PKTL_WG_ILP : AESGCM_PKTL_WG), AESGCM_PKTL_LDS, st, c->km, c->tables, p)
+#define LP(NR, D) do { if (ilp) LPI(NR, D, 1); else LPI(NR, D, 0); } while (0)
         if (decrypt) { if (c->nr == 10) LP(10, 1); else if (c->nr == 12) LP(12, 1); else LP(14, 1); }
         else         { if (c->nr == 10) LP(10, 0); else if (c->nr == 12) LP(12, 0); else LP(14, 0); }
+#undef LPI
 #undef LP
     } else {
         const u32 P = 64u >> lg;                                                    // packets per wave-iteration

@@ -88,7 +88,7 @@ class debug_library:
 
     def __exit__(self, *a):
         global _L
-        for k in ("pkt_lanes", "pkt_deal", "batch_lanes", "batch_deal", "batch_order"):
+        for k in ("pkt_lanes", "pkt_deal", "batch_lanes", "batch_deal", "batch_order", "pkt_ilp"):
             _DBG.aesgcm_debug_force_shape(k.encode(), 0)
         _L = self._prev
 

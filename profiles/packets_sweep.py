@@ -17,7 +17,7 @@ nmax = 1 << 20
 counts = sorted({1 << k for k in range(10, 21, 2)} | {1 << k for k in range(15, 19)} | {3 << (k - 1) for k in range(15, 19)})
 d_ivs = lib.DeviceBuffer(12 * nmax); d_ivs.fill_splitmix64(2, nbytes=12 * nmax // 8 * 8)
 d_tags = lib.DeviceBuffer(16 * nmax)
-print("AES-%d   n_pkts  pkt_B     wave  group16   group8   group4     lane     auto   (GiB/s)" % (kb * 8))
+print("AES-%d   n_pkts  pkt_B     wave  group16   group8   group4     lane     auto   (GiB/s)   lane: 768-lane form / ILP form" % (kb * 8))
 if var:
     import random, struct
     rng = random.Random(5)
@@ -55,5 +55,15 @@ for pkt in (64, 256, 1024, 4096, 16384):
                 ctx.packets_crypt_dev(False, n, d_ivs.ptr, d_pt.ptr, d_ct.ptr, d_tags.ptr, pkt_len=pkt)
                 lib.dev_sync(); best = min(best, time.perf_counter() - t0)
             row.append(n * pkt / best / (1 << 30))
-        print("        %8d %6d %8.1f %8.1f %8.1f %8.1f %8.1f %8.1f" % (n, pkt, *row), flush=True)
+        extra = []
+        for ilp in (2, 1):
+            _dbg.force(pkt_lanes=1, pkt_ilp=ilp)
+            best = 1e9
+            for it in range(4):
+                lib.dev_sync(); t0 = time.perf_counter()
+                ctx.packets_crypt_dev(False, n, d_ivs.ptr, d_pt.ptr, d_ct.ptr, d_tags.ptr, pkt_len=pkt)
+                lib.dev_sync(); best = min(best, time.perf_counter() - t0)
+            extra.append(n * pkt / best / (1 << 30))
+        _dbg.force(pkt_ilp=0)
+        print("        %8d %6d %8.1f %8.1f %8.1f %8.1f %8.1f %8.1f   %8.1f %8.1f" % (n, pkt, *row, *extra), flush=True)
     del d_pt, d_ct

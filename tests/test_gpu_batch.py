@@ -150,10 +150,12 @@ def test_variable_length_packets_macsec_shaped(hip, orc, batch_shape):
     assert set(struct.unpack("<%di" % n, bytes(d_auth.download()))) == {1}
 
 
-@pytest.mark.parametrize("shape", ["wave", "group16", "g8", "g4", "lane"])
+@pytest.mark.parametrize("shape", ["wave", "group16", "g8", "g4", "lane", "lane_ilp"])
 def test_packets_under_one_key(hip, orc, shape):
     with hip.debug_library() as dbg:
-        dbg.force(pkt_lanes=PKT_LANES[shape])
+        # one lane per packet has two forms: 768-lane workgroups with one keystream chain per lane, and (for batches that do not fill the chip) 512-lane
+        # workgroups with four chains side by side; a batch of this size would take the second by the library's own rule
+        dbg.force(pkt_lanes=PKT_LANES[shape.split("_")[0]], pkt_ilp={"lane": 2, "lane_ilp": 1}.get(shape, 0))
         _packets_under_one_key(hip, orc)
 
 
