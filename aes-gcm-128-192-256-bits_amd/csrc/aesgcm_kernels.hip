@@ -2605,7 +2605,10 @@ int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const vo
         // all CUs, a wave of 64 packets each first
         // Measured, AES-256, GiB/s 768-lane form / ILP form (profiles/r04/packets_sweep_ilp_aes256.txt): 1 KiB packets 16384 66 / 78, 65536 255 / 306, 131072 481 / 592;
         // 256 B 32768 99 / 95, 98304 245 / 266, 131072 295 / 330; 64 B (no whole line to work on) 16384 27 / 19.
-        bool ilp = n_pkts <= (size_t)n_cu * AESGCM_PKTL_WG_ILP && (d_data_off || pkt_len >= 512 || (pkt_len >= 256 && n_pkts >= 49152));
+        // Packets shorter than two lines gain from it only once they fill the chip (fewer, fatter waves): 196608 x 256 B 380 / 414, 262144 442 / 460 (2^20: 682 / 642);
+        // 64 B 196608 127 / 146, 393216 183 / 201, 2^20 254 / 266.
+        bool ilp = n_pkts <= (size_t)n_cu * AESGCM_PKTL_WG_ILP ? (d_data_off || pkt_len >= 512 || (pkt_len >= 256 && n_pkts >= 49152))
+                                                                : (!d_data_off && n_pkts >= (size_t)n_cu * AESGCM_PKTL_WG && (pkt_len <= 64 || (pkt_len <= 256 && n_pkts <= 300000)));
 #ifdef AESGCM_DEBUG_KNOBS
         if (g_force.pkt_ilp) ilp = g_force.pkt_ilp == 1;
 #endif
