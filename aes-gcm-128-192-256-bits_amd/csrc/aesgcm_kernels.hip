@@ -1444,6 +1444,7 @@ struct aesgcm_ctx {
     uint4 *d_tag = nullptr;            // [0] tag / poly result, [1] streaming state Y
     u64 *d_trace = nullptr;            // per-workgroup trace of the last k_main launch (timing mode only)
     u32 last_np = 0;
+    uint8_t *d_keystage = nullptr;     // 256 bytes: where a key (or schedule) waits for k_setup; zeroed behind it
     hipStream_t stream = nullptr;
     hipEvent_t ev_sync = nullptr;      // aesgcm_ctx_wait: marks "everything enqueued so far on this context's stream"
     hipEvent_t ev_fused = nullptr;     // aesgcm_ctx_wait_fused: recorded behind every fused-kernel launch once somebody has asked for it
@@ -1969,6 +1970,24 @@ int aesgcm_device_name(int device, char *buf, size_t buflen) {
     return AESGCM_OK;
 }
 
+// Key material of a context from a key (or a pre-expanded schedule): aes_kexp, H, the H-power tables -- k_setup and k_setup_ptab on the context's stream, waited
+// for.  The staging buffer for the key bytes belongs to the context (aesgcm_ctx_rekey comes through here without an allocation) and is wiped behind the kernels.
+static int ctx_load_key(aesgcm_ctx *c, const uint8_t *key, size_t key_len, int pre_nr) {
+    hipError_t e;
+    if (!c->d_keystage && (e = hipMalloc((void **)&c->d_keystage, 256)) != hipSuccess) return hip_fail(e, "hipMalloc");
+    const size_t kb = pre_nr ? (size_t)16 * (pre_nr + 1) : key_len;
+    c->nr = pre_nr ? pre_nr : (int)(key_len / 4 + 6);
+    e = hipMemcpyAsync(c->d_keystage, key, kb, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_setup, dim3(1), dim3(AESGCM_WG), 0, c->stream, c->km, c->tables, c->d_keystage, (int)key_len, pre_nr, (u32)c->G);
+        hipLaunchKernelGGL(k_setup_ptab, dim3(AESGCM_NPTAB + AESGCM_NLTAB), dim3(512), 0, c->stream, c->km);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_keystage, 0, 256, c->stream);    // do not leave key bytes behind
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return hip_fail(e, "k_setup");
+    return AESGCM_OK;
+}
 static int ctx_create_common(aesgcm_ctx **out, int device, const uint8_t *key, size_t key_len, int pre_nr) {
     if (!out || !key) return AESGCM_EARG;
     *out = nullptr;
@@ -2002,19 +2021,7 @@ static int ctx_create_common(aesgcm_ctx **out, int device, const uint8_t *key, s
         (e = hipHostGetDevicePointer((void **)&c->h_tag_dev, c->h_tag, 0)) != hipSuccess ||
         (memset(c->h_tag, 0, 64), false) ||
         (e = hipMalloc(&c->d_trace, sizeof(u64) * 4 * AESGCM_GMAX)) != hipSuccess) { aesgcm_ctx_destroy(c); return hip_fail(e, "hipMalloc"); }
-    uint8_t *d_key = nullptr;
-    size_t kb = pre_nr ? (size_t)16 * (pre_nr + 1) : key_len;
-    if ((e = hipMalloc(&d_key, 256)) != hipSuccess) { aesgcm_ctx_destroy(c); return hip_fail(e, "hipMalloc"); }
-    e = hipMemcpyAsync(d_key, key, kb, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_setup, dim3(1), dim3(AESGCM_WG), 0, c->stream, c->km, c->tables, d_key, (int)key_len, pre_nr, (u32)G);
-        hipLaunchKernelGGL(k_setup_ptab, dim3(AESGCM_NPTAB + AESGCM_NLTAB), dim3(512), 0, c->stream, c->km);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipMemsetAsync(d_key, 0, 256, c->stream);    // do not leave key bytes behind
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    hipFree(d_key);
-    if (e != hipSuccess) { aesgcm_ctx_destroy(c); return hip_fail(e, "k_setup"); }
+    if ((rc = ctx_load_key(c, key, key_len, pre_nr))) { aesgcm_ctx_destroy(c); return rc; }
     { std::lock_guard<std::mutex> lk(g_mu); g_ctxs.push_back(c); }
     *out = c;
     return AESGCM_OK;
@@ -2028,6 +2035,16 @@ int aesgcm_ctx_create_preexpanded(aesgcm_ctx **out, int device, const uint8_t *r
     if (nr != 10 && nr != 12 && nr != 14) return AESGCM_EKEYLEN;
     return ctx_create_common(out, device, rk, (size_t)(4 * (nr - 6)), nr);
 }
+// A new key for an existing context (the reference core's "load key" between frames, tb/gcm_gctr.py:144-175; H is recomputed only then, src/gcm_gctr.vhd:142-144):
+// everything the context owns stays -- stream, scratch, host slot, options -- only the key material is rebuilt.  Waits for the context's queued work first.
+int aesgcm_ctx_rekey(aesgcm_ctx *c, const uint8_t *key, size_t key_len) {
+    if (!c || !key) return AESGCM_EARG;
+    if (key_len != 16 && key_len != 24 && key_len != 32) return AESGCM_EKEYLEN;
+    if (c->s_active) return AESGCM_ESTATE;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return ctx_load_key(c, key, key_len, 0);
+}
 int aesgcm_ctx_destroy(aesgcm_ctx *c) {
     if (!c) return AESGCM_OK;
     { std::lock_guard<std::mutex> lk(g_mu); g_ctxs.erase(std::remove(g_ctxs.begin(), g_ctxs.end(), c), g_ctxs.end()); }
@@ -2036,6 +2053,7 @@ int aesgcm_ctx_destroy(aesgcm_ctx *c) {
     for (auto &e : c->ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto &e : c->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     if (c->km) { hipMemset(c->km, 0, sizeof(KeyMaterial)); hipFree(c->km); }
+    if (c->d_keystage) hipFree(c->d_keystage);
     if (c->parts) hipFree(c->parts);
     if (c->fold_a) hipFree(c->fold_a);
     if (c->fold_b) hipFree(c->fold_b);

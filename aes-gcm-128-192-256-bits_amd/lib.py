@@ -18,7 +18,7 @@ ABI_VERSION = 3         # AESGCM_ABI_VERSION of include/aesgcm.h this binding wa
 SYMBOLS = [
     "aesgcm_abi_version", "aesgcm_strerror", "aesgcm_last_error", "aesgcm_device_count", "aesgcm_device_name",
     "aesgcm_key_expand", "aesgcm_ecb_encrypt", "aesgcm_gfmul", "aesgcm_ghash", "aesgcm_get_h",
-    "aesgcm_ctx_create", "aesgcm_ctx_create_preexpanded", "aesgcm_ctx_destroy", "aesgcm_ctx_device", "aesgcm_ctx_set_option", "aesgcm_ctx_stream", "aesgcm_ctx_wait", "aesgcm_ctx_wait_fused",
+    "aesgcm_ctx_create", "aesgcm_ctx_create_preexpanded", "aesgcm_ctx_rekey", "aesgcm_ctx_destroy", "aesgcm_ctx_device", "aesgcm_ctx_set_option", "aesgcm_ctx_stream", "aesgcm_ctx_wait", "aesgcm_ctx_wait_fused",
     "aesgcm_encrypt_pipelined", "aesgcm_decrypt_pipelined", "aesgcm_host_alloc", "aesgcm_host_free",
     "aesgcm_encrypt", "aesgcm_decrypt", "aesgcm_encrypt_dev", "aesgcm_decrypt_dev", "aesgcm_last_tag",
     "aesgcm_keystream", "aesgcm_keystream_dev",
@@ -106,6 +106,7 @@ def _typed(L):
     L.aesgcm_get_h.argtypes = [vp, vp]
     L.aesgcm_ctx_create.argtypes = [ctypes.POINTER(vp), cint, vp, sz]
     L.aesgcm_ctx_create_preexpanded.argtypes = [ctypes.POINTER(vp), cint, vp, cint]
+    L.aesgcm_ctx_rekey.argtypes = [vp, vp, sz]
     L.aesgcm_ctx_destroy.argtypes = [vp]
     L.aesgcm_ctx_device.argtypes = [vp]
     L.aesgcm_ctx_set_option.argtypes = [vp, cp, ctypes.c_int64]
@@ -420,6 +421,12 @@ class Context:
 
     def __exit__(self, *a):
         self.close()
+
+    def rekey(self, key):
+        """aesgcm_ctx_rekey: a new key (16 / 24 / 32 bytes) for this context -- the reference core's key load between frames; everything else stays"""
+        key = bytes(key)
+        _chk(load().aesgcm_ctx_rekey(self._c, key, len(key)))
+        return self
 
     def set_option(self, key, value):
         """aesgcm_ctx_set_option: "tw", "body_min", "cyc_min", "cyc_max", "cyc_close", "fold_close", "cyc_prio", "pkt_order", "poll_us" (include/aesgcm.h)"""

@@ -102,6 +102,11 @@ AESGCM_API int aesgcm_ctx_create(aesgcm_ctx **out, int device, const uint8_t *ke
 /* Pre-expanded key load path (config/config_aes_kprexp.py:66-106, tb/gcm_gctr.py:180-214):
  * rk = 16*(nr+1) bytes exactly as aesgcm_key_expand / tb/key_exp.py produce them. */
 AESGCM_API int aesgcm_ctx_create_preexpanded(aesgcm_ctx **out, int device, const uint8_t *rk, int nr);
+/* A new key for an existing context: the reference core's "load key" between frames (tb/gcm_gctr.py:144-175; H is recomputed only then,
+ * src/gcm_gctr.vhd:142-144).  The context keeps its stream, scratch, host slot and options; only the key schedule, H and the H-power tables
+ * are rebuilt (about half a millisecond, against 4.5 ms for destroying the context and creating another).  Waits for the context's queued
+ * work first; AESGCM_ESTATE inside an open aesgcm_stream_* session. */
+AESGCM_API int aesgcm_ctx_rekey(aesgcm_ctx *ctx, const uint8_t *key, size_t key_len);
 AESGCM_API int aesgcm_ctx_destroy(aesgcm_ctx *ctx);
 AESGCM_API int aesgcm_ctx_device(const aesgcm_ctx *ctx);
 /* Tunables of one context, for tests and profiling scripts; the library reads no environment variable and the defaults are the

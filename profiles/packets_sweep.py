@@ -10,6 +10,7 @@ var = len(sys.argv) > 2 and sys.argv[2] in ("var", "packed")       # frames of m
 packed = len(sys.argv) > 2 and sys.argv[2] == "packed"             # or back to back as they come (starts at any byte)
 _dbg = lib.debug_library(); _dbg.__enter__()
 ctx = lib.Context(bytes(range(kb)))
+aad_len = int(os.environ.get("SWEEP_AAD", "0"))        # a header of this many bytes per frame as AAD (MACsec: 20 or 28), fixed-size records
 if len(sys.argv) > 3:
     ctx.set_option("pkt_order", {"noorder": 0, "order": 1}[sys.argv[3]])      # never / always by length class (default: from 98304 packets)
 nmax = 1 << 20
@@ -28,6 +29,9 @@ if var:
     d_off = lib.DeviceBuffer(8 * (nmax + 1)); d_off.upload(struct.pack("<%dQ" % (nmax + 1), *off))
     d_pt, d_ct = lib.DeviceBuffer(off[-1] + 64), lib.DeviceBuffer(off[-1] + 64)
     d_pt.fill_splitmix64(3)
+    d_aad = lib.DeviceBuffer(max(aad_len, 1) * nmax + 64); d_aad.fill_splitmix64(4)
+    if aad_len:
+        print("        (with %d bytes of AAD per frame)" % aad_len)
     for n in counts:
         row = []
         for lanes in (64, 16, 8, 4, 1, 0):
@@ -35,7 +39,7 @@ if var:
             best = 1e9
             for it in range(4):
                 lib.dev_sync(); t0 = time.perf_counter()
-                ctx.packets_crypt_dev(False, n, d_ivs.ptr, d_pt.ptr, d_ct.ptr, d_tags.ptr, d_data_off=d_off.ptr)
+                ctx.packets_crypt_dev(False, n, d_ivs.ptr, d_pt.ptr, d_ct.ptr, d_tags.ptr, d_data_off=d_off.ptr, d_aad=d_aad.ptr if aad_len else None, aad_len=aad_len)
                 lib.dev_sync(); best = min(best, time.perf_counter() - t0)
             row.append(off[n] / best / (1 << 30))
         print("        %8d  mixed %8.1f %8.1f %8.1f %8.1f %8.1f %8.1f" % (n, *row), flush=True)

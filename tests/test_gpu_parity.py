@@ -423,3 +423,51 @@ def test_body_split_forced_on_small_messages(hip, orc, tw):
             first = end
         assert c.shard_finalize_dev(iv, parts.ptr, ranks, al, n) == want_tag
         assert bytes(dout.download(n)) == want_ct
+
+
+@pytest.mark.gpu
+def test_rekey_equals_a_fresh_context(hip, orc):
+    """aesgcm_ctx_rekey (the reference core's key load between frames, tb/gcm_gctr.py:144-175): one context through keys of all three sizes in turn -- every result
+    equals the oracle's under that key (message sizes of every launch structure, packets under the context's key too), options survive, a rekey inside an open
+    streaming session is refused, and it is an order of magnitude cheaper than a new context."""
+    import struct, time
+    ctx = hip.Context(splitmix_bytes(1, 16)).set_option("cyc_half", 1)
+    sizes = (0, 17, 4096, 70000, (1 << 20) + 5, 24 << 20)
+    d_in, d_out = hip.DeviceBuffer(max(sizes) + 64), hip.DeviceBuffer(max(sizes) + 64)
+    pt = splitmix_bytes(77, max(sizes))
+    d_in.upload(pt)
+    for it, klen in enumerate((32, 16, 24, 32, 16)):
+        key, iv, aad = splitmix_bytes(100 + it, klen), splitmix_bytes(200 + it, 12), splitmix_bytes(300 + it, 20)
+        ctx.rekey(key)
+        f = orc.Fast(key)
+        d_aad = hip.DeviceBuffer(64); d_aad.upload(aad)
+        for n in sizes:
+            tag = ctx.encrypt_dev(iv, d_in.ptr, n, d_out.ptr, d_aad=d_aad.ptr, aad_len=20)
+            want_ct, want_tag = f.encrypt(iv, aad, pt[:n])
+            assert tag == want_tag and bytes(d_out.download(n) if n else b"") == want_ct, (it, klen, n)
+        # packets under the context's (new) key
+        m, plen = 200, 1000
+        ivs = splitmix_bytes(400 + it, 12 * m)
+        d_ivs, d_tags = hip.DeviceBuffer(12 * m), hip.DeviceBuffer(16 * m)
+        d_ivs.upload(ivs)
+        ctx.packets_crypt_dev(False, m, d_ivs.ptr, d_in.ptr, d_out.ptr, d_tags.ptr, pkt_len=plen)
+        hip.dev_sync()
+        ct, tags = bytes(d_out.download(m * plen)), bytes(d_tags.download())
+        for p in (0, 57, 199):
+            assert (ct[p * plen:(p + 1) * plen], tags[16 * p:16 * p + 16]) == f.encrypt(ivs[12 * p:12 * p + 12], b"", pt[p * plen:(p + 1) * plen]), (it, p)
+    ctx.stream_begin(bytes(12))
+    with pytest.raises(hip.AesGcmError):
+        ctx.rekey(bytes(16))
+    ctx.stream_aad(b"")
+    ctx.stream_final()
+    # cost: rekey against destroy + create
+    t0 = time.perf_counter()
+    for i in range(10):
+        ctx.rekey(bytes([i]) * 32)
+    t_rekey = (time.perf_counter() - t0) / 10
+    t0 = time.perf_counter()
+    for i in range(10):
+        hip.Context(bytes([i]) * 32).close()
+    t_new = (time.perf_counter() - t0) / 10
+    print("rekey %.0f us, destroy + create %.0f us" % (t_rekey * 1e6, t_new * 1e6))
+    assert t_rekey * 3 < t_new, (t_rekey, t_new)
