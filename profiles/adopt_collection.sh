@@ -4,7 +4,7 @@
 O=$1; R=$2
 for d in $O/prof_*; do t=$(basename $d); t=${t#prof_}; mkdir -p profiles/$R/$t; cp $d/* profiles/$R/$t/; done
 cp $O/bench_*.json profiles/$R/
-for f in inflight_sweep.txt inflight_sweep_half.txt latency_c.txt size_sweep.txt so_sha256.txt smoke.txt pipeline_time.txt packets_sweep_mixed_aes256.txt packets_sweep_packed_aes256.txt packets_sweep_aes256.txt batch_mixed_aes128.txt; do
+for f in inflight_sweep.txt inflight_sweep_half.txt latency_c.txt size_sweep.txt so_sha256.txt smoke.txt pipeline_time.txt ctx_time.txt packets_sweep_mixed_aes256.txt packets_sweep_packed_aes256.txt packets_sweep_aes256.txt batch_mixed_aes128.txt; do
   [ -f $O/$f ] && cp $O/$f profiles/$R/
 done
 [ -f $O/cyc_timeline_aes256.txt ] && cp $O/cyc_timeline_aes256.txt profiles/$R/cyc_timeline_aes256_final.txt
