@@ -44,6 +44,7 @@ rate = lambda j: 2**30 / (j["kernel_avg_ns_under_rocprof"] * 1e-9) / 2**30
 frac = lambda j: ALG_PKTL / (j["kernel_avg_ns_under_rocprof"] * 1e-9) / 8e12
 cpus = [b["cpu_baseline"]["value"] for b in (b3, b2, b5) if b.get("cpu_baseline")]
 cpu1 = b3["cpu_baseline"].get("value_1core")
+ck = re.search(r"aesgcm_ctx_create (\d+) us, aesgcm_ctx_destroy (\d+) us, aesgcm_ctx_rekey (\d+) us", open(os.path.join(D, "ctx_time.txt")).read())
 tests = re.search(r"(\d+) passed, (\d+) skipped", open(os.path.join(D, "pytest_tail.txt")).read())
 
 status = """## Status (round 4; one MI355X; every number from `profiles/%s/`, library SHA-256 %s..., `runs/%s`)
@@ -61,13 +62,14 @@ status = """## Status (round 4; one MI355X; every number from `profiles/%s/`, li
 | 2^20 x 1 KiB packets under one key, AES-256 (`k_pktl`), encrypt / decrypt | %.0f / %.0f | %.3f / %.3f | **1.00 x** (round 3: 1.41 x) | `pktl_768_ab.txt`, `pktl_1k/`, `pktl_1k_dec/` |
 | 2^20 frames of 64 .. 1514 bytes (offset arrays), one key AES-256 / a key each AES-128; one key, packed back to back | %.0f / %.0f (array order: 426 / %.0f); %.0f (byte-wise blocks: 133) | -- | -- | `packets_sweep_mixed_aes256*.txt`, `batch_mixed_aes128.txt`, `packets_sweep_packed_aes256*.txt` |
 | 64 KiB message, waited call from C | %.1f us | -- | -- | `latency_c.txt` |
+| a new key: `aesgcm_ctx_rekey` / destroying the context and creating another | %s us / %d us | -- | -- | `ctx_time.txt` |
 | host memory to host memory, pipelined (PCIe-inclusive; never the metric) | %.1f (0.97 of the link's two-way rate, `pcie_probe.txt`) | -- | -- | `pipeline_time.txt` |
 | CPU beside it (libcrypto on the box's 16 cores / 1 core; pycryptodome is absent) | %.0f - %.0f / %.1f | -- | -- | `cpu_baseline` of the bench lines |
 
 Parity: %s GPU tests green (%s more skip without a second GPU)""" % (
     R, sha, RUN, b3["value"], b3["roofline"]["frac"], bd["value"], bd["roofline"]["frac"], b2["value"], b2["roofline"]["frac"],
     e0["value"], e0["value"] / b3["value"], e0["roofline"]["frac"], b5["value"], b5["roofline"]["frac"], b5d["value"], b5a["value"], b5d["roofline"]["frac"], b5a["roofline"]["frac"],
-    i16[1], i16[2], i16[3], i64[1], i64[2], i64[3], rate(pl), rate(pld), frac(pl), frac(pld), mixed, bm[2], bm[0], packed, lat[65536], pipe, min(cpus), max(cpus), cpu1, tests.group(1), tests.group(2))
+    i16[1], i16[2], i16[3], i64[1], i64[2], i64[3], rate(pl), rate(pld), frac(pl), frac(pld), mixed, bm[2], bm[0], packed, lat[65536], ck.group(3), int(ck.group(1)) + int(ck.group(2)), pipe, min(cpus), max(cpus), cpu1, tests.group(1), tests.group(2))
 p = os.path.join(ROOT, "README.md")
 s = open(p).read()
 a, b = s.index("## Status (round 4;"), s.index(", 41 CPU tests;")
