@@ -1537,10 +1537,10 @@ static inline CombineParams plan_combine_final(uint4 *state, const uint8_t iv[12
 // The packet polynomial is evaluated as: lane L runs serial Horner with H over its q consecutive blocks,
 // then a 6-level cross-lane tree multiplies by c_j = H^(q*2^j) (c_{j+1} = c_j^2, table rebuilt per level).
 // ================================================================================================
-#define BATCH_WAVE_LDS 512u                     /* per wave: table of H (256 B) + table of the tree constant (256 B) */
-#define BATCH_LDS_WAVE_OFF 0u                   /* the 8 KiB the bulk kernel uses for the K table: 16 waves x 512 B */
-#define BATCH_LDS_RTAB_OFF (AESGCM_LDS_AES_OFF + AESGCM_LDS_AES)            /* 16 x u32 reduction table */
-#define BATCH_LDS_BYTES (BATCH_LDS_RTAB_OFF + 64u)
+#define BATCH_WAVE_LDS 1024u                    /* per wave: the two-table Shoup form (Th | Tl, 512 B) of H and of the tree constant: shoup2_mul_dr since round 4 */
+#define BATCH_LDS_RTAB_OFF (AESGCM_LDS_AES_OFF + AESGCM_LDS_AES)            /* 16 x u32 reduction table (shoup_mul: the round-2 multiply, kept as a unit-tested reference) */
+#define BATCH_LDS_WAVE_OFF (BATCH_LDS_RTAB_OFF + 256u)                     /* behind the T-tables, 256-byte aligned (the multiply ORs the entry offset into the slot address) */
+#define BATCH_LDS_BYTES (BATCH_LDS_WAVE_OFF + (AESGCM_WG / 64u) * BATCH_WAVE_LDS)
 
 struct BatchParams {
     const unsigned char *keys;   // n_pkts * key_len bytes

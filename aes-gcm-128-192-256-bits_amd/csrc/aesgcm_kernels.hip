@@ -759,6 +759,19 @@ __device__ __forceinline__ G128 batch_seq_block(bool aligned, u32 aad_len, u32 p
     return mo_to_be(m);
 }
 
+// the two-table Shoup form of a constant c at LDS offset `tab` (Th at tab, Tl = Th * x^4 at tab + 256), built by the 2^LG lanes that share it
+template <int LG>
+__device__ __forceinline__ void shoup2_build(unsigned char *smem, u32 tab, G128 c, u32 l) {
+#pragma unroll
+    for (u32 v = l; v < 16; v += (1u << LG)) {               // 16 entries per table, built by the group's own lanes
+        const G128 e = shoup_entry(c, v), el = gf_mulx4(e);
+        *reinterpret_cast<uint4 *>(smem + tab + 16 * v) = make_uint4(e.w[0], e.w[1], e.w[2], e.w[3]);
+        *reinterpret_cast<uint4 *>(smem + tab + 256 + 16 * v) = make_uint4(el.w[0], el.w[1], el.w[2], el.w[3]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 #ifndef BATCH1_WPS
 #define BATCH1_WPS (AESGCM_WG / 256)      /* waves per SIMD the register budget is sized for: 4 = 128 registers (8 = 64 registers spilled 92 - 116 bytes into the packet loop) */
 #endif
@@ -770,7 +783,7 @@ __global__ __launch_bounds__(AESGCM_WG, BATCH1_WPS) void k_batch(const DevTables
     if (tid < 16) *reinterpret_cast<u32 *>(smem + BATCH_LDS_RTAB_OFF + 4 * tid) = shoup_rem_calc(tid);
     __syncthreads();
     const u32 lb = (lane & 31u) << 2;
-    const u32 tabH = BATCH_LDS_WAVE_OFF + wave * BATCH_WAVE_LDS, tabC = tabH + 256u;
+    const u32 tabH = BATCH_LDS_WAVE_OFF + wave * BATCH_WAVE_LDS, tabC = tabH + 512u;
     constexpr u32 KEYLEN = 4 * (NR - 6);
     // packets are dealt in blocks of p.deal per dispenser fetch (see k_pkt); the loop is bounded on purpose:
     // a wave can never own more than n_pkts packets
@@ -817,7 +830,7 @@ __global__ __launch_bounds__(AESGCM_WG, BATCH1_WPS) void k_batch(const DevTables
             h = wave_bcast(e, 0);
             ej0 = wave_bcast(e, 1);
         }
-        shoup_build(smem, tabH, h, lane);
+        shoup2_build<6>(smem, tabH, h, lane);
 
         G128 acc; acc.w[0] = acc.w[1] = acc.w[2] = acc.w[3] = 0;
         // GHASH over the input must precede the CTR pass when decrypting (in-place safe); after it when encrypting
@@ -827,7 +840,7 @@ __global__ __launch_bounds__(AESGCM_WG, BATCH1_WPS) void k_batch(const DevTables
             if (do_ghash) {
                 if (!DEC) __threadfence_block();           // this wave's ciphertext stores are visible to its other lanes
                 for (u32 k = 0; k < q; k++) {
-                    if (k) acc = shoup_mul(acc, smem, tabH);
+                    if (k) acc = shoup2_mul_dr(acc, smem, tabH);
                     const u32 v = lane * q + k;
                     if (v >= pad) {
                         const G128 b = batch_seq_block(aligned, aad_len, pkt_len, aad, DEC ? in : out, n_aad, v - pad);
@@ -856,14 +869,14 @@ __global__ __launch_bounds__(AESGCM_WG, BATCH1_WPS) void k_batch(const DevTables
         if (q > 1) {
             for (int b = 30 - (int)__builtin_clz(q); b >= 0; b--) {
                 cpow = gf_sqr(cpow);
-                if ((q >> b) & 1u) cpow = shoup_mul(cpow, smem, tabH);
+                if ((q >> b) & 1u) cpow = shoup2_mul_dr(cpow, smem, tabH);
             }
         }
         if (q) {
 #pragma unroll
             for (int j = 0; j < 6; j++) {
-                shoup_build(smem, tabC, cpow, lane);
-                const G128 t = shoup_mul(acc, smem, tabC);
+                shoup2_build<6>(smem, tabC, cpow, lane);
+                const G128 t = shoup2_mul_dr(acc, smem, tabC);
                 G128 o;
                 o.w[0] = lane_xor_pow2(t.w[0], j); o.w[1] = lane_xor_pow2(t.w[1], j);
                 o.w[2] = lane_xor_pow2(t.w[2], j); o.w[3] = lane_xor_pow2(t.w[3], j);
@@ -872,9 +885,9 @@ __global__ __launch_bounds__(AESGCM_WG, BATCH1_WPS) void k_batch(const DevTables
             }
         }
         // ---- lane 63 holds P = sum X_i H^(n-1-i); tag = ((P*H) ^ L)*H ^ E_K(J0)
-        G128 y = shoup_mul(acc, smem, tabH);
+        G128 y = shoup2_mul_dr(acc, smem, tabH);
         y.w[1] ^= aad_len * 8u; y.w[3] ^= pkt_len * 8u;           // both < 2^32 bits by the ABI's limits
-        y = shoup_mul(y, smem, tabH);
+        y = shoup2_mul_dr(y, smem, tabH);
         y.w[0] ^= ej0.w[0]; y.w[1] ^= ej0.w[1]; y.w[2] ^= ej0.w[2]; y.w[3] ^= ej0.w[3];
         if (lane == 63) {
             const uint4 tag = be_to_mo(y);
@@ -894,18 +907,6 @@ __global__ __launch_bounds__(AESGCM_WG, BATCH1_WPS) void k_batch(const DevTables
 // ------------------------------------------------------------------------------------------------
 // Lane-group helpers of the packet kernels (G = 2^LG lanes per packet, 64 / G packets per wave)
 // ------------------------------------------------------------------------------------------------
-template <int LG>
-__device__ __forceinline__ void shoup2_build(unsigned char *smem, u32 tab, G128 c, u32 l) {
-#pragma unroll
-    for (u32 v = l; v < 16; v += (1u << LG)) {               // 16 entries per table, built by the group's own lanes
-        const G128 e = shoup_entry(c, v), el = gf_mulx4(e);
-        *reinterpret_cast<uint4 *>(smem + tab + 16 * v) = make_uint4(e.w[0], e.w[1], e.w[2], e.w[3]);
-        *reinterpret_cast<uint4 *>(smem + tab + 256 + 16 * v) = make_uint4(el.w[0], el.w[1], el.w[2], el.w[3]);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 // the largest value of a group-uniform quantity over the wave's 64 >> LG packet groups (wave-uniform result)
 template <int LG>
 __device__ __forceinline__ u32 groups_max(u32 v) {
