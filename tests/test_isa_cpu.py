@@ -3,7 +3,7 @@ a GPU) and reads it with tools/isa_census.py: a register spill that lands inside
 (round 1: three scratch_load per row in k_body = 13 % extra traffic; round 2: nine scratch ops in k_pkt's row loop), and it
 arrives silently with any change of a launch bound or of the lane code.  Fails if
 
-  * k_body (every key size, ENC / DEC / PROBE, dealt chunks and cyclic rows with their fused closing), k_pktl, k_pktg (every shape), k_batch3 or the KS / ECB instances of k_main use scratch at all;
+  * k_body (every key size, ENC / DEC / PROBE, dealt chunks and cyclic rows with their fused closing), k_pktl, k_pktg (every shape), k_batch3, k_batch or the KS / ECB instances of k_main use scratch at all;
   * any scratch_* op sits at the innermost loop depth of k_main ENC / DEC (the row loop), of k_pktg (the iteration loop of a
     packet's lane group), of k_batch / k_batch3 (the block loops);
   * a kernel needs more registers than its launch geometry allows;
@@ -43,7 +43,7 @@ def _inner_scratch(k):
 
 def test_scratch_free_kernels(census):
     for name, k in census.items():
-        if name.startswith(("k_body<", "k_pktl<", "k_pktg<", "k_batch3<")) or name.startswith("k_main<") and name.endswith((", 2>", ", 3>")):
+        if name.startswith(("k_body<", "k_pktl<", "k_pktg<", "k_batch3<", "k_batch<")) or name.startswith("k_main<") and name.endswith((", 2>", ", 3>")):
             assert k["scratch"] == 0, (name, k["scratch"])
 
 
