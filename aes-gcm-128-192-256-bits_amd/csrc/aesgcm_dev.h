@@ -1804,6 +1804,7 @@ struct PktParams {
     u32 n_pkts, pkt_len, aad_len;
     u32 aligned;                 // in/out base pointers 16-byte aligned
     const u32 *perm;             // the order in which the launch takes the packets (k_len_*: by falling length), or NULL = as they come
+    u32 plain;                   // k_pktg<.., 6>: fixed-size aligned records of whole 64-block rows, no AAD
 };
 HD u32 pkt_map(const PktParams &p, u32 i) { return p.perm ? p.perm[i] : i; }
 // Packets of mixed length (offset arrays).  The lanes (k_pktl) or lane groups (k_pktg, k_batch3) of a wave run to the longest packet among them: with frames
@@ -1865,6 +1866,21 @@ HD uint4 pktg_lane(const KeyMaterial *__restrict__ km, const PktParams &p, const
     unsigned char *dst = p.out + q.doff;
     const bool aligned = q.aligned != 0;
     uint4 acc = make_uint4(0, 0, 0, 0);
+    if (LG == 6 && p.plain) {              // a wave per packet (768-lane workgroups: registers to spare), records of one size, whole rows, no AAD, aligned: no per-iteration tests
+        const unsigned char *s = src + 16u * l;
+        unsigned char *d = dst + 16u * l;
+        for (u32 k = 0; k < iters; k++) {
+            if (k) acc = ghash_mul_const_lds(acc, smem);
+            const uint4 x = gload16(s);
+            u32 s0, s1, s2, s3;
+            ctr_rounds_lds<NR>(bswap32(2u + k * G + l), cc, s0, s1, s2, s3, rk, smem, lb);
+            const uint4 y = make_uint4(x.x ^ s0, x.y ^ s1, x.z ^ s2, x.w ^ s3);
+            if (act) gstore16(d, y);
+            acc = xor4(acc, DEC ? x : y);
+            s += 16u * G; d += 16u * G;
+        }
+        return acc;
+    }
     for (u32 k = 0; k < iters; k++) {
         if (k) acc = ghash_mul_const_lds(acc, smem);
         const u32 v = k * G + l;
