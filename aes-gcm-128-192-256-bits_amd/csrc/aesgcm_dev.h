@@ -1804,7 +1804,7 @@ struct PktParams {
     u32 n_pkts, pkt_len, aad_len;
     u32 aligned;                 // in/out base pointers 16-byte aligned
     const u32 *perm;             // the order in which the launch takes the packets (k_len_*: by falling length), or NULL = as they come
-    u32 plain;                   // k_pktg<.., 6>: fixed-size aligned records of whole 64-block rows, no AAD
+    u32 plain;                   // k_pktg<.., 6 | 2>: fixed-size aligned records of whole group-iterations, no AAD
 };
 HD u32 pkt_map(const PktParams &p, u32 i) { return p.perm ? p.perm[i] : i; }
 // Packets of mixed length (offset arrays).  The lanes (k_pktl) or lane groups (k_pktg, k_batch3) of a wave run to the longest packet among them: with frames
@@ -1866,7 +1866,7 @@ HD uint4 pktg_lane(const KeyMaterial *__restrict__ km, const PktParams &p, const
     unsigned char *dst = p.out + q.doff;
     const bool aligned = q.aligned != 0;
     uint4 acc = make_uint4(0, 0, 0, 0);
-    if (LG == 6 && p.plain) {              // a wave per packet (768-lane workgroups: registers to spare), records of one size, whole rows, no AAD, aligned: no per-iteration tests
+    if ((LG == 6 || LG == 2) && p.plain) {   // a wave or four lanes per packet (the instances with registers to spare), records of one size, whole group-iterations, no AAD, aligned: no per-iteration tests
         const unsigned char *s = src + 16u * l;
         unsigned char *d = dst + 16u * l;
         for (u32 k = 0; k < iters; k++) {

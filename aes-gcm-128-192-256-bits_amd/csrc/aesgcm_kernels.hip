@@ -2643,7 +2643,7 @@ int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const vo
 #undef LP
     } else {
         const u32 P = 64u >> lg;                                                    // packets per wave-iteration
-        p.plain = lg == 6 && !d_data_off && !d_aad_off && !aad_len && p.aligned && pkt_len && pkt_len % 1024 == 0;
+        p.plain = (lg == 6 || lg == 2) && !d_data_off && !d_aad_off && !aad_len && p.aligned && pkt_len && pkt_len % ((size_t)16 << lg) == 0;
         const u32 waves_per_wg = (u32)PKTG_WG(lg) / 64;
         // deal: about 4 dispenser fetches per resident wave, a multiple of P, at most 64 packets (one E_K(J0) pass per fetch)
         u32 deal = (u32)(n_pkts / ((size_t)n_cu * waves_per_wg * 4));
