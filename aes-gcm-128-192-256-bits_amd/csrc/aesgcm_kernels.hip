@@ -10,7 +10,7 @@
 //   k_fold          reduces the chunks' items (64 lane accumulators each) by Horner with wave-uniform constants; its first level may close the tag (FoldClose).
 //   k_combine       per message: H^(65-L) on the last item, lane fold, optional H^e weighting / chaining value
 //                   (shards, streaming), length block, E_K(J0) -> tag.  k_combine_batch: up to 8 messages, one workgroup each.
-//   k_batch3<NR,DEC,LG>, k_batch   packets with their OWN key: 8 or 16 lanes per packet in one pass / one wave per packet.
+//   k_batch3<NR,DEC,LG>   packets with their OWN key: 8, 16 or 64 lanes per packet, one pass (per-packet aes_kexp, CTR, GHASH with the packet's own tables).
 //   k_pktg<NR,DEC,LG>, k_pktl      packets under the context's key: 2^LG lanes per packet (4, 8, 16, 64) / one lane per packet.
 //   k_len_hist, k_len_scan, k_len_scatter   the order in which a launch takes packets of mixed length: a counting sort by falling length class.
 //   k_gfmul, k_fill_splitmix64, k_copy16   small utility kernels.
@@ -725,40 +725,6 @@ __global__ __launch_bounds__(COMBINE_THREADS) void k_combine_batch(const KeyMate
     combine_body(km, tb, b.p[blockIdx.x], smem);
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_batch: BASELINE config 5 -- independent packets, per-packet key and IV.  One wave per packet, packets
-// pulled from the dispenser.  See the "Batch path" block in aesgcm_dev.h for the algorithm.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ G128 wave_bcast(G128 v, int src) {
-    G128 r;
-    r.w[0] = __builtin_amdgcn_readlane(v.w[0], src); r.w[1] = __builtin_amdgcn_readlane(v.w[1], src);
-    r.w[2] = __builtin_amdgcn_readlane(v.w[2], src); r.w[3] = __builtin_amdgcn_readlane(v.w[3], src);
-    return r;
-}
-__device__ __forceinline__ void shoup_build(unsigned char *smem, u32 tab, G128 c, u32 lane) {
-    if (lane < 16) {
-        const G128 e = shoup_entry(c, lane);
-        *reinterpret_cast<uint4 *>(smem + tab + 16 * lane) = make_uint4(e.w[0], e.w[1], e.w[2], e.w[3]);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-// block j of the packet's GHASH sequence (AAD blocks then data blocks), zero padded, as big-endian words
-__device__ __forceinline__ G128 batch_seq_block(bool aligned, u32 aad_len, u32 pkt_len, const unsigned char *aad, const unsigned char *data,
-                                                u32 n_aad, u32 j) {
-    uint4 m;
-    if (j < n_aad) {
-        const u32 off = 16 * j, rem = aad_len - off;
-        m = load_block_bytes(aad + off, rem < 16 ? rem : 16);
-    } else {
-        const u32 off = 16 * (j - n_aad), rem = pkt_len - off;
-        if (aligned && rem >= 16) m = *reinterpret_cast<const uint4 *>(data + off);
-        else m = load_block_bytes(data + off, rem < 16 ? rem : 16);
-    }
-    return mo_to_be(m);
-}
-
 // the two-table Shoup form of a constant c at LDS offset `tab` (Th at tab, Tl = Th * x^4 at tab + 256), built by the 2^LG lanes that share it
 template <int LG>
 __device__ __forceinline__ void shoup2_build(unsigned char *smem, u32 tab, G128 c, u32 l) {
@@ -772,138 +738,6 @@ __device__ __forceinline__ void shoup2_build(unsigned char *smem, u32 tab, G128 
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-#ifndef BATCH1_WPS
-#define BATCH1_WPS (AESGCM_WG / 256)      /* waves per SIMD the register budget is sized for: 4 = 128 registers (8 = 64 registers spilled 92 - 116 bytes into the packet loop) */
-#endif
-template <int NR, int DEC>
-__global__ __launch_bounds__(AESGCM_WG, BATCH1_WPS) void k_batch(const DevTables *__restrict__ tb, const BatchParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    main_fill_lds(smem, nullptr, tb, tid, false, AESGCM_WG);
-    if (tid < 16) *reinterpret_cast<u32 *>(smem + BATCH_LDS_RTAB_OFF + 4 * tid) = shoup_rem_calc(tid);
-    __syncthreads();
-    const u32 lb = (lane & 31u) << 2;
-    const u32 tabH = BATCH_LDS_WAVE_OFF + wave * BATCH_WAVE_LDS, tabC = tabH + 512u;
-    constexpr u32 KEYLEN = 4 * (NR - 6);
-    // packets are dealt in blocks of p.deal per dispenser fetch (see k_pkt); the loop is bounded on purpose:
-    // a wave can never own more than n_pkts packets
-    const u32 K = p.deal, nb = (p.n_pkts + K - 1) / K;
-    u32 pkt = 0, pkt_end = 0;
-    for (u32 guard = 0; guard <= p.n_pkts; ++guard, ++pkt) {
-        if (pkt == pkt_end) {
-            u32 b = 0;
-            if (lane == 0) b = atomicAdd(p.counter, 1u) - p.counter_base;
-            b = __builtin_amdgcn_readfirstlane(b);
-            if (b >= nb) break;
-            pkt = b * K;
-            pkt_end = pkt + K < p.n_pkts ? pkt + K : p.n_pkts;
-        }
-        const unsigned char *key = p.keys + (size_t)pkt * KEYLEN;
-        const unsigned char *ivp = p.ivs + (size_t)pkt * 12;
-        // packet geometry: fixed-size records, or per-packet extents from the offset arrays (MACsec-shaped traffic)
-        u32 pkt_len = p.pkt_len, aad_len = p.aad_len;
-        u64 doff = (u64)pkt * p.pkt_len, aoff = (u64)pkt * p.aad_len;
-        if (p.data_off) { doff = p.data_off[pkt]; pkt_len = (u32)(p.data_off[pkt + 1] - doff); }
-        if (p.aad_off) { aoff = p.aad_off[pkt]; aad_len = (u32)(p.aad_off[pkt + 1] - aoff); }
-        const bool aligned = p.aligned && ((doff & 15) == 0);
-        const unsigned char *aad = p.aad ? p.aad + aoff : nullptr;
-        const unsigned char *in = p.in + doff;
-        unsigned char *out = p.out + doff;
-        const u32 n_aad = (aad_len + 15) / 16, n_ct = (pkt_len + 15) / 16, n_seq = n_aad + n_ct;
-        const u32 q = (n_seq + 63) / 64;                   // blocks per lane (0 for an empty packet)
-        const u32 pad = 64 * q - n_seq;                    // front padding slots
-
-        // ---- aes_kexp for this packet; round keys become wave-uniform scalars
-        u32 rk[4 * (NR + 1)];
-        batch_key_expand<NR>(key, rk, smem, lb);
-#pragma unroll
-        for (int w = 0; w < 4 * (NR + 1); w++) rk[w] = __builtin_amdgcn_readfirstlane(rk[w]);
-        const u32 iv0 = load_le32(ivp), iv1 = load_le32(ivp + 4), iv2 = load_le32(ivp + 8);
-
-        // ---- H = E_K(0^128) on lane 0 and E_K(IV || 1) on lane 1 (gcm_gctr.vhd:141-145), one pass for both
-        G128 h, ej0;
-        {
-            u32 s0 = (lane == 0 ? 0u : iv0) ^ rk[0], s1 = (lane == 0 ? 0u : iv1) ^ rk[1], s2 = (lane == 0 ? 0u : iv2) ^ rk[2];
-            u32 s3 = (lane == 0 ? 0u : 0x01000000u) ^ rk[3];
-            aes_rounds_lds<NR>(s0, s1, s2, s3, rk, smem, lb);
-            const G128 e = mo_to_be(make_uint4(s0, s1, s2, s3));
-            h = wave_bcast(e, 0);
-            ej0 = wave_bcast(e, 1);
-        }
-        shoup2_build<6>(smem, tabH, h, lane);
-
-        G128 acc; acc.w[0] = acc.w[1] = acc.w[2] = acc.w[3] = 0;
-        // GHASH over the input must precede the CTR pass when decrypting (in-place safe); after it when encrypting
-#pragma unroll
-        for (int phase = 0; phase < 2; phase++) {
-            const bool do_ghash = (phase == 0) == (DEC != 0);
-            if (do_ghash) {
-                if (!DEC) __threadfence_block();           // this wave's ciphertext stores are visible to its other lanes
-                for (u32 k = 0; k < q; k++) {
-                    if (k) acc = shoup2_mul_dr(acc, smem, tabH);
-                    const u32 v = lane * q + k;
-                    if (v >= pad) {
-                        const G128 b = batch_seq_block(aligned, aad_len, pkt_len, aad, DEC ? in : out, n_aad, v - pad);
-                        acc.w[0] ^= b.w[0]; acc.w[1] ^= b.w[1]; acc.w[2] ^= b.w[2]; acc.w[3] ^= b.w[3];
-                    }
-                }
-            } else {
-                const CtrConsts cc = ctr_round1_consts(iv0, iv1, iv2, rk, smem, lb);
-                for (u32 i = lane; i < n_ct; i += 64) {
-                    const u32 off = 16 * i, rem = pkt_len - off;
-                    uint4 x;
-                    const bool full = aligned && rem >= 16;
-                    if (full) x = *reinterpret_cast<const uint4 *>(in + off);
-                    else x = load_block_bytes(in + off, rem < 16 ? rem : 16);
-                    u32 s0, s1, s2, s3;
-                    ctr_rounds_lds<NR>(bswap32(2u + i), cc, s0, s1, s2, s3, rk, smem, lb);
-                    const uint4 y = make_uint4(x.x ^ s0, x.y ^ s1, x.z ^ s2, x.w ^ s3);
-                    if (full) *reinterpret_cast<uint4 *>(out + off) = y;
-                    else store_block_bytes(out + off, y, rem < 16 ? rem : 16);
-                }
-            }
-        }
-
-        // ---- cross-lane tree: c_0 = H^q, c_{j+1} = c_j^2 (squaring is linear: gf_sqr, no table)
-        G128 cpow = h;                                      // H^q by square-and-multiply (q is wave-uniform)
-        if (q > 1) {
-            for (int b = 30 - (int)__builtin_clz(q); b >= 0; b--) {
-                cpow = gf_sqr(cpow);
-                if ((q >> b) & 1u) cpow = shoup2_mul_dr(cpow, smem, tabH);
-            }
-        }
-        if (q) {
-#pragma unroll
-            for (int j = 0; j < 6; j++) {
-                shoup2_build<6>(smem, tabC, cpow, lane);
-                const G128 t = shoup2_mul_dr(acc, smem, tabC);
-                G128 o;
-                o.w[0] = lane_xor_pow2(t.w[0], j); o.w[1] = lane_xor_pow2(t.w[1], j);
-                o.w[2] = lane_xor_pow2(t.w[2], j); o.w[3] = lane_xor_pow2(t.w[3], j);
-                if (lane & (1u << j)) { acc.w[0] ^= o.w[0]; acc.w[1] ^= o.w[1]; acc.w[2] ^= o.w[2]; acc.w[3] ^= o.w[3]; }
-                if (j < 5) cpow = gf_sqr(cpow);
-            }
-        }
-        // ---- lane 63 holds P = sum X_i H^(n-1-i); tag = ((P*H) ^ L)*H ^ E_K(J0)
-        G128 y = shoup2_mul_dr(acc, smem, tabH);
-        y.w[1] ^= aad_len * 8u; y.w[3] ^= pkt_len * 8u;           // both < 2^32 bits by the ABI's limits
-        y = shoup2_mul_dr(y, smem, tabH);
-        y.w[0] ^= ej0.w[0]; y.w[1] ^= ej0.w[1]; y.w[2] ^= ej0.w[2]; y.w[3] ^= ej0.w[3];
-        if (lane == 63) {
-            const uint4 tag = be_to_mo(y);
-            store_block_bytes(p.tags + (size_t)pkt * 16, tag, 16);
-            if (DEC && p.auth) {
-                int ok = 1;
-                if (p.expect) {
-                    const uint4 e = load_block_bytes(p.expect + (size_t)pkt * 16, 16);
-                    ok = ((e.x ^ tag.x) | (e.y ^ tag.y) | (e.z ^ tag.z) | (e.w ^ tag.w)) == 0;
-                }
-                p.auth[pkt] = ok;
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // Lane-group helpers of the packet kernels (G = 2^LG lanes per packet, 64 / G packets per wave)
 // ------------------------------------------------------------------------------------------------
@@ -970,7 +804,9 @@ __device__ __forceinline__ u32 batch3_groups_max(u32 v) {                     //
     for (u32 g = 0; g < (64u >> LG); g++) { const u32 x = (u32)__builtin_amdgcn_readlane((int)v, (int)batch3_first_lane<LG>(g)); m = x > m ? x : m; }
     return m;
 }
+template <int LG>
 __device__ __forceinline__ u32 batch3_partner(u32 x, int j) {                 // the value of the lane whose position differs in bit j
+    if (LG == 6) return lane_xor_pow2(x, j);                                   // a wave per packet: positions are the lanes
 #if BATCH3_PERM
     switch (j) {
     case 0: return lane_xor<1>(x);
@@ -1079,7 +915,8 @@ __global__ __launch_bounds__(BATCH3_LANES(NR), (BATCH3_LANES(NR) + 255) / 256) v
             const uint4 hv = *reinterpret_cast<const uint4 *>(smem + hsA);
             G128 h; h.w[0] = hv.x; h.w[1] = hv.y; h.w[2] = hv.z; h.w[3] = hv.w;
             G128 hs = gf_sqr(gf_sqr(gf_sqr(h)));                                       // Horner stride H^(lanes per packet): LG squarings (linear: gf_sqr, no table)
-            if (LG == 4) hs = gf_sqr(hs);
+#pragma unroll
+            for (int j = 3; j < LG; j++) hs = gf_sqr(hs);
             shoup2_build<LG>(smem, tabA, hs, l);
         }
 
@@ -1156,8 +993,8 @@ __global__ __launch_bounds__(BATCH3_LANES(NR), (BATCH3_LANES(NR) + 255) / 256) v
             else if (j >= 2) { c = gf_sqr(c); shoup2_build<LG>(smem, (j & 1) ? tabB2 : tabA2, c, l2); }
             const G128 t = PAIR ? batch3_mul_pair(acc, smem, tabA2, tabAp2, pair_first2) : BATCH3_MUL(acc, smem, (j & 1) ? tabB2 : tabA2);
             G128 o;
-            o.w[0] = batch3_partner(t.w[0], j); o.w[1] = batch3_partner(t.w[1], j);
-            o.w[2] = batch3_partner(t.w[2], j); o.w[3] = batch3_partner(t.w[3], j);
+            o.w[0] = batch3_partner<LG>(t.w[0], j); o.w[1] = batch3_partner<LG>(t.w[1], j);
+            o.w[2] = batch3_partner<LG>(t.w[2], j); o.w[3] = batch3_partner<LG>(t.w[3], j);
             if (l2 & (1u << j)) { acc.w[0] ^= o.w[0]; acc.w[1] ^= o.w[1]; acc.w[2] ^= o.w[2]; acc.w[3] ^= o.w[3]; }
         }
         { const uint4 ev = *reinterpret_cast<const uint4 *>(smem + hsA2 + 16u); acc.w[0] ^= ev.x; acc.w[1] ^= ev.y; acc.w[2] ^= ev.z; acc.w[3] ^= ev.w; }
@@ -1518,8 +1355,7 @@ static int set_lds_attrs(int device, DeviceState *ds) {
     SETATTRH(10, MODE_ENC); SETATTRH(12, MODE_ENC); SETATTRH(14, MODE_ENC); SETATTRH(10, MODE_DEC); SETATTRH(12, MODE_DEC); SETATTRH(14, MODE_DEC);
 #undef SETATTRH
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fold), hipFuncAttributeMaxDynamicSharedMemorySize, FOLD_LDS_CLOSE_BYTES));
-#define SETATTRB(NR, D) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch<NR, D>), hipFuncAttributeMaxDynamicSharedMemorySize, BATCH_LDS_BYTES)); \
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktg<NR, D, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, PKTG_LDS_TOTAL(2))); \
+#define SETATTRB(NR, D) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktg<NR, D, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, PKTG_LDS_TOTAL(2))); \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktg<NR, D, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, PKTG_LDS_TOTAL(3))); \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktg<NR, D, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, PKTG_LDS_TOTAL(4))); \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktg<NR, D, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, PKTG_LDS_TOTAL(6))); \
@@ -1529,7 +1365,8 @@ static int set_lds_attrs(int device, DeviceState *ds) {
 #undef SETATTRB
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_combine), hipFuncAttributeMaxDynamicSharedMemorySize, CMB_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_combine_batch), hipFuncAttributeMaxDynamicSharedMemorySize, CMB_LDS_BYTES));
-#define SETATTRB3(NR, D) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch3<NR, D, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, BATCH3_LDS_BYTES_LG(4))); \
+#define SETATTRB3(NR, D) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch3<NR, D, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, BATCH3_LDS_BYTES_LG(6))); \
+                         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch3<NR, D, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, BATCH3_LDS_BYTES_LG(4))); \
                          HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch3<NR, D, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, BATCH3_LDS_BYTES_LG(3)))
     SETATTRB3(10, 0); SETATTRB3(12, 0); SETATTRB3(14, 0); SETATTRB3(10, 1); SETATTRB3(12, 1); SETATTRB3(14, 1);
 #undef SETATTRB3
@@ -2547,7 +2384,8 @@ static int packets_pick_lg(u32 n_cu, size_t n_pkts, size_t pkt_len, bool var, bo
     const size_t g = fill < cap ? fill : cap;
     return g >= 64 ? 6 : g >= 16 ? 4 : g >= 8 ? 3 : 2;
 }
-// Packets with their OWN key (k_batch3 / k_batch): lanes per packet as log2 (3, 4 = k_batch3 with 8 / 16 lanes, 6 = one wave per packet, k_batch).  16 lanes once
+// Packets with their OWN key (k_batch3): lanes per packet as log2 (3, 4, 6 = 8 / 16 lanes, a whole wave; the two-pass kernel k_batch of rounds 2 - 3 that
+// the numbers below call by name is gone since round 4: k_batch3<.., 6> took its place, 4096 x 1 MiB 443 -> 637 GiB/s).  16 lanes once
 // there are packets enough to fill the machine that way (one 1024-lane workgroup per CU = 64 packets per CU) or the packets are short, else one wave per packet.
 // Measured, AES-128, GiB/s k_batch / k_batch3 (profiles/r03/batch_sweep_aes128.txt): 4096 x 1 KiB 30 / 56, 4096 x 256 B 7.5 / 17, 1024 x 1 KiB 14 / 16.5; 1024 x 4 KiB
 // 45 / 33, 4096 x 4 KiB 108 / 120, 4096 x 16 KiB 286 / 168; from 16384 packets k_batch3 wins at every size (4 KiB 179 / 350).  8 lanes (eight packets per wave
@@ -2683,36 +2521,25 @@ static int batch_launch(int device, int decrypt, size_t n_pkts, size_t key_len, 
     if ((rc = set_lds_attrs(device, ds))) return rc;
     HIPCHK(hipSetDevice(device));
     p.n_pkts = (u32)n_pkts;
-    const u32 waves_per_wg = AESGCM_WG / 64;
-    u32 wgs = (u32)((n_pkts + waves_per_wg - 1) / waves_per_wg);
-    const u32 gmax = (u32)(2 * ds->n_cu > AESGCM_GMAX ? AESGCM_GMAX : 2 * ds->n_cu);
-    if (wgs > gmax) wgs = gmax;
+    u32 wgs = 0;
     {   // a fresh dispenser per launch (zeroed on the launch stream), so launches on different streams may overlap
         std::lock_guard<std::mutex> lk(g_mu);
         p.counter = ds->batch_counter + (ds->batch_slot++ % BATCH_DISPENSERS);
         p.counter_base = 0;
     }
-    {   // deal: about 16 dispenser fetches per wave, at most 16 packets per fetch
-        u32 deal = (u32)(n_pkts / ((size_t)wgs * waves_per_wg * 16));
-        deal = deal < 1 ? 1 : deal > 16 ? 16 : deal;
-#ifdef AESGCM_DEBUG_KNOBS
-        if (g_force.batch_deal >= 1 && g_force.batch_deal <= 4096) deal = (u32)g_force.batch_deal;
-#endif
-        p.deal = deal;
-    }
     const int nr = (int)(key_len / 4 + 6);
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipMemsetAsync(p.counter, 0, 4, st));
-    int lg = batch_pick_lg(ds->n_cu, n_pkts, p.pkt_len, p.data_off != nullptr);          // 3 / 4: k_batch3 with 8 / 16 lanes per packet; 6: k_batch
+    int lg = batch_pick_lg(ds->n_cu, n_pkts, p.pkt_len, p.data_off != nullptr);          // k_batch3 with 8 / 16 / 64 lanes per packet
 #ifdef AESGCM_DEBUG_KNOBS
     if (g_force.batch_lanes) lg = g_force.batch_lanes == 8 ? 3 : g_force.batch_lanes == 16 ? 4 : 6;
 #endif
-    if (lg < 6) {
+    if (lg <= 6) {
         // packets of mixed length: by falling length class once the batch fills the machine several times over (BATCH_ORDER_MIN; as aesgcm_packets_crypt_dev)
         OrderSlot *oslot = nullptr;
-        bool ordered = p.data_off && n_pkts >= BATCH_ORDER_MIN(nr);
+        bool ordered = lg < 6 && p.data_off && n_pkts >= BATCH_ORDER_MIN(nr);
 #ifdef AESGCM_DEBUG_KNOBS
-        if (g_force.batch_order) ordered = p.data_off && g_force.batch_order == 1;
+        if (g_force.batch_order) ordered = lg < 6 && p.data_off && g_force.batch_order == 1;
 #endif
         std::unique_lock<std::mutex> order_lock(g_mu, std::defer_lock);             // held from the choice of the slot to the event behind its reader: callers on other threads queue up here
         if (ordered) {
@@ -2727,23 +2554,22 @@ static int batch_launch(int device, int decrypt, size_t n_pkts, size_t key_len, 
         if (wgs > (u32)ds->n_cu) wgs = (u32)ds->n_cu;
         u32 deal = (u32)(n_pkts / ((size_t)wgs * waves_per_wg * 16));
         deal = deal < P ? P : deal > 8 * P ? 8 * P : (deal + P - 1) / P * P;
+#ifdef AESGCM_DEBUG_KNOBS
+        if (g_force.batch_deal >= 1 && g_force.batch_deal <= 4096) deal = ((u32)g_force.batch_deal + P - 1) / P * P;
+#endif
         p.deal = deal;
 #define LB3(NR, D, LG) hipLaunchKernelGGL((k_batch3<NR, D, LG>), dim3(wgs), dim3(BATCH3_LANES(NR)), BATCH3_LDS_BYTES_LG(LG), st, ds->tables, p)
 #define LB3N(D, LG) do { if (nr == 10) LB3(10, D, LG); else if (nr == 12) LB3(12, D, LG); else LB3(14, D, LG); } while (0)
         if (lg == 3) { if (decrypt) LB3N(1, 3); else LB3N(0, 3); }
-        else { if (decrypt) LB3N(1, 4); else LB3N(0, 4); }
+        else if (lg == 4) { if (decrypt) LB3N(1, 4); else LB3N(0, 4); }
+        else { if (decrypt) LB3N(1, 6); else LB3N(0, 6); }
 #undef LB3N
 #undef LB3
         HIPCHK(hipGetLastError());
         if (oslot && p.perm) HIPCHK(hipEventRecord(oslot->done, st));
         return AESGCM_OK;
     }
-#define LB(NR, D) hipLaunchKernelGGL((k_batch<NR, D>), dim3(wgs), dim3(AESGCM_WG), BATCH_LDS_BYTES, st, ds->tables, p)
-    if (decrypt) { if (nr == 10) LB(10, 1); else if (nr == 12) LB(12, 1); else LB(14, 1); }
-    else         { if (nr == 10) LB(10, 0); else if (nr == 12) LB(12, 0); else LB(14, 0); }
-#undef LB
-    HIPCHK(hipGetLastError());
-    return AESGCM_OK;
+    return AESGCM_EARG;                                         // batch_pick_lg gives 3, 4 or 6
 }
 
 int aesgcm_batch_crypt_dev(int device, int decrypt, size_t n_pkts, size_t key_len, const void *d_keys, const void *d_ivs,

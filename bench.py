@@ -419,7 +419,7 @@ def run_cfg5(args, rank, world, dev, ex, cpu_base):
         same_build = bool(pm) and pm.get("so_sha256") == so_sha
         nr = key_bits // 32 + 6
         lanes = lib.batch_shape(n, pkt, device=dev)                # the shape the library's own rule gives this call (aesgcm_batch_shape)
-        kname = "k_batch<%d,%d>" % (nr, int(args.decrypt)) if lanes == 64 else "k_batch3<%d,%d,%d>" % (nr, int(args.decrypt), 3 if lanes == 8 else 4)
+        kname = "k_batch3<%d,%d,%d>" % (nr, int(args.decrypt), {8: 3, 16: 4, 64: 6}[lanes])
         roofline = {"bound": "hbm", "kernel": "%s (%d lanes per packet%s: per-packet aes_kexp + AES-CTR + GHASH)" % (kname, lanes, ", FORCED through the debug build" if args.batch_lanes else ""),
                     "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_BYTES_PER_S, 4), "traffic": pm.get("hbm_bytes_per_launch") if same_build else None,
@@ -691,7 +691,7 @@ def main(argv=None):
                     help="--inflight: the cyclic rows in their half shape (context option cyc_half: 256 workgroups of 512 lanes, two per CU, so that one message's "
                          "staging and closing run beside another's rows): 1 always, 0 never, -1 (default) the library's own rule -- half when another context has a message under way")
     ap.add_argument("--batch-lanes", type=int, default=0, choices=(0, 8, 16, 64),
-                    help="cfg5, A/B runs only: force the lanes per packet (k_batch3 with 8 / 16, k_batch with 64) -- through the DEBUG build of the library "
+                    help="cfg5, A/B runs only: force the lanes per packet (k_batch3 with 8 / 16 / 64) -- through the DEBUG build of the library "
                          "(libaesgcm_hip_dbg.so, include/aesgcm_debug.h); the line then says so and is not a product measurement")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
                     help="--inflight: a context option for every context (aesgcm_ctx_set_option), e.g. --opt cyc_max=0 --opt body_min=16777216; repeatable")

@@ -15,8 +15,8 @@ extern "C" {
 
 /* what = "pkt_lanes"   : aesgcm_packets_crypt_dev takes 1 (k_pktl), 4 / 8 / 16 (k_pktg lane groups) or 64 (k_pktg, a wave per packet) lanes per packet
  *        "pkt_deal"    : packets per dispenser fetch of k_pktg (rounded up to a multiple of the packets per wave, at most 64)
- *        "batch_lanes" : aesgcm_batch_crypt[_var]_dev takes 8 / 16 (k_batch3) or 64 (k_batch) lanes per packet
- *        "batch_deal"  : packets per dispenser fetch of k_batch (one wave per packet)
+ *        "batch_lanes" : aesgcm_batch_crypt[_var]_dev takes 8 / 16 / 64 lanes per packet (k_batch3)
+ *        "batch_deal"  : packets per dispenser fetch of k_batch3 (rounded up to a multiple of the packets per wave)
  *        "pkt_ilp"     : k_pktl in its form for batches that do not fill the chip (512-lane workgroups, eight keystream chains per line) always (1) or never (2)
  *        "batch_order" : aesgcm_batch_crypt_var_dev takes its packets by falling length class always (1) or never (2) instead of from 262144 (AES-128) / 98304 packets
  * value 0 = the library's own choice again.  Not thread-safe; set it between launches. */

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The one-wave-per-packet fallback of the per-packet-key batch (k_batch) in the regime where the library picks it: 1024 packets of 16 KiB, AES-128 (GPU box; for rocprofv3)."""
+"""The one-wave-per-packet shape of the per-packet-key batch (k_batch3<.., 6>; until round 4: k_batch) in the regime where the library picks it: 1024 packets of 16 KiB, AES-128 (GPU box; for rocprofv3)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import aesgcm_amd  # noqa
@@ -14,4 +14,4 @@ for it in range(8):
     lib.dev_sync(); t0 = time.perf_counter()
     lib.batch_crypt_dev(False, n, kb, d_keys.ptr, d_ivs.ptr, d_pt.ptr, pkt, d_ct.ptr, d_tags.ptr)
     lib.dev_sync(); best = min(best, time.perf_counter() - t0)
-print("k_batch 1024 x 16 KiB AES-128: %.1f GiB/s, %.1f us" % (n * pkt / best / 2**30, best * 1e6))
+print("wave per packet, 1024 x 16 KiB AES-128: %.1f GiB/s, %.1f us" % (n * pkt / best / 2**30, best * 1e6))

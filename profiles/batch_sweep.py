@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-packet-key batch (aesgcm_batch_crypt_dev): the kernel shapes over packet count and size (GPU box) -- one wave per packet (k_batch), 16 and 8 lanes per
+"""Per-packet-key batch (aesgcm_batch_crypt_dev): the kernel shapes over packet count and size (GPU box) -- one wave per packet (k_batch3<.., 6>), 16 and 8 lanes per
 packet (k_batch3), and the library's own choice.  Shapes are forced through the debug build (libaesgcm_hip_dbg.so).  GiB/s, best of 4.
 python profiles/batch_sweep.py [key bytes]      (round 3's version also had the two-phase k_batch2, deleted in round 4)"""
 import os, sys, time

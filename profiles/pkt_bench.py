@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Packet-path workloads for profiling (GPU box):  python profiles/pkt_bench.py KIND [--n N] [--len L] [--key-bits B] [--steps K]
-  KIND = batch  BASELINE config 5: N packets of L bytes, per-packet key and IV (k_batch), SplitMix64 inputs of SURVEY 8(d)
+  KIND = batch  BASELINE config 5: N packets of L bytes, per-packet key and IV (k_batch3), SplitMix64 inputs of SURVEY 8(d)
          pktw   N packets under ONE key, one wave per packet (k_pktg<.., 6>)
          pktg   N packets under ONE key, 16 lanes per packet (k_pktg<.., 4>)
          pktl   N packets under ONE key, one lane per packet (k_pktl)

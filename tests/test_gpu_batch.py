@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 def batch_shape(request, hip):
     """the batch tests run with the host's own choice of kernel shape (the product library) and with each shape forced: 16 lanes per packet (k_batch3: four
     packets per wave, GHASH fused into the CTR loop), 8 lanes per packet (eight packets per wave, one table slot each, every multiply split over a lane pair) and
-    64 lanes per packet (k_batch).  Forcing a shape is a function of the debug build only (libaesgcm_hip_dbg.so, include/aesgcm_debug.h)."""
+    64 lanes per packet (k_batch3<.., 6>; the two-pass k_batch of rounds 2 - 3 is gone).  Forcing a shape is a function of the debug build only (libaesgcm_hip_dbg.so, include/aesgcm_debug.h)."""
     lanes = {"lanes16": 16, "lanes8": 8, "lanes64": 64}.get(request.param)
     if lanes is None:
         yield request.param

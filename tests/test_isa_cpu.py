@@ -3,11 +3,11 @@ a GPU) and reads it with tools/isa_census.py: a register spill that lands inside
 (round 1: three scratch_load per row in k_body = 13 % extra traffic; round 2: nine scratch ops in k_pkt's row loop), and it
 arrives silently with any change of a launch bound or of the lane code.  Fails if
 
-  * k_body (every key size, ENC / DEC / PROBE, dealt chunks and cyclic rows with their fused closing), k_pktl, k_pktg (every shape), k_batch3, k_batch or the KS / ECB instances of k_main use scratch at all;
+  * k_body (every key size, ENC / DEC / PROBE, dealt chunks and cyclic rows with their fused closing), k_pktl, k_pktg (every shape), k_batch3 (every shape) or the KS / ECB instances of k_main use scratch at all;
   * any scratch_* op sits at the innermost loop depth of k_main ENC / DEC (the row loop), of k_pktg (the iteration loop of a
-    packet's lane group), of k_batch / k_batch3 (the block loops);
+    packet's lane group), of k_batch3 (the block loops);
   * a kernel needs more registers than its launch geometry allows;
-  * a retired kernel is back in the library (k_batch2, deleted in round 4), or the kernel set is not the one DESIGN.md lists;
+  * a retired kernel is back in the library (k_batch2 and k_batch, deleted in round 4), or the kernel set is not the one DESIGN.md lists;
   * a through-the-L2 store (inline asm: the compiler's hazard recognizer does not see it) reads a base SGPR that a VALU instruction wrote fewer than 5 wait
     states earlier (tools/isa_census.py wt_store_hazards).
 
@@ -54,7 +54,7 @@ def test_no_scratch_in_the_hot_loops(census):
             n, depth = _inner_scratch(k)
             assert n == 0, "%s: %d scratch ops at loop depth %d" % (name, n, depth)
             seen += 1
-    assert seen == 12 + 15 + 24 + 12 + 6 + 12           # k_main (3 key sizes x 4 modes), k_body (x ENC, DEC dealt and cyclic + the dealt probe), k_pktg (x 2 x 4 shapes), k_pktl (x 2 forms), k_batch, k_batch3 (x 2 shapes)
+    assert seen == 12 + 15 + 24 + 12 + 18               # k_main (3 key sizes x 4 modes), k_body (x ENC, DEC dealt and cyclic + the dealt probe), k_pktg (x 2 x 4 shapes), k_pktl (x 2 forms), k_batch3 (x 3 shapes)
 
 
 def test_register_budgets(census):
@@ -77,9 +77,9 @@ def test_kernel_set(census):
     fam = {}
     for name in census:
         fam.setdefault(name.split("<")[0], []).append(name)
-    assert sorted(fam) == ["k_batch", "k_batch3", "k_body", "k_bodyh", "k_combine", "k_combine_batch", "k_copy16", "k_fill_splitmix64", "k_fold", "k_gfmul", "k_init_tables",
+    assert sorted(fam) == ["k_batch3", "k_body", "k_bodyh", "k_combine", "k_combine_batch", "k_copy16", "k_fill_splitmix64", "k_fold", "k_gfmul", "k_init_tables",
                            "k_len_hist", "k_len_scan", "k_len_scatter", "k_main", "k_pktg", "k_pktl", "k_setup", "k_setup_ptab"], sorted(fam)
-    assert (len(fam["k_main"]), len(fam["k_body"]), len(fam["k_bodyh"]), len(fam["k_pktg"]), len(fam["k_pktl"]), len(fam["k_batch"]), len(fam["k_batch3"])) == (12, 15, 6, 24, 12, 6, 12)
+    assert (len(fam["k_main"]), len(fam["k_body"]), len(fam["k_bodyh"]), len(fam["k_pktg"]), len(fam["k_pktl"]), len(fam["k_batch3"])) == (12, 15, 6, 24, 12, 18)
 
 
 def test_no_sgpr_hazard_in_front_of_the_write_through_stores(census):
