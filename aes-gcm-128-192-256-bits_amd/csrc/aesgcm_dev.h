@@ -1528,19 +1528,15 @@ static inline CombineParams plan_combine_final(uint4 *state, const uint8_t iv[12
 }
 
 // ================================================================================================
-// Batch path (BASELINE config 5): many short independent packets, each with its OWN key and IV.
-// One wave per packet.  No per-key context exists, so everything key-dependent is rebuilt per packet
-// inside the kernel: aes_kexp (round keys end up wave-uniform -> scalar registers), H and E_K(J0), and
-// -- because H-power tables cannot be amortised -- GHASH uses Shoup's 4-bit method: a 16-entry table
-// T[v] = v*c per constant c (256 B in LDS per wave; one bank row, conflict-free) and
-//     Y*c = Horner over Y's 32 nibbles:  Z = Z*x^4 xor T[nibble]   (x^4 = shift right 4 + 16-bit reduction).
-// The packet polynomial is evaluated as: lane L runs serial Horner with H over its q consecutive blocks,
-// then a 6-level cross-lane tree multiplies by c_j = H^(q*2^j) (c_{j+1} = c_j^2, table rebuilt per level).
+// Batch path (BASELINE config 5): many independent packets, each with its OWN key and IV (k_batch3: 8, 16 or 64 lanes per packet).  No per-key context exists,
+// so everything key-dependent is rebuilt per packet inside the kernel: aes_kexp, H and E_K(J0), and -- because H-power tables cannot be amortised -- GHASH
+// multiplies through Shoup tables of the packet's own constants built in LDS (the two-table form with the reduction delayed: shoup2_mul_dr, "k_batch3
+// pieces" below).  Lane l of a packet's group runs Horner with H^(lanes per packet) over its slots; an LG-level cross-lane tree closes the packet.
+// shoup_mul (one 16-entry table and a reduction-table read per nibble: the round-2 form) stays as the unit-tested reference of the later multiplies
+// (tests/host_emul); BATCH_LDS_* is the LDS image that test gives it.
 // ================================================================================================
-#define BATCH_WAVE_LDS 1024u                    /* per wave: the two-table Shoup form (Th | Tl, 512 B) of H and of the tree constant: shoup2_mul_dr since round 4 */
-#define BATCH_LDS_RTAB_OFF (AESGCM_LDS_AES_OFF + AESGCM_LDS_AES)            /* 16 x u32 reduction table (shoup_mul: the round-2 multiply, kept as a unit-tested reference) */
-#define BATCH_LDS_WAVE_OFF (BATCH_LDS_RTAB_OFF + 256u)                     /* behind the T-tables, 256-byte aligned (the multiply ORs the entry offset into the slot address) */
-#define BATCH_LDS_BYTES (BATCH_LDS_WAVE_OFF + (AESGCM_WG / 64u) * BATCH_WAVE_LDS)
+#define BATCH_LDS_RTAB_OFF (AESGCM_LDS_AES_OFF + AESGCM_LDS_AES)            /* 16 x u32 reduction table of shoup_mul */
+#define BATCH_LDS_BYTES (BATCH_LDS_RTAB_OFF + 64u)
 
 struct BatchParams {
     const unsigned char *keys;   // n_pkts * key_len bytes
