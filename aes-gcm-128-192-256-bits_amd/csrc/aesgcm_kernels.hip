@@ -1205,9 +1205,12 @@ static int hip_fail(hipError_t e, const char *what) {
 // The launch order of packets of mixed length (k_len_*): scratch of one launch.  `done` is recorded behind the packet kernel that reads the order, and the next
 // user of the slot makes its stream wait for it: slots may be reused by launches on other streams at any rate.
 struct OrderSlot { u32 *perm = nullptr; size_t cap = 0; u32 *bins = nullptr; hipEvent_t done = nullptr; };
-struct DeviceState { DevTables *tables = nullptr; int n_cu = 0; bool attrs = false; u32 *batch_counter = nullptr; u32 batch_slot = 0; OrderSlot order[4]; unsigned order_next = 0; };   // ring of dispensers: concurrent batch launches never share one
-static std::mutex g_mu;
-static std::vector<DeviceState> g_dev;
+// `streams`: the streams of destroyed contexts, for the next context of the device -- hipStreamCreate takes 2 ms and hipStreamDestroy half a millisecond on this
+// runtime (profiles/microbench/runtime_costs.cpp), more than everything else a context costs together (k_setup: 0.4 ms).
+struct DeviceState { DevTables *tables = nullptr; int n_cu = 0; bool attrs = false; u32 *batch_counter = nullptr; u32 batch_slot = 0; OrderSlot order[4]; unsigned order_next = 0;
+                     std::vector<hipStream_t> streams; };   // ring of dispensers: concurrent batch launches never share one
+static std::mutex &g_mu = *new std::mutex();
+static std::vector<DeviceState> &g_dev = *new std::vector<DeviceState>();     // never destroyed (as g_ctxs): contexts may outlive this library's static destructors
 
 static int device_state(int device, DeviceState **out) {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -1846,7 +1849,11 @@ static int ctx_create_common(aesgcm_ctx **out, int device, const uint8_t *key, s
     c->G = G;
     hipError_t e;
     if ((e = hipSetDevice(device)) != hipSuccess) { delete c; return hip_fail(e, "hipSetDevice"); }
-    if ((e = hipStreamCreate(&c->stream)) != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate"); }
+    {   // a stream a destroyed context left behind, or a new one
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (!ds->streams.empty()) { c->stream = ds->streams.back(); ds->streams.pop_back(); }
+    }
+    if (!c->stream && (e = hipStreamCreate(&c->stream)) != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate"); }
     if ((e = hipMalloc(&c->km, sizeof(KeyMaterial))) != hipSuccess ||
         (e = hipMalloc(&c->fold_a, sizeof(uint4) * 64 * FOLD_A_ITEMS)) != hipSuccess ||
         (e = hipMalloc(&c->fold_b, sizeof(uint4) * 64 * FOLD_B_ITEMS)) != hipSuccess ||
@@ -1909,6 +1916,10 @@ int aesgcm_ctx_destroy(aesgcm_ctx *c) {
     if (c->st_aad) hipFree(c->st_aad);
     if (c->ev_sync) hipEventDestroy(c->ev_sync);
     if (c->ev_fused) hipEventDestroy(c->ev_fused);
+    if (c->stream) {                                            // idle by now (synchronised above): kept for the device's next context, up to 64 of them
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (c->device >= 0 && c->device < (int)g_dev.size() && g_dev[c->device].streams.size() < 64) { g_dev[c->device].streams.push_back(c->stream); c->stream = nullptr; }
+    }
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
     return AESGCM_OK;

@@ -104,7 +104,7 @@ AESGCM_API int aesgcm_ctx_create(aesgcm_ctx **out, int device, const uint8_t *ke
 AESGCM_API int aesgcm_ctx_create_preexpanded(aesgcm_ctx **out, int device, const uint8_t *rk, int nr);
 /* A new key for an existing context: the reference core's "load key" between frames (tb/gcm_gctr.py:144-175; H is recomputed only then,
  * src/gcm_gctr.vhd:142-144).  The context keeps its stream, scratch, host slot and options; only the key schedule, H and the H-power tables
- * are rebuilt (about half a millisecond, against 4.5 ms for destroying the context and creating another).  Waits for the context's queued
+ * are rebuilt (0.4 ms, half of what destroying the context and creating another costs).  Waits for the context's queued
  * work first; AESGCM_ESTATE inside an open aesgcm_stream_* session. */
 AESGCM_API int aesgcm_ctx_rekey(aesgcm_ctx *ctx, const uint8_t *key, size_t key_len);
 AESGCM_API int aesgcm_ctx_destroy(aesgcm_ctx *ctx);
