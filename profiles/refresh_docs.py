@@ -51,7 +51,7 @@ status = """## Status (round 4; one MI355X; every number from `profiles/%s/`, li
 
 | Workload | GiB/s of plaintext | HBM roofline fraction | HBM bytes vs algorithmic | Evidence |
 |---|---|---|---|---|
-| **cfg3: AES-256-GCM, one 16 GiB message (the metric)** | **%.1f** (boxes of this round: 933 - 984) | **%.3f** (target 0.70: missed, DESIGN.md §9) | 1.008 x | `bench_default.json`, `cfg3_n1/` |
+| **cfg3: AES-256-GCM, one 16 GiB message (the metric)** | **%.1f** (boxes of this round: 933 - 991) | **%.3f** (target 0.70: missed, DESIGN.md §9) | 1.008 x | `bench_default.json`, `cfg3_n1/` |
 | cfg3, decrypt + authenticate | %.1f | %.3f | 1.008 x | `bench_dec.json`, `cfg3_dec/` |
 | cfg2: AES-128-GCM, 1 GiB | %.1f | %.3f | 1.016 x | `bench_cfg2.json`, `cfg2_n1/` |
 | cfg4: rank step of the 8-GPU 128 GiB job, emulated on one GPU | %.0f per rank (%.3f of the N = 1 step) | %.3f | -- | `bench_emu_r0.json`, `bench_emu_r7.json` |
@@ -84,7 +84,8 @@ pmc_<tag>.json, stats_run.json}`, the bench lines of the same call in `%s/bench_
 `profiles/adopt_collection.sh`, table by `profiles/collection_table.py`, these lines by `profiles/refresh_docs.py`;
 `profiles/pmc_cfg{2,3,5}_n1.json` are copies of this collection's, so `bench.py` reports `roofline.traffic` on this build).  Boxes
 differ by their clock under load: this one ran cfg3 at %.1f GiB/s (sclk %s MHz); the same kernel measured between 933 and
-984 on the boxes of this round's collections (calls 12 .. 68; sclk 1976 .. 2104).  The last column is algorithmic bytes / kernel
+991 on the boxes of this round's collections (calls 12 .. 70; sclk 1976 .. 2104; the three tags marked call 69 were collected on the
+library of call 68, whose kernels are the same).  The last column is algorithmic bytes / kernel
 time under the profiler / 8 TB/s.
 
 %s
