@@ -10,6 +10,12 @@ from util import splitmix_bytes
 
 pytestmark = pytest.mark.gpu
 
+# AESGCM_FUZZ_SEED=k re-draws every randomized test below (shapes, lengths AND the key / IV / data streams); AESGCM_FUZZ_SCALE multiplies the iteration
+# counts.  The suite runs k = 0, scale 1; profiles/runs/r04_run72.sh went through k = 1 .. 8.
+SEED = int(os.environ.get("AESGCM_FUZZ_SEED", "0"))
+SCALE = float(os.environ.get("AESGCM_FUZZ_SCALE", "1"))
+S0 = 1000003 * SEED                                    # offset of the SplitMix64 stream seeds
+
 
 def _len(rng, cap):
     kind = rng.random()
@@ -22,15 +28,15 @@ def _len(rng, cap):
 
 
 def test_fuzz_one_shot_and_device_paths(hip, orc):
-    rng = random.Random(20260101)
+    rng = random.Random(20260101 + SEED)
     if True:
-        for it in range(220):
+        for it in range(int(220 * SCALE)):
             klen = rng.choice((16, 24, 32))
             tw = rng.choice((None, None, 1, 2, 3, 5, 16, 64))
-            key, iv = splitmix_bytes(9000 + it, klen), splitmix_bytes(9500 + it, 12)
+            key, iv = splitmix_bytes(S0 + 9000 + it, klen), splitmix_bytes(S0 + 9500 + it, 12)
             al = _len(rng, 1 << 16) if rng.random() < 0.7 else 0
             n = _len(rng, 6 << 20)
-            aad, pt = splitmix_bytes(10000 + it, al), splitmix_bytes(11000 + it, n)
+            aad, pt = splitmix_bytes(S0 + 10000 + it, al), splitmix_bytes(S0 + 11000 + it, n)
             f = orc.Fast(key)
             want = f.encrypt(iv, aad, pt)
             ctx = hip.Context(key)
@@ -59,12 +65,12 @@ def test_fuzz_one_shot_and_device_paths(hip, orc):
 
 
 def test_fuzz_random_shard_splits(hip, orc):
-    rng = random.Random(77)
-    for it in range(40):
+    rng = random.Random(77 + SEED)
+    for it in range(int(40 * SCALE)):
         klen = rng.choice((16, 24, 32))
-        key, iv = splitmix_bytes(12000 + it, klen), splitmix_bytes(12500 + it, 12)
+        key, iv = splitmix_bytes(S0 + 12000 + it, klen), splitmix_bytes(S0 + 12500 + it, 12)
         al, n = rng.choice((0, 13, 64, 1000)), _len(rng, 3 << 20)
-        aad, pt = splitmix_bytes(13000 + it, al), splitmix_bytes(14000 + it, n)
+        aad, pt = splitmix_bytes(S0 + 13000 + it, al), splitmix_bytes(S0 + 14000 + it, n)
         want = orc.Fast(key).encrypt(iv, aad, pt)
         ctx = hip.Context(key)
         nb = (n + 15) // 16
@@ -120,16 +126,17 @@ def test_fuzz_packets_and_batches(hip, orc):
     MACsec-sized, a few long ones), AAD, fixed records or offset arrays with aligned or arbitrary starts, every kernel shape (forced through the debug build) or
     the library's own, taken in array order or by length class; encrypt, then decrypt in place with a few forged tags.  A sample of packets against the oracle."""
     import struct
-    rng = random.Random(20260102)
+    rng = random.Random(20260102 + SEED)
     shapes = {"wave": 64, "group16": 16, "g8": 8, "g4": 4, "lane": 1}
 
     def up(b):
         d = hip.DeviceBuffer(max(len(b), 16)); d.upload(b); return d
     with hip.debug_library() as dbg:
-        for it in range(150):
+        for it in range(int(150 * SCALE)):
             per_key = it % 3 == 2
             klen = rng.choice((16, 24, 32))
-            m = rng.choice((1, 7, 63, 64, 65, 300, 1000, 4097, 9000))
+            m = rng.choice((1, 7, 63, 64, 65, 300, 1000, 4097, 9000) + ((20000, 120000, 140000) if SEED else ()))      # re-seeded runs also cross the counts where the
+            #                                                                 library itself changes shape (one lane per packet, its ILP form, the ordering)
             mix = rng.choice(("macsec", "tiny", "ragged", "long"))
             def one():
                 if mix == "macsec":
@@ -138,7 +145,7 @@ def test_fuzz_packets_and_batches(hip, orc):
                     return rng.choice((0, 1, 15, 16, 17, 31, 32, 48))
                 if mix == "ragged":
                     return rng.randrange(0, 700)
-                return rng.choice((64, 1000, 4096, 9000, 70000 if m <= 300 else 5000))
+                return rng.choice((64, 1000, 4096, 9000, 70000 if m <= 300 else 5000)) if m <= 9000 else rng.choice((64, 1000, 2048))
             align = rng.choice((True, False))
             lens = [one() for _ in range(m)]
             if align:
@@ -147,9 +154,9 @@ def test_fuzz_packets_and_batches(hip, orc):
             doff, aoff = [0], [0]
             for a, b in zip(lens, aads):
                 doff.append(doff[-1] + a); aoff.append(aoff[-1] + b)
-            key = splitmix_bytes(30000 + it, klen)
-            keys = splitmix_bytes(31000 + it, klen * m) if per_key else key * m
-            ivs, aad, pt = splitmix_bytes(32000 + it, 12 * m), splitmix_bytes(33000 + it, max(aoff[-1], 16)), splitmix_bytes(34000 + it, max(doff[-1], 16))
+            key = splitmix_bytes(S0 + 30000 + it, klen)
+            keys = splitmix_bytes(S0 + 31000 + it, klen * m) if per_key else key * m
+            ivs, aad, pt = splitmix_bytes(S0 + 32000 + it, 12 * m), splitmix_bytes(S0 + 33000 + it, max(aoff[-1], 16)), splitmix_bytes(S0 + 34000 + it, max(doff[-1], 16))
             order = rng.choice((0, 1))
             shape = rng.choice((None,) + tuple(shapes))
             d_ivs, d_aad, d_buf = up(ivs), up(aad), up(pt)
