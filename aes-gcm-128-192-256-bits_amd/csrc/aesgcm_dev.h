@@ -94,11 +94,11 @@ HD void gstore16_wt_at(void *p, uint4 v) {
 HD void gstore4_wt_at(void *p, u32 v) { asm volatile("global_store_dword %0, %1, off sc0 sc1" :: "v"(p), "v"(v) : "memory"); }
 HD void gstore1_wt_at(void *p, u32 v) { asm volatile("global_store_byte %0, %1, off sc0 sc1" :: "v"(p), "v"(v) : "memory"); }
 #else
-HD uint4 gload16(const void *p) { return *reinterpret_cast<const uint4 *>(p); }
-HD void gstore16(void *p, uint4 v) { *reinterpret_cast<uint4 *>(p) = v; }
+HD uint4 gload16(const void *p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }           // (host harness: the row code of k_rows runs on packets packed from any byte address)
+HD void gstore16(void *p, uint4 v) { __builtin_memcpy(p, &v, 16); }
 HD uint4 gload16_any(const void *p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }
 HD void gstore16_any(void *p, uint4 v) { __builtin_memcpy(p, &v, 16); }
-HD void gstore16_wt(unsigned char *base, u32 off, uint4 v) { *reinterpret_cast<uint4 *>(base + off) = v; }
+HD void gstore16_wt(unsigned char *base, u32 off, uint4 v) { __builtin_memcpy(base + off, &v, 16); }
 HD void gstore16_wt_at(void *p, uint4 v) { __builtin_memcpy(p, &v, 16); }
 HD void gstore4_wt_at(void *p, u32 v) { *reinterpret_cast<u32 *>(p) = v; }
 HD void gstore1_wt_at(void *p, u32 v) { *reinterpret_cast<unsigned char *>(p) = (unsigned char)v; }
@@ -1164,8 +1164,10 @@ HD void body_prio(u32 i, u32 rows, u32 slot) {
 }
 // lane `lane` of a wave that takes the n super-rows q0, q0 + qstep, ... in row phase v: returns sum_i X[row 4(q0 + i qstep) + v, lane] * K^(n-1-i),
 // K = H^(256 qstep) = the constant whose tables the launch staged in LDS
+// (body_strand_rows: the same over an explicit range -- `in` / `out` = the first block of the aligned body, ctr_hi0 = that block's message index >> 8 -- for callers
+// whose body is not described by a BodyParams: the chunks of k_rows, aesgcm_rows.h)
 template <int NR, int MODE, bool T4 = (AESGCM_T4 != 0)>
-HD uint4 body_strand_lane(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const BodyParams &p,
+HD uint4 body_strand_rows(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const unsigned char *in, unsigned char *out, u32 ctr_hi0,
                           const unsigned char *smem, const CtrConsts &cc, u32 q0, u32 qstep, u32 n, u32 v, u32 lane,
                           uint4 acc_in = make_uint4(0, 0, 0, 0), bool continued = false,        // continued: acc_in is the strand so far (one more multiply in front of the first row)
                           u32 prio_rows = 0, u32 prio_slot = 0) {                               // prio_rows > 0: rotate the wave's issue priority every prio_rows rows (body_prio)
@@ -1186,13 +1188,13 @@ HD uint4 body_strand_lane(const KeyMaterial *__restrict__ km, const DevTables *_
         if (prio_rows) body_prio(i, prio_rows, prio_slot);
         if (i || continued) acc = ghash_mul_const_lds(acc, smem);
         const u64 off = ((u64)q * 4 + v) * 1024;                       // byte offset of the row in the body
-        const unsigned char *src = reinterpret_cast<const unsigned char *>(uniform64((u64)(uintptr_t)p.in + off));
-        unsigned char *dst = reinterpret_cast<unsigned char *>(uniform64((u64)(uintptr_t)p.out + off));
+        const unsigned char *src = reinterpret_cast<const unsigned char *>(uniform64((u64)(uintptr_t)in + off));
+        unsigned char *dst = reinterpret_cast<unsigned char *>(uniform64((u64)(uintptr_t)out + off));
         // MODE_PROBE: the same instruction stream without HBM traffic -- the ceiling of the formulation itself
         // (aesgcm_ctx_ceiling_probe); the "plaintext" is a lane/row pattern and the ciphertext only feeds GHASH
         const uint4 x = (MODE == MODE_PROBE) ? make_uint4(lane, q, v, 0u) : gload16(src + lane16);
         u32 s0, s1, s2, s3;
-        body_state(s0, s1, s2, s3, b, p.ctr_hi0 + q, v, lane, cc, rk, tb);
+        body_state(s0, s1, s2, s3, b, ctr_hi0 + q, v, lane, cc, rk, tb);
         body_rounds<NR, T4>(s0, s1, s2, s3, rk, smem, lb);
         const uint4 y = make_uint4(x.x ^ s0, x.y ^ s1, x.z ^ s2, x.w ^ s3);                  // gcm_gctr.vhd:150
         if (MODE != MODE_PROBE) {
@@ -1205,6 +1207,12 @@ HD uint4 body_strand_lane(const KeyMaterial *__restrict__ km, const DevTables *_
         acc = xor4(acc, (MODE == MODE_DEC) ? x : y);                  // aes_gcm.vhd:207-211
     }
     return acc;
+}
+template <int NR, int MODE, bool T4 = (AESGCM_T4 != 0)>
+HD uint4 body_strand_lane(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const BodyParams &p,
+                          const unsigned char *smem, const CtrConsts &cc, u32 q0, u32 qstep, u32 n, u32 v, u32 lane,
+                          uint4 acc_in = make_uint4(0, 0, 0, 0), bool continued = false, u32 prio_rows = 0, u32 prio_slot = 0) {
+    return body_strand_rows<NR, MODE, T4>(km, tb, p.in, p.out, p.ctr_hi0, smem, cc, q0, qstep, n, v, lane, acc_in, continued, prio_rows, prio_slot);
 }
 // dealt chunks: lane `lane` of the wave that owns chunk c = 4*s + v: returns sum_i X[row 4(sT+i)+v, lane] * (H^256)^(T-1-i)
 template <int NR, int MODE>
@@ -1414,7 +1422,7 @@ HD G128 gf_pow_h_serial(const KeyMaterial *km, u64 e) {
 static inline void iv_to_words(const uint8_t iv[12], u32 w[3]) { for (int q = 0; q < 3; q++) w[q] = load_le32(iv + 4 * q); }
 
 // how many dispenser queues a launch of C chunks uses, and the chunks per queue
-static inline void plan_queues(u32 C, u32 *nq, u32 *seg) {
+HD void plan_queues(u32 C, u32 *nq, u32 *seg) {
     u32 n = C >= 4096 ? AESGCM_NQ : C >= 512 ? 4 : 1;
     *nq = n; *seg = (C + n - 1) / n;
 }

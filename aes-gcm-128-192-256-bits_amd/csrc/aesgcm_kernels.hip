@@ -23,6 +23,7 @@
 // lane-wise (B_L = sum_i item_i[L] * H^(blocks to the end)), k_combine forms P = sum_L B_L * H^(63-L).
 // The tag is (P*H ^ L)*H ^ E_K(J0) = P*H^2 ^ L*H ^ E_K(J0).
 #include "aesgcm_dev.h"
+#include "aesgcm_rows.h"
 #include "../../include/aesgcm.h"
 
 #include <algorithm>
@@ -1191,6 +1192,152 @@ __global__ __launch_bounds__(ILP ? AESGCM_PKTL_WG_ILP : AESGCM_PKTL_WG, ILP ? 2 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_rows / k_rows_close (+ k_rows_plan, k_rows_expand with offset arrays): MANY messages under the context's key through k_body's row code; the algebra and the
+// lane pieces are in aesgcm_rows.h.  k_rows is k_body's dealt form with a descriptor per chunk instead of one body per launch: same LDS image, same row loop
+// (body_strand_rows), same dispensers; what a wave leaves per chunk is 16 bytes.
+// ------------------------------------------------------------------------------------------------
+template <int NR, int MODE>
+__global__ __launch_bounds__(AESGCM_BODY_WG, AESGCM_BODY_WPS) void k_rows(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const RowsParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const u32 tid = threadIdx.x, lane = tid & 63u;
+    main_fill_lds(smem, km, tb, tid, true, AESGCM_BODY_WG, GH_TAB_K256);
+#if AESGCM_T4
+    fill_lds_t4(smem, tb, tid, AESGCM_BODY_WG);
+#endif
+    if (tid == 0) *reinterpret_cast<u32 *>(smem + AESGCM_LDS_DRY_OFF) = 0;   // dry-queue mask of the workgroup (next_chunk)
+    // the accumulators and arrival counters of the closing launch behind this one
+    for (u32 i = blockIdx.x * AESGCM_BODY_WG + tid; i < p.n_pkts; i += gridDim.x * AESGCM_BODY_WG) { p.acc[2u * i] = 0ull; p.acc[2u * i + 1u] = 0ull; p.cnt[i] = 0u; }
+    __syncthreads();
+    const u32 n_sc = __builtin_amdgcn_readfirstlane(p.hdr ? p.hdr->n_sc : p.n_sc);
+    const u32 C4 = 4u * n_sc, C = rows_chunks(p, n_sc);
+    u32 nq, seg;
+    plan_queues(C, &nq, &seg);
+    u32 q = (blockIdx.x * (AESGCM_BODY_WG / 64) + (tid >> 6)) % nq;
+    q = __builtin_amdgcn_readfirstlane(q);
+    for (u32 guard = 0; guard <= C; ++guard) {                               // bounded, as every dispenser loop here
+        const u32 c = next_chunk(p.queues, smem, nq, seg, C, q, lane);
+        if (c == DISPENSER_DONE) break;
+        if (c >= C4) {                                                        // a message's tail (and E_K(J0)), or its AAD
+            const bool is_aad = c - C4 >= p.n_pkts;
+            const u32 m = c - C4 - (is_aad ? p.n_pkts : 0u);
+            RowsMsg mq = rows_msg(p, m);
+            mq.doff = uniform64(mq.doff); mq.aoff = uniform64(mq.aoff); mq.len = uniform32(mq.len); mq.alen = uniform32(mq.alen);
+            if (is_aad) {
+                if (!mq.alen) continue;
+                const G128 a = wave_xor(rows_aad_lane(km, p, mq, lane));
+                if (lane == 0) p.waad[m] = a;
+                continue;
+            }
+            const unsigned char *ivp = p.ivs + (size_t)m * 12;
+            CtrConsts cc = ctr_round1_consts(uniform32(load_le32(ivp)), uniform32(load_le32(ivp + 4)), uniform32(load_le32(ivp + 8)), km->rk, smem, (lane & 31u) << 2);
+            cc.c0 = __builtin_amdgcn_readfirstlane(cc.c0); cc.c1 = __builtin_amdgcn_readfirstlane(cc.c1);
+            cc.c2 = __builtin_amdgcn_readfirstlane(cc.c2); cc.c3 = __builtin_amdgcn_readfirstlane(cc.c3);
+            uint4 ej0;
+            G128 z = wave_xor(rows_tail_lane<NR, MODE == MODE_DEC>(km, p, mq, smem, cc, lane, &ej0));
+            const G128 e = mo_to_be(make_uint4((u32)__builtin_amdgcn_readlane((int)ej0.x, 63), (u32)__builtin_amdgcn_readlane((int)ej0.y, 63),
+                                               (u32)__builtin_amdgcn_readlane((int)ej0.z, 63), (u32)__builtin_amdgcn_readlane((int)ej0.w, 63)));
+            z.w[0] ^= e.w[0]; z.w[1] ^= e.w[1]; z.w[2] ^= e.w[2]; z.w[3] ^= e.w[3];
+            if (lane == 0) p.wtail[m] = z;
+            continue;
+        }
+        const u32 v = c & 3u;
+        RowsSc e = rows_desc(p, c >> 2);
+        e.off = uniform64(e.off); e.q0 = uniform32(e.q0); e.shape = uniform32(e.shape);
+        if (v >= (e.shape >> 28)) continue;                                   // the single super-row behind the last whole one: only R mod 4 phases exist
+        CtrConsts cc = ctr_round1_consts(uniform32(e.iv0), uniform32(e.iv1), uniform32(e.iv2), km->rk, smem, (lane & 31u) << 2);   // key and IV only: wave-uniform
+        cc.c0 = __builtin_amdgcn_readfirstlane(cc.c0); cc.c1 = __builtin_amdgcn_readfirstlane(cc.c1);
+        cc.c2 = __builtin_amdgcn_readfirstlane(cc.c2); cc.c3 = __builtin_amdgcn_readfirstlane(cc.c3);
+        const uint4 acc = rows_chunk_lane<NR, MODE>(km, tb, p, e, smem, cc, v, lane);
+        const G128 z = wave_xor(rows_chunk_term(km, acc, lane));
+        if (lane == 0) p.wsum[c] = z;
+    }
+}
+
+// One contribution to message m's tag and its arrival; the contributor that counts the last arrival holds the tag: it stores it and (decrypt) compares.
+// Memory-side atomics only, as acc_arrive: the XORs have returned before the arrival is counted.
+template <int DEC>
+__device__ __forceinline__ void rows_arrive(const RowsParams &p, u32 m, u32 expected, G128 z, bool nonzero) {
+    u32 dep = 0;
+    if (nonzero) {
+        const unsigned long long ohi = atomicXor(p.acc + 2u * m, ((unsigned long long)z.w[0] << 32) | z.w[1]);
+        const unsigned long long olo = atomicXor(p.acc + 2u * m + 1u, ((unsigned long long)z.w[2] << 32) | z.w[3]);
+        asm volatile("v_and_b32 %0, 0, %1" : "=v"(dep) : "v"((u32)(ohi ^ olo) | (u32)((ohi ^ olo) >> 32)));
+    }
+    const u32 arrived = atomicAdd(p.cnt + m, 1u + dep);
+    if (arrived + 1u != expected) return;
+    const unsigned long long hi = atomicOr(p.acc + 2u * m, 0ull), lo = atomicOr(p.acc + 2u * m + 1u, 0ull);
+    G128 t; t.w[0] = (u32)(hi >> 32); t.w[1] = (u32)hi; t.w[2] = (u32)(lo >> 32); t.w[3] = (u32)lo;
+    const uint4 tag = be_to_mo(t);
+    store_block_bytes(p.tags + (size_t)m * 16, tag, 16);
+    if (DEC && p.auth) {
+        int ok = 1;
+        if (p.expect) {
+            const uint4 x = load_block_bytes(p.expect + (size_t)m * 16, 16);
+            ok = ((x.x ^ tag.x) | (x.y ^ tag.y) | (x.z ^ tag.z) | (x.w ^ tag.w)) == 0;
+        }
+        p.auth[m] = ok;
+    }
+}
+// a lane per slot: 4 cap_sc chunk slots, then a tail slot and an AAD slot per message (rows_weight_lane)
+template <int DEC>
+__global__ __launch_bounds__(ROWS_CLOSE_WG) void k_rows_close(const KeyMaterial *__restrict__ km, const RowsParams p) {
+    const u32 n_sc = p.hdr ? p.hdr->n_sc : p.n_sc;
+    if (blockIdx.x == 0 && threadIdx.x < ROWS_NQ) p.queues[16u * threadIdx.x] = 0;   // the dispensers of the next call's k_rows
+    const u32 slot = blockIdx.x * ROWS_CLOSE_WG + threadIdx.x;
+    u32 m; G128 z;
+    rows_weight_lane(km, p, n_sc, slot, &m, &z);
+    if (m == 0xFFFFFFFFu) return;
+    const u32 nsc_m = p.msg_sc ? p.msg_sc[m + 1] - p.msg_sc[m] : p.S;
+    rows_arrive<DEC>(p, m, rows_expected(nsc_m), z, (z.w[0] | z.w[1] | z.w[2] | z.w[3]) != 0);
+}
+
+// The plan of a call with offset arrays, on the device (the host does not know the lengths).  k_rows_plan, ONE workgroup: the super-rows of the call, the chunk
+// size T (rows_pick_T), the scan of super-chunks per message -> msg_sc[0 .. n], the header.  k_rows_expand, a wave per message: its super-chunk descriptors.
+__global__ __launch_bounds__(1024) void k_rows_plan(const u64 *__restrict__ off, u32 n, u32 cap_sc, u32 tmin, u32 tmax, RowsHdr *hdr, u32 *msg_sc, u32 *queues) {
+    __shared__ unsigned long long tot[1024];
+    __shared__ u32 part[1024];
+    const u32 tid = threadIdx.x, per = (n + 1023u) / 1024u;
+    const u32 lo = tid * per < n ? tid * per : n, hi = lo + per < n ? lo + per : n;
+    if (tid < ROWS_NQ) queues[16u * tid] = 0;
+    unsigned long long sq = 0;
+    for (u32 m = lo; m < hi; ++m) sq += rows_geom(off[m + 1] - off[m]).Q;
+    tot[tid] = sq;
+    __syncthreads();
+    for (u32 d = 512; d; d >>= 1) { if (tid < d) tot[tid] += tot[tid + d]; __syncthreads(); }
+    const u32 T = rows_pick_T(tot[0], n, cap_sc, tmin, tmax);
+    u32 s = 0;
+    for (u32 m = lo; m < hi; ++m) { const RowsGeom g = rows_geom(off[m + 1] - off[m]); s += rows_nsc(g.Q, g.rho, T); }
+    part[tid] = s;
+    __syncthreads();
+    for (u32 d = 1; d < 1024u; d <<= 1) {                                    // Hillis-Steele over the 1024 partial sums
+        const u32 v = tid >= d ? part[tid - d] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    u32 run = part[tid] - s;
+    for (u32 m = lo; m < hi; ++m) { const RowsGeom g = rows_geom(off[m + 1] - off[m]); msg_sc[m] = run; run += rows_nsc(g.Q, g.rho, T); }
+    if (tid == 1023) { msg_sc[n] = part[1023]; hdr->n_sc = part[1023] <= cap_sc ? part[1023] : 0u; hdr->T = T; }   // (rows_pick_T makes it fit; a table too small would be a host-side bug: then nothing is dealt)
+}
+__global__ __launch_bounds__(1024) void k_rows_expand(const RowsParams p, RowsSc *sc) {
+    const u32 m = blockIdx.x * 16u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (m >= p.n_pkts) return;
+    const u32 base = p.msg_sc[m], nsc = p.msg_sc[m + 1] - base, T = p.hdr->T;
+    if (base + nsc > p.hdr->n_sc) return;
+    const RowsMsg q = rows_msg(p, m);
+    const RowsGeom g = rows_geom(q.len);
+    const unsigned char *ivp = p.ivs + (size_t)m * 12;
+    RowsSc e;
+    e.off = q.doff; e.iv0 = load_le32(ivp); e.iv1 = load_le32(ivp + 4); e.iv2 = load_le32(ivp + 8); e.msg = m;
+    for (u32 s = lane; s < nsc; s += 64u) {
+        u32 q0, nrows, nphase;
+        rows_sc_shape(g.Q, g.rho, T, s, q0, nrows, nphase);
+        e.q0 = q0; e.shape = nrows | (nphase << 28);
+        sc[base + s] = e;
+    }
+}
+
 // ================================================================================================
 // host side
 // ================================================================================================
@@ -1301,6 +1448,12 @@ struct aesgcm_ctx {
     OrderSlot order[4];
     unsigned order_next = 0;
     size_t order_min = 98304;          // packets from which the order pays (context option "pkt_order"; 0 = never)
+    // many messages through the row kernel (k_rows, aesgcm_rows.h): one block of device scratch, grown on demand
+    unsigned char *rows_buf = nullptr;
+    size_t rows_cap_sc = 0, rows_cap_n = 0;
+    bool rows_dirty = true;            // the dispensers are not known to be zero (fresh scratch, or a launch failed between k_rows and k_rows_close)
+    u64 rows_min = (u64)64 << 10;      // packets of at least this many bytes go by rows (option "rows_min"; 0 = never).  With offset arrays the caller's pkt_len is the hint that says so
+    u32 rows_tmin = ROWS_T_MIN, rows_tmax = ROWS_T_MAX;   // super-rows per super-chunk (option "rows_t" pins both)
     // streaming state
     bool s_active = false, s_data = false, s_ragged = false;
     int s_dec = 0;
@@ -1357,6 +1510,9 @@ static int set_lds_attrs(int device, DeviceState *ds) {
 #define SETATTRH(NR, MODE) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bodyh<NR, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, AESGCM_LDS_BYTES + CYC_LDS_PARK_BYTES))
     SETATTRH(10, MODE_ENC); SETATTRH(12, MODE_ENC); SETATTRH(14, MODE_ENC); SETATTRH(10, MODE_DEC); SETATTRH(12, MODE_DEC); SETATTRH(14, MODE_DEC);
 #undef SETATTRH
+#define SETATTRR(NR, MODE) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rows<NR, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, AESGCM_BODY_LDS))
+    SETATTRR(10, MODE_ENC); SETATTRR(12, MODE_ENC); SETATTRR(14, MODE_ENC); SETATTRR(10, MODE_DEC); SETATTRR(12, MODE_DEC); SETATTRR(14, MODE_DEC);
+#undef SETATTRR
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fold), hipFuncAttributeMaxDynamicSharedMemorySize, FOLD_LDS_CLOSE_BYTES));
 #define SETATTRB(NR, D) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktg<NR, D, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, PKTG_LDS_TOTAL(2))); \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktg<NR, D, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, PKTG_LDS_TOTAL(3))); \
@@ -1909,6 +2065,7 @@ int aesgcm_ctx_destroy(aesgcm_ctx *c) {
     if (c->h_mtag) hipHostFree(c->h_mtag);
     if (c->d_mtag) hipFree(c->d_mtag);
     if (c->d_trace) hipFree(c->d_trace);
+    if (c->rows_buf) hipFree(c->rows_buf);
     pipeline_release(c);
     for (auto &o : c->order) { if (o.perm) hipFree(o.perm); if (o.bins) hipFree(o.bins); if (o.done) hipEventDestroy(o.done); }
     if (c->st_in) hipFree(c->st_in);
@@ -1942,6 +2099,8 @@ int aesgcm_ctx_set_option(aesgcm_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "fold_close")) c->fold_close = v != 0;                       // 1: behind the dealt k_body the first (or second) k_fold level closes the tag
     else if (!strcmp(key, "cyc_prio")) c->cyc_prio = (u32)v;                           // rows between rotations of the waves' issue priorities in a cyclic launch (0 = off)
     else if (!strcmp(key, "pkt_order")) c->order_min = (size_t)v;                      // packets from which a launch over packets of mixed length takes them by falling length class (k_len_*); 0 = never
+    else if (!strcmp(key, "rows_min")) c->rows_min = v;                                // bytes per packet from which aesgcm_packets_crypt_dev goes by rows (k_rows); 0 = never
+    else if (!strcmp(key, "rows_t")) { c->rows_tmin = v ? (u32)v : ROWS_T_MIN; c->rows_tmax = v ? (u32)v : ROWS_T_MAX; }   // super-rows per super-chunk of k_rows (0 = the library's rule)
     else if (!strcmp(key, "poll_us")) c->poll_ns = 1000L * (long)v;                    // how long a tag is polled for in the host slot before the call blocks in the runtime
     else return AESGCM_EARG;
     return AESGCM_OK;
@@ -2354,7 +2513,7 @@ int aesgcm_stream_final(aesgcm_ctx *c, uint8_t tag[16]) {
 #ifdef AESGCM_DEBUG_KNOBS
 // Test / profiling builds only (libaesgcm_hip_dbg.so, -DAESGCM_DEBUG_KNOBS; include/aesgcm_debug.h): force the kernel shape the next launches take, so that every
 // shape can be checked on inputs the host's own rule would give to another.  The product library has no such switch and reads no environment.
-static struct { int pkt_lanes, pkt_deal, batch_lanes, batch_deal, batch_order, pkt_ilp; } g_force = {0, 0, 0, 0, 0, 0};
+static struct { int pkt_lanes, pkt_deal, batch_lanes, batch_deal, batch_order, pkt_ilp, pkt_rows; } g_force = {0, 0, 0, 0, 0, 0, 0};
 extern "C" __attribute__((visibility("default"))) int aesgcm_debug_force_shape(const char *what, int value) {
     if (!what) return AESGCM_EARG;
     if (!strcmp(what, "pkt_lanes")) { if (value != 0 && value != 1 && value != 4 && value != 8 && value != 16 && value != 64) return AESGCM_EARG; g_force.pkt_lanes = value; }
@@ -2362,6 +2521,7 @@ extern "C" __attribute__((visibility("default"))) int aesgcm_debug_force_shape(c
     else if (!strcmp(what, "batch_lanes")) { if (value != 0 && value != 8 && value != 16 && value != 64) return AESGCM_EARG; g_force.batch_lanes = value; }
     else if (!strcmp(what, "batch_deal")) g_force.batch_deal = value;
     else if (!strcmp(what, "pkt_ilp")) { if (value < 0 || value > 2) return AESGCM_EARG; g_force.pkt_ilp = value; }              // k_pktl's ILP form: 0 = the library's rule, 1 = always, 2 = never
+    else if (!strcmp(what, "pkt_rows")) { if (value < 0 || value > 2) return AESGCM_EARG; g_force.pkt_rows = value; }            // aesgcm_packets_crypt_dev by rows (k_rows): 0 = the library's rule, 1 = always, 2 = never
     else if (!strcmp(what, "batch_order")) { if (value < 0 || value > 2) return AESGCM_EARG; g_force.batch_order = value; }      // variable-length batches by length class: 0 = the library's rule, 1 = always, 2 = never
     else return AESGCM_EARG;
     return AESGCM_OK;
@@ -2440,6 +2600,92 @@ static int packets_order(aesgcm_ctx *c, const u64 *d_off, size_t n_pkts, hipStre
     return order_launch(**slot, d_off, n_pkts, st, perm);
 }
 
+// ---------------------------------------------------------------- many messages under the context's key: by rows (aesgcm_rows.h)
+// the scratch of one call, carved out of one allocation: the plan (offset arrays only), 16 bytes per chunk slot, per message 16 + 16 + 16 + 4 bytes
+struct RowsScratch { RowsHdr *hdr; u32 *queues; RowsSc *sc; u32 *msg_sc; G128 *wsum, *wtail, *waad; unsigned long long *acc; u32 *cnt; };
+static size_t rows_carve(unsigned char *base, size_t cap_sc, size_t n, RowsScratch *r) {
+    size_t o = 0;
+    auto take = [&](size_t bytes) { unsigned char *q = base ? base + o : nullptr; o += (bytes + 255) & ~(size_t)255; return q; };
+    RowsScratch t;
+    t.hdr = (RowsHdr *)take(sizeof(RowsHdr));
+    t.queues = (u32 *)take(64 * ROWS_NQ);
+    t.sc = (RowsSc *)take(sizeof(RowsSc) * cap_sc);
+    t.msg_sc = (u32 *)take(4 * (n + 1));
+    t.wsum = (G128 *)take(64 * cap_sc);
+    t.wtail = (G128 *)take(16 * n);
+    t.waad = (G128 *)take(16 * n);
+    t.acc = (unsigned long long *)take(16 * n);
+    t.cnt = (u32 *)take(4 * n);
+    if (r) *r = t;
+    return o;
+}
+static int rows_scratch(aesgcm_ctx *c, size_t cap_sc, size_t n, RowsScratch *r) {
+    if (cap_sc > c->rows_cap_sc || n > c->rows_cap_n) {
+        if (c->rows_buf) { HIPCHK(hipFree(c->rows_buf)); c->rows_buf = nullptr; c->rows_cap_sc = c->rows_cap_n = 0; }    // hipFree waits for the launches that may still use it
+        const size_t cs = cap_sc < 4096 ? 4096 : cap_sc, cn = n < 256 ? 256 : n;
+        const hipError_t e = hipMalloc((void **)&c->rows_buf, rows_carve(nullptr, cs, cn, nullptr));
+        if (e == hipErrorOutOfMemory) return AESGCM_ENOMEM;
+        if (e != hipSuccess) return hip_fail(e, "hipMalloc");
+        c->rows_cap_sc = cs; c->rows_cap_n = cn; c->rows_dirty = true;
+    }
+    rows_carve(c->rows_buf, c->rows_cap_sc, c->rows_cap_n, r);
+    return AESGCM_OK;
+}
+// p: the caller's pointers, counts and lengths; the geometry and the scratch are filled in here
+static int packets_rows(aesgcm_ctx *c, int decrypt, RowsParams &p, hipStream_t st) {
+    const size_t n = p.n_pkts;
+    RowsScratch r;
+    int rc;
+    const bool var = p.data_off != nullptr;
+    p.has_aad = (p.aad_off || p.aad_len) ? 1u : 0u;
+    if (!var) {
+        const RowsGeom g = rows_geom(p.pkt_len);
+        p.T = rows_pick_T((u64)n * g.Q, n, 0, c->rows_tmin, c->rows_tmax);
+        p.S = rows_nsc(g.Q, g.rho, p.T);
+        if ((u64)n * p.S >= (1ull << 28)) return AESGCM_ETOOLONG;
+        p.n_sc = (u32)(n * p.S); p.cap_sc = p.n_sc;
+    } else {
+        if (2 * n + ROWS_CAP_BASE >= (1ull << 28)) return AESGCM_ETOOLONG;
+        p.cap_sc = (u32)(ROWS_CAP_BASE + 2 * n);
+    }
+    if ((rc = rows_scratch(c, p.cap_sc, n, &r))) return rc;
+    p.wsum = r.wsum; p.wtail = r.wtail; p.waad = r.waad; p.acc = r.acc; p.cnt = r.cnt; p.queues = r.queues;
+    if (c->rows_dirty) HIPCHK(hipMemsetAsync(r.queues, 0, 64 * ROWS_NQ, st));
+    c->rows_dirty = true;                                                    // until k_rows_close, which leaves the dispensers zero, is enqueued
+    u32 wgs = (u32)c->G / 2;                                                 // one 141 KiB workgroup per CU
+    if (var) {
+        p.hdr = r.hdr; p.msg_sc = r.msg_sc;
+        hipLaunchKernelGGL(k_rows_plan, dim3(1), dim3(1024), 0, st, p.data_off, p.n_pkts, p.cap_sc, c->rows_tmin, c->rows_tmax, r.hdr, r.msg_sc, r.queues);
+        hipLaunchKernelGGL(k_rows_expand, dim3((unsigned)((n + 15) / 16)), dim3(1024), 0, st, p, r.sc);
+        HIPCHK(hipGetLastError());
+        p.sc = r.sc;
+    } else {
+        const u64 C = 4ull * p.n_sc + n * (p.has_aad ? 2 : 1);
+        const u64 need = (C + AESGCM_BODY_WG / 64 - 1) / (AESGCM_BODY_WG / 64);
+        if (need < wgs) wgs = (u32)need;
+    }
+    if (wgs < 1) wgs = 1;
+#define LR(NR, M) hipLaunchKernelGGL((k_rows<NR, M>), dim3(wgs), dim3(AESGCM_BODY_WG), AESGCM_BODY_LDS, st, c->km, c->tables, p)
+    if (decrypt) { if (c->nr == 10) LR(10, MODE_DEC); else if (c->nr == 12) LR(12, MODE_DEC); else LR(14, MODE_DEC); }
+    else         { if (c->nr == 10) LR(10, MODE_ENC); else if (c->nr == 12) LR(12, MODE_ENC); else LR(14, MODE_ENC); }
+#undef LR
+    HIPCHK(hipGetLastError());
+    const unsigned cw = (unsigned)((4ull * p.cap_sc + 2 * n + ROWS_CLOSE_WG - 1) / ROWS_CLOSE_WG);
+    if (decrypt) hipLaunchKernelGGL(k_rows_close<1>, dim3(cw), dim3(ROWS_CLOSE_WG), 0, st, c->km, p);
+    else hipLaunchKernelGGL(k_rows_close<0>, dim3(cw), dim3(ROWS_CLOSE_WG), 0, st, c->km, p);
+    HIPCHK(hipGetLastError());
+    c->rows_dirty = false;
+    return AESGCM_OK;
+}
+// does a call go by rows?  Fixed-size records: from rows_min bytes per packet.  Offset arrays: the host does not know the lengths; the caller's pkt_len, otherwise
+// unused in that form, is its word for the typical packet (0 = frames: the packet kernels)
+static bool packets_by_rows(const aesgcm_ctx *c, size_t pkt_len) {
+#ifdef AESGCM_DEBUG_KNOBS
+    if (g_force.pkt_rows) return g_force.pkt_rows == 1;
+#endif
+    return c->rows_min && pkt_len >= c->rows_min;
+}
+
 // ---------------------------------------------------------------- packets under the context's key
 int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const void *d_ivs,
                              const void *d_aad, size_t aad_len, const uint64_t *d_aad_off,
@@ -2450,6 +2696,15 @@ int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const vo
     if (!d_ivs || !d_tags || ((aad_len || d_aad_off) && !d_aad) || ((pkt_len || d_data_off) && (!d_in || !d_out))) return AESGCM_EARG;
     if (n_pkts >= (((size_t)1) << 31) || pkt_len >= (((size_t)1) << 28) || aad_len >= (((size_t)1) << 28)) return AESGCM_ETOOLONG;
     HIPCHK(hipSetDevice(c->device));
+    if (packets_by_rows(c, pkt_len)) {                                        // message-sized packets: the rows of all of them through k_body's row loop
+        RowsParams r;
+        memset(&r, 0, sizeof r);
+        r.ivs = (const unsigned char *)d_ivs; r.aad = (const unsigned char *)d_aad; r.in = (const unsigned char *)d_in;
+        r.out = (unsigned char *)d_out; r.tags = (unsigned char *)d_tags; r.expect = (const unsigned char *)d_expect_tags; r.auth = d_auth;
+        r.data_off = (const u64 *)d_data_off; r.aad_off = (const u64 *)d_aad_off;
+        r.n_pkts = (u32)n_pkts; r.pkt_len = (u32)pkt_len; r.aad_len = (u32)aad_len;
+        return packets_rows(c, decrypt, r, pick_stream(c, stream));
+    }
     PktParams p;
     memset(&p, 0, sizeof p);
     p.ivs = (const unsigned char *)d_ivs; p.aad = (const unsigned char *)d_aad; p.in = (const unsigned char *)d_in;
@@ -2630,6 +2885,7 @@ int aesgcm_batch_shape(int device, size_t n_pkts, size_t pkt_len, int var_len, i
 }
 int aesgcm_packets_shape(const aesgcm_ctx *c, size_t n_pkts, size_t pkt_len, int var_len, int *lanes_per_packet) {
     if (!c || !lanes_per_packet || !n_pkts) return AESGCM_EARG;
+    if (packets_by_rows(c, pkt_len)) { *lanes_per_packet = AESGCM_SHAPE_ROWS; return AESGCM_OK; }
     int lg = packets_pick_lg((u32)c->G / 2, n_pkts, pkt_len, var_len != 0, packets_ordered(c, n_pkts, var_len != 0));
 #ifdef AESGCM_DEBUG_KNOBS
     if (g_force.pkt_lanes) lg = g_force.pkt_lanes == 1 ? 0 : g_force.pkt_lanes == 64 ? 6 : g_force.pkt_lanes == 16 ? 4 : g_force.pkt_lanes == 8 ? 3 : 2;

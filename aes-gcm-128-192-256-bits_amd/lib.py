@@ -12,6 +12,7 @@ from .build import SO, SO_DEBUG, build
 
 OK, EARG, EKEYLEN, EIVLEN, ETOOLONG, EAUTH, EHIP, ENOMEM, ESTATE, EALIGN, ERCCL = 0, -1, -2, -3, -4, -5, -6, -7, -8, -9, -10
 
+SHAPE_ROWS = 1 << 20    # AESGCM_SHAPE_ROWS: what packets_shape says for calls that go by rows
 ABI_VERSION = 3         # AESGCM_ABI_VERSION of include/aesgcm.h this binding was written against
 
 # every symbol include/aesgcm.h declares (tests check the .so exports exactly these)
@@ -88,7 +89,7 @@ class debug_library:
 
     def __exit__(self, *a):
         global _L
-        for k in ("pkt_lanes", "pkt_deal", "batch_lanes", "batch_deal", "batch_order", "pkt_ilp"):
+        for k in ("pkt_lanes", "pkt_deal", "batch_lanes", "batch_deal", "batch_order", "pkt_ilp", "pkt_rows"):
             _DBG.aesgcm_debug_force_shape(k.encode(), 0)
         _L = self._prev
 
@@ -411,7 +412,7 @@ class Context:
     def close(self):
         if self._c:
             if not self._borrowed:
-                (self._lib or load()).aesgcm_ctx_destroy(self._c)
+                self._lib.aesgcm_ctx_destroy(self._c)
             self._c = None
 
     __del__ = close
@@ -425,38 +426,39 @@ class Context:
     def rekey(self, key):
         """aesgcm_ctx_rekey: a new key (16 / 24 / 32 bytes) for this context -- the reference core's key load between frames; everything else stays"""
         key = bytes(key)
-        _chk(load().aesgcm_ctx_rekey(self._c, key, len(key)))
+        _chk(self._lib.aesgcm_ctx_rekey(self._c, key, len(key)))
         return self
 
     def set_option(self, key, value):
-        """aesgcm_ctx_set_option: "tw", "body_min", "cyc_min", "cyc_max", "cyc_close", "fold_close", "cyc_prio", "pkt_order", "poll_us" (include/aesgcm.h)"""
-        _chk(load().aesgcm_ctx_set_option(self._c, key.encode(), int(value)))
+        """aesgcm_ctx_set_option: "tw", "body_min", "cyc_min", "cyc_max", "cyc_close", "fold_close", "cyc_prio", "pkt_order", "rows_min", "rows_t", "poll_us" (include/aesgcm.h)"""
+        _chk(self._lib.aesgcm_ctx_set_option(self._c, key.encode(), int(value)))
         return self
 
     def packets_shape(self, n_pkts, pkt_len=0, var_len=False):
-        """lanes per packet packets_crypt_dev takes for such a call: 1 (k_pktl), 4 / 8 / 16 or 64 (k_pktg)"""
+        """lanes per packet packets_crypt_dev takes for such a call: 1 (k_pktl), 4 / 8 / 16 or 64 (k_pktg), or SHAPE_ROWS: by rows (k_rows; with offset arrays
+        pkt_len is the caller's hint of the typical packet)"""
         v = cint(0)
-        _chk(load().aesgcm_packets_shape(self._c, n_pkts, pkt_len, int(bool(var_len)), ctypes.byref(v)))
+        _chk(self._lib.aesgcm_packets_shape(self._c, n_pkts, pkt_len, int(bool(var_len)), ctypes.byref(v)))
         return v.value
 
     def stream(self):
         """the context's own HIP stream as an integer handle (what stream=None means)"""
         s = vp()
-        _chk(load().aesgcm_ctx_stream(self._c, ctypes.byref(s)))
+        _chk(self._lib.aesgcm_ctx_stream(self._c, ctypes.byref(s)))
         return s.value
 
     def wait(self, other):
         """what is enqueued on this context's stream from now on starts after everything enqueued so far on `other`'s"""
-        _chk(load().aesgcm_ctx_wait(self._c, other._c))
+        _chk(self._lib.aesgcm_ctx_wait(self._c, other._c))
 
     def wait_fused(self, other):
         """... starts after `other`'s most recently enqueued fused kernel (not its fold / combine tail)"""
-        _chk(load().aesgcm_ctx_wait_fused(self._c, other._c))
+        _chk(self._lib.aesgcm_ctx_wait_fused(self._c, other._c))
 
     # unit level
     def h(self):
         b = ctypes.create_string_buffer(16)
-        _chk(load().aesgcm_get_h(self._c, b))
+        _chk(self._lib.aesgcm_get_h(self._c, b))
         return b.raw
 
     def ecb_encrypt(self, blocks):
@@ -465,19 +467,19 @@ class Context:
             raise AesGcmError(EARG, "ECB input must be a multiple of 16 bytes")
         out = bytearray(b.n)
         o = _Buf(out, writable=True)
-        _chk(load().aesgcm_ecb_encrypt(self._c, b.addr, b.n // 16, o.addr))
+        _chk(self._lib.aesgcm_ecb_encrypt(self._c, b.addr, b.n // 16, o.addr))
         return bytes(out)
 
     def ghash(self, data):
         b = _Buf(data)
         y = ctypes.create_string_buffer(16)
-        _chk(load().aesgcm_ghash(self._c, b.addr, b.n, y))
+        _chk(self._lib.aesgcm_ghash(self._c, b.addr, b.n, y))
         return y.raw
 
     def keystream(self, iv, first_block, nblocks):
         out = bytearray(16 * nblocks)
         o = _Buf(out, writable=True)
-        _chk(load().aesgcm_keystream(self._c, _fixed(iv, 12, "iv"), first_block, nblocks, o.addr))
+        _chk(self._lib.aesgcm_keystream(self._c, _fixed(iv, 12, "iv"), first_block, nblocks, o.addr))
         return bytes(out)
 
     # whole messages, host buffers
@@ -487,7 +489,7 @@ class Context:
         ret = out if out is not None else bytearray(p.n)
         o = _Buf(ret, writable=True)
         tag = ctypes.create_string_buffer(16)
-        _chk(load().aesgcm_encrypt(self._c, _fixed(iv, 12, "iv"), a.addr, a.n, p.addr, p.n, o.addr, tag))
+        _chk(self._lib.aesgcm_encrypt(self._c, _fixed(iv, 12, "iv"), a.addr, a.n, p.addr, p.n, o.addr, tag))
         return (bytes(ret) if out is None else ret), tag.raw
 
     def decrypt(self, iv, aad, ct, tag=None, out=None):
@@ -498,7 +500,7 @@ class Context:
         o = _Buf(ret, writable=True)
         tout = ctypes.create_string_buffer(16)
         exp = _fixed(tag, 16, "tag") if tag is not None else None
-        rc = load().aesgcm_decrypt(self._c, _fixed(iv, 12, "iv"), a.addr, a.n, c.addr, c.n, o.addr, exp, tout)
+        rc = self._lib.aesgcm_decrypt(self._c, _fixed(iv, 12, "iv"), a.addr, a.n, c.addr, c.n, o.addr, exp, tout)
         self.last_plaintext = bytes(ret) if out is None else ret
         _chk(rc)
         return self.last_plaintext, tout.raw
@@ -509,7 +511,7 @@ class Context:
         ret = out if out is not None else bytearray(p.n)
         o = _Buf(ret, writable=True)
         tag = ctypes.create_string_buffer(16)
-        _chk(load().aesgcm_encrypt_pipelined(self._c, _fixed(iv, 12, "iv"), a.addr, a.n, p.addr, p.n, o.addr, tag, chunk_bytes))
+        _chk(self._lib.aesgcm_encrypt_pipelined(self._c, _fixed(iv, 12, "iv"), a.addr, a.n, p.addr, p.n, o.addr, tag, chunk_bytes))
         return (bytes(ret) if out is None else ret), tag.raw
 
     def decrypt_pipelined(self, iv, aad, ct, tag=None, out=None, chunk_bytes=0):
@@ -518,7 +520,7 @@ class Context:
         o = _Buf(ret, writable=True)
         tout = ctypes.create_string_buffer(16)
         exp = _fixed(tag, 16, "tag") if tag is not None else None
-        rc = load().aesgcm_decrypt_pipelined(self._c, _fixed(iv, 12, "iv"), a.addr, a.n, c.addr, c.n, o.addr, exp, tout, chunk_bytes)
+        rc = self._lib.aesgcm_decrypt_pipelined(self._c, _fixed(iv, 12, "iv"), a.addr, a.n, c.addr, c.n, o.addr, exp, tout, chunk_bytes)
         self.last_plaintext = bytes(ret) if out is None else ret
         _chk(rc)
         return self.last_plaintext, tout.raw
@@ -526,38 +528,38 @@ class Context:
     # whole messages, device buffers
     def encrypt_dev(self, iv, d_pt, nbytes, d_ct, d_aad=None, aad_len=0, stream=None, want_tag=True):
         tag = ctypes.create_string_buffer(16) if want_tag else None
-        _chk(load().aesgcm_encrypt_dev(self._c, _fixed(iv, 12, "iv"), d_aad, aad_len, d_pt, nbytes, d_ct, tag, stream))
+        _chk(self._lib.aesgcm_encrypt_dev(self._c, _fixed(iv, 12, "iv"), d_aad, aad_len, d_pt, nbytes, d_ct, tag, stream))
         return tag.raw if want_tag else None
 
     def decrypt_dev(self, iv, d_ct, nbytes, d_pt, d_aad=None, aad_len=0, tag=None, stream=None, want_tag=True):
         tout = ctypes.create_string_buffer(16) if want_tag else None
         exp = _fixed(tag, 16, "tag") if tag is not None else None
-        _chk(load().aesgcm_decrypt_dev(self._c, _fixed(iv, 12, "iv"), d_aad, aad_len, d_ct, nbytes, d_pt, exp, tout, stream))
+        _chk(self._lib.aesgcm_decrypt_dev(self._c, _fixed(iv, 12, "iv"), d_aad, aad_len, d_ct, nbytes, d_pt, exp, tout, stream))
         return tout.raw if want_tag else None
 
     def last_tag(self, stream=None):
         t = ctypes.create_string_buffer(16)
-        _chk(load().aesgcm_last_tag(self._c, t, stream))
+        _chk(self._lib.aesgcm_last_tag(self._c, t, stream))
         return t.raw
 
     def keystream_dev(self, iv, first_block, nblocks, d_out, stream=None):
-        _chk(load().aesgcm_keystream_dev(self._c, _fixed(iv, 12, "iv"), first_block, nblocks, d_out, stream))
+        _chk(self._lib.aesgcm_keystream_dev(self._c, _fixed(iv, 12, "iv"), first_block, nblocks, d_out, stream))
 
     # many packets under this context's key
     def packets_crypt_dev(self, decrypt, n_pkts, d_ivs, d_in, d_out, d_tags, pkt_len=0, d_data_off=None,
                           d_aad=None, aad_len=0, d_aad_off=None, d_expect_tags=None, d_auth=None, stream=None):
-        _chk(load().aesgcm_packets_crypt_dev(self._c, int(bool(decrypt)), n_pkts, d_ivs, d_aad, aad_len, d_aad_off,
+        _chk(self._lib.aesgcm_packets_crypt_dev(self._c, int(bool(decrypt)), n_pkts, d_ivs, d_aad, aad_len, d_aad_off,
                                              d_in, pkt_len, d_data_off, d_out, d_tags, d_expect_tags, d_auth, stream))
 
     # shards
     def shard_crypt_dev(self, decrypt, iv, d_in, nbytes, d_out, first_block, total_len, d_partial,
                         d_aad=None, aad_len=0, stream=None):
-        _chk(load().aesgcm_shard_crypt_dev(self._c, int(bool(decrypt)), _fixed(iv, 12, "iv"), d_aad, aad_len,
+        _chk(self._lib.aesgcm_shard_crypt_dev(self._c, int(bool(decrypt)), _fixed(iv, 12, "iv"), d_aad, aad_len,
                                            d_in, nbytes, d_out, first_block, total_len, d_partial, stream))
 
     def shard_finalize_dev(self, iv, d_partials, n_partials, aad_len, total_len, stream=None, want_tag=True, stride_bytes=16):
         tag = ctypes.create_string_buffer(16) if want_tag else None
-        _chk(load().aesgcm_shard_finalize_strided_dev(self._c, _fixed(iv, 12, "iv"), d_partials, n_partials, stride_bytes, aad_len, total_len, tag, stream))
+        _chk(self._lib.aesgcm_shard_finalize_strided_dev(self._c, _fixed(iv, 12, "iv"), d_partials, n_partials, stride_bytes, aad_len, total_len, tag, stream))
         return tag.raw if want_tag else None
 
     def shard_finalize_batch_dev(self, ivs, d_partials, n_partials, total_lens, aad_lens=None, stride_bytes=None, msg_stride_bytes=16, stream=None):
@@ -567,63 +569,63 @@ class Context:
         tl = (u64 * n)(*total_lens)
         al = (sz * n)(*aad_lens) if aad_lens is not None else None
         tags = ctypes.create_string_buffer(16 * n)
-        _chk(load().aesgcm_shard_finalize_batch_dev(self._c, n, ivb, d_partials, n_partials, 16 * n if stride_bytes is None else stride_bytes,
+        _chk(self._lib.aesgcm_shard_finalize_batch_dev(self._c, n, ivb, d_partials, n_partials, 16 * n if stride_bytes is None else stride_bytes,
                                                     msg_stride_bytes, al, tl, tags, stream))
         return [tags.raw[16 * m:16 * m + 16] for m in range(n)]
 
     # streaming
     def stream_begin(self, iv, decrypt=False):
-        _chk(load().aesgcm_stream_begin(self._c, _fixed(iv, 12, "iv"), int(bool(decrypt))))
+        _chk(self._lib.aesgcm_stream_begin(self._c, _fixed(iv, 12, "iv"), int(bool(decrypt))))
 
     def stream_aad(self, aad):
         b = _Buf(aad)
-        _chk(load().aesgcm_stream_aad(self._c, b.addr, b.n))
+        _chk(self._lib.aesgcm_stream_aad(self._c, b.addr, b.n))
 
     def stream_update(self, data):
         b = _Buf(data)
         out = bytearray(b.n)
         o = _Buf(out, writable=True)
-        _chk(load().aesgcm_stream_update(self._c, b.addr, b.n, o.addr))
+        _chk(self._lib.aesgcm_stream_update(self._c, b.addr, b.n, o.addr))
         return bytes(out)
 
     def stream_final(self):
         t = ctypes.create_string_buffer(16)
-        _chk(load().aesgcm_stream_final(self._c, t))
+        _chk(self._lib.aesgcm_stream_final(self._c, t))
         return t.raw
 
     # measurement
     def timing_enable(self, on=True):
-        _chk(load().aesgcm_ctx_timing_enable(self._c, int(on)))
+        _chk(self._lib.aesgcm_ctx_timing_enable(self._c, int(on)))
 
     def timing_read(self, reset=True):
         n, ms = u64(0), ctypes.c_double(0)
-        _chk(load().aesgcm_ctx_timing_read(self._c, ctypes.byref(n), ctypes.byref(ms), int(reset)))
+        _chk(self._lib.aesgcm_ctx_timing_read(self._c, ctypes.byref(n), ctypes.byref(ms), int(reset)))
         return n.value, ms.value
 
     def wg_trace(self, max_wgs=512):
         """[(start, end, hw_id, xcc_id)] per workgroup of the last timed launch (100 MHz wall clock)."""
         buf = (u64 * (4 * max_wgs))()
         n = sz(0)
-        _chk(load().aesgcm_ctx_wg_trace(self._c, buf, max_wgs, ctypes.byref(n)))
+        _chk(self._lib.aesgcm_ctx_wg_trace(self._c, buf, max_wgs, ctypes.byref(n)))
         return [tuple(buf[4 * i:4 * i + 4]) for i in range(n.value)]
 
     def geometry(self, body=False):
         """launch geometry of k_main, or (body=True) of k_body, the kernel of the aligned middle of ranges >= 256 MiB"""
         a, b, c = cint(0), cint(0), cint(0)
-        fn = load().aesgcm_ctx_body_geometry if body else load().aesgcm_ctx_geometry
+        fn = self._lib.aesgcm_ctx_body_geometry if body else self._lib.aesgcm_ctx_geometry
         _chk(fn(self._c, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
         return dict(workgroups=a.value, wg_lanes=b.value, lds_bytes=c.value)
 
     def ceiling_probe(self, nbytes):
         """(ms, blocks) of the fused kernel's instruction stream without its HBM traffic (aesgcm_ctx_ceiling_probe)"""
         ms, nb = ctypes.c_double(0), u64(0)
-        _chk(load().aesgcm_ctx_ceiling_probe(self._c, nbytes, ctypes.byref(ms), ctypes.byref(nb)))
+        _chk(self._lib.aesgcm_ctx_ceiling_probe(self._c, nbytes, ctypes.byref(ms), ctypes.byref(nb)))
         return ms.value, nb.value
 
     def split(self, nbytes, first_block=0):
         """(head_blocks, body_blocks) of the head / k_body / tail cut of a data range; body_blocks = 0: one k_main launch"""
         h, b = u64(0), u64(0)
-        _chk(load().aesgcm_ctx_split(self._c, nbytes, first_block, ctypes.byref(h), ctypes.byref(b)))
+        _chk(self._lib.aesgcm_ctx_split(self._c, nbytes, first_block, ctypes.byref(h), ctypes.byref(b)))
         return h.value, b.value
 
 
@@ -696,7 +698,7 @@ class MultiGpu:
         c = vp()
         _chk(load().aesgcm_mgpu_ctx(self._m, g, ctypes.byref(c)))
         ctx = Context.__new__(Context)
-        ctx._c, ctx.device, ctx._borrowed, ctx._owner = c.value, self.devices[g], True, self
+        ctx._c, ctx.device, ctx._borrowed, ctx._owner, ctx._lib = c.value, self.devices[g], True, self, load()
         return ctx
 
     def close(self):

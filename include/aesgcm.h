@@ -123,6 +123,8 @@ AESGCM_API int aesgcm_ctx_device(const aesgcm_ctx *ctx);
  *   "cyc_prio"    rows between rotations of the waves' issue priorities in a cyclic launch, 0 = off
  *   "pkt_order"   packets from which aesgcm_packets_crypt_dev with offset arrays takes the packets by falling length class (a counting sort on the
  *                 device in front of the launch; default 98304, where it starts to pay), 0 = never.  The results are the same bytes.
+ *   "rows_min"    bytes per packet from which aesgcm_packets_crypt_dev goes by rows (default 65536; 0 = never)
+ *   "rows_t"      super-rows (4 KiB each) per super-chunk of the row kernel, 0 = the library's rule (4 .. 64 by the size of the call)
  *   "poll_us"     how long a tag is polled for in the pinned host slot before the call blocks in the runtime
  * AESGCM_EARG for an unknown key. */
 AESGCM_API int aesgcm_ctx_set_option(aesgcm_ctx *ctx, const char *key, int64_t value);
@@ -252,8 +254,12 @@ AESGCM_API int aesgcm_mgpu_destroy(aesgcm_mgpu *m);
  * packet (src/aes_icb.vhd:60-70 "load IV"): this is that mode.  Per packet: ivs[p] (12 bytes), optional AAD
  * and data either as fixed-size records (aad_len / pkt_len, offset arrays NULL) or delimited by uint64 offset
  * arrays with n_pkts + 1 entries (then aad_len / pkt_len are ignored); tags[p] receives the computed tag; for
- * decrypt d_auth[p] (optional) = 1 if it equals d_expect_tags[p].  At most a wave per packet, so it is meant for
- * packets up to ~1 MiB; larger messages belong to aesgcm_encrypt_dev.  Asynchronous on `stream`.
+ * decrypt d_auth[p] (optional) = 1 if it equals d_expect_tags[p].  Asynchronous on `stream`.
+ * Packets of message size -- from 64 KiB each (context option "rows_min"), up to 2^28 - 1 bytes -- go BY ROWS (round 5): the 64-block rows of all the
+ * call's messages are one pool of work for the row loop a single large message runs through (csrc/aesgcm_rows.h), and one small launch behind it closes
+ * every tag; 4096 x 1 MiB then runs at the rate of one 4 GiB message.  With offset arrays the lengths are on the device and the library cannot see them:
+ * there pkt_len -- otherwise unused in that form -- is the caller's word for the TYPICAL packet size and selects the path (0 = frames; any packet, of any
+ * length, is correct on either path).  Shorter packets take the packet kernels: at most a wave per packet.
  * With offset arrays and many packets (context option "pkt_order", default from 98304) the launch takes the packets in the order of a
  * counting sort by length class, made on the device in front of it (three small launches on `stream`, 4 bytes per packet of scratch in
  * the context): the lanes of a wave run to the longest packet among them, and frames of mixed length in arrival order leave half of
@@ -276,7 +282,9 @@ AESGCM_API int aesgcm_batch_crypt_dev(int device, int decrypt, size_t n_pkts, si
                            void *d_tags, const void *d_expect_tags, int *d_auth, void *stream);
 
 /* Which kernel shape a call with these arguments takes: lanes per packet (1 = one lane per packet, 4 / 8 / 16 = a lane group, 64 = a
- * whole wave).  var_len != 0 describes the offset-array forms (pkt_len ignored: the host does not know the lengths and goes by count). */
+ * whole wave; aesgcm_packets_shape: AESGCM_SHAPE_ROWS = by rows, every message over the whole chip).  var_len != 0 describes the offset-array forms
+ * (the host does not know the lengths and goes by count; pkt_len is then the caller's hint of the typical size, as in aesgcm_packets_crypt_dev). */
+#define AESGCM_SHAPE_ROWS (1 << 20)
 AESGCM_API int aesgcm_batch_shape(int device, size_t n_pkts, size_t pkt_len, int var_len, int *lanes_per_packet);
 AESGCM_API int aesgcm_packets_shape(const aesgcm_ctx *ctx, size_t n_pkts, size_t pkt_len, int var_len, int *lanes_per_packet);
 

@@ -4,8 +4,10 @@
          pktw   N packets under ONE key, one wave per packet (k_pktg<.., 6>)
          pktg   N packets under ONE key, 16 lanes per packet (k_pktg<.., 4>)
          pktl   N packets under ONE key, one lane per packet (k_pktl)
-Prints one JSON line: ms per launch (median and best of K, HIP-synchronised wall time), packets/s, GiB/s and the
-algorithmic HBM bytes per launch (32 B per block + key/IV/tag traffic)."""
+         pkt    N packets under ONE key, the library's own choice (product library): by rows (k_rows) from 64 KiB per packet
+         rows / norows   by rows always / never (debug library)
+Prints one JSON line: ms per launch (median and best of K, HIP-synchronised wall time; ms_queued: K calls enqueued back to back and waited for once, per
+call -- what a caller that keeps the stream busy sees), packets/s, GiB/s and the algorithmic HBM bytes per launch (32 B per block + key/IV/tag traffic)."""
 import argparse
 import json
 import os
@@ -17,7 +19,10 @@ import aesgcm_amd  # noqa: E402,F401
 from aesgcm_amd import lib  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("kind", choices=("batch", "pkt", "pktw", "pktg", "pktg8", "pktg4", "pktl"))
+ap.add_argument("kind", choices=("batch", "pkt", "pktw", "pktg", "pktg8", "pktg4", "pktl", "rows", "norows"))
+ap.add_argument("--var", action="store_true", help="one key: the same packets through offset arrays (pkt_len then is the caller's hint)")
+ap.add_argument("--aad", type=int, default=0, help="one key: bytes of AAD per packet")
+ap.add_argument("--rows-t", type=int, default=0, help="context option rows_t (super-rows per super-chunk of k_rows)")
 ap.add_argument("--n", type=int, default=1 << 20)
 ap.add_argument("--len", type=int, default=4096)
 ap.add_argument("--key-bits", type=int, default=128)
@@ -44,11 +49,25 @@ else:
     if a.kind != "pkt":
         _dbg = lib.debug_library()
         _dbg.__enter__()
-        _dbg.force(pkt_lanes={"pktw": 64, "pktg": 16, "pktg8": 8, "pktg4": 4, "pktl": 1}[a.kind])
+        if a.kind in ("rows", "norows"):
+            _dbg.force(pkt_rows=1 if a.kind == "rows" else 2)
+        else:
+            _dbg.force(pkt_lanes={"pktw": 64, "pktg": 16, "pktg8": 8, "pktg4": 4, "pktl": 1}[a.kind], pkt_rows=2)
     ctx = lib.Context(bytes(range(kb)))
+    if a.rows_t:
+        ctx.set_option("rows_t", a.rows_t)
+    d_off = d_aoff = d_aad = None
+    if a.var:
+        import struct
+        d_off = lib.DeviceBuffer(8 * (n + 1)); d_off.upload(struct.pack("<%dQ" % (n + 1), *[pkt * i for i in range(n + 1)]))
+        if a.aad:
+            d_aoff = lib.DeviceBuffer(8 * (n + 1)); d_aoff.upload(struct.pack("<%dQ" % (n + 1), *[a.aad * i for i in range(n + 1)]))
+    if a.aad:
+        d_aad = lib.DeviceBuffer(a.aad * n); d_aad.fill_splitmix64(0x414144)
 
     def go():
-        ctx.packets_crypt_dev(a.dec, n, d_ivs.ptr, d_pt.ptr, d_ct.ptr, d_tags.ptr, pkt_len=pkt)
+        ctx.packets_crypt_dev(a.dec, n, d_ivs.ptr, d_pt.ptr, d_ct.ptr, d_tags.ptr, pkt_len=pkt, d_data_off=d_off.ptr if d_off else None,
+                              d_aad=d_aad.ptr if d_aad else None, aad_len=0 if d_aoff else a.aad, d_aad_off=d_aoff.ptr if d_aoff else None)
 go(); lib.dev_sync()
 ts = []
 for _ in range(a.steps):
@@ -58,7 +77,15 @@ for _ in range(a.steps):
     lib.dev_sync()
     ts.append(time.perf_counter() - t0)
 med, best = statistics.median(ts), min(ts)
+lib.dev_sync()
+t0 = time.perf_counter()
+for _ in range(a.steps):
+    go()
+lib.dev_sync()
+queued = (time.perf_counter() - t0) / a.steps
 alg = n * (2 * pkt + 16 + 12 + (kb if a.kind == "batch" else 0))
 print(json.dumps({"kind": a.kind, "n_pkts": n, "pkt_len": pkt, "key_bits": a.key_bits, "ms_median": round(med * 1e3, 4), "ms_best": round(best * 1e3, 4),
+                  "ms_queued": round(queued * 1e3, 4), "gib_per_s_queued": round(n * pkt / queued / 2**30, 1),
+                  "shape": (ctx.packets_shape(n, pkt, a.var) if a.kind != "batch" else None),
                   "mpkt_per_s": round(n / med / 1e6, 2), "gib_per_s": round(n * pkt / med / 2**30, 1), "alg_bytes_per_launch": alg,
                   "alg_gb_per_s": round(alg / med / 1e9, 1), "frac_of_hbm_peak": round(alg / med / 8e12, 4)}))

@@ -4,6 +4,7 @@
 // the oracle (oracle/aesgcm_oracle.c, linked in).  It exists because the build container has no GPU:
 // it pins the arithmetic and the index algebra before any GPU minute is spent.  Test infrastructure only.
 #include "../../aes-gcm-128-192-256-bits_amd/csrc/aesgcm_dev.h"
+#include "../../aes-gcm-128-192-256-bits_amd/csrc/aesgcm_rows.h"
 #include "../../profiles/microbench/aesgcm_bs.h"
 #include <stdio.h>
 #include <stdlib.h>
@@ -790,6 +791,141 @@ static void test_keystream_and_ghash(u64 seed) {
     }
 }
 
+// Many messages under one key by rows (k_rows / k_rows_close, csrc/aesgcm_rows.h): the plan (fixed-size records: arithmetic; offset arrays: the planner's scan and
+// the super-chunk table), every chunk -- strands, tails, AAD -- in a scrambled order with the same lane code, the slots of the closing in a scrambled order with
+// plain XORs for the atomics; ciphertext, tags and the arrival counts against the oracle.
+template <int NR>
+static void emu_rows_nr(const KeyMaterial *km, int dec, RowsParams &p, std::vector<RowsSc> &sc, std::vector<u32> &msg_sc, RowsHdr &hdr, u32 tmin, u32 tmax) {
+    static unsigned char smem[AESGCM_LDS_BYTES_T4] __attribute__((aligned(16)));
+    for (u32 tid = 0; tid < AESGCM_MAIN_WG; tid++) main_fill_lds(smem, km, &g_tb, tid, true, AESGCM_MAIN_WG, GH_TAB_K256);
+    for (u32 tid = 0; tid < AESGCM_MAIN_WG; tid++) fill_lds_t4(smem, &g_tb, tid, AESGCM_MAIN_WG);
+    const u32 n = p.n_pkts;
+    p.has_aad = (p.aad_off || p.aad_len) ? 1u : 0u;
+    if (p.data_off) {                                                    // k_rows_plan + k_rows_expand
+        u64 tq = 0;
+        for (u32 m = 0; m < n; m++) tq += rows_geom(p.data_off[m + 1] - p.data_off[m]).Q;
+        p.cap_sc = ROWS_CAP_BASE + 2 * n;
+        hdr.T = rows_pick_T(tq, n, p.cap_sc, tmin, tmax);
+        msg_sc.assign(n + 1, 0);
+        for (u32 m = 0; m < n; m++) { const RowsGeom g = rows_geom(p.data_off[m + 1] - p.data_off[m]); msg_sc[m + 1] = msg_sc[m] + rows_nsc(g.Q, g.rho, hdr.T); }
+        hdr.n_sc = msg_sc[n];
+        sc.assign(hdr.n_sc + 1, RowsSc());
+        p.hdr = &hdr; p.msg_sc = msg_sc.data();
+        for (u32 m = 0; m < n; m++) {
+            const RowsMsg q = rows_msg(p, m);
+            const RowsGeom g = rows_geom(q.len);
+            for (u32 s = 0; s < msg_sc[m + 1] - msg_sc[m]; s++) {
+                RowsSc e; u32 q0, nrows, nphase;
+                rows_sc_shape(g.Q, g.rho, hdr.T, s, q0, nrows, nphase);
+                e.off = q.doff; e.iv0 = load_le32(p.ivs + 12 * m); e.iv1 = load_le32(p.ivs + 12 * m + 4); e.iv2 = load_le32(p.ivs + 12 * m + 8);
+                e.q0 = q0; e.shape = nrows | (nphase << 28); e.msg = m;
+                sc[msg_sc[m] + s] = e;
+            }
+        }
+        p.sc = sc.data();
+    } else {
+        const RowsGeom g = rows_geom(p.pkt_len);
+        p.T = rows_pick_T((u64)n * g.Q, n, 0, tmin, tmax);
+        p.S = rows_nsc(g.Q, g.rho, p.T);
+        p.n_sc = n * p.S; p.cap_sc = p.n_sc;
+    }
+    const u32 n_sc = p.hdr ? p.hdr->n_sc : p.n_sc;
+    std::vector<G128> wsum(4 * (size_t)p.cap_sc + 4), wtail(n + 1), waad(n + 1);
+    std::vector<unsigned long long> acc(2 * (size_t)n + 2, 0);
+    std::vector<u32> cnt(n + 1, 0);
+    memset(wsum.data(), 0xEE, wsum.size() * sizeof(G128)); memset(waad.data(), 0xEE, waad.size() * sizeof(G128));
+    p.wsum = wsum.data(); p.wtail = wtail.data(); p.waad = waad.data(); p.acc = acc.data(); p.cnt = cnt.data();
+    const u32 C4 = 4 * n_sc, C = rows_chunks(p, n_sc);
+    for (u32 k = 0; k < C; k++) {
+        const u32 c = (u32)(((u64)k * 2741u + 17u) % C);                  // any order (C and 2741 need not be coprime: cover the rest below)
+        (void)c;
+    }
+    std::vector<u32> order(C);
+    for (u32 k = 0; k < C; k++) order[k] = C - 1 - k;                    // reverse order: tails and AAD first
+    for (u32 c : order) {
+        if (c >= C4) {
+            const bool is_aad = c - C4 >= n;
+            const u32 m = c - C4 - (is_aad ? n : 0);
+            const RowsMsg mq = rows_msg(p, m);
+            G128 z = {{0, 0, 0, 0}};
+            if (is_aad) {
+                if (!mq.alen) continue;
+                for (u32 lane = 0; lane < 64; lane++) xor_g(z, rows_aad_lane(km, p, mq, lane));
+                waad[m] = z;
+                continue;
+            }
+            uint4 ej0 = make_uint4(0, 0, 0, 0), e63 = ej0;
+            for (u32 lane = 0; lane < 64; lane++) {
+                const CtrConsts cc = ctr_round1_consts(load_le32(p.ivs + 12 * m), load_le32(p.ivs + 12 * m + 4), load_le32(p.ivs + 12 * m + 8), km->rk, smem, (lane & 31u) << 2);
+                xor_g(z, dec ? rows_tail_lane<NR, 1>(km, p, mq, smem, cc, lane, &ej0) : rows_tail_lane<NR, 0>(km, p, mq, smem, cc, lane, &ej0));
+                if (lane == 63) e63 = ej0;
+            }
+            xor_g(z, mo_to_be(e63));
+            wtail[m] = z;
+            continue;
+        }
+        const u32 v = c & 3u;
+        const RowsSc e = rows_desc(p, c >> 2);
+        if (v >= (e.shape >> 28)) continue;
+        G128 z = {{0, 0, 0, 0}};
+        for (u32 lane = 0; lane < 64; lane++) {
+            const CtrConsts cc = ctr_round1_consts(e.iv0, e.iv1, e.iv2, km->rk, smem, (lane & 31u) << 2);
+            const uint4 a = dec ? rows_chunk_lane<NR, MODE_DEC>(km, &g_tb, p, e, smem, cc, v, lane) : rows_chunk_lane<NR, MODE_ENC>(km, &g_tb, p, e, smem, cc, v, lane);
+            xor_g(z, rows_chunk_term(km, a, lane));
+        }
+        wsum[c] = z;
+    }
+    // k_rows_close: every slot, last first
+    const u32 slots = 4 * p.cap_sc + 2 * n;
+    u32 finals = 0;
+    for (u32 k = 0; k < slots; k++) {
+        const u32 slot = slots - 1 - k;
+        u32 m; G128 z;
+        rows_weight_lane(km, p, n_sc, slot, &m, &z);
+        if (m == 0xFFFFFFFFu) continue;
+        acc[2 * m] ^= ((unsigned long long)z.w[0] << 32) | z.w[1]; acc[2 * m + 1] ^= ((unsigned long long)z.w[2] << 32) | z.w[3];
+        const u32 nsc_m = p.msg_sc ? p.msg_sc[m + 1] - p.msg_sc[m] : p.S;
+        if (++cnt[m] == rows_expected(nsc_m)) {
+            G128 t; t.w[0] = (u32)(acc[2 * m] >> 32); t.w[1] = (u32)acc[2 * m]; t.w[2] = (u32)(acc[2 * m + 1] >> 32); t.w[3] = (u32)acc[2 * m + 1];
+            store_block_bytes(p.tags + (size_t)m * 16, be_to_mo(t), 16);
+            ++finals;
+        }
+    }
+    CHECK(finals == n, "rows: %u of %u messages closed", finals, n);
+}
+static void test_rows(int key_len, u64 seed, u32 T, bool var, const std::vector<u32> &lens, const std::vector<u32> &aads, u32 misalign = 0) {
+    auto key = rnd(key_len, seed);
+    Emu E(key.data(), key_len, 0);
+    const u32 n = (u32)lens.size();
+    std::vector<u64> doff(n + 1, misalign), aoff(n + 1, 0);
+    for (u32 i = 0; i < n; i++) { doff[i + 1] = doff[i] + lens[i]; aoff[i + 1] = aoff[i] + aads[i]; }
+    ABuf in(doff[n]), out(doff[n]);
+    auto aad = rnd(aoff[n], seed + 1), ivs = rnd(12 * n, seed + 2);
+    orc_fill_splitmix64(in.p, doff[n], seed + 3, 0);
+    std::vector<uint8_t> tags(16 * n + 16), tags2(16 * n + 16);
+    for (int dec = 0; dec < 2; dec++) {
+        RowsParams p; memset(&p, 0, sizeof p);
+        p.ivs = ivs.data(); p.aad = aad.data(); p.in = dec ? out.p : in.p; p.out = out.p; p.tags = dec ? tags2.data() : tags.data();
+        p.n_pkts = n;
+        if (var) { p.data_off = doff.data(); p.aad_off = aoff.data(); }
+        else { p.pkt_len = lens[0]; p.aad_len = aads[0]; }
+        std::vector<RowsSc> sc; std::vector<u32> msg_sc; RowsHdr hdr;
+        const u32 tmin = T ? T : ROWS_T_MIN, tmax = T ? T : ROWS_T_MAX;
+        if (E.km.nr == 10) emu_rows_nr<10>(&E.km, dec, p, sc, msg_sc, hdr, tmin, tmax); else if (E.km.nr == 12) emu_rows_nr<12>(&E.km, dec, p, sc, msg_sc, hdr, tmin, tmax); else emu_rows_nr<14>(&E.km, dec, p, sc, msg_sc, hdr, tmin, tmax);
+        if (!dec) {
+            for (u32 k = 0; k < n; k++) {
+                std::vector<uint8_t> ref(lens[k] + 16); uint8_t rtag[16];
+                orc_gcm_crypt(0, key.data(), key_len, ivs.data() + 12 * k, aad.data() + aoff[k], aads[k], in.p + doff[k], lens[k], ref.data(), rtag);
+                CHECK(memcmp(ref.data(), out.p + doff[k], lens[k]) == 0, "rows ct %u len %u T %u var %d", k, lens[k], T, (int)var);
+                CHECK(memcmp(rtag, tags.data() + 16 * k, 16) == 0, "rows tag %u len %u aad %u T %u var %d", k, lens[k], aads[k], T, (int)var);
+            }
+        } else {
+            CHECK(memcmp(out.p + misalign, in.p + misalign, doff[n] - misalign) == 0, "rows dec data T %u var %d", T, (int)var);
+            CHECK(memcmp(tags2.data(), tags.data(), 16 * n) == 0, "rows dec tags T %u var %d", T, (int)var);
+        }
+    }
+}
+
 int main(int argc, char **argv) {
     int level = argc > 1 ? atoi(argv[1]) : 1;
     init_tables();
@@ -830,6 +966,16 @@ int main(int argc, char **argv) {
     test_body(32, 1, 1, 16 * 64 * 3 + 1, 114, true);                 // one byte of AAD, one byte behind the body
     test_batch_pieces();
     test_packets(16, 61); test_packets(24, 62); test_packets(32, 63);
+    // many messages by rows: offset arrays with every kind of length (empty, shorter than a block, tails of 63 blocks + 15 bytes = two tail rows, whole super-rows,
+    // 1 .. 3 rows behind them), AAD of none / a ragged block / more than a row; fixed-size records; forced chunk sizes (several super-chunks per message, a short last one)
+    test_rows(16, 201, 1, true, {0, 1, 15, 16, 1023, 1024, 1040, 4096, 4097, 5 * 1024 + 1008 + 15, 3 * 4096 + 2 * 1024 + 17, 9 * 4096, 7 * 4096 + 3 * 1024 + 1023},
+              {0, 20, 0, 16, 1, 0, 33, 0, 13, 1024 + 7, 0, 8, 2048});
+    test_rows(32, 202, 3, true, {10 * 4096 + 5, 0, 4096 * 7, 3 * 1024, 1024 * 6 + 100}, {0, 0, 12, 5, 0});
+    test_rows(24, 203, 0, true, {65536, 65536 + 1024 + 3, 20000, 131072 + 17}, {20, 0, 28, 0});
+    test_rows(32, 204, 0, false, {65536, 65536, 65536}, {0, 0, 0});
+    test_rows(16, 205, 2, false, {4096 * 5 + 2048 + 9, 4096 * 5 + 2048 + 9, 4096 * 5 + 2048 + 9, 4096 * 5 + 2048 + 9, 4096 * 5 + 2048 + 9}, {13, 13, 13, 13, 13});
+    test_rows(24, 206, 4, false, {700, 700}, {0, 0});                       // records shorter than a row: no strand at all, tails only
+    test_rows(32, 207, 2, true, {4096 * 3 + 5, 9000, 1024 * 5}, {7, 0, 16}, 5);   // packed back to back from an odd byte address
     if (level > 1) {
         test_key(32, 1, 7, {{123, 16 * 64 * 1100 + 11}});     // 1100 chunks: two stage-1 workgroups
         test_key(16, 0, 8, {{0, 16 * W * 600}});              // production rule, > GMAX chunks of Tw = 16

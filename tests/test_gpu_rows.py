@@ -1,0 +1,184 @@
+"""GPU: many messages under one key BY ROWS (k_rows / k_rows_close, csrc/aesgcm_rows.h; round 5) -- aesgcm_packets_crypt_dev from 64 KiB per packet.
+The reference's deployment is frame after frame under one key (tb/gcm_test.py:76-85, src/gcm_gctr.vhd:142-144); every message here is compared with the
+oracle byte for byte, tags included, and decrypted in place with per-message authentication."""
+import hashlib
+import random
+import struct
+
+import pytest
+
+from util import splitmix_bytes
+
+pytestmark = pytest.mark.gpu
+
+
+def _up(hip, b):
+    d = hip.DeviceBuffer(max(len(b), 16))
+    d.upload(b)
+    return d
+
+
+def _check_var(hip, orc, ctx, key, lens, aads, seed, hint, misalign=0, forged=()):
+    """encrypt the messages (offset arrays) through ctx, compare with the oracle, decrypt in place with the tags of `forged` spoiled"""
+    m = len(lens)
+    f = orc.Fast(key)
+    doff, aoff = [misalign], [0]
+    for a, b in zip(lens, aads):
+        doff.append(doff[-1] + a)
+        aoff.append(aoff[-1] + b)
+    ivs, aad, pt = splitmix_bytes(seed, 12 * m), splitmix_bytes(seed + 1, max(aoff[-1], 16)), splitmix_bytes(seed + 2, doff[-1])
+    d_ivs, d_aad, d_buf = _up(hip, ivs), _up(hip, aad), _up(hip, pt)
+    d_doff, d_aoff = _up(hip, struct.pack("<%dQ" % (m + 1), *doff)), _up(hip, struct.pack("<%dQ" % (m + 1), *aoff))
+    d_tags, d_auth = hip.DeviceBuffer(16 * m), hip.DeviceBuffer(4 * m)
+    ctx.packets_crypt_dev(False, m, d_ivs.ptr, d_buf.ptr, d_buf.ptr, d_tags.ptr, pkt_len=hint, d_data_off=d_doff.ptr, d_aad=d_aad.ptr, d_aad_off=d_aoff.ptr)
+    hip.dev_sync()
+    ct, tags = bytes(d_buf.download(doff[-1])), bytes(d_tags.download())
+    assert ct[:misalign] == pt[:misalign]
+    for p in range(m):
+        want = f.encrypt(ivs[12 * p:12 * p + 12], aad[aoff[p]:aoff[p + 1]], pt[doff[p]:doff[p + 1]])
+        assert tags[16 * p:16 * p + 16] == want[1], (p, lens[p], aads[p])
+        assert ct[doff[p]:doff[p + 1]] == want[0], (p, lens[p], aads[p])
+    bad = bytearray(tags)
+    for p in forged:
+        bad[16 * p + (p % 16)] ^= 1 << (p % 8)
+    d_exp, d_t2 = _up(hip, bytes(bad)), hip.DeviceBuffer(16 * m)
+    ctx.packets_crypt_dev(True, m, d_ivs.ptr, d_buf.ptr, d_buf.ptr, d_t2.ptr, pkt_len=hint, d_data_off=d_doff.ptr, d_aad=d_aad.ptr, d_aad_off=d_aoff.ptr,
+                          d_expect_tags=d_exp.ptr, d_auth=d_auth.ptr)
+    hip.dev_sync()
+    assert bytes(d_buf.download(doff[-1])) == pt
+    assert bytes(d_t2.download()) == tags
+    auth = struct.unpack("<%di" % m, bytes(d_auth.download()))
+    assert [i for i, a in enumerate(auth) if not a] == sorted(forged)
+
+
+@pytest.mark.parametrize("klen", [16, 24, 32])
+def test_mixed_message_sizes_with_aad_and_ragged_ends(hip, orc, klen):
+    """64 KiB .. 16 MiB, AAD of nothing / a header / more than a row, ends ragged in every way (whole rows, 1 .. 3 rows behind the last super-row, a tail of 63
+    blocks + 15 bytes), one empty and one tiny message in between; the call goes by rows because the caller says its packets are message-sized (pkt_len hint)."""
+    rng = random.Random(500 + klen)
+    key = splitmix_bytes(7000 + klen, klen)
+    ctx = hip.Context(key)
+    assert ctx.packets_shape(10, 1 << 20, True) == hip.SHAPE_ROWS and ctx.packets_shape(10, 0, True) != hip.SHAPE_ROWS
+    lens = [65536, 65536 + 1023, (1 << 20) + 17, 3 * 4096 + 2048 + 5, 0, 16 << 20, 200000, 131072 + 1008 + 15, 7, (4 << 20) - 16, 65536 + 4096 * 3 + 1024 * 3,
+            rng.randrange(65536, 1 << 20), rng.randrange(65536, 1 << 20), (2 << 20) + 1]
+    aads = [0, 20, 28, 0, 13, 16, 1100, 0, 8, 0, 33, 2048, 0, 1]
+    _check_var(hip, orc, ctx, key, lens, aads, 810 + klen, hint=1 << 20, forged=(2, 5, 13))
+
+
+@pytest.mark.parametrize("t", [1, 2, 3, 7])
+def test_forced_chunk_sizes(hip, orc, t):
+    """the chunk size pinned to 1 / 2 / 3 / 7 super-rows: many super-chunks per message, short last ones, the single super-row behind the last whole one"""
+    key = splitmix_bytes(7100 + t, 32)
+    ctx = hip.Context(key).set_option("rows_t", t)
+    lens = [0, 1, 15, 16, 1023, 1024, 1040, 4096, 4097, 5 * 1024 + 1008 + 15, 3 * 4096 + 2 * 1024 + 17, 9 * 4096, 7 * 4096 + 3 * 1024 + 1023, 29 * 4096 + 100, 64 * 4096]
+    aads = [0, 20, 0, 16, 1, 0, 33, 0, 13, 1024 + 7, 0, 8, 2048, 0, 5]
+    _check_var(hip, orc, ctx, key, lens, aads, 830 + t, hint=1 << 16, forged=(0, 14))
+
+
+def test_packed_from_an_odd_byte_address(hip, orc):
+    key = splitmix_bytes(7200, 16)
+    ctx = hip.Context(key)
+    _check_var(hip, orc, ctx, key, [70001, 65536, 99999, 131073], [0, 5, 0, 20], 850, hint=65536, misalign=5, forged=(1,))
+
+
+@pytest.mark.parametrize("klen,pkt,al,n", [(32, 65536, 0, 300), (16, 65536 + 48, 20, 70), (24, 1 << 20, 16, 9), (32, 3 * 4096 + 1024 + 1, 0, 40), (16, 700, 12, 50)])
+def test_fixed_size_records(hip, orc, klen, pkt, al, n):
+    """fixed-size records: the library's own rule (by rows from 64 KiB per packet) and, below that, rows forced through the debug library -- including records
+    shorter than a row, which then are tails only"""
+    key = splitmix_bytes(7300 + pkt % 1000, klen)
+    f = orc.Fast(key)
+    ivs, aad, pt = splitmix_bytes(871, 12 * n), splitmix_bytes(872, max(al * n, 16)), splitmix_bytes(873, pkt * n)
+
+    def run(lib_ctx):
+        d_ivs, d_aad, d_buf = _up(hip, ivs), _up(hip, aad), _up(hip, pt)
+        d_tags, d_auth = hip.DeviceBuffer(16 * n), hip.DeviceBuffer(4 * n)
+        lib_ctx.packets_crypt_dev(False, n, d_ivs.ptr, d_buf.ptr, d_buf.ptr, d_tags.ptr, pkt_len=pkt, d_aad=d_aad.ptr if al else None, aad_len=al)
+        hip.dev_sync()
+        ct, tags = bytes(d_buf.download(pkt * n)), bytes(d_tags.download())
+        for p in range(n):
+            want = f.encrypt(ivs[12 * p:12 * p + 12], aad[al * p:al * (p + 1)], pt[pkt * p:pkt * (p + 1)])
+            assert (ct[pkt * p:pkt * (p + 1)], tags[16 * p:16 * p + 16]) == want, (pkt, al, p)
+        d_exp = _up(hip, tags)
+        lib_ctx.packets_crypt_dev(True, n, d_ivs.ptr, d_buf.ptr, d_buf.ptr, d_tags.ptr, pkt_len=pkt, d_aad=d_aad.ptr if al else None, aad_len=al,
+                                  d_expect_tags=d_exp.ptr, d_auth=d_auth.ptr)
+        hip.dev_sync()
+        assert bytes(d_buf.download(pkt * n)) == pt
+        assert set(struct.unpack("<%di" % n, bytes(d_auth.download()))) == {1}
+
+    if pkt >= 65536:
+        ctx = hip.Context(key)
+        assert ctx.packets_shape(n, pkt) == hip.SHAPE_ROWS
+        return run(ctx)
+    with hip.debug_library() as dbg:
+        dbg.force(pkt_rows=1)
+        run(hip.Context(key))
+
+
+def test_rows_and_packet_kernels_agree_and_calls_queue_back_to_back(hip, orc):
+    """the same 64 messages of 96 KiB through the row kernel (the library's rule) and through the wave-per-packet kernel (rows_min = 0): identical bytes; then
+    six calls over different inputs queued on the context's stream without a wait in between (the scratch and the dispensers of one call are the next call's)"""
+    key = splitmix_bytes(7400, 32)
+    n, pkt = 64, 96 * 1024
+    ivs, pt = splitmix_bytes(881, 12 * n), splitmix_bytes(882, pkt * n)
+    outs = []
+    for rows_min in (65536, 0):
+        ctx = hip.Context(key).set_option("rows_min", rows_min)
+        d_ivs, d_in, d_out, d_tags = _up(hip, ivs), _up(hip, pt), hip.DeviceBuffer(pkt * n), hip.DeviceBuffer(16 * n)
+        ctx.packets_crypt_dev(False, n, d_ivs.ptr, d_in.ptr, d_out.ptr, d_tags.ptr, pkt_len=pkt)
+        hip.dev_sync()
+        outs.append((hashlib.sha256(bytes(d_out.download())).hexdigest(), bytes(d_tags.download())))
+    assert outs[0] == outs[1]
+    f = orc.Fast(key)
+    assert outs[0][1][:16] == f.encrypt(ivs[:12], b"", pt[:pkt])[1]
+    ctx = hip.Context(key)
+    runs = []
+    for r in range(6):
+        m = 20 + 7 * r
+        lens = [65536 + 1000 * r + 17 * k for k in range(m)]
+        doff = [0]
+        for a in lens:
+            doff.append(doff[-1] + a)
+        ivr, ptr = splitmix_bytes(890 + r, 12 * m), splitmix_bytes(900 + r, doff[-1])
+        runs.append((m, doff, ivr, ptr, _up(hip, ivr), _up(hip, ptr), _up(hip, struct.pack("<%dQ" % (m + 1), *doff)), hip.DeviceBuffer(doff[-1] + 16), hip.DeviceBuffer(16 * m)))
+    hip.dev_sync()
+    for m, doff, ivr, ptr, d_iv, d_in, d_off, d_out, d_tags in runs:
+        ctx.packets_crypt_dev(False, m, d_iv.ptr, d_in.ptr, d_out.ptr, d_tags.ptr, pkt_len=65536, d_data_off=d_off.ptr)
+    hip.dev_sync()
+    for m, doff, ivr, ptr, d_iv, d_in, d_off, d_out, d_tags in runs:
+        ct, tags = bytes(d_out.download(doff[-1])), bytes(d_tags.download())
+        for p in range(0, m, 3):
+            assert (ct[doff[p]:doff[p + 1]], tags[16 * p:16 * p + 16]) == f.encrypt(ivr[12 * p:12 * p + 12], b"", ptr[doff[p]:doff[p + 1]]), p
+
+
+@pytest.mark.slow
+def test_4096_messages_of_one_mib_by_checksum(hip, orc):
+    """the benchmark's shape at full size -- 4096 x 1 MiB, 4 GiB -- against the single-message path of the same library (itself pinned to the libcrypto fixtures at
+    1 GiB and 16 GiB by tests/test_gpu_large.py): 64 of the messages re-encrypted one at a time, ciphertext by SHA-256 and tags compared; decrypt restores the
+    SplitMix64 plaintext (checked on the device by re-encrypting: the round trip's tags are the same)"""
+    key = splitmix_bytes(7500, 32)
+    n, pkt = 4096, 1 << 20
+    ctx = hip.Context(key)
+    d_ivw, d_ivs = hip.DeviceBuffer(16 * n), hip.DeviceBuffer(12 * n)
+    d_ivw.fill_splitmix64(0x4956)
+    ivw = bytes(d_ivw.download())
+    ivs = b"".join(ivw[16 * p:16 * p + 12] for p in range(n))
+    d_ivs.upload(ivs)
+    d_pt, d_ct, d_tags, d_auth = hip.DeviceBuffer(pkt * n), hip.DeviceBuffer(pkt * n), hip.DeviceBuffer(16 * n), hip.DeviceBuffer(4 * n)
+    d_pt.fill_splitmix64(0xAE5C0055)
+    assert ctx.packets_shape(n, pkt) == hip.SHAPE_ROWS
+    ctx.packets_crypt_dev(False, n, d_ivs.ptr, d_pt.ptr, d_ct.ptr, d_tags.ptr, pkt_len=pkt)
+    hip.dev_sync()
+    tags = bytes(d_tags.download())
+    one = hip.Context(key)
+    d_one = hip.DeviceBuffer(pkt)
+    for p in list(range(0, n, 67)) + [n - 1]:
+        t = one.encrypt_dev(ivs[12 * p:12 * p + 12], d_pt.ptr + p * pkt, pkt, d_one.ptr)
+        assert t == tags[16 * p:16 * p + 16], p
+        assert hashlib.sha256(bytes(d_one.download())).digest() == hashlib.sha256(bytes(d_ct.download(pkt, p * pkt))).digest(), p
+    f = orc.Fast(key)
+    assert f.encrypt(ivs[:12], b"", bytes(d_pt.download(pkt)))[1] == tags[:16]
+    d_t2 = hip.DeviceBuffer(16 * n)
+    ctx.packets_crypt_dev(True, n, d_ivs.ptr, d_ct.ptr, d_ct.ptr, d_t2.ptr, pkt_len=pkt, d_expect_tags=d_tags.ptr, d_auth=d_auth.ptr)
+    hip.dev_sync()
+    assert bytes(d_t2.download()) == tags and set(struct.unpack("<%di" % n, bytes(d_auth.download()))) == {1}
+    assert bytes(d_ct.download(pkt, 1234 * pkt)) == bytes(d_pt.download(pkt, 1234 * pkt))
