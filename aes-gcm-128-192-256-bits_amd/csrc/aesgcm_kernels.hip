@@ -1193,9 +1193,9 @@ __global__ __launch_bounds__(ILP ? AESGCM_PKTL_WG_ILP : AESGCM_PKTL_WG, ILP ? 2 
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_rows / k_rows_close (+ k_rows_plan, k_rows_expand with offset arrays): MANY messages under the context's key through k_body's row code; the algebra and the
-// lane pieces are in aesgcm_rows.h.  k_rows is k_body's dealt form with a descriptor per chunk instead of one body per launch: same LDS image, same row loop
-// (body_strand_rows), same dispensers; what a wave leaves per chunk is 16 bytes.
+// k_rows / k_rows_close (+ k_rows_plan with offset arrays): MANY messages under the context's key through k_body's row code; the algebra, the cut into blocks and
+// pieces and the lane code are in aesgcm_rows.h.  k_rows has k_body's LDS image and row loop (body_strand_rows); a wave takes a block of the call's unit axis --
+// its own (one block per wave) or the next from the dispensers -- and walks the pieces in it; what it leaves per piece is a 32-byte record.
 // ------------------------------------------------------------------------------------------------
 template <int NR, int MODE>
 __global__ __launch_bounds__(AESGCM_BODY_WG, AESGCM_BODY_WPS) void k_rows(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const RowsParams p) {
@@ -1206,67 +1206,77 @@ __global__ __launch_bounds__(AESGCM_BODY_WG, AESGCM_BODY_WPS) void k_rows(const 
     fill_lds_t4(smem, tb, tid, AESGCM_BODY_WG);
 #endif
     if (tid == 0) *reinterpret_cast<u32 *>(smem + AESGCM_LDS_DRY_OFF) = 0;   // dry-queue mask of the workgroup (next_chunk)
-    // the accumulators and arrival counters of the closing launch behind this one
-    for (u32 i = blockIdx.x * AESGCM_BODY_WG + tid; i < p.n_pkts; i += gridDim.x * AESGCM_BODY_WG) { p.acc[2u * i] = 0ull; p.acc[2u * i + 1u] = 0ull; p.cnt[i] = 0u; }
     __syncthreads();
-    const u32 n_sc = __builtin_amdgcn_readfirstlane(p.hdr ? p.hdr->n_sc : p.n_sc);
-    const u32 C4 = 4u * n_sc, C = rows_chunks(p, n_sc);
+    const u64 G = uniform64(p.hdr ? p.hdr->G : p.G);
+    const u32 D = uniform32(p.hdr ? p.hdr->D : p.D), NB = uniform32(p.hdr ? p.hdr->NB : p.NB), dyn = uniform32(p.hdr ? p.hdr->dyn : p.dyn);
+    const u32 wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (AESGCM_BODY_WG / 64) + (tid >> 6));
     u32 nq, seg;
-    plan_queues(C, &nq, &seg);
-    u32 q = (blockIdx.x * (AESGCM_BODY_WG / 64) + (tid >> 6)) % nq;
-    q = __builtin_amdgcn_readfirstlane(q);
-    for (u32 guard = 0; guard <= C; ++guard) {                               // bounded, as every dispenser loop here
-        const u32 c = next_chunk(p.queues, smem, nq, seg, C, q, lane);
-        if (c == DISPENSER_DONE) break;
-        if (c >= C4) {                                                        // a message's tail (and E_K(J0)), or its AAD
-            const bool is_aad = c - C4 >= p.n_pkts;
-            const u32 m = c - C4 - (is_aad ? p.n_pkts : 0u);
+    plan_queues(NB, &nq, &seg);
+    u32 q = __builtin_amdgcn_readfirstlane(wave % nq);
+    for (u32 guard = 0; guard <= NB; ++guard) {                              // bounded, as every dispenser loop here
+        u32 b;
+        if (dyn) { b = next_chunk(p.queues, smem, nq, seg, NB, q, lane); if (b == DISPENSER_DONE) break; }
+        else { if (guard || wave >= NB) break; b = wave; }
+        u64 g = (u64)b * D;
+        const u64 g_end = g + D < G ? g + D : G;
+        u32 m = uniform32(rows_find_msg(p, g));
+        while (g < g_end) {                                                   // the messages the block meets
             RowsMsg mq = rows_msg(p, m);
             mq.doff = uniform64(mq.doff); mq.aoff = uniform64(mq.aoff); mq.len = uniform32(mq.len); mq.alen = uniform32(mq.alen);
-            if (is_aad) {
-                if (!mq.alen) continue;
-                const G128 a = wave_xor(rows_aad_lane(km, p, mq, lane));
-                if (lane == 0) p.waad[m] = a;
-                continue;
-            }
+            const RowsGeom geo = rows_geom(mq.len);
+            const u64 g0 = uniform64(rows_unit_base(p, m));
+            const u32 U = rows_units(geo, p.has_aad), sbase = uniform32(rows_slot_base(p, m));
             const unsigned char *ivp = p.ivs + (size_t)m * 12;
-            CtrConsts cc = ctr_round1_consts(uniform32(load_le32(ivp)), uniform32(load_le32(ivp + 4)), uniform32(load_le32(ivp + 8)), km->rk, smem, (lane & 31u) << 2);
+            CtrConsts cc = ctr_round1_consts(uniform32(load_le32(ivp)), uniform32(load_le32(ivp + 4)), uniform32(load_le32(ivp + 8)), km->rk, smem, (lane & 31u) << 2);   // key and IV only: wave-uniform
             cc.c0 = __builtin_amdgcn_readfirstlane(cc.c0); cc.c1 = __builtin_amdgcn_readfirstlane(cc.c1);
             cc.c2 = __builtin_amdgcn_readfirstlane(cc.c2); cc.c3 = __builtin_amdgcn_readfirstlane(cc.c3);
-            uint4 ej0;
-            G128 z = wave_xor(rows_tail_lane<NR, MODE == MODE_DEC>(km, p, mq, smem, cc, lane, &ej0));
-            const G128 e = mo_to_be(make_uint4((u32)__builtin_amdgcn_readlane((int)ej0.x, 63), (u32)__builtin_amdgcn_readlane((int)ej0.y, 63),
-                                               (u32)__builtin_amdgcn_readlane((int)ej0.z, 63), (u32)__builtin_amdgcn_readlane((int)ej0.w, 63)));
-            z.w[0] ^= e.w[0]; z.w[1] ^= e.w[1]; z.w[2] ^= e.w[2]; z.w[3] ^= e.w[3];
-            if (lane == 0) p.wtail[m] = z;
-            continue;
+            u32 made = 0;
+            while (g < g_end && g < g0 + U) {                                 // the pieces of this message inside the block
+                const RowsPiece pc = rows_piece(geo, p.has_aad, sbase, g0, (u32)(g - g0), g_end - g, D);
+                G128 z;
+                u32 flags = ROWS_REC_VALID | ROWS_REC_WEIGH;
+                if (pc.kind == ROWS_STRAND) {
+                    z = wave_xor(rows_strand_term(km, rows_strand_lane<NR, MODE>(km, tb, p, mq, pc, smem, cc, lane, dyn ? 0u : p.prio_rows, (tid >> 8) & 3u), lane));
+                } else if (pc.kind == ROWS_AAD) {
+                    z = wave_xor(rows_aad_lane(km, p, mq, lane));
+                } else {
+                    uint4 ej0;
+                    z = wave_xor(rows_tail_lane<NR, MODE == MODE_DEC>(km, p, mq, smem, cc, lane, &ej0));
+                    const G128 e = mo_to_be(make_uint4((u32)__builtin_amdgcn_readlane((int)ej0.x, 63), (u32)__builtin_amdgcn_readlane((int)ej0.y, 63),
+                                                       (u32)__builtin_amdgcn_readlane((int)ej0.z, 63), (u32)__builtin_amdgcn_readlane((int)ej0.w, 63)));
+                    z.w[0] ^= e.w[0]; z.w[1] ^= e.w[1]; z.w[2] ^= e.w[2]; z.w[3] ^= e.w[3];
+                    flags = ROWS_REC_VALID;                                   // weighted already: lane terms H^(64 - L)
+                }
+                if (lane == 0) { RowsRec r; r.w = z; r.e = pc.e; r.msg = m; r.flags = flags; p.rec[pc.slot] = r; }
+                g += pc.len; ++made;
+            }
+            if (lane == 0) atomicAdd(p.npieces + m, made);                    // what k_rows_close waits for
+            ++m;
         }
-        const u32 v = c & 3u;
-        RowsSc e = rows_desc(p, c >> 2);
-        e.off = uniform64(e.off); e.q0 = uniform32(e.q0); e.shape = uniform32(e.shape);
-        if (v >= (e.shape >> 28)) continue;                                   // the single super-row behind the last whole one: only R mod 4 phases exist
-        CtrConsts cc = ctr_round1_consts(uniform32(e.iv0), uniform32(e.iv1), uniform32(e.iv2), km->rk, smem, (lane & 31u) << 2);   // key and IV only: wave-uniform
-        cc.c0 = __builtin_amdgcn_readfirstlane(cc.c0); cc.c1 = __builtin_amdgcn_readfirstlane(cc.c1);
-        cc.c2 = __builtin_amdgcn_readfirstlane(cc.c2); cc.c3 = __builtin_amdgcn_readfirstlane(cc.c3);
-        const uint4 acc = rows_chunk_lane<NR, MODE>(km, tb, p, e, smem, cc, v, lane);
-        const G128 z = wave_xor(rows_chunk_term(km, acc, lane));
-        if (lane == 0) p.wsum[c] = z;
     }
 }
 
-// One contribution to message m's tag and its arrival; the contributor that counts the last arrival holds the tag: it stores it and (decrypt) compares.
-// Memory-side atomics only, as acc_arrive: the XORs have returned before the arrival is counted.
+// a lane per record slot: the record's contribution to its message's tag and its arrival; the lane that counts the message's last piece holds the tag: it stores
+// it and (decrypt) compares.  Memory-side atomics only, as acc_arrive: the XORs have returned before the arrival is counted.  Zero at rest: the lane puts its
+// record's flags back to zero, the closing lane the message's accumulator and counts, workgroup 0 the dispensers.
 template <int DEC>
-__device__ __forceinline__ void rows_arrive(const RowsParams &p, u32 m, u32 expected, G128 z, bool nonzero) {
-    u32 dep = 0;
-    if (nonzero) {
-        const unsigned long long ohi = atomicXor(p.acc + 2u * m, ((unsigned long long)z.w[0] << 32) | z.w[1]);
-        const unsigned long long olo = atomicXor(p.acc + 2u * m + 1u, ((unsigned long long)z.w[2] << 32) | z.w[3]);
-        asm volatile("v_and_b32 %0, 0, %1" : "=v"(dep) : "v"((u32)(ohi ^ olo) | (u32)((ohi ^ olo) >> 32)));
-    }
+__global__ __launch_bounds__(ROWS_CLOSE_WG) void k_rows_close(const KeyMaterial *__restrict__ km, const RowsParams p) {
+    if (blockIdx.x == 0 && threadIdx.x < ROWS_NQ) p.queues[16u * threadIdx.x] = 0;
+    const u32 slot = blockIdx.x * ROWS_CLOSE_WG + threadIdx.x;
+    if (slot >= p.slot_cap) return;
+    const RowsRec r = p.rec[slot];
+    if (!(r.flags & ROWS_REC_VALID)) return;
+    p.rec[slot].flags = 0;
+    const G128 z = rows_weigh(km, r);
+    const u32 m = r.msg, expected = p.npieces[m];
+    const unsigned long long ohi = atomicXor(p.acc + 2u * m, ((unsigned long long)z.w[0] << 32) | z.w[1]);
+    const unsigned long long olo = atomicXor(p.acc + 2u * m + 1u, ((unsigned long long)z.w[2] << 32) | z.w[3]);
+    u32 dep;
+    asm volatile("v_and_b32 %0, 0, %1" : "=v"(dep) : "v"((u32)(ohi ^ olo) | (u32)((ohi ^ olo) >> 32)));
     const u32 arrived = atomicAdd(p.cnt + m, 1u + dep);
     if (arrived + 1u != expected) return;
-    const unsigned long long hi = atomicOr(p.acc + 2u * m, 0ull), lo = atomicOr(p.acc + 2u * m + 1u, 0ull);
+    const unsigned long long hi = atomicExch(p.acc + 2u * m, 0ull), lo = atomicExch(p.acc + 2u * m + 1u, 0ull);
+    p.cnt[m] = 0; p.npieces[m] = 0;
     G128 t; t.w[0] = (u32)(hi >> 32); t.w[1] = (u32)hi; t.w[2] = (u32)(lo >> 32); t.w[3] = (u32)lo;
     const uint4 tag = be_to_mo(t);
     store_block_bytes(p.tags + (size_t)m * 16, tag, 16);
@@ -1279,62 +1289,52 @@ __device__ __forceinline__ void rows_arrive(const RowsParams &p, u32 m, u32 expe
         p.auth[m] = ok;
     }
 }
-// a lane per slot: 4 cap_sc chunk slots, then a tail slot and an AAD slot per message (rows_weight_lane)
-template <int DEC>
-__global__ __launch_bounds__(ROWS_CLOSE_WG) void k_rows_close(const KeyMaterial *__restrict__ km, const RowsParams p) {
-    const u32 n_sc = p.hdr ? p.hdr->n_sc : p.n_sc;
-    if (blockIdx.x == 0 && threadIdx.x < ROWS_NQ) p.queues[16u * threadIdx.x] = 0;   // the dispensers of the next call's k_rows
-    const u32 slot = blockIdx.x * ROWS_CLOSE_WG + threadIdx.x;
-    u32 m; G128 z;
-    rows_weight_lane(km, p, n_sc, slot, &m, &z);
-    if (m == 0xFFFFFFFFu) return;
-    const u32 nsc_m = p.msg_sc ? p.msg_sc[m + 1] - p.msg_sc[m] : p.S;
-    rows_arrive<DEC>(p, m, rows_expected(nsc_m), z, (z.w[0] | z.w[1] | z.w[2] | z.w[3]) != 0);
-}
 
-// The plan of a call with offset arrays, on the device (the host does not know the lengths).  k_rows_plan, ONE workgroup: the super-rows of the call, the chunk
-// size T (rows_pick_T), the scan of super-chunks per message -> msg_sc[0 .. n], the header.  k_rows_expand, a wave per message: its super-chunk descriptors.
-__global__ __launch_bounds__(1024) void k_rows_plan(const u64 *__restrict__ off, u32 n, u32 cap_sc, u32 tmin, u32 tmax, RowsHdr *hdr, u32 *msg_sc, u32 *queues) {
-    __shared__ unsigned long long tot[1024];
-    __shared__ u32 part[1024];
-    const u32 tid = threadIdx.x, per = (n + 1023u) / 1024u;
-    const u32 lo = tid * per < n ? tid * per : n, hi = lo + per < n ? lo + per : n;
-    if (tid < ROWS_NQ) queues[16u * tid] = 0;
-    unsigned long long sq = 0;
-    for (u32 m = lo; m < hi; ++m) sq += rows_geom(off[m + 1] - off[m]).Q;
-    tot[tid] = sq;
+// The cut of a call with offset arrays, on the device (the host does not know the lengths): ONE workgroup.  Units per message -> prefix[0 .. n] and G; the cut
+// (rows_cut); record slots per message -> slot_base[0 .. n]; the header.
+__device__ __forceinline__ u64 block_scan_u64(unsigned long long *part, u64 mine, u32 tid) {      // exclusive prefix of `mine` over the 1024 threads; part[1023] = the total afterwards
+    part[tid] = mine;
     __syncthreads();
-    for (u32 d = 512; d; d >>= 1) { if (tid < d) tot[tid] += tot[tid + d]; __syncthreads(); }
-    const u32 T = rows_pick_T(tot[0], n, cap_sc, tmin, tmax);
-    u32 s = 0;
-    for (u32 m = lo; m < hi; ++m) { const RowsGeom g = rows_geom(off[m + 1] - off[m]); s += rows_nsc(g.Q, g.rho, T); }
-    part[tid] = s;
-    __syncthreads();
-    for (u32 d = 1; d < 1024u; d <<= 1) {                                    // Hillis-Steele over the 1024 partial sums
-        const u32 v = tid >= d ? part[tid - d] : 0u;
+    for (u32 d = 1; d < 1024u; d <<= 1) {                                    // Hillis-Steele
+        const u64 v = tid >= d ? part[tid - d] : 0ull;
         __syncthreads();
         part[tid] += v;
         __syncthreads();
     }
-    u32 run = part[tid] - s;
-    for (u32 m = lo; m < hi; ++m) { const RowsGeom g = rows_geom(off[m + 1] - off[m]); msg_sc[m] = run; run += rows_nsc(g.Q, g.rho, T); }
-    if (tid == 1023) { msg_sc[n] = part[1023]; hdr->n_sc = part[1023] <= cap_sc ? part[1023] : 0u; hdr->T = T; }   // (rows_pick_T makes it fit; a table too small would be a host-side bug: then nothing is dealt)
+    return part[tid] - mine;
 }
-__global__ __launch_bounds__(1024) void k_rows_expand(const RowsParams p, RowsSc *sc) {
-    const u32 m = blockIdx.x * 16u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    if (m >= p.n_pkts) return;
-    const u32 base = p.msg_sc[m], nsc = p.msg_sc[m + 1] - base, T = p.hdr->T;
-    if (base + nsc > p.hdr->n_sc) return;
-    const RowsMsg q = rows_msg(p, m);
-    const RowsGeom g = rows_geom(q.len);
-    const unsigned char *ivp = p.ivs + (size_t)m * 12;
-    RowsSc e;
-    e.off = q.doff; e.iv0 = load_le32(ivp); e.iv1 = load_le32(ivp + 4); e.iv2 = load_le32(ivp + 8); e.msg = m;
-    for (u32 s = lane; s < nsc; s += 64u) {
-        u32 q0, nrows, nphase;
-        rows_sc_shape(g.Q, g.rho, T, s, q0, nrows, nphase);
-        e.q0 = q0; e.shape = nrows | (nphase << 28);
-        sc[base + s] = e;
+__global__ __launch_bounds__(1024) void k_rows_plan(const u64 *__restrict__ off, u32 n, u32 has_aad, u32 waves, u32 force_d, u32 nb_cap, u32 slot_cap,
+                                                    RowsHdr *hdr, u64 *prefix, u32 *slot_base) {
+    __shared__ unsigned long long part[1024];
+    const u32 tid = threadIdx.x, per = (n + 1023u) / 1024u;
+    const u32 lo = tid * per < n ? tid * per : n, hi = lo + per < n ? lo + per : n;
+    u64 s = 0;
+    for (u32 m = lo; m < hi; ++m) s += rows_units(rows_geom(off[m + 1] - off[m]), has_aad);
+    u64 run = block_scan_u64(part, s, tid);
+    const u64 G = part[1023];
+    __syncthreads();
+    u32 D, NB, dyn;
+    rows_cut(G, waves, force_d, nb_cap, &D, &NB, &dyn);
+    u64 t = 0;
+    for (u32 m = lo; m < hi; ++m) {
+        const RowsGeom g = rows_geom(off[m + 1] - off[m]);
+        prefix[m] = run;
+        t += rows_slots(g, has_aad, run, D);
+        run += rows_units(g, has_aad);
+    }
+    u64 srun = block_scan_u64(part, t, tid);
+    const u64 slots = part[1023];
+    run = prefix[lo < n ? lo : 0];
+    for (u32 m = lo; m < hi; ++m) {
+        const RowsGeom g = rows_geom(off[m + 1] - off[m]);
+        slot_base[m] = (u32)srun;
+        srun += rows_slots(g, has_aad, run, D);
+        run += rows_units(g, has_aad);
+    }
+    if (tid == 0) {
+        prefix[n] = G; slot_base[n] = (u32)slots;
+        hdr->G = slots <= slot_cap ? G : 0ull;                               // (the host sizes the scratch for the worst case; a cut that does not fit would be its bug: then nothing runs)
+        hdr->D = D; hdr->NB = slots <= slot_cap ? NB : 0u; hdr->dyn = dyn;
     }
 }
 
@@ -1450,10 +1450,10 @@ struct aesgcm_ctx {
     size_t order_min = 98304;          // packets from which the order pays (context option "pkt_order"; 0 = never)
     // many messages through the row kernel (k_rows, aesgcm_rows.h): one block of device scratch, grown on demand
     unsigned char *rows_buf = nullptr;
-    size_t rows_cap_sc = 0, rows_cap_n = 0;
-    bool rows_dirty = true;            // the dispensers are not known to be zero (fresh scratch, or a launch failed between k_rows and k_rows_close)
+    size_t rows_cap_slots = 0, rows_cap_n = 0;
+    bool rows_dirty = true;            // the scratch is not known to be zero (fresh, or a launch failed between k_rows and k_rows_close)
     u64 rows_min = (u64)64 << 10;      // packets of at least this many bytes go by rows (option "rows_min"; 0 = never).  With offset arrays the caller's pkt_len is the hint that says so
-    u32 rows_tmin = ROWS_T_MIN, rows_tmax = ROWS_T_MAX;   // super-rows per super-chunk (option "rows_t" pins both)
+    u32 rows_block = 0;                // option "rows_block": units per dealt block of k_rows (0 = the library's cut: one block per wave, or blocks of ROWS_DYN_BLOCK for large calls)
     // streaming state
     bool s_active = false, s_data = false, s_ragged = false;
     int s_dec = 0;
@@ -2100,7 +2100,7 @@ int aesgcm_ctx_set_option(aesgcm_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "cyc_prio")) c->cyc_prio = (u32)v;                           // rows between rotations of the waves' issue priorities in a cyclic launch (0 = off)
     else if (!strcmp(key, "pkt_order")) c->order_min = (size_t)v;                      // packets from which a launch over packets of mixed length takes them by falling length class (k_len_*); 0 = never
     else if (!strcmp(key, "rows_min")) c->rows_min = v;                                // bytes per packet from which aesgcm_packets_crypt_dev goes by rows (k_rows); 0 = never
-    else if (!strcmp(key, "rows_t")) { c->rows_tmin = v ? (u32)v : ROWS_T_MIN; c->rows_tmax = v ? (u32)v : ROWS_T_MAX; }   // super-rows per super-chunk of k_rows (0 = the library's rule)
+    else if (!strcmp(key, "rows_block")) c->rows_block = (u32)v;                       // units (rows, tails) per dealt block of k_rows; 0 = the library's cut
     else if (!strcmp(key, "poll_us")) c->poll_ns = 1000L * (long)v;                    // how long a tag is polled for in the host slot before the call blocks in the runtime
     else return AESGCM_EARG;
     return AESGCM_OK;
@@ -2601,76 +2601,77 @@ static int packets_order(aesgcm_ctx *c, const u64 *d_off, size_t n_pkts, hipStre
 }
 
 // ---------------------------------------------------------------- many messages under the context's key: by rows (aesgcm_rows.h)
-// the scratch of one call, carved out of one allocation: the plan (offset arrays only), 16 bytes per chunk slot, per message 16 + 16 + 16 + 4 bytes
-struct RowsScratch { RowsHdr *hdr; u32 *queues; RowsSc *sc; u32 *msg_sc; G128 *wsum, *wtail, *waad; unsigned long long *acc; u32 *cnt; };
-static size_t rows_carve(unsigned char *base, size_t cap_sc, size_t n, RowsScratch *r) {
+// the scratch of the path, carved out of one allocation: per message 16 + 4 + 4 bytes and (offset arrays) the two prefix sums, 32 bytes per record slot.  Zero at rest.
+struct RowsScratch { RowsHdr *hdr; u32 *queues; u64 *prefix; u32 *slot_base; RowsRec *rec; unsigned long long *acc; u32 *cnt, *npieces; };
+static size_t rows_carve(unsigned char *base, size_t slots, size_t n, RowsScratch *r) {
     size_t o = 0;
     auto take = [&](size_t bytes) { unsigned char *q = base ? base + o : nullptr; o += (bytes + 255) & ~(size_t)255; return q; };
     RowsScratch t;
     t.hdr = (RowsHdr *)take(sizeof(RowsHdr));
     t.queues = (u32 *)take(64 * ROWS_NQ);
-    t.sc = (RowsSc *)take(sizeof(RowsSc) * cap_sc);
-    t.msg_sc = (u32 *)take(4 * (n + 1));
-    t.wsum = (G128 *)take(64 * cap_sc);
-    t.wtail = (G128 *)take(16 * n);
-    t.waad = (G128 *)take(16 * n);
+    t.prefix = (u64 *)take(8 * (n + 1));
+    t.slot_base = (u32 *)take(4 * (n + 1));
+    t.rec = (RowsRec *)take(sizeof(RowsRec) * slots);
     t.acc = (unsigned long long *)take(16 * n);
     t.cnt = (u32 *)take(4 * n);
+    t.npieces = (u32 *)take(4 * n);
     if (r) *r = t;
     return o;
 }
-static int rows_scratch(aesgcm_ctx *c, size_t cap_sc, size_t n, RowsScratch *r) {
-    if (cap_sc > c->rows_cap_sc || n > c->rows_cap_n) {
-        if (c->rows_buf) { HIPCHK(hipFree(c->rows_buf)); c->rows_buf = nullptr; c->rows_cap_sc = c->rows_cap_n = 0; }    // hipFree waits for the launches that may still use it
-        const size_t cs = cap_sc < 4096 ? 4096 : cap_sc, cn = n < 256 ? 256 : n;
+static int rows_scratch(aesgcm_ctx *c, size_t slots, size_t n, hipStream_t st, RowsScratch *r) {
+    if (slots > c->rows_cap_slots || n > c->rows_cap_n) {
+        if (c->rows_buf) { HIPCHK(hipFree(c->rows_buf)); c->rows_buf = nullptr; c->rows_cap_slots = c->rows_cap_n = 0; }    // hipFree waits for the launches that may still use it
+        const size_t cs = slots < 65536 ? 65536 : slots, cn = n < 4096 ? 4096 : n;
         const hipError_t e = hipMalloc((void **)&c->rows_buf, rows_carve(nullptr, cs, cn, nullptr));
         if (e == hipErrorOutOfMemory) return AESGCM_ENOMEM;
         if (e != hipSuccess) return hip_fail(e, "hipMalloc");
-        c->rows_cap_sc = cs; c->rows_cap_n = cn; c->rows_dirty = true;
+        c->rows_cap_slots = cs; c->rows_cap_n = cn; c->rows_dirty = true;
     }
-    rows_carve(c->rows_buf, c->rows_cap_sc, c->rows_cap_n, r);
+    if (c->rows_dirty) HIPCHK(hipMemsetAsync(c->rows_buf, 0, rows_carve(nullptr, c->rows_cap_slots, c->rows_cap_n, nullptr), st));   // fresh scratch, or a launch failed half way through a call
+    rows_carve(c->rows_buf, c->rows_cap_slots, c->rows_cap_n, r);
     return AESGCM_OK;
 }
-// p: the caller's pointers, counts and lengths; the geometry and the scratch are filled in here
+// p: the caller's pointers, counts and lengths; the cut and the scratch are filled in here
 static int packets_rows(aesgcm_ctx *c, int decrypt, RowsParams &p, hipStream_t st) {
     const size_t n = p.n_pkts;
     RowsScratch r;
     int rc;
     const bool var = p.data_off != nullptr;
     p.has_aad = (p.aad_off || p.aad_len) ? 1u : 0u;
+    u32 wgs = (u32)c->G / 2;                                                 // one 141 KiB workgroup per CU
+    size_t slots;
     if (!var) {
         const RowsGeom g = rows_geom(p.pkt_len);
-        p.T = rows_pick_T((u64)n * g.Q, n, 0, c->rows_tmin, c->rows_tmax);
-        p.S = rows_nsc(g.Q, g.rho, p.T);
-        if ((u64)n * p.S >= (1ull << 28)) return AESGCM_ETOOLONG;
-        p.n_sc = (u32)(n * p.S); p.cap_sc = p.n_sc;
-    } else {
-        if (2 * n + ROWS_CAP_BASE >= (1ull << 28)) return AESGCM_ETOOLONG;
-        p.cap_sc = (u32)(ROWS_CAP_BASE + 2 * n);
-    }
-    if ((rc = rows_scratch(c, p.cap_sc, n, &r))) return rc;
-    p.wsum = r.wsum; p.wtail = r.wtail; p.waad = r.waad; p.acc = r.acc; p.cnt = r.cnt; p.queues = r.queues;
-    if (c->rows_dirty) HIPCHK(hipMemsetAsync(r.queues, 0, 64 * ROWS_NQ, st));
-    c->rows_dirty = true;                                                    // until k_rows_close, which leaves the dispensers zero, is enqueued
-    u32 wgs = (u32)c->G / 2;                                                 // one 141 KiB workgroup per CU
-    if (var) {
-        p.hdr = r.hdr; p.msg_sc = r.msg_sc;
-        hipLaunchKernelGGL(k_rows_plan, dim3(1), dim3(1024), 0, st, p.data_off, p.n_pkts, p.cap_sc, c->rows_tmin, c->rows_tmax, r.hdr, r.msg_sc, r.queues);
-        hipLaunchKernelGGL(k_rows_expand, dim3((unsigned)((n + 15) / 16)), dim3(1024), 0, st, p, r.sc);
-        HIPCHK(hipGetLastError());
-        p.sc = r.sc;
-    } else {
-        const u64 C = 4ull * p.n_sc + n * (p.has_aad ? 2 : 1);
-        const u64 need = (C + AESGCM_BODY_WG / 64 - 1) / (AESGCM_BODY_WG / 64);
+        p.U = rows_units(g, p.has_aad);
+        p.G = (u64)n * p.U;
+        const u64 need = (p.G + AESGCM_BODY_WG / 64 - 1) / (AESGCM_BODY_WG / 64);     // at least a unit per wave
         if (need < wgs) wgs = (u32)need;
+        p.waves = wgs * (AESGCM_BODY_WG / 64);
+        rows_cut(p.G, p.waves, c->rows_block, (u64)1 << 30, &p.D, &p.NB, &p.dyn);
+        p.SM = rows_nat_count(g, p.has_aad) + (p.U - 1u) / p.D + 1u;
+        if ((u64)n * p.SM >= (1ull << 31)) return AESGCM_ETOOLONG;
+        slots = n * p.SM;
+    } else {
+        p.waves = wgs * (AESGCM_BODY_WG / 64);
+        slots = 11 * n + ROWS_NB_CAP;                                        // at most 9 natural segments per message (four strands, three rows, tail, AAD) and one more slot per block boundary inside it
+        if (slots >= (1ull << 31)) return AESGCM_ETOOLONG;
     }
-    if (wgs < 1) wgs = 1;
+    if ((rc = rows_scratch(c, slots, n, st, &r))) return rc;
+    p.slot_cap = (u32)slots;
+    p.rec = r.rec; p.acc = r.acc; p.cnt = r.cnt; p.npieces = r.npieces; p.queues = r.queues;
+    c->rows_dirty = true;                                                    // until both launches are enqueued
+    if (var) {
+        p.hdr = r.hdr; p.prefix = r.prefix; p.slot_base = r.slot_base;
+        hipLaunchKernelGGL(k_rows_plan, dim3(1), dim3(1024), 0, st, p.data_off, p.n_pkts, p.has_aad, p.waves, c->rows_block, (u32)ROWS_NB_CAP, p.slot_cap, r.hdr, r.prefix, r.slot_base);
+        HIPCHK(hipGetLastError());
+    }
+    p.prio_rows = c->cyc_prio;
 #define LR(NR, M) hipLaunchKernelGGL((k_rows<NR, M>), dim3(wgs), dim3(AESGCM_BODY_WG), AESGCM_BODY_LDS, st, c->km, c->tables, p)
     if (decrypt) { if (c->nr == 10) LR(10, MODE_DEC); else if (c->nr == 12) LR(12, MODE_DEC); else LR(14, MODE_DEC); }
     else         { if (c->nr == 10) LR(10, MODE_ENC); else if (c->nr == 12) LR(12, MODE_ENC); else LR(14, MODE_ENC); }
 #undef LR
     HIPCHK(hipGetLastError());
-    const unsigned cw = (unsigned)((4ull * p.cap_sc + 2 * n + ROWS_CLOSE_WG - 1) / ROWS_CLOSE_WG);
+    const unsigned cw = (unsigned)((p.slot_cap + ROWS_CLOSE_WG - 1) / ROWS_CLOSE_WG);
     if (decrypt) hipLaunchKernelGGL(k_rows_close<1>, dim3(cw), dim3(ROWS_CLOSE_WG), 0, st, c->km, p);
     else hipLaunchKernelGGL(k_rows_close<0>, dim3(cw), dim3(ROWS_CLOSE_WG), 0, st, c->km, p);
     HIPCHK(hipGetLastError());

@@ -3,47 +3,43 @@
 // The reference's deployment is frame after frame under one key (tb/gcm_test.py:76-85; H is kept while no new key is loaded,
 // src/gcm_gctr.vhd:142-144).  Until round 4 a message-sized packet of aesgcm_packets_crypt_dev went through the wave-per-packet group
 // kernel (two-table round, LDS full of tree tables: 4096 x 1 MiB 731 GiB/s against 980 for one message of the same bytes).  Here the rows
-// of ALL messages of a call are one pool of work for k_body's row loop (four T-tables, rounds 1 - 2 from per-chunk lane constants and the
+// of ALL messages of a call are one pool of work for k_body's row loop (four T-tables, rounds 1 - 2 from per-strand lane constants and the
 // scalar cache, the five-bit table of H^256):
 //
 //   * a message of `len` bytes is R = len / 1024 whole rows of 64 blocks, aligned to its first block (every packet starts at counter 2,
 //     src/aes_icb.vhd:97-118, so every message IS an aligned body), plus a TAIL of tb <= 64 blocks (the last one ragged), plus its AAD;
-//   * Q = R / 4 super-rows are cut into SUPER-CHUNKS of T super-rows; a CHUNK is one row phase v (0 .. 3) of a super-chunk: the rows
-//     4 (q0 + i) + v, i < nrows -- exactly a strand of body_strand_lane, Horner stride H^256.  The R mod 4 rows behind the last whole
-//     super-row are one more super-chunk of ONE super-row in which only the phases v < R mod 4 exist;
-//   * waves pull chunks from dispensers (k_rows).  At the end of a chunk the wave does NOT leave its 64 lane accumulators: lane L's value
-//     times H^(63 - L) through the key's per-lane Shoup tables (KeyMaterial::ltab, one multiply deep), XORed over the wave, is the
-//     polynomial of the whole strand up to its last block -- 16 bytes per chunk (W_c) instead of 1 KiB, so the chunk size is free to
-//     follow the load balance alone (HBM traffic 1.00 x algorithmic at any T);
-//   * what is not a whole row is two more kinds of chunk in the same pool: a message's TAIL -- its tail blocks and the length block as one right-aligned row
-//     (CTR from counter 2 + 64 R; the lane that holds the length block encrypts counter 1 instead, which is E_K(J0)), lane terms H^(64 - L), 16 bytes -- and
-//     its AAD (rows of its own, lane terms H^(63 - L), 16 bytes).  The two-table round they use reads the same T0 | T2 image the row loop does;
-//   * ONE small launch behind the rows closes every tag (k_rows_close): a LANE per chunk slot weights its 16 bytes with H^(blocks behind it + 2) bit-serially --
-//     e = 64 (R - 1 - last row) + tb + 2 for a strand, 64 R + tb + 2 for the AAD, nothing for the tail: any exponent, all lanes in parallel -- and XORs the
-//     product into the message's accumulator with memory-side atomics; every slot then counts itself arrived, and the one that counts a message's last
-//     arrival holds its tag  P H^2 ^ L H ^ E_K(J0)  (gcm_ghash.vhd:257,293 re-associated), stores it and, for decrypt, compares.
+//   * its work is laid on an axis of UNITS: four STRANDS of Q = R / 4 units each (strand k = the rows 4 q + k, q < Q: one row phase, exactly what
+//     body_strand_lane runs with the Horner stride H^256), then the R mod 4 rows behind the last whole super-row (a unit each), then ONE unit for the
+//     tail -- its blocks and the length block as a right-aligned row; the lane that holds the length block encrypts counter 1 instead, which is
+//     E_K(J0) -- and, when the call has AAD, one for the AAD.  The axes of all messages, end to end, are the call: G units;
+//   * the axis is cut into BLOCKS of D units.  A small or mid-size call is cut into exactly one block per wave of the launch (equal shares, no dispenser:
+//     the launch is as long as its rows and nothing waits for a last chunk); a large one into blocks of 64 units dealt from dispensers, as k_body deals
+//     its chunks.  Where a block's range meets the natural boundaries of a message it falls into PIECES -- a run of super-rows of one strand, a single
+//     row, a tail, an AAD -- and ANY run of a strand is a piece: the row loop takes (first super-row, count);
+//   * at the end of a piece the wave does not leave its 64 lane accumulators: lane L's value times H^(63 - L) through the key's per-lane Shoup tables
+//     (KeyMaterial::ltab), XORed over the wave, is the polynomial of the run up to its last block -- a 32-byte RECORD per piece: those 16 bytes, the
+//     message, and the exponent still due: H^(blocks behind the piece + 2), e = 64 (R - 1 - last row) + tb + 2 (AAD: 64 R + tb + 2; the tail, whose
+//     lane terms are H^(64 - L), needs none).  HBM traffic is 1.00 x algorithmic whatever the cut;
+//   * ONE small launch behind the rows closes every tag (k_rows_close): a LANE per record slot multiplies by H^e bit-serially (any exponent, all lanes
+//     in parallel), XORs the product into the message's accumulator with memory-side atomics and counts itself arrived; the lane that counts a
+//     message's last piece holds its tag  P H^2 ^ L H ^ E_K(J0)  (gcm_ghash.vhd:257,293 re-associated), stores it and, for decrypt, compares.
 //
-// Fixed-size records need no plan: super-chunk sc belongs to message sc / S.  With offset arrays the lengths are on the device, so two small
-// launches in front make the plan there: k_rows_plan (totals, the chunk size, the scan of super-chunks per message) and k_rows_expand (a
-// 32-byte descriptor per super-chunk: where, which IV, which rows).
+// Fixed-size records need no plan: message m owns the units [m U, (m + 1) U).  With offset arrays the lengths are on the device, and one small launch in
+// front (k_rows_plan) makes the two prefix sums there: units and record slots in front of every message.  Everything the two launches share between
+// calls -- accumulators, arrival and piece counts, record flags, dispensers -- is zero at rest: whoever consumes a thing puts the zero back.
 #pragma once
 #include "aesgcm_dev.h"
 
 #define ROWS_NQ AESGCM_NQ                     /* dispenser queues of k_rows (one cache line each) */
-#define ROWS_T_MIN 4u                         /* fewest super-rows per super-chunk (a chunk then is 4 rows: small calls want parallelism) */
-#define ROWS_T_MAX 64u                        /* most, unless the table of super-chunks would not hold the call (rows_pick_T) */
-#define ROWS_SC_TARGET 8192u                  /* super-chunks a call is cut into when it is large enough: 32768 chunks = 8 per resident wave of k_rows */
-#define ROWS_CAP_BASE 65536u                  /* offset-array form: the table holds ROWS_CAP_BASE + 2 n_pkts super-chunks (rows_pick_T doubles T until the call fits) */
+#define ROWS_DYN_BLOCK 64u                    /* units per dealt block (measured, 4096 x 1 MiB: 16 units 885 GiB/s, 32: 925, 64: 932, 128: 922, 256: 876; profiles/r05/rows_v1_chunk_sweep.txt) */
+#define ROWS_STATIC_MAX 192u                  /* units per wave up to which a call is cut into one block per wave */
 #define ROWS_CLOSE_WG 256u                    /* lanes per k_rows_close workgroup */
+#define ROWS_NB_CAP 65536u                    /* offset-array form: blocks the scratch is sized for (k_rows_plan falls back to one block per wave beyond) */
+#define ROWS_REC_VALID 1u
+#define ROWS_REC_WEIGH 2u
 
-struct RowsSc {                               // one super-chunk, 32 bytes: all a wave of k_rows needs for its chunk (the phase is chunk & 3)
-    u64 off;                                  // byte offset of the message's data in `in` / `out`
-    u32 iv0, iv1, iv2;                        // the message's IV, memory-order words
-    u32 q0;                                   // first super-row
-    u32 shape;                                // super-rows | phases << 28  (4; or R mod 4 for the single super-row behind the last whole one)
-    u32 msg;
-};
-struct RowsHdr { u32 n_sc, T; u32 pad[14]; }; // made by k_rows_plan (offset-array form)
+struct RowsRec { G128 w; u64 e; u32 msg; u32 flags; };     // one piece: 32 bytes
+struct RowsHdr { u64 G; u32 D, NB, dyn, pad[11]; };         // the cut of a call with offset arrays, made by k_rows_plan
 
 struct RowsParams {
     const unsigned char *ivs;                 // n_pkts * 12 bytes
@@ -55,45 +51,52 @@ struct RowsParams {
     int *auth;                                // dec: per message 1 / 0, or NULL
     const u64 *data_off, *aad_off;            // n_pkts + 1 byte offsets, or NULL = fixed pkt_len / aad_len records
     u32 n_pkts, pkt_len, aad_len;
-    u32 T, S, n_sc;                           // fixed-size form: super-rows per super-chunk, super-chunks per message, super-chunks of the call
-    const RowsHdr *hdr;                       // offset-array form: the plan on the device ...
-    const RowsSc *sc;                         // ... the super-chunk table (NULL in the fixed-size form) ...
-    const u32 *msg_sc;                        // ... and the first super-chunk of every message (n_pkts + 1 entries)
-    u32 cap_sc;                               // super-chunks the table (and wsum / 4) can hold
-    G128 *wsum;                               // one strand polynomial per chunk (4 per super-chunk)
-    G128 *wtail;                              // per message: (tail polynomial) H^2 ^ (length block) H ^ E_K(J0)
-    G128 *waad;                               // per message: the AAD's polynomial (written only when the message has AAD)
-    u32 has_aad;                              // the call has AAD (fixed aad_len > 0, or an offset array): k_rows deals an AAD chunk per message
+    u32 has_aad;                              // the call has AAD (fixed aad_len > 0, or an offset array): every message has an AAD unit
+    u32 waves;                                // waves of the k_rows launch
+    // the cut: fixed-size form (the host knows it) ...
+    u64 G;                                    // units of the call
+    u32 D, NB, dyn;                           // units per block, blocks, 1 = blocks come from the dispensers / 0 = wave w takes block w
+    u32 U, SM;                                // units and record slots per message
+    // ... or with offset arrays (k_rows_plan made it)
+    const RowsHdr *hdr;
+    const u64 *prefix;                        // units in front of message m (n_pkts + 1 entries)
+    const u32 *slot_base;                     // record slots in front of message m (n_pkts + 1 entries)
+    u32 slot_cap;                             // record slots the scratch holds (k_rows_close has a lane for each)
+    RowsRec *rec;
     unsigned long long *acc;                  // per message {hi, lo}: the XOR of everything that makes its tag
-    u32 *cnt;                                 // per message: contributors arrived
-    u32 *queues;                              // ROWS_NQ dispensers, 16 u32 apart, zero when k_rows starts (k_rows_close leaves them so)
+    u32 *cnt;                                 // per message: pieces arrived (k_rows_close)
+    u32 *npieces;                             // per message: pieces made (k_rows)
+    u32 *queues;                              // ROWS_NQ dispensers, 16 u32 apart
+    u32 prio_rows;                            // rotate the waves' issue priorities every so many rows (one block per wave: equal shares must also run at equal speed)
 };
 
 // ---- geometry (host, planner and kernels agree through these) -------------------------------------
-struct RowsGeom { u32 R, Q, rho, tb, tail_bytes; };
+struct RowsGeom { u32 R, Q, rho, tb; };
 HD RowsGeom rows_geom(u64 len) {
     RowsGeom g;
     g.R = (u32)(len >> 10); g.Q = g.R >> 2; g.rho = g.R & 3u;
-    g.tail_bytes = (u32)(len & 1023u); g.tb = (g.tail_bytes + 15u) >> 4;
+    g.tb = ((u32)(len & 1023u) + 15u) >> 4;
     return g;
 }
-HD u32 rows_nsc(u32 Q, u32 rho, u32 T) { return (Q + T - 1u) / T + (rho ? 1u : 0u); }
-// super-chunk s (of rows_nsc) of a message: first super-row, super-rows, phases
-HD void rows_sc_shape(u32 Q, u32 rho, u32 T, u32 s, u32 &q0, u32 &nrows, u32 &nphase) {
-    const u32 S = (Q + T - 1u) / T;
-    if (s < S) { q0 = s * T; nrows = Q - q0 < T ? Q - q0 : T; nphase = 4u; }
-    else { q0 = Q; nrows = 1u; nphase = rho; }
+HD u32 rows_units(const RowsGeom &g, u32 has_aad) { return 4u * g.Q + g.rho + 1u + (has_aad ? 1u : 0u); }
+// the natural segment of unit u of a message (strands 0 .. 3 when Q > 0, then a segment per single row, the tail, the AAD)
+HD u32 rows_nat(const RowsGeom &g, u32 u) { return u < 4u * g.Q ? u / g.Q : (g.Q ? 4u : 0u) + (u - 4u * g.Q); }
+HD u32 rows_nat_count(const RowsGeom &g, u32 has_aad) { return (g.Q ? 4u : 0u) + g.rho + 1u + (has_aad ? 1u : 0u); }
+// record slots of a message whose units are [g0, g0 + U): a slot per (natural segment, block) pair it can have -- slot = base + nat + (block - first block)
+HD u32 rows_slots(const RowsGeom &g, u32 has_aad, u64 g0, u32 D) {
+    const u32 U = rows_units(g, has_aad);
+    return rows_nat_count(g, has_aad) + (u32)((g0 + U - 1u) / D - g0 / D);
 }
-// Super-rows per super-chunk of a call with total_q super-rows in n messages: about ROWS_SC_TARGET super-chunks when the call is large, never fewer than tmin
-// super-rows (per-chunk work: a dispenser fetch, the descriptor, the round-1 constants, one Shoup multiply and a wave fold -- about one row's worth) nor more than
-// tmax (the granularity of the dealing), unless the table would overflow.
-HD u32 rows_pick_T(u64 total_q, u64 n, u64 cap_sc, u32 tmin, u32 tmax) {
-    u64 T = (total_q + ROWS_SC_TARGET - 1u) / ROWS_SC_TARGET;
-    if (T < tmin) T = tmin;
-    if (T > tmax) T = tmax;
-    if (T < 1) T = 1;
-    while (cap_sc && total_q / T + 2 * n > cap_sc && T < (1u << 20)) T *= 2;
-    return (u32)T;
+// the cut of a call of G units for `waves` waves: one block per wave while that is at most ROWS_STATIC_MAX units (or when the dealt cut would not fit the
+// scratch: nb_cap blocks), else blocks of ROWS_DYN_BLOCK units from the dispensers.  force_d > 0: dealt blocks of that many units (tests)
+HD void rows_cut(u64 G, u32 waves, u32 force_d, u64 nb_cap, u32 *D, u32 *NB, u32 *dyn) {
+    if (waves < 1) waves = 1;
+    u64 d = (G + waves - 1u) / waves;
+    u32 dy = 0;
+    if (d < 1) d = 1;
+    const u64 dd = force_d ? force_d : ROWS_DYN_BLOCK;
+    if ((force_d || d > ROWS_STATIC_MAX) && (G + dd - 1u) / dd <= nb_cap) { d = dd; dy = 1; }
+    *D = (u32)d; *NB = (u32)((G + d - 1u) / d); *dyn = dy;
 }
 // the message's lengths and offsets
 struct RowsMsg { u64 doff, aoff; u32 len, alen; };
@@ -105,38 +108,50 @@ HD RowsMsg rows_msg(const RowsParams &p, u32 m) {
     if (p.aad_off) { q.aoff = p.aad_off[m]; q.alen = (u32)(p.aad_off[m + 1] - q.aoff); }
     return q;
 }
-// the descriptor of super-chunk sc (offset-array form: from the table; fixed-size form: arithmetic)
-HD RowsSc rows_desc(const RowsParams &p, u32 sc) {
-    if (p.sc) return p.sc[sc];
-    RowsSc e;
-    const u32 m = sc / p.S, s = sc - m * p.S;
-    const RowsGeom g = rows_geom(p.pkt_len);
-    u32 q0, nrows, nphase;
-    rows_sc_shape(g.Q, g.rho, p.T, s, q0, nrows, nphase);
-    const unsigned char *ivp = p.ivs + (size_t)m * 12;
-    e.off = (u64)m * p.pkt_len;
-    e.iv0 = load_le32(ivp); e.iv1 = load_le32(ivp + 4); e.iv2 = load_le32(ivp + 8);
-    e.q0 = q0; e.shape = nrows | (nphase << 28); e.msg = m;
-    return e;
+// the message that owns unit g, and the units in front of a message
+HD u32 rows_find_msg(const RowsParams &p, u64 g) {
+    if (!p.prefix) return (u32)(g / p.U);
+    u32 lo = 0, hi = p.n_pkts;                                           // prefix[lo] <= g < prefix[hi]; every message has at least its tail unit
+    while (hi - lo > 1u) { const u32 mid = lo + ((hi - lo) >> 1); if (p.prefix[mid] <= g) lo = mid; else hi = mid; }
+    return lo;
 }
-// chunks of k_rows: [0, 4 n_sc) strands, then a tail chunk per message, then (has_aad) an AAD chunk per message
-HD u32 rows_chunks(const RowsParams &p, u32 n_sc) { return 4u * n_sc + p.n_pkts * (p.has_aad ? 2u : 1u); }
-// what arrives at a message's accumulator: every chunk slot of its super-chunks (whether the phase exists or not), its tail slot, its AAD slot
-HD u32 rows_expected(u32 nsc) { return 4u * nsc + 2u; }
+HD u64 rows_unit_base(const RowsParams &p, u32 m) { return p.prefix ? p.prefix[m] : (u64)m * p.U; }
+HD u32 rows_slot_base(const RowsParams &p, u32 m) { return p.slot_base ? p.slot_base[m] : m * p.SM; }
 
-// ---- k_rows: one chunk ---------------------------------------------------------------------------
-// lane `lane` of the wave that owns phase v of the super-chunk e: CTR over the rows 4 (q0 + i) + v and the lane's Horner accumulator (stride H^256)
+// ---- k_rows: one piece ---------------------------------------------------------------------------
+enum { ROWS_STRAND = 0, ROWS_TAIL = 1, ROWS_AAD = 2 };
+struct RowsPiece { u32 kind, k, q0, len, slot; u64 e; };                // strand: phase k, super-rows [q0, q0 + len); len = units taken
+// the piece that starts at unit u of the message (geometry g, first unit g0) and may take up to `room` units; D = units per block, gpos = g0 + u
+HD RowsPiece rows_piece(const RowsGeom &g, u32 has_aad, u32 slot_base, u64 g0, u32 u, u64 room, u32 D) {
+    RowsPiece pc;
+    pc.slot = slot_base + rows_nat(g, u) + (u32)((g0 + u) / D - g0 / D);
+    pc.len = 1; pc.k = 0; pc.q0 = 0; pc.e = 0;
+    if (u < 4u * g.Q + g.rho) {
+        pc.kind = ROWS_STRAND;
+        if (u < 4u * g.Q) { pc.k = u / g.Q; pc.q0 = u - pc.k * g.Q; const u32 left = g.Q - pc.q0; pc.len = room < left ? (u32)room : left; }
+        else { pc.k = u - 4u * g.Q; pc.q0 = g.Q; }
+        const u32 r_last = 4u * (pc.q0 + pc.len - 1u) + pc.k;
+        pc.e = 64ull * (g.R - 1u - r_last) + g.tb + 2u;
+    } else if (u == 4u * g.Q + g.rho) {
+        pc.kind = ROWS_TAIL;
+    } else {
+        pc.kind = ROWS_AAD;
+        pc.e = 64ull * g.R + g.tb + 2u;
+    }
+    (void)has_aad;
+    return pc;
+}
+// lane `lane` of the wave that runs a strand piece: CTR over the rows 4 (q0 + i) + k, i < len, and the lane's Horner accumulator (stride H^256)
 template <int NR, int MODE>
-HD uint4 rows_chunk_lane(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const RowsParams &p, const RowsSc &e,
-                         const unsigned char *smem, const CtrConsts &cc, u32 v, u32 lane) {
-    return body_strand_rows<NR, MODE>(km, tb, p.in + e.off, p.out + e.off, 0u, smem, cc, e.q0, 1u, e.shape & 0x0FFFFFFFu, v, lane);
+HD uint4 rows_strand_lane(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const RowsParams &p, const RowsMsg &q, const RowsPiece &pc,
+                          const unsigned char *smem, const CtrConsts &cc, u32 lane, u32 prio_rows, u32 prio_slot) {
+    return body_strand_rows<NR, MODE>(km, tb, p.in + q.doff, p.out + q.doff, 0u, smem, cc, pc.q0, 1u, pc.len, pc.k, lane, make_uint4(0, 0, 0, 0), false, prio_rows, prio_slot);
 }
-// the lane's term of the strand polynomial: B_L H^(63 - L) (XOR over the wave = the polynomial of the strand up to its last block)
-HD G128 rows_chunk_term(const KeyMaterial *__restrict__ km, uint4 acc, u32 lane) { return shoup2_gmul_lds(mo_to_be(acc), km->ltab[63u - lane]); }
+// the lane's term of the run's polynomial: B_L H^(63 - L) (XOR over the wave = the polynomial of the run up to its last block)
+HD G128 rows_strand_term(const KeyMaterial *__restrict__ km, uint4 acc, u32 lane) { return shoup2_gmul_lds(mo_to_be(acc), km->ltab[63u - lane]); }
 
-// ---- k_rows: the tail chunk and the AAD chunk of message m -------------------------------------------
-// a further row of such a chunk (a tail of a full 64 blocks; AAD beyond 1 KiB): the accumulator times H^64, bit-serially -- k_rows has the table of H^256 in LDS, not of H^64,
-// and these rows are rare
+// a further row of a tail or an AAD (a tail of a full 64 blocks; AAD beyond 1 KiB): the accumulator times H^64, bit-serially -- k_rows has the table of H^256 in LDS,
+// not of H^64, and these rows are rare
 HD uint4 rows_mul_h64(const KeyMaterial *__restrict__ km, uint4 acc) { return gf_mul_mo(acc, km->pw[0][64]); }
 // The tail blocks (data blocks 64 R ..., the last one ragged) and the length block [8 len(A)]_64 || [8 len(C)]_64 (gcm_ghash.vhd:257) as ONE right-aligned
 // sequence of tb + 1 <= 65 slots: one row, or two when the tail is a full 64 blocks.  Every lane runs the cipher once per row: data lanes on counter
@@ -179,7 +194,8 @@ HD G128 rows_tail_lane(const KeyMaterial *__restrict__ km, const RowsParams &p, 
     }
     return shoup2_gmul_lds(mo_to_be(acc), km->ltab[64u - lane]);
 }
-// The AAD of message m as rows of its own (right-aligned, Horner with H^64: one row up to 1 KiB of AAD): the lane's term  A_L H^(63 - L)  of the AAD's polynomial.  alen > 0.
+// The AAD of a message as rows of its own (right-aligned, Horner with H^64: one row up to 1 KiB of AAD): the lane's term  A_L H^(63 - L)  of the AAD's polynomial.
+// alen = 0: zero.
 HD G128 rows_aad_lane(const KeyMaterial *__restrict__ km, const RowsParams &p, const RowsMsg &q, u32 lane) {
     const u32 n_aad = (q.alen + 15u) >> 4, rows = (n_aad + 63u) >> 6, pad = 64u * rows - n_aad;
     const unsigned char *a = p.aad + q.aoff;
@@ -194,42 +210,5 @@ HD G128 rows_aad_lane(const KeyMaterial *__restrict__ km, const RowsParams &p, c
     return shoup2_gmul_lds(mo_to_be(acc), km->ltab[63u - lane]);
 }
 
-// ---- k_rows_close: the lane of slot `slot` -- [0, 4 cap_sc) chunk slots, then a tail slot and an AAD slot per message ----------------------------------
-// *msg = the message it contributes to (or 0xFFFFFFFF: the slot is beyond the call), *z = its contribution (zero when the phase does not exist / no AAD)
-HD void rows_weight_lane(const KeyMaterial *__restrict__ km, const RowsParams &p, u32 n_sc, u32 slot, u32 *msg, G128 *z) {
-    z->w[0] = z->w[1] = z->w[2] = z->w[3] = 0;
-    *msg = 0xFFFFFFFFu;
-    G128 w;
-    u64 e;
-    if (slot < 4u * p.cap_sc) {
-        if (slot >= 4u * n_sc) return;
-        const u32 sc = slot >> 2, v = slot & 3u;
-        u32 m, q0, shape;
-        if (p.sc) { m = p.sc[sc].msg; q0 = p.sc[sc].q0; shape = p.sc[sc].shape; }
-        else {
-            m = sc / p.S;
-            const RowsGeom g = rows_geom(p.pkt_len);
-            u32 nrows, nphase;
-            rows_sc_shape(g.Q, g.rho, p.T, sc - m * p.S, q0, nrows, nphase);
-            shape = nrows | (nphase << 28);
-        }
-        *msg = m;
-        if (v >= (shape >> 28)) return;
-        const RowsGeom g = rows_geom(rows_msg(p, m).len);
-        const u32 r_last = 4u * (q0 + (shape & 0x0FFFFFFFu) - 1u) + v;
-        e = 64ull * (g.R - 1u - r_last) + g.tb + 2u;
-        w = p.wsum[slot];
-    } else {
-        u32 m = slot - 4u * p.cap_sc;
-        if (m < p.n_pkts) { *msg = m; *z = p.wtail[m]; return; }              // the tail: already weighted
-        m -= p.n_pkts;
-        if (m >= p.n_pkts) return;
-        *msg = m;
-        const RowsMsg q = rows_msg(p, m);
-        if (!p.has_aad || !q.alen) return;
-        const RowsGeom g = rows_geom(q.len);
-        e = 64ull * g.R + g.tb + 2u;
-        w = p.waad[m];
-    }
-    *z = gf_mul(w, gf_pow_h_serial(km, e));
-}
+// ---- k_rows_close: a record's contribution ----------------------------------------------------------
+HD G128 rows_weigh(const KeyMaterial *__restrict__ km, const RowsRec &r) { return (r.flags & ROWS_REC_WEIGH) ? gf_mul(r.w, gf_pow_h_serial(km, r.e)) : r.w; }

@@ -430,7 +430,7 @@ class Context:
         return self
 
     def set_option(self, key, value):
-        """aesgcm_ctx_set_option: "tw", "body_min", "cyc_min", "cyc_max", "cyc_close", "fold_close", "cyc_prio", "pkt_order", "rows_min", "rows_t", "poll_us" (include/aesgcm.h)"""
+        """aesgcm_ctx_set_option: "tw", "body_min", "cyc_min", "cyc_max", "cyc_close", "fold_close", "cyc_prio", "pkt_order", "rows_min", "rows_block", "poll_us" (include/aesgcm.h)"""
         _chk(self._lib.aesgcm_ctx_set_option(self._c, key.encode(), int(value)))
         return self
 

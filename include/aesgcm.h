@@ -124,7 +124,7 @@ AESGCM_API int aesgcm_ctx_device(const aesgcm_ctx *ctx);
  *   "pkt_order"   packets from which aesgcm_packets_crypt_dev with offset arrays takes the packets by falling length class (a counting sort on the
  *                 device in front of the launch; default 98304, where it starts to pay), 0 = never.  The results are the same bytes.
  *   "rows_min"    bytes per packet from which aesgcm_packets_crypt_dev goes by rows (default 65536; 0 = never)
- *   "rows_t"      super-rows (4 KiB each) per super-chunk of the row kernel, 0 = the library's rule (4 .. 64 by the size of the call)
+ *   "rows_block"  units (rows of 64 blocks; a message's tail) per dealt block of the row kernel, 0 = the library's cut (one block per wave; blocks of 64 for large calls)
  *   "poll_us"     how long a tag is polled for in the pinned host slot before the call blocks in the runtime
  * AESGCM_EARG for an unknown key. */
 AESGCM_API int aesgcm_ctx_set_option(aesgcm_ctx *ctx, const char *key, int64_t value);

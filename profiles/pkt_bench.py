@@ -22,7 +22,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("kind", choices=("batch", "pkt", "pktw", "pktg", "pktg8", "pktg4", "pktl", "rows", "norows"))
 ap.add_argument("--var", action="store_true", help="one key: the same packets through offset arrays (pkt_len then is the caller's hint)")
 ap.add_argument("--aad", type=int, default=0, help="one key: bytes of AAD per packet")
-ap.add_argument("--rows-t", type=int, default=0, help="context option rows_t (super-rows per super-chunk of k_rows)")
+ap.add_argument("--rows-block", type=int, default=0, help="context option rows_block (units per dealt block of k_rows; 0 = the library's cut)")
 ap.add_argument("--n", type=int, default=1 << 20)
 ap.add_argument("--len", type=int, default=4096)
 ap.add_argument("--key-bits", type=int, default=128)
@@ -54,8 +54,8 @@ else:
         else:
             _dbg.force(pkt_lanes={"pktw": 64, "pktg": 16, "pktg8": 8, "pktg4": 4, "pktl": 1}[a.kind], pkt_rows=2)
     ctx = lib.Context(bytes(range(kb)))
-    if a.rows_t:
-        ctx.set_option("rows_t", a.rows_t)
+    if a.rows_block:
+        ctx.set_option("rows_block", a.rows_block)
     d_off = d_aoff = d_aad = None
     if a.var:
         import struct

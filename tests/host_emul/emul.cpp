@@ -791,109 +791,106 @@ static void test_keystream_and_ghash(u64 seed) {
     }
 }
 
-// Many messages under one key by rows (k_rows / k_rows_close, csrc/aesgcm_rows.h): the plan (fixed-size records: arithmetic; offset arrays: the planner's scan and
-// the super-chunk table), every chunk -- strands, tails, AAD -- in a scrambled order with the same lane code, the slots of the closing in a scrambled order with
-// plain XORs for the atomics; ciphertext, tags and the arrival counts against the oracle.
+// Many messages under one key by rows (k_rows / k_rows_close, csrc/aesgcm_rows.h): the cut (fixed-size records: arithmetic; offset arrays: the planner's two
+// prefix sums), every block in a scrambled order with the same piece walk and lane code as k_rows, the record slots of the closing in a scrambled order with plain
+// XORs for the atomics; ciphertext and tags against the oracle, and the zero-at-rest rule of the shared scratch.
 template <int NR>
-static void emu_rows_nr(const KeyMaterial *km, int dec, RowsParams &p, std::vector<RowsSc> &sc, std::vector<u32> &msg_sc, RowsHdr &hdr, u32 tmin, u32 tmax) {
+static void emu_rows_nr(const KeyMaterial *km, int dec, RowsParams &p, u32 waves, u32 force_d) {
     static unsigned char smem[AESGCM_LDS_BYTES_T4] __attribute__((aligned(16)));
     for (u32 tid = 0; tid < AESGCM_MAIN_WG; tid++) main_fill_lds(smem, km, &g_tb, tid, true, AESGCM_MAIN_WG, GH_TAB_K256);
     for (u32 tid = 0; tid < AESGCM_MAIN_WG; tid++) fill_lds_t4(smem, &g_tb, tid, AESGCM_MAIN_WG);
     const u32 n = p.n_pkts;
     p.has_aad = (p.aad_off || p.aad_len) ? 1u : 0u;
-    if (p.data_off) {                                                    // k_rows_plan + k_rows_expand
-        u64 tq = 0;
-        for (u32 m = 0; m < n; m++) tq += rows_geom(p.data_off[m + 1] - p.data_off[m]).Q;
-        p.cap_sc = ROWS_CAP_BASE + 2 * n;
-        hdr.T = rows_pick_T(tq, n, p.cap_sc, tmin, tmax);
-        msg_sc.assign(n + 1, 0);
-        for (u32 m = 0; m < n; m++) { const RowsGeom g = rows_geom(p.data_off[m + 1] - p.data_off[m]); msg_sc[m + 1] = msg_sc[m] + rows_nsc(g.Q, g.rho, hdr.T); }
-        hdr.n_sc = msg_sc[n];
-        sc.assign(hdr.n_sc + 1, RowsSc());
-        p.hdr = &hdr; p.msg_sc = msg_sc.data();
-        for (u32 m = 0; m < n; m++) {
-            const RowsMsg q = rows_msg(p, m);
-            const RowsGeom g = rows_geom(q.len);
-            for (u32 s = 0; s < msg_sc[m + 1] - msg_sc[m]; s++) {
-                RowsSc e; u32 q0, nrows, nphase;
-                rows_sc_shape(g.Q, g.rho, hdr.T, s, q0, nrows, nphase);
-                e.off = q.doff; e.iv0 = load_le32(p.ivs + 12 * m); e.iv1 = load_le32(p.ivs + 12 * m + 4); e.iv2 = load_le32(p.ivs + 12 * m + 8);
-                e.q0 = q0; e.shape = nrows | (nphase << 28); e.msg = m;
-                sc[msg_sc[m] + s] = e;
-            }
-        }
-        p.sc = sc.data();
+    p.waves = waves;
+    std::vector<u64> prefix(n + 1, 0);
+    std::vector<u32> slot_base(n + 1, 0);
+    RowsHdr hdr;
+    size_t slots;
+    if (p.data_off) {                                                    // k_rows_plan
+        for (u32 m = 0; m < n; m++) prefix[m + 1] = prefix[m] + rows_units(rows_geom(p.data_off[m + 1] - p.data_off[m]), p.has_aad);
+        hdr.G = prefix[n];
+        rows_cut(hdr.G, waves, force_d, ROWS_NB_CAP, &hdr.D, &hdr.NB, &hdr.dyn);
+        for (u32 m = 0; m < n; m++) slot_base[m + 1] = slot_base[m] + rows_slots(rows_geom(p.data_off[m + 1] - p.data_off[m]), p.has_aad, prefix[m], hdr.D);
+        slots = 11 * (size_t)n + ROWS_NB_CAP;
+        CHECK(slot_base[n] <= slots, "rows: %u slots planned, %zu held", slot_base[n], slots);
+        p.hdr = &hdr; p.prefix = prefix.data(); p.slot_base = slot_base.data();
     } else {
         const RowsGeom g = rows_geom(p.pkt_len);
-        p.T = rows_pick_T((u64)n * g.Q, n, 0, tmin, tmax);
-        p.S = rows_nsc(g.Q, g.rho, p.T);
-        p.n_sc = n * p.S; p.cap_sc = p.n_sc;
+        p.U = rows_units(g, p.has_aad); p.G = (u64)n * p.U;
+        rows_cut(p.G, waves, force_d, (u64)1 << 30, &p.D, &p.NB, &p.dyn);
+        p.SM = rows_nat_count(g, p.has_aad) + (p.U - 1u) / p.D + 1u;
+        slots = (size_t)n * p.SM;
     }
-    const u32 n_sc = p.hdr ? p.hdr->n_sc : p.n_sc;
-    std::vector<G128> wsum(4 * (size_t)p.cap_sc + 4), wtail(n + 1), waad(n + 1);
+    p.slot_cap = (u32)slots;
+    std::vector<RowsRec> rec(slots + 1);
+    memset(rec.data(), 0, rec.size() * sizeof(RowsRec));
     std::vector<unsigned long long> acc(2 * (size_t)n + 2, 0);
-    std::vector<u32> cnt(n + 1, 0);
-    memset(wsum.data(), 0xEE, wsum.size() * sizeof(G128)); memset(waad.data(), 0xEE, waad.size() * sizeof(G128));
-    p.wsum = wsum.data(); p.wtail = wtail.data(); p.waad = waad.data(); p.acc = acc.data(); p.cnt = cnt.data();
-    const u32 C4 = 4 * n_sc, C = rows_chunks(p, n_sc);
-    for (u32 k = 0; k < C; k++) {
-        const u32 c = (u32)(((u64)k * 2741u + 17u) % C);                  // any order (C and 2741 need not be coprime: cover the rest below)
-        (void)c;
-    }
-    std::vector<u32> order(C);
-    for (u32 k = 0; k < C; k++) order[k] = C - 1 - k;                    // reverse order: tails and AAD first
-    for (u32 c : order) {
-        if (c >= C4) {
-            const bool is_aad = c - C4 >= n;
-            const u32 m = c - C4 - (is_aad ? n : 0);
+    std::vector<u32> cnt(n + 1, 0), npieces(n + 1, 0);
+    p.rec = rec.data(); p.acc = acc.data(); p.cnt = cnt.data(); p.npieces = npieces.data();
+    const u64 G = p.hdr ? p.hdr->G : p.G;
+    const u32 D = p.hdr ? p.hdr->D : p.D, NB = p.hdr ? p.hdr->NB : p.NB, dyn = p.hdr ? p.hdr->dyn : p.dyn;
+    CHECK(dyn || NB <= waves, "rows: %u blocks for %u waves", NB, waves);
+    for (u32 kb = 0; kb < NB; kb++) {
+        const u32 b = NB - 1 - kb;                                       // last block first
+        u64 g = (u64)b * D;
+        const u64 g_end = g + D < G ? g + D : G;
+        u32 m = rows_find_msg(p, g);
+        while (g < g_end) {
             const RowsMsg mq = rows_msg(p, m);
-            G128 z = {{0, 0, 0, 0}};
-            if (is_aad) {
-                if (!mq.alen) continue;
-                for (u32 lane = 0; lane < 64; lane++) xor_g(z, rows_aad_lane(km, p, mq, lane));
-                waad[m] = z;
-                continue;
+            const RowsGeom geo = rows_geom(mq.len);
+            const u64 g0 = rows_unit_base(p, m);
+            const u32 U = rows_units(geo, p.has_aad), sbase = rows_slot_base(p, m);
+            CHECK(g >= g0 && g < g0 + U, "rows: unit %llu outside message %u", (unsigned long long)g, m);
+            u32 made = 0;
+            while (g < g_end && g < g0 + U) {
+                const RowsPiece pc = rows_piece(geo, p.has_aad, sbase, g0, (u32)(g - g0), g_end - g, D);
+                G128 z = {{0, 0, 0, 0}};
+                u32 flags = ROWS_REC_VALID | ROWS_REC_WEIGH;
+                uint4 e63 = make_uint4(0, 0, 0, 0);
+                for (u32 lane = 0; lane < 64; lane++) {
+                    const CtrConsts cc = ctr_round1_consts(load_le32(p.ivs + 12 * m), load_le32(p.ivs + 12 * m + 4), load_le32(p.ivs + 12 * m + 8), km->rk, smem, (lane & 31u) << 2);
+                    if (pc.kind == ROWS_STRAND) {
+                        const uint4 a = dec ? rows_strand_lane<NR, MODE_DEC>(km, &g_tb, p, mq, pc, smem, cc, lane, 0, 0) : rows_strand_lane<NR, MODE_ENC>(km, &g_tb, p, mq, pc, smem, cc, lane, 0, 0);
+                        xor_g(z, rows_strand_term(km, a, lane));
+                    } else if (pc.kind == ROWS_AAD) {
+                        xor_g(z, rows_aad_lane(km, p, mq, lane));
+                    } else {
+                        uint4 ej0;
+                        xor_g(z, dec ? rows_tail_lane<NR, 1>(km, p, mq, smem, cc, lane, &ej0) : rows_tail_lane<NR, 0>(km, p, mq, smem, cc, lane, &ej0));
+                        if (lane == 63) e63 = ej0;
+                    }
+                }
+                if (pc.kind == ROWS_TAIL) { xor_g(z, mo_to_be(e63)); flags = ROWS_REC_VALID; }
+                CHECK(pc.slot < slots && !rec[pc.slot].flags, "rows: slot %u of %zu taken twice (message %u)", pc.slot, slots, m);
+                RowsRec r; r.w = z; r.e = pc.e; r.msg = m; r.flags = flags;
+                rec[pc.slot] = r;
+                g += pc.len; ++made;
             }
-            uint4 ej0 = make_uint4(0, 0, 0, 0), e63 = ej0;
-            for (u32 lane = 0; lane < 64; lane++) {
-                const CtrConsts cc = ctr_round1_consts(load_le32(p.ivs + 12 * m), load_le32(p.ivs + 12 * m + 4), load_le32(p.ivs + 12 * m + 8), km->rk, smem, (lane & 31u) << 2);
-                xor_g(z, dec ? rows_tail_lane<NR, 1>(km, p, mq, smem, cc, lane, &ej0) : rows_tail_lane<NR, 0>(km, p, mq, smem, cc, lane, &ej0));
-                if (lane == 63) e63 = ej0;
-            }
-            xor_g(z, mo_to_be(e63));
-            wtail[m] = z;
-            continue;
+            npieces[m] += made;
+            ++m;
         }
-        const u32 v = c & 3u;
-        const RowsSc e = rows_desc(p, c >> 2);
-        if (v >= (e.shape >> 28)) continue;
-        G128 z = {{0, 0, 0, 0}};
-        for (u32 lane = 0; lane < 64; lane++) {
-            const CtrConsts cc = ctr_round1_consts(e.iv0, e.iv1, e.iv2, km->rk, smem, (lane & 31u) << 2);
-            const uint4 a = dec ? rows_chunk_lane<NR, MODE_DEC>(km, &g_tb, p, e, smem, cc, v, lane) : rows_chunk_lane<NR, MODE_ENC>(km, &g_tb, p, e, smem, cc, v, lane);
-            xor_g(z, rows_chunk_term(km, a, lane));
-        }
-        wsum[c] = z;
     }
     // k_rows_close: every slot, last first
-    const u32 slots = 4 * p.cap_sc + 2 * n;
     u32 finals = 0;
-    for (u32 k = 0; k < slots; k++) {
-        const u32 slot = slots - 1 - k;
-        u32 m; G128 z;
-        rows_weight_lane(km, p, n_sc, slot, &m, &z);
-        if (m == 0xFFFFFFFFu) continue;
+    for (size_t k = 0; k < slots; k++) {
+        const size_t slot = slots - 1 - k;
+        const RowsRec r = rec[slot];
+        if (!(r.flags & ROWS_REC_VALID)) continue;
+        rec[slot].flags = 0;
+        const G128 z = rows_weigh(km, r);
+        const u32 m = r.msg;
         acc[2 * m] ^= ((unsigned long long)z.w[0] << 32) | z.w[1]; acc[2 * m + 1] ^= ((unsigned long long)z.w[2] << 32) | z.w[3];
-        const u32 nsc_m = p.msg_sc ? p.msg_sc[m + 1] - p.msg_sc[m] : p.S;
-        if (++cnt[m] == rows_expected(nsc_m)) {
+        if (++cnt[m] == npieces[m]) {
             G128 t; t.w[0] = (u32)(acc[2 * m] >> 32); t.w[1] = (u32)acc[2 * m]; t.w[2] = (u32)(acc[2 * m + 1] >> 32); t.w[3] = (u32)acc[2 * m + 1];
+            acc[2 * m] = acc[2 * m + 1] = 0; cnt[m] = 0; npieces[m] = 0;
             store_block_bytes(p.tags + (size_t)m * 16, be_to_mo(t), 16);
             ++finals;
         }
     }
     CHECK(finals == n, "rows: %u of %u messages closed", finals, n);
+    for (u32 m = 0; m < n; m++) CHECK(!acc[2 * m] && !acc[2 * m + 1] && !cnt[m] && !npieces[m], "rows: message %u not zero at rest", m);
 }
-static void test_rows(int key_len, u64 seed, u32 T, bool var, const std::vector<u32> &lens, const std::vector<u32> &aads, u32 misalign = 0) {
+static void test_rows(int key_len, u64 seed, u32 waves, u32 force_d, bool var, const std::vector<u32> &lens, const std::vector<u32> &aads, u32 misalign = 0) {
     auto key = rnd(key_len, seed);
     Emu E(key.data(), key_len, 0);
     const u32 n = (u32)lens.size();
@@ -909,19 +906,17 @@ static void test_rows(int key_len, u64 seed, u32 T, bool var, const std::vector<
         p.n_pkts = n;
         if (var) { p.data_off = doff.data(); p.aad_off = aoff.data(); }
         else { p.pkt_len = lens[0]; p.aad_len = aads[0]; }
-        std::vector<RowsSc> sc; std::vector<u32> msg_sc; RowsHdr hdr;
-        const u32 tmin = T ? T : ROWS_T_MIN, tmax = T ? T : ROWS_T_MAX;
-        if (E.km.nr == 10) emu_rows_nr<10>(&E.km, dec, p, sc, msg_sc, hdr, tmin, tmax); else if (E.km.nr == 12) emu_rows_nr<12>(&E.km, dec, p, sc, msg_sc, hdr, tmin, tmax); else emu_rows_nr<14>(&E.km, dec, p, sc, msg_sc, hdr, tmin, tmax);
+        if (E.km.nr == 10) emu_rows_nr<10>(&E.km, dec, p, waves, force_d); else if (E.km.nr == 12) emu_rows_nr<12>(&E.km, dec, p, waves, force_d); else emu_rows_nr<14>(&E.km, dec, p, waves, force_d);
         if (!dec) {
             for (u32 k = 0; k < n; k++) {
                 std::vector<uint8_t> ref(lens[k] + 16); uint8_t rtag[16];
                 orc_gcm_crypt(0, key.data(), key_len, ivs.data() + 12 * k, aad.data() + aoff[k], aads[k], in.p + doff[k], lens[k], ref.data(), rtag);
-                CHECK(memcmp(ref.data(), out.p + doff[k], lens[k]) == 0, "rows ct %u len %u T %u var %d", k, lens[k], T, (int)var);
-                CHECK(memcmp(rtag, tags.data() + 16 * k, 16) == 0, "rows tag %u len %u aad %u T %u var %d", k, lens[k], aads[k], T, (int)var);
+                CHECK(memcmp(ref.data(), out.p + doff[k], lens[k]) == 0, "rows ct %u len %u waves %u D %u var %d", k, lens[k], waves, force_d, (int)var);
+                CHECK(memcmp(rtag, tags.data() + 16 * k, 16) == 0, "rows tag %u len %u aad %u waves %u D %u var %d", k, lens[k], aads[k], waves, force_d, (int)var);
             }
         } else {
-            CHECK(memcmp(out.p + misalign, in.p + misalign, doff[n] - misalign) == 0, "rows dec data T %u var %d", T, (int)var);
-            CHECK(memcmp(tags2.data(), tags.data(), 16 * n) == 0, "rows dec tags T %u var %d", T, (int)var);
+            CHECK(memcmp(out.p + misalign, in.p + misalign, doff[n] - misalign) == 0, "rows dec data waves %u D %u var %d", waves, force_d, (int)var);
+            CHECK(memcmp(tags2.data(), tags.data(), 16 * n) == 0, "rows dec tags waves %u D %u var %d", waves, force_d, (int)var);
         }
     }
 }
@@ -967,15 +962,21 @@ int main(int argc, char **argv) {
     test_batch_pieces();
     test_packets(16, 61); test_packets(24, 62); test_packets(32, 63);
     // many messages by rows: offset arrays with every kind of length (empty, shorter than a block, tails of 63 blocks + 15 bytes = two tail rows, whole super-rows,
-    // 1 .. 3 rows behind them), AAD of none / a ragged block / more than a row; fixed-size records; forced chunk sizes (several super-chunks per message, a short last one)
-    test_rows(16, 201, 1, true, {0, 1, 15, 16, 1023, 1024, 1040, 4096, 4097, 5 * 1024 + 1008 + 15, 3 * 4096 + 2 * 1024 + 17, 9 * 4096, 7 * 4096 + 3 * 1024 + 1023},
-              {0, 20, 0, 16, 1, 0, 33, 0, 13, 1024 + 7, 0, 8, 2048});
-    test_rows(32, 202, 3, true, {10 * 4096 + 5, 0, 4096 * 7, 3 * 1024, 1024 * 6 + 100}, {0, 0, 12, 5, 0});
-    test_rows(24, 203, 0, true, {65536, 65536 + 1024 + 3, 20000, 131072 + 17}, {20, 0, 28, 0});
-    test_rows(32, 204, 0, false, {65536, 65536, 65536}, {0, 0, 0});
-    test_rows(16, 205, 2, false, {4096 * 5 + 2048 + 9, 4096 * 5 + 2048 + 9, 4096 * 5 + 2048 + 9, 4096 * 5 + 2048 + 9, 4096 * 5 + 2048 + 9}, {13, 13, 13, 13, 13});
-    test_rows(24, 206, 4, false, {700, 700}, {0, 0});                       // records shorter than a row: no strand at all, tails only
-    test_rows(32, 207, 2, true, {4096 * 3 + 5, 9000, 1024 * 5}, {7, 0, 16}, 5);   // packed back to back from an odd byte address
+    // 1 .. 3 rows behind them), AAD of none / a ragged block / more than a row; fixed-size records; one block per wave for few and for many waves (cuts in the
+    // middle of strands), dealt blocks of 1 / 2 / 3 / 7 units
+    const std::vector<u32> rl = {0, 1, 15, 16, 1023, 1024, 1040, 4096, 4097, 5 * 1024 + 1008 + 15, 3 * 4096 + 2 * 1024 + 17, 9 * 4096, 7 * 4096 + 3 * 1024 + 1023};
+    const std::vector<u32> ra = {0, 20, 0, 16, 1, 0, 33, 0, 13, 1024 + 7, 0, 8, 2048};
+    test_rows(16, 201, 5, 0, true, rl, ra);
+    test_rows(24, 208, 64, 0, true, rl, ra);
+    test_rows(32, 209, 4096, 1, true, rl, ra);
+    test_rows(32, 202, 16, 3, true, {10 * 4096 + 5, 0, 4096 * 7, 3 * 1024, 1024 * 6 + 100}, {0, 0, 12, 5, 0});
+    test_rows(24, 203, 7, 0, true, {65536, 65536 + 1024 + 3, 20000, 131072 + 17}, {20, 0, 28, 0});
+    test_rows(32, 204, 3, 0, false, {65536, 65536, 65536}, {0, 0, 0});            // 65 units per message, one message per wave
+    test_rows(16, 210, 13, 0, false, {65536, 65536, 65536}, {0, 0, 0});           // 15 units per wave: cuts inside the strands
+    test_rows(16, 205, 16, 2, false, {4096 * 5 + 2048 + 9, 4096 * 5 + 2048 + 9, 4096 * 5 + 2048 + 9, 4096 * 5 + 2048 + 9, 4096 * 5 + 2048 + 9}, {13, 13, 13, 13, 13});
+    test_rows(24, 211, 16, 7, false, {4096 * 5 + 2048 + 9, 4096 * 5 + 2048 + 9, 4096 * 5 + 2048 + 9}, {0, 0, 0});
+    test_rows(24, 206, 16, 0, false, {700, 700}, {0, 0});                       // records shorter than a row: no strand at all, tails only
+    test_rows(32, 207, 4, 2, true, {4096 * 3 + 5, 9000, 1024 * 5}, {7, 0, 16}, 5);   // packed back to back from an odd byte address
     if (level > 1) {
         test_key(32, 1, 7, {{123, 16 * 64 * 1100 + 11}});     // 1100 chunks: two stage-1 workgroups
         test_key(16, 0, 8, {{0, 16 * W * 600}});              // production rule, > GMAX chunks of Tw = 16

@@ -65,14 +65,15 @@ def test_mixed_message_sizes_with_aad_and_ragged_ends(hip, orc, klen):
     _check_var(hip, orc, ctx, key, lens, aads, 810 + klen, hint=1 << 20, forged=(2, 5, 13))
 
 
-@pytest.mark.parametrize("t", [1, 2, 3, 7])
-def test_forced_chunk_sizes(hip, orc, t):
-    """the chunk size pinned to 1 / 2 / 3 / 7 super-rows: many super-chunks per message, short last ones, the single super-row behind the last whole one"""
-    key = splitmix_bytes(7100 + t, 32)
-    ctx = hip.Context(key).set_option("rows_t", t)
+@pytest.mark.parametrize("d", [1, 2, 3, 7, 64])
+def test_dealt_blocks_of_forced_sizes(hip, orc, d):
+    """blocks of 1 / 2 / 3 / 7 / 64 units dealt from the dispensers (the library's own cut of a call this small is one block per wave): cuts in the middle of
+    strands, pieces of a single row, messages that are a tail and nothing else"""
+    key = splitmix_bytes(7100 + d, 32)
+    ctx = hip.Context(key).set_option("rows_block", d)
     lens = [0, 1, 15, 16, 1023, 1024, 1040, 4096, 4097, 5 * 1024 + 1008 + 15, 3 * 4096 + 2 * 1024 + 17, 9 * 4096, 7 * 4096 + 3 * 1024 + 1023, 29 * 4096 + 100, 64 * 4096]
     aads = [0, 20, 0, 16, 1, 0, 33, 0, 13, 1024 + 7, 0, 8, 2048, 0, 5]
-    _check_var(hip, orc, ctx, key, lens, aads, 830 + t, hint=1 << 16, forged=(0, 14))
+    _check_var(hip, orc, ctx, key, lens, aads, 830 + d, hint=1 << 16, forged=(0, 14))
 
 
 def test_packed_from_an_odd_byte_address(hip, orc):
