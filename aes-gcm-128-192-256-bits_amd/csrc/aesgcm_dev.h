@@ -1214,6 +1214,48 @@ HD uint4 body_strand_lane(const KeyMaterial *__restrict__ km, const DevTables *_
                           uint4 acc_in = make_uint4(0, 0, 0, 0), bool continued = false, u32 prio_rows = 0, u32 prio_slot = 0) {
     return body_strand_rows<NR, MODE, T4>(km, tb, p.in, p.out, p.ctr_hi0, smem, cc, q0, qstep, n, v, lane, acc_in, continued, prio_rows, prio_slot);
 }
+// The same row code over CONSECUTIVE rows r0, r0 + 1, ... of an aligned body (k_rows: a run of rows of one of many messages, aesgcm_rows.h): the row phase
+// v = r & 3 changes with every row, so the wave holds the lane constants of all four phases (sixteen registers instead of four; one select per row and word)
+// and ONE Horner accumulator with the stride H^64 of consecutive rows (main_fill_lds(GH_TAB_K64)) -- a run of any length is one piece of work with one value
+// to leave behind, where four strands would be four.  Returns sum_i X[row r0 + i, lane] * (H^64)^(n-1-i).
+template <int NR, int MODE, bool T4 = (AESGCM_T4 != 0)>
+HD uint4 body_rows_lane(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const unsigned char *in, unsigned char *out, u32 ctr_hi0,
+                        const unsigned char *smem, const CtrConsts &cc, u32 r0, u32 n, u32 lane, u32 prio_rows = 0, u32 prio_slot = 0) {
+    const u32 *__restrict__ rk0 = km->rk;
+    const u32 lb = (lane & 31u) << 2, lane16 = lane * 16u;
+    const BodyLane b0 = body_lane_consts(rk0, cc, smem, 0u, lane), b1 = body_lane_consts(rk0, cc, smem, 1u, lane);
+    const BodyLane b2 = body_lane_consts(rk0, cc, smem, 2u, lane), b3 = body_lane_consts(rk0, cc, smem, 3u, lane);
+    u32 rk[4 * (NR + 1)];                                              // the keys of the late rounds in vector registers: see body_strand_rows
+#pragma unroll
+    for (int w = 0; w < 4 * (NR + 1); w++) rk[w] = (w >= (T4 ? AESGCM_BODY_RKV_FROM(NR) : AESGCM_BODY_RKV_FROM_HALF(NR))) ? pin_vgpr(rk0[w]) : rk0[w];
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    for (u32 i = 0; i < n; ++i) {
+        const u32 r = r0 + i, v = r & 3u, q = r >> 2;                  // wave-uniform
+        if (prio_rows) body_prio(i, prio_rows, prio_slot);
+        if (i) acc = ghash_mul_const_lds(acc, smem);
+        const u64 off = (u64)r * 1024;
+        const unsigned char *src = reinterpret_cast<const unsigned char *>(uniform64((u64)(uintptr_t)in + off));
+        unsigned char *dst = reinterpret_cast<unsigned char *>(uniform64((u64)(uintptr_t)out + off));
+        const uint4 x = (MODE == MODE_PROBE) ? make_uint4(lane, q, v, 0u) : gload16(src + lane16);
+        const bool hi = (v & 2u) != 0, odd = (v & 1u) != 0;
+        BodyLane b;
+        b.p0 = hi ? (odd ? b3.p0 : b2.p0) : (odd ? b1.p0 : b0.p0); b.p1 = hi ? (odd ? b3.p1 : b2.p1) : (odd ? b1.p1 : b0.p1);
+        b.p2 = hi ? (odd ? b3.p2 : b2.p2) : (odd ? b1.p2 : b0.p2); b.p3 = hi ? (odd ? b3.p3 : b2.p3) : (odd ? b1.p3 : b0.p3);
+        u32 s0, s1, s2, s3;
+        body_state(s0, s1, s2, s3, b, ctr_hi0 + q, v, lane, cc, rk, tb);
+        body_rounds<NR, T4>(s0, s1, s2, s3, rk, smem, lb);
+        const uint4 y = make_uint4(x.x ^ s0, x.y ^ s1, x.z ^ s2, x.w ^ s3);                  // gcm_gctr.vhd:150
+        if (MODE != MODE_PROBE) {
+#if AESGCM_BODY_WT
+            gstore16_wt(dst, lane16, y);
+#else
+            gstore16(dst + lane16, y);
+#endif
+        }
+        acc = xor4(acc, (MODE == MODE_DEC) ? x : y);                  // aes_gcm.vhd:207-211
+    }
+    return acc;
+}
 // dealt chunks: lane `lane` of the wave that owns chunk c = 4*s + v: returns sum_i X[row 4(sT+i)+v, lane] * (H^256)^(T-1-i)
 template <int NR, int MODE>
 HD uint4 body_chunk_lane(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const BodyParams &p,

@@ -1197,11 +1197,12 @@ __global__ __launch_bounds__(ILP ? AESGCM_PKTL_WG_ILP : AESGCM_PKTL_WG, ILP ? 2 
 // pieces and the lane code are in aesgcm_rows.h.  k_rows has k_body's LDS image and row loop (body_strand_rows); a wave takes a block of the call's unit axis --
 // its own (one block per wave) or the next from the dispensers -- and walks the pieces in it; what it leaves per piece is a 32-byte record.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 opaque_sgpr(u32 x) { u32 r; asm volatile("s_mov_b32 %0, %1" : "=s"(r) : "s"(x)); return r; }   // the same value, of unknown origin to the compiler
 template <int NR, int MODE>
 __global__ __launch_bounds__(AESGCM_BODY_WG, AESGCM_BODY_WPS) void k_rows(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const RowsParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 tid = threadIdx.x, lane = tid & 63u;
-    main_fill_lds(smem, km, tb, tid, true, AESGCM_BODY_WG, GH_TAB_K256);
+    main_fill_lds(smem, km, tb, tid, true, AESGCM_BODY_WG, GH_TAB_K64);            // consecutive rows: Horner stride H^64
 #if AESGCM_T4
     fill_lds_t4(smem, tb, tid, AESGCM_BODY_WG);
 #endif
@@ -1220,38 +1221,42 @@ __global__ __launch_bounds__(AESGCM_BODY_WG, AESGCM_BODY_WPS) void k_rows(const 
         u64 g = (u64)b * D;
         const u64 g_end = g + D < G ? g + D : G;
         u32 m = uniform32(rows_find_msg(p, g));
-        while (g < g_end) {                                                   // the messages the block meets
+        // The pieces of the block.  Every iteration derives what it needs from (g, m) alone -- lengths, offsets, the IV's constants are loaded again per piece, and
+        // the record's header is written BEFORE the rows -- so that almost nothing but g, m and the record's address is live across the row loop (an earlier form
+        // that carried the message's geometry through it spilled 114 scalars and 252 bytes of scratch).
+        for (u32 guard2 = 0; g < g_end && guard2 <= 2u * D + 4u; ++guard2) {
+            m = opaque_sgpr(m);
             RowsMsg mq = rows_msg(p, m);
             mq.doff = uniform64(mq.doff); mq.aoff = uniform64(mq.aoff); mq.len = uniform32(mq.len); mq.alen = uniform32(mq.alen);
             const RowsGeom geo = rows_geom(mq.len);
             const u64 g0 = uniform64(rows_unit_base(p, m));
-            const u32 U = rows_units(geo, p.has_aad), sbase = uniform32(rows_slot_base(p, m));
-            const unsigned char *ivp = p.ivs + (size_t)m * 12;
-            CtrConsts cc = ctr_round1_consts(uniform32(load_le32(ivp)), uniform32(load_le32(ivp + 4)), uniform32(load_le32(ivp + 8)), km->rk, smem, (lane & 31u) << 2);   // key and IV only: wave-uniform
-            cc.c0 = __builtin_amdgcn_readfirstlane(cc.c0); cc.c1 = __builtin_amdgcn_readfirstlane(cc.c1);
-            cc.c2 = __builtin_amdgcn_readfirstlane(cc.c2); cc.c3 = __builtin_amdgcn_readfirstlane(cc.c3);
-            u32 made = 0;
-            while (g < g_end && g < g0 + U) {                                 // the pieces of this message inside the block
-                const RowsPiece pc = rows_piece(geo, p.has_aad, sbase, g0, (u32)(g - g0), g_end - g, D);
-                G128 z;
-                u32 flags = ROWS_REC_VALID | ROWS_REC_WEIGH;
-                if (pc.kind == ROWS_STRAND) {
-                    z = wave_xor(rows_strand_term(km, rows_strand_lane<NR, MODE>(km, tb, p, mq, pc, smem, cc, lane, dyn ? 0u : p.prio_rows, (tid >> 8) & 3u), lane));
-                } else if (pc.kind == ROWS_AAD) {
-                    z = wave_xor(rows_aad_lane(km, p, mq, lane));
+            if (g >= g0 + rows_units(geo, p.has_aad)) { ++m; continue; }     // the next message (every message has at least its tail unit)
+            const RowsPiece pc = rows_piece(geo, uniform32(rows_slot_base(p, m)), g0, (u32)(g - g0), g_end - g, D);
+            RowsRec *rr = p.rec + pc.slot;
+            if (lane == 0) {
+                rr->e = pc.e; rr->msg = m; rr->flags = pc.kind == ROWS_TAIL ? ROWS_REC_VALID : (ROWS_REC_VALID | ROWS_REC_WEIGH);    // (the tail is weighted already: lane terms H^(64 - L))
+                atomicAdd(p.npieces + m, 1u);                                 // what k_rows_close waits for
+            }
+            G128 z;
+            if (pc.kind == ROWS_AAD) {
+                z = wave_xor(rows_aad_lane(km, p, mq, smem, lane));
+            } else {
+                const unsigned char *ivp = p.ivs + (size_t)m * 12;
+                CtrConsts cc = ctr_round1_consts(uniform32(load_le32(ivp)), uniform32(load_le32(ivp + 4)), uniform32(load_le32(ivp + 8)), km->rk, smem, (lane & 31u) << 2);   // key and IV only: wave-uniform
+                cc.c0 = __builtin_amdgcn_readfirstlane(cc.c0); cc.c1 = __builtin_amdgcn_readfirstlane(cc.c1);
+                cc.c2 = __builtin_amdgcn_readfirstlane(cc.c2); cc.c3 = __builtin_amdgcn_readfirstlane(cc.c3);
+                if (pc.kind == ROWS_RUN) {
+                    z = wave_xor(rows_run_term(km, rows_run_lane<NR, MODE>(km, tb, p, mq, pc, smem, cc, lane, dyn ? 0u : p.prio_rows, (tid >> 8) & 3u), lane));
                 } else {
                     uint4 ej0;
                     z = wave_xor(rows_tail_lane<NR, MODE == MODE_DEC>(km, p, mq, smem, cc, lane, &ej0));
                     const G128 e = mo_to_be(make_uint4((u32)__builtin_amdgcn_readlane((int)ej0.x, 63), (u32)__builtin_amdgcn_readlane((int)ej0.y, 63),
                                                        (u32)__builtin_amdgcn_readlane((int)ej0.z, 63), (u32)__builtin_amdgcn_readlane((int)ej0.w, 63)));
                     z.w[0] ^= e.w[0]; z.w[1] ^= e.w[1]; z.w[2] ^= e.w[2]; z.w[3] ^= e.w[3];
-                    flags = ROWS_REC_VALID;                                   // weighted already: lane terms H^(64 - L)
                 }
-                if (lane == 0) { RowsRec r; r.w = z; r.e = pc.e; r.msg = m; r.flags = flags; p.rec[pc.slot] = r; }
-                g += pc.len; ++made;
             }
-            if (lane == 0) atomicAdd(p.npieces + m, made);                    // what k_rows_close waits for
-            ++m;
+            if (lane == 0) rr->w = z;
+            g += pc.len;
         }
     }
 }
@@ -2653,7 +2658,7 @@ static int packets_rows(aesgcm_ctx *c, int decrypt, RowsParams &p, hipStream_t s
         slots = n * p.SM;
     } else {
         p.waves = wgs * (AESGCM_BODY_WG / 64);
-        slots = 11 * n + ROWS_NB_CAP;                                        // at most 9 natural segments per message (four strands, three rows, tail, AAD) and one more slot per block boundary inside it
+        slots = 4 * n + ROWS_NB_CAP;                                         // at most 3 natural segments per message (rows, tail, AAD) and one more slot per block boundary inside it
         if (slots >= (1ull << 31)) return AESGCM_ETOOLONG;
     }
     if ((rc = rows_scratch(c, slots, n, st, &r))) return rc;

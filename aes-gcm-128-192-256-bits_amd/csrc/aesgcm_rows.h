@@ -4,18 +4,17 @@
 // src/gcm_gctr.vhd:142-144).  Until round 4 a message-sized packet of aesgcm_packets_crypt_dev went through the wave-per-packet group
 // kernel (two-table round, LDS full of tree tables: 4096 x 1 MiB 731 GiB/s against 980 for one message of the same bytes).  Here the rows
 // of ALL messages of a call are one pool of work for k_body's row loop (four T-tables, rounds 1 - 2 from per-strand lane constants and the
-// scalar cache, the five-bit table of H^256):
+// scalar cache, a five-bit GHASH table in LDS):
 //
 //   * a message of `len` bytes is R = len / 1024 whole rows of 64 blocks, aligned to its first block (every packet starts at counter 2,
 //     src/aes_icb.vhd:97-118, so every message IS an aligned body), plus a TAIL of tb <= 64 blocks (the last one ragged), plus its AAD;
-//   * its work is laid on an axis of UNITS: four STRANDS of Q = R / 4 units each (strand k = the rows 4 q + k, q < Q: one row phase, exactly what
-//     body_strand_lane runs with the Horner stride H^256), then the R mod 4 rows behind the last whole super-row (a unit each), then ONE unit for the
-//     tail -- its blocks and the length block as a right-aligned row; the lane that holds the length block encrypts counter 1 instead, which is
-//     E_K(J0) -- and, when the call has AAD, one for the AAD.  The axes of all messages, end to end, are the call: G units;
+//   * its work is laid on an axis of UNITS: a unit per row, in their order, then ONE unit for the tail -- its blocks and the length block as a right-aligned
+//     row; the lane that holds the length block encrypts counter 1 instead, which is E_K(J0) -- and, when the call has AAD, one for the AAD.  The axes of all
+//     messages, end to end, are the call: G units.  A RUN of consecutive rows is body_rows_lane's: k_body's row code with the lane constants of all four row
+//     phases in registers and one Horner accumulator of stride H^64, so a run of any length leaves ONE value behind;
 //   * the axis is cut into BLOCKS of D units.  A small or mid-size call is cut into exactly one block per wave of the launch (equal shares, no dispenser:
 //     the launch is as long as its rows and nothing waits for a last chunk); a large one into blocks of 64 units dealt from dispensers, as k_body deals
-//     its chunks.  Where a block's range meets the natural boundaries of a message it falls into PIECES -- a run of super-rows of one strand, a single
-//     row, a tail, an AAD -- and ANY run of a strand is a piece: the row loop takes (first super-row, count);
+//     its chunks.  Where a block's range meets the boundaries of a message it falls into PIECES: a run of rows, a tail, an AAD;
 //   * at the end of a piece the wave does not leave its 64 lane accumulators: lane L's value times H^(63 - L) through the key's per-lane Shoup tables
 //     (KeyMaterial::ltab), XORed over the wave, is the polynomial of the run up to its last block -- a 32-byte RECORD per piece: those 16 bytes, the
 //     message, and the exponent still due: H^(blocks behind the piece + 2), e = 64 (R - 1 - last row) + tb + 2 (AAD: 64 R + tb + 2; the tail, whose
@@ -78,10 +77,10 @@ HD RowsGeom rows_geom(u64 len) {
     g.tb = ((u32)(len & 1023u) + 15u) >> 4;
     return g;
 }
-HD u32 rows_units(const RowsGeom &g, u32 has_aad) { return 4u * g.Q + g.rho + 1u + (has_aad ? 1u : 0u); }
-// the natural segment of unit u of a message (strands 0 .. 3 when Q > 0, then a segment per single row, the tail, the AAD)
-HD u32 rows_nat(const RowsGeom &g, u32 u) { return u < 4u * g.Q ? u / g.Q : (g.Q ? 4u : 0u) + (u - 4u * g.Q); }
-HD u32 rows_nat_count(const RowsGeom &g, u32 has_aad) { return (g.Q ? 4u : 0u) + g.rho + 1u + (has_aad ? 1u : 0u); }
+HD u32 rows_units(const RowsGeom &g, u32 has_aad) { return g.R + 1u + (has_aad ? 1u : 0u); }
+// the natural segment of unit u of a message: its rows (when it has any), the tail, the AAD
+HD u32 rows_nat(const RowsGeom &g, u32 u) { return u < g.R ? 0u : (g.R ? 1u : 0u) + (u - g.R); }
+HD u32 rows_nat_count(const RowsGeom &g, u32 has_aad) { return (g.R ? 1u : 0u) + 1u + (has_aad ? 1u : 0u); }
 // record slots of a message whose units are [g0, g0 + U): a slot per (natural segment, block) pair it can have -- slot = base + nat + (block - first block)
 HD u32 rows_slots(const RowsGeom &g, u32 has_aad, u64 g0, u32 D) {
     const u32 U = rows_units(g, has_aad);
@@ -119,40 +118,36 @@ HD u64 rows_unit_base(const RowsParams &p, u32 m) { return p.prefix ? p.prefix[m
 HD u32 rows_slot_base(const RowsParams &p, u32 m) { return p.slot_base ? p.slot_base[m] : m * p.SM; }
 
 // ---- k_rows: one piece ---------------------------------------------------------------------------
-enum { ROWS_STRAND = 0, ROWS_TAIL = 1, ROWS_AAD = 2 };
-struct RowsPiece { u32 kind, k, q0, len, slot; u64 e; };                // strand: phase k, super-rows [q0, q0 + len); len = units taken
-// the piece that starts at unit u of the message (geometry g, first unit g0) and may take up to `room` units; D = units per block, gpos = g0 + u
-HD RowsPiece rows_piece(const RowsGeom &g, u32 has_aad, u32 slot_base, u64 g0, u32 u, u64 room, u32 D) {
+enum { ROWS_RUN = 0, ROWS_TAIL = 1, ROWS_AAD = 2 };
+struct RowsPiece { u32 kind, r0, len, slot; u64 e; };                   // run: rows [r0, r0 + len); len = units taken
+// the piece that starts at unit u of the message (geometry g, first unit g0) and may take up to `room` units; D = units per block
+HD RowsPiece rows_piece(const RowsGeom &g, u32 slot_base, u64 g0, u32 u, u64 room, u32 D) {
     RowsPiece pc;
     pc.slot = slot_base + rows_nat(g, u) + (u32)((g0 + u) / D - g0 / D);
-    pc.len = 1; pc.k = 0; pc.q0 = 0; pc.e = 0;
-    if (u < 4u * g.Q + g.rho) {
-        pc.kind = ROWS_STRAND;
-        if (u < 4u * g.Q) { pc.k = u / g.Q; pc.q0 = u - pc.k * g.Q; const u32 left = g.Q - pc.q0; pc.len = room < left ? (u32)room : left; }
-        else { pc.k = u - 4u * g.Q; pc.q0 = g.Q; }
-        const u32 r_last = 4u * (pc.q0 + pc.len - 1u) + pc.k;
-        pc.e = 64ull * (g.R - 1u - r_last) + g.tb + 2u;
-    } else if (u == 4u * g.Q + g.rho) {
+    pc.len = 1; pc.r0 = 0; pc.e = 0;
+    if (u < g.R) {
+        pc.kind = ROWS_RUN;
+        pc.r0 = u;
+        const u32 left = g.R - u;
+        pc.len = room < left ? (u32)room : left;
+        pc.e = 64ull * (g.R - (pc.r0 + pc.len)) + g.tb + 2u;              // blocks behind the run's last row, and H^2
+    } else if (u == g.R) {
         pc.kind = ROWS_TAIL;
     } else {
         pc.kind = ROWS_AAD;
         pc.e = 64ull * g.R + g.tb + 2u;
     }
-    (void)has_aad;
     return pc;
 }
-// lane `lane` of the wave that runs a strand piece: CTR over the rows 4 (q0 + i) + k, i < len, and the lane's Horner accumulator (stride H^256)
+// lane `lane` of the wave that runs a piece of rows: CTR over the rows r0 .. r0 + len - 1 and the lane's Horner accumulator (stride H^64)
 template <int NR, int MODE>
-HD uint4 rows_strand_lane(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const RowsParams &p, const RowsMsg &q, const RowsPiece &pc,
-                          const unsigned char *smem, const CtrConsts &cc, u32 lane, u32 prio_rows, u32 prio_slot) {
-    return body_strand_rows<NR, MODE>(km, tb, p.in + q.doff, p.out + q.doff, 0u, smem, cc, pc.q0, 1u, pc.len, pc.k, lane, make_uint4(0, 0, 0, 0), false, prio_rows, prio_slot);
+HD uint4 rows_run_lane(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const RowsParams &p, const RowsMsg &q, const RowsPiece &pc,
+                       const unsigned char *smem, const CtrConsts &cc, u32 lane, u32 prio_rows, u32 prio_slot) {
+    return body_rows_lane<NR, MODE>(km, tb, p.in + q.doff, p.out + q.doff, 0u, smem, cc, pc.r0, pc.len, lane, prio_rows, prio_slot);
 }
 // the lane's term of the run's polynomial: B_L H^(63 - L) (XOR over the wave = the polynomial of the run up to its last block)
-HD G128 rows_strand_term(const KeyMaterial *__restrict__ km, uint4 acc, u32 lane) { return shoup2_gmul_lds(mo_to_be(acc), km->ltab[63u - lane]); }
+HD G128 rows_run_term(const KeyMaterial *__restrict__ km, uint4 acc, u32 lane) { return shoup2_gmul_lds(mo_to_be(acc), km->ltab[63u - lane]); }
 
-// a further row of a tail or an AAD (a tail of a full 64 blocks; AAD beyond 1 KiB): the accumulator times H^64, bit-serially -- k_rows has the table of H^256 in LDS,
-// not of H^64, and these rows are rare
-HD uint4 rows_mul_h64(const KeyMaterial *__restrict__ km, uint4 acc) { return gf_mul_mo(acc, km->pw[0][64]); }
 // The tail blocks (data blocks 64 R ..., the last one ragged) and the length block [8 len(A)]_64 || [8 len(C)]_64 (gcm_ghash.vhd:257) as ONE right-aligned
 // sequence of tb + 1 <= 65 slots: one row, or two when the tail is a full 64 blocks.  Every lane runs the cipher once per row: data lanes on counter
 // 2 + block index (aes_icb.vhd:97-118), the lane of the length block on counter 1 -- E_K(IV || 0^31 1), the J0 block the RTL latches first
@@ -168,7 +163,7 @@ HD G128 rows_tail_lane(const KeyMaterial *__restrict__ km, const RowsParams &p, 
     uint4 acc = make_uint4(0, 0, 0, 0);
     *ej0 = make_uint4(0, 0, 0, 0);
     for (u32 k = 0; k < rows; k++) {
-        if (k) acc = rows_mul_h64(km, acc);
+        if (k) acc = ghash_mul_const_lds(acc, smem);
         const u32 slot = k * 64u + lane;
         if (slot < pad) continue;
         const u32 j = slot - pad;
@@ -196,12 +191,12 @@ HD G128 rows_tail_lane(const KeyMaterial *__restrict__ km, const RowsParams &p, 
 }
 // The AAD of a message as rows of its own (right-aligned, Horner with H^64: one row up to 1 KiB of AAD): the lane's term  A_L H^(63 - L)  of the AAD's polynomial.
 // alen = 0: zero.
-HD G128 rows_aad_lane(const KeyMaterial *__restrict__ km, const RowsParams &p, const RowsMsg &q, u32 lane) {
+HD G128 rows_aad_lane(const KeyMaterial *__restrict__ km, const RowsParams &p, const RowsMsg &q, const unsigned char *smem, u32 lane) {
     const u32 n_aad = (q.alen + 15u) >> 4, rows = (n_aad + 63u) >> 6, pad = 64u * rows - n_aad;
     const unsigned char *a = p.aad + q.aoff;
     uint4 acc = make_uint4(0, 0, 0, 0);
     for (u32 k = 0; k < rows; k++) {
-        if (k) acc = rows_mul_h64(km, acc);
+        if (k) acc = ghash_mul_const_lds(acc, smem);
         const u32 slot = k * 64u + lane;
         if (slot < pad) continue;
         const u32 off = 16u * (slot - pad), rem = q.alen - off;

@@ -797,7 +797,7 @@ static void test_keystream_and_ghash(u64 seed) {
 template <int NR>
 static void emu_rows_nr(const KeyMaterial *km, int dec, RowsParams &p, u32 waves, u32 force_d) {
     static unsigned char smem[AESGCM_LDS_BYTES_T4] __attribute__((aligned(16)));
-    for (u32 tid = 0; tid < AESGCM_MAIN_WG; tid++) main_fill_lds(smem, km, &g_tb, tid, true, AESGCM_MAIN_WG, GH_TAB_K256);
+    for (u32 tid = 0; tid < AESGCM_MAIN_WG; tid++) main_fill_lds(smem, km, &g_tb, tid, true, AESGCM_MAIN_WG, GH_TAB_K64);
     for (u32 tid = 0; tid < AESGCM_MAIN_WG; tid++) fill_lds_t4(smem, &g_tb, tid, AESGCM_MAIN_WG);
     const u32 n = p.n_pkts;
     p.has_aad = (p.aad_off || p.aad_len) ? 1u : 0u;
@@ -811,7 +811,7 @@ static void emu_rows_nr(const KeyMaterial *km, int dec, RowsParams &p, u32 waves
         hdr.G = prefix[n];
         rows_cut(hdr.G, waves, force_d, ROWS_NB_CAP, &hdr.D, &hdr.NB, &hdr.dyn);
         for (u32 m = 0; m < n; m++) slot_base[m + 1] = slot_base[m] + rows_slots(rows_geom(p.data_off[m + 1] - p.data_off[m]), p.has_aad, prefix[m], hdr.D);
-        slots = 11 * (size_t)n + ROWS_NB_CAP;
+        slots = 4 * (size_t)n + ROWS_NB_CAP;
         CHECK(slot_base[n] <= slots, "rows: %u slots planned, %zu held", slot_base[n], slots);
         p.hdr = &hdr; p.prefix = prefix.data(); p.slot_base = slot_base.data();
     } else {
@@ -843,17 +843,17 @@ static void emu_rows_nr(const KeyMaterial *km, int dec, RowsParams &p, u32 waves
             CHECK(g >= g0 && g < g0 + U, "rows: unit %llu outside message %u", (unsigned long long)g, m);
             u32 made = 0;
             while (g < g_end && g < g0 + U) {
-                const RowsPiece pc = rows_piece(geo, p.has_aad, sbase, g0, (u32)(g - g0), g_end - g, D);
+                const RowsPiece pc = rows_piece(geo, sbase, g0, (u32)(g - g0), g_end - g, D);
                 G128 z = {{0, 0, 0, 0}};
                 u32 flags = ROWS_REC_VALID | ROWS_REC_WEIGH;
                 uint4 e63 = make_uint4(0, 0, 0, 0);
                 for (u32 lane = 0; lane < 64; lane++) {
                     const CtrConsts cc = ctr_round1_consts(load_le32(p.ivs + 12 * m), load_le32(p.ivs + 12 * m + 4), load_le32(p.ivs + 12 * m + 8), km->rk, smem, (lane & 31u) << 2);
-                    if (pc.kind == ROWS_STRAND) {
-                        const uint4 a = dec ? rows_strand_lane<NR, MODE_DEC>(km, &g_tb, p, mq, pc, smem, cc, lane, 0, 0) : rows_strand_lane<NR, MODE_ENC>(km, &g_tb, p, mq, pc, smem, cc, lane, 0, 0);
-                        xor_g(z, rows_strand_term(km, a, lane));
+                    if (pc.kind == ROWS_RUN) {
+                        const uint4 a = dec ? rows_run_lane<NR, MODE_DEC>(km, &g_tb, p, mq, pc, smem, cc, lane, 0, 0) : rows_run_lane<NR, MODE_ENC>(km, &g_tb, p, mq, pc, smem, cc, lane, 0, 0);
+                        xor_g(z, rows_run_term(km, a, lane));
                     } else if (pc.kind == ROWS_AAD) {
-                        xor_g(z, rows_aad_lane(km, p, mq, lane));
+                        xor_g(z, rows_aad_lane(km, p, mq, smem, lane));
                     } else {
                         uint4 ej0;
                         xor_g(z, dec ? rows_tail_lane<NR, 1>(km, p, mq, smem, cc, lane, &ej0) : rows_tail_lane<NR, 0>(km, p, mq, smem, cc, lane, &ej0));
