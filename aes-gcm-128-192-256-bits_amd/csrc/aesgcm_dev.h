@@ -1223,11 +1223,18 @@ HD uint4 body_rows_lane(const KeyMaterial *__restrict__ km, const DevTables *__r
                         const unsigned char *smem, const CtrConsts &cc, u32 r0, u32 n, u32 lane, u32 prio_rows = 0, u32 prio_slot = 0) {
     const u32 *__restrict__ rk0 = km->rk;
     const u32 lb = (lane & 31u) << 2, lane16 = lane * 16u;
-    const BodyLane b0 = body_lane_consts(rk0, cc, smem, 0u, lane), b1 = body_lane_consts(rk0, cc, smem, 1u, lane);
-    const BodyLane b2 = body_lane_consts(rk0, cc, smem, 2u, lane), b3 = body_lane_consts(rk0, cc, smem, 3u, lane);
+#ifndef AESGCM_ROWS_HOLD_PHASES
+#define AESGCM_ROWS_HOLD_PHASES(NR) ((NR) != 14)                        /* AES-256 keeps 32 round-key words in vector registers: with sixteen more for the phases its row loop spilled (12 scratch accesses per row); it computes the row's lane constants per row instead (five lookups) */
+#endif
+    constexpr bool HOLD = AESGCM_ROWS_HOLD_PHASES(NR);
+    BodyLane b0 = {0, 0, 0, 0}, b1 = b0, b2 = b0, b3 = b0;
+    if (HOLD) { b0 = body_lane_consts(rk0, cc, smem, 0u, lane); b1 = body_lane_consts(rk0, cc, smem, 1u, lane); b2 = body_lane_consts(rk0, cc, smem, 2u, lane); b3 = body_lane_consts(rk0, cc, smem, 3u, lane); }
+#ifndef AESGCM_ROWS_RKV_FROM
+#define AESGCM_ROWS_RKV_FROM(NR) ((NR) == 14 ? 36 : 4 * ((NR) + 1))
+#endif
     u32 rk[4 * (NR + 1)];                                              // the keys of the late rounds in vector registers: see body_strand_rows
 #pragma unroll
-    for (int w = 0; w < 4 * (NR + 1); w++) rk[w] = (w >= (T4 ? AESGCM_BODY_RKV_FROM(NR) : AESGCM_BODY_RKV_FROM_HALF(NR))) ? pin_vgpr(rk0[w]) : rk0[w];
+    for (int w = 0; w < 4 * (NR + 1); w++) rk[w] = (w >= AESGCM_ROWS_RKV_FROM(NR)) ? pin_vgpr(rk0[w]) : rk0[w];
     uint4 acc = make_uint4(0, 0, 0, 0);
     for (u32 i = 0; i < n; ++i) {
         const u32 r = r0 + i, v = r & 3u, q = r >> 2;                  // wave-uniform
@@ -1239,8 +1246,10 @@ HD uint4 body_rows_lane(const KeyMaterial *__restrict__ km, const DevTables *__r
         const uint4 x = (MODE == MODE_PROBE) ? make_uint4(lane, q, v, 0u) : gload16(src + lane16);
         const bool hi = (v & 2u) != 0, odd = (v & 1u) != 0;
         BodyLane b;
-        b.p0 = hi ? (odd ? b3.p0 : b2.p0) : (odd ? b1.p0 : b0.p0); b.p1 = hi ? (odd ? b3.p1 : b2.p1) : (odd ? b1.p1 : b0.p1);
-        b.p2 = hi ? (odd ? b3.p2 : b2.p2) : (odd ? b1.p2 : b0.p2); b.p3 = hi ? (odd ? b3.p3 : b2.p3) : (odd ? b1.p3 : b0.p3);
+        if (HOLD) {
+            b.p0 = hi ? (odd ? b3.p0 : b2.p0) : (odd ? b1.p0 : b0.p0); b.p1 = hi ? (odd ? b3.p1 : b2.p1) : (odd ? b1.p1 : b0.p1);
+            b.p2 = hi ? (odd ? b3.p2 : b2.p2) : (odd ? b1.p2 : b0.p2); b.p3 = hi ? (odd ? b3.p3 : b2.p3) : (odd ? b1.p3 : b0.p3);
+        } else b = body_lane_consts(rk0, cc, smem, v, lane);
         u32 s0, s1, s2, s3;
         body_state(s0, s1, s2, s3, b, ctr_hi0 + q, v, lane, cc, rk, tb);
         body_rounds<NR, T4>(s0, s1, s2, s3, rk, smem, lb);

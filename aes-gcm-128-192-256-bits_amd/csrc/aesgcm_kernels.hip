@@ -1233,29 +1233,32 @@ __global__ __launch_bounds__(AESGCM_BODY_WG, AESGCM_BODY_WPS) void k_rows(const 
             if (g >= g0 + rows_units(geo, p.has_aad)) { ++m; continue; }     // the next message (every message has at least its tail unit)
             const RowsPiece pc = rows_piece(geo, uniform32(rows_slot_base(p, m)), g0, (u32)(g - g0), g_end - g, D);
             RowsRec *rr = p.rec + pc.slot;
-            if (lane == 0) {
+            if (lane_id_fresh() == 0) {
                 rr->e = pc.e; rr->msg = m; rr->flags = pc.kind == ROWS_TAIL ? ROWS_REC_VALID : (ROWS_REC_VALID | ROWS_REC_WEIGH);    // (the tail is weighted already: lane terms H^(64 - L))
                 atomicAdd(p.npieces + m, 1u);                                 // what k_rows_close waits for
             }
+            // every kind of piece takes the lane's index FRESH (lane_id_fresh: opaque to the compiler), so that nothing lane-dependent of the tail and AAD code -- table
+            // addresses, byte masks -- is hoisted out of the piece loop and kept in registers across the row loop (first build: 26 scratch accesses per row)
             G128 z;
             if (pc.kind == ROWS_AAD) {
-                z = wave_xor(rows_aad_lane(km, p, mq, smem, lane));
+                z = wave_xor(rows_aad_lane(km, p, mq, smem, lane_id_fresh()));
             } else {
                 const unsigned char *ivp = p.ivs + (size_t)m * 12;
-                CtrConsts cc = ctr_round1_consts(uniform32(load_le32(ivp)), uniform32(load_le32(ivp + 4)), uniform32(load_le32(ivp + 8)), km->rk, smem, (lane & 31u) << 2);   // key and IV only: wave-uniform
+                CtrConsts cc = ctr_round1_consts(uniform32(load_le32(ivp)), uniform32(load_le32(ivp + 4)), uniform32(load_le32(ivp + 8)), km->rk, smem, (lane_id_fresh() & 31u) << 2);   // key and IV only: wave-uniform
                 cc.c0 = __builtin_amdgcn_readfirstlane(cc.c0); cc.c1 = __builtin_amdgcn_readfirstlane(cc.c1);
                 cc.c2 = __builtin_amdgcn_readfirstlane(cc.c2); cc.c3 = __builtin_amdgcn_readfirstlane(cc.c3);
                 if (pc.kind == ROWS_RUN) {
-                    z = wave_xor(rows_run_term(km, rows_run_lane<NR, MODE>(km, tb, p, mq, pc, smem, cc, lane, dyn ? 0u : p.prio_rows, (tid >> 8) & 3u), lane));
+                    const uint4 acc = rows_run_lane<NR, MODE>(km, tb, p, mq, pc, smem, cc, lane_id_fresh(), dyn ? 0u : p.prio_rows, (tid >> 8) & 3u);
+                    z = wave_xor(rows_run_term(km, acc, lane_id_fresh()));
                 } else {
                     uint4 ej0;
-                    z = wave_xor(rows_tail_lane<NR, MODE == MODE_DEC>(km, p, mq, smem, cc, lane, &ej0));
+                    z = wave_xor(rows_tail_lane<NR, MODE == MODE_DEC>(km, p, mq, smem, cc, lane_id_fresh(), &ej0));
                     const G128 e = mo_to_be(make_uint4((u32)__builtin_amdgcn_readlane((int)ej0.x, 63), (u32)__builtin_amdgcn_readlane((int)ej0.y, 63),
                                                        (u32)__builtin_amdgcn_readlane((int)ej0.z, 63), (u32)__builtin_amdgcn_readlane((int)ej0.w, 63)));
                     z.w[0] ^= e.w[0]; z.w[1] ^= e.w[1]; z.w[2] ^= e.w[2]; z.w[3] ^= e.w[3];
                 }
             }
-            if (lane == 0) rr->w = z;
+            if (lane_id_fresh() == 0) rr->w = z;
             g += pc.len;
         }
     }
