@@ -22,6 +22,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("kind", choices=("batch", "pkt", "pktw", "pktg", "pktg8", "pktg4", "pktl", "rows", "norows"))
 ap.add_argument("--var", action="store_true", help="one key: the same packets through offset arrays (pkt_len then is the caller's hint)")
 ap.add_argument("--aad", type=int, default=0, help="one key: bytes of AAD per packet")
+ap.add_argument("--opt", action="append", default=[], help="context option key=value (aesgcm_ctx_set_option), repeatable")
 ap.add_argument("--rows-block", type=int, default=0, help="context option rows_block (units per dealt block of k_rows; 0 = the library's cut)")
 ap.add_argument("--n", type=int, default=1 << 20)
 ap.add_argument("--len", type=int, default=4096)
@@ -56,6 +57,8 @@ else:
     ctx = lib.Context(bytes(range(kb)))
     if a.rows_block:
         ctx.set_option("rows_block", a.rows_block)
+    for kv in a.opt:
+        ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     d_off = d_aoff = d_aad = None
     if a.var:
         import struct
