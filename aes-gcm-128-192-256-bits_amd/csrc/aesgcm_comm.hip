@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>      // types and prototypes only: nothing here links against librccl
 
+#include <algorithm>
 #include <mutex>
 #include <new>
 #include <stdio.h>
@@ -83,13 +84,20 @@ struct aesgcm_comm {
     double *d_scalar = nullptr;        // 2 doubles of device scratch
 };
 
+#define MGPU_RING 8                     /* messages that may be queued (tag = NULL) before their tags are collected */
 struct aesgcm_mgpu {
     int ndev = 0;
     std::vector<int> dev;
     std::vector<aesgcm_ctx *> ctx;
     std::vector<ncclComm_t> comm;
     std::vector<hipStream_t> st;
-    std::vector<unsigned char *> part, all;    // per device: own 16-byte partial, ndev gathered partials
+    std::vector<unsigned char *> part, all;    // per device: own 16-byte partial, ndev gathered partials.  all[0] is a ring of MGPU_RING such rows: a queued message's row waits there for its finalize
+    // the queued messages, oldest first: what their finalize needs
+    unsigned long long seq = 0;                 // messages queued so far
+    int pending = 0;
+    uint8_t iv[MGPU_RING][12];
+    size_t aad_len[MGPU_RING];
+    uint64_t total[MGPU_RING];
 };
 
 extern "C" {
@@ -189,7 +197,7 @@ int aesgcm_mgpu_create(aesgcm_mgpu **out, int ndev, const int *devices, const ui
         hipError_t e = hipSetDevice(devices[g]);
         if (e == hipSuccess) e = hipStreamCreate(&m->st[g]);     // a blocking stream, as a context's own: ordered behind work the caller left on the NULL stream
         if (e == hipSuccess) e = hipMalloc(&m->part[g], 16);
-        if (e == hipSuccess) e = hipMalloc(&m->all[g], (size_t)16 * ndev);
+        if (e == hipSuccess) e = hipMalloc(&m->all[g], (size_t)16 * ndev * (g == 0 ? MGPU_RING : 1));
         if (e != hipSuccess) { aesgcm_mgpu_destroy(m); return hip_fail(e, "mgpu buffers"); }
     }
     ncclResult_t e = r->CommInitAll(m->comm.data(), ndev, devices);
@@ -213,9 +221,35 @@ int aesgcm_mgpu_ctx(aesgcm_mgpu *m, int g, aesgcm_ctx **out) {
     return AESGCM_OK;
 }
 
+// the tags of the last n queued messages (oldest of them first), finalized in one launch per contiguous run of ring rows (aesgcm_shard_finalize_batch_dev) on device 0
+int aesgcm_mgpu_last_tags(aesgcm_mgpu *m, size_t n, uint8_t *tags) {
+    if (!m || !tags || n > (size_t)m->pending) return AESGCM_EARG;
+    if (!n) return AESGCM_OK;
+    HCHK(hipSetDevice(m->dev[0]));
+    const unsigned long long first = m->seq - n;
+    size_t done = 0;
+    while (done < n) {
+        const size_t slot = (size_t)((first + done) % MGPU_RING);
+        const size_t run = std::min(n - done, (size_t)MGPU_RING - slot);
+        uint8_t ivs[MGPU_RING * 12];
+        size_t al[MGPU_RING];
+        uint64_t tl[MGPU_RING];
+        for (size_t k = 0; k < run; k++) { memcpy(ivs + 12 * k, m->iv[slot + k], 12); al[k] = m->aad_len[slot + k]; tl[k] = m->total[slot + k]; }
+        const int rc = aesgcm_shard_finalize_batch_dev(m->ctx[0], run, ivs, m->all[0] + slot * 16 * (size_t)m->ndev, (size_t)m->ndev, 16, (size_t)16 * m->ndev, al, tl, tags + 16 * done, m->st[0]);
+        if (rc) return rc;
+        done += run;
+    }
+    m->pending -= (int)n;
+    return AESGCM_OK;
+}
+
+// tag != NULL: the message's tag, all streams synchronised on return.  tag == NULL: the call only enqueues -- every device's shard, the one grouped all-gather -- and
+// the message waits in a ring of MGPU_RING rows on device 0 for aesgcm_mgpu_last_tags; no host synchronisation anywhere (what a caller that keeps several messages
+// in flight wants: bench.py --single-process queues its four)
 int aesgcm_mgpu_crypt_dev(aesgcm_mgpu *m, int decrypt, const uint8_t iv[12], const void *d_aad_on_dev0, size_t aad_len,
                           const void *const *d_in, const size_t *shard_len, void *const *d_out, uint8_t tag[16]) {
     if (!m || !iv || !d_in || !shard_len || !d_out || (aad_len && !d_aad_on_dev0)) return AESGCM_EARG;
+    if (m->pending >= MGPU_RING) { snprintf(g_cerr, sizeof g_cerr, "%d messages queued: collect their tags first (aesgcm_mgpu_last_tags)", m->pending); return AESGCM_ESTATE; }
     uint64_t total = 0;
     for (int g = 0; g < m->ndev; g++) {
         if (g + 1 < m->ndev && (shard_len[g] & 15)) return AESGCM_EARG;      // shards are cut at 16-byte block boundaries; only the last may be ragged
@@ -229,19 +263,27 @@ int aesgcm_mgpu_crypt_dev(aesgcm_mgpu *m, int decrypt, const uint8_t iv[12], con
         if (rc) return rc;
         first += shard_len[g] / 16;
     }
+    const size_t slot = (size_t)(m->seq % MGPU_RING);
     // the ONE exchange of the path: 16 bytes per device
     NCHK(g_rccl.GroupStart());
     for (int g = 0; g < m->ndev; g++) {
         HCHK(hipSetDevice(m->dev[g]));
-        ncclResult_t e = g_rccl.AllGather(m->part[g], m->all[g], 16, ncclUint8, m->comm[g], m->st[g]);
+        ncclResult_t e = g_rccl.AllGather(m->part[g], g == 0 ? m->all[0] + slot * 16 * (size_t)m->ndev : m->all[g], 16, ncclUint8, m->comm[g], m->st[g]);
         if (e != ncclSuccess) { g_rccl.GroupEnd(); return nccl_fail(e, "ncclAllGather"); }
     }
     NCHK(g_rccl.GroupEnd());
+    memcpy(m->iv[slot], iv, 12); m->aad_len[slot] = aad_len; m->total[slot] = total;
+    ++m->seq; ++m->pending;
+    if (!tag) return AESGCM_OK;
+    if ((rc = aesgcm_mgpu_last_tags(m, 1, tag))) return rc;                   // waits for stream 0
     for (int g = 1; g < m->ndev; g++) { HCHK(hipSetDevice(m->dev[g])); HCHK(hipStreamSynchronize(m->st[g])); }
     HCHK(hipSetDevice(m->dev[0]));
-    uint8_t t[16];
-    if ((rc = aesgcm_shard_finalize_dev(m->ctx[0], iv, m->all[0], (size_t)m->ndev, aad_len, total, t, m->st[0]))) return rc;   // syncs stream 0
-    if (tag) memcpy(tag, t, 16);
+    return AESGCM_OK;
+}
+// every stream of the object drained: what a caller of the queued form does before it reads the outputs on the host side
+int aesgcm_mgpu_sync(aesgcm_mgpu *m) {
+    if (!m) return AESGCM_EARG;
+    for (int g = 0; g < m->ndev; g++) { HCHK(hipSetDevice(m->dev[g])); HCHK(hipStreamSynchronize(m->st[g])); }
     return AESGCM_OK;
 }
 

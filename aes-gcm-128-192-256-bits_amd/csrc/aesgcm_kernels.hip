@@ -1346,6 +1346,20 @@ __global__ __launch_bounds__(1024) void k_rows_plan(const u64 *__restrict__ off,
     }
 }
 
+// k_wipe_failed: a wave per packet; packets whose auth[] says 0 get their output bytes zeroed (context option "wipe_on_auth_fail", aesgcm_wipe_failed_dev)
+__global__ __launch_bounds__(256) void k_wipe_failed(unsigned char *out, const int *auth, const u64 *data_off, u32 n_pkts, u32 pkt_len) {
+    const u32 pkt = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (pkt >= n_pkts || auth[pkt]) return;
+    const u64 lo = data_off ? data_off[pkt] : (u64)pkt * pkt_len, hi = data_off ? data_off[pkt + 1] : lo + pkt_len;
+    unsigned char *p = out + lo;
+    const u64 len = hi - lo, head = len < 16 ? len : ((16u - ((uintptr_t)p & 15u)) & 15u);
+    if (lane < head) p[lane] = 0;
+    const u64 nvec = (len - head) / 16;
+    for (u64 i = lane; i < nvec; i += 64) gstore16(p + head + 16 * i, make_uint4(0, 0, 0, 0));
+    const u64 done = head + 16 * nvec;
+    if (done + lane < len) p[done + lane] = 0;
+}
+
 // ================================================================================================
 // host side
 // ================================================================================================
@@ -1438,6 +1452,8 @@ struct aesgcm_ctx {
     uint4 *h_mtag = nullptr, *h_mtag_dev = nullptr;   // COMBINE_BATCH_MAX slots of {tag, generation} in pinned host memory (batched finalize); created on first use
     uint4 *d_mtag = nullptr;
     uint4 *d_tag = nullptr;            // [0] tag / poly result, [1] streaming state Y
+    int last_shape = AESGCM_LAUNCH_NONE;   // which launch structure the context's last whole-message call took (aesgcm_ctx_last_launch)
+    bool wipe_on_auth_fail = false;    // option "wipe_on_auth_fail": decrypt calls that verify a tag zero the output of what fails (the reference's model returns the plaintext and raises: default off)
     u64 *d_trace = nullptr;            // per-workgroup trace of the last k_main launch (timing mode only)
     u32 last_np = 0;
     uint8_t *d_keystage = nullptr;     // 256 bytes: where a key (or schedule) waits for k_setup; zeroed behind it
@@ -1475,6 +1491,11 @@ struct aesgcm_ctx {
 };
 
 static void pipeline_release(aesgcm_ctx *c);
+// the generation number of the context's host slot: written by the thread that launches, read by other contexts' launches (others_in_flight) -- atomics both ways;
+// a launch that fails after taking a number gives it back, so that no context is ever taken for "under way" on account of a launch that never ran
+static inline u64 gen_take(aesgcm_ctx *c) { return __atomic_add_fetch(&c->tag_gen, 1, __ATOMIC_RELAXED); }
+static inline void gen_give_back(aesgcm_ctx *c) { __atomic_sub_fetch(&c->tag_gen, 1, __ATOMIC_RELAXED); }
+static inline u64 gen_now(const aesgcm_ctx *c) { return __atomic_load_n(&c->tag_gen, __ATOMIC_RELAXED); }
 static inline hipStream_t pick_stream(aesgcm_ctx *c, void *s) { return s ? (hipStream_t)s : c->stream; }
 
 static const u64 MAX_DATA = (((u64)1) << 36) - 32;      // aes_icb.vhd:114
@@ -1621,7 +1642,7 @@ static int enqueue_main(aesgcm_ctx *c, int mode, const uint8_t iv[12], const voi
     p.counter = c->d_counter + 16 * (1 + AESGCM_NQ * c->qset);
     p.counter_zero = c->d_counter + 16 * (1 + AESGCM_NQ * (c->qset ^ 1u));
     if (gh && po) { p.ej0 = c->d_tag + 3; po->ej0 = p.ej0; }
-    if (gh && po && want_tail && C == 1) { p.tail = 1; p.tag_out = c->d_tag; p.tag_host = c->h_tag_dev; p.gen = ++c->tag_gen; po->done = true; }
+    if (gh && po && want_tail && C == 1) { p.tail = 1; p.tag_out = c->d_tag; p.tag_host = c->h_tag_dev; p.gen = gen_take(c); po->done = true; }
     p.trace = nullptr;
     const bool timed = c->timing && !c->timing_mute;
     if (timed) {
@@ -1639,6 +1660,7 @@ static int enqueue_main(aesgcm_ctx *c, int mode, const uint8_t iv[12], const voi
         const hipError_t le = launch_main(mode, c->nr, dim3(wgs), st, c->km, c->tables, p);
         if (le != hipSuccess) {                      // nothing ran: the queues were not touched on the device
             if (timed) c->ev_pool.push_back(evp);
+            if (p.tail) gen_give_back(c);
             return hip_fail(le, "k_main launch");
         }
         if (p.nq) c->qset ^= 1u;                      // the launch leaves the other set zeroed for the next dynamic one
@@ -1762,9 +1784,12 @@ static int enqueue_cyc(aesgcm_ctx *c, int mode, const uint8_t iv[12], const void
     p.prio_rows = c->cyc_prio;
     if (fused) {                                                                // the launch closes the tag itself (cyc_close): nothing behind it
         p.fuse = 1; p.aad_len = aad_len; p.ct_len = len; p.acc = c->d_cyc;
-        p.tag_out = c->d_tag; p.tag_host = c->h_tag_dev; p.gen = ++c->tag_gen;
+        p.tag_out = c->d_tag; p.tag_host = c->h_tag_dev; p.gen = gen_take(c);
         po->done = true;
-        return launch_body(c, mode, p, half ? BODY_CYC_WAVES_HALF / (AESGCM_BODYH_WG / 64) : BODY_CYC_WAVES / (AESGCM_BODY_WG / 64), st);
+        c->last_shape = half ? AESGCM_LAUNCH_CYCLIC_HALF : AESGCM_LAUNCH_CYCLIC;
+        rc = launch_body(c, mode, p, half ? BODY_CYC_WAVES_HALF / (AESGCM_BODYH_WG / 64) : BODY_CYC_WAVES / (AESGCM_BODY_WG / 64), st);
+        if (rc) gen_give_back(c);
+        return rc;
     }
     p.ej0 = c->d_tag + 3; po->ej0 = p.ej0;
     if ((rc = launch_body(c, mode, p, BODY_CYC_WAVES / (AESGCM_BODY_WG / 64), st))) return rc;
@@ -1820,15 +1845,17 @@ static int absorb_range(aesgcm_ctx *c, int mode, const uint8_t iv[12], const voi
 
 static int enqueue_combine(aesgcm_ctx *c, const CombineParams &p0, hipStream_t st) {
     CombineParams p = p0;
-    if (p.out == c->d_tag) { p.out_host = c->h_tag_dev; p.gen = ++c->tag_gen; }   // results that go to the tag slot are mirrored to the pinned host slot
+    const bool to_slot = p.out == c->d_tag;
+    if (to_slot) { p.out_host = c->h_tag_dev; p.gen = gen_take(c); }          // results that go to the tag slot are mirrored to the pinned host slot
     if (p.kind == PARTS_ITEM && p.np > 1) {                       // the launch folds the items itself: tables of H^eA, H^(8 eA)
         p.tabA = ptab_ptr(c, p.eA);
         p.tabB = p.np > 4 ? ptab_ptr(c, 4 * p.eA) : nullptr;
         p.tabC = p.np > 16 ? ptab_ptr(c, 16 * p.eA) : nullptr;
-        if (p.np > COMBINE_MAX_ITEMS || !p.tabA || (p.np > 4 && !p.tabB) || (p.np > 16 && !p.tabC)) { snprintf(g_err, sizeof g_err, "k_combine: %u items, spacing %llu not foldable in the launch", p.np, (unsigned long long)p.eA); return AESGCM_EHIP; }
+        if (p.np > COMBINE_MAX_ITEMS || !p.tabA || (p.np > 4 && !p.tabB) || (p.np > 16 && !p.tabC)) { if (to_slot) gen_give_back(c); snprintf(g_err, sizeof g_err, "k_combine: %u items, spacing %llu not foldable in the launch", p.np, (unsigned long long)p.eA); return AESGCM_EHIP; }
     }
     hipLaunchKernelGGL(k_combine, dim3(1), dim3(COMBINE_THREADS), CMB_LDS_BYTES, st, c->km, c->tables, p);
-    HIPCHK(hipGetLastError());
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess) { if (to_slot) gen_give_back(c); return hip_fail(le, "k_combine launch"); }
     return AESGCM_OK;
 }
 
@@ -1852,6 +1879,7 @@ static int crypt_dev(aesgcm_ctx *c, int dec, const uint8_t iv[12], const void *d
         if ((rc = enqueue_cyc(c, dec ? MODE_DEC : MODE_ENC, iv, d_aad, aad_len, d_in, len, d_out, 0, st, &pc, &took, true))) return rc;
         if (took && pc.done) return AESGCM_OK;                   // the launch left the tag in d_tag and in the host slot
         if (took) {
+            c->last_shape = AESGCM_LAUNCH_CYCLIC;
             CombineParams q = combine_with_items(plan_combine_tag(pc.ptr, pc.np, pc.kind, iv, aad_len, len, c->d_tag), pc.eA, pc.tail_item, pc.tail_blocks);
             q.ej0 = pc.ej0;
             return enqueue_combine(c, q, st);
@@ -1859,6 +1887,7 @@ static int crypt_dev(aesgcm_ctx *c, int dec, const uint8_t iv[12], const void *d
     }
     BodySplit b;
     if (ctx_body_split(c, len, 0, &b)) {
+        c->last_shape = AESGCM_LAUNCH_DEALT;
         if (!aad_len && !b.head_blocks && len == 16 * b.body_blocks) {
             // the whole message is one aligned body (the benchmark's shape): no chaining value to carry, k_body's items go
             // straight to the tag
@@ -1866,10 +1895,10 @@ static int crypt_dev(aesgcm_ctx *c, int dec, const uint8_t iv[12], const void *d
             FoldClose fc = {};
             if (c->fold_close) {                                 // k_fold's first level closes the tag (when there is a k_fold launch at all)
                 fc.aad_len = 0; fc.ct_len = len; fc.ej0 = c->d_tag + 3; fc.acc = c->d_cyc;
-                fc.tag_out = c->d_tag; fc.tag_host = c->h_tag_dev; fc.gen = c->tag_gen + 1;
+                fc.tag_out = c->d_tag; fc.tag_host = c->h_tag_dev; fc.gen = gen_now(c) + 1;
             }
             if ((rc = enqueue_body(c, dec ? MODE_DEC : MODE_ENC, iv, b, d_in, d_out, 0, st, &pb, c->fold_close ? &fc : nullptr))) return rc;
-            if (pb.done) { ++c->tag_gen; return AESGCM_OK; }
+            if (pb.done) { gen_take(c); return AESGCM_OK; }
             CombineParams q = combine_with_items(plan_combine_tag(pb.ptr, pb.np, pb.kind, iv, 0, len, c->d_tag), pb.eA);
             q.ej0 = pb.ej0;
             return enqueue_combine(c, q, st);
@@ -1884,6 +1913,7 @@ static int crypt_dev(aesgcm_ctx *c, int dec, const uint8_t iv[12], const void *d
         return enqueue_combine(c, q, st);
     }
     Partials pp;
+    c->last_shape = AESGCM_LAUNCH_MAIN;
     rc = enqueue_main(c, dec ? MODE_DEC : MODE_ENC, iv, d_aad, aad_len, d_in, len, d_out, 0, st, &pp, true);
     if (rc) return rc;
     if (pp.done) return AESGCM_OK;                               // single chunk: k_main's tail left the tag in d_tag and in the host slot
@@ -1903,7 +1933,7 @@ static int crypt_dev(aesgcm_ctx *c, int dec, const uint8_t iv[12], const void *d
 // retires a few microseconds later.  examples/early_read.cpp (tests/test_gpu_cyclic.py) is the standing check: a copy ordered behind nothing reads the whole
 // result the moment the tag is there.  Tags that come from k_combine or k_main's tail are published by the last kernel of the call.
 static int fetch_tag(aesgcm_ctx *c, hipStream_t st, uint8_t tag[16]) {
-    const u64 want = c->tag_gen;
+    const u64 want = gen_now(c);
     volatile u64 *gen = reinterpret_cast<volatile u64 *>(c->h_tag + 1);
     bool seen = false;
     struct timespec t0, t1;
@@ -1918,7 +1948,14 @@ static int fetch_tag(aesgcm_ctx *c, hipStream_t st, uint8_t tag[16]) {
         __builtin_ia32_pause();
 #endif
     }
-    if (!seen) HIPCHK(hipStreamSynchronize(st));
+    if (!seen) {
+        HIPCHK(hipStreamSynchronize(st));
+        // the stream the message was enqueued on has drained: its tag is there -- unless `st` is not that stream, or the launch failed after the number was taken
+        if (__atomic_load_n(gen, __ATOMIC_ACQUIRE) != want) {
+            snprintf(g_err, sizeof g_err, "the host slot shows generation %llu, not %llu: the stream passed is not the one the message was enqueued on", (unsigned long long)__atomic_load_n(gen, __ATOMIC_ACQUIRE), (unsigned long long)want);
+            return AESGCM_ESTATE;
+        }
+    }
     memcpy(tag, c->h_tag, 16);
     return AESGCM_OK;
 }
@@ -1981,7 +2018,6 @@ static int ctx_load_key(aesgcm_ctx *c, const uint8_t *key, size_t key_len, int p
     hipError_t e;
     if (!c->d_keystage && (e = hipMalloc((void **)&c->d_keystage, 256)) != hipSuccess) return hip_fail(e, "hipMalloc");
     const size_t kb = pre_nr ? (size_t)16 * (pre_nr + 1) : key_len;
-    c->nr = pre_nr ? pre_nr : (int)(key_len / 4 + 6);
     e = hipMemcpyAsync(c->d_keystage, key, kb, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_setup, dim3(1), dim3(AESGCM_WG), 0, c->stream, c->km, c->tables, c->d_keystage, (int)key_len, pre_nr, (u32)c->G);
@@ -1991,6 +2027,7 @@ static int ctx_load_key(aesgcm_ctx *c, const uint8_t *key, size_t key_len, int p
     if (e == hipSuccess) e = hipMemsetAsync(c->d_keystage, 0, 256, c->stream);    // do not leave key bytes behind
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) return hip_fail(e, "k_setup");
+    c->nr = pre_nr ? pre_nr : (int)(key_len / 4 + 6);                               // only now: a load that failed leaves the context's round count with its old key material
     return AESGCM_OK;
 }
 static int ctx_create_common(aesgcm_ctx **out, int device, const uint8_t *key, size_t key_len, int pre_nr) {
@@ -2051,7 +2088,9 @@ int aesgcm_ctx_rekey(aesgcm_ctx *c, const uint8_t *key, size_t key_len) {
     if (key_len != 16 && key_len != 24 && key_len != 32) return AESGCM_EKEYLEN;
     if (c->s_active) return AESGCM_ESTATE;
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    // every *_dev entry point takes a caller's stream, so work that reads this context's key material may be queued on any stream of the device: wait for them all
+    // (round 4 waited for the context's own stream only -- a message in flight on another stream would have read half-rebuilt tables)
+    HIPCHK(hipDeviceSynchronize());
     return ctx_load_key(c, key, key_len, 0);
 }
 int aesgcm_ctx_destroy(aesgcm_ctx *c) {
@@ -2090,6 +2129,13 @@ int aesgcm_ctx_destroy(aesgcm_ctx *c) {
     return AESGCM_OK;
 }
 int aesgcm_ctx_device(const aesgcm_ctx *c) { return c ? c->device : AESGCM_EARG; }
+// which launch structure the context's last whole-message call took (AESGCM_LAUNCH_*): the choice between the full and the half shape of the cyclic rows depends on
+// what other contexts had under way at the moment of the call, so benches and profiles ask instead of assuming
+int aesgcm_ctx_last_launch(const aesgcm_ctx *c, int *shape) {
+    if (!c || !shape) return AESGCM_EARG;
+    *shape = c->last_shape;
+    return AESGCM_OK;
+}
 // Tunables of ONE context, for tests and profiling scripts (the defaults are the measured best; nothing in the library reads the environment).
 // Every value selects between paths that produce the same bytes; the parity tests use them to reach each path at sizes a CPU check finishes in seconds.
 int aesgcm_ctx_set_option(aesgcm_ctx *c, const char *key, int64_t value) {
@@ -2107,6 +2153,7 @@ int aesgcm_ctx_set_option(aesgcm_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "fold_close")) c->fold_close = v != 0;                       // 1: behind the dealt k_body the first (or second) k_fold level closes the tag
     else if (!strcmp(key, "cyc_prio")) c->cyc_prio = (u32)v;                           // rows between rotations of the waves' issue priorities in a cyclic launch (0 = off)
     else if (!strcmp(key, "pkt_order")) c->order_min = (size_t)v;                      // packets from which a launch over packets of mixed length takes them by falling length class (k_len_*); 0 = never
+    else if (!strcmp(key, "wipe_on_auth_fail")) c->wipe_on_auth_fail = v != 0;         // decrypt with verification: zero the output of a message / packet whose tag does not match
     else if (!strcmp(key, "rows_min")) c->rows_min = v;                                // bytes per packet from which aesgcm_packets_crypt_dev goes by rows (k_rows); 0 = never
     else if (!strcmp(key, "rows_block")) c->rows_block = (u32)v;                       // units (rows, tails) per dealt block of k_rows; 0 = the library's cut
     else if (!strcmp(key, "poll_us")) c->poll_ns = 1000L * (long)v;                    // how long a tag is polled for in the host slot before the call blocks in the runtime
@@ -2256,7 +2303,10 @@ int aesgcm_decrypt_dev(aesgcm_ctx *c, const uint8_t iv[12], const void *d_aad, s
         uint8_t t[16];
         if ((rc = fetch_tag(c, st, t))) return rc;
         if (tag_out) memcpy(tag_out, t, 16);
-        if (expect_tag && !ct_compare16(t, expect_tag)) return AESGCM_EAUTH;
+        if (expect_tag && !ct_compare16(t, expect_tag)) {
+            if (c->wipe_on_auth_fail && len) { HIPCHK(hipMemsetAsync(d_pt, 0, len, st)); HIPCHK(hipStreamSynchronize(st)); }   // nothing unauthenticated is left in the caller's buffer
+            return AESGCM_EAUTH;
+        }
     }
     return AESGCM_OK;
 }
@@ -2291,10 +2341,15 @@ int aesgcm_decrypt(aesgcm_ctx *c, const uint8_t iv[12], const uint8_t *aad, size
     if ((rc = stage_in(c, aad, aad_len, ct, len))) return rc;
     if ((rc = crypt_dev(c, 1, iv, c->st_aad, aad_len, c->st_in, len, c->st_out, c->stream))) return rc;
     uint8_t t[16];
-    if (len) { HIPCHK(hipMemcpyAsync(pt, c->st_out, len, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); }   // as aesgcm_encrypt: never return while `pt` is still landing
+    const bool hold = expect_tag && c->wipe_on_auth_fail;        // the plaintext leaves the device only once its tag has been checked
+    if (len && !hold) { HIPCHK(hipMemcpyAsync(pt, c->st_out, len, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); }   // as aesgcm_encrypt: never return while `pt` is still landing
     if ((rc = fetch_tag(c, c->stream, t))) return rc;
     if (tag_out) memcpy(tag_out, t, 16);
-    if (expect_tag && !ct_compare16(t, expect_tag)) return AESGCM_EAUTH;
+    if (expect_tag && !ct_compare16(t, expect_tag)) {
+        if (hold && len) { memset(pt, 0, len); HIPCHK(hipMemsetAsync(c->st_out, 0, len, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); }
+        return AESGCM_EAUTH;
+    }
+    if (len && hold) { HIPCHK(hipMemcpyAsync(pt, c->st_out, len, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); }
     return AESGCM_OK;
 }
 
@@ -2419,7 +2474,7 @@ int aesgcm_shard_finalize_batch_dev(aesgcm_ctx *c, size_t n_msgs, const uint8_t 
     hipStream_t st = pick_stream(c, stream);
     CombineBatch b;
     memset(&b, 0, sizeof b);
-    const u64 gen = ++c->tag_gen;
+    const u64 gen = gen_take(c);
     for (size_t m = 0; m < n_msgs; m++) {
         CombineParams q = plan_combine_tag((const uint4 *)((const unsigned char *)d_partials + m * msg_stride_bytes), (u32)n_partials, PARTS_GATHERED,
                                            ivs + 12 * m, aad_lens ? aad_lens[m] : 0, total_lens[m], c->d_mtag + m);
@@ -2428,7 +2483,7 @@ int aesgcm_shard_finalize_batch_dev(aesgcm_ctx *c, size_t n_msgs, const uint8_t 
         b.p[m] = q;
     }
     hipLaunchKernelGGL(k_combine_batch, dim3((unsigned)n_msgs), dim3(COMBINE_THREADS), CMB_LDS_BYTES, st, c->km, c->tables, b);
-    HIPCHK(hipGetLastError());
+    { const hipError_t le = hipGetLastError(); if (le != hipSuccess) { gen_give_back(c); return hip_fail(le, "k_combine_batch launch"); } }
     // every workgroup publishes its own generation word behind its tag: poll them all (short), then fall back to the stream
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
@@ -2695,6 +2750,20 @@ static bool packets_by_rows(const aesgcm_ctx *c, size_t pkt_len) {
     return c->rows_min && pkt_len >= c->rows_min;
 }
 
+// zero the output of every packet whose d_auth[] entry is 0 (behind the launch that wrote it, on the same stream)
+static int wipe_failed(int device, size_t n_pkts, void *d_out, size_t pkt_len, const u64 *d_data_off, const int *d_auth, hipStream_t st) {
+    if (!n_pkts || !d_auth || !d_out) return AESGCM_OK;
+    HIPCHK(hipSetDevice(device));
+    hipLaunchKernelGGL(k_wipe_failed, dim3((unsigned)((n_pkts + 3) / 4)), dim3(256), 0, st, (unsigned char *)d_out, d_auth, d_data_off, (u32)n_pkts, (u32)pkt_len);
+    HIPCHK(hipGetLastError());
+    return AESGCM_OK;
+}
+int aesgcm_wipe_failed_dev(int device, size_t n_pkts, void *d_out, size_t pkt_len, const uint64_t *d_data_off, const int *d_auth, void *stream) {
+    if (n_pkts >= (((size_t)1) << 31) || pkt_len >= (((size_t)1) << 32)) return AESGCM_ETOOLONG;
+    if (n_pkts && (!d_out || !d_auth)) return AESGCM_EARG;
+    return wipe_failed(device, n_pkts, d_out, pkt_len, (const u64 *)d_data_off, d_auth, (hipStream_t)stream);
+}
+
 // ---------------------------------------------------------------- packets under the context's key
 int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const void *d_ivs,
                              const void *d_aad, size_t aad_len, const uint64_t *d_aad_off,
@@ -2712,7 +2781,9 @@ int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const vo
         r.out = (unsigned char *)d_out; r.tags = (unsigned char *)d_tags; r.expect = (const unsigned char *)d_expect_tags; r.auth = d_auth;
         r.data_off = (const u64 *)d_data_off; r.aad_off = (const u64 *)d_aad_off;
         r.n_pkts = (u32)n_pkts; r.pkt_len = (u32)pkt_len; r.aad_len = (u32)aad_len;
-        return packets_rows(c, decrypt, r, pick_stream(c, stream));
+        const int rc = packets_rows(c, decrypt, r, pick_stream(c, stream));
+        if (!rc && decrypt && c->wipe_on_auth_fail && d_expect_tags) return wipe_failed(c->device, n_pkts, d_out, pkt_len, (const u64 *)d_data_off, d_auth, pick_stream(c, stream));
+        return rc;
     }
     PktParams p;
     memset(&p, 0, sizeof p);
@@ -2780,6 +2851,7 @@ int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const vo
     const hipError_t le = hipGetLastError();
     if (le != hipSuccess) { c->counter_base = p.counter_base; return hip_fail(le, "k_pkt launch"); }
     if (oslot && p.perm) HIPCHK(hipEventRecord(oslot->done, st));
+    if (decrypt && c->wipe_on_auth_fail && d_expect_tags) return wipe_failed(c->device, n_pkts, d_out, pkt_len, (const u64 *)d_data_off, d_auth, st);
     return AESGCM_OK;
 }
 
@@ -3001,7 +3073,14 @@ int aesgcm_decrypt_pipelined(aesgcm_ctx *c, const uint8_t iv[12], const uint8_t 
     int rc = crypt_pipelined(c, 1, iv, aad, aad_len, ct, len, pt, t, chunk_bytes);
     if (rc) return rc;
     if (tag_out) memcpy(tag_out, t, 16);
-    if (expect_tag && !ct_compare16(t, expect_tag)) return AESGCM_EAUTH;
+    if (expect_tag && !ct_compare16(t, expect_tag)) {
+        if (c->wipe_on_auth_fail && len) {                       // the chunks have landed in `pt` already (that is the pipeline): wipe them, and the device's two chunk slots
+            memset(pt, 0, len);
+            for (int i = 0; i < 2; i++) if (c->pl_buf[i]) HIPCHK(hipMemsetAsync(c->pl_buf[i], 0, c->pl_cap, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+        }
+        return AESGCM_EAUTH;
+    }
     return AESGCM_OK;
 }
 // page-locked host memory, so that the pipelined path's copies are true DMA (pageable buffers work, slower)

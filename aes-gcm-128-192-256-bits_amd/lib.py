@@ -12,8 +12,9 @@ from .build import SO, SO_DEBUG, build
 
 OK, EARG, EKEYLEN, EIVLEN, ETOOLONG, EAUTH, EHIP, ENOMEM, ESTATE, EALIGN, ERCCL = 0, -1, -2, -3, -4, -5, -6, -7, -8, -9, -10
 
+LAUNCH_NONE, LAUNCH_MAIN, LAUNCH_CYCLIC, LAUNCH_CYCLIC_HALF, LAUNCH_DEALT = range(5)      # aesgcm_ctx_last_launch
 SHAPE_ROWS = 1 << 20    # AESGCM_SHAPE_ROWS: what packets_shape says for calls that go by rows
-ABI_VERSION = 3         # AESGCM_ABI_VERSION of include/aesgcm.h this binding was written against
+ABI_VERSION = 4         # AESGCM_ABI_VERSION of include/aesgcm.h this binding was written against
 
 # every symbol include/aesgcm.h declares (tests check the .so exports exactly these)
 SYMBOLS = [
@@ -33,6 +34,7 @@ SYMBOLS = [
     "aesgcm_comm_last_error", "aesgcm_comm_unique_id", "aesgcm_comm_create", "aesgcm_comm_ranks", "aesgcm_comm_allgather_dev",
     "aesgcm_comm_allreduce_f64", "aesgcm_comm_barrier", "aesgcm_comm_destroy",
     "aesgcm_mgpu_create", "aesgcm_mgpu_ranks", "aesgcm_mgpu_ctx", "aesgcm_mgpu_crypt_dev", "aesgcm_mgpu_destroy",
+    "aesgcm_ctx_last_launch", "aesgcm_wipe_failed_dev", "aesgcm_mgpu_last_tags", "aesgcm_mgpu_sync",
 ]
 
 
@@ -170,6 +172,10 @@ def _typed(L):
     L.aesgcm_mgpu_ctx.argtypes = [vp, cint, ctypes.POINTER(vp)]
     L.aesgcm_mgpu_crypt_dev.argtypes = [vp, cint, vp, vp, sz, ctypes.POINTER(vp), ctypes.POINTER(sz), ctypes.POINTER(vp), vp]
     L.aesgcm_mgpu_destroy.argtypes = [vp]
+    L.aesgcm_mgpu_last_tags.argtypes = [vp, sz, vp]
+    L.aesgcm_mgpu_sync.argtypes = [vp]
+    L.aesgcm_ctx_last_launch.argtypes = [vp, ctypes.POINTER(cint)]
+    L.aesgcm_wipe_failed_dev.argtypes = [cint, sz, vp, sz, vp, vp, vp]
     if L.aesgcm_abi_version() != ABI_VERSION:
         raise ImportError("libaesgcm_hip.so ABI %d, expected %d (stale build? rebuild with `make -C csrc`)" % (L.aesgcm_abi_version(), ABI_VERSION))
     return L
@@ -321,6 +327,11 @@ def batch_crypt_var_dev(decrypt, n_pkts, key_len, d_keys, d_ivs, d_in, d_data_of
                                            d_in, d_data_off, d_out, d_tags, d_expect_tags, d_auth, stream))
 
 
+def wipe_failed_dev(n_pkts, d_out, d_auth, pkt_len=0, d_data_off=None, device=0, stream=None):
+    """aesgcm_wipe_failed_dev: zero the output of every packet whose d_auth entry is 0 (what the context option wipe_on_auth_fail does for the packet calls of a context)"""
+    _chk(load().aesgcm_wipe_failed_dev(device, n_pkts, d_out, pkt_len, d_data_off, d_auth, stream))
+
+
 def batch_shape(n_pkts, pkt_len=0, var_len=False, device=0):
     """lanes per packet the batch entry points take for such a call: 8 / 16 (k_batch3) or 64 (k_batch)"""
     v = cint(0)
@@ -433,6 +444,12 @@ class Context:
         """aesgcm_ctx_set_option: "tw", "body_min", "cyc_min", "cyc_max", "cyc_close", "fold_close", "cyc_prio", "pkt_order", "rows_min", "rows_block", "poll_us" (include/aesgcm.h)"""
         _chk(self._lib.aesgcm_ctx_set_option(self._c, key.encode(), int(value)))
         return self
+
+    def last_launch(self):
+        """aesgcm_ctx_last_launch: which launch structure the last whole-message call took (LAUNCH_MAIN / CYCLIC / CYCLIC_HALF / DEALT)"""
+        v = cint(0)
+        _chk(self._lib.aesgcm_ctx_last_launch(self._c, ctypes.byref(v)))
+        return v.value
 
     def packets_shape(self, n_pkts, pkt_len=0, var_len=False):
         """lanes per packet packets_crypt_dev takes for such a call: 1 (k_pktl), 4 / 8 / 16 or 64 (k_pktg), or SHAPE_ROWS: by rows (k_rows; with offset arrays
@@ -683,15 +700,24 @@ class MultiGpu:
         _chk(load().aesgcm_mgpu_ranks(self._m, ctypes.byref(n)))
         self.n_ranks = n.value                             # communicator size RCCL reports
 
-    def crypt_dev(self, decrypt, iv, d_in, shard_len, d_out, d_aad=None, aad_len=0):
-        """d_in / d_out / shard_len: one entry per device -> tag"""
+    def crypt_dev(self, decrypt, iv, d_in, shard_len, d_out, d_aad=None, aad_len=0, want_tag=True):
+        """d_in / d_out / shard_len: one entry per device -> tag.  want_tag=False: the message is only enqueued (up to 8 may wait); last_tags() collects"""
         g = len(self.devices)
         if not (len(d_in) == len(d_out) == len(shard_len) == g):
             raise AesGcmError(EARG, "one shard per device")
         pin, pout, ln = (vp * g)(*d_in), (vp * g)(*d_out), (sz * g)(*shard_len)
-        tag = ctypes.create_string_buffer(16)
+        tag = ctypes.create_string_buffer(16) if want_tag else None
         _chk(load().aesgcm_mgpu_crypt_dev(self._m, int(bool(decrypt)), _fixed(iv, 12, "iv"), d_aad, aad_len, pin, ln, pout, tag))
-        return tag.raw
+        return tag.raw if want_tag else None
+
+    def last_tags(self, n):
+        """the tags of the last n messages queued with want_tag=False, oldest first (one finalize launch on the first device)"""
+        t = ctypes.create_string_buffer(16 * n)
+        _chk(load().aesgcm_mgpu_last_tags(self._m, n, t))
+        return [t.raw[16 * k:16 * k + 16] for k in range(n)]
+
+    def sync(self):
+        _chk(load().aesgcm_mgpu_sync(self._m))
 
     def context(self, g):
         """device g's Context, borrowed from the mgpu object (closing it is a no-op)"""

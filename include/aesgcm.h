@@ -37,7 +37,9 @@
 extern "C" {
 #endif
 
-#define AESGCM_ABI_VERSION 3   /* 2: aesgcm_ctx_wait, aesgcm_comm_* / aesgcm_mgpu_*, packet and batch entry points; 3: aesgcm_ctx_set_option (the library no longer reads
+#define AESGCM_ABI_VERSION 4   /* 4 (round 5): packets of message size by rows (AESGCM_SHAPE_ROWS), aesgcm_ctx_last_launch, aesgcm_wipe_failed_dev and the option "wipe_on_auth_fail",
+                                  aesgcm_mgpu_crypt_dev with tag = NULL + aesgcm_mgpu_last_tags / aesgcm_mgpu_sync;
+                                  2: aesgcm_ctx_wait, aesgcm_comm_* / aesgcm_mgpu_*, packet and batch entry points; 3: aesgcm_ctx_set_option (the library no longer reads
                                   any environment variable), aesgcm_batch_shape / aesgcm_packets_shape, aesgcm_mgpu_ctx, aesgcm_last_tag through the host slot */
 
 #if defined(__GNUC__)
@@ -109,6 +111,14 @@ AESGCM_API int aesgcm_ctx_create_preexpanded(aesgcm_ctx **out, int device, const
 AESGCM_API int aesgcm_ctx_rekey(aesgcm_ctx *ctx, const uint8_t *key, size_t key_len);
 AESGCM_API int aesgcm_ctx_destroy(aesgcm_ctx *ctx);
 AESGCM_API int aesgcm_ctx_device(const aesgcm_ctx *ctx);
+/* Which launch structure the context's last whole-message call (aesgcm_encrypt[_dev] / aesgcm_decrypt[_dev]) took.  The library chooses by size and -- for the
+ * half shape of the cyclic rows -- by whether another context of the device had a message under way at that moment; benches and profiles report it. */
+#define AESGCM_LAUNCH_NONE 0
+#define AESGCM_LAUNCH_MAIN 1            /* k_main (+ k_combine): below 64 KiB */
+#define AESGCM_LAUNCH_CYCLIC 2          /* one k_body launch of cyclic rows */
+#define AESGCM_LAUNCH_CYCLIC_HALF 3     /* ... in its half shape (k_bodyh) */
+#define AESGCM_LAUNCH_DEALT 4           /* k_body's dealt chunks (+ k_fold): from 1 GiB */
+AESGCM_API int aesgcm_ctx_last_launch(const aesgcm_ctx *ctx, int *shape);
 /* Tunables of one context, for tests and profiling scripts; the library reads no environment variable and the defaults are the
  * measured best.  Every value selects between paths that produce the same bytes.  Keys (value >= 0):
  *   "tw"          rows of 64 blocks per chunk of the dealt kernels, 0 = the library's rule
@@ -123,6 +133,10 @@ AESGCM_API int aesgcm_ctx_device(const aesgcm_ctx *ctx);
  *   "cyc_prio"    rows between rotations of the waves' issue priorities in a cyclic launch, 0 = off
  *   "pkt_order"   packets from which aesgcm_packets_crypt_dev with offset arrays takes the packets by falling length class (a counting sort on the
  *                 device in front of the launch; default 98304, where it starts to pay), 0 = never.  The results are the same bytes.
+ *   "wipe_on_auth_fail"  1: a decrypt call that verifies a tag (expect_tag / d_expect_tags) leaves ZEROS, not unauthenticated plaintext, where verification fails:
+ *                 aesgcm_decrypt and aesgcm_decrypt_pipelined wipe the caller's buffer (aesgcm_decrypt does not even copy the plaintext out before the tag is
+ *                 checked), aesgcm_decrypt_dev the device buffer, aesgcm_packets_crypt_dev every packet whose d_auth entry is 0 (d_auth must be given).  Default 0:
+ *                 the reference model returns the plaintext and raises (tb/gcm_model.py:29-30,47-51), and so does the class that mirrors it.
  *   "rows_min"    bytes per packet from which aesgcm_packets_crypt_dev goes by rows (default 65536; 0 = never)
  *   "rows_block"  units (rows of 64 blocks; a message's tail) per dealt block of the row kernel, 0 = the library's cut (one block per wave; blocks of 64 for large calls)
  *   "poll_us"     how long a tag is polled for in the pinned host slot before the call blocks in the runtime
@@ -174,6 +188,7 @@ AESGCM_API int aesgcm_encrypt_dev(aesgcm_ctx *ctx, const uint8_t iv[12], const v
 AESGCM_API int aesgcm_decrypt_dev(aesgcm_ctx *ctx, const uint8_t iv[12], const void *d_aad, size_t aad_len,
                        const void *d_ct, size_t len, void *d_pt, const uint8_t *expect_tag,
                        uint8_t tag_out[16], void *stream);
+/* (`stream` must be the stream the message was enqueued on: AESGCM_ESTATE if that stream has drained and the host slot still does not show the message's tag) */
 AESGCM_API int aesgcm_last_tag(aesgcm_ctx *ctx, uint8_t tag[16], void *stream);
 
 /* CTR keystream blocks [first_block, first_block+nblocks): E_K(IV || (2+i) mod 2^32)
@@ -247,6 +262,11 @@ AESGCM_API int aesgcm_mgpu_ranks(const aesgcm_mgpu *m, int *n_ranks);
 AESGCM_API int aesgcm_mgpu_ctx(aesgcm_mgpu *m, int g, aesgcm_ctx **out);     /* device g's context, borrowed: never destroy it */
 AESGCM_API int aesgcm_mgpu_crypt_dev(aesgcm_mgpu *m, int decrypt, const uint8_t iv[12], const void *d_aad_on_dev0, size_t aad_len,
                           const void *const *d_in, const size_t *shard_len, void *const *d_out, uint8_t tag[16]);
+/* tag = NULL in aesgcm_mgpu_crypt_dev only ENQUEUES the message -- shards, the all-gather -- without a host synchronisation on any device; up to 8 such messages may
+ * wait.  aesgcm_mgpu_last_tags finalizes the last n of them in one launch on devices[0] and returns their tags, oldest first (16 n bytes); aesgcm_mgpu_sync drains
+ * every device's stream (before the outputs are read by anything not ordered behind those streams).  AESGCM_ESTATE when a ninth message is queued. */
+AESGCM_API int aesgcm_mgpu_last_tags(aesgcm_mgpu *m, size_t n, uint8_t *tags);
+AESGCM_API int aesgcm_mgpu_sync(aesgcm_mgpu *m);
 AESGCM_API int aesgcm_mgpu_destroy(aesgcm_mgpu *m);
 
 /* ---------------------------------------------------------------- many packets under the context's key
@@ -280,6 +300,10 @@ AESGCM_API int aesgcm_packets_crypt_dev(aesgcm_ctx *ctx, int decrypt, size_t n_p
 AESGCM_API int aesgcm_batch_crypt_dev(int device, int decrypt, size_t n_pkts, size_t key_len, const void *d_keys, const void *d_ivs,
                            const void *d_aad, size_t aad_len, const void *d_in, size_t pkt_len, void *d_out,
                            void *d_tags, const void *d_expect_tags, int *d_auth, void *stream);
+
+/* Zero the output of every packet whose d_auth entry is 0: what the context option "wipe_on_auth_fail" does behind aesgcm_packets_crypt_dev, for callers of the
+ * context-free batch entry points (fixed-size records: d_data_off = NULL).  Asynchronous on `stream`, which must be the stream the decrypt call ran on. */
+AESGCM_API int aesgcm_wipe_failed_dev(int device, size_t n_pkts, void *d_out, size_t pkt_len, const uint64_t *d_data_off, const int *d_auth, void *stream);
 
 /* Which kernel shape a call with these arguments takes: lanes per packet (1 = one lane per packet, 4 / 8 / 16 = a lane group, 64 = a
  * whole wave; aesgcm_packets_shape: AESGCM_SHAPE_ROWS = by rows, every message over the whole chip).  var_len != 0 describes the offset-array forms

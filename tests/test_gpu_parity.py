@@ -460,14 +460,14 @@ def test_rekey_equals_a_fresh_context(hip, orc):
         ctx.rekey(bytes(16))
     ctx.stream_aad(b"")
     ctx.stream_final()
-    # cost: rekey against destroy + create
-    t0 = time.perf_counter()
-    for i in range(10):
-        ctx.rekey(bytes([i]) * 32)
-    t_rekey = (time.perf_counter() - t0) / 10
-    t0 = time.perf_counter()
-    for i in range(10):
-        hip.Context(bytes([i]) * 32).close()
-    t_new = (time.perf_counter() - t0) / 10
-    print("rekey %.0f us, destroy + create %.0f us" % (t_rekey * 1e6, t_new * 1e6))
-    assert t_rekey < t_new, (t_rekey, t_new)                        # both are mostly k_setup (0.4 ms) since contexts reuse the streams of destroyed ones
+    # a message queued on ANOTHER stream with tag = NULL is still reading the key material when rekey is called: rekey waits for every stream of the device
+    # (round 4 waited for the context's own stream only), so the queued message is encrypted under the key it was enqueued with
+    key_a, key_b, iv = splitmix_bytes(501, 32), splitmix_bytes(502, 32), splitmix_bytes(503, 12)
+    other = hip.Context(key_a)                                      # its stream carries the queued message
+    ctx.rekey(key_a)
+    n = 24 << 20
+    ctx.encrypt_dev(iv, d_in.ptr, n, d_out.ptr, stream=other.stream(), want_tag=False)
+    ctx.rekey(key_b)
+    want_ct, want_tag = orc.Fast(key_a).encrypt(iv, b"", pt[:n])
+    assert bytes(d_out.download(n)) == want_ct
+    # (the cost of a rekey against destroy + create is a profiling matter: profiles/ctx_time.py; a wall-clock comparison does not belong in a parity test)

@@ -78,8 +78,9 @@ def test_kernel_set(census):
     for name in census:
         fam.setdefault(name.split("<")[0], []).append(name)
     assert sorted(fam) == ["k_batch3", "k_body", "k_bodyh", "k_combine", "k_combine_batch", "k_copy16", "k_fill_splitmix64", "k_fold", "k_gfmul", "k_init_tables",
-                           "k_len_hist", "k_len_scan", "k_len_scatter", "k_main", "k_pktg", "k_pktl", "k_setup", "k_setup_ptab"], sorted(fam)
+                           "k_len_hist", "k_len_scan", "k_len_scatter", "k_main", "k_pktg", "k_pktl", "k_rows", "k_rows_close", "k_rows_plan", "k_setup", "k_setup_ptab"], sorted(fam)
     assert (len(fam["k_main"]), len(fam["k_body"]), len(fam["k_bodyh"]), len(fam["k_pktg"]), len(fam["k_pktl"]), len(fam["k_batch3"])) == (12, 15, 6, 24, 12, 18)
+    assert (len(fam["k_rows"]), len(fam["k_rows_close"])) == (6, 2)
 
 
 def test_no_sgpr_hazard_in_front_of_the_write_through_stores(census):
@@ -101,3 +102,19 @@ def test_half_shape_keeps_its_spills_out_of_the_row_loop(census):
             blocks = isa_loops.census(path, "_Z7k_bodyhILi%dELi%dEE" % (nr, dec))
             rows = [c for _, c in blocks if c["lds"] == 16 * (nr - 2) or c["lds"] == 52]
             assert rows and all(c["scratch"] == 0 for c in rows), (nr, dec, [(c["lds"], c["scratch"]) for c in rows])
+
+
+def test_row_kernel_keeps_its_spills_out_of_the_row_loop(census):
+    """k_rows (round 5: k_body's row loop over runs of rows of many messages, with the tail / AAD code and the piece walk of a whole call around it) may spill a
+    few dwords around the general code -- a tail or an AAD is one row per message -- but nothing in the row loop: the basic blocks with the (NR - 2) x 16 T-table
+    lookups of rounds 3 .. NR, or with the 52 reads of the GHASH table multiply, hold no scratch access and at most two lane moves (AES-256 with sixteen more
+    registers for the row phases spilled five round keys per row; its build computes the phase constants per row and keeps 24 key words in vector registers)."""
+    import isa_loops
+    path = os.path.join(CSRC, "aesgcm_kernels.gfx950.s")
+    for nr in (10, 12, 14):
+        for dec in (0, 1):
+            k = census["k_rows<%d, %d>" % (nr, dec)]
+            assert k["vgpr"] <= 128 and k["scratch"] <= 64, k
+            blocks = isa_loops.census(path, "_Z6k_rowsILi%dELi%dEE" % (nr, dec))
+            rows = [c for _, c in blocks if c["lds"] == 16 * (nr - 2) or c["lds"] == 52]
+            assert len(rows) >= 2 and all(c["scratch"] == 0 and c["lane"] <= 2 for c in rows), (nr, dec, [(c["lds"], c["scratch"], c["lane"]) for c in rows])
