@@ -49,7 +49,11 @@ Rccl g_rccl;
 std::once_flag g_rccl_once;
 
 void rccl_load() {
+#ifdef AESGCM_TEST_RCCL_LIB
+    const char *names[] = {AESGCM_TEST_RCCL_LIB};             // tests/fake_hip: the host side linked against a fake runtime (no product build defines this)
+#else
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+#endif
     for (const char *n : names) { g_rccl.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (g_rccl.h) break; }
     if (!g_rccl.h) return;
 #define SYM(f) g_rccl.f = reinterpret_cast<decltype(g_rccl.f)>(dlsym(g_rccl.h, "nccl" #f)); if (!g_rccl.f) return

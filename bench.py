@@ -548,8 +548,8 @@ def run_single_process(args):
     """The N-GPU stream job (cfg4 cut to N devices, as the N-rank launch runs it) from ONE process: aesgcm_mgpu_* --
     ncclCommInitAll, one grouped 16-byte all-gather per message, every device's context derived from the key locally.
     The fallback of self_launch when no RCCL communicator comes up between processes (and --single-process asks for it).
-    Messages run one after the other (aesgcm_mgpu_crypt_dev returns the tag), so this path has a host round trip per message
-    that the N-rank path does not; the line names the path it is (config.exchange.backend)."""
+    The messages of a step are queued without a host synchronisation and their tags collected by one finalize launch (aesgcm_mgpu_last_tags), as the N-rank
+    path does; the line names the path it is (config.exchange.backend) and says whether its tags equal a single device's ("validated")."""
     import aesgcm_amd  # noqa: F401
     from aesgcm_amd import lib, sharding
     from aesgcm_amd.build import SO
@@ -588,24 +588,52 @@ def run_single_process(args):
     ivs = [sharding.tweak_iv(iv0, m["iv_tweak"]) for m in plans[0]]
 
     def step():
-        return [mg.crypt_dev(False, ivs[i], [d_pt[r].ptr + plans[r][i]["off"] for r in range(N)], [plans[r][i]["len"] for r in range(N)],
-                             [d_ct[r].ptr + plans[r][i]["off"] for r in range(N)]) for i in range(M)]
+        # the M messages are only ENQUEUED (tag = NULL: no host synchronisation on any device) and their tags collected with one finalize launch on device 0, as
+        # the N-rank path does with aesgcm_shard_finalize_batch_dev (round 5; until then every message waited for its tag)
+        for i in range(M):
+            mg.crypt_dev(False, ivs[i], [d_pt[r].ptr + plans[r][i]["off"] for r in range(N)], [plans[r][i]["len"] for r in range(N)],
+                         [d_ct[r].ptr + plans[r][i]["off"] for r in range(N)], want_tag=False)
+        return mg.last_tags(M)
 
     def sync_all():
         for r in range(N):
             lib.dev_sync(r)
 
+    if M > 8:
+        log("bench.py: the single-process path queues at most 8 messages per step (this job has %d)" % M)
+        return 2
     tags = None
     for _ in range(max(args.warmup, 1)):
         tags = step()
+    sync_all()
     checked = []
     for m, t in zip(plans[0], tags):
         fx = load_fixture("cfg4_aes256_msg%d_32GiB" % m["msg"]) if standard and m["total"] == 32 * GiB else None
         if fx is not None:
             checked.append(t.hex() == fx["tag"])
     tag_ok = all(checked) if checked else None
-    if tag_ok is False:
-        log("PARITY FAILURE (single process): tags=%s" % [t.hex() for t in tags])
+    # whatever the size: every message once more on device 0 ALONE -- shard by shard from the same SplitMix64 stream, the partials folded there -- and the
+    # tags compared: the shard order of plan_job and the cumulative first blocks of aesgcm_mgpu_crypt_dev must describe the same message
+    validated = True
+    try:
+        one = lib.Context(key, device=0)
+        biggest = max(plans[r][i]["len"] for r in range(N) for i in range(M))
+        d_a, d_b, d_parts = lib.DeviceBuffer(biggest, device=0), lib.DeviceBuffer(biggest, device=0), lib.DeviceBuffer(16 * N, device=0)
+        for i in range(M):
+            for r in range(N):
+                m = plans[r][i]
+                d_a.fill_splitmix64(cfg["pt_seed"], m["stream_word"], nbytes=m["len"])
+                one.shard_crypt_dev(False, ivs[i], d_a.ptr, m["len"], d_b.ptr, m["first_block"], m["total"], d_parts.ptr + 16 * r)
+            alone = one.shard_finalize_dev(ivs[i], d_parts.ptr, N, 0, plans[0][i]["total"])
+            validated = validated and alone == tags[i]
+        for o in (d_a, d_b, d_parts):
+            o.free()
+        one.close()
+    except lib.AesGcmError as e:
+        log("bench.py: the single-device cross-check could not run: %r" % (e,))
+        validated = False
+    if tag_ok is False or not validated:
+        log("PARITY FAILURE (single process): tags=%s fixture %s single-device %s" % ([t.hex() for t in tags], tag_ok, validated))
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -639,7 +667,7 @@ def run_single_process(args):
                    "bytes_per_gpu": per_gpu, "messages_per_step": M, "parallelism": "shard%d" % N, "key_bits": key_bits,
                    "workgroups": geo["workgroups"], "wg_lanes": geo["wg_lanes"], "lds_bytes_per_wg": geo["lds_bytes"],
                    "exchange": {"backend": "rccl (single process)", "ranks_seen": mg.n_ranks, "init": "ncclCommInitAll", "torch": "not imported"}},
-        "tag_ok": tag_ok, "tags": [t.hex() for t in tags],
+        "tag_ok": tag_ok, "validated": validated, "tags": [t.hex() for t in tags],
         "roofline": {"bound": "hbm", "kernel": "%s<%d,ENC> (fused AES-CTR + GHASH), device 0" % ("k_body" if body_blocks else "k_main", key_bits // 32 + 6),
                      "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_BYTES_PER_S, 4),
                      "traffic": None, "alg_bytes_per_launch": alg_bytes, "launches_timed": n_launch, "avg_launch_ms": round(avg_s * 1e3, 4),
@@ -647,7 +675,7 @@ def run_single_process(args):
                      "traffic_build": {"running_so_sha256": sha256_file(SO), "running_git": git_head()}},
     }
     emit(line)
-    ok = mg.n_ranks == N and tag_ok is not False
+    ok = mg.n_ranks == N and tag_ok is not False and validated
     mg.close()
     return 0 if ok else 1
 
