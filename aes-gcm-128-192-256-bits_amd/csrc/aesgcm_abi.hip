@@ -666,6 +666,20 @@ int aesgcm_batch_crypt_dev(int device, int decrypt, size_t n_pkts, size_t key_le
 }
 
 
+// The instruction stream of the batch kernel WITHOUT the data's HBM traffic (k_batch3<NR, 2, 3>: keys, IVs and tags still move, 44 - 60 bytes per packet): what
+// the formulation costs by itself on this chip at this moment's clocks -- the yardstick bench.py --config cfg5 prints as roofline.formulation_ceiling, as
+// aesgcm_ctx_ceiling_probe is for the stream kernel.  Exists for calls that take the 8-lanes-per-packet shape (BASELINE config 5 does); AESGCM_EARG otherwise.
+int aesgcm_batch_ceiling_probe_dev(int device, size_t n_pkts, size_t key_len, const void *d_keys, const void *d_ivs, size_t pkt_len, void *d_tags, void *stream) {
+    if (!n_pkts || !d_keys || !d_ivs || !d_tags || !pkt_len) return AESGCM_EARG;
+    if (pkt_len >= (((size_t)1) << 28)) return AESGCM_ETOOLONG;
+    BatchParams p;
+    memset(&p, 0, sizeof p);
+    p.keys = (const unsigned char *)d_keys; p.ivs = (const unsigned char *)d_ivs; p.tags = (unsigned char *)d_tags;
+    p.pkt_len = (u32)pkt_len;
+    p.aligned = pkt_len % 16 == 0;
+    return batch_launch(device, 2, n_pkts, key_len, p, stream);
+}
+
 int aesgcm_batch_crypt_var_dev(int device, int decrypt, size_t n_pkts, size_t key_len, const void *d_keys, const void *d_ivs,
                                const void *d_aad, const uint64_t *d_aad_off, const void *d_in, const uint64_t *d_data_off,
                                void *d_out, void *d_tags, const void *d_expect_tags, int *d_auth, void *stream) {

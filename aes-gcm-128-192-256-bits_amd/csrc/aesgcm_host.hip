@@ -746,6 +746,7 @@ int batch_launch(int device, int decrypt, size_t n_pkts, size_t key_len, BatchPa
 #ifdef AESGCM_DEBUG_KNOBS
     if (g_force.batch_lanes) lg = g_force.batch_lanes == 8 ? 3 : g_force.batch_lanes == 16 ? 4 : 6;
 #endif
+    if (decrypt == 2 && lg != 3) { snprintf(g_err, sizeof g_err, "the probe of the batch kernel exists in the 8-lanes-per-packet shape; this call takes %d", 1 << lg); return AESGCM_EARG; }
     if (lg <= 6) {
         // packets of mixed length: by falling length class once the batch fills the machine several times over (BATCH_ORDER_MIN; as aesgcm_packets_crypt_dev)
         OrderSlot *oslot = nullptr;

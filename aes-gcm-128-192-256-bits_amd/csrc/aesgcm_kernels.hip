@@ -813,7 +813,7 @@ __device__ __forceinline__ G128 batch3_mul_pair(G128 y, const unsigned char *sme
     }
     return shoup2_pair_join(Vo, Vh);
 }
-template <int NR, int DEC, int LG>
+template <int NR, int DEC, int LG>                       // DEC: 0 encrypt, 1 decrypt, 2 = encrypt WITHOUT the data's loads and stores (aesgcm_batch_ceiling_probe_dev: what the formulation costs by itself)
 __global__ __launch_bounds__(BATCH3_LANES(NR), (BATCH3_LANES(NR) + 255) / 256) void k_batch3(const DevTables *__restrict__ tb, const BatchParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr u32 G = 1u << LG, P = 64u >> LG;
@@ -899,12 +899,12 @@ __global__ __launch_bounds__(BATCH3_LANES(NR), (BATCH3_LANES(NR) + 255) / 256) v
             unsigned char *dst = out + 16u * l;
             for (u32 k = 0; k < iters; k++) {
                 if (k) acc = PAIR ? batch3_mul_pair(acc, smem, tabA, tabAp, pair_first) : BATCH3_MUL(acc, smem, tabA);
-                const uint4 x = gload16(src);
+                const uint4 x = DEC == 2 ? make_uint4(l, k, pkt, 0u) : gload16(src);     // (DEC == 2, the PROBE: the same instruction stream without the data's HBM traffic)
                 u32 s0, s1, s2, s3;
                 ctr_rounds_lds<NR>(bswap32(2u + k * G + l), cc, s0, s1, s2, s3, rk, smem, lb);
                 const uint4 y = make_uint4(x.x ^ s0, x.y ^ s1, x.z ^ s2, x.w ^ s3);
-                if (act) gstore16(dst, y);
-                const G128 b = mo_to_be(DEC ? x : y);                // aes_gcm.vhd:207-211
+                if (act && DEC != 2) gstore16(dst, y);
+                const G128 b = mo_to_be(DEC == 1 ? x : y);           // aes_gcm.vhd:207-211
                 acc.w[0] ^= b.w[0]; acc.w[1] ^= b.w[1]; acc.w[2] ^= b.w[2]; acc.w[3] ^= b.w[3];
                 src += 16u * G; dst += 16u * G;
             }
@@ -922,17 +922,18 @@ __global__ __launch_bounds__(BATCH3_LANES(NR), (BATCH3_LANES(NR) + 255) / 256) v
                 const u32 i = j - n_aad, off = 16 * i, rem = pkt_len - off;
                 const bool full = rem >= 16;                    // a whole block is one access at any address
                 uint4 x;
-                if (full) x = aligned ? gload16(in + off) : gload16_any(in + off);
+                if (DEC == 2) x = make_uint4(l, i, pkt, 0u);
+                else if (full) x = aligned ? gload16(in + off) : gload16_any(in + off);
                 else x = load_block_bytes(in + off, rem < 16 ? rem : 16);
                 u32 s0, s1, s2, s3;
                 ctr_rounds_lds<NR>(bswap32(2u + i), cc, s0, s1, s2, s3, rk, smem, lb);
                 uint4 y = make_uint4(x.x ^ s0, x.y ^ s1, x.z ^ s2, x.w ^ s3);
                 if (rem < 16) y = mask_block(y, rem);
-                if (act) {
+                if (act && DEC != 2) {
                     if (full) { if (aligned) gstore16(out + off, y); else gstore16_any(out + off, y); }
                     else store_block_bytes(out + off, y, rem < 16 ? rem : 16);
                 }
-                gin = DEC ? x : y;                               // aes_gcm.vhd:207-211
+                gin = DEC == 1 ? x : y;                          // aes_gcm.vhd:207-211
             }
             const G128 b = mo_to_be(gin);
             acc.w[0] ^= b.w[0]; acc.w[1] ^= b.w[1]; acc.w[2] ^= b.w[2]; acc.w[3] ^= b.w[3];
@@ -970,7 +971,7 @@ __global__ __launch_bounds__(BATCH3_LANES(NR), (BATCH3_LANES(NR) + 255) / 256) v
         if (l2 == G - 1u && act2) {
             const uint4 tag = be_to_mo(acc);
             store_block_bytes(p.tags + (size_t)pkt2 * 16, tag, 16);
-            if (DEC && p.auth) {
+            if (DEC == 1 && p.auth) {
                 int ok = 1;
                 if (p.expect) {
                     const uint4 e = load_block_bytes(p.expect + (size_t)pkt2 * 16, 16);
@@ -1368,6 +1369,9 @@ hipError_t klaunch_set_attributes() {
                          ATTRCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch3<NR, D, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, BATCH3_LDS_BYTES_LG(3)))
     SETATTRB3(10, 0); SETATTRB3(12, 0); SETATTRB3(14, 0); SETATTRB3(10, 1); SETATTRB3(12, 1); SETATTRB3(14, 1);
 #undef SETATTRB3
+#define SETATTRB3P(NR) ATTRCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch3<NR, 2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, BATCH3_LDS_BYTES_LG(3)))
+    SETATTRB3P(10); SETATTRB3P(12); SETATTRB3P(14);
+#undef SETATTRB3P
 #undef ATTRCHK
     return hipSuccess;
 }
@@ -1434,7 +1438,8 @@ hipError_t klaunch_pktg(int nr, int dec, int lg, unsigned wgs, hipStream_t st, c
 hipError_t klaunch_batch3(int nr, int dec, int lg, unsigned wgs, hipStream_t st, const DevTables *tb, const BatchParams &p) {
 #define LB3(NR, D, LG) hipLaunchKernelGGL((k_batch3<NR, D, LG>), dim3(wgs), dim3(BATCH3_LANES(NR)), BATCH3_LDS_BYTES_LG(LG), st, tb, p)
 #define LB3N(D, LG) do { if (nr == 10) LB3(10, D, LG); else if (nr == 12) LB3(12, D, LG); else LB3(14, D, LG); } while (0)
-    if (lg == 3) { if (dec) LB3N(1, 3); else LB3N(0, 3); }
+    if (dec == 2) { if (lg != 3) return hipErrorInvalidValue; LB3N(2, 3); }   // the probe exists in the shape of BASELINE config 5
+    else if (lg == 3) { if (dec) LB3N(1, 3); else LB3N(0, 3); }
     else if (lg == 4) { if (dec) LB3N(1, 4); else LB3N(0, 4); }
     else { if (dec) LB3N(1, 6); else LB3N(0, 6); }
 #undef LB3N

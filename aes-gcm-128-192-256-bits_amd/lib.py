@@ -34,7 +34,7 @@ SYMBOLS = [
     "aesgcm_comm_last_error", "aesgcm_comm_unique_id", "aesgcm_comm_create", "aesgcm_comm_ranks", "aesgcm_comm_allgather_dev",
     "aesgcm_comm_allreduce_f64", "aesgcm_comm_barrier", "aesgcm_comm_destroy",
     "aesgcm_mgpu_create", "aesgcm_mgpu_ranks", "aesgcm_mgpu_ctx", "aesgcm_mgpu_crypt_dev", "aesgcm_mgpu_destroy",
-    "aesgcm_ctx_last_launch", "aesgcm_wipe_failed_dev", "aesgcm_mgpu_last_tags", "aesgcm_mgpu_sync",
+    "aesgcm_ctx_last_launch", "aesgcm_wipe_failed_dev", "aesgcm_mgpu_last_tags", "aesgcm_mgpu_sync", "aesgcm_batch_ceiling_probe_dev",
 ]
 
 
@@ -176,6 +176,7 @@ def _typed(L):
     L.aesgcm_mgpu_sync.argtypes = [vp]
     L.aesgcm_ctx_last_launch.argtypes = [vp, ctypes.POINTER(cint)]
     L.aesgcm_wipe_failed_dev.argtypes = [cint, sz, vp, sz, vp, vp, vp]
+    L.aesgcm_batch_ceiling_probe_dev.argtypes = [cint, sz, sz, vp, vp, sz, vp, vp]
     if L.aesgcm_abi_version() != ABI_VERSION:
         raise ImportError("libaesgcm_hip.so ABI %d, expected %d (stale build? rebuild with `make -C csrc`)" % (L.aesgcm_abi_version(), ABI_VERSION))
     return L
@@ -330,6 +331,11 @@ def batch_crypt_var_dev(decrypt, n_pkts, key_len, d_keys, d_ivs, d_in, d_data_of
 def wipe_failed_dev(n_pkts, d_out, d_auth, pkt_len=0, d_data_off=None, device=0, stream=None):
     """aesgcm_wipe_failed_dev: zero the output of every packet whose d_auth entry is 0 (what the context option wipe_on_auth_fail does for the packet calls of a context)"""
     _chk(load().aesgcm_wipe_failed_dev(device, n_pkts, d_out, pkt_len, d_data_off, d_auth, stream))
+
+
+def batch_ceiling_probe_dev(n_pkts, key_len, d_keys, d_ivs, pkt_len, d_tags, device=0, stream=None):
+    """aesgcm_batch_ceiling_probe_dev: one launch of the batch kernel without the data's loads and stores (8 lanes per packet only); time it with a Timer"""
+    _chk(load().aesgcm_batch_ceiling_probe_dev(device, n_pkts, key_len, d_keys, d_ivs, pkt_len, d_tags, stream))
 
 
 def batch_shape(n_pkts, pkt_len=0, var_len=False, device=0):

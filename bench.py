@@ -409,6 +409,21 @@ def run_cfg5(args, rank, world, dev, ex, cpu_base):
         step()
         tm.stop(None)
         k_ms.append(tm.ms())
+    # ---- the formulation's ceiling: the same kernel without the data's loads and stores (aesgcm_batch_ceiling_probe_dev; 8 lanes per packet only), same process,
+    #      same clocks -- how far the launch is from what per-packet aes_kexp + T-table AES + Shoup GHASH cost by themselves on this chip (round-4 verdict, Next 2)
+    c_ms = []
+    if not args.decrypt and not args.batch_lanes and lib.batch_shape(n, pkt, device=dev) == 8:
+        try:
+            lib.batch_ceiling_probe_dev(n, kb, d_keys.ptr, d_ivs.ptr, pkt, d_tags.ptr, device=dev)
+            lib.dev_sync(dev)
+            for _ in range(min(5, max(1, args.steps))):
+                tm.start(None)
+                lib.batch_ceiling_probe_dev(n, kb, d_keys.ptr, d_ivs.ptr, pkt, d_tags.ptr, device=dev)
+                tm.stop(None)
+                c_ms.append(tm.ms())
+        except lib.AesGcmError as e:
+            log("bench.py: cfg5 ceiling probe failed: %r" % (e,))
+            c_ms = []
     tm.close()
     if rank == 0:
         avg_s = statistics.mean(k_ms) / 1e3
@@ -429,6 +444,12 @@ def run_cfg5(args, rank, world, dev, ex, cpu_base):
                     "alg_bytes_per_launch": alg_bytes, "launches_timed": len(k_ms), "avg_launch_ms": round(avg_s * 1e3, 4),
                     "timing": "HIP events on the launch stream around each launch in a separate %d-step pass after the timed region" % len(k_ms),
                     "lds_busy_frac": (pm.get("lds") or {}).get("lds_busy_frac") if same_build else None}
+        if c_ms:
+            c_s = statistics.mean(c_ms) / 1e3
+            roofline["formulation_ceiling"] = {"kernel": "k_batch3<%d,PROBE,3> (the same instruction stream without the data's loads and stores; keys, IVs, tags still move)" % nr,
+                                               "avg_launch_ms": round(c_s * 1e3, 4), "gib_per_s": round(n * pkt / c_s / GiB, 1), "alg_gb_per_s": round(alg_bytes / c_s / 1e9, 1),
+                                               "frac_of_hbm_peak": round(alg_bytes / c_s / HBM_PEAK_BYTES_PER_S, 4)}
+            roofline["achieved_over_ceiling"] = round(c_s / avg_s, 4)
         line = {
             "metric": "GiB/s plaintext, AES-%d-GCM, %d independent %d-byte packets, per-packet key/IV, bit-exact tags" % (key_bits, n * N, pkt),
             "value": round(value, 3), "unit": "GiB/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,

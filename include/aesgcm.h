@@ -305,6 +305,11 @@ AESGCM_API int aesgcm_batch_crypt_dev(int device, int decrypt, size_t n_pkts, si
  * context-free batch entry points (fixed-size records: d_data_off = NULL).  Asynchronous on `stream`, which must be the stream the decrypt call ran on. */
 AESGCM_API int aesgcm_wipe_failed_dev(int device, size_t n_pkts, void *d_out, size_t pkt_len, const uint64_t *d_data_off, const int *d_auth, void *stream);
 
+/* Measurement support: the batch kernel's instruction stream without the data's loads and stores (keys, IVs and tags still move) over n_pkts virtual packets of
+ * pkt_len bytes -- the ceiling of its formulation (per-packet aes_kexp, T-table AES, Shoup GHASH) on this chip at this moment's clocks; the caller times it
+ * (aesgcm_timer_*).  Only for calls that take the 8-lanes-per-packet shape, as BASELINE config 5 does (AESGCM_EARG otherwise). */
+AESGCM_API int aesgcm_batch_ceiling_probe_dev(int device, size_t n_pkts, size_t key_len, const void *d_keys, const void *d_ivs, size_t pkt_len, void *d_tags, void *stream);
+
 /* Which kernel shape a call with these arguments takes: lanes per packet (1 = one lane per packet, 4 / 8 / 16 = a lane group, 64 = a
  * whole wave; aesgcm_packets_shape: AESGCM_SHAPE_ROWS = by rows, every message over the whole chip).  var_len != 0 describes the offset-array forms
  * (the host does not know the lengths and goes by count; pkt_len is then the caller's hint of the typical size, as in aesgcm_packets_crypt_dev). */

@@ -130,6 +130,50 @@ def test_external_libcrypto_agrees_when_present(orc):
         assert R.encrypt(key, iv, aad, pt) == orc.Fast(key).encrypt(iv, aad, pt)
 
 
+def test_pycryptodome_agrees_when_present():
+    """The reference's own arithmetic is pycryptodome (tb/gcm_model.py:1,18: `AES.new(key, AES.MODE_GCM, nonce=iv)`, update(aad), encrypt / digest, decrypt / verify),
+    which the build container and the GPU boxes seen so far do not have: the fixtures were generated by two OpenSSL builds and pinned to the reference through its
+    key schedule only.  On ANY machine that has the wheel this test closes that link by itself: every KAT, all 243 cells of the length
+    matrix and the streams of up to 64 MiB through the very calls tb/gcm_model.py makes, against the committed fixtures.  Skips otherwise.  (Round-4 verdict,
+    Missing 3.)"""
+    try:
+        from Crypto.Cipher import AES
+    except ImportError:
+        pytest.skip("pycryptodome not installed on this machine (DESIGN.md section 2 lists the boxes that have run this test)")
+    from oracle import oracle as O
+
+    def model_encrypt(key, iv, aad, pt):                                # tb/gcm_model.py:18-35
+        c = AES.new(key, AES.MODE_GCM, nonce=iv)
+        c.update(aad)
+        ct = c.encrypt(pt)
+        return ct, c.digest()
+
+    def model_decrypt(key, iv, aad, ct, tag):                           # tb/gcm_model.py:37-51
+        c = AES.new(key, AES.MODE_GCM, nonce=iv)
+        c.update(aad)
+        pt = c.decrypt(ct)
+        c.verify(tag)
+        return pt
+
+    for v in golden("kat.json")["vectors"]:
+        key, iv, aad, pt = (bytes.fromhex(v[k]) for k in ("key", "iv", "aad", "pt"))
+        assert model_encrypt(key, iv, aad, pt) == (bytes.fromhex(v["ct"]), bytes.fromhex(v["tag"])), v["name"]
+        assert model_decrypt(key, iv, aad, bytes.fromhex(v["ct"]), bytes.fromhex(v["tag"])) == pt, v["name"]
+    cells = golden("length_matrix.json")["cells"]
+    assert len(cells) == 243
+    for c in cells:
+        key, iv, aad, pt = matrix_inputs(c["kbits"], c["aad_len"], c["pt_len"])
+        ct, tag = model_encrypt(key, iv, aad, pt)
+        assert tag.hex() == c["tag"] and hashlib.sha256(ct).hexdigest() == c["ct_sha256"], c
+    for c in golden("streams.json")["cases"]:
+        if c["n_bytes"] > (64 << 20):
+            continue
+        key, iv = stream_key_iv(c)
+        pt = bytes(O.fill_splitmix64(c["n_bytes"], c["pt_seed"], c["first_word"]))
+        ct, tag = model_encrypt(key, iv, bytes.fromhex(c["aad"]), pt)
+        assert tag.hex() == c["tag"] and hashlib.sha256(ct).hexdigest() == c["ct_sha256"] and ct[:64].hex() == c["ct_head"], c["name"]
+
+
 def test_cfg5_cpu_baseline_loop_matches_the_batch_fixture():
     """oracle/evp_batch.c (the per-packet EVP loop bench.py --config cfg5 times as its CPU baseline) over the first 64 cfg5 packets:
     tags and ciphertext equal tests/golden/batch.json -- the baseline measures the same job the GPU does"""
