@@ -35,20 +35,26 @@ d_ivs.fill_splitmix64(0x4956, nbytes=(12 * nmax) // 8 * 8)
 lib.dev_sync()
 
 
-def timed(step, units_per_step, sync):
-    for _ in range(3):
-        step()
+def timed(step, units_per_step, sync, queued=1):
+    """units per second over at least min_s seconds.  queued > 1: asynchronous steps, enqueued `queued` at a time and waited for (never more: an unbounded loop
+    enqueues thousands of 5 ms calls in the time it measures -- the first run of this script spent 25 GPU-minutes draining such a queue)"""
+    def burst():
+        for _ in range(queued):
+            step()
+        if queued > 1:
+            sync()
+    burst()
     sync()
     t_end = time.perf_counter() + 0.05
     while time.perf_counter() < t_end:                           # warm-up under load
-        step()
+        burst()
     sync()
     n = 0
     t0 = time.perf_counter()
     while True:
-        step()
-        n += 1
-        if (n & 3) == 0 and time.perf_counter() - t0 > a.min_s:
+        burst()
+        n += queued
+        if time.perf_counter() - t0 > a.min_s:
             break
     sync()
     return units_per_step * n / (time.perf_counter() - t0)
@@ -95,7 +101,7 @@ for kib in a.sizes_kib:
 
         def pk():
             ctx.packets_crypt_dev(False, n, d_ivs.ptr, d_in.ptr, d_out.ptr, d_tags.ptr, pkt_len=size)
-        res.append((timed(pk, n * size, lib.dev_sync) / GiB, shape))
+        res.append((timed(pk, n * size, lib.dev_sync, queued=4) / GiB, shape))
         ctx.close()
     print("%-10s %8d %10.1f %10.1f %12.1f %14.1f  %s / %s" % ("%d KiB" % kib, n, r_wait, r_k3, res[0][0], res[1][0],
           "rows" if res[0][1] == lib.SHAPE_ROWS else "%d lanes" % res[0][1], "%d lanes per packet" % res[1][1]))
