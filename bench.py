@@ -61,6 +61,9 @@ CONFIGS = {                            # BASELINE.json configs that fit one GPU
     "cfg3": dict(key_bits=256, gib=16.0, pt_seed=0xAE5C0003, fixture="cfg3_aes256_16GiB"),
     "cfg2": dict(key_bits=128, gib=1.0, pt_seed=0xAE5C0002, fixture="cfg2_aes128_1GiB"),
     "cfg5": dict(key_bits=128, n_pkts=1 << 20, pkt_len=4096, pt_seed=0xAE5C0005),
+    # not a BASELINE config: the reference's own deployment (tb/gcm_test.py:76-85: message after message under one key) at message size -- 4096 x 1 MiB as the
+    # packets of one aesgcm_packets_crypt_dev call, which goes by rows (round 5)
+    "msgs": dict(key_bits=256, n_pkts=4096, pkt_len=1 << 20, pt_seed=0xAE5C0055),
 }
 EXIT_NOT_RCCL = 3                      # the exchange that came up is not RCCL and --allow-file-exchange was not given
 
@@ -470,6 +473,95 @@ def run_cfg5(args, rank, world, dev, ex, cpu_base):
     return tag_ok
 
 
+# ------------------------------------------------------------------------------------------------ many messages under one key
+def run_msgs(args, dev, cpu_base):
+    """--config msgs: n messages of one size under ONE key as the packets of one aesgcm_packets_crypt_dev call (by rows from 64 KiB per message: k_rows +
+    k_rows_close).  A step is one call; calls are queued four at a time.  Parity in the run: the tags of a sample of the messages equal what the single-message
+    path of the same library (pinned to the libcrypto fixtures by the test-suite) gives for the same bytes, and so does their ciphertext by SHA-256."""
+    import aesgcm_amd  # noqa: F401
+    from aesgcm_amd import lib, sharding
+    from aesgcm_amd.build import SO
+    cfg = CONFIGS["msgs"]
+    n = args.n_pkts if args.n_pkts else cfg["n_pkts"]
+    size = args.pkt_len if args.pkt_len else cfg["pkt_len"]
+    key_bits = args.key_bits or cfg["key_bits"]
+    key = sharding.splitmix64_bytes(KEY_SEED, key_bits // 8)
+    d_ivw, d_ivs = lib.DeviceBuffer(16 * n, device=dev), lib.DeviceBuffer(12 * n, device=dev)
+    d_ivw.fill_splitmix64(IV_SEED)
+    ivw = bytes(d_ivw.download())
+    ivs = b"".join(ivw[16 * p:16 * p + 12] for p in range(n))
+    d_ivs.upload(ivs)
+    d_ivw.free()
+    d_pt, d_ct, d_tags = lib.DeviceBuffer(size * n, device=dev), lib.DeviceBuffer(size * n, device=dev), lib.DeviceBuffer(16 * n, device=dev)
+    d_pt.fill_splitmix64(cfg["pt_seed"])
+    ctx = lib.Context(key, device=dev)
+    shape = ctx.packets_shape(n, size)
+
+    def step():
+        ctx.packets_crypt_dev(args.decrypt, n, d_ivs.ptr, d_ct.ptr if args.decrypt else d_pt.ptr, d_pt.ptr if args.decrypt else d_ct.ptr, d_tags.ptr, pkt_len=size)
+
+    if args.decrypt:
+        ctx.packets_crypt_dev(False, n, d_ivs.ptr, d_pt.ptr, d_ct.ptr, d_tags.ptr, pkt_len=size)
+    for _ in range(max(args.warmup, 1)):
+        step()
+    lib.dev_sync(dev)
+    tags = bytes(d_tags.download())
+    one = lib.Context(key, device=dev)
+    d_one = lib.DeviceBuffer(size, device=dev)
+    sample = sorted(set([0, n - 1] + [(k * 977) % n for k in range(6)]))
+    tag_ok = True
+    for p_ in sample:
+        t = one.encrypt_dev(ivs[12 * p_:12 * p_ + 12], d_pt.ptr + p_ * size, size, d_one.ptr)
+        same_ct = args.decrypt or hashlib.sha256(bytes(d_one.download())).digest() == hashlib.sha256(bytes(d_ct.download(size, p_ * size))).digest()
+        tag_ok = tag_ok and t == tags[16 * p_:16 * p_ + 16] and same_ct
+    if not tag_ok:
+        log("PARITY FAILURE msgs: the packets call and the single-message path disagree")
+    lib.dev_sync(dev)
+    t0 = time.perf_counter()
+    done = 0
+    while done < args.steps:
+        for _ in range(min(4, args.steps - done)):
+            step()
+            done += 1
+        lib.dev_sync(dev)
+    dt = time.perf_counter() - t0
+    value = n * size * args.steps / dt / GiB
+    tm = lib.Timer(device=dev)
+    k_ms = []
+    for _ in range(min(5, max(1, args.steps))):
+        tm.start(ctx.stream())
+        step()
+        tm.stop(ctx.stream())
+        k_ms.append(tm.ms())
+    tm.close()
+    avg_s = statistics.mean(k_ms) / 1e3
+    alg_bytes = n * (2 * size + 12 + 16)
+    achieved = alg_bytes / avg_s
+    so_sha = sha256_file(SO)
+    pm = pmc_summary("rows_1m") if (n, size, key_bits) == (cfg["n_pkts"], cfg["pkt_len"], cfg["key_bits"]) and not args.decrypt else {}
+    same_build = bool(pm) and pm.get("so_sha256") == so_sha
+    nr = key_bits // 32 + 6
+    line = {
+        "metric": "GiB/s plaintext, AES-%d-GCM, %d messages of %d bytes under one key as the packets of one call, bit-exact tags" % (key_bits, n, size),
+        "value": round(value, 3), "unit": "GiB/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "msgs: %d x %d B AES-%d-GCM messages under ONE key (stream 0x4B4559), per-message IV (stream 0x4956), plaintext stream 0xAE5C0055, one "
+                               "aesgcm_packets_crypt_dev call per step%s" % (n, size, key_bits, ", DECRYPT" if args.decrypt else ""),
+                   "messages": n, "message_bytes": size, "key_bits": key_bits, "shape": "rows" if shape == lib.SHAPE_ROWS else "%d lanes per packet" % shape, "parallelism": "single"},
+        "tag_ok": tag_ok, "tags_checked": len(sample),
+        "roofline": {"bound": "hbm", "kernel": ("k_rows<%d,%d> + k_rows_close (the rows of all messages through k_body's row loop; one call)" % (nr, int(args.decrypt))) if shape == lib.SHAPE_ROWS else "the packet kernels",
+                     "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_BYTES_PER_S, 4),
+                     "traffic": pm.get("hbm_bytes_per_launch") if same_build else None, "traffic_source": "profiles/pmc_rows_1m.json" if pm else None,
+                     "traffic_build": {"pmc_so_sha256": pm.get("so_sha256"), "running_so_sha256": so_sha, "running_git": git_head(), "match": same_build},
+                     "alg_bytes_per_launch": alg_bytes, "launches_timed": len(k_ms), "avg_launch_ms": round(avg_s * 1e3, 4),
+                     "timing": "HIP events on the context's stream around each call (both launches) in a separate %d-step pass after the timed region" % len(k_ms)},
+    }
+    if cpu_base is not None:
+        line["cpu_baseline"] = cpu_base
+    emit(line)
+    return tag_ok
+
+
 # ------------------------------------------------------------------------------------------------ messages in flight
 def run_inflight(args, dev):
     """Sustained rate of mid-size messages with K of them queued (the reference's back-to-back packets under one key,
@@ -849,6 +941,11 @@ def main(argv=None):
                 dbg.force(batch_lanes=args.batch_lanes)
                 return finish(run_cfg5(args, rank, world, dev, ex, cpu_base))
         return finish(run_cfg5(args, rank, world, dev, ex, cpu_base))
+    if args.config == "msgs":
+        if N != 1 or emu is not None:
+            log("bench.py: --config msgs runs on one GPU")
+            return 2
+        return finish(run_msgs(args, dev, cpu_base))
     if args.inflight:
         if N != 1 or args.gib_per_gpu is None or emu is not None or args.decrypt:
             log("bench.py: --inflight K needs --gib-per-gpu S, one GPU, encrypt")
