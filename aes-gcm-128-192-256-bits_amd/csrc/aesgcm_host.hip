@@ -701,15 +701,17 @@ int packets_rows(aesgcm_ctx *c, int decrypt, RowsParams &p, hipStream_t st) {
     return AESGCM_OK;
 }
 
-// does a call go by rows?  Fixed-size records: from rows_min bytes per packet.  Offset arrays: the host does not know the lengths; the caller's pkt_len, otherwise
-// unused in that form, is its word for the typical packet (0 = frames: the packet kernels)
-bool packets_by_rows(const aesgcm_ctx *c, size_t pkt_len) {
+// does a call go by rows?  Fixed-size records: from rows_min bytes per packet (32 KiB), and from half of that while the packets would not fill the packet kernels'
+// resident lanes.  Measured, AES-256, GiB/s by rows / by the packet kernels (profiles/r05/rows_min_sweep.txt): 32 KiB x 131072 856 / 747, x 8192 804 / 372,
+// x 1024 420 / 207; 16 KiB x 262144 779 / 820, x 16384 722 / 647, x 4096 640 / 435; 8 KiB x 524288 626 / 745, x 32768 576 / 649; 4 KiB x 2^20 416 / 829.
+// Offset arrays: the host does not know the lengths; the caller's pkt_len, otherwise unused in that form, is its word for the typical packet (0 = frames)
+bool packets_by_rows(const aesgcm_ctx *c, size_t n_pkts, size_t pkt_len) {
 #ifdef AESGCM_DEBUG_KNOBS
     if (g_force.pkt_rows) return g_force.pkt_rows == 1;
 #endif
-    return c->rows_min && pkt_len >= c->rows_min;
+    if (!c->rows_min) return false;
+    return pkt_len >= c->rows_min || (2 * pkt_len >= c->rows_min && n_pkts < 98304);
 }
-
 
 // zero the output of every packet whose d_auth[] entry is 0 (behind the launch that wrote it, on the same stream)
 int wipe_failed(int device, size_t n_pkts, void *d_out, size_t pkt_len, const u64 *d_data_off, const int *d_auth, hipStream_t st) {

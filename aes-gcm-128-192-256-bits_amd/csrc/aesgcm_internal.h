@@ -165,7 +165,7 @@ struct aesgcm_ctx {
     unsigned char *rows_buf = nullptr;
     size_t rows_cap_slots = 0, rows_cap_n = 0;
     bool rows_dirty = true;            // the scratch is not known to be zero (fresh, or a launch failed between k_rows and k_rows_close)
-    u64 rows_min = (u64)64 << 10;      // packets of at least this many bytes go by rows (option "rows_min"; 0 = never).  With offset arrays the caller's pkt_len is the hint that says so
+    u64 rows_min = (u64)32 << 10;      // packets of at least this many bytes go by rows (option "rows_min"; 0 = never).  With offset arrays the caller's pkt_len is the hint that says so
     u32 rows_block = 0;                // option "rows_block": units per dealt block of k_rows (0 = the library's cut: one block per wave, or blocks of ROWS_DYN_BLOCK for large calls)
     // streaming state
     bool s_active = false, s_data = false, s_ragged = false;
@@ -224,7 +224,7 @@ int packets_order(aesgcm_ctx *c, const u64 *d_off, size_t n_pkts, hipStream_t st
 size_t rows_carve(unsigned char *base, size_t slots, size_t n, RowsScratch *r);
 int rows_scratch(aesgcm_ctx *c, size_t slots, size_t n, hipStream_t st, RowsScratch *r);
 int packets_rows(aesgcm_ctx *c, int decrypt, RowsParams &p, hipStream_t st);
-bool packets_by_rows(const aesgcm_ctx *c, size_t pkt_len);
+bool packets_by_rows(const aesgcm_ctx *c, size_t n_pkts, size_t pkt_len);
 int wipe_failed(int device, size_t n_pkts, void *d_out, size_t pkt_len, const u64 *d_data_off, const int *d_auth, hipStream_t st);
 int batch_launch(int device, int decrypt, size_t n_pkts, size_t key_len, BatchParams &p, void *stream);
 void pipeline_release(aesgcm_ctx *c);
