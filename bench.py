@@ -847,7 +847,9 @@ def main(argv=None):
         log("bench.py: --gib-per-gpu must be positive")
         return 2
     est_ms = None
-    if args.config != "cfg5":                                    # ~1 ms per GiB; N > 1 stream runs are the 16 GiB-per-GPU cfg4 job whatever --config says
+    if args.config == "msgs":                                    # ~1.1 ms per GiB by rows
+        est_ms = 1.1 * (args.n_pkts or CONFIGS["msgs"]["n_pkts"]) * (args.pkt_len or CONFIGS["msgs"]["pkt_len"]) / GiB
+    elif args.config != "cfg5":                                    # ~1 ms per GiB; N > 1 stream runs are the 16 GiB-per-GPU cfg4 job whatever --config says
         est_ms = (args.gib_per_gpu if args.gib_per_gpu is not None else 16.0 if (args.gpus > 1 or args.emulate_rank is not None) else
                   {"cfg2": 1.0, "cfg3": 16.0}.get(args.config, 16.0)) * 1.0
     short_steps = est_ms is not None and 0.0 < est_ms < 5.0
