@@ -266,15 +266,23 @@ __attribute__((visibility("default"))) ncclResult_t ncclCommInitAll(ncclComm_t *
 __attribute__((visibility("default"))) ncclResult_t ncclCommDestroy(ncclComm_t c) { delete reinterpret_cast<FakeComm *>(c); return ncclSuccess; }
 __attribute__((visibility("default"))) ncclResult_t ncclCommCount(const ncclComm_t c, int *n) { *n = reinterpret_cast<FakeComm *>(c)->n; return ncclSuccess; }
 __attribute__((visibility("default"))) ncclResult_t ncclCommUserRank(const ncclComm_t c, int *r) { *r = reinterpret_cast<FakeComm *>(c)->rank; return ncclSuccess; }
-static ncclResult_t collective(const char *W, const void *send, void *recv, ncclComm_t c, hipStream_t st) {
+static size_t type_bytes(ncclDataType_t t) { return (t == ncclDouble || t == ncclInt64 || t == ncclUint64) ? 8 : (t == ncclFloat || t == ncclInt32 || t == ncclUint32) ? 4 : (t == ncclHalf || t == ncclBfloat16) ? 2 : 1; }
+// a collective moves THIS rank's contribution only (there is no other process to hear from): all-reduce = copy, all-gather = the rank's own slot.  Enough for the
+// host logic (a maximum over ranks of a time is that time); what is checked is the device, the stream and the buffers the call is made with
+static ncclResult_t collective(const char *W, const void *send, void *recv, size_t bytes, size_t recv_off, ncclComm_t c, hipStream_t st) {
     std::lock_guard<std::mutex> lk(mu); touch(); ++n_collective;
     const FakeComm *f = reinterpret_cast<FakeComm *>(c);
     if (f->dev != cur) bad("%s: communicator of device %d (rank %d) used while device %d is current", W, f->dev, f->rank, cur);
     chk_stream(W, st); P(send); P(recv);
+    if (send && recv && bytes) memmove((char *)recv + recv_off, send, bytes);
     return ncclSuccess;
 }
-__attribute__((visibility("default"))) ncclResult_t ncclAllGather(const void *send, void *recv, size_t, ncclDataType_t, ncclComm_t c, hipStream_t st) { return collective("ncclAllGather", send, recv, c, st); }
-__attribute__((visibility("default"))) ncclResult_t ncclAllReduce(const void *send, void *recv, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t c, hipStream_t st) { return collective("ncclAllReduce", send, recv, c, st); }
+__attribute__((visibility("default"))) ncclResult_t ncclAllGather(const void *send, void *recv, size_t n, ncclDataType_t t, ncclComm_t c, hipStream_t st) {
+    return collective("ncclAllGather", send, recv, n * type_bytes(t), n * type_bytes(t) * (size_t)reinterpret_cast<FakeComm *>(c)->rank, c, st);
+}
+__attribute__((visibility("default"))) ncclResult_t ncclAllReduce(const void *send, void *recv, size_t n, ncclDataType_t t, ncclRedOp_t, ncclComm_t c, hipStream_t st) {
+    return collective("ncclAllReduce", send, recv, n * type_bytes(t), 0, c, st);
+}
 __attribute__((visibility("default"))) ncclResult_t ncclGroupStart(void) { return ncclSuccess; }
 __attribute__((visibility("default"))) ncclResult_t ncclGroupEnd(void) { return ncclSuccess; }
 __attribute__((visibility("default"))) const char *ncclGetErrorString(ncclResult_t) { return "fake rccl"; }

@@ -47,3 +47,60 @@ def test_bench_single_process_queues_its_messages_without_a_host_sync_per_messag
         assert seen[steps][3] == 0 and seen[steps][4] == 0b1111, seen
     assert seen[4][0] == seen[9][0], "host synchronisations grow with the steps: %r" % (seen,)
     assert seen[9][2] > seen[4][2]                                      # ... while the collectives do
+
+
+@pytest.mark.parametrize("n", [2, 4])
+def test_bench_ranks_each_keep_to_their_own_device(n):
+    """bench.py --gpus N the way the driver's launcher would not even have to: the parent starts N rank processes itself (one per device, LOCAL_RANK = device), the
+    ranks exchange the RCCL id through the rendezvous directory, create their communicators (ncclCommInitRank, here the fake one), run the sharded job with the
+    all-gather of the partials on their own stream, and rank 0 prints the line.  Over the fake runtime: every rank touches exactly its own device, no call is made
+    with another device's stream, event or pointer, and the line says N GPUs over RCCL."""
+    import json
+    import re
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc (the HIP headers)")
+    d = os.path.join(HERE, "fake_hip")
+    subprocess.run(["make", "-C", d, "-s"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    env = dict(os.environ, AESGCM_LIB=os.path.join(d, "libaesgcm_fake.so"), FAKEHIP_REPORT="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", str(n), "--gib-per-gpu", "0.0625", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == n and line["config"]["exchange"]["backend"] == "rccl" and line["config"]["exchange"]["ranks_seen"] == n, line["config"]["exchange"]
+    reports = re.findall(r"fakehip: syncs=(\d+) launches=(\d+) collectives=(\d+) violations=(\d+) touched=(\d+)", out.stderr)
+    ranks = [r for r in reports if int(r[1]) > 0]                       # the parent makes no launch (and must not touch a device at all)
+    assert len(ranks) == n, out.stderr[-3000:]
+    assert all(int(r[3]) == 0 for r in reports), reports
+    assert sorted(int(r[4]) for r in ranks) == [1 << k for k in range(n)], reports
+    assert all(int(r[4]) == 0 for r in reports if int(r[1]) == 0), reports
+
+
+def test_bench_under_the_drivers_launcher_command():
+    """the driver's own command line for N > 1 -- python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
+    --gpus N ... -- over the fake runtime: the ranks read RANK / LOCAL_RANK / WORLD_SIZE from the launcher (nothing imports torch), each keeps to its device, rank 0
+    prints ONE line for N GPUs over RCCL"""
+    import json
+    import re
+    import socket
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc (the HIP headers)")
+    try:
+        import torch.distributed.run  # noqa: F401
+    except ImportError:
+        pytest.skip("no torch.distributed.run")
+    d = os.path.join(HERE, "fake_hip")
+    subprocess.run(["make", "-C", d, "-s"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    env = dict(os.environ, AESGCM_LIB=os.path.join(d, "libaesgcm_fake.so"), FAKEHIP_REPORT="1")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--gib-per-gpu", "0.0625", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["exchange"]["backend"] == "rccl" and line["config"]["exchange"]["ranks_seen"] == 2
+    reports = re.findall(r"fakehip: syncs=(\d+) launches=(\d+) collectives=(\d+) violations=(\d+) touched=(\d+)", out.stderr)
+    assert sorted(int(r[4]) for r in reports) == [1, 2] and all(int(r[3]) == 0 for r in reports), reports
