@@ -122,6 +122,48 @@ def test_mgpu_two_devices_equals_single_launch_and_oracle(two, orc):
             x.free()
 
 
+def test_mgpu_queued_messages_and_their_tags(two, orc):
+    """the queued form (round 5): four messages enqueued with tag = NULL -- no host synchronisation -- and their tags collected by one finalize launch, against the
+    oracle; the ring refuses a ninth message; rows on device 1 (many messages under one key through k_rows) ride along"""
+    hip = two
+    key = bytes(orc.fill_splitmix64(32, 0x4B4559))
+    m = hip.MultiGpu(key, [0, 1])
+    n, n0 = (3 << 20) + 21, (1 << 20) + 16 * 7
+    msgs = []
+    for k in range(4):
+        iv = bytes(orc.fill_splitmix64(12, 0x4956 + k))
+        pt = bytes(orc.fill_splitmix64(n, 0xAE5C0100 + k))
+        a, b = hip.DeviceBuffer(n0, device=0), hip.DeviceBuffer(n - n0, device=1)
+        a.upload(pt[:n0]); b.upload(pt[n0:])
+        msgs.append((iv, pt, a, b))
+    for iv, pt, a, b in msgs:
+        assert m.crypt_dev(False, iv, [a.ptr, b.ptr], [n0, n - n0], [a.ptr, b.ptr], want_tag=False) is None
+    tags = m.last_tags(4)
+    m.sync()
+    f = orc.Fast(key)
+    for (iv, pt, a, b), t in zip(msgs, tags):
+        want_ct, want_tag = f.encrypt(iv, b"", pt)
+        assert t == want_tag and bytes(a.download()) + bytes(b.download()) == want_ct
+    for k in range(8):
+        m.crypt_dev(False, msgs[0][0], [msgs[0][2].ptr, msgs[0][3].ptr], [n0, n - n0], [msgs[0][2].ptr, msgs[0][3].ptr], want_tag=False)
+    with pytest.raises(hip.AesGcmError):
+        m.crypt_dev(False, msgs[0][0], [msgs[0][2].ptr, msgs[0][3].ptr], [n0, n - n0], [msgs[0][2].ptr, msgs[0][3].ptr], want_tag=False)
+    assert len(m.last_tags(8)) == 8
+    m.close()
+    # many messages under one key by rows, on device 1
+    cnt, size = 40, 65536 + 1024 + 5
+    ivs, pt = bytes(orc.fill_splitmix64(12 * cnt, 91)), bytes(orc.fill_splitmix64(cnt * size, 92))
+    with hip.Context(key, device=1) as c:
+        d_ivs, d_buf, d_tags = hip.DeviceBuffer(len(ivs), device=1), hip.DeviceBuffer(len(pt), device=1), hip.DeviceBuffer(16 * cnt, device=1)
+        d_ivs.upload(ivs); d_buf.upload(pt)
+        assert c.packets_shape(cnt, size) == hip.SHAPE_ROWS
+        c.packets_crypt_dev(False, cnt, d_ivs.ptr, d_buf.ptr, d_buf.ptr, d_tags.ptr, pkt_len=size)
+        hip.dev_sync(1)
+        ct, tags = bytes(d_buf.download()), bytes(d_tags.download())
+    for p_ in range(cnt):
+        assert (ct[p_ * size:(p_ + 1) * size], tags[16 * p_:16 * p_ + 16]) == f.encrypt(ivs[12 * p_:12 * p_ + 12], b"", pt[p_ * size:(p_ + 1) * size]), p_
+
+
 def _bench(extra, timeout=1500):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "AESGCM_RDZV_DIR")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--gib-per-gpu", "0.5", "--steps", "3", "--warmup", "1",
