@@ -381,6 +381,18 @@ def test_plain_c_caller_frames(hip, frames):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,size", [(200, 65536 + 4096 + 16), (37, (1 << 20) + 48), (300, 20000)])
+def test_plain_c_caller_messages(hip, n, size):
+    """examples/messages.c: many messages under one key as ONE aesgcm_packets_crypt_dev call from C (by rows from 32 KiB per message, from 16 KiB when few) -- a sample
+    against aesgcm_encrypt_dev, all decrypted in place and authenticated, a forged tag reported and its message wiped (wipe_on_auth_fail)"""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "examples"), "-s", "messages"], check=True)
+    r = subprocess.run([os.path.join(root, "examples", "messages"), str(n), str(size)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0 and "MESSAGES OK" in r.stdout and "by rows" in r.stdout, (r.stdout, r.stderr)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("tw", ["", "1", "3", "cyc"])
 def test_body_split_forced_on_small_messages(hip, orc, tw):
     """The head / k_body / tail cut (aesgcm_ctx_split) normally starts at 256 MiB and the cyclic rows at 64 KiB; the context options
