@@ -1,9 +1,9 @@
 // Microbenchmark (round 2): CTR-only AES, BITSLICED over 32 blocks per lane, S-box as a circuit of
-// v_bitop3_b32 (csrc/aesgcm_bs.h), no LDS, no GHASH.  Writes the keystream to HBM (16 B per block, coalesced) like
+// v_bitop3_b32 (tests/host_emul/aesgcm_bs.h), no LDS, no GHASH.  Writes the keystream to HBM (16 B per block, coalesced) like
 // k_main<NR, MODE_KS> does, verifies sampled blocks against the literal byte-wise cipher on the host, and prints GB/s
 // of keystream and the shader clock it sustained -- to be put beside k_main<NR, KS> (profiles/ks_time.py).
 //   hipcc --offload-arch=gfx950 -O3 -o bs_ctr bs_ctr.hip && ./bs_ctr
-#include "aesgcm_bs.h"
+#include "../../tests/host_emul/aesgcm_bs.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>

@@ -8,7 +8,7 @@ is then technology-mapped into 3-input LUTs by cut enumeration and area-oriented
 area with reference counting), which fuses XOR chains into XOR3 and AND-XOR pairs into single instructions.
 
     python tools/sbox_lut3.py            # map, verify, print statistics
-    python tools/sbox_lut3.py --emit profiles/microbench/aesgcm_bs_sbox.inc   # write the mapped S-box (bs_sbox(u32 &x0..&x7))
+    python tools/sbox_lut3.py --emit tests/host_emul/aesgcm_bs_sbox.inc   # write the mapped S-box (bs_sbox(u32 &x0..&x7))
 
 Bit convention: U0 = most significant input bit (x7), S0 = most significant output bit.
 """
