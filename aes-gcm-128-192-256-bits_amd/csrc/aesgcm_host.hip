@@ -628,8 +628,8 @@ int packets_order(aesgcm_ctx *c, const u64 *d_off, size_t n_pkts, hipStream_t st
 
 
 // ---------------------------------------------------------------- many messages under the context's key: by rows (aesgcm_rows.h)
-// the scratch of the path, carved out of one allocation: per message 16 + 4 + 4 bytes and (offset arrays) the two prefix sums, 32 bytes per record slot.  Zero at rest.
-struct RowsScratch { RowsHdr *hdr; u32 *queues; u64 *prefix; u32 *slot_base; RowsRec *rec; unsigned long long *acc; u32 *cnt, *npieces; };
+// the scratch of the path, carved out of one allocation: per message 16 + 4 bytes and (offset arrays) the two prefix sums, 32 bytes per record slot.  Zero at rest.
+struct RowsScratch { RowsHdr *hdr; u32 *queues; u64 *prefix; u32 *slot_base; RowsRec *rec; unsigned long long *acc; u32 *cnt; };
 
 size_t rows_carve(unsigned char *base, size_t slots, size_t n, RowsScratch *r) {
     size_t o = 0;
@@ -642,7 +642,6 @@ size_t rows_carve(unsigned char *base, size_t slots, size_t n, RowsScratch *r) {
     t.rec = (RowsRec *)take(sizeof(RowsRec) * slots);
     t.acc = (unsigned long long *)take(16 * n);
     t.cnt = (u32 *)take(4 * n);
-    t.npieces = (u32 *)take(4 * n);
     if (r) *r = t;
     return o;
 }
@@ -678,7 +677,7 @@ int packets_rows(aesgcm_ctx *c, int decrypt, RowsParams &p, hipStream_t st) {
         if (need < wgs) wgs = (u32)need;
         p.waves = wgs * (AESGCM_BODY_WG / 64);
         rows_cut(p.G, p.waves, c->rows_block, (u64)1 << 30, &p.D, &p.NB, &p.dyn);
-        p.SM = rows_nat_count(g, p.has_aad) + (p.U - 1u) / p.D + 1u;
+        p.SM = p.U ? rows_nat_count(g, p.has_aad) + (p.U - 1u) / p.D + 1u : 0u;
         if ((u64)n * p.SM >= (1ull << 31)) return AESGCM_ETOOLONG;
         slots = n * p.SM;
     } else {
@@ -688,15 +687,16 @@ int packets_rows(aesgcm_ctx *c, int decrypt, RowsParams &p, hipStream_t st) {
     }
     if ((rc = rows_scratch(c, slots, n, st, &r))) return rc;
     p.slot_cap = (u32)slots;
-    p.rec = r.rec; p.acc = r.acc; p.cnt = r.cnt; p.npieces = r.npieces; p.queues = r.queues;
+    p.rec = r.rec; p.acc = r.acc; p.cnt = r.cnt; p.queues = r.queues;
     c->rows_dirty = true;                                                    // until both launches are enqueued
     if (var) {
         p.hdr = r.hdr; p.prefix = r.prefix; p.slot_base = r.slot_base;
         HIPCHK(klaunch_rows_plan(st, p.data_off, p.n_pkts, p.has_aad, p.waves, c->rows_block, (u32)ROWS_NB_CAP, p.slot_cap, r.hdr, r.prefix, r.slot_base));
     }
     p.prio_rows = c->cyc_prio;
-    HIPCHK(klaunch_rows(c->nr, decrypt, wgs, st, c->km, c->tables, p));
-    HIPCHK(klaunch_rows_close(decrypt, (unsigned)((p.slot_cap + ROWS_CLOSE_WG - 1) / ROWS_CLOSE_WG), st, c->km, p));
+    if (wgs) HIPCHK(klaunch_rows(c->nr, decrypt, wgs, st, c->km, c->tables, p));                          // (fixed-size records of no bytes and no AAD have no units: their tags are the closing's alone)
+    const size_t close_lanes = p.slot_cap > n ? p.slot_cap : n;                                              // a lane per record slot and per message
+    HIPCHK(klaunch_rows_close(decrypt, (unsigned)((close_lanes + ROWS_CLOSE_WG - 1) / ROWS_CLOSE_WG), st, c->km, c->tables, p));
     c->rows_dirty = false;
     return AESGCM_OK;
 }

@@ -75,7 +75,7 @@ hipError_t klaunch_batch3(int nr, int dec, int lg, unsigned wgs, hipStream_t st,
 hipError_t klaunch_len_sort(hipStream_t st, const u64 *d_off, u32 n, u32 *bins, u32 *perm);                                                  // k_len_hist, k_len_scan, k_len_scatter
 hipError_t klaunch_rows_plan(hipStream_t st, const u64 *d_off, u32 n, u32 has_aad, u32 waves, u32 force_d, u32 nb_cap, u32 slot_cap, RowsHdr *hdr, u64 *prefix, u32 *slot_base);
 hipError_t klaunch_rows(int nr, int dec, unsigned wgs, hipStream_t st, const KeyMaterial *km, const DevTables *tb, const RowsParams &p);
-hipError_t klaunch_rows_close(int dec, unsigned wgs, hipStream_t st, const KeyMaterial *km, const RowsParams &p);
+hipError_t klaunch_rows_close(int dec, unsigned wgs, hipStream_t st, const KeyMaterial *km, const DevTables *tb, const RowsParams &p);
 hipError_t klaunch_wipe_failed(hipStream_t st, unsigned char *out, const int *auth, const u64 *data_off, u32 n_pkts, u32 pkt_len);
 
 // ---------------------------------------------------------------- host runtime (aesgcm_host.hip)

@@ -1176,18 +1176,17 @@ __global__ __launch_bounds__(AESGCM_BODY_WG, AESGCM_BODY_WPS) void k_rows(const 
         // The pieces of the block.  Every iteration derives what it needs from (g, m) alone -- lengths, offsets, the IV's constants are loaded again per piece, and
         // the record's header is written BEFORE the rows -- so that almost nothing but g, m and the record's address is live across the row loop (an earlier form
         // that carried the message's geometry through it spilled 114 scalars and 252 bytes of scratch).
-        for (u32 guard2 = 0; g < g_end && guard2 <= 2u * D + 4u; ++guard2) {
+        for (u32 guard2 = 0, skipped = 0; g < g_end && guard2 <= 2u * D + 4u && skipped <= p.n_pkts; ++guard2) {
             m = opaque_sgpr(m);
             RowsMsg mq = rows_msg(p, m);
             mq.doff = uniform64(mq.doff); mq.aoff = uniform64(mq.aoff); mq.len = uniform32(mq.len); mq.alen = uniform32(mq.alen);
             const RowsGeom geo = rows_geom(mq.len);
             const u64 g0 = uniform64(rows_unit_base(p, m));
-            if (g >= g0 + rows_units(geo, p.has_aad)) { ++m; continue; }     // the next message (every message has at least its tail unit)
+            if (g >= g0 + rows_units(geo, p.has_aad)) { ++m; if (rows_units(geo, p.has_aad) == 0) { ++skipped; --guard2; } continue; }     // the next message (one without units -- empty, no AAD -- does not count against the bound of the walk)
             const RowsPiece pc = rows_piece(geo, uniform32(rows_slot_base(p, m)), g0, (u32)(g - g0), g_end - g, D);
             RowsRec *rr = p.rec + pc.slot;
             if (lane_id_fresh() == 0) {
-                rr->e = pc.e; rr->msg = m; rr->flags = pc.kind == ROWS_TAIL ? ROWS_REC_VALID : (ROWS_REC_VALID | ROWS_REC_WEIGH);    // (the tail is weighted already: lane terms H^(64 - L))
-                atomicAdd(p.npieces + m, 1u);                                 // what k_rows_close waits for
+                rr->e = pc.e; rr->msg = m; rr->flags = pc.kind == ROWS_TAIL ? ROWS_REC_VALID : (ROWS_REC_VALID | ROWS_REC_WEIGH);    // (the tail is weighted already: lane terms H^(65 - L))
             }
             // every kind of piece takes the lane's index FRESH (lane_id_fresh: opaque to the compiler), so that nothing lane-dependent of the tail and AAD code -- table
             // addresses, byte masks -- is hoisted out of the piece loop and kept in registers across the row loop (first build: 26 scratch accesses per row)
@@ -1203,11 +1202,7 @@ __global__ __launch_bounds__(AESGCM_BODY_WG, AESGCM_BODY_WPS) void k_rows(const 
                     const uint4 acc = rows_run_lane<NR, MODE>(km, tb, p, mq, pc, smem, cc, lane_id_fresh(), dyn ? 0u : p.prio_rows, (tid >> 8) & 3u);
                     z = wave_xor(rows_run_term(km, acc, lane_id_fresh()));
                 } else {
-                    uint4 ej0;
-                    z = wave_xor(rows_tail_lane<NR, MODE == MODE_DEC>(km, p, mq, smem, cc, lane_id_fresh(), &ej0));
-                    const G128 e = mo_to_be(make_uint4((u32)__builtin_amdgcn_readlane((int)ej0.x, 63), (u32)__builtin_amdgcn_readlane((int)ej0.y, 63),
-                                                       (u32)__builtin_amdgcn_readlane((int)ej0.z, 63), (u32)__builtin_amdgcn_readlane((int)ej0.w, 63)));
-                    z.w[0] ^= e.w[0]; z.w[1] ^= e.w[1]; z.w[2] ^= e.w[2]; z.w[3] ^= e.w[3];
+                    z = wave_xor(rows_tail_lane<NR, MODE == MODE_DEC>(km, p, mq, smem, cc, lane_id_fresh()));
                 }
             }
             if (lane_id_fresh() == 0) rr->w = z;
@@ -1216,27 +1211,21 @@ __global__ __launch_bounds__(AESGCM_BODY_WG, AESGCM_BODY_WPS) void k_rows(const 
     }
 }
 
-// a lane per record slot: the record's contribution to its message's tag and its arrival; the lane that counts the message's last piece holds the tag: it stores
-// it and (decrypt) compares.  Memory-side atomics only, as acc_arrive: the XORs have returned before the arrival is counted.  Zero at rest: the lane puts its
-// record's flags back to zero, the closing lane the message's accumulator and counts, workgroup 0 the dispensers.
+// k_rows_close: a lane per message brings what the message owes once, (length block) H ^ E_K(J0) (rows_msg_term), a lane per record slot the record's contribution
+// (the same lanes: index i is message i and slot i), each XORs into the message's accumulator and counts itself arrived; the lane that counts the message's last
+// arrival holds the tag: it stores it and (decrypt) compares.  Memory-side atomics only, as acc_arrive: the XORs have returned before the arrival is counted.  Zero
+// at rest: the lane puts its record's flags back to zero, the closing lane the message's accumulator and count, workgroup 0 the dispensers.
 template <int DEC>
-__global__ __launch_bounds__(ROWS_CLOSE_WG) void k_rows_close(const KeyMaterial *__restrict__ km, const RowsParams p) {
-    if (blockIdx.x == 0 && threadIdx.x < ROWS_NQ) p.queues[16u * threadIdx.x] = 0;
-    const u32 slot = blockIdx.x * ROWS_CLOSE_WG + threadIdx.x;
-    if (slot >= p.slot_cap) return;
-    const RowsRec r = p.rec[slot];
-    if (!(r.flags & ROWS_REC_VALID)) return;
-    p.rec[slot].flags = 0;
-    const G128 z = rows_weigh(km, r);
-    const u32 m = r.msg, expected = p.npieces[m];
+__device__ __forceinline__ void rows_arrive(const RowsParams &p, u32 m, const G128 &z) {
     const unsigned long long ohi = atomicXor(p.acc + 2u * m, ((unsigned long long)z.w[0] << 32) | z.w[1]);
     const unsigned long long olo = atomicXor(p.acc + 2u * m + 1u, ((unsigned long long)z.w[2] << 32) | z.w[3]);
     u32 dep;
     asm volatile("v_and_b32 %0, 0, %1" : "=v"(dep) : "v"((u32)(ohi ^ olo) | (u32)((ohi ^ olo) >> 32)));
     const u32 arrived = atomicAdd(p.cnt + m, 1u + dep);
-    if (arrived + 1u != expected) return;
+    const RowsMsg mq = rows_msg(p, m);
+    if (arrived + 1u != rows_pieces(rows_geom(mq.len), p.has_aad, rows_unit_base(p, m), p.hdr ? p.hdr->D : p.D)) return;
     const unsigned long long hi = atomicExch(p.acc + 2u * m, 0ull), lo = atomicExch(p.acc + 2u * m + 1u, 0ull);
-    p.cnt[m] = 0; p.npieces[m] = 0;
+    p.cnt[m] = 0;
     G128 t; t.w[0] = (u32)(hi >> 32); t.w[1] = (u32)hi; t.w[2] = (u32)(lo >> 32); t.w[3] = (u32)lo;
     const uint4 tag = be_to_mo(t);
     store_block_bytes(p.tags + (size_t)m * 16, tag, 16);
@@ -1248,6 +1237,22 @@ __global__ __launch_bounds__(ROWS_CLOSE_WG) void k_rows_close(const KeyMaterial 
         }
         p.auth[m] = ok;
     }
+}
+static_assert(offsetof(DevTables, te3) - offsetof(DevTables, te0) == 3072 && offsetof(DevTables, te0) % 16 == 0 && ROWS_CLOSE_WG == 256, "rows_close_fill_te: te0 .. te3 as 256 consecutive uint4, one per thread");
+template <int DEC>
+__global__ __launch_bounds__(ROWS_CLOSE_WG) void k_rows_close(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const RowsParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4096];
+    rows_close_fill_te(smem, tb, threadIdx.x);
+    if (blockIdx.x == 0 && threadIdx.x < ROWS_NQ) p.queues[16u * threadIdx.x] = 0;
+    __syncthreads();
+    const u32 i = blockIdx.x * ROWS_CLOSE_WG + threadIdx.x;
+    if (i < p.n_pkts && !(p.hdr && p.hdr->bad))
+        rows_arrive<DEC>(p, i, rows_msg_term(km, reinterpret_cast<const u32 *>(smem + ROWS_CLOSE_LDS_TE), p, i));
+    if (i >= p.slot_cap) return;
+    const RowsRec r = p.rec[i];
+    if (!(r.flags & ROWS_REC_VALID)) return;
+    p.rec[i].flags = 0;
+    rows_arrive<DEC>(p, r.msg, rows_weigh(km, r));
 }
 
 // The cut of a call with offset arrays, on the device (the host does not know the lengths): ONE workgroup.  Units per message -> prefix[0 .. n] and G; the cut
@@ -1294,7 +1299,7 @@ __global__ __launch_bounds__(1024) void k_rows_plan(const u64 *__restrict__ off,
     if (tid == 0) {
         prefix[n] = G; slot_base[n] = (u32)slots;
         hdr->G = slots <= slot_cap ? G : 0ull;                               // (the host sizes the scratch for the worst case; a cut that does not fit would be its bug: then nothing runs)
-        hdr->D = D; hdr->NB = slots <= slot_cap ? NB : 0u; hdr->dyn = dyn;
+        hdr->D = D; hdr->NB = slots <= slot_cap ? NB : 0u; hdr->dyn = dyn; hdr->bad = slots <= slot_cap ? 0u : 1u;
     }
 }
 
@@ -1463,9 +1468,9 @@ hipError_t klaunch_rows(int nr, int dec, unsigned wgs, hipStream_t st, const Key
 #undef LR
     return hipGetLastError();
 }
-hipError_t klaunch_rows_close(int dec, unsigned wgs, hipStream_t st, const KeyMaterial *km, const RowsParams &p) {
-    if (dec) hipLaunchKernelGGL(k_rows_close<1>, dim3(wgs), dim3(ROWS_CLOSE_WG), 0, st, km, p);
-    else hipLaunchKernelGGL(k_rows_close<0>, dim3(wgs), dim3(ROWS_CLOSE_WG), 0, st, km, p);
+hipError_t klaunch_rows_close(int dec, unsigned wgs, hipStream_t st, const KeyMaterial *km, const DevTables *tb, const RowsParams &p) {
+    if (dec) hipLaunchKernelGGL(k_rows_close<1>, dim3(wgs), dim3(ROWS_CLOSE_WG), 0, st, km, tb, p);
+    else hipLaunchKernelGGL(k_rows_close<0>, dim3(wgs), dim3(ROWS_CLOSE_WG), 0, st, km, tb, p);
     return hipGetLastError();
 }
 hipError_t klaunch_wipe_failed(hipStream_t st, unsigned char *out, const int *auth, const u64 *data_off, u32 n_pkts, u32 pkt_len) {

@@ -8,20 +8,27 @@
 //
 //   * a message of `len` bytes is R = len / 1024 whole rows of 64 blocks, aligned to its first block (every packet starts at counter 2,
 //     src/aes_icb.vhd:97-118, so every message IS an aligned body), plus a TAIL of tb <= 64 blocks (the last one ragged), plus its AAD;
-//   * its work is laid on an axis of UNITS: a unit per row, in their order, then ONE unit for the tail -- its blocks and the length block as a right-aligned
-//     row; the lane that holds the length block encrypts counter 1 instead, which is E_K(J0) -- and, when the call has AAD, one for the AAD.  The axes of all
+//   * its work is laid on an axis of UNITS: a unit per row, in their order, then -- when the message does not end on a row -- ONE unit for the tail, its
+//     blocks as a right-aligned row, and, when the call has AAD, one for the AAD.  (Until the middle of round 5 every message had a tail unit, which also held
+//     the length block and encrypted counter 1, E_K(J0): a whole wave's pass through the cipher for one lane's block -- 0.95 ms per 262 144 messages, 5 % of a call
+//     of 64 KiB messages, profiles/r05/rows_tail_cost.txt.  What a message owes ONCE now waits for the closing launch, where a lane does it.)  The axes of all
 //     messages, end to end, are the call: G units.  A RUN of consecutive rows is body_rows_lane's: k_body's row code with the lane constants of all four row
 //     phases in registers and one Horner accumulator of stride H^64, so a run of any length leaves ONE value behind;
 //   * the axis is cut into BLOCKS of D units.  A small or mid-size call is cut into exactly one block per wave of the launch (equal shares, no dispenser:
 //     the launch is as long as its rows and nothing waits for a last chunk); a large one into blocks of 64 units dealt from dispensers, as k_body deals
 //     its chunks.  Where a block's range meets the boundaries of a message it falls into PIECES: a run of rows, a tail, an AAD;
 //   * at the end of a piece the wave does not leave its 64 lane accumulators: lane L's value times H^(63 - L) through the key's per-lane Shoup tables
-//     (KeyMaterial::ltab), XORed over the wave, is the polynomial of the run up to its last block -- a 32-byte RECORD per piece: those 16 bytes, the
+//     (KeyMaterial::ltab, read from DEVICE memory: the vector-memory path is idle in this kernel and its LDS is not -- the same tables staged in the 19 KiB of
+//     LDS behind the T-tables made every size slower on one box, tail-only calls 0.95 -> 1.25 ms, 64 KiB messages 4.55 -> 4.61 ms,
+//     profiles/r05/rows_ab2/lds_lane_tables_ab.txt), XORed over the wave, is the polynomial of the run up to its last block -- a 32-byte RECORD per piece:
+//     those 16 bytes, the
 //     message, and the exponent still due: H^(blocks behind the piece + 2), e = 64 (R - 1 - last row) + tb + 2 (AAD: 64 R + tb + 2; the tail, whose
-//     lane terms are H^(64 - L), needs none).  HBM traffic is 1.00 x algorithmic whatever the cut;
-//   * ONE small launch behind the rows closes every tag (k_rows_close): a LANE per record slot multiplies by H^e bit-serially (any exponent, all lanes
-//     in parallel), XORs the product into the message's accumulator with memory-side atomics and counts itself arrived; the lane that counts a
-//     message's last piece holds its tag  P H^2 ^ L H ^ E_K(J0)  (gcm_ghash.vhd:257,293 re-associated), stores it and, for decrypt, compares.
+//     lane terms are H^(65 - L), needs none).  HBM traffic is 1.00 x algorithmic whatever the cut;
+//   * ONE small launch behind the rows closes every tag (k_rows_close).  A LANE per record slot multiplies by H^e bit-serially (any exponent, all lanes
+//     in parallel), XORs the product into the message's accumulator with memory-side atomics and counts itself arrived; a LANE per message brings what
+//     the message owes once -- (length block) H ^ E_K(J0), the cipher through a 4 KiB copy of the four T-tables in the workgroup's LDS (rows_msg_term) --
+//     the same way.  The lane that counts a message's last arrival holds its tag  P H^2 ^ L H ^ E_K(J0)  (gcm_ghash.vhd:257,293 re-associated), stores
+//     it and, for decrypt, compares.
 //
 // Fixed-size records need no plan: message m owns the units [m U, (m + 1) U).  With offset arrays the lengths are on the device, and one small launch in
 // front (k_rows_plan) makes the two prefix sums there: units and record slots in front of every message.  Everything the two launches share between
@@ -38,7 +45,7 @@
 #define ROWS_REC_WEIGH 2u
 
 struct RowsRec { G128 w; u64 e; u32 msg; u32 flags; };     // one piece: 32 bytes
-struct RowsHdr { u64 G; u32 D, NB, dyn, pad[11]; };         // the cut of a call with offset arrays, made by k_rows_plan
+struct RowsHdr { u64 G; u32 D, NB, dyn, bad, pad[10]; };    // the cut of a call with offset arrays, made by k_rows_plan (bad: it does not fit the scratch -- nothing runs)
 
 struct RowsParams {
     const unsigned char *ivs;                 // n_pkts * 12 bytes
@@ -63,8 +70,7 @@ struct RowsParams {
     u32 slot_cap;                             // record slots the scratch holds (k_rows_close has a lane for each)
     RowsRec *rec;
     unsigned long long *acc;                  // per message {hi, lo}: the XOR of everything that makes its tag
-    u32 *cnt;                                 // per message: pieces arrived (k_rows_close)
-    u32 *npieces;                             // per message: pieces made (k_rows)
+    u32 *cnt;                                 // per message: pieces arrived (k_rows_close; the number due is rows_pieces)
     u32 *queues;                              // ROWS_NQ dispensers, 16 u32 apart
     u32 prio_rows;                            // rotate the waves' issue priorities every so many rows (one block per wave: equal shares must also run at equal speed)
 };
@@ -77,14 +83,14 @@ HD RowsGeom rows_geom(u64 len) {
     g.tb = ((u32)(len & 1023u) + 15u) >> 4;
     return g;
 }
-HD u32 rows_units(const RowsGeom &g, u32 has_aad) { return g.R + 1u + (has_aad ? 1u : 0u); }
-// the natural segment of unit u of a message: its rows (when it has any), the tail, the AAD
+HD u32 rows_units(const RowsGeom &g, u32 has_aad) { return g.R + (g.tb ? 1u : 0u) + (has_aad ? 1u : 0u); }         // 0 for an empty message without AAD: only the closing sees it
+// the natural segment of unit u of a message: its rows (when it has any), the tail (when it has one), the AAD
 HD u32 rows_nat(const RowsGeom &g, u32 u) { return u < g.R ? 0u : (g.R ? 1u : 0u) + (u - g.R); }
-HD u32 rows_nat_count(const RowsGeom &g, u32 has_aad) { return (g.R ? 1u : 0u) + 1u + (has_aad ? 1u : 0u); }
+HD u32 rows_nat_count(const RowsGeom &g, u32 has_aad) { return (g.R ? 1u : 0u) + (g.tb ? 1u : 0u) + (has_aad ? 1u : 0u); }
 // record slots of a message whose units are [g0, g0 + U): a slot per (natural segment, block) pair it can have -- slot = base + nat + (block - first block)
 HD u32 rows_slots(const RowsGeom &g, u32 has_aad, u64 g0, u32 D) {
     const u32 U = rows_units(g, has_aad);
-    return rows_nat_count(g, has_aad) + (u32)((g0 + U - 1u) / D - g0 / D);
+    return U ? rows_nat_count(g, has_aad) + (u32)((g0 + U - 1u) / D - g0 / D) : 0u;
 }
 // the cut of a call of G units for `waves` waves: one block per wave while that is at most ROWS_STATIC_MAX units (or when the dealt cut would not fit the
 // scratch: nb_cap blocks), else blocks of ROWS_DYN_BLOCK units from the dispensers.  force_d > 0: dealt blocks of that many units (tests)
@@ -96,6 +102,11 @@ HD void rows_cut(u64 G, u32 waves, u32 force_d, u64 nb_cap, u32 *D, u32 *NB, u32
     const u64 dd = force_d ? force_d : ROWS_DYN_BLOCK;
     if ((force_d || d > ROWS_STATIC_MAX) && (G + dd - 1u) / dd <= nb_cap) { d = dd; dy = 1; }
     *D = (u32)d; *NB = (u32)((G + d - 1u) / d); *dyn = dy;
+}
+// arrivals k_rows_close counts for a message: the pieces it falls into under the cut -- its run of rows one per block it touches, the tail, the AAD -- and the
+// message's own lane
+HD u32 rows_pieces(const RowsGeom &g, u32 has_aad, u64 g0, u32 D) {
+    return (g.R ? (u32)((g0 + g.R - 1u) / D - g0 / D) + 1u : 0u) + (g.tb ? 1u : 0u) + (has_aad ? 1u : 0u) + 1u;
 }
 // the message's lengths and offsets
 struct RowsMsg { u64 doff, aoff; u32 len, alen; };
@@ -110,7 +121,7 @@ HD RowsMsg rows_msg(const RowsParams &p, u32 m) {
 // the message that owns unit g, and the units in front of a message
 HD u32 rows_find_msg(const RowsParams &p, u64 g) {
     if (!p.prefix) return (u32)(g / p.U);
-    u32 lo = 0, hi = p.n_pkts;                                           // prefix[lo] <= g < prefix[hi]; every message has at least its tail unit
+    u32 lo = 0, hi = p.n_pkts;                                           // prefix[lo] <= g < prefix[hi]: the LAST message that starts at or in front of g -- the one that owns it (messages without units share their successor's start)
     while (hi - lo > 1u) { const u32 mid = lo + ((hi - lo) >> 1); if (p.prefix[mid] <= g) lo = mid; else hi = mid; }
     return lo;
 }
@@ -131,7 +142,7 @@ HD RowsPiece rows_piece(const RowsGeom &g, u32 slot_base, u64 g0, u32 u, u64 roo
         const u32 left = g.R - u;
         pc.len = room < left ? (u32)room : left;
         pc.e = 64ull * (g.R - (pc.r0 + pc.len)) + g.tb + 2u;              // blocks behind the run's last row, and H^2
-    } else if (u == g.R) {
+    } else if (g.tb && u == g.R) {
         pc.kind = ROWS_TAIL;
     } else {
         pc.kind = ROWS_AAD;
@@ -148,46 +159,30 @@ HD uint4 rows_run_lane(const KeyMaterial *__restrict__ km, const DevTables *__re
 // the lane's term of the run's polynomial: B_L H^(63 - L) (XOR over the wave = the polynomial of the run up to its last block)
 HD G128 rows_run_term(const KeyMaterial *__restrict__ km, uint4 acc, u32 lane) { return shoup2_gmul_lds(mo_to_be(acc), km->ltab[63u - lane]); }
 
-// The tail blocks (data blocks 64 R ..., the last one ragged) and the length block [8 len(A)]_64 || [8 len(C)]_64 (gcm_ghash.vhd:257) as ONE right-aligned
-// sequence of tb + 1 <= 65 slots: one row, or two when the tail is a full 64 blocks.  Every lane runs the cipher once per row: data lanes on counter
-// 2 + block index (aes_icb.vhd:97-118), the lane of the length block on counter 1 -- E_K(IV || 0^31 1), the J0 block the RTL latches first
-// (gcm_ghash.vhd:158-169) -- returned in *ej0 by that lane (lane 63).  Returns the lane's term  X_L H^(64 - L)  of  (tail polynomial) H^2 ^ (length block) H.
+// The tail blocks (data blocks 64 R ..., tb of them, 1 <= tb <= 64, the last one ragged) as ONE right-aligned row: lane L >= 64 - tb runs the cipher on counter
+// 2 + block index (aes_icb.vhd:97-118).  Returns the lane's term  X_L H^(65 - L)  of  (tail polynomial) H^2.
 template <int NR, int DEC>
-HD G128 rows_tail_lane(const KeyMaterial *__restrict__ km, const RowsParams &p, const RowsMsg &q, const unsigned char *smem, const CtrConsts &cc, u32 lane, uint4 *ej0) {
+HD G128 rows_tail_lane(const KeyMaterial *__restrict__ km, const RowsParams &p, const RowsMsg &q, const unsigned char *smem, const CtrConsts &cc, u32 lane) {
     const u32 *__restrict__ rk = km->rk;
     const u32 lb = (lane & 31u) << 2;
     const RowsGeom g = rows_geom(q.len);
-    const u32 n_slots = g.tb + 1u, rows = (n_slots + 63u) >> 6, pad = 64u * rows - n_slots;
+    const u32 pad = 64u - g.tb;
     const unsigned char *src = p.in + q.doff;
     unsigned char *dst = p.out + q.doff;
-    uint4 acc = make_uint4(0, 0, 0, 0);
-    *ej0 = make_uint4(0, 0, 0, 0);
-    for (u32 k = 0; k < rows; k++) {
-        if (k) acc = ghash_mul_const_lds(acc, smem);
-        const u32 slot = k * 64u + lane;
-        if (slot < pad) continue;
-        const u32 j = slot - pad;
-        const bool is_len = j == g.tb;
-        const u32 i = 64u * g.R + j;                                                    // block index in the message
+    uint4 gin = make_uint4(0, 0, 0, 0);
+    if (lane >= pad) {
+        const u32 i = 64u * g.R + (lane - pad);                                         // block index in the message
         u32 s0, s1, s2, s3;
-        ctr_rounds_lds<NR>(bswap32(is_len ? 1u : 2u + i), cc, s0, s1, s2, s3, rk, smem, lb);
-        uint4 gin;
-        if (is_len) {
-            *ej0 = make_uint4(s0, s1, s2, s3);
-            const u64 a = (u64)q.alen * 8u, c = (u64)q.len * 8u;
-            gin = make_uint4(bswap32((u32)(a >> 32)), bswap32((u32)a), bswap32((u32)(c >> 32)), bswap32((u32)c));
-        } else {
-            const u32 off = 16u * i, rem = q.len - off;
-            const bool full = rem >= 16u;
-            const uint4 x = full ? gload16_any(src + off) : load_block_bytes(src + off, rem);
-            uint4 y = make_uint4(x.x ^ s0, x.y ^ s1, x.z ^ s2, x.w ^ s3);                // gcm_gctr.vhd:150
-            if (!full) y = mask_block(y, rem);
-            if (full) gstore16_any(dst + off, y); else store_block_bytes(dst + off, y, rem);
-            gin = DEC ? x : y;                                                          // aes_gcm.vhd:207-211
-        }
-        acc = xor4(acc, gin);
+        ctr_rounds_lds<NR>(bswap32(2u + i), cc, s0, s1, s2, s3, rk, smem, lb);
+        const u32 off = 16u * i, rem = q.len - off;
+        const bool full = rem >= 16u;
+        const uint4 x = full ? gload16_any(src + off) : load_block_bytes(src + off, rem);
+        uint4 y = make_uint4(x.x ^ s0, x.y ^ s1, x.z ^ s2, x.w ^ s3);                    // gcm_gctr.vhd:150
+        if (!full) y = mask_block(y, rem);
+        if (full) gstore16_any(dst + off, y); else store_block_bytes(dst + off, y, rem);
+        gin = DEC ? x : y;                                                              // aes_gcm.vhd:207-211
     }
-    return shoup2_gmul_lds(mo_to_be(acc), km->ltab[64u - lane]);
+    return shoup2_gmul_lds(mo_to_be(gin), km->ltab[65u - lane]);
 }
 // The AAD of a message as rows of its own (right-aligned, Horner with H^64: one row up to 1 KiB of AAD): the lane's term  A_L H^(63 - L)  of the AAD's polynomial.
 // alen = 0: zero.
@@ -203,6 +198,43 @@ HD G128 rows_aad_lane(const KeyMaterial *__restrict__ km, const RowsParams &p, c
         acc = xor4(acc, rem >= 16u ? gload16_any(a + off) : load_block_bytes(a + off, rem));
     }
     return shoup2_gmul_lds(mo_to_be(acc), km->ltab[63u - lane]);
+}
+
+// ---- k_rows_close: what a message owes once: (length block) H ^ E_K(J0) -------------------------------
+#define ROWS_CLOSE_LDS_TE 0u                  /* te0 | te1 | te2 | te3 of DevTables, 4 KiB, one copy: the lanes of a wave read where their bytes say (a few-way bank conflict, in a launch that is short) */
+HD void rows_close_fill_te(unsigned char *smem, const DevTables *__restrict__ tb, u32 tid) {          // thread tid of ROWS_CLOSE_WG = 256: one uint4 each
+    *reinterpret_cast<uint4 *>(smem + ROWS_CLOSE_LDS_TE + 16u * tid) = reinterpret_cast<const uint4 *>(tb->te0)[tid];     // te0 .. te3 are consecutive
+}
+// one block through the cipher with the four T-tables at `te` (aes_round.vhd's SB -> SR -> MC as table lookups, config/config_aes_round.py:120-124; the last round,
+// aes_last_round.vhd:76, takes S[x] from byte 1 of te0[x]); memory-order words in and out
+HD uint4 aes_encrypt_te(const u32 *te, const u32 *__restrict__ rk, u32 nr, uint4 in) {
+    const u32 *te0 = te, *te1 = te + 256, *te2 = te + 512, *te3 = te + 768;
+    u32 s0 = in.x ^ rk[0], s1 = in.y ^ rk[1], s2 = in.z ^ rk[2], s3 = in.w ^ rk[3];
+    for (u32 r = 1; r < nr; r++) {
+        const u32 *k = rk + 4u * r;
+        const u32 t0 = te0[s0 & 255u] ^ te1[(s1 >> 8) & 255u] ^ te2[(s2 >> 16) & 255u] ^ te3[s3 >> 24] ^ k[0];
+        const u32 t1 = te0[s1 & 255u] ^ te1[(s2 >> 8) & 255u] ^ te2[(s3 >> 16) & 255u] ^ te3[s0 >> 24] ^ k[1];
+        const u32 t2 = te0[s2 & 255u] ^ te1[(s3 >> 8) & 255u] ^ te2[(s0 >> 16) & 255u] ^ te3[s1 >> 24] ^ k[2];
+        const u32 t3 = te0[s3 & 255u] ^ te1[(s0 >> 8) & 255u] ^ te2[(s1 >> 16) & 255u] ^ te3[s2 >> 24] ^ k[3];
+        s0 = t0; s1 = t1; s2 = t2; s3 = t3;
+    }
+    const u32 *k = rk + 4u * nr;
+#define ROWS_SB(x) ((te0[(x) & 255u] >> 8) & 255u)
+    const u32 o0 = (ROWS_SB(s0) | (ROWS_SB(s1 >> 8) << 8) | (ROWS_SB(s2 >> 16) << 16) | (ROWS_SB(s3 >> 24) << 24)) ^ k[0];
+    const u32 o1 = (ROWS_SB(s1) | (ROWS_SB(s2 >> 8) << 8) | (ROWS_SB(s3 >> 16) << 16) | (ROWS_SB(s0 >> 24) << 24)) ^ k[1];
+    const u32 o2 = (ROWS_SB(s2) | (ROWS_SB(s3 >> 8) << 8) | (ROWS_SB(s0 >> 16) << 16) | (ROWS_SB(s1 >> 24) << 24)) ^ k[2];
+    const u32 o3 = (ROWS_SB(s3) | (ROWS_SB(s0 >> 8) << 8) | (ROWS_SB(s1 >> 16) << 16) | (ROWS_SB(s2 >> 24) << 24)) ^ k[3];
+#undef ROWS_SB
+    return make_uint4(o0, o1, o2, o3);
+}
+// the lane of message m: [8 len(A)]_64 || [8 len(C)]_64 (gcm_ghash.vhd:257) times H, and E_K(IV || 0^31 1), the J0 block the RTL latches first (gcm_ghash.vhd:158-169)
+HD G128 rows_msg_term(const KeyMaterial *__restrict__ km, const u32 *te, const RowsParams &p, u32 m) {
+    const RowsMsg q = rows_msg(p, m);
+    G128 z = tag_len_term(km, q.alen, q.len);
+    const unsigned char *ivp = p.ivs + (size_t)m * 12;
+    const G128 e = mo_to_be(aes_encrypt_te(te, km->rk, km->nr, make_uint4(load_le32(ivp), load_le32(ivp + 4), load_le32(ivp + 8), 0x01000000u)));
+    z.w[0] ^= e.w[0]; z.w[1] ^= e.w[1]; z.w[2] ^= e.w[2]; z.w[3] ^= e.w[3];
+    return z;
 }
 
 // ---- k_rows_close: a record's contribution ----------------------------------------------------------

@@ -243,10 +243,10 @@ hipError_t klaunch_rows_plan(hipStream_t st, const u64 *d_off, u32, u32, u32, u3
 }
 static void rows_ptrs(const char *W, const KeyMaterial *km, const RowsParams &p) {
     P(km); P(p.ivs); P(p.aad); P(p.in); P(p.out); P(p.tags); P(p.expect); P(p.auth); P(p.data_off); P(p.aad_off); P(p.hdr); P(p.prefix); P(p.slot_base);
-    P(p.rec); P(p.acc); P(p.cnt); P(p.npieces); P(p.queues);
+    P(p.rec); P(p.acc); P(p.cnt); P(p.queues);
 }
 hipError_t klaunch_rows(int, int, unsigned, hipStream_t st, const KeyMaterial *km, const DevTables *tb, const RowsParams &p) { LAUNCH("k_rows", st); BIG_LDS(); P(tb); rows_ptrs(W, km, p); return hipSuccess; }
-hipError_t klaunch_rows_close(int, unsigned, hipStream_t st, const KeyMaterial *km, const RowsParams &p) { LAUNCH("k_rows_close", st); rows_ptrs(W, km, p); return hipSuccess; }
+hipError_t klaunch_rows_close(int, unsigned, hipStream_t st, const KeyMaterial *km, const DevTables *tb, const RowsParams &p) { LAUNCH("k_rows_close", st); P(tb); rows_ptrs(W, km, p); return hipSuccess; }
 hipError_t klaunch_wipe_failed(hipStream_t st, unsigned char *out, const int *auth, const u64 *data_off, u32, u32) { LAUNCH("k_wipe_failed", st); P(out); P(auth); P(data_off); return hipSuccess; }
 
 // ---------------------------------------------------------------- RCCL (reached by csrc/aesgcm_comm.hip through dlopen of this very library)

@@ -818,15 +818,15 @@ static void emu_rows_nr(const KeyMaterial *km, int dec, RowsParams &p, u32 waves
         const RowsGeom g = rows_geom(p.pkt_len);
         p.U = rows_units(g, p.has_aad); p.G = (u64)n * p.U;
         rows_cut(p.G, waves, force_d, (u64)1 << 30, &p.D, &p.NB, &p.dyn);
-        p.SM = rows_nat_count(g, p.has_aad) + (p.U - 1u) / p.D + 1u;
+        p.SM = p.U ? rows_nat_count(g, p.has_aad) + (p.U - 1u) / p.D + 1u : 0u;
         slots = (size_t)n * p.SM;
     }
     p.slot_cap = (u32)slots;
     std::vector<RowsRec> rec(slots + 1);
     memset(rec.data(), 0, rec.size() * sizeof(RowsRec));
     std::vector<unsigned long long> acc(2 * (size_t)n + 2, 0);
-    std::vector<u32> cnt(n + 1, 0), npieces(n + 1, 0);
-    p.rec = rec.data(); p.acc = acc.data(); p.cnt = cnt.data(); p.npieces = npieces.data();
+    std::vector<u32> cnt(n + 1, 0), made_of(n + 1, 0);
+    p.rec = rec.data(); p.acc = acc.data(); p.cnt = cnt.data();
     const u64 G = p.hdr ? p.hdr->G : p.G;
     const u32 D = p.hdr ? p.hdr->D : p.D, NB = p.hdr ? p.hdr->NB : p.NB, dyn = p.hdr ? p.hdr->dyn : p.dyn;
     CHECK(dyn || NB <= waves, "rows: %u blocks for %u waves", NB, waves);
@@ -840,13 +840,13 @@ static void emu_rows_nr(const KeyMaterial *km, int dec, RowsParams &p, u32 waves
             const RowsGeom geo = rows_geom(mq.len);
             const u64 g0 = rows_unit_base(p, m);
             const u32 U = rows_units(geo, p.has_aad), sbase = rows_slot_base(p, m);
+            if (U == 0) { ++m; continue; }                                 // an empty message without AAD has no unit: the closing alone makes its tag
             CHECK(g >= g0 && g < g0 + U, "rows: unit %llu outside message %u", (unsigned long long)g, m);
             u32 made = 0;
             while (g < g_end && g < g0 + U) {
                 const RowsPiece pc = rows_piece(geo, sbase, g0, (u32)(g - g0), g_end - g, D);
                 G128 z = {{0, 0, 0, 0}};
                 u32 flags = ROWS_REC_VALID | ROWS_REC_WEIGH;
-                uint4 e63 = make_uint4(0, 0, 0, 0);
                 for (u32 lane = 0; lane < 64; lane++) {
                     const CtrConsts cc = ctr_round1_consts(load_le32(p.ivs + 12 * m), load_le32(p.ivs + 12 * m + 4), load_le32(p.ivs + 12 * m + 8), km->rk, smem, (lane & 31u) << 2);
                     if (pc.kind == ROWS_RUN) {
@@ -855,40 +855,47 @@ static void emu_rows_nr(const KeyMaterial *km, int dec, RowsParams &p, u32 waves
                     } else if (pc.kind == ROWS_AAD) {
                         xor_g(z, rows_aad_lane(km, p, mq, smem, lane));
                     } else {
-                        uint4 ej0;
-                        xor_g(z, dec ? rows_tail_lane<NR, 1>(km, p, mq, smem, cc, lane, &ej0) : rows_tail_lane<NR, 0>(km, p, mq, smem, cc, lane, &ej0));
-                        if (lane == 63) e63 = ej0;
+                        xor_g(z, dec ? rows_tail_lane<NR, 1>(km, p, mq, smem, cc, lane) : rows_tail_lane<NR, 0>(km, p, mq, smem, cc, lane));
                     }
                 }
-                if (pc.kind == ROWS_TAIL) { xor_g(z, mo_to_be(e63)); flags = ROWS_REC_VALID; }
+                if (pc.kind == ROWS_TAIL) flags = ROWS_REC_VALID;
                 CHECK(pc.slot < slots && !rec[pc.slot].flags, "rows: slot %u of %zu taken twice (message %u)", pc.slot, slots, m);
                 RowsRec r; r.w = z; r.e = pc.e; r.msg = m; r.flags = flags;
                 rec[pc.slot] = r;
                 g += pc.len; ++made;
             }
-            npieces[m] += made;
+            made_of[m] += made;
             ++m;
         }
     }
-    // k_rows_close: every slot, last first
+    // k_rows_close: a lane per message and per record slot, last first; lane i is message i (its length block and E_K(J0)) and slot i
     u32 finals = 0;
-    for (size_t k = 0; k < slots; k++) {
-        const size_t slot = slots - 1 - k;
-        const RowsRec r = rec[slot];
-        if (!(r.flags & ROWS_REC_VALID)) continue;
-        rec[slot].flags = 0;
-        const G128 z = rows_weigh(km, r);
-        const u32 m = r.msg;
+    auto arrive = [&](u32 m, const G128 &z) {
         acc[2 * m] ^= ((unsigned long long)z.w[0] << 32) | z.w[1]; acc[2 * m + 1] ^= ((unsigned long long)z.w[2] << 32) | z.w[3];
-        if (++cnt[m] == npieces[m]) {
+        const RowsMsg mq = rows_msg(p, m);
+        if (++cnt[m] == rows_pieces(rows_geom(mq.len), p.has_aad, rows_unit_base(p, m), D)) {
             G128 t; t.w[0] = (u32)(acc[2 * m] >> 32); t.w[1] = (u32)acc[2 * m]; t.w[2] = (u32)(acc[2 * m + 1] >> 32); t.w[3] = (u32)acc[2 * m + 1];
-            acc[2 * m] = acc[2 * m + 1] = 0; cnt[m] = 0; npieces[m] = 0;
+            acc[2 * m] = acc[2 * m + 1] = 0; cnt[m] = 0;
             store_block_bytes(p.tags + (size_t)m * 16, be_to_mo(t), 16);
             ++finals;
         }
+    };
+    const size_t lanes = slots > n ? slots : n;
+    for (size_t k = 0; k < lanes; k++) {
+        const size_t i = lanes - 1 - k;
+        if (i < n) arrive((u32)i, rows_msg_term(km, g_tb.te0, p, (u32)i));
+        if (i >= slots) continue;
+        const RowsRec r = rec[i];
+        if (!(r.flags & ROWS_REC_VALID)) continue;
+        rec[i].flags = 0;
+        arrive(r.msg, rows_weigh(km, r));
     }
     CHECK(finals == n, "rows: %u of %u messages closed", finals, n);
-    for (u32 m = 0; m < n; m++) CHECK(!acc[2 * m] && !acc[2 * m + 1] && !cnt[m] && !npieces[m], "rows: message %u not zero at rest", m);
+    for (u32 m = 0; m < n; m++) {
+        CHECK(!acc[2 * m] && !acc[2 * m + 1] && !cnt[m], "rows: message %u not zero at rest", m);
+        const RowsMsg mq = rows_msg(p, m);
+        CHECK(made_of[m] + 1u == rows_pieces(rows_geom(mq.len), p.has_aad, rows_unit_base(p, m), D), "rows: message %u fell into %u pieces", m, made_of[m]);
+    }
 }
 static void test_rows(int key_len, u64 seed, u32 waves, u32 force_d, bool var, const std::vector<u32> &lens, const std::vector<u32> &aads, u32 misalign = 0) {
     auto key = rnd(key_len, seed);
@@ -904,7 +911,7 @@ static void test_rows(int key_len, u64 seed, u32 waves, u32 force_d, bool var, c
         RowsParams p; memset(&p, 0, sizeof p);
         p.ivs = ivs.data(); p.aad = aad.data(); p.in = dec ? out.p : in.p; p.out = out.p; p.tags = dec ? tags2.data() : tags.data();
         p.n_pkts = n;
-        if (var) { p.data_off = doff.data(); p.aad_off = aoff.data(); }
+        if (var) { p.data_off = doff.data(); if (aoff[n]) p.aad_off = aoff.data(); }        // (no AAD anywhere: no AAD array -- empty messages then have no unit at all)
         else { p.pkt_len = lens[0]; p.aad_len = aads[0]; }
         if (E.km.nr == 10) emu_rows_nr<10>(&E.km, dec, p, waves, force_d); else if (E.km.nr == 12) emu_rows_nr<12>(&E.km, dec, p, waves, force_d); else emu_rows_nr<14>(&E.km, dec, p, waves, force_d);
         if (!dec) {
@@ -977,6 +984,12 @@ int main(int argc, char **argv) {
     test_rows(24, 211, 16, 7, false, {4096 * 5 + 2048 + 9, 4096 * 5 + 2048 + 9, 4096 * 5 + 2048 + 9}, {0, 0, 0});
     test_rows(24, 206, 16, 0, false, {700, 700}, {0, 0});                       // records shorter than a row: no strand at all, tails only
     test_rows(32, 207, 4, 2, true, {4096 * 3 + 5, 9000, 1024 * 5}, {7, 0, 16}, 5);   // packed back to back from an odd byte address
+    test_rows(32, 212, 3, 0, true, {0, 0, 0, 2048, 0, 1024, 1024 + 1009, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0, 0});   // messages without a unit (empty, no AAD) first, in a row and last; a tail of 64 blocks
+    test_rows(16, 213, 5, 1, true, {0, 0, 3000, 0}, {0, 0, 0, 0});
+    test_rows(24, 214, 4, 0, false, {0, 0, 0}, {0, 0, 0});                       // fixed-size records of no bytes: no unit in the whole call, the closing makes the tags
+    test_rows(24, 215, 4, 0, false, {0, 0, 0}, {5, 5, 5});                       // ... with AAD: an AAD unit each
+    test_rows(32, 216, 4, 0, false, {1024, 1024, 1024, 1024, 1024}, {0, 0, 0, 0, 0});   // one row and nothing else per message
+    test_rows(16, 217, 2, 0, false, {2033, 2033, 2033}, {0, 0, 0});              // a tail of 64 blocks (the last one byte long)
     if (level > 1) {
         test_key(32, 1, 7, {{123, 16 * 64 * 1100 + 11}});     // 1100 chunks: two stage-1 workgroups
         test_key(16, 0, 8, {{0, 16 * W * 600}});              // production rule, > GMAX chunks of Tw = 16

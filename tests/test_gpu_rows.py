@@ -18,8 +18,9 @@ def _up(hip, b):
     return d
 
 
-def _check_var(hip, orc, ctx, key, lens, aads, seed, hint, misalign=0, forged=()):
-    """encrypt the messages (offset arrays) through ctx, compare with the oracle, decrypt in place with the tags of `forged` spoiled"""
+def _check_var(hip, orc, ctx, key, lens, aads, seed, hint, misalign=0, forged=(), aad_array=True):
+    """encrypt the messages (offset arrays) through ctx, compare with the oracle, decrypt in place with the tags of `forged` spoiled (aad_array = False: the call
+    has no AAD at all -- an empty message then has no unit of work in the row launch, its tag is the closing launch's alone)"""
     m = len(lens)
     f = orc.Fast(key)
     doff, aoff = [misalign], [0]
@@ -30,7 +31,9 @@ def _check_var(hip, orc, ctx, key, lens, aads, seed, hint, misalign=0, forged=()
     d_ivs, d_aad, d_buf = _up(hip, ivs), _up(hip, aad), _up(hip, pt)
     d_doff, d_aoff = _up(hip, struct.pack("<%dQ" % (m + 1), *doff)), _up(hip, struct.pack("<%dQ" % (m + 1), *aoff))
     d_tags, d_auth = hip.DeviceBuffer(16 * m), hip.DeviceBuffer(4 * m)
-    ctx.packets_crypt_dev(False, m, d_ivs.ptr, d_buf.ptr, d_buf.ptr, d_tags.ptr, pkt_len=hint, d_data_off=d_doff.ptr, d_aad=d_aad.ptr, d_aad_off=d_aoff.ptr)
+    akw = dict(d_aad=d_aad.ptr, d_aad_off=d_aoff.ptr) if aad_array else {}
+    assert aad_array or not any(aads)
+    ctx.packets_crypt_dev(False, m, d_ivs.ptr, d_buf.ptr, d_buf.ptr, d_tags.ptr, pkt_len=hint, d_data_off=d_doff.ptr, **akw)
     hip.dev_sync()
     ct, tags = bytes(d_buf.download(doff[-1])), bytes(d_tags.download())
     assert ct[:misalign] == pt[:misalign]
@@ -42,8 +45,7 @@ def _check_var(hip, orc, ctx, key, lens, aads, seed, hint, misalign=0, forged=()
     for p in forged:
         bad[16 * p + (p % 16)] ^= 1 << (p % 8)
     d_exp, d_t2 = _up(hip, bytes(bad)), hip.DeviceBuffer(16 * m)
-    ctx.packets_crypt_dev(True, m, d_ivs.ptr, d_buf.ptr, d_buf.ptr, d_t2.ptr, pkt_len=hint, d_data_off=d_doff.ptr, d_aad=d_aad.ptr, d_aad_off=d_aoff.ptr,
-                          d_expect_tags=d_exp.ptr, d_auth=d_auth.ptr)
+    ctx.packets_crypt_dev(True, m, d_ivs.ptr, d_buf.ptr, d_buf.ptr, d_t2.ptr, pkt_len=hint, d_data_off=d_doff.ptr, d_expect_tags=d_exp.ptr, d_auth=d_auth.ptr, **akw)
     hip.dev_sync()
     assert bytes(d_buf.download(doff[-1])) == pt
     assert bytes(d_t2.download()) == tags
@@ -76,13 +78,27 @@ def test_dealt_blocks_of_forced_sizes(hip, orc, d):
     _check_var(hip, orc, ctx, key, lens, aads, 830 + d, hint=1 << 16, forged=(0, 14))
 
 
+@pytest.mark.parametrize("klen", [16, 32])
+def test_messages_without_a_unit_of_work(hip, orc, klen):
+    """no AAD in the call and empty messages among the others -- first, several in a row, last: the row launch has nothing for them (rows_units = 0), the closing
+    launch's message lanes make their tags, E_K(J0) alone; messages that end on a row have no tail unit; a tail of 64 blocks"""
+    key = splitmix_bytes(7150 + klen, klen)
+    ctx = hip.Context(key)
+    lens = [0, 0, 0, 65536, 0, 1024, 70000, 0, 0, 66560 + 1009, 3 * 1024, 0]
+    _check_var(hip, orc, ctx, key, lens, [0] * len(lens), 840 + klen, hint=65536, forged=(1, 3, 11), aad_array=False)
+    with hip.debug_library() as dbg:
+        dbg.force(pkt_rows=1)
+        _check_var(hip, orc, hip.Context(key), key, [0] * 300, [0] * 300, 845 + klen, hint=65536, forged=(7,), aad_array=False)      # nothing but empty messages: no row launch work at all
+
+
 def test_packed_from_an_odd_byte_address(hip, orc):
     key = splitmix_bytes(7200, 16)
     ctx = hip.Context(key)
     _check_var(hip, orc, ctx, key, [70001, 65536, 99999, 131073], [0, 5, 0, 20], 850, hint=65536, misalign=5, forged=(1,))
 
 
-@pytest.mark.parametrize("klen,pkt,al,n", [(32, 65536, 0, 300), (16, 65536 + 48, 20, 70), (24, 1 << 20, 16, 9), (32, 3 * 4096 + 1024 + 1, 0, 40), (16, 700, 12, 50)])
+@pytest.mark.parametrize("klen,pkt,al,n", [(32, 65536, 0, 300), (16, 65536 + 48, 20, 70), (24, 1 << 20, 16, 9), (32, 3 * 4096 + 1024 + 1, 0, 40), (16, 700, 12, 50),
+                                           (32, 1024, 0, 77), (16, 2033, 0, 30), (24, 0, 0, 20), (24, 0, 7, 20), (32, 4096, 20, 1000)])
 def test_fixed_size_records(hip, orc, klen, pkt, al, n):
     """fixed-size records: the library's own rule (by rows from 64 KiB per packet) and, below that, rows forced through the debug library -- including records
     shorter than a row, which then are tails only"""
