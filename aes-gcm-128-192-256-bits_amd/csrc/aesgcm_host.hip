@@ -701,16 +701,20 @@ int packets_rows(aesgcm_ctx *c, int decrypt, RowsParams &p, hipStream_t st) {
     return AESGCM_OK;
 }
 
-// does a call go by rows?  Fixed-size records: from rows_min bytes per packet (32 KiB), and from half of that while the packets would not fill the packet kernels'
-// resident lanes.  Measured, AES-256, GiB/s by rows / by the packet kernels (profiles/r05/rows_min_sweep.txt): 32 KiB x 131072 856 / 747, x 8192 804 / 372,
-// x 1024 420 / 207; 16 KiB x 262144 779 / 820, x 16384 722 / 647, x 4096 640 / 435; 8 KiB x 524288 626 / 745, x 32768 576 / 649; 4 KiB x 2^20 416 / 829.
+// does a call go by rows?  A packet that does not end on a 1 KiB row costs the row launch a tail piece -- a wave's pass through the cipher for at most 64 blocks --
+// so the mark is rows_min (16 KiB) for those and half of it for packets that are whole rows.  Measured on one box after E_K(J0) moved to the closing launch,
+// AES-256, GiB/s by rows / by the packet kernels (profiles/r05/rows_min_sweep2.txt): whole rows -- 32 KiB x 131072 906 / 737; 16 KiB x 262144 862 / 798, x 16384
+// 635 / 563, x 4096 595 / 400; 8 KiB x 524288 785 / 737, x 32768 602 / 562, x 4096 465 / 255, x 1024 189 / 130; 4 KiB x 2^20 623 / 828, x 65536 528 / 566;
+// with a tail of one block -- 32 KiB + 16 832 / 680; 16 KiB + 16 x 262144 757 / 763, x 16384 594 / 551, x 4096 540 / 371; 8 KiB + 16 x 524288 601 / 707.
 // Offset arrays: the host does not know the lengths; the caller's pkt_len, otherwise unused in that form, is its word for the typical packet (0 = frames)
 bool packets_by_rows(const aesgcm_ctx *c, size_t n_pkts, size_t pkt_len) {
+    (void)n_pkts;
 #ifdef AESGCM_DEBUG_KNOBS
     if (g_force.pkt_rows) return g_force.pkt_rows == 1;
+    if (g_force.pkt_lanes) return false;                                     // a forced shape of the packet kernels means the packet kernels
 #endif
     if (!c->rows_min) return false;
-    return pkt_len >= c->rows_min || (2 * pkt_len >= c->rows_min && n_pkts < 98304);
+    return pkt_len >= c->rows_min || (2 * pkt_len >= c->rows_min && pkt_len % 1024 == 0);
 }
 
 // zero the output of every packet whose d_auth[] entry is 0 (behind the launch that wrote it, on the same stream)

@@ -165,7 +165,7 @@ struct aesgcm_ctx {
     unsigned char *rows_buf = nullptr;
     size_t rows_cap_slots = 0, rows_cap_n = 0;
     bool rows_dirty = true;            // the scratch is not known to be zero (fresh, or a launch failed between k_rows and k_rows_close)
-    u64 rows_min = (u64)32 << 10;      // packets of at least this many bytes go by rows (option "rows_min"; 0 = never).  With offset arrays the caller's pkt_len is the hint that says so
+    u64 rows_min = (u64)16 << 10;      // packets of at least this many bytes go by rows, packets that are whole 1 KiB rows from half of it (option "rows_min"; 0 = never).  With offset arrays the caller's pkt_len is the hint that says so
     u32 rows_block = 0;                // option "rows_block": units per dealt block of k_rows (0 = the library's cut: one block per wave, or blocks of ROWS_DYN_BLOCK for large calls)
     // streaming state
     bool s_active = false, s_data = false, s_ragged = false;

@@ -169,8 +169,9 @@ HD G128 rows_tail_lane(const KeyMaterial *__restrict__ km, const RowsParams &p, 
     const u32 pad = 64u - g.tb;
     const unsigned char *src = p.in + q.doff;
     unsigned char *dst = p.out + q.doff;
-    uint4 gin = make_uint4(0, 0, 0, 0);
-    if (lane >= pad) {
+    G128 z = {{0, 0, 0, 0}};
+    if (lane >= pad) {                                                                  // (the table multiply too: its 32 reads per lane go to 64 different tables, and the memory path takes them a lane at a time)
+        uint4 gin;
         const u32 i = 64u * g.R + (lane - pad);                                         // block index in the message
         u32 s0, s1, s2, s3;
         ctr_rounds_lds<NR>(bswap32(2u + i), cc, s0, s1, s2, s3, rk, smem, lb);
@@ -181,8 +182,9 @@ HD G128 rows_tail_lane(const KeyMaterial *__restrict__ km, const RowsParams &p, 
         if (!full) y = mask_block(y, rem);
         if (full) gstore16_any(dst + off, y); else store_block_bytes(dst + off, y, rem);
         gin = DEC ? x : y;                                                              // aes_gcm.vhd:207-211
+        z = shoup2_gmul_lds(mo_to_be(gin), km->ltab[65u - lane]);
     }
-    return shoup2_gmul_lds(mo_to_be(gin), km->ltab[65u - lane]);
+    return z;
 }
 // The AAD of a message as rows of its own (right-aligned, Horner with H^64: one row up to 1 KiB of AAD): the lane's term  A_L H^(63 - L)  of the AAD's polynomial.
 // alen = 0: zero.
@@ -197,7 +199,9 @@ HD G128 rows_aad_lane(const KeyMaterial *__restrict__ km, const RowsParams &p, c
         const u32 off = 16u * (slot - pad), rem = q.alen - off;
         acc = xor4(acc, rem >= 16u ? gload16_any(a + off) : load_block_bytes(a + off, rem));
     }
-    return shoup2_gmul_lds(mo_to_be(acc), km->ltab[63u - lane]);
+    G128 z = {{0, 0, 0, 0}};
+    if (rows && lane >= (n_aad < 64u ? 64u - n_aad : 0u)) z = shoup2_gmul_lds(mo_to_be(acc), km->ltab[63u - lane]);      // only the lanes that hold a block
+    return z;
 }
 
 // ---- k_rows_close: what a message owes once: (length block) H ^ E_K(J0) -------------------------------

@@ -100,8 +100,8 @@ def test_packed_from_an_odd_byte_address(hip, orc):
 @pytest.mark.parametrize("klen,pkt,al,n", [(32, 65536, 0, 300), (16, 65536 + 48, 20, 70), (24, 1 << 20, 16, 9), (32, 3 * 4096 + 1024 + 1, 0, 40), (16, 700, 12, 50),
                                            (32, 1024, 0, 77), (16, 2033, 0, 30), (24, 0, 0, 20), (24, 0, 7, 20), (32, 4096, 20, 1000)])
 def test_fixed_size_records(hip, orc, klen, pkt, al, n):
-    """fixed-size records: the library's own rule (by rows from 64 KiB per packet) and, below that, rows forced through the debug library -- including records
-    shorter than a row, which then are tails only"""
+    """fixed-size records: the library's own rule (by rows from 16 KiB per packet, from 8 KiB for whole rows) and, below that, rows forced through the debug
+    library -- including records shorter than a row, which then are tails only, and records of no bytes, which are the closing launch's alone"""
     key = splitmix_bytes(7300 + pkt % 1000, klen)
     f = orc.Fast(key)
     ivs, aad, pt = splitmix_bytes(871, 12 * n), splitmix_bytes(872, max(al * n, 16)), splitmix_bytes(873, pkt * n)
@@ -122,13 +122,26 @@ def test_fixed_size_records(hip, orc, klen, pkt, al, n):
         assert bytes(d_buf.download(pkt * n)) == pt
         assert set(struct.unpack("<%di" % n, bytes(d_auth.download()))) == {1}
 
-    if pkt >= 65536:
+    if pkt >= 16384:
         ctx = hip.Context(key)
         assert ctx.packets_shape(n, pkt) == hip.SHAPE_ROWS
         return run(ctx)
     with hip.debug_library() as dbg:
         dbg.force(pkt_rows=1)
         run(hip.Context(key))
+
+
+def test_the_rule_that_sends_a_call_by_rows(hip):
+    """aesgcm_packets_shape: by rows from 16 KiB per packet, from 8 KiB when the packets are whole 1 KiB rows (no tail piece); "rows_min" moves the mark, 0 = never"""
+    ctx = hip.Context(bytes(32))
+    rows = lambda n, pkt, var=False: ctx.packets_shape(n, pkt, var) == hip.SHAPE_ROWS
+    assert rows(1000, 16384) and rows(1000, 16400) and rows(1 << 20, 1 << 20) and rows(5, 8192) and rows(1 << 19, 9216)
+    assert not rows(1000, 8208) and not rows(1000, 4096) and not rows(1000, 16383) and not rows(10, 1514)
+    assert rows(1000, 65536, True) and not rows(1000, 0, True)
+    ctx.set_option("rows_min", 65536)
+    assert rows(10, 65536) and rows(10, 32768) and not rows(10, 32784) and not rows(10, 16384)
+    ctx.set_option("rows_min", 0)
+    assert not rows(10, 1 << 20)
 
 
 def test_rows_and_packet_kernels_agree_and_calls_queue_back_to_back(hip, orc):
