@@ -628,8 +628,8 @@ int packets_order(aesgcm_ctx *c, const u64 *d_off, size_t n_pkts, hipStream_t st
 
 
 // ---------------------------------------------------------------- many messages under the context's key: by rows (aesgcm_rows.h)
-// the scratch of the path, carved out of one allocation: per message 16 + 4 bytes and (offset arrays) the two prefix sums, 32 bytes per record slot.  Zero at rest.
-struct RowsScratch { RowsHdr *hdr; u32 *queues; u64 *prefix; u32 *slot_base; RowsRec *rec; unsigned long long *acc; u32 *cnt; };
+// the scratch of the path, carved out of one allocation: per message 16 + 4 bytes and (offset arrays) the three prefix sums, 32 bytes per record slot.  Zero at rest.
+struct RowsScratch { RowsHdr *hdr; u32 *queues; u64 *prefix, *sprefix; u32 *slot_base; RowsRec *rec; unsigned long long *acc; u32 *cnt; };
 
 size_t rows_carve(unsigned char *base, size_t slots, size_t n, RowsScratch *r) {
     size_t o = 0;
@@ -638,6 +638,7 @@ size_t rows_carve(unsigned char *base, size_t slots, size_t n, RowsScratch *r) {
     t.hdr = (RowsHdr *)take(sizeof(RowsHdr));
     t.queues = (u32 *)take(64 * ROWS_NQ);
     t.prefix = (u64 *)take(8 * (n + 1));
+    t.sprefix = (u64 *)take(8 * (n + 1));
     t.slot_base = (u32 *)take(4 * (n + 1));
     t.rec = (RowsRec *)take(sizeof(RowsRec) * slots);
     t.acc = (unsigned long long *)take(16 * n);
@@ -665,24 +666,24 @@ int packets_rows(aesgcm_ctx *c, int decrypt, RowsParams &p, hipStream_t st) {
     const size_t n = p.n_pkts;
     RowsScratch r;
     int rc;
-    const bool var = p.data_off != nullptr;
-    p.has_aad = (p.aad_off || p.aad_len) ? 1u : 0u;
+    const bool var = p.data_off != nullptr || p.aad_off != nullptr;          // a length of either kind on the device: the plan is made there
     u32 wgs = (u32)c->G / 2;                                                 // one 141 KiB workgroup per CU
     size_t slots;
     if (!var) {
         const RowsGeom g = rows_geom(p.pkt_len);
-        p.U = rows_units(g, p.has_aad);
+        const u32 na = rows_na(p.aad_len);
+        p.U = rows_units(g, na); p.S = rows_smalls(g, na);
         p.G = (u64)n * p.U;
         const u64 need = (p.G + AESGCM_BODY_WG / 64 - 1) / (AESGCM_BODY_WG / 64);     // at least a unit per wave
         if (need < wgs) wgs = (u32)need;
         p.waves = wgs * (AESGCM_BODY_WG / 64);
         rows_cut(p.G, p.waves, c->rows_block, (u64)1 << 30, &p.D, &p.NB, &p.dyn);
-        p.SM = p.U ? rows_nat_count(g, p.has_aad) + (p.U - 1u) / p.D + 1u : 0u;
+        p.SM = p.U ? rows_nat_count(g, na) + (p.U - 1u) / p.D + 1u : 0u;
         if ((u64)n * p.SM >= (1ull << 31)) return AESGCM_ETOOLONG;
         slots = n * p.SM;
     } else {
         p.waves = wgs * (AESGCM_BODY_WG / 64);
-        slots = 4 * n + ROWS_NB_CAP;                                         // at most 3 natural segments per message (rows, tail, AAD) and one more slot per block boundary inside it
+        slots = ROWS_SLOTS_PER_MSG * n + ROWS_NB_CAP;                        // a run and a long AAD per message, and one more slot per block boundary inside its rows
         if (slots >= (1ull << 31)) return AESGCM_ETOOLONG;
     }
     if ((rc = rows_scratch(c, slots, n, st, &r))) return rc;
@@ -690,31 +691,31 @@ int packets_rows(aesgcm_ctx *c, int decrypt, RowsParams &p, hipStream_t st) {
     p.rec = r.rec; p.acc = r.acc; p.cnt = r.cnt; p.queues = r.queues;
     c->rows_dirty = true;                                                    // until both launches are enqueued
     if (var) {
-        p.hdr = r.hdr; p.prefix = r.prefix; p.slot_base = r.slot_base;
-        HIPCHK(klaunch_rows_plan(st, p.data_off, p.n_pkts, p.has_aad, p.waves, c->rows_block, (u32)ROWS_NB_CAP, p.slot_cap, r.hdr, r.prefix, r.slot_base));
+        p.hdr = r.hdr; p.prefix = r.prefix; p.sprefix = r.sprefix; p.slot_base = r.slot_base;
+        HIPCHK(klaunch_rows_plan(st, p.data_off, p.pkt_len, p.aad_off, p.aad_len, p.n_pkts, p.waves, c->rows_block, (u32)ROWS_NB_CAP, p.slot_cap, r.hdr, r.prefix, r.sprefix, r.slot_base));
     }
     p.prio_rows = c->cyc_prio;
     if (wgs) HIPCHK(klaunch_rows(c->nr, decrypt, wgs, st, c->km, c->tables, p));                          // (fixed-size records of no bytes and no AAD have no units: their tags are the closing's alone)
-    const size_t close_lanes = p.slot_cap > n ? p.slot_cap : n;                                              // a lane per record slot and per message
+    const size_t close_lanes = p.slot_cap > n ? p.slot_cap : n;                                              // a lane per record slot and per message (the smalls blocks are walked by whatever lanes there are)
     HIPCHK(klaunch_rows_close(decrypt, (unsigned)((close_lanes + ROWS_CLOSE_WG - 1) / ROWS_CLOSE_WG), st, c->km, c->tables, p));
     c->rows_dirty = false;
     return AESGCM_OK;
 }
 
-// does a call go by rows?  A packet that does not end on a 1 KiB row costs the row launch a tail piece -- a wave's pass through the cipher for at most 64 blocks --
-// so the mark is rows_min (16 KiB) for those and half of it for packets that are whole rows.  Measured on one box after E_K(J0) moved to the closing launch,
-// AES-256, GiB/s by rows / by the packet kernels (profiles/r05/rows_min_sweep2.txt): whole rows -- 32 KiB x 131072 906 / 737; 16 KiB x 262144 862 / 798, x 16384
-// 635 / 563, x 4096 595 / 400; 8 KiB x 524288 785 / 737, x 32768 602 / 562, x 4096 465 / 255, x 1024 189 / 130; 4 KiB x 2^20 623 / 828, x 65536 528 / 566;
-// with a tail of one block -- 32 KiB + 16 832 / 680; 16 KiB + 16 x 262144 757 / 763, x 16384 594 / 551, x 4096 540 / 371; 8 KiB + 16 x 524288 601 / 707.
+// does a call go by rows?  From rows_min bytes per packet (8 KiB), and from a quarter of that while the packets are few: the packet kernels need a packet per lane
+// (or per lane group) to fill the chip, the rows of a call fill it whatever the count.  Measured on one box with the smalls in the closing launch, AES-256,
+// GiB/s by rows / by the packet kernels (profiles/r05/rows_min_sweep2.txt, rows_min_sweep3.txt): 32 KiB x 131072 885 / 721, + 16 bytes 870 / 666; 16 KiB x 262144
+// 845 / 792, + 16 827 / 749, x 16384 634 / 563, x 4096 571 / 400; 8 KiB x 524288 770 / 727, + 16 746 / 695, x 32768 596 / 545, x 4096 464 / 254, x 1024 189 / 129;
+// 6 KiB x 699050 709 / 802, x 65536 613 / 613, x 8192 501 / 282; 4 KiB x 2^20 620 / 810, x 131072 557 / 667, x 32768 495 / 485, x 16384 502 / 384, x 4096 339 / 151;
+// 2 KiB x 2^20 429 / 804, x 16384 352 / 242, x 4096 206 / 115; 1 KiB x 262144 264 / 616, x 4096 116 / 83.
 // Offset arrays: the host does not know the lengths; the caller's pkt_len, otherwise unused in that form, is its word for the typical packet (0 = frames)
 bool packets_by_rows(const aesgcm_ctx *c, size_t n_pkts, size_t pkt_len) {
-    (void)n_pkts;
 #ifdef AESGCM_DEBUG_KNOBS
     if (g_force.pkt_rows) return g_force.pkt_rows == 1;
     if (g_force.pkt_lanes) return false;                                     // a forced shape of the packet kernels means the packet kernels
 #endif
     if (!c->rows_min) return false;
-    return pkt_len >= c->rows_min || (2 * pkt_len >= c->rows_min && pkt_len % 1024 == 0);
+    return pkt_len >= c->rows_min || (4 * pkt_len >= c->rows_min && n_pkts <= 16384);
 }
 
 // zero the output of every packet whose d_auth[] entry is 0 (behind the launch that wrote it, on the same stream)

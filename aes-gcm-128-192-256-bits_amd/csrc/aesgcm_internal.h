@@ -73,7 +73,7 @@ hipError_t klaunch_pktl(int nr, int dec, bool ilp, unsigned wgs, hipStream_t st,
 hipError_t klaunch_pktg(int nr, int dec, int lg, unsigned wgs, hipStream_t st, const KeyMaterial *km, const DevTables *tb, const PktParams &p);
 hipError_t klaunch_batch3(int nr, int dec, int lg, unsigned wgs, hipStream_t st, const DevTables *tb, const BatchParams &p);
 hipError_t klaunch_len_sort(hipStream_t st, const u64 *d_off, u32 n, u32 *bins, u32 *perm);                                                  // k_len_hist, k_len_scan, k_len_scatter
-hipError_t klaunch_rows_plan(hipStream_t st, const u64 *d_off, u32 n, u32 has_aad, u32 waves, u32 force_d, u32 nb_cap, u32 slot_cap, RowsHdr *hdr, u64 *prefix, u32 *slot_base);
+hipError_t klaunch_rows_plan(hipStream_t st, const u64 *d_off, u32 pkt_len, const u64 *d_aoff, u32 aad_len, u32 n, u32 waves, u32 force_d, u32 nb_cap, u32 slot_cap, RowsHdr *hdr, u64 *prefix, u64 *sprefix, u32 *slot_base);
 hipError_t klaunch_rows(int nr, int dec, unsigned wgs, hipStream_t st, const KeyMaterial *km, const DevTables *tb, const RowsParams &p);
 hipError_t klaunch_rows_close(int dec, unsigned wgs, hipStream_t st, const KeyMaterial *km, const DevTables *tb, const RowsParams &p);
 hipError_t klaunch_wipe_failed(hipStream_t st, unsigned char *out, const int *auth, const u64 *data_off, u32 n_pkts, u32 pkt_len);
@@ -165,7 +165,7 @@ struct aesgcm_ctx {
     unsigned char *rows_buf = nullptr;
     size_t rows_cap_slots = 0, rows_cap_n = 0;
     bool rows_dirty = true;            // the scratch is not known to be zero (fresh, or a launch failed between k_rows and k_rows_close)
-    u64 rows_min = (u64)16 << 10;      // packets of at least this many bytes go by rows, packets that are whole 1 KiB rows from half of it (option "rows_min"; 0 = never).  With offset arrays the caller's pkt_len is the hint that says so
+    u64 rows_min = (u64)8 << 10;       // packets of at least this many bytes go by rows, and from a quarter of it while they are at most 16384 (option "rows_min"; 0 = never).  With offset arrays the caller's pkt_len is the hint that says so
     u32 rows_block = 0;                // option "rows_block": units per dealt block of k_rows (0 = the library's cut: one block per wave, or blocks of ROWS_DYN_BLOCK for large calls)
     // streaming state
     bool s_active = false, s_data = false, s_ragged = false;

@@ -1173,22 +1173,21 @@ __global__ __launch_bounds__(AESGCM_BODY_WG, AESGCM_BODY_WPS) void k_rows(const 
         u64 g = (u64)b * D;
         const u64 g_end = g + D < G ? g + D : G;
         u32 m = uniform32(rows_find_msg(p, g));
-        // The pieces of the block.  Every iteration derives what it needs from (g, m) alone -- lengths, offsets, the IV's constants are loaded again per piece, and
-        // the record's header is written BEFORE the rows -- so that almost nothing but g, m and the record's address is live across the row loop (an earlier form
-        // that carried the message's geometry through it spilled 114 scalars and 252 bytes of scratch).
+        // The pieces of the block.  Every iteration derives what it needs from (g, m) alone -- lengths, offsets, the IV's constants are loaded again
+        // per piece, and the record's header is written BEFORE the rows -- so that almost nothing but g, m and the record's address is live across the row loop (an
+        // earlier form that carried the message's geometry through it spilled 114 scalars and 252 bytes of scratch).
         for (u32 guard2 = 0, skipped = 0; g < g_end && guard2 <= 2u * D + 4u && skipped <= p.n_pkts; ++guard2) {
             m = opaque_sgpr(m);
             RowsMsg mq = rows_msg(p, m);
             mq.doff = uniform64(mq.doff); mq.aoff = uniform64(mq.aoff); mq.len = uniform32(mq.len); mq.alen = uniform32(mq.alen);
             const RowsGeom geo = rows_geom(mq.len);
             const u64 g0 = uniform64(rows_unit_base(p, m));
-            if (g >= g0 + rows_units(geo, p.has_aad)) { ++m; if (rows_units(geo, p.has_aad) == 0) { ++skipped; --guard2; } continue; }     // the next message (one without units -- empty, no AAD -- does not count against the bound of the walk)
+            const u32 U = rows_units(geo, rows_na(mq.alen));
+            if (g >= g0 + U) { ++m; if (U == 0) { ++skipped; --guard2; } continue; }     // the next message (one without a unit -- shorter than a row -- does not count against the bound of the walk)
             const RowsPiece pc = rows_piece(geo, uniform32(rows_slot_base(p, m)), g0, (u32)(g - g0), g_end - g, D);
             RowsRec *rr = p.rec + pc.slot;
-            if (lane_id_fresh() == 0) {
-                rr->e = pc.e; rr->msg = m; rr->flags = pc.kind == ROWS_TAIL ? ROWS_REC_VALID : (ROWS_REC_VALID | ROWS_REC_WEIGH);    // (the tail is weighted already: lane terms H^(65 - L))
-            }
-            // every kind of piece takes the lane's index FRESH (lane_id_fresh: opaque to the compiler), so that nothing lane-dependent of the tail and AAD code -- table
+            if (lane_id_fresh() == 0) { rr->e = pc.e; rr->msg = m; rr->flags = ROWS_REC_VALID | ROWS_REC_WEIGH; }
+            // every kind of piece takes the lane's index FRESH (lane_id_fresh: opaque to the compiler), so that nothing lane-dependent of the AAD code -- table
             // addresses, byte masks -- is hoisted out of the piece loop and kept in registers across the row loop (first build: 26 scratch accesses per row)
             G128 z;
             if (pc.kind == ROWS_AAD) {
@@ -1198,12 +1197,8 @@ __global__ __launch_bounds__(AESGCM_BODY_WG, AESGCM_BODY_WPS) void k_rows(const 
                 CtrConsts cc = ctr_round1_consts(uniform32(load_le32(ivp)), uniform32(load_le32(ivp + 4)), uniform32(load_le32(ivp + 8)), km->rk, smem, (lane_id_fresh() & 31u) << 2);   // key and IV only: wave-uniform
                 cc.c0 = __builtin_amdgcn_readfirstlane(cc.c0); cc.c1 = __builtin_amdgcn_readfirstlane(cc.c1);
                 cc.c2 = __builtin_amdgcn_readfirstlane(cc.c2); cc.c3 = __builtin_amdgcn_readfirstlane(cc.c3);
-                if (pc.kind == ROWS_RUN) {
-                    const uint4 acc = rows_run_lane<NR, MODE>(km, tb, p, mq, pc, smem, cc, lane_id_fresh(), dyn ? 0u : p.prio_rows, (tid >> 8) & 3u);
-                    z = wave_xor(rows_run_term(km, acc, lane_id_fresh()));
-                } else {
-                    z = wave_xor(rows_tail_lane<NR, MODE == MODE_DEC>(km, p, mq, smem, cc, lane_id_fresh()));
-                }
+                const uint4 acc = rows_run_lane<NR, MODE>(km, tb, p, mq, pc, smem, cc, lane_id_fresh(), dyn ? 0u : p.prio_rows, (tid >> 8) & 3u);
+                z = wave_xor(rows_run_term(km, acc, lane_id_fresh()));
             }
             if (lane_id_fresh() == 0) rr->w = z;
             g += pc.len;
@@ -1211,10 +1206,11 @@ __global__ __launch_bounds__(AESGCM_BODY_WG, AESGCM_BODY_WPS) void k_rows(const 
     }
 }
 
-// k_rows_close: a lane per message brings what the message owes once, (length block) H ^ E_K(J0) (rows_msg_term), a lane per record slot the record's contribution
-// (the same lanes: index i is message i and slot i), each XORs into the message's accumulator and counts itself arrived; the lane that counts the message's last
-// arrival holds the tag: it stores it and (decrypt) compares.  Memory-side atomics only, as acc_arrive: the XORs have returned before the arrival is counted.  Zero
-// at rest: the lane puts its record's flags back to zero, the closing lane the message's accumulator and count, workgroup 0 the dispensers.
+// k_rows_close: the lanes of the launch walk three things -- index i is message i, record slot i, and the blocks i, i + lanes, ... of the smalls axis.  A message's
+// lane brings what the message owes once, (length block) H ^ E_K(J0) (rows_msg_term); a record's lane the record times H^e; a smalls block's lane the block
+// through the cipher and times its power of H (rows_small_block).  Each XORs into the message's accumulator and counts itself arrived; the lane that counts the
+// message's last arrival holds the tag: it stores it and (decrypt) compares.  Memory-side atomics only, as acc_arrive: the XORs have returned before the arrival
+// is counted.  Zero at rest: the lane puts its record's flags back to zero, the closing lane the message's accumulator and count, workgroup 0 the dispensers.
 template <int DEC>
 __device__ __forceinline__ void rows_arrive(const RowsParams &p, u32 m, const G128 &z) {
     const unsigned long long ohi = atomicXor(p.acc + 2u * m, ((unsigned long long)z.w[0] << 32) | z.w[1]);
@@ -1223,7 +1219,7 @@ __device__ __forceinline__ void rows_arrive(const RowsParams &p, u32 m, const G1
     asm volatile("v_and_b32 %0, 0, %1" : "=v"(dep) : "v"((u32)(ohi ^ olo) | (u32)((ohi ^ olo) >> 32)));
     const u32 arrived = atomicAdd(p.cnt + m, 1u + dep);
     const RowsMsg mq = rows_msg(p, m);
-    if (arrived + 1u != rows_pieces(rows_geom(mq.len), p.has_aad, rows_unit_base(p, m), p.hdr ? p.hdr->D : p.D)) return;
+    if (arrived + 1u != rows_pieces(rows_geom(mq.len), rows_na(mq.alen), rows_unit_base(p, m), p.hdr ? p.hdr->D : p.D)) return;
     const unsigned long long hi = atomicExch(p.acc + 2u * m, 0ull), lo = atomicExch(p.acc + 2u * m + 1u, 0ull);
     p.cnt[m] = 0;
     G128 t; t.w[0] = (u32)(hi >> 32); t.w[1] = (u32)hi; t.w[2] = (u32)(lo >> 32); t.w[3] = (u32)lo;
@@ -1246,8 +1242,15 @@ __global__ __launch_bounds__(ROWS_CLOSE_WG) void k_rows_close(const KeyMaterial 
     if (blockIdx.x == 0 && threadIdx.x < ROWS_NQ) p.queues[16u * threadIdx.x] = 0;
     __syncthreads();
     const u32 i = blockIdx.x * ROWS_CLOSE_WG + threadIdx.x;
-    if (i < p.n_pkts && !(p.hdr && p.hdr->bad))
-        rows_arrive<DEC>(p, i, rows_msg_term(km, reinterpret_cast<const u32 *>(smem + ROWS_CLOSE_LDS_TE), p, i));
+    const u32 *te = reinterpret_cast<const u32 *>(smem + ROWS_CLOSE_LDS_TE);
+    if (p.hdr && p.hdr->bad) return;
+    if (i < p.n_pkts) rows_arrive<DEC>(p, i, rows_msg_term(km, te, p, i));
+    const u64 total = rows_small_total(p), lanes = (u64)gridDim.x * ROWS_CLOSE_WG;
+    for (u64 t = i, guard = 0; t < total && guard <= 2u * ROWS_SMALL_AAD + 2u; t += lanes, ++guard) {      // (the launch has a lane per message at least, a message at most 128 blocks here)
+        G128 z;
+        const u32 m = rows_small_block<DEC>(km, te, p, t, &z);
+        rows_arrive<DEC>(p, m, z);
+    }
     if (i >= p.slot_cap) return;
     const RowsRec r = p.rec[i];
     if (!(r.flags & ROWS_REC_VALID)) return;
@@ -1268,38 +1271,45 @@ __device__ __forceinline__ u64 block_scan_u64(unsigned long long *part, u64 mine
     }
     return part[tid] - mine;
 }
-__global__ __launch_bounds__(1024) void k_rows_plan(const u64 *__restrict__ off, u32 n, u32 has_aad, u32 waves, u32 force_d, u32 nb_cap, u32 slot_cap,
-                                                    RowsHdr *hdr, u64 *prefix, u32 *slot_base) {
+__global__ __launch_bounds__(1024) void k_rows_plan(const u64 *__restrict__ off, u32 pkt_len, const u64 *__restrict__ aoff, u32 aad_len, u32 n, u32 waves, u32 force_d, u32 nb_cap, u32 slot_cap,
+                                                    RowsHdr *hdr, u64 *prefix, u64 *sprefix, u32 *slot_base) {
     __shared__ unsigned long long part[1024];
     const u32 tid = threadIdx.x, per = (n + 1023u) / 1024u;
     const u32 lo = tid * per < n ? tid * per : n, hi = lo + per < n ? lo + per : n;
-    u64 s = 0;
-    for (u32 m = lo; m < hi; ++m) s += rows_units(rows_geom(off[m + 1] - off[m]), has_aad);
-    u64 run = block_scan_u64(part, s, tid);
-    const u64 G = part[1023];
+    auto geom_of = [&](u32 m) { return rows_geom(off ? off[m + 1] - off[m] : (u64)pkt_len); };
+    auto na_of = [&](u32 m) { return rows_na(aoff ? (u32)(aoff[m + 1] - aoff[m]) : aad_len); };
+    u64 s = 0, ss = 0;
+    for (u32 m = lo; m < hi; ++m) { const RowsGeom g = geom_of(m); const u32 na = na_of(m); s += rows_units(g, na); ss += rows_smalls(g, na); }
+    u64 run = block_scan_u64(part, s, tid);                                  // row units in front of the thread's messages
+    const u64 GR = part[1023];
     __syncthreads();
+    u64 srun = block_scan_u64(part, ss, tid);                                // smalls blocks in front of them
+    const u64 ST = part[1023];
+    __syncthreads();
+    const u64 G = GR;
     u32 D, NB, dyn;
     rows_cut(G, waves, force_d, nb_cap, &D, &NB, &dyn);
     u64 t = 0;
     for (u32 m = lo; m < hi; ++m) {
-        const RowsGeom g = rows_geom(off[m + 1] - off[m]);
-        prefix[m] = run;
-        t += rows_slots(g, has_aad, run, D);
-        run += rows_units(g, has_aad);
+        const RowsGeom g = geom_of(m); const u32 na = na_of(m);
+        prefix[m] = run; sprefix[m] = srun;
+        t += rows_slots(g, na, run, D);
+        run += rows_units(g, na); srun += rows_smalls(g, na);
     }
-    u64 srun = block_scan_u64(part, t, tid);
+    u64 slot = block_scan_u64(part, t, tid);
     const u64 slots = part[1023];
-    run = prefix[lo < n ? lo : 0];
+    run = lo < n ? prefix[lo] : 0; srun = lo < n ? sprefix[lo] : 0;
     for (u32 m = lo; m < hi; ++m) {
-        const RowsGeom g = rows_geom(off[m + 1] - off[m]);
-        slot_base[m] = (u32)srun;
-        srun += rows_slots(g, has_aad, run, D);
-        run += rows_units(g, has_aad);
+        const RowsGeom g = geom_of(m); const u32 na = na_of(m);
+        slot_base[m] = (u32)slot;
+        slot += rows_slots(g, na, run, D);
+        run += rows_units(g, na); srun += rows_smalls(g, na);
     }
     if (tid == 0) {
-        prefix[n] = G; slot_base[n] = (u32)slots;
-        hdr->G = slots <= slot_cap ? G : 0ull;                               // (the host sizes the scratch for the worst case; a cut that does not fit would be its bug: then nothing runs)
-        hdr->D = D; hdr->NB = slots <= slot_cap ? NB : 0u; hdr->dyn = dyn; hdr->bad = slots <= slot_cap ? 0u : 1u;
+        const bool fits = slots <= slot_cap;                                 // (the host sizes the scratch for the worst case; a cut that does not fit would be its bug: then nothing runs)
+        prefix[n] = GR; sprefix[n] = ST; slot_base[n] = (u32)slots;
+        hdr->G = fits ? G : 0ull;
+        hdr->D = D; hdr->NB = fits ? NB : 0u; hdr->dyn = dyn; hdr->bad = fits ? 0u : 1u;
     }
 }
 
@@ -1457,8 +1467,8 @@ hipError_t klaunch_len_sort(hipStream_t st, const u64 *d_off, u32 n, u32 *bins, 
     hipLaunchKernelGGL(k_len_scatter, dim3(LEN_SORT_WGS), dim3(256), 0, st, d_off, n, bins, perm);
     return hipGetLastError();
 }
-hipError_t klaunch_rows_plan(hipStream_t st, const u64 *d_off, u32 n, u32 has_aad, u32 waves, u32 force_d, u32 nb_cap, u32 slot_cap, RowsHdr *hdr, u64 *prefix, u32 *slot_base) {
-    hipLaunchKernelGGL(k_rows_plan, dim3(1), dim3(1024), 0, st, d_off, n, has_aad, waves, force_d, nb_cap, slot_cap, hdr, prefix, slot_base);
+hipError_t klaunch_rows_plan(hipStream_t st, const u64 *d_off, u32 pkt_len, const u64 *d_aoff, u32 aad_len, u32 n, u32 waves, u32 force_d, u32 nb_cap, u32 slot_cap, RowsHdr *hdr, u64 *prefix, u64 *sprefix, u32 *slot_base) {
+    hipLaunchKernelGGL(k_rows_plan, dim3(1), dim3(1024), 0, st, d_off, pkt_len, d_aoff, aad_len, n, waves, force_d, nb_cap, slot_cap, hdr, prefix, sprefix, slot_base);
     return hipGetLastError();
 }
 hipError_t klaunch_rows(int nr, int dec, unsigned wgs, hipStream_t st, const KeyMaterial *km, const DevTables *tb, const RowsParams &p) {

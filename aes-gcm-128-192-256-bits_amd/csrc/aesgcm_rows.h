@@ -8,31 +8,35 @@
 //
 //   * a message of `len` bytes is R = len / 1024 whole rows of 64 blocks, aligned to its first block (every packet starts at counter 2,
 //     src/aes_icb.vhd:97-118, so every message IS an aligned body), plus a TAIL of tb <= 64 blocks (the last one ragged), plus its AAD;
-//   * its work is laid on an axis of UNITS: a unit per row, in their order, then -- when the message does not end on a row -- ONE unit for the tail, its
-//     blocks as a right-aligned row, and, when the call has AAD, one for the AAD.  (Until the middle of round 5 every message had a tail unit, which also held
-//     the length block and encrypted counter 1, E_K(J0): a whole wave's pass through the cipher for one lane's block -- 0.95 ms per 262 144 messages, 5 % of a call
-//     of 64 KiB messages, profiles/r05/rows_tail_cost.txt.  What a message owes ONCE now waits for the closing launch, where a lane does it.)  The axes of all
-//     messages, end to end, are the call: G units.  A RUN of consecutive rows is body_rows_lane's: k_body's row code with the lane constants of all four row
-//     phases in registers and one Horner accumulator of stride H^64, so a run of any length leaves ONE value behind;
+//   * the ROWS are laid on an axis of UNITS: a unit per row of every message, in their order (and one for an AAD of more than 64 blocks, as rows of its
+//     own).  A RUN of consecutive rows is body_rows_lane's: k_body's row code with the lane constants of all four row phases in registers and one Horner
+//     accumulator of stride H^64, so a run of any length leaves ONE value behind;
 //   * the axis is cut into BLOCKS of D units.  A small or mid-size call is cut into exactly one block per wave of the launch (equal shares, no dispenser:
 //     the launch is as long as its rows and nothing waits for a last chunk); a large one into blocks of 64 units dealt from dispensers, as k_body deals
-//     its chunks.  Where a block's range meets the boundaries of a message it falls into PIECES: a run of rows, a tail, an AAD;
-//   * at the end of a piece the wave does not leave its 64 lane accumulators: lane L's value times H^(63 - L) through the key's per-lane Shoup tables
+//     its chunks.  Where a block's range meets the boundaries of a message it falls into PIECES: a run of rows, a long AAD;
+//   * at the end of a run the wave does not leave its 64 lane accumulators: lane L's value times H^(63 - L) through the key's per-lane Shoup tables
 //     (KeyMaterial::ltab, read from DEVICE memory: the vector-memory path is idle in this kernel and its LDS is not -- the same tables staged in the 19 KiB of
 //     LDS behind the T-tables made every size slower on one box, tail-only calls 0.95 -> 1.25 ms, 64 KiB messages 4.55 -> 4.61 ms,
 //     profiles/r05/rows_ab2/lds_lane_tables_ab.txt), XORed over the wave, is the polynomial of the run up to its last block -- a 32-byte RECORD per piece:
-//     those 16 bytes, the
-//     message, and the exponent still due: H^(blocks behind the piece + 2), e = 64 (R - 1 - last row) + tb + 2 (AAD: 64 R + tb + 2; the tail, whose
-//     lane terms are H^(65 - L), needs none).  HBM traffic is 1.00 x algorithmic whatever the cut;
-//   * ONE small launch behind the rows closes every tag (k_rows_close).  A LANE per record slot multiplies by H^e bit-serially (any exponent, all lanes
-//     in parallel), XORs the product into the message's accumulator with memory-side atomics and counts itself arrived; a LANE per message brings what
-//     the message owes once -- (length block) H ^ E_K(J0), the cipher through a 4 KiB copy of the four T-tables in the workgroup's LDS (rows_msg_term) --
-//     the same way.  The lane that counts a message's last arrival holds its tag  P H^2 ^ L H ^ E_K(J0)  (gcm_ghash.vhd:257,293 re-associated), stores
-//     it and, for decrypt, compares.
+//     those 16 bytes, the message, and the exponent still due: H^(blocks behind the piece + 2), e = 64 (R - 1 - last row) + tb + 2 (the long AAD:
+//     64 R + tb + 2).  HBM traffic is 1.00 x algorithmic whatever the cut;
+//   * everything that is NOT a whole row -- the AAD blocks (up to 64) and the tail blocks of every message, and what a message owes once: the length block and
+//     E_K(J0) -- is the SMALLS: message after message, block after block, one more axis, walked by the LANES of the closing launch (k_rows_close), a lane per
+//     block, whatever message it belongs to.  The lane finds its message (arithmetic, or a search in the plan's prefix sums), runs the cipher under ITS
+//     message's IV through a 4 KiB copy of the four T-tables in the workgroup's LDS, and weighs its block with the power of H its place in its message asks
+//     for (rows_small_block).  (Until the middle of round 5 every message had a unit of the row launch for its tail -- which also held the length block and
+//     encrypted counter 1 -- and one for its AAD: a wave's pass each, for a block or two.  64 KiB messages with a 13-byte header and a ragged end ran 7 %
+//     below whole ones, 16 KiB ones 16 %, profiles/r05/rows_aad_cost.txt.  Packing the smalls into units of the row launch itself was built too: its code
+//     around the row loop cost AES-256 nine scratch accesses per row.)
+//   * the same small launch closes every tag: a LANE per record slot multiplies by H^e bit-serially (any exponent, all lanes in parallel); records, smalls
+//     blocks and the message's own lane each XOR their product into the message's accumulator with memory-side atomics and count themselves arrived.  The
+//     lane that counts a message's last arrival holds its tag  P H^2 ^ L H ^ E_K(J0)  (gcm_ghash.vhd:257,293 re-associated), stores it and, for decrypt,
+//     compares.
 //
-// Fixed-size records need no plan: message m owns the units [m U, (m + 1) U).  With offset arrays the lengths are on the device, and one small launch in
-// front (k_rows_plan) makes the two prefix sums there: units and record slots in front of every message.  Everything the two launches share between
-// calls -- accumulators, arrival and piece counts, record flags, dispensers -- is zero at rest: whoever consumes a thing puts the zero back.
+// Fixed-size records need no plan: message m owns the units [m U, (m + 1) U) and the smalls blocks [m S, (m + 1) S).  With offset arrays the lengths are
+// on the device, and one small launch in front (k_rows_plan) makes the three prefix sums there: units, smalls blocks and record slots in front of every
+// message.  Everything the launches share between calls -- accumulators, arrival counts, record flags, dispensers -- is zero at rest: whoever consumes a
+// thing puts the zero back.
 #pragma once
 #include "aesgcm_dev.h"
 
@@ -41,6 +45,8 @@
 #define ROWS_STATIC_MAX 192u                  /* units per wave up to which a call is cut into one block per wave */
 #define ROWS_CLOSE_WG 256u                    /* lanes per k_rows_close workgroup */
 #define ROWS_NB_CAP 65536u                    /* offset-array form: blocks the scratch is sized for (k_rows_plan falls back to one block per wave beyond) */
+#define ROWS_SMALL_AAD 64u                    /* an AAD of up to this many blocks lies on the smalls axis; a longer one is a unit of the row axis (rows of its own, Horner with H^64) */
+#define ROWS_SLOTS_PER_MSG 2u                 /* offset-array form: record slots per message besides one per block boundary -- a run, a long AAD */
 #define ROWS_REC_VALID 1u
 #define ROWS_REC_WEIGH 2u
 
@@ -57,15 +63,15 @@ struct RowsParams {
     int *auth;                                // dec: per message 1 / 0, or NULL
     const u64 *data_off, *aad_off;            // n_pkts + 1 byte offsets, or NULL = fixed pkt_len / aad_len records
     u32 n_pkts, pkt_len, aad_len;
-    u32 has_aad;                              // the call has AAD (fixed aad_len > 0, or an offset array): every message has an AAD unit
     u32 waves;                                // waves of the k_rows launch
     // the cut: fixed-size form (the host knows it) ...
     u64 G;                                    // units of the call
     u32 D, NB, dyn;                           // units per block, blocks, 1 = blocks come from the dispensers / 0 = wave w takes block w
-    u32 U, SM;                                // units and record slots per message
+    u32 U, S, SM;                             // per message: units, blocks of the smalls axis, record slots
     // ... or with offset arrays (k_rows_plan made it)
     const RowsHdr *hdr;
     const u64 *prefix;                        // units in front of message m (n_pkts + 1 entries)
+    const u64 *sprefix;                       // smalls blocks in front of message m (n_pkts + 1 entries)
     const u32 *slot_base;                     // record slots in front of message m (n_pkts + 1 entries)
     u32 slot_cap;                             // record slots the scratch holds (k_rows_close has a lane for each)
     RowsRec *rec;
@@ -83,14 +89,23 @@ HD RowsGeom rows_geom(u64 len) {
     g.tb = ((u32)(len & 1023u) + 15u) >> 4;
     return g;
 }
-HD u32 rows_units(const RowsGeom &g, u32 has_aad) { return g.R + (g.tb ? 1u : 0u) + (has_aad ? 1u : 0u); }         // 0 for an empty message without AAD: only the closing sees it
-// the natural segment of unit u of a message: its rows (when it has any), the tail (when it has one), the AAD
-HD u32 rows_nat(const RowsGeom &g, u32 u) { return u < g.R ? 0u : (g.R ? 1u : 0u) + (u - g.R); }
-HD u32 rows_nat_count(const RowsGeom &g, u32 has_aad) { return (g.R ? 1u : 0u) + (g.tb ? 1u : 0u) + (has_aad ? 1u : 0u); }
+HD u32 rows_na(u32 alen) { return (alen + 15u) >> 4; }                                   // AAD blocks
+HD u32 rows_long_aad(u32 na) { return na > ROWS_SMALL_AAD ? 1u : 0u; }
+HD u32 rows_small_aad(u32 na) { return na > ROWS_SMALL_AAD ? 0u : na; }
+HD u32 rows_units(const RowsGeom &g, u32 na) { return g.R + rows_long_aad(na); }         // units of the row launch (0 for a message shorter than a row: only the closing sees it)
+HD u32 rows_smalls(const RowsGeom &g, u32 na) { return rows_small_aad(na) + g.tb; }      // blocks on the smalls axis: the (short) AAD, then the tail
+// the natural segment of unit u of a message: its rows (when it has any), then the long AAD
+HD u32 rows_nat(const RowsGeom &g, u32 u) { return u < g.R ? 0u : (g.R ? 1u : 0u); }
+HD u32 rows_nat_count(const RowsGeom &g, u32 na) { return (g.R ? 1u : 0u) + rows_long_aad(na); }
 // record slots of a message whose units are [g0, g0 + U): a slot per (natural segment, block) pair it can have -- slot = base + nat + (block - first block)
-HD u32 rows_slots(const RowsGeom &g, u32 has_aad, u64 g0, u32 D) {
-    const u32 U = rows_units(g, has_aad);
-    return U ? rows_nat_count(g, has_aad) + (u32)((g0 + U - 1u) / D - g0 / D) : 0u;
+HD u32 rows_slots(const RowsGeom &g, u32 na, u64 g0, u32 D) {
+    const u32 U = rows_units(g, na);
+    return U ? rows_nat_count(g, na) + (u32)((g0 + U - 1u) / D - g0 / D) : 0u;
+}
+// arrivals k_rows_close counts for a message: the pieces it falls into under the cut -- its run of rows one per block it touches, the long AAD --, its blocks
+// of the smalls axis, and the message's own lane
+HD u32 rows_pieces(const RowsGeom &g, u32 na, u64 g0, u32 D) {
+    return (g.R ? (u32)((g0 + g.R - 1u) / D - g0 / D) + 1u : 0u) + rows_long_aad(na) + rows_smalls(g, na) + 1u;
 }
 // the cut of a call of G units for `waves` waves: one block per wave while that is at most ROWS_STATIC_MAX units (or when the dealt cut would not fit the
 // scratch: nb_cap blocks), else blocks of ROWS_DYN_BLOCK units from the dispensers.  force_d > 0: dealt blocks of that many units (tests)
@@ -103,11 +118,6 @@ HD void rows_cut(u64 G, u32 waves, u32 force_d, u64 nb_cap, u32 *D, u32 *NB, u32
     if ((force_d || d > ROWS_STATIC_MAX) && (G + dd - 1u) / dd <= nb_cap) { d = dd; dy = 1; }
     *D = (u32)d; *NB = (u32)((G + d - 1u) / d); *dyn = dy;
 }
-// arrivals k_rows_close counts for a message: the pieces it falls into under the cut -- its run of rows one per block it touches, the tail, the AAD -- and the
-// message's own lane
-HD u32 rows_pieces(const RowsGeom &g, u32 has_aad, u64 g0, u32 D) {
-    return (g.R ? (u32)((g0 + g.R - 1u) / D - g0 / D) + 1u : 0u) + (g.tb ? 1u : 0u) + (has_aad ? 1u : 0u) + 1u;
-}
 // the message's lengths and offsets
 struct RowsMsg { u64 doff, aoff; u32 len, alen; };
 HD RowsMsg rows_msg(const RowsParams &p, u32 m) {
@@ -118,34 +128,34 @@ HD RowsMsg rows_msg(const RowsParams &p, u32 m) {
     if (p.aad_off) { q.aoff = p.aad_off[m]; q.alen = (u32)(p.aad_off[m + 1] - q.aoff); }
     return q;
 }
-// the message that owns unit g, and the units in front of a message
-HD u32 rows_find_msg(const RowsParams &p, u64 g) {
-    if (!p.prefix) return (u32)(g / p.U);
-    u32 lo = 0, hi = p.n_pkts;                                           // prefix[lo] <= g < prefix[hi]: the LAST message that starts at or in front of g -- the one that owns it (messages without units share their successor's start)
-    while (hi - lo > 1u) { const u32 mid = lo + ((hi - lo) >> 1); if (p.prefix[mid] <= g) lo = mid; else hi = mid; }
+// the LAST message of [lo, hi) whose entry of a prefix array is <= x: the one that owns position x (messages without a share have their successor's start)
+HD u32 rows_search(const u64 *pre, u64 x, u32 lo, u32 hi) {
+    while (hi - lo > 1u) { const u32 mid = lo + ((hi - lo) >> 1); if (pre[mid] <= x) lo = mid; else hi = mid; }
     return lo;
 }
+// the message that owns unit g, and the units / smalls blocks / record slots in front of a message
+HD u32 rows_find_msg(const RowsParams &p, u64 g) { return p.prefix ? rows_search(p.prefix, g, 0u, p.n_pkts) : (u32)(g / p.U); }
 HD u64 rows_unit_base(const RowsParams &p, u32 m) { return p.prefix ? p.prefix[m] : (u64)m * p.U; }
+HD u64 rows_small_base(const RowsParams &p, u32 m) { return p.sprefix ? p.sprefix[m] : (u64)m * p.S; }
+HD u64 rows_small_total(const RowsParams &p) { return p.sprefix ? p.sprefix[p.n_pkts] : (u64)p.n_pkts * p.S; }
 HD u32 rows_slot_base(const RowsParams &p, u32 m) { return p.slot_base ? p.slot_base[m] : m * p.SM; }
 
 // ---- k_rows: one piece ---------------------------------------------------------------------------
-enum { ROWS_RUN = 0, ROWS_TAIL = 1, ROWS_AAD = 2 };
+enum { ROWS_RUN = 0, ROWS_AAD = 2 };
 struct RowsPiece { u32 kind, r0, len, slot; u64 e; };                   // run: rows [r0, r0 + len); len = units taken
 // the piece that starts at unit u of the message (geometry g, first unit g0) and may take up to `room` units; D = units per block
 HD RowsPiece rows_piece(const RowsGeom &g, u32 slot_base, u64 g0, u32 u, u64 room, u32 D) {
     RowsPiece pc;
     pc.slot = slot_base + rows_nat(g, u) + (u32)((g0 + u) / D - g0 / D);
-    pc.len = 1; pc.r0 = 0; pc.e = 0;
+    pc.len = 1; pc.r0 = 0;
     if (u < g.R) {
         pc.kind = ROWS_RUN;
         pc.r0 = u;
         const u32 left = g.R - u;
         pc.len = room < left ? (u32)room : left;
         pc.e = 64ull * (g.R - (pc.r0 + pc.len)) + g.tb + 2u;              // blocks behind the run's last row, and H^2
-    } else if (g.tb && u == g.R) {
-        pc.kind = ROWS_TAIL;
     } else {
-        pc.kind = ROWS_AAD;
+        pc.kind = ROWS_AAD;                                               // the long AAD, whole
         pc.e = 64ull * g.R + g.tb + 2u;
     }
     return pc;
@@ -158,38 +168,9 @@ HD uint4 rows_run_lane(const KeyMaterial *__restrict__ km, const DevTables *__re
 }
 // the lane's term of the run's polynomial: B_L H^(63 - L) (XOR over the wave = the polynomial of the run up to its last block)
 HD G128 rows_run_term(const KeyMaterial *__restrict__ km, uint4 acc, u32 lane) { return shoup2_gmul_lds(mo_to_be(acc), km->ltab[63u - lane]); }
-
-// The tail blocks (data blocks 64 R ..., tb of them, 1 <= tb <= 64, the last one ragged) as ONE right-aligned row: lane L >= 64 - tb runs the cipher on counter
-// 2 + block index (aes_icb.vhd:97-118).  Returns the lane's term  X_L H^(65 - L)  of  (tail polynomial) H^2.
-template <int NR, int DEC>
-HD G128 rows_tail_lane(const KeyMaterial *__restrict__ km, const RowsParams &p, const RowsMsg &q, const unsigned char *smem, const CtrConsts &cc, u32 lane) {
-    const u32 *__restrict__ rk = km->rk;
-    const u32 lb = (lane & 31u) << 2;
-    const RowsGeom g = rows_geom(q.len);
-    const u32 pad = 64u - g.tb;
-    const unsigned char *src = p.in + q.doff;
-    unsigned char *dst = p.out + q.doff;
-    G128 z = {{0, 0, 0, 0}};
-    if (lane >= pad) {                                                                  // (the table multiply too: its 32 reads per lane go to 64 different tables, and the memory path takes them a lane at a time)
-        uint4 gin;
-        const u32 i = 64u * g.R + (lane - pad);                                         // block index in the message
-        u32 s0, s1, s2, s3;
-        ctr_rounds_lds<NR>(bswap32(2u + i), cc, s0, s1, s2, s3, rk, smem, lb);
-        const u32 off = 16u * i, rem = q.len - off;
-        const bool full = rem >= 16u;
-        const uint4 x = full ? gload16_any(src + off) : load_block_bytes(src + off, rem);
-        uint4 y = make_uint4(x.x ^ s0, x.y ^ s1, x.z ^ s2, x.w ^ s3);                    // gcm_gctr.vhd:150
-        if (!full) y = mask_block(y, rem);
-        if (full) gstore16_any(dst + off, y); else store_block_bytes(dst + off, y, rem);
-        gin = DEC ? x : y;                                                              // aes_gcm.vhd:207-211
-        z = shoup2_gmul_lds(mo_to_be(gin), km->ltab[65u - lane]);
-    }
-    return z;
-}
-// The AAD of a message as rows of its own (right-aligned, Horner with H^64: one row up to 1 KiB of AAD): the lane's term  A_L H^(63 - L)  of the AAD's polynomial.
-// alen = 0: zero.
+// An AAD of more than ROWS_SMALL_AAD blocks as rows of its own (right-aligned, Horner with H^64): the lane's term  A_L H^(63 - L)  of the AAD's polynomial
 HD G128 rows_aad_lane(const KeyMaterial *__restrict__ km, const RowsParams &p, const RowsMsg &q, const unsigned char *smem, u32 lane) {
-    const u32 n_aad = (q.alen + 15u) >> 4, rows = (n_aad + 63u) >> 6, pad = 64u * rows - n_aad;
+    const u32 n_aad = rows_na(q.alen), rows = (n_aad + 63u) >> 6, pad = 64u * rows - n_aad;
     const unsigned char *a = p.aad + q.aoff;
     uint4 acc = make_uint4(0, 0, 0, 0);
     for (u32 k = 0; k < rows; k++) {
@@ -199,9 +180,7 @@ HD G128 rows_aad_lane(const KeyMaterial *__restrict__ km, const RowsParams &p, c
         const u32 off = 16u * (slot - pad), rem = q.alen - off;
         acc = xor4(acc, rem >= 16u ? gload16_any(a + off) : load_block_bytes(a + off, rem));
     }
-    G128 z = {{0, 0, 0, 0}};
-    if (rows && lane >= (n_aad < 64u ? 64u - n_aad : 0u)) z = shoup2_gmul_lds(mo_to_be(acc), km->ltab[63u - lane]);      // only the lanes that hold a block
-    return z;
+    return shoup2_gmul_lds(mo_to_be(acc), km->ltab[63u - lane]);
 }
 
 // ---- k_rows_close: what a message owes once: (length block) H ^ E_K(J0) -------------------------------
@@ -239,6 +218,43 @@ HD G128 rows_msg_term(const KeyMaterial *__restrict__ km, const u32 *te, const R
     const G128 e = mo_to_be(aes_encrypt_te(te, km->rk, km->nr, make_uint4(load_le32(ivp), load_le32(ivp + 4), load_le32(ivp + 8), 0x01000000u)));
     z.w[0] ^= e.w[0]; z.w[1] ^= e.w[1]; z.w[2] ^= e.w[2]; z.w[3] ^= e.w[3];
     return z;
+}
+
+// ---- k_rows_close: block t of the smalls axis ------------------------------------------------------------
+// Block i of the short AAD, or of the tail, of the message that owns t; returns the message, and in *z the block's whole contribution to its tag:
+//   AAD block i of na:   A H^(na - 1 - i + 64 R + tb + 2);
+//   tail block i of tb:  the cipher on counter 2 + 64 R + i under the message's IV (aes_icb.vhd:97-118), the data block XORed with it (gcm_gctr.vhd:150), the
+//                        ciphertext X -- the input, for decrypt (aes_gcm.vhd:207-211) -- times H^(tb - i + 1).
+template <int DEC>
+HD u32 rows_small_block(const KeyMaterial *__restrict__ km, const u32 *te, const RowsParams &p, u64 t, G128 *z) {
+    const u32 m = p.sprefix ? rows_search(p.sprefix, t, 0u, p.n_pkts) : (u32)(t / p.S);
+    const RowsMsg q = rows_msg(p, m);
+    const RowsGeom g = rows_geom(q.len);
+    const u32 nas = rows_small_aad(rows_na(q.alen)), r = (u32)(t - rows_small_base(p, m));
+    uint4 x;
+    u64 e;
+    if (r < nas) {
+        const unsigned char *a = p.aad + q.aoff;
+        const u32 off = 16u * r, rem = q.alen - off;
+        x = rem >= 16u ? gload16_any(a + off) : load_block_bytes(a + off, rem);
+        e = (u64)(nas - 1u - r) + 64ull * g.R + g.tb + 2u;
+    } else {
+        const u32 i = r - nas, bi = 64u * g.R + i;                                       // block of the tail, block of the message
+        const unsigned char *ivp = p.ivs + (size_t)m * 12;
+        const uint4 ks = aes_encrypt_te(te, km->rk, km->nr, make_uint4(load_le32(ivp), load_le32(ivp + 4), load_le32(ivp + 8), bswap32(2u + bi)));
+        const unsigned char *src = p.in + q.doff;
+        unsigned char *dst = p.out + q.doff;
+        const u32 off = 16u * bi, rem = q.len - off;
+        const bool full = rem >= 16u;
+        const uint4 in = full ? gload16_any(src + off) : load_block_bytes(src + off, rem);
+        uint4 y = make_uint4(in.x ^ ks.x, in.y ^ ks.y, in.z ^ ks.z, in.w ^ ks.w);
+        if (!full) y = mask_block(y, rem);
+        if (full) gstore16_any(dst + off, y); else store_block_bytes(dst + off, y, rem);
+        x = DEC ? in : y;
+        e = g.tb - i + 1u;
+    }
+    *z = gf_mul(mo_to_be(x), gf_pow_h_serial(km, e));
+    return m;
 }
 
 // ---- k_rows_close: a record's contribution ----------------------------------------------------------

@@ -137,7 +137,7 @@ AESGCM_API int aesgcm_ctx_last_launch(const aesgcm_ctx *ctx, int *shape);
  *                 aesgcm_decrypt and aesgcm_decrypt_pipelined wipe the caller's buffer (aesgcm_decrypt does not even copy the plaintext out before the tag is
  *                 checked), aesgcm_decrypt_dev the device buffer, aesgcm_packets_crypt_dev every packet whose d_auth entry is 0 (d_auth must be given).  Default 0:
  *                 the reference model returns the plaintext and raises (tb/gcm_model.py:29-30,47-51), and so does the class that mirrors it.
- *   "rows_min"    bytes per packet from which aesgcm_packets_crypt_dev goes by rows (default 16384; packets that are whole 1 KiB rows go from half of it; 0 = never)
+ *   "rows_min"    bytes per packet from which aesgcm_packets_crypt_dev goes by rows (default 8192; from a quarter of it while the packets are at most 16384; 0 = never)
  *   "rows_block"  units (rows of 64 blocks; a message's tail) per dealt block of the row kernel, 0 = the library's cut (one block per wave; blocks of 64 for large calls)
  *   "poll_us"     how long a tag is polled for in the pinned host slot before the call blocks in the runtime
  * AESGCM_EARG for an unknown key. */
@@ -275,9 +275,9 @@ AESGCM_API int aesgcm_mgpu_destroy(aesgcm_mgpu *m);
  * and data either as fixed-size records (aad_len / pkt_len, offset arrays NULL) or delimited by uint64 offset
  * arrays with n_pkts + 1 entries (then aad_len / pkt_len are ignored); tags[p] receives the computed tag; for
  * decrypt d_auth[p] (optional) = 1 if it equals d_expect_tags[p].  Asynchronous on `stream`.
- * Packets of message size -- from 16 KiB each (context option "rows_min"; from 8 KiB when the size is a multiple of 1 KiB), up to 2^28 - 1 bytes -- go BY ROWS (round 5): the 64-block rows of all the
- * call's messages are one pool of work for the row loop a single large message runs through (csrc/aesgcm_rows.h), and one small launch behind it closes
- * every tag; 4096 x 1 MiB then runs at the rate of one 4 GiB message.  With offset arrays the lengths are on the device and the library cannot see them:
+ * Packets of message size -- from 8 KiB each (context option "rows_min"; from 2 KiB while there are at most 16384 of them), up to 2^28 - 1 bytes -- go BY ROWS (round 5): the 64-block rows of all the
+ * call's messages are one pool of work for the row loop a single large message runs through (csrc/aesgcm_rows.h), and one small launch behind it takes what
+ * is not a whole row -- headers, ragged ends -- block by block and closes every tag; 4096 x 1 MiB then runs at the rate of one 4 GiB message.  With offset arrays the lengths are on the device and the library cannot see them:
  * there pkt_len -- otherwise unused in that form -- is the caller's word for the TYPICAL packet size and selects the path (0 = frames; any packet, of any
  * length, is correct on either path).  Shorter packets take the packet kernels: at most a wave per packet.
  * With offset arrays and many packets (context option "pkt_order", default from 98304) the launch takes the packets in the order of a

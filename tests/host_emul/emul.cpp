@@ -800,25 +800,29 @@ static void emu_rows_nr(const KeyMaterial *km, int dec, RowsParams &p, u32 waves
     for (u32 tid = 0; tid < AESGCM_MAIN_WG; tid++) main_fill_lds(smem, km, &g_tb, tid, true, AESGCM_MAIN_WG, GH_TAB_K64);
     for (u32 tid = 0; tid < AESGCM_MAIN_WG; tid++) fill_lds_t4(smem, &g_tb, tid, AESGCM_MAIN_WG);
     const u32 n = p.n_pkts;
-    p.has_aad = (p.aad_off || p.aad_len) ? 1u : 0u;
     p.waves = waves;
-    std::vector<u64> prefix(n + 1, 0);
+    std::vector<u64> prefix(n + 1, 0), sprefix(n + 1, 0);
     std::vector<u32> slot_base(n + 1, 0);
     RowsHdr hdr;
     size_t slots;
-    if (p.data_off) {                                                    // k_rows_plan
-        for (u32 m = 0; m < n; m++) prefix[m + 1] = prefix[m] + rows_units(rows_geom(p.data_off[m + 1] - p.data_off[m]), p.has_aad);
+    if (p.data_off || p.aad_off) {                                       // k_rows_plan
+        for (u32 m = 0; m < n; m++) {
+            const RowsMsg q = rows_msg(p, m);
+            prefix[m + 1] = prefix[m] + rows_units(rows_geom(q.len), rows_na(q.alen));
+            sprefix[m + 1] = sprefix[m] + rows_smalls(rows_geom(q.len), rows_na(q.alen));
+        }
         hdr.G = prefix[n];
         rows_cut(hdr.G, waves, force_d, ROWS_NB_CAP, &hdr.D, &hdr.NB, &hdr.dyn);
-        for (u32 m = 0; m < n; m++) slot_base[m + 1] = slot_base[m] + rows_slots(rows_geom(p.data_off[m + 1] - p.data_off[m]), p.has_aad, prefix[m], hdr.D);
-        slots = 4 * (size_t)n + ROWS_NB_CAP;
+        for (u32 m = 0; m < n; m++) { const RowsMsg q = rows_msg(p, m); slot_base[m + 1] = slot_base[m] + rows_slots(rows_geom(q.len), rows_na(q.alen), prefix[m], hdr.D); }
+        slots = ROWS_SLOTS_PER_MSG * (size_t)n + ROWS_NB_CAP;
         CHECK(slot_base[n] <= slots, "rows: %u slots planned, %zu held", slot_base[n], slots);
-        p.hdr = &hdr; p.prefix = prefix.data(); p.slot_base = slot_base.data();
+        p.hdr = &hdr; p.prefix = prefix.data(); p.sprefix = sprefix.data(); p.slot_base = slot_base.data();
     } else {
         const RowsGeom g = rows_geom(p.pkt_len);
-        p.U = rows_units(g, p.has_aad); p.G = (u64)n * p.U;
+        const u32 na = rows_na(p.aad_len);
+        p.U = rows_units(g, na); p.S = rows_smalls(g, na); p.G = (u64)n * p.U;
         rows_cut(p.G, waves, force_d, (u64)1 << 30, &p.D, &p.NB, &p.dyn);
-        p.SM = p.U ? rows_nat_count(g, p.has_aad) + (p.U - 1u) / p.D + 1u : 0u;
+        p.SM = p.U ? rows_nat_count(g, na) + (p.U - 1u) / p.D + 1u : 0u;
         slots = (size_t)n * p.SM;
     }
     p.slot_cap = (u32)slots;
@@ -830,6 +834,12 @@ static void emu_rows_nr(const KeyMaterial *km, int dec, RowsParams &p, u32 waves
     const u64 G = p.hdr ? p.hdr->G : p.G;
     const u32 D = p.hdr ? p.hdr->D : p.D, NB = p.hdr ? p.hdr->NB : p.NB, dyn = p.hdr ? p.hdr->dyn : p.dyn;
     CHECK(dyn || NB <= waves, "rows: %u blocks for %u waves", NB, waves);
+    auto put = [&](u32 slot, const G128 &z, u64 e, u32 m, u32 flags) {
+        CHECK(slot < slots && !rec[slot].flags, "rows: slot %u of %zu taken twice (message %u)", slot, slots, m);
+        RowsRec r; r.w = z; r.e = e; r.msg = m; r.flags = flags;
+        rec[slot] = r;
+        ++made_of[m];
+    };
     for (u32 kb = 0; kb < NB; kb++) {
         const u32 b = NB - 1 - kb;                                       // last block first
         u64 g = (u64)b * D;
@@ -839,41 +849,33 @@ static void emu_rows_nr(const KeyMaterial *km, int dec, RowsParams &p, u32 waves
             const RowsMsg mq = rows_msg(p, m);
             const RowsGeom geo = rows_geom(mq.len);
             const u64 g0 = rows_unit_base(p, m);
-            const u32 U = rows_units(geo, p.has_aad), sbase = rows_slot_base(p, m);
-            if (U == 0) { ++m; continue; }                                 // an empty message without AAD has no unit: the closing alone makes its tag
+            const u32 U = rows_units(geo, rows_na(mq.alen)), sbase = rows_slot_base(p, m);
+            if (U == 0) { ++m; continue; }                                 // a message shorter than a row has no unit: the closing alone sees it
             CHECK(g >= g0 && g < g0 + U, "rows: unit %llu outside message %u", (unsigned long long)g, m);
-            u32 made = 0;
             while (g < g_end && g < g0 + U) {
                 const RowsPiece pc = rows_piece(geo, sbase, g0, (u32)(g - g0), g_end - g, D);
                 G128 z = {{0, 0, 0, 0}};
-                u32 flags = ROWS_REC_VALID | ROWS_REC_WEIGH;
                 for (u32 lane = 0; lane < 64; lane++) {
                     const CtrConsts cc = ctr_round1_consts(load_le32(p.ivs + 12 * m), load_le32(p.ivs + 12 * m + 4), load_le32(p.ivs + 12 * m + 8), km->rk, smem, (lane & 31u) << 2);
                     if (pc.kind == ROWS_RUN) {
                         const uint4 a = dec ? rows_run_lane<NR, MODE_DEC>(km, &g_tb, p, mq, pc, smem, cc, lane, 0, 0) : rows_run_lane<NR, MODE_ENC>(km, &g_tb, p, mq, pc, smem, cc, lane, 0, 0);
                         xor_g(z, rows_run_term(km, a, lane));
-                    } else if (pc.kind == ROWS_AAD) {
-                        xor_g(z, rows_aad_lane(km, p, mq, smem, lane));
                     } else {
-                        xor_g(z, dec ? rows_tail_lane<NR, 1>(km, p, mq, smem, cc, lane) : rows_tail_lane<NR, 0>(km, p, mq, smem, cc, lane));
+                        xor_g(z, rows_aad_lane(km, p, mq, smem, lane));
                     }
                 }
-                if (pc.kind == ROWS_TAIL) flags = ROWS_REC_VALID;
-                CHECK(pc.slot < slots && !rec[pc.slot].flags, "rows: slot %u of %zu taken twice (message %u)", pc.slot, slots, m);
-                RowsRec r; r.w = z; r.e = pc.e; r.msg = m; r.flags = flags;
-                rec[pc.slot] = r;
-                g += pc.len; ++made;
+                put(pc.slot, z, pc.e, m, ROWS_REC_VALID | ROWS_REC_WEIGH);
+                g += pc.len;
             }
-            made_of[m] += made;
             ++m;
         }
     }
-    // k_rows_close: a lane per message and per record slot, last first; lane i is message i (its length block and E_K(J0)) and slot i
+    // k_rows_close: the lanes last first; lane i is message i (its length block and E_K(J0)), slot i, and the blocks i, i + lanes, ... of the smalls axis
     u32 finals = 0;
+    auto due = [&](u32 m) { const RowsMsg mq = rows_msg(p, m); return rows_pieces(rows_geom(mq.len), rows_na(mq.alen), rows_unit_base(p, m), D); };
     auto arrive = [&](u32 m, const G128 &z) {
         acc[2 * m] ^= ((unsigned long long)z.w[0] << 32) | z.w[1]; acc[2 * m + 1] ^= ((unsigned long long)z.w[2] << 32) | z.w[3];
-        const RowsMsg mq = rows_msg(p, m);
-        if (++cnt[m] == rows_pieces(rows_geom(mq.len), p.has_aad, rows_unit_base(p, m), D)) {
+        if (++cnt[m] == due(m)) {
             G128 t; t.w[0] = (u32)(acc[2 * m] >> 32); t.w[1] = (u32)acc[2 * m]; t.w[2] = (u32)(acc[2 * m + 1] >> 32); t.w[3] = (u32)acc[2 * m + 1];
             acc[2 * m] = acc[2 * m + 1] = 0; cnt[m] = 0;
             store_block_bytes(p.tags + (size_t)m * 16, be_to_mo(t), 16);
@@ -884,6 +886,12 @@ static void emu_rows_nr(const KeyMaterial *km, int dec, RowsParams &p, u32 waves
     for (size_t k = 0; k < lanes; k++) {
         const size_t i = lanes - 1 - k;
         if (i < n) arrive((u32)i, rows_msg_term(km, g_tb.te0, p, (u32)i));
+        for (u64 t = i; t < rows_small_total(p); t += lanes) {
+            G128 z;
+            const u32 m = dec ? rows_small_block<1>(km, g_tb.te0, p, t, &z) : rows_small_block<0>(km, g_tb.te0, p, t, &z);
+            ++made_of[m];
+            arrive(m, z);
+        }
         if (i >= slots) continue;
         const RowsRec r = rec[i];
         if (!(r.flags & ROWS_REC_VALID)) continue;
@@ -893,8 +901,7 @@ static void emu_rows_nr(const KeyMaterial *km, int dec, RowsParams &p, u32 waves
     CHECK(finals == n, "rows: %u of %u messages closed", finals, n);
     for (u32 m = 0; m < n; m++) {
         CHECK(!acc[2 * m] && !acc[2 * m + 1] && !cnt[m], "rows: message %u not zero at rest", m);
-        const RowsMsg mq = rows_msg(p, m);
-        CHECK(made_of[m] + 1u == rows_pieces(rows_geom(mq.len), p.has_aad, rows_unit_base(p, m), D), "rows: message %u fell into %u pieces", m, made_of[m]);
+        CHECK(made_of[m] + 1u == due(m), "rows: message %u fell into %u pieces", m, made_of[m]);
     }
 }
 static void test_rows(int key_len, u64 seed, u32 waves, u32 force_d, bool var, const std::vector<u32> &lens, const std::vector<u32> &aads, u32 misalign = 0) {
@@ -990,6 +997,10 @@ int main(int argc, char **argv) {
     test_rows(24, 215, 4, 0, false, {0, 0, 0}, {5, 5, 5});                       // ... with AAD: an AAD unit each
     test_rows(32, 216, 4, 0, false, {1024, 1024, 1024, 1024, 1024}, {0, 0, 0, 0, 0});   // one row and nothing else per message
     test_rows(16, 217, 2, 0, false, {2033, 2033, 2033}, {0, 0, 0});              // a tail of 64 blocks (the last one byte long)
+    test_rows(32, 218, 6, 0, true, {16400, 16400, 100, 16384 + 1023, 0, 5000, 16, 40 * 16 + 3, 2048 + 700}, {13, 13, 1024, 1025, 20, 0, 1023, 600, 16});   // short AADs and tails share units and straddle them; an AAD of exactly 64 blocks; one of 65 (a unit of its own)
+    test_rows(24, 219, 5, 2, false, {16400, 16400, 16400, 16400, 16400, 16400, 16400}, {13, 13, 13, 13, 13, 13, 13});      // TLS-shaped records: 2 + 1 blocks of smalls each
+    test_rows(16, 220, 9, 0, false, {1024 + 40 * 16, 1024 + 40 * 16, 1024 + 40 * 16, 1024 + 40 * 16, 1024 + 40 * 16}, {30 * 16 + 1, 30 * 16 + 1, 30 * 16 + 1, 30 * 16 + 1, 30 * 16 + 1});   // 31 + 40 blocks per message: every unit boundary inside a segment
+    test_rows(32, 221, 3, 1, false, {700, 700, 700}, {2000, 2000, 2000});          // a long AAD (125 blocks) and a tail, no row
     if (level > 1) {
         test_key(32, 1, 7, {{123, 16 * 64 * 1100 + 11}});     // 1100 chunks: two stage-1 workgroups
         test_key(16, 0, 8, {{0, 16 * W * 600}});              // production rule, > GMAX chunks of Tw = 16

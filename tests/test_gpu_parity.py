@@ -383,7 +383,7 @@ def test_plain_c_caller_frames(hip, frames):
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,size", [(200, 65536 + 4096 + 16), (37, (1 << 20) + 48), (300, 20000)])
 def test_plain_c_caller_messages(hip, n, size):
-    """examples/messages.c: many messages under one key as ONE aesgcm_packets_crypt_dev call from C (by rows from 16 KiB per message) -- a sample
+    """examples/messages.c: many messages under one key as ONE aesgcm_packets_crypt_dev call from C (by rows from 8 KiB per message) -- a sample
     against aesgcm_encrypt_dev, all decrypted in place and authenticated, a forged tag reported and its message wiped (wipe_on_auth_fail)"""
     import os, subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

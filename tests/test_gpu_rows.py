@@ -91,6 +91,23 @@ def test_messages_without_a_unit_of_work(hip, orc, klen):
         _check_var(hip, orc, hip.Context(key), key, [0] * 300, [0] * 300, 845 + klen, hint=65536, forged=(7,), aad_array=False)      # nothing but empty messages: no row launch work at all
 
 
+@pytest.mark.parametrize("klen", [16, 24, 32])
+def test_headers_and_ragged_ends_of_every_kind(hip, orc, klen):
+    """what is not a whole row -- AAD and tail blocks -- is walked block by block by the lanes of the closing launch, whatever message a block belongs to: AAD of
+    1 byte .. 64 blocks (and 65: rows of its own in the row launch), tails of 1 .. 64 blocks with ragged last blocks, messages shorter than a row (no unit in the
+    row launch at all), messages that are all AAD; TLS-shaped records (16 KiB + 13 bytes of header) by the hundred"""
+    rng = random.Random(900 + klen)
+    key = splitmix_bytes(7400 + klen, klen)
+    ctx = hip.Context(key)
+    lens = [16400, 16384, 100, 16384 + 1023, 0, 5000, 16, 40 * 16 + 3, 2048 + 700, 0, 65536 + 1, 1024 * 9 + 1009, 33] + [rng.randrange(0, 70000) for _ in range(40)]
+    aads = [13, 13, 1024, 1025, 20, 0, 1023, 600, 16, 2000, 1, 1040, 0] + [rng.choice((0, 5, 13, 16, 17, 64, 333, 1024, 1025, 3000)) for _ in range(40)]
+    _check_var(hip, orc, ctx, key, lens, aads, 860 + klen, hint=65536, forged=(0, 9, 30))
+    with hip.debug_library() as dbg:
+        dbg.force(pkt_rows=1)
+        c2 = hip.Context(key)
+        _check_var(hip, orc, c2, key, [16384 + 16 * (i % 3) + (i % 5) for i in range(700)], [13] * 700, 865 + klen, hint=16384, forged=(699,))
+
+
 def test_packed_from_an_odd_byte_address(hip, orc):
     key = splitmix_bytes(7200, 16)
     ctx = hip.Context(key)
@@ -98,9 +115,10 @@ def test_packed_from_an_odd_byte_address(hip, orc):
 
 
 @pytest.mark.parametrize("klen,pkt,al,n", [(32, 65536, 0, 300), (16, 65536 + 48, 20, 70), (24, 1 << 20, 16, 9), (32, 3 * 4096 + 1024 + 1, 0, 40), (16, 700, 12, 50),
-                                           (32, 1024, 0, 77), (16, 2033, 0, 30), (24, 0, 0, 20), (24, 0, 7, 20), (32, 4096, 20, 1000)])
+                                           (32, 1024, 0, 77), (16, 2033, 0, 30), (24, 0, 0, 20), (24, 0, 7, 20), (32, 4096, 20, 1000),
+                                           (32, 16400, 13, 500), (16, 16384, 1024, 40), (24, 17000, 1040, 40), (32, 500, 3000, 33)])
 def test_fixed_size_records(hip, orc, klen, pkt, al, n):
-    """fixed-size records: the library's own rule (by rows from 16 KiB per packet, from 8 KiB for whole rows) and, below that, rows forced through the debug
+    """fixed-size records: the library's own rule (by rows from 8 KiB per packet, from 2 KiB when few) and, below that, rows forced through the debug
     library -- including records shorter than a row, which then are tails only, and records of no bytes, which are the closing launch's alone"""
     key = splitmix_bytes(7300 + pkt % 1000, klen)
     f = orc.Fast(key)
@@ -122,7 +140,7 @@ def test_fixed_size_records(hip, orc, klen, pkt, al, n):
         assert bytes(d_buf.download(pkt * n)) == pt
         assert set(struct.unpack("<%di" % n, bytes(d_auth.download()))) == {1}
 
-    if pkt >= 16384:
+    if pkt >= 2048:
         ctx = hip.Context(key)
         assert ctx.packets_shape(n, pkt) == hip.SHAPE_ROWS
         return run(ctx)
@@ -132,14 +150,15 @@ def test_fixed_size_records(hip, orc, klen, pkt, al, n):
 
 
 def test_the_rule_that_sends_a_call_by_rows(hip):
-    """aesgcm_packets_shape: by rows from 16 KiB per packet, from 8 KiB when the packets are whole 1 KiB rows (no tail piece); "rows_min" moves the mark, 0 = never"""
+    """aesgcm_packets_shape: by rows from 8 KiB per packet, from 2 KiB while the packets are at most 16384 (the packet kernels want a packet per lane to fill the
+    chip); "rows_min" moves the mark, 0 = never"""
     ctx = hip.Context(bytes(32))
     rows = lambda n, pkt, var=False: ctx.packets_shape(n, pkt, var) == hip.SHAPE_ROWS
-    assert rows(1000, 16384) and rows(1000, 16400) and rows(1 << 20, 1 << 20) and rows(5, 8192) and rows(1 << 19, 9216)
-    assert not rows(1000, 8208) and not rows(1000, 4096) and not rows(1000, 16383) and not rows(10, 1514)
-    assert rows(1000, 65536, True) and not rows(1000, 0, True)
+    assert rows(1 << 20, 8192) and rows(1 << 19, 8208) and rows(1000, 16400) and rows(5, 1 << 20) and rows(16384, 2048) and rows(100, 4100)
+    assert not rows(16385, 8191) and not rows(1 << 20, 4096) and not rows(1000, 2047) and not rows(10, 1514)
+    assert rows(100000, 65536, True) and not rows(1000, 0, True)
     ctx.set_option("rows_min", 65536)
-    assert rows(10, 65536) and rows(10, 32768) and not rows(10, 32784) and not rows(10, 16384)
+    assert rows(10, 65536) and rows(10, 16384) and not rows(16385, 32768) and not rows(10, 16383)
     ctx.set_option("rows_min", 0)
     assert not rows(10, 1 << 20)
 
