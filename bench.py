@@ -475,7 +475,7 @@ def run_cfg5(args, rank, world, dev, ex, cpu_base):
 
 # ------------------------------------------------------------------------------------------------ many messages under one key
 def run_msgs(args, dev, cpu_base):
-    """--config msgs: n messages of one size under ONE key as the packets of one aesgcm_packets_crypt_dev call (by rows from 64 KiB per message: k_rows +
+    """--config msgs: n messages of one size under ONE key as the packets of one aesgcm_packets_crypt_dev call (by rows: k_rows +
     k_rows_close).  A step is one call; calls are queued four at a time.  Parity in the run: the tags of a sample of the messages equal what the single-message
     path of the same library (pinned to the libcrypto fixtures by the test-suite) gives for the same bytes, and so does their ciphertext by SHA-256."""
     import aesgcm_amd  # noqa: F401

@@ -1,5 +1,5 @@
 /* Plain-C caller of libaesgcm_hip.so: MANY MESSAGES under one key -- the reference's deployment (frame after frame under one key, tb/gcm_test.py:76-85; H kept
- * while no key is loaded, src/gcm_gctr.vhd:142-144) at message size -- as ONE device call: aesgcm_packets_crypt_dev over fixed-size records, which from 32 KiB
+ * while no key is loaded, src/gcm_gctr.vhd:142-144) at message size -- as ONE device call: aesgcm_packets_crypt_dev over fixed-size records, which from 8 KiB
  * per packet goes by rows (aesgcm_packets_shape says AESGCM_SHAPE_ROWS; csrc/aesgcm_rows.h).  A sample of the messages is encrypted once more through the
  * single-message entry point (aesgcm_encrypt_dev) and must give the same tag; all are decrypted in place and authenticated, one forged tag must be reported
  * and -- with the context option wipe_on_auth_fail -- its message come back as zeros.

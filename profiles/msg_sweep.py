@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Messages of 64 KiB .. 16 MiB under ONE key, every way the library offers to run them, from one box in one process (GPU box):
+"""Messages of 8 KiB .. 16 MiB under ONE key, every way the library offers to run them, from one box in one process (GPU box):
 
     python profiles/msg_sweep.py [--total-gib 4] [--key-bits 256] > profiles/r05/size_sweep.txt
 
   waited     one context, aesgcm_encrypt_dev with the tag waited for, message after message (the reference model's call order, tb/gcm_model.py:21-35)
   K = 3      three contexts with a stream each, calls enqueued with tag = NULL, the tag collected when the context comes round again (bench.py --inflight 3)
-  packets    ALL the messages as the packets of one aesgcm_packets_crypt_dev call: by rows (k_rows, round 5: the library's rule from 64 KiB per packet) ...
+  packets    ALL the messages as the packets of one aesgcm_packets_crypt_dev call: by rows (k_rows, round 5: the library's rule from 8 KiB per packet) ...
   pkt kernels   ... and with rows switched off (context option rows_min = 0): the wave-per-packet / lane-group kernels of round 4
 The buffers of one measurement total --total-gib (beyond the 256 MiB Infinity Cache), every form runs for at least 0.25 s after a warm-up of its own (the chip
 takes some milliseconds of load to reach its clock), the packet calls are queued back to back and waited for once.  GiB/s of plaintext; `shape` is what
@@ -21,7 +21,7 @@ from aesgcm_amd import lib  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--total-gib", type=float, default=4.0)
 ap.add_argument("--key-bits", type=int, default=256)
-ap.add_argument("--sizes-kib", type=int, nargs="*", default=[64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384])
+ap.add_argument("--sizes-kib", type=int, nargs="*", default=[8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384])
 ap.add_argument("--min-s", type=float, default=0.25)
 a = ap.parse_args()
 GiB = 1 << 30
@@ -93,7 +93,7 @@ for kib in a.sizes_kib:
         c.close()
     # all of them as packets of one call: by rows, and by the packet kernels
     res = []
-    for rows_min in (65536, 0):
+    for rows_min in (8192, 0):                                       # the library's own rule / never
         ctx = lib.Context(key)
         if rows_min == 0:
             ctx.set_option("rows_min", 0)

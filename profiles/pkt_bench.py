@@ -4,7 +4,7 @@
          pktw   N packets under ONE key, one wave per packet (k_pktg<.., 6>)
          pktg   N packets under ONE key, 16 lanes per packet (k_pktg<.., 4>)
          pktl   N packets under ONE key, one lane per packet (k_pktl)
-         pkt    N packets under ONE key, the library's own choice (product library): by rows (k_rows) from 64 KiB per packet
+         pkt    N packets under ONE key, the library's own choice (product library): by rows (k_rows) from 8 KiB per packet, from 2 KiB when few
          rows / norows   by rows always / never (debug library)
 Prints one JSON line: ms per launch (median and best of K, HIP-synchronised wall time; ms_queued: K calls enqueued back to back and waited for once, per
 call -- what a caller that keeps the stream busy sees), packets/s, GiB/s and the algorithmic HBM bytes per launch (32 B per block + key/IV/tag traffic)."""

@@ -27,7 +27,7 @@ for p in sorted(glob.glob(sys.argv[1]+"/bench*.json")):
     except Exception as e:
         print(p, "unreadable", e)
 PY
-timeout 600 python profiles/msg_sweep.py > $O/size_sweep.txt 2> $O/size_sweep.err; cat $O/size_sweep.txt
+timeout 900 python profiles/msg_sweep.py > $O/size_sweep.txt 2> $O/size_sweep.err; cat $O/size_sweep.txt
 timeout 600 python profiles/msg_sweep.py --total-gib 0.25 --sizes-kib 64 256 1024 4096 16384 > $O/size_sweep_256m.txt 2>> $O/size_sweep.err; cat $O/size_sweep_256m.txt
 INFLIGHT_KS="1 3" bash profiles/inflight_sweep.sh $O/inflight 1 16 64 2>&1 | tee $O/inflight_sweep.txt
 timeout 600 python profiles/packets_sweep.py 32 var > $O/packets_sweep_mixed_aes256.txt 2>&1
@@ -42,7 +42,10 @@ bash profiles/collect.sh rows_1m 'k_rows<' bench.py --config msgs --steps 8 --wa
 bash profiles/collect.sh rows_1m_dec 'k_rows<' bench.py --config msgs --decrypt --steps 8 --warmup 2 --no-cpu-baseline > $O/collect_rows_1m_dec.txt 2>&1
 bash profiles/collect.sh rows_64k 'k_rows<' bench.py --config msgs --n-pkts 4096 --pkt-len 65536 --steps 100 --warmup 20 --no-cpu-baseline > $O/collect_rows_64k.txt 2>&1
 bash profiles/collect.sh rows_mixed 'k_rows<' profiles/rows_mixed.py > $O/collect_rows_mixed.txt 2>&1
-for t in cfg3_n1 cfg2_n1 cfg5_n1 rows_1m rows_1m_dec rows_64k rows_mixed; do
+bash profiles/collect.sh rows_tls 'k_rows<' profiles/pkt_bench.py pkt --n 262144 --len 16400 --aad 13 --key-bits 256 --steps 9 > $O/collect_rows_tls.txt 2>&1
+bash profiles/runs/r05_rows_min2.sh > /dev/null 2>&1; bash profiles/runs/r05_rows_min3.sh > /dev/null 2>&1; bash profiles/runs/r05_aad_cost.sh > /dev/null 2>&1
+cp gpurun_out/r05/rows_min_sweep2.txt gpurun_out/r05/rows_min_sweep3.txt $O/; cp gpurun_out/r05/rows_aad_cost.txt $O/rows_aad_cost_after.txt
+for t in cfg3_n1 cfg2_n1 cfg5_n1 rows_1m rows_1m_dec rows_64k rows_mixed rows_tls; do
   mkdir -p $O/prof_$t; cp gpurun_out/prof_$t/summary*.txt gpurun_out/prof_$t/pmc_$t.json gpurun_out/prof_$t/pmc_cfg3_probe.json gpurun_out/prof_$t/stats_run.json $O/prof_$t/ 2>/dev/null
   find gpurun_out/prof_$t/stats -name "*kernel_stats.csv" -exec cp {} $O/prof_$t/kernel_stats.csv \;
   echo "== $t"; grep -E "hot_kernel|hot_avg_ns|hbm_bytes_per_launch|lds_busy_frac|SQ_LDS_BANK_CONFLICT|SQ_LDS_IDX_ACTIVE " gpurun_out/prof_$t/summary.txt | head -8
