@@ -138,7 +138,7 @@ AESGCM_API int aesgcm_ctx_last_launch(const aesgcm_ctx *ctx, int *shape);
  *                 checked), aesgcm_decrypt_dev the device buffer, aesgcm_packets_crypt_dev every packet whose d_auth entry is 0 (d_auth must be given).  Default 0:
  *                 the reference model returns the plaintext and raises (tb/gcm_model.py:29-30,47-51), and so does the class that mirrors it.
  *   "rows_min"    bytes per packet from which aesgcm_packets_crypt_dev goes by rows (default 8192; from a quarter of it while the packets are at most 16384; 0 = never)
- *   "rows_block"  units (rows of 64 blocks; a message's tail) per dealt block of the row kernel, 0 = the library's cut (one block per wave; blocks of 64 for large calls)
+ *   "rows_block"  units (rows of 64 blocks) per dealt block of the row kernel, 0 = the library's cut (one block per wave; blocks of 64 for large calls)
  *   "poll_us"     how long a tag is polled for in the pinned host slot before the call blocks in the runtime
  * AESGCM_EARG for an unknown key. */
 AESGCM_API int aesgcm_ctx_set_option(aesgcm_ctx *ctx, const char *key, int64_t value);

@@ -108,6 +108,33 @@ def test_headers_and_ragged_ends_of_every_kind(hip, orc, klen):
         _check_var(hip, orc, c2, key, [16384 + 16 * (i % 3) + (i % 5) for i in range(700)], [13] * 700, 865 + klen, hint=16384, forged=(699,))
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_random_calls_by_rows(hip, orc, seed):
+    """random calls forced by rows: 1 .. 250 messages, lengths drawn from empty / shorter than a block / shorter than a row / whole rows / ragged / a few
+    hundred KiB, AAD from none / a header / exactly 64 blocks / 65 and more, with or without an AAD array at all, random units per dealt block (or the
+    library's cut), a random byte address to pack from, random forged tags -- every message against the oracle, decrypt in place"""
+    rng = random.Random(4200 + seed)
+    klen = rng.choice((16, 24, 32))
+    key = splitmix_bytes(7500 + seed, klen)
+    n = rng.randrange(1, 251)
+
+    def length():
+        k = rng.randrange(7)
+        return (0, rng.randrange(1, 16), rng.randrange(16, 1024), 1024 * rng.randrange(1, 40), rng.randrange(1024, 70000), 1024 * rng.randrange(1, 9) + 1008 + rng.randrange(1, 16),
+                rng.randrange(100000, 400000))[k]
+    lens = [length() for _ in range(n)]
+    with_aad = rng.random() < 0.7
+    aads = [rng.choice((0, 0, 13, 20, rng.randrange(1, 1025), 1024, 1025, rng.randrange(1025, 5000))) if with_aad else 0 for _ in range(n)]
+    forged = tuple(sorted(rng.sample(range(n), min(n, rng.randrange(0, 4)))))
+    with hip.debug_library() as dbg:
+        dbg.force(pkt_rows=1)
+        ctx = hip.Context(key)
+        d = rng.choice((0, 0, 1, 2, 5, 64, 300))
+        if d:
+            ctx.set_option("rows_block", d)
+        _check_var(hip, orc, ctx, key, lens, aads, 9000 + seed, hint=rng.choice((0, 4096, 1 << 20)), misalign=rng.choice((0, 0, 3, 16, 21)), forged=forged, aad_array=with_aad or rng.random() < 0.5)
+
+
 def test_packed_from_an_odd_byte_address(hip, orc):
     key = splitmix_bytes(7200, 16)
     ctx = hip.Context(key)
