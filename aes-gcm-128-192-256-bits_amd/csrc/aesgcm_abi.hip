@@ -576,7 +576,7 @@ int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const vo
     if (!d_ivs || !d_tags || ((aad_len || d_aad_off) && !d_aad) || ((pkt_len || d_data_off) && (!d_in || !d_out))) return AESGCM_EARG;
     if (n_pkts >= (((size_t)1) << 31) || pkt_len >= (((size_t)1) << 28) || aad_len >= (((size_t)1) << 28)) return AESGCM_ETOOLONG;
     HIPCHK(hipSetDevice(c->device));
-    if (packets_by_rows(c, n_pkts, pkt_len)) {                                        // message-sized packets: the rows of all of them through k_body's row loop
+    if (packets_by_rows(c, n_pkts, pkt_len, d_data_off != nullptr)) {                    // message-sized packets: the rows of all of them through k_body's row loop
         RowsParams r;
         memset(&r, 0, sizeof r);
         r.ivs = (const unsigned char *)d_ivs; r.aad = (const unsigned char *)d_aad; r.in = (const unsigned char *)d_in;
@@ -713,7 +713,7 @@ int aesgcm_batch_shape(int device, size_t n_pkts, size_t pkt_len, int var_len, i
 
 int aesgcm_packets_shape(const aesgcm_ctx *c, size_t n_pkts, size_t pkt_len, int var_len, int *lanes_per_packet) {
     if (!c || !lanes_per_packet || !n_pkts) return AESGCM_EARG;
-    if (packets_by_rows(c, n_pkts, pkt_len)) { *lanes_per_packet = AESGCM_SHAPE_ROWS; return AESGCM_OK; }
+    if (packets_by_rows(c, n_pkts, pkt_len, var_len != 0)) { *lanes_per_packet = AESGCM_SHAPE_ROWS; return AESGCM_OK; }
     int lg = packets_pick_lg((u32)c->G / 2, n_pkts, pkt_len, var_len != 0, packets_ordered(c, n_pkts, var_len != 0));
 #ifdef AESGCM_DEBUG_KNOBS
     if (g_force.pkt_lanes) lg = g_force.pkt_lanes == 1 ? 0 : g_force.pkt_lanes == 64 ? 6 : g_force.pkt_lanes == 16 ? 4 : g_force.pkt_lanes == 8 ? 3 : 2;

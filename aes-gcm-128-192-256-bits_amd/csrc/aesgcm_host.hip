@@ -709,13 +709,20 @@ int packets_rows(aesgcm_ctx *c, int decrypt, RowsParams &p, hipStream_t st) {
 // 6 KiB x 699050 709 / 802, x 65536 613 / 613, x 8192 501 / 282; 4 KiB x 2^20 620 / 810, x 131072 557 / 667, x 32768 495 / 485, x 16384 502 / 384, x 4096 339 / 151;
 // 2 KiB x 2^20 429 / 804, x 16384 352 / 242, x 4096 206 / 115; 1 KiB x 262144 264 / 616, x 4096 116 / 83.
 // Offset arrays: the host does not know the lengths; the caller's pkt_len, otherwise unused in that form, is its word for the typical packet (0 = frames)
-bool packets_by_rows(const aesgcm_ctx *c, size_t n_pkts, size_t pkt_len) {
+bool packets_by_rows(const aesgcm_ctx *c, size_t n_pkts, size_t pkt_len, bool var_len) {
 #ifdef AESGCM_DEBUG_KNOBS
     if (g_force.pkt_rows) return g_force.pkt_rows == 1;
     if (g_force.pkt_lanes) return false;                                     // a forced shape of the packet kernels means the packet kernels
 #endif
     if (!c->rows_min) return false;
-    return pkt_len >= c->rows_min || (4 * pkt_len >= c->rows_min && n_pkts <= 16384);
+    if (n_pkts <= 16384) return 4 * pkt_len >= c->rows_min;
+    if (pkt_len < c->rows_min) return false;
+    // many packets of 8 .. 16 KiB whose last, partial row has more than a few blocks: what is not a whole row costs a message about a row and a half either way (a
+    // pass of a wave in the row launch, or a lane per block of the closing launch), and the lane-per-packet kernel keeps them -- 262 144 x 9000 bytes (8 rows + 51
+    // blocks) 613 by rows, 768 there; x 8448 (8 rows + 16 blocks) 696 / 821; from 16 KiB rows win again: 131 072 x 16 656 744 / 682
+    // (profiles/r05/rows_ragged_many.txt).  Fixed-size records only: with offset arrays the host does not see the lengths
+    if (!var_len && pkt_len < 2 * c->rows_min && rows_geom(pkt_len).tb > ROWS_FEW_TAIL) return false;
+    return true;
 }
 
 // zero the output of every packet whose d_auth[] entry is 0 (behind the launch that wrote it, on the same stream)

@@ -224,7 +224,7 @@ int packets_order(aesgcm_ctx *c, const u64 *d_off, size_t n_pkts, hipStream_t st
 size_t rows_carve(unsigned char *base, size_t slots, size_t n, RowsScratch *r);
 int rows_scratch(aesgcm_ctx *c, size_t slots, size_t n, hipStream_t st, RowsScratch *r);
 int packets_rows(aesgcm_ctx *c, int decrypt, RowsParams &p, hipStream_t st);
-bool packets_by_rows(const aesgcm_ctx *c, size_t n_pkts, size_t pkt_len);
+bool packets_by_rows(const aesgcm_ctx *c, size_t n_pkts, size_t pkt_len, bool var_len);
 int wipe_failed(int device, size_t n_pkts, void *d_out, size_t pkt_len, const u64 *d_data_off, const int *d_auth, hipStream_t st);
 int batch_launch(int device, int decrypt, size_t n_pkts, size_t key_len, BatchParams &p, void *stream);
 void pipeline_release(aesgcm_ctx *c);

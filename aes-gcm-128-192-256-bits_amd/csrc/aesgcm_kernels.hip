@@ -1186,7 +1186,7 @@ __global__ __launch_bounds__(AESGCM_BODY_WG, AESGCM_BODY_WPS) void k_rows(const 
             if (g >= g0 + U) { ++m; if (U == 0) { ++skipped; --guard2; } continue; }     // the next message (one without a unit -- shorter than a row -- does not count against the bound of the walk)
             const RowsPiece pc = rows_piece(geo, uniform32(rows_slot_base(p, m)), g0, (u32)(g - g0), g_end - g, D);
             RowsRec *rr = p.rec + pc.slot;
-            if (lane_id_fresh() == 0) { rr->e = pc.e; rr->msg = m; rr->flags = ROWS_REC_VALID | ROWS_REC_WEIGH; }
+            if (lane_id_fresh() == 0) { rr->e = pc.e; rr->msg = m; rr->flags = pc.kind == ROWS_TAIL ? ROWS_REC_VALID : (ROWS_REC_VALID | ROWS_REC_WEIGH); }    // (the tail is weighted already: lane terms H^(65 - L))
             // every kind of piece takes the lane's index FRESH (lane_id_fresh: opaque to the compiler), so that nothing lane-dependent of the AAD code -- table
             // addresses, byte masks -- is hoisted out of the piece loop and kept in registers across the row loop (first build: 26 scratch accesses per row)
             G128 z;
@@ -1197,8 +1197,12 @@ __global__ __launch_bounds__(AESGCM_BODY_WG, AESGCM_BODY_WPS) void k_rows(const 
                 CtrConsts cc = ctr_round1_consts(uniform32(load_le32(ivp)), uniform32(load_le32(ivp + 4)), uniform32(load_le32(ivp + 8)), km->rk, smem, (lane_id_fresh() & 31u) << 2);   // key and IV only: wave-uniform
                 cc.c0 = __builtin_amdgcn_readfirstlane(cc.c0); cc.c1 = __builtin_amdgcn_readfirstlane(cc.c1);
                 cc.c2 = __builtin_amdgcn_readfirstlane(cc.c2); cc.c3 = __builtin_amdgcn_readfirstlane(cc.c3);
-                const uint4 acc = rows_run_lane<NR, MODE>(km, tb, p, mq, pc, smem, cc, lane_id_fresh(), dyn ? 0u : p.prio_rows, (tid >> 8) & 3u);
-                z = wave_xor(rows_run_term(km, acc, lane_id_fresh()));
+                if (pc.kind == ROWS_RUN) {
+                    const uint4 acc = rows_run_lane<NR, MODE>(km, tb, p, mq, pc, smem, cc, lane_id_fresh(), dyn ? 0u : p.prio_rows, (tid >> 8) & 3u);
+                    z = wave_xor(rows_run_term(km, acc, lane_id_fresh()));
+                } else {
+                    z = wave_xor(rows_tail_lane<NR, MODE == MODE_DEC>(km, p, mq, smem, cc, lane_id_fresh()));
+                }
             }
             if (lane_id_fresh() == 0) rr->w = z;
             g += pc.len;
@@ -1212,14 +1216,14 @@ __global__ __launch_bounds__(AESGCM_BODY_WG, AESGCM_BODY_WPS) void k_rows(const 
 // message's last arrival holds the tag: it stores it and (decrypt) compares.  Memory-side atomics only, as acc_arrive: the XORs have returned before the arrival
 // is counted.  Zero at rest: the lane puts its record's flags back to zero, the closing lane the message's accumulator and count, workgroup 0 the dispensers.
 template <int DEC>
-__device__ __forceinline__ void rows_arrive(const RowsParams &p, u32 m, const G128 &z) {
+__device__ __forceinline__ void rows_arrive(const RowsParams &p, u32 m, const G128 &z, u32 count) {           // count: arrivals the caller stands for (a run of smalls blocks folded into one lane)
     const unsigned long long ohi = atomicXor(p.acc + 2u * m, ((unsigned long long)z.w[0] << 32) | z.w[1]);
     const unsigned long long olo = atomicXor(p.acc + 2u * m + 1u, ((unsigned long long)z.w[2] << 32) | z.w[3]);
     u32 dep;
     asm volatile("v_and_b32 %0, 0, %1" : "=v"(dep) : "v"((u32)(ohi ^ olo) | (u32)((ohi ^ olo) >> 32)));
-    const u32 arrived = atomicAdd(p.cnt + m, 1u + dep);
+    const u32 arrived = atomicAdd(p.cnt + m, count + dep);
     const RowsMsg mq = rows_msg(p, m);
-    if (arrived + 1u != rows_pieces(rows_geom(mq.len), rows_na(mq.alen), rows_unit_base(p, m), p.hdr ? p.hdr->D : p.D)) return;
+    if (arrived + count != rows_pieces(rows_geom(mq.len), rows_na(mq.alen), rows_unit_base(p, m), p.hdr ? p.hdr->D : p.D)) return;
     const unsigned long long hi = atomicExch(p.acc + 2u * m, 0ull), lo = atomicExch(p.acc + 2u * m + 1u, 0ull);
     p.cnt[m] = 0;
     G128 t; t.w[0] = (u32)(hi >> 32); t.w[1] = (u32)hi; t.w[2] = (u32)(lo >> 32); t.w[3] = (u32)lo;
@@ -1244,18 +1248,40 @@ __global__ __launch_bounds__(ROWS_CLOSE_WG) void k_rows_close(const KeyMaterial 
     const u32 i = blockIdx.x * ROWS_CLOSE_WG + threadIdx.x;
     const u32 *te = reinterpret_cast<const u32 *>(smem + ROWS_CLOSE_LDS_TE);
     if (p.hdr && p.hdr->bad) return;
-    if (i < p.n_pkts) rows_arrive<DEC>(p, i, rows_msg_term(km, te, p, i));
+    if (i < p.n_pkts) rows_arrive<DEC>(p, i, rows_msg_term(km, te, p, i), 1u);
+    // The smalls: the waves of the launch take 64 consecutive blocks of the axis at a time.  The blocks of one message are neighbours, and one address serves
+    // 87 M atomics a second (aesgcm_stream.h): the lanes of a segment -- one message's AAD, or its tail -- fold their terms first (a segmented reduction by doubling) and the first of them pays what is
+    // still due of the segment's power of H and arrives for all -- 13-byte headers and tails of 51 blocks one by one made 262 144 x 9000 bytes 325 GiB/s, profiles/r05/rows_ragged_few.txt.
     const u64 total = rows_small_total(p), lanes = (u64)gridDim.x * ROWS_CLOSE_WG;
-    for (u64 t = i, guard = 0; t < total && guard <= 2u * ROWS_SMALL_AAD + 2u; t += lanes, ++guard) {      // (the launch has a lane per message at least, a message at most 128 blocks here)
-        G128 z;
-        const u32 m = rows_small_block<DEC>(km, te, p, t, &z);
-        rows_arrive<DEC>(p, m, z);
+    const u32 lane = threadIdx.x & 63u;
+    for (u64 base = (u64)blockIdx.x * ROWS_CLOSE_WG + (threadIdx.x & ~63u), guard = 0; base < total && guard <= ROWS_SMALL_AAD + ROWS_SMALL_TAIL + 2u; base += lanes, ++guard) {   // (a lane per message at least, a message at most 80 blocks here)
+        const u64 t = base + lane;
+        const bool active = t < total;
+        G128 z; z.w[0] = z.w[1] = z.w[2] = z.w[3] = 0;
+        u32 m = 0xFFFFFFFFu;
+        u64 e_run = 0;
+        if (active) m = rows_small_block<DEC>(km, te, p, t, &z, &e_run);
+        const u32 key = active ? 2u * m + (e_run ? 1u : 0u) : 0xFFFFFFFFu;               // a segment: one message's AAD, or its tail
+        const u32 before = __shfl_up(key, 1);
+        const bool head = active && (lane == 0 || before != key);
+        const unsigned long long heads = __ballot(head), act = __ballot(active);
+#pragma unroll
+        for (u32 off = 1; off < 64u; off <<= 1) {
+            const u32 ok = __shfl_down(key, off);
+            const u32 z0 = __shfl_down(z.w[0], off), z1 = __shfl_down(z.w[1], off), z2 = __shfl_down(z.w[2], off), z3 = __shfl_down(z.w[3], off);
+            if (lane + off < 64u && ok == key) { z.w[0] ^= z0; z.w[1] ^= z1; z.w[2] ^= z2; z.w[3] ^= z3; }
+        }
+        if (head) {
+            const unsigned long long later = lane == 63u ? 0ull : heads >> (lane + 1u);
+            const u32 next = later ? lane + 1u + (u32)__builtin_ctzll(later) : 64u, n_act = (u32)__builtin_popcountll(act);
+            rows_arrive<DEC>(p, m, rows_small_due(km, z, e_run), (next < n_act ? next : n_act) - lane);
+        }
     }
     if (i >= p.slot_cap) return;
     const RowsRec r = p.rec[i];
     if (!(r.flags & ROWS_REC_VALID)) return;
     p.rec[i].flags = 0;
-    rows_arrive<DEC>(p, r.msg, rows_weigh(km, r));
+    rows_arrive<DEC>(p, r.msg, rows_weigh(km, r), 1u);
 }
 
 // The cut of a call with offset arrays, on the device (the host does not know the lengths): ONE workgroup.  Units per message -> prefix[0 .. n] and G; the cut

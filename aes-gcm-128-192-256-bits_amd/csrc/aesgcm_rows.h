@@ -10,7 +10,8 @@
 //     src/aes_icb.vhd:97-118, so every message IS an aligned body), plus a TAIL of tb <= 64 blocks (the last one ragged), plus its AAD;
 //   * the ROWS are laid on an axis of UNITS: a unit per row of every message, in their order (and one for an AAD of more than 64 blocks, as rows of its
 //     own).  A RUN of consecutive rows is body_rows_lane's: k_body's row code with the lane constants of all four row phases in registers and one Horner
-//     accumulator of stride H^64, so a run of any length leaves ONE value behind;
+//     accumulator of stride H^64, so a run of any length leaves ONE value behind.  A tail of more than 16 blocks is one more unit behind the message's rows: a
+//     right-aligned row through the general cipher code, one pass of a wave;
 //   * the axis is cut into BLOCKS of D units.  A small or mid-size call is cut into exactly one block per wave of the launch (equal shares, no dispenser:
 //     the launch is as long as its rows and nothing waits for a last chunk); a large one into blocks of 64 units dealt from dispensers, as k_body deals
 //     its chunks.  Where a block's range meets the boundaries of a message it falls into PIECES: a run of rows, a long AAD;
@@ -20,7 +21,7 @@
 //     profiles/r05/rows_ab2/lds_lane_tables_ab.txt), XORed over the wave, is the polynomial of the run up to its last block -- a 32-byte RECORD per piece:
 //     those 16 bytes, the message, and the exponent still due: H^(blocks behind the piece + 2), e = 64 (R - 1 - last row) + tb + 2 (the long AAD:
 //     64 R + tb + 2).  HBM traffic is 1.00 x algorithmic whatever the cut;
-//   * everything that is NOT a whole row -- the AAD blocks (up to 64) and the tail blocks of every message, and what a message owes once: the length block and
+//   * everything else -- the AAD blocks (up to 64) and the blocks of SHORT tails (up to 16) of every message, and what a message owes once: the length block and
 //     E_K(J0) -- is the SMALLS: message after message, block after block, one more axis, walked by the LANES of the closing launch (k_rows_close), a lane per
 //     block, whatever message it belongs to.  The lane finds its message (arithmetic, or a search in the plan's prefix sums), runs the cipher under ITS
 //     message's IV through a 4 KiB copy of the four T-tables in the workgroup's LDS, and weighs its block with the power of H its place in its message asks
@@ -45,8 +46,12 @@
 #define ROWS_STATIC_MAX 192u                  /* units per wave up to which a call is cut into one block per wave */
 #define ROWS_CLOSE_WG 256u                    /* lanes per k_rows_close workgroup */
 #define ROWS_NB_CAP 65536u                    /* offset-array form: blocks the scratch is sized for (k_rows_plan falls back to one block per wave beyond) */
-#define ROWS_SMALL_AAD 64u                    /* an AAD of up to this many blocks lies on the smalls axis; a longer one is a unit of the row axis (rows of its own, Horner with H^64) */
-#define ROWS_SLOTS_PER_MSG 2u                 /* offset-array form: record slots per message besides one per block boundary -- a run, a long AAD */
+#define ROWS_SMALL_AAD 64u                    /* an AAD of up to this many blocks lies on the smalls axis; a longer one is a unit of the row launch (rows of its own, Horner with H^64) */
+#define ROWS_SMALL_TAIL 16u                   /* a tail of up to this many blocks lies on the smalls axis; a longer one is a unit of the row launch: one pass of a wave (a block of the smalls costs the
+                                                 closing launch about a sixteenth of such a pass; 262 144 x 9000 bytes -- tails of 51 blocks -- 325 GiB/s with every tail in the closing launch,
+                                                 profiles/r05/rows_ragged_few.txt) */
+#define ROWS_FEW_TAIL 4u                      /* the routing rule's word for "ends (almost) on a row" (packets_by_rows) */
+#define ROWS_SLOTS_PER_MSG 3u                 /* offset-array form: record slots per message besides one per block boundary -- a run, a long tail, a long AAD */
 #define ROWS_REC_VALID 1u
 #define ROWS_REC_WEIGH 2u
 
@@ -92,20 +97,22 @@ HD RowsGeom rows_geom(u64 len) {
 HD u32 rows_na(u32 alen) { return (alen + 15u) >> 4; }                                   // AAD blocks
 HD u32 rows_long_aad(u32 na) { return na > ROWS_SMALL_AAD ? 1u : 0u; }
 HD u32 rows_small_aad(u32 na) { return na > ROWS_SMALL_AAD ? 0u : na; }
-HD u32 rows_units(const RowsGeom &g, u32 na) { return g.R + rows_long_aad(na); }         // units of the row launch (0 for a message shorter than a row: only the closing sees it)
-HD u32 rows_smalls(const RowsGeom &g, u32 na) { return rows_small_aad(na) + g.tb; }      // blocks on the smalls axis: the (short) AAD, then the tail
-// the natural segment of unit u of a message: its rows (when it has any), then the long AAD
-HD u32 rows_nat(const RowsGeom &g, u32 u) { return u < g.R ? 0u : (g.R ? 1u : 0u); }
-HD u32 rows_nat_count(const RowsGeom &g, u32 na) { return (g.R ? 1u : 0u) + rows_long_aad(na); }
+HD u32 rows_long_tail(const RowsGeom &g) { return g.tb > ROWS_SMALL_TAIL ? 1u : 0u; }
+HD u32 rows_small_tail(const RowsGeom &g) { return g.tb > ROWS_SMALL_TAIL ? 0u : g.tb; }
+HD u32 rows_units(const RowsGeom &g, u32 na) { return g.R + rows_long_tail(g) + rows_long_aad(na); }      // units of the row launch: the rows, the long tail, the long AAD (0 for a short message: only the closing sees it)
+HD u32 rows_smalls(const RowsGeom &g, u32 na) { return rows_small_aad(na) + rows_small_tail(g); }         // blocks on the smalls axis: the (short) AAD, then the (short) tail
+// the natural segment of unit u of a message: its rows (when it has any), then the long tail, then the long AAD
+HD u32 rows_nat(const RowsGeom &g, u32 u) { return u < g.R ? 0u : (g.R ? 1u : 0u) + (u - g.R); }
+HD u32 rows_nat_count(const RowsGeom &g, u32 na) { return (g.R ? 1u : 0u) + rows_long_tail(g) + rows_long_aad(na); }
 // record slots of a message whose units are [g0, g0 + U): a slot per (natural segment, block) pair it can have -- slot = base + nat + (block - first block)
 HD u32 rows_slots(const RowsGeom &g, u32 na, u64 g0, u32 D) {
     const u32 U = rows_units(g, na);
     return U ? rows_nat_count(g, na) + (u32)((g0 + U - 1u) / D - g0 / D) : 0u;
 }
-// arrivals k_rows_close counts for a message: the pieces it falls into under the cut -- its run of rows one per block it touches, the long AAD --, its blocks
-// of the smalls axis, and the message's own lane
+// arrivals k_rows_close counts for a message: the pieces it falls into under the cut -- its run of rows one per block it touches, the long tail, the long AAD --,
+// its blocks of the smalls axis, and the message's own lane
 HD u32 rows_pieces(const RowsGeom &g, u32 na, u64 g0, u32 D) {
-    return (g.R ? (u32)((g0 + g.R - 1u) / D - g0 / D) + 1u : 0u) + rows_long_aad(na) + rows_smalls(g, na) + 1u;
+    return (g.R ? (u32)((g0 + g.R - 1u) / D - g0 / D) + 1u : 0u) + rows_long_tail(g) + rows_long_aad(na) + rows_smalls(g, na) + 1u;
 }
 // the cut of a call of G units for `waves` waves: one block per wave while that is at most ROWS_STATIC_MAX units (or when the dealt cut would not fit the
 // scratch: nb_cap blocks), else blocks of ROWS_DYN_BLOCK units from the dispensers.  force_d > 0: dealt blocks of that many units (tests)
@@ -141,7 +148,7 @@ HD u64 rows_small_total(const RowsParams &p) { return p.sprefix ? p.sprefix[p.n_
 HD u32 rows_slot_base(const RowsParams &p, u32 m) { return p.slot_base ? p.slot_base[m] : m * p.SM; }
 
 // ---- k_rows: one piece ---------------------------------------------------------------------------
-enum { ROWS_RUN = 0, ROWS_AAD = 2 };
+enum { ROWS_RUN = 0, ROWS_TAIL = 1, ROWS_AAD = 2 };
 struct RowsPiece { u32 kind, r0, len, slot; u64 e; };                   // run: rows [r0, r0 + len); len = units taken
 // the piece that starts at unit u of the message (geometry g, first unit g0) and may take up to `room` units; D = units per block
 HD RowsPiece rows_piece(const RowsGeom &g, u32 slot_base, u64 g0, u32 u, u64 room, u32 D) {
@@ -154,6 +161,9 @@ HD RowsPiece rows_piece(const RowsGeom &g, u32 slot_base, u64 g0, u32 u, u64 roo
         const u32 left = g.R - u;
         pc.len = room < left ? (u32)room : left;
         pc.e = 64ull * (g.R - (pc.r0 + pc.len)) + g.tb + 2u;              // blocks behind the run's last row, and H^2
+    } else if (rows_long_tail(g) && u == g.R) {
+        pc.kind = ROWS_TAIL;                                              // the long tail, whole: its lanes weigh their blocks in full
+        pc.e = 0;
     } else {
         pc.kind = ROWS_AAD;                                               // the long AAD, whole
         pc.e = 64ull * g.R + g.tb + 2u;
@@ -168,6 +178,33 @@ HD uint4 rows_run_lane(const KeyMaterial *__restrict__ km, const DevTables *__re
 }
 // the lane's term of the run's polynomial: B_L H^(63 - L) (XOR over the wave = the polynomial of the run up to its last block)
 HD G128 rows_run_term(const KeyMaterial *__restrict__ km, uint4 acc, u32 lane) { return shoup2_gmul_lds(mo_to_be(acc), km->ltab[63u - lane]); }
+// A tail of more than ROWS_SMALL_TAIL blocks (data blocks 64 R ..., tb of them, tb <= 64, the last one ragged) as ONE right-aligned row: lane L >= 64 - tb runs the cipher on counter
+// 2 + block index (aes_icb.vhd:97-118).  Returns the lane's term  X_L H^(65 - L)  of  (tail polynomial) H^2.
+template <int NR, int DEC>
+HD G128 rows_tail_lane(const KeyMaterial *__restrict__ km, const RowsParams &p, const RowsMsg &q, const unsigned char *smem, const CtrConsts &cc, u32 lane) {
+    const u32 *__restrict__ rk = km->rk;
+    const u32 lb = (lane & 31u) << 2;
+    const RowsGeom g = rows_geom(q.len);
+    const u32 pad = 64u - g.tb;
+    const unsigned char *src = p.in + q.doff;
+    unsigned char *dst = p.out + q.doff;
+    G128 z = {{0, 0, 0, 0}};
+    if (lane >= pad) {                                                                  // (the table multiply too: its 32 reads per lane go to 64 different tables, and the memory path takes them a lane at a time)
+        uint4 gin;
+        const u32 i = 64u * g.R + (lane - pad);                                         // block index in the message
+        u32 s0, s1, s2, s3;
+        ctr_rounds_lds<NR>(bswap32(2u + i), cc, s0, s1, s2, s3, rk, smem, lb);
+        const u32 off = 16u * i, rem = q.len - off;
+        const bool full = rem >= 16u;
+        const uint4 x = full ? gload16_any(src + off) : load_block_bytes(src + off, rem);
+        uint4 y = make_uint4(x.x ^ s0, x.y ^ s1, x.z ^ s2, x.w ^ s3);                    // gcm_gctr.vhd:150
+        if (!full) y = mask_block(y, rem);
+        if (full) gstore16_any(dst + off, y); else store_block_bytes(dst + off, y, rem);
+        gin = DEC ? x : y;                                                              // aes_gcm.vhd:207-211
+        z = shoup2_gmul_lds(mo_to_be(gin), km->ltab[65u - lane]);
+    }
+    return z;
+}
 // An AAD of more than ROWS_SMALL_AAD blocks as rows of its own (right-aligned, Horner with H^64): the lane's term  A_L H^(63 - L)  of the AAD's polynomial
 HD G128 rows_aad_lane(const KeyMaterial *__restrict__ km, const RowsParams &p, const RowsMsg &q, const unsigned char *smem, u32 lane) {
     const u32 n_aad = rows_na(q.alen), rows = (n_aad + 63u) >> 6, pad = 64u * rows - n_aad;
@@ -221,23 +258,26 @@ HD G128 rows_msg_term(const KeyMaterial *__restrict__ km, const u32 *te, const R
 }
 
 // ---- k_rows_close: block t of the smalls axis ------------------------------------------------------------
-// Block i of the short AAD, or of the tail, of the message that owns t; returns the message, and in *z the block's whole contribution to its tag:
-//   AAD block i of na:   A H^(na - 1 - i + 64 R + tb + 2);
+// Block i of the short AAD, or of the short tail, of the message that owns t.  Returns the message; *z is the block times the part of its power of H that the
+// key's per-exponent Shoup tables hold (KeyMaterial::ltab, e < 130), *e_run the exponent that is still due -- the same for every block of the segment, so the
+// lanes of a segment are XORed together first and ONE of them pays the bit-serial power (k_rows_close):
+//   AAD block i of na:   A H^(na - 1 - i),  still due H^(64 R + tb + 2);
 //   tail block i of tb:  the cipher on counter 2 + 64 R + i under the message's IV (aes_icb.vhd:97-118), the data block XORed with it (gcm_gctr.vhd:150), the
-//                        ciphertext X -- the input, for decrypt (aes_gcm.vhd:207-211) -- times H^(tb - i + 1).
+//                        ciphertext X -- the input, for decrypt (aes_gcm.vhd:207-211) -- times H^(tb - i + 1): nothing due.
 template <int DEC>
-HD u32 rows_small_block(const KeyMaterial *__restrict__ km, const u32 *te, const RowsParams &p, u64 t, G128 *z) {
-    const u32 m = p.sprefix ? rows_search(p.sprefix, t, 0u, p.n_pkts) : (u32)(t / p.S);
+HD u32 rows_small_block(const KeyMaterial *__restrict__ km, const u32 *te, const RowsParams &p, u64 t, G128 *z, u64 *e_run) {
+    const u32 m = p.sprefix ? rows_search(p.sprefix, t, 0u, p.n_pkts) : ((t >> 32) ? (u32)(t / p.S) : (u32)t / p.S);
     const RowsMsg q = rows_msg(p, m);
     const RowsGeom g = rows_geom(q.len);
-    const u32 nas = rows_small_aad(rows_na(q.alen)), r = (u32)(t - rows_small_base(p, m));
+    const u32 nas = rows_small_aad(rows_na(q.alen)), r = (u32)(t - rows_small_base(p, m));      // (a block behind the short AAD is a block of a SHORT tail: a long one is not on this axis)
     uint4 x;
-    u64 e;
+    u32 e;
     if (r < nas) {
         const unsigned char *a = p.aad + q.aoff;
         const u32 off = 16u * r, rem = q.alen - off;
         x = rem >= 16u ? gload16_any(a + off) : load_block_bytes(a + off, rem);
-        e = (u64)(nas - 1u - r) + 64ull * g.R + g.tb + 2u;
+        e = nas - 1u - r;
+        *e_run = 64ull * g.R + g.tb + 2u;
     } else {
         const u32 i = r - nas, bi = 64u * g.R + i;                                       // block of the tail, block of the message
         const unsigned char *ivp = p.ivs + (size_t)m * 12;
@@ -252,10 +292,13 @@ HD u32 rows_small_block(const KeyMaterial *__restrict__ km, const u32 *te, const
         if (full) gstore16_any(dst + off, y); else store_block_bytes(dst + off, y, rem);
         x = DEC ? in : y;
         e = g.tb - i + 1u;
+        *e_run = 0;
     }
-    *z = gf_mul(mo_to_be(x), gf_pow_h_serial(km, e));
+    *z = shoup2_gmul_lds(mo_to_be(x), km->ltab[e]);                                     // e <= 64 < AESGCM_NLTAB
     return m;
 }
+// the rest of a segment's power, paid once for the XOR of its blocks
+HD G128 rows_small_due(const KeyMaterial *__restrict__ km, const G128 &z, u64 e_run) { return e_run ? gf_mul(z, gf_pow_h_serial(km, e_run)) : z; }
 
 // ---- k_rows_close: a record's contribution ----------------------------------------------------------
 HD G128 rows_weigh(const KeyMaterial *__restrict__ km, const RowsRec &r) { return (r.flags & ROWS_REC_WEIGH) ? gf_mul(r.w, gf_pow_h_serial(km, r.e)) : r.w; }

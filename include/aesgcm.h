@@ -275,7 +275,8 @@ AESGCM_API int aesgcm_mgpu_destroy(aesgcm_mgpu *m);
  * and data either as fixed-size records (aad_len / pkt_len, offset arrays NULL) or delimited by uint64 offset
  * arrays with n_pkts + 1 entries (then aad_len / pkt_len are ignored); tags[p] receives the computed tag; for
  * decrypt d_auth[p] (optional) = 1 if it equals d_expect_tags[p].  Asynchronous on `stream`.
- * Packets of message size -- from 8 KiB each (context option "rows_min"; from 2 KiB while there are at most 16384 of them), up to 2^28 - 1 bytes -- go BY ROWS (round 5): the 64-block rows of all the
+ * Packets of message size -- from 8 KiB each (context option "rows_min"; from 2 KiB while there are at most 16384 of them; many fixed-size packets below 16 KiB whose last
+ * partial row is longer than 4 blocks stay with the packet kernels), up to 2^28 - 1 bytes -- go BY ROWS (round 5): the 64-block rows of all the
  * call's messages are one pool of work for the row loop a single large message runs through (csrc/aesgcm_rows.h), and one small launch behind it takes what
  * is not a whole row -- headers, ragged ends -- block by block and closes every tag; 4096 x 1 MiB then runs at the rate of one 4 GiB message.  With offset arrays the lengths are on the device and the library cannot see them:
  * there pkt_len -- otherwise unused in that form -- is the caller's word for the TYPICAL packet size and selects the path (0 = frames; any packet, of any

@@ -860,11 +860,13 @@ static void emu_rows_nr(const KeyMaterial *km, int dec, RowsParams &p, u32 waves
                     if (pc.kind == ROWS_RUN) {
                         const uint4 a = dec ? rows_run_lane<NR, MODE_DEC>(km, &g_tb, p, mq, pc, smem, cc, lane, 0, 0) : rows_run_lane<NR, MODE_ENC>(km, &g_tb, p, mq, pc, smem, cc, lane, 0, 0);
                         xor_g(z, rows_run_term(km, a, lane));
+                    } else if (pc.kind == ROWS_TAIL) {
+                        xor_g(z, dec ? rows_tail_lane<NR, 1>(km, p, mq, smem, cc, lane) : rows_tail_lane<NR, 0>(km, p, mq, smem, cc, lane));
                     } else {
                         xor_g(z, rows_aad_lane(km, p, mq, smem, lane));
                     }
                 }
-                put(pc.slot, z, pc.e, m, ROWS_REC_VALID | ROWS_REC_WEIGH);
+                put(pc.slot, z, pc.e, m, pc.kind == ROWS_TAIL ? ROWS_REC_VALID : (ROWS_REC_VALID | ROWS_REC_WEIGH));
                 g += pc.len;
             }
             ++m;
@@ -888,9 +890,10 @@ static void emu_rows_nr(const KeyMaterial *km, int dec, RowsParams &p, u32 waves
         if (i < n) arrive((u32)i, rows_msg_term(km, g_tb.te0, p, (u32)i));
         for (u64 t = i; t < rows_small_total(p); t += lanes) {
             G128 z;
-            const u32 m = dec ? rows_small_block<1>(km, g_tb.te0, p, t, &z) : rows_small_block<0>(km, g_tb.te0, p, t, &z);
+            u64 e_run = 0;
+            const u32 m = dec ? rows_small_block<1>(km, g_tb.te0, p, t, &z, &e_run) : rows_small_block<0>(km, g_tb.te0, p, t, &z, &e_run);
             ++made_of[m];
-            arrive(m, z);
+            arrive(m, rows_small_due(km, z, e_run));                       // (the kernel XORs the blocks of a segment first and pays once: the multiply is linear)
         }
         if (i >= slots) continue;
         const RowsRec r = rec[i];

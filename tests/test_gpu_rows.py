@@ -184,6 +184,8 @@ def test_the_rule_that_sends_a_call_by_rows(hip):
     assert rows(1 << 20, 8192) and rows(1 << 19, 8208) and rows(1000, 16400) and rows(5, 1 << 20) and rows(16384, 2048) and rows(100, 4100)
     assert not rows(16385, 8191) and not rows(1 << 20, 4096) and not rows(1000, 2047) and not rows(10, 1514)
     assert rows(100000, 65536, True) and not rows(1000, 0, True)
+    # many fixed-size packets of 8 .. 16 KiB whose last, partial row has more than four blocks stay with the packet kernels
+    assert not rows(262144, 9000) and rows(262144, 9000, True) and rows(262144, 8192 + 64) and not rows(262144, 8192 + 80) and rows(262144, 16384 + 1000) and rows(16384, 9000)
     ctx.set_option("rows_min", 65536)
     assert rows(10, 65536) and rows(10, 16384) and not rows(16385, 32768) and not rows(10, 16383)
     ctx.set_option("rows_min", 0)
