@@ -29,8 +29,9 @@
 //     encrypted counter 1 -- and one for its AAD: a wave's pass each, for a block or two.  64 KiB messages with a 13-byte header and a ragged end ran 7 %
 //     below whole ones, 16 KiB ones 16 %, profiles/r05/rows_aad_cost.txt.  Packing the smalls into units of the row launch itself was built too: its code
 //     around the row loop cost AES-256 nine scratch accesses per row.)
-//   * the same small launch closes every tag: a LANE per record slot multiplies by H^e bit-serially (any exponent, all lanes in parallel); records, smalls
-//     blocks and the message's own lane each XOR their product into the message's accumulator with memory-side atomics and count themselves arrived.  The
+//   * the same small launch closes every tag: a LANE per record slot multiplies by H^e bit-serially (any exponent, all lanes in parallel); records, the
+//     segments of the smalls axis (one message's AAD, or its tail: the lanes of a segment XOR their terms together first -- one address serves 87 M atomics a
+//     second) and the message's own lane each XOR their product into the message's accumulator with memory-side atomics and count themselves arrived.  The
 //     lane that counts a message's last arrival holds its tag  P H^2 ^ L H ^ E_K(J0)  (gcm_ghash.vhd:257,293 re-associated), stores it and, for decrypt,
 //     compares.
 //
