@@ -83,6 +83,9 @@ for k in range(4):
         ctx.packets_crypt_dev(True, np_, d_ivs.ptr, d_out.ptr, d_out.ptr, d_tags.ptr, pkt_len=plen, d_expect_tags=d_tags.ptr, d_auth=d_auth.ptr)
     ctx.packets_crypt_dev(False, n, d_ivs.ptr, d_in.ptr, d_out.ptr, d_tags.ptr, d_data_off=d_off.ptr)                      # taken by length class (n >= 98304)
     ctx.packets_crypt_dev(False, 1000, d_ivs.ptr, d_in.ptr, d_out.ptr, d_tags.ptr, pkt_len=65536, d_data_off=d_off.ptr)   # by rows, planned on the device
+    ctx.packets_crypt_dev(True, 1000, d_ivs.ptr, d_in.ptr, d_out.ptr, d_tags.ptr, pkt_len=65536, d_data_off=d_off.ptr, d_aad=d_aad.ptr, d_aad_off=d_off.ptr,
+                          d_expect_tags=d_tags.ptr, d_auth=d_auth.ptr)                                                   # ... with an AAD array (the smalls of the closing launch), verified, wiped
+    ctx.packets_crypt_dev(False, 300, d_ivs.ptr, d_in.ptr, d_out.ptr, d_tags.ptr, pkt_len=16400, d_aad=d_aad.ptr, aad_len=13)   # by rows, fixed-size records with a header and a ragged end
     check("packets", k)
     # a key per packet (context-free: the device is an argument)
     d_keys = lib.DeviceBuffer(32 * n, k)

@@ -2,6 +2,7 @@
 The reference's deployment is frame after frame under one key (tb/gcm_test.py:76-85, src/gcm_gctr.vhd:142-144); every message here is compared with the
 oracle byte for byte, tags included, and decrypted in place with per-message authentication."""
 import hashlib
+import os
 import random
 import struct
 
@@ -108,7 +109,7 @@ def test_headers_and_ragged_ends_of_every_kind(hip, orc, klen):
         _check_var(hip, orc, c2, key, [16384 + 16 * (i % 3) + (i % 5) for i in range(700)], [13] * 700, 865 + klen, hint=16384, forged=(699,))
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AESGCM_ROWS_SEEDS", "6"))))       # (a soak: AESGCM_ROWS_SEEDS=400, profiles/r05/rows_soak.txt)
 def test_random_calls_by_rows(hip, orc, seed):
     """random calls forced by rows: 1 .. 250 messages, lengths drawn from empty / shorter than a block / shorter than a row / whole rows / ragged / a few
     hundred KiB, AAD from none / a header / exactly 64 blocks / 65 and more, with or without an AAD array at all, random units per dealt block (or the
@@ -226,6 +227,59 @@ def test_rows_and_packet_kernels_agree_and_calls_queue_back_to_back(hip, orc):
         ct, tags = bytes(d_out.download(doff[-1])), bytes(d_tags.download())
         for p in range(0, m, 3):
             assert (ct[doff[p]:doff[p + 1]], tags[16 * p:16 * p + 16]) == f.encrypt(ivr[12 * p:12 * p + 12], b"", ptr[doff[p]:doff[p + 1]]), p
+
+
+def test_three_hundred_thousand_small_messages_rows_and_packet_kernels_agree(hip, orc):
+    """300 000 messages of 0 .. 3000 bytes with headers of 0 .. 40 bytes in one call (offset arrays): nearly all of the work is the closing launch's -- smalls
+    blocks by the million, three prefix sums over 300 000 messages, tails that straddle the waves -- and a third of the messages has a row for the row launch.
+    Forced by rows and through the packet kernels (themselves held to the oracle by test_gpu_batch.py): the same ciphertext (SHA-256) and the same tags; the
+    first and last hundred messages against the oracle; decrypt by rows restores the plaintext and finds the forged tags"""
+    rng = random.Random(77)
+    n = 300000
+    key = splitmix_bytes(7600, 32)
+    lens = [rng.randrange(0, 3001) for _ in range(n)]
+    aads = [rng.choice((0, 13, 16, 40)) for _ in range(n)]
+    doff, aoff = [0], [0]
+    for a, b in zip(lens, aads):
+        doff.append(doff[-1] + a)
+        aoff.append(aoff[-1] + b)
+    d_in, d_aad, d_ivs = hip.DeviceBuffer(doff[-1] + 16), hip.DeviceBuffer(aoff[-1] + 16), hip.DeviceBuffer(12 * n)
+    d_in.fill_splitmix64(0x51, nbytes=(doff[-1] + 16) // 8 * 8)
+    d_aad.fill_splitmix64(0x52, nbytes=(aoff[-1] + 16) // 8 * 8)
+    d_ivs.fill_splitmix64(0x53, nbytes=12 * n)
+    d_doff, d_aoff = _up(hip, struct.pack("<%dQ" % (n + 1), *doff)), _up(hip, struct.pack("<%dQ" % (n + 1), *aoff))
+    res = []
+    with hip.debug_library() as dbg:
+        for rows in (1, 2):
+            dbg.force(pkt_rows=rows)
+            ctx = hip.Context(key)
+            d_out, d_tags = hip.DeviceBuffer(doff[-1] + 16), hip.DeviceBuffer(16 * n)
+            ctx.packets_crypt_dev(False, n, d_ivs.ptr, d_in.ptr, d_out.ptr, d_tags.ptr, pkt_len=2048, d_data_off=d_doff.ptr, d_aad=d_aad.ptr, d_aad_off=d_aoff.ptr)
+            hip.dev_sync()
+            res.append((hashlib.sha256(bytes(d_out.download(doff[-1]))).hexdigest(), bytes(d_tags.download())))
+            if rows == 1:
+                assert ctx.packets_shape(n, 2048, True) == hip.SHAPE_ROWS
+                ct_head, ct_tail = bytes(d_out.download(doff[100])), bytes(d_out.download(doff[n] - doff[n - 100], doff[n - 100]))
+                forged = (0, 12345, n - 1)
+                bad = bytearray(res[0][1])
+                for p in forged:
+                    bad[16 * p] ^= 0x40
+                d_exp, d_auth, d_t2 = _up(hip, bytes(bad)), hip.DeviceBuffer(4 * n), hip.DeviceBuffer(16 * n)
+                ctx.packets_crypt_dev(True, n, d_ivs.ptr, d_out.ptr, d_out.ptr, d_t2.ptr, pkt_len=2048, d_data_off=d_doff.ptr, d_aad=d_aad.ptr, d_aad_off=d_aoff.ptr,
+                                      d_expect_tags=d_exp.ptr, d_auth=d_auth.ptr)
+                hip.dev_sync()
+                assert bytes(d_out.download(doff[-1])) == bytes(d_in.download(doff[-1]))
+                assert bytes(d_t2.download()) == res[0][1]
+                auth = struct.unpack("<%di" % n, bytes(d_auth.download()))
+                assert sum(auth) == n - len(forged) and all(auth[p] == 0 for p in forged)
+    assert res[0] == res[1]
+    f = orc.Fast(key)
+    ivs, pt_head, aad_all = bytes(d_ivs.download()), bytes(d_in.download(doff[100])), bytes(d_aad.download(aoff[-1]))
+    pt_tail = bytes(d_in.download(doff[n] - doff[n - 100], doff[n - 100]))
+    for p in list(range(100)) + list(range(n - 100, n)):
+        base, pt, ct = (0, pt_head, ct_head) if p < 100 else (doff[n - 100], pt_tail, ct_tail)
+        want = f.encrypt(ivs[12 * p:12 * p + 12], aad_all[aoff[p]:aoff[p + 1]], pt[doff[p] - base:doff[p + 1] - base])
+        assert (ct[doff[p] - base:doff[p + 1] - base], res[0][1][16 * p:16 * p + 16]) == want, p
 
 
 @pytest.mark.slow
