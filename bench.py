@@ -494,24 +494,32 @@ def run_msgs(args, dev, cpu_base):
     d_ivw.free()
     d_pt, d_ct, d_tags = lib.DeviceBuffer(size * n, device=dev), lib.DeviceBuffer(size * n, device=dev), lib.DeviceBuffer(16 * n, device=dev)
     d_pt.fill_splitmix64(cfg["pt_seed"])
+    al = args.aad_len
+    d_aad = lib.DeviceBuffer((al * n + 23) // 8 * 8, device=dev) if al else None
+    if al:
+        d_aad.fill_splitmix64(0x414144)
+    akw = dict(d_aad=d_aad.ptr, aad_len=al) if al else {}
     ctx = lib.Context(key, device=dev)
     shape = ctx.packets_shape(n, size)
 
     def step():
-        ctx.packets_crypt_dev(args.decrypt, n, d_ivs.ptr, d_ct.ptr if args.decrypt else d_pt.ptr, d_pt.ptr if args.decrypt else d_ct.ptr, d_tags.ptr, pkt_len=size)
+        ctx.packets_crypt_dev(args.decrypt, n, d_ivs.ptr, d_ct.ptr if args.decrypt else d_pt.ptr, d_pt.ptr if args.decrypt else d_ct.ptr, d_tags.ptr, pkt_len=size, **akw)
 
     if args.decrypt:
-        ctx.packets_crypt_dev(False, n, d_ivs.ptr, d_pt.ptr, d_ct.ptr, d_tags.ptr, pkt_len=size)
+        ctx.packets_crypt_dev(False, n, d_ivs.ptr, d_pt.ptr, d_ct.ptr, d_tags.ptr, pkt_len=size, **akw)
     for _ in range(max(args.warmup, 1)):
         step()
     lib.dev_sync(dev)
     tags = bytes(d_tags.download())
     one = lib.Context(key, device=dev)
     d_one = lib.DeviceBuffer(size, device=dev)
+    d_a1 = lib.DeviceBuffer(max(al, 16), device=dev) if al else None            # (a message's AAD copied to an aligned buffer of its own for the single-message call)
     sample = sorted(p_ for p_ in set([0, n - 1] + [(k * 977) % n for k in range(6)] + [(k * 976) % n for k in range(1, 4)]) if (p_ * size) % 16 == 0)   # the single-message path wants 16-byte aligned buffers
     tag_ok = True
     for p_ in sample:
-        t = one.encrypt_dev(ivs[12 * p_:12 * p_ + 12], d_pt.ptr + p_ * size, size, d_one.ptr)
+        if al:
+            d_a1.upload(bytes(d_aad.download(al, p_ * al)))
+        t = one.encrypt_dev(ivs[12 * p_:12 * p_ + 12], d_pt.ptr + p_ * size, size, d_one.ptr, d_aad=d_a1.ptr if al else None, aad_len=al)
         same_ct = args.decrypt or hashlib.sha256(bytes(d_one.download())).digest() == hashlib.sha256(bytes(d_ct.download(size, p_ * size))).digest()
         tag_ok = tag_ok and t == tags[16 * p_:16 * p_ + 16] and same_ct
     if not tag_ok:
@@ -535,19 +543,19 @@ def run_msgs(args, dev, cpu_base):
         k_ms.append(tm.ms())
     tm.close()
     avg_s = statistics.mean(k_ms) / 1e3
-    alg_bytes = n * (2 * size + 12 + 16)
+    alg_bytes = n * (2 * size + 12 + 16 + al)
     achieved = alg_bytes / avg_s
     so_sha = sha256_file(SO)
-    pm = pmc_summary("rows_1m") if (n, size, key_bits) == (cfg["n_pkts"], cfg["pkt_len"], cfg["key_bits"]) and not args.decrypt else {}
+    pm = pmc_summary("rows_1m") if (n, size, key_bits, al) == (cfg["n_pkts"], cfg["pkt_len"], cfg["key_bits"], 0) and not args.decrypt else {}
     same_build = bool(pm) and pm.get("so_sha256") == so_sha
     nr = key_bits // 32 + 6
     line = {
-        "metric": "GiB/s plaintext, AES-%d-GCM, %d messages of %d bytes under one key as the packets of one call, bit-exact tags" % (key_bits, n, size),
+        "metric": "GiB/s plaintext, AES-%d-GCM, %d messages of %d bytes%s under one key as the packets of one call, bit-exact tags" % (key_bits, n, size, " with %d bytes of AAD each" % al if al else ""),
         "value": round(value, 3), "unit": "GiB/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": "msgs: %d x %d B AES-%d-GCM messages under ONE key (stream 0x4B4559), per-message IV (stream 0x4956), plaintext stream 0xAE5C0055, one "
                                "aesgcm_packets_crypt_dev call per step%s" % (n, size, key_bits, ", DECRYPT" if args.decrypt else ""),
-                   "messages": n, "message_bytes": size, "key_bits": key_bits, "shape": "rows" if shape == lib.SHAPE_ROWS else "%d lanes per packet" % shape, "parallelism": "single"},
+                   "messages": n, "message_bytes": size, "aad_bytes": al, "key_bits": key_bits, "shape": "rows" if shape == lib.SHAPE_ROWS else "%d lanes per packet" % shape, "parallelism": "single"},
         "tag_ok": tag_ok, "tags_checked": len(sample),
         "roofline": {"bound": "hbm", "kernel": ("k_rows<%d,%d> + k_rows_close (the rows of all messages through k_body's row loop; one call)" % (nr, int(args.decrypt))) if shape == lib.SHAPE_ROWS else "the packet kernels",
                      "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_BYTES_PER_S, 4),
@@ -806,6 +814,7 @@ def main(argv=None):
     ap.add_argument("--key-bits", type=int, default=None, choices=(128, 192, 256), help="override (no fixture check)")
     ap.add_argument("--n-pkts", type=int, default=None, help="cfg5 override: packets in all (no fixture check)")
     ap.add_argument("--pkt-len", type=int, default=None, help="cfg5 override: bytes per packet (no fixture check)")
+    ap.add_argument("--aad-len", type=int, default=0, help="--config msgs: bytes of AAD per message (a header: 13 for TLS-shaped records)")
     ap.add_argument("--decrypt", action="store_true", help="time decrypt + authenticate instead of encrypt (N = 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="rccl", choices=("rccl", "nccl", "file", "gloo"),
