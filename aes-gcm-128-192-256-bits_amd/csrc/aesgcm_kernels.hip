@@ -1238,6 +1238,26 @@ __device__ __forceinline__ void rows_arrive(const RowsParams &p, u32 m, const G1
         p.auth[m] = ok;
     }
 }
+// The lanes of a wave that hold terms of the same thing (`key`; neighbours) fold them -- a segmented reduction by doubling -- and the first lane of every run
+// answers true and gets the run's length: it arrives for all.  One address serves 87 M atomics a second (aesgcm_stream.h), and far fewer when the 64 lanes of a
+// wave want their old values back from it: an arrival per block made 262 144 x 9000 bytes 325 GiB/s (profiles/r05/rows_ragged_few_before.txt), an arrival per
+// record made the closing of 16 messages of 16 MiB -- 256 records each -- 87 us against 14 for 4096 of 64 KiB (rows_few_large_stats.txt).  key 0xFFFFFFFF: the
+// lane holds nothing.
+__device__ __forceinline__ bool rows_fold(u32 key, G128 &z, u32 lane, u32 *count) {
+    const u32 before = __shfl_up(key, 1);
+    const bool first = lane == 0 || before != key;
+    const unsigned long long firsts = __ballot(first);
+    const u32 run = (u32)__builtin_popcountll(firsts & (lane == 63u ? ~0ull : (2ull << lane) - 1ull));     // the lane's run: runs are told apart by their number, not by their key -- a record slot that was not used lies between two runs of ONE message
+#pragma unroll
+    for (u32 off = 1; off < 64u; off <<= 1) {
+        const u32 orun = __shfl_down(run, off);
+        const u32 z0 = __shfl_down(z.w[0], off), z1 = __shfl_down(z.w[1], off), z2 = __shfl_down(z.w[2], off), z3 = __shfl_down(z.w[3], off);
+        if (lane + off < 64u && orun == run) { z.w[0] ^= z0; z.w[1] ^= z1; z.w[2] ^= z2; z.w[3] ^= z3; }
+    }
+    const unsigned long long later = lane == 63u ? 0ull : firsts >> (lane + 1u);
+    *count = (later ? lane + 1u + (u32)__builtin_ctzll(later) : 64u) - lane;
+    return first && key != 0xFFFFFFFFu;
+}
 static_assert(offsetof(DevTables, te3) - offsetof(DevTables, te0) == 3072 && offsetof(DevTables, te0) % 16 == 0 && ROWS_CLOSE_WG == 256, "rows_close_fill_te: te0 .. te3 as 256 consecutive uint4, one per thread");
 template <int DEC>
 __global__ __launch_bounds__(ROWS_CLOSE_WG) void k_rows_close(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const RowsParams p) {
@@ -1249,9 +1269,8 @@ __global__ __launch_bounds__(ROWS_CLOSE_WG) void k_rows_close(const KeyMaterial 
     const u32 *te = reinterpret_cast<const u32 *>(smem + ROWS_CLOSE_LDS_TE);
     if (p.hdr && p.hdr->bad) return;
     if (i < p.n_pkts) rows_arrive<DEC>(p, i, rows_msg_term(km, te, p, i), 1u);
-    // The smalls: the waves of the launch take 64 consecutive blocks of the axis at a time.  The blocks of one message are neighbours, and one address serves
-    // 87 M atomics a second (aesgcm_stream.h): the lanes of a segment -- one message's AAD, or its tail -- fold their terms first (a segmented reduction by doubling) and the first of them pays what is
-    // still due of the segment's power of H and arrives for all -- 13-byte headers and tails of 51 blocks one by one made 262 144 x 9000 bytes 325 GiB/s, profiles/r05/rows_ragged_few.txt.
+    // The smalls: the waves of the launch take 64 consecutive blocks of the axis at a time.  The blocks of a segment -- one message's AAD, or its tail -- are
+    // neighbours: their lanes fold their terms first (rows_fold) and the first of them pays what is still due of the segment's power of H and arrives for all.
     const u64 total = rows_small_total(p), lanes = (u64)gridDim.x * ROWS_CLOSE_WG;
     const u32 lane = threadIdx.x & 63u;
     for (u64 base = (u64)blockIdx.x * ROWS_CLOSE_WG + (threadIdx.x & ~63u), guard = 0; base < total && guard <= ROWS_SMALL_AAD + ROWS_SMALL_TAIL + 2u; base += lanes, ++guard) {   // (a lane per message at least, a message at most 80 blocks here)
@@ -1261,27 +1280,18 @@ __global__ __launch_bounds__(ROWS_CLOSE_WG) void k_rows_close(const KeyMaterial 
         u32 m = 0xFFFFFFFFu;
         u64 e_run = 0;
         if (active) m = rows_small_block<DEC>(km, te, p, t, &z, &e_run);
-        const u32 key = active ? 2u * m + (e_run ? 1u : 0u) : 0xFFFFFFFFu;               // a segment: one message's AAD, or its tail
-        const u32 before = __shfl_up(key, 1);
-        const bool head = active && (lane == 0 || before != key);
-        const unsigned long long heads = __ballot(head), act = __ballot(active);
-#pragma unroll
-        for (u32 off = 1; off < 64u; off <<= 1) {
-            const u32 ok = __shfl_down(key, off);
-            const u32 z0 = __shfl_down(z.w[0], off), z1 = __shfl_down(z.w[1], off), z2 = __shfl_down(z.w[2], off), z3 = __shfl_down(z.w[3], off);
-            if (lane + off < 64u && ok == key) { z.w[0] ^= z0; z.w[1] ^= z1; z.w[2] ^= z2; z.w[3] ^= z3; }
-        }
-        if (head) {
-            const unsigned long long later = lane == 63u ? 0ull : heads >> (lane + 1u);
-            const u32 next = later ? lane + 1u + (u32)__builtin_ctzll(later) : 64u, n_act = (u32)__builtin_popcountll(act);
-            rows_arrive<DEC>(p, m, rows_small_due(km, z, e_run), (next < n_act ? next : n_act) - lane);
-        }
+        u32 key = active ? 2u * m + (e_run ? 1u : 0u) : 0xFFFFFFFFu, count;            // a segment: one message's AAD, or its tail
+        if (rows_fold(key, z, lane, &count)) rows_arrive<DEC>(p, m, rows_small_due(km, z, e_run), count);
     }
-    if (i >= p.slot_cap) return;
-    const RowsRec r = p.rec[i];
-    if (!(r.flags & ROWS_REC_VALID)) return;
-    p.rec[i].flags = 0;
-    rows_arrive<DEC>(p, r.msg, rows_weigh(km, r), 1u);
+    // The records: those of one message have neighbouring slots; they fold the same way.
+    RowsRec r;
+    r.flags = 0; r.msg = 0;
+    if (i < p.slot_cap) r = p.rec[i];
+    const bool valid = (r.flags & ROWS_REC_VALID) != 0;
+    G128 z; z.w[0] = z.w[1] = z.w[2] = z.w[3] = 0;
+    if (valid) { p.rec[i].flags = 0; z = rows_weigh(km, r); }
+    u32 count;
+    if (rows_fold(valid ? r.msg : 0xFFFFFFFFu, z, lane, &count)) rows_arrive<DEC>(p, r.msg, z, count);
 }
 
 // The cut of a call with offset arrays, on the device (the host does not know the lengths): ONE workgroup.  Units per message -> prefix[0 .. n] and G; the cut
