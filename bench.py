@@ -476,7 +476,7 @@ def run_cfg5(args, rank, world, dev, ex, cpu_base):
 # ------------------------------------------------------------------------------------------------ many messages under one key
 def run_msgs(args, dev, cpu_base):
     """--config msgs: n messages of one size under ONE key as the packets of one aesgcm_packets_crypt_dev call (by rows: k_rows +
-    k_rows_close).  A step is one call; calls are queued four at a time.  Parity in the run: the tags of a sample of the messages equal what the single-message
+    k_rows_close).  A step is one call; the calls of the timed region are queued back to back and waited for once.  Parity in the run: the tags of a sample of the messages equal what the single-message
     path of the same library (pinned to the libcrypto fixtures by the test-suite) gives for the same bytes, and so does their ciphertext by SHA-256."""
     import aesgcm_amd  # noqa: F401
     from aesgcm_amd import lib, sharding
@@ -507,8 +507,7 @@ def run_msgs(args, dev, cpu_base):
 
     if args.decrypt:
         ctx.packets_crypt_dev(False, n, d_ivs.ptr, d_pt.ptr, d_ct.ptr, d_tags.ptr, pkt_len=size, **akw)
-    for _ in range(max(args.warmup, 1)):
-        step()
+    step()
     lib.dev_sync(dev)
     tags = bytes(d_tags.download())
     one = lib.Context(key, device=dev)
@@ -524,11 +523,13 @@ def run_msgs(args, dev, cpu_base):
         tag_ok = tag_ok and t == tags[16 * p_:16 * p_ + 16] and same_ct
     if not tag_ok:
         log("PARITY FAILURE msgs: the packets call and the single-message path disagree")
+    for _ in range(max(args.warmup, 1)):                        # the warm-up steps directly in front of the timed ones (the cross-check above leaves the chip idle for a while)
+        step()
     lib.dev_sync(dev)
     t0 = time.perf_counter()
     done = 0
-    while done < args.steps:
-        for _ in range(min(4, args.steps - done)):
+    while done < args.steps:                                    # the calls are asynchronous and their tags stay on the device: queued back to back (at most 64 deep), waited for once
+        for _ in range(min(64, args.steps - done)):
             step()
             done += 1
         lib.dev_sync(dev)
