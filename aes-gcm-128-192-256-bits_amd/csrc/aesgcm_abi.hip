@@ -566,6 +566,26 @@ int aesgcm_wipe_failed_dev(int device, size_t n_pkts, void *d_out, size_t pkt_le
 }
 
 
+// ---------------------------------------------------------------- messages wherever they live: by rows, always
+int aesgcm_messages_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_msgs, const void *d_ivs,
+                              const uint64_t *d_aad_ptr, const uint32_t *d_aad_len,
+                              const uint64_t *d_in_ptr, const uint32_t *d_len, const uint64_t *d_out_ptr,
+                              void *d_tags, const void *d_expect_tags, int *d_auth, void *stream) {
+    if (!c) return AESGCM_EARG;
+    if (!n_msgs) return AESGCM_OK;
+    if (!d_ivs || !d_tags || !d_in_ptr || !d_len || !d_out_ptr || ((d_aad_ptr != nullptr) != (d_aad_len != nullptr))) return AESGCM_EARG;
+    if (n_msgs >= (((size_t)1) << 31)) return AESGCM_ETOOLONG;
+    HIPCHK(hipSetDevice(c->device));
+    RowsParams r;
+    memset(&r, 0, sizeof r);
+    r.ivs = (const unsigned char *)d_ivs; r.tags = (unsigned char *)d_tags; r.expect = (const unsigned char *)d_expect_tags; r.auth = d_auth;
+    r.in_ptr = (const u64 *)d_in_ptr; r.out_ptr = (const u64 *)d_out_ptr; r.aad_ptr = (const u64 *)d_aad_ptr; r.len_arr = d_len; r.alen_arr = d_aad_len;
+    r.n_pkts = (u32)n_msgs;
+    const int rc = packets_rows(c, decrypt, r, pick_stream(c, stream));
+    if (!rc && decrypt && c->wipe_on_auth_fail && d_expect_tags) return wipe_failed(c->device, n_msgs, nullptr, 0, nullptr, d_auth, pick_stream(c, stream), (const u64 *)d_out_ptr, d_len);
+    return rc;
+}
+
 // ---------------------------------------------------------------- packets under the context's key
 int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const void *d_ivs,
                              const void *d_aad, size_t aad_len, const uint64_t *d_aad_off,

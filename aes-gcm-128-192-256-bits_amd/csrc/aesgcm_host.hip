@@ -629,7 +629,7 @@ int packets_order(aesgcm_ctx *c, const u64 *d_off, size_t n_pkts, hipStream_t st
 
 // ---------------------------------------------------------------- many messages under the context's key: by rows (aesgcm_rows.h)
 // the scratch of the path, carved out of one allocation: per message 16 + 4 bytes and (offset arrays) the three prefix sums, 32 bytes per record slot.  Zero at rest.
-struct RowsScratch { RowsHdr *hdr; u32 *queues; u64 *prefix, *sprefix; u32 *slot_base; RowsRec *rec; unsigned long long *acc; u32 *cnt; };
+struct RowsScratch { RowsHdr *hdr; u32 *queues; u64 *prefix, *sprefix, *plan_part; u32 *slot_base; RowsRec *rec; unsigned long long *acc; u32 *cnt; };
 
 size_t rows_carve(unsigned char *base, size_t slots, size_t n, RowsScratch *r) {
     size_t o = 0;
@@ -639,6 +639,7 @@ size_t rows_carve(unsigned char *base, size_t slots, size_t n, RowsScratch *r) {
     t.queues = (u32 *)take(64 * ROWS_NQ);
     t.prefix = (u64 *)take(8 * (n + 1));
     t.sprefix = (u64 *)take(8 * (n + 1));
+    t.plan_part = (u64 *)take(8 * 3 * (n / 1024 + 2));                   // the planner's sums per workgroup of 1024 messages
     t.slot_base = (u32 *)take(4 * (n + 1));
     t.rec = (RowsRec *)take(sizeof(RowsRec) * slots);
     t.acc = (unsigned long long *)take(16 * n);
@@ -666,7 +667,7 @@ int packets_rows(aesgcm_ctx *c, int decrypt, RowsParams &p, hipStream_t st) {
     const size_t n = p.n_pkts;
     RowsScratch r;
     int rc;
-    const bool var = p.data_off != nullptr || p.aad_off != nullptr;          // a length of either kind on the device: the plan is made there
+    const bool var = p.data_off != nullptr || p.aad_off != nullptr || p.len_arr != nullptr;          // a length of any kind on the device: the plan is made there
     u32 wgs = (u32)c->G / 2;                                                 // one 141 KiB workgroup per CU
     size_t slots;
     if (!var) {
@@ -692,7 +693,7 @@ int packets_rows(aesgcm_ctx *c, int decrypt, RowsParams &p, hipStream_t st) {
     c->rows_dirty = true;                                                    // until both launches are enqueued
     if (var) {
         p.hdr = r.hdr; p.prefix = r.prefix; p.sprefix = r.sprefix; p.slot_base = r.slot_base;
-        HIPCHK(klaunch_rows_plan(st, p.data_off, p.pkt_len, p.aad_off, p.aad_len, p.n_pkts, p.waves, c->rows_block, (u32)ROWS_NB_CAP, p.slot_cap, r.hdr, r.prefix, r.sprefix, r.slot_base));
+        HIPCHK(klaunch_rows_plan(st, p.data_off, p.pkt_len, p.aad_off, p.aad_len, p.len_arr, p.alen_arr, p.n_pkts, p.waves, c->rows_block, (u32)ROWS_NB_CAP, p.slot_cap, r.hdr, r.prefix, r.sprefix, r.slot_base, r.plan_part));
     }
     p.prio_rows = c->cyc_prio;
     if (wgs) HIPCHK(klaunch_rows(c->nr, decrypt, wgs, st, c->km, c->tables, p));                          // (fixed-size records of no bytes and no AAD have no units: their tags are the closing's alone)
@@ -726,10 +727,10 @@ bool packets_by_rows(const aesgcm_ctx *c, size_t n_pkts, size_t pkt_len, bool va
 }
 
 // zero the output of every packet whose d_auth[] entry is 0 (behind the launch that wrote it, on the same stream)
-int wipe_failed(int device, size_t n_pkts, void *d_out, size_t pkt_len, const u64 *d_data_off, const int *d_auth, hipStream_t st) {
-    if (!n_pkts || !d_auth || !d_out) return AESGCM_OK;
+int wipe_failed(int device, size_t n_pkts, void *d_out, size_t pkt_len, const u64 *d_data_off, const int *d_auth, hipStream_t st, const u64 *d_out_ptr, const u32 *d_len) {
+    if (!n_pkts || !d_auth || (!d_out && !d_len)) return AESGCM_OK;
     HIPCHK(hipSetDevice(device));
-    HIPCHK(klaunch_wipe_failed(st, (unsigned char *)d_out, d_auth, d_data_off, (u32)n_pkts, (u32)pkt_len));
+    HIPCHK(klaunch_wipe_failed(st, (unsigned char *)d_out, d_auth, d_data_off, (u32)n_pkts, (u32)pkt_len, d_out_ptr, d_len));
     return AESGCM_OK;
 }
 

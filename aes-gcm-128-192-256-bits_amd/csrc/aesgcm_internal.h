@@ -73,10 +73,10 @@ hipError_t klaunch_pktl(int nr, int dec, bool ilp, unsigned wgs, hipStream_t st,
 hipError_t klaunch_pktg(int nr, int dec, int lg, unsigned wgs, hipStream_t st, const KeyMaterial *km, const DevTables *tb, const PktParams &p);
 hipError_t klaunch_batch3(int nr, int dec, int lg, unsigned wgs, hipStream_t st, const DevTables *tb, const BatchParams &p);
 hipError_t klaunch_len_sort(hipStream_t st, const u64 *d_off, u32 n, u32 *bins, u32 *perm);                                                  // k_len_hist, k_len_scan, k_len_scatter
-hipError_t klaunch_rows_plan(hipStream_t st, const u64 *d_off, u32 pkt_len, const u64 *d_aoff, u32 aad_len, u32 n, u32 waves, u32 force_d, u32 nb_cap, u32 slot_cap, RowsHdr *hdr, u64 *prefix, u64 *sprefix, u32 *slot_base);
+hipError_t klaunch_rows_plan(hipStream_t st, const u64 *d_off, u32 pkt_len, const u64 *d_aoff, u32 aad_len, const u32 *d_len, const u32 *d_alen, u32 n, u32 waves, u32 force_d, u32 nb_cap, u32 slot_cap, RowsHdr *hdr, u64 *prefix, u64 *sprefix, u32 *slot_base, u64 *part);
 hipError_t klaunch_rows(int nr, int dec, unsigned wgs, hipStream_t st, const KeyMaterial *km, const DevTables *tb, const RowsParams &p);
 hipError_t klaunch_rows_close(int dec, unsigned wgs, hipStream_t st, const KeyMaterial *km, const DevTables *tb, const RowsParams &p);
-hipError_t klaunch_wipe_failed(hipStream_t st, unsigned char *out, const int *auth, const u64 *data_off, u32 n_pkts, u32 pkt_len);
+hipError_t klaunch_wipe_failed(hipStream_t st, unsigned char *out, const int *auth, const u64 *data_off, u32 n_pkts, u32 pkt_len, const u64 *out_ptr = nullptr, const u32 *len_arr = nullptr);
 
 // ---------------------------------------------------------------- host runtime (aesgcm_host.hip)
 extern thread_local char g_err[256];
@@ -225,7 +225,7 @@ size_t rows_carve(unsigned char *base, size_t slots, size_t n, RowsScratch *r);
 int rows_scratch(aesgcm_ctx *c, size_t slots, size_t n, hipStream_t st, RowsScratch *r);
 int packets_rows(aesgcm_ctx *c, int decrypt, RowsParams &p, hipStream_t st);
 bool packets_by_rows(const aesgcm_ctx *c, size_t n_pkts, size_t pkt_len, bool var_len);
-int wipe_failed(int device, size_t n_pkts, void *d_out, size_t pkt_len, const u64 *d_data_off, const int *d_auth, hipStream_t st);
+int wipe_failed(int device, size_t n_pkts, void *d_out, size_t pkt_len, const u64 *d_data_off, const int *d_auth, hipStream_t st, const u64 *d_out_ptr = nullptr, const u32 *d_len = nullptr);
 int batch_launch(int device, int decrypt, size_t n_pkts, size_t key_len, BatchParams &p, void *stream);
 void pipeline_release(aesgcm_ctx *c);
 int pipeline_prepare(aesgcm_ctx *c, size_t chunk);

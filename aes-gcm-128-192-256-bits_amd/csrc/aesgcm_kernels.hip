@@ -1179,7 +1179,7 @@ __global__ __launch_bounds__(AESGCM_BODY_WG, AESGCM_BODY_WPS) void k_rows(const 
         for (u32 guard2 = 0, skipped = 0; g < g_end && guard2 <= 2u * D + 4u && skipped <= p.n_pkts; ++guard2) {
             m = opaque_sgpr(m);
             RowsMsg mq = rows_msg(p, m);
-            mq.doff = uniform64(mq.doff); mq.aoff = uniform64(mq.aoff); mq.len = uniform32(mq.len); mq.alen = uniform32(mq.alen);
+            mq.doff = uniform64(mq.doff); mq.ooff = uniform64(mq.ooff); mq.aoff = uniform64(mq.aoff); mq.len = uniform32(mq.len); mq.alen = uniform32(mq.alen);
             const RowsGeom geo = rows_geom(mq.len);
             const u64 g0 = uniform64(rows_unit_base(p, m));
             const u32 U = rows_units(geo, rows_na(mq.alen));
@@ -1307,13 +1307,13 @@ __device__ __forceinline__ u64 block_scan_u64(unsigned long long *part, u64 mine
     }
     return part[tid] - mine;
 }
-__global__ __launch_bounds__(1024) void k_rows_plan(const u64 *__restrict__ off, u32 pkt_len, const u64 *__restrict__ aoff, u32 aad_len, u32 n, u32 waves, u32 force_d, u32 nb_cap, u32 slot_cap,
+__global__ __launch_bounds__(1024) void k_rows_plan(const u64 *__restrict__ off, u32 pkt_len, const u64 *__restrict__ aoff, u32 aad_len, const u32 *__restrict__ len_arr, const u32 *__restrict__ alen_arr, u32 n, u32 waves, u32 force_d, u32 nb_cap, u32 slot_cap,
                                                     RowsHdr *hdr, u64 *prefix, u64 *sprefix, u32 *slot_base) {
     __shared__ unsigned long long part[1024];
     const u32 tid = threadIdx.x, per = (n + 1023u) / 1024u;
     const u32 lo = tid * per < n ? tid * per : n, hi = lo + per < n ? lo + per : n;
-    auto geom_of = [&](u32 m) { return rows_geom(off ? off[m + 1] - off[m] : (u64)pkt_len); };
-    auto na_of = [&](u32 m) { return rows_na(aoff ? (u32)(aoff[m + 1] - aoff[m]) : aad_len); };
+    auto geom_of = [&](u32 m) { return rows_geom(len_arr ? (u64)len_arr[m] : off ? off[m + 1] - off[m] : (u64)pkt_len); };                 // (len_arr: the scattered form, lengths per message)
+    auto na_of = [&](u32 m) { return rows_na(len_arr ? (alen_arr ? alen_arr[m] : 0u) : aoff ? (u32)(aoff[m + 1] - aoff[m]) : aad_len); };
     u64 s = 0, ss = 0;
     for (u32 m = lo; m < hi; ++m) { const RowsGeom g = geom_of(m); const u32 na = na_of(m); s += rows_units(g, na); ss += rows_smalls(g, na); }
     u64 run = block_scan_u64(part, s, tid);                                  // row units in front of the thread's messages
@@ -1349,12 +1349,93 @@ __global__ __launch_bounds__(1024) void k_rows_plan(const u64 *__restrict__ off,
     }
 }
 
+// The same plan for MANY messages: the one workgroup above takes 4 ns a message -- 2.1 ms in front of a 5.1 ms row launch for 524 288 messages of 8 KiB
+// (profiles/r05/rows_var_stats_before.txt).  Five small launches instead, a thread per message and a workgroup per 1024 of them: sums per workgroup; their scan
+// and the cut (one workgroup); the first two prefix sums and the slot counts; the scan of those; the third prefix sum.
+struct RowsPlan {
+    const u64 *off, *aoff; const u32 *len_arr, *alen_arr;
+    u32 pkt_len, aad_len, n, waves, force_d, nb_cap, slot_cap, nwg;
+    RowsHdr *hdr; u64 *prefix, *sprefix; u32 *slot_base;
+    u64 *part;                                                               // 3 x nwg: units, smalls blocks, slots per workgroup -- then what lies in front of each
+};
+__device__ __forceinline__ RowsGeom plan_geom(const RowsPlan &a, u32 m) { return rows_geom(a.len_arr ? (u64)a.len_arr[m] : a.off ? a.off[m + 1] - a.off[m] : (u64)a.pkt_len); }
+__device__ __forceinline__ u32 plan_na(const RowsPlan &a, u32 m) { return rows_na(a.len_arr ? (a.alen_arr ? a.alen_arr[m] : 0u) : a.aoff ? (u32)(a.aoff[m + 1] - a.aoff[m]) : a.aad_len); }
+__global__ __launch_bounds__(1024) void k_rows_plan_sums(const RowsPlan a) {
+    __shared__ unsigned long long part[1024];
+    const u32 tid = threadIdx.x, m = blockIdx.x * 1024u + tid;
+    u64 u = 0, s = 0;
+    if (m < a.n) { const RowsGeom g = plan_geom(a, m); const u32 na = plan_na(a, m); u = rows_units(g, na); s = rows_smalls(g, na); }
+    block_scan_u64(part, u, tid);
+    const u64 U = part[1023];
+    __syncthreads();
+    block_scan_u64(part, s, tid);
+    if (tid == 0) { a.part[blockIdx.x] = U; a.part[a.nwg + blockIdx.x] = part[1023]; }
+}
+// exclusive scan of v[0 .. n) in place by ONE workgroup (tiles of 1024 with a carry); returns the total
+__device__ __forceinline__ u64 plan_scan_in_place(unsigned long long *part, u64 *v, u32 n, u32 tid) {
+    u64 carry = 0;
+    for (u32 base = 0; base < n; base += 1024u) {
+        const u32 i = base + tid;
+        const u64 mine = i < n ? v[i] : 0ull;
+        const u64 before = block_scan_u64(part, mine, tid);
+        const u64 total = part[1023];
+        if (i < n) v[i] = carry + before;
+        carry += total;
+        __syncthreads();
+    }
+    return carry;
+}
+__global__ __launch_bounds__(1024) void k_rows_plan_cut(const RowsPlan a) {
+    __shared__ unsigned long long part[1024];
+    const u32 tid = threadIdx.x;
+    const u64 GR = plan_scan_in_place(part, a.part, a.nwg, tid), ST = plan_scan_in_place(part, a.part + a.nwg, a.nwg, tid);
+    if (tid == 0) {
+        u32 D, NB, dyn;
+        rows_cut(GR, a.waves, a.force_d, a.nb_cap, &D, &NB, &dyn);
+        a.hdr->G = GR; a.hdr->D = D; a.hdr->NB = NB; a.hdr->dyn = dyn; a.hdr->bad = 0;
+        a.prefix[a.n] = GR; a.sprefix[a.n] = ST;
+    }
+}
+__global__ __launch_bounds__(1024) void k_rows_plan_place(const RowsPlan a) {
+    __shared__ unsigned long long part[1024];
+    const u32 tid = threadIdx.x, m = blockIdx.x * 1024u + tid;
+    RowsGeom g = rows_geom(0);
+    u32 na = 0;
+    u64 u = 0, s = 0;
+    if (m < a.n) { g = plan_geom(a, m); na = plan_na(a, m); u = rows_units(g, na); s = rows_smalls(g, na); }
+    const u64 g0 = a.part[blockIdx.x] + block_scan_u64(part, u, tid);
+    __syncthreads();
+    const u64 s0 = a.part[a.nwg + blockIdx.x] + block_scan_u64(part, s, tid);
+    __syncthreads();
+    u64 t = 0;
+    if (m < a.n) { a.prefix[m] = g0; a.sprefix[m] = s0; t = rows_slots(g, na, g0, a.hdr->D); a.slot_base[m] = (u32)t; }
+    block_scan_u64(part, t, tid);
+    if (tid == 0) a.part[2u * a.nwg + blockIdx.x] = part[1023];
+}
+__global__ __launch_bounds__(1024) void k_rows_plan_slots(const RowsPlan a) {
+    __shared__ unsigned long long part[1024];
+    const u32 tid = threadIdx.x;
+    const u64 slots = plan_scan_in_place(part, a.part + 2u * a.nwg, a.nwg, tid);
+    if (tid == 0) {
+        a.slot_base[a.n] = (u32)slots;
+        if (slots > a.slot_cap) { a.hdr->G = 0; a.hdr->NB = 0; a.hdr->bad = 1; }      // (the host sizes the scratch for the worst case; a cut that does not fit would be its bug: then nothing runs)
+    }
+}
+__global__ __launch_bounds__(1024) void k_rows_plan_base(const RowsPlan a) {
+    __shared__ unsigned long long part[1024];
+    const u32 tid = threadIdx.x, m = blockIdx.x * 1024u + tid;
+    const u64 t = m < a.n ? a.slot_base[m] : 0u;
+    const u64 before = block_scan_u64(part, t, tid);
+    if (m < a.n) a.slot_base[m] = (u32)(a.part[2u * a.nwg + blockIdx.x] + before);
+}
+
 // k_wipe_failed: a wave per packet; packets whose auth[] says 0 get their output bytes zeroed (context option "wipe_on_auth_fail", aesgcm_wipe_failed_dev)
-__global__ __launch_bounds__(256) void k_wipe_failed(unsigned char *out, const int *auth, const u64 *data_off, u32 n_pkts, u32 pkt_len) {
+__global__ __launch_bounds__(256) void k_wipe_failed(unsigned char *out, const int *auth, const u64 *data_off, u32 n_pkts, u32 pkt_len, const u64 *out_ptr, const u32 *len_arr) {
     const u32 pkt = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (pkt >= n_pkts || auth[pkt]) return;
-    const u64 lo = data_off ? data_off[pkt] : (u64)pkt * pkt_len, hi = data_off ? data_off[pkt + 1] : lo + pkt_len;
-    unsigned char *p = out + lo;
+    u64 lo = data_off ? data_off[pkt] : (u64)pkt * pkt_len, hi = data_off ? data_off[pkt + 1] : lo + pkt_len;
+    if (len_arr) { lo = out_ptr[pkt]; hi = lo + len_arr[pkt]; }                 // the scattered form: addresses (out is NULL)
+    unsigned char *p = reinterpret_cast<unsigned char *>((uintptr_t)out + lo);
     const u64 len = hi - lo, head = len < 16 ? len : ((16u - ((uintptr_t)p & 15u)) & 15u);
     if (lane < head) p[lane] = 0;
     const u64 nvec = (len - head) / 16;
@@ -1503,8 +1584,19 @@ hipError_t klaunch_len_sort(hipStream_t st, const u64 *d_off, u32 n, u32 *bins, 
     hipLaunchKernelGGL(k_len_scatter, dim3(LEN_SORT_WGS), dim3(256), 0, st, d_off, n, bins, perm);
     return hipGetLastError();
 }
-hipError_t klaunch_rows_plan(hipStream_t st, const u64 *d_off, u32 pkt_len, const u64 *d_aoff, u32 aad_len, u32 n, u32 waves, u32 force_d, u32 nb_cap, u32 slot_cap, RowsHdr *hdr, u64 *prefix, u64 *sprefix, u32 *slot_base) {
-    hipLaunchKernelGGL(k_rows_plan, dim3(1), dim3(1024), 0, st, d_off, pkt_len, d_aoff, aad_len, n, waves, force_d, nb_cap, slot_cap, hdr, prefix, sprefix, slot_base);
+hipError_t klaunch_rows_plan(hipStream_t st, const u64 *d_off, u32 pkt_len, const u64 *d_aoff, u32 aad_len, const u32 *d_len, const u32 *d_alen, u32 n, u32 waves, u32 force_d, u32 nb_cap, u32 slot_cap, RowsHdr *hdr, u64 *prefix, u64 *sprefix, u32 *slot_base, u64 *part) {
+    if (n <= ROWS_PLAN_ONE_WG) {
+        hipLaunchKernelGGL(k_rows_plan, dim3(1), dim3(1024), 0, st, d_off, pkt_len, d_aoff, aad_len, d_len, d_alen, n, waves, force_d, nb_cap, slot_cap, hdr, prefix, sprefix, slot_base);
+        return hipGetLastError();
+    }
+    RowsPlan a;
+    a.off = d_off; a.aoff = d_aoff; a.len_arr = d_len; a.alen_arr = d_alen; a.pkt_len = pkt_len; a.aad_len = aad_len; a.n = n; a.waves = waves; a.force_d = force_d;
+    a.nb_cap = nb_cap; a.slot_cap = slot_cap; a.nwg = (n + 1023u) / 1024u; a.hdr = hdr; a.prefix = prefix; a.sprefix = sprefix; a.slot_base = slot_base; a.part = part;
+    hipLaunchKernelGGL(k_rows_plan_sums, dim3(a.nwg), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(k_rows_plan_cut, dim3(1), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(k_rows_plan_place, dim3(a.nwg), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(k_rows_plan_slots, dim3(1), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(k_rows_plan_base, dim3(a.nwg), dim3(1024), 0, st, a);
     return hipGetLastError();
 }
 hipError_t klaunch_rows(int nr, int dec, unsigned wgs, hipStream_t st, const KeyMaterial *km, const DevTables *tb, const RowsParams &p) {
@@ -1519,7 +1611,7 @@ hipError_t klaunch_rows_close(int dec, unsigned wgs, hipStream_t st, const KeyMa
     else hipLaunchKernelGGL(k_rows_close<0>, dim3(wgs), dim3(ROWS_CLOSE_WG), 0, st, km, tb, p);
     return hipGetLastError();
 }
-hipError_t klaunch_wipe_failed(hipStream_t st, unsigned char *out, const int *auth, const u64 *data_off, u32 n_pkts, u32 pkt_len) {
-    hipLaunchKernelGGL(k_wipe_failed, dim3((n_pkts + 3u) / 4u), dim3(256), 0, st, out, auth, data_off, n_pkts, pkt_len);
+hipError_t klaunch_wipe_failed(hipStream_t st, unsigned char *out, const int *auth, const u64 *data_off, u32 n_pkts, u32 pkt_len, const u64 *out_ptr, const u32 *len_arr) {
+    hipLaunchKernelGGL(k_wipe_failed, dim3((n_pkts + 3u) / 4u), dim3(256), 0, st, out, auth, data_off, n_pkts, pkt_len, out_ptr, len_arr);
     return hipGetLastError();
 }

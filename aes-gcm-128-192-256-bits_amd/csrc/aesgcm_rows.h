@@ -53,6 +53,7 @@
                                                  profiles/r05/rows_ragged_few.txt) */
 #define ROWS_FEW_TAIL 4u                      /* the routing rule's word for "ends (almost) on a row" (packets_by_rows) */
 #define ROWS_SLOTS_PER_MSG 3u                 /* offset-array form: record slots per message besides one per block boundary -- a run, a long tail, a long AAD */
+#define ROWS_PLAN_ONE_WG 4096u                /* offset-array form: up to this many messages one workgroup makes the plan (16 us); beyond, five small launches with a thread per message */
 #define ROWS_REC_VALID 1u
 #define ROWS_REC_WEIGH 2u
 
@@ -68,6 +69,9 @@ struct RowsParams {
     const unsigned char *expect;              // dec: expected tags or NULL
     int *auth;                                // dec: per message 1 / 0, or NULL
     const u64 *data_off, *aad_off;            // n_pkts + 1 byte offsets, or NULL = fixed pkt_len / aad_len records
+    // ... or messages WHEREVER THEY LIVE (aesgcm_messages_crypt_dev): device addresses and lengths per message; in / out / aad above are NULL then
+    const u64 *in_ptr, *out_ptr, *aad_ptr;    // n_pkts device addresses each (aad_ptr: or NULL = no AAD)
+    const u32 *len_arr, *alen_arr;            // n_pkts lengths each (alen_arr: NULL with aad_ptr)
     u32 n_pkts, pkt_len, aad_len;
     u32 waves;                                // waves of the k_rows launch
     // the cut: fixed-size form (the host knows it) ...
@@ -126,16 +130,25 @@ HD void rows_cut(u64 G, u32 waves, u32 force_d, u64 nb_cap, u32 *D, u32 *NB, u32
     if ((force_d || d > ROWS_STATIC_MAX) && (G + dd - 1u) / dd <= nb_cap) { d = dd; dy = 1; }
     *D = (u32)d; *NB = (u32)((G + d - 1u) / d); *dyn = dy;
 }
-// the message's lengths and offsets
-struct RowsMsg { u64 doff, aoff; u32 len, alen; };
+// the message's lengths and where it lies: offsets from the call's in / out / aad (the scattered form: from 0, i.e. addresses)
+struct RowsMsg { u64 doff, ooff, aoff; u32 len, alen; };
 HD RowsMsg rows_msg(const RowsParams &p, u32 m) {
     RowsMsg q;
+    if (p.len_arr) {
+        q.doff = p.in_ptr[m]; q.ooff = p.out_ptr[m]; q.len = p.len_arr[m];
+        q.aoff = p.aad_ptr ? p.aad_ptr[m] : 0; q.alen = p.aad_ptr ? p.alen_arr[m] : 0u;
+        return q;
+    }
     q.len = p.pkt_len; q.alen = p.aad_len;
     q.doff = (u64)m * p.pkt_len; q.aoff = (u64)m * p.aad_len;
     if (p.data_off) { q.doff = p.data_off[m]; q.len = (u32)(p.data_off[m + 1] - q.doff); }
     if (p.aad_off) { q.aoff = p.aad_off[m]; q.alen = (u32)(p.aad_off[m + 1] - q.aoff); }
+    q.ooff = q.doff;
     return q;
 }
+HD const unsigned char *rows_src(const RowsParams &p, const RowsMsg &q) { return reinterpret_cast<const unsigned char *>((uintptr_t)p.in + q.doff); }
+HD unsigned char *rows_dst(const RowsParams &p, const RowsMsg &q) { return reinterpret_cast<unsigned char *>((uintptr_t)p.out + q.ooff); }
+HD const unsigned char *rows_aadp(const RowsParams &p, const RowsMsg &q) { return reinterpret_cast<const unsigned char *>((uintptr_t)p.aad + q.aoff); }
 // the LAST message of [lo, hi) whose entry of a prefix array is <= x: the one that owns position x (messages without a share have their successor's start)
 HD u32 rows_search(const u64 *pre, u64 x, u32 lo, u32 hi) {
     while (hi - lo > 1u) { const u32 mid = lo + ((hi - lo) >> 1); if (pre[mid] <= x) lo = mid; else hi = mid; }
@@ -175,7 +188,7 @@ HD RowsPiece rows_piece(const RowsGeom &g, u32 slot_base, u64 g0, u32 u, u64 roo
 template <int NR, int MODE>
 HD uint4 rows_run_lane(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const RowsParams &p, const RowsMsg &q, const RowsPiece &pc,
                        const unsigned char *smem, const CtrConsts &cc, u32 lane, u32 prio_rows, u32 prio_slot) {
-    return body_rows_lane<NR, MODE>(km, tb, p.in + q.doff, p.out + q.doff, 0u, smem, cc, pc.r0, pc.len, lane, prio_rows, prio_slot);
+    return body_rows_lane<NR, MODE>(km, tb, rows_src(p, q), rows_dst(p, q), 0u, smem, cc, pc.r0, pc.len, lane, prio_rows, prio_slot);
 }
 // the lane's term of the run's polynomial: B_L H^(63 - L) (XOR over the wave = the polynomial of the run up to its last block)
 HD G128 rows_run_term(const KeyMaterial *__restrict__ km, uint4 acc, u32 lane) { return shoup2_gmul_lds(mo_to_be(acc), km->ltab[63u - lane]); }
@@ -187,8 +200,8 @@ HD G128 rows_tail_lane(const KeyMaterial *__restrict__ km, const RowsParams &p, 
     const u32 lb = (lane & 31u) << 2;
     const RowsGeom g = rows_geom(q.len);
     const u32 pad = 64u - g.tb;
-    const unsigned char *src = p.in + q.doff;
-    unsigned char *dst = p.out + q.doff;
+    const unsigned char *src = rows_src(p, q);
+    unsigned char *dst = rows_dst(p, q);
     G128 z = {{0, 0, 0, 0}};
     if (lane >= pad) {                                                                  // (the table multiply too: its 32 reads per lane go to 64 different tables, and the memory path takes them a lane at a time)
         uint4 gin;
@@ -209,7 +222,7 @@ HD G128 rows_tail_lane(const KeyMaterial *__restrict__ km, const RowsParams &p, 
 // An AAD of more than ROWS_SMALL_AAD blocks as rows of its own (right-aligned, Horner with H^64): the lane's term  A_L H^(63 - L)  of the AAD's polynomial
 HD G128 rows_aad_lane(const KeyMaterial *__restrict__ km, const RowsParams &p, const RowsMsg &q, const unsigned char *smem, u32 lane) {
     const u32 n_aad = rows_na(q.alen), rows = (n_aad + 63u) >> 6, pad = 64u * rows - n_aad;
-    const unsigned char *a = p.aad + q.aoff;
+    const unsigned char *a = rows_aadp(p, q);
     uint4 acc = make_uint4(0, 0, 0, 0);
     for (u32 k = 0; k < rows; k++) {
         if (k) acc = ghash_mul_const_lds(acc, smem);
@@ -274,7 +287,7 @@ HD u32 rows_small_block(const KeyMaterial *__restrict__ km, const u32 *te, const
     uint4 x;
     u32 e;
     if (r < nas) {
-        const unsigned char *a = p.aad + q.aoff;
+        const unsigned char *a = rows_aadp(p, q);
         const u32 off = 16u * r, rem = q.alen - off;
         x = rem >= 16u ? gload16_any(a + off) : load_block_bytes(a + off, rem);
         e = nas - 1u - r;
@@ -283,8 +296,8 @@ HD u32 rows_small_block(const KeyMaterial *__restrict__ km, const u32 *te, const
         const u32 i = r - nas, bi = 64u * g.R + i;                                       // block of the tail, block of the message
         const unsigned char *ivp = p.ivs + (size_t)m * 12;
         const uint4 ks = aes_encrypt_te(te, km->rk, km->nr, make_uint4(load_le32(ivp), load_le32(ivp + 4), load_le32(ivp + 8), bswap32(2u + bi)));
-        const unsigned char *src = p.in + q.doff;
-        unsigned char *dst = p.out + q.doff;
+        const unsigned char *src = rows_src(p, q);
+        unsigned char *dst = rows_dst(p, q);
         const u32 off = 16u * bi, rem = q.len - off;
         const bool full = rem >= 16u;
         const uint4 in = full ? gload16_any(src + off) : load_block_bytes(src + off, rem);

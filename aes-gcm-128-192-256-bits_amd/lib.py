@@ -24,7 +24,7 @@ SYMBOLS = [
     "aesgcm_encrypt_pipelined", "aesgcm_decrypt_pipelined", "aesgcm_host_alloc", "aesgcm_host_free",
     "aesgcm_encrypt", "aesgcm_decrypt", "aesgcm_encrypt_dev", "aesgcm_decrypt_dev", "aesgcm_last_tag",
     "aesgcm_keystream", "aesgcm_keystream_dev",
-    "aesgcm_shard_crypt_dev", "aesgcm_shard_finalize_dev", "aesgcm_shard_finalize_strided_dev", "aesgcm_shard_finalize_batch_dev", "aesgcm_batch_crypt_dev", "aesgcm_batch_crypt_var_dev", "aesgcm_packets_crypt_dev", "aesgcm_batch_shape", "aesgcm_packets_shape",
+    "aesgcm_shard_crypt_dev", "aesgcm_shard_finalize_dev", "aesgcm_shard_finalize_strided_dev", "aesgcm_shard_finalize_batch_dev", "aesgcm_batch_crypt_dev", "aesgcm_batch_crypt_var_dev", "aesgcm_packets_crypt_dev", "aesgcm_messages_crypt_dev", "aesgcm_batch_shape", "aesgcm_packets_shape",
     "aesgcm_stream_begin", "aesgcm_stream_aad", "aesgcm_stream_update", "aesgcm_stream_final",
     "aesgcm_dev_alloc", "aesgcm_dev_free", "aesgcm_dev_upload", "aesgcm_dev_download", "aesgcm_dev_sync", "aesgcm_dev_copy",
     "aesgcm_fill_splitmix64_dev",
@@ -134,6 +134,7 @@ def _typed(L):
     L.aesgcm_batch_crypt_dev.argtypes = [cint, cint, sz, sz, vp, vp, vp, sz, vp, sz, vp, vp, vp, vp, vp]
     L.aesgcm_batch_crypt_var_dev.argtypes = [cint, cint, sz, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.aesgcm_packets_crypt_dev.argtypes = [vp, cint, sz, vp, vp, sz, vp, vp, sz, vp, vp, vp, vp, vp, vp]
+    L.aesgcm_messages_crypt_dev.argtypes = [vp, cint, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.aesgcm_batch_shape.argtypes = [cint, sz, sz, cint, ctypes.POINTER(cint)]
     L.aesgcm_packets_shape.argtypes = [vp, sz, sz, cint, ctypes.POINTER(cint)]
     L.aesgcm_stream_begin.argtypes = [vp, vp, cint]
@@ -573,6 +574,10 @@ class Context:
                           d_aad=None, aad_len=0, d_aad_off=None, d_expect_tags=None, d_auth=None, stream=None):
         _chk(self._lib.aesgcm_packets_crypt_dev(self._c, int(bool(decrypt)), n_pkts, d_ivs, d_aad, aad_len, d_aad_off,
                                              d_in, pkt_len, d_data_off, d_out, d_tags, d_expect_tags, d_auth, stream))
+
+    def messages_crypt_dev(self, decrypt, n_msgs, d_ivs, d_in_ptr, d_len, d_out_ptr, d_tags, d_aad_ptr=None, d_aad_len=None, d_expect_tags=None, d_auth=None, stream=None):
+        """aesgcm_messages_crypt_dev: n_msgs messages wherever they live -- device arrays of addresses (uint64) and lengths (uint32) -- under the context's key, by rows"""
+        _chk(self._lib.aesgcm_messages_crypt_dev(self._c, int(bool(decrypt)), n_msgs, d_ivs, d_aad_ptr, d_aad_len, d_in_ptr, d_len, d_out_ptr, d_tags, d_expect_tags, d_auth, stream))
 
     # shards
     def shard_crypt_dev(self, decrypt, iv, d_in, nbytes, d_out, first_block, total_len, d_partial,

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define AESGCM_ABI_VERSION 4   /* 4 (round 5): packets of message size by rows (AESGCM_SHAPE_ROWS), aesgcm_ctx_last_launch, aesgcm_wipe_failed_dev and the option "wipe_on_auth_fail",
+#define AESGCM_ABI_VERSION 4   /* 4 (round 5): packets of message size by rows (AESGCM_SHAPE_ROWS), aesgcm_messages_crypt_dev, aesgcm_ctx_last_launch, aesgcm_wipe_failed_dev and the option "wipe_on_auth_fail",
                                   aesgcm_mgpu_crypt_dev with tag = NULL + aesgcm_mgpu_last_tags / aesgcm_mgpu_sync;
                                   2: aesgcm_ctx_wait, aesgcm_comm_* / aesgcm_mgpu_*, packet and batch entry points; 3: aesgcm_ctx_set_option (the library no longer reads
                                   any environment variable), aesgcm_batch_shape / aesgcm_packets_shape, aesgcm_mgpu_ctx, aesgcm_last_tag through the host slot */
@@ -289,6 +289,18 @@ AESGCM_API int aesgcm_packets_crypt_dev(aesgcm_ctx *ctx, int decrypt, size_t n_p
                              const void *d_aad, size_t aad_len, const uint64_t *d_aad_off,
                              const void *d_in, size_t pkt_len, const uint64_t *d_data_off, void *d_out,
                              void *d_tags, const void *d_expect_tags, int *d_auth, void *stream);
+
+/* Messages WHEREVER THEY LIVE under the context's key (round 5): the same work as aesgcm_packets_crypt_dev by rows, but every message has its own buffers --
+ * the reference's harness hands the core one frame after the other, each its own object (tb/gcm_test.py:76-85, tb/gcm_gctr.py:233-276); a caller with a queue
+ * of messages in separate allocations has exactly that, and copying them into one buffer to batch them would cost what the batch saves.  All arrays are in
+ * device memory, n_msgs entries each: d_in_ptr / d_out_ptr device addresses of the messages' input and output (in == out allowed), d_len their lengths
+ * (each < 2^28 bytes), d_aad_ptr / d_aad_len the same for AAD (both NULL: none); d_ivs n_msgs x 12 bytes, d_tags n_msgs x 16; decrypt: d_expect_tags / d_auth
+ * as aesgcm_packets_crypt_dev.  Always by rows (any number, any size -- a call of a few hundred tiny messages is better served by the packet kernels through
+ * aesgcm_packets_crypt_dev); the context option "wipe_on_auth_fail" applies.  Asynchronous on `stream`. */
+AESGCM_API int aesgcm_messages_crypt_dev(aesgcm_ctx *ctx, int decrypt, size_t n_msgs, const void *d_ivs,
+                              const uint64_t *d_aad_ptr, const uint32_t *d_aad_len,
+                              const uint64_t *d_in_ptr, const uint32_t *d_len, const uint64_t *d_out_ptr,
+                              void *d_tags, const void *d_expect_tags, int *d_auth, void *stream);
 
 /* ---------------------------------------------------------------- batch: independent packets, per-packet key + IV
  * (BASELINE config 5; the RTL equivalent is reloading key and IV between packets, tb/gcm_gctr.py:144-175,

@@ -20,6 +20,7 @@ from aesgcm_amd import lib  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("kind", choices=("batch", "pkt", "pktw", "pktg", "pktg8", "pktg4", "pktl", "rows", "norows"))
+ap.add_argument("--scatter", action="store_true", help="one key: the same packets as messages wherever they live (aesgcm_messages_crypt_dev: arrays of addresses and lengths; always by rows)")
 ap.add_argument("--var", action="store_true", help="one key: the same packets through offset arrays (pkt_len then is the caller's hint)")
 ap.add_argument("--aad", type=int, default=0, help="one key: bytes of AAD per packet")
 ap.add_argument("--opt", action="append", default=[], help="context option key=value (aesgcm_ctx_set_option), repeatable")
@@ -68,7 +69,19 @@ else:
     if a.aad:
         d_aad = lib.DeviceBuffer(a.aad * n); d_aad.fill_splitmix64(0x414144)
 
+    if a.scatter:
+        import struct
+        d_ip, d_op, d_ln = lib.DeviceBuffer(8 * n), lib.DeviceBuffer(8 * n), lib.DeviceBuffer(4 * n)
+        d_ip.upload(struct.pack("<%dQ" % n, *[d_pt.ptr + pkt * i for i in range(n)])); d_op.upload(struct.pack("<%dQ" % n, *[d_ct.ptr + pkt * i for i in range(n)]))
+        d_ln.upload(struct.pack("<%dI" % n, *([pkt] * n)))
+        d_ap = d_al = None
+        if a.aad:
+            d_ap, d_al = lib.DeviceBuffer(8 * n), lib.DeviceBuffer(4 * n)
+            d_ap.upload(struct.pack("<%dQ" % n, *[d_aad.ptr + a.aad * i for i in range(n)])); d_al.upload(struct.pack("<%dI" % n, *([a.aad] * n)))
+
     def go():
+        if a.scatter:
+            return ctx.messages_crypt_dev(a.dec, n, d_ivs.ptr, d_ip.ptr, d_ln.ptr, d_op.ptr, d_tags.ptr, d_aad_ptr=d_ap.ptr if d_ap else None, d_aad_len=d_al.ptr if d_al else None)
         ctx.packets_crypt_dev(a.dec, n, d_ivs.ptr, d_pt.ptr, d_ct.ptr, d_tags.ptr, pkt_len=pkt, d_data_off=d_off.ptr if d_off else None,
                               d_aad=d_aad.ptr if d_aad else None, aad_len=0 if d_aoff else a.aad, d_aad_off=d_aoff.ptr if d_aoff else None)
 go(); lib.dev_sync()

@@ -86,6 +86,11 @@ for k in range(4):
     ctx.packets_crypt_dev(True, 1000, d_ivs.ptr, d_in.ptr, d_out.ptr, d_tags.ptr, pkt_len=65536, d_data_off=d_off.ptr, d_aad=d_aad.ptr, d_aad_off=d_off.ptr,
                           d_expect_tags=d_tags.ptr, d_auth=d_auth.ptr)                                                   # ... with an AAD array (the smalls of the closing launch), verified, wiped
     ctx.packets_crypt_dev(False, 300, d_ivs.ptr, d_in.ptr, d_out.ptr, d_tags.ptr, pkt_len=16400, d_aad=d_aad.ptr, aad_len=13)   # by rows, fixed-size records with a header and a ragged end
+    d_ptrs, d_lens = lib.DeviceBuffer(8 * 1000, k), lib.DeviceBuffer(4 * 1000, k)
+    d_ptrs.upload(struct.pack("<1000Q", *[d_in.ptr + 4096 * i for i in range(1000)]))
+    d_lens.upload(struct.pack("<1000I", *([4000] * 1000)))
+    ctx.messages_crypt_dev(False, 1000, d_ivs.ptr, d_ptrs.ptr, d_lens.ptr, d_ptrs.ptr, d_tags.ptr)                          # messages wherever they live: arrays of addresses and lengths
+    ctx.messages_crypt_dev(True, 1000, d_ivs.ptr, d_ptrs.ptr, d_lens.ptr, d_ptrs.ptr, d_tags.ptr, d_aad_ptr=d_ptrs.ptr, d_aad_len=d_lens.ptr, d_expect_tags=d_tags.ptr, d_auth=d_auth.ptr)
     check("packets", k)
     # a key per packet (context-free: the device is an argument)
     d_keys = lib.DeviceBuffer(32 * n, k)

@@ -237,17 +237,17 @@ hipError_t klaunch_batch3(int, int, int, unsigned, hipStream_t st, const DevTabl
     return hipSuccess;
 }
 hipError_t klaunch_len_sort(hipStream_t st, const u64 *d_off, u32, u32 *bins, u32 *perm) { LAUNCH("k_len_*", st); P(d_off); P(bins); P(perm); return hipSuccess; }
-hipError_t klaunch_rows_plan(hipStream_t st, const u64 *d_off, u32, const u64 *d_aoff, u32, u32, u32, u32, u32, u32, RowsHdr *hdr, u64 *prefix, u64 *sprefix, u32 *slot_base) {
-    LAUNCH("k_rows_plan", st); P(d_off); P(d_aoff); P(hdr); P(prefix); P(sprefix); P(slot_base);
+hipError_t klaunch_rows_plan(hipStream_t st, const u64 *d_off, u32, const u64 *d_aoff, u32, const u32 *d_len, const u32 *d_alen, u32, u32, u32, u32, u32, RowsHdr *hdr, u64 *prefix, u64 *sprefix, u32 *slot_base, u64 *part) {
+    LAUNCH("k_rows_plan", st); P(d_off); P(d_aoff); P(d_len); P(d_alen); P(part); P(hdr); P(prefix); P(sprefix); P(slot_base);
     return hipSuccess;
 }
 static void rows_ptrs(const char *W, const KeyMaterial *km, const RowsParams &p) {
-    P(km); P(p.ivs); P(p.aad); P(p.in); P(p.out); P(p.tags); P(p.expect); P(p.auth); P(p.data_off); P(p.aad_off); P(p.hdr); P(p.prefix); P(p.sprefix); P(p.slot_base);
+    P(km); P(p.ivs); P(p.aad); P(p.in); P(p.out); P(p.tags); P(p.expect); P(p.auth); P(p.data_off); P(p.aad_off); P(p.in_ptr); P(p.out_ptr); P(p.aad_ptr); P(p.len_arr); P(p.alen_arr); P(p.hdr); P(p.prefix); P(p.sprefix); P(p.slot_base);
     P(p.rec); P(p.acc); P(p.cnt); P(p.queues);
 }
 hipError_t klaunch_rows(int, int, unsigned, hipStream_t st, const KeyMaterial *km, const DevTables *tb, const RowsParams &p) { LAUNCH("k_rows", st); BIG_LDS(); P(tb); rows_ptrs(W, km, p); return hipSuccess; }
 hipError_t klaunch_rows_close(int, unsigned, hipStream_t st, const KeyMaterial *km, const DevTables *tb, const RowsParams &p) { LAUNCH("k_rows_close", st); P(tb); rows_ptrs(W, km, p); return hipSuccess; }
-hipError_t klaunch_wipe_failed(hipStream_t st, unsigned char *out, const int *auth, const u64 *data_off, u32, u32) { LAUNCH("k_wipe_failed", st); P(out); P(auth); P(data_off); return hipSuccess; }
+hipError_t klaunch_wipe_failed(hipStream_t st, unsigned char *out, const int *auth, const u64 *data_off, u32, u32, const u64 *out_ptr, const u32 *len_arr) { LAUNCH("k_wipe_failed", st); P(out); P(auth); P(data_off); P(out_ptr); P(len_arr); return hipSuccess; }
 
 // ---------------------------------------------------------------- RCCL (reached by csrc/aesgcm_comm.hip through dlopen of this very library)
 struct FakeComm { int dev, rank, n; };

@@ -805,7 +805,7 @@ static void emu_rows_nr(const KeyMaterial *km, int dec, RowsParams &p, u32 waves
     std::vector<u32> slot_base(n + 1, 0);
     RowsHdr hdr;
     size_t slots;
-    if (p.data_off || p.aad_off) {                                       // k_rows_plan
+    if (p.data_off || p.aad_off || p.len_arr) {                          // k_rows_plan
         for (u32 m = 0; m < n; m++) {
             const RowsMsg q = rows_msg(p, m);
             prefix[m + 1] = prefix[m] + rows_units(rows_geom(q.len), rows_na(q.alen));
@@ -907,33 +907,50 @@ static void emu_rows_nr(const KeyMaterial *km, int dec, RowsParams &p, u32 waves
         CHECK(made_of[m] + 1u == due(m), "rows: message %u fell into %u pieces", m, made_of[m]);
     }
 }
-static void test_rows(int key_len, u64 seed, u32 waves, u32 force_d, bool var, const std::vector<u32> &lens, const std::vector<u32> &aads, u32 misalign = 0) {
+// var: 0 fixed-size records, 1 offset arrays, 2 messages wherever they live (arrays of addresses and lengths: every message with a gap of its own in front, in and
+// out at different spacings)
+static void test_rows(int key_len, u64 seed, u32 waves, u32 force_d, int var, const std::vector<u32> &lens, const std::vector<u32> &aads, u32 misalign = 0) {
     auto key = rnd(key_len, seed);
     Emu E(key.data(), key_len, 0);
     const u32 n = (u32)lens.size();
+    const u64 gi = var == 2 ? 48 : 0, go = var == 2 ? 80 : 0;                // gaps between the messages of the scattered form (input, output)
     std::vector<u64> doff(n + 1, misalign), aoff(n + 1, 0);
     for (u32 i = 0; i < n; i++) { doff[i + 1] = doff[i] + lens[i]; aoff[i + 1] = aoff[i] + aads[i]; }
-    ABuf in(doff[n]), out(doff[n]);
+    ABuf in(doff[n] + gi * n), out(doff[n] + go * n), back(doff[n] + gi * n);
     auto aad = rnd(aoff[n], seed + 1), ivs = rnd(12 * n, seed + 2);
-    orc_fill_splitmix64(in.p, doff[n], seed + 3, 0);
+    orc_fill_splitmix64(in.p, doff[n] + gi * n, seed + 3, 0);
     std::vector<uint8_t> tags(16 * n + 16), tags2(16 * n + 16);
+    std::vector<u64> in_ptr(n), out_ptr(n), aad_ptr(n);
+    std::vector<u32> alens(aads);
     for (int dec = 0; dec < 2; dec++) {
         RowsParams p; memset(&p, 0, sizeof p);
-        p.ivs = ivs.data(); p.aad = aad.data(); p.in = dec ? out.p : in.p; p.out = out.p; p.tags = dec ? tags2.data() : tags.data();
+        p.ivs = ivs.data(); p.tags = dec ? tags2.data() : tags.data();
         p.n_pkts = n;
-        if (var) { p.data_off = doff.data(); if (aoff[n]) p.aad_off = aoff.data(); }        // (no AAD anywhere: no AAD array -- empty messages then have no unit at all)
-        else { p.pkt_len = lens[0]; p.aad_len = aads[0]; }
+        if (var == 2) {                                                  // encrypt in -> out, decrypt out -> back
+            for (u32 k = 0; k < n; k++) {
+                in_ptr[k] = (u64)(uintptr_t)((dec ? out.p : in.p) + doff[k] + (dec ? go : gi) * k);
+                out_ptr[k] = (u64)(uintptr_t)((dec ? back.p : out.p) + doff[k] + (dec ? gi : go) * k);
+                aad_ptr[k] = (u64)(uintptr_t)(aad.data() + aoff[k]);
+            }
+            p.in_ptr = in_ptr.data(); p.out_ptr = out_ptr.data(); p.len_arr = lens.data();
+            if (aoff[n]) { p.aad_ptr = aad_ptr.data(); p.alen_arr = alens.data(); }
+        } else {
+            p.aad = aad.data(); p.in = dec ? out.p : in.p; p.out = out.p;
+            if (var) { p.data_off = doff.data(); if (aoff[n]) p.aad_off = aoff.data(); }        // (no AAD anywhere: no AAD array -- empty messages then have no unit at all)
+            else { p.pkt_len = lens[0]; p.aad_len = aads[0]; }
+        }
         if (E.km.nr == 10) emu_rows_nr<10>(&E.km, dec, p, waves, force_d); else if (E.km.nr == 12) emu_rows_nr<12>(&E.km, dec, p, waves, force_d); else emu_rows_nr<14>(&E.km, dec, p, waves, force_d);
         if (!dec) {
             for (u32 k = 0; k < n; k++) {
                 std::vector<uint8_t> ref(lens[k] + 16); uint8_t rtag[16];
-                orc_gcm_crypt(0, key.data(), key_len, ivs.data() + 12 * k, aad.data() + aoff[k], aads[k], in.p + doff[k], lens[k], ref.data(), rtag);
-                CHECK(memcmp(ref.data(), out.p + doff[k], lens[k]) == 0, "rows ct %u len %u waves %u D %u var %d", k, lens[k], waves, force_d, (int)var);
-                CHECK(memcmp(rtag, tags.data() + 16 * k, 16) == 0, "rows tag %u len %u aad %u waves %u D %u var %d", k, lens[k], aads[k], waves, force_d, (int)var);
+                orc_gcm_crypt(0, key.data(), key_len, ivs.data() + 12 * k, aad.data() + aoff[k], aads[k], in.p + doff[k] + gi * k, lens[k], ref.data(), rtag);
+                CHECK(memcmp(ref.data(), out.p + doff[k] + go * k, lens[k]) == 0, "rows ct %u len %u waves %u D %u var %d", k, lens[k], waves, force_d, var);
+                CHECK(memcmp(rtag, tags.data() + 16 * k, 16) == 0, "rows tag %u len %u aad %u waves %u D %u var %d", k, lens[k], aads[k], waves, force_d, var);
             }
         } else {
-            CHECK(memcmp(out.p + misalign, in.p + misalign, doff[n] - misalign) == 0, "rows dec data waves %u D %u var %d", waves, force_d, (int)var);
-            CHECK(memcmp(tags2.data(), tags.data(), 16 * n) == 0, "rows dec tags waves %u D %u var %d", waves, force_d, (int)var);
+            if (var == 2) { for (u32 k = 0; k < n; k++) CHECK(memcmp(back.p + doff[k] + gi * k, in.p + doff[k] + gi * k, lens[k]) == 0, "rows dec data %u (scattered) waves %u D %u", k, waves, force_d); }
+            else CHECK(memcmp(out.p + misalign, in.p + misalign, doff[n] - misalign) == 0, "rows dec data waves %u D %u var %d", waves, force_d, var);
+            CHECK(memcmp(tags2.data(), tags.data(), 16 * n) == 0, "rows dec tags waves %u D %u var %d", waves, force_d, var);
         }
     }
 }
@@ -1004,6 +1021,9 @@ int main(int argc, char **argv) {
     test_rows(24, 219, 5, 2, false, {16400, 16400, 16400, 16400, 16400, 16400, 16400}, {13, 13, 13, 13, 13, 13, 13});      // TLS-shaped records: 2 + 1 blocks of smalls each
     test_rows(16, 220, 9, 0, false, {1024 + 40 * 16, 1024 + 40 * 16, 1024 + 40 * 16, 1024 + 40 * 16, 1024 + 40 * 16}, {30 * 16 + 1, 30 * 16 + 1, 30 * 16 + 1, 30 * 16 + 1, 30 * 16 + 1});   // 31 + 40 blocks per message: every unit boundary inside a segment
     test_rows(32, 221, 3, 1, false, {700, 700, 700}, {2000, 2000, 2000});          // a long AAD (125 blocks) and a tail, no row
+    test_rows(32, 222, 6, 0, 2, rl, ra);                                         // messages wherever they live: the lengths of the first case, every message in buffers of its own
+    test_rows(16, 223, 4, 2, 2, {16400, 0, 100, 16384 + 1023, 5000, 16, 2048 + 700, 65536 + 1}, {13, 0, 1024, 1025, 0, 20, 16, 0}, 7);
+    test_rows(24, 224, 5, 0, 2, {4096, 0, 1024, 3000}, {0, 0, 0, 0});              // ... without AAD arrays
     if (level > 1) {
         test_key(32, 1, 7, {{123, 16 * 64 * 1100 + 11}});     // 1100 chunks: two stage-1 workgroups
         test_key(16, 0, 8, {{0, 16 * W * 600}});              // production rule, > GMAX chunks of Tw = 16
