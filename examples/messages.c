@@ -2,7 +2,8 @@
  * while no key is loaded, src/gcm_gctr.vhd:142-144) at message size -- as ONE device call: aesgcm_packets_crypt_dev over fixed-size records, which from 8 KiB
  * per packet goes by rows (aesgcm_packets_shape says AESGCM_SHAPE_ROWS; csrc/aesgcm_rows.h).  A sample of the messages is encrypted once more through the
  * single-message entry point (aesgcm_encrypt_dev) and must give the same tag; all are decrypted in place and authenticated, one forged tag must be reported
- * and -- with the context option wipe_on_auth_fail -- its message come back as zeros.
+ * and -- with the context option wipe_on_auth_fail -- its message come back as zeros.  The same messages also go through aesgcm_messages_crypt_dev (arrays of
+ * device addresses and lengths: messages wherever they live) and must give the same tags.
  *
  *   make -C examples messages && examples/messages [n_messages] [bytes_per_message]
  */
@@ -49,6 +50,29 @@ int main(int argc, char **argv) {
         if ((p * size) % 16) continue;
         CHECK(aesgcm_encrypt_dev(one, ivs + 12 * p, NULL, 0, (const char *)d_pt + p * size, size, d_one, t1, NULL));
         if (memcmp(t1, tags + 16 * p, 16)) { fprintf(stderr, "message %zu: the packets call and aesgcm_encrypt_dev disagree\n", p); return 1; }
+    }
+    /* the same messages "wherever they live": arrays of device addresses and lengths (aesgcm_messages_crypt_dev) -- here they point into the same buffers, in
+     * reverse order; the tags must be the same ones */
+    {
+        uint64_t *ip = malloc(8 * n), *op = malloc(8 * n);
+        uint32_t *ln = malloc(4 * n);
+        unsigned char *ivr = malloc(12 * n), *tr = malloc(16 * n);
+        void *d_ip, *d_op, *d_ln, *d_ivr, *d_tr;
+        for (size_t p = 0; p < n; p++) {
+            const size_t q = n - 1 - p;
+            ip[p] = (uint64_t)(uintptr_t)((const char *)d_pt + q * size); op[p] = (uint64_t)(uintptr_t)((char *)d_ct + q * size); ln[p] = (uint32_t)size;
+            memcpy(ivr + 12 * p, ivs + 12 * q, 12);
+        }
+        CHECK(aesgcm_dev_alloc(0, &d_ip, 8 * n)); CHECK(aesgcm_dev_alloc(0, &d_op, 8 * n)); CHECK(aesgcm_dev_alloc(0, &d_ln, 4 * n));
+        CHECK(aesgcm_dev_alloc(0, &d_ivr, 12 * n + 16)); CHECK(aesgcm_dev_alloc(0, &d_tr, 16 * n));
+        CHECK(aesgcm_dev_upload(0, d_ip, ip, 8 * n)); CHECK(aesgcm_dev_upload(0, d_op, op, 8 * n)); CHECK(aesgcm_dev_upload(0, d_ln, ln, 4 * n)); CHECK(aesgcm_dev_upload(0, d_ivr, ivr, 12 * n));
+        CHECK(aesgcm_messages_crypt_dev(ctx, 0, n, d_ivr, NULL, NULL, (const uint64_t *)d_ip, (const uint32_t *)d_ln, (const uint64_t *)d_op, d_tr, NULL, NULL, NULL));
+        CHECK(aesgcm_dev_sync(0));
+        CHECK(aesgcm_dev_download(0, tr, d_tr, 16 * n));
+        for (size_t p = 0; p < n; p++)
+            if (memcmp(tr + 16 * p, tags + 16 * (n - 1 - p), 16)) { fprintf(stderr, "message %zu: aesgcm_messages_crypt_dev and aesgcm_packets_crypt_dev disagree\n", n - 1 - p); return 1; }
+        free(ip); free(op); free(ln); free(ivr); free(tr);
+        aesgcm_dev_free(0, d_ip); aesgcm_dev_free(0, d_op); aesgcm_dev_free(0, d_ln); aesgcm_dev_free(0, d_ivr); aesgcm_dev_free(0, d_tr);
     }
     /* decrypt in place with verification; the tag of message 1 forged */
     const size_t bad = n > 1 ? 1 : 0;
