@@ -500,9 +500,22 @@ def run_msgs(args, dev, cpu_base):
         d_aad.fill_splitmix64(0x414144)
     akw = dict(d_aad=d_aad.ptr, aad_len=al) if al else {}
     ctx = lib.Context(key, device=dev)
-    shape = ctx.packets_shape(n, size)
+    shape = lib.SHAPE_ROWS if args.scattered else ctx.packets_shape(n, size)
+
+    if args.scattered:
+        import struct
+        u64s = lambda base, stride: struct.pack("<%dQ" % n, *[base + stride * i for i in range(n)])
+        d_pp, d_cp, d_ln = lib.DeviceBuffer(8 * n, device=dev), lib.DeviceBuffer(8 * n, device=dev), lib.DeviceBuffer(4 * n, device=dev)
+        d_pp.upload(u64s(d_pt.ptr, size)); d_cp.upload(u64s(d_ct.ptr, size)); d_ln.upload(struct.pack("<%dI" % n, *([size] * n)))
+        skw = {}
+        if al:
+            d_ap, d_aln = lib.DeviceBuffer(8 * n, device=dev), lib.DeviceBuffer(4 * n, device=dev)
+            d_ap.upload(u64s(d_aad.ptr, al)); d_aln.upload(struct.pack("<%dI" % n, *([al] * n)))
+            skw = dict(d_aad_ptr=d_ap.ptr, d_aad_len=d_aln.ptr)
 
     def step():
+        if args.scattered:
+            return ctx.messages_crypt_dev(args.decrypt, n, d_ivs.ptr, (d_cp if args.decrypt else d_pp).ptr, d_ln.ptr, (d_pp if args.decrypt else d_cp).ptr, d_tags.ptr, **skw)
         ctx.packets_crypt_dev(args.decrypt, n, d_ivs.ptr, d_ct.ptr if args.decrypt else d_pt.ptr, d_pt.ptr if args.decrypt else d_ct.ptr, d_tags.ptr, pkt_len=size, **akw)
 
     if args.decrypt:
@@ -547,16 +560,17 @@ def run_msgs(args, dev, cpu_base):
     alg_bytes = n * (2 * size + 12 + 16 + al)
     achieved = alg_bytes / avg_s
     so_sha = sha256_file(SO)
-    pm = pmc_summary("rows_1m") if (n, size, key_bits, al) == (cfg["n_pkts"], cfg["pkt_len"], cfg["key_bits"], 0) and not args.decrypt else {}
+    pm = pmc_summary("rows_1m") if (n, size, key_bits, al) == (cfg["n_pkts"], cfg["pkt_len"], cfg["key_bits"], 0) and not args.decrypt and not args.scattered else {}
     same_build = bool(pm) and pm.get("so_sha256") == so_sha
     nr = key_bits // 32 + 6
     line = {
-        "metric": "GiB/s plaintext, AES-%d-GCM, %d messages of %d bytes%s under one key as the packets of one call, bit-exact tags" % (key_bits, n, size, " with %d bytes of AAD each" % al if al else ""),
+        "metric": "GiB/s plaintext, AES-%d-GCM, %d messages of %d bytes%s under one key as %s, bit-exact tags" % (key_bits, n, size, " with %d bytes of AAD each" % al if al else "",
+                                                                                                                   "one call over arrays of their addresses and lengths" if args.scattered else "the packets of one call"),
         "value": round(value, 3), "unit": "GiB/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": "msgs: %d x %d B AES-%d-GCM messages under ONE key (stream 0x4B4559), per-message IV (stream 0x4956), plaintext stream 0xAE5C0055, one "
                                "aesgcm_packets_crypt_dev call per step%s" % (n, size, key_bits, ", DECRYPT" if args.decrypt else ""),
-                   "messages": n, "message_bytes": size, "aad_bytes": al, "key_bits": key_bits, "shape": "rows" if shape == lib.SHAPE_ROWS else "%d lanes per packet" % shape, "parallelism": "single"},
+                   "messages": n, "message_bytes": size, "aad_bytes": al, "scattered": bool(args.scattered), "key_bits": key_bits, "shape": "rows" if shape == lib.SHAPE_ROWS else "%d lanes per packet" % shape, "parallelism": "single"},
         "tag_ok": tag_ok, "tags_checked": len(sample),
         "roofline": {"bound": "hbm", "kernel": ("k_rows<%d,%d> + k_rows_close (the rows of all messages through k_body's row loop; one call)" % (nr, int(args.decrypt))) if shape == lib.SHAPE_ROWS else "the packet kernels",
                      "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_BYTES_PER_S, 4),
@@ -815,6 +829,7 @@ def main(argv=None):
     ap.add_argument("--key-bits", type=int, default=None, choices=(128, 192, 256), help="override (no fixture check)")
     ap.add_argument("--n-pkts", type=int, default=None, help="cfg5 override: packets in all (no fixture check)")
     ap.add_argument("--pkt-len", type=int, default=None, help="cfg5 override: bytes per packet (no fixture check)")
+    ap.add_argument("--scattered", action="store_true", help="--config msgs: the same messages through aesgcm_messages_crypt_dev (device arrays of addresses and lengths: messages wherever they live)")
     ap.add_argument("--aad-len", type=int, default=0, help="--config msgs: bytes of AAD per message (a header: 13 for TLS-shaped records)")
     ap.add_argument("--decrypt", action="store_true", help="time decrypt + authenticate instead of encrypt (N = 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -381,8 +381,8 @@ def test_4096_messages_of_one_mib_by_checksum(hip, orc):
     assert bytes(d_ct.download(pkt, 1234 * pkt)) == bytes(d_pt.download(pkt, 1234 * pkt))
 
 
-@pytest.mark.parametrize("aad_len", [0, 13])
-def test_bench_line_of_the_messages_config(aad_len):
+@pytest.mark.parametrize("aad_len,scattered", [(0, False), (13, False), (13, True)])
+def test_bench_line_of_the_messages_config(aad_len, scattered):
     """bench.py --config msgs at a small size (and with a header per message: --aad-len): one JSON line, the call goes by rows, the tags and ciphertext of the
     sampled messages equal the single-message path's"""
     import json
@@ -391,8 +391,8 @@ def test_bench_line_of_the_messages_config(aad_len):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "msgs", "--n-pkts", "300", "--pkt-len", str(65536 + 1024 * 3 + 17), "--steps", "3", "--warmup", "1",
-                          "--aad-len", str(aad_len), "--no-cpu-baseline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+                          "--aad-len", str(aad_len), "--no-cpu-baseline"] + (["--scattered"] if scattered else []), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
-    assert line["tag_ok"] is True and line["config"]["shape"] == "rows" and line["unit"] == "GiB/s" and line["n_gpus"] == 1 and line["config"]["aad_bytes"] == aad_len
+    assert line["tag_ok"] is True and line["config"]["shape"] == "rows" and line["unit"] == "GiB/s" and line["n_gpus"] == 1 and line["config"]["aad_bytes"] == aad_len and line["config"]["scattered"] == scattered
     assert line["roofline"]["kernel"].startswith("k_rows<14,0>") and 0 < line["roofline"]["frac"] < 1
