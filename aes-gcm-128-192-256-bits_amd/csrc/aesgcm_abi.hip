@@ -93,7 +93,6 @@ int aesgcm_ctx_destroy(aesgcm_ctx *c) {
     if (c->d_trace) hipFree(c->d_trace);
     if (c->rows_buf) hipFree(c->rows_buf);
     pipeline_release(c);
-    for (auto &o : c->order) { if (o.perm) hipFree(o.perm); if (o.bins) hipFree(o.bins); if (o.done) hipEventDestroy(o.done); }
     if (c->st_in) hipFree(c->st_in);
     if (c->st_out) hipFree(c->st_out);
     if (c->st_aad) hipFree(c->st_aad);
@@ -134,7 +133,7 @@ int aesgcm_ctx_set_option(aesgcm_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "cyc_close")) c->cyc_fuse = v != 0;                          // 1: a whole message's cyclic launch closes the tag itself; 0: k_fold + k_combine behind it
     else if (!strcmp(key, "fold_close")) c->fold_close = v != 0;                       // 1: behind the dealt k_body the first (or second) k_fold level closes the tag
     else if (!strcmp(key, "cyc_prio")) c->cyc_prio = (u32)v;                           // rows between rotations of the waves' issue priorities in a cyclic launch (0 = off)
-    else if (!strcmp(key, "pkt_order")) c->order_min = (size_t)v;                      // packets from which a launch over packets of mixed length takes them by falling length class (k_len_*); 0 = never
+    else if (!strcmp(key, "pkt_order")) { }                                           // accepted and ignored since round 6: with offset arrays the packet kernels always take their messages by falling size class (the routing sort makes the order anyway)
     else if (!strcmp(key, "wipe_on_auth_fail")) c->wipe_on_auth_fail = v != 0;         // decrypt with verification: zero the output of a message / packet whose tag does not match
     else if (!strcmp(key, "rows_min")) c->rows_min = v;                                // bytes per packet from which aesgcm_packets_crypt_dev goes by rows (k_rows); 0 = never
     else if (!strcmp(key, "rows_block")) c->rows_block = (u32)v;                       // units (rows, tails) per dealt block of k_rows; 0 = the library's cut
@@ -153,8 +152,27 @@ int aesgcm_ctx_stream(const aesgcm_ctx *c, void **stream) {
 // has completed (one event record + one stream wait; no host synchronisation).  Two contexts of one key on one device
 // have separate scratch sets and streams, so consecutive messages can alternate between them and message m+1's fused
 // kernel starts while message m's k_fold / k_combine drain; this call orders the step that needs both (the all-gather).
+// the context's status word (pinned host memory, h_tag[2]: {code, 0, detail lo, detail hi}; written by k_rows_plan* when it refuses a call): as an error code, without clearing it
+static int status_pending(const aesgcm_ctx *c) {
+    const u32 code = __atomic_load_n(reinterpret_cast<const u32 *>(c->h_tag + 2), __ATOMIC_ACQUIRE);
+    if (code == AESGCM_STATUS_OK) return AESGCM_OK;
+    snprintf(g_err, sizeof g_err, "an asynchronous call on this context was refused on the device (status %u; aesgcm_ctx_status has the detail)", code);
+    return code == AESGCM_STATUS_PLAN ? AESGCM_ESTATE : AESGCM_ETOOLONG;
+}
+int aesgcm_ctx_status(aesgcm_ctx *c, int *code, uint64_t *detail) {
+    if (!c || !code) return AESGCM_EARG;
+    volatile u32 *w = reinterpret_cast<volatile u32 *>(c->h_tag + 2);
+    const u32 st = __atomic_load_n(reinterpret_cast<const u32 *>(c->h_tag + 2), __ATOMIC_ACQUIRE);
+    *code = (int)st;
+    if (detail) *detail = st ? ((u64)w[3] << 32) | w[2] : 0;
+    if (st) { w[2] = 0; w[3] = 0; __atomic_store_n(reinterpret_cast<u32 *>(c->h_tag + 2), 0u, __ATOMIC_RELEASE); }
+    return AESGCM_OK;
+}
+
 int aesgcm_ctx_wait(aesgcm_ctx *c, aesgcm_ctx *other) {
     if (!c || !other) return AESGCM_EARG;
+    { const int rc = status_pending(other); if (rc) return rc; }            // what `other` was asked to do and refused (aesgcm_ctx_status)
+    { const int rc = status_pending(c); if (rc) return rc; }
     if (c == other) return AESGCM_OK;
     if (c->device != other->device) return AESGCM_EARG;
     HIPCHK(hipSetDevice(c->device));
@@ -297,6 +315,7 @@ int aesgcm_last_tag(aesgcm_ctx *c, uint8_t tag[16], void *stream) {
     if (!c || !tag) return AESGCM_EARG;
     hipStream_t st = pick_stream(c, stream);
     HIPCHK(hipSetDevice(c->device));
+    { const int rc = status_pending(c); if (rc) return rc; }                // an asynchronous call on this context was refused on the device: say so rather than hand out a tag from before it
     return fetch_tag(c, st, tag);
 }
 
@@ -574,6 +593,7 @@ int aesgcm_messages_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_msgs, const v
     if (!c) return AESGCM_EARG;
     if (!n_msgs) return AESGCM_OK;
     if (!d_ivs || !d_tags || !d_in_ptr || !d_len || !d_out_ptr || ((d_aad_ptr != nullptr) != (d_aad_len != nullptr))) return AESGCM_EARG;
+    if (decrypt && c->wipe_on_auth_fail && d_expect_tags && !d_auth) return AESGCM_EARG;      // "no unauthenticated plaintext" needs the per-message verdicts: without d_auth nothing would be compared, nothing wiped
     if (n_msgs >= (((size_t)1) << 31)) return AESGCM_ETOOLONG;
     HIPCHK(hipSetDevice(c->device));
     RowsParams r;
@@ -581,7 +601,13 @@ int aesgcm_messages_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_msgs, const v
     r.ivs = (const unsigned char *)d_ivs; r.tags = (unsigned char *)d_tags; r.expect = (const unsigned char *)d_expect_tags; r.auth = d_auth;
     r.in_ptr = (const u64 *)d_in_ptr; r.out_ptr = (const u64 *)d_out_ptr; r.aad_ptr = (const u64 *)d_aad_ptr; r.len_arr = d_len; r.alen_arr = d_aad_len;
     r.n_pkts = (u32)n_msgs;
-    const int rc = packets_rows(c, decrypt, r, pick_stream(c, stream));
+    // routed per message (round 6): the short ones are the packet kernels', which read the same arrays
+    PktParams k;
+    memset(&k, 0, sizeof k);
+    k.ivs = r.ivs; k.tags = r.tags; k.expect = r.expect; k.auth = d_auth;
+    k.in_ptr = r.in_ptr; k.out_ptr = r.out_ptr; k.aad_ptr = r.aad_ptr; k.len_arr = d_len; k.alen_arr = d_aad_len;
+    k.aligned = 1;                                                                      // per message: its two addresses decide (pkt_info)
+    const int rc = packets_rows(c, decrypt, r, pick_stream(c, stream), &k);
     if (!rc && decrypt && c->wipe_on_auth_fail && d_expect_tags) return wipe_failed(c->device, n_msgs, nullptr, 0, nullptr, d_auth, pick_stream(c, stream), (const u64 *)d_out_ptr, d_len);
     return rc;
 }
@@ -594,19 +620,9 @@ int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const vo
     if (!c) return AESGCM_EARG;
     if (!n_pkts) return AESGCM_OK;
     if (!d_ivs || !d_tags || ((aad_len || d_aad_off) && !d_aad) || ((pkt_len || d_data_off) && (!d_in || !d_out))) return AESGCM_EARG;
+    if (decrypt && c->wipe_on_auth_fail && d_expect_tags && !d_auth) return AESGCM_EARG;      // "no unauthenticated plaintext" needs the per-packet verdicts: without d_auth nothing would be compared, nothing wiped
     if (n_pkts >= (((size_t)1) << 31) || pkt_len >= (((size_t)1) << 28) || aad_len >= (((size_t)1) << 28)) return AESGCM_ETOOLONG;
     HIPCHK(hipSetDevice(c->device));
-    if (packets_by_rows(c, n_pkts, pkt_len, d_data_off != nullptr)) {                    // message-sized packets: the rows of all of them through k_body's row loop
-        RowsParams r;
-        memset(&r, 0, sizeof r);
-        r.ivs = (const unsigned char *)d_ivs; r.aad = (const unsigned char *)d_aad; r.in = (const unsigned char *)d_in;
-        r.out = (unsigned char *)d_out; r.tags = (unsigned char *)d_tags; r.expect = (const unsigned char *)d_expect_tags; r.auth = d_auth;
-        r.data_off = (const u64 *)d_data_off; r.aad_off = (const u64 *)d_aad_off;
-        r.n_pkts = (u32)n_pkts; r.pkt_len = (u32)pkt_len; r.aad_len = (u32)aad_len;
-        const int rc = packets_rows(c, decrypt, r, pick_stream(c, stream));
-        if (!rc && decrypt && c->wipe_on_auth_fail && d_expect_tags) return wipe_failed(c->device, n_pkts, d_out, pkt_len, (const u64 *)d_data_off, d_auth, pick_stream(c, stream));
-        return rc;
-    }
     PktParams p;
     memset(&p, 0, sizeof p);
     p.ivs = (const unsigned char *)d_ivs; p.aad = (const unsigned char *)d_aad; p.in = (const unsigned char *)d_in;
@@ -614,8 +630,23 @@ int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const vo
     p.data_off = (const u64 *)d_data_off; p.aad_off = (const u64 *)d_aad_off;
     p.n_pkts = (u32)n_pkts; p.pkt_len = (u32)pkt_len; p.aad_len = (u32)aad_len;
     p.aligned = (((uintptr_t)d_in | (uintptr_t)d_out) & 15) == 0 && (d_data_off || pkt_len % 16 == 0);
+    // Offset arrays: the lengths are on the device, and so is the choice (round 6) -- every message is ROUTED by its own size, the long ones by rows, the short ones
+    // through the packet kernels, in one call (the reference's own traffic is both at once: tb/gcm_gctr.py:279-281 draws lengths from a U-shaped distribution).
+    // pkt_len is ignored in this form.  Fixed-size records: the host knows the one size and routes the whole call (packets_by_rows).
+    const bool routed = d_data_off != nullptr;
+    if (routed || packets_by_rows(c, n_pkts, pkt_len)) {                          // message-sized packets: the rows of all of them through k_body's row loop
+        RowsParams r;
+        memset(&r, 0, sizeof r);
+        r.ivs = (const unsigned char *)d_ivs; r.aad = (const unsigned char *)d_aad; r.in = (const unsigned char *)d_in;
+        r.out = (unsigned char *)d_out; r.tags = (unsigned char *)d_tags; r.expect = (const unsigned char *)d_expect_tags; r.auth = d_auth;
+        r.data_off = (const u64 *)d_data_off; r.aad_off = (const u64 *)d_aad_off;
+        r.n_pkts = (u32)n_pkts; r.pkt_len = routed ? 0u : (u32)pkt_len; r.aad_len = (u32)aad_len;
+        const int rc = packets_rows(c, decrypt, r, pick_stream(c, stream), routed ? &p : nullptr);
+        if (!rc && decrypt && c->wipe_on_auth_fail && d_expect_tags) return wipe_failed(c->device, n_pkts, d_out, pkt_len, (const u64 *)d_data_off, d_auth, pick_stream(c, stream));
+        return rc;
+    }
     const u32 n_cu = (u32)c->G / 2;                                                 // c->G = two workgroups per CU
-    int lg = packets_pick_lg(n_cu, n_pkts, pkt_len, d_data_off != nullptr, packets_ordered(c, n_pkts, d_data_off != nullptr));
+    int lg = packets_pick_lg(n_cu, n_pkts, pkt_len);                       // (fixed-size records from here on: offset arrays took the routed path above)
 #ifdef AESGCM_DEBUG_KNOBS
     if (g_force.pkt_lanes) lg = g_force.pkt_lanes == 1 ? 0 : g_force.pkt_lanes == 64 ? 6 : g_force.pkt_lanes == 16 ? 4 : g_force.pkt_lanes == 8 ? 3 : 2;
 #endif
@@ -623,8 +654,6 @@ int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const vo
     hipError_t launch_err = hipSuccess;
     hipStream_t st = pick_stream(c, stream);
     p.counter = c->d_counter; p.counter_base = c->counter_base;
-    OrderSlot *oslot = nullptr;
-    if (d_data_off) { const int rc = packets_order(c, (const u64 *)d_data_off, n_pkts, st, &p.perm, &oslot); if (rc) return rc; }
     if (shape == 'l') {
         const u32 nb = (u32)((n_pkts + 63) / 64);
         // the ILP form (512-lane workgroups, eight independent keystream chains per line) while the packets fit one round of it; its workgroups are spread over
@@ -633,8 +662,8 @@ int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const vo
         // 256 B 32768 99 / 95, 98304 245 / 266, 131072 295 / 330; 64 B (no whole line to work on) 16384 27 / 19.
         // Packets shorter than two lines gain from it only once they fill the chip (fewer, fatter waves): 196608 x 256 B 380 / 414, 262144 442 / 460 (2^20: 682 / 642);
         // 64 B 196608 127 / 146, 393216 183 / 201, 2^20 254 / 266.
-        bool ilp = n_pkts <= (size_t)n_cu * AESGCM_PKTL_WG_ILP ? (d_data_off || pkt_len >= 512 || (pkt_len >= 256 && n_pkts >= 49152))
-                                                                : (!d_data_off && n_pkts >= (size_t)n_cu * AESGCM_PKTL_WG && (pkt_len <= 64 || (pkt_len <= 256 && n_pkts <= 300000)));
+        bool ilp = n_pkts <= (size_t)n_cu * AESGCM_PKTL_WG_ILP ? (pkt_len >= 512 || (pkt_len >= 256 && n_pkts >= 49152))
+                                                                : (n_pkts >= (size_t)n_cu * AESGCM_PKTL_WG && (pkt_len <= 64 || (pkt_len <= 256 && n_pkts <= 300000)));
 #ifdef AESGCM_DEBUG_KNOBS
         if (g_force.pkt_ilp) ilp = g_force.pkt_ilp == 1;
 #endif
@@ -645,7 +674,7 @@ int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const vo
         launch_err = klaunch_pktl(c->nr, decrypt, ilp, wgs, st, c->km, c->tables, p);
     } else {
         const u32 P = 64u >> lg;                                                    // packets per wave-iteration
-        p.plain = (lg == 6 || lg == 2) && !d_data_off && !d_aad_off && !aad_len && p.aligned && pkt_len && pkt_len % ((size_t)16 << lg) == 0;
+        p.plain = (lg == 6 || lg == 2) && !d_aad_off && !aad_len && p.aligned && pkt_len && pkt_len % ((size_t)16 << lg) == 0;
         const u32 waves_per_wg = (u32)PKTG_WG(lg) / 64;
         // deal: about 4 dispenser fetches per resident wave, a multiple of P, at most 64 packets (one E_K(J0) pass per fetch)
         u32 deal = (u32)(n_pkts / ((size_t)n_cu * waves_per_wg * 4));
@@ -663,8 +692,7 @@ int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const vo
     }
     const hipError_t le = launch_err;
     if (le != hipSuccess) { c->counter_base = p.counter_base; return hip_fail(le, "k_pkt launch"); }
-    if (oslot && p.perm) HIPCHK(hipEventRecord(oslot->done, st));
-    if (decrypt && c->wipe_on_auth_fail && d_expect_tags) return wipe_failed(c->device, n_pkts, d_out, pkt_len, (const u64 *)d_data_off, d_auth, st);
+    if (decrypt && c->wipe_on_auth_fail && d_expect_tags) return wipe_failed(c->device, n_pkts, d_out, pkt_len, nullptr, d_auth, st);
     return AESGCM_OK;
 }
 
@@ -733,8 +761,9 @@ int aesgcm_batch_shape(int device, size_t n_pkts, size_t pkt_len, int var_len, i
 
 int aesgcm_packets_shape(const aesgcm_ctx *c, size_t n_pkts, size_t pkt_len, int var_len, int *lanes_per_packet) {
     if (!c || !lanes_per_packet || !n_pkts) return AESGCM_EARG;
-    if (packets_by_rows(c, n_pkts, pkt_len, var_len != 0)) { *lanes_per_packet = AESGCM_SHAPE_ROWS; return AESGCM_OK; }
-    int lg = packets_pick_lg((u32)c->G / 2, n_pkts, pkt_len, var_len != 0, packets_ordered(c, n_pkts, var_len != 0));
+    if (var_len) { *lanes_per_packet = AESGCM_SHAPE_MIXED; return AESGCM_OK; }         // the lengths are on the device: every message is routed there, by rows or to the packet kernels
+    if (packets_by_rows(c, n_pkts, pkt_len)) { *lanes_per_packet = AESGCM_SHAPE_ROWS; return AESGCM_OK; }
+    int lg = packets_pick_lg((u32)c->G / 2, n_pkts, pkt_len);
 #ifdef AESGCM_DEBUG_KNOBS
     if (g_force.pkt_lanes) lg = g_force.pkt_lanes == 1 ? 0 : g_force.pkt_lanes == 64 ? 6 : g_force.pkt_lanes == 16 ? 4 : g_force.pkt_lanes == 8 ? 3 : 2;
 #endif

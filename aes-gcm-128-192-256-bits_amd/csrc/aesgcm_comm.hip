@@ -225,12 +225,15 @@ int aesgcm_mgpu_ctx(aesgcm_mgpu *m, int g, aesgcm_ctx **out) {
     return AESGCM_OK;
 }
 
-// the tags of the last n queued messages (oldest of them first), finalized in one launch per contiguous run of ring rows (aesgcm_shard_finalize_batch_dev) on device 0
+// the tags of the OLDEST n queued messages, in the order they were queued, finalized in one launch per contiguous run of ring rows (aesgcm_shard_finalize_batch_dev) on
+// device 0.  The queue is a FIFO: the window starts at the oldest message still waiting (seq - pending) and what is collected leaves from that end, so a partial
+// collect -- pending 5, last_tags(2), then last_tags(3) -- returns messages {0, 1} and then {2, 3, 4}, and the `pending >= MGPU_RING` gate of aesgcm_mgpu_crypt_dev
+// protects exactly the ring rows that have not been read.  (Round 5 took the NEWEST n and still counted the oldest as collected: the advisor's finding.)
 int aesgcm_mgpu_last_tags(aesgcm_mgpu *m, size_t n, uint8_t *tags) {
     if (!m || !tags || n > (size_t)m->pending) return AESGCM_EARG;
     if (!n) return AESGCM_OK;
     HCHK(hipSetDevice(m->dev[0]));
-    const unsigned long long first = m->seq - n;
+    const unsigned long long first = m->seq - (unsigned long long)m->pending;
     size_t done = 0;
     while (done < n) {
         const size_t slot = (size_t)((first + done) % MGPU_RING);
@@ -253,6 +256,8 @@ int aesgcm_mgpu_last_tags(aesgcm_mgpu *m, size_t n, uint8_t *tags) {
 int aesgcm_mgpu_crypt_dev(aesgcm_mgpu *m, int decrypt, const uint8_t iv[12], const void *d_aad_on_dev0, size_t aad_len,
                           const void *const *d_in, const size_t *shard_len, void *const *d_out, uint8_t tag[16]) {
     if (!m || !iv || !d_in || !shard_len || !d_out || (aad_len && !d_aad_on_dev0)) return AESGCM_EARG;
+    // a call that wants its tag back while older messages still wait for aesgcm_mgpu_last_tags would have to jump the queue: refused before anything is enqueued
+    if (tag && m->pending > 0) { snprintf(g_cerr, sizeof g_cerr, "%d messages queued with tag = NULL: collect their tags (aesgcm_mgpu_last_tags) before a call that returns its own", m->pending); return AESGCM_ESTATE; }
     if (m->pending >= MGPU_RING) { snprintf(g_cerr, sizeof g_cerr, "%d messages queued: collect their tags first (aesgcm_mgpu_last_tags)", m->pending); return AESGCM_ESTATE; }
     uint64_t total = 0;
     for (int g = 0; g < m->ndev; g++) {

@@ -558,24 +558,21 @@ extern "C" __attribute__((visibility("default"))) int aesgcm_debug_force_shape(c
 // 362 / 172 / 95 / 49 / 13 (the one regime where a whole wave per packet is right: at most 4096 packets of at least 4 KiB) -- but never more lanes than an
 // eighth of the packet's blocks once the machine is full (closing cost per byte: 16384 x 1 KiB 62 / 128 / 176 / 138 / 50, 16384 x 256 B 16 / 35 / 58 / 72 / 41),
 // a quarter when it is not (4096 x 1 KiB 34 / 69 / 57 / 38 / 13).  Lanes win from 131072 packets (2^20 x 1 KiB 303 / 592 / 657 / 742 / 767; 262144 x 4 KiB
-// 496 / 656 / 704 / 722 / 724), short packets from 32768 (65536 x 256 B 51 / 61 / 95 / 129 / 148).  With offset arrays the host does not know the lengths: it
-// goes by count and assumes 1 KiB.
-int packets_pick_lg(u32 n_cu, size_t n_pkts, size_t pkt_len, bool var, bool ordered) {
+// 496 / 656 / 704 / 722 / 724), short packets from 32768 (65536 x 256 B 51 / 61 / 95 / 129 / 148).
+int packets_pick_lg(u32 n_cu, size_t n_pkts, size_t pkt_len) {
     const size_t lanes_total = (size_t)n_cu * (AESGCM_PKT_WG / 64) * 64, lanes_l = (size_t)n_cu * AESGCM_PKTL_WG;
-    const size_t blocks = var ? 64 : (pkt_len + 15) / 16;
+    const size_t blocks = (pkt_len + 15) / 16;
     // One lane per packet once the packets fill k_pktl's resident lanes (256 x 768); frames of up to 1 KiB from three quarters of that, short ones much earlier.
     // Round 4 (profiles/r04/packets_sweep_aes256.txt, after k_pktl's rebuild): 131072 x 4 KiB 553 by lanes against 722 by groups of 4 (196608: 795 / 713),
     // 131072 x 16 KiB 573 / 789, 131072 x 1 KiB 488 / 509 (196608: 677 / 577), 49152 x 256 B 142 / 124, 16384 x 64 B 28 / 23.
-    // Offset arrays (the host does not know the lengths): as 1 KiB frames in array order (mixed 64 .. 1514 bytes: 131072 frames 243 by lanes / 277 by groups of
-    // 4, 196608: 346 / 296); taken by length class the groups hold on longer (196608: 323 / 394, 262144: 421 / 429, 393216: 584 / 505).
+    // (Offset arrays -- the host does not know the lengths -- are routed on the device since round 6: route_pick_lg, aesgcm_pkt.h, with the measurements behind it.)
     // k_pktl's ILP form (512-lane workgroups) moves the 1 KiB mark down: 131072 x 1 KiB 592 by lanes against 500 by groups of 4, 98304: 454 / 456.
     const size_t lanes_ilp = (size_t)n_cu * AESGCM_PKTL_WG_ILP;
-    if (var ? (ordered ? 3 * n_pkts >= 4 * lanes_l : 4 * n_pkts >= 3 * lanes_l)
-            : (n_pkts >= lanes_l || (pkt_len <= 1024 && 8 * n_pkts >= 7 * lanes_ilp) || (pkt_len <= 256 && n_pkts >= 32768) || (pkt_len <= 64 && n_pkts >= 16384))) return 0;
+    if (n_pkts >= lanes_l || (pkt_len <= 1024 && 8 * n_pkts >= 7 * lanes_ilp) || (pkt_len <= 256 && n_pkts >= 32768) || (pkt_len <= 64 && n_pkts >= 16384)) return 0;
     // Lane groups: the group that just fills the resident lanes.  Packets of 4 KiB and more round the fill UP to a power of two (half again as many lanes as
     // are resident is cheaper than rows twice as long: 49152 x 4 KiB 474 with 4 lanes, 576 with 8; x 16 KiB 542 / 722), shorter ones down (49152 x 1 KiB 325 / 291).
     size_t fill = lanes_total / n_pkts;
-    if (!var && pkt_len >= 4096 && (fill & (fill - 1))) { size_t f = 1; while (f < fill) f <<= 1; fill = f; }
+    if (pkt_len >= 4096 && (fill & (fill - 1))) { size_t f = 1; while (f < fill) f <<= 1; fill = f; }
     const size_t cap = n_pkts >= 16384 ? blocks / 8 : blocks / 4;
     const size_t g = fill < cap ? fill : cap;
     return g >= 64 ? 6 : g >= 16 ? 4 : g >= 8 ? 3 : 2;
@@ -602,8 +599,6 @@ int batch_pick_lg(int n_cu, size_t n_pkts, size_t pkt_len, bool var) {
 // k_len_scatter).  *perm = NULL when it does not pay or is switched off.  Three launches of about 10 us in front of the packet kernel: mixed frames of
 // 64 .. 1514 bytes, AES-256, best shape each (profiles/r04/packets_sweep_mixed_*.txt): 16384 frames 101 GiB/s in array order, 79 by class; 65536 223 / 199; 98304
 // 256 / 271; 131072 284 / 320; 262144 382 / 429; 2^20 426 / 717 -- the order pays once the machine is full, and the default threshold is there.
-bool packets_ordered(const aesgcm_ctx *c, size_t n_pkts, bool var) { return var && c->order_min && n_pkts >= c->order_min; }
-
 int order_launch(OrderSlot &o, const u64 *d_off, size_t n_pkts, hipStream_t st, const u32 **perm) {
     if (!o.done) HIPCHK(hipEventCreateWithFlags(&o.done, hipEventDisableTiming));
     else HIPCHK(hipStreamWaitEvent(st, o.done, 0));                                // the slot's previous reader, on whatever stream it ran
@@ -614,22 +609,17 @@ int order_launch(OrderSlot &o, const u64 *d_off, size_t n_pkts, hipStream_t st, 
         if (hipMalloc((void **)&o.perm, n_pkts * sizeof(u32)) != hipSuccess) { o.perm = nullptr; (void)hipGetLastError(); *perm = nullptr; return AESGCM_OK; }
         o.cap = n_pkts;
     }
-    HIPCHK(klaunch_len_sort(st, d_off, (u32)n_pkts, o.bins, o.perm));
+    LenSrc src = {d_off, nullptr, nullptr, nullptr, 0u};                            // by data length (a batch packet's AAD is short)
+    RouteCfg none = {nullptr, (u32)n_pkts, 0u, 0u, 0u, 0u, 0xFFu, 0u};             // a plain order: nothing is routed
+    HIPCHK(klaunch_len_sort(st, src, (u32)n_pkts, o.bins, o.perm, none));
     *perm = o.perm;
     return AESGCM_OK;
-}
-
-int packets_order(aesgcm_ctx *c, const u64 *d_off, size_t n_pkts, hipStream_t st, const u32 **perm, OrderSlot **slot) {
-    *perm = nullptr; *slot = nullptr;
-    if (!packets_ordered(c, n_pkts, true)) return AESGCM_OK;
-    *slot = &c->order[c->order_next++ & 3u];
-    return order_launch(**slot, d_off, n_pkts, st, perm);
 }
 
 
 // ---------------------------------------------------------------- many messages under the context's key: by rows (aesgcm_rows.h)
 // the scratch of the path, carved out of one allocation: per message 16 + 4 bytes and (offset arrays) the three prefix sums, 32 bytes per record slot.  Zero at rest.
-struct RowsScratch { RowsHdr *hdr; u32 *queues; u64 *prefix, *sprefix, *plan_part; u32 *slot_base; RowsRec *rec; unsigned long long *acc; u32 *cnt; };
+struct RowsScratch { RowsHdr *hdr; u32 *queues; u64 *prefix, *sprefix, *plan_part; u32 *slot_base; RowsRec *rec; unsigned long long *acc; u32 *cnt; u32 *perm, *bins; };
 
 size_t rows_carve(unsigned char *base, size_t slots, size_t n, RowsScratch *r) {
     size_t o = 0;
@@ -639,11 +629,13 @@ size_t rows_carve(unsigned char *base, size_t slots, size_t n, RowsScratch *r) {
     t.queues = (u32 *)take(64 * ROWS_NQ);
     t.prefix = (u64 *)take(8 * (n + 1));
     t.sprefix = (u64 *)take(8 * (n + 1));
-    t.plan_part = (u64 *)take(8 * 3 * (n / 1024 + 2));                   // the planner's sums per workgroup of 1024 messages
+    t.plan_part = (u64 *)take(8 * 4 * (n / 1024 + 2));                   // the planner's sums per workgroup of 1024 messages (units, smalls, slots, first refused length)
     t.slot_base = (u32 *)take(4 * (n + 1));
     t.rec = (RowsRec *)take(sizeof(RowsRec) * slots);
     t.acc = (unsigned long long *)take(16 * n);
     t.cnt = (u32 *)take(4 * n);
+    t.perm = (u32 *)take(4 * n);                                         // a routed call: the launch order of the messages that take the packet kernels (k_len_*)
+    t.bins = (u32 *)take(4 * (size_t)LEN_SORT_ENTRIES);
     if (r) *r = t;
     return o;
 }
@@ -662,13 +654,28 @@ int rows_scratch(aesgcm_ctx *c, size_t slots, size_t n, hipStream_t st, RowsScra
     return AESGCM_OK;
 }
 
-// p: the caller's pointers, counts and lengths; the cut and the scratch are filled in here
-int packets_rows(aesgcm_ctx *c, int decrypt, RowsParams &p, hipStream_t st) {
+// The marks of a ROUTED call as length classes (64 bytes each) for k_len_scan: the context's "rows_min" (8 KiB) while more than 16384 messages lie below it, a
+// quarter of it otherwise -- the rule packets_by_rows applies to fixed-size records, evaluated per message on the device.  The classes resolve up to 16320 bytes.
+static void route_marks(const aesgcm_ctx *c, u32 *c_hi, u32 *c_lo) {
+    const u64 hi = c->rows_min / 64, lo = c->rows_min / 4 / 64;
+    *c_hi = c->rows_min ? (u32)(hi < PKT_LEN_CLASSES ? hi : PKT_LEN_CLASSES - 1u) : PKT_LEN_CLASSES;      // rows_min = 0: never by rows
+    *c_lo = c->rows_min ? (u32)(lo < PKT_LEN_CLASSES ? lo : PKT_LEN_CLASSES - 1u) : PKT_LEN_CLASSES;
+#ifdef AESGCM_DEBUG_KNOBS
+    if (g_force.pkt_rows == 1) *c_hi = *c_lo = 0;                                          // everything by rows
+    else if (g_force.pkt_rows == 2 || g_force.pkt_lanes) *c_hi = *c_lo = PKT_LEN_CLASSES;  // everything through the packet kernels (a forced shape of theirs means them)
+#endif
+}
+
+// p: the caller's pointers, counts and lengths; the cut and the scratch are filled in here.  k != NULL: the call is ROUTED per message (round 6; the lengths are on the
+// device): *k describes the same call for the packet kernels, which take the messages below the mark k_len_scan chooses; the row launches see those as nothing.
+int packets_rows(aesgcm_ctx *c, int decrypt, RowsParams &p, hipStream_t st, PktParams *k) {
     const size_t n = p.n_pkts;
     RowsScratch r;
     int rc;
     const bool var = p.data_off != nullptr || p.aad_off != nullptr || p.len_arr != nullptr;          // a length of any kind on the device: the plan is made there
+    if (k && !var) return AESGCM_EARG;
     u32 wgs = (u32)c->G / 2;                                                 // one 141 KiB workgroup per CU
+    const u32 n_cu = wgs;
     size_t slots;
     if (!var) {
         const RowsGeom g = rows_geom(p.pkt_len);
@@ -693,24 +700,60 @@ int packets_rows(aesgcm_ctx *c, int decrypt, RowsParams &p, hipStream_t st) {
     c->rows_dirty = true;                                                    // until both launches are enqueued
     if (var) {
         p.hdr = r.hdr; p.prefix = r.prefix; p.sprefix = r.sprefix; p.slot_base = r.slot_base;
-        HIPCHK(klaunch_rows_plan(st, p.data_off, p.pkt_len, p.aad_off, p.aad_len, p.len_arr, p.alen_arr, p.n_pkts, p.waves, c->rows_block, (u32)ROWS_NB_CAP, p.slot_cap, r.hdr, r.prefix, r.sprefix, r.slot_base, r.plan_part));
+        p.routed = k ? 1u : 0u;
+        if (k) {
+            // the route: a counting sort of the messages by falling size class (data + AAD) whose scan also decides -- which messages go by rows, how many are the packet
+            // kernels', and in which shape (aesgcm_rows.h RowsHdr)
+            LenSrc src = {p.data_off, p.aad_off, p.len_arr, p.alen_arr, p.aad_len};
+            RouteCfg cfg = {r.hdr, (u32)n, n_cu, 0u, 0u, 16384u, 0xFFu, 0u};
+            route_marks(c, &cfg.c_hi, &cfg.c_lo);
+#ifdef AESGCM_DEBUG_KNOBS
+            if (g_force.pkt_lanes) cfg.force_lg = g_force.pkt_lanes == 1 ? 0u : g_force.pkt_lanes == 64 ? 6u : g_force.pkt_lanes == 16 ? 4u : g_force.pkt_lanes == 8 ? 3u : 2u;
+            if (g_force.pkt_deal >= 1 && g_force.pkt_deal <= (int)PKTG_MAX_DEAL) cfg.force_deal = (u32)g_force.pkt_deal;
+#endif
+            HIPCHK(klaunch_len_sort(st, src, (u32)n, r.bins, r.perm, cfg));
+            k->perm = r.perm; k->route = r.hdr; k->counter = &r.hdr->pkt_counter; k->counter_base = 0; k->plain = 0;
+            k->n_pkts = (u32)n;
+            // (the plan below may refuse the call -- a length of 2^28 bytes or more --: then the packet kernels return at once as well)
+            HIPCHK(klaunch_rows_plan(st, p, c->rows_block, (u32)ROWS_NB_CAP, r.plan_part, reinterpret_cast<u32 *>(c->h_tag_dev + 2)));
+            // every shape the count of small messages -- anything up to n -- could ask for; all but the one k_len_scan named return before they stage a table
+            const u32 lg_min = cfg.force_lg != 0xFFu ? cfg.force_lg : route_pick_lg(n_cu, n), lg_max = cfg.force_lg != 0xFFu ? cfg.force_lg : 4u;
+            static const u32 shapes[] = {0u, 2u, 3u, 4u, 6u};
+            for (u32 lg : shapes) {
+                if (lg < lg_min || lg > lg_max || cfg.c_hi == 0u) continue;                  // (c_hi = 0: everything by rows, forced)
+                if (lg == 0u) {
+                    const u32 waves_per_wg = AESGCM_PKTL_WG / 64, nb = (u32)((n + 63) / 64);
+                    u32 w = (nb + waves_per_wg - 1) / waves_per_wg;
+                    if (w > n_cu) w = n_cu;
+                    HIPCHK(klaunch_pktl(c->nr, decrypt, false, w, st, c->km, c->tables, *k));
+                } else {
+                    const u32 P = 64u >> lg, waves_per_wg = (u32)PKTG_WG(lg) / 64, nb = (u32)((n + P - 1) / P);
+                    u32 w = (nb + waves_per_wg - 1) / waves_per_wg;
+                    if (w > n_cu) w = n_cu;
+                    HIPCHK(klaunch_pktg(c->nr, decrypt, (int)lg, w, st, c->km, c->tables, *k));
+                }
+            }
+        } else {
+            HIPCHK(klaunch_rows_plan(st, p, c->rows_block, (u32)ROWS_NB_CAP, r.plan_part, reinterpret_cast<u32 *>(c->h_tag_dev + 2)));
+        }
     }
     p.prio_rows = c->cyc_prio;
     if (wgs) HIPCHK(klaunch_rows(c->nr, decrypt, wgs, st, c->km, c->tables, p));                          // (fixed-size records of no bytes and no AAD have no units: their tags are the closing's alone)
-    const size_t close_lanes = p.slot_cap > n ? p.slot_cap : n;                                              // a lane per record slot and per message (the smalls blocks are walked by whatever lanes there are)
+    size_t close_lanes = p.slot_cap > n ? p.slot_cap : n;                                                    // a lane per record slot and per message; the lanes stride, so the grid is capped (and with offset arrays most slots of the worst case are never given out)
+    if (close_lanes > (size_t)4096 * ROWS_CLOSE_WG) close_lanes = (size_t)4096 * ROWS_CLOSE_WG;
     HIPCHK(klaunch_rows_close(decrypt, (unsigned)((close_lanes + ROWS_CLOSE_WG - 1) / ROWS_CLOSE_WG), st, c->km, c->tables, p));
     c->rows_dirty = false;
     return AESGCM_OK;
 }
 
-// does a call go by rows?  From rows_min bytes per packet (8 KiB), and from a quarter of that while the packets are few: the packet kernels need a packet per lane
+// Does a call of FIXED-SIZE records go by rows?  (With offset arrays every message is routed by its own size on the device: k_len_scan applies the same two marks per
+// message, aesgcm_rows.h.)  From rows_min bytes per packet (8 KiB), and from a quarter of that while the packets are few: the packet kernels need a packet per lane
 // (or per lane group) to fill the chip, the rows of a call fill it whatever the count.  Measured on one box with the smalls in the closing launch, AES-256,
 // GiB/s by rows / by the packet kernels (profiles/r05/rows_min_sweep2.txt, rows_min_sweep3.txt): 32 KiB x 131072 885 / 721, + 16 bytes 870 / 666; 16 KiB x 262144
 // 845 / 792, + 16 827 / 749, x 16384 634 / 563, x 4096 571 / 400; 8 KiB x 524288 770 / 727, + 16 746 / 695, x 32768 596 / 545, x 4096 464 / 254, x 1024 189 / 129;
 // 6 KiB x 699050 709 / 802, x 65536 613 / 613, x 8192 501 / 282; 4 KiB x 2^20 620 / 810, x 131072 557 / 667, x 32768 495 / 485, x 16384 502 / 384, x 4096 339 / 151;
 // 2 KiB x 2^20 429 / 804, x 16384 352 / 242, x 4096 206 / 115; 1 KiB x 262144 264 / 616, x 4096 116 / 83.
-// Offset arrays: the host does not know the lengths; the caller's pkt_len, otherwise unused in that form, is its word for the typical packet (0 = frames)
-bool packets_by_rows(const aesgcm_ctx *c, size_t n_pkts, size_t pkt_len, bool var_len) {
+bool packets_by_rows(const aesgcm_ctx *c, size_t n_pkts, size_t pkt_len) {
 #ifdef AESGCM_DEBUG_KNOBS
     if (g_force.pkt_rows) return g_force.pkt_rows == 1;
     if (g_force.pkt_lanes) return false;                                     // a forced shape of the packet kernels means the packet kernels
@@ -721,8 +764,8 @@ bool packets_by_rows(const aesgcm_ctx *c, size_t n_pkts, size_t pkt_len, bool va
     // many packets of 8 .. 16 KiB whose last, partial row has more than a few blocks: what is not a whole row costs a message about a row and a half either way (a
     // pass of a wave in the row launch, or a lane per block of the closing launch), and the lane-per-packet kernel keeps them -- 262 144 x 9000 bytes (8 rows + 51
     // blocks) 613 by rows, 768 there; x 8448 (8 rows + 16 blocks) 696 / 821; from 16 KiB rows win again: 131 072 x 16 656 744 / 682
-    // (profiles/r05/rows_ragged_many.txt).  Fixed-size records only: with offset arrays the host does not see the lengths
-    if (!var_len && pkt_len < 2 * c->rows_min && rows_geom(pkt_len).tb > ROWS_FEW_TAIL) return false;
+    // (profiles/r05/rows_ragged_many.txt)
+    if (pkt_len < 2 * c->rows_min && rows_geom(pkt_len).tb > ROWS_FEW_TAIL) return false;
     return true;
 }
 

@@ -44,9 +44,6 @@
 #endif
 #define PKTG_WAVE_SLOT 1280u                                                                                /* per wave: 64 E_K(J0) values and the 64 packet numbers of its dispenser block */
 #define PKTG_LDS_TOTAL(LG) (PKTG_LDS_BYTES(LG) + ((LG) <= 4 ? (u32)(PKTG_WG(LG) / 64) * PKTG_WAVE_SLOT : 0u))
-#ifndef AESGCM_PKTL_WG
-#define AESGCM_PKTL_WG 768            // lanes per k_pktl workgroup: 3 waves per SIMD = 168 registers, what eight held blocks beside the table multiply need
-#endif
 #define AESGCM_PKTL_LDS (AESGCM_PKTL_T4 ? AESGCM_LDS_BYTES_T4 : AESGCM_LDS_BYTES)
 #ifndef AESGCM_PKTL_WAVES
 #define AESGCM_PKTL_WAVES ((AESGCM_PKTL_WG + 255) / 256)          // waves per SIMD the register budget is sized for (one workgroup per CU)
@@ -72,8 +69,8 @@ hipError_t klaunch_combine_batch(unsigned n, hipStream_t st, const KeyMaterial *
 hipError_t klaunch_pktl(int nr, int dec, bool ilp, unsigned wgs, hipStream_t st, const KeyMaterial *km, const DevTables *tb, const PktParams &p);
 hipError_t klaunch_pktg(int nr, int dec, int lg, unsigned wgs, hipStream_t st, const KeyMaterial *km, const DevTables *tb, const PktParams &p);
 hipError_t klaunch_batch3(int nr, int dec, int lg, unsigned wgs, hipStream_t st, const DevTables *tb, const BatchParams &p);
-hipError_t klaunch_len_sort(hipStream_t st, const u64 *d_off, u32 n, u32 *bins, u32 *perm);                                                  // k_len_hist, k_len_scan, k_len_scatter
-hipError_t klaunch_rows_plan(hipStream_t st, const u64 *d_off, u32 pkt_len, const u64 *d_aoff, u32 aad_len, const u32 *d_len, const u32 *d_alen, u32 n, u32 waves, u32 force_d, u32 nb_cap, u32 slot_cap, RowsHdr *hdr, u64 *prefix, u64 *sprefix, u32 *slot_base, u64 *part);
+hipError_t klaunch_len_sort(hipStream_t st, const LenSrc &src, u32 n, u32 *bins, u32 *perm, const RouteCfg &rc);                           // k_len_hist, k_len_scan (+ the route of the call), k_len_scatter
+hipError_t klaunch_rows_plan(hipStream_t st, const RowsParams &p, u32 force_d, u32 nb_cap, u64 *part, u32 *host_status);      // p: the lengths' arrays, n_pkts, waves, slot_cap, routed, and the scratch arrays the plan fills (hdr, prefix, sprefix, slot_base)
 hipError_t klaunch_rows(int nr, int dec, unsigned wgs, hipStream_t st, const KeyMaterial *km, const DevTables *tb, const RowsParams &p);
 hipError_t klaunch_rows_close(int dec, unsigned wgs, hipStream_t st, const KeyMaterial *km, const DevTables *tb, const RowsParams &p);
 hipError_t klaunch_wipe_failed(hipStream_t st, unsigned char *out, const int *auth, const u64 *data_off, u32 n_pkts, u32 pkt_len, const u64 *out_ptr = nullptr, const u32 *len_arr = nullptr);
@@ -157,15 +154,11 @@ struct aesgcm_ctx {
     size_t pl_cap = 0;
     hipStream_t pl_in = nullptr, pl_out = nullptr;
     hipEvent_t pl_ev_h2d[2] = {nullptr, nullptr}, pl_ev_k[2] = {nullptr, nullptr}, pl_ev_d2h[2] = {nullptr, nullptr};
-    // packets of mixed length: the launch order by length class (k_len_*).  A ring of slots, so that calls on different streams do not share one.
-    OrderSlot order[4];
-    unsigned order_next = 0;
-    size_t order_min = 98304;          // packets from which the order pays (context option "pkt_order"; 0 = never)
     // many messages through the row kernel (k_rows, aesgcm_rows.h): one block of device scratch, grown on demand
     unsigned char *rows_buf = nullptr;
     size_t rows_cap_slots = 0, rows_cap_n = 0;
     bool rows_dirty = true;            // the scratch is not known to be zero (fresh, or a launch failed between k_rows and k_rows_close)
-    u64 rows_min = (u64)8 << 10;       // packets of at least this many bytes go by rows, and from a quarter of it while they are at most 16384 (option "rows_min"; 0 = never).  With offset arrays the caller's pkt_len is the hint that says so
+    u64 rows_min = (u64)8 << 10;       // packets of at least this many bytes go by rows, and from a quarter of it while they are at most 16384 (option "rows_min"; 0 = never).  With offset arrays the device applies the same marks per message (k_len_scan)
     u32 rows_block = 0;                // option "rows_block": units per dealt block of k_rows (0 = the library's cut: one block per wave, or blocks of ROWS_DYN_BLOCK for large calls)
     // streaming state
     bool s_active = false, s_data = false, s_ragged = false;
@@ -216,15 +209,13 @@ int ctx_load_key(aesgcm_ctx *c, const uint8_t *key, size_t key_len, int pre_nr);
 int ctx_create_common(aesgcm_ctx **out, int device, const uint8_t *key, size_t key_len, int pre_nr);
 int stage_in(aesgcm_ctx *c, const uint8_t *aad, size_t aad_len, const uint8_t *in, size_t len);
 int stream_absorb(aesgcm_ctx *c, const void *d_aad, u64 aad_len, const void *d_in, u64 len, void *d_out, u64 first_block);
-int packets_pick_lg(u32 n_cu, size_t n_pkts, size_t pkt_len, bool var, bool ordered = false);
+int packets_pick_lg(u32 n_cu, size_t n_pkts, size_t pkt_len);
 int batch_pick_lg(int n_cu, size_t n_pkts, size_t pkt_len, bool var);
-bool packets_ordered(const aesgcm_ctx *c, size_t n_pkts, bool var);
 int order_launch(OrderSlot &o, const u64 *d_off, size_t n_pkts, hipStream_t st, const u32 **perm);
-int packets_order(aesgcm_ctx *c, const u64 *d_off, size_t n_pkts, hipStream_t st, const u32 **perm, OrderSlot **slot);
 size_t rows_carve(unsigned char *base, size_t slots, size_t n, RowsScratch *r);
 int rows_scratch(aesgcm_ctx *c, size_t slots, size_t n, hipStream_t st, RowsScratch *r);
-int packets_rows(aesgcm_ctx *c, int decrypt, RowsParams &p, hipStream_t st);
-bool packets_by_rows(const aesgcm_ctx *c, size_t n_pkts, size_t pkt_len, bool var_len);
+int packets_rows(aesgcm_ctx *c, int decrypt, RowsParams &p, hipStream_t st, PktParams *k = nullptr);
+bool packets_by_rows(const aesgcm_ctx *c, size_t n_pkts, size_t pkt_len);
 int wipe_failed(int device, size_t n_pkts, void *d_out, size_t pkt_len, const u64 *d_data_off, const int *d_auth, hipStream_t st, const u64 *d_out_ptr = nullptr, const u32 *d_len = nullptr);
 int batch_launch(int device, int decrypt, size_t n_pkts, size_t key_len, BatchParams &p, void *stream);
 void pipeline_release(aesgcm_ctx *c);

@@ -994,17 +994,21 @@ __device__ __forceinline__ void len_sort_slice(u32 n, u32 &lo, u32 &hi) {
     lo = blockIdx.x * per < n ? blockIdx.x * per : n;
     hi = lo + per < n ? lo + per : n;
 }
-__global__ __launch_bounds__(256) void k_len_hist(const u64 *__restrict__ off, u32 n, u32 *__restrict__ counts) {
+__global__ __launch_bounds__(256) void k_len_hist(const LenSrc src, u32 n, u32 *__restrict__ counts) {
     __shared__ u32 h[PKT_LEN_CLASSES];
     h[threadIdx.x] = 0;
     __syncthreads();
     u32 lo, hi;
     len_sort_slice(n, lo, hi);
-    for (u32 i = lo + threadIdx.x; i < hi; i += 256u) atomicAdd(&h[pkt_len_class(off[i + 1] - off[i])], 1u);
+    for (u32 i = lo + threadIdx.x; i < hi; i += 256u) atomicAdd(&h[pkt_len_class(len_src_size(src, i))], 1u);
     __syncthreads();
     counts[(PKT_LEN_CLASSES - 1u - threadIdx.x) * LEN_SORT_WGS + blockIdx.x] = h[threadIdx.x];
 }
-__global__ __launch_bounds__(1024) void k_len_scan(u32 *__restrict__ counts) {         // exclusive prefix sums over the 65536 entries, in place; one workgroup
+// exclusive prefix sums over the 65536 entries, in place; one workgroup.  With a route (round 6: a call whose lengths are on the device, aesgcm_rows.h RowsHdr) the same
+// workgroup then reads off the sums how many messages lie at or above each mark, and DECIDES: which messages go by rows (route_min), how many are left for the packet
+// kernels (n_small), and the packet kernel shape and deal for that many (route_pick_lg, pktg_deal) -- the host launches every shape that count could ask for and
+// all but the one named here return at once.
+__global__ __launch_bounds__(1024) void k_len_scan(u32 *__restrict__ counts, const RouteCfg rc) {
     __shared__ u32 part[1024];
     constexpr u32 PER = LEN_SORT_ENTRIES / 1024u;
     u32 *mine = counts + threadIdx.x * PER;
@@ -1020,14 +1024,39 @@ __global__ __launch_bounds__(1024) void k_len_scan(u32 *__restrict__ counts) {  
     }
     u32 run = part[threadIdx.x] - s;
     for (u32 k = 0; k < PER; ++k) { const u32 c = mine[k]; mine[k] = run; run += c; }
+    if (!rc.hdr) return;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // messages of class >= c: the position of the first message of class c - 1 (classes are laid out falling)
+        auto n_ge = [&](u32 c) { return c == 0u ? rc.n : c >= PKT_LEN_CLASSES ? 0u : counts[(PKT_LEN_CLASSES - c) * LEN_SORT_WGS]; };
+        u32 route_min, n_large;
+        if (rc.c_hi >= PKT_LEN_CLASSES) { route_min = ROWS_ROUTE_NEVER; n_large = 0; }           // rows switched off
+        else {
+            // the high mark (8 KiB) while the messages below it are many enough to fill the chip for the packet kernels, else the low one (2 KiB): aesgcm_host.hip, packets_by_rows
+            const u32 c = rc.n - n_ge(rc.c_hi) > rc.few ? rc.c_hi : rc.c_lo;
+            route_min = c * 64u; n_large = n_ge(c);
+        }
+        const u32 n_small = rc.n - n_large;
+        const u32 lg = rc.force_lg != 0xFFu ? rc.force_lg : n_small ? route_pick_lg(rc.n_cu, n_small) : 0u;
+        rc.hdr->route_min = route_min; rc.hdr->n_small = n_small; rc.hdr->pkt_lg = lg;
+        rc.hdr->pkt_deal = rc.force_deal ? (rc.force_deal + (64u >> lg) - 1u) / (64u >> lg) * (64u >> lg) : pktg_deal(rc.n_cu, n_small, lg);
+        rc.hdr->pkt_counter = 0;
+    }
 }
-__global__ __launch_bounds__(256) void k_len_scatter(const u64 *__restrict__ off, u32 n, const u32 *__restrict__ base, u32 *__restrict__ perm) {
+// small ones FIRST (what the packet kernels take, by falling class: perm[0 .. n_small)), the messages that go by rows behind them (nobody reads those: the row
+// launches walk prefix sums) -- without a route n_small is everything
+__global__ __launch_bounds__(256) void k_len_scatter(const LenSrc src, u32 n, const u32 *__restrict__ base, u32 *__restrict__ perm, const RowsHdr *__restrict__ hdr) {
     __shared__ u32 cur[PKT_LEN_CLASSES];
     cur[threadIdx.x] = base[(PKT_LEN_CLASSES - 1u - threadIdx.x) * LEN_SORT_WGS + blockIdx.x];
     __syncthreads();
+    const u32 n_small = hdr ? hdr->n_small : n, n_large = n - n_small;
     u32 lo, hi;
     len_sort_slice(n, lo, hi);
-    for (u32 i = lo + threadIdx.x; i < hi; i += 256u) perm[atomicAdd(&cur[pkt_len_class(off[i + 1] - off[i])], 1u)] = i;
+    for (u32 i = lo + threadIdx.x; i < hi; i += 256u) {
+        const u32 pos = atomicAdd(&cur[pkt_len_class(len_src_size(src, i))], 1u);
+        perm[pos >= n_large ? pos - n_large : n_small + pos] = i;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1056,19 +1085,25 @@ __global__ __launch_bounds__(PKTG_WG(LG), (PKTG_WG(LG) + 255) / 256) void k_pktg
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr u32 G = 1u << LG, P = 64u >> LG;
     const u32 tid = threadIdx.x, lane = tid & 63u;
+    // a ROUTED call (aesgcm_rows.h RowsHdr): the count and the deal are the device's, and the instance runs only if it is the shape k_len_scan chose for that count
+    u32 n_pkts = p.n_pkts, K = p.deal;
+    if (p.route) {
+        if (p.route->bad || p.route->pkt_lg != (u32)LG || !p.route->n_small) return;
+        n_pkts = uniform32(p.route->n_small); K = uniform32(p.route->pkt_deal);
+    }
     pktg_fill_lds(smem, km, tb, tid, PKTG_WG(LG), LG);
     __syncthreads();
     const u32 wave_slot = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6)) * PKTG_WAVE_SLOT;       // scalar
     // packets are dealt to the waves in blocks of p.deal (a multiple of P, at most 64) from a dispenser: one atomic per block
     // keeps the single dispenser address far below its ~87 M fetches/s ceiling (measured), and late waves still level the
     // tail.  The loop is bounded on purpose (a wave can never own more than nb blocks).
-    const u32 K = p.deal, nb = (p.n_pkts + K - 1) / K;
+    const u32 nb = (n_pkts + K - 1) / K;
     for (u32 guard = 0; guard <= nb; ++guard) {
         u32 b = 0;
         if (lane == 0) b = atomicAdd(p.counter, 1u) - p.counter_base;
         b = __builtin_amdgcn_readfirstlane(b);
         if (b >= nb) break;
-        const u32 p0 = b * K, cnt = (p0 + K < p.n_pkts ? p0 + K : p.n_pkts) - p0;
+        const u32 p0 = b * K, cnt = (p0 + K < n_pkts ? p0 + K : n_pkts) - p0;
         // E_K(IV || 1) of the block's packets, one lane each, in ONE AES pass.  Lane groups park the 64 values in the wave's own 1 KiB of LDS
         // (behind the tree tables): held in registers across the packet loop they were spilled at 128 registers; one packet per wave keeps them.
         constexpr bool EJ_LDS = LG <= 4;
@@ -1128,19 +1163,24 @@ __global__ __launch_bounds__(ILP ? AESGCM_PKTL_WG_ILP : AESGCM_PKTL_WG, ILP ? 2 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr u32 WG = ILP ? AESGCM_PKTL_WG_ILP : AESGCM_PKTL_WG;
     const u32 tid = threadIdx.x, lane = tid & 63u;
+    u32 n_pkts = p.n_pkts;
+    if (p.route) {                                             // a ROUTED call: the count is the device's, and a lane per packet may not be the shape chosen for it (k_pktg above)
+        if (p.route->bad || p.route->pkt_lg != 0u || !p.route->n_small) return;
+        n_pkts = uniform32(p.route->n_small);
+    }
     main_fill_lds(smem, km, tb, tid, true, WG, GH_TAB_H);
 #if AESGCM_PKTL_T4
     fill_lds_t4(smem, tb, tid, WG);
 #endif
     __syncthreads();
-    const u32 nb = (p.n_pkts + 63u) / 64u;
+    const u32 nb = (n_pkts + 63u) / 64u;
     for (u32 guard = 0; guard <= nb; ++guard) {                // bounded, as every dispenser loop here
         u32 b = 0;
         if (lane == 0) b = atomicAdd(p.counter, 1u) - p.counter_base;
         b = __builtin_amdgcn_readfirstlane(b);
         if (b >= nb) break;
         const u32 idx = b * 64u + lane;
-        if (idx < p.n_pkts) pktl_lane<NR, DEC, AESGCM_PKTL_T4 != 0, ILP != 0>(km, p, smem, pkt_map(p, idx), lane);
+        if (idx < n_pkts) pktl_lane<NR, DEC, AESGCM_PKTL_T4 != 0, ILP != 0>(km, p, smem, pkt_map(p, idx), lane);
     }
 }
 
@@ -1154,13 +1194,14 @@ template <int NR, int MODE>
 __global__ __launch_bounds__(AESGCM_BODY_WG, AESGCM_BODY_WPS) void k_rows(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const RowsParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 tid = threadIdx.x, lane = tid & 63u;
+    const u64 G = uniform64(p.hdr ? p.hdr->G : p.G);
+    if (!G || (p.hdr && p.hdr->bad)) return;                                 // nothing by rows (a routed call whose messages are all the packet kernels'), or a plan that was refused: before the 141 KiB of tables are staged
     main_fill_lds(smem, km, tb, tid, true, AESGCM_BODY_WG, GH_TAB_K64);            // consecutive rows: Horner stride H^64
 #if AESGCM_T4
     fill_lds_t4(smem, tb, tid, AESGCM_BODY_WG);
 #endif
     if (tid == 0) *reinterpret_cast<u32 *>(smem + AESGCM_LDS_DRY_OFF) = 0;   // dry-queue mask of the workgroup (next_chunk)
     __syncthreads();
-    const u64 G = uniform64(p.hdr ? p.hdr->G : p.G);
     const u32 D = uniform32(p.hdr ? p.hdr->D : p.D), NB = uniform32(p.hdr ? p.hdr->NB : p.NB), dyn = uniform32(p.hdr ? p.hdr->dyn : p.dyn);
     const u32 wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (AESGCM_BODY_WG / 64) + (tid >> 6));
     u32 nq, seg;
@@ -1180,7 +1221,7 @@ __global__ __launch_bounds__(AESGCM_BODY_WG, AESGCM_BODY_WPS) void k_rows(const 
             m = opaque_sgpr(m);
             RowsMsg mq = rows_msg(p, m);
             mq.doff = uniform64(mq.doff); mq.ooff = uniform64(mq.ooff); mq.aoff = uniform64(mq.aoff); mq.len = uniform32(mq.len); mq.alen = uniform32(mq.alen);
-            const RowsGeom geo = rows_geom(mq.len);
+            const RowsGeom geo = rows_geom_of(mq, uniform32(rows_route_min(p)));          // (a message of the packet kernels: no unit -- skipped below like one shorter than a row)
             const u64 g0 = uniform64(rows_unit_base(p, m));
             const u32 U = rows_units(geo, rows_na(mq.alen));
             if (g >= g0 + U) { ++m; if (U == 0) { ++skipped; --guard2; } continue; }     // the next message (one without a unit -- shorter than a row -- does not count against the bound of the walk)
@@ -1262,18 +1303,25 @@ static_assert(offsetof(DevTables, te3) - offsetof(DevTables, te0) == 3072 && off
 template <int DEC>
 __global__ __launch_bounds__(ROWS_CLOSE_WG) void k_rows_close(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const RowsParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[4096];
-    rows_close_fill_te(smem, tb, threadIdx.x);
+    if (p.hdr && p.hdr->bad) return;                                             // a plan that was refused: nothing ran, nothing to close (the scratch is at rest)
     if (blockIdx.x == 0 && threadIdx.x < ROWS_NQ) p.queues[16u * threadIdx.x] = 0;
+    const u32 route_min = rows_route_min(p);
+    if (p.routed && p.hdr->n_small == p.n_pkts) return;                          // every message went to the packet kernels: no unit, no smalls block, no tag of this launch's
+    rows_close_fill_te(smem, tb, threadIdx.x);
     __syncthreads();
-    const u32 i = blockIdx.x * ROWS_CLOSE_WG + threadIdx.x;
     const u32 *te = reinterpret_cast<const u32 *>(smem + ROWS_CLOSE_LDS_TE);
-    if (p.hdr && p.hdr->bad) return;
-    if (i < p.n_pkts) rows_arrive<DEC>(p, i, rows_msg_term(km, te, p, i), 1u);
+    // The launch is a grid of lanes that STRIDE over three things (round 6; until then a lane per record slot the scratch was sized for -- 3 n + 65536 with offset
+    // arrays, nearly all of them empty): message i (what it owes once), the blocks of the smalls axis, record slot i up to the slots the plan actually gave out.
+    const u64 lanes = (u64)gridDim.x * ROWS_CLOSE_WG, gid = (u64)blockIdx.x * ROWS_CLOSE_WG + threadIdx.x;
+    for (u64 i = gid; i < p.n_pkts; i += lanes) {
+        const RowsMsg q = rows_msg(p, (u32)i);
+        if (!rows_is_small(q.len, q.alen, route_min)) rows_arrive<DEC>(p, (u32)i, rows_msg_term(km, te, p, (u32)i), 1u);     // (a message of the packet kernels has its tag from there)
+    }
     // The smalls: the waves of the launch take 64 consecutive blocks of the axis at a time.  The blocks of a segment -- one message's AAD, or its tail -- are
     // neighbours: their lanes fold their terms first (rows_fold) and the first of them pays what is still due of the segment's power of H and arrives for all.
-    const u64 total = rows_small_total(p), lanes = (u64)gridDim.x * ROWS_CLOSE_WG;
+    const u64 total = rows_small_total(p), wave_base = (u64)blockIdx.x * ROWS_CLOSE_WG + (threadIdx.x & ~63u);
     const u32 lane = threadIdx.x & 63u;
-    for (u64 base = (u64)blockIdx.x * ROWS_CLOSE_WG + (threadIdx.x & ~63u), guard = 0; base < total && guard <= ROWS_SMALL_AAD + ROWS_SMALL_TAIL + 2u; base += lanes, ++guard) {   // (a lane per message at least, a message at most 80 blocks here)
+    for (u64 base = wave_base, guard = 0; base < total && guard <= total / lanes + 1u; base += lanes, ++guard) {
         const u64 t = base + lane;
         const bool active = t < total;
         G128 z; z.w[0] = z.w[1] = z.w[2] = z.w[3] = 0;
@@ -1284,18 +1332,33 @@ __global__ __launch_bounds__(ROWS_CLOSE_WG) void k_rows_close(const KeyMaterial 
         if (rows_fold(key, z, lane, &count)) rows_arrive<DEC>(p, m, rows_small_due(km, z, e_run), count);
     }
     // The records: those of one message have neighbouring slots; they fold the same way.
-    RowsRec r;
-    r.flags = 0; r.msg = 0;
-    if (i < p.slot_cap) r = p.rec[i];
-    const bool valid = (r.flags & ROWS_REC_VALID) != 0;
-    G128 z; z.w[0] = z.w[1] = z.w[2] = z.w[3] = 0;
-    if (valid) { p.rec[i].flags = 0; z = rows_weigh(km, r); }
-    u32 count;
-    if (rows_fold(valid ? r.msg : 0xFFFFFFFFu, z, lane, &count)) rows_arrive<DEC>(p, r.msg, z, count);
+    const u64 slots = p.slot_base ? p.slot_base[p.n_pkts] : p.slot_cap;
+    for (u64 base = wave_base, guard = 0; base < slots && guard <= slots / lanes + 1u; base += lanes, ++guard) {
+        const u64 i = base + lane;
+        RowsRec r;
+        r.flags = 0; r.msg = 0;
+        if (i < slots) r = p.rec[i];
+        const bool valid = (r.flags & ROWS_REC_VALID) != 0;
+        G128 z; z.w[0] = z.w[1] = z.w[2] = z.w[3] = 0;
+        if (valid) { p.rec[i].flags = 0; z = rows_weigh(km, r); }
+        u32 count;
+        if (rows_fold(valid ? r.msg : 0xFFFFFFFFu, z, lane, &count)) rows_arrive<DEC>(p, r.msg, z, count);
+    }
 }
 
-// The cut of a call with offset arrays, on the device (the host does not know the lengths): ONE workgroup.  Units per message -> prefix[0 .. n] and G; the cut
-// (rows_cut); record slots per message -> slot_base[0 .. n]; the header.
+// The cut of a call with offset arrays, on the device (the host does not know the lengths).  Units per message -> prefix[0 .. n] and G; the cut (rows_cut);
+// record slots per message -> slot_base[0 .. n]; the header.  Round 6: a ROUTED call (a.routed: k_len_scan left route_min in the header) counts the messages
+// below the mark as nothing -- they are the packet kernels' --, and every length is CHECKED here, where the round-5 code truncated it: a length or an
+// offset difference of 2^28 or more (offsets that do not rise are one: the difference wraps) refuses the whole call -- hdr->bad, nothing runs, outputs untouched --
+// and says so in the context's pinned host slot (status, detail = the first such message; aesgcm_ctx_status), as the RTL raises its flag when the counter cannot
+// go on (src/aes_icb.vhd:65,98,114,119).
+struct RowsPlan {
+    const u64 *off, *aoff; const u32 *len_arr, *alen_arr;
+    u32 pkt_len, aad_len, n, waves, force_d, nb_cap, slot_cap, nwg, routed;
+    RowsHdr *hdr; u64 *prefix, *sprefix; u32 *slot_base;
+    u64 *part;                                                               // 4 x nwg: units, smalls blocks, slots, first bad message per workgroup -- then what lies in front of each
+    volatile u32 *host_status;                                               // the context's pinned host slot: {code, 0, detail lo, detail hi}, or NULL
+};
 __device__ __forceinline__ u64 block_scan_u64(unsigned long long *part, u64 mine, u32 tid) {      // exclusive prefix of `mine` over the 1024 threads; part[1023] = the total afterwards
     part[tid] = mine;
     __syncthreads();
@@ -1307,69 +1370,89 @@ __device__ __forceinline__ u64 block_scan_u64(unsigned long long *part, u64 mine
     }
     return part[tid] - mine;
 }
-__global__ __launch_bounds__(1024) void k_rows_plan(const u64 *__restrict__ off, u32 pkt_len, const u64 *__restrict__ aoff, u32 aad_len, const u32 *__restrict__ len_arr, const u32 *__restrict__ alen_arr, u32 n, u32 waves, u32 force_d, u32 nb_cap, u32 slot_cap,
-                                                    RowsHdr *hdr, u64 *prefix, u64 *sprefix, u32 *slot_base) {
+__device__ __forceinline__ u64 block_min_u64(unsigned long long *part, u64 mine, u32 tid) {       // the minimum of `mine` over the 1024 threads (everybody gets it)
+    __syncthreads();
+    part[tid] = mine;
+    __syncthreads();
+    for (u32 d = 512u; d; d >>= 1) { if (tid < d && part[tid + d] < part[tid]) part[tid] = part[tid + d]; __syncthreads(); }
+    const u64 r = part[0];
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ u64 plan_len(const RowsPlan &a, u32 m) { return a.len_arr ? (u64)a.len_arr[m] : a.off ? a.off[m + 1] - a.off[m] : (u64)a.pkt_len; }
+__device__ __forceinline__ u64 plan_alen(const RowsPlan &a, u32 m) { return a.len_arr ? (a.alen_arr ? (u64)a.alen_arr[m] : 0ull) : a.aoff ? a.aoff[m + 1] - a.aoff[m] : (u64)a.aad_len; }
+__device__ __forceinline__ bool plan_bad_len(const RowsPlan &a, u32 m) { return plan_len(a, m) >= ROWS_LEN_LIMIT || plan_alen(a, m) >= ROWS_LEN_LIMIT; }
+// (lengths beyond the limit count as nothing: the call is refused anyway, and the sums stay in range)
+__device__ __forceinline__ RowsGeom plan_geom(const RowsPlan &a, u32 m, u32 route_min) { return plan_bad_len(a, m) ? rows_geom(0) : rows_geom_routed(plan_len(a, m), plan_alen(a, m), route_min); }
+__device__ __forceinline__ u32 plan_na(const RowsPlan &a, u32 m) { return plan_bad_len(a, m) ? 0u : rows_na((u32)plan_alen(a, m)); }
+__device__ __forceinline__ u32 plan_route_min(const RowsPlan &a) { return a.routed ? a.hdr->route_min : 0u; }
+__device__ __forceinline__ void plan_refuse(const RowsPlan &a, u32 status, u64 detail) {          // one thread
+    a.hdr->G = 0; a.hdr->NB = 0; a.hdr->bad = 1; a.hdr->status = status; a.hdr->detail = detail;
+    if (a.host_status) { a.host_status[2] = (u32)detail; a.host_status[3] = (u32)(detail >> 32); __threadfence_system(); a.host_status[0] = status; }
+}
+// up to ROWS_PLAN_ONE_WG messages: ONE workgroup
+__global__ __launch_bounds__(1024) void k_rows_plan(const RowsPlan a) {
     __shared__ unsigned long long part[1024];
-    const u32 tid = threadIdx.x, per = (n + 1023u) / 1024u;
+    const u32 tid = threadIdx.x, n = a.n, per = (n + 1023u) / 1024u;
     const u32 lo = tid * per < n ? tid * per : n, hi = lo + per < n ? lo + per : n;
-    auto geom_of = [&](u32 m) { return rows_geom(len_arr ? (u64)len_arr[m] : off ? off[m + 1] - off[m] : (u64)pkt_len); };                 // (len_arr: the scattered form, lengths per message)
-    auto na_of = [&](u32 m) { return rows_na(len_arr ? (alen_arr ? alen_arr[m] : 0u) : aoff ? (u32)(aoff[m + 1] - aoff[m]) : aad_len); };
-    u64 s = 0, ss = 0;
-    for (u32 m = lo; m < hi; ++m) { const RowsGeom g = geom_of(m); const u32 na = na_of(m); s += rows_units(g, na); ss += rows_smalls(g, na); }
+    const u32 route_min = plan_route_min(a);
+    u64 s = 0, ss = 0, bad = ~0ull;
+    for (u32 m = lo; m < hi; ++m) {
+        const RowsGeom g = plan_geom(a, m, route_min); const u32 na = plan_na(a, m);
+        s += rows_units(g, na); ss += rows_smalls(g, na);
+        if (bad == ~0ull && plan_bad_len(a, m)) bad = m;
+    }
     u64 run = block_scan_u64(part, s, tid);                                  // row units in front of the thread's messages
     const u64 GR = part[1023];
     __syncthreads();
     u64 srun = block_scan_u64(part, ss, tid);                                // smalls blocks in front of them
     const u64 ST = part[1023];
     __syncthreads();
+    const u64 first_bad = block_min_u64(part, bad, tid);
     const u64 G = GR;
     u32 D, NB, dyn;
-    rows_cut(G, waves, force_d, nb_cap, &D, &NB, &dyn);
+    const bool cut_ok = rows_cut(G, a.waves, a.force_d, a.nb_cap, &D, &NB, &dyn);
     u64 t = 0;
     for (u32 m = lo; m < hi; ++m) {
-        const RowsGeom g = geom_of(m); const u32 na = na_of(m);
-        prefix[m] = run; sprefix[m] = srun;
+        const RowsGeom g = plan_geom(a, m, route_min); const u32 na = plan_na(a, m);
+        a.prefix[m] = run; a.sprefix[m] = srun;
         t += rows_slots(g, na, run, D);
         run += rows_units(g, na); srun += rows_smalls(g, na);
     }
     u64 slot = block_scan_u64(part, t, tid);
     const u64 slots = part[1023];
-    run = lo < n ? prefix[lo] : 0; srun = lo < n ? sprefix[lo] : 0;
+    run = lo < n ? a.prefix[lo] : 0;
     for (u32 m = lo; m < hi; ++m) {
-        const RowsGeom g = geom_of(m); const u32 na = na_of(m);
-        slot_base[m] = (u32)slot;
+        const RowsGeom g = plan_geom(a, m, route_min); const u32 na = plan_na(a, m);
+        a.slot_base[m] = (u32)slot;
         slot += rows_slots(g, na, run, D);
-        run += rows_units(g, na); srun += rows_smalls(g, na);
+        run += rows_units(g, na);
     }
     if (tid == 0) {
-        const bool fits = slots <= slot_cap;                                 // (the host sizes the scratch for the worst case; a cut that does not fit would be its bug: then nothing runs)
-        prefix[n] = GR; sprefix[n] = ST; slot_base[n] = (u32)slots;
-        hdr->G = fits ? G : 0ull;
-        hdr->D = D; hdr->NB = fits ? NB : 0u; hdr->dyn = dyn; hdr->bad = fits ? 0u : 1u;
+        a.prefix[n] = GR; a.sprefix[n] = ST; a.slot_base[n] = (u32)(slots <= a.slot_cap ? slots : 0);
+        a.hdr->G = G; a.hdr->D = D; a.hdr->NB = NB; a.hdr->dyn = dyn; a.hdr->bad = 0; a.hdr->status = ROWS_ST_OK; a.hdr->detail = 0;
+        if (first_bad != ~0ull) plan_refuse(a, ROWS_ST_LENGTH, first_bad);
+        else if (!cut_ok) plan_refuse(a, ROWS_ST_UNITS, G);
+        else if (slots > a.slot_cap) plan_refuse(a, ROWS_ST_PLAN_FIT, slots);   // (the host sizes the scratch for the worst case; a cut that does not fit would be its bug: then nothing runs)
     }
 }
 
 // The same plan for MANY messages: the one workgroup above takes 4 ns a message -- 2.1 ms in front of a 5.1 ms row launch for 524 288 messages of 8 KiB
 // (profiles/r05/rows_var_stats_before.txt).  Five small launches instead, a thread per message and a workgroup per 1024 of them: sums per workgroup; their scan
 // and the cut (one workgroup); the first two prefix sums and the slot counts; the scan of those; the third prefix sum.
-struct RowsPlan {
-    const u64 *off, *aoff; const u32 *len_arr, *alen_arr;
-    u32 pkt_len, aad_len, n, waves, force_d, nb_cap, slot_cap, nwg;
-    RowsHdr *hdr; u64 *prefix, *sprefix; u32 *slot_base;
-    u64 *part;                                                               // 3 x nwg: units, smalls blocks, slots per workgroup -- then what lies in front of each
-};
-__device__ __forceinline__ RowsGeom plan_geom(const RowsPlan &a, u32 m) { return rows_geom(a.len_arr ? (u64)a.len_arr[m] : a.off ? a.off[m + 1] - a.off[m] : (u64)a.pkt_len); }
-__device__ __forceinline__ u32 plan_na(const RowsPlan &a, u32 m) { return rows_na(a.len_arr ? (a.alen_arr ? a.alen_arr[m] : 0u) : a.aoff ? (u32)(a.aoff[m + 1] - a.aoff[m]) : a.aad_len); }
 __global__ __launch_bounds__(1024) void k_rows_plan_sums(const RowsPlan a) {
     __shared__ unsigned long long part[1024];
     const u32 tid = threadIdx.x, m = blockIdx.x * 1024u + tid;
-    u64 u = 0, s = 0;
-    if (m < a.n) { const RowsGeom g = plan_geom(a, m); const u32 na = plan_na(a, m); u = rows_units(g, na); s = rows_smalls(g, na); }
+    const u32 route_min = plan_route_min(a);
+    u64 u = 0, s = 0, bad = ~0ull;
+    if (m < a.n) { const RowsGeom g = plan_geom(a, m, route_min); const u32 na = plan_na(a, m); u = rows_units(g, na); s = rows_smalls(g, na); if (plan_bad_len(a, m)) bad = m; }
     block_scan_u64(part, u, tid);
     const u64 U = part[1023];
     __syncthreads();
     block_scan_u64(part, s, tid);
-    if (tid == 0) { a.part[blockIdx.x] = U; a.part[a.nwg + blockIdx.x] = part[1023]; }
+    const u64 S = part[1023];
+    const u64 first_bad = block_min_u64(part, bad, tid);
+    if (tid == 0) { a.part[blockIdx.x] = U; a.part[a.nwg + blockIdx.x] = S; a.part[3u * a.nwg + blockIdx.x] = first_bad; }
 }
 // exclusive scan of v[0 .. n) in place by ONE workgroup (tiles of 1024 with a carry); returns the total
 __device__ __forceinline__ u64 plan_scan_in_place(unsigned long long *part, u64 *v, u32 n, u32 tid) {
@@ -1389,20 +1472,26 @@ __global__ __launch_bounds__(1024) void k_rows_plan_cut(const RowsPlan a) {
     __shared__ unsigned long long part[1024];
     const u32 tid = threadIdx.x;
     const u64 GR = plan_scan_in_place(part, a.part, a.nwg, tid), ST = plan_scan_in_place(part, a.part + a.nwg, a.nwg, tid);
+    u64 bad = ~0ull;
+    for (u32 i = tid; i < a.nwg; i += 1024u) { const u64 b = a.part[3u * a.nwg + i]; if (b < bad) bad = b; }
+    const u64 first_bad = block_min_u64(part, bad, tid);
     if (tid == 0) {
         u32 D, NB, dyn;
-        rows_cut(GR, a.waves, a.force_d, a.nb_cap, &D, &NB, &dyn);
-        a.hdr->G = GR; a.hdr->D = D; a.hdr->NB = NB; a.hdr->dyn = dyn; a.hdr->bad = 0;
+        const bool cut_ok = rows_cut(GR, a.waves, a.force_d, a.nb_cap, &D, &NB, &dyn);
+        a.hdr->G = GR; a.hdr->D = D; a.hdr->NB = NB; a.hdr->dyn = dyn; a.hdr->bad = 0; a.hdr->status = ROWS_ST_OK; a.hdr->detail = 0;
         a.prefix[a.n] = GR; a.sprefix[a.n] = ST;
+        if (first_bad != ~0ull) plan_refuse(a, ROWS_ST_LENGTH, first_bad);
+        else if (!cut_ok) plan_refuse(a, ROWS_ST_UNITS, GR);
     }
 }
 __global__ __launch_bounds__(1024) void k_rows_plan_place(const RowsPlan a) {
     __shared__ unsigned long long part[1024];
     const u32 tid = threadIdx.x, m = blockIdx.x * 1024u + tid;
+    const u32 route_min = plan_route_min(a);
     RowsGeom g = rows_geom(0);
     u32 na = 0;
     u64 u = 0, s = 0;
-    if (m < a.n) { g = plan_geom(a, m); na = plan_na(a, m); u = rows_units(g, na); s = rows_smalls(g, na); }
+    if (m < a.n) { g = plan_geom(a, m, route_min); na = plan_na(a, m); u = rows_units(g, na); s = rows_smalls(g, na); }
     const u64 g0 = a.part[blockIdx.x] + block_scan_u64(part, u, tid);
     __syncthreads();
     const u64 s0 = a.part[a.nwg + blockIdx.x] + block_scan_u64(part, s, tid);
@@ -1417,8 +1506,8 @@ __global__ __launch_bounds__(1024) void k_rows_plan_slots(const RowsPlan a) {
     const u32 tid = threadIdx.x;
     const u64 slots = plan_scan_in_place(part, a.part + 2u * a.nwg, a.nwg, tid);
     if (tid == 0) {
-        a.slot_base[a.n] = (u32)slots;
-        if (slots > a.slot_cap) { a.hdr->G = 0; a.hdr->NB = 0; a.hdr->bad = 1; }      // (the host sizes the scratch for the worst case; a cut that does not fit would be its bug: then nothing runs)
+        a.slot_base[a.n] = (u32)(slots <= a.slot_cap ? slots : 0);
+        if (slots > a.slot_cap && !a.hdr->bad) plan_refuse(a, ROWS_ST_PLAN_FIT, slots);      // (the host sizes the scratch for the worst case; a cut that does not fit would be its bug: then nothing runs)
     }
 }
 __global__ __launch_bounds__(1024) void k_rows_plan_base(const RowsPlan a) {
@@ -1578,20 +1667,22 @@ hipError_t klaunch_batch3(int nr, int dec, int lg, unsigned wgs, hipStream_t st,
 #undef LB3
     return hipGetLastError();
 }
-hipError_t klaunch_len_sort(hipStream_t st, const u64 *d_off, u32 n, u32 *bins, u32 *perm) {
-    hipLaunchKernelGGL(k_len_hist, dim3(LEN_SORT_WGS), dim3(256), 0, st, d_off, n, bins);
-    hipLaunchKernelGGL(k_len_scan, dim3(1), dim3(1024), 0, st, bins);
-    hipLaunchKernelGGL(k_len_scatter, dim3(LEN_SORT_WGS), dim3(256), 0, st, d_off, n, bins, perm);
+hipError_t klaunch_len_sort(hipStream_t st, const LenSrc &src, u32 n, u32 *bins, u32 *perm, const RouteCfg &rc) {
+    hipLaunchKernelGGL(k_len_hist, dim3(LEN_SORT_WGS), dim3(256), 0, st, src, n, bins);
+    hipLaunchKernelGGL(k_len_scan, dim3(1), dim3(1024), 0, st, bins, rc);
+    hipLaunchKernelGGL(k_len_scatter, dim3(LEN_SORT_WGS), dim3(256), 0, st, src, n, bins, perm, (const RowsHdr *)rc.hdr);
     return hipGetLastError();
 }
-hipError_t klaunch_rows_plan(hipStream_t st, const u64 *d_off, u32 pkt_len, const u64 *d_aoff, u32 aad_len, const u32 *d_len, const u32 *d_alen, u32 n, u32 waves, u32 force_d, u32 nb_cap, u32 slot_cap, RowsHdr *hdr, u64 *prefix, u64 *sprefix, u32 *slot_base, u64 *part) {
-    if (n <= ROWS_PLAN_ONE_WG) {
-        hipLaunchKernelGGL(k_rows_plan, dim3(1), dim3(1024), 0, st, d_off, pkt_len, d_aoff, aad_len, d_len, d_alen, n, waves, force_d, nb_cap, slot_cap, hdr, prefix, sprefix, slot_base);
+hipError_t klaunch_rows_plan(hipStream_t st, const RowsParams &p, u32 force_d, u32 nb_cap, u64 *part, u32 *host_status) {
+    RowsPlan a;
+    a.off = p.data_off; a.aoff = p.aad_off; a.len_arr = p.len_arr; a.alen_arr = p.alen_arr; a.pkt_len = p.pkt_len; a.aad_len = p.aad_len; a.n = p.n_pkts; a.waves = p.waves; a.force_d = force_d;
+    a.nb_cap = nb_cap; a.slot_cap = p.slot_cap; a.nwg = (p.n_pkts + 1023u) / 1024u; a.routed = p.routed;
+    a.hdr = const_cast<RowsHdr *>(p.hdr); a.prefix = const_cast<u64 *>(p.prefix); a.sprefix = const_cast<u64 *>(p.sprefix); a.slot_base = const_cast<u32 *>(p.slot_base); a.part = part;
+    a.host_status = host_status;
+    if (a.n <= ROWS_PLAN_ONE_WG) {
+        hipLaunchKernelGGL(k_rows_plan, dim3(1), dim3(1024), 0, st, a);
         return hipGetLastError();
     }
-    RowsPlan a;
-    a.off = d_off; a.aoff = d_aoff; a.len_arr = d_len; a.alen_arr = d_alen; a.pkt_len = pkt_len; a.aad_len = aad_len; a.n = n; a.waves = waves; a.force_d = force_d;
-    a.nb_cap = nb_cap; a.slot_cap = slot_cap; a.nwg = (n + 1023u) / 1024u; a.hdr = hdr; a.prefix = prefix; a.sprefix = sprefix; a.slot_base = slot_base; a.part = part;
     hipLaunchKernelGGL(k_rows_plan_sums, dim3(a.nwg), dim3(1024), 0, st, a);
     hipLaunchKernelGGL(k_rows_plan_cut, dim3(1), dim3(1024), 0, st, a);
     hipLaunchKernelGGL(k_rows_plan_place, dim3(a.nwg), dim3(1024), 0, st, a);

@@ -44,8 +44,16 @@ struct PktParams {
     u32 aligned;                 // in/out base pointers 16-byte aligned
     const u32 *perm;             // the order in which the launch takes the packets (k_len_*: by falling length), or NULL = as they come
     u32 plain;                   // k_pktg<.., 6 | 2>: fixed-size aligned records of whole group-iterations, no AAD
+    // messages WHEREVER THEY LIVE (aesgcm_messages_crypt_dev, round 6: the short ones of such a call are the packet kernels'): device addresses and lengths per message; in / out / aad are NULL then
+    const u64 *in_ptr, *out_ptr, *aad_ptr;
+    const u32 *len_arr, *alen_arr;
+    // a ROUTED call (lengths on the device): how many packets the launch has (the first n_small entries of perm), whether this instance is the shape chosen for
+    // that count, and its deal, are in the header k_len_scan left (aesgcm_rows.h RowsHdr); NULL = the host's numbers above
+    const struct RowsHdr *route;
 };
 HD u32 pkt_map(const PktParams &p, u32 i) { return p.perm ? p.perm[i] : i; }
+HD const unsigned char *pkt_at(const unsigned char *base, u64 off) { return reinterpret_cast<const unsigned char *>((uintptr_t)base + off); }
+HD unsigned char *pkt_at(unsigned char *base, u64 off) { return reinterpret_cast<unsigned char *>((uintptr_t)base + off); }
 // Packets of mixed length (offset arrays).  The lanes (k_pktl) or lane groups (k_pktg, k_batch3) of a wave run to the longest packet among them: with frames
 // of 64 .. 1514 bytes in arrival order a wave's 64 packets average 700 bytes and the wave takes as long as 1514 -- less than half the lanes work
 // (profiles/r04/packets_sweep_mixed_*.txt: 2^20 frames 426 GiB/s against 854 for 2^20 x 1 KiB).  The launch therefore takes the packets in the order of a
@@ -53,6 +61,26 @@ HD u32 pkt_map(const PktParams &p, u32 i) { return p.perm ? p.perm[i] : i; }
 // same stream in front of it -- histogram, scan, scatter; the order inside a class is whatever the atomics make it, results do not depend on it.
 #define PKT_LEN_CLASSES 256u
 HD u32 pkt_len_class(u64 len) { const u64 c = len >> 6; return c < PKT_LEN_CLASSES ? (u32)c : PKT_LEN_CLASSES - 1u; }
+#ifndef AESGCM_PKTL_WG
+#define AESGCM_PKTL_WG 768            // lanes per k_pktl workgroup: 3 waves per SIMD = 168 registers, what eight held blocks beside the table multiply need
+#endif
+// Packets of mixed length taken by length class: lanes per packet as log2 for n of them (0 = a lane per packet, k_pktl; 2 / 3 / 4 = lane groups, k_pktg) -- the
+// host's rule for offset arrays (packets_pick_lg: measured in profiles/r04/packets_sweep_mixed_*.txt: by class the groups hold on until the packets fill k_pktl's
+// resident lanes 4/3 times over) as a function the DEVICE can evaluate too: a routed call (round 6) learns the count only there (k_len_scan).
+HD u32 route_pick_lg(u32 n_cu, u64 n) {
+    const u64 lanes_total = (u64)n_cu * (AESGCM_PKT_WG / 64) * 64, lanes_l = (u64)n_cu * AESGCM_PKTL_WG;
+    if (3 * n >= 4 * lanes_l) return 0u;
+    const u64 fill = n ? lanes_total / n : lanes_total, cap = n >= 16384 ? 8 : 16;          // never more lanes than an eighth (a quarter, while the chip is not full) of a 1 KiB frame's blocks
+    const u64 g = fill < cap ? fill : cap;
+    return g >= 16 ? 4u : g >= 8 ? 3u : 2u;
+}
+// k_pktg: packets per dispenser fetch -- about 4 fetches per resident wave, a multiple of the packets per wave-iteration, at most 64 (one E_K(J0) pass per fetch)
+HD u32 pktg_deal(u32 n_cu, u64 n, u32 lg) {
+    const u32 P = 64u >> lg, waves_per_wg = (lg == 6u ? 768u : (u32)AESGCM_PKT_WG) / 64u;
+    u32 deal = (u32)(n / ((u64)n_cu * waves_per_wg * 4));
+    deal = deal / P * P;
+    return deal < P ? P : deal > 64u ? 64u : deal;
+}
 #define PKTG_LDS_TREE_OFF (AESGCM_LDS_AES_OFF + AESGCM_LDS_AES)                       /* 79104 */
 #define PKTG_LDS_BYTES(LG) (PKTG_LDS_TREE_OFF + (u32)(LG) * (u32)AESGCM_LDS_GH)
 #define PKTG_MAX_DEAL 64u
@@ -65,14 +93,23 @@ HD void pktg_fill_lds(unsigned char *smem, const KeyMaterial *km, const DevTable
 }
 
 // per-packet geometry and constants: uniform over the packet's lane group
-struct PktInfo { u64 doff, aoff; u32 pkt_len, aad_len, iv0, iv1, iv2, aligned; };
+struct PktInfo { u64 doff, ooff, aoff; u32 pkt_len, aad_len, iv0, iv1, iv2, aligned; };      // doff / ooff: where the packet's input / output lies (the same offset, except for messages in buffers of their own)
+HD void pkt_place(const PktParams &p, u32 pkt, u64 *doff, u64 *ooff, u64 *aoff, u32 *pkt_len, u32 *aad_len) {
+    if (p.len_arr) {                                            // addresses and lengths per message (in / out / aad are NULL: the "offsets" are addresses)
+        *doff = p.in_ptr[pkt]; *ooff = p.out_ptr[pkt]; *pkt_len = p.len_arr[pkt];
+        *aoff = p.aad_ptr ? p.aad_ptr[pkt] : 0; *aad_len = p.aad_ptr ? p.alen_arr[pkt] : 0u;
+        return;
+    }
+    *pkt_len = p.pkt_len; *aad_len = p.aad_len;
+    *doff = (u64)pkt * p.pkt_len; *aoff = (u64)pkt * p.aad_len;
+    if (p.data_off) { *doff = p.data_off[pkt]; *pkt_len = (u32)(p.data_off[pkt + 1] - *doff); }
+    if (p.aad_off) { *aoff = p.aad_off[pkt]; *aad_len = (u32)(p.aad_off[pkt + 1] - *aoff); }
+    *ooff = *doff;
+}
 HD PktInfo pkt_info(const PktParams &p, u32 pkt) {
     PktInfo q;
-    q.pkt_len = p.pkt_len; q.aad_len = p.aad_len;
-    q.doff = (u64)pkt * p.pkt_len; q.aoff = (u64)pkt * p.aad_len;
-    if (p.data_off) { q.doff = p.data_off[pkt]; q.pkt_len = (u32)(p.data_off[pkt + 1] - q.doff); }
-    if (p.aad_off) { q.aoff = p.aad_off[pkt]; q.aad_len = (u32)(p.aad_off[pkt + 1] - q.aoff); }
-    q.aligned = (p.aligned && ((q.doff & 15) == 0)) ? 1u : 0u;
+    pkt_place(p, pkt, &q.doff, &q.ooff, &q.aoff, &q.pkt_len, &q.aad_len);
+    q.aligned = (p.aligned && (((q.doff | q.ooff) & 15) == 0)) ? 1u : 0u;
     const unsigned char *ivp = p.ivs + (size_t)pkt * 12;
     q.iv0 = load_le32(ivp); q.iv1 = load_le32(ivp + 4); q.iv2 = load_le32(ivp + 8);
     return q;
@@ -101,8 +138,9 @@ HD uint4 pktg_lane(const KeyMaterial *__restrict__ km, const PktParams &p, const
     const CtrConsts cc = ctr_round1_consts(q.iv0, q.iv1, q.iv2, rk, smem, lb);      // key and IV only: uniform over the group
     const u32 n_aad = (q.aad_len + 15) / 16, n_ct = (q.pkt_len + 15) / 16, n_seq = n_aad + n_ct;
     const u32 pad = G * iters - n_seq;                                              // front padding slots (whole idle iterations included)
-    const unsigned char *src = p.in + q.doff;
-    unsigned char *dst = p.out + q.doff;
+    const unsigned char *src = pkt_at(p.in, q.doff);
+    unsigned char *dst = pkt_at(p.out, q.ooff);
+    const unsigned char *aadp = pkt_at(p.aad, q.aoff);
     const bool aligned = q.aligned != 0;
     uint4 acc = make_uint4(0, 0, 0, 0);
     if ((LG == 6 || LG == 2) && p.plain) {   // a wave or four lanes per packet (the instances with registers to spare), records of one size, whole group-iterations, no AAD, aligned: no per-iteration tests
@@ -128,7 +166,7 @@ HD uint4 pktg_lane(const KeyMaterial *__restrict__ km, const PktParams &p, const
         uint4 gin;
         if (j < n_aad) {
             const u32 off = 16 * j, rem = q.aad_len - off;
-            gin = rem >= 16 ? gload16_any(p.aad + q.aoff + off) : load_block_bytes(p.aad + q.aoff + off, rem);
+            gin = rem >= 16 ? gload16_any(aadp + off) : load_block_bytes(aadp + off, rem);
         } else {
             const u32 i = j - n_aad, off = 16 * i, rem = q.pkt_len - off;
             const bool full = rem >= 16;                                                // a whole block is one access at any address (gload16_any)
@@ -180,21 +218,20 @@ template <int NR, int DEC, bool T4 = false, bool ILP = false>
 HD void pktl_lane(const KeyMaterial *__restrict__ km, const PktParams &p, const unsigned char *smem, u32 pkt, u32 lane) {
     const u32 *__restrict__ rk = km->rk;
     const u32 lb = (lane & 31u) << 2;
-    u32 pkt_len = p.pkt_len, aad_len = p.aad_len;
-    u64 doff = (u64)pkt * p.pkt_len, aoff = (u64)pkt * p.aad_len;
-    if (p.data_off) { doff = p.data_off[pkt]; pkt_len = (u32)(p.data_off[pkt + 1] - doff); }
-    if (p.aad_off) { aoff = p.aad_off[pkt]; aad_len = (u32)(p.aad_off[pkt + 1] - aoff); }
+    u32 pkt_len, aad_len;
+    u64 doff, ooff, aoff;
+    pkt_place(p, pkt, &doff, &ooff, &aoff, &pkt_len, &aad_len);
     const unsigned char *ivp = p.ivs + (size_t)pkt * 12;
     const CtrConsts cc = ctr_round1_consts(load_le32(ivp), load_le32(ivp + 4), load_le32(ivp + 8), rk, smem, lb);
     uint4 acc = make_uint4(0, 0, 0, 0);
-    const unsigned char *a = p.aad + aoff;
+    const unsigned char *a = pkt_at(p.aad, aoff);
     for (u32 left = aad_len; left; ) {
         const u32 nb = left < 16 ? left : 16;
         acc = ghash_mul_const_lds(xor4(acc, nb == 16 ? gload16_any(a) : load_block_bytes(a, nb)), smem);
         a += nb; left -= nb;
     }
-    const unsigned char *src = p.in + doff;
-    unsigned char *dst = p.out + doff;
+    const unsigned char *src = pkt_at(p.in, doff);
+    unsigned char *dst = pkt_at(p.out, ooff);
     u32 ctr = 2, left = pkt_len;
     // whole groups of AESGCM_PKTL_GROUP blocks: the lane reads and writes 64 contiguous bytes at a time, so a cache
     // line is touched twice and not eight times (lanes of a wave are a packet apart: nothing coalesces across lanes).

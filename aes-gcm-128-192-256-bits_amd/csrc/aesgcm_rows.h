@@ -58,7 +58,25 @@
 #define ROWS_REC_WEIGH 2u
 
 struct RowsRec { G128 w; u64 e; u32 msg; u32 flags; };     // one piece: 32 bytes
-struct RowsHdr { u64 G; u32 D, NB, dyn, bad, pad[10]; };    // the cut of a call with offset arrays, made by k_rows_plan (bad: it does not fit the scratch -- nothing runs)
+// What the device decides about a call whose lengths are on the device (64 bytes of the context's scratch, rewritten by every such call):
+//   * by k_len_scan (round 6, the ROUTE of the call): route_min -- messages of at least this many bytes (data + AAD) go by rows, the others to the packet kernels --,
+//     n_small (how many take the packet kernels: the first n_small entries of the launch order `perm`), pkt_lg / pkt_deal (the packet kernel shape for that count and
+//     its packets per dispenser fetch), pkt_counter (that launch's dispenser, zero again);
+//   * by k_rows_plan*: the cut (G, D, NB, dyn) and the verdict: bad != 0 -- NOTHING of the call runs (every kernel behind the plan returns at once, outputs and tags are
+//     untouched) -- with the reason in status / detail, which the plan also stores in the context's pinned host slot (aesgcm_ctx_status).
+struct RowsHdr { u64 G; u32 D, NB, dyn, bad; u32 route_min, n_small, pkt_lg, pkt_deal, pkt_counter, status; u64 detail; u32 pad[2]; };
+static_assert(sizeof(RowsHdr) == 64, "RowsHdr: one 64-byte line");
+#define ROWS_LEN_LIMIT (1ull << 28)           /* a message's data and its AAD: each below this (include/aesgcm.h) */
+#define ROWS_ST_OK 0u
+#define ROWS_ST_PLAN_FIT 1u                   /* AESGCM_STATUS_PLAN: the plan does not fit the scratch the host sized for it */
+#define ROWS_ST_LENGTH 2u                     /* AESGCM_STATUS_LENGTH: a length of 2^28 bytes or more, or offsets that do not rise (detail: the first such message) */
+#define ROWS_ST_UNITS 3u                      /* AESGCM_STATUS_UNITS: the cut does not fit 32-bit block numbers */
+#define ROWS_ROUTE_NEVER 0xFFFFFFFFu          /* route_min: nothing goes by rows */
+// where the sizes of a launch order (k_len_*) come from: offset arrays (aoff NULL: fixed aad_len) or per-message length arrays
+struct LenSrc { const u64 *off, *aoff; const u32 *len_arr, *alen_arr; u32 aad_len; };
+// how k_len_scan routes a call: hdr NULL = no route (a plain launch order); marks as length classes (64 bytes each; >= PKT_LEN_CLASSES = never by rows): c_hi while more than
+// `few` messages lie below it, else c_lo; force_lg != 0xFF / force_deal != 0: the debug library's forced packet kernel shape
+struct RouteCfg { RowsHdr *hdr; u32 n, n_cu, c_hi, c_lo, few, force_lg, force_deal; };
 
 struct RowsParams {
     const unsigned char *ivs;                 // n_pkts * 12 bytes
@@ -89,14 +107,29 @@ struct RowsParams {
     u32 *cnt;                                 // per message: pieces arrived (k_rows_close; the number due is rows_pieces)
     u32 *queues;                              // ROWS_NQ dispensers, 16 u32 apart
     u32 prio_rows;                            // rotate the waves' issue priorities every so many rows (one block per wave: equal shares must also run at equal speed)
+    u32 routed;                               // 1: the call is ROUTED per message (hdr->route_min, made by k_len_scan): messages below it are the packet kernels', the row launches see them as nothing
 };
 
 // ---- geometry (host, planner and kernels agree through these) -------------------------------------
-struct RowsGeom { u32 R, Q, rho, tb; };
+struct RowsGeom { u32 R, Q, rho, tb, pk; };     // pk: the message is the packet kernels' (a routed call, below route_min): no unit, no smalls block, no record slot, no arrival here
 HD RowsGeom rows_geom(u64 len) {
     RowsGeom g;
     g.R = (u32)(len >> 10); g.Q = g.R >> 2; g.rho = g.R & 3u;
     g.tb = ((u32)(len & 1023u) + 15u) >> 4;
+    g.pk = 0;
+    return g;
+}
+// the size a routed call goes by: data + AAD (a lane of the packet kernels walks both, block by block); saturating, so that lengths beyond the limit -- which the plan refuses -- route somewhere defined
+HD u32 rows_route_size(u64 len, u64 alen) { const u64 t = len + alen; return t < len || t > 0xFFFFFFFEull ? 0xFFFFFFFEu : (u32)t; }
+HD u32 len_src_size(const LenSrc &s, u32 i) {
+    const u64 len = s.len_arr ? (u64)s.len_arr[i] : s.off[i + 1] - s.off[i];
+    const u64 alen = s.len_arr ? (s.alen_arr ? (u64)s.alen_arr[i] : 0ull) : s.aoff ? s.aoff[i + 1] - s.aoff[i] : (u64)s.aad_len;
+    return rows_route_size(len, alen);
+}
+HD bool rows_is_small(u64 len, u64 alen, u32 route_min) { return rows_route_size(len, alen) < route_min; }
+HD RowsGeom rows_geom_routed(u64 len, u64 alen, u32 route_min) {
+    RowsGeom g = rows_geom(len);
+    if (rows_is_small(len, alen, route_min)) { g.R = g.Q = g.rho = g.tb = 0; g.pk = 1; }
     return g;
 }
 HD u32 rows_na(u32 alen) { return (alen + 15u) >> 4; }                                   // AAD blocks
@@ -104,11 +137,11 @@ HD u32 rows_long_aad(u32 na) { return na > ROWS_SMALL_AAD ? 1u : 0u; }
 HD u32 rows_small_aad(u32 na) { return na > ROWS_SMALL_AAD ? 0u : na; }
 HD u32 rows_long_tail(const RowsGeom &g) { return g.tb > ROWS_SMALL_TAIL ? 1u : 0u; }
 HD u32 rows_small_tail(const RowsGeom &g) { return g.tb > ROWS_SMALL_TAIL ? 0u : g.tb; }
-HD u32 rows_units(const RowsGeom &g, u32 na) { return g.R + rows_long_tail(g) + rows_long_aad(na); }      // units of the row launch: the rows, the long tail, the long AAD (0 for a short message: only the closing sees it)
-HD u32 rows_smalls(const RowsGeom &g, u32 na) { return rows_small_aad(na) + rows_small_tail(g); }         // blocks on the smalls axis: the (short) AAD, then the (short) tail
+HD u32 rows_units(const RowsGeom &g, u32 na) { return g.pk ? 0u : g.R + rows_long_tail(g) + rows_long_aad(na); }      // units of the row launch: the rows, the long tail, the long AAD (0 for a short message: only the closing sees it)
+HD u32 rows_smalls(const RowsGeom &g, u32 na) { return g.pk ? 0u : rows_small_aad(na) + rows_small_tail(g); }         // blocks on the smalls axis: the (short) AAD, then the (short) tail
 // the natural segment of unit u of a message: its rows (when it has any), then the long tail, then the long AAD
 HD u32 rows_nat(const RowsGeom &g, u32 u) { return u < g.R ? 0u : (g.R ? 1u : 0u) + (u - g.R); }
-HD u32 rows_nat_count(const RowsGeom &g, u32 na) { return (g.R ? 1u : 0u) + rows_long_tail(g) + rows_long_aad(na); }
+HD u32 rows_nat_count(const RowsGeom &g, u32 na) { return g.pk ? 0u : (g.R ? 1u : 0u) + rows_long_tail(g) + rows_long_aad(na); }
 // record slots of a message whose units are [g0, g0 + U): a slot per (natural segment, block) pair it can have -- slot = base + nat + (block - first block)
 HD u32 rows_slots(const RowsGeom &g, u32 na, u64 g0, u32 D) {
     const u32 U = rows_units(g, na);
@@ -117,11 +150,11 @@ HD u32 rows_slots(const RowsGeom &g, u32 na, u64 g0, u32 D) {
 // arrivals k_rows_close counts for a message: the pieces it falls into under the cut -- its run of rows one per block it touches, the long tail, the long AAD --,
 // its blocks of the smalls axis, and the message's own lane
 HD u32 rows_pieces(const RowsGeom &g, u32 na, u64 g0, u32 D) {
-    return (g.R ? (u32)((g0 + g.R - 1u) / D - g0 / D) + 1u : 0u) + rows_long_tail(g) + rows_long_aad(na) + rows_smalls(g, na) + 1u;
+    return (g.R ? (u32)((g0 + g.R - 1u) / D - g0 / D) + 1u : 0u) + rows_long_tail(g) + rows_long_aad(na) + rows_smalls(g, na) + 1u;      // (never asked for a message of the packet kernels: nothing of it arrives here)
 }
 // the cut of a call of G units for `waves` waves: one block per wave while that is at most ROWS_STATIC_MAX units (or when the dealt cut would not fit the
 // scratch: nb_cap blocks), else blocks of ROWS_DYN_BLOCK units from the dispensers.  force_d > 0: dealt blocks of that many units (tests)
-HD void rows_cut(u64 G, u32 waves, u32 force_d, u64 nb_cap, u32 *D, u32 *NB, u32 *dyn) {
+HD bool rows_cut(u64 G, u32 waves, u32 force_d, u64 nb_cap, u32 *D, u32 *NB, u32 *dyn) {
     if (waves < 1) waves = 1;
     u64 d = (G + waves - 1u) / waves;
     u32 dy = 0;
@@ -129,6 +162,7 @@ HD void rows_cut(u64 G, u32 waves, u32 force_d, u64 nb_cap, u32 *D, u32 *NB, u32
     const u64 dd = force_d ? force_d : ROWS_DYN_BLOCK;
     if ((force_d || d > ROWS_STATIC_MAX) && (G + dd - 1u) / dd <= nb_cap) { d = dd; dy = 1; }
     *D = (u32)d; *NB = (u32)((G + d - 1u) / d); *dyn = dy;
+    return d <= 0xFFFFFFFFull && (G + d - 1u) / d <= 0xFFFFFFFFull;                    // false: the cut does not fit its 32-bit numbers (ROWS_ST_UNITS; more rows than any memory holds)
 }
 // the message's lengths and where it lies: offsets from the call's in / out / aad (the scattered form: from 0, i.e. addresses)
 struct RowsMsg { u64 doff, ooff, aoff; u32 len, alen; };
@@ -146,6 +180,9 @@ HD RowsMsg rows_msg(const RowsParams &p, u32 m) {
     q.ooff = q.doff;
     return q;
 }
+// (the (u32) casts above are safe: k_rows_plan* refuses a call -- hdr->bad, nothing runs -- in which any length or offset difference is 2^28 or more)
+HD u32 rows_route_min(const RowsParams &p) { return p.routed ? p.hdr->route_min : 0u; }
+HD RowsGeom rows_geom_of(const RowsMsg &q, u32 route_min) { return rows_geom_routed(q.len, q.alen, route_min); }
 HD const unsigned char *rows_src(const RowsParams &p, const RowsMsg &q) { return reinterpret_cast<const unsigned char *>((uintptr_t)p.in + q.doff); }
 HD unsigned char *rows_dst(const RowsParams &p, const RowsMsg &q) { return reinterpret_cast<unsigned char *>((uintptr_t)p.out + q.ooff); }
 HD const unsigned char *rows_aadp(const RowsParams &p, const RowsMsg &q) { return reinterpret_cast<const unsigned char *>((uintptr_t)p.aad + q.aoff); }

@@ -493,7 +493,7 @@ HD uint4 fold_wg_lane(const unsigned char *smem, u32 J, u32 lane) {
 static inline u64 fold_out_step(const FoldParams &p) { return FOLD_WAVES * p.eC; }
 // fill the constants of a level: items eA blocks apart (period 1), or phases eA apart and periods eB apart
 static inline void plan_fold(FoldParams &p, const uint4 *in, uint4 *out, u32 n, u32 period, u64 eA, u64 eB) {
-    p.close.on = 0;
+    p.close = FoldClose{};                                       // (all of it: a level that does not close carries no stale pointers -- the fake runtime checks every pointer a launch carries)
     p.in = in; p.out = out; p.n = n; p.period = period; p.eA = eA; p.eB = period > 1 ? eB : 0;
     p.group = fold_group(n, period);
     p.eC = period > 1 ? (p.group / period) * eB : p.group * eA;

@@ -14,7 +14,9 @@ OK, EARG, EKEYLEN, EIVLEN, ETOOLONG, EAUTH, EHIP, ENOMEM, ESTATE, EALIGN, ERCCL 
 
 LAUNCH_NONE, LAUNCH_MAIN, LAUNCH_CYCLIC, LAUNCH_CYCLIC_HALF, LAUNCH_DEALT = range(5)      # aesgcm_ctx_last_launch
 SHAPE_ROWS = 1 << 20    # AESGCM_SHAPE_ROWS: what packets_shape says for calls that go by rows
-ABI_VERSION = 4         # AESGCM_ABI_VERSION of include/aesgcm.h this binding was written against
+SHAPE_MIXED = 1 << 21   # AESGCM_SHAPE_MIXED: ... for calls with offset arrays: every message is routed by its own size on the device
+STATUS_OK, STATUS_PLAN, STATUS_LENGTH, STATUS_UNITS = range(4)      # aesgcm_ctx_status
+ABI_VERSION = 5         # AESGCM_ABI_VERSION of include/aesgcm.h this binding was written against
 
 # every symbol include/aesgcm.h declares (tests check the .so exports exactly these)
 SYMBOLS = [
@@ -35,6 +37,7 @@ SYMBOLS = [
     "aesgcm_comm_allreduce_f64", "aesgcm_comm_barrier", "aesgcm_comm_destroy",
     "aesgcm_mgpu_create", "aesgcm_mgpu_ranks", "aesgcm_mgpu_ctx", "aesgcm_mgpu_crypt_dev", "aesgcm_mgpu_destroy",
     "aesgcm_ctx_last_launch", "aesgcm_wipe_failed_dev", "aesgcm_mgpu_last_tags", "aesgcm_mgpu_sync", "aesgcm_batch_ceiling_probe_dev",
+    "aesgcm_ctx_status",
 ]
 
 
@@ -178,6 +181,7 @@ def _typed(L):
     L.aesgcm_ctx_last_launch.argtypes = [vp, ctypes.POINTER(cint)]
     L.aesgcm_wipe_failed_dev.argtypes = [cint, sz, vp, sz, vp, vp, vp]
     L.aesgcm_batch_ceiling_probe_dev.argtypes = [cint, sz, sz, vp, vp, sz, vp, vp]
+    L.aesgcm_ctx_status.argtypes = [vp, ctypes.POINTER(cint), ctypes.POINTER(u64)]
     if L.aesgcm_abi_version() != ABI_VERSION:
         raise ImportError("libaesgcm_hip.so ABI %d, expected %d (stale build? rebuild with `make -C csrc`)" % (L.aesgcm_abi_version(), ABI_VERSION))
     return L
@@ -458,9 +462,16 @@ class Context:
         _chk(self._lib.aesgcm_ctx_last_launch(self._c, ctypes.byref(v)))
         return v.value
 
+    def status(self):
+        """aesgcm_ctx_status -> (code, detail): what an asynchronous call on this context (packets with offset arrays, messages) was refused for on the device --
+        STATUS_LENGTH / STATUS_PLAN / STATUS_UNITS, detail = the first offending message for LENGTH -- or (STATUS_OK, 0).  Reading clears it.  Synchronise first."""
+        code, detail = cint(0), u64(0)
+        _chk(self._lib.aesgcm_ctx_status(self._c, ctypes.byref(code), ctypes.byref(detail)))
+        return code.value, detail.value
+
     def packets_shape(self, n_pkts, pkt_len=0, var_len=False):
-        """lanes per packet packets_crypt_dev takes for such a call: 1 (k_pktl), 4 / 8 / 16 or 64 (k_pktg), or SHAPE_ROWS: by rows (k_rows; with offset arrays
-        pkt_len is the caller's hint of the typical packet)"""
+        """lanes per packet packets_crypt_dev takes for such a call: 1 (k_pktl), 4 / 8 / 16 or 64 (k_pktg), or SHAPE_ROWS: by rows (k_rows); with offset arrays
+        (var_len) SHAPE_MIXED: every message is routed by its own size on the device, pkt_len is ignored"""
         v = cint(0)
         _chk(self._lib.aesgcm_packets_shape(self._c, n_pkts, pkt_len, int(bool(var_len)), ctypes.byref(v)))
         return v.value
@@ -722,7 +733,7 @@ class MultiGpu:
         return tag.raw if want_tag else None
 
     def last_tags(self, n):
-        """the tags of the last n messages queued with want_tag=False, oldest first (one finalize launch on the first device)"""
+        """the tags of the OLDEST n messages still queued (want_tag=False), in the order queued; they leave the queue, the rest stays (one finalize launch on the first device)"""
         t = ctypes.create_string_buffer(16 * n)
         _chk(load().aesgcm_mgpu_last_tags(self._m, n, t))
         return [t.raw[16 * k:16 * k + 16] for k in range(n)]

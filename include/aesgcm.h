@@ -37,7 +37,10 @@
 extern "C" {
 #endif
 
-#define AESGCM_ABI_VERSION 4   /* 4 (round 5): packets of message size by rows (AESGCM_SHAPE_ROWS), aesgcm_messages_crypt_dev, aesgcm_ctx_last_launch, aesgcm_wipe_failed_dev and the option "wipe_on_auth_fail",
+#define AESGCM_ABI_VERSION 5   /* 5 (round 6): calls with offset arrays and aesgcm_messages_crypt_dev are ROUTED per message on the device (AESGCM_SHAPE_MIXED; pkt_len is no longer a hint),
+                                  aesgcm_ctx_status (what an asynchronous call could not say when it returned), aesgcm_stream_export / _import / _update_dev, aesgcm_frames_ceiling_probe_dev,
+                                  aesgcm_mgpu_last_tags collects the OLDEST queued messages;
+                                  4 (round 5): packets of message size by rows (AESGCM_SHAPE_ROWS), aesgcm_messages_crypt_dev, aesgcm_ctx_last_launch, aesgcm_wipe_failed_dev and the option "wipe_on_auth_fail",
                                   aesgcm_mgpu_crypt_dev with tag = NULL + aesgcm_mgpu_last_tags / aesgcm_mgpu_sync;
                                   2: aesgcm_ctx_wait, aesgcm_comm_* / aesgcm_mgpu_*, packet and batch entry points; 3: aesgcm_ctx_set_option (the library no longer reads
                                   any environment variable), aesgcm_batch_shape / aesgcm_packets_shape, aesgcm_mgpu_ctx, aesgcm_last_tag through the host slot */
@@ -131,13 +134,15 @@ AESGCM_API int aesgcm_ctx_last_launch(const aesgcm_ctx *ctx, int *shape);
  *                 messages in flight on contexts of their own; a single message alone on the chip is slower in that shape
  *   "fold_close"  1: behind the dealt k_body a k_fold level closes the tag; 0: further levels and k_combine
  *   "cyc_prio"    rows between rotations of the waves' issue priorities in a cyclic launch, 0 = off
- *   "pkt_order"   packets from which aesgcm_packets_crypt_dev with offset arrays takes the packets by falling length class (a counting sort on the
- *                 device in front of the launch; default 98304, where it starts to pay), 0 = never.  The results are the same bytes.
+ *   "pkt_order"   accepted and ignored since round 6 (it was the packet count from which a call with offset arrays took its packets by falling length class: the
+ *                 routing sort of such a call makes that order anyway)
  *   "wipe_on_auth_fail"  1: a decrypt call that verifies a tag (expect_tag / d_expect_tags) leaves ZEROS, not unauthenticated plaintext, where verification fails:
  *                 aesgcm_decrypt and aesgcm_decrypt_pipelined wipe the caller's buffer (aesgcm_decrypt does not even copy the plaintext out before the tag is
- *                 checked), aesgcm_decrypt_dev the device buffer, aesgcm_packets_crypt_dev every packet whose d_auth entry is 0 (d_auth must be given).  Default 0:
+ *                 checked), aesgcm_decrypt_dev the device buffer, aesgcm_packets_crypt_dev / aesgcm_messages_crypt_dev every packet whose d_auth entry is 0 (d_auth must be given:
+ *                 AESGCM_EARG for a decrypt call with d_expect_tags and without d_auth while the option is on).  Default 0:
  *                 the reference model returns the plaintext and raises (tb/gcm_model.py:29-30,47-51), and so does the class that mirrors it.
- *   "rows_min"    bytes per packet from which aesgcm_packets_crypt_dev goes by rows (default 8192; from a quarter of it while the packets are at most 16384; 0 = never)
+ *   "rows_min"    bytes per packet from which aesgcm_packets_crypt_dev goes by rows (default 8192; from a quarter of it while the packets below it are at most 16384; 0 = never).
+ *                 With offset arrays the mark is applied per message on the device, to data + AAD, in steps of 64 bytes and up to 16320
  *   "rows_block"  units (rows of 64 blocks) per dealt block of the row kernel, 0 = the library's cut (one block per wave; blocks of 64 for large calls)
  *   "poll_us"     how long a tag is polled for in the pinned host slot before the call blocks in the runtime
  * AESGCM_EARG for an unknown key. */
@@ -156,6 +161,19 @@ AESGCM_API int aesgcm_ctx_wait(aesgcm_ctx *ctx, aesgcm_ctx *other);
  * lets every fold / combine tail but the last hide behind the next message.  Tracking starts with the first call (which,
  * like any call made before other has launched a fused kernel, waits for nothing). */
 AESGCM_API int aesgcm_ctx_wait_fused(aesgcm_ctx *ctx, aesgcm_ctx *other);
+/* What an ASYNCHRONOUS call could not say when it returned (round 6).  aesgcm_packets_crypt_dev with offset arrays and aesgcm_messages_crypt_dev read their lengths on the
+ * device, behind the call: when the plan kernel finds one it cannot take -- the RTL raises a flag when its counter cannot go on (src/aes_icb.vhd:65,98,114,119) -- NOTHING
+ * of that call runs (outputs, tags and d_auth are left as they were) and the reason goes to a status word in the context's pinned host memory, next to its tag slot:
+ *   AESGCM_STATUS_LENGTH   a message's data or AAD is 2^28 bytes or more, or an offset array does not rise; *detail = the first such message
+ *   AESGCM_STATUS_PLAN     the call's plan does not fit the scratch the library sized for it; *detail = the record slots it asked for
+ *   AESGCM_STATUS_UNITS    more rows than 32-bit block numbers hold; *detail = the rows
+ * aesgcm_ctx_status reads the word and clears it (no wait: synchronise the stream the call ran on first -- a status is there when that stream has drained); 0 = nothing
+ * to report.  While a status is unread, aesgcm_last_tag and aesgcm_ctx_wait on the context return AESGCM_ETOOLONG (LENGTH, UNITS) or AESGCM_ESTATE (PLAN). */
+#define AESGCM_STATUS_OK     0
+#define AESGCM_STATUS_PLAN   1
+#define AESGCM_STATUS_LENGTH 2
+#define AESGCM_STATUS_UNITS  3
+AESGCM_API int aesgcm_ctx_status(aesgcm_ctx *ctx, int *code, uint64_t *detail);
 
 /* ---------------------------------------------------------------- whole messages, host pointers
  * Replaces the model's update/encrypt/digest sequence (tb/gcm_model.py:21-35) i.e. the aes_gcm
@@ -263,8 +281,9 @@ AESGCM_API int aesgcm_mgpu_ctx(aesgcm_mgpu *m, int g, aesgcm_ctx **out);     /* 
 AESGCM_API int aesgcm_mgpu_crypt_dev(aesgcm_mgpu *m, int decrypt, const uint8_t iv[12], const void *d_aad_on_dev0, size_t aad_len,
                           const void *const *d_in, const size_t *shard_len, void *const *d_out, uint8_t tag[16]);
 /* tag = NULL in aesgcm_mgpu_crypt_dev only ENQUEUES the message -- shards, the all-gather -- without a host synchronisation on any device; up to 8 such messages may
- * wait.  aesgcm_mgpu_last_tags finalizes the last n of them in one launch on devices[0] and returns their tags, oldest first (16 n bytes); aesgcm_mgpu_sync drains
- * every device's stream (before the outputs are read by anything not ordered behind those streams).  AESGCM_ESTATE when a ninth message is queued. */
+ * wait.  The queue is a FIFO: aesgcm_mgpu_last_tags finalizes the OLDEST n of them in one launch on devices[0] and returns their tags in the order they were queued (16 n bytes;
+ * n may be less than what waits: the rest stays queued); aesgcm_mgpu_sync drains every device's stream (before the outputs are read by anything not ordered behind those
+ * streams).  AESGCM_ESTATE when a ninth message is queued, and when a call with tag != NULL is made while messages wait (it would have to jump the queue). */
 AESGCM_API int aesgcm_mgpu_last_tags(aesgcm_mgpu *m, size_t n, uint8_t *tags);
 AESGCM_API int aesgcm_mgpu_sync(aesgcm_mgpu *m);
 AESGCM_API int aesgcm_mgpu_destroy(aesgcm_mgpu *m);
@@ -275,28 +294,28 @@ AESGCM_API int aesgcm_mgpu_destroy(aesgcm_mgpu *m);
  * and data either as fixed-size records (aad_len / pkt_len, offset arrays NULL) or delimited by uint64 offset
  * arrays with n_pkts + 1 entries (then aad_len / pkt_len are ignored); tags[p] receives the computed tag; for
  * decrypt d_auth[p] (optional) = 1 if it equals d_expect_tags[p].  Asynchronous on `stream`.
- * Packets of message size -- from 8 KiB each (context option "rows_min"; from 2 KiB while there are at most 16384 of them; many fixed-size packets below 16 KiB whose last
- * partial row is longer than 4 blocks stay with the packet kernels), up to 2^28 - 1 bytes -- go BY ROWS (round 5): the 64-block rows of all the
- * call's messages are one pool of work for the row loop a single large message runs through (csrc/aesgcm_rows.h), and one small launch behind it takes what
- * is not a whole row -- headers, ragged ends -- block by block and closes every tag; 4096 x 1 MiB then runs at the rate of one 4 GiB message.  With offset arrays the lengths are on the device and the library cannot see them:
- * there pkt_len -- otherwise unused in that form -- is the caller's word for the TYPICAL packet size and selects the path (0 = frames; any packet, of any
- * length, is correct on either path).  Shorter packets take the packet kernels: at most a wave per packet.
- * With offset arrays and many packets (context option "pkt_order", default from 98304) the launch takes the packets in the order of a
- * counting sort by length class, made on the device in front of it (three small launches on `stream`, 4 bytes per packet of scratch in
- * the context): the lanes of a wave run to the longest packet among them, and frames of mixed length in arrival order leave half of
- * them idle.  Which packet a lane takes never shows in the results. */
+ * Two families of kernels do the work.  Packets of message size -- from 8 KiB each (context option "rows_min"; from 2 KiB while at most 16384 packets lie below that), up to
+ * 2^28 - 1 bytes -- go BY ROWS (round 5): the 64-block rows of all such messages are one pool of work for the row loop a single large message runs through
+ * (csrc/aesgcm_rows.h), and one small launch behind it takes what is not a whole row -- headers, ragged ends -- block by block and closes every tag; 4096 x 1 MiB then runs
+ * at the rate of one 4 GiB message.  Shorter packets take the packet kernels: a lane, or a group of 4 .. 16 lanes, per packet.
+ * FIXED-SIZE records: the host knows the one size and the whole call goes one way (many records of 8 .. 16 KiB whose last partial row is longer than 4 blocks stay with the
+ * packet kernels).  OFFSET ARRAYS: the lengths are on the device, and so is the choice -- every message is ROUTED BY ITS OWN SIZE (data + AAD) inside the one call (round 6):
+ * a counting sort by size class on the device (three small launches on `stream`) splits the call at the mark, hands the short messages to the packet kernels longest first
+ * (the lanes of a wave run to the longest packet among them) and the others to the rows; which path a message takes never shows in its bytes or its tag.  The reference's
+ * own traffic is of both kinds at once (tb/gcm_gctr.py:279-281: lengths from a U-shaped distribution).  pkt_len is IGNORED with offset arrays (until round 5 it was a hint
+ * that sent the whole call one way).  Lengths of 2^28 bytes or more, or offsets that do not rise, are found on the device: nothing of the call runs then, see aesgcm_ctx_status. */
 AESGCM_API int aesgcm_packets_crypt_dev(aesgcm_ctx *ctx, int decrypt, size_t n_pkts, const void *d_ivs,
                              const void *d_aad, size_t aad_len, const uint64_t *d_aad_off,
                              const void *d_in, size_t pkt_len, const uint64_t *d_data_off, void *d_out,
                              void *d_tags, const void *d_expect_tags, int *d_auth, void *stream);
 
-/* Messages WHEREVER THEY LIVE under the context's key (round 5): the same work as aesgcm_packets_crypt_dev by rows, but every message has its own buffers --
+/* Messages WHEREVER THEY LIVE under the context's key (round 5): the same work as aesgcm_packets_crypt_dev with offset arrays, but every message has its own buffers --
  * the reference's harness hands the core one frame after the other, each its own object (tb/gcm_test.py:76-85, tb/gcm_gctr.py:233-276); a caller with a queue
  * of messages in separate allocations has exactly that, and copying them into one buffer to batch them would cost what the batch saves.  All arrays are in
  * device memory, n_msgs entries each: d_in_ptr / d_out_ptr device addresses of the messages' input and output (in == out allowed), d_len their lengths
  * (each < 2^28 bytes), d_aad_ptr / d_aad_len the same for AAD (both NULL: none); d_ivs n_msgs x 12 bytes, d_tags n_msgs x 16; decrypt: d_expect_tags / d_auth
- * as aesgcm_packets_crypt_dev.  Always by rows (any number, any size -- a call of a few hundred tiny messages is better served by the packet kernels through
- * aesgcm_packets_crypt_dev); the context option "wipe_on_auth_fail" applies.  Asynchronous on `stream`. */
+ * as aesgcm_packets_crypt_dev.  Routed per message like the offset-array form (round 6: until then always by rows, and a call of tiny messages paid for it); the
+ * context option "wipe_on_auth_fail" applies; a length of 2^28 or more is reported through aesgcm_ctx_status.  Asynchronous on `stream`. */
 AESGCM_API int aesgcm_messages_crypt_dev(aesgcm_ctx *ctx, int decrypt, size_t n_msgs, const void *d_ivs,
                               const uint64_t *d_aad_ptr, const uint32_t *d_aad_len,
                               const uint64_t *d_in_ptr, const uint32_t *d_len, const uint64_t *d_out_ptr,
@@ -324,9 +343,11 @@ AESGCM_API int aesgcm_wipe_failed_dev(int device, size_t n_pkts, void *d_out, si
 AESGCM_API int aesgcm_batch_ceiling_probe_dev(int device, size_t n_pkts, size_t key_len, const void *d_keys, const void *d_ivs, size_t pkt_len, void *d_tags, void *stream);
 
 /* Which kernel shape a call with these arguments takes: lanes per packet (1 = one lane per packet, 4 / 8 / 16 = a lane group, 64 = a
- * whole wave; aesgcm_packets_shape: AESGCM_SHAPE_ROWS = by rows, every message over the whole chip).  var_len != 0 describes the offset-array forms
- * (the host does not know the lengths and goes by count; pkt_len is then the caller's hint of the typical size, as in aesgcm_packets_crypt_dev). */
+ * whole wave; aesgcm_packets_shape: AESGCM_SHAPE_ROWS = by rows, every message over the whole chip).  var_len != 0 describes the offset-array forms:
+ * aesgcm_batch_shape goes by count (the host does not know the lengths); aesgcm_packets_shape answers AESGCM_SHAPE_MIXED -- every message is routed by
+ * its own size on the device, by rows or to the packet kernel shape chosen there for the count of short ones (pkt_len is ignored). */
 #define AESGCM_SHAPE_ROWS (1 << 20)
+#define AESGCM_SHAPE_MIXED (1 << 21)
 AESGCM_API int aesgcm_batch_shape(int device, size_t n_pkts, size_t pkt_len, int var_len, int *lanes_per_packet);
 AESGCM_API int aesgcm_packets_shape(const aesgcm_ctx *ctx, size_t n_pkts, size_t pkt_len, int var_len, int *lanes_per_packet);
 

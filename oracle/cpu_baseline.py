@@ -183,6 +183,7 @@ def evp_batch_lib():
     L = ctypes.CDLL(so)
     vp, sz = ctypes.c_void_p, ctypes.c_size_t
     L.evp_batch_encrypt.argtypes = [sz, sz, vp, vp, vp, sz, vp, vp]
+    L.evp_frames_crypt.argtypes = [sz, sz, vp, vp, vp, vp, ctypes.c_uint64, vp, vp, ctypes.c_uint64, vp, vp]
     return L
 
 

@@ -229,6 +229,7 @@ hipError_t klaunch_combine_batch(unsigned n, hipStream_t st, const KeyMaterial *
 }
 static void pkt_ptrs(const char *W, const KeyMaterial *km, const DevTables *tb, const PktParams &p) {
     P(km); P(tb); P(p.ivs); P(p.aad); P(p.in); P(p.out); P(p.tags); P(p.expect); P(p.auth); P(p.data_off); P(p.aad_off); P(p.counter); P(p.perm);
+    P(p.in_ptr); P(p.out_ptr); P(p.aad_ptr); P(p.len_arr); P(p.alen_arr); P(p.route);
 }
 hipError_t klaunch_pktl(int, int, bool, unsigned, hipStream_t st, const KeyMaterial *km, const DevTables *tb, const PktParams &p) { LAUNCH("k_pktl", st); BIG_LDS(); pkt_ptrs(W, km, tb, p); return hipSuccess; }
 hipError_t klaunch_pktg(int, int, int, unsigned, hipStream_t st, const KeyMaterial *km, const DevTables *tb, const PktParams &p) { LAUNCH("k_pktg", st); BIG_LDS(); pkt_ptrs(W, km, tb, p); return hipSuccess; }
@@ -236,9 +237,12 @@ hipError_t klaunch_batch3(int, int, int, unsigned, hipStream_t st, const DevTabl
     LAUNCH("k_batch3", st); BIG_LDS(); P(tb); P(p.keys); P(p.ivs); P(p.aad); P(p.in); P(p.out); P(p.tags); P(p.expect); P(p.auth); P(p.counter); P(p.data_off); P(p.aad_off); P(p.perm);
     return hipSuccess;
 }
-hipError_t klaunch_len_sort(hipStream_t st, const u64 *d_off, u32, u32 *bins, u32 *perm) { LAUNCH("k_len_*", st); P(d_off); P(bins); P(perm); return hipSuccess; }
-hipError_t klaunch_rows_plan(hipStream_t st, const u64 *d_off, u32, const u64 *d_aoff, u32, const u32 *d_len, const u32 *d_alen, u32, u32, u32, u32, u32, RowsHdr *hdr, u64 *prefix, u64 *sprefix, u32 *slot_base, u64 *part) {
-    LAUNCH("k_rows_plan", st); P(d_off); P(d_aoff); P(d_len); P(d_alen); P(part); P(hdr); P(prefix); P(sprefix); P(slot_base);
+hipError_t klaunch_len_sort(hipStream_t st, const LenSrc &src, u32, u32 *bins, u32 *perm, const RouteCfg &rc) {
+    LAUNCH("k_len_*", st); P(src.off); P(src.aoff); P(src.len_arr); P(src.alen_arr); P(bins); P(perm); P(rc.hdr);
+    return hipSuccess;
+}
+hipError_t klaunch_rows_plan(hipStream_t st, const RowsParams &p, u32, u32, u64 *part, u32 *host_status) {
+    LAUNCH("k_rows_plan", st); P(p.data_off); P(p.aad_off); P(p.len_arr); P(p.alen_arr); P(part); P(p.hdr); P(p.prefix); P(p.sprefix); P(p.slot_base); P(host_status);
     return hipSuccess;
 }
 static void rows_ptrs(const char *W, const KeyMaterial *km, const RowsParams &p) {

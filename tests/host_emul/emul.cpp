@@ -794,6 +794,9 @@ static void test_keystream_and_ghash(u64 seed) {
 // Many messages under one key by rows (k_rows / k_rows_close, csrc/aesgcm_rows.h): the cut (fixed-size records: arithmetic; offset arrays: the planner's two
 // prefix sums), every block in a scrambled order with the same piece walk and lane code as k_rows, the record slots of the closing in a scrambled order with plain
 // XORs for the atomics; ciphertext and tags against the oracle, and the zero-at-rest rule of the shared scratch.
+// g_route_min != 0 (offset arrays / scattered only): the call is ROUTED per message as k_len_scan + k_rows_plan do on the device (round 6) -- messages whose data + AAD
+// lie below the mark are the packet kernels' (here: pktl_lane, a lane each), the row launches must see them as nothing: no unit, no smalls block, no slot, no arrival
+static u32 g_route_min = 0;
 template <int NR>
 static void emu_rows_nr(const KeyMaterial *km, int dec, RowsParams &p, u32 waves, u32 force_d) {
     static unsigned char smem[AESGCM_LDS_BYTES_T4] __attribute__((aligned(16)));
@@ -804,19 +807,28 @@ static void emu_rows_nr(const KeyMaterial *km, int dec, RowsParams &p, u32 waves
     std::vector<u64> prefix(n + 1, 0), sprefix(n + 1, 0);
     std::vector<u32> slot_base(n + 1, 0);
     RowsHdr hdr;
+    memset(&hdr, 0, sizeof hdr);
     size_t slots;
-    if (p.data_off || p.aad_off || p.len_arr) {                          // k_rows_plan
+    const bool var = p.data_off || p.aad_off || p.len_arr;
+    const u32 route_min = var ? g_route_min : 0u;
+    u32 n_small = 0;
+    auto geom_m = [&](u32 m) { return rows_geom_of(rows_msg(p, m), route_min); };
+    if (var) {                                                           // k_rows_plan
+        hdr.route_min = route_min;
+        p.hdr = &hdr; p.routed = route_min ? 1u : 0u;
+        CHECK(rows_route_min(p) == route_min, "rows: route_min");
         for (u32 m = 0; m < n; m++) {
             const RowsMsg q = rows_msg(p, m);
-            prefix[m + 1] = prefix[m] + rows_units(rows_geom(q.len), rows_na(q.alen));
-            sprefix[m + 1] = sprefix[m] + rows_smalls(rows_geom(q.len), rows_na(q.alen));
+            if (geom_m(m).pk) { ++n_small; CHECK(rows_units(geom_m(m), rows_na(q.alen)) == 0 && rows_smalls(geom_m(m), rows_na(q.alen)) == 0 && rows_slots(geom_m(m), rows_na(q.alen), prefix[m], 7) == 0, "rows: a routed message counts"); }
+            prefix[m + 1] = prefix[m] + rows_units(geom_m(m), rows_na(q.alen));
+            sprefix[m + 1] = sprefix[m] + rows_smalls(geom_m(m), rows_na(q.alen));
         }
-        hdr.G = prefix[n];
+        hdr.G = prefix[n]; hdr.n_small = n_small;
         rows_cut(hdr.G, waves, force_d, ROWS_NB_CAP, &hdr.D, &hdr.NB, &hdr.dyn);
-        for (u32 m = 0; m < n; m++) { const RowsMsg q = rows_msg(p, m); slot_base[m + 1] = slot_base[m] + rows_slots(rows_geom(q.len), rows_na(q.alen), prefix[m], hdr.D); }
+        for (u32 m = 0; m < n; m++) { const RowsMsg q = rows_msg(p, m); slot_base[m + 1] = slot_base[m] + rows_slots(geom_m(m), rows_na(q.alen), prefix[m], hdr.D); }
         slots = ROWS_SLOTS_PER_MSG * (size_t)n + ROWS_NB_CAP;
         CHECK(slot_base[n] <= slots, "rows: %u slots planned, %zu held", slot_base[n], slots);
-        p.hdr = &hdr; p.prefix = prefix.data(); p.sprefix = sprefix.data(); p.slot_base = slot_base.data();
+        p.prefix = prefix.data(); p.sprefix = sprefix.data(); p.slot_base = slot_base.data();
     } else {
         const RowsGeom g = rows_geom(p.pkt_len);
         const u32 na = rows_na(p.aad_len);
@@ -847,7 +859,7 @@ static void emu_rows_nr(const KeyMaterial *km, int dec, RowsParams &p, u32 waves
         u32 m = rows_find_msg(p, g);
         while (g < g_end) {
             const RowsMsg mq = rows_msg(p, m);
-            const RowsGeom geo = rows_geom(mq.len);
+            const RowsGeom geo = geom_m(m);
             const u64 g0 = rows_unit_base(p, m);
             const u32 U = rows_units(geo, rows_na(mq.alen)), sbase = rows_slot_base(p, m);
             if (U == 0) { ++m; continue; }                                 // a message shorter than a row has no unit: the closing alone sees it
@@ -874,7 +886,7 @@ static void emu_rows_nr(const KeyMaterial *km, int dec, RowsParams &p, u32 waves
     }
     // k_rows_close: the lanes last first; lane i is message i (its length block and E_K(J0)), slot i, and the blocks i, i + lanes, ... of the smalls axis
     u32 finals = 0;
-    auto due = [&](u32 m) { const RowsMsg mq = rows_msg(p, m); return rows_pieces(rows_geom(mq.len), rows_na(mq.alen), rows_unit_base(p, m), D); };
+    auto due = [&](u32 m) { const RowsMsg mq = rows_msg(p, m); return rows_pieces(geom_m(m), rows_na(mq.alen), rows_unit_base(p, m), D); };
     auto arrive = [&](u32 m, const G128 &z) {
         acc[2 * m] ^= ((unsigned long long)z.w[0] << 32) | z.w[1]; acc[2 * m + 1] ^= ((unsigned long long)z.w[2] << 32) | z.w[3];
         if (++cnt[m] == due(m)) {
@@ -884,10 +896,22 @@ static void emu_rows_nr(const KeyMaterial *km, int dec, RowsParams &p, u32 waves
             ++finals;
         }
     };
+    // the messages of the packet kernels: a lane each (k_pktl), reading the same arrays
+    if (n_small) {
+        static unsigned char smem_h[AESGCM_LDS_BYTES] __attribute__((aligned(16)));
+        for (u32 tid = 0; tid < AESGCM_MAIN_WG; tid++) main_fill_lds(smem_h, km, &g_tb, tid, true, AESGCM_MAIN_WG, GH_TAB_H);
+        PktParams k; memset(&k, 0, sizeof k);
+        k.ivs = p.ivs; k.aad = p.aad; k.in = p.in; k.out = p.out; k.tags = p.tags; k.data_off = p.data_off; k.aad_off = p.aad_off; k.n_pkts = n; k.aad_len = p.aad_len; k.aligned = 1;
+        k.in_ptr = p.in_ptr; k.out_ptr = p.out_ptr; k.aad_ptr = p.aad_ptr; k.len_arr = p.len_arr; k.alen_arr = p.alen_arr;
+        for (u32 m = 0; m < n; m++) {
+            if (!geom_m(m).pk) continue;
+            if (dec) pktl_lane<NR, 1>(km, k, smem_h, m, (m * 5u) % 64u); else pktl_lane<NR, 0>(km, k, smem_h, m, (m * 5u) % 64u);
+        }
+    }
     const size_t lanes = slots > n ? slots : n;
     for (size_t k = 0; k < lanes; k++) {
         const size_t i = lanes - 1 - k;
-        if (i < n) arrive((u32)i, rows_msg_term(km, g_tb.te0, p, (u32)i));
+        if (i < n && !geom_m((u32)i).pk) arrive((u32)i, rows_msg_term(km, g_tb.te0, p, (u32)i));
         for (u64 t = i; t < rows_small_total(p); t += lanes) {
             G128 z;
             u64 e_run = 0;
@@ -901,10 +925,11 @@ static void emu_rows_nr(const KeyMaterial *km, int dec, RowsParams &p, u32 waves
         rec[i].flags = 0;
         arrive(r.msg, rows_weigh(km, r));
     }
-    CHECK(finals == n, "rows: %u of %u messages closed", finals, n);
+    CHECK(finals == n - n_small, "rows: %u of %u messages closed", finals, n - n_small);
     for (u32 m = 0; m < n; m++) {
         CHECK(!acc[2 * m] && !acc[2 * m + 1] && !cnt[m], "rows: message %u not zero at rest", m);
-        CHECK(made_of[m] + 1u == due(m), "rows: message %u fell into %u pieces", m, made_of[m]);
+        if (geom_m(m).pk) CHECK(made_of[m] == 0, "rows: message %u is the packet kernels' and fell into %u pieces here", m, made_of[m]);
+        else CHECK(made_of[m] + 1u == due(m), "rows: message %u fell into %u pieces", m, made_of[m]);
     }
 }
 // var: 0 fixed-size records, 1 offset arrays, 2 messages wherever they live (arrays of addresses and lengths: every message with a gap of its own in front, in and
@@ -1024,6 +1049,22 @@ int main(int argc, char **argv) {
     test_rows(32, 222, 6, 0, 2, rl, ra);                                         // messages wherever they live: the lengths of the first case, every message in buffers of its own
     test_rows(16, 223, 4, 2, 2, {16400, 0, 100, 16384 + 1023, 5000, 16, 2048 + 700, 65536 + 1}, {13, 0, 1024, 1025, 0, 20, 16, 0}, 7);
     test_rows(24, 224, 5, 0, 2, {4096, 0, 1024, 3000}, {0, 0, 0, 0});              // ... without AAD arrays
+    // ROUTED calls (round 6): the messages below the mark (data + AAD) are the packet kernels', the others go by rows -- the same lengths at three marks: a few
+    // small ones, most of them, all of them (no unit in the whole call)
+    for (u32 mark : {1024u, 4160u, 200000u}) {
+        g_route_min = mark;
+        test_rows(16, 230, 5, 0, true, rl, ra);
+        test_rows(32, 231, 4, 2, 2, {16400, 0, 100, 16384 + 1023, 5000, 16, 2048 + 700, 65536 + 1}, {13, 0, 1024, 1025, 0, 20, 16, 0}, 7);
+        test_rows(24, 232, 3, 0, true, {0, 0, 0, 2048, 0, 1024, 1024 + 1009, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0, 0});
+        g_route_min = 0;
+    }
+    for (u64 nn = 1, prev = 4; nn < (1u << 22); nn += 1 + nn / 7) {               // the packet kernel shape a routed call takes for nn short messages: never more lanes per packet as they get more
+        const u32 lg = route_pick_lg(256, nn);
+        CHECK((lg == 0 || lg == 2 || lg == 3 || lg == 4) && lg <= prev, "route_pick_lg(%llu) = %u after %llu", (unsigned long long)nn, lg, (unsigned long long)prev);
+        const u32 d = pktg_deal(256, nn, lg ? lg : 2);
+        CHECK(d >= (64u >> (lg ? lg : 2)) && d <= 64u && d % (64u >> (lg ? lg : 2)) == 0, "pktg_deal(%llu, %u) = %u", (unsigned long long)nn, lg, d);
+        prev = lg;
+    }
     if (level > 1) {
         test_key(32, 1, 7, {{123, 16 * 64 * 1100 + 11}});     // 1100 chunks: two stage-1 workgroups
         test_key(16, 0, 8, {{0, 16 * W * 600}});              // production rule, > GMAX chunks of Tw = 16

@@ -104,6 +104,46 @@ def test_mgpu_one_device_equals_cfg3_fixture(hip):
     m.close(); buf.free()
 
 
+def test_mgpu_one_device_queue_is_a_fifo_partial_and_mixed_collection(hip, orc):
+    """aesgcm_mgpu_* queued form on ONE device (so that it runs on the single-GPU pool, with real tags): five messages queued with tag = NULL, collected two and
+    then three -- each tag against the oracle, in the order queued (round 5 returned the newest n and lost the oldest: ADVICE r05); a call that wants its own tag
+    while messages wait is refused with ESTATE before anything is enqueued, and works again once the queue is empty; the ring takes eight, not nine"""
+    key = bytes(orc.fill_splitmix64(32, 0x4B4559))
+    f = orc.Fast(key)
+    m = hip.MultiGpu(key, [0])
+    msgs = []
+    for k in range(5):
+        n = (1 << 20) + 4096 * k + 3 * k
+        iv, pt = bytes(orc.fill_splitmix64(12, 0x4956 + k)), bytes(orc.fill_splitmix64(n, 0xAE5C0200 + k))
+        buf = hip.DeviceBuffer(n)
+        buf.upload(pt)
+        msgs.append((iv, pt, buf, n))
+    for iv, pt, buf, n in msgs:
+        assert m.crypt_dev(False, iv, [buf.ptr], [n], [buf.ptr], want_tag=False) is None
+    with pytest.raises(hip.AesGcmError) as ei:                   # a sixth message that wants its tag back would jump the queue
+        m.crypt_dev(False, msgs[0][0], [msgs[0][2].ptr], [msgs[0][3]], [msgs[0][2].ptr])
+    assert ei.value.code == hip.ESTATE
+    first, rest = m.last_tags(2), m.last_tags(3)
+    m.sync()
+    want = [f.encrypt(iv, b"", pt) for iv, pt, buf, n in msgs]
+    assert first == [w[1] for w in want[:2]] and rest == [w[1] for w in want[2:]]
+    for (iv, pt, buf, n), w in zip(msgs, want):
+        assert bytes(buf.download(n)) == w[0]
+    with pytest.raises(hip.AesGcmError):
+        m.last_tags(1)                                           # nothing waits any more
+    # the queue is empty: a call with its own tag works again (decrypt the first message back), and eight messages fit the ring, a ninth does not
+    iv, pt, buf, n = msgs[0]
+    assert m.crypt_dev(True, iv, [buf.ptr], [n], [buf.ptr]) == want[0][1] and bytes(buf.download(n)) == pt
+    for k in range(8):
+        m.crypt_dev(False, iv, [buf.ptr], [n], [buf.ptr], want_tag=False)
+    with pytest.raises(hip.AesGcmError):
+        m.crypt_dev(False, iv, [buf.ptr], [n], [buf.ptr], want_tag=False)
+    tags = m.last_tags(3) + m.last_tags(5)
+    m.sync()
+    assert len(tags) == 8 and tags[0] == want[0][1]              # (in place eight times: encrypt, "encrypt" again = decrypt under the same IV, ...: the first is the message's tag)
+    m.close()
+
+
 def test_launcher_ranks_without_rccl_hand_over_to_one_process(hip):
     """Two ranks as an outside launcher would start them (RANK / WORLD_SIZE in the environment, no --one-device), both landing on GPU 0, where RCCL refuses to form
     a communicator: the ranks must not measure through the file exchange -- rank 1 leaves with 0, rank 0 starts ONE fresh child over both devices

@@ -61,7 +61,7 @@ def test_mixed_message_sizes_with_aad_and_ragged_ends(hip, orc, klen):
     rng = random.Random(500 + klen)
     key = splitmix_bytes(7000 + klen, klen)
     ctx = hip.Context(key)
-    assert ctx.packets_shape(10, 1 << 20, True) == hip.SHAPE_ROWS and ctx.packets_shape(10, 0, True) != hip.SHAPE_ROWS
+    assert ctx.packets_shape(10, 1 << 20, True) == hip.SHAPE_MIXED and ctx.packets_shape(10, 0, True) == hip.SHAPE_MIXED      # offset arrays: routed per message on the device, whatever pkt_len says
     lens = [65536, 65536 + 1023, (1 << 20) + 17, 3 * 4096 + 2048 + 5, 0, 16 << 20, 200000, 131072 + 1008 + 15, 7, (4 << 20) - 16, 65536 + 4096 * 3 + 1024 * 3,
             rng.randrange(65536, 1 << 20), rng.randrange(65536, 1 << 20), (2 << 20) + 1]
     aads = [0, 20, 28, 0, 13, 16, 1100, 0, 8, 0, 33, 2048, 0, 1]
@@ -184,9 +184,9 @@ def test_the_rule_that_sends_a_call_by_rows(hip):
     rows = lambda n, pkt, var=False: ctx.packets_shape(n, pkt, var) == hip.SHAPE_ROWS
     assert rows(1 << 20, 8192) and rows(1 << 19, 8208) and rows(1000, 16400) and rows(5, 1 << 20) and rows(16384, 2048) and rows(100, 4100)
     assert not rows(16385, 8191) and not rows(1 << 20, 4096) and not rows(1000, 2047) and not rows(10, 1514)
-    assert rows(100000, 65536, True) and not rows(1000, 0, True)
+    assert ctx.packets_shape(100000, 65536, True) == ctx.packets_shape(1000, 0, True) == hip.SHAPE_MIXED      # with offset arrays the device routes every message; pkt_len is ignored
     # many fixed-size packets of 8 .. 16 KiB whose last, partial row has more than four blocks stay with the packet kernels
-    assert not rows(262144, 9000) and rows(262144, 9000, True) and rows(262144, 8192 + 64) and not rows(262144, 8192 + 80) and rows(262144, 16384 + 1000) and rows(16384, 9000)
+    assert not rows(262144, 9000) and rows(262144, 8192 + 64) and not rows(262144, 8192 + 80) and rows(262144, 16384 + 1000) and rows(16384, 9000)
     ctx.set_option("rows_min", 65536)
     assert rows(10, 65536) and rows(10, 16384) and not rows(16385, 32768) and not rows(10, 16383)
     ctx.set_option("rows_min", 0)
@@ -323,7 +323,7 @@ def test_three_hundred_thousand_small_messages_rows_and_packet_kernels_agree(hip
             hip.dev_sync()
             res.append((hashlib.sha256(bytes(d_out.download(doff[-1]))).hexdigest(), bytes(d_tags.download())))
             if rows == 1:
-                assert ctx.packets_shape(n, 2048, True) == hip.SHAPE_ROWS
+                assert ctx.packets_shape(n, 2048, True) == hip.SHAPE_MIXED
                 ct_head, ct_tail = bytes(d_out.download(doff[100])), bytes(d_out.download(doff[n] - doff[n - 100], doff[n - 100]))
                 forged = (0, 1234, n - 1)
                 bad = bytearray(res[0][1])
