@@ -14,7 +14,7 @@ def needs_build():
     if not os.path.exists(SO) or not os.path.exists(SO_DEBUG):
         return True
     t = min(os.path.getmtime(SO), os.path.getmtime(SO_DEBUG))
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")) or f == "Makefile"]
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".inc")) or f == "Makefile"]
     srcs += [os.path.join(os.path.dirname(HERE), "include", f) for f in ("aesgcm.h", "aesgcm_debug.h")]
     return any(os.path.getmtime(s) > t for s in srcs)
 

@@ -605,7 +605,6 @@ int aesgcm_messages_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_msgs, const v
     PktParams k;
     memset(&k, 0, sizeof k);
     k.ivs = r.ivs; k.tags = r.tags; k.expect = r.expect; k.auth = d_auth;
-    k.in_ptr = r.in_ptr; k.out_ptr = r.out_ptr; k.aad_ptr = r.aad_ptr; k.len_arr = d_len; k.alen_arr = d_aad_len;
     k.aligned = 1;                                                                      // per message: its two addresses decide (pkt_info)
     const int rc = packets_rows(c, decrypt, r, pick_stream(c, stream), &k);
     if (!rc && decrypt && c->wipe_on_auth_fail && d_expect_tags) return wipe_failed(c->device, n_msgs, nullptr, 0, nullptr, d_auth, pick_stream(c, stream), (const u64 *)d_out_ptr, d_len);

@@ -610,7 +610,7 @@ int order_launch(OrderSlot &o, const u64 *d_off, size_t n_pkts, hipStream_t st, 
         o.cap = n_pkts;
     }
     LenSrc src = {d_off, nullptr, nullptr, nullptr, 0u};                            // by data length (a batch packet's AAD is short)
-    RouteCfg none = {nullptr, (u32)n_pkts, 0u, 0u, 0u, 0u, 0xFFu, 0u};             // a plain order: nothing is routed
+    RouteCfg none = {nullptr, (u32)n_pkts, 0u, 0u, 0u, 0u, 0xFFu, 0u, 0, 0, 0, 0, 0};    // a plain order: nothing is routed
     HIPCHK(klaunch_len_sort(st, src, (u32)n_pkts, o.bins, o.perm, none));
     *perm = o.perm;
     return AESGCM_OK;
@@ -700,22 +700,22 @@ int packets_rows(aesgcm_ctx *c, int decrypt, RowsParams &p, hipStream_t st, PktP
     c->rows_dirty = true;                                                    // until both launches are enqueued
     if (var) {
         p.hdr = r.hdr; p.prefix = r.prefix; p.sprefix = r.sprefix; p.slot_base = r.slot_base;
-        p.routed = k ? 1u : 0u;
         if (k) {
             // the route: a counting sort of the messages by falling size class (data + AAD) whose scan also decides -- which messages go by rows, how many are the packet
             // kernels', and in which shape (aesgcm_rows.h RowsHdr)
             LenSrc src = {p.data_off, p.aad_off, p.len_arr, p.alen_arr, p.aad_len};
-            RouteCfg cfg = {r.hdr, (u32)n, n_cu, 0u, 0u, 16384u, 0xFFu, 0u};
+            RouteCfg cfg = {r.hdr, (u32)n, n_cu, 0u, 0u, 16384u, 0xFFu, 0u, (u64)(uintptr_t)p.in_ptr, (u64)(uintptr_t)p.out_ptr, (u64)(uintptr_t)p.aad_ptr, (u64)(uintptr_t)p.len_arr, (u64)(uintptr_t)p.alen_arr};
+            k->scattered = p.len_arr ? 1u : 0u;
             route_marks(c, &cfg.c_hi, &cfg.c_lo);
 #ifdef AESGCM_DEBUG_KNOBS
-            if (g_force.pkt_lanes) cfg.force_lg = g_force.pkt_lanes == 1 ? 0u : g_force.pkt_lanes == 64 ? 6u : g_force.pkt_lanes == 16 ? 4u : g_force.pkt_lanes == 8 ? 3u : 2u;
+            if (g_force.pkt_lanes) cfg.force_lg = g_force.pkt_lanes == 1 ? 0u : g_force.pkt_lanes == 64 ? (p.len_arr ? 4u : 6u) : g_force.pkt_lanes == 16 ? 4u : g_force.pkt_lanes == 8 ? 3u : 2u;      // (messages wherever they live have no wave-per-packet instance: 16 lanes)
             if (g_force.pkt_deal >= 1 && g_force.pkt_deal <= (int)PKTG_MAX_DEAL) cfg.force_deal = (u32)g_force.pkt_deal;
 #endif
             HIPCHK(klaunch_len_sort(st, src, (u32)n, r.bins, r.perm, cfg));
             k->perm = r.perm; k->route = r.hdr; k->counter = &r.hdr->pkt_counter; k->counter_base = 0; k->plain = 0;
             k->n_pkts = (u32)n;
             // (the plan below may refuse the call -- a length of 2^28 bytes or more --: then the packet kernels return at once as well)
-            HIPCHK(klaunch_rows_plan(st, p, c->rows_block, (u32)ROWS_NB_CAP, r.plan_part, reinterpret_cast<u32 *>(c->h_tag_dev + 2)));
+            HIPCHK(klaunch_rows_plan(st, p, k != nullptr, c->rows_block, (u32)ROWS_NB_CAP, r.plan_part, reinterpret_cast<u32 *>(c->h_tag_dev + 2)));
             // every shape the count of small messages -- anything up to n -- could ask for; all but the one k_len_scan named return before they stage a table
             const u32 lg_min = cfg.force_lg != 0xFFu ? cfg.force_lg : route_pick_lg(n_cu, n), lg_max = cfg.force_lg != 0xFFu ? cfg.force_lg : 4u;
             static const u32 shapes[] = {0u, 2u, 3u, 4u, 6u};
@@ -734,7 +734,7 @@ int packets_rows(aesgcm_ctx *c, int decrypt, RowsParams &p, hipStream_t st, PktP
                 }
             }
         } else {
-            HIPCHK(klaunch_rows_plan(st, p, c->rows_block, (u32)ROWS_NB_CAP, r.plan_part, reinterpret_cast<u32 *>(c->h_tag_dev + 2)));
+            HIPCHK(klaunch_rows_plan(st, p, k != nullptr, c->rows_block, (u32)ROWS_NB_CAP, r.plan_part, reinterpret_cast<u32 *>(c->h_tag_dev + 2)));
         }
     }
     p.prio_rows = c->cyc_prio;

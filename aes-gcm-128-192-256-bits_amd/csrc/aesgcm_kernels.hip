@@ -1042,6 +1042,7 @@ __global__ __launch_bounds__(1024) void k_len_scan(u32 *__restrict__ counts, con
         rc.hdr->route_min = route_min; rc.hdr->n_small = n_small; rc.hdr->pkt_lg = lg;
         rc.hdr->pkt_deal = rc.force_deal ? (rc.force_deal + (64u >> lg) - 1u) / (64u >> lg) * (64u >> lg) : pktg_deal(rc.n_cu, n_small, lg);
         rc.hdr->pkt_counter = 0;
+        rc.hdr->sc_in = rc.sc_in; rc.hdr->sc_out = rc.sc_out; rc.hdr->sc_aad = rc.sc_aad; rc.hdr->sc_len = rc.sc_len; rc.hdr->sc_alen = rc.sc_alen;
     }
 }
 // small ones FIRST (what the packet kernels take, by falling class: perm[0 .. n_small)), the messages that go by rows behind them (nobody reads those: the row
@@ -1082,74 +1083,16 @@ __device__ __forceinline__ void pktg_tree(uint4 &acc, const unsigned char *smem,
 // wave keeps its E_K(J0) values in registers and stays at 768 lanes, where it needs no scratch.  AESGCM_PKTG_WG forces one geometry for all.
 template <int NR, int DEC, int LG>
 __global__ __launch_bounds__(PKTG_WG(LG), (PKTG_WG(LG) + 255) / 256) void k_pktg(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const PktParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr u32 G = 1u << LG, P = 64u >> LG;
-    const u32 tid = threadIdx.x, lane = tid & 63u;
-    // a ROUTED call (aesgcm_rows.h RowsHdr): the count and the deal are the device's, and the instance runs only if it is the shape k_len_scan chose for that count
-    u32 n_pkts = p.n_pkts, K = p.deal;
-    if (p.route) {
-        if (p.route->bad || p.route->pkt_lg != (u32)LG || !p.route->n_small) return;
-        n_pkts = uniform32(p.route->n_small); K = uniform32(p.route->pkt_deal);
-    }
-    pktg_fill_lds(smem, km, tb, tid, PKTG_WG(LG), LG);
-    __syncthreads();
-    const u32 wave_slot = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6)) * PKTG_WAVE_SLOT;       // scalar
-    // packets are dealt to the waves in blocks of p.deal (a multiple of P, at most 64) from a dispenser: one atomic per block
-    // keeps the single dispenser address far below its ~87 M fetches/s ceiling (measured), and late waves still level the
-    // tail.  The loop is bounded on purpose (a wave can never own more than nb blocks).
-    const u32 nb = (n_pkts + K - 1) / K;
-    for (u32 guard = 0; guard <= nb; ++guard) {
-        u32 b = 0;
-        if (lane == 0) b = atomicAdd(p.counter, 1u) - p.counter_base;
-        b = __builtin_amdgcn_readfirstlane(b);
-        if (b >= nb) break;
-        const u32 p0 = b * K, cnt = (p0 + K < n_pkts ? p0 + K : n_pkts) - p0;
-        // E_K(IV || 1) of the block's packets, one lane each, in ONE AES pass.  Lane groups park the 64 values in the wave's own 1 KiB of LDS
-        // (behind the tree tables): held in registers across the packet loop they were spilled at 128 registers; one packet per wave keeps them.
-        constexpr bool EJ_LDS = LG <= 4;
-        unsigned char *ej_slot = smem + PKTG_LDS_BYTES(LG) + wave_slot;
-        // the block's packet numbers (pkt_map: the launch order of packets of mixed length) beside them, read back per group: the pointer chase stays out of the packet loop
-        const u32 mine = pkt_map(p, p0 + (lane < cnt ? lane : 0u));
-        uint4 ej = pktg_ej0_lane<NR>(km, p, smem, mine, lane);
-        if (EJ_LDS) {                                           // addresses from a fresh lane id: hoisted out of the dispenser loop they were two more registers held across it (spilled at 128)
-            const u32 lf = lane_id_fresh();
-            *reinterpret_cast<uint4 *>(ej_slot + lf * 16u) = ej; ej = make_uint4(0, 0, 0, 0);
-            *reinterpret_cast<u32 *>(ej_slot + 1024u + lf * 4u) = mine;
-        }
-        for (u32 t = 0; t * P < cnt; ++t) {
-            const u32 lane1 = lane_id_fresh(), l = lane1 & (G - 1u), idx = t * P + (lane1 >> LG);
-            const bool act = idx < cnt;                          // groups past the end shadow the block's first packet; their stores are masked
-            const u32 pkt = EJ_LDS ? *reinterpret_cast<const u32 *>(ej_slot + 1024u + (act ? idx : 0u) * 4u) : pkt_map(p, p0 + (act ? idx : 0u));
-            const PktInfo q = pkt_info(p, pkt);
-            // the wave runs to the longest packet of its groups
-            u32 iters = pktg_iters(q, G);
-            iters = groups_max<LG>(iters);                      // wave-uniform: the first lane of every group, through scalar registers
-            uint4 acc = pktg_lane<NR, DEC, LG>(km, p, q, smem, l, lane1, iters, act);
-            // what follows needs the lane's position again.  Taken from a FRESH lane id (lane_id_fresh: the compiler cannot tie it to the one above), so that
-            // l / grp / idx / pkt need not stay in registers across the packet loop -- at 128 registers they were spilled there
-            const u32 lane2 = lane_id_fresh(), l2 = lane2 & (G - 1u), idx2 = t * P + (lane2 >> LG);
-            const bool act2 = idx2 < cnt;
-            const u32 pkt2 = EJ_LDS ? *reinterpret_cast<const u32 *>(ej_slot + 1024u + (act2 ? idx2 : 0u) * 4u) : pkt_map(p, p0 + (act2 ? idx2 : 0u));
-            acc = pktg_close_lane<LG>(acc, q, smem, l2);
-            pktg_tree<LG, 0>(acc, smem, l2);
-            // lane G-1 of the group holds P H^2 ^ L H; its packet's E_K(IV || 1) sits in lane idx of `ej`
-            const int srcl = (int)(act2 ? idx2 : 0u);
-            const uint4 e = EJ_LDS ? *reinterpret_cast<const uint4 *>(ej_slot + (u32)srcl * 16u)
-                                   : make_uint4((u32)__shfl((int)ej.x, srcl), (u32)__shfl((int)ej.y, srcl), (u32)__shfl((int)ej.z, srcl), (u32)__shfl((int)ej.w, srcl));
-            if (l2 == G - 1u && act2) {
-                const uint4 tag = xor4(acc, e);                  // gcm_ghash.vhd:293
-                store_block_bytes(p.tags + (size_t)pkt2 * 16, tag, 16);
-                if (DEC && p.auth) {
-                    int ok = 1;
-                    if (p.expect) {
-                        const uint4 x = load_block_bytes(p.expect + (size_t)pkt2 * 16, 16);
-                        ok = ((x.x ^ tag.x) | (x.y ^ tag.y) | (x.z ^ tag.z) | (x.w ^ tag.w)) == 0;
-                    }
-                    p.auth[pkt2] = ok;
-                }
-            }
-        }
-    }
+#define PKT_SC false
+#include "aesgcm_pktg_body.inc"
+#undef PKT_SC
+}
+// ... of messages WHEREVER THEY LIVE (aesgcm_messages_crypt_dev: the short ones of a routed call): the packets' places are addresses from the arrays behind p.route
+template <int NR, int DEC, int LG>
+__global__ __launch_bounds__(PKTG_WG(LG), (PKTG_WG(LG) + 255) / 256) void k_pktgs(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const PktParams p) {
+#define PKT_SC true
+#include "aesgcm_pktg_body.inc"
+#undef PKT_SC
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1158,8 +1101,8 @@ __global__ __launch_bounds__(PKTG_WG(LG), (PKTG_WG(LG) + 255) / 256) void k_pktg
 // ------------------------------------------------------------------------------------------------
 // ILP = 1: the same lane code compiled for 512-lane workgroups (two waves per SIMD, 256 registers) with the eight keystream blocks of a line as independent
 // chains: for batches that do not fill the chip, where a wave has to hide its own LDS latency (pktl_lane, AESGCM_PKTL_WG_ILP).
-template <int NR, int DEC, int ILP>
-__global__ __launch_bounds__(ILP ? AESGCM_PKTL_WG_ILP : AESGCM_PKTL_WG, ILP ? 2 : AESGCM_PKTL_WAVES) void k_pktl(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const PktParams p) {
+template <int NR, int DEC, int ILP, bool SC>
+__device__ __forceinline__ void pktl_body(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const PktParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr u32 WG = ILP ? AESGCM_PKTL_WG_ILP : AESGCM_PKTL_WG;
     const u32 tid = threadIdx.x, lane = tid & 63u;
@@ -1180,8 +1123,16 @@ __global__ __launch_bounds__(ILP ? AESGCM_PKTL_WG_ILP : AESGCM_PKTL_WG, ILP ? 2 
         b = __builtin_amdgcn_readfirstlane(b);
         if (b >= nb) break;
         const u32 idx = b * 64u + lane;
-        if (idx < n_pkts) pktl_lane<NR, DEC, AESGCM_PKTL_T4 != 0, ILP != 0>(km, p, smem, pkt_map(p, idx), lane);
+        if (idx < n_pkts) pktl_lane<NR, DEC, AESGCM_PKTL_T4 != 0, ILP != 0, SC>(km, p, smem, pkt_map(p, idx), lane);
     }
+}
+template <int NR, int DEC, int ILP>
+__global__ __launch_bounds__(ILP ? AESGCM_PKTL_WG_ILP : AESGCM_PKTL_WG, ILP ? 2 : AESGCM_PKTL_WAVES) void k_pktl(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const PktParams p) {
+    pktl_body<NR, DEC, ILP, false>(km, tb, p);
+}
+template <int NR, int DEC>                                     // ... of messages wherever they live (as k_pktgs)
+__global__ __launch_bounds__(AESGCM_PKTL_WG, AESGCM_PKTL_WAVES) void k_pktls(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const PktParams p) {
+    pktl_body<NR, DEC, 0, true>(km, tb, p);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1194,14 +1145,14 @@ template <int NR, int MODE>
 __global__ __launch_bounds__(AESGCM_BODY_WG, AESGCM_BODY_WPS) void k_rows(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const RowsParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 tid = threadIdx.x, lane = tid & 63u;
-    const u64 G = uniform64(p.hdr ? p.hdr->G : p.G);
-    if (!G || (p.hdr && p.hdr->bad)) return;                                 // nothing by rows (a routed call whose messages are all the packet kernels'), or a plan that was refused: before the 141 KiB of tables are staged
+    if (p.hdr && (p.hdr->bad || !p.hdr->NB)) return;                         // nothing by rows (a routed call whose messages are all the packet kernels'), or a plan that was refused: before the 141 KiB of tables are staged
     main_fill_lds(smem, km, tb, tid, true, AESGCM_BODY_WG, GH_TAB_K64);            // consecutive rows: Horner stride H^64
 #if AESGCM_T4
     fill_lds_t4(smem, tb, tid, AESGCM_BODY_WG);
 #endif
     if (tid == 0) *reinterpret_cast<u32 *>(smem + AESGCM_LDS_DRY_OFF) = 0;   // dry-queue mask of the workgroup (next_chunk)
     __syncthreads();
+    const u64 G = uniform64(p.hdr ? p.hdr->G : p.G);
     const u32 D = uniform32(p.hdr ? p.hdr->D : p.D), NB = uniform32(p.hdr ? p.hdr->NB : p.NB), dyn = uniform32(p.hdr ? p.hdr->dyn : p.dyn);
     const u32 wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (AESGCM_BODY_WG / 64) + (tid >> 6));
     u32 nq, seg;
@@ -1221,9 +1172,10 @@ __global__ __launch_bounds__(AESGCM_BODY_WG, AESGCM_BODY_WPS) void k_rows(const 
             m = opaque_sgpr(m);
             RowsMsg mq = rows_msg(p, m);
             mq.doff = uniform64(mq.doff); mq.ooff = uniform64(mq.ooff); mq.aoff = uniform64(mq.aoff); mq.len = uniform32(mq.len); mq.alen = uniform32(mq.alen);
-            const RowsGeom geo = rows_geom_of(mq, uniform32(rows_route_min(p)));          // (a message of the packet kernels: no unit -- skipped below like one shorter than a row)
+            const u32 route_min = uniform32(rows_route_min(p));
+            const RowsGeom geo = rows_geom_of(mq, route_min);                        // (a message of the packet kernels counts as empty: no unit -- skipped below like one shorter than a row)
             const u64 g0 = uniform64(rows_unit_base(p, m));
-            const u32 U = rows_units(geo, rows_na(mq.alen));
+            const u32 U = rows_units(geo, rows_na_of(mq, route_min));
             if (g >= g0 + U) { ++m; if (U == 0) { ++skipped; --guard2; } continue; }     // the next message (one without a unit -- shorter than a row -- does not count against the bound of the walk)
             const RowsPiece pc = rows_piece(geo, uniform32(rows_slot_base(p, m)), g0, (u32)(g - g0), g_end - g, D);
             RowsRec *rr = p.rec + pc.slot;
@@ -1306,7 +1258,7 @@ __global__ __launch_bounds__(ROWS_CLOSE_WG) void k_rows_close(const KeyMaterial 
     if (p.hdr && p.hdr->bad) return;                                             // a plan that was refused: nothing ran, nothing to close (the scratch is at rest)
     if (blockIdx.x == 0 && threadIdx.x < ROWS_NQ) p.queues[16u * threadIdx.x] = 0;
     const u32 route_min = rows_route_min(p);
-    if (p.routed && p.hdr->n_small == p.n_pkts) return;                          // every message went to the packet kernels: no unit, no smalls block, no tag of this launch's
+    if (p.hdr && p.hdr->n_small == p.n_pkts) return;                             // every message went to the packet kernels: no unit, no smalls block, no tag of this launch's
     rows_close_fill_te(smem, tb, threadIdx.x);
     __syncthreads();
     const u32 *te = reinterpret_cast<const u32 *>(smem + ROWS_CLOSE_LDS_TE);
@@ -1384,7 +1336,7 @@ __device__ __forceinline__ u64 plan_alen(const RowsPlan &a, u32 m) { return a.le
 __device__ __forceinline__ bool plan_bad_len(const RowsPlan &a, u32 m) { return plan_len(a, m) >= ROWS_LEN_LIMIT || plan_alen(a, m) >= ROWS_LEN_LIMIT; }
 // (lengths beyond the limit count as nothing: the call is refused anyway, and the sums stay in range)
 __device__ __forceinline__ RowsGeom plan_geom(const RowsPlan &a, u32 m, u32 route_min) { return plan_bad_len(a, m) ? rows_geom(0) : rows_geom_routed(plan_len(a, m), plan_alen(a, m), route_min); }
-__device__ __forceinline__ u32 plan_na(const RowsPlan &a, u32 m) { return plan_bad_len(a, m) ? 0u : rows_na((u32)plan_alen(a, m)); }
+__device__ __forceinline__ u32 plan_na(const RowsPlan &a, u32 m, u32 route_min) { return plan_bad_len(a, m) ? 0u : rows_na_routed(plan_len(a, m), plan_alen(a, m), route_min); }
 __device__ __forceinline__ u32 plan_route_min(const RowsPlan &a) { return a.routed ? a.hdr->route_min : 0u; }
 __device__ __forceinline__ void plan_refuse(const RowsPlan &a, u32 status, u64 detail) {          // one thread
     a.hdr->G = 0; a.hdr->NB = 0; a.hdr->bad = 1; a.hdr->status = status; a.hdr->detail = detail;
@@ -1398,7 +1350,7 @@ __global__ __launch_bounds__(1024) void k_rows_plan(const RowsPlan a) {
     const u32 route_min = plan_route_min(a);
     u64 s = 0, ss = 0, bad = ~0ull;
     for (u32 m = lo; m < hi; ++m) {
-        const RowsGeom g = plan_geom(a, m, route_min); const u32 na = plan_na(a, m);
+        const RowsGeom g = plan_geom(a, m, route_min); const u32 na = plan_na(a, m, route_min);
         s += rows_units(g, na); ss += rows_smalls(g, na);
         if (bad == ~0ull && plan_bad_len(a, m)) bad = m;
     }
@@ -1414,7 +1366,7 @@ __global__ __launch_bounds__(1024) void k_rows_plan(const RowsPlan a) {
     const bool cut_ok = rows_cut(G, a.waves, a.force_d, a.nb_cap, &D, &NB, &dyn);
     u64 t = 0;
     for (u32 m = lo; m < hi; ++m) {
-        const RowsGeom g = plan_geom(a, m, route_min); const u32 na = plan_na(a, m);
+        const RowsGeom g = plan_geom(a, m, route_min); const u32 na = plan_na(a, m, route_min);
         a.prefix[m] = run; a.sprefix[m] = srun;
         t += rows_slots(g, na, run, D);
         run += rows_units(g, na); srun += rows_smalls(g, na);
@@ -1423,7 +1375,7 @@ __global__ __launch_bounds__(1024) void k_rows_plan(const RowsPlan a) {
     const u64 slots = part[1023];
     run = lo < n ? a.prefix[lo] : 0;
     for (u32 m = lo; m < hi; ++m) {
-        const RowsGeom g = plan_geom(a, m, route_min); const u32 na = plan_na(a, m);
+        const RowsGeom g = plan_geom(a, m, route_min); const u32 na = plan_na(a, m, route_min);
         a.slot_base[m] = (u32)slot;
         slot += rows_slots(g, na, run, D);
         run += rows_units(g, na);
@@ -1431,6 +1383,7 @@ __global__ __launch_bounds__(1024) void k_rows_plan(const RowsPlan a) {
     if (tid == 0) {
         a.prefix[n] = GR; a.sprefix[n] = ST; a.slot_base[n] = (u32)(slots <= a.slot_cap ? slots : 0);
         a.hdr->G = G; a.hdr->D = D; a.hdr->NB = NB; a.hdr->dyn = dyn; a.hdr->bad = 0; a.hdr->status = ROWS_ST_OK; a.hdr->detail = 0;
+        if (!a.routed) { a.hdr->route_min = 0; a.hdr->n_small = 0; }           // (not routed: everything by rows -- what the row launches read the header for)
         if (first_bad != ~0ull) plan_refuse(a, ROWS_ST_LENGTH, first_bad);
         else if (!cut_ok) plan_refuse(a, ROWS_ST_UNITS, G);
         else if (slots > a.slot_cap) plan_refuse(a, ROWS_ST_PLAN_FIT, slots);   // (the host sizes the scratch for the worst case; a cut that does not fit would be its bug: then nothing runs)
@@ -1445,7 +1398,7 @@ __global__ __launch_bounds__(1024) void k_rows_plan_sums(const RowsPlan a) {
     const u32 tid = threadIdx.x, m = blockIdx.x * 1024u + tid;
     const u32 route_min = plan_route_min(a);
     u64 u = 0, s = 0, bad = ~0ull;
-    if (m < a.n) { const RowsGeom g = plan_geom(a, m, route_min); const u32 na = plan_na(a, m); u = rows_units(g, na); s = rows_smalls(g, na); if (plan_bad_len(a, m)) bad = m; }
+    if (m < a.n) { const RowsGeom g = plan_geom(a, m, route_min); const u32 na = plan_na(a, m, route_min); u = rows_units(g, na); s = rows_smalls(g, na); if (plan_bad_len(a, m)) bad = m; }
     block_scan_u64(part, u, tid);
     const u64 U = part[1023];
     __syncthreads();
@@ -1479,6 +1432,7 @@ __global__ __launch_bounds__(1024) void k_rows_plan_cut(const RowsPlan a) {
         u32 D, NB, dyn;
         const bool cut_ok = rows_cut(GR, a.waves, a.force_d, a.nb_cap, &D, &NB, &dyn);
         a.hdr->G = GR; a.hdr->D = D; a.hdr->NB = NB; a.hdr->dyn = dyn; a.hdr->bad = 0; a.hdr->status = ROWS_ST_OK; a.hdr->detail = 0;
+        if (!a.routed) { a.hdr->route_min = 0; a.hdr->n_small = 0; }
         a.prefix[a.n] = GR; a.sprefix[a.n] = ST;
         if (first_bad != ~0ull) plan_refuse(a, ROWS_ST_LENGTH, first_bad);
         else if (!cut_ok) plan_refuse(a, ROWS_ST_UNITS, GR);
@@ -1491,7 +1445,7 @@ __global__ __launch_bounds__(1024) void k_rows_plan_place(const RowsPlan a) {
     RowsGeom g = rows_geom(0);
     u32 na = 0;
     u64 u = 0, s = 0;
-    if (m < a.n) { g = plan_geom(a, m, route_min); na = plan_na(a, m); u = rows_units(g, na); s = rows_smalls(g, na); }
+    if (m < a.n) { g = plan_geom(a, m, route_min); na = plan_na(a, m, route_min); u = rows_units(g, na); s = rows_smalls(g, na); }
     const u64 g0 = a.part[blockIdx.x] + block_scan_u64(part, u, tid);
     __syncthreads();
     const u64 s0 = a.part[a.nwg + blockIdx.x] + block_scan_u64(part, s, tid);
@@ -1583,6 +1537,12 @@ hipError_t klaunch_set_attributes() {
     ATTRCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktl<NR, D, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, AESGCM_PKTL_LDS))
     SETATTRB(10, 0); SETATTRB(12, 0); SETATTRB(14, 0); SETATTRB(10, 1); SETATTRB(12, 1); SETATTRB(14, 1);
 #undef SETATTRB
+#define SETATTRS(NR, D) ATTRCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktgs<NR, D, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, PKTG_LDS_TOTAL(2))); \
+    ATTRCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktgs<NR, D, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, PKTG_LDS_TOTAL(3))); \
+    ATTRCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktgs<NR, D, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, PKTG_LDS_TOTAL(4))); \
+    ATTRCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktls<NR, D>), hipFuncAttributeMaxDynamicSharedMemorySize, AESGCM_PKTL_LDS))
+    SETATTRS(10, 0); SETATTRS(12, 0); SETATTRS(14, 0); SETATTRS(10, 1); SETATTRS(12, 1); SETATTRS(14, 1);
+#undef SETATTRS
     ATTRCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_combine), hipFuncAttributeMaxDynamicSharedMemorySize, CMB_LDS_BYTES));
     ATTRCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_combine_batch), hipFuncAttributeMaxDynamicSharedMemorySize, CMB_LDS_BYTES));
 #define SETATTRB3(NR, D) ATTRCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch3<NR, D, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, BATCH3_LDS_BYTES_LG(6))); \
@@ -1639,6 +1599,13 @@ hipError_t klaunch_combine_batch(unsigned n, hipStream_t st, const KeyMaterial *
     return hipGetLastError();
 }
 hipError_t klaunch_pktl(int nr, int dec, bool ilp, unsigned wgs, hipStream_t st, const KeyMaterial *km, const DevTables *tb, const PktParams &p) {
+    if (p.scattered) {                                          // messages wherever they live: k_pktls (no ILP form: a routed call takes a lane per packet only when the packets fill the chip)
+#define LS(NR, D) hipLaunchKernelGGL((k_pktls<NR, D>), dim3(wgs), dim3(AESGCM_PKTL_WG), AESGCM_PKTL_LDS, st, km, tb, p)
+        if (dec) { if (nr == 10) LS(10, 1); else if (nr == 12) LS(12, 1); else LS(14, 1); }
+        else     { if (nr == 10) LS(10, 0); else if (nr == 12) LS(12, 0); else LS(14, 0); }
+#undef LS
+        return hipGetLastError();
+    }
 #define LPI(NR, D, I) hipLaunchKernelGGL((k_pktl<NR, D, I>), dim3(wgs), dim3(I ? AESGCM_PKTL_WG_ILP : AESGCM_PKTL_WG), AESGCM_PKTL_LDS, st, km, tb, p)
 #define LP(NR, D) do { if (ilp) LPI(NR, D, 1); else LPI(NR, D, 0); } while (0)
     if (dec) { if (nr == 10) LP(10, 1); else if (nr == 12) LP(12, 1); else LP(14, 1); }
@@ -1648,6 +1615,16 @@ hipError_t klaunch_pktl(int nr, int dec, bool ilp, unsigned wgs, hipStream_t st,
     return hipGetLastError();
 }
 hipError_t klaunch_pktg(int nr, int dec, int lg, unsigned wgs, hipStream_t st, const KeyMaterial *km, const DevTables *tb, const PktParams &p) {
+    if (p.scattered) {                                          // messages wherever they live: k_pktgs, lane groups of 4 / 8 / 16
+        if (lg != 2 && lg != 3 && lg != 4) return hipErrorInvalidValue;
+#define LSG(NR, D, LG) hipLaunchKernelGGL((k_pktgs<NR, D, LG>), dim3(wgs), dim3(PKTG_WG(LG)), PKTG_LDS_TOTAL(LG), st, km, tb, p)
+#define LS(NR, D) do { if (lg == 2) LSG(NR, D, 2); else if (lg == 3) LSG(NR, D, 3); else LSG(NR, D, 4); } while (0)
+        if (dec) { if (nr == 10) LS(10, 1); else if (nr == 12) LS(12, 1); else LS(14, 1); }
+        else     { if (nr == 10) LS(10, 0); else if (nr == 12) LS(12, 0); else LS(14, 0); }
+#undef LS
+#undef LSG
+        return hipGetLastError();
+    }
 #define LPG(NR, D, LG) hipLaunchKernelGGL((k_pktg<NR, D, LG>), dim3(wgs), dim3(PKTG_WG(LG)), PKTG_LDS_TOTAL(LG), st, km, tb, p)
 #define LP(NR, D) do { if (lg == 2) LPG(NR, D, 2); else if (lg == 3) LPG(NR, D, 3); else if (lg == 4) LPG(NR, D, 4); else LPG(NR, D, 6); } while (0)
     if (dec) { if (nr == 10) LP(10, 1); else if (nr == 12) LP(12, 1); else LP(14, 1); }
@@ -1673,10 +1650,10 @@ hipError_t klaunch_len_sort(hipStream_t st, const LenSrc &src, u32 n, u32 *bins,
     hipLaunchKernelGGL(k_len_scatter, dim3(LEN_SORT_WGS), dim3(256), 0, st, src, n, bins, perm, (const RowsHdr *)rc.hdr);
     return hipGetLastError();
 }
-hipError_t klaunch_rows_plan(hipStream_t st, const RowsParams &p, u32 force_d, u32 nb_cap, u64 *part, u32 *host_status) {
+hipError_t klaunch_rows_plan(hipStream_t st, const RowsParams &p, bool routed, u32 force_d, u32 nb_cap, u64 *part, u32 *host_status) {
     RowsPlan a;
     a.off = p.data_off; a.aoff = p.aad_off; a.len_arr = p.len_arr; a.alen_arr = p.alen_arr; a.pkt_len = p.pkt_len; a.aad_len = p.aad_len; a.n = p.n_pkts; a.waves = p.waves; a.force_d = force_d;
-    a.nb_cap = nb_cap; a.slot_cap = p.slot_cap; a.nwg = (p.n_pkts + 1023u) / 1024u; a.routed = p.routed;
+    a.nb_cap = nb_cap; a.slot_cap = p.slot_cap; a.nwg = (p.n_pkts + 1023u) / 1024u; a.routed = routed ? 1u : 0u;
     a.hdr = const_cast<RowsHdr *>(p.hdr); a.prefix = const_cast<u64 *>(p.prefix); a.sprefix = const_cast<u64 *>(p.sprefix); a.slot_base = const_cast<u32 *>(p.slot_base); a.part = part;
     a.host_status = host_status;
     if (a.n <= ROWS_PLAN_ONE_WG) {

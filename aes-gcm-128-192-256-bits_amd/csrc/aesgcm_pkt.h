@@ -44,12 +44,12 @@ struct PktParams {
     u32 aligned;                 // in/out base pointers 16-byte aligned
     const u32 *perm;             // the order in which the launch takes the packets (k_len_*: by falling length), or NULL = as they come
     u32 plain;                   // k_pktg<.., 6 | 2>: fixed-size aligned records of whole group-iterations, no AAD
-    // messages WHEREVER THEY LIVE (aesgcm_messages_crypt_dev, round 6: the short ones of such a call are the packet kernels'): device addresses and lengths per message; in / out / aad are NULL then
-    const u64 *in_ptr, *out_ptr, *aad_ptr;
-    const u32 *len_arr, *alen_arr;
     // a ROUTED call (lengths on the device): how many packets the launch has (the first n_small entries of perm), whether this instance is the shape chosen for
-    // that count, and its deal, are in the header k_len_scan left (aesgcm_rows.h RowsHdr); NULL = the host's numbers above
+    // that count, and its deal, are in the header k_len_scan left (aesgcm_rows.h RowsHdr); NULL = the host's numbers above.  For messages WHEREVER THEY LIVE
+    // (aesgcm_messages_crypt_dev: the short ones of such a call are the packet kernels') the header also holds the arrays of addresses and lengths (sc_*); in / out /
+    // aad are NULL then
     const struct RowsHdr *route;
+    u32 scattered;               // 1: the packets' places come from route->sc_* (the host launches k_pktgs / k_pktls then)
 };
 HD u32 pkt_map(const PktParams &p, u32 i) { return p.perm ? p.perm[i] : i; }
 HD const unsigned char *pkt_at(const unsigned char *base, u64 off) { return reinterpret_cast<const unsigned char *>((uintptr_t)base + off); }
@@ -94,21 +94,23 @@ HD void pktg_fill_lds(unsigned char *smem, const KeyMaterial *km, const DevTable
 
 // per-packet geometry and constants: uniform over the packet's lane group
 struct PktInfo { u64 doff, ooff, aoff; u32 pkt_len, aad_len, iv0, iv1, iv2, aligned; };      // doff / ooff: where the packet's input / output lies (the same offset, except for messages in buffers of their own)
+HD void pkt_place_scattered(const struct RowsHdr *h, u32 pkt, u64 *doff, u64 *ooff, u64 *aoff, u32 *pkt_len, u32 *aad_len);      // aesgcm_rows.h (the header's layout)
+// SC (compile time): the packets' places come from the arrays of addresses behind p.route (messages wherever they live) -- kernels of their own (k_pktgs, k_pktls):
+// as a run-time branch beside the offset form the two places of a packet stopped being one offset from two scalar bases, and k_pktg's 4-lane shape spilled (121 -> 128
+// registers and 20 - 28 bytes of scratch)
+template <bool SC>
 HD void pkt_place(const PktParams &p, u32 pkt, u64 *doff, u64 *ooff, u64 *aoff, u32 *pkt_len, u32 *aad_len) {
-    if (p.len_arr) {                                            // addresses and lengths per message (in / out / aad are NULL: the "offsets" are addresses)
-        *doff = p.in_ptr[pkt]; *ooff = p.out_ptr[pkt]; *pkt_len = p.len_arr[pkt];
-        *aoff = p.aad_ptr ? p.aad_ptr[pkt] : 0; *aad_len = p.aad_ptr ? p.alen_arr[pkt] : 0u;
-        return;
-    }
+    if (SC) { pkt_place_scattered(p.route, pkt, doff, ooff, aoff, pkt_len, aad_len); return; }     // addresses and lengths per message (in / out / aad are NULL: the "offsets" are addresses)
     *pkt_len = p.pkt_len; *aad_len = p.aad_len;
     *doff = (u64)pkt * p.pkt_len; *aoff = (u64)pkt * p.aad_len;
     if (p.data_off) { *doff = p.data_off[pkt]; *pkt_len = (u32)(p.data_off[pkt + 1] - *doff); }
     if (p.aad_off) { *aoff = p.aad_off[pkt]; *aad_len = (u32)(p.aad_off[pkt + 1] - *aoff); }
     *ooff = *doff;
 }
+template <bool SC = false>
 HD PktInfo pkt_info(const PktParams &p, u32 pkt) {
     PktInfo q;
-    pkt_place(p, pkt, &q.doff, &q.ooff, &q.aoff, &q.pkt_len, &q.aad_len);
+    pkt_place<SC>(p, pkt, &q.doff, &q.ooff, &q.aoff, &q.pkt_len, &q.aad_len);
     q.aligned = (p.aligned && (((q.doff | q.ooff) & 15) == 0)) ? 1u : 0u;
     const unsigned char *ivp = p.ivs + (size_t)pkt * 12;
     q.iv0 = load_le32(ivp); q.iv1 = load_le32(ivp + 4); q.iv2 = load_le32(ivp + 8);
@@ -140,7 +142,6 @@ HD uint4 pktg_lane(const KeyMaterial *__restrict__ km, const PktParams &p, const
     const u32 pad = G * iters - n_seq;                                              // front padding slots (whole idle iterations included)
     const unsigned char *src = pkt_at(p.in, q.doff);
     unsigned char *dst = pkt_at(p.out, q.ooff);
-    const unsigned char *aadp = pkt_at(p.aad, q.aoff);
     const bool aligned = q.aligned != 0;
     uint4 acc = make_uint4(0, 0, 0, 0);
     if ((LG == 6 || LG == 2) && p.plain) {   // a wave or four lanes per packet (the instances with registers to spare), records of one size, whole group-iterations, no AAD, aligned: no per-iteration tests
@@ -166,7 +167,8 @@ HD uint4 pktg_lane(const KeyMaterial *__restrict__ km, const PktParams &p, const
         uint4 gin;
         if (j < n_aad) {
             const u32 off = 16 * j, rem = q.aad_len - off;
-            gin = rem >= 16 ? gload16_any(aadp + off) : load_block_bytes(aadp + off, rem);
+            const unsigned char *a = pkt_at(p.aad, q.aoff + off);
+            gin = rem >= 16 ? gload16_any(a) : load_block_bytes(a, rem);
         } else {
             const u32 i = j - n_aad, off = 16 * i, rem = q.pkt_len - off;
             const bool full = rem >= 16;                                                // a whole block is one access at any address (gload16_any)
@@ -214,13 +216,13 @@ HD uint4 pktg_tree_offer(uint4 acc, const unsigned char *smem, int j) { return g
 // most lanes idle.  The lane runs the whole frame serially, as the reference core does (tb/gcm_test.py:76-85):
 // AAD blocks, data blocks (CTR from 2, aes_icb.vhd:97-118; whole blocks as one access at whatever byte address the packet starts: gload16_any), the length block, Y = (Y ^ X) * H with the LDS
 // nibble tables of H (main_fill_lds(GH_TAB_H)), tag = Y ^ E_K(IV || 1).  Nothing here is wave-uniform except the key.
-template <int NR, int DEC, bool T4 = false, bool ILP = false>
+template <int NR, int DEC, bool T4 = false, bool ILP = false, bool SC = false>
 HD void pktl_lane(const KeyMaterial *__restrict__ km, const PktParams &p, const unsigned char *smem, u32 pkt, u32 lane) {
     const u32 *__restrict__ rk = km->rk;
     const u32 lb = (lane & 31u) << 2;
     u32 pkt_len, aad_len;
     u64 doff, ooff, aoff;
-    pkt_place(p, pkt, &doff, &ooff, &aoff, &pkt_len, &aad_len);
+    pkt_place<SC>(p, pkt, &doff, &ooff, &aoff, &pkt_len, &aad_len);
     const unsigned char *ivp = p.ivs + (size_t)pkt * 12;
     const CtrConsts cc = ctr_round1_consts(load_le32(ivp), load_le32(ivp + 4), load_le32(ivp + 8), rk, smem, lb);
     uint4 acc = make_uint4(0, 0, 0, 0);

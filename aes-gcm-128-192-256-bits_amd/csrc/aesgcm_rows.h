@@ -64,8 +64,18 @@ struct RowsRec { G128 w; u64 e; u32 msg; u32 flags; };     // one piece: 32 byte
 //     its packets per dispenser fetch), pkt_counter (that launch's dispenser, zero again);
 //   * by k_rows_plan*: the cut (G, D, NB, dyn) and the verdict: bad != 0 -- NOTHING of the call runs (every kernel behind the plan returns at once, outputs and tags are
 //     untouched) -- with the reason in status / detail, which the plan also stores in the context's pinned host slot (aesgcm_ctx_status).
-struct RowsHdr { u64 G; u32 D, NB, dyn, bad; u32 route_min, n_small, pkt_lg, pkt_deal, pkt_counter, status; u64 detail; u32 pad[2]; };
-static_assert(sizeof(RowsHdr) == 64, "RowsHdr: one 64-byte line");
+//   * for the packet kernels of a call whose messages live WHEREVER (aesgcm_messages_crypt_dev): the five arrays of addresses and lengths (sc_*; zero = offsets from the
+//     call's buffers).  They ride here, behind the one pointer the packet kernels get, rather than in the kernels' own arguments: ten more scalar registers held across
+//     the packet loops cost k_pktg its last free vector register (16 - 24 bytes of scratch in the 4-lane shape).
+struct RowsHdr { u64 G; u32 D, NB, dyn, bad; u32 route_min, n_small, pkt_lg, pkt_deal, pkt_counter, status; u64 detail; u32 pad[2];
+                 u64 sc_in, sc_out, sc_aad, sc_len, sc_alen; u64 pad2[3]; };
+static_assert(sizeof(RowsHdr) == 128, "RowsHdr: two 64-byte lines");
+HD void pkt_place_scattered(const RowsHdr *h, u32 pkt, u64 *doff, u64 *ooff, u64 *aoff, u32 *pkt_len, u32 *aad_len) {
+    const u64 *in_ptr = reinterpret_cast<const u64 *>((uintptr_t)h->sc_in), *out_ptr = reinterpret_cast<const u64 *>((uintptr_t)h->sc_out), *aad_ptr = reinterpret_cast<const u64 *>((uintptr_t)h->sc_aad);
+    const u32 *len_arr = reinterpret_cast<const u32 *>((uintptr_t)h->sc_len), *alen_arr = reinterpret_cast<const u32 *>((uintptr_t)h->sc_alen);
+    *doff = in_ptr[pkt]; *ooff = out_ptr[pkt]; *pkt_len = len_arr[pkt];
+    *aoff = aad_ptr ? aad_ptr[pkt] : 0; *aad_len = aad_ptr ? alen_arr[pkt] : 0u;
+}
 #define ROWS_LEN_LIMIT (1ull << 28)           /* a message's data and its AAD: each below this (include/aesgcm.h) */
 #define ROWS_ST_OK 0u
 #define ROWS_ST_PLAN_FIT 1u                   /* AESGCM_STATUS_PLAN: the plan does not fit the scratch the host sized for it */
@@ -76,7 +86,7 @@ static_assert(sizeof(RowsHdr) == 64, "RowsHdr: one 64-byte line");
 struct LenSrc { const u64 *off, *aoff; const u32 *len_arr, *alen_arr; u32 aad_len; };
 // how k_len_scan routes a call: hdr NULL = no route (a plain launch order); marks as length classes (64 bytes each; >= PKT_LEN_CLASSES = never by rows): c_hi while more than
 // `few` messages lie below it, else c_lo; force_lg != 0xFF / force_deal != 0: the debug library's forced packet kernel shape
-struct RouteCfg { RowsHdr *hdr; u32 n, n_cu, c_hi, c_lo, few, force_lg, force_deal; };
+struct RouteCfg { RowsHdr *hdr; u32 n, n_cu, c_hi, c_lo, few, force_lg, force_deal; u64 sc_in, sc_out, sc_aad, sc_len, sc_alen; };
 
 struct RowsParams {
     const unsigned char *ivs;                 // n_pkts * 12 bytes
@@ -107,16 +117,14 @@ struct RowsParams {
     u32 *cnt;                                 // per message: pieces arrived (k_rows_close; the number due is rows_pieces)
     u32 *queues;                              // ROWS_NQ dispensers, 16 u32 apart
     u32 prio_rows;                            // rotate the waves' issue priorities every so many rows (one block per wave: equal shares must also run at equal speed)
-    u32 routed;                               // 1: the call is ROUTED per message (hdr->route_min, made by k_len_scan): messages below it are the packet kernels', the row launches see them as nothing
 };
 
 // ---- geometry (host, planner and kernels agree through these) -------------------------------------
-struct RowsGeom { u32 R, Q, rho, tb, pk; };     // pk: the message is the packet kernels' (a routed call, below route_min): no unit, no smalls block, no record slot, no arrival here
+struct RowsGeom { u32 R, Q, rho, tb; };
 HD RowsGeom rows_geom(u64 len) {
     RowsGeom g;
     g.R = (u32)(len >> 10); g.Q = g.R >> 2; g.rho = g.R & 3u;
     g.tb = ((u32)(len & 1023u) + 15u) >> 4;
-    g.pk = 0;
     return g;
 }
 // the size a routed call goes by: data + AAD (a lane of the packet kernels walks both, block by block); saturating, so that lengths beyond the limit -- which the plan refuses -- route somewhere defined
@@ -126,22 +134,22 @@ HD u32 len_src_size(const LenSrc &s, u32 i) {
     const u64 alen = s.len_arr ? (s.alen_arr ? (u64)s.alen_arr[i] : 0ull) : s.aoff ? s.aoff[i + 1] - s.aoff[i] : (u64)s.aad_len;
     return rows_route_size(len, alen);
 }
+// A message of a ROUTED call below the mark is the packet kernels': to the row launches it is a message of NO bytes and NO AAD that also owes nothing -- no unit, no
+// smalls block, no record slot, no arrival (its tag comes from the packet kernel).  Everything that counts a message's share goes through these two (the geometry of
+// an empty message, an AAD of no blocks), so the counts below need no word about routing
 HD bool rows_is_small(u64 len, u64 alen, u32 route_min) { return rows_route_size(len, alen) < route_min; }
-HD RowsGeom rows_geom_routed(u64 len, u64 alen, u32 route_min) {
-    RowsGeom g = rows_geom(len);
-    if (rows_is_small(len, alen, route_min)) { g.R = g.Q = g.rho = g.tb = 0; g.pk = 1; }
-    return g;
-}
+HD RowsGeom rows_geom_routed(u64 len, u64 alen, u32 route_min) { return rows_geom(rows_is_small(len, alen, route_min) ? 0ull : len); }
+HD u32 rows_na_routed(u64 len, u64 alen, u32 route_min) { return rows_is_small(len, alen, route_min) ? 0u : (u32)((alen + 15u) >> 4); }
 HD u32 rows_na(u32 alen) { return (alen + 15u) >> 4; }                                   // AAD blocks
 HD u32 rows_long_aad(u32 na) { return na > ROWS_SMALL_AAD ? 1u : 0u; }
 HD u32 rows_small_aad(u32 na) { return na > ROWS_SMALL_AAD ? 0u : na; }
 HD u32 rows_long_tail(const RowsGeom &g) { return g.tb > ROWS_SMALL_TAIL ? 1u : 0u; }
 HD u32 rows_small_tail(const RowsGeom &g) { return g.tb > ROWS_SMALL_TAIL ? 0u : g.tb; }
-HD u32 rows_units(const RowsGeom &g, u32 na) { return g.pk ? 0u : g.R + rows_long_tail(g) + rows_long_aad(na); }      // units of the row launch: the rows, the long tail, the long AAD (0 for a short message: only the closing sees it)
-HD u32 rows_smalls(const RowsGeom &g, u32 na) { return g.pk ? 0u : rows_small_aad(na) + rows_small_tail(g); }         // blocks on the smalls axis: the (short) AAD, then the (short) tail
+HD u32 rows_units(const RowsGeom &g, u32 na) { return g.R + rows_long_tail(g) + rows_long_aad(na); }      // units of the row launch: the rows, the long tail, the long AAD (0 for a short message: only the closing sees it)
+HD u32 rows_smalls(const RowsGeom &g, u32 na) { return rows_small_aad(na) + rows_small_tail(g); }         // blocks on the smalls axis: the (short) AAD, then the (short) tail
 // the natural segment of unit u of a message: its rows (when it has any), then the long tail, then the long AAD
 HD u32 rows_nat(const RowsGeom &g, u32 u) { return u < g.R ? 0u : (g.R ? 1u : 0u) + (u - g.R); }
-HD u32 rows_nat_count(const RowsGeom &g, u32 na) { return g.pk ? 0u : (g.R ? 1u : 0u) + rows_long_tail(g) + rows_long_aad(na); }
+HD u32 rows_nat_count(const RowsGeom &g, u32 na) { return (g.R ? 1u : 0u) + rows_long_tail(g) + rows_long_aad(na); }
 // record slots of a message whose units are [g0, g0 + U): a slot per (natural segment, block) pair it can have -- slot = base + nat + (block - first block)
 HD u32 rows_slots(const RowsGeom &g, u32 na, u64 g0, u32 D) {
     const u32 U = rows_units(g, na);
@@ -181,8 +189,10 @@ HD RowsMsg rows_msg(const RowsParams &p, u32 m) {
     return q;
 }
 // (the (u32) casts above are safe: k_rows_plan* refuses a call -- hdr->bad, nothing runs -- in which any length or offset difference is 2^28 or more)
-HD u32 rows_route_min(const RowsParams &p) { return p.routed ? p.hdr->route_min : 0u; }
+// a ROUTED call (hdr->route_min, made by k_len_scan; the plan of a call that is not routed writes 0 there): messages below the mark are the packet kernels', the row launches see them as nothing
+HD u32 rows_route_min(const RowsParams &p) { return p.hdr ? p.hdr->route_min : 0u; }
 HD RowsGeom rows_geom_of(const RowsMsg &q, u32 route_min) { return rows_geom_routed(q.len, q.alen, route_min); }
+HD u32 rows_na_of(const RowsMsg &q, u32 route_min) { return rows_na_routed(q.len, q.alen, route_min); }
 HD const unsigned char *rows_src(const RowsParams &p, const RowsMsg &q) { return reinterpret_cast<const unsigned char *>((uintptr_t)p.in + q.doff); }
 HD unsigned char *rows_dst(const RowsParams &p, const RowsMsg &q) { return reinterpret_cast<unsigned char *>((uintptr_t)p.out + q.ooff); }
 HD const unsigned char *rows_aadp(const RowsParams &p, const RowsMsg &q) { return reinterpret_cast<const unsigned char *>((uintptr_t)p.aad + q.aoff); }

@@ -229,7 +229,7 @@ hipError_t klaunch_combine_batch(unsigned n, hipStream_t st, const KeyMaterial *
 }
 static void pkt_ptrs(const char *W, const KeyMaterial *km, const DevTables *tb, const PktParams &p) {
     P(km); P(tb); P(p.ivs); P(p.aad); P(p.in); P(p.out); P(p.tags); P(p.expect); P(p.auth); P(p.data_off); P(p.aad_off); P(p.counter); P(p.perm);
-    P(p.in_ptr); P(p.out_ptr); P(p.aad_ptr); P(p.len_arr); P(p.alen_arr); P(p.route);
+    P(p.route);
 }
 hipError_t klaunch_pktl(int, int, bool, unsigned, hipStream_t st, const KeyMaterial *km, const DevTables *tb, const PktParams &p) { LAUNCH("k_pktl", st); BIG_LDS(); pkt_ptrs(W, km, tb, p); return hipSuccess; }
 hipError_t klaunch_pktg(int, int, int, unsigned, hipStream_t st, const KeyMaterial *km, const DevTables *tb, const PktParams &p) { LAUNCH("k_pktg", st); BIG_LDS(); pkt_ptrs(W, km, tb, p); return hipSuccess; }
@@ -238,10 +238,10 @@ hipError_t klaunch_batch3(int, int, int, unsigned, hipStream_t st, const DevTabl
     return hipSuccess;
 }
 hipError_t klaunch_len_sort(hipStream_t st, const LenSrc &src, u32, u32 *bins, u32 *perm, const RouteCfg &rc) {
-    LAUNCH("k_len_*", st); P(src.off); P(src.aoff); P(src.len_arr); P(src.alen_arr); P(bins); P(perm); P(rc.hdr);
+    LAUNCH("k_len_*", st); P(src.off); P(src.aoff); P(src.len_arr); P(src.alen_arr); P(bins); P(perm); P(rc.hdr); P((const void *)(uintptr_t)rc.sc_in); P((const void *)(uintptr_t)rc.sc_out); P((const void *)(uintptr_t)rc.sc_aad); P((const void *)(uintptr_t)rc.sc_len); P((const void *)(uintptr_t)rc.sc_alen);
     return hipSuccess;
 }
-hipError_t klaunch_rows_plan(hipStream_t st, const RowsParams &p, u32, u32, u64 *part, u32 *host_status) {
+hipError_t klaunch_rows_plan(hipStream_t st, const RowsParams &p, bool, u32, u32, u64 *part, u32 *host_status) {
     LAUNCH("k_rows_plan", st); P(p.data_off); P(p.aad_off); P(p.len_arr); P(p.alen_arr); P(part); P(p.hdr); P(p.prefix); P(p.sprefix); P(p.slot_base); P(host_status);
     return hipSuccess;
 }

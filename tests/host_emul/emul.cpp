@@ -813,19 +813,20 @@ static void emu_rows_nr(const KeyMaterial *km, int dec, RowsParams &p, u32 waves
     const u32 route_min = var ? g_route_min : 0u;
     u32 n_small = 0;
     auto geom_m = [&](u32 m) { return rows_geom_of(rows_msg(p, m), route_min); };
+    auto na_m = [&](u32 m) { return rows_na_of(rows_msg(p, m), route_min); };
+    auto small_m = [&](u32 m) { const RowsMsg q = rows_msg(p, m); return rows_is_small(q.len, q.alen, route_min); };
     if (var) {                                                           // k_rows_plan
         hdr.route_min = route_min;
-        p.hdr = &hdr; p.routed = route_min ? 1u : 0u;
+        p.hdr = &hdr;
         CHECK(rows_route_min(p) == route_min, "rows: route_min");
         for (u32 m = 0; m < n; m++) {
-            const RowsMsg q = rows_msg(p, m);
-            if (geom_m(m).pk) { ++n_small; CHECK(rows_units(geom_m(m), rows_na(q.alen)) == 0 && rows_smalls(geom_m(m), rows_na(q.alen)) == 0 && rows_slots(geom_m(m), rows_na(q.alen), prefix[m], 7) == 0, "rows: a routed message counts"); }
-            prefix[m + 1] = prefix[m] + rows_units(geom_m(m), rows_na(q.alen));
-            sprefix[m + 1] = sprefix[m] + rows_smalls(geom_m(m), rows_na(q.alen));
+            if (small_m(m)) { ++n_small; CHECK(rows_units(geom_m(m), na_m(m)) == 0 && rows_smalls(geom_m(m), na_m(m)) == 0 && rows_slots(geom_m(m), na_m(m), prefix[m], 7) == 0, "rows: a routed message counts"); }
+            prefix[m + 1] = prefix[m] + rows_units(geom_m(m), na_m(m));
+            sprefix[m + 1] = sprefix[m] + rows_smalls(geom_m(m), na_m(m));
         }
         hdr.G = prefix[n]; hdr.n_small = n_small;
         rows_cut(hdr.G, waves, force_d, ROWS_NB_CAP, &hdr.D, &hdr.NB, &hdr.dyn);
-        for (u32 m = 0; m < n; m++) { const RowsMsg q = rows_msg(p, m); slot_base[m + 1] = slot_base[m] + rows_slots(geom_m(m), rows_na(q.alen), prefix[m], hdr.D); }
+        for (u32 m = 0; m < n; m++) slot_base[m + 1] = slot_base[m] + rows_slots(geom_m(m), na_m(m), prefix[m], hdr.D);
         slots = ROWS_SLOTS_PER_MSG * (size_t)n + ROWS_NB_CAP;
         CHECK(slot_base[n] <= slots, "rows: %u slots planned, %zu held", slot_base[n], slots);
         p.prefix = prefix.data(); p.sprefix = sprefix.data(); p.slot_base = slot_base.data();
@@ -861,7 +862,7 @@ static void emu_rows_nr(const KeyMaterial *km, int dec, RowsParams &p, u32 waves
             const RowsMsg mq = rows_msg(p, m);
             const RowsGeom geo = geom_m(m);
             const u64 g0 = rows_unit_base(p, m);
-            const u32 U = rows_units(geo, rows_na(mq.alen)), sbase = rows_slot_base(p, m);
+            const u32 U = rows_units(geo, na_m(m)), sbase = rows_slot_base(p, m);
             if (U == 0) { ++m; continue; }                                 // a message shorter than a row has no unit: the closing alone sees it
             CHECK(g >= g0 && g < g0 + U, "rows: unit %llu outside message %u", (unsigned long long)g, m);
             while (g < g_end && g < g0 + U) {
@@ -886,7 +887,7 @@ static void emu_rows_nr(const KeyMaterial *km, int dec, RowsParams &p, u32 waves
     }
     // k_rows_close: the lanes last first; lane i is message i (its length block and E_K(J0)), slot i, and the blocks i, i + lanes, ... of the smalls axis
     u32 finals = 0;
-    auto due = [&](u32 m) { const RowsMsg mq = rows_msg(p, m); return rows_pieces(geom_m(m), rows_na(mq.alen), rows_unit_base(p, m), D); };
+    auto due = [&](u32 m) { const RowsMsg mq = rows_msg(p, m); return rows_pieces(geom_m(m), na_m(m), rows_unit_base(p, m), D); };
     auto arrive = [&](u32 m, const G128 &z) {
         acc[2 * m] ^= ((unsigned long long)z.w[0] << 32) | z.w[1]; acc[2 * m + 1] ^= ((unsigned long long)z.w[2] << 32) | z.w[3];
         if (++cnt[m] == due(m)) {
@@ -902,16 +903,18 @@ static void emu_rows_nr(const KeyMaterial *km, int dec, RowsParams &p, u32 waves
         for (u32 tid = 0; tid < AESGCM_MAIN_WG; tid++) main_fill_lds(smem_h, km, &g_tb, tid, true, AESGCM_MAIN_WG, GH_TAB_H);
         PktParams k; memset(&k, 0, sizeof k);
         k.ivs = p.ivs; k.aad = p.aad; k.in = p.in; k.out = p.out; k.tags = p.tags; k.data_off = p.data_off; k.aad_off = p.aad_off; k.n_pkts = n; k.aad_len = p.aad_len; k.aligned = 1;
-        k.in_ptr = p.in_ptr; k.out_ptr = p.out_ptr; k.aad_ptr = p.aad_ptr; k.len_arr = p.len_arr; k.alen_arr = p.alen_arr;
+        hdr.sc_in = (u64)(uintptr_t)p.in_ptr; hdr.sc_out = (u64)(uintptr_t)p.out_ptr; hdr.sc_aad = (u64)(uintptr_t)p.aad_ptr; hdr.sc_len = (u64)(uintptr_t)p.len_arr; hdr.sc_alen = (u64)(uintptr_t)p.alen_arr;
+        k.route = &hdr; k.scattered = p.len_arr ? 1u : 0u;
         for (u32 m = 0; m < n; m++) {
-            if (!geom_m(m).pk) continue;
-            if (dec) pktl_lane<NR, 1>(km, k, smem_h, m, (m * 5u) % 64u); else pktl_lane<NR, 0>(km, k, smem_h, m, (m * 5u) % 64u);
+            if (!small_m(m)) continue;
+            if (k.scattered) { if (dec) pktl_lane<NR, 1, false, false, true>(km, k, smem_h, m, (m * 5u) % 64u); else pktl_lane<NR, 0, false, false, true>(km, k, smem_h, m, (m * 5u) % 64u); }
+            else if (dec) pktl_lane<NR, 1>(km, k, smem_h, m, (m * 5u) % 64u); else pktl_lane<NR, 0>(km, k, smem_h, m, (m * 5u) % 64u);
         }
     }
     const size_t lanes = slots > n ? slots : n;
     for (size_t k = 0; k < lanes; k++) {
         const size_t i = lanes - 1 - k;
-        if (i < n && !geom_m((u32)i).pk) arrive((u32)i, rows_msg_term(km, g_tb.te0, p, (u32)i));
+        if (i < n && !small_m((u32)i)) arrive((u32)i, rows_msg_term(km, g_tb.te0, p, (u32)i));
         for (u64 t = i; t < rows_small_total(p); t += lanes) {
             G128 z;
             u64 e_run = 0;
@@ -928,7 +931,7 @@ static void emu_rows_nr(const KeyMaterial *km, int dec, RowsParams &p, u32 waves
     CHECK(finals == n - n_small, "rows: %u of %u messages closed", finals, n - n_small);
     for (u32 m = 0; m < n; m++) {
         CHECK(!acc[2 * m] && !acc[2 * m + 1] && !cnt[m], "rows: message %u not zero at rest", m);
-        if (geom_m(m).pk) CHECK(made_of[m] == 0, "rows: message %u is the packet kernels' and fell into %u pieces here", m, made_of[m]);
+        if (small_m(m)) CHECK(made_of[m] == 0, "rows: message %u is the packet kernels' and fell into %u pieces here", m, made_of[m]);
         else CHECK(made_of[m] + 1u == due(m), "rows: message %u fell into %u pieces", m, made_of[m]);
     }
 }

@@ -3,7 +3,8 @@ a GPU) and reads it with tools/isa_census.py: a register spill that lands inside
 (round 1: three scratch_load per row in k_body = 13 % extra traffic; round 2: nine scratch ops in k_pkt's row loop), and it
 arrives silently with any change of a launch bound or of the lane code.  Fails if
 
-  * k_body (every key size, ENC / DEC / PROBE, dealt chunks and cyclic rows with their fused closing), k_pktl, k_pktg (every shape), k_batch3 (every shape) or the KS / ECB instances of k_main use scratch at all;
+  * k_body (every key size, ENC / DEC / PROBE, dealt chunks and cyclic rows with their fused closing), k_pktl, k_pktg (every shape), their twins for messages wherever
+    they live (k_pktls, k_pktgs: round 6), k_batch3 (every shape) or the KS / ECB instances of k_main use scratch at all;
   * any scratch_* op sits at the innermost loop depth of k_main ENC / DEC (the row loop), of k_pktg (the iteration loop of a
     packet's lane group), of k_batch3 (the block loops);
   * a kernel needs more registers than its launch geometry allows;
@@ -43,32 +44,32 @@ def _inner_scratch(k):
 
 def test_scratch_free_kernels(census):
     for name, k in census.items():
-        if name.startswith(("k_body<", "k_pktl<", "k_pktg<", "k_batch3<", "k_batch<")) or name.startswith("k_main<") and name.endswith((", 2>", ", 3>")):
+        if name.startswith(("k_body<", "k_pktl<", "k_pktg<", "k_pktls<", "k_pktgs<", "k_batch3<", "k_batch<")) or name.startswith("k_main<") and name.endswith((", 2>", ", 3>")):
             assert k["scratch"] == 0, (name, k["scratch"])
 
 
 def test_no_scratch_in_the_hot_loops(census):
     seen = 0
     for name, k in census.items():
-        if name.startswith(("k_main<", "k_body<", "k_pktg<", "k_pktl<", "k_batch<", "k_batch3<")):
+        if name.startswith(("k_main<", "k_body<", "k_pktg<", "k_pktl<", "k_pktgs<", "k_pktls<", "k_batch<", "k_batch3<")):
             n, depth = _inner_scratch(k)
             assert n == 0, "%s: %d scratch ops at loop depth %d" % (name, n, depth)
             seen += 1
-    assert seen == 12 + 15 + 24 + 12 + 21               # k_main (3 key sizes x 4 modes), k_body (x ENC, DEC dealt and cyclic + the dealt probe), k_pktg (x 2 x 4 shapes), k_pktl (x 2 forms), k_batch3 (x 3 shapes)
+    assert seen == 12 + 15 + 24 + 12 + 18 + 6 + 21      # k_main (3 key sizes x 4 modes), k_body (x ENC, DEC dealt and cyclic + the dealt probe), k_pktg (x 2 x 4 shapes), k_pktl (x 2 forms), k_pktgs (x 2 x 3 shapes), k_pktls, k_batch3 (x 3 shapes)
 
 
 def test_register_budgets(census):
     for name, k in census.items():
         if name.startswith("k_main<"):
             assert k["vgpr"] <= 80, (name, k["vgpr"])          # 768 lanes x 2 workgroups per CU = 6 waves per SIMD
-        wide = name.startswith("k_pktg<") and name.endswith(", 6>") or name.startswith("k_pktl<") and name.endswith(", 0>")      # 768-lane workgroups: 3 waves per SIMD, 168 registers
+        wide = name.startswith("k_pktg<") and name.endswith(", 6>") or name.startswith("k_pktl<") and name.endswith(", 0>") or name.startswith("k_pktls<")      # 768-lane workgroups: 3 waves per SIMD, 168 registers
         if wide:
             assert k["vgpr"] <= 168 and k["scratch"] == 0, (name, k["vgpr"], k["scratch"])
         elif name.startswith("k_pktl<"):                       # the ILP form: 512-lane workgroups, 2 waves per SIMD, 256 registers
             assert k["vgpr"] <= 256 and k["scratch"] == 0, (name, k["vgpr"], k["scratch"])
-        elif name.startswith(("k_body<", "k_bodyh<", "k_pktg<", "k_batch<", "k_batch3<")):
+        elif name.startswith(("k_body<", "k_bodyh<", "k_pktg<", "k_pktgs<", "k_batch<", "k_batch3<")):
             assert k["vgpr"] <= 128, (name, k["vgpr"])         # one 1024-lane workgroup per CU = 4 waves per SIMD
-            if name.startswith(("k_pktg<", "k_batch3<")):
+            if name.startswith(("k_pktg<", "k_pktgs<", "k_batch3<")):
                 assert k["scratch"] == 0, (name, k["scratch"])  # nothing spilled (ds_swizzle exchanges, per-packet values parked in LDS, fresh lane id)
 
 
@@ -78,9 +79,9 @@ def test_kernel_set(census):
     for name in census:
         fam.setdefault(name.split("<")[0], []).append(name)
     assert sorted(fam) == ["k_batch3", "k_body", "k_bodyh", "k_combine", "k_combine_batch", "k_copy16", "k_fill_splitmix64", "k_fold", "k_gfmul", "k_init_tables",
-                           "k_len_hist", "k_len_scan", "k_len_scatter", "k_main", "k_pktg", "k_pktl", "k_rows", "k_rows_close", "k_rows_plan", "k_rows_plan_base", "k_rows_plan_cut", "k_rows_plan_place", "k_rows_plan_slots", "k_rows_plan_sums", "k_setup", "k_setup_ptab", "k_wipe_failed"], sorted(fam)
+                           "k_len_hist", "k_len_scan", "k_len_scatter", "k_main", "k_pktg", "k_pktgs", "k_pktl", "k_pktls", "k_rows", "k_rows_close", "k_rows_plan", "k_rows_plan_base", "k_rows_plan_cut", "k_rows_plan_place", "k_rows_plan_slots", "k_rows_plan_sums", "k_setup", "k_setup_ptab", "k_wipe_failed"], sorted(fam)
     assert (len(fam["k_main"]), len(fam["k_body"]), len(fam["k_bodyh"]), len(fam["k_pktg"]), len(fam["k_pktl"]), len(fam["k_batch3"])) == (12, 15, 6, 24, 12, 21)
-    assert (len(fam["k_rows"]), len(fam["k_rows_close"])) == (6, 2)
+    assert (len(fam["k_rows"]), len(fam["k_rows_close"]), len(fam["k_pktgs"]), len(fam["k_pktls"])) == (6, 2, 18, 6)
 
 
 def test_no_sgpr_hazard_in_front_of_the_write_through_stores(census):
