@@ -610,7 +610,7 @@ int order_launch(OrderSlot &o, const u64 *d_off, size_t n_pkts, hipStream_t st, 
         o.cap = n_pkts;
     }
     LenSrc src = {d_off, nullptr, nullptr, nullptr, 0u};                            // by data length (a batch packet's AAD is short)
-    RouteCfg none = {nullptr, (u32)n_pkts, 0u, 0u, 0u, 0u, 0xFFu, 0u, 0, 0, 0, 0, 0};    // a plain order: nothing is routed
+    RouteCfg none = {nullptr, (u32)n_pkts, 0u, 0u, 0u, 0u, 0xFFu, 0u, 0, 0, 0, 0, 0, 0};    // a plain order: nothing is routed
     HIPCHK(klaunch_len_sort(st, src, (u32)n_pkts, o.bins, o.perm, none));
     *perm = o.perm;
     return AESGCM_OK;
@@ -654,8 +654,8 @@ int rows_scratch(aesgcm_ctx *c, size_t slots, size_t n, hipStream_t st, RowsScra
     return AESGCM_OK;
 }
 
-// The marks of a ROUTED call as length classes (64 bytes each) for k_len_scan: the context's "rows_min" (8 KiB) while more than 16384 messages lie below it, a
-// quarter of it otherwise -- the rule packets_by_rows applies to fixed-size records, evaluated per message on the device.  The classes resolve up to 16320 bytes.
+// The marks of a ROUTED call as length classes (64 bytes each) for k_len_scan: the context's "rows_min" (8 KiB) and a quarter of it -- the two marks packets_by_rows applies
+// to fixed-size records, chosen between per call on the device by what lies between them (k_len_scan).  The classes resolve up to 16320 bytes.
 static void route_marks(const aesgcm_ctx *c, u32 *c_hi, u32 *c_lo) {
     const u64 hi = c->rows_min / 64, lo = c->rows_min / 4 / 64;
     *c_hi = c->rows_min ? (u32)(hi < PKT_LEN_CLASSES ? hi : PKT_LEN_CLASSES - 1u) : PKT_LEN_CLASSES;      // rows_min = 0: never by rows
@@ -704,7 +704,7 @@ int packets_rows(aesgcm_ctx *c, int decrypt, RowsParams &p, hipStream_t st, PktP
             // the route: a counting sort of the messages by falling size class (data + AAD) whose scan also decides -- which messages go by rows, how many are the packet
             // kernels', and in which shape (aesgcm_rows.h RowsHdr)
             LenSrc src = {p.data_off, p.aad_off, p.len_arr, p.alen_arr, p.aad_len};
-            RouteCfg cfg = {r.hdr, (u32)n, n_cu, 0u, 0u, 16384u, 0xFFu, 0u, (u64)(uintptr_t)p.in_ptr, (u64)(uintptr_t)p.out_ptr, (u64)(uintptr_t)p.aad_ptr, (u64)(uintptr_t)p.len_arr, (u64)(uintptr_t)p.alen_arr};
+            RouteCfg cfg = {r.hdr, (u32)n, n_cu, 0u, 0u, c->route_mid_min, 0xFFu, 0u, c->route_blocks_min, (u64)(uintptr_t)p.in_ptr, (u64)(uintptr_t)p.out_ptr, (u64)(uintptr_t)p.aad_ptr, (u64)(uintptr_t)p.len_arr, (u64)(uintptr_t)p.alen_arr};
             k->scattered = p.len_arr ? 1u : 0u;
             route_marks(c, &cfg.c_hi, &cfg.c_lo);
 #ifdef AESGCM_DEBUG_KNOBS

@@ -1005,15 +1005,24 @@ __global__ __launch_bounds__(256) void k_len_hist(const LenSrc src, u32 n, u32 *
     counts[(PKT_LEN_CLASSES - 1u - threadIdx.x) * LEN_SORT_WGS + blockIdx.x] = h[threadIdx.x];
 }
 // exclusive prefix sums over the 65536 entries, in place; one workgroup.  With a route (round 6: a call whose lengths are on the device, aesgcm_rows.h RowsHdr) the same
-// workgroup then reads off the sums how many messages lie at or above each mark, and DECIDES: which messages go by rows (route_min), how many are left for the packet
+// workgroup then reads off the sums how many messages lie in each size class, and DECIDES: which messages go by rows (route_min), how many are left for the packet
 // kernels (n_small), and the packet kernel shape and deal for that many (route_pick_lg, pktg_deal) -- the host launches every shape that count could ask for and
-// all but the one named here return at once.
+// all but the one named here return at once.  The rule, from profiles/r06/route_sweep.txt (one box, AES-256, short messages only, by rows / by the packet kernels):
+//   * the MARK.  Messages between the low mark (2 KiB) and the high one (8 KiB) are slow packets -- a lane, or four, walks 128 .. 512 blocks, a few microseconds each --
+//     and fast rows; the packet kernels take them only when there are enough of them to keep every lane of the chip busy that long: U-shaped lengths below 8 KiB (half
+//     the messages tiny, half near 8 KiB), 65536 of them 0.69 ms by rows / 0.85 by packets, 131072 1.22 / 1.02, 524288 4.25 / 3.03.  So: the high mark when at least
+//     `mid_min` (65536) messages lie between the marks, else the low one.
+//   * WORTH IT AT ALL?  What is left below the mark costs the rows' closing launch a lane per block, about 11 G blocks/s; the packet kernels do 34 G blocks/s behind a
+//     start of 0.1 ms or so (their launch, the staging of 141 KiB of tables per CU, the last wave's longest packet): frames of 64 .. 1514 bytes, 16384 of them
+//     0.177 / 0.172 ms, 65536 0.35 / 0.26, 2^20 4.32 / 1.52; messages of 0 .. 128 bytes, 262144 0.19 / 0.21, 2^20 0.55 / 0.40.  So: below `blocks_min` (2^21) blocks of
+//     short messages in the whole call everything goes by rows.
 __global__ __launch_bounds__(1024) void k_len_scan(u32 *__restrict__ counts, const RouteCfg rc) {
     __shared__ u32 part[1024];
     constexpr u32 PER = LEN_SORT_ENTRIES / 1024u;
-    u32 *mine = counts + threadIdx.x * PER;
+    static_assert(PER % 4u == 0, "k_len_scan: a thread's entries as whole uint4");
+    uint4 *mine = reinterpret_cast<uint4 *>(counts + threadIdx.x * PER);                  // (16-byte accesses: a thread's 64 entries one dword at a time were 64 dependent trips to memory, 32 us of a 0.1 ms call)
     u32 s = 0;
-    for (u32 k = 0; k < PER; ++k) s += mine[k];
+    for (u32 k = 0; k < PER / 4u; ++k) { const uint4 v = mine[k]; s += v.x + v.y + v.z + v.w; }
     part[threadIdx.x] = s;
     __syncthreads();
     for (u32 d = 1; d < 1024u; d <<= 1) {                                              // Hillis-Steele over the 1024 partial sums
@@ -1023,19 +1032,36 @@ __global__ __launch_bounds__(1024) void k_len_scan(u32 *__restrict__ counts, con
         __syncthreads();
     }
     u32 run = part[threadIdx.x] - s;
-    for (u32 k = 0; k < PER; ++k) { const u32 c = mine[k]; mine[k] = run; run += c; }
+    for (u32 k = 0; k < PER / 4u; ++k) {
+        const uint4 c = mine[k];
+        uint4 o;
+        o.x = run; o.y = o.x + c.x; o.z = o.y + c.y; o.w = o.z + c.z; run = o.w + c.w;
+        mine[k] = o;
+    }
     if (!rc.hdr) return;
     __threadfence();
     __syncthreads();
+    // messages of class >= c: the position of the first message of class c - 1 (classes are laid out falling)
+    auto n_ge = [&](u32 c) { return c == 0u ? rc.n : c >= PKT_LEN_CLASSES ? 0u : counts[(PKT_LEN_CLASSES - c) * LEN_SORT_WGS]; };
+    // blocks of the messages below each mark: thread c < 256 brings its class (a message of class c has 4 c + 2 blocks, give or take two)
+    const u32 cls = threadIdx.x;
+    const u64 mine_blocks = cls < PKT_LEN_CLASSES ? (u64)(n_ge(cls) - n_ge(cls + 1u)) * (4u * cls + 2u) : 0ull;
+    __shared__ unsigned long long blk[2];
+    if (threadIdx.x < 2) blk[threadIdx.x] = 0ull;
+    __syncthreads();
+    if (cls < rc.c_lo && cls < PKT_LEN_CLASSES) atomicAdd(&blk[0], (unsigned long long)mine_blocks);
+    else if (cls < rc.c_hi && cls < PKT_LEN_CLASSES) atomicAdd(&blk[1], (unsigned long long)mine_blocks);
+    __syncthreads();
     if (threadIdx.x == 0) {
-        // messages of class >= c: the position of the first message of class c - 1 (classes are laid out falling)
-        auto n_ge = [&](u32 c) { return c == 0u ? rc.n : c >= PKT_LEN_CLASSES ? 0u : counts[(PKT_LEN_CLASSES - c) * LEN_SORT_WGS]; };
         u32 route_min, n_large;
         if (rc.c_hi >= PKT_LEN_CLASSES) { route_min = ROWS_ROUTE_NEVER; n_large = 0; }           // rows switched off
         else {
-            // the high mark (8 KiB) while the messages below it are many enough to fill the chip for the packet kernels, else the low one (2 KiB): aesgcm_host.hip, packets_by_rows
-            const u32 c = rc.n - n_ge(rc.c_hi) > rc.few ? rc.c_hi : rc.c_lo;
-            route_min = c * 64u; n_large = n_ge(c);
+            const u32 mid = n_ge(rc.c_lo) - n_ge(rc.c_hi);
+            const bool high = mid >= rc.mid_min;
+            const u32 c = high ? rc.c_hi : rc.c_lo;
+            const u64 short_blocks = blk[0] + (high ? blk[1] : 0ull);
+            if (short_blocks < rc.blocks_min) { route_min = 0; n_large = rc.n; }               // not worth a packet launch: everything by rows
+            else { route_min = c * 64u; n_large = n_ge(c); }
         }
         const u32 n_small = rc.n - n_large;
         const u32 lg = rc.force_lg != 0xFFu ? rc.force_lg : n_small ? route_pick_lg(rc.n_cu, n_small) : 0u;

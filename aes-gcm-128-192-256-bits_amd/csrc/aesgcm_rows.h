@@ -84,9 +84,10 @@ HD void pkt_place_scattered(const RowsHdr *h, u32 pkt, u64 *doff, u64 *ooff, u64
 #define ROWS_ROUTE_NEVER 0xFFFFFFFFu          /* route_min: nothing goes by rows */
 // where the sizes of a launch order (k_len_*) come from: offset arrays (aoff NULL: fixed aad_len) or per-message length arrays
 struct LenSrc { const u64 *off, *aoff; const u32 *len_arr, *alen_arr; u32 aad_len; };
-// how k_len_scan routes a call: hdr NULL = no route (a plain launch order); marks as length classes (64 bytes each; >= PKT_LEN_CLASSES = never by rows): c_hi while more than
-// `few` messages lie below it, else c_lo; force_lg != 0xFF / force_deal != 0: the debug library's forced packet kernel shape
-struct RouteCfg { RowsHdr *hdr; u32 n, n_cu, c_hi, c_lo, few, force_lg, force_deal; u64 sc_in, sc_out, sc_aad, sc_len, sc_alen; };
+// how k_len_scan routes a call: hdr NULL = no route (a plain launch order); marks as length classes (64 bytes each; >= PKT_LEN_CLASSES = never by rows): c_hi when at
+// least mid_min messages lie between the marks, else c_lo; below blocks_min blocks of short messages in all, everything goes by rows (the rule and its measurements:
+// k_len_scan); force_lg != 0xFF / force_deal != 0: the debug library's forced packet kernel shape
+struct RouteCfg { RowsHdr *hdr; u32 n, n_cu, c_hi, c_lo, mid_min, force_lg, force_deal; u64 blocks_min; u64 sc_in, sc_out, sc_aad, sc_len, sc_alen; };
 
 struct RowsParams {
     const unsigned char *ivs;                 // n_pkts * 12 bytes

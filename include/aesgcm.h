@@ -141,8 +141,11 @@ AESGCM_API int aesgcm_ctx_last_launch(const aesgcm_ctx *ctx, int *shape);
  *                 checked), aesgcm_decrypt_dev the device buffer, aesgcm_packets_crypt_dev / aesgcm_messages_crypt_dev every packet whose d_auth entry is 0 (d_auth must be given:
  *                 AESGCM_EARG for a decrypt call with d_expect_tags and without d_auth while the option is on).  Default 0:
  *                 the reference model returns the plaintext and raises (tb/gcm_model.py:29-30,47-51), and so does the class that mirrors it.
- *   "rows_min"    bytes per packet from which aesgcm_packets_crypt_dev goes by rows (default 8192; from a quarter of it while the packets below it are at most 16384; 0 = never).
- *                 With offset arrays the mark is applied per message on the device, to data + AAD, in steps of 64 bytes and up to 16320
+ *   "rows_min"    bytes per packet from which aesgcm_packets_crypt_dev goes by rows (default 8192; fixed-size records: from a quarter of it while the packets are at most 16384; 0 = never).
+ *                 With offset arrays the mark is applied per message on the device, to data + AAD, in steps of 64 bytes and up to 16320 (see "route_mid_min")
+ *   "route_mid_min", "route_blocks_min"   how a call with offset arrays is routed on the device: the mark is "rows_min" when at least route_mid_min (65536) of its messages lie
+ *                 between a quarter of rows_min and rows_min, else that quarter; and nothing goes to the packet kernels at all while the messages below the mark hold
+ *                 fewer than route_blocks_min (2^21) 16-byte blocks between them (csrc/aesgcm_kernels.hip k_len_scan has the measurements).  0 / 0: always the high mark, always split
  *   "rows_block"  units (rows of 64 blocks) per dealt block of the row kernel, 0 = the library's cut (one block per wave; blocks of 64 for large calls)
  *   "poll_us"     how long a tag is polled for in the pinned host slot before the call blocks in the runtime
  * AESGCM_EARG for an unknown key. */
@@ -294,7 +297,7 @@ AESGCM_API int aesgcm_mgpu_destroy(aesgcm_mgpu *m);
  * and data either as fixed-size records (aad_len / pkt_len, offset arrays NULL) or delimited by uint64 offset
  * arrays with n_pkts + 1 entries (then aad_len / pkt_len are ignored); tags[p] receives the computed tag; for
  * decrypt d_auth[p] (optional) = 1 if it equals d_expect_tags[p].  Asynchronous on `stream`.
- * Two families of kernels do the work.  Packets of message size -- from 8 KiB each (context option "rows_min"; from 2 KiB while at most 16384 packets lie below that), up to
+ * Two families of kernels do the work.  Packets of message size -- from 8 KiB each (context option "rows_min"; from 2 KiB unless there are many between the two), up to
  * 2^28 - 1 bytes -- go BY ROWS (round 5): the 64-block rows of all such messages are one pool of work for the row loop a single large message runs through
  * (csrc/aesgcm_rows.h), and one small launch behind it takes what is not a whole row -- headers, ragged ends -- block by block and closes every tag; 4096 x 1 MiB then runs
  * at the rate of one 4 GiB message.  Shorter packets take the packet kernels: a lane, or a group of 4 .. 16 lanes, per packet.

@@ -18,7 +18,9 @@ extern "C" {
  *        "batch_lanes" : aesgcm_batch_crypt[_var]_dev takes 8 / 16 / 64 lanes per packet (k_batch3)
  *        "batch_deal"  : packets per dispenser fetch of k_batch3 (rounded up to a multiple of the packets per wave)
  *        "pkt_ilp"     : k_pktl in its form for batches that do not fill the chip (512-lane workgroups, eight keystream chains per line) always (1) or never (2)
- *        "pkt_rows"    : aesgcm_packets_crypt_dev by rows (k_rows / k_rows_close, csrc/aesgcm_rows.h) always (1) or never (2) instead of from 64 KiB per packet
+ *        "pkt_rows"    : aesgcm_packets_crypt_dev / aesgcm_messages_crypt_dev by rows (k_rows / k_rows_close, csrc/aesgcm_rows.h) always (1) or never (2) instead of the library's
+ *                        rule (fixed-size records: from 8 KiB per packet, from 2 KiB while the packets are at most 16384; offset arrays: per message, on the device)
+ *        (a forced "pkt_lanes" also means never by rows; with offset arrays it names the shape the routed call's packet launch takes)
  *        "batch_order" : aesgcm_batch_crypt_var_dev takes its packets by falling length class always (1) or never (2) instead of from 262144 (AES-128) / 98304 packets
  * value 0 = the library's own choice again.  Not thread-safe; set it between launches. */
 AESGCM_API int aesgcm_debug_force_shape(const char *what, int value);

@@ -61,7 +61,10 @@ def check_against_libcrypto(hip, key, ivs, aad, aoff, doff, d_in, d_out, tags, c
         a = b
 
 
-def _mixed_call(hip, orc, klen, lens, aads, seed, misalign=0, sample=200):
+SPLIT = dict(route_mid_min=0, route_blocks_min=0)      # context options: always the high mark (8 KiB), always a packet launch for what lies below it -- the library's own rule sends small calls by rows altogether
+
+
+def _mixed_call(hip, orc, klen, lens, aads, seed, misalign=0, sample=200, opts=None):
     n = len(lens)
     key = splitmix_bytes(seed, klen)
     doff, aoff = [misalign], [0]
@@ -76,6 +79,8 @@ def _mixed_call(hip, orc, klen, lens, aads, seed, misalign=0, sample=200):
     d_doff, d_aoff = _up(hip, struct.pack("<%dQ" % (n + 1), *doff)), _up(hip, struct.pack("<%dQ" % (n + 1), *aoff))
     d_tags, d_auth = hip.DeviceBuffer(16 * n), hip.DeviceBuffer(4 * n)
     ctx = hip.Context(key)
+    for k, v in (opts or {}).items():
+        ctx.set_option(k, v)
     assert ctx.packets_shape(n, 0, True) == hip.SHAPE_MIXED
     ctx.packets_crypt_dev(False, n, d_ivs.ptr, d_in.ptr, d_out.ptr, d_tags.ptr, d_data_off=d_doff.ptr, d_aad=d_aad.ptr, d_aad_off=d_aoff.ptr)
     hip.dev_sync()
@@ -140,13 +145,15 @@ def test_u_shaped_lengths_up_to_1m_in_one_call(hip, orc):
     _mixed_call(hip, orc, 32, lens, aads, 62000)
 
 
-@pytest.mark.parametrize("klen,n,top", [(16, 3000, 20000), (24, 40000, 12000), (32, 300, 300000), (32, 20000, 2100)])
-def test_small_mixed_calls(hip, orc, klen, n, top):
-    """fewer messages: the low mark (2 KiB) applies while at most 16384 lie below the high one; calls whose short messages are a handful, or all of them"""
+@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("klen,n,top", [(16, 3000, 20000), (24, 40000, 12000), (32, 300, 300000), (32, 20000, 2100), (16, 150000, 3000)])
+def test_small_mixed_calls(hip, orc, klen, n, top, split):
+    """fewer messages -- by the library's own rule (the low mark, 2 KiB, unless 65536 messages lie between the marks; everything by rows while the short messages hold
+    fewer than 2^21 blocks between them) and with the split forced (context options): calls whose short messages are a handful, or all of them"""
     rng = random.Random(6200 + n)
     lens = u_shaped(rng, n, top)
     aads = [rng.choice((0, 0, 13, 20, 28, 1024)) for _ in range(n)]
-    _mixed_call(hip, orc, klen, lens, aads, 63000 + n, misalign=rng.choice((0, 3, 16)))
+    _mixed_call(hip, orc, klen, lens, aads, 63000 + n, misalign=rng.choice((0, 3, 16)), opts=SPLIT if split else None)
 
 
 @pytest.mark.parametrize("lanes", [1, 4, 8, 16, 64])
@@ -192,7 +199,7 @@ def test_messages_wherever_they_live_are_routed_too(hip, orc, klen):
     d_ivs, d_len, d_alen = _up(hip, ivs), u32s(lens), u32s(aads)
     d_inp, d_outp, d_backp, d_aadp = u64s([d_in.ptr + x for x in pos_in]), u64s([d_out.ptr + x for x in pos_out]), u64s([d_back.ptr + x for x in pos_in]), u64s([d_aad.ptr + x for x in pos_aad])
     d_tags, d_auth = hip.DeviceBuffer(16 * n), hip.DeviceBuffer(4 * n)
-    ctx = hip.Context(key)
+    ctx = hip.Context(key).set_option("route_blocks_min", 0).set_option("route_mid_min", 0)      # (the library's own rule would send a call this small by rows altogether)
     ctx.messages_crypt_dev(False, n, d_ivs.ptr, d_inp.ptr, d_len.ptr, d_outp.ptr, d_tags.ptr, d_aad_ptr=d_aadp.ptr, d_aad_len=d_alen.ptr)
     hip.dev_sync()
     assert ctx.status() == (hip.STATUS_OK, 0)
