@@ -64,7 +64,7 @@ int aesgcm_ctx_create_preexpanded(aesgcm_ctx **out, int device, const uint8_t *r
 int aesgcm_ctx_rekey(aesgcm_ctx *c, const uint8_t *key, size_t key_len) {
     if (!c || !key) return AESGCM_EARG;
     if (key_len != 16 && key_len != 24 && key_len != 32) return AESGCM_EKEYLEN;
-    if (c->s_active) return AESGCM_ESTATE;
+    if (c->s.active) return AESGCM_ESTATE;
     HIPCHK(hipSetDevice(c->device));
     // every *_dev entry point takes a caller's stream, so work that reads this context's key material may be queued on any stream of the device: wait for them all
     // (round 4 waited for the context's own stream only -- a message in flight on another stream would have read half-rebuilt tables)
@@ -524,59 +524,130 @@ int aesgcm_shard_finalize_dev(aesgcm_ctx *c, const uint8_t iv[12], const void *d
 
 
 // ---------------------------------------------------------------- streaming
-// state Y (c->d_tag[1]) = polynomial of everything absorbed so far: sum X_i H^(n-1-i)
+// state Y (c->d_tag[1]) = polynomial of everything absorbed so far: sum X_i H^(n-1-i); the bookkeeping is aesgcm_ctx::StreamState (aesgcm_internal.h)
 int aesgcm_stream_begin(aesgcm_ctx *c, const uint8_t iv[12], int decrypt) {
     if (!c || !iv) return AESGCM_EARG;
     HIPCHK(hipSetDevice(c->device));
-    memcpy(c->s_iv, iv, 12);
-    c->s_active = true; c->s_data = false; c->s_ragged = false; c->s_dec = decrypt ? 1 : 0;
-    c->s_aad_len = 0; c->s_len = 0; c->s_blocks = 0;
-    HIPCHK(hipMemsetAsync(c->d_tag + 1, 0, 16, c->stream));
-    return AESGCM_OK;
+    return stream_open(c, iv, decrypt, c->stream);
 }
 
 int aesgcm_stream_aad(aesgcm_ctx *c, const uint8_t *aad, size_t len) {
     if (!c || (len && !aad)) return AESGCM_EARG;
-    if (!c->s_active || c->s_data || c->s_ragged) return AESGCM_ESTATE;
+    if (!c->s.active || c->s.data || c->s.ragged) return AESGCM_ESTATE;
     if (!len) return AESGCM_OK;
-    if (check_lengths(c->s_aad_len + len, 0)) return AESGCM_ETOOLONG;
+    if (check_lengths(c->s.aad_len + len, 0)) return AESGCM_ETOOLONG;
     HIPCHK(hipSetDevice(c->device));
     int rc;
     if ((rc = stage_in(c, aad, len, nullptr, 0))) return rc;
     if ((rc = stream_absorb(c, c->st_aad, len, c->st_in, 0, c->st_out, 0))) return rc;
-    c->s_aad_len += len;
-    if (len & 15) c->s_ragged = true;
+    c->s.aad_len += len;
+    if (len & 15) c->s.ragged = true;
     HIPCHK(hipStreamSynchronize(c->stream));
     return AESGCM_OK;
 }
 
 int aesgcm_stream_update(aesgcm_ctx *c, const uint8_t *in, size_t len, uint8_t *out) {
     if (!c || (len && (!in || !out))) return AESGCM_EARG;
-    if (!c->s_active) return AESGCM_ESTATE;
-    if (c->s_data && c->s_ragged) return AESGCM_ESTATE;      // a ragged data chunk must be the last one
+    if (!c->s.active) return AESGCM_ESTATE;
+    if (c->s.data && c->s.ragged) return AESGCM_ESTATE;      // a ragged data chunk must be the last one
     if (!len) return AESGCM_OK;
-    if (check_lengths(c->s_aad_len, c->s_len + len)) return AESGCM_ETOOLONG;
+    if (check_lengths(c->s.aad_len, c->s.len + len)) return AESGCM_ETOOLONG;
     HIPCHK(hipSetDevice(c->device));
     int rc;
     if ((rc = stage_in(c, nullptr, 0, in, len))) return rc;
-    c->s_ragged = false;
-    if ((rc = stream_absorb(c, nullptr, 0, c->st_in, len, c->st_out, c->s_len / 16))) return rc;
-    c->s_data = true;
-    c->s_len += len;
-    if (len & 15) c->s_ragged = true;
+    c->s.ragged = false;
+    if ((rc = stream_absorb(c, nullptr, 0, c->st_in, len, c->st_out, c->s.len / 16))) return rc;
+    c->s.data = true;
+    c->s.len += len;
+    if (len & 15) c->s.ragged = true;
     HIPCHK(hipMemcpyAsync(out, c->st_out, len, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return AESGCM_OK;
 }
 
+// The same step on DEVICE pointers, asynchronous on `stream` (round 6): a chunk of any size -- it takes the launch structure a shard of that size takes -- of a message
+// whose total length nobody knows yet.  The chunks of one session must be stream-ordered (one stream, or the caller orders them), as every call on a context.
+int aesgcm_stream_update_dev(aesgcm_ctx *c, const void *d_in, size_t len, void *d_out, void *stream) {
+    if (!c || (len && (!d_in || !d_out))) return AESGCM_EARG;
+    if (!c->s.active) return AESGCM_ESTATE;
+    if (c->s.data && c->s.ragged) return AESGCM_ESTATE;
+    if (!len) return AESGCM_OK;
+    if (check_lengths(c->s.aad_len, c->s.len + len)) return AESGCM_ETOOLONG;
+    if (((uintptr_t)d_in | (uintptr_t)d_out) & 15) return AESGCM_EALIGN;
+    HIPCHK(hipSetDevice(c->device));
+    const bool was_ragged = c->s.ragged;
+    c->s.ragged = false;
+    const int rc = stream_absorb(c, nullptr, 0, d_in, len, d_out, c->s.len / 16, pick_stream(c, stream), true);
+    if (rc) { c->s.ragged = was_ragged; return rc; }
+    c->s.data = true;
+    c->s.len += len;
+    if (len & 15) c->s.ragged = true;
+    return AESGCM_OK;
+}
+
 int aesgcm_stream_final(aesgcm_ctx *c, uint8_t tag[16]) {
     if (!c || !tag) return AESGCM_EARG;
-    if (!c->s_active) return AESGCM_ESTATE;
+    if (!c->s.active) return AESGCM_ESTATE;
     HIPCHK(hipSetDevice(c->device));
-    int rc = enqueue_combine(c, plan_combine_final(c->d_tag + 1, c->s_iv, c->s_aad_len, c->s_len, c->d_tag), c->stream);
+    int rc = enqueue_combine(c, plan_combine_final(c->d_tag + 1, c->s.iv, c->s.aad_len, c->s.len, c->d_tag), c->stream);
     if (rc) return rc;
     if ((rc = fetch_tag(c, c->stream, tag))) return rc;
-    c->s_active = false;
+    c->s.active = false;
+    return AESGCM_OK;
+}
+
+// ---- the state of a message under way as 64 bytes a caller can keep, move to another context, device or process, and pick up again (SURVEY.md 5 "checkpoint /
+// resume", 8(f2): the state the RTL and the pycryptodome model cannot export -- the Y register, src/gcm_ghash.vhd:174-186, and the counter, src/aes_icb.vhd:97-100).
+//   [0] version 1   [1] direction (1 = decrypt)   [2] bit 0: data has begun, bit 1: the last chunk was ragged   [3] 0
+//   [4, 16) IV      [16, 24) AAD bytes so far     [24, 32) data bytes so far (the next counter is 2 + this / 16)      [32, 48) Y, in the library's form (the RTL's Y / H)
+//   [48, 56) GHASH blocks so far    [56, 60) key check: the first four bytes of E_K(A5 .. A5) -- NOT key material (H = E_K(0) is, and stays out)   [60, 64) sum check over [0, 60)
+// No key, no H, no table.  Y itself is a secret-dependent value of the same kind as a tag before its final XOR: treat the blob like the message's tag-in-progress.
+#define STREAM_BLOB_VERSION 1
+static u32 blob_sum(const uint8_t *b) { u32 s = 0x5EC0DE5u; for (int i = 0; i < 60; i++) s = (s << 5 | s >> 27) ^ b[i]; return s; }
+static int key_check(aesgcm_ctx *c, uint8_t out[4]) {
+    uint8_t in[16], ct[16];
+    memset(in, 0xA5, 16);
+    const int rc = aesgcm_ecb_encrypt(c, in, 1, ct);
+    if (rc) return rc;
+    memcpy(out, ct, 4);
+    return AESGCM_OK;
+}
+int aesgcm_stream_export(aesgcm_ctx *c, uint8_t blob[64]) {
+    if (!c || !blob) return AESGCM_EARG;
+    if (!c->s.active) return AESGCM_ESTATE;
+    HIPCHK(hipSetDevice(c->device));
+    memset(blob, 0, 64);
+    blob[0] = STREAM_BLOB_VERSION; blob[1] = c->s.dec ? 1 : 0; blob[2] = (uint8_t)((c->s.data ? 1 : 0) | (c->s.ragged ? 2 : 0));
+    memcpy(blob + 4, c->s.iv, 12);
+    memcpy(blob + 16, &c->s.aad_len, 8); memcpy(blob + 24, &c->s.len, 8); memcpy(blob + 48, &c->s.blocks, 8);
+    // everything this session enqueued -- on the context's stream or, for aesgcm_stream_update_dev, on the caller's -- before Y is read
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(blob + 32, c->d_tag + 1, 16, hipMemcpyDeviceToHost));
+    int rc = key_check(c, blob + 56);
+    if (rc) return rc;
+    const u32 sum = blob_sum(blob);
+    memcpy(blob + 60, &sum, 4);
+    return AESGCM_OK;
+}
+int aesgcm_stream_import(aesgcm_ctx *c, const uint8_t blob[64]) {
+    if (!c || !blob) return AESGCM_EARG;
+    if (c->s.active) return AESGCM_ESTATE;                      // a session of this context's own is open
+    u32 sum;
+    memcpy(&sum, blob + 60, 4);
+    if (blob[0] != STREAM_BLOB_VERSION || blob[1] > 1 || (blob[2] & ~3u) || blob[3] || sum != blob_sum(blob)) return AESGCM_EARG;
+    HIPCHK(hipSetDevice(c->device));
+    uint8_t kc[4];
+    int rc = key_check(c, kc);
+    if (rc) return rc;
+    if (memcmp(kc, blob + 56, 4)) { snprintf(g_err, sizeof g_err, "aesgcm_stream_import: the state was exported under another key"); return AESGCM_EARG; }
+    aesgcm_ctx::StreamState st;
+    st.active = true; st.dec = blob[1]; st.data = (blob[2] & 1) != 0; st.ragged = (blob[2] & 2) != 0;
+    memcpy(st.iv, blob + 4, 12);
+    memcpy(&st.aad_len, blob + 16, 8); memcpy(&st.len, blob + 24, 8); memcpy(&st.blocks, blob + 48, 8);
+    if (check_lengths(st.aad_len, st.len) || st.blocks != (st.aad_len + 15) / 16 + (st.len + 15) / 16 || (!st.ragged && (st.len & 15)) || (st.data ? false : st.len != 0)) return AESGCM_EARG;
+    HIPCHK(hipMemcpyAsync(c->d_tag + 1, blob + 32, 16, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->s = st;
     return AESGCM_OK;
 }
 

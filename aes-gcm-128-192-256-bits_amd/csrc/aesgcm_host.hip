@@ -523,13 +523,30 @@ int stage_in(aesgcm_ctx *c, const uint8_t *aad, size_t aad_len, const uint8_t *i
     return AESGCM_OK;
 }
 
-int stream_absorb(aesgcm_ctx *c, const void *d_aad, u64 aad_len, const void *d_in, u64 len, void *d_out, u64 first_block) {
-    Partials pp;
-    int rc = enqueue_main(c, c->s_dec ? MODE_DEC : MODE_ENC, c->s_iv, d_aad, aad_len, d_in, len, d_out, first_block, c->stream, &pp);
-    if (rc) return rc;
+// A message under way: Y <- 0 and the bookkeeping of aesgcm_ctx::StreamState (aesgcm_stream_begin, the pipelined path, aesgcm_stream_import build on this)
+int stream_open(aesgcm_ctx *c, const uint8_t iv[12], int decrypt, hipStream_t st) {
+    c->s = aesgcm_ctx::StreamState();
+    memcpy(c->s.iv, iv, 12);
+    c->s.active = true; c->s.dec = decrypt ? 1 : 0;
+    HIPCHK(hipMemsetAsync(c->d_tag + 1, 0, 16, st));
+    return AESGCM_OK;
+}
+// Y' = Y * H^nb ^ P(aad, data) on `st` (NULL: the context's stream).  large: the range may be of any size on device pointers (aesgcm_stream_update_dev) -- it takes the
+// launch structure a shard of that size takes (cyclic rows, dealt chunks; absorb_range); else one k_main launch (chunks that came through the staging buffers).
+int stream_absorb(aesgcm_ctx *c, const void *d_aad, u64 aad_len, const void *d_in, u64 len, void *d_out, u64 first_block, hipStream_t st, bool large) {
+    if (!st) st = c->stream;
     const u64 nb = (aad_len + 15) / 16 + (len + 15) / 16;
-    c->s_blocks += nb;
-    return enqueue_combine(c, combine_with_items(plan_combine_carry(pp.ptr, pp.np, pp.kind, c->d_tag + 1, nb), pp.eA), c->stream);       // Y' = Y * H^nb ^ P
+    if (large) {
+        const int rc = absorb_range(c, c->s.dec ? MODE_DEC : MODE_ENC, c->s.iv, d_aad, aad_len, d_in, len, d_out, first_block, st, c->d_tag + 1);
+        if (rc) return rc;
+        c->s.blocks += nb;
+        return AESGCM_OK;
+    }
+    Partials pp;
+    int rc = enqueue_main(c, c->s.dec ? MODE_DEC : MODE_ENC, c->s.iv, d_aad, aad_len, d_in, len, d_out, first_block, st, &pp);
+    if (rc) return rc;
+    c->s.blocks += nb;
+    return enqueue_combine(c, combine_with_items(plan_combine_carry(pp.ptr, pp.np, pp.kind, c->d_tag + 1, nb), pp.eA), st);       // Y' = Y * H^nb ^ P
 }
 
 
@@ -889,17 +906,17 @@ int crypt_pipelined(aesgcm_ctx *c, int dec, const uint8_t iv[12], const uint8_t 
     if (rc) return rc;
     // the chunk-to-chunk GHASH value lives in the streaming slot (d_tag[1], s_iv, s_dec): refuse to run inside an open
     // stream_begin .. stream_final session instead of silently corrupting its running GHASH
-    if (c->s_active) return AESGCM_ESTATE;
+    if (c->s.active) return AESGCM_ESTATE;
     if (!chunk) chunk = (size_t)64 << 20;
     chunk = (chunk + 1023) / 1024 * 1024;                    // whole rows, 16-byte aligned chunk starts
     if (chunk > len) chunk = (len + 1023) / 1024 * 1024;
     if (!chunk) chunk = 1024;
     HIPCHK(hipSetDevice(c->device));
     if ((rc = pipeline_prepare(c, chunk))) return rc;
-    // state Y <- 0, then the AAD (small; through the staging buffer on the compute stream)
-    memcpy(c->s_iv, iv, 12);
-    c->s_dec = dec ? 1 : 0;
-    HIPCHK(hipMemsetAsync(c->d_tag + 1, 0, 16, c->stream));
+    // state Y <- 0, then the AAD (small; through the staging buffer on the compute stream): the same StreamState the beat-by-beat interface keeps, open for the
+    // length of this call
+    if ((rc = stream_open(c, iv, dec, c->stream))) return rc;
+    struct Close { aesgcm_ctx *c; ~Close() { c->s.active = false; } } close_on_return{c};
     if (aad_len) {
         if ((rc = stage_in(c, aad, aad_len, nullptr, 0))) return rc;
         if ((rc = stream_absorb(c, c->st_aad, aad_len, c->st_in, 0, c->st_out, 0))) return rc;

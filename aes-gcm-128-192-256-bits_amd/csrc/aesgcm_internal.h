@@ -162,11 +162,16 @@ struct aesgcm_ctx {
     u32 route_mid_min = 65536;         // option "route_mid_min": a routed call takes the high mark (rows_min) when at least this many messages lie between a quarter of it and it, else the low one (k_len_scan)
     u64 route_blocks_min = 1u << 21;   // option "route_blocks_min": ... and sends nothing to the packet kernels when the short messages hold fewer 16-byte blocks than this in all
     u32 rows_block = 0;                // option "rows_block": units per dealt block of k_rows (0 = the library's cut: one block per wave, or blocks of ROWS_DYN_BLOCK for large calls)
-    // streaming state
-    bool s_active = false, s_data = false, s_ragged = false;
-    int s_dec = 0;
-    uint8_t s_iv[12];
-    u64 s_aad_len = 0, s_len = 0, s_blocks = 0;   // s_blocks = GHASH blocks absorbed so far
+    // The state of a message under way (round 6: ONE struct for the beat-by-beat interface, the pipelined host-buffer path and what aesgcm_stream_export carries between
+    // contexts, devices and processes): the RTL's Y register (src/gcm_ghash.vhd:174-186) and its counter (src/aes_icb.vhd:97-100) are d_tag[1] on the device -- in the
+    // library's form, the polynomial sum X_i H^(n-1-i) of the blocks absorbed so far (the RTL's Y is this value times H) -- and `len` here (the next block's counter is
+    // 2 + len / 16).
+    struct StreamState {
+        bool active = false, data = false, ragged = false;     // a session is open; data has begun (no more AAD); the last chunk was ragged (nothing but the tag may follow)
+        int dec = 0;
+        uint8_t iv[12] = {0};
+        u64 aad_len = 0, len = 0, blocks = 0;                  // bytes of AAD and of data absorbed so far; GHASH blocks absorbed so far
+    } s;
     // timing
     bool timing = false;
     bool timing_mute = false;          // head / tail launches beside k_body are not the measured kernel
@@ -210,7 +215,8 @@ int grow(unsigned char **p, size_t *cap, size_t need);
 int ctx_load_key(aesgcm_ctx *c, const uint8_t *key, size_t key_len, int pre_nr);
 int ctx_create_common(aesgcm_ctx **out, int device, const uint8_t *key, size_t key_len, int pre_nr);
 int stage_in(aesgcm_ctx *c, const uint8_t *aad, size_t aad_len, const uint8_t *in, size_t len);
-int stream_absorb(aesgcm_ctx *c, const void *d_aad, u64 aad_len, const void *d_in, u64 len, void *d_out, u64 first_block);
+int stream_absorb(aesgcm_ctx *c, const void *d_aad, u64 aad_len, const void *d_in, u64 len, void *d_out, u64 first_block, hipStream_t st = nullptr, bool large = false);
+int stream_open(aesgcm_ctx *c, const uint8_t iv[12], int decrypt, hipStream_t st);
 int packets_pick_lg(u32 n_cu, size_t n_pkts, size_t pkt_len);
 int batch_pick_lg(int n_cu, size_t n_pkts, size_t pkt_len, bool var);
 int order_launch(OrderSlot &o, const u64 *d_off, size_t n_pkts, hipStream_t st, const u32 **perm);

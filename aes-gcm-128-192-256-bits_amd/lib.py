@@ -37,7 +37,7 @@ SYMBOLS = [
     "aesgcm_comm_allreduce_f64", "aesgcm_comm_barrier", "aesgcm_comm_destroy",
     "aesgcm_mgpu_create", "aesgcm_mgpu_ranks", "aesgcm_mgpu_ctx", "aesgcm_mgpu_crypt_dev", "aesgcm_mgpu_destroy",
     "aesgcm_ctx_last_launch", "aesgcm_wipe_failed_dev", "aesgcm_mgpu_last_tags", "aesgcm_mgpu_sync", "aesgcm_batch_ceiling_probe_dev",
-    "aesgcm_ctx_status",
+    "aesgcm_ctx_status", "aesgcm_stream_update_dev", "aesgcm_stream_export", "aesgcm_stream_import",
 ]
 
 
@@ -182,6 +182,9 @@ def _typed(L):
     L.aesgcm_wipe_failed_dev.argtypes = [cint, sz, vp, sz, vp, vp, vp]
     L.aesgcm_batch_ceiling_probe_dev.argtypes = [cint, sz, sz, vp, vp, sz, vp, vp]
     L.aesgcm_ctx_status.argtypes = [vp, ctypes.POINTER(cint), ctypes.POINTER(u64)]
+    L.aesgcm_stream_update_dev.argtypes = [vp, vp, sz, vp, vp]
+    L.aesgcm_stream_export.argtypes = [vp, vp]
+    L.aesgcm_stream_import.argtypes = [vp, vp]
     if L.aesgcm_abi_version() != ABI_VERSION:
         raise ImportError("libaesgcm_hip.so ABI %d, expected %d (stale build? rebuild with `make -C csrc`)" % (L.aesgcm_abi_version(), ABI_VERSION))
     return L
@@ -631,6 +634,20 @@ class Context:
         t = ctypes.create_string_buffer(16)
         _chk(self._lib.aesgcm_stream_final(self._c, t))
         return t.raw
+
+    def stream_update_dev(self, d_in, nbytes, d_out, stream=None):
+        """aesgcm_stream_update_dev: the next chunk of the open session on device pointers, asynchronous on `stream` (None = the context's own)"""
+        _chk(self._lib.aesgcm_stream_update_dev(self._c, d_in, nbytes, d_out, stream))
+
+    def stream_export(self):
+        """aesgcm_stream_export -> the 64-byte state of the open session (no key in it); the session stays open"""
+        b = ctypes.create_string_buffer(64)
+        _chk(self._lib.aesgcm_stream_export(self._c, b))
+        return b.raw
+
+    def stream_import(self, blob):
+        """aesgcm_stream_import: open a session in this context at the point `blob` (another context's stream_export under the same key) was taken"""
+        _chk(self._lib.aesgcm_stream_import(self._c, _fixed(blob, 64, "blob")))
 
     # measurement
     def timing_enable(self, on=True):

@@ -369,11 +369,25 @@ AESGCM_API int aesgcm_batch_crypt_var_dev(int device, int decrypt, size_t n_pkts
  * tb/gcm_model.py:21-35): all AAD first, then data; every chunk except the last of its kind must be
  * a multiple of 16 bytes (the harness sends 16-byte beats, tb/gcm_sequencer.py:129-140).  Output for a
  * chunk is complete when the call returns.  State (running GHASH value, block counter) lives on the
- * device between calls. */
+ * device between calls, and can be exported and imported (below). */
 AESGCM_API int aesgcm_stream_begin(aesgcm_ctx *ctx, const uint8_t iv[12], int decrypt);
 AESGCM_API int aesgcm_stream_aad(aesgcm_ctx *ctx, const uint8_t *aad, size_t len);
 AESGCM_API int aesgcm_stream_update(aesgcm_ctx *ctx, const uint8_t *in, size_t len, uint8_t *out);
 AESGCM_API int aesgcm_stream_final(aesgcm_ctx *ctx, uint8_t tag[16]);
+/* The same step on DEVICE pointers (round 6): d_in / d_out 16-byte aligned, may alias; asynchronous on `stream` (NULL = the context's own; the chunks of one session must be
+ * stream-ordered, as every call on a context).  A chunk of any size takes the launch structure a shard of that size takes, so a message of unknown total length that is
+ * already on the GPU runs at the rate of aesgcm_shard_crypt_dev.  Every chunk but the last a multiple of 16 bytes. */
+AESGCM_API int aesgcm_stream_update_dev(aesgcm_ctx *ctx, const void *d_in, size_t len, void *d_out, void *stream);
+/* The state of the open session as 64 bytes the caller can keep, move and pick up again -- in another context of the same key, on another device, in another process
+ * (SURVEY.md 5 "checkpoint / resume", 8(f2)): what the RTL holds in its Y register (src/gcm_ghash.vhd:174-186) and its counter (src/aes_icb.vhd:97-100) and cannot hand out.
+ * blob: version, direction, IV, AAD and data bytes so far, GHASH blocks so far, the running GHASH value (in the library's form: the RTL's Y divided by H), a four-byte key
+ * check (E_K of a constant block; NOT key material -- no key, no H and no table is in the blob) and a sum check.  The running GHASH value depends on the key and the data
+ * like a tag before its final XOR: handle the blob as you would the tag-in-progress.  aesgcm_stream_export waits for everything the session has enqueued (a device
+ * synchronisation) and leaves the session open; aesgcm_stream_import opens a session in `ctx` at exactly that point (AESGCM_ESTATE if one is open already; AESGCM_EARG for
+ * a blob that is damaged, of another version, or exported under another key), after which aesgcm_stream_aad / _update / _update_dev / _final go on as if nothing had happened. */
+#define AESGCM_STREAM_STATE_BYTES 64
+AESGCM_API int aesgcm_stream_export(aesgcm_ctx *ctx, uint8_t blob[AESGCM_STREAM_STATE_BYTES]);
+AESGCM_API int aesgcm_stream_import(aesgcm_ctx *ctx, const uint8_t blob[AESGCM_STREAM_STATE_BYTES]);
 
 /* ---------------------------------------------------------------- whole messages, host pointers, pipelined
  * For data that does not start on the GPU: the message is cut into chunk_bytes
