@@ -92,6 +92,9 @@ int aesgcm_ctx_destroy(aesgcm_ctx *c) {
     if (c->d_mtag) hipFree(c->d_mtag);
     if (c->d_trace) hipFree(c->d_trace);
     if (c->rows_buf) hipFree(c->rows_buf);
+    if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->ev_join) hipEventDestroy(c->ev_join);
     pipeline_release(c);
     if (c->st_in) hipFree(c->st_in);
     if (c->st_out) hipFree(c->st_out);

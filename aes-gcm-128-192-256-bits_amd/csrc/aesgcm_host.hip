@@ -636,7 +636,7 @@ int order_launch(OrderSlot &o, const u64 *d_off, size_t n_pkts, hipStream_t st, 
 
 // ---------------------------------------------------------------- many messages under the context's key: by rows (aesgcm_rows.h)
 // the scratch of the path, carved out of one allocation: per message 16 + 4 bytes and (offset arrays) the three prefix sums, 32 bytes per record slot.  Zero at rest.
-struct RowsScratch { RowsHdr *hdr; u32 *queues; u64 *prefix, *sprefix, *plan_part; u32 *slot_base; RowsRec *rec; unsigned long long *acc; u32 *cnt; u32 *perm, *bins; };
+struct RowsScratch { RowsHdr *hdr; u32 *queues; u64 *prefix, *sprefix, *plan_part; u32 *slot_base; RowsRec *rec; unsigned long long *acc; u32 *cnt; u32 *perm, *bins; u64 *bad_part; };
 
 size_t rows_carve(unsigned char *base, size_t slots, size_t n, RowsScratch *r) {
     size_t o = 0;
@@ -653,6 +653,7 @@ size_t rows_carve(unsigned char *base, size_t slots, size_t n, RowsScratch *r) {
     t.cnt = (u32 *)take(4 * n);
     t.perm = (u32 *)take(4 * n);                                         // a routed call: the launch order of the messages that take the packet kernels (k_len_*)
     t.bins = (u32 *)take(4 * (size_t)LEN_SORT_ENTRIES);
+    t.bad_part = (u64 *)take(8 * (size_t)LEN_SORT_WGS);                  // ... and the first length each slice of the sort found it cannot take
     if (r) *r = t;
     return o;
 }
@@ -693,6 +694,7 @@ int packets_rows(aesgcm_ctx *c, int decrypt, RowsParams &p, hipStream_t st, PktP
     if (k && !var) return AESGCM_EARG;
     u32 wgs = (u32)c->G / 2;                                                 // one 141 KiB workgroup per CU
     const u32 n_cu = wgs;
+    hipStream_t rows_st = st;                                                // where the row launches go: the caller's stream, or (a routed call) the side stream
     size_t slots;
     if (!var) {
         const RowsGeom g = rows_geom(p.pkt_len);
@@ -728,11 +730,23 @@ int packets_rows(aesgcm_ctx *c, int decrypt, RowsParams &p, hipStream_t st, PktP
             if (g_force.pkt_lanes) cfg.force_lg = g_force.pkt_lanes == 1 ? 0u : g_force.pkt_lanes == 64 ? (p.len_arr ? 4u : 6u) : g_force.pkt_lanes == 16 ? 4u : g_force.pkt_lanes == 8 ? 3u : 2u;      // (messages wherever they live have no wave-per-packet instance: 16 lanes)
             if (g_force.pkt_deal >= 1 && g_force.pkt_deal <= (int)PKTG_MAX_DEAL) cfg.force_deal = (u32)g_force.pkt_deal;
 #endif
-            HIPCHK(klaunch_len_sort(st, src, (u32)n, r.bins, r.perm, cfg));
+            // (the sort also checks every length: a call with one of 2^28 bytes or more is refused by its scan -- hdr->bad -- and every launch behind returns at once)
+            HIPCHK(klaunch_len_sort(st, src, (u32)n, r.bins, r.perm, cfg, r.bad_part, reinterpret_cast<u32 *>(c->h_tag_dev + 2)));
             k->perm = r.perm; k->route = r.hdr; k->counter = &r.hdr->pkt_counter; k->counter_base = 0; k->plain = 0;
             k->n_pkts = (u32)n;
-            // (the plan below may refuse the call -- a length of 2^28 bytes or more --: then the packet kernels return at once as well)
-            HIPCHK(klaunch_rows_plan(st, p, k != nullptr, c->rows_block, (u32)ROWS_NB_CAP, r.plan_part, reinterpret_cast<u32 *>(c->h_tag_dev + 2)));
+            // Behind the sort the call FORKS: the row launches (plan, k_rows, k_rows_close) go to the context's side stream, the packet kernels stay on the caller's, and
+            // the caller's stream waits for the side stream at the end.  The two halves share nothing but the header the scan left (read-only from here on, except the
+            // plan's own fields); a call of frames alone no longer waits for seven launches that find nothing to do, and the tail of the packet launch -- its last
+            // waves' longest packets -- runs beside the first rows.
+            if (!c->side) {
+                HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+                HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+                HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+            }
+            HIPCHK(hipEventRecord(c->ev_fork, st));
+            HIPCHK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+            rows_st = c->side;
+            HIPCHK(klaunch_rows_plan(rows_st, p, true, c->rows_block, (u32)ROWS_NB_CAP, r.plan_part, reinterpret_cast<u32 *>(c->h_tag_dev + 2)));
             // every shape the count of small messages -- anything up to n -- could ask for; all but the one k_len_scan named return before they stage a table
             const u32 lg_min = cfg.force_lg != 0xFFu ? cfg.force_lg : route_pick_lg(n_cu, n), lg_max = cfg.force_lg != 0xFFu ? cfg.force_lg : 4u;
             static const u32 shapes[] = {0u, 2u, 3u, 4u, 6u};
@@ -751,14 +765,15 @@ int packets_rows(aesgcm_ctx *c, int decrypt, RowsParams &p, hipStream_t st, PktP
                 }
             }
         } else {
-            HIPCHK(klaunch_rows_plan(st, p, k != nullptr, c->rows_block, (u32)ROWS_NB_CAP, r.plan_part, reinterpret_cast<u32 *>(c->h_tag_dev + 2)));
+            HIPCHK(klaunch_rows_plan(st, p, false, c->rows_block, (u32)ROWS_NB_CAP, r.plan_part, reinterpret_cast<u32 *>(c->h_tag_dev + 2)));
         }
     }
     p.prio_rows = c->cyc_prio;
-    if (wgs) HIPCHK(klaunch_rows(c->nr, decrypt, wgs, st, c->km, c->tables, p));                          // (fixed-size records of no bytes and no AAD have no units: their tags are the closing's alone)
+    if (wgs) HIPCHK(klaunch_rows(c->nr, decrypt, wgs, rows_st, c->km, c->tables, p));                          // (fixed-size records of no bytes and no AAD have no units: their tags are the closing's alone)
     size_t close_lanes = p.slot_cap > n ? p.slot_cap : n;                                                    // a lane per record slot and per message; the lanes stride, so the grid is capped (and with offset arrays most slots of the worst case are never given out)
     if (close_lanes > (size_t)4096 * ROWS_CLOSE_WG) close_lanes = (size_t)4096 * ROWS_CLOSE_WG;
-    HIPCHK(klaunch_rows_close(decrypt, (unsigned)((close_lanes + ROWS_CLOSE_WG - 1) / ROWS_CLOSE_WG), st, c->km, c->tables, p));
+    HIPCHK(klaunch_rows_close(decrypt, (unsigned)((close_lanes + ROWS_CLOSE_WG - 1) / ROWS_CLOSE_WG), rows_st, c->km, c->tables, p));
+    if (rows_st != st) { HIPCHK(hipEventRecord(c->ev_join, rows_st)); HIPCHK(hipStreamWaitEvent(st, c->ev_join, 0)); }      // the join
     c->rows_dirty = false;
     return AESGCM_OK;
 }

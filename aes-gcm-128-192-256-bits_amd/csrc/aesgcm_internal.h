@@ -69,7 +69,7 @@ hipError_t klaunch_combine_batch(unsigned n, hipStream_t st, const KeyMaterial *
 hipError_t klaunch_pktl(int nr, int dec, bool ilp, unsigned wgs, hipStream_t st, const KeyMaterial *km, const DevTables *tb, const PktParams &p);
 hipError_t klaunch_pktg(int nr, int dec, int lg, unsigned wgs, hipStream_t st, const KeyMaterial *km, const DevTables *tb, const PktParams &p);
 hipError_t klaunch_batch3(int nr, int dec, int lg, unsigned wgs, hipStream_t st, const DevTables *tb, const BatchParams &p);
-hipError_t klaunch_len_sort(hipStream_t st, const LenSrc &src, u32 n, u32 *bins, u32 *perm, const RouteCfg &rc);                           // k_len_hist, k_len_scan (+ the route of the call), k_len_scatter
+hipError_t klaunch_len_sort(hipStream_t st, const LenSrc &src, u32 n, u32 *bins, u32 *perm, const RouteCfg &rc, u64 *bad_part = nullptr, u32 *host_status = nullptr);                           // k_len_hist, k_len_scan (+ the route of the call), k_len_scatter
 hipError_t klaunch_rows_plan(hipStream_t st, const RowsParams &p, bool routed, u32 force_d, u32 nb_cap, u64 *part, u32 *host_status);      // p: the lengths' arrays, n_pkts, waves, slot_cap, and the scratch arrays the plan fills (hdr, prefix, sprefix, slot_base)
 hipError_t klaunch_rows(int nr, int dec, unsigned wgs, hipStream_t st, const KeyMaterial *km, const DevTables *tb, const RowsParams &p);
 hipError_t klaunch_rows_close(int dec, unsigned wgs, hipStream_t st, const KeyMaterial *km, const DevTables *tb, const RowsParams &p);
@@ -155,6 +155,8 @@ struct aesgcm_ctx {
     hipStream_t pl_in = nullptr, pl_out = nullptr;
     hipEvent_t pl_ev_h2d[2] = {nullptr, nullptr}, pl_ev_k[2] = {nullptr, nullptr}, pl_ev_d2h[2] = {nullptr, nullptr};
     // many messages through the row kernel (k_rows, aesgcm_rows.h): one block of device scratch, grown on demand
+    hipStream_t side = nullptr;        // a routed call's row launches (plan, k_rows, k_rows_close) run here, beside the packet kernels on the caller's stream: forked and joined with the two events
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     unsigned char *rows_buf = nullptr;
     size_t rows_cap_slots = 0, rows_cap_n = 0;
     bool rows_dirty = true;            // the scratch is not known to be zero (fresh, or a launch failed between k_rows and k_rows_close)

@@ -994,15 +994,25 @@ __device__ __forceinline__ void len_sort_slice(u32 n, u32 &lo, u32 &hi) {
     lo = blockIdx.x * per < n ? blockIdx.x * per : n;
     hi = lo + per < n ? lo + per : n;
 }
-__global__ __launch_bounds__(256) void k_len_hist(const LenSrc src, u32 n, u32 *__restrict__ counts) {
+// bad_part != NULL (a routed call): the launch also CHECKS every length it reads -- data or AAD of 2^28 bytes or more, offsets that do not rise (the difference wraps) --
+// and leaves the first such message of its slice (or ~0) for k_len_scan, which refuses the call before anything else has run
+__global__ __launch_bounds__(256) void k_len_hist(const LenSrc src, u32 n, u32 *__restrict__ counts, unsigned long long *__restrict__ bad_part) {
     __shared__ u32 h[PKT_LEN_CLASSES];
+    __shared__ unsigned long long first_bad;
     h[threadIdx.x] = 0;
+    if (threadIdx.x == 0) first_bad = ~0ull;
     __syncthreads();
     u32 lo, hi;
     len_sort_slice(n, lo, hi);
-    for (u32 i = lo + threadIdx.x; i < hi; i += 256u) atomicAdd(&h[pkt_len_class(len_src_size(src, i))], 1u);
+    unsigned long long bad = ~0ull;
+    for (u32 i = lo + threadIdx.x; i < hi; i += 256u) {
+        atomicAdd(&h[pkt_len_class(len_src_size(src, i))], 1u);
+        if (bad_part && bad == ~0ull && (len_src_data(src, i) >= ROWS_LEN_LIMIT || len_src_aad(src, i) >= ROWS_LEN_LIMIT)) bad = i;
+    }
+    if (bad != ~0ull) atomicMin(&first_bad, bad);
     __syncthreads();
     counts[(PKT_LEN_CLASSES - 1u - threadIdx.x) * LEN_SORT_WGS + blockIdx.x] = h[threadIdx.x];
+    if (bad_part && threadIdx.x == 0) bad_part[blockIdx.x] = first_bad;
 }
 // exclusive prefix sums over the 65536 entries, in place; one workgroup.  With a route (round 6: a call whose lengths are on the device, aesgcm_rows.h RowsHdr) the same
 // workgroup then reads off the sums how many messages lie in each size class, and DECIDES: which messages go by rows (route_min), how many are left for the packet
@@ -1016,7 +1026,7 @@ __global__ __launch_bounds__(256) void k_len_hist(const LenSrc src, u32 n, u32 *
 //     start of 0.1 ms or so (their launch, the staging of 141 KiB of tables per CU, the last wave's longest packet): frames of 64 .. 1514 bytes, 16384 of them
 //     0.177 / 0.172 ms, 65536 0.35 / 0.26, 2^20 4.32 / 1.52; messages of 0 .. 128 bytes, 262144 0.19 / 0.21, 2^20 0.55 / 0.40.  So: below `blocks_min` (2^21) blocks of
 //     short messages in the whole call everything goes by rows.
-__global__ __launch_bounds__(1024) void k_len_scan(u32 *__restrict__ counts, const RouteCfg rc) {
+__global__ __launch_bounds__(1024) void k_len_scan(u32 *__restrict__ counts, const RouteCfg rc, const unsigned long long *__restrict__ bad_part, volatile u32 *host_status) {
     __shared__ u32 part[1024];
     constexpr u32 PER = LEN_SORT_ENTRIES / 1024u;
     static_assert(PER % 4u == 0, "k_len_scan: a thread's entries as whole uint4");
@@ -1039,20 +1049,27 @@ __global__ __launch_bounds__(1024) void k_len_scan(u32 *__restrict__ counts, con
         mine[k] = o;
     }
     if (!rc.hdr) return;
-    __threadfence();
-    __syncthreads();
-    // messages of class >= c: the position of the first message of class c - 1 (classes are laid out falling)
-    auto n_ge = [&](u32 c) { return c == 0u ? rc.n : c >= PKT_LEN_CLASSES ? 0u : counts[(PKT_LEN_CLASSES - c) * LEN_SORT_WGS]; };
+    // messages of class >= c: the position of the first message of class c - 1 (classes are laid out falling) -- entry (256 - c) * LEN_SORT_WGS, the first entry of
+    // thread (256 - c) * LEN_SORT_WGS / PER, whose exclusive prefix is the inclusive one of the thread in front of it: straight from the scan's LDS (reading it back from
+    // memory needed a device-scope fence behind 256 KiB of stores: 20 us of this launch)
+    static_assert(LEN_SORT_WGS % PER == 0, "k_len_scan: a class starts at a thread's first entry");
+    auto n_ge = [&](u32 c) { return c == 0u ? rc.n : c >= PKT_LEN_CLASSES ? 0u : part[(PKT_LEN_CLASSES - c) * (LEN_SORT_WGS / PER) - 1u]; };
     // blocks of the messages below each mark: thread c < 256 brings its class (a message of class c has 4 c + 2 blocks, give or take two)
     const u32 cls = threadIdx.x;
     const u64 mine_blocks = cls < PKT_LEN_CLASSES ? (u64)(n_ge(cls) - n_ge(cls + 1u)) * (4u * cls + 2u) : 0ull;
-    __shared__ unsigned long long blk[2];
+    __shared__ unsigned long long blk[3];
     if (threadIdx.x < 2) blk[threadIdx.x] = 0ull;
+    if (threadIdx.x == 2) blk[2] = ~0ull;
     __syncthreads();
     if (cls < rc.c_lo && cls < PKT_LEN_CLASSES) atomicAdd(&blk[0], (unsigned long long)mine_blocks);
     else if (cls < rc.c_hi && cls < PKT_LEN_CLASSES) atomicAdd(&blk[1], (unsigned long long)mine_blocks);
+    if (bad_part && threadIdx.x < LEN_SORT_WGS && bad_part[threadIdx.x] != ~0ull) atomicMin(&blk[2], bad_part[threadIdx.x]);      // the first length the call cannot take (k_len_hist)
     __syncthreads();
     if (threadIdx.x == 0) {
+        // the verdict on the call's lengths: refused here, before the packet kernels or the row launches (which run side by side behind this launch) have touched anything
+        const u64 first_bad = blk[2];
+        rc.hdr->bad = first_bad != ~0ull ? 1u : 0u; rc.hdr->status = first_bad != ~0ull ? ROWS_ST_LENGTH : ROWS_ST_OK; rc.hdr->detail = first_bad != ~0ull ? first_bad : 0ull;
+        if (first_bad != ~0ull && host_status) { host_status[2] = (u32)first_bad; host_status[3] = (u32)(first_bad >> 32); __threadfence_system(); host_status[0] = ROWS_ST_LENGTH; }
         u32 route_min, n_large;
         if (rc.c_hi >= PKT_LEN_CLASSES) { route_min = ROWS_ROUTE_NEVER; n_large = 0; }           // rows switched off
         else {
@@ -1337,16 +1354,25 @@ struct RowsPlan {
     u64 *part;                                                               // 4 x nwg: units, smalls blocks, slots, first bad message per workgroup -- then what lies in front of each
     volatile u32 *host_status;                                               // the context's pinned host slot: {code, 0, detail lo, detail hi}, or NULL
 };
-__device__ __forceinline__ u64 block_scan_u64(unsigned long long *part, u64 mine, u32 tid) {      // exclusive prefix of `mine` over the 1024 threads; part[1023] = the total afterwards
-    part[tid] = mine;
+// exclusive prefix of `mine` over the 1024 threads; part[1023] = the total afterwards.  Wave scans by lane shuffles and one scan of the 16 wave totals (round 6: the
+// Hillis-Steele form over LDS -- ten steps, two barriers each -- made the three scans of a plan launch 17 - 20 us for 2^20 messages)
+__device__ __forceinline__ u64 block_scan_u64(unsigned long long *part, u64 mine, u32 tid) {
+    const u32 lane = tid & 63u, w = tid >> 6;
+    unsigned long long v = mine;
+#pragma unroll
+    for (u32 off = 1; off < 64u; off <<= 1) { const unsigned long long t = __shfl_up(v, off); if (lane >= off) v += t; }
+    __syncthreads();                                                         // (whoever still reads part[] from an earlier call)
+    if (lane == 63u) part[w] = v;
     __syncthreads();
-    for (u32 d = 1; d < 1024u; d <<= 1) {                                    // Hillis-Steele
-        const u64 v = tid >= d ? part[tid - d] : 0ull;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
+    if (w == 0) {
+        unsigned long long x = lane < 16u ? part[lane] : 0ull;
+#pragma unroll
+        for (u32 off = 1; off < 16u; off <<= 1) { const unsigned long long t = __shfl_up(x, off); if (lane >= off) x += t; }
+        if (lane < 16u) part[16u + lane] = x;
+        if (lane == 15u) part[1023] = x;
     }
-    return part[tid] - mine;
+    __syncthreads();
+    return (w ? part[16u + w - 1u] : 0ull) + v - mine;
 }
 __device__ __forceinline__ u64 block_min_u64(unsigned long long *part, u64 mine, u32 tid) {       // the minimum of `mine` over the 1024 threads (everybody gets it)
     __syncthreads();
@@ -1408,9 +1434,10 @@ __global__ __launch_bounds__(1024) void k_rows_plan(const RowsPlan a) {
     }
     if (tid == 0) {
         a.prefix[n] = GR; a.sprefix[n] = ST; a.slot_base[n] = (u32)(slots <= a.slot_cap ? slots : 0);
-        a.hdr->G = G; a.hdr->D = D; a.hdr->NB = NB; a.hdr->dyn = dyn; a.hdr->bad = 0; a.hdr->status = ROWS_ST_OK; a.hdr->detail = 0;
-        if (!a.routed) { a.hdr->route_min = 0; a.hdr->n_small = 0; }           // (not routed: everything by rows -- what the row launches read the header for)
-        if (first_bad != ~0ull) plan_refuse(a, ROWS_ST_LENGTH, first_bad);
+        a.hdr->G = G; a.hdr->D = D; a.hdr->NB = NB; a.hdr->dyn = dyn;
+        if (!a.routed) { a.hdr->bad = 0; a.hdr->status = ROWS_ST_OK; a.hdr->detail = 0; a.hdr->route_min = 0; a.hdr->n_small = 0; }           // (not routed: everything by rows -- what the row launches read the header for; a routed call has its verdict on the lengths from k_len_scan already)
+        if (a.hdr->bad) { a.hdr->G = 0; a.hdr->NB = 0; }
+        else if (first_bad != ~0ull) plan_refuse(a, ROWS_ST_LENGTH, first_bad);
         else if (!cut_ok) plan_refuse(a, ROWS_ST_UNITS, G);
         else if (slots > a.slot_cap) plan_refuse(a, ROWS_ST_PLAN_FIT, slots);   // (the host sizes the scratch for the worst case; a cut that does not fit would be its bug: then nothing runs)
     }
@@ -1457,10 +1484,11 @@ __global__ __launch_bounds__(1024) void k_rows_plan_cut(const RowsPlan a) {
     if (tid == 0) {
         u32 D, NB, dyn;
         const bool cut_ok = rows_cut(GR, a.waves, a.force_d, a.nb_cap, &D, &NB, &dyn);
-        a.hdr->G = GR; a.hdr->D = D; a.hdr->NB = NB; a.hdr->dyn = dyn; a.hdr->bad = 0; a.hdr->status = ROWS_ST_OK; a.hdr->detail = 0;
-        if (!a.routed) { a.hdr->route_min = 0; a.hdr->n_small = 0; }
+        a.hdr->G = GR; a.hdr->D = D; a.hdr->NB = NB; a.hdr->dyn = dyn;
+        if (!a.routed) { a.hdr->bad = 0; a.hdr->status = ROWS_ST_OK; a.hdr->detail = 0; a.hdr->route_min = 0; a.hdr->n_small = 0; }
         a.prefix[a.n] = GR; a.sprefix[a.n] = ST;
-        if (first_bad != ~0ull) plan_refuse(a, ROWS_ST_LENGTH, first_bad);
+        if (a.hdr->bad) { a.hdr->G = 0; a.hdr->NB = 0; }
+        else if (first_bad != ~0ull) plan_refuse(a, ROWS_ST_LENGTH, first_bad);
         else if (!cut_ok) plan_refuse(a, ROWS_ST_UNITS, GR);
     }
 }
@@ -1670,9 +1698,9 @@ hipError_t klaunch_batch3(int nr, int dec, int lg, unsigned wgs, hipStream_t st,
 #undef LB3
     return hipGetLastError();
 }
-hipError_t klaunch_len_sort(hipStream_t st, const LenSrc &src, u32 n, u32 *bins, u32 *perm, const RouteCfg &rc) {
-    hipLaunchKernelGGL(k_len_hist, dim3(LEN_SORT_WGS), dim3(256), 0, st, src, n, bins);
-    hipLaunchKernelGGL(k_len_scan, dim3(1), dim3(1024), 0, st, bins, rc);
+hipError_t klaunch_len_sort(hipStream_t st, const LenSrc &src, u32 n, u32 *bins, u32 *perm, const RouteCfg &rc, u64 *bad_part, u32 *host_status) {
+    hipLaunchKernelGGL(k_len_hist, dim3(LEN_SORT_WGS), dim3(256), 0, st, src, n, bins, (unsigned long long *)bad_part);
+    hipLaunchKernelGGL(k_len_scan, dim3(1), dim3(1024), 0, st, bins, rc, (const unsigned long long *)bad_part, (volatile u32 *)host_status);
     hipLaunchKernelGGL(k_len_scatter, dim3(LEN_SORT_WGS), dim3(256), 0, st, src, n, bins, perm, (const RowsHdr *)rc.hdr);
     return hipGetLastError();
 }

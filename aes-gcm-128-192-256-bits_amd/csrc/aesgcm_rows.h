@@ -61,9 +61,11 @@ struct RowsRec { G128 w; u64 e; u32 msg; u32 flags; };     // one piece: 32 byte
 // What the device decides about a call whose lengths are on the device (64 bytes of the context's scratch, rewritten by every such call):
 //   * by k_len_scan (round 6, the ROUTE of the call): route_min -- messages of at least this many bytes (data + AAD) go by rows, the others to the packet kernels --,
 //     n_small (how many take the packet kernels: the first n_small entries of the launch order `perm`), pkt_lg / pkt_deal (the packet kernel shape for that count and
-//     its packets per dispenser fetch), pkt_counter (that launch's dispenser, zero again);
-//   * by k_rows_plan*: the cut (G, D, NB, dyn) and the verdict: bad != 0 -- NOTHING of the call runs (every kernel behind the plan returns at once, outputs and tags are
-//     untouched) -- with the reason in status / detail, which the plan also stores in the context's pinned host slot (aesgcm_ctx_status).
+//     its packets per dispenser fetch), pkt_counter (that launch's dispenser, zero again); and the VERDICT on the call's lengths (k_len_hist checks every one it reads):
+//     bad != 0 -- NOTHING of the call runs (every kernel behind returns at once, outputs and tags are untouched) -- with the reason in status / detail, also stored in the
+//     context's pinned host slot (aesgcm_ctx_status);
+//   * by k_rows_plan*: the cut (G, D, NB, dyn) -- and the verdict itself for a call that is not routed (fixed-size data with an AAD offset array), or when the cut does not
+//     fit (PLAN, UNITS: not reachable with the scratch the host sizes; the row launches do not run then);
 //   * for the packet kernels of a call whose messages live WHEREVER (aesgcm_messages_crypt_dev): the five arrays of addresses and lengths (sc_*; zero = offsets from the
 //     call's buffers).  They ride here, behind the one pointer the packet kernels get, rather than in the kernels' own arguments: ten more scalar registers held across
 //     the packet loops cost k_pktg its last free vector register (16 - 24 bytes of scratch in the 4-lane shape).
@@ -130,11 +132,9 @@ HD RowsGeom rows_geom(u64 len) {
 }
 // the size a routed call goes by: data + AAD (a lane of the packet kernels walks both, block by block); saturating, so that lengths beyond the limit -- which the plan refuses -- route somewhere defined
 HD u32 rows_route_size(u64 len, u64 alen) { const u64 t = len + alen; return t < len || t > 0xFFFFFFFEull ? 0xFFFFFFFEu : (u32)t; }
-HD u32 len_src_size(const LenSrc &s, u32 i) {
-    const u64 len = s.len_arr ? (u64)s.len_arr[i] : s.off[i + 1] - s.off[i];
-    const u64 alen = s.len_arr ? (s.alen_arr ? (u64)s.alen_arr[i] : 0ull) : s.aoff ? s.aoff[i + 1] - s.aoff[i] : (u64)s.aad_len;
-    return rows_route_size(len, alen);
-}
+HD u64 len_src_data(const LenSrc &s, u32 i) { return s.len_arr ? (u64)s.len_arr[i] : s.off[i + 1] - s.off[i]; }
+HD u64 len_src_aad(const LenSrc &s, u32 i) { return s.len_arr ? (s.alen_arr ? (u64)s.alen_arr[i] : 0ull) : s.aoff ? s.aoff[i + 1] - s.aoff[i] : (u64)s.aad_len; }
+HD u32 len_src_size(const LenSrc &s, u32 i) { return rows_route_size(len_src_data(s, i), len_src_aad(s, i)); }
 // A message of a ROUTED call below the mark is the packet kernels': to the row launches it is a message of NO bytes and NO AAD that also owes nothing -- no unit, no
 // smalls block, no record slot, no arrival (its tag comes from the packet kernel).  Everything that counts a message's share goes through these two (the geometry of
 // an empty message, an AAD of no blocks), so the counts below need no word about routing

@@ -101,9 +101,14 @@ def test_refusals(hip, orc):
     want_ct, want_tag = orc.Fast(key).encrypt(iv, b"header", bytes(64) + tail)
     for x in (a, b):
         assert x.stream_update(tail) == want_ct[64:] and x.stream_final() == want_tag
-    with pytest.raises(hip.AesGcmError):
-        a.encrypt_pipelined                                      # (attribute exists)
-        a.stream_begin(iv); a.encrypt_pipelined(iv, b"", bytes(100))     # the pipelined path shares the state slot: refused inside an open session
+    a.stream_begin(iv)
+    with pytest.raises(hip.AesGcmError) as ei:
+        a.encrypt_pipelined(iv, b"", bytes(100))                 # the pipelined path keeps its state in the same slot: refused inside an open session
+    assert ei.value.code == hip.ESTATE
+    a.stream_final()
+    assert a.encrypt_pipelined(iv, b"header", bytes(64) + tail) == (want_ct, want_tag)      # ... and is itself a session that closes behind it
+    a.stream_begin(iv)
+    a.stream_final()
 
 
 CHILD = r"""
@@ -111,7 +116,8 @@ import json, sys
 sys.path.insert(0, %(root)r)
 import aesgcm_amd
 from aesgcm_amd import lib
-key, iv, aad, head = (bytes.fromhex(x) for x in sys.argv[1:5])
+key, iv, aad = (bytes.fromhex(x) for x in sys.argv[1:4])
+head = open(sys.argv[4], "rb").read()
 c = lib.Context(key)
 c.stream_begin(iv)
 c.stream_aad(aad)
@@ -128,8 +134,10 @@ def test_across_two_processes_through_a_file(hip, orc, tmp_path):
     key, iv, aad = splitmix_bytes(8200, 32), splitmix_bytes(8201, 12), splitmix_bytes(8202, 28)
     pt = splitmix_bytes(8203, (1 << 20) + 48 + 70001)
     cut = (1 << 20) + 48
-    path = str(tmp_path / "state.json")
-    p = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}, key.hex(), iv.hex(), aad.hex(), pt[:cut].hex(), path], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    path, head = str(tmp_path / "state.json"), str(tmp_path / "head.bin")
+    with open(head, "wb") as fh:
+        fh.write(pt[:cut])
+    p = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}, key.hex(), iv.hex(), aad.hex(), head, path], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     st = json.load(open(path))
     c = hip.Context(key)
