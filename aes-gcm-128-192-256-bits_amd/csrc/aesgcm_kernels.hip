@@ -1022,38 +1022,45 @@ __global__ __launch_bounds__(256) void k_len_hist(const LenSrc src, u32 n, u32 *
 //     and fast rows; the packet kernels take them only when there are enough of them to keep every lane of the chip busy that long: U-shaped lengths below 8 KiB (half
 //     the messages tiny, half near 8 KiB), 65536 of them 0.69 ms by rows / 0.85 by packets, 131072 1.22 / 1.02, 524288 4.25 / 3.03.  So: the high mark when at least
 //     `mid_min` (65536) messages lie between the marks, else the low one.
-//   * WORTH IT AT ALL?  What is left below the mark costs the rows' closing launch a lane per block, about 11 G blocks/s; the packet kernels do 34 G blocks/s behind a
-//     start of 0.1 ms or so (their launch, the staging of 141 KiB of tables per CU, the last wave's longest packet): frames of 64 .. 1514 bytes, 16384 of them
-//     0.177 / 0.172 ms, 65536 0.35 / 0.26, 2^20 4.32 / 1.52; messages of 0 .. 128 bytes, 262144 0.19 / 0.21, 2^20 0.55 / 0.40.  So: below `blocks_min` (2^21) blocks of
-//     short messages in the whole call everything goes by rows.
+//   * WORTH IT AT ALL?  What is left below the mark costs the rows' closing launch a lane per block, 12 G blocks/s, and next to nothing per message; the packet kernels
+//     do 45 G blocks/s but pay for every message (its E_K(J0), its length block, its closing) and for their own start: fitted to the sweep, ms for n messages of B
+//     blocks, rows 0.10 + 0.08 n/10^6 + 0.080 B/10^6, packets 0.12 + 0.17 n/10^6 + 0.022 B/10^6 (and more per message where lane groups, not lanes, take them).
+//     Frames of 64 .. 1514 bytes, 16384 of them 0.194 / 0.147 ms, 131072 0.62 / 0.32, 2^20 4.34 / 1.44; messages of 0 .. 128 bytes, 131072 0.161 / 0.242, 2^20
+//     0.56 / 0.40.  So: the packet kernels when the short messages hold at least `blocks_min` (2^18) + 4 per message blocks, else everything goes by rows.
+#define ROUTE_BLOCKS_PER_MSG 4ull
 __global__ __launch_bounds__(1024) void k_len_scan(u32 *__restrict__ counts, const RouteCfg rc, const unsigned long long *__restrict__ bad_part, volatile u32 *host_status) {
-    __shared__ u32 part[1024];
-    constexpr u32 PER = LEN_SORT_ENTRIES / 1024u;
-    static_assert(PER % 4u == 0, "k_len_scan: a thread's entries as whole uint4");
-    uint4 *mine = reinterpret_cast<uint4 *>(counts + threadIdx.x * PER);                  // (16-byte accesses: a thread's 64 entries one dword at a time were 64 dependent trips to memory, 32 us of a 0.1 ms call)
+    // Every wave owns 4096 consecutive entries (16 classes) and walks them 64 at a time, a lane per entry: coalesced loads and stores, a wave scan by lane shuffles per
+    // step and a carry.  (Until round 6 a thread owned 64 consecutive entries: every load of a wave touched 64 cache lines, 128 KiB of lines in flight per step through
+    // one CU's 32 KiB of L1 -- the launch took 29 - 32 us, a third of what a call of 16384 frames costs.)
+    __shared__ u32 wave_base[16];
+    __shared__ u32 start_of_class[PKT_LEN_CLASSES];                                        // exclusive prefix at the first entry of every class row: messages of a LONGER class
+    constexpr u32 PER_WAVE = LEN_SORT_ENTRIES / 16u;
+    static_assert(LEN_SORT_ENTRIES % (16u * 64u) == 0 && LEN_SORT_WGS % 64u == 0, "k_len_scan: whole steps of 64 entries per wave, class rows that start on a step");
+    const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    u32 *seg = counts + w * PER_WAVE;
     u32 s = 0;
-    for (u32 k = 0; k < PER / 4u; ++k) { const uint4 v = mine[k]; s += v.x + v.y + v.z + v.w; }
-    part[threadIdx.x] = s;
+    for (u32 k = 0; k < PER_WAVE / 64u; ++k) s += seg[k * 64u + lane];
+#pragma unroll
+    for (u32 off = 32u; off; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) wave_base[w] = s;
     __syncthreads();
-    for (u32 d = 1; d < 1024u; d <<= 1) {                                              // Hillis-Steele over the 1024 partial sums
-        const u32 v = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
-        __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
-    }
-    u32 run = part[threadIdx.x] - s;
-    for (u32 k = 0; k < PER / 4u; ++k) {
-        const uint4 c = mine[k];
-        uint4 o;
-        o.x = run; o.y = o.x + c.x; o.z = o.y + c.y; o.w = o.z + c.z; run = o.w + c.w;
-        mine[k] = o;
+    u32 carry = 0;
+    for (u32 i = 0; i < w; ++i) carry += wave_base[i];
+    for (u32 k = 0; k < PER_WAVE / 64u; ++k) {
+        const u32 v = seg[k * 64u + lane];
+        u32 incl = v;
+#pragma unroll
+        for (u32 off = 1; off < 64u; off <<= 1) { const u32 t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+        const u32 excl = carry + incl - v;
+        seg[k * 64u + lane] = excl;
+        const u32 e = w * PER_WAVE + k * 64u;                                             // the step's first entry
+        if (lane == 0 && e % LEN_SORT_WGS == 0) start_of_class[e / LEN_SORT_WGS] = excl;
+        carry += __shfl(incl, 63);
     }
     if (!rc.hdr) return;
-    // messages of class >= c: the position of the first message of class c - 1 (classes are laid out falling) -- entry (256 - c) * LEN_SORT_WGS, the first entry of
-    // thread (256 - c) * LEN_SORT_WGS / PER, whose exclusive prefix is the inclusive one of the thread in front of it: straight from the scan's LDS (reading it back from
-    // memory needed a device-scope fence behind 256 KiB of stores: 20 us of this launch)
-    static_assert(LEN_SORT_WGS % PER == 0, "k_len_scan: a class starts at a thread's first entry");
-    auto n_ge = [&](u32 c) { return c == 0u ? rc.n : c >= PKT_LEN_CLASSES ? 0u : part[(PKT_LEN_CLASSES - c) * (LEN_SORT_WGS / PER) - 1u]; };
+    __syncthreads();
+    // messages of class >= c: the position of the first message of class c - 1 (classes are laid out falling: row 255 - class) -- from the scan's LDS, not read back from memory
+    auto n_ge = [&](u32 c) { return c == 0u ? rc.n : c >= PKT_LEN_CLASSES ? 0u : start_of_class[PKT_LEN_CLASSES - c]; };
     // blocks of the messages below each mark: thread c < 256 brings its class (a message of class c has 4 c + 2 blocks, give or take two)
     const u32 cls = threadIdx.x;
     const u64 mine_blocks = cls < PKT_LEN_CLASSES ? (u64)(n_ge(cls) - n_ge(cls + 1u)) * (4u * cls + 2u) : 0ull;
@@ -1076,8 +1083,8 @@ __global__ __launch_bounds__(1024) void k_len_scan(u32 *__restrict__ counts, con
             const u32 mid = n_ge(rc.c_lo) - n_ge(rc.c_hi);
             const bool high = mid >= rc.mid_min;
             const u32 c = high ? rc.c_hi : rc.c_lo;
-            const u64 short_blocks = blk[0] + (high ? blk[1] : 0ull);
-            if (short_blocks < rc.blocks_min) { route_min = 0; n_large = rc.n; }               // not worth a packet launch: everything by rows
+            const u64 short_blocks = blk[0] + (high ? blk[1] : 0ull), n_short = rc.n - n_ge(c);
+            if (rc.blocks_min && short_blocks < rc.blocks_min + ROUTE_BLOCKS_PER_MSG * n_short) { route_min = 0; n_large = rc.n; }      // not worth a packet launch: everything by rows
             else { route_min = c * 64u; n_large = n_ge(c); }
         }
         const u32 n_small = rc.n - n_large;
