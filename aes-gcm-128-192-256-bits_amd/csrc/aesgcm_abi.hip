@@ -772,6 +772,39 @@ int aesgcm_packets_crypt_dev(aesgcm_ctx *c, int decrypt, size_t n_pkts, const vo
 }
 
 
+// What the device decided about the context's most recent ROUTED call (offset arrays, messages wherever they live): waits for the device, then reads the header
+// k_len_scan and the plan left in the context's scratch.  For benches, profiles and tests -- the host never needs it.
+int aesgcm_ctx_last_route(aesgcm_ctx *c, uint64_t out[4]) {
+    if (!c || !out) return AESGCM_EARG;
+    if (!c->rows_buf) return AESGCM_ESTATE;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    RowsHdr h;
+    HIPCHK(hipMemcpy(&h, c->rows_buf, sizeof h, hipMemcpyDeviceToHost));      // (the header is the first thing rows_carve hands out)
+    out[0] = h.route_min; out[1] = h.n_small; out[2] = h.n_small ? 1ull << h.pkt_lg : 0ull; out[3] = h.G;
+    return AESGCM_OK;
+}
+
+// The instruction stream of the packet kernels WITHOUT the data's HBM traffic (k_pktl<NR, 2, 0> / k_pktg<NR, 2, LG>: IVs, offsets, AAD and tags still move): what the
+// formulation of the frame path costs by itself -- one lane (or lane group) per frame, T-table AES, the H-table GHASH, per-frame E_K(J0) and length block -- on this chip
+// at this moment's clocks.  The yardstick bench.py --config frames prints as roofline.formulation_ceiling, as aesgcm_ctx_ceiling_probe is for the stream kernel and
+// aesgcm_batch_ceiling_probe_dev for cfg5.  The call takes the routed path of aesgcm_packets_crypt_dev with offset arrays (the sort, the shape chosen on the device for the
+// count), every frame to the packet kernels whatever its size; no data buffer is touched (none is passed).  Asynchronous on `stream`; the caller times it (aesgcm_timer_*).
+int aesgcm_frames_ceiling_probe_dev(aesgcm_ctx *c, size_t n_pkts, const void *d_ivs, const void *d_aad, const uint64_t *d_aad_off, const uint64_t *d_data_off, void *d_tags, void *stream) {
+    if (!c || !n_pkts || !d_ivs || !d_tags || !d_data_off || (d_aad_off && !d_aad)) return AESGCM_EARG;
+    if (n_pkts >= (((size_t)1) << 31)) return AESGCM_ETOOLONG;
+    HIPCHK(hipSetDevice(c->device));
+    PktParams p;
+    memset(&p, 0, sizeof p);
+    p.ivs = (const unsigned char *)d_ivs; p.aad = (const unsigned char *)d_aad; p.tags = (unsigned char *)d_tags;
+    p.data_off = (const u64 *)d_data_off; p.aad_off = (const u64 *)d_aad_off;
+    p.n_pkts = (u32)n_pkts; p.aligned = 1;
+    RowsParams r;
+    memset(&r, 0, sizeof r);
+    r.ivs = p.ivs; r.aad = p.aad; r.tags = p.tags; r.data_off = p.data_off; r.aad_off = p.aad_off; r.n_pkts = (u32)n_pkts;
+    return packets_rows(c, 2, r, pick_stream(c, stream), &p);
+}
+
 int aesgcm_batch_crypt_dev(int device, int decrypt, size_t n_pkts, size_t key_len, const void *d_keys, const void *d_ivs,
                            const void *d_aad, size_t aad_len, const void *d_in, size_t pkt_len, void *d_out,
                            void *d_tags, const void *d_expect_tags, int *d_auth, void *stream) {

@@ -726,6 +726,8 @@ int packets_rows(aesgcm_ctx *c, int decrypt, RowsParams &p, hipStream_t st, PktP
             RouteCfg cfg = {r.hdr, (u32)n, n_cu, 0u, 0u, c->route_mid_min, 0xFFu, 0u, c->route_blocks_min, (u64)(uintptr_t)p.in_ptr, (u64)(uintptr_t)p.out_ptr, (u64)(uintptr_t)p.aad_ptr, (u64)(uintptr_t)p.len_arr, (u64)(uintptr_t)p.alen_arr};
             k->scattered = p.len_arr ? 1u : 0u;
             route_marks(c, &cfg.c_hi, &cfg.c_lo);
+            const bool probe = decrypt == 2;                                 // aesgcm_frames_ceiling_probe_dev: the packet kernels' instruction stream without the data's traffic -- every message theirs, no row launch
+            if (probe) { if (p.len_arr) return AESGCM_EARG; cfg.c_hi = cfg.c_lo = PKT_LEN_CLASSES; }
 #ifdef AESGCM_DEBUG_KNOBS
             if (g_force.pkt_lanes) cfg.force_lg = g_force.pkt_lanes == 1 ? 0u : g_force.pkt_lanes == 64 ? (p.len_arr ? 4u : 6u) : g_force.pkt_lanes == 16 ? 4u : g_force.pkt_lanes == 8 ? 3u : 2u;      // (messages wherever they live have no wave-per-packet instance: 16 lanes)
             if (g_force.pkt_deal >= 1 && g_force.pkt_deal <= (int)PKTG_MAX_DEAL) cfg.force_deal = (u32)g_force.pkt_deal;
@@ -738,15 +740,17 @@ int packets_rows(aesgcm_ctx *c, int decrypt, RowsParams &p, hipStream_t st, PktP
             // the caller's stream waits for the side stream at the end.  The two halves share nothing but the header the scan left (read-only from here on, except the
             // plan's own fields); a call of frames alone no longer waits for seven launches that find nothing to do, and the tail of the packet launch -- its last
             // waves' longest packets -- runs beside the first rows.
-            if (!c->side) {
+            if (!probe && !c->side) {
                 HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
                 HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
                 HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
             }
-            HIPCHK(hipEventRecord(c->ev_fork, st));
-            HIPCHK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
-            rows_st = c->side;
-            HIPCHK(klaunch_rows_plan(rows_st, p, true, c->rows_block, (u32)ROWS_NB_CAP, r.plan_part, reinterpret_cast<u32 *>(c->h_tag_dev + 2)));
+            if (!probe) {
+                HIPCHK(hipEventRecord(c->ev_fork, st));
+                HIPCHK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+                rows_st = c->side;
+                HIPCHK(klaunch_rows_plan(rows_st, p, true, c->rows_block, (u32)ROWS_NB_CAP, r.plan_part, reinterpret_cast<u32 *>(c->h_tag_dev + 2)));
+            }
             // every shape the count of small messages -- anything up to n -- could ask for; all but the one k_len_scan named return before they stage a table
             const u32 lg_min = cfg.force_lg != 0xFFu ? cfg.force_lg : route_pick_lg(n_cu, n), lg_max = cfg.force_lg != 0xFFu ? cfg.force_lg : 4u;
             static const u32 shapes[] = {0u, 2u, 3u, 4u, 6u};
@@ -764,6 +768,7 @@ int packets_rows(aesgcm_ctx *c, int decrypt, RowsParams &p, hipStream_t st, PktP
                     HIPCHK(klaunch_pktg(c->nr, decrypt, (int)lg, w, st, c->km, c->tables, *k));
                 }
             }
+            if (probe) { c->rows_dirty = false; return AESGCM_OK; }           // (nothing of the row path ran: its scratch is at rest)
         } else {
             HIPCHK(klaunch_rows_plan(st, p, false, c->rows_block, (u32)ROWS_NB_CAP, r.plan_part, reinterpret_cast<u32 *>(c->h_tag_dev + 2)));
         }

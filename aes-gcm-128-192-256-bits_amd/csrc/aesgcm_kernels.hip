@@ -1026,8 +1026,9 @@ __global__ __launch_bounds__(256) void k_len_hist(const LenSrc src, u32 n, u32 *
 //     do 45 G blocks/s but pay for every message (its E_K(J0), its length block, its closing) and for their own start: fitted to the sweep, ms for n messages of B
 //     blocks, rows 0.10 + 0.08 n/10^6 + 0.080 B/10^6, packets 0.12 + 0.17 n/10^6 + 0.022 B/10^6 (and more per message where lane groups, not lanes, take them).
 //     Frames of 64 .. 1514 bytes, 16384 of them 0.194 / 0.147 ms, 131072 0.62 / 0.32, 2^20 4.34 / 1.44; messages of 0 .. 128 bytes, 131072 0.161 / 0.242, 2^20
-//     0.56 / 0.40.  So: the packet kernels when the short messages hold at least `blocks_min` (2^18) + 4 per message blocks, else everything goes by rows.
-#define ROUTE_BLOCKS_PER_MSG 4ull
+//     0.56 / 0.40; 4096 frames 0.149 / 0.112.  So: the packet kernels when the short messages hold at least `blocks_min` (2^17) + 3 per message blocks (counted by size class:
+//     a message of class c as 4 c + 2), else everything goes by rows.  profiles/r06/route_sweep.txt: the rule's choice against both, 35 populations.
+#define ROUTE_BLOCKS_PER_MSG 3ull
 __global__ __launch_bounds__(1024) void k_len_scan(u32 *__restrict__ counts, const RouteCfg rc, const unsigned long long *__restrict__ bad_part, volatile u32 *host_status) {
     // Every wave owns 4096 consecutive entries (16 classes) and walks them 64 at a time, a lane per entry: coalesced loads and stores, a wave scan by lane shuffles per
     // step and a carry.  (Until round 6 a thread owned 64 consecutive entries: every load of a wave touched 64 cache lines, 128 KiB of lines in flight per step through
@@ -1038,24 +1039,45 @@ __global__ __launch_bounds__(1024) void k_len_scan(u32 *__restrict__ counts, con
     static_assert(LEN_SORT_ENTRIES % (16u * 64u) == 0 && LEN_SORT_WGS % 64u == 0, "k_len_scan: whole steps of 64 entries per wave, class rows that start on a step");
     const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     u32 *seg = counts + w * PER_WAVE;
+    constexpr u32 STEPS = PER_WAVE / 64u, CH = 16u;                                        // 64 steps, in chunks of 16 held in registers
+    static_assert(STEPS % CH == 0, "k_len_scan: whole chunks");
+    // A load behind the previous step's store to the same array waits for that store: step by step the launch made 64 dependent trips to the L2 per pass, 30 of its
+    // 35 us.  So: the loads of a whole chunk are issued together, and the NEXT chunk's loads before this chunk's stores.
     u32 s = 0;
-    for (u32 k = 0; k < PER_WAVE / 64u; ++k) s += seg[k * 64u + lane];
+    for (u32 c0 = 0; c0 < STEPS; c0 += CH) {
+        u32 v[CH];
+#pragma unroll
+        for (u32 k = 0; k < CH; ++k) v[k] = seg[(c0 + k) * 64u + lane];
+#pragma unroll
+        for (u32 k = 0; k < CH; ++k) s += v[k];
+    }
 #pragma unroll
     for (u32 off = 32u; off; off >>= 1) s += __shfl_xor(s, off);
     if (lane == 0) wave_base[w] = s;
     __syncthreads();
     u32 carry = 0;
     for (u32 i = 0; i < w; ++i) carry += wave_base[i];
-    for (u32 k = 0; k < PER_WAVE / 64u; ++k) {
-        const u32 v = seg[k * 64u + lane];
-        u32 incl = v;
+    u32 cur[CH], nxt[CH];
 #pragma unroll
-        for (u32 off = 1; off < 64u; off <<= 1) { const u32 t = __shfl_up(incl, off); if (lane >= off) incl += t; }
-        const u32 excl = carry + incl - v;
-        seg[k * 64u + lane] = excl;
-        const u32 e = w * PER_WAVE + k * 64u;                                             // the step's first entry
-        if (lane == 0 && e % LEN_SORT_WGS == 0) start_of_class[e / LEN_SORT_WGS] = excl;
-        carry += __shfl(incl, 63);
+    for (u32 k = 0; k < CH; ++k) cur[k] = seg[k * 64u + lane];
+    for (u32 c0 = 0; c0 < STEPS; c0 += CH) {
+        if (c0 + CH < STEPS) {
+#pragma unroll
+            for (u32 k = 0; k < CH; ++k) nxt[k] = seg[(c0 + CH + k) * 64u + lane];
+        }
+#pragma unroll
+        for (u32 k = 0; k < CH; ++k) {
+            u32 incl = cur[k];
+#pragma unroll
+            for (u32 off = 1; off < 64u; off <<= 1) { const u32 t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+            const u32 excl = carry + incl - cur[k];
+            seg[(c0 + k) * 64u + lane] = excl;
+            const u32 e = w * PER_WAVE + (c0 + k) * 64u;                                  // the step's first entry
+            if (lane == 0 && e % LEN_SORT_WGS == 0) start_of_class[e / LEN_SORT_WGS] = excl;
+            carry += __shfl(incl, 63);
+        }
+#pragma unroll
+        for (u32 k = 0; k < CH; ++k) cur[k] = nxt[k];
     }
     if (!rc.hdr) return;
     __syncthreads();
@@ -1604,6 +1626,12 @@ hipError_t klaunch_set_attributes() {
     ATTRCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktls<NR, D>), hipFuncAttributeMaxDynamicSharedMemorySize, AESGCM_PKTL_LDS))
     SETATTRS(10, 0); SETATTRS(12, 0); SETATTRS(14, 0); SETATTRS(10, 1); SETATTRS(12, 1); SETATTRS(14, 1);
 #undef SETATTRS
+#define SETATTRP(NR) ATTRCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktg<NR, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, PKTG_LDS_TOTAL(2))); \
+    ATTRCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktg<NR, 2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, PKTG_LDS_TOTAL(3))); \
+    ATTRCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktg<NR, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, PKTG_LDS_TOTAL(4))); \
+    ATTRCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pktl<NR, 2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, AESGCM_PKTL_LDS))
+    SETATTRP(10); SETATTRP(12); SETATTRP(14);                     // the probes of the packet kernels (aesgcm_frames_ceiling_probe_dev)
+#undef SETATTRP
     ATTRCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_combine), hipFuncAttributeMaxDynamicSharedMemorySize, CMB_LDS_BYTES));
     ATTRCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_combine_batch), hipFuncAttributeMaxDynamicSharedMemorySize, CMB_LDS_BYTES));
 #define SETATTRB3(NR, D) ATTRCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch3<NR, D, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, BATCH3_LDS_BYTES_LG(6))); \
@@ -1669,7 +1697,8 @@ hipError_t klaunch_pktl(int nr, int dec, bool ilp, unsigned wgs, hipStream_t st,
     }
 #define LPI(NR, D, I) hipLaunchKernelGGL((k_pktl<NR, D, I>), dim3(wgs), dim3(I ? AESGCM_PKTL_WG_ILP : AESGCM_PKTL_WG), AESGCM_PKTL_LDS, st, km, tb, p)
 #define LP(NR, D) do { if (ilp) LPI(NR, D, 1); else LPI(NR, D, 0); } while (0)
-    if (dec) { if (nr == 10) LP(10, 1); else if (nr == 12) LP(12, 1); else LP(14, 1); }
+    if (dec == 2) { if (ilp) return hipErrorInvalidValue; if (nr == 10) LPI(10, 2, 0); else if (nr == 12) LPI(12, 2, 0); else LPI(14, 2, 0); }      // the probe: the 768-lane form
+    else if (dec) { if (nr == 10) LP(10, 1); else if (nr == 12) LP(12, 1); else LP(14, 1); }
     else     { if (nr == 10) LP(10, 0); else if (nr == 12) LP(12, 0); else LP(14, 0); }
 #undef LPI
 #undef LP
@@ -1688,9 +1717,12 @@ hipError_t klaunch_pktg(int nr, int dec, int lg, unsigned wgs, hipStream_t st, c
     }
 #define LPG(NR, D, LG) hipLaunchKernelGGL((k_pktg<NR, D, LG>), dim3(wgs), dim3(PKTG_WG(LG)), PKTG_LDS_TOTAL(LG), st, km, tb, p)
 #define LP(NR, D) do { if (lg == 2) LPG(NR, D, 2); else if (lg == 3) LPG(NR, D, 3); else if (lg == 4) LPG(NR, D, 4); else LPG(NR, D, 6); } while (0)
-    if (dec) { if (nr == 10) LP(10, 1); else if (nr == 12) LP(12, 1); else LP(14, 1); }
+#define LPP(NR) do { if (lg == 2) LPG(NR, 2, 2); else if (lg == 3) LPG(NR, 2, 3); else LPG(NR, 2, 4); } while (0)
+    if (dec == 2) { if (lg != 2 && lg != 3 && lg != 4) return hipErrorInvalidValue; if (nr == 10) LPP(10); else if (nr == 12) LPP(12); else LPP(14); }      // the probe: lane groups of 4 / 8 / 16
+    else if (dec) { if (nr == 10) LP(10, 1); else if (nr == 12) LP(12, 1); else LP(14, 1); }
     else     { if (nr == 10) LP(10, 0); else if (nr == 12) LP(12, 0); else LP(14, 0); }
 #undef LP
+#undef LPP
 #undef LPG
     return hipGetLastError();
 }

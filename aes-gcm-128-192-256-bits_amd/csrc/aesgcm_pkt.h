@@ -92,6 +92,19 @@ HD void pktg_fill_lds(unsigned char *smem, const KeyMaterial *km, const DevTable
     for (int j = 0; j < lg; j++) fill_lds_q5(smem, km->q5pow[j], tid, nthreads, PKTG_LDS_TREE_OFF + (u32)j * (u32)AESGCM_LDS_GH);
 }
 
+// the packets' data accesses.  DEC == 2 is the PROBE of a packet kernel (aesgcm_frames_ceiling_probe_dev): the same instruction stream WITHOUT the data's loads and
+// stores -- IVs, AAD and tags still move --, what the formulation costs by itself on this chip at this moment's clocks; the "data" is then a value made of the block's
+// number, so that nothing downstream folds away
+template <int DEC>
+HD uint4 pkt_ld(const unsigned char *p, u32 salt, bool aligned) {
+    if (DEC == 2) return make_uint4(salt, salt * 3u, ~salt, 0x9E3779B9u ^ salt);
+    return aligned ? gload16(p) : gload16_any(p);
+}
+template <int DEC>
+HD void pkt_st(unsigned char *p, uint4 v, bool aligned) {
+    if (DEC == 2) return;
+    if (aligned) gstore16(p, v); else gstore16_any(p, v);
+}
 // per-packet geometry and constants: uniform over the packet's lane group
 struct PktInfo { u64 doff, ooff, aoff; u32 pkt_len, aad_len, iv0, iv1, iv2, aligned; };      // doff / ooff: where the packet's input / output lies (the same offset, except for messages in buffers of their own)
 HD void pkt_place_scattered(const struct RowsHdr *h, u32 pkt, u64 *doff, u64 *ooff, u64 *aoff, u32 *pkt_len, u32 *aad_len);      // aesgcm_rows.h (the header's layout)
@@ -149,12 +162,12 @@ HD uint4 pktg_lane(const KeyMaterial *__restrict__ km, const PktParams &p, const
         unsigned char *d = dst + 16u * l;
         for (u32 k = 0; k < iters; k++) {
             if (k) acc = ghash_mul_const_lds(acc, smem);
-            const uint4 x = gload16(s);
+            const uint4 x = pkt_ld<DEC>(s, k, true);
             u32 s0, s1, s2, s3;
             ctr_rounds_lds<NR>(bswap32(2u + k * G + l), cc, s0, s1, s2, s3, rk, smem, lb);
             const uint4 y = make_uint4(x.x ^ s0, x.y ^ s1, x.z ^ s2, x.w ^ s3);
-            if (act) gstore16(d, y);
-            acc = xor4(acc, DEC ? x : y);
+            if (act) pkt_st<DEC>(d, y, true);
+            acc = xor4(acc, DEC == 1 ? x : y);
             s += 16u * G; d += 16u * G;
         }
         return acc;
@@ -173,17 +186,17 @@ HD uint4 pktg_lane(const KeyMaterial *__restrict__ km, const PktParams &p, const
             const u32 i = j - n_aad, off = 16 * i, rem = q.pkt_len - off;
             const bool full = rem >= 16;                                                // a whole block is one access at any address (gload16_any)
             uint4 x;
-            if (full) x = aligned ? gload16(src + off) : gload16_any(src + off);
-            else x = load_block_bytes(src + off, rem < 16 ? rem : 16);
+            if (full) x = pkt_ld<DEC>(src + off, i, aligned);
+            else x = DEC == 2 ? mask_block(pkt_ld<DEC>(src + off, i, false), rem) : load_block_bytes(src + off, rem < 16 ? rem : 16);
             u32 s0, s1, s2, s3;
             ctr_rounds_lds<NR>(bswap32(2u + i), cc, s0, s1, s2, s3, rk, smem, lb);     // aes_icb.vhd:97-118: counter 2 + i
             uint4 y = make_uint4(x.x ^ s0, x.y ^ s1, x.z ^ s2, x.w ^ s3);                // gcm_gctr.vhd:150
             if (rem < 16) y = mask_block(y, rem);
-            if (act) {
+            if (act && DEC != 2) {
                 if (full) { if (aligned) gstore16(dst + off, y); else gstore16_any(dst + off, y); }
                 else store_block_bytes(dst + off, y, rem < 16 ? rem : 16);
             }
-            gin = DEC ? x : y;                                                          // aes_gcm.vhd:207-211
+            gin = DEC == 1 ? x : y;                                                          // aes_gcm.vhd:207-211
         }
         acc = xor4(acc, gin);
     }
@@ -254,30 +267,30 @@ HD void pktl_lane(const KeyMaterial *__restrict__ km, const PktParams &p, const 
     while (ILP && left >= 128) {
         uint4 x[8], ks[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) x[k] = gload16_any(src + 16 * k);
+        for (int k = 0; k < 8; k++) x[k] = pkt_ld<DEC>(src + 16 * k, ctr + k, false);
         ctr_rounds_lds_n<NR, T4, AESGCM_PKTL_CHAINS>(ctr, cc, ks, rk, smem, lb);
         ctr_rounds_lds_n<NR, T4, AESGCM_PKTL_CHAINS>(ctr + AESGCM_PKTL_CHAINS, cc, ks + AESGCM_PKTL_CHAINS, rk, smem, lb);
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const uint4 y = xor4(x[k], ks[k]);
-            gstore16_any(dst + 16 * k, y);
-            acc = ghash_mul_const_lds(xor4(acc, DEC ? x[k] : y), smem);
+            pkt_st<DEC>(dst + 16 * k, y, false);
+            acc = ghash_mul_const_lds(xor4(acc, DEC == 1 ? x[k] : y), smem);
         }
         src += 128; dst += 128; left -= 128; ctr += 8;
     }
     while (left >= 128) {
         uint4 xa[4], xb[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) xa[k] = gload16_any(src + 16 * k);
+        for (int k = 0; k < 4; k++) xa[k] = pkt_ld<DEC>(src + 16 * k, ctr + k, false);
 #pragma unroll
-        for (int k = 0; k < 4; k++) xb[k] = gload16_any(src + 64 + 16 * k);
+        for (int k = 0; k < 4; k++) xb[k] = pkt_ld<DEC>(src + 64 + 16 * k, ctr + 4 + k, false);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             u32 s0, s1, s2, s3;
             ctr_rounds_lds<NR, T4>(bswap32(ctr + k), cc, s0, s1, s2, s3, rk, smem, lb);
-            if (DEC) acc = ghash_mul_const_lds(xor4(acc, xa[k]), smem);
+            if (DEC == 1) acc = ghash_mul_const_lds(xor4(acc, xa[k]), smem);
             xa[k] = make_uint4(xa[k].x ^ s0, xa[k].y ^ s1, xa[k].z ^ s2, xa[k].w ^ s3);
-            if (!DEC) acc = ghash_mul_const_lds(xor4(acc, xa[k]), smem);
+            if (DEC != 1) acc = ghash_mul_const_lds(xor4(acc, xa[k]), smem);
         }
 #if defined(__HIP_DEVICE_COMPILE__)
         __builtin_amdgcn_sched_barrier(0);
@@ -286,17 +299,17 @@ HD void pktl_lane(const KeyMaterial *__restrict__ km, const PktParams &p, const 
         for (int k = 0; k < 4; k++) {
             u32 s0, s1, s2, s3;
             ctr_rounds_lds<NR, T4>(bswap32(ctr + 4 + k), cc, s0, s1, s2, s3, rk, smem, lb);
-            if (DEC) acc = ghash_mul_const_lds(xor4(acc, xb[k]), smem);
+            if (DEC == 1) acc = ghash_mul_const_lds(xor4(acc, xb[k]), smem);
             xb[k] = make_uint4(xb[k].x ^ s0, xb[k].y ^ s1, xb[k].z ^ s2, xb[k].w ^ s3);
-            if (!DEC) acc = ghash_mul_const_lds(xor4(acc, xb[k]), smem);
+            if (DEC != 1) acc = ghash_mul_const_lds(xor4(acc, xb[k]), smem);
         }
         // all eight stores back to back: the 128 bytes meet in the L2 and leave it as one full line (WRITE_SIZE = the ciphertext, 1.00 x).  In two groups of
         // four, a tenth of a millisecond apart, 1.22 x; block by block 3.2 x -- the L2 turns over many times while a lane works through its line
         // (profiles/r04/pktl_store_ab.txt).
 #pragma unroll
-        for (int k = 0; k < 4; k++) gstore16_any(dst + 16 * k, xa[k]);
+        for (int k = 0; k < 4; k++) pkt_st<DEC>(dst + 16 * k, xa[k], false);
 #pragma unroll
-        for (int k = 0; k < 4; k++) gstore16_any(dst + 64 + 16 * k, xb[k]);
+        for (int k = 0; k < 4; k++) pkt_st<DEC>(dst + 64 + 16 * k, xb[k], false);
 #if defined(__HIP_DEVICE_COMPILE__)
         __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -306,29 +319,29 @@ HD void pktl_lane(const KeyMaterial *__restrict__ km, const PktParams &p, const 
     while (left >= 16 * AESGCM_PKTL_GROUP) {
         uint4 x[AESGCM_PKTL_GROUP];
 #pragma unroll
-        for (int k = 0; k < AESGCM_PKTL_GROUP; k++) x[k] = gload16_any(src + 16 * k);
+        for (int k = 0; k < AESGCM_PKTL_GROUP; k++) x[k] = pkt_ld<DEC>(src + 16 * k, ctr + k, false);
 #pragma unroll
         for (int k = 0; k < AESGCM_PKTL_GROUP; k++) {
             u32 s0, s1, s2, s3;
             ctr_rounds_lds<NR, T4>(bswap32(ctr + k), cc, s0, s1, s2, s3, rk, smem, lb);
             const uint4 y = make_uint4(x[k].x ^ s0, x[k].y ^ s1, x[k].z ^ s2, x[k].w ^ s3);
-            acc = ghash_mul_const_lds(xor4(acc, DEC ? x[k] : y), smem);
+            acc = ghash_mul_const_lds(xor4(acc, DEC == 1 ? x[k] : y), smem);
             x[k] = y;
         }
 #pragma unroll
-        for (int k = 0; k < AESGCM_PKTL_GROUP; k++) gstore16_any(dst + 16 * k, x[k]);
+        for (int k = 0; k < AESGCM_PKTL_GROUP; k++) pkt_st<DEC>(dst + 16 * k, x[k], false);
         src += 16 * AESGCM_PKTL_GROUP; dst += 16 * AESGCM_PKTL_GROUP; left -= 16 * AESGCM_PKTL_GROUP; ctr += AESGCM_PKTL_GROUP;
     }
     for (; left; ctr++) {
         const u32 nb = left < 16 ? left : 16;
         const bool full = nb == 16;
-        const uint4 x = full ? gload16_any(src) : load_block_bytes(src, nb);
+        const uint4 x = full ? pkt_ld<DEC>(src, ctr, false) : DEC == 2 ? mask_block(pkt_ld<DEC>(src, ctr, false), nb) : load_block_bytes(src, nb);
         u32 s0, s1, s2, s3;
         ctr_rounds_lds<NR, T4>(bswap32(ctr), cc, s0, s1, s2, s3, rk, smem, lb);
         uint4 y = make_uint4(x.x ^ s0, x.y ^ s1, x.z ^ s2, x.w ^ s3);
-        if (full) gstore16_any(dst, y);
-        else { y = mask_block(y, nb); store_block_bytes(dst, y, nb); }
-        acc = ghash_mul_const_lds(xor4(acc, DEC ? x : y), smem);
+        if (full) pkt_st<DEC>(dst, y, false);
+        else { y = mask_block(y, nb); if (DEC != 2) store_block_bytes(dst, y, nb); }
+        acc = ghash_mul_const_lds(xor4(acc, DEC == 1 ? x : y), smem);
         src += nb; dst += nb; left -= nb;
     }
     // [8*len(A)]_64 || [8*len(C)]_64 (gcm_ghash.vhd:257) in memory order
@@ -338,7 +351,7 @@ HD void pktl_lane(const KeyMaterial *__restrict__ km, const PktParams &p, const 
     const uint4 tag = make_uint4(acc.x ^ s0, acc.y ^ s1, acc.z ^ s2, acc.w ^ s3);       // gcm_ghash.vhd:293
     if ((((uintptr_t)p.tags) & 15) == 0) *reinterpret_cast<uint4 *>(p.tags + (size_t)pkt * 16) = tag;
     else store_block_bytes(p.tags + (size_t)pkt * 16, tag, 16);
-    if (DEC && p.auth) {
+    if (DEC == 1 && p.auth) {
         int ok = 1;
         if (p.expect) {
             const uint4 e = load_block_bytes(p.expect + (size_t)pkt * 16, 16);

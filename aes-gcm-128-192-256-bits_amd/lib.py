@@ -37,7 +37,7 @@ SYMBOLS = [
     "aesgcm_comm_allreduce_f64", "aesgcm_comm_barrier", "aesgcm_comm_destroy",
     "aesgcm_mgpu_create", "aesgcm_mgpu_ranks", "aesgcm_mgpu_ctx", "aesgcm_mgpu_crypt_dev", "aesgcm_mgpu_destroy",
     "aesgcm_ctx_last_launch", "aesgcm_wipe_failed_dev", "aesgcm_mgpu_last_tags", "aesgcm_mgpu_sync", "aesgcm_batch_ceiling_probe_dev",
-    "aesgcm_ctx_status", "aesgcm_stream_update_dev", "aesgcm_stream_export", "aesgcm_stream_import",
+    "aesgcm_ctx_status", "aesgcm_stream_update_dev", "aesgcm_stream_export", "aesgcm_stream_import", "aesgcm_frames_ceiling_probe_dev", "aesgcm_ctx_last_route",
 ]
 
 
@@ -185,6 +185,8 @@ def _typed(L):
     L.aesgcm_stream_update_dev.argtypes = [vp, vp, sz, vp, vp]
     L.aesgcm_stream_export.argtypes = [vp, vp]
     L.aesgcm_stream_import.argtypes = [vp, vp]
+    L.aesgcm_frames_ceiling_probe_dev.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp]
+    L.aesgcm_ctx_last_route.argtypes = [vp, ctypes.POINTER(u64)]
     if L.aesgcm_abi_version() != ABI_VERSION:
         raise ImportError("libaesgcm_hip.so ABI %d, expected %d (stale build? rebuild with `make -C csrc`)" % (L.aesgcm_abi_version(), ABI_VERSION))
     return L
@@ -472,6 +474,12 @@ class Context:
         _chk(self._lib.aesgcm_ctx_status(self._c, ctypes.byref(code), ctypes.byref(detail)))
         return code.value, detail.value
 
+    def last_route(self):
+        """aesgcm_ctx_last_route -> dict(route_min, n_small, lanes, row_units): what the device decided for the last call with offset arrays / scattered messages"""
+        v = (u64 * 4)()
+        _chk(self._lib.aesgcm_ctx_last_route(self._c, v))
+        return {"route_min": v[0], "n_small": v[1], "lanes": v[2], "row_units": v[3]}
+
     def packets_shape(self, n_pkts, pkt_len=0, var_len=False):
         """lanes per packet packets_crypt_dev takes for such a call: 1 (k_pktl), 4 / 8 / 16 or 64 (k_pktg), or SHAPE_ROWS: by rows (k_rows); with offset arrays
         (var_len) SHAPE_MIXED: every message is routed by its own size on the device, pkt_len is ignored"""
@@ -588,6 +596,10 @@ class Context:
                           d_aad=None, aad_len=0, d_aad_off=None, d_expect_tags=None, d_auth=None, stream=None):
         _chk(self._lib.aesgcm_packets_crypt_dev(self._c, int(bool(decrypt)), n_pkts, d_ivs, d_aad, aad_len, d_aad_off,
                                              d_in, pkt_len, d_data_off, d_out, d_tags, d_expect_tags, d_auth, stream))
+
+    def frames_ceiling_probe_dev(self, n_pkts, d_ivs, d_data_off, d_tags, d_aad=None, d_aad_off=None, stream=None):
+        """aesgcm_frames_ceiling_probe_dev: the packet kernels' instruction stream over these frames without the data's loads and stores (measurement support)"""
+        _chk(self._lib.aesgcm_frames_ceiling_probe_dev(self._c, n_pkts, d_ivs, d_aad, d_aad_off, d_data_off, d_tags, stream))
 
     def messages_crypt_dev(self, decrypt, n_msgs, d_ivs, d_in_ptr, d_len, d_out_ptr, d_tags, d_aad_ptr=None, d_aad_len=None, d_expect_tags=None, d_auth=None, stream=None):
         """aesgcm_messages_crypt_dev: n_msgs messages wherever they live -- device arrays of addresses (uint64) and lengths (uint32) -- under the context's key, by rows"""

@@ -64,6 +64,10 @@ CONFIGS = {                            # BASELINE.json configs that fit one GPU
     # not a BASELINE config: the reference's own deployment (tb/gcm_test.py:76-85: message after message under one key) at message size -- 4096 x 1 MiB as the
     # packets of one aesgcm_packets_crypt_dev call, which goes by rows (round 5)
     "msgs": dict(key_bits=256, n_pkts=4096, pkt_len=1 << 20, pt_seed=0xAE5C0055),
+    # ... and at FRAME size (round 6): 2^20 MACsec-shaped frames -- 64 .. 1514 bytes (lengths from SplitMix64 stream 0x4C454E), 28 bytes of SecTAG-like AAD each, packed
+    # back to back -- under one key through the offset arrays of one aesgcm_packets_crypt_dev call.  The reference's documented deployment: its README vectors are
+    # IEEE 802.1AE frames (README.md:251-257) and its `short` traffic class tops out at 2^12 - 1 bytes (config/gcm_utils.py:144).
+    "frames": dict(key_bits=256, n_pkts=1 << 20, aad_len=28, pt_seed=0xAE5C0006, len_seed=0x4C454E),
 }
 EXIT_NOT_RCCL = 3                      # the exchange that came up is not RCCL and --allow-file-exchange was not given
 
@@ -140,7 +144,7 @@ def cpu_baseline(config):
     """The reference's CPU path timed on this box's host cores (oracle/cpu_baseline.py: pycryptodome if importable, else
     libcrypto; 1 core and all cores as worker processes).  The ONLY place bench.py touches oracle/."""
     from oracle import cpu_baseline as cb
-    return cb.measure_cfg5() if config == "cfg5" else cb.measure()
+    return cb.measure_cfg5() if config == "cfg5" else cb.measure_frames() if config == "frames" else cb.measure()
 
 
 def sclk_from_trace(trace, waves_per_wg):
@@ -494,7 +498,7 @@ def run_msgs(args, dev, cpu_base):
     d_ivw.free()
     d_pt, d_ct, d_tags = lib.DeviceBuffer(size * n, device=dev), lib.DeviceBuffer(size * n, device=dev), lib.DeviceBuffer(16 * n, device=dev)
     d_pt.fill_splitmix64(cfg["pt_seed"])
-    al = args.aad_len
+    al = args.aad_len or 0
     d_aad = lib.DeviceBuffer((al * n + 23) // 8 * 8, device=dev) if al else None
     if al:
         d_aad.fill_splitmix64(0x414144)
@@ -578,6 +582,164 @@ def run_msgs(args, dev, cpu_base):
                      "traffic_build": {"pmc_so_sha256": pm.get("so_sha256"), "running_so_sha256": so_sha, "running_git": git_head(), "match": same_build},
                      "alg_bytes_per_launch": alg_bytes, "launches_timed": len(k_ms), "avg_launch_ms": round(avg_s * 1e3, 4),
                      "timing": "HIP events on the context's stream around each call (both launches) in a separate %d-step pass after the timed region" % len(k_ms)},
+    }
+    if cpu_base is not None:
+        line["cpu_baseline"] = cpu_base
+    emit(line)
+    return tag_ok
+
+
+# ------------------------------------------------------------------------------------------------ frames under one key
+def run_frames(args, rank, world, dev, ex, cpu_base):
+    """--config frames: n MACsec-shaped frames under ONE key through the offset arrays of one aesgcm_packets_crypt_dev call per step (routed on the device: frames this
+    short all take the packet kernels, a lane per frame when they fill the chip).  N > 1: replicas of n / N frames, no collective on the data path.  Parity in the run:
+    a sample of the frames through the single-message path of the same library (pinned to the libcrypto fixtures and the 802.1AE vectors by the test-suite).
+    The line carries the roofline of the call (algorithmic bytes = 2 len + AAD + 12 + 16 per frame), the ceiling of the formulation (the same packet kernel without the
+    data's loads and stores, aesgcm_frames_ceiling_probe_dev) and the CPU baseline (libcrypto, per-frame loop in C)."""
+    import struct
+    import numpy as np
+    import aesgcm_amd  # noqa: F401
+    from aesgcm_amd import lib, sharding
+    from aesgcm_amd.build import SO
+    cfg = CONFIGS["frames"]
+    N = world
+    n_all = args.n_pkts if args.n_pkts else cfg["n_pkts"]
+    n = n_all // N
+    first = rank * n
+    key_bits = args.key_bits or cfg["key_bits"]
+    al = cfg["aad_len"] if args.aad_len is None else args.aad_len
+    standard = (n_all, key_bits, al) == (cfg["n_pkts"], cfg["key_bits"], cfg["aad_len"]) and not args.decrypt
+    key = sharding.splitmix64_bytes(KEY_SEED, key_bits // 8)
+    d_w = lib.DeviceBuffer(8 * n, device=dev)                    # the lengths' stream, made on the device (the host generator is a Python loop)
+    d_w.fill_splitmix64(cfg["len_seed"], first)
+    w = np.frombuffer(bytes(d_w.download()), dtype="<u8")
+    d_w.free()
+    lens = (64 + (w % np.uint64(1451))).astype(np.int64)
+    doff = np.zeros(n + 1, dtype=np.uint64); doff[1:] = np.cumsum(lens)
+    aoff = np.arange(n + 1, dtype=np.uint64) * np.uint64(al)
+    total = int(doff[-1])
+    d_ivw, d_ivs = lib.DeviceBuffer(16 * n, device=dev), lib.DeviceBuffer(12 * n + 16, device=dev)
+    d_ivw.fill_splitmix64(IV_SEED, first * 2)
+    ivw = bytes(d_ivw.download())
+    ivs = b"".join(ivw[16 * p:16 * p + 12] for p in range(n))
+    d_ivs.upload(ivs)
+    d_ivw.free()
+    d_pt, d_ct, d_tags = lib.DeviceBuffer(total + 64, device=dev), lib.DeviceBuffer(total + 64, device=dev), lib.DeviceBuffer(16 * n, device=dev)
+    d_pt.fill_splitmix64(cfg["pt_seed"] + rank, nbytes=(total + 64) // 8 * 8)
+    d_aad = lib.DeviceBuffer(al * n + 64, device=dev)
+    d_aad.fill_splitmix64(0x414144 + rank, nbytes=(al * n + 64) // 8 * 8)
+    d_doff, d_aoff = lib.DeviceBuffer(8 * (n + 1), device=dev), lib.DeviceBuffer(8 * (n + 1), device=dev)
+    d_doff.upload(doff.tobytes()); d_aoff.upload(aoff.tobytes())
+    akw = dict(d_aad=d_aad.ptr, d_aad_off=d_aoff.ptr) if al else {}
+    ctx = lib.Context(key, device=dev)
+    for kv in args.opt:
+        ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+
+    def step():
+        ctx.packets_crypt_dev(args.decrypt, n, d_ivs.ptr, d_ct.ptr if args.decrypt else d_pt.ptr, d_pt.ptr if args.decrypt else d_ct.ptr, d_tags.ptr, d_data_off=d_doff.ptr, **akw)
+
+    def barrier():
+        lib.dev_sync(dev)
+        if ex is not None:
+            ex.barrier()
+            lib.dev_sync(dev)
+
+    if args.decrypt:
+        ctx.packets_crypt_dev(False, n, d_ivs.ptr, d_pt.ptr, d_ct.ptr, d_tags.ptr, d_data_off=d_doff.ptr, **akw)
+    step()
+    lib.dev_sync(dev)
+    route = ctx.last_route()
+    status = ctx.status()
+    tags = bytes(d_tags.download())
+    # ---- parity: a sample of the frames through the single-message path (host buffers) of the same library
+    one = lib.Context(key, device=dev)
+    sample = sorted(set([0, n - 1] + [(k * 104729) % n for k in range(14)] + [int(np.argmin(lens)), int(np.argmax(lens))]))
+    tag_ok = status == (lib.STATUS_OK, 0)
+    for p_ in sample:
+        lo, ln = int(doff[p_]), int(lens[p_])
+        pt = bytes(d_ct.download(ln, lo)) if args.decrypt else bytes(d_pt.download(ln, lo))     # (decrypt steps run in place of the buffers' roles: d_ct holds the ciphertext made above)
+        aad = bytes(d_aad.download(al, al * p_)) if al else b""
+        if args.decrypt:
+            want_pt, want_tag = one.decrypt(ivs[12 * p_:12 * p_ + 12], aad, pt)
+            got = bytes(d_pt.download(ln, lo))
+            tag_ok = tag_ok and got == want_pt and tags[16 * p_:16 * p_ + 16] == want_tag
+        else:
+            want_ct, want_tag = one.encrypt(ivs[12 * p_:12 * p_ + 12], aad, pt)
+            tag_ok = tag_ok and bytes(d_ct.download(ln, lo)) == want_ct and tags[16 * p_:16 * p_ + 16] == want_tag
+    if not tag_ok:
+        log("PARITY FAILURE frames: the packets call and the single-message path disagree (status %r)" % (status,))
+    for _ in range(max(args.warmup, 1)):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    done = 0
+    while done < args.steps:                                    # asynchronous calls, tags stay on the device: queued back to back (at most 64 deep), waited for once
+        for _ in range(min(64, args.steps - done)):
+            step()
+            done += 1
+        lib.dev_sync(dev)
+    barrier()
+    dt = time.perf_counter() - t0
+    if ex is not None:
+        dt = ex.allreduce(dt, "max")
+        tag_ok = bool(ex.allreduce(1.0 if tag_ok else 0.0, "min"))
+        total_all = ex.allreduce(float(total), "sum")
+    else:
+        total_all = float(total)
+    value = total_all * args.steps / dt / GiB
+    tm = lib.Timer(device=dev)
+    k_ms, c_ms = [], []
+    for _ in range(min(7, max(1, args.steps))):
+        tm.start(ctx.stream()); step(); tm.stop(ctx.stream())
+        k_ms.append(tm.ms())
+    if not args.decrypt:
+        try:
+            ctx.frames_ceiling_probe_dev(n, d_ivs.ptr, d_doff.ptr, d_tags.ptr, **akw)
+            lib.dev_sync(dev)
+            for _ in range(min(7, max(1, args.steps))):
+                tm.start(ctx.stream()); ctx.frames_ceiling_probe_dev(n, d_ivs.ptr, d_doff.ptr, d_tags.ptr, **akw); tm.stop(ctx.stream())
+                c_ms.append(tm.ms())
+            probe_route = ctx.last_route()
+        except lib.AesGcmError as e:
+            log("bench.py: frames ceiling probe failed: %r" % (e,))
+            c_ms = []
+    tm.close()
+    if rank != 0:
+        return tag_ok
+    avg_s = statistics.mean(k_ms) / 1e3
+    alg_bytes = int(2 * total + n * (al + 12 + 16))
+    achieved = alg_bytes / avg_s
+    so_sha = sha256_file(SO)
+    pm = pmc_summary("frames") if standard and N == 1 else {}
+    same_build = bool(pm) and pm.get("so_sha256") == so_sha
+    nr = key_bits // 32 + 6
+    lanes = int(route["lanes"])
+    kname = ("k_pktl<%d,%d,0>" % (nr, int(args.decrypt))) if lanes == 1 else ("k_pktg<%d,%d,%d>" % (nr, int(args.decrypt), {4: 2, 8: 3, 16: 4, 64: 6}.get(lanes, 0))) if lanes else "k_rows (the device sent every frame by rows)"
+    roofline = {"bound": "hbm", "kernel": "%s: %d lane(s) per frame, frames taken by falling size class (k_len_hist / _scan / _scatter in front; the device's route: mark %d, %d of %d frames to the packet kernels)"
+                                          % (kname, lanes, route["route_min"], route["n_small"], n),
+                "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_BYTES_PER_S, 4),
+                "traffic": pm.get("hbm_bytes_per_launch") if same_build else None, "traffic_source": "profiles/pmc_frames.json" if pm else None,
+                "traffic_build": {"pmc_so_sha256": pm.get("so_sha256"), "running_so_sha256": so_sha, "running_git": git_head(), "match": same_build},
+                "alg_bytes_per_launch": alg_bytes, "alg_bytes": "per frame 2 x length + %d (AAD) + 12 (IV) + 16 (tag)" % al, "launches_timed": len(k_ms), "avg_launch_ms": round(avg_s * 1e3, 4),
+                "timing": "HIP events on the context's stream around each call (the sort, the packet kernel, the empty row launches) in a separate %d-step pass after the timed region" % len(k_ms),
+                "lds_busy_frac": (pm.get("lds") or {}).get("lds_busy_frac") if same_build else None}
+    if c_ms:
+        c_s = statistics.mean(c_ms) / 1e3
+        roofline["formulation_ceiling"] = {"kernel": "the same call with the packet kernel in its PROBE form (%d lane(s) per frame: the instruction stream without the data's loads and stores; IVs, offsets, AAD and tags still move)" % int(probe_route["lanes"]),
+                                           "avg_launch_ms": round(c_s * 1e3, 4), "gib_per_s": round(total / c_s / GiB, 1), "alg_gb_per_s": round(alg_bytes / c_s / 1e9, 1),
+                                           "frac_of_hbm_peak": round(alg_bytes / c_s / HBM_PEAK_BYTES_PER_S, 4)}
+        roofline["achieved_over_ceiling"] = round(c_s / avg_s, 4)
+    line = {
+        "metric": "GiB/s plaintext, AES-%d-GCM, %d frames of 64 .. 1514 bytes with %d bytes of AAD each under one key (offset arrays, one call), bit-exact tags" % (key_bits, n * N, al),
+        "value": round(value, 3), "unit": "GiB/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "strong" if N > 1 else "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "frames%s: %d MACsec-shaped frames (64 .. 1514 bytes, lengths stream 0x4C454E; %d bytes of AAD each, stream 0x414144), AES-%d-GCM under ONE key (stream 0x4B4559), "
+                               "per-frame IV (stream 0x4956), plaintext stream 0xAE5C0006, packed back to back; one aesgcm_packets_crypt_dev call with offset arrays per step%s%s"
+                               % ("" if standard else " (custom)", n * N, al, key_bits, ", DECRYPT + computed tags" if args.decrypt else "", "; %d replicas of %d frames, no collective" % (N, n) if N > 1 else ""),
+                   "frames_per_gpu": n, "bytes_per_gpu": total, "mean_frame_bytes": round(total / n, 1), "aad_bytes": al, "key_bits": key_bits, "mframes_per_s": round(n * N * args.steps / dt / 1e6, 2),
+                   "parallelism": "single" if N == 1 else "replicas%d" % N,
+                   "exchange": None if ex is None else {"backend": ex.name, "ranks_seen": ex.world, "use": "barrier and max-over-ranks timing only", "torch": "not imported"}},
+        "tag_ok": tag_ok, "tags_checked": len(sample), "roofline": roofline,
     }
     if cpu_base is not None:
         line["cpu_baseline"] = cpu_base
@@ -830,7 +992,7 @@ def main(argv=None):
     ap.add_argument("--n-pkts", type=int, default=None, help="cfg5 override: packets in all (no fixture check)")
     ap.add_argument("--pkt-len", type=int, default=None, help="cfg5 override: bytes per packet (no fixture check)")
     ap.add_argument("--scattered", action="store_true", help="--config msgs: the same messages through aesgcm_messages_crypt_dev (device arrays of addresses and lengths: messages wherever they live)")
-    ap.add_argument("--aad-len", type=int, default=0, help="--config msgs: bytes of AAD per message (a header: 13 for TLS-shaped records)")
+    ap.add_argument("--aad-len", type=int, default=None, help="--config msgs: bytes of AAD per message (a header: 13 for TLS-shaped records; default none); --config frames: default 28")
     ap.add_argument("--decrypt", action="store_true", help="time decrypt + authenticate instead of encrypt (N = 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="rccl", choices=("rccl", "nccl", "file", "gloo"),
@@ -872,7 +1034,9 @@ def main(argv=None):
         log("bench.py: --gib-per-gpu must be positive")
         return 2
     est_ms = None
-    if args.config == "msgs":                                    # ~1.1 ms per GiB by rows
+    if args.config == "frames":                                  # ~1.4 ms per 2^20 frames
+        est_ms = 1.4 * (args.n_pkts or CONFIGS["frames"]["n_pkts"]) / (1 << 20) / max(args.gpus, 1)
+    elif args.config == "msgs":                                    # ~1.1 ms per GiB by rows
         est_ms = 1.1 * (args.n_pkts or CONFIGS["msgs"]["n_pkts"]) * (args.pkt_len or CONFIGS["msgs"]["pkt_len"]) / GiB
     elif args.config != "cfg5":                                    # ~1 ms per GiB; N > 1 stream runs are the 16 GiB-per-GPU cfg4 job whatever --config says
         est_ms = (args.gib_per_gpu if args.gib_per_gpu is not None else 16.0 if (args.gpus > 1 or args.emulate_rank is not None) else
@@ -968,6 +1132,11 @@ def main(argv=None):
                 dbg.force(batch_lanes=args.batch_lanes)
                 return finish(run_cfg5(args, rank, world, dev, ex, cpu_base))
         return finish(run_cfg5(args, rank, world, dev, ex, cpu_base))
+    if args.config == "frames":
+        if emu is not None:
+            log("bench.py: --config frames has no --emulate-rank")
+            return 2
+        return finish(run_frames(args, rank, world, dev, ex, cpu_base))
     if args.config == "msgs":
         if N != 1 or emu is not None:
             log("bench.py: --config msgs runs on one GPU")

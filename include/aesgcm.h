@@ -145,7 +145,7 @@ AESGCM_API int aesgcm_ctx_last_launch(const aesgcm_ctx *ctx, int *shape);
  *                 With offset arrays the mark is applied per message on the device, to data + AAD, in steps of 64 bytes and up to 16320 (see "route_mid_min")
  *   "route_mid_min", "route_blocks_min"   how a call with offset arrays is routed on the device: the mark is "rows_min" when at least route_mid_min (65536) of its messages lie
  *                 between a quarter of rows_min and rows_min, else that quarter; and nothing goes to the packet kernels at all while the messages below the mark hold
- *                 fewer than route_blocks_min (2^18) + 4 per message 16-byte blocks between them (csrc/aesgcm_kernels.hip k_len_scan has the measurements).  0 / 0: always the high mark, always split
+ *                 fewer than route_blocks_min (2^17) + 3 per message 16-byte blocks between them (csrc/aesgcm_kernels.hip k_len_scan has the measurements).  0 / 0: always the high mark, always split
  *   "rows_block"  units (rows of 64 blocks) per dealt block of the row kernel, 0 = the library's cut (one block per wave; blocks of 64 for large calls)
  *   "poll_us"     how long a tag is polled for in the pinned host slot before the call blocks in the runtime
  * AESGCM_EARG for an unknown key. */
@@ -345,12 +345,21 @@ AESGCM_API int aesgcm_wipe_failed_dev(int device, size_t n_pkts, void *d_out, si
  * (aesgcm_timer_*).  Only for calls that take the 8-lanes-per-packet shape, as BASELINE config 5 does (AESGCM_EARG otherwise). */
 AESGCM_API int aesgcm_batch_ceiling_probe_dev(int device, size_t n_pkts, size_t key_len, const void *d_keys, const void *d_ivs, size_t pkt_len, void *d_tags, void *stream);
 
+/* The same for the frame path (round 6): the packet kernels' instruction stream over n_pkts frames delimited by d_data_off (and d_aad_off: or NULL) as aesgcm_packets_crypt_dev
+ * takes them, WITHOUT the data's loads and stores (IVs, offsets, AAD and tags still move; no data buffer is passed) -- every frame to the packet kernels, in the shape the
+ * device chooses for the count.  bench.py --config frames prints it as roofline.formulation_ceiling.  Asynchronous on `stream`; the caller times it. */
+AESGCM_API int aesgcm_frames_ceiling_probe_dev(aesgcm_ctx *ctx, size_t n_pkts, const void *d_ivs, const void *d_aad, const uint64_t *d_aad_off, const uint64_t *d_data_off, void *d_tags, void *stream);
+
 /* Which kernel shape a call with these arguments takes: lanes per packet (1 = one lane per packet, 4 / 8 / 16 = a lane group, 64 = a
  * whole wave; aesgcm_packets_shape: AESGCM_SHAPE_ROWS = by rows, every message over the whole chip).  var_len != 0 describes the offset-array forms:
  * aesgcm_batch_shape goes by count (the host does not know the lengths); aesgcm_packets_shape answers AESGCM_SHAPE_MIXED -- every message is routed by
  * its own size on the device, by rows or to the packet kernel shape chosen there for the count of short ones (pkt_len is ignored). */
 #define AESGCM_SHAPE_ROWS (1 << 20)
 #define AESGCM_SHAPE_MIXED (1 << 21)
+/* ... and what the device DID decide for the context's most recent call of that kind (waits for the device): out[0] = the mark in bytes -- messages of at least that size
+ * (data + AAD) went by rows; 0 = all of them, 0xFFFFFFFF = none --, out[1] = messages that took the packet kernels, out[2] = lanes per packet of the packet kernel shape
+ * chosen for that count (0: no packet launch did anything), out[3] = units (rows, long tails, long AADs) of the row launch.  AESGCM_ESTATE before the first such call. */
+AESGCM_API int aesgcm_ctx_last_route(aesgcm_ctx *ctx, uint64_t out[4]);
 AESGCM_API int aesgcm_batch_shape(int device, size_t n_pkts, size_t pkt_len, int var_len, int *lanes_per_packet);
 AESGCM_API int aesgcm_packets_shape(const aesgcm_ctx *ctx, size_t n_pkts, size_t pkt_len, int var_len, int *lanes_per_packet);
 

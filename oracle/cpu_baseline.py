@@ -259,6 +259,90 @@ def measure_cfg5(reps=3, pkts_per_worker=1 << 15, passes=32, pkt_len=4096, key_l
     }
 
 
+# ---------------------------------------------------------------- frames under one key (bench.py --config frames)
+FRAME_LEN_SEED, FRAME_AAD = 0x4C454E, 28
+
+
+def frame_lengths(first, n):
+    """lengths of frames [first, first + n) of the frames workload: 64 + (word mod 1451) of SplitMix64 stream 0x4C454E -- uniform over 64 .. 1514, MACsec-shaped
+    (the reference's README vectors are 802.1AE frames, README.md:251-257)"""
+    import numpy as np
+    from oracle import oracle as O
+    w = np.frombuffer(O.fill_splitmix64(8 * n, FRAME_LEN_SEED, first), dtype="<u8")
+    return (64 + (w % np.uint64(1451))).astype(np.int64)
+
+
+def _worker_frames(idx, n, key_len, passes, reps, start, done, out_q):
+    import numpy as np
+    from oracle import oracle as O
+    L = evp_batch_lib()
+    lens = frame_lengths(idx * n, n)
+    doff = np.zeros(n + 1, dtype=np.uint64); doff[1:] = np.cumsum(lens)
+    aoff = (np.arange(n + 1, dtype=np.uint64) * np.uint64(FRAME_AAD))
+    total = int(doff[-1])
+    key = np.frombuffer(O.fill_splitmix64(key_len, KEY_SEED, 0), dtype=np.uint8)
+    ivw = np.frombuffer(O.fill_splitmix64(16 * n, IV_SEED, idx * n * 2), dtype=np.uint8).reshape(n, 16)
+    ivs = np.ascontiguousarray(ivw[:, :12]).reshape(-1)
+    pt = np.frombuffer(O.fill_splitmix64((total + 7) // 8 * 8, 0xAE5C0006, 0), dtype=np.uint8)
+    aad = np.frombuffer(O.fill_splitmix64(FRAME_AAD * n + 8, 0x414144, 0), dtype=np.uint8)
+    ct, tags = np.empty(total + 16, dtype=np.uint8), np.empty(16 * n, dtype=np.uint8)
+    for _ in range(reps):
+        start.wait()
+        t0 = time.perf_counter()
+        for _ in range(passes):
+            rc = L.evp_frames_crypt(n, key_len, key.ctypes.data, ivs.ctypes.data, aad.ctypes.data, aoff.ctypes.data, 0, pt.ctypes.data, doff.ctypes.data, 0, ct.ctypes.data, tags.ctypes.data)
+        dt = time.perf_counter() - t0
+        done.wait()
+        out_q.put((idx, dt, rc, total))
+
+
+def _run_frames(n_workers, n, key_len, passes, reps):
+    ctx = mp.get_context("fork")
+    start, done, q = ctx.Barrier(n_workers + 1), ctx.Barrier(n_workers + 1), ctx.Queue()
+    ps = [ctx.Process(target=_worker_frames, args=(i, n, key_len, passes, reps, start, done, q), daemon=True) for i in range(n_workers)]
+    for p in ps:
+        p.start()
+    rates = []
+    for _ in range(reps):
+        start.wait(timeout=600)
+        t0 = time.perf_counter()
+        done.wait(timeout=600)
+        wall = time.perf_counter() - t0
+        total = 0
+        for _ in range(n_workers):
+            r = q.get(timeout=60)
+            if r[2] != 0:
+                raise RuntimeError("evp_frames_crypt failed")
+            total += r[3]
+        rates.append((total * passes / wall, n_workers * n * passes / wall))     # bytes per second, frames per second
+    for p in ps:
+        p.join(timeout=30)
+    return rates
+
+
+def measure_frames(reps=3, frames_per_worker=1 << 16, passes=16, key_len=32):
+    """-> the `cpu_baseline` object of the frames bench line: libcrypto, ONE key, one EVP init (IV) per frame, AAD + data + tag per frame, the loop in C
+    (oracle/evp_batch.c evp_frames_crypt).  A bounded sample: every worker encrypts `frames_per_worker` frames of the workload's streams `passes` times per repetition."""
+    from oracle import libcrypto_ref as R
+    cores = usable_cores()
+    model, flags = cpu_info()
+    if not R.available():
+        return {"error": "libcrypto not available", "cores": cores, "cpu_model": model}
+    r1 = _run_frames(1, frames_per_worker, key_len, passes, reps)
+    rn = _run_frames(cores, frames_per_worker, key_len, passes, reps)
+    best = max(rn)
+    return {
+        "value": round(best[0] / GiB, 3), "unit": "GiB/s", "cores": cores, "kind": "library",
+        "lib": "libcrypto EVP_aes_%d_gcm (%s), one key, one EVP_EncryptInit_ex(iv) + AAD + data + tag per frame, per-frame loop in C (oracle/evp_batch.c); stands in for "
+               "pycryptodome, which is not installed (BASELINE.md 2)" % (8 * key_len, R.version()),
+        "value_median": round(statistics.median(x[0] for x in rn) / GiB, 3), "mframes_per_s": round(best[1] / 1e6, 3),
+        "value_1core": round(max(r1)[0] / GiB, 3), "mframes_per_s_1core": round(max(r1)[1] / 1e6, 3),
+        "cpu_model": model, "cpu_flags": flags, "reps": reps,
+        "sample": "AES-%d-GCM, frames of 64 .. 1514 bytes (lengths stream 0x4C454E) with %d bytes of AAD each under one key: %d worker process(es) x %d frames, encrypted "
+                  "%d times over per repetition; wall clock around the calls, best of %d (median beside it)" % (8 * key_len, FRAME_AAD, cores, frames_per_worker, passes, reps),
+    }
+
+
 if __name__ == "__main__":
     import json
     print(json.dumps(measure(), indent=1))
