@@ -1026,9 +1026,9 @@ __global__ __launch_bounds__(256) void k_len_hist(const LenSrc src, u32 n, u32 *
 //     do 45 G blocks/s but pay for every message (its E_K(J0), its length block, its closing) and for their own start: fitted to the sweep, ms for n messages of B
 //     blocks, rows 0.10 + 0.08 n/10^6 + 0.080 B/10^6, packets 0.12 + 0.17 n/10^6 + 0.022 B/10^6 (and more per message where lane groups, not lanes, take them).
 //     Frames of 64 .. 1514 bytes, 16384 of them 0.194 / 0.147 ms, 131072 0.62 / 0.32, 2^20 4.34 / 1.44; messages of 0 .. 128 bytes, 131072 0.161 / 0.242, 2^20
-//     0.56 / 0.40; 4096 frames 0.149 / 0.112.  So: the packet kernels when the short messages hold at least `blocks_min` (2^17) + 3 per message blocks (counted by size class:
+//     0.56 / 0.40; 4096 frames 0.149 / 0.112.  So: the packet kernels when the short messages hold at least `blocks_min` (2^17) + 3.5 per message blocks (counted by size class:
 //     a message of class c as 4 c + 2), else everything goes by rows.  profiles/r06/route_sweep.txt: the rule's choice against both, 35 populations.
-#define ROUTE_BLOCKS_PER_MSG 3ull
+#define ROUTE_HALF_BLOCKS_PER_MSG 7ull      /* 3.5 blocks per message */
 __global__ __launch_bounds__(1024) void k_len_scan(u32 *__restrict__ counts, const RouteCfg rc, const unsigned long long *__restrict__ bad_part, volatile u32 *host_status) {
     // Every wave owns 4096 consecutive entries (16 classes) and walks them 64 at a time, a lane per entry: coalesced loads and stores, a wave scan by lane shuffles per
     // step and a carry.  (Until round 6 a thread owned 64 consecutive entries: every load of a wave touched 64 cache lines, 128 KiB of lines in flight per step through
@@ -1106,7 +1106,7 @@ __global__ __launch_bounds__(1024) void k_len_scan(u32 *__restrict__ counts, con
             const bool high = mid >= rc.mid_min;
             const u32 c = high ? rc.c_hi : rc.c_lo;
             const u64 short_blocks = blk[0] + (high ? blk[1] : 0ull), n_short = rc.n - n_ge(c);
-            if (rc.blocks_min && short_blocks < rc.blocks_min + ROUTE_BLOCKS_PER_MSG * n_short) { route_min = 0; n_large = rc.n; }      // not worth a packet launch: everything by rows
+            if (rc.blocks_min && 2ull * short_blocks < 2ull * rc.blocks_min + ROUTE_HALF_BLOCKS_PER_MSG * n_short) { route_min = 0; n_large = rc.n; }      // not worth a packet launch: everything by rows
             else { route_min = c * 64u; n_large = n_ge(c); }
         }
         const u32 n_small = rc.n - n_large;
