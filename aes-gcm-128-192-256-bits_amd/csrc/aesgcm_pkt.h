@@ -308,15 +308,18 @@ HD void pktl_lane(const KeyMaterial *__restrict__ km, const PktParams &p, const 
         };
         fetch(xa, src, ctr);
         for (;;) {
+            // (the request is made ALWAYS -- for the half in work once more when there is no next one: behind a branch the compiler's wait in front of the arithmetic
+            // has to hold for the path without the four requests too, vmcnt(3), and on the path with them that waits for the first of the new ones as well: the
+            // first build of this loop was 4 % slower than no pipelining at all, profiles/r06/frames/pipe_ab.txt)
             const bool b = left >= 128;                            // another half behind the one in work?
-            if (b) fetch(xb, src + 64, ctr + 4);
+            fetch(xb, b ? src + 64 : src, ctr + 4);
 #if defined(__HIP_DEVICE_COMPILE__)
             __builtin_amdgcn_sched_barrier(0);                    // (the requests stay in front of the arithmetic)
 #endif
             work(xa);
             if (!b) break;
             const bool a = left >= 128;
-            if (a) fetch(xa, src + 64, ctr + 4);
+            fetch(xa, a ? src + 64 : src, ctr + 4);
 #if defined(__HIP_DEVICE_COMPILE__)
             __builtin_amdgcn_sched_barrier(0);
 #endif
