@@ -222,9 +222,6 @@ HD uint4 pktg_tree_offer(uint4 acc, const unsigned char *smem, int j) { return g
 #ifndef AESGCM_PKTL_CHAINS
 #define AESGCM_PKTL_CHAINS 4              /* k_pktl's ILP form: keystream blocks computed side by side (two passes of four per 128-byte line) */
 #endif
-#ifndef AESGCM_PKTL_PIPE
-#define AESGCM_PKTL_PIPE 1               /* k_pktl: a lane requests its next 64 bytes before it works on the current 64 (round 6) */
-#endif
 #ifndef AESGCM_PKTL_LINE
 #define AESGCM_PKTL_LINE 1               /* k_pktl: a lane fetches its packet's whole 128-byte line at once (round 4) */
 #endif
@@ -281,53 +278,10 @@ HD void pktl_lane(const KeyMaterial *__restrict__ km, const PktParams &p, const 
         }
         src += 128; dst += 128; left -= 128; ctr += 8;
     }
-#if AESGCM_PKTL_PIPE
-    // Round 6: the lane's loads one HALF line ahead of its arithmetic.  The form below issues a line's eight loads and then waits for them: a lane works about 25 us on a
-    // line (768 lanes share the CU's LDS) and waited 2 - 4 us in front of each -- with three waves per SIMD, each a dependent chain of lookups, nobody filled the
-    // gap: 2^20 frames of 64 .. 1514 bytes took 16.5 % more cycles than the same kernel without its loads and stores (profiles/r06/frames/probe_vs_real.txt).  Here the
-    // next 64 bytes are requested before the current 64 are worked on (the same 32 registers: one half in work, one in flight), and a half's four stores go out together
-    // behind its arithmetic.
-    if (!ILP && left >= 64) {
-        uint4 xa[4], xb[4];
-        auto fetch = [&](uint4 *x, const unsigned char *s, u32 c0) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) x[k] = pkt_ld<DEC>(s + 16 * k, c0 + k, false);
-        };
-        auto work = [&](uint4 *x) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                u32 s0, s1, s2, s3;
-                ctr_rounds_lds<NR, T4>(bswap32(ctr + k), cc, s0, s1, s2, s3, rk, smem, lb);
-                if (DEC == 1) acc = ghash_mul_const_lds(xor4(acc, x[k]), smem);
-                x[k] = make_uint4(x[k].x ^ s0, x[k].y ^ s1, x[k].z ^ s2, x[k].w ^ s3);
-                if (DEC != 1) acc = ghash_mul_const_lds(xor4(acc, x[k]), smem);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; k++) pkt_st<DEC>(dst + 16 * k, x[k], false);
-            src += 64; dst += 64; left -= 64; ctr += 4;
-        };
-        fetch(xa, src, ctr);
-        for (;;) {
-            // (the request is made ALWAYS -- for the half in work once more when there is no next one: behind a branch the compiler's wait in front of the arithmetic
-            // has to hold for the path without the four requests too, vmcnt(3), and on the path with them that waits for the first of the new ones as well: the
-            // first build of this loop was 4 % slower than no pipelining at all, profiles/r06/frames/pipe_ab.txt)
-            const bool b = left >= 128;                            // another half behind the one in work?
-            fetch(xb, b ? src + 64 : src, ctr + 4);
-#if defined(__HIP_DEVICE_COMPILE__)
-            __builtin_amdgcn_sched_barrier(0);                    // (the requests stay in front of the arithmetic)
-#endif
-            work(xa);
-            if (!b) break;
-            const bool a = left >= 128;
-            fetch(xa, a ? src + 64 : src, ctr + 4);
-#if defined(__HIP_DEVICE_COMPILE__)
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-            work(xb);
-            if (!a) break;
-        }
-    }
-#endif
+    // (Round 6 tried the lane's loads half a line AHEAD of its arithmetic -- the next 64 bytes requested before the current 64 are worked on, same 32 registers, stores in
+    // groups of 64 bytes -- because the real kernel spends 16.5 % more cycles than its no-data twin, all of them waiting (SQ_WAIT_ANY + 256 M wave cycles for 2^20 frames,
+    // instruction counts equal: profiles/r06/frames/probe_vs_real.txt).  It was SLOWER on the same box, 2^20 frames 1.58 ms against 1.49, AES-128 1.52 against 1.36
+    // (profiles/r06/frames/pipe_ab.txt): the waiting is not a line's eight loads in front of its arithmetic.)
     while (left >= 128) {
         uint4 xa[4], xb[4];
 #pragma unroll
