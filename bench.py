@@ -478,26 +478,31 @@ def run_cfg5(args, rank, world, dev, ex, cpu_base):
 
 
 # ------------------------------------------------------------------------------------------------ many messages under one key
-def run_msgs(args, dev, cpu_base):
+def run_msgs(args, rank, world, dev, ex, cpu_base):
     """--config msgs: n messages of one size under ONE key as the packets of one aesgcm_packets_crypt_dev call (by rows: k_rows +
-    k_rows_close).  A step is one call; the calls of the timed region are queued back to back and waited for once.  Parity in the run: the tags of a sample of the messages equal what the single-message
+    k_rows_close).  A step is one call; the calls of the timed region are queued back to back and waited for once.  N > 1: replicas -- rank r takes messages
+    [r n / N, (r + 1) n / N) of the same streams, no collective on the data path (messages are independent objects, as cfg5's packets), one max-over-ranks of the time.
+    Parity in the run: the tags of a sample of the messages equal what the single-message
     path of the same library (pinned to the libcrypto fixtures by the test-suite) gives for the same bytes, and so does their ciphertext by SHA-256."""
     import aesgcm_amd  # noqa: F401
     from aesgcm_amd import lib, sharding
     from aesgcm_amd.build import SO
     cfg = CONFIGS["msgs"]
-    n = args.n_pkts if args.n_pkts else cfg["n_pkts"]
+    N = world
+    n_all = args.n_pkts if args.n_pkts else cfg["n_pkts"]
+    n = n_all // N
+    first = rank * n
     size = args.pkt_len if args.pkt_len else cfg["pkt_len"]
     key_bits = args.key_bits or cfg["key_bits"]
     key = sharding.splitmix64_bytes(KEY_SEED, key_bits // 8)
     d_ivw, d_ivs = lib.DeviceBuffer(16 * n, device=dev), lib.DeviceBuffer(12 * n, device=dev)
-    d_ivw.fill_splitmix64(IV_SEED)
+    d_ivw.fill_splitmix64(IV_SEED, first * 2)
     ivw = bytes(d_ivw.download())
     ivs = b"".join(ivw[16 * p:16 * p + 12] for p in range(n))
     d_ivs.upload(ivs)
     d_ivw.free()
     d_pt, d_ct, d_tags = lib.DeviceBuffer(size * n, device=dev), lib.DeviceBuffer(size * n, device=dev), lib.DeviceBuffer(16 * n, device=dev)
-    d_pt.fill_splitmix64(cfg["pt_seed"])
+    d_pt.fill_splitmix64(cfg["pt_seed"], first * size // 8)
     al = args.aad_len or 0
     d_aad = lib.DeviceBuffer((al * n + 23) // 8 * 8, device=dev) if al else None
     if al:
@@ -543,6 +548,9 @@ def run_msgs(args, dev, cpu_base):
     for _ in range(max(args.warmup, 1)):                        # the warm-up steps directly in front of the timed ones (the cross-check above leaves the chip idle for a while)
         step()
     lib.dev_sync(dev)
+    if ex is not None:
+        ex.barrier()
+        lib.dev_sync(dev)
     t0 = time.perf_counter()
     done = 0
     while done < args.steps:                                    # the calls are asynchronous and their tags stay on the device: queued back to back (at most 64 deep), waited for once
@@ -550,8 +558,13 @@ def run_msgs(args, dev, cpu_base):
             step()
             done += 1
         lib.dev_sync(dev)
+    if ex is not None:
+        ex.barrier()
     dt = time.perf_counter() - t0
-    value = n * size * args.steps / dt / GiB
+    if ex is not None:
+        dt = ex.allreduce(dt, "max")
+        tag_ok = bool(ex.allreduce(1.0 if tag_ok else 0.0, "min"))
+    value = n * N * size * args.steps / dt / GiB
     tm = lib.Timer(device=dev)
     k_ms = []
     for _ in range(min(5, max(1, args.steps))):
@@ -560,21 +573,25 @@ def run_msgs(args, dev, cpu_base):
         tm.stop(ctx.stream())
         k_ms.append(tm.ms())
     tm.close()
+    if rank != 0:
+        return tag_ok
     avg_s = statistics.mean(k_ms) / 1e3
     alg_bytes = n * (2 * size + 12 + 16 + al)
     achieved = alg_bytes / avg_s
     so_sha = sha256_file(SO)
-    pm = pmc_summary("rows_1m") if (n, size, key_bits, al) == (cfg["n_pkts"], cfg["pkt_len"], cfg["key_bits"], 0) and not args.decrypt and not args.scattered else {}
+    pm = pmc_summary("rows_1m") if (n, N, size, key_bits, al) == (cfg["n_pkts"], 1, cfg["pkt_len"], cfg["key_bits"], 0) and not args.decrypt and not args.scattered else {}
     same_build = bool(pm) and pm.get("so_sha256") == so_sha
     nr = key_bits // 32 + 6
     line = {
-        "metric": "GiB/s plaintext, AES-%d-GCM, %d messages of %d bytes%s under one key as %s, bit-exact tags" % (key_bits, n, size, " with %d bytes of AAD each" % al if al else "",
+        "metric": "GiB/s plaintext, AES-%d-GCM, %d messages of %d bytes%s under one key as %s, bit-exact tags" % (key_bits, n * N, size, " with %d bytes of AAD each" % al if al else "",
                                                                                                                    "one call over arrays of their addresses and lengths" if args.scattered else "the packets of one call"),
-        "value": round(value, 3), "unit": "GiB/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "value": round(value, 3), "unit": "GiB/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "strong" if N > 1 else "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": "msgs: %d x %d B AES-%d-GCM messages under ONE key (stream 0x4B4559), per-message IV (stream 0x4956), plaintext stream 0xAE5C0055, one "
-                               "aesgcm_packets_crypt_dev call per step%s" % (n, size, key_bits, ", DECRYPT" if args.decrypt else ""),
-                   "messages": n, "message_bytes": size, "aad_bytes": al, "scattered": bool(args.scattered), "key_bits": key_bits, "shape": "rows" if shape == lib.SHAPE_ROWS else "%d lanes per packet" % shape, "parallelism": "single"},
+                               "aesgcm_packets_crypt_dev call per step%s%s" % (n * N, size, key_bits, ", DECRYPT" if args.decrypt else "", "; %d replicas of %d messages, no collective" % (N, n) if N > 1 else ""),
+                   "messages": n * N, "messages_per_gpu": n, "message_bytes": size, "aad_bytes": al, "scattered": bool(args.scattered), "key_bits": key_bits, "shape": "rows" if shape == lib.SHAPE_ROWS else "%d lanes per packet" % shape,
+                   "parallelism": "single" if N == 1 else "replicas%d" % N,
+                   "exchange": None if ex is None else {"backend": ex.name, "ranks_seen": ex.world, "use": "barrier and max-over-ranks timing only", "torch": "not imported"}},
         "tag_ok": tag_ok, "tags_checked": len(sample),
         "roofline": {"bound": "hbm", "kernel": ("k_rows<%d,%d> + k_rows_close (the rows of all messages through k_body's row loop; one call)" % (nr, int(args.decrypt))) if shape == lib.SHAPE_ROWS else "the packet kernels",
                      "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_BYTES_PER_S, 4),
@@ -1037,7 +1054,7 @@ def main(argv=None):
     if args.config == "frames":                                  # ~1.4 ms per 2^20 frames
         est_ms = 1.4 * (args.n_pkts or CONFIGS["frames"]["n_pkts"]) / (1 << 20) / max(args.gpus, 1)
     elif args.config == "msgs":                                    # ~1.1 ms per GiB by rows
-        est_ms = 1.1 * (args.n_pkts or CONFIGS["msgs"]["n_pkts"]) * (args.pkt_len or CONFIGS["msgs"]["pkt_len"]) / GiB
+        est_ms = 1.1 * (args.n_pkts or CONFIGS["msgs"]["n_pkts"]) * (args.pkt_len or CONFIGS["msgs"]["pkt_len"]) / GiB / max(args.gpus, 1)
     elif args.config != "cfg5":                                    # ~1 ms per GiB; N > 1 stream runs are the 16 GiB-per-GPU cfg4 job whatever --config says
         est_ms = (args.gib_per_gpu if args.gib_per_gpu is not None else 16.0 if (args.gpus > 1 or args.emulate_rank is not None) else
                   {"cfg2": 1.0, "cfg3": 16.0}.get(args.config, 16.0)) * 1.0
@@ -1138,10 +1155,10 @@ def main(argv=None):
             return 2
         return finish(run_frames(args, rank, world, dev, ex, cpu_base))
     if args.config == "msgs":
-        if N != 1 or emu is not None:
-            log("bench.py: --config msgs runs on one GPU")
+        if emu is not None:
+            log("bench.py: --config msgs has no --emulate-rank")
             return 2
-        return finish(run_msgs(args, dev, cpu_base))
+        return finish(run_msgs(args, rank, world, dev, ex, cpu_base))
     if args.inflight:
         if N != 1 or args.gib_per_gpu is None or emu is not None or args.decrypt:
             log("bench.py: --inflight K needs --gib-per-gpu S, one GPU, encrypt")

@@ -62,6 +62,16 @@ for k in range(4):
     ctx.encrypt(iv, b"a" * 20, bytes(70000)); ctx.decrypt(iv, b"", bytes(3 * MB))
     ctx.encrypt_pipelined(iv, b"hdr", bytes(5 * MB + 3), chunk_bytes=MB); ctx.decrypt_pipelined(iv, b"", bytes(2 * MB), chunk_bytes=MB)
     ctx.stream_begin(iv); ctx.stream_aad(b"x" * 16); ctx.stream_update(bytes(4096)); ctx.stream_update(bytes(100)); ctx.stream_final()
+    # the state of a message under way leaves its context (round 6): export, import into another context of the device, device-pointer updates of every launch structure
+    other = lib.Context(key, device=k)
+    ctx.stream_begin(iv); ctx.stream_aad(b"y" * 32); ctx.stream_update_dev(d_in.ptr, 4096, d_out.ptr)
+    blob = ctx.stream_export()
+    other.stream_import(blob)
+    for nb in (1024, 3 * MB, 33 * MB + 16):
+        other.stream_update_dev(d_in.ptr, nb, d_out.ptr)
+    other.stream_update_dev(d_in.ptr, 100, d_out.ptr, stream=ctx.stream()); other.stream_final(); ctx.stream_final()
+    assert ctx.status() == (lib.STATUS_OK, 0)
+    other.close()
     ctx.keystream(iv, 0, 100); ctx.ecb_encrypt(bytes(64)); ctx.ghash(bytes(1000)); ctx.h(); ctx.rekey(bytes(16)); ctx.rekey(key)
     lib.key_expand(key, device=k); lib.gfmul(bytes(32), bytes(32), device=k)
     check("host-buffer paths", k)
@@ -91,6 +101,10 @@ for k in range(4):
     d_lens.upload(struct.pack("<1000I", *([4000] * 1000)))
     ctx.messages_crypt_dev(False, 1000, d_ivs.ptr, d_ptrs.ptr, d_lens.ptr, d_ptrs.ptr, d_tags.ptr)                          # messages wherever they live: arrays of addresses and lengths
     ctx.messages_crypt_dev(True, 1000, d_ivs.ptr, d_ptrs.ptr, d_lens.ptr, d_ptrs.ptr, d_tags.ptr, d_aad_ptr=d_ptrs.ptr, d_aad_len=d_lens.ptr, d_expect_tags=d_tags.ptr, d_auth=d_auth.ptr)
+    # routed calls fork: the row launches on the context's side stream, the packet kernels on the caller's -- with the caller's own stream too; the probe of the frame path
+    ctx.packets_crypt_dev(False, n, d_ivs.ptr, d_in.ptr, d_out.ptr, d_tags.ptr, d_data_off=d_off.ptr, d_aad=d_aad.ptr, d_aad_off=d_off.ptr, stream=lib.Context(key, device=k).stream())
+    ctx.frames_ceiling_probe_dev(n, d_ivs.ptr, d_off.ptr, d_tags.ptr, d_aad=d_aad.ptr, d_aad_off=d_off.ptr)
+    assert set(ctx.last_route()) == {"route_min", "n_small", "lanes", "row_units"} and ctx.status() == (lib.STATUS_OK, 0)
     check("packets", k)
     # a key per packet (context-free: the device is an argument)
     d_keys = lib.DeviceBuffer(32 * n, k)
@@ -134,8 +148,18 @@ for msg in range(4):
     m.crypt_dev(False, bytes([msg]) * 12, [b[0].ptr for b in bufs], [2 * MB, 2 * MB, 2 * MB, 2 * MB - 5], [b[1].ptr for b in bufs], want_tag=False)
 assert F.fake_syncs() == 0, "queued multi-GPU messages made %d host synchronisations" % F.fake_syncs()
 assert F.fake_collectives() == 16 and F.fake_touched() == 0b1111
-tags = m.last_tags(4)
+try:
+    m.crypt_dev(False, bytes(12), [b[0].ptr for b in bufs], [MB] * 4, [b[1].ptr for b in bufs])     # a call that wants its own tag while four wait: refused, nothing enqueued
+    raise SystemExit("a call with its own tag jumped the queue")
+except lib.AesGcmError as e:
+    assert e.code == lib.ESTATE and F.fake_collectives() == 16
+tags = m.last_tags(1) + m.last_tags(3)                      # the queue is a FIFO: a partial collect, then the rest
 assert len(tags) == 4
+try:
+    m.last_tags(1)
+    raise SystemExit("a tag was collected from an empty queue")
+except lib.AesGcmError as e:
+    assert e.code == lib.EARG
 m.sync()
 check("mgpu queued")
 t = m.crypt_dev(True, bytes(12), [b[0].ptr for b in bufs], [MB] * 4, [b[1].ptr for b in bufs])

@@ -104,3 +104,29 @@ def test_bench_under_the_drivers_launcher_command():
     assert line["n_gpus"] == 2 and line["config"]["exchange"]["backend"] == "rccl" and line["config"]["exchange"]["ranks_seen"] == 2
     reports = re.findall(r"fakehip: syncs=(\d+) launches=(\d+) collectives=(\d+) violations=(\d+) touched=(\d+)", out.stderr)
     assert sorted(int(r[4]) for r in reports) == [1, 2] and all(int(r[3]) == 0 for r in reports), reports
+
+
+@pytest.mark.parametrize("config,n,extra", [("msgs", 4, ["--n-pkts", "64", "--pkt-len", "65536"]), ("msgs", 2, ["--n-pkts", "32", "--pkt-len", "70001", "--scattered"]), ("frames", 4, ["--n-pkts", "16384"]),
+                                            ("cfg5", 2, ["--n-pkts", "4096", "--pkt-len", "1024"])])
+def test_bench_replica_configs_keep_to_their_devices(config, n, extra):
+    """the workloads that shard as REPLICAS (independent messages / frames / packets: no collective on the data path) as N ranks over the fake runtime: rank r takes its
+    1 / N of the streams on device r alone, the line says N GPUs and `replicasN` (round 6: --config msgs refused N > 1 until then, DESIGN.md 7 said it was a replica
+    workload like cfg5; --config frames is new)"""
+    import json
+    import re
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc (the HIP headers)")
+    d = os.path.join(HERE, "fake_hip")
+    subprocess.run(["make", "-C", d, "-s"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    env = dict(os.environ, AESGCM_LIB=os.path.join(d, "libaesgcm_fake.so"), FAKEHIP_REPORT="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", str(n), "--config", config, "--steps", "3", "--warmup", "1", "--no-cpu-baseline"] + extra,
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == n and line["config"]["parallelism"] == "replicas%d" % n and line["scaling"] == "strong" and line["config"]["exchange"]["ranks_seen"] == n, line["config"]
+    reports = re.findall(r"fakehip: syncs=(\d+) launches=(\d+) collectives=(\d+) violations=(\d+) touched=(\d+)", out.stderr)
+    ranks = [r for r in reports if int(r[1]) > 0]
+    assert len(ranks) == n and all(int(r[3]) == 0 for r in reports), (reports, out.stderr[-2000:])
+    assert sorted(int(r[4]) for r in ranks) == [1 << k for k in range(n)], reports

@@ -164,6 +164,55 @@ def test_mgpu_queued_messages_and_their_tags(two, orc):
         assert (ct[p_ * size:(p_ + 1) * size], tags[16 * p_:16 * p_ + 16]) == f.encrypt(ivs[12 * p_:12 * p_ + 12], b"", pt[p_ * size:(p_ + 1) * size]), p_
 
 
+def test_routed_calls_and_scattered_messages_on_device_1(two, orc):
+    """device 1 (skips on a single-GPU box, runs by itself on any box with two): one offset-array call whose messages are of both kinds -- the long ones by rows on the
+    context's side stream, the short ones through the packet kernels --, the same messages in buffers of their own (aesgcm_messages_crypt_dev), the route the device
+    chose, a refused length, and the state of a stream moved from a context of device 0 to one of device 1"""
+    import random
+    import struct
+    hip = two
+    rng = random.Random(4141)
+    key = bytes(orc.fill_splitmix64(32, 0x4B4559))
+    f = orc.Fast(key)
+    n = 3000
+    lens = [int(rng.betavariate(0.1, 0.1) * 40000) for _ in range(n)]
+    doff = [0]
+    for x in lens:
+        doff.append(doff[-1] + x)
+    ivs, pt = bytes(orc.fill_splitmix64(12 * n, 93)), bytes(orc.fill_splitmix64(doff[-1], 94))
+
+    def up(b):
+        d = hip.DeviceBuffer(max(len(b), 16), device=1); d.upload(b); return d
+    with hip.Context(key, device=1) as c:
+        c.set_option("route_blocks_min", 0)
+        d_ivs, d_in, d_out, d_tags = up(ivs), up(pt), hip.DeviceBuffer(doff[-1] + 16, device=1), hip.DeviceBuffer(16 * n, device=1)
+        d_off = up(struct.pack("<%dQ" % (n + 1), *doff))
+        c.packets_crypt_dev(False, n, d_ivs.ptr, d_in.ptr, d_out.ptr, d_tags.ptr, d_data_off=d_off.ptr)
+        hip.dev_sync(1)
+        r = c.last_route()
+        assert c.status() == (hip.STATUS_OK, 0) and r["route_min"] == 2048 and 0 < r["n_small"] < n and r["row_units"] > 0, r
+        ct, tags = bytes(d_out.download(doff[-1])), bytes(d_tags.download())
+        for p_ in range(0, n, 3):
+            assert (ct[doff[p_]:doff[p_ + 1]], tags[16 * p_:16 * p_ + 16]) == f.encrypt(ivs[12 * p_:12 * p_ + 12], b"", pt[doff[p_]:doff[p_ + 1]]), p_
+        d_ptr_in, d_ptr_out = up(struct.pack("<%dQ" % n, *[d_in.ptr + x for x in doff[:-1]])), up(struct.pack("<%dQ" % n, *[d_out.ptr + x for x in doff[:-1]]))
+        d_len = up(struct.pack("<%dI" % n, *lens))
+        d_out.upload(bytes(doff[-1]))
+        c.messages_crypt_dev(False, n, d_ivs.ptr, d_ptr_in.ptr, d_len.ptr, d_ptr_out.ptr, d_tags.ptr)
+        hip.dev_sync(1)
+        assert bytes(d_out.download(doff[-1])) == ct and bytes(d_tags.download()) == tags
+        bad = list(lens); bad[7] = 1 << 28
+        c.messages_crypt_dev(False, n, d_ivs.ptr, d_ptr_in.ptr, up(struct.pack("<%dI" % n, *bad)).ptr, d_ptr_out.ptr, d_tags.ptr)
+        hip.dev_sync(1)
+        assert c.status() == (hip.STATUS_LENGTH, 7)
+        with hip.Context(key, device=0) as c0:
+            c0.stream_begin(ivs[:12]); c0.stream_update(pt[:4096])
+            c.stream_import(c0.stream_export())
+            c0.stream_final()
+        rest = c.stream_update(pt[4096:70001])
+        want = f.encrypt(ivs[:12], b"", pt[:70001])
+        assert c.stream_final() == want[1] and rest == want[0][4096:]
+
+
 def _bench(extra, timeout=1500):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "AESGCM_RDZV_DIR")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--gib-per-gpu", "0.5", "--steps", "3", "--warmup", "1",
