@@ -720,7 +720,7 @@ HD uint4 body_rows_lane(const KeyMaterial *__restrict__ km, const DevTables *__r
         const u64 off = (u64)r * 1024;
         const unsigned char *src = reinterpret_cast<const unsigned char *>(uniform64((u64)(uintptr_t)in + off));
         unsigned char *dst = reinterpret_cast<unsigned char *>(uniform64((u64)(uintptr_t)out + off));
-        const uint4 x = (MODE == MODE_PROBE) ? make_uint4(lane, q, v, 0u) : gload16(src + lane16);
+        const uint4 x = (MODE == MODE_PROBE) ? make_uint4(lane, q, v, 0u) : gload16_any(src + lane16);      // (k_rows feeds this loop rows of packets packed from ANY byte address: the accessor whose vector type promises no alignment -- the same global_load_dwordx4; the store below is inline asm and promises nothing)
         const bool hi = (v & 2u) != 0, odd = (v & 1u) != 0;
         BodyLane b;
         if (HOLD) {
