@@ -471,7 +471,7 @@ int aesgcm_shard_finalize_strided_dev(aesgcm_ctx *c, const uint8_t iv[12], const
 
 // The tags of n_msgs messages in ONE launch (one workgroup per message) and one wait: what a multi-GPU step does after its single
 // all-gather.  Per message a k_combine launch costs ~15 us (E_K(IV || 1) bytewise on one lane) plus a host round trip for its tag;
-// four of them were ~140 us of a 17 ms rank step (profiles/r03/rank_step_trace.txt).
+// four of them were ~140 us of a 17 ms rank step (profiles/archive/r03/rank_step_trace.txt).
 int aesgcm_shard_finalize_batch_dev(aesgcm_ctx *c, size_t n_msgs, const uint8_t *ivs, const void *d_partials, size_t n_partials,
                                     size_t stride_bytes, size_t msg_stride_bytes, const size_t *aad_lens, const uint64_t *total_lens,
                                     uint8_t *tags, void *stream) {

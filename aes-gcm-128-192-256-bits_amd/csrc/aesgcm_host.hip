@@ -91,7 +91,7 @@ int enqueue_fold(aesgcm_ctx *c, const uint4 *items, u32 n, u32 period, u64 eA, u
         if (close && G <= FOLD_CLOSE_MAX_WGS) {
             // a whole message: this level closes the tag itself (FoldClose) -- no further level, no k_combine.  Every closing workgroup stages the lanes' tables (33 KB)
             // and spends ~4 us: the 256 workgroups of a 1 GiB message's first level are one round on the chip and the step gains 11 us (cfg2: 976 -> 963 us); the
-            // 2048 of 16 GiB would be eight rounds and cost what they save (profiles/r03c/fold_close_ab.txt), so there the first level stays plain and the second
+            // 2048 of 16 GiB would be eight rounds and cost what they save (profiles/archive/r03c/fold_close_ab.txt), so there the first level stays plain and the second
             // (64 workgroups) closes
             f.close = *close;
             f.close.on = 1; f.close.step = fold_out_step(f);
@@ -248,7 +248,7 @@ int enqueue_cyc(aesgcm_ctx *c, int mode, const uint8_t iv[12], const void *d_aad
     if (rc) return rc;
     BodyParams p;
     // a range with pieces around its body (AAD, an odd first block, a ragged end) costs the other paths a launch pair per piece (+45 .. 80 us,
-    // profiles/r03c/general_shape.txt): for those the cyclic launch stays ahead for longer
+    // profiles/archive/r03c/general_shape.txt): for those the cyclic launch stays ahead for longer
     const bool pieces = aad_len || (first_block & 255) || (len & 1023);
     const u64 lo = fused ? c->cyc_min_fused : c->cyc_min, hi = pieces ? c->cyc_max_pieces : fused ? c->cyc_max_fused : c->cyc_max;
     const bool half = fused && len < c->cyc_half_max && (c->cyc_half == 1 || (c->cyc_half == 2 && others_in_flight(c)));   // two workgroups per CU: for messages in flight beside each other
@@ -570,7 +570,7 @@ extern "C" __attribute__((visibility("default"))) int aesgcm_debug_force_shape(c
 #endif
 
 // Packets under ONE key: how many lanes work on one packet, as log2 (0 = one LANE per packet, k_pktl; 2, 3, 4 = a lane GROUP of 4, 8, 16, k_pktg; 6 = a whole
-// wave, k_pktg<.., 6>).  Measured (profiles/r03/packets_sweep_aes256.txt, GiB/s wave / g16 / g8 / g4 / lane): the best shape is the one that just fills the
+// wave, k_pktg<.., 6>).  Measured (profiles/archive/r03/packets_sweep_aes256.txt, GiB/s wave / g16 / g8 / g4 / lane): the best shape is the one that just fills the
 // resident lanes (256 CUs x 16 waves x 64) -- 65536 x 1 KiB 203 / 232 / 340 / 384 / 194, 16384 x 4 KiB 235 / 367 / 290 / 177 / 53, 4096 x 16 KiB
 // 362 / 172 / 95 / 49 / 13 (the one regime where a whole wave per packet is right: at most 4096 packets of at least 4 KiB) -- but never more lanes than an
 // eighth of the packet's blocks once the machine is full (closing cost per byte: 16384 x 1 KiB 62 / 128 / 176 / 138 / 50, 16384 x 256 B 16 / 35 / 58 / 72 / 41),
@@ -598,11 +598,11 @@ int packets_pick_lg(u32 n_cu, size_t n_pkts, size_t pkt_len) {
 // Packets with their OWN key (k_batch3): lanes per packet as log2 (3, 4, 6 = 8 / 16 lanes, a whole wave; the two-pass kernel k_batch of rounds 2 - 3 that
 // the numbers below call by name is gone since round 4: k_batch3<.., 6> took its place, 4096 x 1 MiB 443 -> 637 GiB/s).  16 lanes once
 // there are packets enough to fill the machine that way (one 1024-lane workgroup per CU = 64 packets per CU) or the packets are short, else one wave per packet.
-// Measured, AES-128, GiB/s k_batch / k_batch3 (profiles/r03/batch_sweep_aes128.txt): 4096 x 1 KiB 30 / 56, 4096 x 256 B 7.5 / 17, 1024 x 1 KiB 14 / 16.5; 1024 x 4 KiB
+// Measured, AES-128, GiB/s k_batch / k_batch3 (profiles/archive/r03/batch_sweep_aes128.txt): 4096 x 1 KiB 30 / 56, 4096 x 256 B 7.5 / 17, 1024 x 1 KiB 14 / 16.5; 1024 x 4 KiB
 // 45 / 33, 4096 x 4 KiB 108 / 120, 4096 x 16 KiB 286 / 168; from 16384 packets k_batch3 wins at every size (4 KiB 179 / 350).  8 lanes (eight packets per wave
 // share what a wave-iteration pays once) when there are packets enough to fill the chip that way and they are not long: 2^20 packets of 64 B 42 -> 74 GiB/s,
 // 256 B 163 -> 265, 1 KiB 424 -> 560, 1500 B 484 -> 598, 4 KiB 658 -> 706, 16 KiB 770 -> 736; 16384 packets: 1 KiB 125 -> 155, 4 KiB 352 -> 273
-// (profiles/r03c/batch_sweep_lanes8_aes128.txt).  Batches with per-packet lengths (offset arrays on the device: the host does not know the lengths) go by count
+// (profiles/archive/r03c/batch_sweep_lanes8_aes128.txt).  Batches with per-packet lengths (offset arrays on the device: the host does not know the lengths) go by count
 // alone and assume frames of MACsec size, where 8 lanes gain most; a batch of frames beyond 8 KiB loses ~5 % by it.
 int batch_pick_lg(int n_cu, size_t n_pkts, size_t pkt_len, bool var) {
     int lg = (n_pkts >= (size_t)64 * n_cu || (!var && pkt_len <= 2048)) ? 4 : 6;

@@ -44,7 +44,7 @@ __global__ void k_gfmul(const uint4 *h, const uint4 *x, uint4 *z, size_t n) {
 
 // plain copy, 16 bytes per lane, ONE element per thread and no loop: the measured HBM read+write rate bench.py prints beside
 // the peak.  Round 2's grid-stride form (8192 x 256 threads looping) reached 4.9 TB/s; this form 6.16 TB/s over the same two
-// 16 GiB buffers on the same box (profiles/r03/copy_variants.txt: tiles of 4 .. 16 loads in flight per lane, nontemporal
+// 16 GiB buffers on the same box (profiles/archive/r03/copy_variants.txt: tiles of 4 .. 16 loads in flight per lane, nontemporal
 // accesses and hipMemcpyAsync all sit between 4.6 and 5.6) -- the guide's float4-copy figure is 6.29.
 __global__ __launch_bounds__(256) void k_copy16(uint4 *__restrict__ dst, const uint4 *__restrict__ src, u64 n) {
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
@@ -733,11 +733,11 @@ __device__ __forceinline__ u32 groups_max(u32 v) {
 // length block into lane G-2, an LG-level tree with the group-uniform constants H, H^2, H^4, (H^8) -- q + LG + 1 table multiplies per wave-iteration, no
 // ciphertext read-back, no fence.  Decrypt is the same pass (the lane reads its ciphertext block before it writes the plaintext: in place is safe).
 // (Rounds 2 and 3 kept a two-phase predecessor, k_batch2 -- encrypt, fence, read the ciphertext back for GHASH: 1.57 x the algorithmic HBM traffic,
-// profiles/r02g/cfg5_batch -- for A/B runs; round 4 deleted it.  HISTORY.md.)
+// profiles/archive/r02g/cfg5_batch -- for A/B runs; round 4 deleted it.  HISTORY.md.)
 // ------------------------------------------------------------------------------------------------
 // Lanes per k_batch3 workgroup (one per CU).  The first round-3 build (1024 lanes, 128 registers, round keys in VGPRs) spilled 104 - 124 bytes around its
 // packet loop and moved 11.1e9 bytes against 8.64e9 algorithmic; with 768-lane workgroups (160 registers, no scratch) 8.68e9 at the same speed -- the
-// extra traffic was scratch (profiles/r03/batch3_wg768_ab.txt).  What was being spilled was bookkeeping, as in k_pktg: the packet's H and E_K(J0) held
+// extra traffic was scratch (profiles/archive/r03/batch3_wg768_ab.txt).  What was being spilled was bookkeeping, as in k_pktg: the packet's H and E_K(J0) held
 // across the block loop (now in the group's LDS slot), the lane's position (lane_id_fresh behind the loop), ds_bpermute index registers (ds_swizzle).
 // Without them every instance fits 98 - 115 registers at 1024 lanes with ScratchSize 0.  BATCH3_WG forces another geometry.
 // LG = 4: 16 lanes per packet, four packets per wave, two table slots per packet (the closing alternates between them).  LG = 3: 8 lanes per packet, eight
@@ -746,7 +746,7 @@ __device__ __forceinline__ u32 groups_max(u32 v) {
 // Which lanes are a packet (round 4).  A ds_read_b128 is served in four groups of 16 lanes -- {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the
 // same + 32 (MI355X_MICROARCH.md, LDS) -- and a packet's Shoup table is a full 256-byte bank row, so lanes of DIFFERENT packets in one service group
 // collide whenever they pick the same bank with different entries.  With packets on consecutive lanes a service group holds FOUR packets at 8 lanes per
-// packet (lanes 0-3, 12-15, 20-23, 24-27) and two at 16: profiles/r03e/cfg5_n1 counted 9.1e8 conflict cycles in 2.83e9 LDS-array cycles, a table read
+// packet (lanes 0-3, 12-15, 20-23, 24-27) and two at 16: profiles/archive/r03e/cfg5_n1 counted 9.1e8 conflict cycles in 2.83e9 LDS-array cycles, a table read
 // at 10.3 cycles instead of 4.  BATCH3_PERM=1 makes the packets unions of service-group quads: at 16 lanes per packet a packet IS a service group (no
 // collision possible), at 8 a service group holds two packets.  With b = the lane's bits: 16 lanes: grp = b5 | b2^b3^b4, l = b4 b3 b1 b0; 8 lanes:
 // grp = b5 b4 | b2^b3, l = b3 b1 b0.  The tree partner l ^ 2^j is then lane ^ {1, 2, 12, 20}[j]: still a ds_swizzle, no index register.
@@ -1148,7 +1148,7 @@ __device__ __forceinline__ void pktg_tree(uint4 &acc, const unsigned char *smem,
 }
 // Lanes per k_pktg workgroup (one workgroup per CU).  The first round-3 build (1024 lanes, 128 registers) spilled 68 - 88 bytes around its packet
 // loop, and that scratch is what its extra HBM traffic was: 2^20 x 1 KiB at 16 lanes per packet read 1.658e9 bytes against 1.086e9 algorithmic, all
-// 128-byte requests; with 768-lane workgroups (148 - 165 registers, no scratch) 1.104e9 (profiles/r03/pktg_wg768_ab.txt).  What was being spilled was
+// 128-byte requests; with 768-lane workgroups (148 - 165 registers, no scratch) 1.104e9 (profiles/archive/r03/pktg_wg768_ab.txt).  What was being spilled was
 // bookkeeping, and it is gone at 1024 lanes too: the index registers of ds_bpermute exchanges (now ds_swizzle, lane_xor), the 64 E_K(J0) values held
 // across the packet loop (now in the wave's LDS slot) and the lane's position (recomputed from lane_id_fresh after the loop).  Lane groups therefore
 // run 1024-lane workgroups again (4 waves per SIMD: 16 lanes per packet 517 -> 530, 681 -> 700 GiB/s at 1 / 4 KiB against 768 lanes); one packet per

@@ -10,7 +10,7 @@
 // AAD and length; key schedule, H and every GHASH table come from the context.
 //
 // k_pktg<NR, DEC, LG>: G = 2^LG lanes per packet, 64 / G packets per wave (LG = 4: four packets of 16 lanes; LG = 6: one
-// packet per wave).  Round 3 rework of k_pkt (one wave per packet), whose counters said (profiles/r02g/pktw_1k: frac 0.05,
+// packet per wave).  Round 3 rework of k_pkt (one wave per packet), whose counters said (profiles/archive/r02g/pktw_1k: frac 0.05,
 // 2.5 x its algorithmic traffic, LDS busy 0.37): the length block took a slot of the row structure (a 1 KiB packet was two
 // rows, one of them 63/64 empty), the closing was a 128-step bit-serial multiply per lane per packet (~1300 VALU, three AES
 // rows' worth), and the byte loops spilled to scratch inside the row loop.  Now:
@@ -254,7 +254,7 @@ HD void pktl_lane(const KeyMaterial *__restrict__ km, const PktParams &p, const 
 #if AESGCM_PKTL_LINE
     // Round 4: the lane's whole 128-byte line at once, loads and stores.  With 64 bytes per step a line was touched twice, a tenth of a millisecond apart (a
     // lane needs ~0.2 ms for 128 bytes: 768 lanes share the CU's LDS), and the lines of all lanes in flight -- 32 CUs x 768 x (128 in + 128 out) = 6 MiB per
-    // XCD -- turn the 4 MiB L2 over many times in between: the input was fetched 1.8 x (profiles/r03e/pktl_1k), and output stored in two 64-byte groups left
+    // XCD -- turn the 4 MiB L2 over many times in between: the input was fetched 1.8 x (profiles/archive/r03e/pktl_1k), and output stored in two 64-byte groups left
     // the L2 as 1.22 x the ciphertext (block by block: 3.2 x; profiles/r04/pktl_store_ab.txt).  All eight loads are issued back to back, all eight stores
     // too; the blocks wait in 32 registers in between, which is why the workgroup is 768 lanes (3 waves per SIMD, 168 registers: at 1024 lanes AES-256
     // spilled, and decrypt -- whose GHASH runs on the loaded block while the plaintext waits -- did not fit at all).  The scheduling barrier keeps the

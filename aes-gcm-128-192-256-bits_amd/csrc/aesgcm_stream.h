@@ -105,7 +105,7 @@ HD G128 shoup2_gmul_lds(G128 y, const uint4 *__restrict__ tab) {
 // dry queues are remembered per workgroup in LDS, so only the first wave of a workgroup to find one pays a failing fetch.
 // Round 1 never reset the queues: every wave made one FAILING fetch on every queue so that the next launch knew the base
 // values -- waves x queues serialized atomics (6144 x 16 at 11.5 ns per address = 70 - 100 us) at the end of every dynamic
-// launch, which is why chunk counts above the wave count cost mid-size messages +100 us (profiles/r02f/tw_sweep_before.txt).
+// launch, which is why chunk counts above the wave count cost mid-size messages +100 us (profiles/archive/r02f/tw_sweep_before.txt).
 // Now there are two sets of queues: a launch uses one and zeroes the other for the next launch on the stream.
 #define AESGCM_NQ 16
 struct MainParams {
@@ -143,7 +143,7 @@ struct MainParams {
 // full.  Small inputs want MANY short chunks (parallelism); large ones enough chunks per resident wave for the
 // dynamic dealing to level the age-ordered issue arbitration, but not so many that the dispensers (16 queues x
 // ~87 M fetches/s) or k_fold show up.  Measured (profiles/tw_sweep.py; round 2 after the dispenser and k_fold changes:
-// profiles/r02f/tw_sweep_after.txt): 16 .. 64 MiB best at 8 rows, 100 .. 256 MiB at 16, beyond at 32; never more than
+// profiles/archive/r02f/tw_sweep_after.txt): 16 .. 64 MiB best at 8 rows, 100 .. 256 MiB at 16, beyond at 32; never more than
 // AESGCM_MAX_CHUNKS chunks.
 HD void main_geometry(u64 n_seq, u32 tw_override, u64 *rows, u32 *Tw, u32 *C) {
     const u64 R = (n_seq + 63) / 64;
@@ -152,7 +152,7 @@ HD void main_geometry(u64 n_seq, u32 tw_override, u64 *rows, u32 *Tw, u32 *C) {
     else if (R <= 2) t = R;                                        // <= 2 KiB: ONE chunk; its wave finishes the tag itself (k_main's tail: a single launch).  A lone wave needs ~2.2 us per row, so longer messages are faster as one row per wave + k_combine
     else if (R <= 256) t = (R + 63) / 64;                          // <= 256 KiB: at most 64 chunks, which k_combine folds itself (no k_fold launch)
     else if (R <= 16384) { t = R / 2048; if (t < 1) t = 1; }      // <= 16 MiB: ~2k chunks, a wave each (static assignment)
-    else if (R <= 65536) t = 8;                                    // <= 64 MiB: measured best (profiles/r02f/tw_sweep_after.txt): 4096 static chunks at 32 MiB, 8192 dealt ones at 64 MiB
+    else if (R <= 65536) t = 8;                                    // <= 64 MiB: measured best (profiles/archive/r02f/tw_sweep_after.txt): 4096 static chunks at 32 MiB, 8192 dealt ones at 64 MiB
     else t = R < (1u << 18) ? 16 : 32;
     const u64 tmin = (R + AESGCM_MAX_CHUNKS - 1) / AESGCM_MAX_CHUNKS;
     if (t < tmin) t = tmin;
@@ -414,9 +414,9 @@ struct FoldParams {
 #define FOLD_GROUP 16u           /* most items per wave */
 #ifndef FOLD_WAVES
 /* waves per workgroup: at most 128 items per workgroup.  With 512 lanes the compiler takes 176 VGPRs (batches of 8 items in flight):
-   two waves per SIMD, i.e. ONE such workgroup per CU (profiles/r03/isa_census.txt; forcing 128 registers, -DFOLD_WPS=4, spills 188 bytes into
+   two waves per SIMD, i.e. ONE such workgroup per CU (profiles/archive/r03/isa_census.txt; forcing 128 registers, -DFOLD_WPS=4, spills 188 bytes into
    the item loop) -- round 2's "two workgroups share a CU" was wrong, its measurement stands: half as many items behind one CU's LDS array.
-   Measured per k_fold launch over a 16 GiB message's 2^18 items (profiles/r02f/fold_waves.txt): 16 waves 115 us, 8 waves 73 us,
+   Measured per k_fold launch over a 16 GiB message's 2^18 items (profiles/archive/r02f/fold_waves.txt): 16 waves 115 us, 8 waves 73 us,
    4 waves 66 us; a rolled loop at 64 VGPRs with two 16-wave workgroups per CU: 172 us. */
 #define FOLD_WAVES 8u
 #endif
@@ -608,7 +608,7 @@ HD void body_rounds(u32 &s0, u32 &s1, u32 &s2, u32 &s3, const u32 *__restrict__ 
 }
 #ifndef AESGCM_BODY_WT
 #define AESGCM_BODY_WT 1                 /* k_body's rows store their ciphertext through the L2 (gstore16_wt): nothing of it is left dirty for the end of the launch -- the cyclic launch shows
-                                            its tag from inside (cyc_close), and a dealt 16 GiB launch ends 0.1 ms sooner (profiles/r03c/body_wt_ab: step 16.90 -> 16.79 ms).  0: plain stores;
+                                            its tag from inside (cyc_close), and a dealt 16 GiB launch ends 0.1 ms sooner (profiles/archive/r03c/body_wt_ab: step 16.90 -> 16.79 ms).  0: plain stores;
                                             cyc_close then writes the XCD's L2 back (an agent-scope release, 5 us) before the workgroup counts itself arrived */
 #endif
 // the state of super-row q after round 2: per-chunk lane constants xor the row-uniform part (two values in phase 3)
@@ -746,7 +746,7 @@ HD uint4 body_rows_lane(const KeyMaterial *__restrict__ km, const DevTables *__r
 template <int NR, int MODE>
 HD uint4 body_chunk_lane(const KeyMaterial *__restrict__ km, const DevTables *__restrict__ tb, const BodyParams &p,
                          const unsigned char *smem, const CtrConsts &cc, u32 c, u32 lane) {
-    return body_strand_lane<NR, MODE>(km, tb, p, smem, cc, (c >> 2) * p.T, 1u, p.T, c & 3u, lane);      // (rotating priorities here was tried: nothing, profiles/r03c/body_prio_dealt.txt)
+    return body_strand_lane<NR, MODE>(km, tb, p, smem, cc, (c >> 2) * p.T, 1u, p.T, c & 3u, lane);      // (rotating priorities here was tried: nothing, profiles/archive/r03c/body_prio_dealt.txt)
 }
 // Cyclic rows (mid-size ranges, BodyParams::cyc): no dispenser, no item per chunk, and the whole range -- AAD, odd first block, ragged end -- in ONE launch.
 // The GHASH sequence of the range is laid on a grid of 64-block rows that is aligned to the BODY: F front rows (the AAD blocks and the data blocks up to the

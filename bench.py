@@ -1002,7 +1002,7 @@ def main(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default 20; cfg2, whose step is 1 ms: 100)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed steps in front (default 3; cfg2: 50 -- the chip takes 10 - 20 ms under load to reach its clock, "
-                    "profiles/r03c/cfg2_warmup.txt: 3 warmup + 20 timed steps of 1 ms measure the ramp, 1030 GiB/s against 1165)")
+                    "profiles/archive/r03c/cfg2_warmup.txt: 3 warmup + 20 timed steps of 1 ms measure the ramp, 1030 GiB/s against 1165)")
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS), help="workload (default: the metric's cfg3; N > 1 stream runs are cfg4)")
     ap.add_argument("--gib-per-gpu", type=float, default=None, help="override: resident plaintext per GPU (no fixture check)")
     ap.add_argument("--key-bits", type=int, default=None, choices=(128, 192, 256), help="override (no fixture check)")
@@ -1021,7 +1021,7 @@ def main(argv=None):
     ap.add_argument("--selfcheck", action="store_true",
                     help="rank 0 also encrypts every whole message alone and compares tags (needs the extra memory)")
     ap.add_argument("--contexts", type=int, default=0,
-                    help="N > 1 / --emulate-rank: contexts (stream + scratch set each) a rank's messages rotate over; 0 = the default, 2 (measured best of 1 / 2 / 4, profiles/r03/emulate_rank.txt)")
+                    help="N > 1 / --emulate-rank: contexts (stream + scratch set each) a rank's messages rotate over; 0 = the default, 2 (measured best of 1 / 2 / 4, profiles/archive/r03/emulate_rank.txt)")
     ap.add_argument("--no-batch-finalize", action="store_true", help="debug: one aesgcm_shard_finalize_strided_dev call per message instead of the batched one")
     ap.add_argument("--no-chain", action="store_true", help="debug: do not chain message i's fused kernel behind message i-1's (the contexts start together)")
     ap.add_argument("--emulate-rank", type=int, default=None, help="on ONE GPU, run exactly this rank's step of the --of W job")

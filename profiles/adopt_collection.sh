@@ -1,5 +1,5 @@
 #!/bin/bash
-# Copy what a final-collection call (profiles/runs/r04_run*.sh, merged into gpurun_out/<run>/) left into profiles/<round>/ and profiles/pmc_cfg{2,3,5}_n1.json:
+# Copy what a final-collection call (profiles/archive/runs/r04_run*.sh, merged into gpurun_out/<run>/) left into profiles/<round>/ and profiles/pmc_cfg{2,3,5}_n1.json:
 #   bash profiles/adopt_collection.sh gpurun_out/r04_run29 r04
 O=$1; R=$2
 for d in $O/prof_*; do t=$(basename $d); t=${t#prof_}; mkdir -p profiles/$R/$t; cp $d/* profiles/$R/$t/; done

@@ -44,7 +44,7 @@ bash profiles/collect.sh rows_1m_dec 'k_rows<' bench.py --config msgs --decrypt 
 bash profiles/collect.sh rows_64k 'k_rows<' bench.py --config msgs --n-pkts 4096 --pkt-len 65536 --steps 100 --warmup 20 --no-cpu-baseline > $O/collect_rows_64k.txt 2>&1
 bash profiles/collect.sh rows_mixed 'k_rows<' profiles/rows_mixed.py > $O/collect_rows_mixed.txt 2>&1
 bash profiles/collect.sh rows_tls 'k_rows<' profiles/pkt_bench.py pkt --n 262144 --len 16400 --aad 13 --key-bits 256 --steps 9 > $O/collect_rows_tls.txt 2>&1
-bash profiles/runs/r05_rows_min2.sh > /dev/null 2>&1; bash profiles/runs/r05_rows_min3.sh > /dev/null 2>&1; bash profiles/runs/r05_aad_cost.sh > /dev/null 2>&1; bash profiles/runs/r05_ragged_many.sh > /dev/null 2>&1; bash profiles/runs/r05_few_large_stats.sh > /dev/null 2>&1; bash profiles/runs/r05_rows_8k_stats.sh > /dev/null 2>&1; bash profiles/runs/r05_var_stats.sh > /dev/null 2>&1; bash profiles/runs/r05_scatter.sh > /dev/null 2>&1
+bash profiles/archive/runs/r05_rows_min2.sh > /dev/null 2>&1; bash profiles/archive/runs/r05_rows_min3.sh > /dev/null 2>&1; bash profiles/archive/runs/r05_aad_cost.sh > /dev/null 2>&1; bash profiles/archive/runs/r05_ragged_many.sh > /dev/null 2>&1; bash profiles/archive/runs/r05_few_large_stats.sh > /dev/null 2>&1; bash profiles/archive/runs/r05_rows_8k_stats.sh > /dev/null 2>&1; bash profiles/archive/runs/r05_var_stats.sh > /dev/null 2>&1; bash profiles/archive/runs/r05_scatter.sh > /dev/null 2>&1
 cp gpurun_out/r05/rows_min_sweep2.txt gpurun_out/r05/rows_min_sweep3.txt gpurun_out/r05/rows_ragged_many.txt gpurun_out/r05/rows_few_large_stats.txt gpurun_out/r05/rows_small_end_stats.txt gpurun_out/r05/rows_var_stats.txt gpurun_out/r05/rows_scatter.txt $O/; cp gpurun_out/r05/rows_aad_cost.txt $O/rows_aad_cost_after.txt
 for t in cfg3_n1 cfg2_n1 cfg5_n1 rows_1m rows_1m_dec rows_64k rows_mixed rows_tls; do
   mkdir -p $O/prof_$t; cp gpurun_out/prof_$t/summary*.txt gpurun_out/prof_$t/pmc_$t.json gpurun_out/prof_$t/pmc_cfg3_probe.json gpurun_out/prof_$t/stats_run.json $O/prof_$t/ 2>/dev/null

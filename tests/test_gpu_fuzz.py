@@ -11,7 +11,7 @@ from util import splitmix_bytes
 pytestmark = pytest.mark.gpu
 
 # AESGCM_FUZZ_SEED=k re-draws every randomized test below (shapes, lengths AND the key / IV / data streams); AESGCM_FUZZ_SCALE multiplies the iteration
-# counts.  The suite runs k = 0, scale 1; profiles/runs/r04_run72.sh, 73, 78 went through k = 1 .. 32.
+# counts.  The suite runs k = 0, scale 1; profiles/archive/runs/r04_run72.sh, 73, 78 went through k = 1 .. 32.
 SEED = int(os.environ.get("AESGCM_FUZZ_SEED", "0"))
 SCALE = float(os.environ.get("AESGCM_FUZZ_SCALE", "1"))
 S0 = 1000003 * SEED                                    # offset of the SplitMix64 stream seeds

@@ -20,7 +20,7 @@ import pytest
 
 pytestmark = [pytest.mark.gpu, pytest.mark.slow]
 MiB = 1 << 20
-SEED = int(os.environ.get("AESGCM_SOAK_SEED", "0"))      # re-draws the two message soaks (lengths, offsets, IVs, keys, source bytes); the suite runs 0, profiles/runs/r04_run74.sh / 79 1 .. 60
+SEED = int(os.environ.get("AESGCM_SOAK_SEED", "0"))      # re-draws the two message soaks (lengths, offsets, IVs, keys, source bytes); the suite runs 0, profiles/archive/runs/r04_run74.sh / 79 1 .. 60
 
 
 def _u_len(rng, lo, hi):

@@ -4,7 +4,7 @@ static LDS, and -- per loop depth, from the assembler's own loop comments -- the
 v_readlane/v_writelane counts, so that a spill that lands inside a hot loop shows up as a number and not as a surprise in a
 counter run.  `hot` = basic blocks that hold at least HOT_LDS ds_read ops (an AES row or a GHASH table multiply).
 
-    python tools/isa_census.py [path.s]            -> table on stdout (profiles/r03/isa_census.txt is this output)
+    python tools/isa_census.py [path.s]            -> table on stdout (profiles/archive/r03/isa_census.txt is this output)
     census(path) -> {kernel: {...}} for tests/test_isa_cpu.py
 """
 import os
