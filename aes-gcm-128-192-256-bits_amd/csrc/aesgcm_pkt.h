@@ -95,13 +95,21 @@ HD void pktg_fill_lds(unsigned char *smem, const KeyMaterial *km, const DevTable
 // the packets' data accesses.  DEC == 2 is the PROBE of a packet kernel (aesgcm_frames_ceiling_probe_dev): the same instruction stream WITHOUT the data's loads and
 // stores -- IVs, AAD and tags still move --, what the formulation costs by itself on this chip at this moment's clocks; the "data" is then a value made of the block's
 // number, so that nothing downstream folds away
+// (-DAESGCM_PKT_NO_LOADS / -DAESGCM_PKT_NO_STORES: experiment builds in which the REAL instances lose one side of their data traffic -- which side the cycles between
+// the probe and the real kernel belong to, profiles/r06/frames/loads_stores_ab.txt; no shipped library defines them)
 template <int DEC>
 HD uint4 pkt_ld(const unsigned char *p, u32 salt, bool aligned) {
+#ifdef AESGCM_PKT_NO_LOADS
+    return make_uint4(salt, salt * 3u, ~salt, 0x9E3779B9u ^ salt);
+#endif
     if (DEC == 2) return make_uint4(salt, salt * 3u, ~salt, 0x9E3779B9u ^ salt);
     return aligned ? gload16(p) : gload16_any(p);
 }
 template <int DEC>
 HD void pkt_st(unsigned char *p, uint4 v, bool aligned) {
+#ifdef AESGCM_PKT_NO_STORES
+    return;
+#endif
     if (DEC == 2) return;
     if (aligned) gstore16(p, v); else gstore16_any(p, v);
 }
