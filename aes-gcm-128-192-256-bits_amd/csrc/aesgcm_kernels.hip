@@ -996,6 +996,9 @@ __device__ __forceinline__ void len_sort_slice(u32 n, u32 &lo, u32 &hi) {
 }
 // bad_part != NULL (a routed call): the launch also CHECKS every length it reads -- data or AAD of 2^28 bytes or more, offsets that do not rise (the difference wraps) --
 // and leaves the first such message of its slice (or ~0) for k_len_scan, which refuses the call before anything else has run
+// (the lengths of LEN_SORT_BATCH messages are requested before the first of them is counted: a thread's sixteen messages of a 2^20-frame call were sixteen
+// round trips to memory one behind the other, 23 us of launch; profiles/r06/len_sort_ab.txt)
+#define LEN_SORT_BATCH 8u
 __global__ __launch_bounds__(256) void k_len_hist(const LenSrc src, u32 n, u32 *__restrict__ counts, unsigned long long *__restrict__ bad_part) {
     __shared__ u32 h[PKT_LEN_CLASSES];
     __shared__ unsigned long long first_bad;
@@ -1005,9 +1008,22 @@ __global__ __launch_bounds__(256) void k_len_hist(const LenSrc src, u32 n, u32 *
     u32 lo, hi;
     len_sort_slice(n, lo, hi);
     unsigned long long bad = ~0ull;
-    for (u32 i = lo + threadIdx.x; i < hi; i += 256u) {
-        atomicAdd(&h[pkt_len_class(len_src_size(src, i))], 1u);
-        if (bad_part && bad == ~0ull && (len_src_data(src, i) >= ROWS_LEN_LIMIT || len_src_aad(src, i) >= ROWS_LEN_LIMIT)) bad = i;
+    for (u32 i0 = lo + threadIdx.x; i0 < hi; i0 += 256u * LEN_SORT_BATCH) {
+        u64 dl[LEN_SORT_BATCH], al[LEN_SORT_BATCH];
+#pragma unroll
+        for (u32 k = 0; k < LEN_SORT_BATCH; ++k) {
+            const u32 i = i0 + 256u * k;
+            dl[k] = 0; al[k] = 0;
+            if (i < hi) { dl[k] = len_src_data(src, i); al[k] = len_src_aad(src, i); }
+        }
+#pragma unroll
+        for (u32 k = 0; k < LEN_SORT_BATCH; ++k) {
+            const u32 i = i0 + 256u * k;
+            if (i < hi) {
+                atomicAdd(&h[pkt_len_class(rows_route_size(dl[k], al[k]))], 1u);
+                if (bad_part && bad == ~0ull && (dl[k] >= ROWS_LEN_LIMIT || al[k] >= ROWS_LEN_LIMIT)) bad = i;
+            }
+        }
     }
     if (bad != ~0ull) atomicMin(&first_bad, bad);
     __syncthreads();
@@ -1030,54 +1046,39 @@ __global__ __launch_bounds__(256) void k_len_hist(const LenSrc src, u32 n, u32 *
 //     a message of class c as 4 c + 2), else everything goes by rows.  profiles/r06/route_sweep.txt: the rule's choice against both, 35 populations.
 #define ROUTE_HALF_BLOCKS_PER_MSG 7ull      /* 3.5 blocks per message */
 __global__ __launch_bounds__(1024) void k_len_scan(u32 *__restrict__ counts, const RouteCfg rc, const unsigned long long *__restrict__ bad_part, volatile u32 *host_status) {
-    // Every wave owns 4096 consecutive entries (16 classes) and walks them 64 at a time, a lane per entry: coalesced loads and stores, a wave scan by lane shuffles per
-    // step and a carry.  (Until round 6 a thread owned 64 consecutive entries: every load of a wave touched 64 cache lines, 128 KiB of lines in flight per step through
-    // one CU's 32 KiB of L1 -- the launch took 29 - 32 us, a third of what a call of 16384 frames costs.)
+    // Every wave owns 4096 consecutive entries (16 class rows of LEN_SORT_WGS = 256) and holds ALL of them in registers, four consecutive entries per lane and step:
+    // one trip to memory for the whole array (the counts were written by other XCDs: every load is a miss), a lane's prefix of four, a wave scan by lane shuffles per
+    // step, a carry -- and the same registers are what the exclusive sums are stored from.  (Round 6, first form: a lane per entry, 64 steps in chunks of 16 loads,
+    // read once for the totals and again for the scan: eight dependent trips, 26 - 30 us of launch -- a third of what a call of 16384 frames costs; until then a
+    // thread owned 64 consecutive entries.  profiles/r06/len_sort_ab.txt.)
     __shared__ u32 wave_base[16];
     __shared__ u32 start_of_class[PKT_LEN_CLASSES];                                        // exclusive prefix at the first entry of every class row: messages of a LONGER class
-    constexpr u32 PER_WAVE = LEN_SORT_ENTRIES / 16u;
-    static_assert(LEN_SORT_ENTRIES % (16u * 64u) == 0 && LEN_SORT_WGS % 64u == 0, "k_len_scan: whole steps of 64 entries per wave, class rows that start on a step");
+    constexpr u32 PER_WAVE = LEN_SORT_ENTRIES / 16u, STEPS = PER_WAVE / 256u;
+    static_assert(LEN_SORT_ENTRIES % (16u * 256u) == 0 && LEN_SORT_WGS == 256u && STEPS == 16u, "k_len_scan: a step of 64 lanes x 4 entries is one class row");
     const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    u32 *seg = counts + w * PER_WAVE;
-    constexpr u32 STEPS = PER_WAVE / 64u, CH = 16u;                                        // 64 steps, in chunks of 16 held in registers
-    static_assert(STEPS % CH == 0, "k_len_scan: whole chunks");
-    // A load behind the previous step's store to the same array waits for that store: step by step the launch made 64 dependent trips to the L2 per pass, 30 of its
-    // 35 us.  So: the loads of a whole chunk are issued together, and the NEXT chunk's loads before this chunk's stores.
+    uint4 *seg = reinterpret_cast<uint4 *>(counts + w * PER_WAVE);
+    uint4 v[STEPS];
+#pragma unroll
+    for (u32 k = 0; k < STEPS; ++k) v[k] = seg[k * 64u + lane];
     u32 s = 0;
-    for (u32 c0 = 0; c0 < STEPS; c0 += CH) {
-        u32 v[CH];
 #pragma unroll
-        for (u32 k = 0; k < CH; ++k) v[k] = seg[(c0 + k) * 64u + lane];
-#pragma unroll
-        for (u32 k = 0; k < CH; ++k) s += v[k];
-    }
+    for (u32 k = 0; k < STEPS; ++k) s += v[k].x + v[k].y + v[k].z + v[k].w;
 #pragma unroll
     for (u32 off = 32u; off; off >>= 1) s += __shfl_xor(s, off);
     if (lane == 0) wave_base[w] = s;
     __syncthreads();
     u32 carry = 0;
     for (u32 i = 0; i < w; ++i) carry += wave_base[i];
-    u32 cur[CH], nxt[CH];
 #pragma unroll
-    for (u32 k = 0; k < CH; ++k) cur[k] = seg[k * 64u + lane];
-    for (u32 c0 = 0; c0 < STEPS; c0 += CH) {
-        if (c0 + CH < STEPS) {
+    for (u32 k = 0; k < STEPS; ++k) {
+        const u32 mine = v[k].x + v[k].y + v[k].z + v[k].w;
+        u32 incl = mine;
 #pragma unroll
-            for (u32 k = 0; k < CH; ++k) nxt[k] = seg[(c0 + CH + k) * 64u + lane];
-        }
-#pragma unroll
-        for (u32 k = 0; k < CH; ++k) {
-            u32 incl = cur[k];
-#pragma unroll
-            for (u32 off = 1; off < 64u; off <<= 1) { const u32 t = __shfl_up(incl, off); if (lane >= off) incl += t; }
-            const u32 excl = carry + incl - cur[k];
-            seg[(c0 + k) * 64u + lane] = excl;
-            const u32 e = w * PER_WAVE + (c0 + k) * 64u;                                  // the step's first entry
-            if (lane == 0 && e % LEN_SORT_WGS == 0) start_of_class[e / LEN_SORT_WGS] = excl;
-            carry += __shfl(incl, 63);
-        }
-#pragma unroll
-        for (u32 k = 0; k < CH; ++k) cur[k] = nxt[k];
+        for (u32 off = 1; off < 64u; off <<= 1) { const u32 t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+        const u32 e0 = carry + incl - mine;
+        if (lane == 0) start_of_class[w * STEPS + k] = e0;                                 // (a step is a class row)
+        seg[k * 64u + lane] = make_uint4(e0, e0 + v[k].x, e0 + v[k].x + v[k].y, e0 + v[k].x + v[k].y + v[k].z);
+        carry += __shfl(incl, 63);
     }
     if (!rc.hdr) return;
     __syncthreads();
@@ -1122,13 +1123,26 @@ __global__ __launch_bounds__(1024) void k_len_scan(u32 *__restrict__ counts, con
 __global__ __launch_bounds__(256) void k_len_scatter(const LenSrc src, u32 n, const u32 *__restrict__ base, u32 *__restrict__ perm, const RowsHdr *__restrict__ hdr) {
     __shared__ u32 cur[PKT_LEN_CLASSES];
     cur[threadIdx.x] = base[(PKT_LEN_CLASSES - 1u - threadIdx.x) * LEN_SORT_WGS + blockIdx.x];
-    __syncthreads();
     const u32 n_small = hdr ? hdr->n_small : n, n_large = n - n_small;
     u32 lo, hi;
     len_sort_slice(n, lo, hi);
-    for (u32 i = lo + threadIdx.x; i < hi; i += 256u) {
-        const u32 pos = atomicAdd(&cur[pkt_len_class(len_src_size(src, i))], 1u);
-        perm[pos >= n_large ? pos - n_large : n_small + pos] = i;
+    __syncthreads();
+    for (u32 i0 = lo + threadIdx.x; i0 < hi; i0 += 256u * LEN_SORT_BATCH) {               // (lengths in batches, as k_len_hist)
+        u32 sz[LEN_SORT_BATCH];
+#pragma unroll
+        for (u32 k = 0; k < LEN_SORT_BATCH; ++k) {
+            const u32 i = i0 + 256u * k;
+            sz[k] = 0;
+            if (i < hi) sz[k] = len_src_size(src, i);
+        }
+#pragma unroll
+        for (u32 k = 0; k < LEN_SORT_BATCH; ++k) {
+            const u32 i = i0 + 256u * k;
+            if (i < hi) {
+                const u32 pos = atomicAdd(&cur[pkt_len_class(sz[k])], 1u);
+                perm[pos >= n_large ? pos - n_large : n_small + pos] = i;
+            }
+        }
     }
 }
 

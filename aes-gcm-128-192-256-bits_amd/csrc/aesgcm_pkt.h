@@ -289,7 +289,10 @@ HD void pktl_lane(const KeyMaterial *__restrict__ km, const PktParams &p, const 
     // (Round 6 tried the lane's loads half a line AHEAD of its arithmetic -- the next 64 bytes requested before the current 64 are worked on, same 32 registers, stores in
     // groups of 64 bytes -- because the real kernel spends 16.5 % more cycles than its no-data twin, all of them waiting (SQ_WAIT_ANY + 256 M wave cycles for 2^20 frames,
     // instruction counts equal: profiles/r06/frames/probe_vs_real.txt).  It was SLOWER on the same box, 2^20 frames 1.58 ms against 1.49, AES-128 1.52 against 1.36
-    // (profiles/r06/frames/pipe_ab.txt): the waiting is not a line's eight loads in front of its arithmetic.)
+    // (profiles/r06/frames/pipe_ab.txt): the waiting is not a line's eight loads in front of its arithmetic.  Nor is it the packet's end: the loops below as ONE more
+    // line under per-block predicates -- whole blocks and the ragged one requested together, dwords instead of byte loops, the IV as three dwords -- moved the call by
+    // - 2 % .. + 3 % (tail_ab.txt, the patch beside it).  It is where the packets lie: 0.16 ms behind the twin on 64-byte boundaries, 0.33 ms byte-packed, loads and
+    // stores in equal parts, and every other cache policy slower (align_probe.txt, loads_stores_ab.txt).)
     while (left >= 128) {
         uint4 xa[4], xb[4];
 #pragma unroll

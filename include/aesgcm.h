@@ -306,7 +306,11 @@ AESGCM_API int aesgcm_mgpu_destroy(aesgcm_mgpu *m);
  * a counting sort by size class on the device (three small launches on `stream`) splits the call at the mark, hands the short messages to the packet kernels longest first
  * (the lanes of a wave run to the longest packet among them) and the others to the rows; which path a message takes never shows in its bytes or its tag.  The reference's
  * own traffic is of both kinds at once (tb/gcm_gctr.py:279-281: lengths from a U-shaped distribution).  pkt_len is IGNORED with offset arrays (until round 5 it was a hint
- * that sent the whole call one way).  Lengths of 2^28 bytes or more, or offsets that do not rise, are found on the device: nothing of the call runs then, see aesgcm_ctx_status. */
+ * that sent the whole call one way).  Lengths of 2^28 bytes or more, or offsets that do not rise, are found on the device: nothing of the call runs then, see aesgcm_ctx_status.
+ * CAPTURE: for given pointers and count the host's side of a routed call is a fixed sequence of launches on `stream` and the context's side stream (forked and joined by
+ * events).  After one ordinary call of the same context with sizes at least as large, this call and aesgcm_messages_crypt_dev allocate nothing, wait for nothing and read
+ * nothing back, so they may run under hipStreamBeginCapture on `stream`; the graph may be replayed over other lengths, offsets and bytes (examples/graph_replay.cpp,
+ * tests/test_gpu_mixed.py; on ROCm 7.2 a replay costs what the direct call costs). */
 AESGCM_API int aesgcm_packets_crypt_dev(aesgcm_ctx *ctx, int decrypt, size_t n_pkts, const void *d_ivs,
                              const void *d_aad, size_t aad_len, const uint64_t *d_aad_off,
                              const void *d_in, size_t pkt_len, const uint64_t *d_data_off, void *d_out,

@@ -7,6 +7,7 @@ the other half.
 Every message of every call here is compared with libcrypto (the survey's primary external oracle O1, through the per-frame EVP loop in C of oracle/evp_batch.c --
 2^18 messages / 8 GiB in seconds) and a sample of them, chosen around the routing mark, with the C restatement of the reference's RTL (oracle/aesgcm_oracle.c)."""
 import ctypes
+import os
 import random
 import struct
 
@@ -286,3 +287,17 @@ def test_a_length_the_call_cannot_take_is_reported_not_truncated(hip, orc):
             ct, tags = bytes(d_out.download(doff[-1])), bytes(d_tags.download())
             for i, p in enumerate(range(0, n, 7)):
                 assert (ct[doff[p]:doff[p + 1]], tags[16 * p:16 * p + 16]) == want[i], (n, name, p)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,max_len", [(3000, 1514), (2000, 40000)])
+def test_a_routed_call_is_capture_safe(n, max_len):
+    """examples/graph_replay: after one ordinary call, aesgcm_packets_crypt_dev with offset arrays is captured into a hipGraph on the caller's stream (the context's
+    side stream joins the capture through its fork / join events), and the graph -- replayed over OTHER lengths than at capture time, the route being the device's --
+    gives the bytes and tags of a direct call: the enqueue path allocates nothing, waits for nothing and reads nothing back (include/aesgcm.h "capture")"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "examples"), "-s", "graph_replay"], check=True)
+    r = subprocess.run([os.path.join(root, "examples", "graph_replay"), str(n), "5", str(max_len)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0 and "GRAPH REPLAY OK" in r.stdout, (r.stdout, r.stderr)
+    assert '"equal": true' in r.stdout
