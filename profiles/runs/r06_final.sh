@@ -6,6 +6,18 @@ O=$PWD/gpurun_out/r06_final; mkdir -p $O
 sha256sum aes-gcm-128-192-256-bits_amd/libaesgcm_hip.so aes-gcm-128-192-256-bits_amd/libaesgcm_hip_dbg.so > $O/so_sha256.txt
 timeout 3000 python -m pytest tests -q -m gpu --durations=8 > $O/pytest.txt 2>&1; echo "pytest rc=$?" >> $O/pytest.txt; tail -14 $O/pytest.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; cat $O/smoke.txt
+bash profiles/collect.sh cfg3_n1 'k_body<14, 0, false>' bench.py --steps 4 --warmup 1 --no-cpu-baseline > $O/collect_cfg3.txt 2>&1
+bash profiles/collect.sh cfg2_n1 'k_body<10, 0, false>' bench.py --config cfg2 --steps 8 --warmup 2 --no-cpu-baseline > $O/collect_cfg2.txt 2>&1
+bash profiles/collect.sh cfg5_n1 'k_batch3<10, 0' bench.py --config cfg5 --steps 5 --warmup 1 --no-cpu-baseline > $O/collect_cfg5.txt 2>&1
+bash profiles/collect.sh rows_1m 'k_rows<' bench.py --config msgs --steps 8 --warmup 2 --no-cpu-baseline > $O/collect_rows_1m.txt 2>&1
+bash profiles/collect.sh frames 'k_pktl<14, 0' profiles/frames_one.py > $O/collect_frames.txt 2>&1
+bash profiles/collect.sh frames_probe 'k_pktl<14, 2' profiles/frames_one.py --probe > $O/collect_frames_probe.txt 2>&1
+bash profiles/collect.sh pktl_1k 'k_pktl<14, 0' profiles/frames_one.py --fixed 1024 --aad 0 > $O/collect_pktl_1k.txt 2>&1
+bash profiles/collect.sh pktg_1k 'k_pktg<14, 0' profiles/frames_one.py --fixed 1024 --aad 0 --n 65536 > $O/collect_pktg_1k.txt 2>&1
+bash profiles/collect.sh mixed_u 'k_rows<' profiles/mixed_bench.py --only mixed --n 262144 --max-len 65535 --aad 28 > $O/collect_mixed_u.txt 2>&1
+bash profiles/collect.sh mixed_u_1m 'k_rows<' profiles/mixed_bench.py --only mixed --n 16384 --max-len 1048576 > $O/collect_mixed_u_1m.txt 2>&1
+# (the counters of THIS library first, so that the bench lines behind them carry roofline.traffic: bench.py reads profiles/pmc_<tag>.json only when its hash is the running library's)
+for t in cfg2_n1 cfg3_n1 cfg5_n1 rows_1m frames; do cp gpurun_out/prof_$t/pmc_$t.json profiles/ 2>/dev/null; done
 b() { n=$1; shift; timeout 900 python bench.py "$@" > $O/bench_$n.json 2> $O/bench_$n.err; }
 b default
 b cfg2 --config cfg2
@@ -45,16 +57,7 @@ for l in open(sys.argv[1]+"/route_sweep.jsonl"):
     d=json.loads(l); print(d["kind"], d["n"], d["blocks"], d["ms_rows"], d["ms_pkt"], d["ms_lib"], d["lib_vs_best"])
 PY
 timeout 900 python profiles/msg_sweep.py > $O/size_sweep.txt 2> $O/size_sweep.err; tail -14 $O/size_sweep.txt
-bash profiles/collect.sh cfg3_n1 'k_body<14, 0, false>' bench.py --steps 4 --warmup 1 --no-cpu-baseline > $O/collect_cfg3.txt 2>&1
-bash profiles/collect.sh cfg2_n1 'k_body<10, 0, false>' bench.py --config cfg2 --steps 8 --warmup 2 --no-cpu-baseline > $O/collect_cfg2.txt 2>&1
-bash profiles/collect.sh cfg5_n1 'k_batch3<10, 0' bench.py --config cfg5 --steps 5 --warmup 1 --no-cpu-baseline > $O/collect_cfg5.txt 2>&1
-bash profiles/collect.sh rows_1m 'k_rows<' bench.py --config msgs --steps 8 --warmup 2 --no-cpu-baseline > $O/collect_rows_1m.txt 2>&1
-bash profiles/collect.sh frames 'k_pktl<14, 0' profiles/frames_one.py > $O/collect_frames.txt 2>&1
-bash profiles/collect.sh frames_probe 'k_pktl<14, 2' profiles/frames_one.py --probe > $O/collect_frames_probe.txt 2>&1
-bash profiles/collect.sh pktl_1k 'k_pktl<14, 0' profiles/frames_one.py --fixed 1024 --aad 0 > $O/collect_pktl_1k.txt 2>&1
-bash profiles/collect.sh pktg_1k 'k_pktg<14, 0' profiles/frames_one.py --fixed 1024 --aad 0 --n 65536 > $O/collect_pktg_1k.txt 2>&1
-bash profiles/collect.sh mixed_u 'k_rows<' profiles/mixed_bench.py --only mixed --n 262144 --max-len 65535 --aad 28 > $O/collect_mixed_u.txt 2>&1
-bash profiles/collect.sh mixed_u_1m 'k_rows<' profiles/mixed_bench.py --only mixed --n 16384 --max-len 1048576 > $O/collect_mixed_u_1m.txt 2>&1
+for n in 4096 16384 65536 1048576; do timeout 120 examples/graph_replay $n 200 >> $O/graph_replay.jsonl 2>> $O/graph_replay.err; done
 for t in cfg3_n1 cfg2_n1 cfg5_n1 rows_1m frames frames_probe pktl_1k pktg_1k mixed_u mixed_u_1m; do
   mkdir -p $O/prof_$t; cp gpurun_out/prof_$t/summary*.txt gpurun_out/prof_$t/pmc_$t.json gpurun_out/prof_$t/stats_run.json $O/prof_$t/ 2>/dev/null
   find gpurun_out/prof_$t/stats -name "*kernel_stats.csv" -exec cp {} $O/prof_$t/kernel_stats.csv \;
