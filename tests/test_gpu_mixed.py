@@ -290,6 +290,22 @@ def test_a_length_the_call_cannot_take_is_reported_not_truncated(hip, orc):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("n", [1, 2, 63, 65, 257, 2049, 4097])
+def test_counts_at_the_edges_of_the_sort_and_lengths_at_the_marks(hip, orc, n, split):
+    """the counting sort's slices (256 workgroups, eight messages per thread and batch) and the scan's rows at counts that leave most of them empty or one over, with
+    lengths on and beside everything that decides: a block, the two routing marks (2 KiB, 8 KiB), the last size class (16 320 bytes), and messages of no bytes --
+    with and without AAD, so that data + AAD straddles a mark where data alone does not"""
+    rng = random.Random(9000 + n)
+    pool = [0, 0, 1, 15, 16, 17, 63, 64, 65, 2019, 2020, 2047, 2048, 2049, 8163, 8164, 8191, 8192, 8193, 16319, 16320, 16383, 16384, 16385, 70001]
+    lens = [pool[(p * 7 + rng.randrange(3)) % len(pool)] for p in range(n)]
+    aads = [rng.choice([0, 0, 1, 16, 28, 29]) for _ in range(n)]
+    if n > 2:
+        lens[1], aads[1] = 0, 0                                   # a message of nothing at all
+    _mixed_call(hip, orc, 32 if n % 2 else 16, lens, aads, 9100 + n, misalign=n % 16, opts=SPLIT if split else None).close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,max_len", [(3000, 1514), (2000, 40000)])
 def test_a_routed_call_is_capture_safe(n, max_len):
     """examples/graph_replay: after one ordinary call, aesgcm_packets_crypt_dev with offset arrays is captured into a hipGraph on the caller's stream (the context's
