@@ -141,6 +141,7 @@ int aesgcm_ctx_set_option(aesgcm_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "rows_min")) c->rows_min = v;                                // bytes per packet from which aesgcm_packets_crypt_dev goes by rows (k_rows); 0 = never
     else if (!strcmp(key, "route_mid_min")) c->route_mid_min = v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)v;   // routed calls: messages between the marks from which the high mark applies
     else if (!strcmp(key, "route_blocks_min")) c->route_blocks_min = v;                  // routed calls: blocks of short messages below which nothing goes to the packet kernels
+    else if (!strcmp(key, "route_top_min")) c->route_top_min = v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)v;   // routed calls: messages between rows_min and 16 320 bytes from which the packet kernels take them too
     else if (!strcmp(key, "rows_block")) c->rows_block = (u32)v;                       // units (rows, tails) per dealt block of k_rows; 0 = the library's cut
     else if (!strcmp(key, "poll_us")) c->poll_ns = 1000L * (long)v;                    // how long a tag is polled for in the host slot before the call blocks in the runtime
     else return AESGCM_EARG;

@@ -725,6 +725,7 @@ int packets_rows(aesgcm_ctx *c, int decrypt, RowsParams &p, hipStream_t st, PktP
             LenSrc src = {p.data_off, p.aad_off, p.len_arr, p.alen_arr, p.aad_len};
             RouteCfg cfg = {r.hdr, (u32)n, n_cu, 0u, 0u, c->route_mid_min, 0xFFu, 0u, c->route_blocks_min, (u64)(uintptr_t)p.in_ptr, (u64)(uintptr_t)p.out_ptr, (u64)(uintptr_t)p.aad_ptr, (u64)(uintptr_t)p.len_arr, (u64)(uintptr_t)p.alen_arr};
             k->scattered = p.len_arr ? 1u : 0u;
+            cfg.top_min = c->route_top_min;
             route_marks(c, &cfg.c_hi, &cfg.c_lo);
             const bool probe = decrypt == 2;                                 // aesgcm_frames_ceiling_probe_dev: the packet kernels' instruction stream without the data's traffic -- every message theirs, no row launch
             if (probe) { if (p.len_arr) return AESGCM_EARG; cfg.c_hi = cfg.c_lo = PKT_LEN_CLASSES; }

@@ -1038,6 +1038,10 @@ __global__ __launch_bounds__(256) void k_len_hist(const LenSrc src, u32 n, u32 *
 //     and fast rows; the packet kernels take them only when there are enough of them to keep every lane of the chip busy that long: U-shaped lengths below 8 KiB (half
 //     the messages tiny, half near 8 KiB), 65536 of them 0.69 ms by rows / 0.85 by packets, 131072 1.22 / 1.02, 524288 4.25 / 3.03.  So: the high mark when at least
 //     `mid_min` (65536) messages lie between the marks, else the low one.
+//   * THE BAND ABOVE.  Ragged messages of 8 .. 16 KiB are the rows' -- 262 144 of them 648 against 606 GiB/s -- until there are enough to fill a lane per packet twice
+//     over: 393 216 of them 643 by rows, 691 by the packet kernels, 524 288 649 / 712, 2^20 659 / 753 (profiles/r06/route_band.txt).  From `top_min` (344 064: between
+//     the two counts measured on either side) messages between the high mark and the last class the sort resolves (16 320 bytes) the mark is that class.  What the
+//     classes do not resolve stays by rows: 2^20 U-shaped messages of up to 16 383 bytes -- three in ten of them in the last 64 -- run at 602 routed, 738 by lanes alone.
 //   * WORTH IT AT ALL?  What is left below the mark costs the rows' closing launch a lane per block, 12 G blocks/s, and next to nothing per message; the packet kernels
 //     do 45 G blocks/s but pay for every message (its E_K(J0), its length block, its closing) and for their own start: fitted to the sweep, ms for n messages of B
 //     blocks, rows 0.10 + 0.08 n/10^6 + 0.080 B/10^6, packets 0.12 + 0.17 n/10^6 + 0.022 B/10^6 (and more per message where lane groups, not lanes, take them).
@@ -1087,12 +1091,13 @@ __global__ __launch_bounds__(1024) void k_len_scan(u32 *__restrict__ counts, con
     // blocks of the messages below each mark: thread c < 256 brings its class (a message of class c has 4 c + 2 blocks, give or take two)
     const u32 cls = threadIdx.x;
     const u64 mine_blocks = cls < PKT_LEN_CLASSES ? (u64)(n_ge(cls) - n_ge(cls + 1u)) * (4u * cls + 2u) : 0ull;
-    __shared__ unsigned long long blk[3];
-    if (threadIdx.x < 2) blk[threadIdx.x] = 0ull;
+    __shared__ unsigned long long blk[4];
+    if (threadIdx.x < 2 || threadIdx.x == 3) blk[threadIdx.x] = 0ull;
     if (threadIdx.x == 2) blk[2] = ~0ull;
     __syncthreads();
     if (cls < rc.c_lo && cls < PKT_LEN_CLASSES) atomicAdd(&blk[0], (unsigned long long)mine_blocks);
     else if (cls < rc.c_hi && cls < PKT_LEN_CLASSES) atomicAdd(&blk[1], (unsigned long long)mine_blocks);
+    else if (cls < PKT_LEN_CLASSES - 1u) atomicAdd(&blk[3], (unsigned long long)mine_blocks);                   // the band between the high mark and the last class the sort resolves
     if (bad_part && threadIdx.x < LEN_SORT_WGS && bad_part[threadIdx.x] != ~0ull) atomicMin(&blk[2], bad_part[threadIdx.x]);      // the first length the call cannot take (k_len_hist)
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1103,10 +1108,10 @@ __global__ __launch_bounds__(1024) void k_len_scan(u32 *__restrict__ counts, con
         u32 route_min, n_large;
         if (rc.c_hi >= PKT_LEN_CLASSES) { route_min = ROWS_ROUTE_NEVER; n_large = 0; }           // rows switched off
         else {
-            const u32 mid = n_ge(rc.c_lo) - n_ge(rc.c_hi);
-            const bool high = mid >= rc.mid_min;
-            const u32 c = high ? rc.c_hi : rc.c_lo;
-            const u64 short_blocks = blk[0] + (high ? blk[1] : 0ull), n_short = rc.n - n_ge(c);
+            const u32 mid = n_ge(rc.c_lo) - n_ge(rc.c_hi), band = n_ge(rc.c_hi) - n_ge(PKT_LEN_CLASSES - 1u);
+            const bool top = rc.top_min && rc.c_hi && rc.c_hi < PKT_LEN_CLASSES - 1u && band >= rc.top_min, high = top || mid >= rc.mid_min;      // (c_hi = 0: everything by rows, forced -- the host has launched no packet kernel)
+            const u32 c = top ? PKT_LEN_CLASSES - 1u : high ? rc.c_hi : rc.c_lo;
+            const u64 short_blocks = blk[0] + (high ? blk[1] : 0ull) + (top ? blk[3] : 0ull), n_short = rc.n - n_ge(c);
             if (rc.blocks_min && 2ull * short_blocks < 2ull * rc.blocks_min + ROUTE_HALF_BLOCKS_PER_MSG * n_short) { route_min = 0; n_large = rc.n; }      // not worth a packet launch: everything by rows
             else { route_min = c * 64u; n_large = n_ge(c); }
         }

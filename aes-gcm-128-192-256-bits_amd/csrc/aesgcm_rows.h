@@ -89,7 +89,7 @@ struct LenSrc { const u64 *off, *aoff; const u32 *len_arr, *alen_arr; u32 aad_le
 // how k_len_scan routes a call: hdr NULL = no route (a plain launch order); marks as length classes (64 bytes each; >= PKT_LEN_CLASSES = never by rows): c_hi when at
 // least mid_min messages lie between the marks, else c_lo; below blocks_min blocks of short messages in all, everything goes by rows (the rule and its measurements:
 // k_len_scan); force_lg != 0xFF / force_deal != 0: the debug library's forced packet kernel shape
-struct RouteCfg { RowsHdr *hdr; u32 n, n_cu, c_hi, c_lo, mid_min, force_lg, force_deal; u64 blocks_min; u64 sc_in, sc_out, sc_aad, sc_len, sc_alen; };
+struct RouteCfg { RowsHdr *hdr; u32 n, n_cu, c_hi, c_lo, mid_min, force_lg, force_deal; u64 blocks_min; u64 sc_in, sc_out, sc_aad, sc_len, sc_alen; u32 top_min, pad; };
 
 struct RowsParams {
     const unsigned char *ivs;                 // n_pkts * 12 bytes

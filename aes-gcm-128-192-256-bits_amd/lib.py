@@ -457,7 +457,7 @@ class Context:
         return self
 
     def set_option(self, key, value):
-        """aesgcm_ctx_set_option: "tw", "body_min", "cyc_min", "cyc_max", "cyc_close", "fold_close", "cyc_prio", "pkt_order", "rows_min", "route_mid_min", "route_blocks_min", "rows_block", "wipe_on_auth_fail", "poll_us" (include/aesgcm.h)"""
+        """aesgcm_ctx_set_option: "tw", "body_min", "cyc_min", "cyc_max", "cyc_close", "fold_close", "cyc_prio", "pkt_order", "rows_min", "route_top_min", "route_mid_min", "route_blocks_min", "rows_block", "wipe_on_auth_fail", "poll_us" (include/aesgcm.h)"""
         _chk(self._lib.aesgcm_ctx_set_option(self._c, key.encode(), int(value)))
         return self
 

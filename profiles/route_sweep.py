@@ -19,6 +19,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--key-bits", type=int, default=256)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--counts", default="4096,16384,65536,131072,262144,524288,1048576")
+ap.add_argument("--kinds", default="u8k,u1500,frames,1k,tiny")
 a = ap.parse_args()
 kb = a.key_bits // 8
 
@@ -32,6 +33,14 @@ def draw(kind, n, rng):
         return [rng.randrange(64, 1515) for _ in range(n)]
     if kind == "1k":
         return [rng.randrange(768, 1281) for _ in range(n)]
+    if kind == "band8_16":                                       # the band above the high mark, ragged (what decides whether the mark should rise with the count)
+        return [rng.randrange(8192, 16384) for _ in range(n)]
+    if kind == "band8_16w":                                      # ... in whole rows of 1 KiB
+        return [1024 * rng.randrange(8, 16) for _ in range(n)]
+    if kind == "band16_32":
+        return [rng.randrange(16384, 32768) for _ in range(n)]
+    if kind == "u16k":
+        return [int(rng.betavariate(0.1, 0.1) * 16383) for _ in range(n)]
     if kind == "tiny":
         return [rng.randrange(0, 129) for _ in range(n)]
     raise ValueError(kind)
@@ -69,7 +78,7 @@ def run(ls, force):
     return statistics.median(ts), total
 
 
-for kind in ("u8k", "u1500", "frames", "1k", "tiny"):
+for kind in a.kinds.split(","):
     for n in [int(x) for x in a.counts.split(",")]:
         rng = random.Random(99 + n)
         ls = draw(kind, n, rng)

@@ -290,6 +290,24 @@ def test_a_length_the_call_cannot_take_is_reported_not_truncated(hip, orc):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("klen", [16, 32])
+def test_a_full_band_above_the_high_mark_moves_the_mark_to_the_last_class(hip, orc, klen):
+    """option route_top_min (344 064 in the library: profiles/r06/route_band.txt) brought down to 1000: a call with that many messages of 8 .. 16 KiB sends them to the
+    packet kernels as well -- the mark becomes 16 320 bytes, the last size the sort resolves -- and only what is longer goes by rows; bytes and tags as ever"""
+    rng = random.Random(777 + klen)
+    n = 3000
+    lens = [rng.choice((rng.randrange(8192, 16320), rng.randrange(8192, 16320), rng.randrange(0, 3000), rng.randrange(16320, 40000))) for _ in range(n)]
+    aads = [rng.choice((0, 13, 28)) for _ in range(n)]
+    ctx = _mixed_call(hip, orc, klen, lens, aads, 88000 + klen, misalign=5, opts=dict(route_top_min=1000, route_blocks_min=0))
+    r = ctx.last_route()
+    assert r["route_min"] == 16320 and r["n_small"] == sum(1 for a, b in zip(lens, aads) if a + b < 16320), r
+    ctx.close()
+    ctx = _mixed_call(hip, orc, klen, lens[:900], aads[:900], 88100 + klen, opts=dict(route_top_min=1000, route_blocks_min=0))      # fewer than that in the band: the usual marks
+    assert ctx.last_route()["route_min"] in (2048, 8192)
+    ctx.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("n", [1, 2, 63, 65, 257, 2049, 4097])
 def test_counts_at_the_edges_of_the_sort_and_lengths_at_the_marks(hip, orc, n, split):
