@@ -163,7 +163,7 @@ struct aesgcm_ctx {
     u64 rows_min = (u64)8 << 10;       // packets of at least this many bytes go by rows, and from a quarter of it while they are at most 16384 (option "rows_min"; 0 = never).  With offset arrays the device applies the same marks per message (k_len_scan)
     u32 route_mid_min = 65536;         // option "route_mid_min": a routed call takes the high mark (rows_min) when at least this many messages lie between a quarter of it and it, else the low one (k_len_scan)
     u64 route_blocks_min = 1u << 17;   // option "route_blocks_min": ... and sends nothing to the packet kernels when the short messages hold fewer 16-byte blocks than this + 3.5 per message in all (0: always split)
-    u32 route_top_min = 344064;        // option "route_top_min": ... and the mark rises to the last size class (16 320 bytes) when at least this many messages lie between "rows_min" and it (0: never)
+    u32 route_top_min = 458752;        // option "route_top_min": ... and the mark rises to the last size class (16 320 bytes) when at least this many messages lie between "rows_min" and it (0: never)
     u32 rows_block = 0;                // option "rows_block": units per dealt block of k_rows (0 = the library's cut: one block per wave, or blocks of ROWS_DYN_BLOCK for large calls)
     // The state of a message under way (round 6: ONE struct for the beat-by-beat interface, the pipelined host-buffer path and what aesgcm_stream_export carries between
     // contexts, devices and processes): the RTL's Y register (src/gcm_ghash.vhd:174-186) and its counter (src/aes_icb.vhd:97-100) are d_tag[1] on the device -- in the

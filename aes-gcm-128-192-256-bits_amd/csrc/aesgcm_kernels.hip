@@ -1038,10 +1038,12 @@ __global__ __launch_bounds__(256) void k_len_hist(const LenSrc src, u32 n, u32 *
 //     and fast rows; the packet kernels take them only when there are enough of them to keep every lane of the chip busy that long: U-shaped lengths below 8 KiB (half
 //     the messages tiny, half near 8 KiB), 65536 of them 0.69 ms by rows / 0.85 by packets, 131072 1.22 / 1.02, 524288 4.25 / 3.03.  So: the high mark when at least
 //     `mid_min` (65536) messages lie between the marks, else the low one.
-//   * THE BAND ABOVE.  Ragged messages of 8 .. 16 KiB are the rows' -- 262 144 of them 648 against 606 GiB/s -- until there are enough to fill a lane per packet twice
-//     over: 393 216 of them 643 by rows, 691 by the packet kernels, 524 288 649 / 712, 2^20 659 / 753 (profiles/r06/route_band.txt).  From `top_min` (344 064: between
-//     the two counts measured on either side) messages between the high mark and the last class the sort resolves (16 320 bytes) the mark is that class.  What the
-//     classes do not resolve stays by rows: 2^20 U-shaped messages of up to 16 383 bytes -- three in ten of them in the last 64 -- run at 602 routed, 738 by lanes alone.
+//   * THE BAND ABOVE.  Ragged messages of 8 .. 16 KiB are the rows' -- 262 144 of them 647 against 606 GiB/s -- until there are enough to fill a lane per packet twice
+//     over: 393 216 of them 643 by rows, 681 by the packet kernels, 524 288 647 / 713, 2^20 654 / 736 (profiles/r06/route_band.txt).  From `top_min` messages between
+//     the high mark and the last class the sort resolves (16 320 bytes) the mark is that class.  top_min is 458 752, not the crossing of the two curves: what still
+//     lies above the mark goes by rows BEHIND the packet launch, not beside it (a 141 KiB workgroup per CU until the end) -- at 393 216 that tail made the routed call
+//     622, slower than either pure way; at 524 288 it is 718.  What the classes do not resolve stays by rows: 2^20 U-shaped messages of up to 16 383 bytes -- three in
+//     ten of them in the last 64 -- run at 619 routed, 738 by lanes alone.
 //   * WORTH IT AT ALL?  What is left below the mark costs the rows' closing launch a lane per block, 12 G blocks/s, and next to nothing per message; the packet kernels
 //     do 45 G blocks/s but pay for every message (its E_K(J0), its length block, its closing) and for their own start: fitted to the sweep, ms for n messages of B
 //     blocks, rows 0.10 + 0.08 n/10^6 + 0.080 B/10^6, packets 0.12 + 0.17 n/10^6 + 0.022 B/10^6 (and more per message where lane groups, not lanes, take them).

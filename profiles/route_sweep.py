@@ -20,6 +20,7 @@ ap.add_argument("--key-bits", type=int, default=256)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--counts", default="4096,16384,65536,131072,262144,524288,1048576")
 ap.add_argument("--kinds", default="u8k,u1500,frames,1k,tiny")
+ap.add_argument("--only", default="", help="rows | pkt | lib: that way alone (for the profiler)")
 a = ap.parse_args()
 kb = a.key_bits // 8
 
@@ -82,6 +83,10 @@ for kind in a.kinds.split(","):
     for n in [int(x) for x in a.counts.split(",")]:
         rng = random.Random(99 + n)
         ls = draw(kind, n, rng)
+        if a.only:
+            t_, total = run(ls, dict(pkt_rows=1) if a.only == "rows" else dict(pkt_rows=2) if a.only == "pkt" else None)
+            print(json.dumps({"kind": kind, "n": n, "only": a.only, "ms": round(t_, 4), "gib_s": round(total / t_ / 1e-3 / 2**30, 1)}), flush=True)
+            continue
         r, total = run(ls, dict(pkt_rows=1))
         p, _ = run(ls, dict(pkt_rows=2))
         own, _ = run(ls, None)

@@ -292,7 +292,7 @@ def test_a_length_the_call_cannot_take_is_reported_not_truncated(hip, orc):
 @pytest.mark.gpu
 @pytest.mark.parametrize("klen", [16, 32])
 def test_a_full_band_above_the_high_mark_moves_the_mark_to_the_last_class(hip, orc, klen):
-    """option route_top_min (344 064 in the library: profiles/r06/route_band.txt) brought down to 1000: a call with that many messages of 8 .. 16 KiB sends them to the
+    """option route_top_min (458 752 in the library: profiles/r06/route_band.txt) brought down to 1000: a call with that many messages of 8 .. 16 KiB sends them to the
     packet kernels as well -- the mark becomes 16 320 bytes, the last size the sort resolves -- and only what is longer goes by rows; bytes and tags as ever"""
     rng = random.Random(777 + klen)
     n = 3000
