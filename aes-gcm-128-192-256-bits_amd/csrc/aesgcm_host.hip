@@ -739,8 +739,8 @@ int packets_rows(aesgcm_ctx *c, int decrypt, RowsParams &p, hipStream_t st, PktP
             k->n_pkts = (u32)n;
             // Behind the sort the call FORKS: the row launches (plan, k_rows, k_rows_close) go to the context's side stream, the packet kernels stay on the caller's, and
             // the caller's stream waits for the side stream at the end.  The two halves share nothing but the header the scan left (read-only from here on, except the
-            // plan's own fields); a call of frames alone no longer waits for seven launches that find nothing to do, and the tail of the packet launch -- its last
-            // waves' longest packets -- runs beside the first rows.
+            // plan's own fields); a call of frames alone no longer waits for seven launches that find nothing to do.  (The two big launches do not share the chip: k_pktl and
+            // k_rows each hold a CU with one 141 KiB workgroup, so k_rows runs when the packet launch ends -- profiles/r06/route_band.txt.)
             if (!probe && !c->side) {
                 HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
                 HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
