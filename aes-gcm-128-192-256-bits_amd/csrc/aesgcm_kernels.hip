@@ -12,7 +12,7 @@
 //                   (shards, streaming), length block, E_K(J0) -> tag.  k_combine_batch: up to 8 messages, one workgroup each.
 //   k_batch3<NR,DEC,LG>   packets with their OWN key: 8, 16 or 64 lanes per packet, one pass (per-packet aes_kexp, CTR, GHASH with the packet's own tables).
 //   k_pktg<NR,DEC,LG>, k_pktl      packets under the context's key: 2^LG lanes per packet (4, 8, 16, 64) / one lane per packet.
-//   k_len_hist, k_len_scan, k_len_scatter   the order in which a launch takes packets of mixed length: a counting sort by falling length class.
+//   k_len_hist, k_len_scan, k_len_scatter (k_len_sort1: small calls, one launch)   a counting sort by falling size class; with a route, the scan DECIDES per message.
 //   k_gfmul, k_fill_splitmix64, k_copy16   small utility kernels.
 //
 // GHASH re-association (DESIGN.md "GHASH as a polynomial"): the GHASH input sequence
@@ -1051,6 +1051,47 @@ __global__ __launch_bounds__(256) void k_len_hist(const LenSrc src, u32 n, u32 *
 //     0.56 / 0.40; 4096 frames 0.149 / 0.112.  So: the packet kernels when the short messages hold at least `blocks_min` (2^17) + 3.5 per message blocks (counted by size class:
 //     a message of class c as 4 c + 2), else everything goes by rows.  profiles/r06/route_sweep.txt: the rule's choice against both, 35 populations.
 #define ROUTE_HALF_BLOCKS_PER_MSG 7ull      /* 3.5 blocks per message */
+// The DECISION of a routed call, by the workgroup that holds the sorted counts (k_len_scan, or k_len_sort1 for a small call): start_of_class[row] (LDS) = messages of a
+// LONGER class than row's (row = 255 - class); my_bad = this thread's candidate for the first message whose length the call cannot take, or ~0.  Every thread of the
+// workgroup calls it (at least 256 of them); thread 0 writes the header.
+__device__ __forceinline__ void route_decide(const RouteCfg &rc, const u32 *start_of_class, unsigned long long my_bad, volatile u32 *host_status) {
+    // messages of class >= c: the position of the first message of class c - 1 (classes are laid out falling: row 255 - class) -- from the scan's LDS, not read back from memory
+    auto n_ge = [&](u32 c) { return c == 0u ? rc.n : c >= PKT_LEN_CLASSES ? 0u : start_of_class[PKT_LEN_CLASSES - c]; };
+    // blocks of the messages below each mark: thread c < 256 brings its class (a message of class c has 4 c + 2 blocks, give or take two)
+    const u32 cls = threadIdx.x;
+    const u64 mine_blocks = cls < PKT_LEN_CLASSES ? (u64)(n_ge(cls) - n_ge(cls + 1u)) * (4u * cls + 2u) : 0ull;
+    __shared__ unsigned long long blk[4];
+    if (threadIdx.x < 2 || threadIdx.x == 3) blk[threadIdx.x] = 0ull;
+    if (threadIdx.x == 2) blk[2] = ~0ull;
+    __syncthreads();
+    if (cls < rc.c_lo && cls < PKT_LEN_CLASSES) atomicAdd(&blk[0], (unsigned long long)mine_blocks);
+    else if (cls < rc.c_hi && cls < PKT_LEN_CLASSES) atomicAdd(&blk[1], (unsigned long long)mine_blocks);
+    else if (cls < PKT_LEN_CLASSES - 1u) atomicAdd(&blk[3], (unsigned long long)mine_blocks);                   // the band between the high mark and the last class the sort resolves
+    if (my_bad != ~0ull) atomicMin(&blk[2], my_bad);                                         // the first length the call cannot take
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // the verdict on the call's lengths: refused here, before the packet kernels or the row launches (which run side by side behind this launch) have touched anything
+        const u64 first_bad = blk[2];
+        rc.hdr->bad = first_bad != ~0ull ? 1u : 0u; rc.hdr->status = first_bad != ~0ull ? ROWS_ST_LENGTH : ROWS_ST_OK; rc.hdr->detail = first_bad != ~0ull ? first_bad : 0ull;
+        if (first_bad != ~0ull && host_status) { host_status[2] = (u32)first_bad; host_status[3] = (u32)(first_bad >> 32); __threadfence_system(); host_status[0] = ROWS_ST_LENGTH; }
+        u32 route_min, n_large;
+        if (rc.c_hi >= PKT_LEN_CLASSES) { route_min = ROWS_ROUTE_NEVER; n_large = 0; }           // rows switched off
+        else {
+            const u32 mid = n_ge(rc.c_lo) - n_ge(rc.c_hi), band = n_ge(rc.c_hi) - n_ge(PKT_LEN_CLASSES - 1u);
+            const bool top = rc.top_min && rc.c_hi && rc.c_hi < PKT_LEN_CLASSES - 1u && band >= rc.top_min, high = top || mid >= rc.mid_min;      // (c_hi = 0: everything by rows, forced -- the host has launched no packet kernel)
+            const u32 c = top ? PKT_LEN_CLASSES - 1u : high ? rc.c_hi : rc.c_lo;
+            const u64 short_blocks = blk[0] + (high ? blk[1] : 0ull) + (top ? blk[3] : 0ull), n_short = rc.n - n_ge(c);
+            if (rc.blocks_min && 2ull * short_blocks < 2ull * rc.blocks_min + ROUTE_HALF_BLOCKS_PER_MSG * n_short) { route_min = 0; n_large = rc.n; }      // not worth a packet launch: everything by rows
+            else { route_min = c * 64u; n_large = n_ge(c); }
+        }
+        const u32 n_small = rc.n - n_large;
+        const u32 lg = rc.force_lg != 0xFFu ? rc.force_lg : n_small ? route_pick_lg(rc.n_cu, n_small) : 0u;
+        rc.hdr->route_min = route_min; rc.hdr->n_small = n_small; rc.hdr->pkt_lg = lg;
+        rc.hdr->pkt_deal = rc.force_deal ? (rc.force_deal + (64u >> lg) - 1u) / (64u >> lg) * (64u >> lg) : pktg_deal(rc.n_cu, n_small, lg);
+        rc.hdr->pkt_counter = 0;
+        rc.hdr->sc_in = rc.sc_in; rc.hdr->sc_out = rc.sc_out; rc.hdr->sc_aad = rc.sc_aad; rc.hdr->sc_len = rc.sc_len; rc.hdr->sc_alen = rc.sc_alen;
+    }
+}
 __global__ __launch_bounds__(1024) void k_len_scan(u32 *__restrict__ counts, const RouteCfg rc, const unsigned long long *__restrict__ bad_part, volatile u32 *host_status) {
     // Every wave owns 4096 consecutive entries (16 class rows of LEN_SORT_WGS = 256) and holds ALL of them in registers, four consecutive entries per lane and step:
     // one trip to memory for the whole array (the counts were written by other XCDs: every load is a miss), a lane's prefix of four, a wave scan by lane shuffles per
@@ -1088,42 +1129,7 @@ __global__ __launch_bounds__(1024) void k_len_scan(u32 *__restrict__ counts, con
     }
     if (!rc.hdr) return;
     __syncthreads();
-    // messages of class >= c: the position of the first message of class c - 1 (classes are laid out falling: row 255 - class) -- from the scan's LDS, not read back from memory
-    auto n_ge = [&](u32 c) { return c == 0u ? rc.n : c >= PKT_LEN_CLASSES ? 0u : start_of_class[PKT_LEN_CLASSES - c]; };
-    // blocks of the messages below each mark: thread c < 256 brings its class (a message of class c has 4 c + 2 blocks, give or take two)
-    const u32 cls = threadIdx.x;
-    const u64 mine_blocks = cls < PKT_LEN_CLASSES ? (u64)(n_ge(cls) - n_ge(cls + 1u)) * (4u * cls + 2u) : 0ull;
-    __shared__ unsigned long long blk[4];
-    if (threadIdx.x < 2 || threadIdx.x == 3) blk[threadIdx.x] = 0ull;
-    if (threadIdx.x == 2) blk[2] = ~0ull;
-    __syncthreads();
-    if (cls < rc.c_lo && cls < PKT_LEN_CLASSES) atomicAdd(&blk[0], (unsigned long long)mine_blocks);
-    else if (cls < rc.c_hi && cls < PKT_LEN_CLASSES) atomicAdd(&blk[1], (unsigned long long)mine_blocks);
-    else if (cls < PKT_LEN_CLASSES - 1u) atomicAdd(&blk[3], (unsigned long long)mine_blocks);                   // the band between the high mark and the last class the sort resolves
-    if (bad_part && threadIdx.x < LEN_SORT_WGS && bad_part[threadIdx.x] != ~0ull) atomicMin(&blk[2], bad_part[threadIdx.x]);      // the first length the call cannot take (k_len_hist)
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        // the verdict on the call's lengths: refused here, before the packet kernels or the row launches (which run side by side behind this launch) have touched anything
-        const u64 first_bad = blk[2];
-        rc.hdr->bad = first_bad != ~0ull ? 1u : 0u; rc.hdr->status = first_bad != ~0ull ? ROWS_ST_LENGTH : ROWS_ST_OK; rc.hdr->detail = first_bad != ~0ull ? first_bad : 0ull;
-        if (first_bad != ~0ull && host_status) { host_status[2] = (u32)first_bad; host_status[3] = (u32)(first_bad >> 32); __threadfence_system(); host_status[0] = ROWS_ST_LENGTH; }
-        u32 route_min, n_large;
-        if (rc.c_hi >= PKT_LEN_CLASSES) { route_min = ROWS_ROUTE_NEVER; n_large = 0; }           // rows switched off
-        else {
-            const u32 mid = n_ge(rc.c_lo) - n_ge(rc.c_hi), band = n_ge(rc.c_hi) - n_ge(PKT_LEN_CLASSES - 1u);
-            const bool top = rc.top_min && rc.c_hi && rc.c_hi < PKT_LEN_CLASSES - 1u && band >= rc.top_min, high = top || mid >= rc.mid_min;      // (c_hi = 0: everything by rows, forced -- the host has launched no packet kernel)
-            const u32 c = top ? PKT_LEN_CLASSES - 1u : high ? rc.c_hi : rc.c_lo;
-            const u64 short_blocks = blk[0] + (high ? blk[1] : 0ull) + (top ? blk[3] : 0ull), n_short = rc.n - n_ge(c);
-            if (rc.blocks_min && 2ull * short_blocks < 2ull * rc.blocks_min + ROUTE_HALF_BLOCKS_PER_MSG * n_short) { route_min = 0; n_large = rc.n; }      // not worth a packet launch: everything by rows
-            else { route_min = c * 64u; n_large = n_ge(c); }
-        }
-        const u32 n_small = rc.n - n_large;
-        const u32 lg = rc.force_lg != 0xFFu ? rc.force_lg : n_small ? route_pick_lg(rc.n_cu, n_small) : 0u;
-        rc.hdr->route_min = route_min; rc.hdr->n_small = n_small; rc.hdr->pkt_lg = lg;
-        rc.hdr->pkt_deal = rc.force_deal ? (rc.force_deal + (64u >> lg) - 1u) / (64u >> lg) * (64u >> lg) : pktg_deal(rc.n_cu, n_small, lg);
-        rc.hdr->pkt_counter = 0;
-        rc.hdr->sc_in = rc.sc_in; rc.hdr->sc_out = rc.sc_out; rc.hdr->sc_aad = rc.sc_aad; rc.hdr->sc_len = rc.sc_len; rc.hdr->sc_alen = rc.sc_alen;
-    }
+    route_decide(rc, start_of_class, bad_part && threadIdx.x < LEN_SORT_WGS ? bad_part[threadIdx.x] : ~0ull, host_status);
 }
 // small ones FIRST (what the packet kernels take, by falling class: perm[0 .. n_small)), the messages that go by rows behind them (nobody reads those: the row
 // launches walk prefix sums) -- without a route n_small is everything
@@ -1149,6 +1155,67 @@ __global__ __launch_bounds__(256) void k_len_scatter(const LenSrc src, u32 n, co
                 const u32 pos = atomicAdd(&cur[pkt_len_class(sz[k])], 1u);
                 perm[pos >= n_large ? pos - n_large : n_small + pos] = i;
             }
+        }
+    }
+}
+
+// The whole sort of a SMALL call in one launch, one workgroup (round 6): lengths read once and kept in registers, a histogram in LDS, the scan of its 256 classes, the
+// decision, the scatter with LDS cursors.  Three dependent launches cost a call of 4096 frames 20 of its 84 us, one of 16 384 frames 20 of 130
+// (profiles/r06/len_sort_ab.txt); the order inside a class is whatever the atomics make it, as in the three-launch form.
+#define LEN_SORT1_MAX 16384u
+#define LEN_SORT1_PER (LEN_SORT1_MAX / 1024u)
+__global__ __launch_bounds__(1024) void k_len_sort1(const LenSrc src, u32 n, u32 *__restrict__ perm, const RouteCfg rc, volatile u32 *host_status) {
+    __shared__ u32 h[PKT_LEN_CLASSES], start_of_class[PKT_LEN_CLASSES], cur[PKT_LEN_CLASSES], wave_sum[4];
+    const u32 tid = threadIdx.x, lane = tid & 63u;
+    if (tid < PKT_LEN_CLASSES) h[tid] = 0;
+    __syncthreads();
+    u32 sz[LEN_SORT1_PER];
+    unsigned long long bad = ~0ull;
+#pragma unroll
+    for (u32 k = 0; k < LEN_SORT1_PER; ++k) {                                              // every length of the call is in flight at once
+        const u32 i = tid + 1024u * k;
+        sz[k] = 0;
+        if (i < n) {
+            const u64 dl = len_src_data(src, i), al = len_src_aad(src, i);
+            sz[k] = rows_route_size(dl, al);
+            if (rc.hdr && bad == ~0ull && (dl >= ROWS_LEN_LIMIT || al >= ROWS_LEN_LIMIT)) bad = i;
+        }
+    }
+#pragma unroll
+    for (u32 k = 0; k < LEN_SORT1_PER; ++k)
+        if (tid + 1024u * k < n) atomicAdd(&h[pkt_len_class(sz[k])], 1u);
+    __syncthreads();
+    // exclusive prefix over the rows (row = 255 - class: longest first): four waves of 64 rows
+    u32 v = 0, incl = 0;
+    if (tid < PKT_LEN_CLASSES) {
+        v = h[PKT_LEN_CLASSES - 1u - tid]; incl = v;
+#pragma unroll
+        for (u32 off = 1; off < 64u; off <<= 1) { const u32 t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+        if (lane == 63u) wave_sum[tid >> 6] = incl;
+    }
+    __syncthreads();
+    if (tid < PKT_LEN_CLASSES) {
+        u32 carry = 0;
+        for (u32 w = 0; w < (tid >> 6); ++w) carry += wave_sum[w];
+        start_of_class[tid] = carry + incl - v;
+        cur[PKT_LEN_CLASSES - 1u - tid] = carry + incl - v;                                 // where the class's first message goes
+    }
+    __syncthreads();
+    __shared__ u32 n_small_s;
+    if (tid == 0) n_small_s = n;
+    if (rc.hdr) {
+        route_decide(rc, start_of_class, bad, host_status);
+        if (tid == 0) n_small_s = rc.hdr->bad ? 0u : rc.hdr->n_small;                     // (thread 0 reads what it has just written; a refused call scatters nothing anyone reads)
+    }
+    __syncthreads();
+    const u32 n_small = n_small_s;
+    const u32 n_large = n - n_small;
+#pragma unroll
+    for (u32 k = 0; k < LEN_SORT1_PER; ++k) {
+        const u32 i = tid + 1024u * k;
+        if (i < n) {
+            const u32 pos = atomicAdd(&cur[pkt_len_class(sz[k])], 1u);
+            perm[pos >= n_large ? pos - n_large : n_small + pos] = i;
         }
     }
 }
@@ -1759,6 +1826,10 @@ hipError_t klaunch_batch3(int nr, int dec, int lg, unsigned wgs, hipStream_t st,
     return hipGetLastError();
 }
 hipError_t klaunch_len_sort(hipStream_t st, const LenSrc &src, u32 n, u32 *bins, u32 *perm, const RouteCfg &rc, u64 *bad_part, u32 *host_status) {
+    if (n <= LEN_SORT1_MAX) {                                                                // a small call: the whole sort in one launch
+        hipLaunchKernelGGL(k_len_sort1, dim3(1), dim3(1024), 0, st, src, n, perm, rc, (volatile u32 *)host_status);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_len_hist, dim3(LEN_SORT_WGS), dim3(256), 0, st, src, n, bins, (unsigned long long *)bad_part);
     hipLaunchKernelGGL(k_len_scan, dim3(1), dim3(1024), 0, st, bins, rc, (const unsigned long long *)bad_part, (volatile u32 *)host_status);
     hipLaunchKernelGGL(k_len_scatter, dim3(LEN_SORT_WGS), dim3(256), 0, st, src, n, bins, perm, (const RowsHdr *)rc.hdr);

@@ -79,7 +79,7 @@ def test_kernel_set(census):
     for name in census:
         fam.setdefault(name.split("<")[0], []).append(name)
     assert sorted(fam) == ["k_batch3", "k_body", "k_bodyh", "k_combine", "k_combine_batch", "k_copy16", "k_fill_splitmix64", "k_fold", "k_gfmul", "k_init_tables",
-                           "k_len_hist", "k_len_scan", "k_len_scatter", "k_main", "k_pktg", "k_pktgs", "k_pktl", "k_pktls", "k_rows", "k_rows_close", "k_rows_plan", "k_rows_plan_base", "k_rows_plan_cut", "k_rows_plan_place", "k_rows_plan_slots", "k_rows_plan_sums", "k_setup", "k_setup_ptab", "k_wipe_failed"], sorted(fam)
+                           "k_len_hist", "k_len_scan", "k_len_scatter", "k_len_sort1", "k_main", "k_pktg", "k_pktgs", "k_pktl", "k_pktls", "k_rows", "k_rows_close", "k_rows_plan", "k_rows_plan_base", "k_rows_plan_cut", "k_rows_plan_place", "k_rows_plan_slots", "k_rows_plan_sums", "k_setup", "k_setup_ptab", "k_wipe_failed"], sorted(fam)
     assert (len(fam["k_main"]), len(fam["k_body"]), len(fam["k_bodyh"]), len(fam["k_pktg"]), len(fam["k_pktl"]), len(fam["k_batch3"])) == (12, 15, 6, 33, 15, 21)
     assert (len(fam["k_rows"]), len(fam["k_rows_close"]), len(fam["k_pktgs"]), len(fam["k_pktls"])) == (6, 2, 18, 6)
 
