@@ -1051,6 +1051,7 @@ __global__ __launch_bounds__(256) void k_len_hist(const LenSrc src, u32 n, u32 *
 //     0.56 / 0.40; 4096 frames 0.149 / 0.112.  So: the packet kernels when the short messages hold at least `blocks_min` (2^17) + 3.5 per message blocks (counted by size class:
 //     a message of class c as 4 c + 2), else everything goes by rows.  profiles/r06/route_sweep.txt: the rule's choice against both, 35 populations.
 #define ROUTE_HALF_BLOCKS_PER_MSG 7ull      /* 3.5 blocks per message */
+#define ROUTE_SMALL_CALL 4096u
 // The DECISION of a routed call, by the workgroup that holds the sorted counts (k_len_scan, or k_len_sort1 for a small call): start_of_class[row] (LDS) = messages of a
 // LONGER class than row's (row = 255 - class); my_bad = this thread's candidate for the first message whose length the call cannot take, or ~0.  Every thread of the
 // workgroup calls it (at least 256 of them); thread 0 writes the header.
@@ -1081,7 +1082,10 @@ __device__ __forceinline__ void route_decide(const RouteCfg &rc, const u32 *star
             const bool top = rc.top_min && rc.c_hi && rc.c_hi < PKT_LEN_CLASSES - 1u && band >= rc.top_min, high = top || mid >= rc.mid_min;      // (c_hi = 0: everything by rows, forced -- the host has launched no packet kernel)
             const u32 c = top ? PKT_LEN_CLASSES - 1u : high ? rc.c_hi : rc.c_lo;
             const u64 short_blocks = blk[0] + (high ? blk[1] : 0ull) + (top ? blk[3] : 0ull), n_short = rc.n - n_ge(c);
-            if (rc.blocks_min && 2ull * short_blocks < 2ull * rc.blocks_min + ROUTE_HALF_BLOCKS_PER_MSG * n_short) { route_min = 0; n_large = rc.n; }      // not worth a packet launch: everything by rows
+            // (a SMALL call with nothing above the mark is one family's whichever way, and then the packet kernels': 2048 frames 102 us by rows, 73 by lane groups; 512
+            // frames 93 / 70 -- the rows' plan, row launch and closing are three dependent launches, the packet kernel is one; profiles/r06/pkt_shape_sweep.txt)
+            const bool small_call = n_ge(c) == 0u && n_short <= ROUTE_SMALL_CALL;
+            if (rc.blocks_min && !small_call && 2ull * short_blocks < 2ull * rc.blocks_min + ROUTE_HALF_BLOCKS_PER_MSG * n_short) { route_min = 0; n_large = rc.n; }      // not worth a packet launch: everything by rows
             else { route_min = c * 64u; n_large = n_ge(c); }
         }
         const u32 n_small = rc.n - n_large;
