@@ -145,7 +145,8 @@ AESGCM_API int aesgcm_ctx_last_launch(const aesgcm_ctx *ctx, int *shape);
  *                 With offset arrays the mark is applied per message on the device, to data + AAD, in steps of 64 bytes and up to 16320 (see "route_mid_min")
  *   "route_mid_min", "route_blocks_min"   how a call with offset arrays is routed on the device: the mark is "rows_min" when at least route_mid_min (65536) of its messages lie
  *                 between a quarter of rows_min and rows_min, else that quarter; and nothing goes to the packet kernels at all while the messages below the mark hold
- *                 fewer than route_blocks_min (2^17) + 3.5 per message 16-byte blocks between them (csrc/aesgcm_kernels.hip k_len_scan has the measurements).  0 / 0: always the high mark, always split
+ *                 fewer than route_blocks_min (2^17) + 3.5 per message 16-byte blocks between them -- unless the call has at most 4096 messages and none above the mark: that is one packet
+ *                 launch against three row launches (csrc/aesgcm_kernels.hip route_decide has the measurements).  0 / 0: always the high mark, always split
  *   "route_top_min"   ... and the mark rises to 16320 bytes, the last size the sort resolves, when at least this many messages (458752) lie between "rows_min" and it; 0 = never
  *   "rows_block"  units (rows of 64 blocks) per dealt block of the row kernel, 0 = the library's cut (one block per wave; blocks of 64 for large calls)
  *   "poll_us"     how long a tag is polled for in the pinned host slot before the call blocks in the runtime
