@@ -309,9 +309,9 @@ def test_a_full_band_above_the_high_mark_moves_the_mark_to_the_last_class(hip, o
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("split", [False, True])
-@pytest.mark.parametrize("n", [1, 2, 63, 65, 257, 2049, 4097])
+@pytest.mark.parametrize("n", [1, 2, 63, 65, 257, 2049, 4097, 16384, 16385])
 def test_counts_at_the_edges_of_the_sort_and_lengths_at_the_marks(hip, orc, n, split):
-    """the counting sort's slices (256 workgroups, eight messages per thread and batch) and the scan's rows at counts that leave most of them empty or one over, with
+    """the counting sort -- one launch of one workgroup up to 16 384 messages, three launches with 256 slices beyond -- at counts that leave most slices empty or one over, with
     lengths on and beside everything that decides: a block, the two routing marks (2 KiB, 8 KiB), the last size class (16 320 bytes), and messages of no bytes --
     with and without AAD, so that data + AAD straddles a mark where data alone does not"""
     rng = random.Random(9000 + n)
