@@ -78,6 +78,9 @@ HD void gstore16_any(void *p, uint4 v) {
     gvec4u_t w = {v.x, v.y, v.z, v.w};
     *(__attribute__((address_space(1))) gvec4u_t *)(uintptr_t)p = w;
 }
+// ... a dword at any byte address (the IVs of a call: 12 bytes apart from a base of any alignment)
+typedef u32 gu32u_t __attribute__((aligned(1)));
+HD u32 gload4_any(const void *p) { return *(const __attribute__((address_space(1))) gu32u_t *)(uintptr_t)p; }
 // ... written THROUGH the XCD's L2 to memory (sc0 sc1): the line does not stay dirty in the L2, so nothing of it is left for a write-back at the end
 // of the launch -- or, in a launch that publishes its result from inside (k_body's fused closing), before the result may be shown.  `base` is
 // wave-uniform, `off` the lane's byte offset.  The s_nop covers the store-data hazard the compiler cannot see inside
@@ -98,6 +101,7 @@ HD uint4 gload16(const void *p) { uint4 v; __builtin_memcpy(&v, p, 16); return v
 HD void gstore16(void *p, uint4 v) { __builtin_memcpy(p, &v, 16); }
 HD uint4 gload16_any(const void *p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }
 HD void gstore16_any(void *p, uint4 v) { __builtin_memcpy(p, &v, 16); }
+HD u32 gload4_any(const void *p) { u32 v; __builtin_memcpy(&v, p, 4); return v; }
 HD void gstore16_wt(unsigned char *base, u32 off, uint4 v) { __builtin_memcpy(base + off, &v, 16); }
 HD void gstore16_wt_at(void *p, uint4 v) { __builtin_memcpy(p, &v, 16); }
 HD void gstore4_wt_at(void *p, u32 v) { *reinterpret_cast<u32 *>(p) = v; }

@@ -636,8 +636,9 @@ int order_launch(OrderSlot &o, const u64 *d_off, size_t n_pkts, hipStream_t st, 
 
 // ---------------------------------------------------------------- many messages under the context's key: by rows (aesgcm_rows.h)
 // the scratch of the path, carved out of one allocation: per message 16 + 4 bytes and (offset arrays) the three prefix sums, 32 bytes per record slot.  Zero at rest.
-struct RowsScratch { RowsHdr *hdr; u32 *queues; u64 *prefix, *sprefix, *plan_part; u32 *slot_base; RowsRec *rec; unsigned long long *acc; u32 *cnt; u32 *perm, *bins; u64 *bad_part; };
+struct RowsScratch { RowsHdr *hdr; u32 *queues; u64 *prefix, *sprefix, *plan_part; u32 *slot_base; RowsRec *rec; unsigned long long *acc; u32 *cnt; u32 *perm, *bins; u64 *bad_part; PktDesc *desc; };
 
+#define ROWS_DESC_MAX_N ((size_t)1 << 24)
 size_t rows_carve(unsigned char *base, size_t slots, size_t n, RowsScratch *r) {
     size_t o = 0;
     auto take = [&](size_t bytes) { unsigned char *q = base ? base + o : nullptr; o += (bytes + 255) & ~(size_t)255; return q; };
@@ -654,6 +655,7 @@ size_t rows_carve(unsigned char *base, size_t slots, size_t n, RowsScratch *r) {
     t.perm = (u32 *)take(4 * n);                                         // a routed call: the launch order of the messages that take the packet kernels (k_len_*)
     t.bins = (u32 *)take(4 * (size_t)LEN_SORT_ENTRIES);
     t.bad_part = (u64 *)take(8 * (size_t)LEN_SORT_WGS);                  // ... and the first length each slice of the sort found it cannot take
+    t.desc = n <= ROWS_DESC_MAX_N ? (PktDesc *)take(sizeof(PktDesc) * n) : nullptr;      // ... and, for a lane per packet, the launch's packet records (48 bytes each: not for calls of more than 2^24 messages)
     if (r) *r = t;
     return o;
 }
@@ -734,8 +736,9 @@ int packets_rows(aesgcm_ctx *c, int decrypt, RowsParams &p, hipStream_t st, PktP
             if (g_force.pkt_deal >= 1 && g_force.pkt_deal <= (int)PKTG_MAX_DEAL) cfg.force_deal = (u32)g_force.pkt_deal;
 #endif
             // (the sort also checks every length: a call with one of 2^28 bytes or more is refused by its scan -- hdr->bad -- and every launch behind returns at once)
-            HIPCHK(klaunch_len_sort(st, src, (u32)n, r.bins, r.perm, cfg, r.bad_part, reinterpret_cast<u32 *>(c->h_tag_dev + 2)));
-            k->perm = r.perm; k->route = r.hdr; k->counter = &r.hdr->pkt_counter; k->counter_base = 0; k->plain = 0;
+            const DescSrc ds = {r.desc, p.ivs, p.in_ptr, p.out_ptr, p.aad_ptr};                 // (r.desc is NULL beyond 2^24 messages: rows_carve)
+            HIPCHK(klaunch_len_sort(st, src, (u32)n, r.bins, r.perm, cfg, r.bad_part, reinterpret_cast<u32 *>(c->h_tag_dev + 2), ds));
+            k->perm = r.perm; k->route = r.hdr; k->desc = ds.desc; k->counter = &r.hdr->pkt_counter; k->counter_base = 0; k->plain = 0;
             k->n_pkts = (u32)n;
             // Behind the sort the call FORKS: the row launches (plan, k_rows, k_rows_close) go to the context's side stream, the packet kernels stay on the caller's, and
             // the caller's stream waits for the side stream at the end.  The two halves share nothing but the header the scan left (read-only from here on, except the

@@ -69,7 +69,7 @@ hipError_t klaunch_combine_batch(unsigned n, hipStream_t st, const KeyMaterial *
 hipError_t klaunch_pktl(int nr, int dec, bool ilp, unsigned wgs, hipStream_t st, const KeyMaterial *km, const DevTables *tb, const PktParams &p);
 hipError_t klaunch_pktg(int nr, int dec, int lg, unsigned wgs, hipStream_t st, const KeyMaterial *km, const DevTables *tb, const PktParams &p);
 hipError_t klaunch_batch3(int nr, int dec, int lg, unsigned wgs, hipStream_t st, const DevTables *tb, const BatchParams &p);
-hipError_t klaunch_len_sort(hipStream_t st, const LenSrc &src, u32 n, u32 *bins, u32 *perm, const RouteCfg &rc, u64 *bad_part = nullptr, u32 *host_status = nullptr);                           // k_len_hist, k_len_scan (+ the route of the call), k_len_scatter
+hipError_t klaunch_len_sort(hipStream_t st, const LenSrc &src, u32 n, u32 *bins, u32 *perm, const RouteCfg &rc, u64 *bad_part = nullptr, u32 *host_status = nullptr, const DescSrc &ds = DescSrc{});                           // k_len_hist, k_len_scan (+ the route of the call), k_len_scatter
 hipError_t klaunch_rows_plan(hipStream_t st, const RowsParams &p, bool routed, u32 force_d, u32 nb_cap, u64 *part, u32 *host_status);      // p: the lengths' arrays, n_pkts, waves, slot_cap, and the scratch arrays the plan fills (hdr, prefix, sprefix, slot_base)
 hipError_t klaunch_rows(int nr, int dec, unsigned wgs, hipStream_t st, const KeyMaterial *km, const DevTables *tb, const RowsParams &p);
 hipError_t klaunch_rows_close(int dec, unsigned wgs, hipStream_t st, const KeyMaterial *km, const DevTables *tb, const RowsParams &p);

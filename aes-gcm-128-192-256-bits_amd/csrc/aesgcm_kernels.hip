@@ -1137,27 +1137,29 @@ __global__ __launch_bounds__(1024) void k_len_scan(u32 *__restrict__ counts, con
 }
 // small ones FIRST (what the packet kernels take, by falling class: perm[0 .. n_small)), the messages that go by rows behind them (nobody reads those: the row
 // launches walk prefix sums) -- without a route n_small is everything
-__global__ __launch_bounds__(256) void k_len_scatter(const LenSrc src, u32 n, const u32 *__restrict__ base, u32 *__restrict__ perm, const RowsHdr *__restrict__ hdr) {
+__global__ __launch_bounds__(256) void k_len_scatter(const LenSrc src, u32 n, const u32 *__restrict__ base, u32 *__restrict__ perm, const RowsHdr *__restrict__ hdr, const DescSrc ds) {
     __shared__ u32 cur[PKT_LEN_CLASSES];
     cur[threadIdx.x] = base[(PKT_LEN_CLASSES - 1u - threadIdx.x) * LEN_SORT_WGS + blockIdx.x];
     const u32 n_small = hdr ? hdr->n_small : n, n_large = n - n_small;
+    const bool want_desc = ds.desc && hdr && hdr->pkt_lg == 0u && !hdr->bad;               // a lane per packet: the launch reads records, not numbers (aesgcm_pkt.h PktDesc)
     u32 lo, hi;
     len_sort_slice(n, lo, hi);
     __syncthreads();
     for (u32 i0 = lo + threadIdx.x; i0 < hi; i0 += 256u * LEN_SORT_BATCH) {               // (lengths in batches, as k_len_hist)
-        u32 sz[LEN_SORT_BATCH];
+        u64 dl[LEN_SORT_BATCH], al[LEN_SORT_BATCH];
 #pragma unroll
         for (u32 k = 0; k < LEN_SORT_BATCH; ++k) {
             const u32 i = i0 + 256u * k;
-            sz[k] = 0;
-            if (i < hi) sz[k] = len_src_size(src, i);
+            dl[k] = 0; al[k] = 0;
+            if (i < hi) { dl[k] = len_src_data(src, i); al[k] = len_src_aad(src, i); }
         }
 #pragma unroll
         for (u32 k = 0; k < LEN_SORT_BATCH; ++k) {
             const u32 i = i0 + 256u * k;
             if (i < hi) {
-                const u32 pos = atomicAdd(&cur[pkt_len_class(sz[k])], 1u);
+                const u32 pos = atomicAdd(&cur[pkt_len_class(rows_route_size(dl[k], al[k]))], 1u);
                 perm[pos >= n_large ? pos - n_large : n_small + pos] = i;
+                if (want_desc && pos >= n_large) ds.desc[pos - n_large] = len_src_desc(src, ds, i, dl[k], al[k]);
             }
         }
     }
@@ -1168,7 +1170,7 @@ __global__ __launch_bounds__(256) void k_len_scatter(const LenSrc src, u32 n, co
 // (profiles/r06/len_sort_ab.txt); the order inside a class is whatever the atomics make it, as in the three-launch form.
 #define LEN_SORT1_MAX 16384u
 #define LEN_SORT1_PER (LEN_SORT1_MAX / 1024u)
-__global__ __launch_bounds__(1024) void k_len_sort1(const LenSrc src, u32 n, u32 *__restrict__ perm, const RouteCfg rc, volatile u32 *host_status) {
+__global__ __launch_bounds__(1024) void k_len_sort1(const LenSrc src, u32 n, u32 *__restrict__ perm, const RouteCfg rc, volatile u32 *host_status, const DescSrc ds) {
     __shared__ u32 h[PKT_LEN_CLASSES], start_of_class[PKT_LEN_CLASSES], cur[PKT_LEN_CLASSES], wave_sum[4];
     const u32 tid = threadIdx.x, lane = tid & 63u;
     if (tid < PKT_LEN_CLASSES) h[tid] = 0;
@@ -1205,21 +1207,23 @@ __global__ __launch_bounds__(1024) void k_len_sort1(const LenSrc src, u32 n, u32
         cur[PKT_LEN_CLASSES - 1u - tid] = carry + incl - v;                                 // where the class's first message goes
     }
     __syncthreads();
-    __shared__ u32 n_small_s;
-    if (tid == 0) n_small_s = n;
+    __shared__ u32 n_small_s, lg_s;
+    if (tid == 0) { n_small_s = n; lg_s = 0xFFu; }
     if (rc.hdr) {
         route_decide(rc, start_of_class, bad, host_status);
-        if (tid == 0) n_small_s = rc.hdr->bad ? 0u : rc.hdr->n_small;                     // (thread 0 reads what it has just written; a refused call scatters nothing anyone reads)
+        if (tid == 0) { n_small_s = rc.hdr->bad ? 0u : rc.hdr->n_small; lg_s = rc.hdr->pkt_lg; }      // (thread 0 reads what it has just written; a refused call scatters nothing anyone reads)
     }
     __syncthreads();
     const u32 n_small = n_small_s;
     const u32 n_large = n - n_small;
+    const bool want_desc = ds.desc && rc.hdr && n_small && lg_s == 0u;                     // (a lane per packet in a call this small only when forced; the records all the same)
 #pragma unroll
     for (u32 k = 0; k < LEN_SORT1_PER; ++k) {
         const u32 i = tid + 1024u * k;
         if (i < n) {
             const u32 pos = atomicAdd(&cur[pkt_len_class(sz[k])], 1u);
             perm[pos >= n_large ? pos - n_large : n_small + pos] = i;
+            if (want_desc && pos >= n_large) ds.desc[pos - n_large] = len_src_desc(src, ds, i, len_src_data(src, i), len_src_aad(src, i));
         }
     }
 }
@@ -1287,7 +1291,7 @@ __device__ __forceinline__ void pktl_body(const KeyMaterial *__restrict__ km, co
         b = __builtin_amdgcn_readfirstlane(b);
         if (b >= nb) break;
         const u32 idx = b * 64u + lane;
-        if (idx < n_pkts) pktl_lane<NR, DEC, AESGCM_PKTL_T4 != 0, ILP != 0, SC>(km, p, smem, pkt_map(p, idx), lane);
+        if (idx < n_pkts) pktl_lane<NR, DEC, AESGCM_PKTL_T4 != 0, ILP != 0, SC>(km, p, smem, p.desc ? 0u : pkt_map(p, idx), lane, p.desc ? p.desc + idx : nullptr);
     }
 }
 template <int NR, int DEC, int ILP>
@@ -1829,14 +1833,14 @@ hipError_t klaunch_batch3(int nr, int dec, int lg, unsigned wgs, hipStream_t st,
 #undef LB3
     return hipGetLastError();
 }
-hipError_t klaunch_len_sort(hipStream_t st, const LenSrc &src, u32 n, u32 *bins, u32 *perm, const RouteCfg &rc, u64 *bad_part, u32 *host_status) {
+hipError_t klaunch_len_sort(hipStream_t st, const LenSrc &src, u32 n, u32 *bins, u32 *perm, const RouteCfg &rc, u64 *bad_part, u32 *host_status, const DescSrc &ds) {
     if (n <= LEN_SORT1_MAX) {                                                                // a small call: the whole sort in one launch
-        hipLaunchKernelGGL(k_len_sort1, dim3(1), dim3(1024), 0, st, src, n, perm, rc, (volatile u32 *)host_status);
+        hipLaunchKernelGGL(k_len_sort1, dim3(1), dim3(1024), 0, st, src, n, perm, rc, (volatile u32 *)host_status, ds);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(k_len_hist, dim3(LEN_SORT_WGS), dim3(256), 0, st, src, n, bins, (unsigned long long *)bad_part);
     hipLaunchKernelGGL(k_len_scan, dim3(1), dim3(1024), 0, st, bins, rc, (const unsigned long long *)bad_part, (volatile u32 *)host_status);
-    hipLaunchKernelGGL(k_len_scatter, dim3(LEN_SORT_WGS), dim3(256), 0, st, src, n, bins, perm, (const RowsHdr *)rc.hdr);
+    hipLaunchKernelGGL(k_len_scatter, dim3(LEN_SORT_WGS), dim3(256), 0, st, src, n, bins, perm, (const RowsHdr *)rc.hdr, ds);
     return hipGetLastError();
 }
 hipError_t klaunch_rows_plan(hipStream_t st, const RowsParams &p, bool routed, u32 force_d, u32 nb_cap, u64 *part, u32 *host_status) {

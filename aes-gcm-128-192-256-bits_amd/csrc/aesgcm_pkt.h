@@ -28,6 +28,11 @@
 // LDS: [0, 13568) five-bit table of H^G | [13568, +64 KiB) T0 | T2 | [79104 + j * 13568) tree table j | (lane groups) 1 KiB per wave for
 // the E_K(J0) values of a dispenser block.  One workgroup per CU (LG = 4: 130.25 + 16 KiB at 1024 lanes, LG = 6: 156.75 KiB at 768).
 // ================================================================================================
+// What a lane needs to know of its packet, 48 bytes, written IN THE LAUNCH'S ORDER by the sort of a routed call (k_len_scatter, k_len_sort1; round 6) when the shape is
+// a lane per packet: a wave reads 64 consecutive records -- three coalesced 16-byte loads per lane -- where it used to read its packet number, then four offsets and
+// an IV at that number's places (messages wherever they live: five arrays): six cache lines per packet that nobody else touches, two dependent trips before the first
+// byte of data is requested.  a / b / c: data offset, AAD offset, -- (offset arrays; the bases are the launch's) or the addresses of input, AAD and output.
+struct PktDesc { u64 a, b, c; u32 len, alen, pkt, iv0, iv1, iv2; };
 struct PktParams {
     const unsigned char *ivs;    // n_pkts * 12 bytes
     const unsigned char *aad;    // AAD bytes or NULL
@@ -50,6 +55,7 @@ struct PktParams {
     // aad are NULL then
     const struct RowsHdr *route;
     u32 scattered;               // 1: the packets' places come from route->sc_* (the host launches k_pktgs / k_pktls then)
+    const PktDesc *desc;         // a routed call whose shape is a lane per packet: record i = the i-th packet of the launch (NULL: perm and the arrays)
 };
 HD u32 pkt_map(const PktParams &p, u32 i) { return p.perm ? p.perm[i] : i; }
 HD const unsigned char *pkt_at(const unsigned char *base, u64 off) { return reinterpret_cast<const unsigned char *>((uintptr_t)base + off); }
@@ -238,14 +244,21 @@ HD uint4 pktg_tree_offer(uint4 acc, const unsigned char *smem, int j) { return g
 // AAD blocks, data blocks (CTR from 2, aes_icb.vhd:97-118; whole blocks as one access at whatever byte address the packet starts: gload16_any), the length block, Y = (Y ^ X) * H with the LDS
 // nibble tables of H (main_fill_lds(GH_TAB_H)), tag = Y ^ E_K(IV || 1).  Nothing here is wave-uniform except the key.
 template <int NR, int DEC, bool T4 = false, bool ILP = false, bool SC = false>
-HD void pktl_lane(const KeyMaterial *__restrict__ km, const PktParams &p, const unsigned char *smem, u32 pkt, u32 lane) {
+HD void pktl_lane(const KeyMaterial *__restrict__ km, const PktParams &p, const unsigned char *smem, u32 pkt, u32 lane, const PktDesc *d = nullptr) {
     const u32 *__restrict__ rk = km->rk;
     const u32 lb = (lane & 31u) << 2;
-    u32 pkt_len, aad_len;
+    u32 pkt_len, aad_len, iv0, iv1, iv2;
     u64 doff, ooff, aoff;
-    pkt_place<SC>(p, pkt, &doff, &ooff, &aoff, &pkt_len, &aad_len);
-    const unsigned char *ivp = p.ivs + (size_t)pkt * 12;
-    const CtrConsts cc = ctr_round1_consts(load_le32(ivp), load_le32(ivp + 4), load_le32(ivp + 8), rk, smem, lb);
+    if (d) {                                                                               // (uniform: the launch has records or it has not)
+        const uint4 q0 = gload16(d), q1 = gload16(reinterpret_cast<const unsigned char *>(d) + 16), q2 = gload16(reinterpret_cast<const unsigned char *>(d) + 32);
+        doff = ((u64)q0.y << 32) | q0.x; aoff = ((u64)q0.w << 32) | q0.z; ooff = SC ? (((u64)q1.y << 32) | q1.x) : doff;
+        pkt_len = q1.z; aad_len = q1.w; pkt = q2.x; iv0 = q2.y; iv1 = q2.z; iv2 = q2.w;
+    } else {
+        pkt_place<SC>(p, pkt, &doff, &ooff, &aoff, &pkt_len, &aad_len);
+        const unsigned char *ivp = p.ivs + (size_t)pkt * 12;
+        iv0 = load_le32(ivp); iv1 = load_le32(ivp + 4); iv2 = load_le32(ivp + 8);
+    }
+    const CtrConsts cc = ctr_round1_consts(iv0, iv1, iv2, rk, smem, lb);
     uint4 acc = make_uint4(0, 0, 0, 0);
     const unsigned char *a = pkt_at(p.aad, aoff);
     for (u32 left = aad_len; left; ) {

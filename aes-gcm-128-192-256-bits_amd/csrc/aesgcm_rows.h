@@ -135,6 +135,18 @@ HD u32 rows_route_size(u64 len, u64 alen) { const u64 t = len + alen; return t <
 HD u64 len_src_data(const LenSrc &s, u32 i) { return s.len_arr ? (u64)s.len_arr[i] : s.off[i + 1] - s.off[i]; }
 HD u64 len_src_aad(const LenSrc &s, u32 i) { return s.len_arr ? (s.alen_arr ? (u64)s.alen_arr[i] : 0ull) : s.aoff ? s.aoff[i + 1] - s.aoff[i] : (u64)s.aad_len; }
 HD u32 len_src_size(const LenSrc &s, u32 i) { return rows_route_size(len_src_data(s, i), len_src_aad(s, i)); }
+// what the sort needs beside the lengths to write the launch's packet records (aesgcm_pkt.h PktDesc; desc NULL: none wanted): the IVs, and for messages wherever they live
+// the arrays of addresses
+struct DescSrc { PktDesc *desc; const unsigned char *ivs; const u64 *in_ptr, *out_ptr, *aad_ptr; };
+HD PktDesc len_src_desc(const LenSrc &s, const DescSrc &ds, u32 i, u64 dl, u64 al) {
+    PktDesc d;
+    if (s.len_arr) { d.a = ds.in_ptr[i]; d.b = ds.aad_ptr ? ds.aad_ptr[i] : 0ull; d.c = ds.out_ptr[i]; }
+    else { d.a = s.off[i]; d.b = s.aoff ? s.aoff[i] : (u64)i * s.aad_len; d.c = 0; }
+    d.len = (u32)dl; d.alen = (u32)al; d.pkt = i;
+    const unsigned char *iv = ds.ivs + (size_t)i * 12;
+    d.iv0 = gload4_any(iv); d.iv1 = gload4_any(iv + 4); d.iv2 = gload4_any(iv + 8);
+    return d;
+}
 // A message of a ROUTED call below the mark is the packet kernels': to the row launches it is a message of NO bytes and NO AAD that also owes nothing -- no unit, no
 // smalls block, no record slot, no arrival (its tag comes from the packet kernel).  Everything that counts a message's share goes through these two (the geometry of
 // an empty message, an AAD of no blocks), so the counts below need no word about routing

@@ -239,7 +239,7 @@ hipError_t klaunch_batch3(int, int, int, unsigned, hipStream_t st, const DevTabl
     LAUNCH("k_batch3", st); BIG_LDS(); P(tb); P(p.keys); P(p.ivs); P(p.aad); P(p.in); P(p.out); P(p.tags); P(p.expect); P(p.auth); P(p.counter); P(p.data_off); P(p.aad_off); P(p.perm);
     return hipSuccess;
 }
-hipError_t klaunch_len_sort(hipStream_t st, const LenSrc &src, u32, u32 *bins, u32 *perm, const RouteCfg &rc, u64 *bad_part, u32 *host_status) {
+hipError_t klaunch_len_sort(hipStream_t st, const LenSrc &src, u32, u32 *bins, u32 *perm, const RouteCfg &rc, u64 *bad_part, u32 *host_status, const DescSrc &) {
     LAUNCH("k_len_*", st); P(bad_part); P(host_status); P(src.off); P(src.aoff); P(src.len_arr); P(src.alen_arr); P(bins); P(perm); P(rc.hdr); P((const void *)(uintptr_t)rc.sc_in); P((const void *)(uintptr_t)rc.sc_out); P((const void *)(uintptr_t)rc.sc_aad); P((const void *)(uintptr_t)rc.sc_len); P((const void *)(uintptr_t)rc.sc_alen);
     return hipSuccess;
 }

@@ -229,6 +229,56 @@ def test_messages_wherever_they_live_are_routed_too(hip, orc, klen):
         assert back[pos_in[k]:pos_in[k] + lens[k]] == (bytes(lens[k]) if k in forged else pt_all[pos_in[k]:pos_in[k] + lens[k]]), k
 
 
+def test_scattered_messages_a_lane_each_read_the_launchs_records(hip, orc):
+    """a lane per packet (forced: the shape of calls of 2^18 messages and more) takes its packets from the 48-byte records the sort writes in the launch's order (round 6,
+    PktDesc) -- here for messages wherever they live: 4000 of them at odd addresses, outputs elsewhere, AAD of 0 .. 40 bytes, every one against the restatement of the RTL"""
+    rng = random.Random(7400)
+    n = 4000
+    lens = [rng.choice((0, 1, 15, 16, 17, 63, 64, 65, rng.randrange(0, 1600), rng.randrange(0, 1600), rng.randrange(1500, 5000))) for _ in range(n)]
+    aads = [rng.choice((0, 0, 1, 16, 28, 40)) for _ in range(n)]
+    key = splitmix_bytes(7500, 32)
+    f = orc.Fast(key)
+    pos_in, pos_out, pos_aad, a, b, c = [], [], [], 0, 0, 0
+    for k in range(n):
+        a += rng.choice((0, 1, 3, 16)); b += rng.choice((0, 5, 16, 64))
+        pos_in.append(a); pos_out.append(b); pos_aad.append(c)
+        a += lens[k]; b += lens[k]; c += aads[k]
+    d_in, d_out, d_aad = hip.DeviceBuffer(a + 64), hip.DeviceBuffer(b + 64), hip.DeviceBuffer(c + 64)
+    d_in.fill_splitmix64(7600, nbytes=(a + 64) // 8 * 8)
+    d_aad.fill_splitmix64(7601, nbytes=(c + 64) // 8 * 8)
+    ivs = splitmix_bytes(7602, 12 * n)
+    u64s = lambda v: _up(hip, struct.pack("<%dQ" % n, *v))
+    u32s = lambda v: _up(hip, struct.pack("<%dI" % n, *v))
+    d_ivs, d_len, d_alen = _up(hip, ivs), u32s(lens), u32s(aads)
+    d_inp, d_outp, d_aadp = u64s([d_in.ptr + x for x in pos_in]), u64s([d_out.ptr + x for x in pos_out]), u64s([d_aad.ptr + x for x in pos_aad])
+    d_tags, d_t2, d_auth = hip.DeviceBuffer(16 * n), hip.DeviceBuffer(16 * n), hip.DeviceBuffer(4 * n)
+    pt_all, aad_all = bytes(d_in.download()), bytes(d_aad.download())
+    with hip.debug_library() as dbg:
+        dbg.force(pkt_lanes=1)
+        ctx = hip.Context(key)
+        ctx.messages_crypt_dev(False, n, d_ivs.ptr, d_inp.ptr, d_len.ptr, d_outp.ptr, d_tags.ptr, d_aad_ptr=d_aadp.ptr, d_aad_len=d_alen.ptr)
+        hip.dev_sync()
+        assert ctx.status() == (hip.STATUS_OK, 0) and ctx.last_route()["lanes"] == 1
+        tags, ct_all = bytes(d_tags.download()), bytes(d_out.download())
+        for k in range(n):
+            want = f.encrypt(ivs[12 * k:12 * k + 12], aad_all[pos_aad[k]:pos_aad[k] + aads[k]], pt_all[pos_in[k]:pos_in[k] + lens[k]])
+            assert (ct_all[pos_out[k]:pos_out[k] + lens[k]], tags[16 * k:16 * k + 16]) == want, (k, lens[k], aads[k])
+        forged = sorted(set([0, n - 1] + rng.sample(range(n), 9)))
+        bad = bytearray(tags)
+        for k in forged:
+            bad[16 * k + 3] ^= 0x40
+        d_exp = _up(hip, bytes(bad))
+        ctx.messages_crypt_dev(True, n, d_ivs.ptr, d_outp.ptr, d_len.ptr, d_outp.ptr, d_t2.ptr, d_aad_ptr=d_aadp.ptr, d_aad_len=d_alen.ptr, d_expect_tags=d_exp.ptr, d_auth=d_auth.ptr)
+        hip.dev_sync()
+        assert bytes(d_t2.download()) == tags
+        auth = struct.unpack("<%di" % n, bytes(d_auth.download()))
+        assert [k for k in range(n) if not auth[k]] == forged
+        back = bytes(d_out.download())
+        for k in range(n):
+            assert back[pos_out[k]:pos_out[k] + lens[k]] == pt_all[pos_in[k]:pos_in[k] + lens[k]], k
+        ctx.close()
+
+
 def test_a_length_the_call_cannot_take_is_reported_not_truncated(hip, orc):
     """round 5 cast device-side lengths to 32 bits and ran on garbage.  Now: a length of 2^28 in d_len, a 2^29 gap in d_data_off, offsets that fall -- the plan
     kernel refuses the whole call: outputs, tags and verdicts stay as they were, aesgcm_ctx_status names the first such message (AESGCM_STATUS_LENGTH), and
