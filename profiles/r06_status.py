@@ -68,6 +68,12 @@ def readme():
                % (g(m1, "mixed"), g(m1, "all_rows"), g(m1, "all_pkt"), m1["vs_combination"], 2 * m1["mixed"]["bytes"] / (m1["mixed"]["ms_median"] * 1e-3) / 8e12))
     out.append("| **round 6: `--config frames`: 2^20 MACsec-shaped frames, 64 .. 1514 B + 28 B of AAD, byte-packed, one key, one call** | **%.1f** (%.0f M frames/s; %.0f - %.0f on the round's boxes); decrypt %.1f; without AAD %.1f; AES-128 %.1f; **%.2f of the ceiling of its formulation** (no-data twin of `k_pktl`: %.1f; %.2f - %.2f on the round's boxes) -- the 0.9 asked for is missed, with counters and four A/Bs: `frames/probe_vs_real.txt` | %.3f | %.2f x (byte-packed: a lane's 128-byte group lies across two lines; 1 KiB records on line boundaries 1.01 x and 0.89 of the ceiling, `frames/align_probe.txt`) | `bench_frames*.json`, `frames/`, `frames_probe/`, `pktl_1k/` |"
                % (v("frames"), fb["config"]["mframes_per_s"], min(lof, 572.5), max(hif, 591.9), v("frames_dec"), v("frames_noaad"), v("frames_aes128"), ceil("frames"), fc["gib_per_s"], min(cl + [0.772]), max(cl + [0.818]), fr("frames"), tr("frames")))
+    pl = {}
+    if os.path.exists(os.path.join(R, "placed.jsonl")):
+        for l in open(os.path.join(R, "placed.jsonl")):
+            d = json.loads(l); pl[(d["placed"], d["decrypt"])] = d
+        out.append("| the same frames wherever they live -- each in a buffer of its own, arrays of addresses and lengths (`aesgcm_messages_crypt_dev`): byte-packed / at multiples of 64 bytes | %.1f / **%.1f** (decrypt %.1f); the offsets call in the same loop %.1f.  Until this round's packet records 422 / 459: the lane read five arrays at its packet number's places | -- | -- | `placed.jsonl`, `frames/placed.txt` |"
+                   % (pl[(1, False)]["gib_per_s"], pl[(64, False)]["gib_per_s"], pl[(64, True)]["gib_per_s"], pl[(0, False)]["gib_per_s"]))
     f64 = bench("frames_64k")
     out.append("| 65 536 such frames (4 lanes per frame, `k_pktg`) | %.1f (%.3f ms per call, 20 us of it the sort: 35 before this round's change to it); %.2f of its ceiling | %.3f | -- | `bench_frames_64k.json`, `pktg_1k/`, `len_sort_ab.txt` |" % (f64["value"], f64["ms_per_step"], ceil("frames_64k"), fr("frames_64k")))
     out.append("| 8 KiB / 16 KiB / 32 KiB / 64 KiB .. 16 MiB messages under one key, 4 GiB per call | %.0f / %.0f / %.0f / %.0f - %.0f | -- | -- | `size_sweep.txt` |" % (sw[8][2], sw[16][2], sw[32][2], min(big), max(big)))

@@ -3,7 +3,7 @@
 O=gpurun_out/r06_final; R=profiles/r06
 mkdir -p $R
 for d in $O/prof_*; do t=$(basename $d); t=${t#prof_}; mkdir -p $R/$t; cp $d/* $R/$t/; done
-cp $O/bench_*.json $O/so_sha256.txt $O/smoke.txt $O/mixed_u.jsonl $O/route_sweep.jsonl $O/size_sweep.txt $O/graph_replay.jsonl $O/route_band.jsonl $R/ 2>/dev/null
+cp $O/bench_*.json $O/so_sha256.txt $O/smoke.txt $O/mixed_u.jsonl $O/route_sweep.jsonl $O/size_sweep.txt $O/graph_replay.jsonl $O/route_band.jsonl $O/placed.jsonl $R/ 2>/dev/null
 tail -25 $O/pytest.txt > $R/pytest_tail.txt
 for t in cfg2_n1 cfg3_n1 cfg5_n1 rows_1m frames; do [ -f $O/prof_$t/pmc_$t.json ] && cp $O/prof_$t/pmc_$t.json profiles/; done
 python3 tools/isa_census.py > $R/isa_census.txt 2>/dev/null

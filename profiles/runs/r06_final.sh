@@ -58,6 +58,7 @@ for l in open(sys.argv[1]+"/route_sweep.jsonl"):
 PY
 timeout 900 python profiles/route_sweep.py --kinds band8_16,band8_16w,band16_32,u16k --counts 131072,262144,393216,458752,524288,1048576 > $O/route_band.jsonl 2> $O/route_band.err
 timeout 900 python profiles/msg_sweep.py > $O/size_sweep.txt 2> $O/size_sweep.err; tail -14 $O/size_sweep.txt
+for x in "" "--placed 1" "--placed 64" "--placed 64 --dec"; do timeout 200 python3 profiles/frames_one.py --steps 12 $x >> $O/placed.jsonl 2>> $O/placed.err; done
 for n in 4096 16384 65536 1048576; do timeout 120 examples/graph_replay $n 200 >> $O/graph_replay.jsonl 2>> $O/graph_replay.err; done
 for t in cfg3_n1 cfg2_n1 cfg5_n1 rows_1m frames frames_probe pktl_1k pktg_1k mixed_u mixed_u_1m; do
   mkdir -p $O/prof_$t; cp gpurun_out/prof_$t/summary*.txt gpurun_out/prof_$t/pmc_$t.json gpurun_out/prof_$t/stats_run.json $O/prof_$t/ 2>/dev/null
